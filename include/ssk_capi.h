@@ -1,0 +1,139 @@
+/*
+ * ssk_capi.h -- C-ABI drop-in boundary of the MI355X-native srba-stereo-slam hot path.
+ *
+ * One shared library (libssk_hip.so, built from srba-stereo-slam_amd/csrc with hipcc for gfx950)
+ * exports exactly these symbols.  Plain pointers and sizes only; no C++ / torch types.
+ * Every entry point cites the reference call it replaces (paths into the upstream tree,
+ * famoreno/srba-stereo-slam; EST.cpp = src/CSRBAStereoSLAMEstimator.cpp, KF.h = src/CStereoSLAMKF.h,
+ * UTIL.h = src/srba-stereo-slam_utils.h, SRBA.h = src/srba-stereo-slam.h).
+ *
+ * Conventions
+ *   - return value: 0 = SSK_OK, otherwise an ssk_status error code; ssk_last_error(ctx) has the text.
+ *     The C++ facade (srba-stereo-slam_amd/host) turns a non-zero code into std::runtime_error, which is
+ *     how the reference reports errors (MRPT THROW_EXCEPTION, EST.cpp:288-295).
+ *   - "host" entry points take host pointers and copy through the context's staging buffers
+ *     (they are the literal drop-ins for the reference call sites, one keyframe at a time);
+ *     "_dev" entry points take device pointers (HBM-resident batches, nothing crosses PCIe) and are
+ *     asynchronous on the context's HIP stream.
+ *   - there is NO CPU fallback anywhere behind this interface: without a usable gfx950 device
+ *     ssk_create fails with SSK_ERR_NO_DEVICE and every other call needs a context.
+ */
+#ifndef SSK_CAPI_H
+#define SSK_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSK_API_VERSION 1
+
+typedef enum ssk_status {
+	SSK_OK = 0,
+	SSK_ERR_NO_DEVICE = 1,     /* no HIP device / not gfx950 */
+	SSK_ERR_BAD_ARG = 2,
+	SSK_ERR_HIP = 3,           /* a HIP runtime call failed; see ssk_last_error */
+	SSK_ERR_CAPACITY = 4,      /* a caller-provided buffer is too small */
+	SSK_ERR_TOO_FEW_MATCHES = 5, /* < 8 stereo matches: reference throws at EST.cpp:288-295 */
+	SSK_ERR_NOT_POSDEF = 6     /* reduced camera system not positive definite after max lambda */
+} ssk_status;
+
+/* ---- plain records, layout-compatible with the OpenCV 2.4 types the reference stores ----------
+ * cv::KeyPoint {Point2f pt; float size, angle, response; int octave, class_id;}  = 28 B (UTIL.h:47)
+ * cv::DMatch   {int queryIdx, trainIdx, imgIdx; float distance;}                 = 16 B (UTIL.h:48) */
+typedef struct ssk_keypoint { float x, y, size, angle, response; int32_t octave, class_id; } ssk_keypoint;
+typedef struct ssk_dmatch { int32_t queryIdx, trainIdx, imgIdx; float distance; } ssk_dmatch;
+
+#define SSK_DESC_BYTES 32   /* ORB descriptor row: 256 bits, CV_8U x 32 (EST.cpp:1351) */
+
+/* per-match status after the data-association filters; values of
+ * TVectorDAMatchInfo::TDAMatchStatus (src/CSRBAStereoSLAMEstimator.h:102) */
+enum {
+	SSK_DA_TRACKED = 0, SSK_DA_NON_TRACKED = 1, SSK_DA_REJ_SLOPE = 2, SSK_DA_REJ_ORB = 3,
+	SSK_DA_REJ_FUND_MATRIX = 4, SSK_DA_REJ_CHANGE_POSE = 5, SSK_DA_REJ_CONSISTENCY = 6
+};
+
+typedef struct ssk_ctx ssk_ctx;
+
+/* ---- context ----------------------------------------------------------------------------------- */
+int ssk_api_version(void);
+/* device: HIP ordinal.  hip_stream: a hipStream_t to enqueue on (e.g. torch's current stream), or
+ * NULL for a context-owned stream. */
+int ssk_create(ssk_ctx** out, int device, void* hip_stream);
+void ssk_destroy(ssk_ctx* ctx);
+const char* ssk_last_error(const ssk_ctx* ctx);   /* ctx may be NULL: returns the create-time error */
+int ssk_synchronize(ssk_ctx* ctx);                /* hipStreamSynchronize on the context stream */
+void* ssk_stream(ssk_ctx* ctx);                   /* the hipStream_t kernels are launched on */
+/* HIP-event timing on the context stream (bench.py measures kernels on the stream they run on). */
+int ssk_timer_start(ssk_ctx* ctx);
+int ssk_timer_stop_ms(ssk_ctx* ctx, float* ms);   /* records + synchronises the stop event */
+
+/* ---- B2: keyframe <-> keyframe Hamming brute force ---------------------------------------------
+ * Replaces  cv::BFMatcher(NORM_HAMMING,false).match(query, train, out)   EST.cpp:1447-1452.
+ * out[q] = {queryIdx=q, trainIdx=argmin_t popcount(query[q]^train[t]) (lowest t on ties), imgIdx=0,
+ * distance=(float)min}.  nq rows of 32 B, nt rows of 32 B.  nt==0 or nq==0 -> *n_out = 0
+ * (BFMatcher clears the output).  out capacity must be >= nq. */
+int ssk_hamming_match(ssk_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                      ssk_dmatch* out, int* n_out);
+
+/* Batched, device-resident form: P independent (query,train) pairs in one launch.
+ * d_desc_q / d_desc_t: descriptor pools (rows of 32 B; pool base 16-B aligned).  Pair p matches
+ * virtual rows q_off[p]..q_off[p+1] against virtual rows t_off[p]..t_off[p+1] (device int32 arrays of
+ * length P+1).  Optional gather (a5, EST.cpp:1354-1358,1435-1439): d_q_gather[r] / d_t_gather[r]
+ * (may be NULL = identity) is the pool row that virtual row r reads, so the "matched-only, re-indexed
+ * by match" descriptor matrices of the reference are never materialised.
+ * Outputs (device int32, indexed by virtual query row): d_train_idx = argmin relative to t_off[p],
+ * d_dist = the Hamming distance; (-1, INT32_MAX) when the pair has no train rows.
+ * max_query_rows >= max_p (q_off[p+1]-q_off[p]) sizes the grid (offsets live on the device);
+ * a pair may hold at most 2^22 train rows. */
+int ssk_hamming_match_batched_dev(ssk_ctx* ctx,
+                                  const uint8_t* d_desc_q, const int32_t* d_q_off, const int32_t* d_q_gather,
+                                  const uint8_t* d_desc_t, const int32_t* d_t_off, const int32_t* d_t_gather,
+                                  int n_pairs, int max_query_rows, int32_t* d_train_idx, int32_t* d_dist);
+
+/* ---- B2: data-association filters --------------------------------------------------------------
+ * Replaces m_detect_outliers_with_direction (EST.cpp:1883-1946) and
+ * m_detect_outliers_with_orb_distance (EST.cpp:1951-2010), applied in that order as
+ * m_internal_data_association does (EST.cpp:1482-1515). */
+typedef struct ssk_da_params {
+	int32_t filter_by_direction;      /* srba_options.da_filter_by_direction (KITTI.ini:124) */
+	int32_t filter_by_orb_distance;   /* srba_options.da_filter_by_orb_distance (UTIL.h default true) */
+	int32_t rows_offset;              /* stereo_camera.leftCamera.nrows, the 'offset' arg (EST.cpp:1486) */
+	float   max_orb_distance_da;      /* srba_options.max_orb_distance_da (KITTI.ini:120) */
+} ssk_da_params;
+
+/* One keyframe as the reference stores it (KF.h:99-104), host memory, read-only. */
+typedef struct ssk_kf_view {
+	const ssk_keypoint* kp_left;  int32_t n_left;
+	const ssk_keypoint* kp_right; int32_t n_right;
+	const uint8_t* desc_left;     /* n_left  x 32 */
+	const uint8_t* desc_right;    /* n_right x 32 */
+	const ssk_dmatch* matches;    int32_t n_matches;   /* L<->R matches: queryIdx=left kp, trainIdx=right kp */
+} ssk_kf_view;
+
+/* Whole m_internal_data_association up to (not including) the fundamental-matrix / change-in-pose
+ * stages (EST.cpp:1413-1515 + output assembly 1647-1669): gathers matched-only left descriptors of
+ * both KFs (Q3), brute-force match, direction + ORB-distance filters.
+ *   out_matches[k] (k < this.n_matches): the raw BFMatcher result (match-index space)
+ *   out_status[k] : SSK_DA_* ;  *out_tracked = number of SSK_DA_TRACKED.
+ * Capacity of both output arrays: this_kf->n_matches. */
+int ssk_data_association(ssk_ctx* ctx, const ssk_kf_view* this_kf, const ssk_kf_view* other_kf,
+                         const ssk_da_params* params, ssk_dmatch* out_matches, int32_t* out_status,
+                         int32_t* out_tracked);
+
+/* Filters only, on already-computed matches (host arrays).  this_xy / other_xy: left-keypoint pixel
+ * coordinates re-indexed by MATCH index (2 floats per match). status is in/out. */
+int ssk_da_filters(ssk_ctx* ctx, const ssk_dmatch* matches, int n_this, int n_other,
+                   const float* this_xy, const float* other_xy, const ssk_da_params* params,
+                   int32_t* status, int32_t* out_tracked);
+
+/* Test hook: the 19 float thresholds the context derived from the host libm's atanf for the
+ * direction bins 9..27 (see csrc/ssk_context.hip). */
+int ssk_debug_direction_thresholds(ssk_ctx* ctx, float* out19);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSK_CAPI_H */

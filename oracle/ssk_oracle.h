@@ -1,0 +1,75 @@
+/*
+ * ssk_oracle.h -- CPU ORACLE of the srba-stereo-slam per-keyframe hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may call it; libssk_hip.so never links or loads it.
+ *
+ * PARITY STATUS: *** parity unpinned ***.  The reference's arithmetic for this path lives in
+ * un-vendored third-party libraries that are absent from this image and from /root/reference
+ * (stereo-vo [unpinned], OpenCV 2.4.x, MRPT/srba [unpinned], MRPT >= 1.3; reference README.md:12-16),
+ * the reference tree holds no tests, fixtures or golden vectors, and its build
+ * needs those libraries (src/CMakeLists.txt:3-7), so no oracle/_ref build exists.  What is restated
+ * LITERALLY from in-tree reference code is marked [literal file:line]; what restates the published
+ * algorithm of an absent dependency is marked [published: ...] and every choice the publication
+ * leaves open is fixed here, once, and documented in DESIGN.md section "Oracle contract".
+ *
+ * Plain C99, single-threaded, no dependencies beyond libc/libm.  Build: oracle/Makefile
+ * (-O2 -ffp-contract=off: no FMA contraction, so float results are the IEEE sequence written here).
+ */
+#ifndef SSK_ORACLE_H
+#define SSK_ORACLE_H
+
+#include <stdint.h>
+#include "../include/ssk_capi.h"   /* record layouts only (ssk_keypoint, ssk_dmatch, params) */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- data association (oracle_da.c) ---------------- */
+
+/* [published: OpenCV 2.4 BFMatcher(NORM_HAMMING,crossCheck=false).match; call site EST.cpp:1447-1452]
+ * returns number of matches written (nq, or 0 when nq==0 or nt==0). */
+int ssko_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int nt, ssk_dmatch* out);
+
+/* [literal EST.cpp:1883-1946] direction histogram filter.  status in/out (SSK_DA_*).
+ * this_xy[2*k..] = left keypoint of THIS kf for match k; other_xy[2*j..] = left keypoint of the
+ * OTHER kf for its match j (indexed through matches[k].trainIdx).  offset = image rows. */
+void ssko_da_filter_direction(const ssk_dmatch* matches, int n_this, const float* this_xy,
+                              const float* other_xy, int offset, int32_t* status);
+
+/* [literal EST.cpp:1951-2010] ORB-distance threshold + serial uniqueness scan (quirk Q1:
+ * other_matched[].second stores ++stage1_counter, not the distance). */
+void ssko_da_filter_orb_distance(const ssk_dmatch* matches, int n_this, int n_other,
+                                 double max_orb_distance_da, int32_t* status);
+
+/* [literal EST.cpp:1413-1515,1647-1669] gather (Q3) + match + the two filters. returns tracked count.
+ * out_matches/out_status capacity: this_kf->n_matches. */
+int ssko_data_association(const ssk_kf_view* this_kf, const ssk_kf_view* other_kf,
+                          const ssk_da_params* params, ssk_dmatch* out_matches, int32_t* out_status);
+
+/* [literal EST.cpp:572-617] landmark-ID propagation for a new keyframe.
+ * n_matches: matches in the new KF; n_sim: similar KFs, visited in the order given (sortedIndices
+ * order already applied by the caller).  tracking_first[s*n_matches+m] = other match index or -1
+ * (t_kf_da_info::tracking_info[m].first).  other_ids[s] -> that KF's m_matches_ID array.
+ * last_match_id in/out (m_last_match_ID).  out_ids[m] = new_kf.m_matches_ID[m].
+ * out_tracked_per_kf[s] = vectorNumberTrackedFeats. returns numberTrackedFeats. */
+int ssko_propagate_ids(int n_matches, int n_sim, const int32_t* tracking_first,
+                       const uint64_t* const* other_ids, uint64_t* last_match_id,
+                       uint64_t* out_ids, int32_t* out_tracked_per_kf);
+
+/* ---------------- landmark initialisation (oracle_geom.c) ---------------- */
+
+typedef struct ssko_stereo_cam {   /* mrpt::utils::TStereoCamera fields the path reads */
+	double fx_l, fy_l, cx_l, cy_l;
+	double fx_r, fy_r, cx_r, cy_r;
+	double baseline;               /* rightCameraPose[0] */
+} ssko_stereo_cam;
+
+/* [literal UTIL.h:558-574] */
+void ssko_project_match_to_3d(double ul, double vl, double ur, const ssko_stereo_cam* cam, double out_xyz[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""Build libssk_hip.so (HIP kernels + C-ABI, gfx950 only) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU.  Objects go to csrc/_obj (git-ignored); the shared library lands
+next to this file so it travels with a gpurun snapshot.  No torch / pybind: the boundary is the plain
+C-ABI of include/ssk_capi.h.
+"""
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libssk_hip.so")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "-ffp-contract=off",          # float parity contract: no FMA contraction on host or device
+    "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    "-I", os.path.join(ROOT, "include"),
+]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stamp(src):
+    h = hashlib.sha1()
+    h.update(" ".join(FLAGS).encode())
+    for f in [src] + sorted(x for x in os.listdir(CSRC) if x.endswith(".h")) + ["../../include/ssk_capi.h"]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    stamp_file = obj + ".stamp"
+    stamp = _stamp(src)
+    if os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    with open(stamp_file, "w") as fh:
+        fh.write(stamp)
+    return obj, True
+
+
+def build(verbose=True, jobs=4):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = _sources()
+    with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+        res = list(ex.map(_compile, srcs))
+    objs = [o for o, _ in res]
+    rebuilt = any(c for _, c in res)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    if verbose:
+        print("libssk_hip.so: %s (%d sources, %s)" % (LIB, len(srcs), "rebuilt" if rebuilt else "up to date"))
+    return LIB
+
+
+if __name__ == "__main__":
+    build()

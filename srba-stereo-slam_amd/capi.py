@@ -1,0 +1,168 @@
+"""ctypes binding of libssk_hip.so -- exactly the entry points declared in include/ssk_capi.h."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HEADER = os.path.join(ROOT, "include", "ssk_capi.h")
+
+# layout of cv::KeyPoint / cv::DMatch (reference: src/srba-stereo-slam_utils.h:47-48)
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16
+
+
+class SskError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("ssk error %d: %s" % (code, text))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(HERE, "libssk_hip.so")
+
+
+def declared_symbols():
+    """Every function name declared in include/ssk_capi.h (used by the CPU export test)."""
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssk_[a-z0-9_]+)\s*\(", src)))
+
+
+_LIB = None
+
+
+def load_library():
+    """Load libssk_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError("libssk_hip.so is not built: run `python __graft_entry__.py build` "
+                              "(there is no CPU fallback)")
+        _LIB = C.CDLL(p)
+        _LIB.ssk_last_error.restype = C.c_char_p
+        _LIB.ssk_stream.restype = C.c_void_p
+    return _LIB
+
+
+class KfView(C.Structure):
+    _fields_ = [("kp_left", C.c_void_p), ("n_left", C.c_int32),
+                ("kp_right", C.c_void_p), ("n_right", C.c_int32),
+                ("desc_left", C.c_void_p), ("desc_right", C.c_void_p),
+                ("matches", C.c_void_p), ("n_matches", C.c_int32)]
+
+
+class DaParams(C.Structure):
+    _fields_ = [("filter_by_direction", C.c_int32), ("filter_by_orb_distance", C.c_int32),
+                ("rows_offset", C.c_int32), ("max_orb_distance_da", C.c_float)]
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
+
+
+def _dev(p):
+    """device pointer argument: int address, torch tensor (data_ptr) or None."""
+    if p is None:
+        return C.c_void_p(0)
+    if hasattr(p, "data_ptr"):
+        return C.c_void_p(p.data_ptr())
+    return C.c_void_p(int(p))
+
+
+def make_kf_view(kp_left, kp_right, desc_left, desc_right, matches):
+    """Returns (view, keepalive): keep the tuple alive while the view is in use."""
+    kp_left = np.ascontiguousarray(kp_left, dtype=KEYPOINT_DTYPE)
+    kp_right = np.ascontiguousarray(kp_right, dtype=KEYPOINT_DTYPE)
+    desc_left = np.ascontiguousarray(desc_left, dtype=np.uint8).reshape(-1, 32)
+    desc_right = np.ascontiguousarray(desc_right, dtype=np.uint8).reshape(-1, 32)
+    matches = np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
+    v = KfView(_ptr(kp_left), len(kp_left), _ptr(kp_right), len(kp_right), _ptr(desc_left), _ptr(desc_right),
+               _ptr(matches), len(matches))
+    return v, (kp_left, kp_right, desc_left, desc_right, matches)
+
+
+class Context:
+    """ssk_ctx wrapper.  stream: a hipStream_t handle (int) or None for a context-owned stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.ssk_create(C.byref(h), int(device), C.c_void_p(stream or 0))
+        if rc != 0:
+            raise SskError(rc, self.lib.ssk_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ssk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SskError(rc, self.lib.ssk_last_error(self.h).decode())
+
+    # -- context ---------------------------------------------------------------------------------
+    def synchronize(self):
+        self._chk(self.lib.ssk_synchronize(self.h))
+
+    def stream(self):
+        return self.lib.ssk_stream(self.h)
+
+    def timer_start(self):
+        self._chk(self.lib.ssk_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.ssk_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def direction_thresholds(self):
+        out = np.zeros(19, np.float32)
+        self._chk(self.lib.ssk_debug_direction_thresholds(self.h, _ptr(out)))
+        return out
+
+    # -- B2 ------------------------------------------------------------------------------------------
+    def hamming_match(self, query, train):
+        q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(q), DMATCH_DTYPE)
+        n = C.c_int()
+        self._chk(self.lib.ssk_hamming_match(self.h, _ptr(q), len(q), _ptr(t), len(t), _ptr(out), C.byref(n)))
+        return out[:n.value]
+
+    def hamming_match_batched_dev(self, d_q, d_q_off, d_q_gather, d_t, d_t_off, d_t_gather, n_pairs, max_q,
+                                  d_idx, d_dist):
+        self._chk(self.lib.ssk_hamming_match_batched_dev(
+            self.h, _dev(d_q), _dev(d_q_off), _dev(d_q_gather), _dev(d_t), _dev(d_t_off), _dev(d_t_gather),
+            int(n_pairs), int(max_q), _dev(d_idx), _dev(d_dist)))
+
+    def da_filters(self, matches, n_other, this_xy, other_xy, params):
+        m = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        a = np.ascontiguousarray(this_xy, np.float32)
+        b = np.ascontiguousarray(other_xy, np.float32)
+        status = np.zeros(len(m), np.int32)
+        tracked = C.c_int32()
+        self._chk(self.lib.ssk_da_filters(self.h, _ptr(m), len(m), int(n_other), _ptr(a), _ptr(b),
+                                          C.byref(params), _ptr(status), C.byref(tracked)))
+        return status, tracked.value
+
+    def data_association(self, this_view, other_view, params):
+        n = this_view.n_matches
+        out = np.zeros(n, DMATCH_DTYPE)
+        status = np.zeros(n, np.int32)
+        tracked = C.c_int32()
+        self._chk(self.lib.ssk_data_association(self.h, C.byref(this_view), C.byref(other_view), C.byref(params),
+                                                _ptr(out), _ptr(status), C.byref(tracked)))
+        return out, status, tracked.value

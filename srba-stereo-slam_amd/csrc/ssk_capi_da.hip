@@ -1,0 +1,198 @@
+// ssk_capi_da.hip -- C-ABI entry points of seam B2 (keyframe<->keyframe data association):
+// host-pointer drop-ins for the reference call sites plus the device-resident batched forms.
+#include "ssk_internal.h"
+
+int ssk_da_max_matches();
+
+extern "C" {
+
+int ssk_hamming_match_batched_dev(ssk_ctx* ctx,
+                                  const uint8_t* d_desc_q, const int32_t* d_q_off, const int32_t* d_q_gather,
+                                  const uint8_t* d_desc_t, const int32_t* d_t_off, const int32_t* d_t_gather,
+                                  int n_pairs, int max_query_rows, int32_t* d_train_idx, int32_t* d_dist)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (n_pairs < 0 || max_query_rows < 0 || !d_q_off || !d_t_off || !d_train_idx || !d_dist ||
+	    (n_pairs > 0 && (!d_desc_q || !d_desc_t)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_hamming_match_batched_dev: bad argument");
+	return ssk_launch_hamming(ctx, d_desc_q, d_q_off, d_q_gather, d_desc_t, d_t_off, d_t_gather,
+	                          n_pairs, max_query_rows, d_train_idx, d_dist);
+}
+
+int ssk_hamming_match(ssk_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
+                      ssk_dmatch* out, int* n_out)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (nq < 0 || nt < 0 || !n_out || (nq > 0 && (!query || !out)) || (nt > 0 && !train))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_hamming_match: bad argument");
+	*n_out = 0;
+	if (nq == 0 || nt == 0) return SSK_OK;          // BFMatcher clears the output
+	if (nt >= (1 << 22)) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_hamming_match: nt >= 2^22 rows");
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t qb = (size_t)nq * 32, tb = (size_t)nt * 32;
+	int rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad(qb) + ssk_pad(tb) + 2 * ssk_pad((size_t)nq * 4) + 4 * 256))) return rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->pin, 2 * ssk_pad((size_t)nq * 4) + 2 * 256))) return rc;
+	ssk_arena_reset(ctx->dev); ssk_arena_reset(ctx->pin);
+	uint8_t* d_q = ssk_arena_take<uint8_t>(ctx->dev, qb);
+	uint8_t* d_t = ssk_arena_take<uint8_t>(ctx->dev, tb);
+	int32_t* d_off = ssk_arena_take<int32_t>(ctx->dev, 4);
+	int32_t* d_idx = ssk_arena_take<int32_t>(ctx->dev, nq);
+	int32_t* d_dist = ssk_arena_take<int32_t>(ctx->dev, nq);
+	int32_t* h_idx = ssk_arena_take<int32_t>(ctx->pin, nq);
+	int32_t* h_dist = ssk_arena_take<int32_t>(ctx->pin, nq);
+	const int32_t off[4] = {0, nq, 0, nt};
+	SSK_HIP(ctx, hipMemcpyAsync(d_q, query, qb, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_t, train, tb, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
+	if ((rc = ssk_launch_hamming(ctx, d_q, d_off, nullptr, d_t, d_off + 2, nullptr, 1, nq, d_idx, d_dist))) return rc;
+	SSK_HIP(ctx, hipMemcpyAsync(h_idx, d_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(h_dist, d_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (int q = 0; q < nq; ++q) {
+		out[q].queryIdx = q; out[q].trainIdx = h_idx[q]; out[q].imgIdx = 0; out[q].distance = (float)h_dist[q];
+	}
+	*n_out = nq;
+	return SSK_OK;
+}
+
+// shared tail of ssk_da_filters / ssk_data_association: device arrays already in place.
+static int run_filters_and_fetch(ssk_ctx* ctx, const int32_t* d_idx, const int32_t* d_dist, const int32_t* d_off,
+                                 const float* d_axy, const float* d_bxy, const ssk_da_params* p, int na,
+                                 int32_t* d_status, int32_t* d_tracked, int32_t* h_status, int32_t* h_tracked)
+{
+	int rc;
+	if ((rc = ssk_launch_da_filters(ctx, d_idx, d_dist, d_off, d_off + 2, d_axy, d_bxy, 1, *p, d_status, d_tracked))) return rc;
+	SSK_HIP(ctx, hipMemcpyAsync(h_status, d_status, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(h_tracked, d_tracked, 4, hipMemcpyDeviceToHost, ctx->stream));
+	return SSK_OK;
+}
+
+int ssk_da_filters(ssk_ctx* ctx, const ssk_dmatch* matches, int n_this, int n_other,
+                   const float* this_xy, const float* other_xy, const ssk_da_params* params,
+                   int32_t* status, int32_t* out_tracked)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (n_this < 0 || n_other < 0 || !params || !out_tracked ||
+	    (n_this > 0 && (!matches || !this_xy || !status)) || (n_other > 0 && !other_xy))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_da_filters: bad argument");
+	*out_tracked = 0;
+	if (n_this == 0) return SSK_OK;
+	if (n_this > ssk_da_max_matches() || n_other > ssk_da_max_matches())
+		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_da_filters: more than %d matches per keyframe", ssk_da_max_matches());
+	for (int k = 0; k < n_this; ++k)
+		if (matches[k].queryIdx != k || (n_other > 0 && (matches[k].trainIdx < 0 || matches[k].trainIdx >= n_other)))
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_da_filters: matches[%d] is not BFMatcher-shaped", k);
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	const size_t na = (size_t)n_this, nb = (size_t)(n_other > 0 ? n_other : 1);
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, 3 * ssk_pad(na * 4) + ssk_pad(na * 8) + ssk_pad(nb * 8) + 8 * 256))) return rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->pin, 3 * ssk_pad(na * 4) + 4 * 256))) return rc;
+	ssk_arena_reset(ctx->dev); ssk_arena_reset(ctx->pin);
+	int32_t* d_idx = ssk_arena_take<int32_t>(ctx->dev, na);
+	int32_t* d_dist = ssk_arena_take<int32_t>(ctx->dev, na);
+	int32_t* d_status = ssk_arena_take<int32_t>(ctx->dev, na);
+	float* d_axy = ssk_arena_take<float>(ctx->dev, 2 * na);
+	float* d_bxy = ssk_arena_take<float>(ctx->dev, 2 * nb);
+	int32_t* d_off = ssk_arena_take<int32_t>(ctx->dev, 4);
+	int32_t* d_tracked = ssk_arena_take<int32_t>(ctx->dev, 1);
+	int32_t* h_idx = ssk_arena_take<int32_t>(ctx->pin, na);
+	int32_t* h_dist = ssk_arena_take<int32_t>(ctx->pin, na);
+	int32_t* h_status = ssk_arena_take<int32_t>(ctx->pin, na);
+	int32_t* h_tracked = ssk_arena_take<int32_t>(ctx->pin, 1);
+	for (int k = 0; k < n_this; ++k) { h_idx[k] = matches[k].trainIdx; h_dist[k] = (int32_t)matches[k].distance; }
+	const int32_t off[4] = {0, n_this, 0, n_other};
+	SSK_HIP(ctx, hipMemcpyAsync(d_idx, h_idx, na * 4, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_dist, h_dist, na * 4, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_axy, this_xy, na * 8, hipMemcpyHostToDevice, ctx->stream));
+	if (n_other > 0) SSK_HIP(ctx, hipMemcpyAsync(d_bxy, other_xy, (size_t)n_other * 8, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
+	if ((rc = run_filters_and_fetch(ctx, d_idx, d_dist, d_off, d_axy, d_bxy, params, n_this, d_status, d_tracked, h_status, h_tracked))) return rc;
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	std::memcpy(status, h_status, na * 4);
+	*out_tracked = *h_tracked;
+	return SSK_OK;
+}
+
+int ssk_data_association(ssk_ctx* ctx, const ssk_kf_view* a, const ssk_kf_view* b,
+                         const ssk_da_params* params, ssk_dmatch* out_matches, int32_t* out_status,
+                         int32_t* out_tracked)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!a || !b || !params || !out_tracked || a->n_matches < 0 || b->n_matches < 0 ||
+	    (a->n_matches > 0 && (!out_matches || !out_status || !a->matches || !a->desc_left || !a->kp_left)) ||
+	    (b->n_matches > 0 && (!b->matches || !b->desc_left || !b->kp_left)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association: bad argument");
+	*out_tracked = 0;
+	const int na = a->n_matches, nb = b->n_matches;
+	if (na == 0) return SSK_OK;
+	if (na > ssk_da_max_matches() || nb > ssk_da_max_matches())
+		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_data_association: more than %d matches per keyframe", ssk_da_max_matches());
+	for (int k = 0; k < na; ++k)
+		if (a->matches[k].queryIdx < 0 || a->matches[k].queryIdx >= a->n_left)
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association: this_kf match %d out of range", k);
+	for (int k = 0; k < nb; ++k)
+		if (b->matches[k].queryIdx < 0 || b->matches[k].queryIdx >= b->n_left)
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association: other_kf match %d out of range", k);
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	const size_t sa = (size_t)na, sb = (size_t)(nb > 0 ? nb : 1);
+	const size_t nLa = (size_t)a->n_left, nLb = (size_t)(b->n_left > 0 ? b->n_left : 1);
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad(nLa * 32) + ssk_pad(nLb * 32) + 4 * ssk_pad(sa * 4) + ssk_pad(sb * 4) +
+	                                               ssk_pad(sa * 8) + ssk_pad(sb * 8) + 12 * 256))) return rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->pin, 4 * ssk_pad(sa * 4) + ssk_pad(sb * 4) + ssk_pad(sa * 8) + ssk_pad(sb * 8) + 10 * 256))) return rc;
+	ssk_arena_reset(ctx->dev); ssk_arena_reset(ctx->pin);
+	// device: whole left descriptor blocks of both KFs + gather lists (match -> left keypoint row), so the
+	// "matched-only" matrices curLDesc / preLDesc (EST.cpp:1351-1358,1432-1439) are never built.
+	uint8_t* d_da = ssk_arena_take<uint8_t>(ctx->dev, nLa * 32);
+	uint8_t* d_db = ssk_arena_take<uint8_t>(ctx->dev, nLb * 32);
+	int32_t* d_ga = ssk_arena_take<int32_t>(ctx->dev, sa);
+	int32_t* d_gb = ssk_arena_take<int32_t>(ctx->dev, sb);
+	int32_t* d_idx = ssk_arena_take<int32_t>(ctx->dev, sa);
+	int32_t* d_dist = ssk_arena_take<int32_t>(ctx->dev, sa);
+	int32_t* d_status = ssk_arena_take<int32_t>(ctx->dev, sa);
+	float* d_axy = ssk_arena_take<float>(ctx->dev, 2 * sa);
+	float* d_bxy = ssk_arena_take<float>(ctx->dev, 2 * sb);
+	int32_t* d_off = ssk_arena_take<int32_t>(ctx->dev, 4);
+	int32_t* d_tracked = ssk_arena_take<int32_t>(ctx->dev, 1);
+	int32_t* h_ga = ssk_arena_take<int32_t>(ctx->pin, sa);
+	int32_t* h_gb = ssk_arena_take<int32_t>(ctx->pin, sb);
+	float* h_axy = ssk_arena_take<float>(ctx->pin, 2 * sa);
+	float* h_bxy = ssk_arena_take<float>(ctx->pin, 2 * sb);
+	int32_t* h_idx = ssk_arena_take<int32_t>(ctx->pin, sa);
+	int32_t* h_dist = ssk_arena_take<int32_t>(ctx->pin, sa);
+	int32_t* h_status = ssk_arena_take<int32_t>(ctx->pin, sa);
+	int32_t* h_tracked = ssk_arena_take<int32_t>(ctx->pin, 1);
+	for (int k = 0; k < na; ++k) {
+		const int i = a->matches[k].queryIdx;
+		h_ga[k] = i; h_axy[2 * k] = a->kp_left[i].x; h_axy[2 * k + 1] = a->kp_left[i].y;
+	}
+	for (int k = 0; k < nb; ++k) {
+		const int i = b->matches[k].queryIdx;
+		h_gb[k] = i; h_bxy[2 * k] = b->kp_left[i].x; h_bxy[2 * k + 1] = b->kp_left[i].y;
+	}
+	const int32_t off[4] = {0, na, 0, nb};
+	SSK_HIP(ctx, hipMemcpyAsync(d_da, a->desc_left, nLa * 32, hipMemcpyHostToDevice, ctx->stream));
+	if (b->n_left > 0) SSK_HIP(ctx, hipMemcpyAsync(d_db, b->desc_left, (size_t)b->n_left * 32, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_ga, h_ga, sa * 4, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_axy, h_axy, sa * 8, hipMemcpyHostToDevice, ctx->stream));
+	if (nb > 0) {
+		SSK_HIP(ctx, hipMemcpyAsync(d_gb, h_gb, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
+		SSK_HIP(ctx, hipMemcpyAsync(d_bxy, h_bxy, (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream));
+	}
+	SSK_HIP(ctx, hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
+	if ((rc = ssk_launch_hamming(ctx, d_da, d_off, d_ga, d_db, d_off + 2, d_gb, 1, na, d_idx, d_dist))) return rc;
+	if ((rc = run_filters_and_fetch(ctx, d_idx, d_dist, d_off, d_axy, d_bxy, params, na, d_status, d_tracked, h_status, h_tracked))) return rc;
+	SSK_HIP(ctx, hipMemcpyAsync(h_idx, d_idx, sa * 4, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(h_dist, d_dist, sa * 4, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (int k = 0; k < na; ++k) {
+		out_matches[k].queryIdx = k; out_matches[k].trainIdx = h_idx[k]; out_matches[k].imgIdx = 0;
+		out_matches[k].distance = nb > 0 ? (float)h_dist[k] : 3.402823466e+38f;
+		out_status[k] = h_status[k];
+	}
+	*out_tracked = *h_tracked;
+	return SSK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// ssk_context.hip -- context, error text, arenas, stream + HIP-event timer of libssk_hip.so.
+#include "ssk_internal.h"
+#include <cmath>
+
+static std::string g_create_error;
+
+int ssk_set_error(ssk_ctx* ctx, int code, const char* fmt, ...)
+{
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (ctx) ctx->err = buf; else g_create_error = buf;
+	return code;
+}
+
+int ssk_arena_reserve(ssk_ctx* ctx, ssk_arena& a, size_t bytes)
+{
+	bytes += 4096;
+	if (bytes <= a.cap) return SSK_OK;
+	size_t ncap = a.cap ? a.cap : (size_t(1) << 20);
+	while (ncap < bytes) ncap *= 2;
+	// the old block may still be referenced by queued work: make the stream idle first
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (a.base) {
+		if (a.pinned_host) SSK_HIP(ctx, hipHostFree(a.base)); else SSK_HIP(ctx, hipFree(a.base));
+		a.base = nullptr; a.cap = 0;
+	}
+	if (a.pinned_host) SSK_HIP(ctx, hipHostMalloc(&a.base, ncap, hipHostMallocDefault));
+	else SSK_HIP(ctx, hipMalloc(&a.base, ncap));
+	a.cap = ncap;
+	a.used = 0;
+	return SSK_OK;
+}
+
+// ---- direction-filter thresholds -------------------------------------------------------------------
+// The reference bins a match direction as  floor((180/M_PI*atanf(q)+180.)/10)  (EST.cpp:1915-1916) with
+// the C library's atanf.  atanf is monotone, so the bin is a step function of the float quotient q.
+// We find, with THIS host's libm, the smallest float q whose bin is >= b for b = 9..27 (bins 8..27 are
+// the only reachable ones: atanf in [-pi/2,pi/2] rounds to ang in [89.9999975, 270.0000025]).  The GPU
+// then bins by comparing q against the 19 thresholds: identical bins to the libm formula for every
+// float q, with no device atanf involved.
+static int ref_bin(float q)
+{
+	const double ang = 180 / M_PI * atanf(q) + 180.;
+	return (int)std::floor(ang / 10);
+}
+static inline int32_t float_to_ordered(float f)
+{
+	int32_t i; std::memcpy(&i, &f, 4);
+	return i >= 0 ? i : (int32_t)(0x80000000u - (uint32_t)i);   // monotone in f, -0 == +0 -> 0
+}
+static inline float ordered_to_float(int32_t o)
+{
+	int32_t i = o >= 0 ? o : (int32_t)(0x80000000u - (uint32_t)o);
+	float f; std::memcpy(&f, &i, 4);
+	return f;
+}
+static void compute_dir_thresholds(float out[19])
+{
+	const int32_t lo_all = float_to_ordered(-INFINITY), hi_all = float_to_ordered(INFINITY);
+	for (int b = 9; b <= 27; ++b) {
+		// smallest ordered key k in [lo_all, hi_all] with ref_bin(key) >= b; ref_bin(+inf) == 27 >= b
+		int64_t lo = lo_all, hi = hi_all;
+		while (lo < hi) {
+			const int64_t mid = lo + (hi - lo) / 2;
+			if (ref_bin(ordered_to_float((int32_t)mid)) >= b) hi = mid; else lo = mid + 1;
+		}
+		out[b - 9] = ordered_to_float((int32_t)lo);
+	}
+}
+
+extern "C" {
+
+int ssk_api_version(void) { return SSK_API_VERSION; }
+
+const char* ssk_last_error(const ssk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ssk_create(ssk_ctx** out, int device, void* hip_stream)
+{
+	if (!out) return ssk_set_error(nullptr, SSK_ERR_BAD_ARG, "ssk_create: out is NULL");
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return ssk_set_error(nullptr, SSK_ERR_NO_DEVICE,
+		                     "ssk_create: no HIP device (%s); libssk_hip has no CPU fallback",
+		                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+	if (device < 0 || device >= ndev)
+		return ssk_set_error(nullptr, SSK_ERR_BAD_ARG, "ssk_create: device %d out of range [0,%d)", device, ndev);
+	hipDeviceProp_t prop;
+	if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+		return ssk_set_error(nullptr, SSK_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return ssk_set_error(nullptr, SSK_ERR_NO_DEVICE,
+		                     "ssk_create: device %d is %s; this library carries gfx950 (MI355X) code only",
+		                     device, prop.gcnArchName);
+	ssk_ctx* ctx = new ssk_ctx();
+	ctx->device = device;
+	ctx->n_cu = prop.multiProcessorCount;
+	ctx->pin.pinned_host = true;
+#define CREATE_HIP(call)                                                                           \
+	do { hipError_t e2 = (call); if (e2 != hipSuccess) {                                           \
+		int rc = ssk_set_error(nullptr, SSK_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2)); \
+		delete ctx; return rc; } } while (0)
+	CREATE_HIP(hipSetDevice(device));
+	if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
+	else { CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+	CREATE_HIP(hipEventCreate(&ctx->ev_start));
+	CREATE_HIP(hipEventCreate(&ctx->ev_stop));
+	compute_dir_thresholds(ctx->dir_thresh);
+	CREATE_HIP(hipMalloc((void**)&ctx->d_dir_thresh, sizeof ctx->dir_thresh));
+	CREATE_HIP(hipMemcpy(ctx->d_dir_thresh, ctx->dir_thresh, sizeof ctx->dir_thresh, hipMemcpyHostToDevice));
+#undef CREATE_HIP
+	*out = ctx;
+	return SSK_OK;
+}
+
+void ssk_destroy(ssk_ctx* ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	if (ctx->dev.base) (void)hipFree(ctx->dev.base);
+	if (ctx->pin.base) (void)hipHostFree(ctx->pin.base);
+	if (ctx->d_dir_thresh) (void)hipFree(ctx->d_dir_thresh);
+	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+	if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+int ssk_synchronize(ssk_ctx* ctx)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return SSK_OK;
+}
+
+void* ssk_stream(ssk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ssk_timer_start(ssk_ctx* ctx)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	SSK_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+	return SSK_OK;
+}
+
+int ssk_timer_stop_ms(ssk_ctx* ctx, float* ms)
+{
+	if (!ctx || !ms) return SSK_ERR_BAD_ARG;
+	SSK_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+	SSK_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+	SSK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+	return SSK_OK;
+}
+
+// test hook (declared in include/ssk_capi.h): the 19 direction-bin thresholds the context computed.
+int ssk_debug_direction_thresholds(ssk_ctx* ctx, float* out19)
+{
+	if (!ctx || !out19) return SSK_ERR_BAD_ARG;
+	std::memcpy(out19, ctx->dir_thresh, sizeof ctx->dir_thresh);
+	return SSK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// ssk_internal.h -- shared internals of libssk_hip.so (context, error plumbing, arenas).
+// Product code: nothing here may include or call anything under oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/ssk_capi.h"
+
+// Growable bump arena (device or pinned-host).  Host entry points stage one keyframe's worth of
+// data through these; batched "_dev" entry points never touch them.
+struct ssk_arena {
+	void* base = nullptr;
+	size_t cap = 0, used = 0;
+	bool pinned_host = false;
+};
+
+struct ssk_ctx {
+	int device = -1;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	std::string err;
+	ssk_arena dev, pin;
+	std::vector<void*> retired;        // arenas replaced by bigger ones; freed at destroy / next sync
+	// direction-filter bin thresholds (see ssk_da_filters.hip): smallest float quotient mapped to
+	// bin >= b for b = 9..27, computed once on the host with the host libm's atanf.
+	float dir_thresh[19];
+	float* d_dir_thresh = nullptr;
+	int n_cu = 256;
+};
+
+int ssk_set_error(ssk_ctx* ctx, int code, const char* fmt, ...);
+
+#define SSK_HIP(ctx, call)                                                                         \
+	do {                                                                                           \
+		hipError_t e__ = (call);                                                                   \
+		if (e__ != hipSuccess)                                                                     \
+			return ssk_set_error((ctx), SSK_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+			                     hipGetErrorString(e__), __FILE__, __LINE__);                      \
+	} while (0)
+
+#define SSK_LAUNCH_CHECK(ctx, name)                                                                \
+	do {                                                                                           \
+		hipError_t e__ = hipGetLastError();                                                        \
+		if (e__ != hipSuccess)                                                                     \
+			return ssk_set_error((ctx), SSK_ERR_HIP, "launch of %s failed: %s", name,              \
+			                     hipGetErrorString(e__));                                          \
+	} while (0)
+
+// arena helpers: reset at the start of a host entry point, then carve 256-B aligned pieces.
+int ssk_arena_reserve(ssk_ctx* ctx, ssk_arena& a, size_t bytes);
+inline void ssk_arena_reset(ssk_arena& a) { a.used = 0; }
+template <typename T>
+inline T* ssk_arena_take(ssk_arena& a, size_t count)
+{
+	size_t off = (a.used + 255) & ~size_t(255);
+	a.used = off + count * sizeof(T);
+	return reinterpret_cast<T*>(static_cast<char*>(a.base) + off);
+}
+inline size_t ssk_pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+
+// kernels' host-side launchers shared between translation units
+int ssk_launch_hamming(ssk_ctx* ctx, const uint8_t* d_q, const int32_t* d_q_off, const int32_t* d_q_gather,
+                       const uint8_t* d_t, const int32_t* d_t_off, const int32_t* d_t_gather,
+                       int n_pairs, int max_nq, int32_t* d_train_idx, int32_t* d_dist);
+int ssk_launch_da_filters(ssk_ctx* ctx, const int32_t* d_train_idx, const int32_t* d_dist,
+                          const int32_t* d_q_off, const int32_t* d_t_off,
+                          const float* d_this_xy, const float* d_other_xy,
+                          int n_pairs, const ssk_da_params& prm, int32_t* d_status, int32_t* d_tracked);

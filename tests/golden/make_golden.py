@@ -1,0 +1,36 @@
+"""Regenerates the committed golden fixtures from the CPU oracle on seeded synthetic inputs.
+
+The reference tree has no tests, fixtures or golden outputs and cannot be built here (SURVEY.md
+section 4 / 8(c)), so these vectors pin the ORACLE against regressions; they are not reference outputs.
+Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle_lib as ol   # noqa: E402
+import synth              # noqa: E402
+
+
+def make_da(oracle):
+    for i, (seed, nf, nm, prm) in enumerate([(101, 160, 90, (1, 1, 370, 60.0)), (102, 500, 320, (1, 1, 370, 60.0))]):
+        rng = np.random.default_rng(seed)
+        a, b = synth.synth_kf_pair(rng, nf, nm)
+        va, ka = ol.make_kf_view(**a)
+        vb, kb = ol.make_kf_view(**b)
+        out, st, tracked = oracle.data_association(va, vb, ol.DaParams(*prm))
+        d = {"a_" + k: v for k, v in a.items()}
+        d.update({"b_" + k: v for k, v in b.items()})
+        np.savez_compressed(os.path.join(HERE, "da_case%d.npz" % i), prm=np.array(prm, np.float64),
+                            exp_trainIdx=out["trainIdx"], exp_distance=out["distance"], exp_status=st,
+                            exp_tracked=np.int32(tracked), **d)
+
+
+if __name__ == "__main__":
+    o = ol.load()
+    make_da(o)
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,121 @@
+"""ctypes binding of the CPU oracle (oracle/, test infrastructure).  Only tests/, smoke() and the
+cpu_baseline leg of bench.py import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+
+class KfView(C.Structure):
+    _fields_ = [("kp_left", C.c_void_p), ("n_left", C.c_int32),
+                ("kp_right", C.c_void_p), ("n_right", C.c_int32),
+                ("desc_left", C.c_void_p), ("desc_right", C.c_void_p),
+                ("matches", C.c_void_p), ("n_matches", C.c_int32)]
+
+
+class DaParams(C.Structure):
+    _fields_ = [("filter_by_direction", C.c_int32), ("filter_by_orb_distance", C.c_int32),
+                ("rows_offset", C.c_int32), ("max_orb_distance_da", C.c_float)]
+
+
+class StereoCam(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")]
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
+
+
+class Oracle:
+    def __init__(self, path):
+        self.lib = C.CDLL(path)
+
+    def hamming_match(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(q), DMATCH_DTYPE)
+        n = self.lib.ssko_hamming_match(_p(q), len(q), _p(t), len(t), _p(out))
+        return out[:n]
+
+    def da_filter_direction(self, matches, this_xy, other_xy, offset, status):
+        m = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        st = np.ascontiguousarray(status, np.int32).copy()
+        a = np.ascontiguousarray(this_xy, np.float32)
+        b = np.ascontiguousarray(other_xy, np.float32)
+        self.lib.ssko_da_filter_direction(_p(m), len(m), _p(a), _p(b), int(offset), _p(st))
+        return st
+
+    def da_filter_orb_distance(self, matches, n_other, max_orb, status):
+        m = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        st = np.ascontiguousarray(status, np.int32).copy()
+        self.lib.ssko_da_filter_orb_distance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        self.lib.ssko_da_filter_orb_distance(_p(m), len(m), int(n_other), float(max_orb), _p(st))
+        return st
+
+    def da_filters(self, matches, n_other, this_xy, other_xy, prm):
+        st = np.zeros(len(matches), np.int32)
+        if prm.filter_by_direction:
+            st = self.da_filter_direction(matches, this_xy, other_xy, prm.rows_offset, st)
+        if prm.filter_by_orb_distance:
+            st = self.da_filter_orb_distance(matches, n_other, prm.max_orb_distance_da, st)
+        return st, int((st == 0).sum())
+
+    def data_association(self, this_view, other_view, prm):
+        n = this_view.n_matches
+        out = np.zeros(n, DMATCH_DTYPE)
+        st = np.zeros(n, np.int32)
+        tracked = self.lib.ssko_data_association(C.byref(this_view), C.byref(other_view), C.byref(prm), _p(out), _p(st))
+        return out, st, tracked
+
+    def propagate_ids(self, tracking_first, other_ids, last_id):
+        tf = np.ascontiguousarray(tracking_first, np.int32)
+        n_sim, n_m = tf.shape
+        ids = [np.ascontiguousarray(o, np.uint64) for o in other_ids]
+        arr = (C.c_void_p * max(1, n_sim))(*[o.ctypes.data for o in ids])
+        last = C.c_uint64(last_id)
+        out = np.zeros(n_m, np.uint64)
+        per = np.zeros(max(1, n_sim), np.int32)
+        nt = self.lib.ssko_propagate_ids(n_m, n_sim, _p(tf), arr, C.byref(last), _p(out), _p(per))
+        return out, per[:n_sim], nt, last.value
+
+    def project_match_to_3d(self, ul, vl, ur, cam):
+        out = (C.c_double * 3)()
+        self.lib.ssko_project_match_to_3d.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        self.lib.ssko_project_match_to_3d(ul, vl, ur, C.byref(cam), out)
+        return np.array(out[:])
+
+
+def make_kf_view(kp_left, kp_right, desc_left, desc_right, matches):
+    kp_left = np.ascontiguousarray(kp_left, dtype=KEYPOINT_DTYPE)
+    kp_right = np.ascontiguousarray(kp_right, dtype=KEYPOINT_DTYPE)
+    desc_left = np.ascontiguousarray(desc_left, dtype=np.uint8).reshape(-1, 32)
+    desc_right = np.ascontiguousarray(desc_right, dtype=np.uint8).reshape(-1, 32)
+    matches = np.ascontiguousarray(matches, dtype=DMATCH_DTYPE)
+    v = KfView(_p(kp_left), len(kp_left), _p(kp_right), len(kp_right), _p(desc_left), _p(desc_right),
+               _p(matches), len(matches))
+    return v, (kp_left, kp_right, desc_left, desc_right, matches)
+
+
+_ORACLE = None
+
+
+def load(march=None, out=None):
+    global _ORACLE
+    if march or out:
+        import __graft_entry__ as ge
+        return Oracle(ge.build_oracle(march=march, out=out))
+    if _ORACLE is None:
+        path = os.path.join(ROOT, "oracle", "_build", "libssk_oracle.so")
+        srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
+                if f.endswith((".c", ".h"))]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+        _ORACLE = Oracle(path)
+    return _ORACLE

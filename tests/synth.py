@@ -1,0 +1,63 @@
+"""Seeded synthetic inputs shaped like the reference's keyframes."""
+import numpy as np
+
+from oracle_lib import DMATCH_DTYPE, KEYPOINT_DTYPE
+
+W, H = 1241, 376          # BASELINE.json image shape
+KITTI = dict(fx=707.0912, fy=707.0912, cx=601.8873, cy=183.1104, baseline=0.54, rows=370, cols=1226)
+
+
+def random_descriptors(rng, n):
+    return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+
+
+def flip_bits(rng, desc, nbits):
+    """Return a copy of desc with nbits[i] random bit flips in row i."""
+    out = desc.copy()
+    for i, nb in enumerate(np.broadcast_to(nbits, (len(desc),))):
+        pos = rng.choice(256, size=int(nb), replace=False)
+        for p in pos:
+            out[i, p >> 3] ^= np.uint8(1 << (p & 7))
+    return out
+
+
+def synth_kf(rng, n_left=500, n_right=500, n_matches=300, integer_px=True):
+    """One keyframe: keypoints L/R, descriptors L/R, L<->R matches (queryIdx=left, trainIdx=right)."""
+    kpl = np.zeros(n_left, KEYPOINT_DTYPE)
+    kpr = np.zeros(n_right, KEYPOINT_DTYPE)
+    for kp, n in ((kpl, n_left), (kpr, n_right)):
+        xs = rng.uniform(31, W - 32, n)
+        ys = rng.uniform(31, H - 32, n)
+        if integer_px:
+            xs, ys = np.floor(xs), np.floor(ys)
+        kp["x"], kp["y"] = xs, ys
+        kp["size"], kp["angle"], kp["response"] = 31, rng.uniform(0, 360, n), rng.uniform(0, 1, n)
+    dl = random_descriptors(rng, n_left)
+    dr = random_descriptors(rng, n_right)
+    n_matches = min(n_matches, n_left, n_right)
+    m = np.zeros(n_matches, DMATCH_DTYPE)
+    m["queryIdx"] = np.sort(rng.choice(n_left, n_matches, replace=False))
+    m["trainIdx"] = rng.choice(n_right, n_matches, replace=False)
+    m["distance"] = rng.integers(0, 60, n_matches)
+    return dict(kp_left=kpl, kp_right=kpr, desc_left=dl, desc_right=dr, matches=m)
+
+
+def synth_kf_pair(rng, n_feats=500, n_matches=300, overlap=0.7, motion=(6.0, -2.0), noise_bits=12, outlier_frac=0.1):
+    """Two keyframes where a fraction `overlap` of kf_b's matched left features reappear in kf_a moved by
+    roughly `motion` pixels with `noise_bits`-ish descriptor bit flips; a few are gross outliers."""
+    b = synth_kf(rng, n_feats, n_feats, n_matches)
+    a = synth_kf(rng, n_feats, n_feats, n_matches)
+    nm = len(b["matches"])
+    n_shared = int(overlap * min(nm, len(a["matches"])))
+    src = rng.choice(nm, n_shared, replace=False)
+    dst = rng.choice(len(a["matches"]), n_shared, replace=False)
+    for s, d in zip(src, dst):
+        ib = b["matches"]["queryIdx"][s]
+        ia = a["matches"]["queryIdx"][d]
+        bits = int(rng.integers(0, 2 * noise_bits + 1))
+        a["desc_left"][ia] = flip_bits(rng, b["desc_left"][ib:ib + 1], bits)[0]
+        if rng.uniform() < outlier_frac:
+            continue   # descriptor matches, geometry does not
+        a["kp_left"]["x"][ia] = np.clip(np.floor(b["kp_left"]["x"][ib] + motion[0] + rng.normal(0, 1.5)), 31, W - 32)
+        a["kp_left"]["y"][ia] = np.clip(np.floor(b["kp_left"]["y"][ib] + motion[1] + rng.normal(0, 1.5)), 31, H - 32)
+    return a, b
