@@ -44,6 +44,11 @@ def load_library():
         if not os.path.exists(p):
             raise ImportError("libssk_hip.so is not built: run `python __graft_entry__.py build` "
                               "(there is no CPU fallback)")
+        # One HIP/HSA runtime per process: torch ships its own libamdhip64.so.7 / libhsa-runtime64 and
+        # libssk_hip.so needs the same SONAME.  Importing torch first makes the dynamic loader bind our
+        # library to the runtime torch already loaded (a second HSA runtime in the process cannot open
+        # the GPU: "No HIP GPUs are available").  A C++ host without torch simply uses /opt/rocm's.
+        import torch  # noqa: F401
         _LIB = C.CDLL(p)
         _LIB.ssk_last_error.restype = C.c_char_p
         _LIB.ssk_stream.restype = C.c_void_p
