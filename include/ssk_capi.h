@@ -129,6 +129,70 @@ int ssk_da_filters(ssk_ctx* ctx, const ssk_dmatch* matches, int n_this, int n_ot
                    const float* this_xy, const float* other_xy, const ssk_da_params* params,
                    int32_t* status, int32_t* out_tracked);
 
+/* ---- B1: stereo front-end ------------------------------------------------------------------------
+ * Supplies the definition CStereoSLAMKF::create() lacks (declared KF.h:82-86, defined nowhere) and
+ * replaces the live equivalent  m_voEngine.processNewImagePair() + getValues()
+ * (EST.cpp:112,267; KF.h:68-70), i.e. stereo-vo's ORB detect/describe (via cv::ORB) and its
+ * "descriptor row-by-row" L<->R matcher (EST.cpp:1135-1137).  Algorithm contract: DESIGN.md
+ * "Front-end contract"; parameters and their reference origin: */
+typedef struct ssk_frontend_params {
+	int32_t n_feats;          /* ORB nfeatures: srba_options.n_feats -> orb_nfeats (EST.cpp:1142, KITTI.ini:112); <= 2048 */
+	int32_t fast_threshold;   /* FAST threshold: detect_fast_th -> initial_FAST_threshold (EST.cpp:1140, KITTI.ini:114) */
+	int32_t n_levels;         /* must be 1: n_levels -> orb_nlevels (EST.cpp:1141, UTIL.h:288, KITTI.ini:5) */
+	int32_t nms_radius;       /* keypoint non-max suppression half window; 2 = the "5x5 windows" of KITTI.ini:12; 0 = off */
+	int32_t orb_max_distance; /* max Hamming distance of an accepted L<->R match (KITTI.ini:24) */
+	float   max_y_diff;       /* epipolar band |yL-yR| <= max_y_diff (KITTI.ini:17) */
+	float   min_disparity;    /* accepted iff min_disparity <= xL-xR <= max_disparity (positive depth) */
+	float   max_disparity;
+	float   harris_k;         /* 0.04: cv::ORB HARRIS_SCORE */
+} ssk_frontend_params;
+/* KITTI.ini values: {500, 20, 1, 2, 60, 2.0f, 1.0f, (float)width, 0.04f} */
+
+/* One keyframe out, caller-allocated arrays of `capacity` (>= n_feats) records each (a1: KF.h:99-104). */
+typedef struct ssk_kf_out {
+	int32_t capacity;
+	ssk_keypoint* kp_left;  ssk_keypoint* kp_right;
+	uint8_t* desc_left;     uint8_t* desc_right;      /* capacity x 32 */
+	ssk_dmatch* matches;                              /* queryIdx = left kp, trainIdx = right kp */
+	int32_t n_left, n_right, n_matches;               /* filled by the call */
+} ssk_kf_out;
+
+/* BRIEF sampling pattern: 256 tests x (x0,y0,x1,y1) int8, |v| <= 13.  Default: include/ssk_brief_pattern.h. */
+int ssk_set_brief_pattern(ssk_ctx* ctx, const int8_t* pattern1024);
+int ssk_get_brief_pattern(ssk_ctx* ctx, int8_t* pattern1024);
+
+/* Host drop-in, one stereo pair (8-bit gray, `stride` bytes between rows):
+ * detect + describe both images, match L<->R, fill `out`.  Does NOT throw on few matches: the
+ * adaptive-threshold loop and the "< 8 matches" exception (EST.cpp:271-315) live in the C++ facade. */
+int ssk_frontend_run(ssk_ctx* ctx, const uint8_t* left, const uint8_t* right, int width, int height,
+                     int stride, const ssk_frontend_params* params, ssk_kf_out* out);
+
+/* Device-resident batch of keyframes (images, keypoints, descriptors, matches all stay in HBM). */
+typedef struct ssk_kfbatch ssk_kfbatch;
+int ssk_kfbatch_create(ssk_ctx* ctx, int n_kf, int width, int height, int max_feats, ssk_kfbatch** out);
+void ssk_kfbatch_destroy(ssk_kfbatch* b);
+/* Device image storage: pixel (x,y) of eye e (0 left, 1 right) of keyframe k is at
+ * d_images[((k*2+e)*height + y)*pitch + x]. */
+int ssk_kfbatch_images(ssk_kfbatch* b, uint8_t** d_images, int* pitch);
+int ssk_kfbatch_upload(ssk_ctx* ctx, ssk_kfbatch* b, int kf, const uint8_t* left, const uint8_t* right, int stride);
+/* Front-end over keyframes [kf_begin, kf_end) of the batch, asynchronous on the context stream. */
+int ssk_frontend_run_batch(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, const ssk_frontend_params* params);
+/* Synchronises, then packs keyframe `kf` into the reference's AoS records. */
+int ssk_kfbatch_download(ssk_ctx* ctx, ssk_kfbatch* b, int kf, ssk_kf_out* out);
+/* Device-side counts (int32 [n_kf*2] keypoints per image, [n_kf] matches), for benchmarks / checksums. */
+int ssk_kfbatch_counts(ssk_ctx* ctx, ssk_kfbatch* b, int32_t* h_n_kp /* n_kf*2 */, int32_t* h_n_matches /* n_kf */);
+/* Debug/test hook: FAST+NMS candidates of image (kf, eye) as packed keys
+ * (score<<24 | (4095-y)<<12 | (4095-x)), sorted descending. Returns the count in *n (may exceed cap). */
+int ssk_kfbatch_debug_candidates(ssk_ctx* ctx, ssk_kfbatch* b, int kf, int eye, uint32_t* keys, int cap, int* n);
+
+/* Batched data association between keyframes of two device-resident batches (B2 on HBM-resident data):
+ * pair p associates keyframe pairs[2p] of `this_b` with keyframe pairs[2p+1] of `other_b` (host int32
+ * array).  Outputs are device int32 arrays, row p holds max_feats entries (only the first n_matches of
+ * the "this" keyframe are meaningful): d_train_idx, d_dist, d_status [n_pairs*max_feats], d_tracked [n_pairs]. */
+int ssk_da_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
+                     const ssk_da_params* params, int32_t* d_train_idx, int32_t* d_dist, int32_t* d_status,
+                     int32_t* d_tracked);
+
 /* Test hook: the 19 float thresholds the context derived from the host libm's atanf for the
  * direction bins 9..27 (see csrc/ssk_context.hip). */
 int ssk_debug_direction_thresholds(ssk_ctx* ctx, float* out19);

@@ -69,6 +69,20 @@ typedef struct ssko_stereo_cam {   /* mrpt::utils::TStereoCamera fields the path
 /* [literal UTIL.h:558-574] */
 void ssko_project_match_to_3d(double ul, double vl, double ur, const ssko_stereo_cam* cam, double out_xyz[3]);
 
+/* ---------------- stereo front-end (oracle_orb.c): contract C1-C10 in that file ---------------- */
+void ssko_fast_score_map(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score /* w*h */);
+int ssko_fast_candidates(const uint8_t* img, int w, int h, int stride, int threshold, uint32_t* keys, int cap);
+float ssko_harris_response(const uint8_t* img, int stride, int x, int y, float harris_k);
+float ssko_atan2_deg(float y, float x);
+void ssko_orient_describe(const uint8_t* img, int stride, int x, int y, const int8_t* pattern,
+                          float* angle_deg, uint8_t* desc32);
+int ssko_orb_detect(const uint8_t* img, int w, int h, int stride, const ssk_frontend_params* prm,
+                    const int8_t* pattern, ssk_keypoint* kp, uint8_t* desc, int cap);
+int ssko_stereo_match(const ssk_keypoint* kl, int nl, const uint8_t* dl, const ssk_keypoint* kr, int nr,
+                      const uint8_t* dr, const ssk_frontend_params* prm, ssk_dmatch* out);
+int ssko_frontend(const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                  const ssk_frontend_params* prm, const int8_t* pattern, ssk_kf_out* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,97 @@ class DaParams(C.Structure):
                 ("rows_offset", C.c_int32), ("max_orb_distance_da", C.c_float)]
 
 
+class FrontendParams(C.Structure):
+    _fields_ = [("n_feats", C.c_int32), ("fast_threshold", C.c_int32), ("n_levels", C.c_int32),
+                ("nms_radius", C.c_int32), ("orb_max_distance", C.c_int32), ("max_y_diff", C.c_float),
+                ("min_disparity", C.c_float), ("max_disparity", C.c_float), ("harris_k", C.c_float)]
+
+
+class KfOut(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("kp_left", C.c_void_p), ("kp_right", C.c_void_p),
+                ("desc_left", C.c_void_p), ("desc_right", C.c_void_p), ("matches", C.c_void_p),
+                ("n_left", C.c_int32), ("n_right", C.c_int32), ("n_matches", C.c_int32)]
+
+
+def alloc_kf_out(cap):
+    arrs = dict(kp_left=np.zeros(cap, KEYPOINT_DTYPE), kp_right=np.zeros(cap, KEYPOINT_DTYPE),
+                desc_left=np.zeros((cap, 32), np.uint8), desc_right=np.zeros((cap, 32), np.uint8),
+                matches=np.zeros(cap, DMATCH_DTYPE))
+    o = KfOut(cap, arrs["kp_left"].ctypes.data, arrs["kp_right"].ctypes.data, arrs["desc_left"].ctypes.data,
+              arrs["desc_right"].ctypes.data, arrs["matches"].ctypes.data, 0, 0, 0)
+    return o, arrs
+
+
+def trim_kf_out(o, arrs):
+    return dict(kp_left=arrs["kp_left"][:o.n_left].copy(), kp_right=arrs["kp_right"][:o.n_right].copy(),
+                desc_left=arrs["desc_left"][:o.n_left].copy(), desc_right=arrs["desc_right"][:o.n_right].copy(),
+                matches=arrs["matches"][:o.n_matches].copy())
+
+
+class KfBatch:
+    """ssk_kfbatch wrapper: B keyframes resident in HBM (images, keypoints, descriptors, matches)."""
+
+    def __init__(self, ctx, n_kf, width, height, max_feats=512):
+        self.ctx, self.n_kf, self.w, self.h, self.max_feats = ctx, n_kf, width, height, max_feats
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.ssk_kfbatch_create(ctx.h, n_kf, width, height, max_feats, C.byref(h)))
+        self.h_ = h
+        img = C.c_void_p()
+        pitch = C.c_int()
+        ctx._chk(ctx.lib.ssk_kfbatch_images(self.h_, C.byref(img), C.byref(pitch)))
+        self.d_images, self.pitch = img.value, pitch.value
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.ctx.lib.ssk_kfbatch_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def image_tensor(self):
+        """torch uint8 view [n_kf, 2, H, pitch] of the device image storage (no copy)."""
+        import torch
+
+        class _Arr:
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = {"shape": (self.n_kf, 2, self.h, self.pitch), "typestr": "|u1",
+                                      "data": (self.d_images, False), "version": 3}
+        return torch.as_tensor(a, device="cuda")
+
+    def upload(self, kf, left, right):
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        assert left.shape == (self.h, self.w) and right.shape == (self.h, self.w)
+        self.ctx._chk(self.ctx.lib.ssk_kfbatch_upload(self.ctx.h, self.h_, int(kf), _ptr(left), _ptr(right), self.w))
+
+    def run_frontend(self, prm, kf_begin=0, kf_end=None):
+        self.ctx._chk(self.ctx.lib.ssk_frontend_run_batch(self.ctx.h, self.h_, int(kf_begin),
+                                                          int(self.n_kf if kf_end is None else kf_end), C.byref(prm)))
+
+    def download(self, kf):
+        o, arrs = alloc_kf_out(self.max_feats)
+        self.ctx._chk(self.ctx.lib.ssk_kfbatch_download(self.ctx.h, self.h_, int(kf), C.byref(o)))
+        return trim_kf_out(o, arrs)
+
+    def counts(self):
+        nkp = np.zeros(2 * self.n_kf, np.int32)
+        nm = np.zeros(self.n_kf, np.int32)
+        self.ctx._chk(self.ctx.lib.ssk_kfbatch_counts(self.ctx.h, self.h_, _ptr(nkp), _ptr(nm)))
+        return nkp.reshape(-1, 2), nm
+
+    def debug_candidates(self, kf, eye):
+        cap = (self.w // 2 + 1) * (self.h // 2 + 1)
+        keys = np.zeros(cap, np.uint32)
+        n = C.c_int()
+        self.ctx._chk(self.ctx.lib.ssk_kfbatch_debug_candidates(self.ctx.h, self.h_, int(kf), int(eye), _ptr(keys), cap, C.byref(n)))
+        return keys[:n.value].copy()
+
+
 def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
 
@@ -162,6 +253,29 @@ class Context:
         self._chk(self.lib.ssk_da_filters(self.h, _ptr(m), len(m), int(n_other), _ptr(a), _ptr(b),
                                           C.byref(params), _ptr(status), C.byref(tracked)))
         return status, tracked.value
+
+    # -- B1 ------------------------------------------------------------------------------------------
+    def set_brief_pattern(self, pattern):
+        p = np.ascontiguousarray(pattern, np.int8).reshape(1024)
+        self._chk(self.lib.ssk_set_brief_pattern(self.h, _ptr(p)))
+
+    def get_brief_pattern(self):
+        p = np.zeros(1024, np.int8)
+        self._chk(self.lib.ssk_get_brief_pattern(self.h, _ptr(p)))
+        return p
+
+    def frontend_run(self, left, right, prm):
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        h, w = left.shape
+        o, arrs = alloc_kf_out(max(prm.n_feats, 1))
+        self._chk(self.lib.ssk_frontend_run(self.h, _ptr(left), _ptr(right), w, h, w, C.byref(prm), C.byref(o)))
+        return trim_kf_out(o, arrs)
+
+    def da_run_batch(self, this_b, other_b, pairs, params, d_idx, d_dist, d_status, d_tracked):
+        pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        self._chk(self.lib.ssk_da_run_batch(self.h, this_b.h_, other_b.h_, _ptr(pr), len(pr), C.byref(params),
+                                            _dev(d_idx), _dev(d_dist), _dev(d_status), _dev(d_tracked)))
 
     def data_association(self, this_view, other_view, params):
         n = this_view.n_matches

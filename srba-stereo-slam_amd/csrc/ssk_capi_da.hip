@@ -15,8 +15,8 @@ int ssk_hamming_match_batched_dev(ssk_ctx* ctx,
 	if (n_pairs < 0 || max_query_rows < 0 || !d_q_off || !d_t_off || !d_train_idx || !d_dist ||
 	    (n_pairs > 0 && (!d_desc_q || !d_desc_t)))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_hamming_match_batched_dev: bad argument");
-	return ssk_launch_hamming(ctx, d_desc_q, d_q_off, d_q_gather, d_desc_t, d_t_off, d_t_gather,
-	                          n_pairs, max_query_rows, d_train_idx, d_dist);
+	return ssk_launch_hamming(ctx, d_desc_q, d_q_off, d_q_off + 1, d_q_gather, d_desc_t, d_t_off, d_t_off + 1, d_t_gather,
+	                          nullptr, n_pairs, max_query_rows, d_train_idx, d_dist);
 }
 
 int ssk_hamming_match(ssk_ctx* ctx, const uint8_t* query, int nq, const uint8_t* train, int nt,
@@ -45,7 +45,7 @@ int ssk_hamming_match(ssk_ctx* ctx, const uint8_t* query, int nq, const uint8_t*
 	SSK_HIP(ctx, hipMemcpyAsync(d_q, query, qb, hipMemcpyHostToDevice, ctx->stream));
 	SSK_HIP(ctx, hipMemcpyAsync(d_t, train, tb, hipMemcpyHostToDevice, ctx->stream));
 	SSK_HIP(ctx, hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
-	if ((rc = ssk_launch_hamming(ctx, d_q, d_off, nullptr, d_t, d_off + 2, nullptr, 1, nq, d_idx, d_dist))) return rc;
+	if ((rc = ssk_launch_hamming(ctx, d_q, d_off, d_off + 1, nullptr, d_t, d_off + 2, d_off + 3, nullptr, nullptr, 1, nq, d_idx, d_dist))) return rc;
 	SSK_HIP(ctx, hipMemcpyAsync(h_idx, d_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
 	SSK_HIP(ctx, hipMemcpyAsync(h_dist, d_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -62,7 +62,7 @@ static int run_filters_and_fetch(ssk_ctx* ctx, const int32_t* d_idx, const int32
                                  int32_t* d_status, int32_t* d_tracked, int32_t* h_status, int32_t* h_tracked)
 {
 	int rc;
-	if ((rc = ssk_launch_da_filters(ctx, d_idx, d_dist, d_off, d_off + 2, d_axy, d_bxy, 1, *p, d_status, d_tracked))) return rc;
+	if ((rc = ssk_launch_da_filters(ctx, d_idx, d_dist, nullptr, d_off, d_off + 1, d_off + 2, d_off + 3, d_axy, d_bxy, 1, *p, d_status, d_tracked))) return rc;
 	SSK_HIP(ctx, hipMemcpyAsync(h_status, d_status, (size_t)na * 4, hipMemcpyDeviceToHost, ctx->stream));
 	SSK_HIP(ctx, hipMemcpyAsync(h_tracked, d_tracked, 4, hipMemcpyDeviceToHost, ctx->stream));
 	return SSK_OK;
@@ -181,7 +181,7 @@ int ssk_data_association(ssk_ctx* ctx, const ssk_kf_view* a, const ssk_kf_view* 
 		SSK_HIP(ctx, hipMemcpyAsync(d_bxy, h_bxy, (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream));
 	}
 	SSK_HIP(ctx, hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
-	if ((rc = ssk_launch_hamming(ctx, d_da, d_off, d_ga, d_db, d_off + 2, d_gb, 1, na, d_idx, d_dist))) return rc;
+	if ((rc = ssk_launch_hamming(ctx, d_da, d_off, d_off + 1, d_ga, d_db, d_off + 2, d_off + 3, d_gb, nullptr, 1, na, d_idx, d_dist))) return rc;
 	if ((rc = run_filters_and_fetch(ctx, d_idx, d_dist, d_off, d_axy, d_bxy, params, na, d_status, d_tracked, h_status, h_tracked))) return rc;
 	SSK_HIP(ctx, hipMemcpyAsync(h_idx, d_idx, sa * 4, hipMemcpyDeviceToHost, ctx->stream));
 	SSK_HIP(ctx, hipMemcpyAsync(h_dist, d_dist, sa * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -1,6 +1,9 @@
 // ssk_context.hip -- context, error text, arenas, stream + HIP-event timer of libssk_hip.so.
 #include "ssk_internal.h"
 #include <cmath>
+#include "../../include/ssk_brief_pattern.h"
+
+void ssk_kfbatch_destroy_internal(struct ssk_kfbatch* b);
 
 static std::string g_create_error;
 
@@ -112,6 +115,9 @@ int ssk_create(ssk_ctx** out, int device, void* hip_stream)
 	compute_dir_thresholds(ctx->dir_thresh);
 	CREATE_HIP(hipMalloc((void**)&ctx->d_dir_thresh, sizeof ctx->dir_thresh));
 	CREATE_HIP(hipMemcpy(ctx->d_dir_thresh, ctx->dir_thresh, sizeof ctx->dir_thresh, hipMemcpyHostToDevice));
+	std::memcpy(ctx->pattern, ssk_default_brief_pattern, sizeof ctx->pattern);
+	CREATE_HIP(hipMalloc((void**)&ctx->d_pattern, sizeof ctx->pattern));
+	CREATE_HIP(hipMemcpy(ctx->d_pattern, ctx->pattern, sizeof ctx->pattern, hipMemcpyHostToDevice));
 #undef CREATE_HIP
 	*out = ctx;
 	return SSK_OK;
@@ -124,7 +130,9 @@ void ssk_destroy(ssk_ctx* ctx)
 	(void)hipStreamSynchronize(ctx->stream);
 	if (ctx->dev.base) (void)hipFree(ctx->dev.base);
 	if (ctx->pin.base) (void)hipHostFree(ctx->pin.base);
+	if (ctx->single) ssk_kfbatch_destroy_internal(ctx->single);
 	if (ctx->d_dir_thresh) (void)hipFree(ctx->d_dir_thresh);
+	if (ctx->d_pattern) (void)hipFree(ctx->d_pattern);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

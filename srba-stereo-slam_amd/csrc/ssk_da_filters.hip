@@ -22,7 +22,9 @@ constexpr int MAXM = 4096;   // matches per keyframe this kernel supports (refer
 
 __global__ __launch_bounds__(64)
 void da_filters_kernel(const int32_t* __restrict__ train_idx, const int32_t* __restrict__ dist,
-                       const int32_t* __restrict__ q_off, const int32_t* __restrict__ t_off,
+                       const int32_t* __restrict__ out_beg,
+                       const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end,
+                       const int32_t* __restrict__ t_beg, const int32_t* __restrict__ t_end,
                        const float* __restrict__ this_xy, const float* __restrict__ other_xy,
                        const float* __restrict__ dir_thresh,
                        int filter_dir, int filter_orb, float rows_offset, float max_orb,
@@ -37,8 +39,9 @@ void da_filters_kernel(const int32_t* __restrict__ train_idx, const int32_t* __r
 	__shared__ float s_th[19];
 
 	const int pair = blockIdx.x, lane = threadIdx.x;
-	const int q0 = q_off[pair], n_this = q_off[pair + 1] - q0;
-	const int t0 = t_off[pair], n_other = t_off[pair + 1] - t0;
+	const int q0 = q_beg[pair], n_this = min(q_end[pair] - q0, MAXM);
+	const int t0 = t_beg[pair], n_other = min(t_end[pair] - t0, MAXM);
+	const int o0 = out_beg ? out_beg[pair] : q0;          // row of match 0 in train_idx/dist/status
 
 	if (lane < 36) s_hist[lane] = 0;
 	if (lane < 19) s_th[lane] = dir_thresh[lane];
@@ -47,14 +50,14 @@ void da_filters_kernel(const int32_t* __restrict__ train_idx, const int32_t* __r
 	__syncthreads();
 
 	if (n_other <= 0) {       // BFMatcher returned nothing: nothing can be tracked
-		for (int k = lane; k < n_this; k += 64) status_out[q0 + k] = SSK_DA_NON_TRACKED;
+		for (int k = lane; k < n_this; k += 64) status_out[o0 + k] = SSK_DA_NON_TRACKED;
 		if (lane == 0) tracked_out[pair] = 0;
 		return;
 	}
 
 	if (filter_dir) {
 		for (int k = lane; k < n_this; k += 64) {
-			const int j = train_idx[q0 + k];
+			const int j = train_idx[o0 + k];
 			const float tx = this_xy[2 * (size_t)(q0 + k)], ty = this_xy[2 * (size_t)(q0 + k) + 1];
 			const float ox = other_xy[2 * (size_t)(t0 + j)];
 			const float oy = __fadd_rn(other_xy[2 * (size_t)(t0 + j) + 1], rows_offset);   // EST.cpp:1913
@@ -90,8 +93,8 @@ void da_filters_kernel(const int32_t* __restrict__ train_idx, const int32_t* __r
 		float counter = 0.f;   // size_t stage1_counter; exact in float for counts < 2^24
 		for (int k = 0; k < n_this; ++k) {
 			if (s_status[k] != SSK_DA_TRACKED) continue;                                      // :1969
-			const float d = (float)dist[q0 + k];
-			const int t = train_idx[q0 + k];
+			const float d = (float)dist[o0 + k];
+			const int t = train_idx[o0 + k];
 			if ((double)d > (double)max_orb) { s_status[k] = SSK_DA_REJ_ORB; continue; }       // :1980
 			if (d > s_second[t]) { s_status[k] = SSK_DA_NON_TRACKED; continue; }               // :1988
 			const int prev = s_first[t];
@@ -106,7 +109,7 @@ void da_filters_kernel(const int32_t* __restrict__ train_idx, const int32_t* __r
 	int cnt = 0;
 	for (int k = lane; k < n_this; k += 64) {
 		const int s = s_status[k];
-		status_out[q0 + k] = s;
+		status_out[o0 + k] = s;
 		cnt += (s == SSK_DA_TRACKED);
 	}
 	for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
@@ -115,14 +118,14 @@ void da_filters_kernel(const int32_t* __restrict__ train_idx, const int32_t* __r
 
 }  // namespace
 
-int ssk_launch_da_filters(ssk_ctx* ctx, const int32_t* d_train_idx, const int32_t* d_dist,
-                          const int32_t* d_q_off, const int32_t* d_t_off,
+int ssk_launch_da_filters(ssk_ctx* ctx, const int32_t* d_train_idx, const int32_t* d_dist, const int32_t* d_out_beg,
+                          const int32_t* d_q_beg, const int32_t* d_q_end, const int32_t* d_t_beg, const int32_t* d_t_end,
                           const float* d_this_xy, const float* d_other_xy,
                           int n_pairs, const ssk_da_params& prm, int32_t* d_status, int32_t* d_tracked)
 {
 	if (n_pairs <= 0) return SSK_OK;
 	hipLaunchKernelGGL(da_filters_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream,
-	                   d_train_idx, d_dist, d_q_off, d_t_off, d_this_xy, d_other_xy, ctx->d_dir_thresh,
+	                   d_train_idx, d_dist, d_out_beg, d_q_beg, d_q_end, d_t_beg, d_t_end, d_this_xy, d_other_xy, ctx->d_dir_thresh,
 	                   prm.filter_by_direction, prm.filter_by_orb_distance, (float)(size_t)prm.rows_offset,
 	                   prm.max_orb_distance_da, d_status, d_tracked);
 	SSK_LAUNCH_CHECK(ctx, "da_filters_kernel");

@@ -1,0 +1,37 @@
+// ssk_frontend.h -- device-resident keyframe batch and the front-end kernel launchers.
+#pragma once
+#include "ssk_internal.h"
+
+constexpr int SSK_EDGE = 31;         // cv::ORB edgeThreshold: keypoints only in [31, W-31) x [31, H-31)
+constexpr int SSK_MAX_FEATS = 2048;  // n_feats limit (reference: 500)
+
+// HBM layout of a batch of B keyframes (SoA; everything the per-keyframe hot path produces stays here):
+//   img     u8   [B*2][H][pitch]      eye-major inside a keyframe (left, right); pitch % 128 == 0
+//   cand    u32  [B*2][cand_cap]      FAST+NMS candidates, packed score<<24 | (4095-y)<<12 | (4095-x)
+//   ncand   i32  [B*2]
+//   kp_xy   i16x2[B*2][N]   kp_resp f32 [B*2][N]   kp_angle f32 [B*2][N]   kp_cs f32x2 [B*2][N]   nkp i32 [B*2]
+//   desc    u8   [B*2][N][32]
+//   m_q,m_t,m_d i32 [B][N]   nm i32 [B]          L<->R matches in left-keypoint order
+struct ssk_kfbatch {
+	ssk_ctx* ctx = nullptr;
+	int n_kf = 0, w = 0, h = 0, pitch = 0, max_feats = 0, cand_cap = 0;
+	uint8_t* img = nullptr;
+	uint32_t* cand = nullptr;
+	int32_t* ncand = nullptr;
+	short2* kp_xy = nullptr;
+	float* kp_resp = nullptr;
+	float* kp_angle = nullptr;
+	float2* kp_cs = nullptr;
+	int32_t* nkp = nullptr;
+	uint8_t* desc = nullptr;
+	int32_t *m_q = nullptr, *m_t = nullptr, *m_d = nullptr, *nm = nullptr;
+	// match-index gather lists for batched data association: left-keypoint row (absolute in desc pool)
+	// and its pixel coordinates per L<->R match, written by the stereo kernel
+	int32_t* m_row = nullptr;    // [B][N]   absolute descriptor row of the match's left keypoint
+	float2* m_xy = nullptr;      // [B][N]   left keypoint pixel of the match
+};
+
+int ssk_launch_fast(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, int threshold);
+int ssk_launch_select(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, const ssk_frontend_params& p);
+int ssk_launch_describe(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, int n_feats);
+int ssk_launch_stereo(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, const ssk_frontend_params& p);

@@ -20,18 +20,20 @@ constexpr int NW = 4;       // waves per workgroup, each takes every 4th train r
 constexpr int TT = 512;     // train rows per LDS tile (16 KiB)
 
 __global__ __launch_bounds__(QT * NW)
-void hamming_match_kernel(const uint4* __restrict__ desc_q, const int32_t* __restrict__ q_off,
-                          const int32_t* __restrict__ q_gather,
-                          const uint4* __restrict__ desc_t, const int32_t* __restrict__ t_off,
-                          const int32_t* __restrict__ t_gather,
+void hamming_match_kernel(const uint4* __restrict__ desc_q, const int32_t* __restrict__ q_beg,
+                          const int32_t* __restrict__ q_end, const int32_t* __restrict__ q_gather,
+                          const uint4* __restrict__ desc_t, const int32_t* __restrict__ t_beg,
+                          const int32_t* __restrict__ t_end, const int32_t* __restrict__ t_gather,
+                          const int32_t* __restrict__ out_beg,
                           int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist)
 {
 	__shared__ uint4 s_train[TT * 2];
 	__shared__ uint32_t s_key[NW][QT];
 
 	const int pair = blockIdx.y;
-	const int q0 = q_off[pair], q1 = q_off[pair + 1];
-	const int t0 = t_off[pair], t1 = t_off[pair + 1];
+	const int q0 = q_beg[pair], q1 = q_end[pair];
+	const int t0 = t_beg[pair], t1 = t_end[pair];
+	const int o0 = out_beg ? out_beg[pair] - q0 : 0;      // output row = o0 + virtual query row
 	const int qbase = q0 + blockIdx.x * QT;
 	if (qbase >= q1) return;                      // whole workgroup: uniform exit
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -77,26 +79,27 @@ void hamming_match_kernel(const uint4* __restrict__ desc_q, const int32_t* __res
 	if (wave == 0 && q_ok) {
 		const uint32_t k = min(min(s_key[0][lane], s_key[1][lane]), min(s_key[2][lane], s_key[3][lane]));
 		if (nt > 0) {
-			out_idx[qrow] = (int32_t)(k & 0x3FFFFFu);
-			out_dist[qrow] = (int32_t)(k >> 22);
+			out_idx[o0 + qrow] = (int32_t)(k & 0x3FFFFFu);
+			out_dist[o0 + qrow] = (int32_t)(k >> 22);
 		} else {
-			out_idx[qrow] = -1;
-			out_dist[qrow] = 0x7FFFFFFF;
+			out_idx[o0 + qrow] = -1;
+			out_dist[o0 + qrow] = 0x7FFFFFFF;
 		}
 	}
 }
 
 }  // namespace
 
-int ssk_launch_hamming(ssk_ctx* ctx, const uint8_t* d_q, const int32_t* d_q_off, const int32_t* d_q_gather,
-                       const uint8_t* d_t, const int32_t* d_t_off, const int32_t* d_t_gather,
+int ssk_launch_hamming(ssk_ctx* ctx, const uint8_t* d_q, const int32_t* d_q_beg, const int32_t* d_q_end,
+                       const int32_t* d_q_gather, const uint8_t* d_t, const int32_t* d_t_beg, const int32_t* d_t_end,
+                       const int32_t* d_t_gather, const int32_t* d_out_beg,
                        int n_pairs, int max_nq, int32_t* d_train_idx, int32_t* d_dist)
 {
 	if (n_pairs <= 0 || max_nq <= 0) return SSK_OK;
 	dim3 grid((max_nq + QT - 1) / QT, n_pairs);
 	hipLaunchKernelGGL(hamming_match_kernel, grid, dim3(QT * NW), 0, ctx->stream,
-	                   (const uint4*)d_q, d_q_off, d_q_gather, (const uint4*)d_t, d_t_off, d_t_gather,
-	                   d_train_idx, d_dist);
+	                   (const uint4*)d_q, d_q_beg, d_q_end, d_q_gather, (const uint4*)d_t, d_t_beg, d_t_end, d_t_gather,
+	                   d_out_beg, d_train_idx, d_dist);
 	SSK_LAUNCH_CHECK(ctx, "hamming_match_kernel");
 	return SSK_OK;
 }

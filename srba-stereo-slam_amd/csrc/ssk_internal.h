@@ -30,6 +30,9 @@ struct ssk_ctx {
 	// bin >= b for b = 9..27, computed once on the host with the host libm's atanf.
 	float dir_thresh[19];
 	float* d_dir_thresh = nullptr;
+	int8_t pattern[1024];              // BRIEF sampling pattern (default: include/ssk_brief_pattern.h)
+	int8_t* d_pattern = nullptr;
+	struct ssk_kfbatch* single = nullptr;   // 1-keyframe batch behind the host drop-in ssk_frontend_run
 	int n_cu = 256;
 };
 
@@ -63,11 +66,13 @@ inline T* ssk_arena_take(ssk_arena& a, size_t count)
 }
 inline size_t ssk_pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
-// kernels' host-side launchers shared between translation units
-int ssk_launch_hamming(ssk_ctx* ctx, const uint8_t* d_q, const int32_t* d_q_off, const int32_t* d_q_gather,
-                       const uint8_t* d_t, const int32_t* d_t_off, const int32_t* d_t_gather,
+// kernels' host-side launchers shared between translation units.  Pair p works on virtual rows
+// [beg[p], end[p]) of each side; out_beg[p] (NULL = q_beg) is the output row of its first query.
+int ssk_launch_hamming(ssk_ctx* ctx, const uint8_t* d_q, const int32_t* d_q_beg, const int32_t* d_q_end,
+                       const int32_t* d_q_gather, const uint8_t* d_t, const int32_t* d_t_beg, const int32_t* d_t_end,
+                       const int32_t* d_t_gather, const int32_t* d_out_beg,
                        int n_pairs, int max_nq, int32_t* d_train_idx, int32_t* d_dist);
-int ssk_launch_da_filters(ssk_ctx* ctx, const int32_t* d_train_idx, const int32_t* d_dist,
-                          const int32_t* d_q_off, const int32_t* d_t_off,
+int ssk_launch_da_filters(ssk_ctx* ctx, const int32_t* d_train_idx, const int32_t* d_dist, const int32_t* d_out_beg,
+                          const int32_t* d_q_beg, const int32_t* d_q_end, const int32_t* d_t_beg, const int32_t* d_t_end,
                           const float* d_this_xy, const float* d_other_xy,
                           int n_pairs, const ssk_da_params& prm, int32_t* d_status, int32_t* d_tracked);

@@ -1,0 +1,130 @@
+// ssk_stereo.hip -- left<->right stereo matching of one keyframe's ORB features: "descriptor row-by-row"
+// (stereo-vo's smDescRbR, forced at EST.cpp:1136; parameters KITTI.ini:17-24).  Contract C10 of DESIGN.md.
+//
+// For every left keypoint: among right keypoints with |yL-yR| <= max_y_diff and
+// min_disparity <= xL-xR <= max_disparity, the one with the smallest 256-bit Hamming distance (lowest right
+// index on ties), accepted iff distance <= orb_max_distance.  Matches come out in left-keypoint order.
+//
+// Mapping (gfx950): one 256-thread workgroup per keyframe.  Left keypoints are processed in tiles of 64
+// (one per lane, descriptor in 8 VGPRs); right descriptors + coordinates are staged through LDS in tiles of
+// 512 rows; the 4 waves split the right rows (every lane of a wave reads the same LDS row: broadcast).
+// The band test runs first and a wave skips the popcounts of a row no lane accepts (ballot).
+// Argmin = integer min of the packed key (distance<<16 | right index).  The per-left results are then
+// compacted IN ORDER with a workgroup prefix sum, which also writes the gather lists the batched data
+// association reads (descriptor row + pixel of the matched left keypoint, Q3 / a5).
+#include "ssk_frontend.h"
+
+namespace {
+
+constexpr int TT = 512;
+
+__global__ __launch_bounds__(256)
+void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__ kp_xy, const int32_t* __restrict__ nkp,
+                         const uint8_t* __restrict__ desc, float max_y_diff, float min_disp, float max_disp,
+                         int orb_max_distance,
+                         int32_t* __restrict__ m_q, int32_t* __restrict__ m_t, int32_t* __restrict__ m_d,
+                         int32_t* __restrict__ nm, int32_t* __restrict__ m_row, float2* __restrict__ m_xy)
+{
+	__shared__ uint4 s_desc[TT * 2];
+	__shared__ short2 s_rxy[TT];
+	__shared__ uint32_t s_part[4][64];
+	__shared__ uint32_t s_best[SSK_MAX_FEATS];
+	__shared__ int s_scan[256];
+
+	const int kf = kf_begin + blockIdx.x;
+	const int il = kf * 2, ir = kf * 2 + 1;
+	const int nl = min(nkp[il], max_feats), nr = min(nkp[ir], max_feats);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint4* __restrict__ dl = reinterpret_cast<const uint4*>(desc) + (size_t)il * max_feats * 2;
+	const uint4* __restrict__ dr = reinterpret_cast<const uint4*>(desc) + (size_t)ir * max_feats * 2;
+	const short2* __restrict__ xl = kp_xy + (size_t)il * max_feats;
+	const short2* __restrict__ xr = kp_xy + (size_t)ir * max_feats;
+
+	for (int lbase = 0; lbase < nl; lbase += 64) {
+		const int li = lbase + lane;
+		const bool ok = li < nl;
+		uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+		float lx = 0.f, ly = 0.f;
+		if (ok) {
+			qa = dl[2 * li]; qb = dl[2 * li + 1];
+			const short2 p = xl[li];
+			lx = (float)p.x; ly = (float)p.y;
+		}
+		uint32_t best = 0xFFFFFFFFu;
+		for (int tile = 0; tile < nr; tile += TT) {
+			const int rows = min(TT, nr - tile);
+			__syncthreads();
+			for (int c = tid; c < rows * 2; c += 256) s_desc[c] = dr[2 * (size_t)tile + c];
+			for (int c = tid; c < rows; c += 256) s_rxy[c] = xr[tile + c];
+			__syncthreads();
+			for (int r = wave; r < rows; r += 4) {
+				const short2 rp = s_rxy[r];
+				const float disp = __fsub_rn(lx, (float)rp.x);
+				const bool cand = ok && !(fabsf(__fsub_rn(ly, (float)rp.y)) > max_y_diff) &&
+				                  !(disp < min_disp) && !(disp > max_disp);
+				if (__ballot(cand) == 0ull) continue;
+				const uint4 ta = s_desc[2 * r], tb = s_desc[2 * r + 1];
+				uint32_t d = __popc(qa.x ^ ta.x);
+				d += __popc(qa.y ^ ta.y); d += __popc(qa.z ^ ta.z); d += __popc(qa.w ^ ta.w);
+				d += __popc(qb.x ^ tb.x); d += __popc(qb.y ^ tb.y); d += __popc(qb.z ^ tb.z); d += __popc(qb.w ^ tb.w);
+				if (cand) best = min(best, (d << 16) | (uint32_t)(tile + r));
+			}
+		}
+		s_part[wave][lane] = best;
+		__syncthreads();
+		if (wave == 0 && ok)
+			s_best[li] = min(min(s_part[0][lane], s_part[1][lane]), min(s_part[2][lane], s_part[3][lane]));
+		__syncthreads();
+	}
+
+	// ordered compaction: thread t owns left keypoints [t*8, t*8+8)
+	constexpr int PER = SSK_MAX_FEATS / 256;
+	int cnt = 0;
+	uint32_t mine[PER];
+#pragma unroll
+	for (int e = 0; e < PER; ++e) {
+		const int li = tid * PER + e;
+		uint32_t k = 0xFFFFFFFFu;
+		if (li < nl) k = s_best[li];
+		const bool acc = k != 0xFFFFFFFFu && (int)(k >> 16) <= orb_max_distance;
+		mine[e] = acc ? k : 0xFFFFFFFFu;
+		cnt += acc;
+	}
+	s_scan[tid] = cnt;
+	__syncthreads();
+	for (int o = 1; o < 256; o <<= 1) {
+		const int v = tid >= o ? s_scan[tid - o] : 0;
+		__syncthreads();
+		s_scan[tid] += v;
+		__syncthreads();
+	}
+	int pos = s_scan[tid] - cnt;
+	const size_t ob = (size_t)kf * max_feats;
+#pragma unroll
+	for (int e = 0; e < PER; ++e) {
+		if (mine[e] != 0xFFFFFFFFu) {
+			const int li = tid * PER + e;
+			m_q[ob + pos] = li;
+			m_t[ob + pos] = (int32_t)(mine[e] & 0xFFFFu);
+			m_d[ob + pos] = (int32_t)(mine[e] >> 16);
+			m_row[ob + pos] = il * max_feats + li;
+			const short2 p = xl[li];
+			m_xy[ob + pos] = make_float2((float)p.x, (float)p.y);
+			++pos;
+		}
+	}
+	if (tid == 255) nm[kf] = s_scan[255];
+}
+
+}  // namespace
+
+int ssk_launch_stereo(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, const ssk_frontend_params& p)
+{
+	const int nkf = kf_end - kf_begin;
+	if (nkf <= 0) return SSK_OK;
+	hipLaunchKernelGGL(stereo_match_kernel, dim3(nkf), dim3(256), 0, ctx->stream, kf_begin, b->max_feats, b->kp_xy,
+	                   b->nkp, b->desc, p.max_y_diff, p.min_disparity, p.max_disparity, p.orb_max_distance,
+	                   b->m_q, b->m_t, b->m_d, b->nm, b->m_row, b->m_xy);
+	SSK_LAUNCH_CHECK(ctx, "stereo_match_kernel");
+	return SSK_OK;
+}

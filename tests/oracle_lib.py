@@ -24,6 +24,34 @@ class DaParams(C.Structure):
                 ("rows_offset", C.c_int32), ("max_orb_distance_da", C.c_float)]
 
 
+class FrontendParams(C.Structure):
+    _fields_ = [("n_feats", C.c_int32), ("fast_threshold", C.c_int32), ("n_levels", C.c_int32),
+                ("nms_radius", C.c_int32), ("orb_max_distance", C.c_int32), ("max_y_diff", C.c_float),
+                ("min_disparity", C.c_float), ("max_disparity", C.c_float), ("harris_k", C.c_float)]
+
+
+class KfOut(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("kp_left", C.c_void_p), ("kp_right", C.c_void_p),
+                ("desc_left", C.c_void_p), ("desc_right", C.c_void_p), ("matches", C.c_void_p),
+                ("n_left", C.c_int32), ("n_right", C.c_int32), ("n_matches", C.c_int32)]
+
+
+def alloc_kf_out(cls, cap):
+    """(struct, arrays) with numpy-backed output arrays of `cap` records."""
+    arrs = dict(kp_left=np.zeros(cap, KEYPOINT_DTYPE), kp_right=np.zeros(cap, KEYPOINT_DTYPE),
+                desc_left=np.zeros((cap, 32), np.uint8), desc_right=np.zeros((cap, 32), np.uint8),
+                matches=np.zeros(cap, DMATCH_DTYPE))
+    o = cls(cap, arrs["kp_left"].ctypes.data, arrs["kp_right"].ctypes.data, arrs["desc_left"].ctypes.data,
+            arrs["desc_right"].ctypes.data, arrs["matches"].ctypes.data, 0, 0, 0)
+    return o, arrs
+
+
+def trim_kf_out(o, arrs):
+    return dict(kp_left=arrs["kp_left"][:o.n_left].copy(), kp_right=arrs["kp_right"][:o.n_right].copy(),
+                desc_left=arrs["desc_left"][:o.n_left].copy(), desc_right=arrs["desc_right"][:o.n_right].copy(),
+                matches=arrs["matches"][:o.n_matches].copy())
+
+
 class StereoCam(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")]
@@ -85,6 +113,51 @@ class Oracle:
         nt = self.lib.ssko_propagate_ids(n_m, n_sim, _p(tf), arr, C.byref(last), _p(out), _p(per))
         return out, per[:n_sim], nt, last.value
 
+    # ---- front-end -----------------------------------------------------------------------------
+    def fast_score_map(self, img, threshold):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        sc = np.zeros((h, w), np.uint8)
+        self.lib.ssko_fast_score_map(_p(img), w, h, w, int(threshold), _p(sc))
+        return sc
+
+    def fast_candidates(self, img, threshold):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        keys = np.zeros((w // 2 + 1) * (h // 2 + 1), np.uint32)
+        n = self.lib.ssko_fast_candidates(_p(img), w, h, w, int(threshold), _p(keys), len(keys))
+        return keys[:n].copy()
+
+    def orb_detect(self, img, prm, pattern):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = prm.n_feats
+        kp = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        pat = np.ascontiguousarray(pattern, np.int8)
+        n = self.lib.ssko_orb_detect(_p(img), w, h, w, C.byref(prm), _p(pat), _p(kp), _p(desc), cap)
+        assert n >= 0
+        return kp[:n].copy(), desc[:n].copy()
+
+    def stereo_match(self, kl, dl, kr, dr, prm):
+        kl = np.ascontiguousarray(kl, KEYPOINT_DTYPE)
+        kr = np.ascontiguousarray(kr, KEYPOINT_DTYPE)
+        dl = np.ascontiguousarray(dl, np.uint8)
+        dr = np.ascontiguousarray(dr, np.uint8)
+        out = np.zeros(max(1, len(kl)), DMATCH_DTYPE)
+        n = self.lib.ssko_stereo_match(_p(kl), len(kl), _p(dl), _p(kr), len(kr), _p(dr), C.byref(prm), _p(out))
+        return out[:n].copy()
+
+    def frontend(self, left, right, prm, pattern):
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        h, w = left.shape
+        pat = np.ascontiguousarray(pattern, np.int8)
+        o, arrs = alloc_kf_out(KfOut, prm.n_feats)
+        rc = self.lib.ssko_frontend(_p(left), _p(right), w, h, w, C.byref(prm), _p(pat), C.byref(o))
+        assert rc == 0
+        return trim_kf_out(o, arrs)
+
     def project_match_to_3d(self, ul, vl, ur, cam):
         out = (C.c_double * 3)()
         self.lib.ssko_project_match_to_3d.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
@@ -101,6 +174,16 @@ def make_kf_view(kp_left, kp_right, desc_left, desc_right, matches):
     v = KfView(_p(kp_left), len(kp_left), _p(kp_right), len(kp_right), _p(desc_left), _p(desc_right),
                _p(matches), len(matches))
     return v, (kp_left, kp_right, desc_left, desc_right, matches)
+
+
+def default_pattern():
+    """The default BRIEF pattern, parsed from include/ssk_brief_pattern.h (data, not code)."""
+    import re
+    src = open(os.path.join(ROOT, "include", "ssk_brief_pattern.h")).read()
+    body = src[src.index("{") + 1:src.rindex("}")]
+    v = np.array([int(t) for t in re.findall(r"-?\d+", body)], np.int8)
+    assert v.size == 1024
+    return v
 
 
 _ORACLE = None

@@ -61,3 +61,41 @@ def synth_kf_pair(rng, n_feats=500, n_matches=300, overlap=0.7, motion=(6.0, -2.
         a["kp_left"]["x"][ia] = np.clip(np.floor(b["kp_left"]["x"][ib] + motion[0] + rng.normal(0, 1.5)), 31, W - 32)
         a["kp_left"]["y"][ia] = np.clip(np.floor(b["kp_left"]["y"][ib] + motion[1] + rng.normal(0, 1.5)), 31, H - 32)
     return a, b
+
+
+def synth_texture(rng, w, h):
+    """Band-limited random texture with corner-rich structure (uint8): smoothed noise at two scales plus
+    random rectangles, so FAST at threshold 20 finds a few thousand corners on a KITTI-sized image."""
+    from scipy.ndimage import uniform_filter, zoom
+    coarse = zoom(rng.uniform(0, 1, (h // 16 + 2, w // 16 + 2)), 16, order=1)[:h, :w]
+    fine = uniform_filter(rng.uniform(0, 1, (h, w)), 3)
+    img = 90 + 70 * (coarse - 0.5) + 160 * (fine - 0.5)
+    for _ in range(int(w * h / 900)):
+        x0, y0 = int(rng.integers(0, w - 4)), int(rng.integers(0, h - 4))
+        ww, hh = int(rng.integers(3, 24)), int(rng.integers(3, 24))
+        img[y0:y0 + hh, x0:x0 + ww] += rng.uniform(-70, 70)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def synth_stereo_pair(seed, w=W, h=H, noise=2.0):
+    """Rectified stereo pair of a scene made of fronto-parallel strips: row block r has integer disparity
+    d_r = fx*b/Z_r with Z in [5,80] m (KITTI.ini intrinsics), right(y,x) = left(y,x+d_r) + sensor noise."""
+    rng = np.random.default_rng(0x5EED0000 + seed)
+    wide = synth_texture(rng, w + 96, h)
+    left = wide[:, :w].copy()
+    right = np.empty_like(left)
+    y = 0
+    while y < h:
+        bh = int(rng.integers(24, 64))
+        z = rng.uniform(5, 80)
+        d = int(round(KITTI["fx"] * KITTI["baseline"] / z))
+        d = max(1, min(d, 90))
+        right[y:y + bh] = wide[y:y + bh, d:d + w]      # x_R = x_L - d
+        y += bh
+    if noise > 0:
+        right = np.clip(np.rint(right.astype(np.float64) + rng.normal(0, noise, right.shape)), 0, 255).astype(np.uint8)
+    return left, right
+
+
+KITTI_FRONTEND = dict(n_feats=500, fast_threshold=20, n_levels=1, nms_radius=2, orb_max_distance=60,
+                      max_y_diff=2.0, min_disparity=1.0, max_disparity=float(W), harris_k=0.04)

@@ -1,0 +1,149 @@
+"""GPU parity: HIP stereo front-end (FAST+NMS scan, selection, orientation+BRIEF, L<->R match) vs the CPU
+oracle on seeded synthetic KITTI-shaped pairs; bit-exact on every field the reference's own comparison
+helpers look at (compareKeypointLists / compareMatchesLists, src/srba-stereo-slam_utils.cpp:33-80)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def params(pkg, **over):
+    from ssk_amd import capi
+    d = dict(synth.KITTI_FRONTEND)
+    d.update(over)
+    return capi.FrontendParams(**d), ol.FrontendParams(**d)
+
+
+def assert_kf_equal(got, exp):
+    for k in ("kp_left", "kp_right", "matches"):
+        assert len(got[k]) == len(exp[k]), (k, len(got[k]), len(exp[k]))
+        for f in got[k].dtype.names:
+            assert np.array_equal(got[k][f], exp[k][f]), (k, f, np.flatnonzero(got[k][f] != exp[k][f])[:5])
+    assert np.array_equal(got["desc_left"], exp["desc_left"])
+    assert np.array_equal(got["desc_right"], exp["desc_right"])
+
+
+@pytest.mark.parametrize("seed,th", [(1, 20), (2, 20), (3, 7), (4, 60)])
+def test_fast_candidates_vs_oracle(ctx, oracle, pkg, seed, th):
+    from ssk_amd import capi
+    left, right = synth.synth_stereo_pair(seed)
+    b = capi.KfBatch(ctx, 1, synth.W, synth.H, 512)
+    b.upload(0, left, right)
+    cp, op = params(pkg, fast_threshold=th)
+    b.run_frontend(cp)
+    for eye, img in ((0, left), (1, right)):
+        got = b.debug_candidates(0, eye)
+        exp = oracle.fast_candidates(img, th)
+        assert len(got) == len(exp) and np.array_equal(got, exp)
+    b.close()
+
+
+def test_config2_single_kf_bit_exact(ctx, oracle, pkg):
+    """BASELINE.json configs[1]: one 1241x376 pair, FAST 20, N=500, nlevels 1, max_y_diff 2, orb_max_distance 60."""
+    left, right = synth.synth_stereo_pair(1)
+    cp, op = params(pkg)
+    got = ctx.frontend_run(left, right, cp)
+    exp = oracle.frontend(left, right, op, ol.default_pattern())
+    assert len(exp["kp_left"]) == 500 and len(exp["matches"]) >= 100
+    assert_kf_equal(got, exp)
+
+
+@pytest.mark.parametrize("seed,over", [
+    (5, dict(n_feats=500, nms_radius=0)),
+    (6, dict(n_feats=100, fast_threshold=40)),
+    (7, dict(n_feats=512, fast_threshold=10, nms_radius=4, orb_max_distance=30, max_y_diff=0.0)),
+    (8, dict(n_feats=37, fast_threshold=120)),                 # few corners: fewer keypoints than requested
+    (9, dict(n_feats=500, min_disparity=10.0, max_disparity=40.0, max_y_diff=1.0)),
+])
+def test_frontend_param_sweep(ctx, oracle, pkg, seed, over):
+    left, right = synth.synth_stereo_pair(seed)
+    cp, op = params(pkg, **over)
+    got = ctx.frontend_run(left, right, cp)
+    exp = oracle.frontend(left, right, op, ol.default_pattern())
+    assert_kf_equal(got, exp)
+
+
+@pytest.mark.parametrize("w,h", [(63 + 64, 63 + 16), (200, 95), (640, 480), (130, 300)])
+def test_frontend_odd_sizes(ctx, oracle, pkg, w, h):
+    rng = np.random.default_rng(w * 1000 + h)
+    left = synth.synth_texture(rng, w, h)
+    right = np.roll(left, -7, axis=1)
+    cp, op = params(pkg, n_feats=200, max_disparity=float(w))
+    got = ctx.frontend_run(left, right, cp)
+    exp = oracle.frontend(left, right, op, ol.default_pattern())
+    assert_kf_equal(got, exp)
+
+
+def test_frontend_flat_and_saturated_images(ctx, oracle, pkg):
+    """no corners at all / maximal contrast checkerboard (score 254, dense ties)."""
+    cp, op = params(pkg)
+    flat = np.full((synth.H, synth.W), 128, np.uint8)
+    got = ctx.frontend_run(flat, flat, cp)
+    assert len(got["kp_left"]) == 0 and len(got["kp_right"]) == 0 and len(got["matches"]) == 0
+    yy, xx = np.mgrid[0:synth.H, 0:synth.W]
+    chk = (((yy // 5) + (xx // 5)) % 2 * 255).astype(np.uint8)
+    got = ctx.frontend_run(chk, np.roll(chk, -3, axis=1), cp)
+    exp = oracle.frontend(chk, np.roll(chk, -3, axis=1), op, ol.default_pattern())
+    assert_kf_equal(got, exp)
+
+
+def test_custom_brief_pattern(ctx, oracle, pkg):
+    rng = np.random.default_rng(77)
+    pat = rng.integers(-13, 14, 1024).astype(np.int8)
+    old = ctx.get_brief_pattern()
+    assert np.array_equal(old, ol.default_pattern())
+    ctx.set_brief_pattern(pat)
+    try:
+        left, right = synth.synth_stereo_pair(11)
+        cp, op = params(pkg, n_feats=150)
+        assert_kf_equal(ctx.frontend_run(left, right, cp), oracle.frontend(left, right, op, pat))
+    finally:
+        ctx.set_brief_pattern(old)
+
+
+def test_batch_equals_single_and_da_batch(ctx, oracle, pkg):
+    """A batch of keyframes gives, per keyframe, exactly the single-keyframe result; batched DA on the
+    HBM-resident features equals the oracle's data association on the downloaded keyframes."""
+    import torch
+    from ssk_amd import capi
+    B = 5
+    pairs_img = [synth.synth_stereo_pair(20 + i) for i in range(B)]
+    # keyframe i+1 = keyframe i shifted by a few pixels, so KF<->KF association has real inliers
+    for i in range(1, B):
+        pairs_img[i] = (np.roll(pairs_img[0][0], (2 * i, -3 * i), axis=(0, 1)), np.roll(pairs_img[0][1], (2 * i, -3 * i), axis=(0, 1)))
+    b = capi.KfBatch(ctx, B, synth.W, synth.H, 512)
+    for i, (l, r) in enumerate(pairs_img):
+        b.upload(i, l, r)
+    cp, op = params(pkg)
+    b.run_frontend(cp)
+    kfs = [b.download(i) for i in range(B)]
+    for i, (l, r) in enumerate(pairs_img):
+        assert_kf_equal(kfs[i], oracle.frontend(l, r, op, ol.default_pattern()))
+    nkp, nm = b.counts()
+    assert nkp[:, 0].tolist() == [len(k["kp_left"]) for k in kfs] and nm.tolist() == [len(k["matches"]) for k in kfs]
+    # batched DA: (i, i-1) for i=1..B-1 plus a pair against itself and a far pair
+    pairs = [(i, i - 1) for i in range(1, B)] + [(2, 2), (4, 0)]
+    P, N = len(pairs), 512
+    dev = torch.device("cuda:0")
+    d_idx = torch.full((P * N,), -9, dtype=torch.int32, device=dev)
+    d_dist = torch.full((P * N,), -9, dtype=torch.int32, device=dev)
+    d_st = torch.full((P * N,), -9, dtype=torch.int32, device=dev)
+    d_tr = torch.full((P,), -9, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    vals = (1, 1, synth.H, 60.0)
+    ctx.da_run_batch(b, b, pairs, capi.DaParams(*vals), d_idx, d_dist, d_st, d_tr)
+    ctx.synchronize()
+    idx, dist, st, tr = (t.cpu().numpy() for t in (d_idx, d_dist, d_st, d_tr))
+    for p, (ia, ib) in enumerate(pairs):
+        va, ka = ol.make_kf_view(**kfs[ia])
+        vb, kb = ol.make_kf_view(**kfs[ib])
+        em, es, et = oracle.data_association(va, vb, ol.DaParams(*vals))
+        n = len(em)
+        assert np.array_equal(idx[p * N:p * N + n], em["trainIdx"])
+        assert np.array_equal(dist[p * N:p * N + n], em["distance"].astype(np.int32))
+        assert np.array_equal(st[p * N:p * N + n], es) and tr[p] == et
+    assert tr[0] > 30      # consecutive shifted keyframes really associate
+    b.close()
