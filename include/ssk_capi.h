@@ -70,6 +70,26 @@ void* ssk_stream(ssk_ctx* ctx);                   /* the hipStream_t kernels are
 int ssk_timer_start(ssk_ctx* ctx);
 int ssk_timer_stop_ms(ssk_ctx* ctx, float* ms);   /* records + synchronises the stop event */
 
+/* Per-stage kernel timing with HIP events on the context stream (one event pair per kernel launch while
+ * enabled; adds a small serialisation, so bench.py enables it only for its roofline pass). */
+enum {
+	SSK_STAGE_FAST = 0,        /* fast_nms_kernel: the HBM-bound image scan */
+	SSK_STAGE_SELECT,          /* select_kernel */
+	SSK_STAGE_DESCRIBE,        /* describe_kernel */
+	SSK_STAGE_STEREO,          /* stereo_match_kernel */
+	SSK_STAGE_HAMMING,         /* hamming_match_kernel */
+	SSK_STAGE_DA_FILTERS,      /* da_filters_kernel */
+	SSK_STAGE_LM_LINEARIZE,    /* residual + Jacobian + Hessian-block build */
+	SSK_STAGE_LM_SCHUR,        /* Schur complement */
+	SSK_STAGE_LM_SOLVE,        /* dense Cholesky + back-substitution */
+	SSK_STAGE_LM_UPDATE,       /* state update + error evaluation */
+	SSK_STAGE_COUNT
+};
+int ssk_profile_enable(ssk_ctx* ctx, int on);     /* also clears the accumulated sums */
+/* synchronises the stream, then returns accumulated milliseconds and launch counts per stage */
+int ssk_profile_read(ssk_ctx* ctx, double* ms /* SSK_STAGE_COUNT */, int64_t* calls /* SSK_STAGE_COUNT */);
+const char* ssk_stage_name(int stage);
+
 /* ---- B2: keyframe <-> keyframe Hamming brute force ---------------------------------------------
  * Replaces  cv::BFMatcher(NORM_HAMMING,false).match(query, train, out)   EST.cpp:1447-1452.
  * out[q] = {queryIdx=q, trainIdx=argmin_t popcount(query[q]^train[t]) (lowest t on ties), imgIdx=0,
@@ -192,6 +212,83 @@ int ssk_kfbatch_debug_candidates(ssk_ctx* ctx, ssk_kfbatch* b, int kf, int eye, 
 int ssk_da_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
                      const ssk_da_params* params, int32_t* d_train_idx, int32_t* d_dist, int32_t* d_status,
                      int32_t* d_tracked);
+
+/* ---- B3: relative bundle adjustment, Levenberg-Marquardt with Schur complement + dense Cholesky ----
+ * Replaces the numerical core of  rba.define_new_keyframe(listObs, newKFInfo, true)  (EST.cpp:782-784):
+ * SRBA's optimize_edges / optimize_local_area for the problem types of SRBA.h:30-54
+ * (kf2kf_poses::SE3, landmarks::Euclidean3D, observations::StereoCamera, sensor_pose_on_robot_se3,
+ * solver_LM_schur_dense_cholesky).  One "window" = the k2k edges and landmarks optimised by one call plus
+ * everything their observations' spanning-tree paths reference.  Algorithm contract: DESIGN.md "LM contract".
+ *
+ * Conventions: an edge's inv_pose is the pose of its `from` keyframe seen from its `to` keyframe (SRBA's
+ * k2k_edge_t::inv_pose), stored as 12 doubles = row-major 3x4 [R|t]; it maps a point in the `from` frame to
+ * the `to` frame.  A landmark position is relative to its base keyframe.  An observation's path lists the
+ * edges from the OBSERVER keyframe towards the landmark's BASE keyframe; entry = edge*2 + dir: dir 0 applies
+ * inv_pose (the next keyframe on the path is the edge's `from`), dir 1 applies its inverse (the next keyframe
+ * is the edge's `to`).  An empty path = observed from its base keyframe. */
+typedef struct ssk_lm_window {
+	int32_t n_edges_total;             /* edges referenced by any path (optimised + fixed) */
+	const int32_t* edge_unknown_slot;  /* [n_edges_total] 0..E-1 for optimised edges (each slot once), -1 = fixed */
+	const double*  edge_inv_pose;      /* [n_edges_total][12] */
+	int32_t n_lms_total;
+	const int32_t* lm_unknown_slot;    /* [n_lms_total] 0..L-1 for optimised landmarks, -1 = fixed */
+	const double*  lm_pos;             /* [n_lms_total][3] */
+	int32_t n_obs;
+	const int32_t* obs_lm;             /* [n_obs] landmark index */
+	const float*   obs_px;             /* [n_obs][4] left x,y, right x,y (TPixelCoordf, EST.cpp:694-695) */
+	const int32_t* obs_path_off;       /* [n_obs+1] */
+	const int32_t* path_edge;          /* [obs_path_off[n_obs]] edge*2+dir */
+} ssk_lm_window;
+
+typedef struct ssk_lm_params {
+	double fx_l, fy_l, cx_l, cy_l, fx_r, fy_r, cx_r, cy_r, baseline;   /* srba_options.stereo_camera (UTIL.h:366) */
+	double sensor_pose[12];            /* camera on robot, [R|t] (EST.cpp:1105-1112; sensor_pose_on_robot_se3) */
+	int32_t max_iters;                 /* SRBA parameters.srba.max_iters, default 20 */
+	int32_t use_robust_kernel;         /* srba_use_robust_kernel (KITTI.ini:107) */
+	double kernel_param;               /* pseudo-Huber parameter (KITTI.ini:109: 1.5) */
+	double tau;                        /* initial lambda = tau * max diag(H); 1e-3 */
+	double max_lambda;                 /* 1e20 */
+	double max_error_per_obs_to_stop;  /* stop when sqrt(err/n_obs) falls below this; 1e-9 */
+	double converged_rel_decrease;     /* stop when an attempt changes the error by <= this fraction (either sign);
+	                                      1e-9; 0 disables.  The step is kept iff it lowered the error. */
+} ssk_lm_params;
+
+typedef struct ssk_lm_result {
+	int32_t iters;                     /* solve attempts made (accepted + rejected) */
+	int32_t accepted;                  /* accepted steps */
+	int32_t stop_reason;               /* 0 max_iters, 1 error threshold, 2 max_lambda, 3 nothing to optimise, 4 converged */
+	int32_t n_obs;
+	double err_init, err_final;        /* total (robustified) squared error: optimize_results.total_sqr_error_* (EST.cpp:179) */
+	double lambda_final;
+} ssk_lm_result;
+
+/* one attempt of the LM loop, recorded when the batch was created with trace != 0 */
+typedef struct ssk_lm_trace_entry {
+	double lambda, err_before, err_after, delta_p_norm, delta_f_norm;
+	int32_t accepted, cholesky_ok;
+} ssk_lm_trace_entry;
+
+typedef struct ssk_lm_batch ssk_lm_batch;
+/* Uploads n windows (state + symbolic structure) to HBM.  trace != 0 additionally keeps, per attempt, the
+ * trace entry and the full update vectors (tests).  */
+int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out);
+void ssk_lm_batch_destroy(ssk_lm_batch* b);
+/* Restores every window's state to what was uploaded (so a benchmark can repeat the same solve). Async. */
+int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b);
+/* Runs the LM loop of every window of the batch (one launch, asynchronous on the context stream). */
+int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* params);
+int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out /* n_windows */);
+/* Current state of window w: edge_inv_pose [n_edges_total*12], lm_pos [n_lms_total*3]. */
+int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_inv_pose, double* lm_pos);
+/* Trace of window w: entries [max_iters]; delta_p [max_iters][6E], delta_f [max_iters][3L] (may be NULL). */
+int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_entry* entries, int cap,
+                           double* delta_p, double* delta_f, int* n_entries);
+
+/* a10/a11: observation marshalling of EST.cpp:142-161,667-704: per match, feat id + pixels + the initial
+ * landmark position  camera_pose_on_robot (+) projectMatchTo3D(xl,yl,xr)  (UTIL.h:558-574). Host arrays. */
+int ssk_build_observations(ssk_ctx* ctx, const ssk_keypoint* kp_left, const ssk_keypoint* kp_right,
+                           const ssk_dmatch* matches, int n_matches, const ssk_lm_params* cam,
+                           float* obs_px /* n x 4 */, double* init_pos /* n x 3 */);
 
 /* Test hook: the 19 float thresholds the context derived from the host libm's atanf for the
  * direction bins 9..27 (see csrc/ssk_context.hip). */

@@ -83,6 +83,16 @@ int ssko_stereo_match(const ssk_keypoint* kl, int nl, const uint8_t* dl, const s
 int ssko_frontend(const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                   const ssk_frontend_params* prm, const int8_t* pattern, ssk_kf_out* out);
 
+/* ---------------- relative bundle adjustment (oracle_lm.c): contract L1-L5 in that file ---------------- */
+void ssko_se3_left_update(const double* eps6, const double* T12, double* out12);
+double ssko_lm_total_error(const ssk_lm_window* W, const ssk_lm_params* P, const double* poses, const double* lms);
+void ssko_lm_gradient(const ssk_lm_window* W, const ssk_lm_params* P, const double* poses, const double* lms,
+                      double* gp, double* gf);
+int ssko_lm_solve(const ssk_lm_window* W, const ssk_lm_params* P, double* poses, double* lms,
+                  ssk_lm_result* res, ssk_lm_trace_entry* trace, double* dp_trace, double* df_trace);
+void ssko_build_observations(const ssk_keypoint* kl, const ssk_keypoint* kr, const ssk_dmatch* m, int n,
+                             const ssk_lm_params* P, float* obs_px, double* init_pos);
+
 #ifdef __cplusplus
 }
 #endif

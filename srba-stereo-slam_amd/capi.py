@@ -1,7 +1,10 @@
 """ctypes binding of libssk_hip.so -- exactly the entry points declared in include/ssk_capi.h."""
+import atexit
 import ctypes as C
 import os
 import re
+import sys
+import weakref
 
 import numpy as np
 
@@ -34,6 +37,18 @@ def declared_symbols():
 
 
 _LIB = None
+_LIVE = weakref.WeakSet()     # contexts / batches still open: closed before interpreter (and HIP runtime) teardown
+
+
+@atexit.register
+def _close_all():
+    objs = list(_LIVE)
+    for o in objs:
+        if not isinstance(o, Context):
+            o.close()
+    for o in objs:
+        if isinstance(o, Context):
+            o.close()
 
 
 def load_library():
@@ -106,6 +121,7 @@ class KfBatch:
         pitch = C.c_int()
         ctx._chk(ctx.lib.ssk_kfbatch_images(self.h_, C.byref(img), C.byref(pitch)))
         self.d_images, self.pitch = img.value, pitch.value
+        _LIVE.add(self)
 
     def close(self):
         if getattr(self, "h_", None):
@@ -113,6 +129,8 @@ class KfBatch:
             self.h_ = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -158,6 +176,97 @@ class KfBatch:
         return keys[:n.value].copy()
 
 
+class LmWindow(C.Structure):
+    _fields_ = [("n_edges_total", C.c_int32), ("edge_unknown_slot", C.c_void_p), ("edge_inv_pose", C.c_void_p),
+                ("n_lms_total", C.c_int32), ("lm_unknown_slot", C.c_void_p), ("lm_pos", C.c_void_p),
+                ("n_obs", C.c_int32), ("obs_lm", C.c_void_p), ("obs_px", C.c_void_p),
+                ("obs_path_off", C.c_void_p), ("path_edge", C.c_void_p)]
+
+
+class LmParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")] + \
+               [("sensor_pose", C.c_double * 12), ("max_iters", C.c_int32), ("use_robust_kernel", C.c_int32),
+                ("kernel_param", C.c_double), ("tau", C.c_double), ("max_lambda", C.c_double),
+                ("max_error_per_obs_to_stop", C.c_double), ("converged_rel_decrease", C.c_double)]
+
+
+class LmResult(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("accepted", C.c_int32), ("stop_reason", C.c_int32), ("n_obs", C.c_int32),
+                ("err_init", C.c_double), ("err_final", C.c_double), ("lambda_final", C.c_double)]
+
+
+class LmTraceEntry(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("err_before", C.c_double), ("err_after", C.c_double),
+                ("delta_p_norm", C.c_double), ("delta_f_norm", C.c_double), ("accepted", C.c_int32),
+                ("cholesky_ok", C.c_int32)]
+
+
+class LmBatch:
+    """ssk_lm_batch wrapper.  `windows`: objects with the ssk_lm_window arrays as numpy attributes
+    (edge_unknown_slot, edge_inv_pose, lm_unknown_slot, lm_pos, obs_lm, obs_px, obs_path_off, path_edge)."""
+
+    def __init__(self, ctx, windows, trace=False):
+        self.ctx, self.windows = ctx, list(windows)
+        n = len(self.windows)
+        arr = (LmWindow * n)()
+        self._keep = []
+        for i, w in enumerate(self.windows):
+            a = [np.ascontiguousarray(w.edge_unknown_slot, np.int32), np.ascontiguousarray(w.edge_inv_pose, np.float64),
+                 np.ascontiguousarray(w.lm_unknown_slot, np.int32), np.ascontiguousarray(w.lm_pos, np.float64),
+                 np.ascontiguousarray(w.obs_lm, np.int32), np.ascontiguousarray(w.obs_px, np.float32),
+                 np.ascontiguousarray(w.obs_path_off, np.int32), np.ascontiguousarray(w.path_edge, np.int32)]
+            self._keep.append(a)
+            p = lambda x: x.ctypes.data if x.size else 0
+            arr[i] = LmWindow(len(a[0]), p(a[0]), p(a[1]), len(a[2]), p(a[2]), p(a[3]), len(a[4]), p(a[4]), p(a[5]), p(a[6]), p(a[7]))
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.ssk_lm_batch_create(ctx.h, arr, n, int(bool(trace)), C.byref(h)))
+        self.h_, self.n = h, n
+        _LIVE.add(self)
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.ctx.lib.ssk_lm_batch_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_reset(self.ctx.h, self.h_))
+
+    def run(self, prm):
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_run(self.ctx.h, self.h_, C.byref(prm)))
+
+    def results(self):
+        out = (LmResult * self.n)()
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_results(self.ctx.h, self.h_, out))
+        return list(out)
+
+    def state(self, w):
+        win = self.windows[w]
+        poses = np.zeros((len(win.edge_unknown_slot), 12))
+        lms = np.zeros((len(win.lm_unknown_slot), 3))
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_get_state(self.ctx.h, self.h_, int(w), _ptr(poses), _ptr(lms)))
+        return poses, lms
+
+    def trace(self, w, cap=64):
+        win = self.windows[w]
+        E = int((np.asarray(win.edge_unknown_slot) >= 0).sum())
+        L = int((np.asarray(win.lm_unknown_slot) >= 0).sum())
+        ent = (LmTraceEntry * cap)()
+        dp = np.zeros(cap * 6 * E + 1)
+        df = np.zeros(cap * 3 * L + 1)
+        n = C.c_int()
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_get_trace(self.ctx.h, self.h_, int(w), ent, cap, _ptr(dp), _ptr(df), C.byref(n)))
+        k = n.value
+        return list(ent)[:k], dp[:k * 6 * E].reshape(k, 6 * E), df[:k * 3 * L].reshape(k, 3 * L)
+
+
 def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None and a.size else C.c_void_p(0)
 
@@ -193,6 +302,7 @@ class Context:
         if rc != 0:
             raise SskError(rc, self.lib.ssk_last_error(None).decode())
         self.h = h
+        _LIVE.add(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -200,6 +310,8 @@ class Context:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -276,6 +388,28 @@ class Context:
         pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
         self._chk(self.lib.ssk_da_run_batch(self.h, this_b.h_, other_b.h_, _ptr(pr), len(pr), C.byref(params),
                                             _dev(d_idx), _dev(d_dist), _dev(d_status), _dev(d_tracked)))
+
+    # -- B3 ------------------------------------------------------------------------------------------
+    def build_observations(self, kp_left, kp_right, matches, lm_params):
+        kl = np.ascontiguousarray(kp_left, KEYPOINT_DTYPE)
+        kr = np.ascontiguousarray(kp_right, KEYPOINT_DTYPE)
+        m = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        px = np.zeros((len(m), 4), np.float32)
+        pos = np.zeros((len(m), 3), np.float64)
+        self._chk(self.lib.ssk_build_observations(self.h, _ptr(kl), _ptr(kr), _ptr(m), len(m), C.byref(lm_params), _ptr(px), _ptr(pos)))
+        return px, pos
+
+    # -- profiling -------------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.lib.ssk_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        n = 10
+        ms = (C.c_double * n)()
+        calls = (C.c_int64 * n)()
+        self._chk(self.lib.ssk_profile_read(self.h, ms, calls))
+        self.lib.ssk_stage_name.restype = C.c_char_p
+        return {self.lib.ssk_stage_name(i).decode(): (ms[i], calls[i]) for i in range(n)}
 
     def data_association(self, this_view, other_view, params):
         n = this_view.n_matches

@@ -1,0 +1,384 @@
+// ssk_capi_lm.hip -- C-ABI of seam B3 (relative bundle adjustment): builds the symbolic structure of a
+// batch of optimisation windows on the host (graph bookkeeping, as SRBA does symbolically on the CPU),
+// uploads state + structure to HBM once, and runs the persistent LM kernel of ssk_lm.hip on it.
+#include "ssk_lm.h"
+#include <algorithm>
+#include <cmath>
+
+struct ssk_lm_batch {
+	ssk_ctx* ctx = nullptr;
+	int n_windows = 0, trace = 0, max_iters_alloc = 0, max_n6 = 0;
+	std::vector<lm_win> hdr;
+	std::vector<void*> allocs;
+	lm_dev D{};
+	size_t n_pose = 0, n_lm = 0;      // doubles in pose / lm families
+	long long dp_trace_total = 0, df_trace_total = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(ssk_lm_batch* b, const std::vector<T>& v, const T** out)
+{
+	T* d = nullptr;
+	SSK_HIP(b->ctx, hipMalloc((void**)&d, sizeof(T) * (v.size() + 4)));
+	b->allocs.push_back(d);
+	if (!v.empty()) SSK_HIP(b->ctx, hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+	*out = d;
+	return SSK_OK;
+}
+template <typename T>
+int scratch(ssk_lm_batch* b, size_t count, T** out)
+{
+	T* d = nullptr;
+	SSK_HIP(b->ctx, hipMalloc((void**)&d, sizeof(T) * (count + 4)));
+	SSK_HIP(b->ctx, hipMemset(d, 0, sizeof(T) * (count + 4)));
+	b->allocs.push_back(d);
+	*out = d;
+	return SSK_OK;
+}
+
+// a10/a11: one thread per L<->R match: observation pixels + initial landmark position
+// camera_pose_on_robot (+) projectMatchTo3D(xl, yl, xr)   (UTIL.h:558-574, EST.cpp:158,698), FP64, the
+// operation order of the reference expression.
+__global__ void build_obs_kernel(const ssk_keypoint* __restrict__ kl, const ssk_keypoint* __restrict__ kr,
+                                 const ssk_dmatch* __restrict__ m, int n, lm_cam P,
+                                 float* __restrict__ obs_px, double* __restrict__ init_pos)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const ssk_keypoint a = kl[m[i].queryIdx], b = kr[m[i].trainIdx];
+	obs_px[4 * i] = a.x; obs_px[4 * i + 1] = a.y; obs_px[4 * i + 2] = b.x; obs_px[4 * i + 3] = b.y;
+	const double ul = (double)a.x, vl = (double)a.y, ur = (double)b.x;
+	const double b_d = P.baseline / __dadd_rn(__dmul_rn(P.fx_l, P.cx_r - ur), __dmul_rn(P.fx_r, ul - P.cx_l));
+	const double X = __dmul_rn(__dmul_rn(b_d, P.fx_r), ul - P.cx_l);
+	const double Y = __dmul_rn(__dmul_rn(b_d, P.fx_r), vl - P.cy_l);
+	const double Z = __dmul_rn(__dmul_rn(b_d, P.fx_l), P.fx_r);
+	for (int r = 0; r < 3; ++r)
+		init_pos[3 * i + r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P.S[4 * r], X), __dmul_rn(P.S[4 * r + 1], Y)), __dmul_rn(P.S[4 * r + 2], Z)), P.S[4 * r + 3]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssk_build_observations(ssk_ctx* ctx, const ssk_keypoint* kp_left, const ssk_keypoint* kp_right,
+                           const ssk_dmatch* matches, int n_matches, const ssk_lm_params* cam,
+                           float* obs_px, double* init_pos)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (n_matches < 0 || !cam || (n_matches > 0 && (!kp_left || !kp_right || !matches || !obs_px || !init_pos)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_build_observations: bad argument");
+	if (n_matches == 0) return SSK_OK;
+	int max_l = 0, max_r = 0;
+	for (int i = 0; i < n_matches; ++i) {
+		if (matches[i].queryIdx < 0 || matches[i].trainIdx < 0) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_build_observations: negative index in match %d", i);
+		max_l = std::max(max_l, matches[i].queryIdx + 1); max_r = std::max(max_r, matches[i].trainIdx + 1);
+	}
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	const size_t n = (size_t)n_matches;
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad(sizeof(ssk_keypoint) * max_l) + ssk_pad(sizeof(ssk_keypoint) * max_r) +
+	                                               ssk_pad(16 * n) + ssk_pad(16 * n) + ssk_pad(24 * n) + 8 * 256))) return rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->pin, ssk_pad(16 * n) + ssk_pad(24 * n) + 4 * 256))) return rc;
+	ssk_arena_reset(ctx->dev); ssk_arena_reset(ctx->pin);
+	ssk_keypoint* d_kl = ssk_arena_take<ssk_keypoint>(ctx->dev, max_l);
+	ssk_keypoint* d_kr = ssk_arena_take<ssk_keypoint>(ctx->dev, max_r);
+	ssk_dmatch* d_m = ssk_arena_take<ssk_dmatch>(ctx->dev, n);
+	float* d_px = ssk_arena_take<float>(ctx->dev, 4 * n);
+	double* d_pos = ssk_arena_take<double>(ctx->dev, 3 * n);
+	float* h_px = ssk_arena_take<float>(ctx->pin, 4 * n);
+	double* h_pos = ssk_arena_take<double>(ctx->pin, 3 * n);
+	SSK_HIP(ctx, hipMemcpyAsync(d_kl, kp_left, sizeof(ssk_keypoint) * max_l, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_kr, kp_right, sizeof(ssk_keypoint) * max_r, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_m, matches, sizeof(ssk_dmatch) * n, hipMemcpyHostToDevice, ctx->stream));
+	lm_cam P{};
+	P.fx_l = cam->fx_l; P.fy_l = cam->fy_l; P.cx_l = cam->cx_l; P.cy_l = cam->cy_l;
+	P.fx_r = cam->fx_r; P.fy_r = cam->fy_r; P.cx_r = cam->cx_r; P.cy_r = cam->cy_r; P.baseline = cam->baseline;
+	for (int i = 0; i < 12; ++i) P.S[i] = cam->sensor_pose[i];
+	hipLaunchKernelGGL(build_obs_kernel, dim3((n_matches + 255) / 256), dim3(256), 0, ctx->stream, d_kl, d_kr, d_m, n_matches, P, d_px, d_pos);
+	SSK_LAUNCH_CHECK(ctx, "build_obs_kernel");
+	SSK_HIP(ctx, hipMemcpyAsync(h_px, d_px, 16 * n, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(h_pos, d_pos, 24 * n, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	std::memcpy(obs_px, h_px, 16 * n);
+	std::memcpy(init_pos, h_pos, 24 * n);
+	return SSK_OK;
+}
+
+void ssk_lm_batch_destroy(ssk_lm_batch* b)
+{
+	if (!b) return;
+	if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
+	for (void* p : b->allocs) (void)hipFree(p);
+	delete b;
+}
+
+int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!windows || n_windows < 1 || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: bad argument");
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	const int MAX_ITERS_ALLOC = 64;
+	// batch-wide host images of every array family
+	std::vector<int> edge_slot, lm_slot, obs_lm, obs_path_off, path_edge, path_obs, path_lme, slot_edge, slot_lm;
+	std::vector<int> lmo_off, lmo_idx, lme_off, lme_edge, lme_lm, ppo_off, ppl_off, el_off, el_idx, pe_off, pe_idx;
+	std::vector<int2> pair_ee, ppo, ppl;
+	std::vector<double> pose, lm;
+	std::vector<float> obs_px;
+	std::vector<lm_win> hdr((size_t)n_windows);
+	long long h_total = 0, dpt = 0, dft = 0;
+	int max_n6 = 0;
+	for (int w = 0; w < n_windows; ++w) {
+		const ssk_lm_window& Wn = windows[w];
+		lm_win& H = hdr[w];
+		if (Wn.n_edges_total < 0 || Wn.n_lms_total < 0 || Wn.n_obs < 0 ||
+		    (Wn.n_edges_total > 0 && (!Wn.edge_unknown_slot || !Wn.edge_inv_pose)) ||
+		    (Wn.n_lms_total > 0 && (!Wn.lm_unknown_slot || !Wn.lm_pos)) ||
+		    (Wn.n_obs > 0 && (!Wn.obs_lm || !Wn.obs_px || !Wn.obs_path_off)))
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d has NULL arrays", w);
+		int E = 0, L = 0;
+		for (int e = 0; e < Wn.n_edges_total; ++e) if (Wn.edge_unknown_slot[e] >= 0) ++E;
+		for (int l = 0; l < Wn.n_lms_total; ++l) if (Wn.lm_unknown_slot[l] >= 0) ++L;
+		if (6 * E > SSK_LM_MAX_N6) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: window %d optimises %d edges (> %d)", w, E, SSK_LM_MAX_N6 / 6);
+		std::vector<int> s_edge((size_t)E, -1), s_lm((size_t)L, -1);
+		for (int e = 0; e < Wn.n_edges_total; ++e) {
+			const int s = Wn.edge_unknown_slot[e];
+			if (s >= E || (s >= 0 && s_edge[s] != -1)) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d edge slots are not a permutation of 0..E-1", w);
+			if (s >= 0) s_edge[s] = e;
+		}
+		for (int l = 0; l < Wn.n_lms_total; ++l) {
+			const int s = Wn.lm_unknown_slot[l];
+			if (s >= L || (s >= 0 && s_lm[s] != -1)) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d landmark slots are not a permutation of 0..L-1", w);
+			if (s >= 0) s_lm[s] = l;
+		}
+		const int n_path = Wn.n_obs ? Wn.obs_path_off[Wn.n_obs] : 0;
+		if (Wn.n_obs && Wn.obs_path_off[0] != 0) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d obs_path_off[0] != 0", w);
+		for (int o = 0; o < Wn.n_obs; ++o) {
+			const int len = Wn.obs_path_off[o + 1] - Wn.obs_path_off[o];
+			if (len < 0 || len > SSK_LM_MAX_PATH) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d observation %d path length %d outside [0,%d]", w, o, len, SSK_LM_MAX_PATH);
+			if (Wn.obs_lm[o] < 0 || Wn.obs_lm[o] >= Wn.n_lms_total) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d observation %d landmark out of range", w, o);
+		}
+		for (int p = 0; p < n_path; ++p)
+			if (!Wn.path_edge || Wn.path_edge[p] < 0 || (Wn.path_edge[p] >> 1) >= Wn.n_edges_total)
+				return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d path entry %d out of range", w, p);
+
+		H.n_edges = Wn.n_edges_total; H.E = E; H.n_lms = Wn.n_lms_total; H.L = L; H.n_obs = Wn.n_obs; H.n_path = n_path;
+		H.n_pairs = E * (E + 1) / 2;
+		H.edge0 = (int)edge_slot.size(); H.lm0 = (int)lm_slot.size(); H.obs0 = (int)obs_lm.size();
+		H.opo0 = (int)obs_path_off.size(); H.path0 = (int)path_edge.size();
+		H.us0 = (int)slot_edge.size(); H.uso0 = (int)el_off.size(); H.ls0 = (int)slot_lm.size(); H.lso0 = (int)lmo_off.size();
+		H.lmo0 = (int)lmo_idx.size(); H.lme0 = (int)lme_edge.size(); H.pair0 = (int)pair_ee.size(); H.pairo0 = (int)ppo_off.size();
+		H.ppo0 = (int)ppo.size(); H.ppl0 = (int)ppl.size(); H.el0 = (int)el_idx.size(); H.pe0 = (int)pe_idx.size();
+		H.trace0 = w * MAX_ITERS_ALLOC; H.h0 = h_total; H.dp_trace0 = dpt; H.df_trace0 = dft;
+		h_total += (long long)36 * E * E;
+		if (trace) { dpt += (long long)MAX_ITERS_ALLOC * 6 * E; dft += (long long)MAX_ITERS_ALLOC * 3 * L; }
+		max_n6 = std::max(max_n6, 6 * E);
+
+		edge_slot.insert(edge_slot.end(), Wn.edge_unknown_slot, Wn.edge_unknown_slot + Wn.n_edges_total);
+		pose.insert(pose.end(), Wn.edge_inv_pose, Wn.edge_inv_pose + 12 * (size_t)Wn.n_edges_total);
+		lm_slot.insert(lm_slot.end(), Wn.lm_unknown_slot, Wn.lm_unknown_slot + Wn.n_lms_total);
+		lm.insert(lm.end(), Wn.lm_pos, Wn.lm_pos + 3 * (size_t)Wn.n_lms_total);
+		obs_lm.insert(obs_lm.end(), Wn.obs_lm, Wn.obs_lm + Wn.n_obs);
+		obs_px.insert(obs_px.end(), Wn.obs_px, Wn.obs_px + 4 * (size_t)Wn.n_obs);
+		if (Wn.n_obs) obs_path_off.insert(obs_path_off.end(), Wn.obs_path_off, Wn.obs_path_off + Wn.n_obs + 1);
+		else obs_path_off.push_back(0);
+		if (n_path) path_edge.insert(path_edge.end(), Wn.path_edge, Wn.path_edge + n_path);
+		slot_edge.insert(slot_edge.end(), s_edge.begin(), s_edge.end());
+		slot_lm.insert(slot_lm.end(), s_lm.begin(), s_lm.end());
+
+		// ---- symbolic structure ----
+		std::vector<int> p_obs((size_t)n_path), p_lme((size_t)n_path, -1);
+		std::vector<std::vector<int>> lm_obs((size_t)L), lm_edges((size_t)L);
+		for (int o = 0; o < Wn.n_obs; ++o) {
+			const int ls = Wn.lm_unknown_slot[Wn.obs_lm[o]];
+			if (ls >= 0) lm_obs[ls].push_back(o);
+			for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p) {
+				p_obs[p] = o;
+				const int es = Wn.edge_unknown_slot[Wn.path_edge[p] >> 1];
+				if (ls >= 0 && es >= 0) lm_edges[ls].push_back(es);
+			}
+		}
+		std::vector<int> lme_base((size_t)L + 1, 0);
+		for (int l = 0; l < L; ++l) {
+			auto& v = lm_edges[l];
+			std::sort(v.begin(), v.end());
+			v.erase(std::unique(v.begin(), v.end()), v.end());
+			lme_base[l + 1] = lme_base[l] + (int)v.size();
+		}
+		for (int o = 0; o < Wn.n_obs; ++o) {
+			const int ls = Wn.lm_unknown_slot[Wn.obs_lm[o]];
+			if (ls < 0) continue;
+			for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p) {
+				const int es = Wn.edge_unknown_slot[Wn.path_edge[p] >> 1];
+				if (es < 0) continue;
+				const auto& v = lm_edges[ls];
+				p_lme[p] = lme_base[ls] + (int)(std::lower_bound(v.begin(), v.end(), es) - v.begin());
+			}
+		}
+		path_obs.insert(path_obs.end(), p_obs.begin(), p_obs.end());
+		path_lme.insert(path_lme.end(), p_lme.begin(), p_lme.end());
+		int acc = 0;
+		for (int l = 0; l < L; ++l) { lmo_off.push_back(acc); acc += (int)lm_obs[l].size(); lmo_idx.insert(lmo_idx.end(), lm_obs[l].begin(), lm_obs[l].end()); }
+		lmo_off.push_back(acc);
+		std::vector<std::vector<int>> edge_lmes((size_t)E), edge_paths((size_t)E);
+		for (int l = 0; l < L; ++l) {
+			lme_off.push_back(lme_base[l]);
+			for (size_t k = 0; k < lm_edges[l].size(); ++k) {
+				lme_edge.push_back(lm_edges[l][k]);
+				lme_lm.push_back(l);
+				edge_lmes[lm_edges[l][k]].push_back(lme_base[l] + (int)k);
+			}
+		}
+		lme_off.push_back(lme_base[L]);
+		// pair lists
+		auto pid = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
+		std::vector<std::vector<int2>> po((size_t)H.n_pairs), pl((size_t)H.n_pairs);
+		for (int e2 = 0; e2 < E; ++e2) for (int e = 0; e <= e2; ++e) pair_ee.push_back(make_int2(e, e2));
+		for (int o = 0; o < Wn.n_obs; ++o) {
+			int ps[SSK_LM_MAX_PATH], es[SSK_LM_MAX_PATH], n = 0;
+			for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p) {
+				const int s = Wn.edge_unknown_slot[Wn.path_edge[p] >> 1];
+				if (s >= 0) { ps[n] = p; es[n] = s; ++n; edge_paths[s].push_back(p); }
+			}
+			for (int i = 0; i < n; ++i)
+				for (int j = 0; j < n; ++j) {
+					if (es[i] > es[j] || (es[i] == es[j] && i != j)) continue;
+					po[pid(es[i], es[j])].push_back(make_int2(ps[i], ps[j]));
+				}
+		}
+		for (int l = 0; l < L; ++l) {
+			const auto& v = lm_edges[l];
+			for (size_t i = 0; i < v.size(); ++i)
+				for (size_t j = i; j < v.size(); ++j)
+					pl[pid(v[i], v[j])].push_back(make_int2(lme_base[l] + (int)i, lme_base[l] + (int)j));
+		}
+		int ao = 0, al = 0;
+		for (int q = 0; q < H.n_pairs; ++q) {
+			ppo_off.push_back(ao); ao += (int)po[q].size(); ppo.insert(ppo.end(), po[q].begin(), po[q].end());
+			ppl_off.push_back(al); al += (int)pl[q].size(); ppl.insert(ppl.end(), pl[q].begin(), pl[q].end());
+		}
+		ppo_off.push_back(ao); ppl_off.push_back(al);
+		int ae = 0, ap = 0;
+		for (int e = 0; e < E; ++e) {
+			el_off.push_back(ae); ae += (int)edge_lmes[e].size(); el_idx.insert(el_idx.end(), edge_lmes[e].begin(), edge_lmes[e].end());
+			pe_off.push_back(ap); ap += (int)edge_paths[e].size(); pe_idx.insert(pe_idx.end(), edge_paths[e].begin(), edge_paths[e].end());
+		}
+		el_off.push_back(ae); pe_off.push_back(ap);
+	}
+
+	ssk_lm_batch* b = new ssk_lm_batch();
+	b->ctx = ctx; b->n_windows = n_windows; b->trace = trace; b->max_iters_alloc = MAX_ITERS_ALLOC; b->max_n6 = max_n6;
+	b->hdr = hdr; b->n_pose = pose.size(); b->n_lm = lm.size();
+	lm_dev& D = b->D;
+	int rc = SSK_OK;
+#define UP(vec, field) if (!rc) rc = upload(b, vec, &D.field)
+	UP(hdr, win);
+	UP(edge_slot, edge_slot); UP(lm_slot, lm_slot); UP(obs_lm, obs_lm); UP(obs_px, obs_px); UP(obs_path_off, obs_path_off);
+	UP(path_edge, path_edge); UP(path_obs, path_obs); UP(path_lme, path_lme); UP(slot_edge, slot_edge); UP(slot_lm, slot_lm);
+	UP(lmo_off, lmo_off); UP(lmo_idx, lmo_idx); UP(lme_off, lme_off); UP(lme_edge, lme_edge); UP(lme_lm, lme_lm);
+	UP(pair_ee, pair_ee); UP(ppo_off, ppo_off); UP(ppo, ppo); UP(ppl_off, ppl_off); UP(ppl, ppl);
+	UP(el_off, el_off); UP(el_idx, el_idx); UP(pe_off, pe_off); UP(pe_idx, pe_idx);
+	UP(pose, pose0); UP(lm, lm0);
+#undef UP
+	const double *c_pose = nullptr, *c_lm = nullptr;
+	if (!rc) rc = upload(b, pose, &c_pose);
+	if (!rc) rc = upload(b, lm, &c_lm);
+	D.pose = const_cast<double*>(c_pose); D.lm = const_cast<double*>(c_lm);
+	const size_t n_obs = obs_lm.size(), n_path = path_edge.size(), n_ls = slot_lm.size(), n_us = slot_edge.size(), n_lme = lme_edge.size();
+	if (!rc) rc = scratch(b, pose.size(), &D.pose_new);
+	if (!rc) rc = scratch(b, lm.size(), &D.lm_new);
+	if (!rc) rc = scratch(b, 4 * n_obs, &D.obs_r);
+	if (!rc) rc = scratch(b, 12 * n_obs, &D.obs_Jf);
+	if (!rc) rc = scratch(b, 3 * n_path, &D.path_q);
+	if (!rc) rc = scratch(b, 24 * n_path, &D.path_Je);
+	if (!rc) rc = scratch(b, 9 * n_ls, &D.Hff);
+	if (!rc) rc = scratch(b, 9 * n_ls, &D.Vinv);
+	if (!rc) rc = scratch(b, 3 * n_ls, &D.gf);
+	if (!rc) rc = scratch(b, 3 * n_ls, &D.df);
+	if (!rc) rc = scratch(b, 18 * n_lme, &D.Wb);
+	if (!rc) rc = scratch(b, 18 * n_lme, &D.Tb);
+	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hpp);
+	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hred);
+	if (!rc) rc = scratch(b, 6 * n_us, &D.gp);
+	if (!rc) rc = scratch(b, 6 * n_us, &D.dp);
+	if (!rc) rc = scratch(b, (size_t)n_windows, &D.res);
+	if (!rc) rc = scratch(b, trace ? (size_t)n_windows * MAX_ITERS_ALLOC : 1, &D.trace);
+	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
+	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
+	D.trace_on = trace ? 1 : 0;
+	b->dp_trace_total = dpt; b->df_trace_total = dft;
+	if (rc) { ssk_lm_batch_destroy(b); return rc; }
+	*out = b;
+	return SSK_OK;
+}
+
+int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_reset: batch is NULL");
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	return ssk_lm_launch_reset(ctx, b->D.pose, b->D.pose0, b->n_pose, b->D.lm, b->D.lm0, b->n_lm);
+}
+
+int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || !p) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: NULL argument");
+	if (p->max_iters < 0 || (b->trace && p->max_iters > b->max_iters_alloc))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: max_iters %d outside [0,%d] for a traced batch", p->max_iters, b->max_iters_alloc);
+	if (p->use_robust_kernel && !(p->kernel_param > 0)) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: kernel_param must be > 0");
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	lm_cam P;
+	P.fx_l = p->fx_l; P.fy_l = p->fy_l; P.cx_l = p->cx_l; P.cy_l = p->cy_l;
+	P.fx_r = p->fx_r; P.fy_r = p->fy_r; P.cx_r = p->cx_r; P.cy_r = p->cy_r; P.baseline = p->baseline;
+	for (int i = 0; i < 12; ++i) P.S[i] = p->sensor_pose[i];
+	P.max_iters = p->max_iters; P.robust = p->use_robust_kernel; P.kernel = p->kernel_param; P.tau = p->tau;
+	P.max_lambda = p->max_lambda; P.stop_rmse = p->max_error_per_obs_to_stop; P.conv_rel = p->converged_rel_decrease;
+	return ssk_lm_launch(ctx, b->D, P, b->n_windows, b->max_n6);
+}
+
+int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_results: NULL argument");
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	SSK_HIP(ctx, hipMemcpy(out, b->D.res, sizeof(ssk_lm_result) * (size_t)b->n_windows, hipMemcpyDeviceToHost));
+	return SSK_OK;
+}
+
+int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_inv_pose, double* lm_pos)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || w < 0 || w >= b->n_windows) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_state: bad argument");
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const lm_win& H = b->hdr[w];
+	if (edge_inv_pose && H.n_edges) SSK_HIP(ctx, hipMemcpy(edge_inv_pose, b->D.pose + 12 * (size_t)H.edge0, sizeof(double) * 12 * (size_t)H.n_edges, hipMemcpyDeviceToHost));
+	if (lm_pos && H.n_lms) SSK_HIP(ctx, hipMemcpy(lm_pos, b->D.lm + 3 * (size_t)H.lm0, sizeof(double) * 3 * (size_t)H.n_lms, hipMemcpyDeviceToHost));
+	return SSK_OK;
+}
+
+int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_entry* entries, int cap,
+                           double* delta_p, double* delta_f, int* n_entries)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || w < 0 || w >= b->n_windows || !entries || !n_entries) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_trace: bad argument");
+	if (!b->trace) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_trace: the batch was created without trace");
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ssk_lm_result r;
+	SSK_HIP(ctx, hipMemcpy(&r, b->D.res + w, sizeof r, hipMemcpyDeviceToHost));
+	const int n = std::min(r.iters, cap);
+	const lm_win& H = b->hdr[w];
+	if (n > 0) {
+		SSK_HIP(ctx, hipMemcpy(entries, b->D.trace + H.trace0, sizeof(ssk_lm_trace_entry) * (size_t)n, hipMemcpyDeviceToHost));
+		if (delta_p && H.E) SSK_HIP(ctx, hipMemcpy(delta_p, b->D.dp_trace + H.dp_trace0, sizeof(double) * (size_t)n * 6 * H.E, hipMemcpyDeviceToHost));
+		if (delta_f && H.L) SSK_HIP(ctx, hipMemcpy(delta_f, b->D.df_trace + H.df_trace0, sizeof(double) * (size_t)n * 3 * H.L, hipMemcpyDeviceToHost));
+	}
+	*n_entries = n;
+	return SSK_OK;
+}
+
+}  // extern "C"

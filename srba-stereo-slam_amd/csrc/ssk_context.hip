@@ -7,6 +7,16 @@ void ssk_kfbatch_destroy_internal(struct ssk_kfbatch* b);
 
 static std::string g_create_error;
 
+hipEvent_t ssk_prof_event(ssk_ctx* ctx)
+{
+	if (ctx->prof_used == ctx->prof_pool.size()) {
+		hipEvent_t e = nullptr;
+		if (hipEventCreate(&e) != hipSuccess) return nullptr;
+		ctx->prof_pool.push_back(e);
+	}
+	return ctx->prof_pool[ctx->prof_used++];
+}
+
 int ssk_set_error(ssk_ctx* ctx, int code, const char* fmt, ...)
 {
 	char buf[1024];
@@ -133,6 +143,7 @@ void ssk_destroy(ssk_ctx* ctx)
 	if (ctx->single) ssk_kfbatch_destroy_internal(ctx->single);
 	if (ctx->d_dir_thresh) (void)hipFree(ctx->d_dir_thresh);
 	if (ctx->d_pattern) (void)hipFree(ctx->d_pattern);
+	for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -162,6 +173,40 @@ int ssk_timer_stop_ms(ssk_ctx* ctx, float* ms)
 	SSK_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
 	SSK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
 	return SSK_OK;
+}
+
+int ssk_profile_enable(ssk_ctx* ctx, int on)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->prof_on = on != 0;
+	ctx->prof_open.clear();
+	ctx->prof_used = 0;
+	for (int i = 0; i < SSK_STAGE_COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_calls[i] = 0; }
+	return SSK_OK;
+}
+
+int ssk_profile_read(ssk_ctx* ctx, double* ms, int64_t* calls)
+{
+	if (!ctx || !ms || !calls) return SSK_ERR_BAD_ARG;
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (auto& r : ctx->prof_open) {
+		float t = 0.f;
+		SSK_HIP(ctx, hipEventElapsedTime(&t, r.a, r.b));
+		ctx->prof_ms[r.stage] += t;
+		ctx->prof_calls[r.stage] += 1;
+	}
+	ctx->prof_open.clear();
+	ctx->prof_used = 0;
+	for (int i = 0; i < SSK_STAGE_COUNT; ++i) { ms[i] = ctx->prof_ms[i]; calls[i] = ctx->prof_calls[i]; }
+	return SSK_OK;
+}
+
+const char* ssk_stage_name(int stage)
+{
+	static const char* names[SSK_STAGE_COUNT] = {"fast_nms", "select", "describe", "stereo_match", "hamming_match",
+	                                             "da_filters", "lm_linearize", "lm_schur", "lm_solve", "lm_update"};
+	return stage >= 0 && stage < SSK_STAGE_COUNT ? names[stage] : "?";
 }
 
 // test hook (declared in include/ssk_capi.h): the 19 direction-bin thresholds the context computed.

@@ -124,6 +124,7 @@ int ssk_launch_da_filters(ssk_ctx* ctx, const int32_t* d_train_idx, const int32_
                           int n_pairs, const ssk_da_params& prm, int32_t* d_status, int32_t* d_tracked)
 {
 	if (n_pairs <= 0) return SSK_OK;
+	ssk_stage_scope prof(ctx, SSK_STAGE_DA_FILTERS);
 	hipLaunchKernelGGL(da_filters_kernel, dim3(n_pairs), dim3(64), 0, ctx->stream,
 	                   d_train_idx, d_dist, d_out_beg, d_q_beg, d_q_end, d_t_beg, d_t_end, d_this_xy, d_other_xy, ctx->d_dir_thresh,
 	                   prm.filter_by_direction, prm.filter_by_orb_distance, (float)(size_t)prm.rows_offset,

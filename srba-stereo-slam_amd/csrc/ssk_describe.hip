@@ -128,6 +128,7 @@ int ssk_launch_describe(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end
 {
 	const int nimg = img_end - img_begin;
 	if (nimg <= 0 || n_feats <= 0) return SSK_OK;
+	ssk_stage_scope prof(ctx, SSK_STAGE_DESCRIBE);
 	hipLaunchKernelGGL(describe_kernel, dim3(n_feats, nimg), dim3(64), 0, ctx->stream, b->img, b->h, b->pitch,
 	                   img_begin, b->max_feats, b->kp_xy, b->nkp, ctx->d_pattern, b->kp_angle, b->desc);
 	SSK_LAUNCH_CHECK(ctx, "describe_kernel");

@@ -133,6 +133,7 @@ int ssk_launch_fast(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, in
 	SSK_HIP(ctx, hipMemsetAsync(b->ncand + img_begin, 0, sizeof(int32_t) * (size_t)nimg, ctx->stream));
 	const int ew = b->w - 2 * SSK_EDGE, eh = b->h - 2 * SSK_EDGE;
 	dim3 grid((ew + TW - 1) / TW, (eh + TH - 1) / TH, nimg);
+	ssk_stage_scope prof(ctx, SSK_STAGE_FAST);
 	hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, ctx->stream, b->img, b->w, b->h, b->pitch, img_begin,
 	                   threshold, b->cand, b->cand_cap, b->ncand);
 	SSK_LAUNCH_CHECK(ctx, "fast_nms_kernel");

@@ -97,6 +97,7 @@ int ssk_launch_hamming(ssk_ctx* ctx, const uint8_t* d_q, const int32_t* d_q_beg,
 {
 	if (n_pairs <= 0 || max_nq <= 0) return SSK_OK;
 	dim3 grid((max_nq + QT - 1) / QT, n_pairs);
+	ssk_stage_scope prof(ctx, SSK_STAGE_HAMMING);
 	hipLaunchKernelGGL(hamming_match_kernel, grid, dim3(QT * NW), 0, ctx->stream,
 	                   (const uint4*)d_q, d_q_beg, d_q_end, d_q_gather, (const uint4*)d_t, d_t_beg, d_t_end, d_t_gather,
 	                   d_out_beg, d_train_idx, d_dist);

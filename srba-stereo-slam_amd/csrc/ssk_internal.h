@@ -34,6 +34,31 @@ struct ssk_ctx {
 	int8_t* d_pattern = nullptr;
 	struct ssk_kfbatch* single = nullptr;   // 1-keyframe batch behind the host drop-in ssk_frontend_run
 	int n_cu = 256;
+	// per-stage HIP-event profiler (ssk_profile_*): event pairs recorded around kernel launches on the
+	// context stream while enabled; resolved into per-stage sums at ssk_profile_read.
+	bool prof_on = false;
+	std::vector<hipEvent_t> prof_pool;      // created lazily, reused
+	size_t prof_used = 0;
+	struct prof_rec { int stage; hipEvent_t a, b; };
+	std::vector<prof_rec> prof_open;
+	double prof_ms[SSK_STAGE_COUNT] = {0};
+	long long prof_calls[SSK_STAGE_COUNT] = {0};
+};
+
+hipEvent_t ssk_prof_event(ssk_ctx* ctx);
+struct ssk_stage_scope {
+	ssk_ctx* ctx; int stage; hipEvent_t a = nullptr;
+	ssk_stage_scope(ssk_ctx* c, int s) : ctx(c), stage(s)
+	{
+		if (ctx->prof_on) { a = ssk_prof_event(ctx); if (a) (void)hipEventRecord(a, ctx->stream); }
+	}
+	~ssk_stage_scope()
+	{
+		if (a) {
+			hipEvent_t b = ssk_prof_event(ctx);
+			if (b) { (void)hipEventRecord(b, ctx->stream); ctx->prof_open.push_back({stage, a, b}); }
+		}
+	}
 };
 
 int ssk_set_error(ssk_ctx* ctx, int code, const char* fmt, ...);

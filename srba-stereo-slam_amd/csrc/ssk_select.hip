@@ -201,6 +201,7 @@ int ssk_launch_select(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, 
 {
 	const int nimg = img_end - img_begin;
 	if (nimg <= 0) return SSK_OK;
+	ssk_stage_scope prof(ctx, SSK_STAGE_SELECT);
 	hipLaunchKernelGGL(select_kernel, dim3(nimg), dim3(NT), 0, ctx->stream, b->img, b->h, b->pitch, img_begin,
 	                   b->cand, b->cand_cap, b->ncand, p.n_feats, p.nms_radius, p.harris_k, b->max_feats,
 	                   b->kp_xy, b->kp_resp, b->nkp);

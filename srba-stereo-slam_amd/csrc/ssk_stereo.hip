@@ -122,6 +122,7 @@ int ssk_launch_stereo(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, co
 {
 	const int nkf = kf_end - kf_begin;
 	if (nkf <= 0) return SSK_OK;
+	ssk_stage_scope prof(ctx, SSK_STAGE_STEREO);
 	hipLaunchKernelGGL(stereo_match_kernel, dim3(nkf), dim3(256), 0, ctx->stream, kf_begin, b->max_feats, b->kp_xy,
 	                   b->nkp, b->desc, p.max_y_diff, p.min_disparity, p.max_disparity, p.orb_max_distance,
 	                   b->m_q, b->m_t, b->m_d, b->nm, b->m_row, b->m_xy);

@@ -30,7 +30,20 @@ def make_da(oracle):
                             exp_tracked=np.int32(tracked), **d)
 
 
+def make_lm(oracle):
+    import synth_lm as sl
+    win, gt = sl.make_submap_problem(7, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)
+    out = oracle.lm_solve(win, sl.make_params())
+    np.savez_compressed(os.path.join(HERE, "lm_case0.npz"), edge_unknown_slot=win.edge_unknown_slot,
+                        edge_inv_pose=win.edge_inv_pose, lm_unknown_slot=win.lm_unknown_slot, lm_pos=win.lm_pos,
+                        obs_lm=win.obs_lm, obs_px=win.obs_px, obs_path_off=win.obs_path_off, path_edge=win.path_edge,
+                        iters=out["res"].iters, accepted=out["res"].accepted,
+                        err_after=np.array([t.err_after for t in out["trace"]]),
+                        final_poses=out["poses"], final_lms=out["lms"])
+
+
 if __name__ == "__main__":
     o = ol.load()
     make_da(o)
+    make_lm(o)
     print("golden fixtures written to", HERE)

@@ -158,6 +158,49 @@ class Oracle:
         assert rc == 0
         return trim_kf_out(o, arrs)
 
+    # ---- relative bundle adjustment -----------------------------------------------------------------
+    def lm_total_error(self, win, prm, poses=None, lms=None):
+        poses = np.ascontiguousarray(win.edge_inv_pose if poses is None else poses, np.float64)
+        lms = np.ascontiguousarray(win.lm_pos if lms is None else lms, np.float64)
+        wc = win.c()
+        self.lib.ssko_lm_total_error.restype = C.c_double
+        return self.lib.ssko_lm_total_error(C.byref(wc), C.byref(prm), _p(poses), _p(lms))
+
+    def lm_gradient(self, win, prm, poses=None, lms=None):
+        poses = np.ascontiguousarray(win.edge_inv_pose if poses is None else poses, np.float64)
+        lms = np.ascontiguousarray(win.lm_pos if lms is None else lms, np.float64)
+        gp = np.zeros(6 * win.E + 1)
+        gf = np.zeros(3 * win.L + 1)
+        wc = win.c()
+        self.lib.ssko_lm_gradient(C.byref(wc), C.byref(prm), _p(poses), _p(lms), _p(gp), _p(gf))
+        return gp[:6 * win.E], gf[:3 * win.L]
+
+    def se3_left_update(self, eps, T):
+        out = np.zeros(12)
+        e = np.ascontiguousarray(eps, np.float64)
+        t = np.ascontiguousarray(T, np.float64)
+        self.lib.ssko_se3_left_update(_p(e), _p(t), _p(out))
+        return out
+
+    def lm_solve(self, win, prm, trace=True):
+        """Returns dict(poses, lms, result, trace entries, dp, df)."""
+        import synth_lm
+        poses = win.edge_inv_pose.copy()
+        lms = win.lm_pos.copy()
+        res = synth_lm.LmResultC()
+        n = prm.max_iters
+        tr = (synth_lm.LmTraceC * n)()
+        dp = np.zeros((n, 6 * win.E + 1))
+        df = np.zeros((n, 3 * win.L + 1))
+        dpc = np.zeros(n * 6 * win.E + 1)
+        dfc = np.zeros(n * 3 * win.L + 1)
+        wc = win.c()
+        self.lib.ssko_lm_solve(C.byref(wc), C.byref(prm), _p(poses), _p(lms), C.byref(res),
+                               tr if trace else None, _p(dpc) if trace else None, _p(dfc) if trace else None)
+        dp = dpc[:n * 6 * win.E].reshape(n, 6 * win.E) if win.E else np.zeros((n, 0))
+        df = dfc[:n * 3 * win.L].reshape(n, 3 * win.L) if win.L else np.zeros((n, 0))
+        return dict(poses=poses, lms=lms, res=res, trace=list(tr)[:res.iters], dp=dp[:res.iters], df=df[:res.iters])
+
     def project_match_to_3d(self, ul, vl, ur, cam):
         out = (C.c_double * 3)()
         self.lib.ssko_project_match_to_3d.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]

@@ -1,0 +1,216 @@
+"""Seeded synthetic relative-BA problems shaped like BASELINE.json configs[2] ("200-KF / 5k-landmark SRBA
+submap, local LM window"): keyframes on a smooth trajectory, fixed-size submaps joined star-of-stars as
+mySRBA::edge_creation_policy builds them (reference src/srba-stereo-slam.h:144-308), landmarks relative to
+the first keyframe that sees them, stereo observations with N(0, 0.5^2) pixel noise (EST.cpp:1157).
+
+Conventions are those of include/ssk_capi.h (ssk_lm_window): edge inv_pose = pose of `from` seen from `to`.
+"""
+import ctypes as C
+from collections import deque
+
+import numpy as np
+
+KITTI_CAM = dict(fx=707.0912, fy=707.0912, cx=601.8873, cy=183.1104, baseline=0.54, w=1226, h=370)
+# camera_pose_on_robot (+) (0,0,0,-90deg,0,-90deg)  (EST.cpp:1105-1112): camera z forward, x right, y down
+R_SENSOR = np.array([[0.0, 0, 1], [-1, 0, 0], [0, -1, 0]])
+
+
+def se3(R, t):
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    return T
+
+
+def rot_z(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+def so3_exp(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+    if th < 1e-8:
+        return np.eye(3) + K + 0.5 * K @ K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+class LmWindowC(C.Structure):
+    _fields_ = [("n_edges_total", C.c_int32), ("edge_unknown_slot", C.c_void_p), ("edge_inv_pose", C.c_void_p),
+                ("n_lms_total", C.c_int32), ("lm_unknown_slot", C.c_void_p), ("lm_pos", C.c_void_p),
+                ("n_obs", C.c_int32), ("obs_lm", C.c_void_p), ("obs_px", C.c_void_p),
+                ("obs_path_off", C.c_void_p), ("path_edge", C.c_void_p)]
+
+
+class LmParamsC(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")] + \
+               [("sensor_pose", C.c_double * 12), ("max_iters", C.c_int32), ("use_robust_kernel", C.c_int32),
+                ("kernel_param", C.c_double), ("tau", C.c_double), ("max_lambda", C.c_double),
+                ("max_error_per_obs_to_stop", C.c_double), ("converged_rel_decrease", C.c_double)]
+
+
+class LmResultC(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("accepted", C.c_int32), ("stop_reason", C.c_int32), ("n_obs", C.c_int32),
+                ("err_init", C.c_double), ("err_final", C.c_double), ("lambda_final", C.c_double)]
+
+
+class LmTraceC(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("err_before", C.c_double), ("err_after", C.c_double),
+                ("delta_p_norm", C.c_double), ("delta_f_norm", C.c_double), ("accepted", C.c_int32),
+                ("cholesky_ok", C.c_int32)]
+
+
+def make_params(max_iters=20, robust=True, kernel=1.5, sensor_t=(0.0, 0.0, 0.0), conv=1e-9):
+    k = KITTI_CAM
+    S = np.hstack([R_SENSOR, np.array(sensor_t, float).reshape(3, 1)])
+    return LmParamsC(k["fx"], k["fy"], k["cx"], k["cy"], k["fx"], k["fy"], k["cx"], k["cy"], k["baseline"],
+                     (C.c_double * 12)(*S.reshape(-1)), max_iters, int(robust), kernel, 1e-3, 1e20, 1e-9, conv)
+
+
+class Window:
+    """numpy arrays of one ssk_lm_window + its C view (arrays kept alive by the object)."""
+
+    def __init__(self, edge_unknown_slot, edge_inv_pose, lm_unknown_slot, lm_pos, obs_lm, obs_px, obs_path_off, path_edge):
+        self.edge_unknown_slot = np.ascontiguousarray(edge_unknown_slot, np.int32)
+        self.edge_inv_pose = np.ascontiguousarray(edge_inv_pose, np.float64).reshape(-1, 12)
+        self.lm_unknown_slot = np.ascontiguousarray(lm_unknown_slot, np.int32)
+        self.lm_pos = np.ascontiguousarray(lm_pos, np.float64).reshape(-1, 3)
+        self.obs_lm = np.ascontiguousarray(obs_lm, np.int32)
+        self.obs_px = np.ascontiguousarray(obs_px, np.float32).reshape(-1, 4)
+        self.obs_path_off = np.ascontiguousarray(obs_path_off, np.int32)
+        self.path_edge = np.ascontiguousarray(path_edge, np.int32)
+        self.E = int((self.edge_unknown_slot >= 0).sum())
+        self.L = int((self.lm_unknown_slot >= 0).sum())
+
+    def c(self):
+        p = lambda a: a.ctypes.data if a.size else 0
+        return LmWindowC(len(self.edge_unknown_slot), p(self.edge_unknown_slot), p(self.edge_inv_pose),
+                         len(self.lm_unknown_slot), p(self.lm_unknown_slot), p(self.lm_pos),
+                         len(self.obs_lm), p(self.obs_lm), p(self.obs_px), p(self.obs_path_off), p(self.path_edge))
+
+
+def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=4, opt_depth=5, obs_per_kf=250,
+                        px_noise=0.5, edge_noise=(0.05, 0.01), lm_noise=0.05, root=None):
+    """Returns (Window with a perturbed initial state, dict with ground truth)."""
+    rng = np.random.default_rng(0xBA5E0000 + seed)
+    k = KITTI_CAM
+    # ---- trajectory: ~1 m per keyframe, gentle yaw; robot x forward, z up ----
+    Tw = []
+    x, y, yaw = 0.0, 0.0, 0.0
+    for i in range(n_kf):
+        Tw.append(se3(rot_z(yaw), [x, y, 0.0]))
+        yaw += rng.normal(0.0, 0.02) + 0.01
+        x += np.cos(yaw) * 1.0
+        y += np.sin(yaw) * 1.0
+    # ---- graph: fixed-size submaps, star-of-stars (SRBA.h:176-306) ----
+    edges = []          # (from, to)
+    center = 0
+    members = 0
+    centers = [0]
+    adj = {i: [] for i in range(n_kf)}
+    for i in range(1, n_kf):
+        if members < submap_size - 1:
+            edges.append((center, i))
+            members += 1
+        else:
+            edges.append((center, i))       # new centre linked to the previous centre
+            center, members = i, 0
+            centers.append(i)
+        a, b = edges[-1]
+        adj[a].append((b, len(edges) - 1))
+        adj[b].append((a, len(edges) - 1))
+    inv_pose_gt = [np.linalg.inv(Tw[b]) @ Tw[a] for a, b in edges]      # `from` seen from `to`
+    # ---- landmarks along the corridor, observed by keyframes that see them in both cameras ----
+    S = se3(R_SENSOR, [0, 0, 0])
+    lm_world = np.column_stack([rng.uniform(-5, n_kf + 40, n_lm), rng.uniform(-15, 15, n_lm), rng.uniform(-2, 6, n_lm)])
+    base_of = -np.ones(n_lm, int)
+    obs = []            # (kf, lm, px4)
+
+    lm_h = np.column_stack([lm_world, np.ones(n_lm)])
+
+    def project_all(T_kf):
+        pc = (np.linalg.inv(T_kf @ S) @ lm_h.T)[:3].T
+        z = np.where(pc[:, 2] > 1e-9, pc[:, 2], 1.0)
+        u = k["cx"] + k["fx"] * pc[:, 0] / z
+        v = k["cy"] + k["fy"] * pc[:, 1] / z
+        ur = k["cx"] + k["fx"] * (pc[:, 0] - k["baseline"]) / z
+        ok = (pc[:, 2] >= 3.0) & (pc[:, 2] <= 60.0) & (u >= 0) & (u < k["w"]) & (ur >= 0) & (ur < k["w"]) & (v >= 0) & (v < k["h"])
+        return ok, np.column_stack([u, v, ur, v])
+
+    for i in range(n_kf):
+        ok, px = project_all(Tw[i])
+        vis = [(int(l), px[l]) for l in np.flatnonzero(ok)]
+        if len(vis) > obs_per_kf:
+            sel = rng.choice(len(vis), obs_per_kf, replace=False)
+            vis = [vis[s] for s in sorted(sel)]
+        for l, p in vis:
+            if base_of[l] < 0:
+                base_of[l] = i
+            obs.append((i, l, p + rng.normal(0, px_noise, 4) if px_noise > 0 else p))
+    # ---- paths by BFS (tree, so unique), dropped beyond max_tree_depth ----
+    def path(src, dst):
+        prev = {src: None}
+        dq = deque([src])
+        while dq:
+            u = dq.popleft()
+            if u == dst:
+                break
+            for v, e in adj[u]:
+                if v not in prev:
+                    prev[v] = (u, e)
+                    dq.append(v)
+        out, u = [], dst
+        while prev[u] is not None:
+            pu, e = prev[u]
+            out.append((e, pu, u))
+            u = pu
+        return out[::-1]     # steps from src towards dst: (edge, cur, next)
+
+    dist_from_root = {}
+    root = n_kf - 1 if root is None else root
+    dq = deque([(root, 0)])
+    dist_from_root[root] = 0
+    while dq:
+        u, d = dq.popleft()
+        for v, e in adj[u]:
+            if v not in dist_from_root:
+                dist_from_root[v] = d + 1
+                dq.append((v, d + 1))
+    area = {kf for kf, d in dist_from_root.items() if d <= opt_depth}
+    opt_edges = [ei for ei, (a, b) in enumerate(edges) if a in area and b in area]
+    win_obs = []
+    for kf, l, p in obs:
+        if kf not in area or base_of[l] not in area:
+            continue
+        steps = path(kf, base_of[l])
+        if len(steps) > max_tree_depth:
+            continue
+        win_obs.append((kf, l, p, steps))
+    used_edges = sorted({e for _, _, _, st in win_obs for e, _, _ in st} | set(opt_edges))
+    eidx = {e: i for i, e in enumerate(used_edges)}
+    used_lms = sorted({l for _, l, _, _ in win_obs})
+    lidx = {l: i for i, l in enumerate(used_lms)}
+    edge_slot = -np.ones(len(used_edges), np.int32)
+    for s, e in enumerate(opt_edges):
+        edge_slot[eidx[e]] = s
+    lm_slot = np.arange(len(used_lms), dtype=np.int32)       # every landmark of the area is optimised
+    gt_pose = np.array([inv_pose_gt[e][:3, :].reshape(-1) for e in used_edges])
+    gt_lm = np.array([(np.linalg.inv(Tw[base_of[l]]) @ np.append(lm_world[l], 1.0))[:3] for l in used_lms]).reshape(-1, 3)
+    obs_lm = np.array([lidx[l] for _, l, _, _ in win_obs], np.int32)
+    obs_px = np.array([p for _, _, p, _ in win_obs], np.float32).reshape(-1, 4)
+    off, pe = [0], []
+    for _, _, _, st in win_obs:
+        for e, cur, nxt in st:
+            a, b = edges[e]
+            # inv_pose maps `from`-frame points to the `to` frame: applying it goes next=from -> cur=to
+            pe.append(eidx[e] * 2 + (0 if (nxt == a and cur == b) else 1))
+        off.append(len(pe))
+    # ---- perturbed initial state ----
+    init_pose = gt_pose.copy()
+    for i in range(len(used_edges)):
+        if edge_slot[i] >= 0:
+            T = se3(gt_pose[i].reshape(3, 4)[:, :3], gt_pose[i].reshape(3, 4)[:, 3])
+            dT = se3(so3_exp(rng.normal(0, edge_noise[1], 3)), rng.normal(0, edge_noise[0], 3))
+            init_pose[i] = (dT @ T)[:3, :].reshape(-1)
+    init_lm = gt_lm + rng.normal(0, lm_noise, gt_lm.shape) * (1 + np.abs(gt_lm[:, :1]) / 10.0)
+    win = Window(edge_slot, init_pose, lm_slot, init_lm, obs_lm, obs_px, off, pe)
+    return win, dict(gt_pose=gt_pose, gt_lm=gt_lm, n_kf=n_kf, edges=[edges[e] for e in used_edges], area=sorted(area))
