@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- keyframes/sec (detect + match + LM solve) of the MI355X-native srba-stereo-slam hot path.
+
+One "step" = one pass of the whole per-keyframe hot path over a batch of B synthetic KITTI-shaped keyframes that
+is already resident in HBM when the timed region starts:
+    stereo front-end (FAST+NMS scan, selection, orientation+BRIEF, L<->R match)          [seam B1]
+  + keyframe<->previous-keyframe data association (Hamming K=1 + direction/ORB filters)  [seam B2]
+  + one relative-BA LM solve per keyframe on a BASELINE configs[2]-shaped window         [seam B3]
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), keyframe streams are partitioned one
+batch per GPU (weak scaling) and each step ends with ONE all-gather of the shared-landmark blocks.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant HBM-bound kernel (fast_nms_kernel), measured
+live with HIP events on the stream the kernels run on; `cpu_baseline` is the CPU oracle (the port, not the
+reference: the reference's path needs OpenCV/MRPT/SRBA/stereo-vo, absent here) timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 1241, 376
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_workload(pkg, capi, ctx, B, rank, n_base=8):
+    """B keyframes + B 'previous' keyframes resident in HBM, B LM windows uploaded."""
+    import torch
+    import synth
+    import synth_lm as sl
+    cur = capi.KfBatch(ctx, B, W, H, 512)
+    prev = capi.KfBatch(ctx, B, W, H, 512)
+    for i in range(min(n_base, B)):
+        l, r = synth.synth_stereo_pair(1000 * rank + i)
+        cur.upload(i, l, r)
+    ctx.synchronize()
+    ic, ip = cur.image_tensor(), prev.image_tensor()
+    for k in range(n_base, B):      # distinct content per keyframe: circular shifts of the base pairs
+        ic[k, :, :, :W] = torch.roll(ic[k % n_base, :, :, :W], shifts=5 * (k // n_base), dims=-1)
+    ip[:, :, :, :W] = torch.roll(ic[:, :, :, :W], shifts=(2, -3), dims=(-2, -1))   # previous keyframe: small image motion
+    torch.cuda.synchronize()
+    wins = [sl.make_submap_problem(100 * rank + s, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2,
+                                   obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0] for s in range(n_base)]
+    lm = capi.LmBatch(ctx, [wins[k % n_base] for k in range(B)])
+    return cur, prev, lm, wins
+
+
+def params(capi, sl):
+    import ctypes as C
+    import synth
+    fp = capi.FrontendParams(**synth.KITTI_FRONTEND)
+    da = capi.DaParams(1, 1, H, 60.0)
+    lp = capi.LmParams()
+    C.memmove(C.byref(lp), C.byref(sl.make_params()), C.sizeof(lp))
+    return fp, da, lp
+
+
+def cpu_baseline(sample_kf, wins):
+    """The oracle (CPU port, 1 thread, -O2 -march=native -ffp-contract=off) on `sample_kf` keyframes of the same
+    workload: front-end + DA vs a shifted previous keyframe + LM solve."""
+    import oracle_lib as ol
+    import synth
+    import synth_lm as sl
+    out_dir = os.path.join("/tmp", "ssk_oracle_native_%d" % os.getpid())
+    try:
+        oracle = ol.load(march="native", out=out_dir)
+    except Exception:
+        oracle = ol.load()
+    fp = ol.FrontendParams(**synth.KITTI_FRONTEND)
+    da = ol.DaParams(1, 1, H, 60.0)
+    lp = sl.make_params()
+    pat = ol.default_pattern()
+    base = [synth.synth_stereo_pair(i) for i in range(4)]
+    prev_kf = [oracle.frontend(np.roll(l, (2, -3), (0, 1)), np.roll(r, (2, -3), (0, 1)), fp, pat) for l, r in base]
+    t0 = time.perf_counter()
+    t_fe = t_da = t_lm = 0.0
+    for k in range(sample_kf):
+        l, r = base[k % len(base)]
+        a = time.perf_counter()
+        kf = oracle.frontend(l, r, fp, pat)
+        b = time.perf_counter()
+        va, _ka = ol.make_kf_view(**kf)
+        vb, _kb = ol.make_kf_view(**prev_kf[k % len(base)])
+        oracle.data_association(va, vb, da)
+        c = time.perf_counter()
+        oracle.lm_solve(wins[k % len(wins)], lp, trace=False)
+        d = time.perf_counter()
+        t_fe += b - a; t_da += c - b; t_lm += d - c
+    dt = time.perf_counter() - t0
+    return {"value": sample_kf / dt, "unit": "keyframes/s", "cores": 1, "kind": "port",
+            "sample": "%d keyframes of the same workload (CPU oracle, 1 thread): front-end %.1f ms + DA %.2f ms + LM %.1f ms per keyframe"
+                      % (sample_kf, 1e3 * t_fe / sample_kf, 1e3 * t_da / sample_kf, 1e3 * t_lm / sample_kf),
+            "host_cores": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="keyframes per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="keyframes timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--shared-landmarks", type=int, default=256)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    from ssk_amd import capi
+    import synth_lm as sl
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = pkg.Context(local, stream=stream)
+    B = args.batch
+    cur, prev, lm, wins = build_workload(pkg, capi, ctx, B, rank)
+    fp, da, lp = params(capi, sl)
+    pairs = np.stack([np.arange(B), np.arange(B)], 1).astype(np.int32)
+    dev = torch.device("cuda", local)
+    N = 512
+    d_idx = torch.empty(B * N, dtype=torch.int32, device=dev)
+    d_dist = torch.empty(B * N, dtype=torch.int32, device=dev)
+    d_st = torch.empty(B * N, dtype=torch.int32, device=dev)
+    d_tr = torch.empty(B, dtype=torch.int32, device=dev)
+    S = args.shared_landmarks
+    shared = torch.zeros(S * 12, dtype=torch.float64, device=dev)
+    gathered = torch.zeros(world * S * 12, dtype=torch.float64, device=dev) if world > 1 else None
+    fused = torch.zeros(S * 3, dtype=torch.float64, device=dev)
+
+    prev.run_frontend(fp)          # state: the previous keyframes' features (not part of a step)
+    ctx.synchronize()
+
+    def step():
+        cur.run_frontend(fp)
+        ctx.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
+        lm.reset()
+        lm.run(lp)
+        if world > 1:
+            # the one exchange step of the path: every submap's shared-landmark blocks to every GPU,
+            # fused in rank order (deterministic)
+            lm.pack_shared(0, S, shared)
+            dist.all_gather_into_tensor(gathered, shared)
+            ctx.stitch_shared(gathered, world, S, fused)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline pass: per-stage kernel time with HIP events on the same stream (all ranks run it, rank 0 reports)
+    ctx.profile_enable(True)
+    prof_steps = max(3, min(args.steps, 10))
+    for _ in range(prof_steps):
+        step()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    res = lm.results()
+    nkp, nm = cur.counts()
+    tracked = d_tr.cpu().numpy()
+
+    if rank == 0:
+        fast_ms, fast_calls = prof["fast_nms"]
+        fast_avg_ms = fast_ms / max(fast_calls, 1)
+        algo_bytes = float(B) * 2 * W * H                       # 933,232 B read per keyframe by the scan
+        achieved = algo_bytes / (fast_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "fast_nms_traffic.json")
+        if os.path.exists(tf):
+            try:
+                t = json.load(open(tf))
+                if int(t.get("batch", -1)) == B:
+                    traffic = float(t["hbm_bytes_per_launch"])
+            except Exception:
+                traffic = None
+        stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1] > 0}
+        line = {
+            "metric": "keyframes/sec (detect+match+LM solve), KITTI-00 stereo",
+            "value": world * B * args.steps / dt,
+            "unit": "keyframes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/int32 front-end + DA, f64 LM",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]+[2] per keyframe: 1241x376 stereo pair -> ORB(N=500, FAST 20, 1 level) + L<->R "
+                            "(max_y_diff 2, orb_max_distance 60) + KF<->KF Hamming DA with direction/ORB filters + SRBA LM window "
+                            "(200-KF/5k-landmark submap, submap_size 10, max_tree_depth 4, window = 10 most recent edges)",
+                "keyframes_per_gpu_per_step": B,
+                "parallelism": "keyframe streams partitioned one batch per GPU" + ("; 1 RCCL all-gather of %d shared-landmark blocks per step" % S if world > 1 else ""),
+                "mean_keypoints_per_image": float(nkp.mean()),
+                "mean_stereo_matches": float(nm.mean()),
+                "mean_tracked_vs_prev": float(tracked.mean()),
+                "lm_window": {"edges": int(wins[0].E), "landmarks": int(wins[0].L), "observations": int(len(wins[0].obs_lm)),
+                              "mean_iters": float(np.mean([r.iters for r in res]))},
+            },
+            "roofline": {"kernel": "fast_nms_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_avg_ms},
+            "stage_ms_per_launch": stages,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, wins)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    lm.close(); cur.close(); prev.close(); ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

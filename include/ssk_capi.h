@@ -284,6 +284,17 @@ int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_in
 int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_entry* entries, int cap,
                            double* delta_p, double* delta_f, int* n_entries);
 
+/* Multi-GPU exchange (no reference counterpart, the reference is single-process): submaps are
+ * partitioned one per GPU and stitched through landmarks observed from more than one submap.
+ * pack: the first n_shared optimised landmarks of window w as 12 doubles each -- position (3), gradient g_f
+ * (3), upper triangle of H_ff (6) as left by the last linearisation -- into a device buffer: the payload of
+ * the ONE all-gather per step (RCCL, issued by the host layer on the same stream).
+ * stitch: information-weighted fusion x = (sum_r H_r + eps I)^-1 sum_r H_r x_r of the gathered blocks of
+ * n_ranks GPUs ([n_ranks][n_shared][12], rank-major as all_gather lays them out), summed in rank order so
+ * every GPU computes bit-identical fused positions [n_shared*3]. */
+int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, double* d_out);
+int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double* d_fused);
+
 /* a10/a11: observation marshalling of EST.cpp:142-161,667-704: per match, feat id + pixels + the initial
  * landmark position  camera_pose_on_robot (+) projectMatchTo3D(xl,yl,xr)  (UTIL.h:558-574). Host arrays. */
 int ssk_build_observations(ssk_ctx* ctx, const ssk_keypoint* kp_left, const ssk_keypoint* kp_right,

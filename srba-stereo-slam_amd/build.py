@@ -23,7 +23,7 @@ FLAGS = [
     "-ffp-contract=off",          # float parity contract: no FMA contraction on host or device
     "-fno-fast-math", "-Wall", "-Wno-unused-function",
     "-I", os.path.join(ROOT, "include"),
-]
+] + os.environ.get("SSK_EXTRA_CFLAGS", "").split()     # e.g. -DSSK_LM_STAMPS for a diagnostic build
 
 
 def _sources():

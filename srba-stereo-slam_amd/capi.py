@@ -242,6 +242,9 @@ class LmBatch:
     def run(self, prm):
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_run(self.ctx.h, self.h_, C.byref(prm)))
 
+    def pack_shared(self, w, n_shared, d_out):
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_pack_shared(self.ctx.h, self.h_, int(w), int(n_shared), _dev(d_out)))
+
     def results(self):
         out = (LmResult * self.n)()
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_results(self.ctx.h, self.h_, out))
@@ -398,6 +401,9 @@ class Context:
         pos = np.zeros((len(m), 3), np.float64)
         self._chk(self.lib.ssk_build_observations(self.h, _ptr(kl), _ptr(kr), _ptr(m), len(m), C.byref(lm_params), _ptr(px), _ptr(pos)))
         return px, pos
+
+    def stitch_shared(self, d_gathered, n_ranks, n_shared, d_fused):
+        self._chk(self.lib.ssk_lm_stitch_shared(self.h, _dev(d_gathered), int(n_ranks), int(n_shared), _dev(d_fused)))
 
     # -- profiling -------------------------------------------------------------------------------------
     def profile_enable(self, on=True):

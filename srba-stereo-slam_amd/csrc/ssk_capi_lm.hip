@@ -12,7 +12,6 @@ struct ssk_lm_batch {
 	std::vector<void*> allocs;
 	lm_dev D{};
 	size_t n_pose = 0, n_lm = 0;      // doubles in pose / lm families
-	long long dp_trace_total = 0, df_trace_total = 0;
 };
 
 namespace {
@@ -58,9 +57,75 @@ __global__ void build_obs_kernel(const ssk_keypoint* __restrict__ kl, const ssk_
 		init_pos[3 * i + r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P.S[4 * r], X), __dmul_rn(P.S[4 * r + 1], Y)), __dmul_rn(P.S[4 * r + 2], Z)), P.S[4 * r + 3]);
 }
 
+// (e) multi-GPU exchange payload: per shared landmark 12 doubles = position (3), g_f (3), upper H_ff (6)
+__global__ void pack_shared_kernel(lm_dev D, int w, int n_shared, double* __restrict__ out)
+{
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_shared) return;
+	const lm_win W = D.win[w];
+	double* o = out + 12 * (size_t)s;
+	if (s >= W.L) { for (int c = 0; c < 12; ++c) o[c] = 0.0; return; }
+	const int li = D.slot_lm[W.ls0 + s];
+	const double* x = D.lm + 3 * (size_t)(W.lm0 + li);
+	const double* g = D.gf + 3 * (size_t)(W.ls0 + s);
+	const double* Hm = D.Hff + 9 * (size_t)(W.ls0 + s);
+	o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = g[0]; o[4] = g[1]; o[5] = g[2];
+	o[6] = Hm[0]; o[7] = Hm[1]; o[8] = Hm[2]; o[9] = Hm[4]; o[10] = Hm[5]; o[11] = Hm[8];
+}
+
+// fuse the gathered blocks in RANK ORDER (fixed summation order => bitwise identical on every GPU):
+// x = (sum_r H_r + eps I)^-1 (sum_r H_r x_r)
+__global__ void stitch_shared_kernel(const double* __restrict__ g, int n_ranks, int n_shared, double* __restrict__ fused)
+{
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_shared) return;
+	double A[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+	for (int r = 0; r < n_ranks; ++r) {
+		const double* p = g + 12 * ((size_t)r * n_shared + s);
+		const double h00 = p[6], h01 = p[7], h02 = p[8], h11 = p[9], h12 = p[10], h22 = p[11];
+		A[0] += h00; A[1] += h01; A[2] += h02; A[3] += h11; A[4] += h12; A[5] += h22;
+		b[0] += h00 * p[0] + h01 * p[1] + h02 * p[2];
+		b[1] += h01 * p[0] + h11 * p[1] + h12 * p[2];
+		b[2] += h02 * p[0] + h12 * p[1] + h22 * p[2];
+	}
+	const double eps = 1e-9;
+	const double a = A[0] + eps, bb = A[1], c = A[2], d = A[3] + eps, e = A[4], f = A[5] + eps;
+	const double c00 = d * f - e * e, c01 = c * e - bb * f, c02 = bb * e - c * d;
+	const double det = a * c00 + bb * c01 + c * c02;
+	const double id = 1.0 / det;
+	const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = (a * f - c * c) * id, i12 = (bb * c - a * e) * id, i22 = (a * d - bb * bb) * id;
+	fused[3 * s] = i00 * b[0] + i01 * b[1] + i02 * b[2];
+	fused[3 * s + 1] = i01 * b[0] + i11 * b[1] + i12 * b[2];
+	fused[3 * s + 2] = i02 * b[0] + i12 * b[1] + i22 * b[2];
+}
+
 }  // namespace
 
 extern "C" {
+
+int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, double* d_out)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || w < 0 || w >= b->n_windows || n_shared < 0 || (n_shared > 0 && !d_out))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_pack_shared: bad argument");
+	if (n_shared == 0) return SSK_OK;
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(pack_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, b->D, w, n_shared, d_out);
+	SSK_LAUNCH_CHECK(ctx, "pack_shared_kernel");
+	return SSK_OK;
+}
+
+int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double* d_fused)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (n_ranks < 1 || n_shared < 0 || (n_shared > 0 && (!d_gathered || !d_fused)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_stitch_shared: bad argument");
+	if (n_shared == 0) return SSK_OK;
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(stitch_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, d_gathered, n_ranks, n_shared, d_fused);
+	SSK_LAUNCH_CHECK(ctx, "stitch_shared_kernel");
+	return SSK_OK;
+}
 
 int ssk_build_observations(ssk_ctx* ctx, const ssk_keypoint* kp_left, const ssk_keypoint* kp_right,
                            const ssk_dmatch* matches, int n_matches, const ssk_lm_params* cam,
@@ -121,9 +186,11 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	const int MAX_ITERS_ALLOC = 64;
 	// batch-wide host images of every array family
-	std::vector<int> edge_slot, lm_slot, obs_lm, obs_path_off, path_edge, path_obs, path_lme, slot_edge, slot_lm;
-	std::vector<int> lmo_off, lmo_idx, lme_off, lme_edge, lme_lm, ppo_off, ppl_off, el_off, el_idx, pe_off, pe_idx;
-	std::vector<int2> pair_ee, ppo, ppl;
+	std::vector<int> edge_slot, lm_slot, obs_lm, obs_path_off, path_edge, path_obs, slot_edge, slot_lm;
+	std::vector<int> lmo_off, lmo_idx, lsm_off, lme_edge, lme_ls, lme_elpos, lmep_off, lmep_idx, q_off, q_uend, qo_off, el_off, el_idx;
+	std::vector<int2> pair_ee, q_mm, qo;
+	std::vector<int> qp_q, pc_off, sc_off;
+	std::vector<int3> pchunk, schunk;
 	std::vector<double> pose, lm;
 	std::vector<float> obs_px;
 	std::vector<lm_win> hdr((size_t)n_windows);
@@ -163,13 +230,104 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 			if (!Wn.path_edge || Wn.path_edge[p] < 0 || (Wn.path_edge[p] >> 1) >= Wn.n_edges_total)
 				return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d path entry %d out of range", w, p);
 
+		// ---- symbolic structure ----
+		// per landmark index: its (edge slot -> path entries) incidences
+		std::vector<int> p_obs((size_t)n_path);
+		std::vector<std::vector<std::pair<int, int>>> inc((size_t)Wn.n_lms_total);   // (edge slot, path entry)
+		std::vector<std::vector<int>> lm_obs((size_t)L);
+		for (int o = 0; o < Wn.n_obs; ++o) {
+			const int li = Wn.obs_lm[o];
+			const int ls = Wn.lm_unknown_slot[li];
+			if (ls >= 0) lm_obs[ls].push_back(o);
+			for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p) {
+				p_obs[p] = o;
+				const int es = Wn.edge_unknown_slot[Wn.path_edge[p] >> 1];
+				if (es >= 0) inc[li].push_back(std::make_pair(es, p));
+			}
+		}
+		// landmark order of the lme groups: optimised landmarks in slot order, then fixed ones
+		std::vector<int> order;
+		for (int s = 0; s < L; ++s) order.push_back(s_lm[s]);
+		for (int l = 0; l < Wn.n_lms_total; ++l) if (Wn.lm_unknown_slot[l] < 0 && !inc[l].empty()) order.push_back(l);
+		std::vector<int> w_lme_edge, w_lme_ls, w_lmep_off, w_lmep_idx, w_lsm_off;
+		std::vector<int> path_to_lme((size_t)n_path, -1);
+		std::vector<std::vector<int>> lm_lmes((size_t)order.size());
+		int n_lme_unknown = 0;
+		for (size_t oi = 0; oi < order.size(); ++oi) {
+			const int l = order[oi];
+			if ((int)oi < L) w_lsm_off.push_back((int)w_lme_edge.size());
+			auto& v = inc[l];
+			std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+			for (size_t k = 0; k < v.size();) {
+				const int es = v[k].first;
+				const int m = (int)w_lme_edge.size();
+				w_lme_edge.push_back(es);
+				w_lme_ls.push_back(Wn.lm_unknown_slot[l]);
+				w_lmep_off.push_back((int)w_lmep_idx.size());
+				for (; k < v.size() && v[k].first == es; ++k) { w_lmep_idx.push_back(v[k].second); path_to_lme[v[k].second] = m; }
+				lm_lmes[oi].push_back(m);
+			}
+			if ((int)oi == L - 1) n_lme_unknown = (int)w_lme_edge.size();
+		}
+		if (L > 0) w_lsm_off.push_back(n_lme_unknown); else n_lme_unknown = 0;
+		w_lmep_off.push_back((int)w_lmep_idx.size());
+		const int n_lme = (int)w_lme_edge.size();
+		// q entries: per landmark, pairs of its lme entries (edge slots ascending), then sorted pid-major
+		auto pid_of = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
+		struct qrec { int pid, lm_order, mi, mj; };
+		std::vector<qrec> qs;
+		for (size_t oi = 0; oi < order.size(); ++oi)
+			for (size_t i = 0; i < lm_lmes[oi].size(); ++i)
+				for (size_t j = i; j < lm_lmes[oi].size(); ++j)
+					qs.push_back({pid_of(w_lme_edge[lm_lmes[oi][i]], w_lme_edge[lm_lmes[oi][j]]), (int)oi, lm_lmes[oi][i], lm_lmes[oi][j]});
+		std::stable_sort(qs.begin(), qs.end(), [](const qrec& a, const qrec& b) { return a.pid != b.pid ? a.pid < b.pid : a.lm_order < b.lm_order; });
+		const int n_pairs = E * (E + 1) / 2, n_q = (int)qs.size();
+		std::vector<int> w_q_off((size_t)n_pairs + 1, 0), w_qo_off;
+		std::vector<int2> w_q_mm, w_qo;
+		std::vector<int> w_q_uend((size_t)n_pairs + 1, 0);
+		for (const qrec& r : qs) { w_q_off[r.pid + 1]++; if (r.lm_order < L) w_q_uend[r.pid]++; }
+		for (int p = 0; p < n_pairs; ++p) w_q_off[p + 1] += w_q_off[p];
+		for (int p = 0; p < n_pairs; ++p) w_q_uend[p] += w_q_off[p];     // optimised landmarks sort first inside a block
+		for (const qrec& r : qs) {
+			w_q_mm.push_back(make_int2(r.mi, r.mj));
+			w_qo_off.push_back((int)w_qo.size());
+			// observations of this landmark whose path holds both edges: merge the two path-entry lists by observation
+			const int a0 = w_lmep_off[r.mi], a1 = w_lmep_off[r.mi + 1], b0 = w_lmep_off[r.mj], b1 = w_lmep_off[r.mj + 1];
+			int ia = a0, ib = b0;
+			while (ia < a1 && ib < b1) {
+				const int oa = p_obs[w_lmep_idx[ia]], ob = p_obs[w_lmep_idx[ib]];
+				if (oa == ob) { w_qo.push_back(make_int2(w_lmep_idx[ia], w_lmep_idx[ib])); ++ia; ++ib; }
+				else if (oa < ob) ++ia; else ++ib;
+			}
+		}
+		w_qo_off.push_back((int)w_qo.size());
+		std::vector<std::vector<int>> edge_lmes((size_t)E);
+		for (int m = 0; m < n_lme; ++m) edge_lmes[w_lme_edge[m]].push_back(m);
+		// chunks of <= 64 items of one block: H_pp over the q entries with co-observations, Schur over the q
+		// entries of optimised landmarks (which sort first inside a block)
+		std::vector<int> w_qp_q, w_pc_off((size_t)n_pairs + 1, 0), w_sc_off((size_t)n_pairs + 1, 0);
+		std::vector<int3> w_pchunk, w_schunk;
+		for (int p = 0; p < n_pairs; ++p) {
+			w_pc_off[p] = (int)w_pchunk.size();
+			const int first = (int)w_qp_q.size();
+			for (int q = w_q_off[p]; q < w_q_off[p + 1]; ++q) if (w_qo_off[q + 1] > w_qo_off[q]) w_qp_q.push_back(q);
+			for (int k = first; k < (int)w_qp_q.size(); k += 64) w_pchunk.push_back(make_int3(p, k, std::min(64, (int)w_qp_q.size() - k)));
+			w_sc_off[p] = (int)w_schunk.size();
+			for (int q = w_q_off[p]; q < w_q_uend[p]; q += 64) w_schunk.push_back(make_int3(p, q, std::min(64, w_q_uend[p] - q)));
+		}
+		w_pc_off[n_pairs] = (int)w_pchunk.size();
+		w_sc_off[n_pairs] = (int)w_schunk.size();
+
 		H.n_edges = Wn.n_edges_total; H.E = E; H.n_lms = Wn.n_lms_total; H.L = L; H.n_obs = Wn.n_obs; H.n_path = n_path;
-		H.n_pairs = E * (E + 1) / 2;
+		H.n_pairs = n_pairs; H.n_lme = n_lme; H.n_lme_unknown = n_lme_unknown; H.n_q = n_q;
 		H.edge0 = (int)edge_slot.size(); H.lm0 = (int)lm_slot.size(); H.obs0 = (int)obs_lm.size();
 		H.opo0 = (int)obs_path_off.size(); H.path0 = (int)path_edge.size();
 		H.us0 = (int)slot_edge.size(); H.uso0 = (int)el_off.size(); H.ls0 = (int)slot_lm.size(); H.lso0 = (int)lmo_off.size();
-		H.lmo0 = (int)lmo_idx.size(); H.lme0 = (int)lme_edge.size(); H.pair0 = (int)pair_ee.size(); H.pairo0 = (int)ppo_off.size();
-		H.ppo0 = (int)ppo.size(); H.ppl0 = (int)ppl.size(); H.el0 = (int)el_idx.size(); H.pe0 = (int)pe_idx.size();
+		H.lmo0 = (int)lmo_idx.size(); H.lme0 = (int)lme_edge.size(); H.lmeo0 = (int)lmep_off.size(); H.lmep0 = (int)lmep_idx.size();
+		H.pair0 = (int)pair_ee.size(); H.pairo0 = (int)q_off.size(); H.q0 = (int)q_mm.size(); H.qo0 = (int)qo_off.size();
+		H.qe0 = (int)qo.size(); H.el0 = (int)el_idx.size();
+		H.qp0 = (int)qp_q.size(); H.pc0 = (int)pchunk.size(); H.sc0 = (int)schunk.size();
+		H.n_pchunk = (int)w_pchunk.size(); H.n_schunk = (int)w_schunk.size();
 		H.trace0 = w * MAX_ITERS_ALLOC; H.h0 = h_total; H.dp_trace0 = dpt; H.df_trace0 = dft;
 		h_total += (long long)36 * E * E;
 		if (trace) { dpt += (long long)MAX_ITERS_ALLOC * 6 * E; dft += (long long)MAX_ITERS_ALLOC * 3 * L; }
@@ -184,87 +342,38 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		if (Wn.n_obs) obs_path_off.insert(obs_path_off.end(), Wn.obs_path_off, Wn.obs_path_off + Wn.n_obs + 1);
 		else obs_path_off.push_back(0);
 		if (n_path) path_edge.insert(path_edge.end(), Wn.path_edge, Wn.path_edge + n_path);
+		path_obs.insert(path_obs.end(), p_obs.begin(), p_obs.end());
 		slot_edge.insert(slot_edge.end(), s_edge.begin(), s_edge.end());
 		slot_lm.insert(slot_lm.end(), s_lm.begin(), s_lm.end());
-
-		// ---- symbolic structure ----
-		std::vector<int> p_obs((size_t)n_path), p_lme((size_t)n_path, -1);
-		std::vector<std::vector<int>> lm_obs((size_t)L), lm_edges((size_t)L);
-		for (int o = 0; o < Wn.n_obs; ++o) {
-			const int ls = Wn.lm_unknown_slot[Wn.obs_lm[o]];
-			if (ls >= 0) lm_obs[ls].push_back(o);
-			for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p) {
-				p_obs[p] = o;
-				const int es = Wn.edge_unknown_slot[Wn.path_edge[p] >> 1];
-				if (ls >= 0 && es >= 0) lm_edges[ls].push_back(es);
-			}
-		}
-		std::vector<int> lme_base((size_t)L + 1, 0);
-		for (int l = 0; l < L; ++l) {
-			auto& v = lm_edges[l];
-			std::sort(v.begin(), v.end());
-			v.erase(std::unique(v.begin(), v.end()), v.end());
-			lme_base[l + 1] = lme_base[l] + (int)v.size();
-		}
-		for (int o = 0; o < Wn.n_obs; ++o) {
-			const int ls = Wn.lm_unknown_slot[Wn.obs_lm[o]];
-			if (ls < 0) continue;
-			for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p) {
-				const int es = Wn.edge_unknown_slot[Wn.path_edge[p] >> 1];
-				if (es < 0) continue;
-				const auto& v = lm_edges[ls];
-				p_lme[p] = lme_base[ls] + (int)(std::lower_bound(v.begin(), v.end(), es) - v.begin());
-			}
-		}
-		path_obs.insert(path_obs.end(), p_obs.begin(), p_obs.end());
-		path_lme.insert(path_lme.end(), p_lme.begin(), p_lme.end());
 		int acc = 0;
 		for (int l = 0; l < L; ++l) { lmo_off.push_back(acc); acc += (int)lm_obs[l].size(); lmo_idx.insert(lmo_idx.end(), lm_obs[l].begin(), lm_obs[l].end()); }
 		lmo_off.push_back(acc);
-		std::vector<std::vector<int>> edge_lmes((size_t)E), edge_paths((size_t)E);
-		for (int l = 0; l < L; ++l) {
-			lme_off.push_back(lme_base[l]);
-			for (size_t k = 0; k < lm_edges[l].size(); ++k) {
-				lme_edge.push_back(lm_edges[l][k]);
-				lme_lm.push_back(l);
-				edge_lmes[lm_edges[l][k]].push_back(lme_base[l] + (int)k);
-			}
-		}
-		lme_off.push_back(lme_base[L]);
-		// pair lists
-		auto pid = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
-		std::vector<std::vector<int2>> po((size_t)H.n_pairs), pl((size_t)H.n_pairs);
+		if (L > 0) lsm_off.insert(lsm_off.end(), w_lsm_off.begin(), w_lsm_off.end()); else lsm_off.push_back(0);
+		lme_edge.insert(lme_edge.end(), w_lme_edge.begin(), w_lme_edge.end());
+		lme_ls.insert(lme_ls.end(), w_lme_ls.begin(), w_lme_ls.end());
+		lmep_off.insert(lmep_off.end(), w_lmep_off.begin(), w_lmep_off.end());
+		lmep_idx.insert(lmep_idx.end(), w_lmep_idx.begin(), w_lmep_idx.end());
 		for (int e2 = 0; e2 < E; ++e2) for (int e = 0; e <= e2; ++e) pair_ee.push_back(make_int2(e, e2));
-		for (int o = 0; o < Wn.n_obs; ++o) {
-			int ps[SSK_LM_MAX_PATH], es[SSK_LM_MAX_PATH], n = 0;
-			for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p) {
-				const int s = Wn.edge_unknown_slot[Wn.path_edge[p] >> 1];
-				if (s >= 0) { ps[n] = p; es[n] = s; ++n; edge_paths[s].push_back(p); }
-			}
-			for (int i = 0; i < n; ++i)
-				for (int j = 0; j < n; ++j) {
-					if (es[i] > es[j] || (es[i] == es[j] && i != j)) continue;
-					po[pid(es[i], es[j])].push_back(make_int2(ps[i], ps[j]));
-				}
-		}
-		for (int l = 0; l < L; ++l) {
-			const auto& v = lm_edges[l];
-			for (size_t i = 0; i < v.size(); ++i)
-				for (size_t j = i; j < v.size(); ++j)
-					pl[pid(v[i], v[j])].push_back(make_int2(lme_base[l] + (int)i, lme_base[l] + (int)j));
-		}
-		int ao = 0, al = 0;
-		for (int q = 0; q < H.n_pairs; ++q) {
-			ppo_off.push_back(ao); ao += (int)po[q].size(); ppo.insert(ppo.end(), po[q].begin(), po[q].end());
-			ppl_off.push_back(al); al += (int)pl[q].size(); ppl.insert(ppl.end(), pl[q].begin(), pl[q].end());
-		}
-		ppo_off.push_back(ao); ppl_off.push_back(al);
-		int ae = 0, ap = 0;
+		q_off.insert(q_off.end(), w_q_off.begin(), w_q_off.end());
+		q_uend.insert(q_uend.end(), w_q_uend.begin(), w_q_uend.end());
+		pc_off.insert(pc_off.end(), w_pc_off.begin(), w_pc_off.end());
+		sc_off.insert(sc_off.end(), w_sc_off.begin(), w_sc_off.end());
+		qp_q.insert(qp_q.end(), w_qp_q.begin(), w_qp_q.end());
+		pchunk.insert(pchunk.end(), w_pchunk.begin(), w_pchunk.end());
+		schunk.insert(schunk.end(), w_schunk.begin(), w_schunk.end());
+		q_mm.insert(q_mm.end(), w_q_mm.begin(), w_q_mm.end());
+		qo_off.insert(qo_off.end(), w_qo_off.begin(), w_qo_off.end());
+		qo.insert(qo.end(), w_qo.begin(), w_qo.end());
+		int ae = 0;
+		std::vector<int> w_elpos((size_t)n_lme, 0);
 		for (int e = 0; e < E; ++e) {
-			el_off.push_back(ae); ae += (int)edge_lmes[e].size(); el_idx.insert(el_idx.end(), edge_lmes[e].begin(), edge_lmes[e].end());
-			pe_off.push_back(ap); ap += (int)edge_paths[e].size(); pe_idx.insert(pe_idx.end(), edge_paths[e].begin(), edge_paths[e].end());
+			el_off.push_back(ae);
+			for (size_t k = 0; k < edge_lmes[e].size(); ++k) w_elpos[edge_lmes[e][k]] = ae + (int)k;
+			ae += (int)edge_lmes[e].size();
+			el_idx.insert(el_idx.end(), edge_lmes[e].begin(), edge_lmes[e].end());
 		}
-		el_off.push_back(ae); pe_off.push_back(ap);
+		el_off.push_back(ae);
+		lme_elpos.insert(lme_elpos.end(), w_elpos.begin(), w_elpos.end());
 	}
 
 	ssk_lm_batch* b = new ssk_lm_batch();
@@ -275,17 +384,20 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 #define UP(vec, field) if (!rc) rc = upload(b, vec, &D.field)
 	UP(hdr, win);
 	UP(edge_slot, edge_slot); UP(lm_slot, lm_slot); UP(obs_lm, obs_lm); UP(obs_px, obs_px); UP(obs_path_off, obs_path_off);
-	UP(path_edge, path_edge); UP(path_obs, path_obs); UP(path_lme, path_lme); UP(slot_edge, slot_edge); UP(slot_lm, slot_lm);
-	UP(lmo_off, lmo_off); UP(lmo_idx, lmo_idx); UP(lme_off, lme_off); UP(lme_edge, lme_edge); UP(lme_lm, lme_lm);
-	UP(pair_ee, pair_ee); UP(ppo_off, ppo_off); UP(ppo, ppo); UP(ppl_off, ppl_off); UP(ppl, ppl);
-	UP(el_off, el_off); UP(el_idx, el_idx); UP(pe_off, pe_off); UP(pe_idx, pe_idx);
+	UP(path_edge, path_edge); UP(path_obs, path_obs); UP(slot_edge, slot_edge); UP(slot_lm, slot_lm);
+	UP(lmo_off, lmo_off); UP(lmo_idx, lmo_idx); UP(lsm_off, lsm_off);
+	UP(lme_edge, lme_edge); UP(lme_ls, lme_ls); UP(lme_elpos, lme_elpos); UP(lmep_off, lmep_off); UP(lmep_idx, lmep_idx);
+	UP(pair_ee, pair_ee); UP(q_off, q_off); UP(q_uend, q_uend); UP(q_mm, q_mm); UP(qo_off, qo_off); UP(qo, qo);
+	UP(el_off, el_off); UP(el_idx, el_idx);
+	UP(qp_q, qp_q); UP(pchunk, pchunk); UP(pc_off, pc_off); UP(schunk, schunk); UP(sc_off, sc_off);
 	UP(pose, pose0); UP(lm, lm0);
 #undef UP
 	const double *c_pose = nullptr, *c_lm = nullptr;
 	if (!rc) rc = upload(b, pose, &c_pose);
 	if (!rc) rc = upload(b, lm, &c_lm);
 	D.pose = const_cast<double*>(c_pose); D.lm = const_cast<double*>(c_lm);
-	const size_t n_obs = obs_lm.size(), n_path = path_edge.size(), n_ls = slot_lm.size(), n_us = slot_edge.size(), n_lme = lme_edge.size();
+	const size_t n_obs = obs_lm.size(), n_path = path_edge.size(), n_ls = slot_lm.size(), n_us = slot_edge.size();
+	const size_t n_lme = lme_edge.size();
 	if (!rc) rc = scratch(b, pose.size(), &D.pose_new);
 	if (!rc) rc = scratch(b, lm.size(), &D.lm_new);
 	if (!rc) rc = scratch(b, 4 * n_obs, &D.obs_r);
@@ -298,16 +410,18 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	if (!rc) rc = scratch(b, 3 * n_ls, &D.df);
 	if (!rc) rc = scratch(b, 18 * n_lme, &D.Wb);
 	if (!rc) rc = scratch(b, 18 * n_lme, &D.Tb);
-	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hpp);
+	if (!rc) rc = scratch(b, 6 * n_lme, &D.gpe);
+	if (!rc) rc = scratch(b, 6 * n_lme, &D.gre);
+	if (!rc) rc = scratch(b, 36 * pchunk.size(), &D.Ppart);
+	if (!rc) rc = scratch(b, 36 * schunk.size(), &D.Spart);
+	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hpair);
 	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hred);
-	if (!rc) rc = scratch(b, 6 * n_us, &D.gp);
 	if (!rc) rc = scratch(b, 6 * n_us, &D.dp);
 	if (!rc) rc = scratch(b, (size_t)n_windows, &D.res);
 	if (!rc) rc = scratch(b, trace ? (size_t)n_windows * MAX_ITERS_ALLOC : 1, &D.trace);
 	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
 	D.trace_on = trace ? 1 : 0;
-	b->dp_trace_total = dpt; b->df_trace_total = dft;
 	if (rc) { ssk_lm_batch_destroy(b); return rc; }
 	*out = b;
 	return SSK_OK;

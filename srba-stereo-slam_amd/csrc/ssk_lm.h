@@ -4,30 +4,45 @@
 
 constexpr int SSK_LM_MAX_PATH = 8;     // spanning-tree path length limit (reference max_tree_depth = 4, KITTI.ini:104)
 constexpr int SSK_LM_MAX_N6 = 768;     // reduced system limit: 6E <= 768 (E <= 128 optimised edges per window)
+constexpr int SSK_LM_LDS_EDGES = 128;  // edge poses cached in LDS up to this many edges per window
 
-// Per-window header.  Every "…0" member is the window's base offset into a batch-wide array family; values
+// Per-window header.  Every "...0" member is the window's base offset into a batch-wide array family; values
 // stored inside the families (offset tables, indices) are window relative.
+//
+// Symbolic structure (built once on the host, ssk_capi_lm.hip):
+//   lme entry m  = (landmark, optimised edge) incidence: the landmark has an observation whose path crosses
+//                  the edge.  Entries are grouped by landmark: optimised landmarks first, in slot order
+//                  (lsm_off[slot] .. lsm_off[slot+1]), then fixed landmarks.  lmep lists the path entries.
+//   q entry      = (landmark, pair of its lme entries m_i <= m_j by edge slot): one 6x6 block contribution to
+//                  the reduced system.  q entries are sorted by block pair id (pid-major), so the reduction of
+//                  block pid is a contiguous range q_off[pid] .. q_off[pid+1] of the 36-double slabs.
+//                  qo lists the (path entry of e_i, path entry of e_j) of the observations containing both.
 struct lm_win {
-	int n_edges, E, n_lms, L, n_obs, n_path, n_pairs;
+	int n_edges, E, n_lms, L, n_obs, n_path, n_pairs, n_lme, n_lme_unknown, n_q, n_pchunk, n_schunk;
 	int edge0;     // edges:        edge_slot[], pose*[] x12
 	int lm0;       // landmarks:    lm_slot[], lm*[] x3
 	int obs0;      // observations: obs_lm[], obs_px x4, obs_r x4, obs_Jf x12
 	int opo0;      // obs_path_off[] (n_obs+1 entries per window)
-	int path0;     // path entries: path_edge[], path_obs[], path_lme[], path_q x3, path_Je x24
-	int us0;       // optimised-edge slots: slot_edge[], gp x6, dp x6
-	int uso0;      // per optimised edge offset tables (E+1): el_off[], pe_off[]
+	int path0;     // path entries: path_edge[], path_obs[], path_q x3, path_Je x24
+	int us0;       // optimised-edge slots: slot_edge[], dp x6
+	int uso0;      // per optimised edge offset table (E+1): el_off[]
 	int ls0;       // optimised-landmark slots: slot_lm[], Hff x9, Vinv x9, gf x3, df x3
-	int lso0;      // per optimised landmark offset tables (L+1): lmo_off[], lme_off[]
-	int lmo0;      // lmo_idx[]  (observations of a landmark)
-	int lme0;      // (landmark, touched optimised edge) entries: lme_edge[], lme_lm[], Wb x18, Tb x18
+	int lso0;      // per optimised landmark offset tables (L+1): lmo_off[], lsm_off[]
+	int lmo0;      // lmo_idx[]  (observations of an optimised landmark)
+	int lme0;      // lme entries: lme_edge[], lme_ls[], lme_elpos[], Wb x18, Tb x18, gpe x6
+	int lmeo0;     // lmep_off[] (n_lme+1)
+	int lmep0;     // lmep_idx[] path entries of an lme entry
 	int pair0;     // block pairs e<=e': pair_ee[]
-	int pairo0;    // per pair offset tables (n_pairs+1): ppo_off[], ppl_off[]
-	int ppo0;      // ppo[] (path entry of e, path entry of e')
-	int ppl0;      // ppl[] (lme entry of e, lme entry of e')
-	int el0;       // el_idx[] lme entries per optimised edge
-	int pe0;       // pe_idx[] path entries per optimised edge
+	int pairo0;    // q_off[], q_uend[] (n_pairs+1): slabs of a block; those of optimised landmarks come first
+	int q0;        // q entries: q_mm[]
+	int qo0;       // qo_off[] (n_q+1)
+	int qe0;       // qo[] entries
+	int el0;       // el_idx[] lme entries per optimised edge (edge-major order); gre x6 in that order
+	int qp0;       // qp_q[]: q entries that have co-observations, sorted by block
+	int pc0;       // H_pp chunks: pchunk[] (block, first qp item, count <= 64), Ppart x36; pc_off[] lives at pairo0
+	int sc0;       // Schur chunks: schunk[] (block, first q, count <= 64), Spart x36; sc_off[] lives at pairo0
 	int trace0;    // trace entries (window * max_iters)
-	long long h0;  // Hpp / Hred (6E)^2 doubles
+	long long h0;  // Hred (6E)^2 doubles (only used when the matrix does not fit LDS); Hpair 36 x n_pairs
 	long long dp_trace0, df_trace0;
 };
 
@@ -36,15 +51,16 @@ struct lm_dev {
 	const int* edge_slot; double* pose; const double* pose0; double* pose_new;
 	const int* lm_slot; double* lm; const double* lm0; double* lm_new;
 	const int* obs_lm; const float* obs_px; const int* obs_path_off;
-	const int* path_edge; const int* path_obs; const int* path_lme;
+	const int* path_edge; const int* path_obs;
 	const int* slot_edge; const int* slot_lm;
-	const int* lmo_off; const int* lmo_idx;
-	const int* lme_off; const int* lme_edge; const int* lme_lm;
-	const int2* pair_ee; const int* ppo_off; const int2* ppo; const int* ppl_off; const int2* ppl;
-	const int* el_off; const int* el_idx; const int* pe_off; const int* pe_idx;
+	const int* lmo_off; const int* lmo_idx; const int* lsm_off;
+	const int* lme_edge; const int* lme_ls; const int* lme_elpos; const int* lmep_off; const int* lmep_idx;
+	const int2* pair_ee; const int* q_off; const int* q_uend; const int2* q_mm; const int* qo_off; const int2* qo;
+	const int* el_off; const int* el_idx;
+	const int* qp_q; const int3* pchunk; const int* pc_off; const int3* schunk; const int* sc_off;
 	double* obs_r; double* obs_Jf; double* path_q; double* path_Je;
-	double* Hff; double* Vinv; double* gf; double* df; double* Wb; double* Tb;
-	double* Hpp; double* Hred; double* gp; double* dp;
+	double* Hff; double* Vinv; double* gf; double* df; double* Wb; double* Tb; double* gpe; double* gre;
+	double* Ppart; double* Spart; double* Hpair; double* Hred; double* dp;
 	ssk_lm_result* res; ssk_lm_trace_entry* trace; double* dp_trace; double* df_trace;
 	int trace_on;
 };

@@ -89,7 +89,7 @@ class Window:
 
 
 def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=4, opt_depth=5, obs_per_kf=250,
-                        px_noise=0.5, edge_noise=(0.05, 0.01), lm_noise=0.05, root=None):
+                        px_noise=0.5, edge_noise=(0.05, 0.01), lm_noise=0.05, root=None, lm_fwd=(4.0, 45.0), z_vis=(3.0, 60.0)):
     """Returns (Window with a perturbed initial state, dict with ground truth)."""
     rng = np.random.default_rng(0xBA5E0000 + seed)
     k = KITTI_CAM
@@ -121,7 +121,10 @@ def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=
     inv_pose_gt = [np.linalg.inv(Tw[b]) @ Tw[a] for a, b in edges]      # `from` seen from `to`
     # ---- landmarks along the corridor, observed by keyframes that see them in both cameras ----
     S = se3(R_SENSOR, [0, 0, 0])
-    lm_world = np.column_stack([rng.uniform(-5, n_kf + 40, n_lm), rng.uniform(-15, 15, n_lm), rng.uniform(-2, 6, n_lm)])
+    # scattered around the trajectory: each landmark sits ahead of a random keyframe (robot frame: x fwd, y left, z up)
+    anchor = rng.integers(0, n_kf, n_lm)
+    local = np.column_stack([rng.uniform(lm_fwd[0], lm_fwd[1], n_lm), rng.uniform(-15, 15, n_lm), rng.uniform(-2, 6, n_lm), np.ones(n_lm)])
+    lm_world = np.array([(Tw[a] @ p)[:3] for a, p in zip(anchor, local)])
     base_of = -np.ones(n_lm, int)
     obs = []            # (kf, lm, px4)
 
@@ -133,7 +136,7 @@ def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=
         u = k["cx"] + k["fx"] * pc[:, 0] / z
         v = k["cy"] + k["fy"] * pc[:, 1] / z
         ur = k["cx"] + k["fx"] * (pc[:, 0] - k["baseline"]) / z
-        ok = (pc[:, 2] >= 3.0) & (pc[:, 2] <= 60.0) & (u >= 0) & (u < k["w"]) & (ur >= 0) & (ur < k["w"]) & (v >= 0) & (v < k["h"])
+        ok = (pc[:, 2] >= z_vis[0]) & (pc[:, 2] <= z_vis[1]) & (u >= 0) & (u < k["w"]) & (ur >= 0) & (ur < k["w"]) & (v >= 0) & (v < k["h"])
         return ok, np.column_stack([u, v, ur, v])
 
     for i in range(n_kf):
@@ -179,8 +182,8 @@ def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=
     opt_edges = [ei for ei, (a, b) in enumerate(edges) if a in area and b in area]
     win_obs = []
     for kf, l, p in obs:
-        if kf not in area or base_of[l] not in area:
-            continue
+        if kf not in area:          # observed from the local area; the base keyframe may lie outside it
+            continue                # (then the path runs over fixed edges, as in SRBA's optimize_local_area)
         steps = path(kf, base_of[l])
         if len(steps) > max_tree_depth:
             continue
