@@ -3,27 +3,41 @@
 // Replaces the detection half of cv::ORB as driven by stereo-vo's processNewImagePair (reference call
 // sites EST.cpp:112,267); contract C2-C4 of DESIGN.md "Front-end contract".
 //
-// Mapping (gfx950): one 256-thread workgroup per 64x16 output tile of one image; grid.z = image.
-//   phase 0  the (64+8) x (16+8) pixel tile (3-px ring + 1-px NMS halo) is staged in LDS with aligned
-//            dword loads (coalesced 4-B per lane along rows; neighbouring tiles re-read the halo from L2).
-//   phase A  cheap necessary test on the 4 compass ring pixels for every pixel of the 66x18 score region;
-//            survivors are queued in LDS (ds atomics), so phase B runs on dense lanes.
-//   phase B  exact score s-1 (max over the 16 arcs of 9 of the min signed difference, by min/max doubling)
-//            for queued pixels -> 8-bit score tile in LDS.
-//   phase C  strict 3x3 NMS on the score tile, survivors packed score<<24|(4095-y)<<12|(4095-x) into an LDS
-//            list; ONE global atomicAdd per workgroup reserves the output range in the image's list.
+// Mapping (gfx950): one 256-thread workgroup per 128x32 output tile (4 resident per CU: <= 128 VGPRs, 33 KiB
+// of LDS); each XCD owns a contiguous range of tiles, so halo re-reads stay in its L2.  Per tile:
+//   phase 0  the (128+16) x (32+8) pixel tile (ring + NMS halo, 4-byte aligned columns) is staged in LDS with
+//            aligned dword loads, 144 B per row coalesced (neighbouring tiles re-read the halo from L2);
+//   phase A  item = 4 horizontally adjacent pixels: FIVE dword LDS reads (rows y-3, y, y+3) feed the necessary
+//            test on the 4 compass ring pixels of all four (a 9-arc holds two adjacent compass points); survivors
+//            are appended to an LDS queue with ONE ds atomic per wave (ballot + lane prefix), so the later
+//            phases run on dense lanes;
+//   phase B1 queued pixels: 16-bit brighter / darker ring masks, exact "9 contiguous" test by mask doubling
+//            and shifts (~80 ops) -> second queue of real corners (a few % of the pixels);
+//   phase B  corners only: exact score s-1 (max over the 16 arcs of 9 of the min signed difference, by
+//            min/max doubling) -> 8-bit score tile in LDS;
+//   phase C  strict 3x3 NMS, 4 pixels per lane behind one dword read of their scores (all-zero groups skip),
+//            survivors packed score<<24|(4095-y)<<12|(4095-x) into an LDS list; ONE global atomicAdd per
+//            workgroup reserves the output range in the image's candidate list.
 // The candidate order in HBM is not deterministic (atomic reservation order); every consumer orders by
 // the packed key, which is unique per pixel, so results are.
 // Algorithmic bytes: W*H per image read once (+ 4 B per surviving corner written); roofline: HBM.
 #include "ssk_frontend.h"
+#include <cstdlib>
 
 namespace {
 
-constexpr int TW = 64, TH = 16;            // output tile
-constexpr int IW = 80;                     // LDS image tile pitch in bytes (20 dwords)
-constexpr int IH = TH + 8;
-constexpr int SW = TW + 2, SH = TH + 2;    // score region (tile + 1 halo)
-constexpr int SP = 68;                     // score tile pitch
+#ifndef SSK_FAST_WAVES
+#define SSK_FAST_WAVES 4                   // min waves per SIMD = workgroups per CU the register budget must allow
+#endif
+constexpr int TW = 128, TH = 32;           // output tile; tile origin x is a multiple of 4
+constexpr int X_ORG = 28;                  // first tile column (<= SSK_EDGE, multiple of 4)
+constexpr int IWV = TW + 16;               // LDS image tile: columns X0-8 .. X0+TW+7   (144 B = 36 dwords)
+constexpr int IW = IWV + 4;                // row pitch 148 B = 37 dwords (odd: ring gathers of different rows spread over the banks)
+constexpr int IH = TH + 8;                 //                 rows    Y0-4 .. Y0+TH+3
+constexpr int SG = (TW + 8) / 4;           // score groups per row: columns X0-4 .. X0+TW+3
+constexpr int SH = TH + 2;                 // score rows Y0-1 .. Y0+TH
+constexpr int SP = IWV;                    // score tile pitch (column index = gx - (X0-4))
+constexpr int NQ = SG * SH * 4;            // pixels in the score region
 
 __device__ __forceinline__ int fast_s(const int (&d)[16])
 {
@@ -43,85 +57,217 @@ __device__ __forceinline__ int fast_s(const int (&d)[16])
 	return max(sb, -hmin);
 }
 
-__global__ __launch_bounds__(256)
-void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch, int img_begin,
-                     int threshold, uint32_t* __restrict__ cand, int cand_cap, int32_t* __restrict__ ncand)
+// the 16 ring pixels around p (LDS, pitch IW) minus the centre, in ring order
+__device__ __forceinline__ void ring_diffs(const uint8_t* p, int (&d)[16])
+{
+	const int c = p[0];
+	d[0] = p[3 * IW] - c;       d[1] = p[3 * IW + 1] - c;   d[2] = p[2 * IW + 2] - c;   d[3] = p[IW + 3] - c;
+	d[4] = p[3] - c;            d[5] = p[-IW + 3] - c;      d[6] = p[-2 * IW + 2] - c;  d[7] = p[-3 * IW + 1] - c;
+	d[8] = p[-3 * IW] - c;      d[9] = p[-3 * IW - 1] - c;  d[10] = p[-2 * IW - 2] - c; d[11] = p[-IW - 3] - c;
+	d[12] = p[-3] - c;          d[13] = p[IW - 3] - c;      d[14] = p[2 * IW - 2] - c;  d[15] = p[3 * IW - 1] - c;
+}
+
+// append the values of the lanes with pred to an LDS queue: one ds atomic per wave
+__device__ __forceinline__ void wave_push(bool pred, uint16_t val, uint16_t* queue, int* counter)
+{
+	const unsigned long long m = __ballot(pred);
+	if (m == 0ull) return;                                   // wave uniform
+	const int lane = threadIdx.x & 63;
+	int base = 0;
+	if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, __popcll(m));
+	base = __shfl(base, __ffsll((long long)m) - 1, 64);
+	if (pred) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
+}
+// the same for up to 4 flagged values per lane (4 ballots, still ONE atomic per wave)
+template <typename T>
+__device__ __forceinline__ void wave_push4(const bool (&pr)[4], const T (&val)[4], T* queue, int* counter)
+{
+	const unsigned long long m0 = __ballot(pr[0]), m1 = __ballot(pr[1]), m2 = __ballot(pr[2]), m3 = __ballot(pr[3]);
+	const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+	const int n = n0 + n1 + n2 + n3;
+	if (n == 0) return;                                      // wave uniform
+	const int lane = threadIdx.x & 63;
+	int base = 0;
+	if (lane == 0) base = atomicAdd(counter, n);
+	base = __shfl(base, 0, 64);
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	if (pr[0]) queue[base + __popcll(m0 & lt)] = val[0];
+	if (pr[1]) queue[base + n0 + __popcll(m1 & lt)] = val[1];
+	if (pr[2]) queue[base + n0 + n1 + __popcll(m2 & lt)] = val[2];
+	if (pr[3]) queue[base + n0 + n1 + n2 + __popcll(m3 & lt)] = val[3];
+}
+
+__global__ __launch_bounds__(256, SSK_FAST_WAVES)
+void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch, int img_begin, int n_img,
+                     int tiles_x, int tiles_y, int threshold,
+                     uint32_t* __restrict__ cand, int cand_cap, int32_t* __restrict__ ncand)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_img[IH * IW];
-	__shared__ uint8_t s_score[SH * SP];
-	__shared__ uint16_t s_q[SW * SH];
+	__shared__ __attribute__((aligned(16))) uint8_t s_sc[SH * SP];
+	__shared__ uint16_t s_q1[NQ];
+	__shared__ uint16_t s_q2[NQ];
 	__shared__ uint32_t s_out[TW * TH / 4 + 64];
-	__shared__ int s_qn, s_on, s_base;
+	__shared__ int s_q1n, s_q2n, s_on, s_base;
 
-	const int img = img_begin + blockIdx.z;
-	const uint8_t* __restrict__ src = images + (size_t)img * h * pitch;
-	const int x0 = SSK_EDGE + blockIdx.x * TW, y0 = SSK_EDGE + blockIdx.y * TH;
-	const int xs = x0 - 4, xa = xs & ~3, shift = xs - xa;
 	const int tid = threadIdx.x;
+	// persistent workgroups: the tiles are split into 8 contiguous ranges, one per XCD (blocks b and b+8 share an
+	// XCD), so the blocks of an XCD sweep neighbouring tiles together and halo re-reads hit that XCD's L2
+	const int tiles_img = tiles_x * tiles_y, n_tiles = tiles_img * n_img;
+	const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, stride = gridDim.x >> 3;
+	const int per_x = (n_tiles + 7) >> 3;
+	const int t_end = min(n_tiles, (xcd + 1) * per_x);
+	constexpr int NLD = (IH * (IW / 4) + 255) / 256;        // dwords of a tile per thread (6)
+	uint32_t pre[NLD];
 
-	if (tid == 0) { s_qn = 0; s_on = 0; }
-	for (int i = tid; i < IH * (IW / 4); i += 256) {
-		const int row = i / (IW / 4), c = i - row * (IW / 4);
-		const int gy = min(max(y0 - 4 + row, 0), h - 1);
-		const int gx = xa + 4 * c;
-		uint32_t v = 0;
-		if (gx + 4 <= pitch) v = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
-		reinterpret_cast<uint32_t*>(s_img)[row * (IW / 4) + c] = v;
-	}
-	for (int i = tid; i < SH * SP; i += 256) s_score[i] = 0;
-	__syncthreads();
+	auto issue_loads = [&](int t) {
+		const int im = t / tiles_img, r = t - im * tiles_img, by = r / tiles_x, bx = r - by * tiles_x;
+		const uint8_t* __restrict__ src = images + (size_t)(img_begin + im) * h * pitch;
+		const int X0 = X_ORG + bx * TW, Y0 = SSK_EDGE + by * TH;
+#pragma unroll
+		for (int u = 0; u < NLD; ++u) {
+			const int i = tid + 256 * u;
+			uint32_t v = 0;
+			if (i < IH * (IW / 4)) {
+				const int row = i / (IW / 4), c = i - row * (IW / 4);
+				const int gy = min(max(Y0 - 4 + row, 0), h - 1);
+				const int gx = X0 - 8 + 4 * c;
+				if (gx + 4 <= pitch) v = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
+			}
+			pre[u] = v;
+		}
+	};
 
-	// phase A: necessary condition on the compass points 0,4,8,12 of the ring
-	for (int i = tid; i < SW * SH; i += 256) {
-		const int sy = i / SW, sx = i - sy * SW;          // score-region coords
-		const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-		if (gx < 3 || gx >= w - 3 || gy < 3 || gy >= h - 3) continue;
-		const uint8_t* p = s_img + (sy + 3) * IW + shift + (sx + 3);
-		const int c = p[0], hi = c + threshold, lo = c - threshold;
-		const int a0 = p[3 * IW], a4 = p[3], a8 = p[-3 * IW], a12 = p[-3];
-		const int nb = (a0 > hi) + (a4 > hi) + (a8 > hi) + (a12 > hi);
-		const int nd = (a0 < lo) + (a4 < lo) + (a8 < lo) + (a12 < lo);
-		if (nb >= 2 || nd >= 2) s_q[atomicAdd(&s_qn, 1)] = (uint16_t)i;
-	}
-	__syncthreads();
+	int t = xcd * per_x + jb;
+	if (t < t_end) issue_loads(t);
+	for (; t < t_end; t += stride) {
+		// the prefetched tile goes to LDS; the next tile's loads are issued right after and fly during the phases
+#pragma unroll
+		for (int u = 0; u < NLD; ++u) {
+			const int i = tid + 256 * u;
+			if (i < IH * (IW / 4)) reinterpret_cast<uint32_t*>(s_img)[i] = pre[u];
+		}
+		for (int i = tid; i < SH * SP / 4; i += 256) reinterpret_cast<uint32_t*>(s_sc)[i] = 0u;
+		if (tid == 0) { s_q1n = 0; s_q2n = 0; s_on = 0; }
+		__syncthreads();
+		if (t + stride < t_end) issue_loads(t + stride);
 
-	// phase B: exact score on the queued pixels
-	const int qn = s_qn;
-	for (int q = tid; q < qn; q += 256) {
-		const int i = s_q[q];
-		const int sy = i / SW, sx = i - sy * SW;
-		const uint8_t* p = s_img + (sy + 3) * IW + shift + (sx + 3);
-		const int c = p[0];
-		int d[16];
-		d[0] = p[3 * IW] - c;       d[1] = p[3 * IW + 1] - c;   d[2] = p[2 * IW + 2] - c;   d[3] = p[IW + 3] - c;
-		d[4] = p[3] - c;            d[5] = p[-IW + 3] - c;      d[6] = p[-2 * IW + 2] - c;  d[7] = p[-3 * IW + 1] - c;
-		d[8] = p[-3 * IW] - c;      d[9] = p[-3 * IW - 1] - c;  d[10] = p[-2 * IW - 2] - c; d[11] = p[-IW - 3] - c;
-		d[12] = p[-3] - c;          d[13] = p[IW - 3] - c;      d[14] = p[2 * IW - 2] - c;  d[15] = p[3 * IW - 1] - c;
-		const int s = fast_s(d);
-		if (s > threshold) s_score[sy * SP + sx] = (uint8_t)(s - 1);
-	}
-	__syncthreads();
+		const int im = t / tiles_img, rr = t - im * tiles_img, by = rr / tiles_x, bx = rr - by * tiles_x;
+		const int img = img_begin + im;
+		const int X0 = X_ORG + bx * TW, Y0 = SSK_EDGE + by * TH;
 
-	// phase C: strict 3x3 NMS inside the emit region [31,W-31) x [31,H-31)
-	for (int i = tid; i < TW * TH; i += 256) {
-		const int ly = i / TW, lx = i - ly * TW;
-		const int gx = x0 + lx, gy = y0 + ly;
-		if (gx >= w - SSK_EDGE || gy >= h - SSK_EDGE) continue;
-		const uint8_t* s = s_score + (ly + 1) * SP + (lx + 1);
-		const int v = s[0];
-		if (v == 0) continue;
-		if (v > s[-1] && v > s[1] && v > s[-SP - 1] && v > s[-SP] && v > s[-SP + 1] && v > s[SP - 1] && v > s[SP] && v > s[SP + 1])
-			s_out[atomicAdd(&s_on, 1)] = ((uint32_t)v << 24) | ((uint32_t)(4095 - gy) << 12) | (uint32_t)(4095 - gx);
+		// ---- phase A: compass test, 4 pixels per lane ----
+		for (int base = 0; base < SG * SH; base += 256) {
+			const int it = base + tid;
+			bool pr[4] = {false, false, false, false};
+			if (it < SG * SH) {
+				const int sy = it / SG, g = it - sy * SG;
+				const int gy = Y0 - 1 + sy, gx0 = X0 - 4 + 4 * g;
+				if (gy >= 3 && gy < h - 3) {
+					const uint32_t* r = reinterpret_cast<const uint32_t*>(s_img) + (sy + 3) * (IW / 4) + (g + 1);   // dword of (gx0, gy)
+					const uint32_t C = r[0], L = r[-1], R = r[1];
+					const uint32_t Dn = r[3 * (IW / 4)], Up = r[-3 * (IW / 4)];
+					const uint32_t E = (C >> 24) | (R << 8);          // bytes: x+3 of pixels 0..3
+					const uint32_t Wd = (L >> 8) | (C << 24);         // bytes: x-3 of pixels 0..3
+#pragma unroll
+					for (int k = 0; k < 4; ++k) {
+						const int c = (C >> (8 * k)) & 255, hi = c + threshold, lo = c - threshold;
+						const int a0 = (Dn >> (8 * k)) & 255, a8 = (Up >> (8 * k)) & 255;
+						const int a4 = (E >> (8 * k)) & 255, a12 = (Wd >> (8 * k)) & 255;
+						// a 9-arc holds two ADJACENT compass points: one of {0,8} and one of {4,12}
+						const bool bright = ((a0 > hi) | (a8 > hi)) & ((a4 > hi) | (a12 > hi));
+						const bool dark = ((a0 < lo) | (a8 < lo)) & ((a4 < lo) | (a12 < lo));
+						const int gx = gx0 + k;
+						pr[k] = (bright | dark) && gx >= 3 && gx < w - 3;
+					}
+				}
+			}
+			const uint16_t codes[4] = {(uint16_t)(it * 4), (uint16_t)(it * 4 + 1), (uint16_t)(it * 4 + 2), (uint16_t)(it * 4 + 3)};
+			wave_push4(pr, codes, s_q1, &s_q1n);
+		}
+		__syncthreads();
+
+		// ---- phase B1: exact corner test by ring masks ----
+		const int q1n = s_q1n;
+		for (int base = 0; base < q1n; base += 256) {
+			const int q = base + tid;
+			bool corner = false;
+			uint16_t code = 0;
+			if (q < q1n) {
+				code = s_q1[q];
+				const int it = code >> 2, k = code & 3;
+				const int sy = it / SG, g = it - sy * SG;
+				const uint8_t* p = s_img + (sy + 3) * IW + 4 * (g + 1) + k;
+				const int c = p[0], hi = c + threshold, lo = c - threshold;
+				const int r0 = p[3 * IW], r1 = p[3 * IW + 1], r2 = p[2 * IW + 2], r3 = p[IW + 3], r4 = p[3], r5 = p[-IW + 3];
+				const int r6 = p[-2 * IW + 2], r7 = p[-3 * IW + 1], r8 = p[-3 * IW], r9 = p[-3 * IW - 1], r10 = p[-2 * IW - 2];
+				const int r11 = p[-IW - 3], r12 = p[-3], r13 = p[IW - 3], r14 = p[2 * IW - 2], r15 = p[3 * IW - 1];
+				unsigned mb = 0, md = 0;
+#define SSK_RB(i, r) mb |= (unsigned)((r) > hi) << (i); md |= (unsigned)((r) < lo) << (i);
+				SSK_RB(0, r0) SSK_RB(1, r1) SSK_RB(2, r2) SSK_RB(3, r3) SSK_RB(4, r4) SSK_RB(5, r5) SSK_RB(6, r6) SSK_RB(7, r7)
+				SSK_RB(8, r8) SSK_RB(9, r9) SSK_RB(10, r10) SSK_RB(11, r11) SSK_RB(12, r12) SSK_RB(13, r13) SSK_RB(14, r14) SSK_RB(15, r15)
+#undef SSK_RB
+				unsigned xb = mb | (mb << 16), xd = md | (md << 16);
+				unsigned tb = xb & (xb >> 1), td = xd & (xd >> 1);
+				tb &= tb >> 2; td &= td >> 2;
+				tb &= tb >> 4; td &= td >> 4;
+				tb &= xb >> 8; td &= xd >> 8;
+				corner = ((tb | td) & 0xFFFFu) != 0u;
+			}
+			wave_push(corner, code, s_q2, &s_q2n);
+		}
+		__syncthreads();
+
+		// ---- phase B: exact score of the corners ----
+		const int q2n = s_q2n;
+		for (int q = tid; q < q2n; q += 256) {
+			const int code = s_q2[q];
+			const int it = code >> 2, k = code & 3;
+			const int sy = it / SG, g = it - sy * SG;
+			int d[16];
+			ring_diffs(s_img + (sy + 3) * IW + 4 * (g + 1) + k, d);
+			const int s = fast_s(d);
+			if (s > threshold) s_sc[sy * SP + 4 * g + k] = (uint8_t)(s - 1);
+		}
+		__syncthreads();
+
+		// ---- phase C: strict 3x3 NMS inside the emit region [31,W-31) x [31,H-31), 4 pixels per lane ----
+		for (int base = 0; base < (TW / 4) * TH; base += 256) {
+			const int it = base + tid;
+			bool pr[4] = {false, false, false, false};
+			uint32_t key[4] = {0, 0, 0, 0};
+			if (it < (TW / 4) * TH) {
+				const int ly = it / (TW / 4), g = it - ly * (TW / 4);
+				const int gy = Y0 + ly, gx0 = X0 + 4 * g;
+				const uint8_t* s = s_sc + (ly + 1) * SP + 4 * (g + 1);
+				const uint32_t own = *reinterpret_cast<const uint32_t*>(s);
+				if (own != 0u && gy < h - SSK_EDGE) {
+#pragma unroll
+					for (int k = 0; k < 4; ++k) {
+						const int v = (own >> (8 * k)) & 255;
+						const int gx = gx0 + k;
+						if (v == 0 || gx < SSK_EDGE || gx >= w - SSK_EDGE) continue;
+						const uint8_t* tt = s + k;
+						if (v > tt[-1] && v > tt[1] && v > tt[-SP - 1] && v > tt[-SP] && v > tt[-SP + 1] && v > tt[SP - 1] && v > tt[SP] && v > tt[SP + 1]) {
+							pr[k] = true;
+							key[k] = ((uint32_t)v << 24) | ((uint32_t)(4095 - gy) << 12) | (uint32_t)(4095 - gx);
+						}
+					}
+				}
+			}
+			wave_push4(pr, key, s_out, &s_on);
+		}
+		__syncthreads();
+		const int on = s_on;
+		if (tid == 0 && on > 0) s_base = atomicAdd(&ncand[img], on);
+		__syncthreads();
+		if (on > 0) {
+			const int base = s_base;
+			uint32_t* dst = cand + (size_t)img * cand_cap;
+			for (int i = tid; i < on; i += 256)
+				if (base + i < cand_cap) dst[base + i] = s_out[i];
+		}
+		__syncthreads();     // LDS is rewritten by the next tile
 	}
-	__syncthreads();
-	const int on = s_on;
-	if (on == 0) return;
-	if (tid == 0) s_base = atomicAdd(&ncand[img], on);
-	__syncthreads();
-	const int base = s_base;
-	uint32_t* dst = cand + (size_t)img * cand_cap;
-	for (int i = tid; i < on; i += 256)
-		if (base + i < cand_cap) dst[base + i] = s_out[i];
 }
 
 }  // namespace
@@ -131,11 +277,18 @@ int ssk_launch_fast(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, in
 	const int nimg = img_end - img_begin;
 	if (nimg <= 0) return SSK_OK;
 	SSK_HIP(ctx, hipMemsetAsync(b->ncand + img_begin, 0, sizeof(int32_t) * (size_t)nimg, ctx->stream));
-	const int ew = b->w - 2 * SSK_EDGE, eh = b->h - 2 * SSK_EDGE;
-	dim3 grid((ew + TW - 1) / TW, (eh + TH - 1) / TH, nimg);
+	const int ex = b->w - SSK_EDGE - X_ORG, eh = b->h - 2 * SSK_EDGE;     // columns X_ORG .. W-32, rows 31 .. H-32
+	const int tiles_x = (ex + TW - 1) / TW, tiles_y = (eh + TH - 1) / TH;
+	const long long n_tiles = (long long)tiles_x * tiles_y * nimg;
+	// default: one tile per workgroup, tile ranges contiguous per XCD; SSK_FAST_WG_PER_CU=k switches to k persistent
+	// workgroups per CU that prefetch their next tile (measured slower on MI355X: the dispatcher overlaps better)
+	static const int wg_per_cu = [] { const char* e = getenv("SSK_FAST_WG_PER_CU"); return e ? atoi(e) : 0; }();
+	long long g = wg_per_cu > 0 ? (long long)ctx->n_cu * wg_per_cu : n_tiles;    // 0: one tile per workgroup
+	if (g > n_tiles) g = n_tiles;
+	g = (g + 7) / 8 * 8;
 	ssk_stage_scope prof(ctx, SSK_STAGE_FAST);
-	hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, ctx->stream, b->img, b->w, b->h, b->pitch, img_begin,
-	                   threshold, b->cand, b->cand_cap, b->ncand);
+	hipLaunchKernelGGL(fast_nms_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, b->img, b->w, b->h, b->pitch, img_begin, nimg,
+	                   tiles_x, tiles_y, threshold, b->cand, b->cand_cap, b->ncand);
 	SSK_LAUNCH_CHECK(ctx, "fast_nms_kernel");
 	return SSK_OK;
 }
