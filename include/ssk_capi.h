@@ -166,7 +166,7 @@ typedef struct ssk_frontend_params {
 	float   max_disparity;
 	float   harris_k;         /* 0.04: cv::ORB HARRIS_SCORE */
 } ssk_frontend_params;
-/* KITTI.ini values: {500, 20, 1, 2, 60, 2.0f, 1.0f, (float)width, 0.04f} */
+/* KITTI.ini values: {500, 20, 1, 2, 60, 2.0f, 1.0f, 128.0f, 0.04f}  (disparity bound: depth >= 3 m at fx*b = 382) */
 
 /* One keyframe out, caller-allocated arrays of `capacity` (>= n_feats) records each (a1: KF.h:99-104). */
 typedef struct ssk_kf_out {

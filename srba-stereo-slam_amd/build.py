@@ -73,5 +73,24 @@ def build(verbose=True, jobs=4):
     return LIB
 
 
+def build_host(verbose=True):
+    """C++ facade (host/) + its demo driver, linked against libssk_hip.so (rpath: the package directory)."""
+    host = os.path.join(HERE, "host")
+    out = os.path.join(host, "facade_demo")
+    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp")]
+    deps = srcs + [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")] + [LIB]
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
+    cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")] + srcs + \
+          ["-L", HERE, "-lssk_hip", "-Wl,-rpath,$ORIGIN/..", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("host facade build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    if verbose:
+        print("host facade: %s" % out)
+    return out
+
+
 if __name__ == "__main__":
     build()
+    build_host()

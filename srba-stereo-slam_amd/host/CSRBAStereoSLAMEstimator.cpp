@@ -1,0 +1,159 @@
+// CSRBAStereoSLAMEstimator.cpp -- see the header.  EST.cpp = reference src/CSRBAStereoSLAMEstimator.cpp.
+#include "CSRBAStereoSLAMEstimator.h"
+#include <algorithm>
+#include <cstdio>
+#include <iostream>
+#include <set>
+
+namespace ssk {
+
+CSRBAStereoSLAMEstimator::CSRBAStereoSLAMEstimator(Context& ctx, const TSRBAStereoSLAMOptions& opts, const TGeneralOptions& gopts)
+	: srba_options(opts), general_options(gopts), rba(ctx, opts), m_ctx(ctx),
+	  m_fast_th(opts.detect_fast_th), m_orb_th(opts.orb_max_distance) {}
+
+// EST.cpp:263-315: the do { processNewImagePair } while (repeat) loop with the adaptive FAST / ORB thresholds
+void CSRBAStereoSLAMEstimator::m_frontend(const StereoImages& stImgs, CStereoSLAMKF& kf)
+{
+	bool repeat;
+	do {
+		repeat = false;
+		kf.create(m_ctx, stImgs, srba_options, m_fast_th, m_orb_th);
+		const int n_matches = (int)kf.m_matches.size();
+		if (!srba_options.orb_adaptive_fast_th) break;
+		if (n_matches < srba_options.adaptive_th_min_matches) {                          // :273
+			if (m_fast_th > FAST_TH_MIN) { m_fast_th = std::max(FAST_TH_MIN, m_fast_th - 10); repeat = true; }          // :275-280
+			else if (m_orb_th < ORB_TH_MAX) { m_orb_th = std::min(ORB_TH_MAX, m_orb_th + 10); repeat = true; }          // :281-287
+			else if (n_matches >= 8) { /* limits reached but a minimal set of matches exists: continue */ }             // :288-291
+			else throw std::runtime_error("The number of found matches is less than the minimum. Aborting");           // :292-295
+		} else if (n_matches < srba_options.adaptive_th_min_matches * 1.2) {              // :297-306
+			if (m_fast_th > FAST_TH_MIN) m_fast_th = std::max(FAST_TH_MIN, m_fast_th - 5);
+			else if (m_orb_th < ORB_TH_MAX) m_orb_th = std::min(ORB_TH_MAX, m_orb_th + 5);
+		} else {                                                                         // :307-313
+			m_fast_th = std::min(srba_options.detect_fast_th, m_fast_th + 5);
+			m_orb_th = srba_options.orb_max_distance;
+		}
+	} while (repeat);
+}
+
+// EST.cpp:1413-1515 + 1647-1669 on the GPU: gather matched-only descriptors (Q3), Hamming K=1, direction filter,
+// ORB-distance + uniqueness filter, tracking_info assembly
+void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& this_kf, const CStereoSLAMKF& other_kf, t_kf_da_info& out_da)
+{
+	const size_t n = this_kf.m_matches.size();
+	out_da.kf_idx = other_kf.m_kf_ID;                                                    // :1427
+	out_da.tracked_matches = 0;
+	out_da.tracking_info.assign(n, std::make_pair(INVALID_IDX, 0.0));                    // :1429
+	if (n == 0) return;
+	std::vector<DMatch> matches(n);
+	std::vector<int32_t> status(n);
+	int32_t tracked = 0;
+	const ssk_kf_view a = this_kf.view(), b = other_kf.view();
+	const ssk_da_params p = srba_options.da();
+	m_ctx.check(ssk_data_association(m_ctx.get(), &a, &b, &p, matches.data(), status.data(), &tracked), "m_internal_data_association");
+	for (size_t k = 0; k < n; ++k)                                                       // :1657-1669
+		if (status[k] == SSK_DA_TRACKED) {
+			out_da.tracking_info[k] = std::make_pair((size_t)matches[k].trainIdx, (double)matches[k].distance);
+			out_da.tracked_matches++;
+		}
+}
+
+void CSRBAStereoSLAMEstimator::m_data_association(const CStereoSLAMKF& kf, const std::vector<size_t>& similar_kfs, TVectorKfsDaInfo& out_da)
+{
+	out_da.clear();
+	out_da.reserve(similar_kfs.size());                                                  // :1346-1347
+	for (size_t k = 0; k < similar_kfs.size(); ++k) {                                    // :1365-1398
+		out_da.push_back(t_kf_da_info());
+		m_internal_data_association(kf, m_keyframes[similar_kfs[k]], out_da.back());
+	}
+}
+
+// EST.cpp:142-161 / 667-704: observation list; the pixel + initial-position arithmetic (projectMatchTo3D and the
+// camera pose composition) runs on the GPU (ssk_build_observations)
+void CSRBAStereoSLAMEstimator::m_build_observations(const CStereoSLAMKF& kf, new_kf_observations_t& listObs)
+{
+	const size_t n = kf.m_matches.size();
+	listObs.assign(n, new_kf_observation_t());
+	if (n == 0) return;
+	std::vector<float> px(4 * n);
+	std::vector<double> pos(3 * n);
+	const ssk_lm_params cam = srba_options.lm(true);
+	m_ctx.check(ssk_build_observations(m_ctx.get(), kf.m_keypoints_left.data(), kf.m_keypoints_right.data(), kf.m_matches.data(), (int)n,
+	                                   &cam, px.data(), pos.data()), "m_build_observations");
+	for (size_t m = 0; m < n; ++m) {
+		new_kf_observation_t& o = listObs[m];
+		o.is_fixed = false;                                                              // :143
+		o.is_unknown_with_init_val = true;                                               // :144
+		o.obs.feat_id = kf.m_matches_ID[m];                                              // :153
+		o.obs.obs_data.left_px.x = px[4 * m]; o.obs.obs_data.left_px.y = px[4 * m + 1];  // :154
+		o.obs.obs_data.right_px.x = px[4 * m + 2]; o.obs.obs_data.right_px.y = px[4 * m + 3];   // :155
+		o.setRelPos(&pos[3 * m]);                                                        // :158
+	}
+}
+
+TNewKeyFrameInfo CSRBAStereoSLAMEstimator::processKeyframe(const StereoImages& stImgs, const std::vector<size_t>& similar_in, const Pose3D& incr_pose)
+{
+	m_keyframes.push_back(CStereoSLAMKF());                                              // :84 / :413
+	CStereoSLAMKF& new_kf = m_keyframes.back();
+	new_kf.setKFID(m_last_kf_ID++);
+	m_frontend(stImgs, new_kf);
+	TNewKeyFrameInfo newKFInfo;
+	new_kf_observations_t listObs;
+	const size_t nMatches = new_kf.m_matches.size();
+	if (m_keyframes.size() == 1) {
+		// ---- first keyframe, EST.cpp:82-182 ----
+		new_kf.generateMatchesIDs(0);                                                    // IDs as the VO engine hands them over (KF.h:75-80)
+		m_last_match_ID = nMatches ? new_kf.m_matches_ID.back() : 0;                     // :115
+		if (general_options.debug) new_kf.saveInfoToFiles(general_options);              // :130-131
+		m_build_observations(new_kf, listObs);                                           // :134-161
+		rba.define_new_keyframe(listObs, newKFInfo, false);                              // :166-168: not optimised the first time
+		return newKFInfo;
+	}
+	// ---- data association with the similar keyframes, EST.cpp:447-450 ----
+	std::vector<size_t> similar = similar_in;
+	if (similar.empty()) similar.push_back(m_keyframes.size() - 2);                      // the previous keyframe (:1758)
+	TVectorKfsDaInfo daInfo;
+	m_data_association(new_kf, similar, daInfo);
+	// order by tracked matches, descending (DATrackedSorter, KF.h:117-126; EST.cpp:455-470)
+	std::vector<size_t> sortedIndices(daInfo.size());
+	for (size_t i = 0; i < sortedIndices.size(); ++i) sortedIndices[i] = i;
+	std::stable_sort(sortedIndices.begin(), sortedIndices.end(), [&](size_t a, size_t b) { return daInfo[a].tracked_matches > daInfo[b].tracked_matches; });
+	// ---- set ids for the current keyframe matches, EST.cpp:572-617 ----
+	new_kf.m_matches_ID.assign(nMatches, 0);
+	std::set<size_t> foundIds;
+	for (size_t m = 0; m < nMatches; ++m) {
+		bool tracked = false;
+		for (size_t k = 0; !tracked && k < daInfo.size(); ++k) {
+			const t_kf_da_info& da_info = daInfo[sortedIndices[k]];
+			if (da_info.tracking_info[m].first != INVALID_IDX) {                         // :582
+				const size_t other_match_idx = da_info.tracking_info[m].first;
+				const size_t other_match_id = m_keyframes[da_info.kf_idx].m_matches_ID[other_match_idx];   // :585
+				if (foundIds.count(other_match_id)) break;                               // :587-592
+				foundIds.insert(other_match_id);                                         // :593
+				new_kf.m_matches_ID[m] = other_match_id;                                 // :595
+				tracked = true;
+			}
+		}
+		if (!tracked) new_kf.m_matches_ID[m] = ++m_last_match_ID;                        // :607-611
+	}
+	if (general_options.debug) new_kf.saveInfoToFiles(general_options);                  // :735
+	// ---- observation list + SRBA, EST.cpp:667-704, 770-784 ----
+	m_build_observations(new_kf, listObs);
+	if (general_options.debug) {                                                         // :751-763 da_info_%04d.txt = the exact SRBA input
+		char name[1024];
+		std::snprintf(name, sizeof name, "%s/da_info_%04d.txt", general_options.out_dir.c_str(), (int)new_kf.m_kf_ID);
+		if (FILE* f = std::fopen(name, "wt")) {
+			for (const auto& o : listObs)
+				std::fprintf(f, "%llu %.2f %.2f %.2f %.2f\n", (unsigned long long)o.obs.feat_id, o.obs.obs_data.left_px.x, o.obs.obs_data.left_px.y,
+				             o.obs.obs_data.right_px.x, o.obs.obs_data.right_px.y);
+			std::fclose(f);
+		}
+	}
+	rba.setInitialKFPose(srba_options.use_initial_pose ? incr_pose : Pose3D());          // :772-778
+	rba.define_new_keyframe(listObs, newKFInfo, true);                                   // :782-784
+	if (general_options.verbose_level >= 1)                                              // :846-850
+		std::cout << "   Created KF #" << newKFInfo.kf_id << " | # kf-to-kf edges created: " << newKFInfo.created_edge_ids.size() << std::endl
+		          << "   Optimization error: " << newKFInfo.optimize_results.total_sqr_error_init << " -> " << newKFInfo.optimize_results.total_sqr_error_final << std::endl;
+	return newKFInfo;
+}
+
+}  // namespace ssk

@@ -1,0 +1,261 @@
+// srba_stereo_slam.cpp -- see srba_stereo_slam.h.  SRBA.h = reference src/srba-stereo-slam.h.
+#include "srba_stereo_slam.h"
+#include <algorithm>
+#include <functional>
+#include <limits>
+#include <queue>
+
+namespace ssk {
+
+mySRBA::mySRBA(Context& ctx, const TSRBAStereoSLAMOptions& o) : m_ctx(ctx), m_opts(o)
+{
+	// CSRBAStereoSLAMEstimator::initialize, EST.cpp:1149-1160
+	parameters.use_robust_kernel = o.srba_use_robust_kernel;
+	parameters.use_robust_kernel_stage1 = o.srba_use_robust_kernel_stage1;
+	parameters.kernel_param = o.srba_kernel_param;
+	parameters.max_tree_depth = o.srba_max_tree_depth;
+	parameters.max_optimize_depth = o.srba_max_optimize_depth;
+	parameters.submap_size = o.srba_submap_size;
+	parameters.std_noise_observations = 0.5;
+}
+
+size_t mySRBA::create_kf2kf_edge(TKeyFrameID from, TKeyFrameID to)
+{
+	k2k_edge_t e;
+	e.from = from; e.to = to;
+	m_state.k2k_edges.push_back(e);
+	const size_t id = m_state.k2k_edges.size() - 1;
+	if (m_adj.size() <= std::max(from, to)) m_adj.resize(std::max(from, to) + 1);
+	m_adj[from].push_back(std::make_pair(to, id));
+	m_adj[to].push_back(std::make_pair(from, id));
+	return id;
+}
+
+void mySRBA::bfs(TKeyFrameID root, size_t max_depth, std::map<TKeyFrameID, step_t>& out) const
+{
+	out.clear();
+	out[root] = step_t{root, (size_t)-1, 0};
+	std::queue<TKeyFrameID> q;
+	q.push(root);
+	while (!q.empty()) {
+		const TKeyFrameID u = q.front();
+		q.pop();
+		const size_t d = out[u].dist;
+		if (d >= max_depth || u >= m_adj.size()) continue;
+		for (const auto& ne : m_adj[u])
+			if (!out.count(ne.first)) { out[ne.first] = step_t{u, ne.second, d + 1}; q.push(ne.first); }
+	}
+}
+
+size_t mySRBA::topo_distance(TKeyFrameID a, TKeyFrameID b, size_t max_depth) const
+{
+	std::map<TKeyFrameID, step_t> t;
+	bfs(a, max_depth, t);
+	const auto it = t.find(b);
+	return it == t.end() ? std::numeric_limits<size_t>::max() : it->second.dist;
+}
+
+bool mySRBA::get_kf_relative_pose(TKeyFrameID root, TKeyFrameID target, size_t max_depth, Pose3D& out) const
+{
+	std::map<TKeyFrameID, step_t> t;
+	bfs(root, max_depth, t);
+	if (!t.count(target)) return false;
+	// walk target -> root; pose of target in root = prod over steps (prev <- cur)
+	Pose3D acc;      // identity: pose of `cur` in `cur`
+	TKeyFrameID cur = target;
+	while (cur != root) {
+		const step_t& s = t[cur];
+		const k2k_edge_t& e = m_state.k2k_edges[s.edge];
+		// T_{prev<-cur}: inv_pose maps `from`-frame points into the `to` frame
+		const Pose3D step = (e.from == cur && e.to == s.prev) ? e.inv_pose : e.inv_pose.inverse();
+		acc = step + acc;
+		cur = s.prev;
+	}
+	out = acc;
+	return true;
+}
+
+// ---- SRBA.h:144-308, restated line by line -------------------------------------------------------------
+void mySRBA::edge_creation_policy(TKeyFrameID new_kf_id, const new_kf_observations_t& obs, std::vector<TNewEdgeInfo>& new_k2k_edge_ids)
+{
+	if (new_kf_id < 1) throw std::runtime_error("edge_creation_policy: called for the first KF");             // :150
+	if (new_kf_id == 1) {                                                                                     // :153-158
+		m_kf_localmap_center_ID.push_back(std::set<TKeyFrameID>{0});
+		m_localmap_kf_IDs[0] = std::set<TKeyFrameID>();
+	}
+	const size_t MINIMUM_OBS_TO_LOOP_CLOSURE = parameters.min_obs_to_loop_closure;                              // :166
+	const size_t SUBMAP_SIZE = parameters.submap_size;                                                         // :167
+	const TKeyFrameID currentLocalmapBaseId = isKFLocalmapCenter(new_kf_id - 1) ? new_kf_id - 1 : getLocalmapCenterID(new_kf_id - 1);   // :170-173
+	const size_t NUM_KFS_LOCALMAP = m_localmap_kf_IDs.count(currentLocalmapBaseId) ? m_localmap_kf_IDs[currentLocalmapBaseId].size() : (size_t)-1;   // :176
+	if (NUM_KFS_LOCALMAP < SUBMAP_SIZE - 1) {                                                                 // :178
+		m_kf_localmap_center_ID.push_back(std::set<TKeyFrameID>{currentLocalmapBaseId});                       // :182-183
+		TNewEdgeInfo nei;
+		nei.has_approx_init_val = false;
+		nei.id = create_kf2kf_edge(currentLocalmapBaseId, new_kf_id);                                          // :186 (from = centre, to = new)
+		if (NUM_KFS_LOCALMAP == 0) {
+			// :194 as written assigns m_initial_kf_pose (the new KF seen from the previous one) to inv_pose, although
+			// inv_pose means `from` (the centre = previous KF) seen from `to` (the new KF), i.e. its inverse -- the
+			// other branch (:203) is consistent with the inverse.  Reproduced literally by default (only an initial guess).
+			m_state.k2k_edges[nei.id].inv_pose = parameters.literal_first_edge_init ? m_initial_kf_pose : m_initial_kf_pose.inverse();
+		} else {
+			// :203  inv_pose.inverseComposeFrom(prev_edge.inv_pose, m_initial_kf_pose) = initial^-1 (+) prev_edge.inv_pose
+			m_state.k2k_edges[nei.id].inv_pose = m_initial_kf_pose.inverse() + m_state.k2k_edges[nei.id - 1].inv_pose;
+		}
+		new_k2k_edge_ids.push_back(nei);
+		m_localmap_kf_IDs[currentLocalmapBaseId].insert(new_kf_id);                                            // :209
+	} else {
+		// :220-221 make_ordered_list_base_kfs: #observations of already known landmarks per base KF, descending
+		std::map<TKeyFrameID, size_t> obs_per_base;
+		for (const auto& o : obs) {
+			const auto it = m_state.unknown_lms.find(o.obs.feat_id);
+			if (it != m_state.unknown_lms.end()) obs_per_base[it->second.base_kf]++;
+		}
+		std::multimap<size_t, TKeyFrameID, std::greater<size_t>> obs_for_each_base_sorted;
+		for (const auto& kv : obs_per_base) obs_for_each_base_sorted.insert(std::make_pair(kv.second, kv.first));
+		std::map<TKeyFrameID, size_t> obs_for_each_area;                                                       // :224-232
+		for (const auto& kv : obs_for_each_base_sorted) obs_for_each_area[getLocalmapCenterID(kv.second)] += kv.first;
+		std::multimap<size_t, TKeyFrameID, std::greater<size_t>> obs_for_each_area_sorted;                     // :235-239
+		for (const auto& kv : obs_for_each_area) obs_for_each_area_sorted.insert(std::make_pair(kv.second, kv.first));
+		for (const auto& kv : obs_for_each_area_sorted) {                                                      // :242
+			const size_t num_obs_this_base = kv.first;
+			const TKeyFrameID central_kf_id = kv.second;
+			const size_t found_distance = topo_distance(new_kf_id, central_kf_id, parameters.max_tree_depth); // :253-269 (isolated KF: infinity)
+			if (found_distance >= parameters.max_optimize_depth) {                                            // :271
+				if (num_obs_this_base >= MINIMUM_OBS_TO_LOOP_CLOSURE) {                                       // :273
+					TNewEdgeInfo nei;
+					nei.id = create_kf2kf_edge(central_kf_id, new_kf_id);                                      // :278
+					nei.has_approx_init_val = false;
+					new_k2k_edge_ids.push_back(nei);
+					if (new_kf_id < m_kf_localmap_center_ID.size()) m_kf_localmap_center_ID[new_kf_id].insert(central_kf_id);   // :284-290
+					else m_kf_localmap_center_ID.push_back(std::set<TKeyFrameID>{central_kf_id});
+					m_localmap_kf_IDs[central_kf_id].insert(new_kf_id);                                        // :293
+					m_state.k2k_edges[nei.id].inv_pose = nei.id == 0 ? Pose3D() : m_state.k2k_edges[nei.id - 1].inv_pose;   // :294
+				}
+			}
+		}
+		if (new_k2k_edge_ids.empty())                                                                          // :304
+			throw std::runtime_error("Error for new KF: no suitable linking KF found with the minimum of common observations: the node becomes isolated of the graph!");
+		m_localmap_kf_IDs[new_kf_id] = std::set<TKeyFrameID>();                                                // :305
+	}
+}
+
+// one LM solve on the MI355X: window = opt_edges + everything the referenced observations' paths touch
+void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pair<TKeyFrameID, size_t>>& obs_refs,
+                    bool optimize_landmarks, bool robust, TOptimizeResults& res)
+{
+	std::map<TKeyFrameID, std::map<TKeyFrameID, step_t>> trees;
+	std::vector<int32_t> obs_lm, obs_path_off(1, 0), path_edge;
+	std::vector<float> obs_px;
+	std::map<size_t, int> edge_idx;
+	std::map<TLandmarkID, int> lm_idx;
+	std::vector<TLandmarkID> lm_ids;
+	std::vector<size_t> edge_ids;
+	auto edge_index = [&](size_t e) { auto it = edge_idx.find(e); if (it != edge_idx.end()) return it->second; const int i = (int)edge_ids.size(); edge_idx[e] = i; edge_ids.push_back(e); return i; };
+	for (size_t e : opt_edges) edge_index(e);
+	for (const auto& ref : obs_refs) {
+		const TKeyFrameID kf = ref.first;
+		const kf_observation_t& o = m_state.kf_observations[kf][ref.second];
+		const auto lit = m_state.unknown_lms.find(o.feat_id);
+		if (lit == m_state.unknown_lms.end()) continue;
+		if (!trees.count(kf)) bfs(kf, parameters.max_tree_depth, trees[kf]);
+		const auto& tree = trees[kf];
+		const TKeyFrameID base = lit->second.base_kf;
+		if (!tree.count(base)) continue;                    // farther than max_tree_depth: not in the spanning tree
+		std::vector<int32_t> steps;                          // from the base back to the observer
+		for (TKeyFrameID cur = base; cur != kf;) {
+			const step_t& s = tree.at(cur);
+			const k2k_edge_t& e = m_state.k2k_edges[s.edge];
+			// step observer-side keyframe s.prev <- cur: inv_pose applies when cur == from and prev == to
+			steps.push_back(edge_index(s.edge) * 2 + ((e.from == cur && e.to == s.prev) ? 0 : 1));
+			cur = s.prev;
+		}
+		if (steps.size() > 8) continue;
+		path_edge.insert(path_edge.end(), steps.rbegin(), steps.rend());
+		obs_path_off.push_back((int32_t)path_edge.size());
+		if (!lm_idx.count(o.feat_id)) { lm_idx[o.feat_id] = (int)lm_ids.size(); lm_ids.push_back(o.feat_id); }
+		obs_lm.push_back(lm_idx[o.feat_id]);
+		obs_px.insert(obs_px.end(), o.px, o.px + 4);
+	}
+	std::vector<int32_t> edge_slot(edge_ids.size(), -1), lm_slot(lm_ids.size(), -1);
+	std::vector<double> pose(12 * edge_ids.size()), lmpos(3 * lm_ids.size());
+	int s = 0;
+	for (size_t i = 0; i < edge_ids.size(); ++i) {
+		if (opt_edges.count(edge_ids[i])) edge_slot[i] = s++;
+		std::memcpy(&pose[12 * i], m_state.k2k_edges[edge_ids[i]].inv_pose.m, 12 * sizeof(double));
+	}
+	for (size_t i = 0; i < lm_ids.size(); ++i) {
+		if (optimize_landmarks) lm_slot[i] = (int32_t)i;
+		std::memcpy(&lmpos[3 * i], m_state.unknown_lms[lm_ids[i]].pos, 3 * sizeof(double));
+	}
+	ssk_lm_window w;
+	w.n_edges_total = (int32_t)edge_ids.size(); w.edge_unknown_slot = edge_slot.data(); w.edge_inv_pose = pose.data();
+	w.n_lms_total = (int32_t)lm_ids.size(); w.lm_unknown_slot = lm_slot.data(); w.lm_pos = lmpos.data();
+	w.n_obs = (int32_t)obs_lm.size(); w.obs_lm = obs_lm.data(); w.obs_px = obs_px.data();
+	w.obs_path_off = obs_path_off.data(); w.path_edge = path_edge.data();
+	ssk_lm_batch* b = nullptr;
+	m_ctx.check(ssk_lm_batch_create(m_ctx.get(), &w, 1, 0, &b), "ssk_lm_batch_create");
+	const ssk_lm_params prm = m_opts.lm(robust);
+	ssk_lm_result r;
+	int rc = ssk_lm_batch_run(m_ctx.get(), b, &prm);
+	if (rc == SSK_OK) rc = ssk_lm_batch_results(m_ctx.get(), b, &r);
+	if (rc == SSK_OK) rc = ssk_lm_batch_get_state(m_ctx.get(), b, 0, pose.data(), lmpos.data());
+	ssk_lm_batch_destroy(b);
+	m_ctx.check(rc, "LM solve");
+	for (size_t i = 0; i < edge_ids.size(); ++i)
+		if (edge_slot[i] >= 0) std::memcpy(m_state.k2k_edges[edge_ids[i]].inv_pose.m, &pose[12 * i], 12 * sizeof(double));
+	if (optimize_landmarks)
+		for (size_t i = 0; i < lm_ids.size(); ++i) std::memcpy(m_state.unknown_lms[lm_ids[i]].pos, &lmpos[3 * i], 3 * sizeof(double));
+	res.total_sqr_error_init = r.err_init; res.total_sqr_error_final = r.err_final;
+	res.num_observations = (size_t)r.n_obs; res.num_iters = (size_t)r.iters;
+	res.obs_rmse = r.n_obs ? std::sqrt(r.err_final / r.n_obs) : 0.0;
+}
+
+void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameInfo& out, bool run_local_optimization)
+{
+	const TKeyFrameID new_kf_id = m_state.kf_observations.size();               // alloc_keyframe
+	m_state.kf_observations.push_back(std::vector<kf_observation_t>());
+	if (m_adj.size() <= new_kf_id) m_adj.resize(new_kf_id + 1);
+	out = TNewKeyFrameInfo();
+	out.kf_id = new_kf_id;
+	std::vector<TNewEdgeInfo> new_edges;
+	if (new_kf_id >= 1) edge_creation_policy(new_kf_id, obs, new_edges);        // virtual edge_creation_policy
+	for (const auto& e : new_edges) out.created_edge_ids.push_back(e.id);
+	// add_observation: a feature id seen for the first time becomes a landmark based at this keyframe with the given
+	// relative position (is_unknown_with_init_val, EST.cpp:143-158)
+	for (const auto& o : obs) {
+		if (!m_state.unknown_lms.count(o.obs.feat_id)) {
+			landmark_t lm;
+			lm.base_kf = new_kf_id;
+			lm.pos[0] = o.rel_pos[0]; lm.pos[1] = o.rel_pos[1]; lm.pos[2] = o.rel_pos[2];
+			m_state.unknown_lms[o.obs.feat_id] = lm;
+		}
+		kf_observation_t k;
+		k.feat_id = o.obs.feat_id;
+		k.px[0] = o.obs.obs_data.left_px.x; k.px[1] = o.obs.obs_data.left_px.y;
+		k.px[2] = o.obs.obs_data.right_px.x; k.px[3] = o.obs.obs_data.right_px.y;
+		m_state.kf_observations[new_kf_id].push_back(k);
+	}
+	if (!run_local_optimization || new_edges.empty()) return;
+	// stage 1: optimize_edges on the new edges only, with the new keyframe's observations, landmarks held
+	{
+		std::set<size_t> opt;
+		for (const auto& e : new_edges) opt.insert(e.id);
+		std::vector<std::pair<TKeyFrameID, size_t>> refs;
+		for (size_t i = 0; i < m_state.kf_observations[new_kf_id].size(); ++i) refs.push_back(std::make_pair(new_kf_id, i));
+		run_lm(opt, refs, false, parameters.use_robust_kernel_stage1, out.optimize_results_stg1);
+	}
+	// stage 2: optimize_local_area(root = new KF, depth = max_optimize_depth)
+	{
+		std::map<TKeyFrameID, step_t> area;
+		bfs(new_kf_id, parameters.max_optimize_depth, area);
+		std::set<size_t> opt;
+		for (size_t e = 0; e < m_state.k2k_edges.size(); ++e)
+			if (area.count(m_state.k2k_edges[e].from) && area.count(m_state.k2k_edges[e].to)) opt.insert(e);
+		std::vector<std::pair<TKeyFrameID, size_t>> refs;
+		for (const auto& kv : area)
+			for (size_t i = 0; i < m_state.kf_observations[kv.first].size(); ++i) refs.push_back(std::make_pair(kv.first, i));
+		run_lm(opt, refs, true, parameters.use_robust_kernel, out.optimize_results);
+	}
+}
+
+}  // namespace ssk

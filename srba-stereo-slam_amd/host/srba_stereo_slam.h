@@ -1,0 +1,97 @@
+// srba_stereo_slam.h -- the facade of the reference's RBA engine (src/srba-stereo-slam.h:30-310: mySRBA :
+// RbaEngine<kf2kf_poses::SE3, landmarks::Euclidean3D, observations::StereoCamera, my_srba_options>), keeping
+// the names the estimator uses: define_new_keyframe, setInitialKFPose, TNewKeyFrameInfo, new_kf_observation_t,
+// get_rba_state().k2k_edges / unknown_lms, parameters.*.
+//
+// What is host code here (graph bookkeeping, as in SRBA itself): keyframe / edge / landmark containers, the
+// reference's fixed-size-submap edge_creation_policy (restated literally from SRBA.h:144-308), breadth-first
+// spanning-tree paths limited by max_tree_depth, selection of the optimisation window.
+// What runs on the MI355X: every LM solve (stage 1 "optimize_edges" on the new edges, stage 2
+// "optimize_local_area"), through ssk_lm_batch_* (include/ssk_capi.h).
+#pragma once
+#include <deque>
+#include <map>
+#include <set>
+#include "srba_stereo_slam_options.h"
+
+namespace ssk {
+
+typedef size_t TKeyFrameID;
+typedef uint64_t TLandmarkID;
+
+struct new_kf_observation_t {                  // EST.cpp:137-160,671-699
+	struct { TLandmarkID feat_id; struct { struct { float x, y; } left_px, right_px; } obs_data; } obs;
+	bool is_fixed = false, is_unknown_with_init_val = true;
+	double rel_pos[3] = {0, 0, 0};
+	void setRelPos(const double p[3]) { rel_pos[0] = p[0]; rel_pos[1] = p[1]; rel_pos[2] = p[2]; }
+};
+typedef std::vector<new_kf_observation_t> new_kf_observations_t;
+
+struct TOptimizeResults {
+	double total_sqr_error_init = 0, total_sqr_error_final = 0, obs_rmse = 0;
+	size_t num_observations = 0, num_iters = 0;
+};
+struct TNewKeyFrameInfo {                      // EST.cpp:178-180,790,847-849
+	TKeyFrameID kf_id = 0;
+	std::vector<size_t> created_edge_ids;
+	TOptimizeResults optimize_results, optimize_results_stg1;
+};
+
+struct k2k_edge_t { TKeyFrameID from, to; Pose3D inv_pose; };   // inv_pose: `from` as seen from `to`
+struct landmark_t { TKeyFrameID base_kf; double pos[3]; };
+struct kf_observation_t { TLandmarkID feat_id; float px[4]; };
+
+class mySRBA {
+public:
+	struct TParameters {
+		size_t max_tree_depth = 4, max_optimize_depth = 4, submap_size = 15;       // EST.cpp:1154-1156
+		size_t min_obs_to_loop_closure = 6;                                         // SRBA default (never set by the reference, SRBA.h:166)
+		bool use_robust_kernel = true, use_robust_kernel_stage1 = true;             // EST.cpp:1150-1151
+		double kernel_param = 3.0;                                                  // EST.cpp:1152
+		double std_noise_observations = 0.5;                                        // EST.cpp:1157 (uniform: cancels in the solve)
+		bool literal_first_edge_init = true;                                        // SRBA.h:194 as written (see .cpp)
+	} parameters;
+
+	mySRBA(Context& ctx, const TSRBAStereoSLAMOptions& opts);
+
+	inline void setInitialKFPose(const Pose3D& pose) { m_initial_kf_pose = pose; }  // SRBA.h:95-97
+	inline bool isKFLocalmapCenter(TKeyFrameID id) const { return m_localmap_kf_IDs.count(id) != 0; }        // SRBA.h:100-102
+	inline TKeyFrameID getLocalmapCenterID(TKeyFrameID id) const { return *m_kf_localmap_center_ID.at(id).rbegin(); }   // SRBA.h:105-108
+
+	// EST.cpp:166,782
+	void define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameInfo& out_new_kf_info, bool run_local_optimization);
+
+	// pose of `target` as seen from `root` by composing edges along the breadth-first tree (depth limited):
+	// what create_complete_spanning_tree(root, ...)[target] gives the estimator (EST.cpp:909-915).
+	bool get_kf_relative_pose(TKeyFrameID root, TKeyFrameID target, size_t max_depth, Pose3D& out) const;
+
+	struct rba_state_t {
+		std::deque<k2k_edge_t> k2k_edges;
+		std::map<TLandmarkID, landmark_t> unknown_lms;
+		std::vector<std::vector<kf_observation_t>> kf_observations;                // per keyframe
+	};
+	rba_state_t& get_rba_state() { return m_state; }
+	const rba_state_t& get_rba_state() const { return m_state; }
+	size_t num_keyframes() const { return m_state.kf_observations.size(); }
+
+private:
+	struct TNewEdgeInfo { size_t id; bool has_approx_init_val; };
+	void edge_creation_policy(TKeyFrameID new_kf_id, const new_kf_observations_t& obs, std::vector<TNewEdgeInfo>& new_k2k_edge_ids);   // SRBA.h:144-308
+	size_t create_kf2kf_edge(TKeyFrameID from, TKeyFrameID to);
+	size_t topo_distance(TKeyFrameID a, TKeyFrameID b, size_t max_depth) const;    // SIZE_MAX when farther than max_depth
+	// breadth-first tree from `root`: for every keyframe within max_depth the step towards the root
+	struct step_t { TKeyFrameID prev; size_t edge; size_t dist; };
+	void bfs(TKeyFrameID root, size_t max_depth, std::map<TKeyFrameID, step_t>& out) const;
+	void run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pair<TKeyFrameID, size_t>>& obs_refs,
+	            bool optimize_landmarks, bool robust, TOptimizeResults& res);
+
+	Context& m_ctx;
+	TSRBAStereoSLAMOptions m_opts;
+	rba_state_t m_state;
+	std::vector<std::vector<std::pair<TKeyFrameID, size_t>>> m_adj;                // keyframe -> (neighbour, edge id)
+	Pose3D m_initial_kf_pose;
+	std::deque<std::set<TKeyFrameID>> m_kf_localmap_center_ID;                     // SRBA.h:67
+	std::map<TKeyFrameID, std::set<TKeyFrameID>> m_localmap_kf_IDs;                // SRBA.h:68
+};
+
+}  // namespace ssk

@@ -99,5 +99,32 @@ def synth_stereo_pair(seed, w=W, h=H, noise=2.0):
     return left, right
 
 
+def synth_translation_sequence(seed, n_frames, w=W, h=H, noise=1.0, d_max=40):
+    """n_frames rectified stereo pairs of a scene of fronto-parallel strips seen from a camera that moves one baseline
+    (0.54 m) to the RIGHT per frame: strip r has integer disparity d_r, so frame k sees it shifted by k*d_r pixels.
+    Returns ([(left, right)], strip list [(y0, y1, d_r)])."""
+    rng = np.random.default_rng(0x5EED1000 + seed)
+    wide = synth_texture(rng, w + (n_frames + 1) * d_max + 8, h)
+    strips, y = [], 0
+    while y < h:
+        bh = int(rng.integers(24, 64))
+        z = rng.uniform(KITTI["fx"] * KITTI["baseline"] / d_max, 80)
+        d = max(2, min(int(round(KITTI["fx"] * KITTI["baseline"] / z)), d_max))
+        strips.append((y, min(h, y + bh), d))
+        y += bh
+    frames = []
+    for k in range(n_frames):
+        left = np.empty((h, w), np.uint8)
+        right = np.empty((h, w), np.uint8)
+        for y0, y1, d in strips:
+            left[y0:y1] = wide[y0:y1, k * d:k * d + w]
+            right[y0:y1] = wide[y0:y1, (k + 1) * d:(k + 1) * d + w]
+        if noise > 0:
+            left = np.clip(np.rint(left + rng.normal(0, noise, left.shape)), 0, 255).astype(np.uint8)
+            right = np.clip(np.rint(right + rng.normal(0, noise, right.shape)), 0, 255).astype(np.uint8)
+        frames.append((left, right))
+    return frames, strips
+
+
 KITTI_FRONTEND = dict(n_feats=500, fast_threshold=20, n_levels=1, nms_radius=2, orb_max_distance=60,
-                      max_y_diff=2.0, min_disparity=1.0, max_disparity=float(W), harris_k=0.04)
+                      max_y_diff=2.0, min_disparity=1.0, max_disparity=128.0, harris_k=0.04)   # disparity 128 = 3 m at fx*b = 382

@@ -1,0 +1,75 @@
+"""GPU: the C++ facade (CStereoSLAMKF::create, CSRBAStereoSLAMEstimator, mySRBA) end to end on a synthetic
+KITTI-shaped sequence -- BASELINE.json configs[0] plumbing (demo/config_imgdir_kitti_srba.ini parameters) with the
+numerical work on the MI355X.  Checks the per-keyframe front-end against the oracle, the landmark-ID propagation
+and that the relative BA recovers the known camera motion."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "srba-stereo-slam_amd", "host", "facade_demo")
+
+
+def run_demo(tmp_path, frames, w, h, debug=False):
+    for k, (l, r) in enumerate(frames):
+        l.tofile(os.path.join(tmp_path, "left_%04d.raw" % k))
+        r.tofile(os.path.join(tmp_path, "right_%04d.raw" % k))
+    cmd = [DEMO, str(tmp_path), str(len(frames)), str(w), str(h)] + ([str(tmp_path)] if debug else [])
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    rows = []
+    for line in p.stdout.splitlines():
+        if line.startswith("KF "):
+            t = line.split()
+            d = {"id": t[1], "nl": t[3], "nr": t[5], "matches": t[7], "shared_ids": t[9], "edges": t[11], "stg1_rmse": t[13],
+                 "err": t[15], "err_final": float(t[17]), "obs": t[19], "iters": t[21], "has_pose": int(t[23]),
+                 "pose": [float(x) for x in t[24:27]], "fast_th": t[28]}
+            rows.append(d)
+    return rows, p.stdout
+
+
+def test_facade_sequence(tmp_path, oracle):
+    assert os.path.exists(DEMO), "host facade not built: python __graft_entry__.py build"
+    n = 6
+    frames, strips = synth.synth_translation_sequence(3, n)
+    rows, out = run_demo(tmp_path, frames, synth.W, synth.H, debug=True)
+    assert len(rows) == n
+    prm = ol.FrontendParams(**synth.KITTI_FRONTEND)
+    pat = ol.default_pattern()
+    for k, (l, r) in enumerate(frames):
+        exp = oracle.frontend(l, r, prm, pat)
+        assert int(rows[k]["fast_th"]) == 20                      # >= 120 matches: the adaptive loop stays at detect_fast_th
+        assert (int(rows[k]["nl"]), int(rows[k]["nr"]), int(rows[k]["matches"])) == (len(exp["kp_left"]), len(exp["kp_right"]), len(exp["matches"]))
+        # the reference's debug dump format (KF.cpp:77-91): kf_id match_id xl yl xr yr dist
+        dump = np.loadtxt(os.path.join(tmp_path, "info_kf%04d.txt" % k), comments="%")
+        assert dump.shape == (len(exp["matches"]), 7) and np.all(dump[:, 0] == k)
+        assert np.array_equal(dump[:, 2], exp["kp_left"]["x"][exp["matches"]["queryIdx"]])
+        assert np.array_equal(dump[:, 6], exp["matches"]["distance"])
+    assert int(rows[0]["edges"]) == 0 and float(rows[0]["err_final"]) == 0.0     # first KF: inserted, not optimised (EST.cpp:166-168)
+    for k in range(1, n):
+        assert int(rows[k]["edges"]) == 1 and int(rows[k]["shared_ids"]) >= 60
+        assert rows[k]["err_final"] <= float(rows[k]["err"]) and int(rows[k]["iters"]) >= 1
+        assert rows[k]["has_pose"] == 1
+        # the camera moved k baselines to its right = -y of the robot frame (camera_pose_on_robot, EST.cpp:1105-1112)
+        x, y, z = rows[k]["pose"]
+        assert abs(y - (-0.54 * k)) < 0.05 * k + 0.03 and abs(x) < 0.08 and abs(z) < 0.08, (k, rows[k]["pose"])
+    # da_info_%04d.txt = the SRBA input (EST.cpp:751-763): ids shared with the previous keyframe exist
+    a = np.loadtxt(os.path.join(tmp_path, "da_info_0001.txt"))
+    b = np.loadtxt(os.path.join(tmp_path, "info_kf0000.txt"), comments="%")
+    assert len(set(a[:, 0]) & set(b[:, 1])) >= 60
+
+
+def test_facade_too_few_matches_throws(tmp_path):
+    """EST.cpp:288-295: fewer than 8 stereo matches at the threshold limits -> exception (exit code 1, message)."""
+    flat = np.full((synth.H, synth.W), 100, np.uint8)
+    for k in range(1):
+        flat.tofile(os.path.join(tmp_path, "left_%04d.raw" % k))
+        flat.tofile(os.path.join(tmp_path, "right_%04d.raw" % k))
+    p = subprocess.run([DEMO, str(tmp_path), "1", str(synth.W), str(synth.H)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and "less than the minimum" in p.stderr
