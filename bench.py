@@ -111,16 +111,11 @@ def main():
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
     import __graft_entry__ as ge
     pkg = ge.load_package()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    rank, world = pkg.dist.init_from_env("nccl")       # one process per GPU, RCCL
     from ssk_amd import capi
     import synth_lm as sl
 
@@ -153,7 +148,7 @@ def main():
             # the one exchange step of the path: every submap's shared-landmark blocks to every GPU,
             # fused in rank order (deterministic)
             lm.pack_shared(0, S, shared)
-            dist.all_gather_into_tensor(gathered, shared)
+            pkg.dist.exchange_shared(shared, gathered)
             ctx.stitch_shared(gathered, world, S, fused)
 
     def sync_all():

@@ -5,6 +5,7 @@ host/.  This package only loads the library for tests, bench.py and __graft_entr
 numerical code and no CPU fallback: if the library is missing or no gfx950 device is present, loading
 or Context() raises.
 """
+from . import dist  # noqa: F401
 from .capi import (  # noqa: F401
     KEYPOINT_DTYPE, DMATCH_DTYPE, SskError, Context, lib_path, load_library, declared_symbols,
 )

@@ -1,0 +1,34 @@
+"""Multi-GPU plumbing of the hot path: one process per GPU, torch.distributed ("nccl" = RCCL on ROCm,
+"gloo" in the CPU tests).  Keyframe streams / submaps are partitioned over ranks with no data-path collective
+except ONE all-gather per step of the shared-landmark blocks."""
+import os
+
+
+def init_from_env(backend):
+    """Rendezvous from the torchrun environment (RANK / WORLD_SIZE / MASTER_*); returns (rank, world)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def partition(n_items, rank, world):
+    """Contiguous share [begin, end) of n_items for this rank (weak-scaling benches give every rank its own batch;
+    this is for a fixed global list of submaps)."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def exchange_shared(shared, gathered):
+    """The one exchange step: every rank contributes `shared` ([n_shared*12] f64: position 3, g_f 3, upper H_ff 6 per
+    landmark) and receives all of them rank-major in `gathered` ([world*n_shared*12]).  A single all-gather: the
+    payload is tens of KB, i.e. latency-bound on xGMI, so no ring reduction; the fusion is done locally in rank order
+    (ssk_lm_stitch_shared) and is therefore bit-identical on every rank."""
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(gathered, shared)
+    return gathered
