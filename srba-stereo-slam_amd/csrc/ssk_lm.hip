@@ -28,6 +28,9 @@
 
 namespace {
 
+#ifndef SSK_LM_WAVES
+#define SSK_LM_WAVES 2          // min waves per SIMD the register budget must allow (2 = one 512-thread workgroup per CU)
+#endif
 constexpr int NT = 512;
 constexpr int NW = NT / 64;
 
@@ -251,44 +254,48 @@ __device__ __forceinline__ void wave_sum36(const double (&acc)[36], double* red,
 }
 
 // G (fast path): dense Cholesky (lower, in place) + both triangular solves by ONE wavefront, left-looking:
-// column j of L needs only dot products of already final rows (loads only, no store in the inner loop, so the
-// LDS reads pipeline), then one scaling.  A is n x n in LDS with an odd row pitch np (conflict-free column walk);
-// b is the right-hand side in LDS.  Called by wave 0 only; returns the same flag in every lane.
-__device__ __forceinline__ bool chol_solve_wave(double* A, int np, int n, double* b)
+// column j of L needs only dot products of already final rows (loads only, 4 independent partial sums, so the
+// LDS reads pipeline), then one scaling by the reciprocal pivot (rsqrt: no sqrt + divide chain).  The reciprocal
+// pivots live in their own array, the diagonal of A is never rewritten, which saves a hazard barrier per column
+// and every division in the substitutions.  A is n x n in LDS with an odd row pitch np (conflict-free column
+// walk); b is the right-hand side in LDS.  Called by wave 0 only; returns the same flag in every lane.
+__device__ __forceinline__ bool chol_solve_wave(double* A, int np, int n, double* b, double* inv)
 {
 	const int lane = threadIdx.x & 63;
 	for (int j = 0; j < n; ++j) {
+		const double* rj = A + j * np;
 		for (int i = j + lane; i < n; i += 64) {
 			const double* ri = A + i * np;
-			const double* rj = A + j * np;
-			double s0 = ri[j], s1 = 0.0;
+			double s0 = ri[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
 			int k = 0;
-			for (; k + 1 < j; k += 2) { s0 -= ri[k] * rj[k]; s1 -= ri[k + 1] * rj[k + 1]; }
-			if (k < j) s0 -= ri[k] * rj[k];
-			A[i * np + j] = s0 + s1;                     // unscaled column j (row j itself: the pivot square)
+			for (; k + 3 < j; k += 4) {
+				s0 -= ri[k] * rj[k]; s1 -= ri[k + 1] * rj[k + 1]; s2 -= ri[k + 2] * rj[k + 2]; s3 -= ri[k + 3] * rj[k + 3];
+			}
+			for (; k < j; ++k) s0 -= ri[k] * rj[k];
+			A[i * np + j] = (s0 + s1) + (s2 + s3);      // unscaled column j; entry (j,j) = the pivot square
 		}
 		WAVE_SYNC();
 		const double d = A[j * np + j];
 		if (!(d > 0.0)) return false;                     // uniform: every lane read the same value
-		const double piv = sqrt(d), inv = 1.0 / piv;
-		WAVE_SYNC();
-		for (int i = j + lane; i < n; i += 64) A[i * np + j] = i == j ? piv : A[i * np + j] * inv;
+		const double r = rsqrt(d);                        // 1/L_jj
+		if (lane == 0) inv[j] = r;
+		for (int i = j + 1 + lane; i < n; i += 64) A[i * np + j] *= r;
 		WAVE_SYNC();
 	}
-	for (int i = 0; i < n; ++i) {                         // L y = b
-		const double yi = b[i] / A[i * np + i];
-		WAVE_SYNC();
-		if (lane == 0) b[i] = yi;
+	for (int i = 0; i < n; ++i) {                         // L y = b   (b[i] is final once the updates of step i-1 landed)
+		const double yi = b[i] * inv[i];
 		for (int k = i + 1 + lane; k < n; k += 64) b[k] -= A[k * np + i] * yi;
 		WAVE_SYNC();
+		if (lane == 0) b[i] = yi;                         // nobody reads b[i] again before the back substitution
 	}
-	for (int i = n - 1; i >= 0; --i) {                    // L^T x = y
-		const double xi = b[i] / A[i * np + i];
-		WAVE_SYNC();
-		if (lane == 0) b[i] = xi;
+	WAVE_SYNC();
+	for (int i = n - 1; i >= 0; --i) {                    // L^T x = y   (row i of L: contiguous, conflict-free)
+		const double xi = b[i] * inv[i];
 		for (int k = lane; k < i; k += 64) b[k] -= A[i * np + k] * xi;
 		WAVE_SYNC();
+		if (lane == 0) b[i] = xi;
 	}
+	WAVE_SYNC();
 	return true;
 }
 
@@ -332,13 +339,14 @@ __device__ bool chol_solve_block(double* A, int n, double* b, int* s_flag, doubl
 	return true;
 }
 
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
 void lm_solve_kernel(lm_dev D, lm_cam P, int lds_n6_cap)
 {
 	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // Cholesky matrix n6 x (n6|1) when it fits; before that, per-wave reduction scratch
 	__shared__ double s_pose[SSK_LM_LDS_EDGES * 12];
 	__shared__ double s_pose_new[SSK_LM_LDS_EDGES * 12];
 	__shared__ double s_b[SSK_LM_MAX_N6];
+	__shared__ double s_inv[SSK_LM_MAX_N6];                           // reciprocal Cholesky pivots (wave path)
 	__shared__ double s_part[NW];
 	__shared__ double s_lambda, s_nu, s_err, s_piv;
 	__shared__ int s_flag, s_accept, s_stop, s_iters, s_needlin, s_accepted;
@@ -612,7 +620,7 @@ void lm_solve_kernel(lm_dev D, lm_cam P, int lds_n6_cap)
 		bool ok = true;
 		if (n6 > 0) {
 			if (lds_mat) {
-				if (tid < 64) { const bool r = chol_solve_wave(s_dyn, np, n6, s_b); if (tid == 0) s_flag = r; }
+				if (tid < 64) { const bool r = chol_solve_wave(s_dyn, np, n6, s_b, s_inv); if (tid == 0) s_flag = r; }
 				__syncthreads();
 				ok = s_flag != 0;
 			} else {
