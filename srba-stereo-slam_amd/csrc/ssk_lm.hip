@@ -253,49 +253,60 @@ __device__ __forceinline__ void wave_sum36(const double (&acc)[36], double* red,
 	}
 }
 
-// G (fast path): dense Cholesky (lower, in place) + both triangular solves by ONE wavefront, left-looking:
-// column j of L needs only dot products of already final rows (loads only, 4 independent partial sums, so the
-// LDS reads pipeline), then one scaling by the reciprocal pivot (rsqrt: no sqrt + divide chain).  The reciprocal
-// pivots live in their own array, the diagonal of A is never rewritten, which saves a hazard barrier per column
-// and every division in the substitutions.  A is n x n in LDS with an odd row pitch np (conflict-free column
-// walk); b is the right-hand side in LDS.  Called by wave 0 only; returns the same flag in every lane.
-__device__ __forceinline__ bool chol_solve_wave(double* A, int np, int n, double* b, double* inv)
+// G (fast path): the reduced system solved in LDS as a square-root-free LDL^T of the matrix bordered by the
+// right-hand side (row n = g_red^T), right-looking, by the whole workgroup:
+//   column step j:  A(i,k) -= A(i,j) A(k,j) / d_j   for j < k <= i <= n   (one element per thread and pass, one
+//   barrier per column; column j itself stays unscaled: U_ij = L'_ij d_j), d_j = A(j,j) when its turn comes.
+// The border row comes out as z = L'^-1 b (forward substitution for free), so only L'^T x = D^-1 z is left: one
+// wavefront keeps x in registers (lane k owns x_k, x_{k+64}), broadcasts x_i with v_readlane and prefetches row
+// i-1 of U while it applies row i, so the dependent chain per step is one readlane + one FMA.
+// A is (n+1) x n with an odd row pitch np (column walks are bank-conflict free).  Every thread returns the same flag.
+__device__ __forceinline__ double rcp_f64(double d)
 {
-	const int lane = threadIdx.x & 63;
+	double x = __builtin_amdgcn_rcp(d);
+	x = fma(fma(-d, x, 1.0), x, x);
+	x = fma(fma(-d, x, 1.0), x, x);
+	return x;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+	return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* x_out, double* inv)
+{
+	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
 	for (int j = 0; j < n; ++j) {
-		const double* rj = A + j * np;
-		for (int i = j + lane; i < n; i += 64) {
-			const double* ri = A + i * np;
-			double s0 = ri[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-			int k = 0;
-			for (; k + 3 < j; k += 4) {
-				s0 -= ri[k] * rj[k]; s1 -= ri[k + 1] * rj[k + 1]; s2 -= ri[k + 2] * rj[k + 2]; s3 -= ri[k + 3] * rj[k + 3];
-			}
-			for (; k < j; ++k) s0 -= ri[k] * rj[k];
-			A[i * np + j] = (s0 + s1) + (s2 + s3);      // unscaled column j; entry (j,j) = the pivot square
-		}
-		WAVE_SYNC();
+		__syncthreads();
 		const double d = A[j * np + j];
-		if (!(d > 0.0)) return false;                     // uniform: every lane read the same value
-		const double r = rsqrt(d);                        // 1/L_jj
-		if (lane == 0) inv[j] = r;
-		for (int i = j + 1 + lane; i < n; i += 64) A[i * np + j] *= r;
-		WAVE_SYNC();
+		if (!(d > 0.0)) return false;                     // uniform: every thread reads the same settled value
+		const double dinv = rcp_f64(d);
+		if (tid == 0) inv[j] = dinv;
+		for (int i = j + 1 + ty; i <= n; i += NT / 32) {
+			const double aij = A[i * np + j] * dinv;
+			const int kmax = i < n ? i : n - 1;
+			double* ri = A + i * np;
+			for (int k = j + 1 + tx; k <= kmax; k += 32) ri[k] -= aij * A[k * np + j];
+		}
 	}
-	for (int i = 0; i < n; ++i) {                         // L y = b   (b[i] is final once the updates of step i-1 landed)
-		const double yi = b[i] * inv[i];
-		for (int k = i + 1 + lane; k < n; k += 64) b[k] -= A[k * np + i] * yi;
-		WAVE_SYNC();
-		if (lane == 0) b[i] = yi;                         // nobody reads b[i] again before the back substitution
+	__syncthreads();
+	if (tid < 64) {
+		const int k0 = tid, k1 = tid + 64;
+		const double i0 = k0 < n ? inv[k0] : 0.0, i1 = k1 < n ? inv[k1] : 0.0;
+		double y0 = k0 < n ? A[n * np + k0] * i0 : 0.0, y1 = k1 < n ? A[n * np + k1] * i1 : 0.0;
+		double c0 = k0 < n - 1 ? A[(n - 1) * np + k0] * i0 : 0.0, c1 = k1 < n - 1 ? A[(n - 1) * np + k1] * i1 : 0.0;
+		for (int i = n - 1; i > 0; --i) {
+			const double n0 = k0 < i - 1 ? A[(i - 1) * np + k0] * i0 : 0.0, n1 = k1 < i - 1 ? A[(i - 1) * np + k1] * i1 : 0.0;
+			const double xi = i < 64 ? readlane_f64(y0, i) : readlane_f64(y1, i - 64);
+			y0 -= c0 * xi; y1 -= c1 * xi;                 // c = 0 for k >= i: x_k (k >= i) is already final
+			c0 = n0; c1 = n1;
+		}
+		if (k0 < n) x_out[k0] = y0;
+		if (k1 < n) x_out[k1] = y1;
 	}
-	WAVE_SYNC();
-	for (int i = n - 1; i >= 0; --i) {                    // L^T x = y   (row i of L: contiguous, conflict-free)
-		const double xi = b[i] * inv[i];
-		for (int k = lane; k < i; k += 64) b[k] -= A[i * np + k] * xi;
-		WAVE_SYNC();
-		if (lane == 0) b[i] = xi;
-	}
-	WAVE_SYNC();
+	__syncthreads();
 	return true;
 }
 
@@ -346,7 +357,7 @@ void lm_solve_kernel(lm_dev D, lm_cam P, int lds_n6_cap)
 	__shared__ double s_pose[SSK_LM_LDS_EDGES * 12];
 	__shared__ double s_pose_new[SSK_LM_LDS_EDGES * 12];
 	__shared__ double s_b[SSK_LM_MAX_N6];
-	__shared__ double s_inv[SSK_LM_MAX_N6];                           // reciprocal Cholesky pivots (wave path)
+	__shared__ double s_inv[128];                                     // reciprocal pivots of the LDS solve (n6 <= 127)
 	__shared__ double s_part[NW];
 	__shared__ double s_lambda, s_nu, s_err, s_piv;
 	__shared__ int s_flag, s_accept, s_stop, s_iters, s_needlin, s_accepted;
@@ -612,7 +623,7 @@ void lm_solve_kernel(lm_dev D, lm_cam P, int lds_n6_cap)
 			if (k < k1) s0 += src[6 * (size_t)k];
 			double v = s0 + s1;
 			v += __shfl_down(v, 4, 8); v += __shfl_down(v, 2, 8); v += __shfl_down(v, 1, 8);
-			if (j == 0) s_b[comp] = v;
+			if (j == 0) { if (lds_mat) A[n6 * np + comp] = v; else s_b[comp] = v; }
 		}
 		__syncthreads();
 		STAMP(8);
@@ -620,9 +631,7 @@ void lm_solve_kernel(lm_dev D, lm_cam P, int lds_n6_cap)
 		bool ok = true;
 		if (n6 > 0) {
 			if (lds_mat) {
-				if (tid < 64) { const bool r = chol_solve_wave(s_dyn, np, n6, s_b, s_inv); if (tid == 0) s_flag = r; }
-				__syncthreads();
-				ok = s_flag != 0;
+				ok = ldl_solve_lds(s_dyn, np, n6, s_b, s_inv);
 			} else {
 				ok = chol_solve_block(A, n6, s_b, &s_flag, &s_piv);
 			}
@@ -753,10 +762,10 @@ int ssk_lm_launch(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows,
 	int cap = 0;
 	size_t dyn = 0;
 	const size_t LDS_BUDGET = 120 * 1024;
-	const size_t need = (size_t)max_n6 * (size_t)(max_n6 | 1) * sizeof(double);
+	const size_t need = ((size_t)max_n6 + 1) * (size_t)(max_n6 | 1) * sizeof(double);   // + the right-hand-side border row
 	const size_t red_bytes = (size_t)NW * RED_WAVE * sizeof(double);      // wave_sum36 scratch, aliased with the matrix
 	dyn = red_bytes;
-	if (need <= LDS_BUDGET) { cap = max_n6; dyn = need > red_bytes ? need : red_bytes; }
+	if (need <= LDS_BUDGET && max_n6 <= 127) { cap = max_n6; dyn = need > red_bytes ? need : red_bytes; }
 	static bool attr_set = false;
 	if (!attr_set) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
