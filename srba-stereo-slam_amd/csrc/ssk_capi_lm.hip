@@ -4,6 +4,8 @@
 #include "ssk_lm.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 struct ssk_lm_batch {
 	ssk_ctx* ctx = nullptr;
@@ -12,6 +14,8 @@ struct ssk_lm_batch {
 	std::vector<void*> allocs;
 	lm_dev D{};
 	size_t n_pose = 0, n_lm = 0;      // doubles in pose / lm families
+	bool tiled_ok = false;            // every window fits the LDS-tiled kernel
+	size_t tiled_dyn_bytes = 0;       // its dynamic LDS size
 };
 
 namespace {
@@ -194,6 +198,11 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	std::vector<double> pose, lm;
 	std::vector<float> obs_px;
 	std::vector<lm_win> hdr((size_t)n_windows);
+	std::vector<lm_tile> tiles;
+	std::vector<int> tl_slot, tl_obs_off, tobs_o, tobs_info, inc_lml, lmep_loc, pit, pslot0, pcl_off, pcl_idx, qit, sslot0, scl_off, scl_idx;
+	std::vector<int2> pgrp, sgrp;
+	size_t n_pslots_total = 0, n_sslots_total = 0, tiled_dyn = 0;
+	bool tiled_all = true;
 	long long h_total = 0, dpt = 0, dft = 0;
 	int max_n6 = 0;
 	for (int w = 0; w < n_windows; ++w) {
@@ -318,6 +327,154 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		w_pc_off[n_pairs] = (int)w_pchunk.size();
 		w_sc_off[n_pairs] = (int)w_schunk.size();
 
+
+		// ---- tiles of the LDS-tiled kernel (ssk_lm_tiled.hip, data model in ssk_lm.h) ----
+		std::vector<lm_tile> w_tiles;
+		std::vector<int> w_tl_slot, w_tl_obs_off, w_tobs_o, w_tobs_info, w_inc_lml((size_t)n_lme, 0), w_lmep_loc(w_lmep_idx.size(), 0);
+		std::vector<int> w_pit, w_pslot0, w_qit, w_sslot0, w_pcl_off((size_t)n_pairs + 1, 0), w_pcl_idx, w_scl_off((size_t)n_pairs + 1, 0), w_scl_idx;
+		std::vector<int2> w_pgrp, w_sgrp;
+		int n_pslots = 0, n_sslots = 0;
+		const long long region_bytes = (long long)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC - 2LL * 12 * 8 * Wn.n_edges_total;
+		bool tiled = 6 * E <= SSK_LMT_MAX_N6 && (long long)(6 * E + 1) * ((6 * E) | 1) * 8 <= region_bytes;
+		if (tiled) {
+			auto tile_bytes = [](long long nP, long long nO, long long nM, long long nL) {
+				return 8 * (SSK_LMT_ENT * nP + std::max<long long>(SSK_LMT_OBS * nO, SSK_LMT_RED) + SSK_LMT_Y * nM + SSK_LMT_LMR * nL);
+			};
+			std::vector<std::vector<int>> obs_of((size_t)Wn.n_lms_total);
+			for (int o = 0; o < Wn.n_obs; ++o) obs_of[Wn.obs_lm[o]].push_back(o);
+			auto opt_mask = [&](int o) {
+				int om = 0;
+				for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p)
+					if (Wn.edge_unknown_slot[Wn.path_edge[p] >> 1] >= 0) om |= 1 << (p - Wn.obs_path_off[o]);
+				return om;
+			};
+			// balanced cut: the variable footprint of the window spread evenly over the fewest tiles that fit
+			std::vector<long long> fp_P(order.size()), fp_O(order.size()), fp_M(order.size());
+			long long tot = 0;
+			for (size_t oi = 0; oi < order.size(); ++oi) {
+				long long nP = 0;
+				for (int o : obs_of[order[oi]]) nP += __builtin_popcount(opt_mask(o));
+				fp_P[oi] = nP; fp_O[oi] = (long long)obs_of[order[oi]].size(); fp_M[oi] = (long long)lm_lmes[oi].size();
+				tot += 8 * (SSK_LMT_ENT * fp_P[oi] + SSK_LMT_OBS * fp_O[oi] + SSK_LMT_Y * fp_M[oi] + SSK_LMT_LMR);
+			}
+			const long long est_tiles = std::max<long long>(1, (tot + region_bytes * 9 / 10 - 1) / (region_bytes * 9 / 10));
+			const long long target = (tot + est_tiles - 1) / est_tiles;
+			std::vector<int> path_loc((size_t)n_path, -1);
+			std::vector<std::vector<int>> pslots_of((size_t)n_pairs), sslots_of((size_t)n_pairs);
+			struct item { int pid, packed; };
+			auto make_groups = [&](std::vector<item>& items, std::vector<int>& it_out, std::vector<int2>& grp_out, std::vector<int>& slot0_out,
+			                       std::vector<std::vector<int>>& slots_of, int& slot_counter, int& n_grp, int& n_chunk) {
+				std::stable_sort(items.begin(), items.end(), [](const item& a, const item& b) { return a.pid < b.pid; });
+				const int n = (int)items.size(), base = (int)it_out.size();
+				const int R = std::min(255, std::max(1, (n + SSK_LMT_NT - 1) / SSK_LMT_NT));
+				std::vector<int> gkeys;
+				for (int i = 0; i < n;) {
+					int j = i;
+					while (j < n && items[j].pid == items[i].pid) ++j;
+					for (int k = i; k < j; k += R) { grp_out.push_back(make_int2(base + k, std::min(R, j - k) | (items[i].pid << 8))); gkeys.push_back(items[i].pid); }
+					i = j;
+				}
+				for (const item& x : items) it_out.push_back(x.packed);
+				n_grp = (int)gkeys.size(); n_chunk = (n_grp + 63) / 64;
+				for (int c = 0; c < n_chunk; ++c) {
+					slot0_out.push_back(slot_counter);
+					int prev = -1;
+					for (int lane = 0; lane < 64; ++lane) {
+						const int key = gkeys[std::min(64 * c + lane, n_grp - 1)];
+						if ((lane & 15) == 0 || key != prev) slots_of[key].push_back(slot_counter++);
+						prev = key;
+					}
+				}
+			};
+			size_t oi = 0;
+			int lme_cursor = 0;
+			while (oi < order.size() && tiled) {
+				lm_tile T{};
+				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_o.size(); T.inc0 = lme_cursor;
+				long long nP = 0, nO = 0, nM = 0, nL = 0, var = 0;
+				size_t oj = oi;
+				for (; oj < order.size(); ++oj) {
+					const long long aP = nP + fp_P[oj], aO = nO + fp_O[oj], aM = nM + fp_M[oj], aL = nL + 1;
+					if (tile_bytes(aP, aO, aM, aL) > region_bytes || aM + aL > SSK_LMT_NT || aP > 65535 || aO > 65535) break;
+					nP = aP; nO = aO; nM = aM; nL = aL;
+					var += 8 * (SSK_LMT_ENT * fp_P[oj] + SSK_LMT_OBS * fp_O[oj] + SSK_LMT_Y * fp_M[oj] + SSK_LMT_LMR);
+					if (var >= target) { ++oj; break; }
+				}
+				if (oj == oi) { tiled = false; break; }          // one landmark alone does not fit
+				std::vector<item> pitems, qitems;
+				int n_ent = 0;
+				for (size_t ok = oi; ok < oj; ++ok) {
+					const int l = order[ok], j = (int)(ok - oi);
+					w_tl_slot.push_back(Wn.lm_unknown_slot[l]);
+					w_tl_obs_off.push_back((int)w_tobs_o.size());
+					for (int o : obs_of[l]) {
+						const int kl = (int)w_tobs_o.size() - T.obs0, pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
+						w_tobs_o.push_back(o);
+						w_tobs_info.push_back(n_ent | (om << 16) | (len << 24));
+						std::vector<std::pair<int, int>> steps;      // (edge slot, local entry)
+						for (int i = 0; i < len; ++i)
+							if ((om >> i) & 1) {
+								const int le = n_ent + __builtin_popcount(om & ((1 << i) - 1));
+								path_loc[pb + i] = le | (kl << 16);
+								steps.push_back(std::make_pair(Wn.edge_unknown_slot[Wn.path_edge[pb + i] >> 1], le));
+							}
+						n_ent += __builtin_popcount(om);
+						for (size_t a = 0; a < steps.size(); ++a)
+							for (size_t b2 = a; b2 < steps.size(); ++b2) {
+								const bool sw = steps[a].first > steps[b2].first;
+								const auto& lo = sw ? steps[b2] : steps[a];
+								const auto& hi = sw ? steps[a] : steps[b2];
+								pitems.push_back({pid_of(lo.first, hi.first), lo.second | (hi.second << 16)});
+							}
+					}
+					for (int m : lm_lmes[ok]) {
+						w_inc_lml[m] = j;
+						for (int k = w_lmep_off[m]; k < w_lmep_off[m + 1]; ++k) w_lmep_loc[k] = path_loc[w_lmep_idx[k]];
+					}
+					if (Wn.lm_unknown_slot[l] >= 0)
+						for (size_t a = 0; a < lm_lmes[ok].size(); ++a)
+							for (size_t b2 = a; b2 < lm_lmes[ok].size(); ++b2)
+								qitems.push_back({pid_of(w_lme_edge[lm_lmes[ok][a]], w_lme_edge[lm_lmes[ok][b2]]),
+								                  (lm_lmes[ok][a] - T.inc0) | ((lm_lmes[ok][b2] - T.inc0) << 16)});
+					lme_cursor += (int)lm_lmes[ok].size();
+				}
+				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_o.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0;
+				T.pg0 = (int)w_pgrp.size(); T.pc0 = (int)w_pslot0.size();
+				make_groups(pitems, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
+				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size();
+				make_groups(qitems, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
+				w_tiles.push_back(T);
+				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)tile_bytes(T.n_ent, T.n_obs, T.n_inc, T.n_lm));
+				oi = oj;
+			}
+			w_tl_obs_off.push_back((int)w_tobs_o.size());
+			for (int p2 = 0; p2 < n_pairs; ++p2) {
+				w_pcl_off[p2] = (int)w_pcl_idx.size(); w_pcl_idx.insert(w_pcl_idx.end(), pslots_of[p2].begin(), pslots_of[p2].end());
+				w_scl_off[p2] = (int)w_scl_idx.size(); w_scl_idx.insert(w_scl_idx.end(), sslots_of[p2].begin(), sslots_of[p2].end());
+			}
+			w_pcl_off[n_pairs] = (int)w_pcl_idx.size(); w_scl_off[n_pairs] = (int)w_scl_idx.size();
+			tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(6 * E + 1) * ((6 * E) | 1) * 8);
+		}
+		if (!tiled) tiled_all = false;
+		H.n_tiles = tiled ? (int)w_tiles.size() : -1;
+		H.tile0 = (int)tiles.size(); H.tl0 = (int)tl_slot.size(); H.tlo0 = (int)tl_obs_off.size(); H.tobs0 = (int)tobs_o.size();
+		H.pit0 = (int)pit.size(); H.pg0 = (int)pgrp.size(); H.pcx0 = (int)pslot0.size(); H.ps0 = (int)n_pslots_total; H.pcl0 = (int)pcl_idx.size();
+		H.qit0 = (int)qit.size(); H.sg0 = (int)sgrp.size(); H.scx0 = (int)sslot0.size(); H.ss0 = (int)n_sslots_total; H.scl0 = (int)scl_idx.size();
+		n_pslots_total += (size_t)n_pslots; n_sslots_total += (size_t)n_sslots;
+		tiles.insert(tiles.end(), w_tiles.begin(), w_tiles.end());
+		tl_slot.insert(tl_slot.end(), w_tl_slot.begin(), w_tl_slot.end());
+		tl_obs_off.insert(tl_obs_off.end(), w_tl_obs_off.begin(), w_tl_obs_off.end());
+		tobs_o.insert(tobs_o.end(), w_tobs_o.begin(), w_tobs_o.end());
+		tobs_info.insert(tobs_info.end(), w_tobs_info.begin(), w_tobs_info.end());
+		inc_lml.insert(inc_lml.end(), w_inc_lml.begin(), w_inc_lml.end());
+		lmep_loc.insert(lmep_loc.end(), w_lmep_loc.begin(), w_lmep_loc.end());
+		pit.insert(pit.end(), w_pit.begin(), w_pit.end()); pgrp.insert(pgrp.end(), w_pgrp.begin(), w_pgrp.end());
+		pslot0.insert(pslot0.end(), w_pslot0.begin(), w_pslot0.end());
+		pcl_off.insert(pcl_off.end(), w_pcl_off.begin(), w_pcl_off.end()); pcl_idx.insert(pcl_idx.end(), w_pcl_idx.begin(), w_pcl_idx.end());
+		qit.insert(qit.end(), w_qit.begin(), w_qit.end()); sgrp.insert(sgrp.end(), w_sgrp.begin(), w_sgrp.end());
+		sslot0.insert(sslot0.end(), w_sslot0.begin(), w_sslot0.end());
+		scl_off.insert(scl_off.end(), w_scl_off.begin(), w_scl_off.end()); scl_idx.insert(scl_idx.end(), w_scl_idx.begin(), w_scl_idx.end());
+
 		H.n_edges = Wn.n_edges_total; H.E = E; H.n_lms = Wn.n_lms_total; H.L = L; H.n_obs = Wn.n_obs; H.n_path = n_path;
 		H.n_pairs = n_pairs; H.n_lme = n_lme; H.n_lme_unknown = n_lme_unknown; H.n_q = n_q;
 		H.edge0 = (int)edge_slot.size(); H.lm0 = (int)lm_slot.size(); H.obs0 = (int)obs_lm.size();
@@ -391,7 +548,12 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	UP(el_off, el_off); UP(el_idx, el_idx);
 	UP(qp_q, qp_q); UP(pchunk, pchunk); UP(pc_off, pc_off); UP(schunk, schunk); UP(sc_off, sc_off);
 	UP(pose, pose0); UP(lm, lm0);
+	UP(tiles, tile); UP(tl_slot, tl_slot); UP(tl_obs_off, tl_obs_off); UP(tobs_o, tobs_o); UP(tobs_info, tobs_info);
+	UP(inc_lml, inc_lml); UP(lmep_loc, lmep_loc);
+	UP(pit, pit); UP(pgrp, pgrp); UP(pslot0, pslot0); UP(pcl_off, pcl_off); UP(pcl_idx, pcl_idx);
+	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
 #undef UP
+	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
 	const double *c_pose = nullptr, *c_lm = nullptr;
 	if (!rc) rc = upload(b, pose, &c_pose);
 	if (!rc) rc = upload(b, lm, &c_lm);
@@ -414,6 +576,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	if (!rc) rc = scratch(b, 6 * n_lme, &D.gre);
 	if (!rc) rc = scratch(b, 36 * pchunk.size(), &D.Ppart);
 	if (!rc) rc = scratch(b, 36 * schunk.size(), &D.Spart);
+	if (!rc) rc = scratch(b, 36 * n_pslots_total, &D.Ppart2);
+	if (!rc) rc = scratch(b, 36 * n_sslots_total, &D.Spart2);
 	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hpair);
 	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hred);
 	if (!rc) rc = scratch(b, 6 * n_us, &D.dp);
@@ -449,6 +613,10 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	for (int i = 0; i < 12; ++i) P.S[i] = p->sensor_pose[i];
 	P.max_iters = p->max_iters; P.robust = p->use_robust_kernel; P.kernel = p->kernel_param; P.tau = p->tau;
 	P.max_lambda = p->max_lambda; P.stop_rmse = p->max_error_per_obs_to_stop; P.conv_rel = p->converged_rel_decrease;
+	// two kernels, one contract: the LDS-tiled kernel when every window of the batch fits it (SSK_LM_KERNEL=l2 forces
+	// the general scratch-in-L2 kernel, which takes windows of any size)
+	const char* force = std::getenv("SSK_LM_KERNEL");
+	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes);
 	return ssk_lm_launch(ctx, b->D, P, b->n_windows, b->max_n6);
 }
 

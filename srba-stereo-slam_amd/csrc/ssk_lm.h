@@ -42,12 +42,40 @@ struct lm_win {
 	int pc0;       // H_pp chunks: pchunk[] (block, first qp item, count <= 64), Ppart x36; pc_off[] lives at pairo0
 	int sc0;       // Schur chunks: schunk[] (block, first q, count <= 64), Spart x36; sc_off[] lives at pairo0
 	int trace0;    // trace entries (window * max_iters)
+	// ---- LDS-tiled kernel (ssk_lm_tiled.hip); n_tiles < 0: the window does not fit that kernel ----
+	int n_tiles, tile0;   // tile[]
+	int tl0, tlo0;        // tile landmarks (tile order): tl_slot[]; tl_obs_off[] (n_tl + 1 per window, indices into tobs)
+	int tobs0;            // tile-ordered observations: tobs_o[], tobs_info[]
+	int pit0, pg0, pcx0, ps0, pcl0;   // H_pp items pit[], lane groups pgrp[], chunk slot bases pslot0[], partial slots Ppart2 x36, pcl_idx[]
+	int qit0, sg0, scx0, ss0, scl0;   // Schur items qit[], lane groups sgrp[], sslot0[], Spart2 x36, scl_idx[]
 	long long h0;  // Hred (6E)^2 doubles (only used when the matrix does not fit LDS); Hpair 36 x n_pairs
 	long long dp_trace0, df_trace0;
 };
 
+// One tile = a run of the window's landmarks (tile order: optimised landmarks in slot order, then the fixed ones that
+// touch an optimised edge) whose linearisation fits LDS: 15 doubles per optimised path entry (A = w M R 4x3, point q),
+// 17 per observation (Jf 4x3, w r), 19 per (landmark, edge) incidence (Y = W L^-T 6x3), 9 per landmark (L^-1, c).
+// Reductions over the items of a tile: every lane owns a GROUP of <= R consecutive items of ONE block (items are
+// sorted by block pair id), 64 groups form a chunk (one wave pass), a chunk's segments (runs of equal block id,
+// also cut every 16 lanes) are summed in lane order into consecutive 36-double partial slots starting at
+// pslot0[chunk]; pcl lists the slots of a block in ascending order for the final sum.
+struct lm_tile {
+	int lml0, n_lm;       // tile landmarks tl_*[W.tl0 + lml0 ..)
+	int obs0, n_obs;      // tile observations tobs_*[W.tobs0 + obs0 ..)
+	int n_ent;            // optimised path entries of those observations (local index = first entry of the obs + rank)
+	int inc0, n_inc;      // incidences = lme entries W.lme0 + inc0 ..   (n_inc + n_lm <= workgroup size)
+	int pg0, n_pg, pc0, n_pc;   // H_pp lane groups pgrp[W.pg0 + pg0 ..), chunks pslot0[W.pcx0 + pc0 ..)
+	int sg0, n_sg, sc0, n_sc;   // Schur lane groups / chunks
+	int pad;
+};
+
 struct lm_dev {
 	const lm_win* win;
+	const lm_tile* tile; const int* tl_slot; const int* tl_obs_off; const int* tobs_o; const int* tobs_info;
+	const int* inc_lml; const int* lmep_loc;
+	const int* pit; const int2* pgrp; const int* pslot0; const int* pcl_off; const int* pcl_idx;
+	const int* qit; const int2* sgrp; const int* sslot0; const int* scl_off; const int* scl_idx;
+	double* Ppart2; double* Spart2;
 	const int* edge_slot; double* pose; const double* pose0; double* pose_new;
 	const int* lm_slot; double* lm; const double* lm0; double* lm_new;
 	const int* obs_lm; const float* obs_px; const int* obs_path_off;
@@ -73,4 +101,13 @@ struct lm_cam {
 };
 
 int ssk_lm_launch(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int max_n6);
+
+// LDS-tiled kernel: layout constants shared by the host tiler (ssk_capi_lm.hip) and the kernel
+constexpr int SSK_LMT_NT = 512;                    // workgroup size
+constexpr int SSK_LMT_ENT = 15, SSK_LMT_OBS = 17, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;   // record pitches (doubles, odd: conflict-free)
+constexpr int SSK_LMT_RED = (SSK_LMT_NT / 64) * 64 * 9;   // doubles of reduction scratch (aliases the observation records)
+constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024;      // gfx950: LDS per CU = per workgroup limit
+constexpr int SSK_LMT_STATIC = 4096;               // reserve for the kernel's static LDS
+constexpr int SSK_LMT_MAX_N6 = 126;
+int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes);
 int ssk_lm_launch_reset(ssk_ctx* ctx, double* pose, const double* pose0, size_t n_pose, double* lm, const double* lm0, size_t n_lm);

@@ -1,0 +1,170 @@
+// ssk_lm_device.h -- device helpers shared by the two LM kernels (ssk_lm.hip: scratch-in-L2 kernel for windows of
+// any size; ssk_lm_tiled.hip: LDS-tiled kernel).  Include inside the translation unit's anonymous namespace.
+#pragma once
+
+#ifndef SSK_LM_WAVES
+#define SSK_LM_WAVES 2          // min waves per SIMD the register budget must allow (2 = one 512-thread workgroup per CU)
+#endif
+constexpr int NT = 512;
+constexpr int NW = NT / 64;
+
+#define WAVE_SYNC()                                                \
+	do {                                                           \
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+		__builtin_amdgcn_wave_barrier();                           \
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+	} while (0)
+
+__device__ __forceinline__ void se3_apply(const double* T, const double* p, double* q)
+{
+#pragma unroll
+	for (int i = 0; i < 3; ++i) q[i] = T[4 * i] * p[0] + T[4 * i + 1] * p[1] + T[4 * i + 2] * p[2] + T[4 * i + 3];
+}
+__device__ __forceinline__ void se3_apply_inv(const double* T, const double* p, double* q)
+{
+	const double d0 = p[0] - T[3], d1 = p[1] - T[7], d2 = p[2] - T[11];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) q[i] = T[i] * d0 + T[4 + i] * d1 + T[8 + i] * d2;
+}
+__device__ __forceinline__ double huber_rho(double s2, double k) { return 2.0 * k * k * (sqrt(1.0 + s2 / (k * k)) - 1.0); }
+
+__device__ __forceinline__ void project(const lm_cam& P, const double* pc, double* h)
+{
+	const double iz = 1.0 / pc[2];
+	h[0] = P.cx_l + P.fx_l * pc[0] * iz;
+	h[1] = P.cy_l + P.fy_l * pc[1] * iz;
+	h[2] = P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz;
+	h[3] = P.cy_r + P.fy_r * pc[1] * iz;
+}
+
+// robustified squared error of observation o; `pose` is window relative (LDS cache or global), lm batch wide
+__device__ double obs_error(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const double* __restrict__ lm, int o)
+{
+	double q[3], t[3];
+	const double* f = lm + 3 * (size_t)(W.lm0 + D.obs_lm[W.obs0 + o]);
+	q[0] = f[0]; q[1] = f[1]; q[2] = f[2];
+	const int pb = D.obs_path_off[W.opo0 + o], pe = D.obs_path_off[W.opo0 + o + 1];
+	for (int i = pe - 1; i >= pb; --i) {
+		const int c = D.path_edge[W.path0 + i];
+		const double* T = pose + 12 * (c >> 1);
+		if ((c & 1) == 0) se3_apply(T, q, t); else se3_apply_inv(T, q, t);
+		q[0] = t[0]; q[1] = t[1]; q[2] = t[2];
+	}
+	double pc[3], h[4];
+	se3_apply_inv(P.S, q, pc);
+	project(P, pc, h);
+	const float* z = D.obs_px + 4 * (size_t)(W.obs0 + o);
+	double s2 = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { const double r = (double)z[k] - h[k]; s2 += r * r; }
+	return P.robust ? huber_rho(s2, P.kernel) : s2;
+}
+
+// deterministic workgroup reductions: fixed shuffle tree inside a wave, then the NW partials in wave order
+__device__ double block_sum(double v, double* s_part)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+	__syncthreads();
+	double r = 0;
+#pragma unroll
+	for (int w = 0; w < NW; ++w) r += s_part[w];
+	return r;
+}
+__device__ double block_max(double v, double* s_part)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+	__syncthreads();
+	double r = s_part[0];
+#pragma unroll
+	for (int w = 1; w < NW; ++w) r = fmax(r, s_part[w]);
+	return r;
+}
+
+__device__ double total_error(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const double* lm, double* s_part)
+{
+	double e = 0;
+	for (int o = threadIdx.x; o < W.n_obs; o += NT) e += obs_error(D, W, P, pose, lm, o);
+	return block_sum(e, s_part);
+}
+
+__device__ void so3_exp(const double* w, double* R)
+{
+	const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+	const double th = sqrt(th2);
+	double a, b;
+	if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; }
+	else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+	const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+	double K2[9];
+#pragma unroll
+	for (int i = 0; i < 3; ++i)
+#pragma unroll
+		for (int j = 0; j < 3; ++j) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+#pragma unroll
+	for (int i = 0; i < 9; ++i) R[i] = a * K[i] + b * K2[i];
+	R[0] += 1; R[4] += 1; R[8] += 1;
+}
+
+// G (fast path): the reduced system solved in LDS as a square-root-free LDL^T of the matrix bordered by the
+// right-hand side (row n = g_red^T), right-looking, by the whole workgroup:
+//   column step j:  A(i,k) -= A(i,j) A(k,j) / d_j   for j < k <= i <= n   (one element per thread and pass, one
+//   barrier per column; column j itself stays unscaled: U_ij = L'_ij d_j), d_j = A(j,j) when its turn comes.
+// The border row comes out as z = L'^-1 b (forward substitution for free), so only L'^T x = D^-1 z is left: one
+// wavefront keeps x in registers (lane k owns x_k, x_{k+64}), broadcasts x_i with v_readlane and prefetches row
+// i-1 of U while it applies row i, so the dependent chain per step is one readlane + one FMA.
+// A is (n+1) x n with an odd row pitch np (column walks are bank-conflict free).  Every thread returns the same flag.
+__device__ __forceinline__ double rcp_f64(double d)
+{
+	double x = __builtin_amdgcn_rcp(d);
+	x = fma(fma(-d, x, 1.0), x, x);
+	x = fma(fma(-d, x, 1.0), x, x);
+	return x;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+	return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* x_out, double* inv)
+{
+	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+	for (int j = 0; j < n; ++j) {
+		__syncthreads();
+		const double d = A[j * np + j];
+		if (!(d > 0.0)) return false;                     // uniform: every thread reads the same settled value
+		const double dinv = rcp_f64(d);
+		if (tid == 0) inv[j] = dinv;
+		for (int i = j + 1 + ty; i <= n; i += NT / 32) {
+			const double aij = A[i * np + j] * dinv;
+			const int kmax = i < n ? i : n - 1;
+			double* ri = A + i * np;
+			for (int k = j + 1 + tx; k <= kmax; k += 32) ri[k] -= aij * A[k * np + j];
+		}
+	}
+	__syncthreads();
+	if (tid < 64) {
+		const int k0 = tid, k1 = tid + 64;
+		const double i0 = k0 < n ? inv[k0] : 0.0, i1 = k1 < n ? inv[k1] : 0.0;
+		double y0 = k0 < n ? A[n * np + k0] * i0 : 0.0, y1 = k1 < n ? A[n * np + k1] * i1 : 0.0;
+		double c0 = k0 < n - 1 ? A[(n - 1) * np + k0] * i0 : 0.0, c1 = k1 < n - 1 ? A[(n - 1) * np + k1] * i1 : 0.0;
+		for (int i = n - 1; i > 0; --i) {
+			const double n0 = k0 < i - 1 ? A[(i - 1) * np + k0] * i0 : 0.0, n1 = k1 < i - 1 ? A[(i - 1) * np + k1] * i1 : 0.0;
+			const double xi = i < 64 ? readlane_f64(y0, i) : readlane_f64(y1, i - 64);
+			y0 -= c0 * xi; y1 -= c1 * xi;                 // c = 0 for k >= i: x_k (k >= i) is already final
+			c0 = n0; c1 = n1;
+		}
+		if (k0 < n) x_out[k0] = y0;
+		if (k1 < n) x_out[k1] = y1;
+	}
+	__syncthreads();
+	return true;
+}
+

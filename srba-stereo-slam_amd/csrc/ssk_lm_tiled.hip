@@ -1,0 +1,578 @@
+// ssk_lm_tiled.hip -- the relative-BA Levenberg-Marquardt solve of ssk_lm.hip (same contract L1-L5, same results
+// to rounding) with the whole linearisation kept ON CHIP: no Jacobian ever goes to HBM.
+//
+// Why: per LM iteration the algorithm needs 56 B per observation (pixels, ids, landmark) and the edge poses
+// (SURVEY 8(d)); the scratch-in-L2 kernel moves ~9.5 MB per window-iteration because it materialises the 4x6
+// Jacobian blocks and gathers them three times.  Here a window's landmarks are cut (host, ssk_capi_lm.hip) into
+// tiles whose linearisation fits the 160 KB of LDS of a gfx950 CU, and a persistent 512-thread workgroup per
+// window streams the tiles:
+//   I1  lane = observation: SE(3) chain along the spanning-tree path (poses in LDS), stereo projection, IRLS
+//       weight; writes per optimised path entry A = +-w M R (4x3) and the chained point q (the 4x6 block is
+//       [A | q x A], never stored), per observation Jf = w M R_all (4x3) and w r      -> LDS records
+//   I2  lane = (landmark, edge) incidence: W = sum Je^T Jf, g_e part, in REGISTERS across the barrier;
+//       lane = landmark: V = sum Jf^T Jf, g_f, Cholesky V + lambda I = L L^T, L^-1, c = L^-1 g_f      -> LDS
+//   I3  incidence lanes: Y = W L^-T (so the Schur term W V^-1 W'^T = Y Y'^T is symmetric by construction),
+//       reduced gradient term g_e - Y c; Y -> LDS (+ HBM for the back-substitution).
+//       all waves: H_pp items (observation, pair of its optimised path entries): 6x6 block from
+//       C = A_i^T A_j (3x3) and two cross products (90 FMA instead of 144) in 36 registers
+//   I4  Schur items (landmark, pair of its incidences): Y_i Y_j^T
+//   Items are sorted by block pair id; a lane owns a group of consecutive items of one block, a wave sums the
+//   lanes of a chunk by segments of equal block id through an LDS transpose (lane order: deterministic, no
+//   floating-point atomics) into partial slots; the final block sum runs over the slot list of the block.
+// After the tiles: reduced system assembled in LDS over the dead tile buffers, LDL^T + back-substitution in LDS
+// (ssk_lm_device.h), landmark back-substitution from Y, trial state, robust error, lambda schedule: as ssk_lm.hip.
+// A rejected step re-linearises at the same state (bit-identical values) instead of keeping W in HBM.
+// HBM traffic per window-iteration: inputs (~60 KB, L2 resident) + Y (2 x 144 B per incidence) + partial slots.
+#include "ssk_lm.h"
+
+// LM parity is a 1e-6 relative tolerance (contract L5), not bit-exactness: let the compiler fuse multiply-adds here
+// (the build disables contraction globally for the bit-exact front-end kernels)
+#pragma clang fp contract(fast)
+
+namespace {
+
+#include "ssk_lm_device.h"
+
+static_assert(NT == SSK_LMT_NT, "workgroup size of the tiled kernel");
+constexpr int ENT_P = SSK_LMT_ENT, OBS_P = SSK_LMT_OBS, Y_P = SSK_LMT_Y, LMR_P = SSK_LMT_LMR;
+constexpr int RED_P = 9, RED_WAVE_D = 64 * RED_P;
+
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c)
+{
+	c[0] = a[1] * b[2] - a[2] * b[1];
+	c[1] = a[2] * b[0] - a[0] * b[2];
+	c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// Sum of 36-vectors over the lanes of a wave BY SEGMENT, in lane order.  Lanes are sorted by key; a segment starts
+// at every key change and at lanes 0/16/32/48.  Four passes of 9 values through the wave's LDS scratch (row pitch
+// 9): every lane writes its row, then lanes c < 9 of each 16-lane group walk the 16 rows of their group and store
+// a segment's sum to part[36 * (slot0 + segment)] when the next one starts.
+__device__ __forceinline__ void wave_seg_sum36(const double (&acc)[36], int key, double* red, int lane, double* __restrict__ part, int slot0)
+{
+	const int prev = __shfl_up(key, 1, 64);
+	const bool head = (lane & 15) == 0 || key != prev;
+	const unsigned long long hm = __ballot(head);
+	const int grp = lane >> 4, c = lane & 15;
+	const int seg_base = grp == 0 ? 0 : __popcll(hm & ((1ull << (16 * grp)) - 1ull));
+#pragma unroll
+	for (int h = 0; h < 4; ++h) {
+#pragma unroll
+		for (int i = 0; i < 9; ++i) red[lane * RED_P + i] = acc[9 * h + i];
+		WAVE_SYNC();
+		if (c < 9) {
+			double s = 0.0;
+			int seg = seg_base - 1;
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int row = 16 * grp + r;
+				const double v = red[row * RED_P + c];
+				if ((hm >> row) & 1ull) {
+					if (r > 0) part[36 * (size_t)(slot0 + seg) + 9 * h + c] = s;
+					s = 0.0; ++seg;
+				}
+				s += v;
+			}
+			part[36 * (size_t)(slot0 + seg) + 9 * h + c] = s;
+		}
+		WAVE_SYNC();
+	}
+}
+
+// I1: linearise observation o (tile-local entry base / optimised-step mask in `info`) into the LDS records
+__device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, int o, int info,
+                                  double* __restrict__ ent, double* __restrict__ orec)
+{
+	const int pb = D.obs_path_off[W.opo0 + o], n = D.obs_path_off[W.opo0 + o + 1] - pb;
+	const int e0 = info & 0xFFFF, om = (info >> 16) & 0xFF;
+	double q[3], t[3];
+	{
+		const double* f = D.lm + 3 * (size_t)(W.lm0 + D.obs_lm[W.obs0 + o]);
+		q[0] = f[0]; q[1] = f[1]; q[2] = f[2];
+	}
+	// backward pass: q_i = X_i (+) q_{i+1}; an optimised entry keeps the point its Jacobian needs:
+	// dir 0 -> q_i (after the step), dir 1 -> q_{i+1} (before it)
+	for (int i = n - 1; i >= 0; --i) {
+		const int c = D.path_edge[W.path0 + pb + i];
+		const double* T = pose + 12 * (c >> 1);
+		const bool opt = (om >> i) & 1;
+		double* eq = ent + ENT_P * (e0 + __popc(om & ((1 << i) - 1))) + 12;
+		if ((c & 1) == 0) { se3_apply(T, q, t); if (opt) { eq[0] = t[0]; eq[1] = t[1]; eq[2] = t[2]; } }
+		else { if (opt) { eq[0] = q[0]; eq[1] = q[1]; eq[2] = q[2]; } se3_apply_inv(T, q, t); }
+		q[0] = t[0]; q[1] = t[1]; q[2] = t[2];
+	}
+	double pc[3], h[4], r[4];
+	se3_apply_inv(P.S, q, pc);
+	project(P, pc, h);
+	const float* z = D.obs_px + 4 * (size_t)(W.obs0 + o);
+	double s2 = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { r[k] = (double)z[k] - h[k]; s2 += r[k] * r[k]; }
+	const double w = P.robust ? sqrt(1.0 / sqrt(1.0 + s2 / (P.kernel * P.kernel))) : 1.0;
+	const double iz = 1.0 / pc[2], iz2 = iz * iz;
+	const double Dm[12] = {P.fx_l * iz, 0, -P.fx_l * pc[0] * iz2,
+	                       0, P.fy_l * iz, -P.fy_l * pc[1] * iz2,
+	                       P.fx_r * iz, 0, -P.fx_r * (pc[0] - P.baseline) * iz2,
+	                       0, P.fy_r * iz, -P.fy_r * pc[1] * iz2};
+	double M[12];     // D * R_S^T
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 3; ++j)
+			M[3 * i + j] = Dm[3 * i] * P.S[4 * j] + Dm[3 * i + 1] * P.S[4 * j + 1] + Dm[3 * i + 2] * P.S[4 * j + 2];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) orec[12 + k] = w * r[k];
+	// forward pass: RA = product of the step rotations so far
+	double RA[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	for (int i = 0; i < n; ++i) {
+		const int c = D.path_edge[W.path0 + pb + i];
+		const int dir = c & 1;
+		const double* T = pose + 12 * (c >> 1);
+		double RN[9];
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+#pragma unroll
+			for (int b = 0; b < 3; ++b)
+				RN[3 * a + b] = dir == 0 ? RA[3 * a] * T[b] + RA[3 * a + 1] * T[4 + b] + RA[3 * a + 2] * T[8 + b]
+				                         : RA[3 * a] * T[4 * b] + RA[3 * a + 1] * T[4 * b + 1] + RA[3 * a + 2] * T[4 * b + 2];
+		if ((om >> i) & 1) {
+			const double* RR = dir == 0 ? RA : RN;
+			const double sg = dir == 0 ? w : -w;
+			double* ea = ent + ENT_P * (e0 + __popc(om & ((1 << i) - 1)));
+#pragma unroll
+			for (int a = 0; a < 4; ++a) {
+				ea[3 * a] = sg * (M[3 * a] * RR[0] + M[3 * a + 1] * RR[3] + M[3 * a + 2] * RR[6]);
+				ea[3 * a + 1] = sg * (M[3 * a] * RR[1] + M[3 * a + 1] * RR[4] + M[3 * a + 2] * RR[7]);
+				ea[3 * a + 2] = sg * (M[3 * a] * RR[2] + M[3 * a + 1] * RR[5] + M[3 * a + 2] * RR[8]);
+			}
+		}
+#pragma unroll
+		for (int a = 0; a < 9; ++a) RA[a] = RN[a];
+	}
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 3; ++j)
+			orec[3 * i + j] = w * (M[3 * i] * RA[j] + M[3 * i + 1] * RA[3 + j] + M[3 * i + 2] * RA[6 + j]);
+}
+
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
+{
+	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | tile records / reduced system]
+	__shared__ double s_b[128];
+	__shared__ double s_inv[128];
+	__shared__ double s_part[NW];
+	__shared__ double s_lambda, s_nu, s_err;
+	__shared__ int s_accept, s_stop, s_iters, s_accepted;
+
+	const lm_win W = D.win[blockIdx.x];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int n6 = 6 * W.E, np = n6 | 1;
+	double* pose_cur = s_dyn;
+	double* pose_new = s_dyn + 12 * W.n_edges;
+	double* reg = s_dyn + 24 * W.n_edges;
+	double* A = reg;                                   // reduced system (n6 + 1) x np, over the dead tile records
+#ifdef SSK_LM_STAMPS
+	__shared__ unsigned long long s_acc[16];
+	unsigned long long t_last = __builtin_amdgcn_s_memtime();
+	if (tid < 16) s_acc[tid] = 0;
+#define STAMP(i) do { __syncthreads(); if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_acc[i] += t_ - t_last; t_last = t_; } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+	for (int i = tid; i < 12 * W.n_edges; i += NT) {
+		const double v = D.pose[12 * (size_t)W.edge0 + i];
+		pose_cur[i] = v; pose_new[i] = v;
+	}
+	for (int i = tid; i < 3 * W.n_lms; i += NT) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
+	__syncthreads();
+	const double e0 = total_error(D, W, P, pose_cur, D.lm, s_part);
+	if (tid == 0) {
+		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0;
+		ssk_lm_result& R = D.res[blockIdx.x];
+		R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
+	}
+	__syncthreads();
+	if (W.E == 0 && W.L == 0) {
+		if (tid == 0) { ssk_lm_result& R = D.res[blockIdx.x]; R.iters = 0; R.accepted = 0; R.err_final = e0; R.lambda_final = -1.0; }
+		return;
+	}
+	double* const Pp = D.Ppart2 + 36 * (size_t)W.ps0;
+	double* const Sp = D.Spart2 + 36 * (size_t)W.ss0;
+
+	while (true) {
+		__syncthreads();
+		if (s_iters >= P.max_iters) break;
+		if (W.n_obs > 0 && sqrt(s_err / W.n_obs) < P.stop_rmse) { if (tid == 0) s_stop = 1; break; }
+		const double lambda = s_lambda;
+		const bool pre = lambda < 0;                   // first pass of a solve: only the diagonals, for lambda0
+		const int it_idx = s_iters;
+		double vmax = 0.0;
+		STAMP(0);
+		for (int t = 0; t < W.n_tiles; ++t) {
+			const lm_tile T = D.tile[W.tile0 + t];
+			double* ent = reg;
+			double* obsr = ent + ENT_P * T.n_ent;
+			const int obs_d = OBS_P * T.n_obs > SSK_LMT_RED ? OBS_P * T.n_obs : SSK_LMT_RED;
+			double* Yr = obsr + obs_d;
+			double* lmr = Yr + Y_P * T.n_inc;
+			double* red = obsr + wave * RED_WAVE_D;
+			// ---- I1 ----
+			for (int k = tid; k < T.n_obs; k += NT)
+				linearize_obs_lds(D, W, P, pose_cur, D.tobs_o[W.tobs0 + T.obs0 + k], D.tobs_info[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
+			__syncthreads();
+			STAMP(1);
+			// ---- I2 ----
+			double Wm[18], ge[6];
+			bool unk = false;
+			int lml = 0;
+#pragma unroll
+			for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
+#pragma unroll
+			for (int c = 0; c < 6; ++c) ge[c] = 0.0;
+			if (tid < T.n_inc) {
+				lml = D.inc_lml[W.lme0 + T.inc0 + tid];
+				unk = D.tl_slot[W.tl0 + T.lml0 + lml] >= 0;
+				const int k0 = D.lmep_off[W.lmeo0 + T.inc0 + tid], k1 = D.lmep_off[W.lmeo0 + T.inc0 + tid + 1];
+				for (int k = k0; k < k1; ++k) {
+					const int loc = D.lmep_loc[W.lmep0 + k];
+					const double* er = ent + ENT_P * (loc & 0xFFFF);
+					const double* orr = obsr + OBS_P * (loc >> 16);
+					double a[12], q[3], rr[4], tv[3], x[3];
+#pragma unroll
+					for (int c = 0; c < 12; ++c) a[c] = er[c];
+#pragma unroll
+					for (int c = 0; c < 3; ++c) q[c] = er[12 + c];
+#pragma unroll
+					for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
+#pragma unroll
+					for (int c = 0; c < 3; ++c) tv[c] = a[c] * rr[0] + a[3 + c] * rr[1] + a[6 + c] * rr[2] + a[9 + c] * rr[3];
+					cross3(q, tv, x);
+#pragma unroll
+					for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
+					if (unk) {
+						double jf[12];
+#pragma unroll
+						for (int c = 0; c < 12; ++c) jf[c] = orr[c];
+#pragma unroll
+						for (int b = 0; b < 3; ++b) {
+							double cb[3];
+#pragma unroll
+							for (int c = 0; c < 3; ++c) cb[c] = a[c] * jf[b] + a[3 + c] * jf[3 + b] + a[6 + c] * jf[6 + b] + a[9 + c] * jf[9 + b];
+							cross3(q, cb, x);
+#pragma unroll
+							for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
+						}
+					}
+				}
+			}
+			{
+				const int j = NT - 1 - tid;
+				if (j < T.n_lm) {
+					const int slot = D.tl_slot[W.tl0 + T.lml0 + j];
+					if (slot >= 0) {
+						const int o0 = D.tl_obs_off[W.tlo0 + T.lml0 + j] - T.obs0, o1 = D.tl_obs_off[W.tlo0 + T.lml0 + j + 1] - T.obs0;
+						double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
+						for (int k = o0; k < o1; ++k) {
+							const double* orr = obsr + OBS_P * k;
+							double jf[12], rr[4];
+#pragma unroll
+							for (int c = 0; c < 12; ++c) jf[c] = orr[c];
+#pragma unroll
+							for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
+							v00 += jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
+							v01 += jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
+							v02 += jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
+							v11 += jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
+							v12 += jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
+							v22 += jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
+							g0 += jf[0] * rr[0] + jf[3] * rr[1] + jf[6] * rr[2] + jf[9] * rr[3];
+							g1 += jf[1] * rr[0] + jf[4] * rr[1] + jf[7] * rr[2] + jf[10] * rr[3];
+							g2 += jf[2] * rr[0] + jf[5] * rr[1] + jf[8] * rr[2] + jf[11] * rr[3];
+						}
+						if (pre) {
+							vmax = fmax(vmax, fmax(v00, fmax(v11, v22)));
+						} else {
+							double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
+							Hm[0] = v00; Hm[1] = v01; Hm[2] = v02; Hm[3] = v01; Hm[4] = v11; Hm[5] = v12; Hm[6] = v02; Hm[7] = v12; Hm[8] = v22;
+							double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
+							gl[0] = g0; gl[1] = g1; gl[2] = g2;
+							const double l00 = sqrt(v00 + lambda), i00 = 1.0 / l00;
+							const double l10 = v01 * i00, l20 = v02 * i00;
+							const double l11 = sqrt(v11 + lambda - l10 * l10), i11 = 1.0 / l11;
+							const double l21 = (v12 - l20 * l10) * i11;
+							const double l22 = sqrt(v22 + lambda - l20 * l20 - l21 * l21), i22 = 1.0 / l22;
+							const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
+							const double rec[9] = {i00, i10, i11, i20, i21, i22, i00 * g0, i10 * g0 + i11 * g1, i20 * g0 + i21 * g1 + i22 * g2};
+							double* lr = lmr + LMR_P * j;
+							double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
+#pragma unroll
+							for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
+						}
+					}
+				}
+			}
+			__syncthreads();
+			STAMP(2);
+			// ---- I3 ----
+			if (!pre && tid < T.n_inc) {
+				const int mg = W.lme0 + T.inc0 + tid;
+				double* gr = D.gre + 6 * (size_t)(W.el0 + D.lme_elpos[mg]);
+				if (unk) {
+					const double* lr = lmr + LMR_P * lml;
+					const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
+					double* yl = Yr + Y_P * tid;
+					double* yg = D.Tb + 18 * (size_t)mg;
+#pragma unroll
+					for (int a = 0; a < 6; ++a) {
+						const double y0 = Wm[3 * a] * i00;
+						const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
+						const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
+						yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
+						yg[3 * a] = y0; yg[3 * a + 1] = y1; yg[3 * a + 2] = y2;
+						gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
+					}
+				} else {
+#pragma unroll
+					for (int a = 0; a < 6; ++a) gr[a] = ge[a];
+				}
+			}
+			for (int c = wave; c < T.n_pc; c += NW) {
+				const int g = 64 * c + lane;
+				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
+				const int cnt = g < T.n_pg ? (rec.y & 255) : 0, key = rec.y >> 8;
+				double acc[36];
+#pragma unroll
+				for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+				for (int k = 0; k < cnt; ++k) {
+					const int itv = D.pit[W.pit0 + rec.x + k];
+					const double* e1 = ent + ENT_P * (itv & 0xFFFF);
+					const double* e2 = ent + ENT_P * (itv >> 16);
+					double a1[12], a2[12], q1[3], q2[3], C[9];
+#pragma unroll
+					for (int i = 0; i < 12; ++i) { a1[i] = e1[i]; a2[i] = e2[i]; }
+#pragma unroll
+					for (int i = 0; i < 3; ++i) { q1[i] = e1[12 + i]; q2[i] = e2[12 + i]; }
+#pragma unroll
+					for (int r = 0; r < 3; ++r)
+#pragma unroll
+						for (int s = 0; s < 3; ++s)
+							C[3 * r + s] = a1[r] * a2[s] + a1[3 + r] * a2[3 + s] + a1[6 + r] * a2[6 + s] + a1[9 + r] * a2[9 + s];
+					// block = [C, rows(C) x' q2 ; q1 x cols(C), q1 x (cols of the top right)]  with u x' q = q x u
+					double TR[9];
+#pragma unroll
+					for (int r = 0; r < 3; ++r) {
+						cross3(q2, C + 3 * r, TR + 3 * r);
+#pragma unroll
+						for (int s = 0; s < 3; ++s) { acc[6 * r + s] += C[3 * r + s]; acc[6 * r + 3 + s] += TR[3 * r + s]; }
+					}
+#pragma unroll
+					for (int s = 0; s < 3; ++s) {
+						const double cc[3] = {C[s], C[3 + s], C[6 + s]}, tc[3] = {TR[s], TR[3 + s], TR[6 + s]};
+						double x[3], y[3];
+						cross3(q1, cc, x);
+						cross3(q1, tc, y);
+#pragma unroll
+						for (int r = 0; r < 3; ++r) { acc[6 * (3 + r) + s] += x[r]; acc[6 * (3 + r) + 3 + s] += y[r]; }
+					}
+				}
+				wave_seg_sum36(acc, key, red, lane, Pp, D.pslot0[W.pcx0 + T.pc0 + c]);
+			}
+			__syncthreads();
+			STAMP(3);
+			// ---- I4 ----
+			if (!pre)
+				for (int c = wave; c < T.n_sc; c += NW) {
+					const int g = 64 * c + lane;
+					const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
+					const int cnt = g < T.n_sg ? (rec.y & 255) : 0, key = rec.y >> 8;
+					double acc[36];
+#pragma unroll
+					for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+					for (int k = 0; k < cnt; ++k) {
+						const int itv = D.qit[W.qit0 + rec.x + k];
+						const double* Y1 = Yr + Y_P * (itv & 0xFFFF);
+						const double* Y2 = Yr + Y_P * (itv >> 16);
+						double y1[18], y2[18];
+#pragma unroll
+						for (int i = 0; i < 18; ++i) { y1[i] = Y1[i]; y2[i] = Y2[i]; }
+#pragma unroll
+						for (int a = 0; a < 6; ++a)
+#pragma unroll
+							for (int b = 0; b < 6; ++b)
+								acc[6 * a + b] += y1[3 * a] * y2[3 * b] + y1[3 * a + 1] * y2[3 * b + 1] + y1[3 * a + 2] * y2[3 * b + 2];
+					}
+					wave_seg_sum36(acc, key, red, lane, Sp, D.sslot0[W.scx0 + T.sc0 + c]);
+				}
+			__syncthreads();
+			STAMP(4);
+		}
+		if (pre) {
+			// lambda0 = tau * max diag(H): the diagonal blocks' slot sums, and the landmark blocks' diagonals
+			double mx = vmax;
+			for (int it = tid; it < n6; it += NT) {
+				const int e = it / 6, a = it - 6 * e, pid = e * (e + 1) / 2 + e;
+				double s = 0;
+				for (int k = D.pcl_off[W.pairo0 + pid]; k < D.pcl_off[W.pairo0 + pid + 1]; ++k) s += Pp[36 * (size_t)D.pcl_idx[W.pcl0 + k] + 7 * a];
+				mx = fmax(mx, s);
+			}
+			mx = block_max(mx, s_part);
+			if (tid == 0) s_lambda = P.tau * mx;
+			continue;
+		}
+		// ---- F2: H_red block (e,e') = sum of its H_pp slots + lambda I - sum of its Schur slots (slot order); diagonal
+		//      blocks are written from their upper triangle ----
+		for (int it = tid; it < W.n_pairs * 36; it += NT) {
+			const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
+			const int2 ee = D.pair_ee[W.pair0 + pid];
+			if (ee.x == ee.y && a > b) continue;
+			double p = 0, s = 0;
+			for (int k = D.pcl_off[W.pairo0 + pid]; k < D.pcl_off[W.pairo0 + pid + 1]; ++k) p += Pp[36 * (size_t)D.pcl_idx[W.pcl0 + k] + ab];
+			for (int k = D.scl_off[W.pairo0 + pid]; k < D.scl_off[W.pairo0 + pid + 1]; ++k) s += Sp[36 * (size_t)D.scl_idx[W.scl0 + k] + ab];
+			double sres = p - s;
+			if (ee.x == ee.y && a == b) sres += lambda;
+			A[(6 * ee.x + a) * np + 6 * ee.y + b] = sres;
+			A[(6 * ee.y + b) * np + 6 * ee.x + a] = sres;
+		}
+		// g_red(e) = sum of its incidences' terms (contiguous, edge-major): 8 lanes per component
+		for (int it = tid; it < n6 * 8; it += NT) {
+			const int comp = it >> 3, j = it & 7, e = comp / 6, a = comp - e * 6;
+			const int k0 = D.el_off[W.uso0 + e], k1 = D.el_off[W.uso0 + e + 1];
+			const double* src = D.gre + 6 * (size_t)W.el0 + a;
+			double s0 = 0, s1 = 0;
+			int k = k0 + j;
+			for (; k + 8 < k1; k += 16) { s0 += src[6 * (size_t)k]; s1 += src[6 * (size_t)(k + 8)]; }
+			if (k < k1) s0 += src[6 * (size_t)k];
+			double v = s0 + s1;
+			v += __shfl_down(v, 4, 8); v += __shfl_down(v, 2, 8); v += __shfl_down(v, 1, 8);
+			if (j == 0) A[n6 * np + comp] = v;
+		}
+		__syncthreads();
+		STAMP(5);
+		// ---- G ----
+		bool ok = true;
+		if (n6 > 0) ok = ldl_solve_lds(A, np, n6, s_b, s_inv);
+		STAMP(6);
+		double dpn = 0, dfn = 0;
+		if (ok) {
+			for (int i = tid; i < n6; i += NT) { D.dp[6 * (size_t)W.us0 + i] = s_b[i]; dpn += s_b[i] * s_b[i]; }
+			// ---- H: landmarks, delta_f = L^-T (c - sum_e Y_e^T delta_e) ----
+			for (int l = tid; l < W.L; l += NT) {
+				const double* lg = D.Vinv + 9 * (size_t)(W.ls0 + l);
+				double rhs[3] = {lg[6], lg[7], lg[8]};
+				const int m0 = D.lsm_off[W.lso0 + l], m1 = D.lsm_off[W.lso0 + l + 1];
+				for (int m = m0; m < m1; ++m) {
+					const double* Ym = D.Tb + 18 * (size_t)(W.lme0 + m);
+					const int e = D.lme_edge[W.lme0 + m];
+#pragma unroll
+					for (int a = 0; a < 6; ++a) {
+						const double d = s_b[6 * e + a];
+						rhs[0] -= Ym[3 * a] * d; rhs[1] -= Ym[3 * a + 1] * d; rhs[2] -= Ym[3 * a + 2] * d;
+					}
+				}
+				const double d3[3] = {lg[0] * rhs[0] + lg[1] * rhs[1] + lg[3] * rhs[2], lg[2] * rhs[1] + lg[4] * rhs[2], lg[5] * rhs[2]};
+				const int li = D.slot_lm[W.ls0 + l];
+#pragma unroll
+				for (int a = 0; a < 3; ++a) {
+					D.df[3 * (size_t)(W.ls0 + l) + a] = d3[a];
+					dfn += d3[a] * d3[a];
+					D.lm_new[3 * (size_t)(W.lm0 + li) + a] = D.lm[3 * (size_t)(W.lm0 + li) + a] + d3[a];
+				}
+			}
+			// ---- H: edges, T_new = exp(eps) (+) T ----
+			for (int e = tid; e < W.E; e += NT) {
+				const int ei = D.slot_edge[W.us0 + e];
+				const double* T = pose_cur + 12 * ei;
+				double* O = pose_new + 12 * ei;
+				double eps[6], R[9];
+#pragma unroll
+				for (int a = 0; a < 6; ++a) eps[a] = s_b[6 * e + a];
+				so3_exp(eps + 3, R);
+#pragma unroll
+				for (int i = 0; i < 3; ++i) {
+#pragma unroll
+					for (int j = 0; j < 3; ++j) O[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+					O[4 * i + 3] = R[3 * i] * T[3] + R[3 * i + 1] * T[7] + R[3 * i + 2] * T[11] + eps[i];
+				}
+			}
+			if (D.trace_on)
+				for (int i = tid; i < n6; i += NT) D.dp_trace[W.dp_trace0 + (size_t)it_idx * n6 + i] = s_b[i];
+		}
+		dpn = block_sum(dpn, s_part);
+		dfn = block_sum(dfn, s_part);
+		if (ok && D.trace_on)
+			for (int i = tid; i < 3 * W.L; i += NT) D.df_trace[W.df_trace0 + (size_t)it_idx * 3 * W.L + i] = D.df[3 * (size_t)W.ls0 + i];
+		STAMP(7);
+		// ---- I ----
+		double err_new = s_err;
+		if (ok) err_new = total_error(D, W, P, pose_new, D.lm_new, s_part);
+		__syncthreads();
+		if (tid == 0) {
+			const int accepted = ok && err_new < s_err;
+			if (D.trace_on) {
+				ssk_lm_trace_entry& t = D.trace[W.trace0 + it_idx];
+				t.lambda = lambda; t.err_before = s_err; t.err_after = err_new; t.delta_p_norm = sqrt(dpn);
+				t.delta_f_norm = sqrt(dfn); t.accepted = accepted; t.cholesky_ok = ok;
+			}
+			const int converged = ok && P.conv_rel > 0 && fabs(s_err - err_new) <= P.conv_rel * s_err;
+			s_accept = accepted;
+			s_iters = it_idx + 1;
+			if (accepted) {
+				s_err = err_new; s_lambda = lambda * 0.1; s_nu = 2.0; s_accepted += 1;
+				if (converged) s_stop = 4;
+			} else if (converged) {
+				s_stop = 4;
+			} else {
+				s_lambda = lambda * s_nu; s_nu *= 2.0;
+				if (s_lambda > P.max_lambda) s_stop = 2;
+			}
+		}
+		__syncthreads();
+		if (s_accept) {
+			for (int e = tid; e < W.E; e += NT) {
+				const int ei = D.slot_edge[W.us0 + e];
+				for (int c = 0; c < 12; ++c) pose_cur[12 * ei + c] = pose_new[12 * ei + c];
+			}
+			for (int l = tid; l < W.L; l += NT) {
+				const int li = D.slot_lm[W.ls0 + l];
+				for (int c = 0; c < 3; ++c) D.lm[3 * (size_t)(W.lm0 + li) + c] = D.lm_new[3 * (size_t)(W.lm0 + li) + c];
+			}
+		}
+		__syncthreads();
+		STAMP(8);
+		if (s_stop == 2 || s_stop == 4) break;
+	}
+	__syncthreads();
+	// publish the final edge poses (they lived in LDS during the solve)
+	for (int e = tid; e < W.E; e += NT) {
+		const int ei = D.slot_edge[W.us0 + e];
+		for (int c = 0; c < 12; ++c) D.pose[12 * (size_t)(W.edge0 + ei) + c] = pose_cur[12 * ei + c];
+	}
+	if (tid == 0) {
+		ssk_lm_result& R = D.res[blockIdx.x];
+		R.iters = s_iters; R.accepted = s_accepted; R.stop_reason = s_stop; R.err_final = s_err; R.lambda_final = s_lambda;
+#ifdef SSK_LM_STAMPS
+		if (blockIdx.x == 0)
+			printf("LMT stamps (cycles, window 0, %d iters, %d tiles): top %llu I1 %llu I2 %llu I3 %llu I4 %llu F2 %llu G %llu H %llu I+dec %llu\n", s_iters, W.n_tiles,
+			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
+#endif
+	}
+}
+
+}  // namespace
+
+int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes)
+{
+	static bool attr_set = false;
+	if (!attr_set) {
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		attr_set = true;
+	}
+	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
+	hipLaunchKernelGGL(lm_solve_tiled_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P);
+	SSK_LAUNCH_CHECK(ctx, "lm_solve_tiled_kernel");
+	return SSK_OK;
+}
