@@ -199,7 +199,9 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	std::vector<float> obs_px;
 	std::vector<lm_win> hdr((size_t)n_windows);
 	std::vector<lm_tile> tiles;
-	std::vector<int> tl_slot, tl_obs_off, tobs_o, tobs_info, inc_lml, lmep_loc, pit, pslot0, pcl_off, pcl_idx, qit, sslot0, scl_off, scl_idx;
+	std::vector<int4> tobs_a;
+	std::vector<float4> tobs_px;
+	std::vector<int> tl_slot, tl_obs_off, inc_lml, lmep_loc, pit, pslot0, pcl_off, pcl_idx, qit, sslot0, scl_off, scl_idx;
 	std::vector<int2> pgrp, sgrp;
 	size_t n_pslots_total = 0, n_sslots_total = 0, tiled_dyn = 0;
 	bool tiled_all = true;
@@ -330,18 +332,29 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 
 		// ---- tiles of the LDS-tiled kernel (ssk_lm_tiled.hip, data model in ssk_lm.h) ----
 		std::vector<lm_tile> w_tiles;
-		std::vector<int> w_tl_slot, w_tl_obs_off, w_tobs_o, w_tobs_info, w_inc_lml((size_t)n_lme, 0), w_lmep_loc(w_lmep_idx.size(), 0);
+		std::vector<int4> w_tobs_a;
+		std::vector<float4> w_tobs_px;
+		std::vector<int> w_tl_slot, w_tl_obs_off, w_inc_lml((size_t)n_lme, 0), w_lmep_loc(w_lmep_idx.size(), 0);
 		std::vector<int> w_pit, w_pslot0, w_qit, w_sslot0, w_pcl_off((size_t)n_pairs + 1, 0), w_pcl_idx, w_scl_off((size_t)n_pairs + 1, 0), w_scl_idx;
 		std::vector<int2> w_pgrp, w_sgrp;
 		int n_pslots = 0, n_sslots = 0;
 		const long long region_bytes = (long long)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC - 2LL * 12 * 8 * Wn.n_edges_total;
-		bool tiled = 6 * E <= SSK_LMT_MAX_N6 && (long long)(6 * E + 1) * ((6 * E) | 1) * 8 <= region_bytes;
+		bool tiled = 6 * E <= SSK_LMT_MAX_N6 && Wn.n_edges_total <= 128 && (long long)(6 * E + 1) * ((6 * E) | 1) * 8 <= region_bytes;
 		if (tiled) {
 			auto tile_bytes = [](long long nP, long long nO, long long nM, long long nL) {
 				return 8 * (SSK_LMT_ENT * nP + std::max<long long>(SSK_LMT_OBS * nO, SSK_LMT_RED) + SSK_LMT_Y * nM + SSK_LMT_LMR * nL);
 			};
 			std::vector<std::vector<int>> obs_of((size_t)Wn.n_lms_total);
 			for (int o = 0; o < Wn.n_obs; ++o) obs_of[Wn.obs_lm[o]].push_back(o);
+			// packed observation record: everything a lane needs in one coalesced 32-byte load
+			// (x: first local entry | optimised-step mask << 16 | path length << 24, y: landmark, z/w: 8 path codes of 8 bits)
+			std::vector<char> in_tile((size_t)Wn.n_obs, 0);
+			auto pack_obs = [&](int o, int info) {
+				unsigned long long codes = 0;
+				const int pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb;
+				for (int i = 0; i < len; ++i) codes |= (unsigned long long)(Wn.path_edge[pb + i] & 255) << (8 * i);
+				return make_int4(info, Wn.obs_lm[o], (int)(unsigned)(codes & 0xFFFFFFFFull), (int)(unsigned)(codes >> 32));
+			};
 			auto opt_mask = [&](int o) {
 				int om = 0;
 				for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p)
@@ -390,7 +403,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 			int lme_cursor = 0;
 			while (oi < order.size() && tiled) {
 				lm_tile T{};
-				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_o.size(); T.inc0 = lme_cursor;
+				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_a.size(); T.inc0 = lme_cursor;
 				long long nP = 0, nO = 0, nM = 0, nL = 0, var = 0;
 				size_t oj = oi;
 				for (; oj < order.size(); ++oj) {
@@ -406,11 +419,12 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 				for (size_t ok = oi; ok < oj; ++ok) {
 					const int l = order[ok], j = (int)(ok - oi);
 					w_tl_slot.push_back(Wn.lm_unknown_slot[l]);
-					w_tl_obs_off.push_back((int)w_tobs_o.size());
+					w_tl_obs_off.push_back((int)w_tobs_a.size());
 					for (int o : obs_of[l]) {
-						const int kl = (int)w_tobs_o.size() - T.obs0, pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
-						w_tobs_o.push_back(o);
-						w_tobs_info.push_back(n_ent | (om << 16) | (len << 24));
+						const int kl = (int)w_tobs_a.size() - T.obs0, pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
+						w_tobs_a.push_back(pack_obs(o, n_ent | (om << 16) | (len << 24)));
+						w_tobs_px.push_back(make_float4(Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]));
+						in_tile[o] = 1;
 						std::vector<std::pair<int, int>> steps;      // (edge slot, local entry)
 						for (int i = 0; i < len; ++i)
 							if ((om >> i) & 1) {
@@ -438,7 +452,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 								                  (lm_lmes[ok][a] - T.inc0) | ((lm_lmes[ok][b2] - T.inc0) << 16)});
 					lme_cursor += (int)lm_lmes[ok].size();
 				}
-				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_o.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0;
+				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_a.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0;
 				T.pg0 = (int)w_pgrp.size(); T.pc0 = (int)w_pslot0.size();
 				make_groups(pitems, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
 				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size();
@@ -447,7 +461,13 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)tile_bytes(T.n_ent, T.n_obs, T.n_inc, T.n_lm));
 				oi = oj;
 			}
-			w_tl_obs_off.push_back((int)w_tobs_o.size());
+			w_tl_obs_off.push_back((int)w_tobs_a.size());
+			// the observations outside every tile (fixed landmark, no optimised edge on the path) still count in the error
+			for (int o = 0; o < Wn.n_obs && tiled; ++o)
+				if (!in_tile[o]) {
+					w_tobs_a.push_back(pack_obs(o, (Wn.obs_path_off[o + 1] - Wn.obs_path_off[o]) << 24));
+					w_tobs_px.push_back(make_float4(Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]));
+				}
 			for (int p2 = 0; p2 < n_pairs; ++p2) {
 				w_pcl_off[p2] = (int)w_pcl_idx.size(); w_pcl_idx.insert(w_pcl_idx.end(), pslots_of[p2].begin(), pslots_of[p2].end());
 				w_scl_off[p2] = (int)w_scl_idx.size(); w_scl_idx.insert(w_scl_idx.end(), sslots_of[p2].begin(), sslots_of[p2].end());
@@ -457,15 +477,15 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		}
 		if (!tiled) tiled_all = false;
 		H.n_tiles = tiled ? (int)w_tiles.size() : -1;
-		H.tile0 = (int)tiles.size(); H.tl0 = (int)tl_slot.size(); H.tlo0 = (int)tl_obs_off.size(); H.tobs0 = (int)tobs_o.size();
+		H.tile0 = (int)tiles.size(); H.tl0 = (int)tl_slot.size(); H.tlo0 = (int)tl_obs_off.size(); H.tobs0 = (int)tobs_a.size();
 		H.pit0 = (int)pit.size(); H.pg0 = (int)pgrp.size(); H.pcx0 = (int)pslot0.size(); H.ps0 = (int)n_pslots_total; H.pcl0 = (int)pcl_idx.size();
 		H.qit0 = (int)qit.size(); H.sg0 = (int)sgrp.size(); H.scx0 = (int)sslot0.size(); H.ss0 = (int)n_sslots_total; H.scl0 = (int)scl_idx.size();
 		n_pslots_total += (size_t)n_pslots; n_sslots_total += (size_t)n_sslots;
 		tiles.insert(tiles.end(), w_tiles.begin(), w_tiles.end());
 		tl_slot.insert(tl_slot.end(), w_tl_slot.begin(), w_tl_slot.end());
 		tl_obs_off.insert(tl_obs_off.end(), w_tl_obs_off.begin(), w_tl_obs_off.end());
-		tobs_o.insert(tobs_o.end(), w_tobs_o.begin(), w_tobs_o.end());
-		tobs_info.insert(tobs_info.end(), w_tobs_info.begin(), w_tobs_info.end());
+		tobs_a.insert(tobs_a.end(), w_tobs_a.begin(), w_tobs_a.end());
+		tobs_px.insert(tobs_px.end(), w_tobs_px.begin(), w_tobs_px.end());
 		inc_lml.insert(inc_lml.end(), w_inc_lml.begin(), w_inc_lml.end());
 		lmep_loc.insert(lmep_loc.end(), w_lmep_loc.begin(), w_lmep_loc.end());
 		pit.insert(pit.end(), w_pit.begin(), w_pit.end()); pgrp.insert(pgrp.end(), w_pgrp.begin(), w_pgrp.end());
@@ -548,7 +568,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	UP(el_off, el_off); UP(el_idx, el_idx);
 	UP(qp_q, qp_q); UP(pchunk, pchunk); UP(pc_off, pc_off); UP(schunk, schunk); UP(sc_off, sc_off);
 	UP(pose, pose0); UP(lm, lm0);
-	UP(tiles, tile); UP(tl_slot, tl_slot); UP(tl_obs_off, tl_obs_off); UP(tobs_o, tobs_o); UP(tobs_info, tobs_info);
+	UP(tiles, tile); UP(tl_slot, tl_slot); UP(tl_obs_off, tl_obs_off); UP(tobs_a, tobs_a); UP(tobs_px, tobs_px);
 	UP(inc_lml, inc_lml); UP(lmep_loc, lmep_loc);
 	UP(pit, pit); UP(pgrp, pgrp); UP(pslot0, pslot0); UP(pcl_off, pcl_off); UP(pcl_idx, pcl_idx);
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);

@@ -45,7 +45,7 @@ struct lm_win {
 	// ---- LDS-tiled kernel (ssk_lm_tiled.hip); n_tiles < 0: the window does not fit that kernel ----
 	int n_tiles, tile0;   // tile[]
 	int tl0, tlo0;        // tile landmarks (tile order): tl_slot[]; tl_obs_off[] (n_tl + 1 per window, indices into tobs)
-	int tobs0;            // tile-ordered observations: tobs_o[], tobs_info[]
+	int tobs0;            // packed observation records tobs_a[], tobs_px[]: tile order, then the observations outside every tile (n_obs in all)
 	int pit0, pg0, pcx0, ps0, pcl0;   // H_pp items pit[], lane groups pgrp[], chunk slot bases pslot0[], partial slots Ppart2 x36, pcl_idx[]
 	int qit0, sg0, scx0, ss0, scl0;   // Schur items qit[], lane groups sgrp[], sslot0[], Spart2 x36, scl_idx[]
 	long long h0;  // Hred (6E)^2 doubles (only used when the matrix does not fit LDS); Hpair 36 x n_pairs
@@ -71,7 +71,7 @@ struct lm_tile {
 
 struct lm_dev {
 	const lm_win* win;
-	const lm_tile* tile; const int* tl_slot; const int* tl_obs_off; const int* tobs_o; const int* tobs_info;
+	const lm_tile* tile; const int* tl_slot; const int* tl_obs_off; const int4* tobs_a; const float4* tobs_px;
 	const int* inc_lml; const int* lmep_loc;
 	const int* pit; const int2* pgrp; const int* pslot0; const int* pcl_off; const int* pcl_idx;
 	const int* qit; const int2* sgrp; const int* sslot0; const int* scl_off; const int* scl_idx;

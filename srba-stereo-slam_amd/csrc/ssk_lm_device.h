@@ -113,12 +113,15 @@ __device__ void so3_exp(const double* w, double* R)
 
 // G (fast path): the reduced system solved in LDS as a square-root-free LDL^T of the matrix bordered by the
 // right-hand side (row n = g_red^T), right-looking, by the whole workgroup:
-//   column step j:  A(i,k) -= A(i,j) A(k,j) / d_j   for j < k <= i <= n   (one element per thread and pass, one
-//   barrier per column; column j itself stays unscaled: U_ij = L'_ij d_j), d_j = A(j,j) when its turn comes.
+//   A(i,k) -= A(i,j) A(k,j) / d_j   for j < k <= i <= n; column j itself stays unscaled (U_ij = L'_ij d_j), d_j = A(j,j)
+//   when its turn comes.  Blocked by the 6 columns of an edge: the 6x6 diagonal block is factorised in registers by
+//   every thread (no communication), one thread per row finishes the panel, then the whole workgroup applies the
+//   rank-6 update: two barriers per block column.
 // The border row comes out as z = L'^-1 b (forward substitution for free), so only L'^T x = D^-1 z is left: one
 // wavefront keeps x in registers (lane k owns x_k, x_{k+64}), broadcasts x_i with v_readlane and prefetches row
 // i-1 of U while it applies row i, so the dependent chain per step is one readlane + one FMA.
-// A is (n+1) x n with an odd row pitch np (column walks are bank-conflict free).  Every thread returns the same flag.
+// A is (n+1) x n with an odd row pitch np (column walks are bank-conflict free), n a multiple of 6.  Every thread
+// returns the same flag.
 __device__ __forceinline__ double rcp_f64(double d)
 {
 	double x = __builtin_amdgcn_rcp(d);
@@ -136,18 +139,90 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* x_out, double* inv)
 {
 	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-	for (int j = 0; j < n; ++j) {
+	// blocked by the 6 columns of one edge (n = 6E): two barriers per block column instead of one per column
+	for (int c0 = 0; c0 < n; c0 += 6) {
 		__syncthreads();
-		const double d = A[j * np + j];
-		if (!(d > 0.0)) return false;                     // uniform: every thread reads the same settled value
-		const double dinv = rcp_f64(d);
-		if (tid == 0) inv[j] = dinv;
-		for (int i = j + 1 + ty; i <= n; i += NT / 32) {
-			const double aij = A[i * np + j] * dinv;
-			const int kmax = i < n ? i : n - 1;
-			double* ri = A + i * np;
-			for (int k = j + 1 + tx; k <= kmax; k += 32) ri[k] -= aij * A[k * np + j];
+		// (1) the 6x6 diagonal block, factorised redundantly in every thread's registers (broadcast reads)
+		double a[21], iv[6];
+#pragma unroll
+		for (int i = 0; i < 6; ++i)
+#pragma unroll
+			for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = A[(c0 + i) * np + c0 + k];
+		bool bad = false;
+#pragma unroll
+		for (int j = 0; j < 6; ++j) {
+			const double d = a[j * (j + 1) / 2 + j];
+			bad |= !(d > 0.0);
+			iv[j] = rcp_f64(d);
+#pragma unroll
+			for (int i = j + 1; i < 6; ++i) {
+				const double t = a[i * (i + 1) / 2 + j] * iv[j];
+#pragma unroll
+				for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+			}
 		}
+		if (bad) return false;                            // uniform: every thread factorised the same block
+		// (2) panel: one thread per row below the block (the border row included) eliminates inside the block columns
+		for (int i = c0 + 6 + tid; i <= n; i += NT) {
+			double x[6];
+#pragma unroll
+			for (int k = 0; k < 6; ++k) x[k] = A[i * np + c0 + k];
+#pragma unroll
+			for (int j = 0; j < 5; ++j) {
+				const double t = x[j] * iv[j];
+#pragma unroll
+				for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+			}
+#pragma unroll
+			for (int k = 1; k < 6; ++k) A[i * np + c0 + k] = x[k];
+		}
+		__syncthreads();
+		if (tid == 0) {
+#pragma unroll
+			for (int i = 0; i < 6; ++i) {
+				inv[c0 + i] = iv[i];
+#pragma unroll
+				for (int k = 0; k < i; ++k) A[(c0 + i) * np + c0 + k] = a[i * (i + 1) / 2 + k];
+			}
+		}
+		// (3) trailing update A(i,k) -= sum_c U(i,c) U(k,c) / d_c, c0+6 <= k <= min(i, n-1), i <= n: 4 x 2 elements per
+		//     thread and pass, loads before stores
+		const int r0 = c0 + 6;
+		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
+			for (int kb = r0 + tx; kb < n; kb += 64) {
+				double ui[4][6], uk[2][6], v[8];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int i = ib + (NT / 32) * u;
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] = i <= n ? A[i * np + c0 + c] * iv[c] : 0.0;
+				}
+#pragma unroll
+				for (int w = 0; w < 2; ++w) {
+					const int k = kb + 32 * w;
+#pragma unroll
+					for (int c = 0; c < 6; ++c) uk[w][c] = k < n ? A[k * np + c0 + c] : 0.0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						v[2 * u + w] = (i <= n && k < n && k <= i) ? A[i * np + k] : 0.0;
+					}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						if (i <= n && k < n && k <= i) {
+							double sacc = 0.0;
+#pragma unroll
+							for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
+							A[i * np + k] = v[2 * u + w] - sacc;
+						}
+					}
+			}
 	}
 	__syncthreads();
 	if (tid < 64) {

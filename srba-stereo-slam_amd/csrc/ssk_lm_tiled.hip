@@ -79,21 +79,68 @@ __device__ __forceinline__ void wave_seg_sum36(const double (&acc)[36], int key,
 	}
 }
 
-// I1: linearise observation o (tile-local entry base / optimised-step mask in `info`) into the LDS records
-__device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, int o, int info,
+// Robustified squared error of a packed observation record (pose: window-relative poses, lm: the window's landmarks)
+__device__ __forceinline__ double obs_error_packed(const lm_cam& P, const double* pose, const double* __restrict__ lm, const int4 rec, const float4 px)
+{
+	const int n = (rec.x >> 24) & 15;
+	const unsigned long long codes = (unsigned long long)(unsigned)rec.z | ((unsigned long long)(unsigned)rec.w << 32);
+	double q[3], t[3];
+	const double* f = lm + 3 * (size_t)rec.y;
+	q[0] = f[0]; q[1] = f[1]; q[2] = f[2];
+	for (int i = n - 1; i >= 0; --i) {
+		const int c = (int)(codes >> (8 * i)) & 255;
+		const double* T = pose + 12 * (c >> 1);
+		if ((c & 1) == 0) se3_apply(T, q, t); else se3_apply_inv(T, q, t);
+		q[0] = t[0]; q[1] = t[1]; q[2] = t[2];
+	}
+	double pc[3], h[4];
+	se3_apply_inv(P.S, q, pc);
+	project(P, pc, h);
+	const double r0 = (double)px.x - h[0], r1 = (double)px.y - h[1], r2 = (double)px.z - h[2], r3 = (double)px.w - h[3];
+	const double s2 = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+	return P.robust ? huber_rho(s2, P.kernel) : s2;
+}
+
+__device__ double total_error_packed(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const double* lm, double* s_part)
+{
+	double e = 0;
+	for (int k = threadIdx.x; k < W.n_obs; k += NT) e += obs_error_packed(P, pose, lm + 3 * (size_t)W.lm0, D.tobs_a[W.tobs0 + k], D.tobs_px[W.tobs0 + k]);
+	return block_sum(e, s_part);
+}
+
+// Sum of component ab over the partial slots idx[k0..k1) in list order; the slot ids and then the values are loaded
+// eight at a time (independent loads in flight), padding adds +0.0.
+__device__ __forceinline__ double slot_sum(const double* __restrict__ part, const int* __restrict__ idx, int k0, int k1, int ab)
+{
+	double s = 0.0;
+	for (int k = k0; k < k1; k += 8) {
+		int id[8];
+		double v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) id[u] = k + u < k1 ? idx[k + u] : -1;
+#pragma unroll
+		for (int u = 0; u < 8; ++u) v[u] = id[u] >= 0 ? part[36 * (size_t)id[u] + ab] : 0.0;
+#pragma unroll
+		for (int u = 0; u < 8; ++u) s += v[u];
+	}
+	return s;
+}
+
+// I1: linearise one observation (packed record: tile-local entry base / optimised-step mask / path codes) into the LDS records
+__device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const int4 rec, const float4 px,
                                   double* __restrict__ ent, double* __restrict__ orec)
 {
-	const int pb = D.obs_path_off[W.opo0 + o], n = D.obs_path_off[W.opo0 + o + 1] - pb;
-	const int e0 = info & 0xFFFF, om = (info >> 16) & 0xFF;
+	const int n = (rec.x >> 24) & 15, e0 = rec.x & 0xFFFF, om = (rec.x >> 16) & 0xFF;
+	const unsigned long long codes = (unsigned long long)(unsigned)rec.z | ((unsigned long long)(unsigned)rec.w << 32);
 	double q[3], t[3];
 	{
-		const double* f = D.lm + 3 * (size_t)(W.lm0 + D.obs_lm[W.obs0 + o]);
+		const double* f = D.lm + 3 * (size_t)(W.lm0 + rec.y);
 		q[0] = f[0]; q[1] = f[1]; q[2] = f[2];
 	}
 	// backward pass: q_i = X_i (+) q_{i+1}; an optimised entry keeps the point its Jacobian needs:
 	// dir 0 -> q_i (after the step), dir 1 -> q_{i+1} (before it)
 	for (int i = n - 1; i >= 0; --i) {
-		const int c = D.path_edge[W.path0 + pb + i];
+		const int c = (int)(codes >> (8 * i)) & 255;
 		const double* T = pose + 12 * (c >> 1);
 		const bool opt = (om >> i) & 1;
 		double* eq = ent + ENT_P * (e0 + __popc(om & ((1 << i) - 1))) + 12;
@@ -104,7 +151,7 @@ __device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam
 	double pc[3], h[4], r[4];
 	se3_apply_inv(P.S, q, pc);
 	project(P, pc, h);
-	const float* z = D.obs_px + 4 * (size_t)(W.obs0 + o);
+	const float z[4] = {px.x, px.y, px.z, px.w};
 	double s2 = 0;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) { r[k] = (double)z[k] - h[k]; s2 += r[k] * r[k]; }
@@ -125,7 +172,7 @@ __device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam
 	// forward pass: RA = product of the step rotations so far
 	double RA[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 	for (int i = 0; i < n; ++i) {
-		const int c = D.path_edge[W.path0 + pb + i];
+		const int c = (int)(codes >> (8 * i)) & 255;
 		const int dir = c & 1;
 		const double* T = pose + 12 * (c >> 1);
 		double RN[9];
@@ -178,8 +225,15 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 	unsigned long long t_last = __builtin_amdgcn_s_memtime();
 	if (tid < 16) s_acc[tid] = 0;
 #define STAMP(i) do { __syncthreads(); if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_acc[i] += t_ - t_last; t_last = t_; } } while (0)
+	__shared__ unsigned long long s_fine[16];
+	unsigned long long f_last = 0;
+	if (tid < 16) s_fine[tid] = 0;
+#define FTICK0() do { if (tid == 0) f_last = __builtin_amdgcn_s_memtime(); } while (0)
+#define FTICK(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_fine[i] += t_ - f_last; f_last = t_; } } while (0)
 #else
 #define STAMP(i) do {} while (0)
+#define FTICK0() do {} while (0)
+#define FTICK(i) do {} while (0)
 #endif
 
 	for (int i = tid; i < 12 * W.n_edges; i += NT) {
@@ -188,7 +242,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 	}
 	for (int i = tid; i < 3 * W.n_lms; i += NT) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
 	__syncthreads();
-	const double e0 = total_error(D, W, P, pose_cur, D.lm, s_part);
+	const double e0 = total_error_packed(D, W, P, pose_cur, D.lm, s_part);
 	if (tid == 0) {
 		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0;
 		ssk_lm_result& R = D.res[blockIdx.x];
@@ -220,19 +274,24 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			double* lmr = Yr + Y_P * T.n_inc;
 			double* red = obsr + wave * RED_WAVE_D;
 			// ---- I1 ----
+			FTICK0();
 			for (int k = tid; k < T.n_obs; k += NT)
-				linearize_obs_lds(D, W, P, pose_cur, D.tobs_o[W.tobs0 + T.obs0 + k], D.tobs_info[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
+				linearize_obs_lds(D, W, P, pose_cur, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
+			FTICK(0);
 			__syncthreads();
+			FTICK(1);
 			STAMP(1);
+			FTICK0();
 			// ---- I2 ----
-			double Wm[18], ge[6];
+			double ge[6];
 			bool unk = false;
 			int lml = 0;
 #pragma unroll
-			for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
-#pragma unroll
 			for (int c = 0; c < 6; ++c) ge[c] = 0.0;
 			if (tid < T.n_inc) {
+				double Wm[18];
+#pragma unroll
+				for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
 				lml = D.inc_lml[W.lme0 + T.inc0 + tid];
 				unk = D.tl_slot[W.tl0 + T.lml0 + lml] >= 0;
 				const int k0 = D.lmep_off[W.lmeo0 + T.inc0 + tid], k1 = D.lmep_off[W.lmeo0 + T.inc0 + tid + 1];
@@ -267,7 +326,13 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 						}
 					}
 				}
+				if (unk) {                                 // W waits in the incidence's Y record for L^-1 (next interval)
+					double* yl = Yr + Y_P * tid;
+#pragma unroll
+					for (int c = 0; c < 18; ++c) yl[c] = Wm[c];
+				}
 			}
+			FTICK(2);
 			{
 				const int j = NT - 1 - tid;
 				if (j < T.n_lm) {
@@ -315,7 +380,9 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 				}
 			}
 			__syncthreads();
+			FTICK(3);
 			STAMP(2);
+			FTICK0();
 			// ---- I3 ----
 			if (!pre && tid < T.n_inc) {
 				const int mg = W.lme0 + T.inc0 + tid;
@@ -325,6 +392,9 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 					const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
 					double* yl = Yr + Y_P * tid;
 					double* yg = D.Tb + 18 * (size_t)mg;
+					double Wm[18];
+#pragma unroll
+					for (int c = 0; c < 18; ++c) Wm[c] = yl[c];
 #pragma unroll
 					for (int a = 0; a < 6; ++a) {
 						const double y0 = Wm[3 * a] * i00;
@@ -339,6 +409,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 					for (int a = 0; a < 6; ++a) gr[a] = ge[a];
 				}
 			}
+			FTICK(4);
 			for (int c = wave; c < T.n_pc; c += NW) {
 				const int g = 64 * c + lane;
 				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
@@ -346,8 +417,10 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 				double acc[36];
 #pragma unroll
 				for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+				int nxt = cnt > 0 ? D.pit[W.pit0 + rec.x] : 0;
 				for (int k = 0; k < cnt; ++k) {
-					const int itv = D.pit[W.pit0 + rec.x + k];
+					const int itv = nxt;
+					if (k + 1 < cnt) nxt = D.pit[W.pit0 + rec.x + k + 1];    // next item id in flight during this item's arithmetic
 					const double* e1 = ent + ENT_P * (itv & 0xFFFF);
 					const double* e2 = ent + ENT_P * (itv >> 16);
 					double a1[12], a2[12], q1[3], q2[3], C[9];
@@ -378,9 +451,12 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 						for (int r = 0; r < 3; ++r) { acc[6 * (3 + r) + s] += x[r]; acc[6 * (3 + r) + 3 + s] += y[r]; }
 					}
 				}
+				FTICK(5);
 				wave_seg_sum36(acc, key, red, lane, Pp, D.pslot0[W.pcx0 + T.pc0 + c]);
+				FTICK(6);
 			}
 			__syncthreads();
+			FTICK(7);
 			STAMP(3);
 			// ---- I4 ----
 			if (!pre)
@@ -391,8 +467,10 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 					double acc[36];
 #pragma unroll
 					for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+					int nxt = cnt > 0 ? D.qit[W.qit0 + rec.x] : 0;
 					for (int k = 0; k < cnt; ++k) {
-						const int itv = D.qit[W.qit0 + rec.x + k];
+						const int itv = nxt;
+						if (k + 1 < cnt) nxt = D.qit[W.qit0 + rec.x + k + 1];
 						const double* Y1 = Yr + Y_P * (itv & 0xFFFF);
 						const double* Y2 = Yr + Y_P * (itv >> 16);
 						double y1[18], y2[18];
@@ -414,9 +492,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			double mx = vmax;
 			for (int it = tid; it < n6; it += NT) {
 				const int e = it / 6, a = it - 6 * e, pid = e * (e + 1) / 2 + e;
-				double s = 0;
-				for (int k = D.pcl_off[W.pairo0 + pid]; k < D.pcl_off[W.pairo0 + pid + 1]; ++k) s += Pp[36 * (size_t)D.pcl_idx[W.pcl0 + k] + 7 * a];
-				mx = fmax(mx, s);
+				mx = fmax(mx, slot_sum(Pp, D.pcl_idx + W.pcl0, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], 7 * a));
 			}
 			mx = block_max(mx, s_part);
 			if (tid == 0) s_lambda = P.tau * mx;
@@ -428,10 +504,9 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
 			const int2 ee = D.pair_ee[W.pair0 + pid];
 			if (ee.x == ee.y && a > b) continue;
-			double p = 0, s = 0;
-			for (int k = D.pcl_off[W.pairo0 + pid]; k < D.pcl_off[W.pairo0 + pid + 1]; ++k) p += Pp[36 * (size_t)D.pcl_idx[W.pcl0 + k] + ab];
-			for (int k = D.scl_off[W.pairo0 + pid]; k < D.scl_off[W.pairo0 + pid + 1]; ++k) s += Sp[36 * (size_t)D.scl_idx[W.scl0 + k] + ab];
-			double sres = p - s;
+			const double p = slot_sum(Pp, D.pcl_idx + W.pcl0, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], ab);
+			const double sc = slot_sum(Sp, D.scl_idx + W.scl0, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
+			double sres = p - sc;
 			if (ee.x == ee.y && a == b) sres += lambda;
 			A[(6 * ee.x + a) * np + 6 * ee.y + b] = sres;
 			A[(6 * ee.y + b) * np + 6 * ee.x + a] = sres;
@@ -507,7 +582,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 		STAMP(7);
 		// ---- I ----
 		double err_new = s_err;
-		if (ok) err_new = total_error(D, W, P, pose_new, D.lm_new, s_part);
+		if (ok) err_new = total_error_packed(D, W, P, pose_new, D.lm_new, s_part);
 		__syncthreads();
 		if (tid == 0) {
 			const int accepted = ok && err_new < s_err;
@@ -555,8 +630,12 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 		R.iters = s_iters; R.accepted = s_accepted; R.stop_reason = s_stop; R.err_final = s_err; R.lambda_final = s_lambda;
 #ifdef SSK_LM_STAMPS
 		if (blockIdx.x == 0)
+			{
 			printf("LMT stamps (cycles, window 0, %d iters, %d tiles): top %llu I1 %llu I2 %llu I3 %llu I4 %llu F2 %llu G %llu H %llu I+dec %llu\n", s_iters, W.n_tiles,
 			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
+			printf("LMT fine (wave 0): I1 work %llu wait %llu | I2 inc %llu lm+wait %llu | I3 Y %llu items %llu segsum %llu wait %llu\n",
+			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[4], s_fine[5], s_fine[6], s_fine[7]);
+			}
 #endif
 	}
 }
