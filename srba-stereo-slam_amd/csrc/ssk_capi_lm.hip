@@ -4,6 +4,7 @@
 #include "ssk_lm.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -201,7 +202,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	std::vector<lm_tile> tiles;
 	std::vector<int4> tobs_a;
 	std::vector<float4> tobs_px;
-	std::vector<int> tl_slot, tl_obs_off, inc_lml, lmep_loc, pit, pslot0, pcl_off, pcl_idx, qit, sslot0, scl_off, scl_idx;
+	std::vector<int4> tl_rec, inc_rec;
+	std::vector<int> lmep_loc, pit, pslot0, pcl_off, pcl_idx, qit, sslot0, scl_off, scl_idx;
 	std::vector<int2> pgrp, sgrp;
 	size_t n_pslots_total = 0, n_sslots_total = 0, tiled_dyn = 0;
 	bool tiled_all = true;
@@ -334,7 +336,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		std::vector<lm_tile> w_tiles;
 		std::vector<int4> w_tobs_a;
 		std::vector<float4> w_tobs_px;
-		std::vector<int> w_tl_slot, w_tl_obs_off, w_inc_lml((size_t)n_lme, 0), w_lmep_loc(w_lmep_idx.size(), 0);
+		std::vector<int4> w_tl_rec, w_inc_rec((size_t)n_lme, make_int4(0, 0, 0, 0));
+		std::vector<int> w_lmep_loc(w_lmep_idx.size(), 0);
 		std::vector<int> w_pit, w_pslot0, w_qit, w_sslot0, w_pcl_off((size_t)n_pairs + 1, 0), w_pcl_idx, w_scl_off((size_t)n_pairs + 1, 0), w_scl_idx;
 		std::vector<int2> w_pgrp, w_sgrp;
 		int n_pslots = 0, n_sslots = 0;
@@ -375,11 +378,15 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 			std::vector<int> path_loc((size_t)n_path, -1);
 			std::vector<std::vector<int>> pslots_of((size_t)n_pairs), sslots_of((size_t)n_pairs);
 			struct item { int pid, packed; };
-			auto make_groups = [&](std::vector<item>& items, std::vector<int>& it_out, std::vector<int2>& grp_out, std::vector<int>& slot0_out,
+			// lane groups of <= R consecutive items of one block; n_groups(R) for a sorted item list
+			auto count_groups = [](const std::vector<item>& items, int R) {
+				int n = (int)items.size(), g = 0;
+				for (int i = 0; i < n;) { int j = i; while (j < n && items[j].pid == items[i].pid) ++j; g += (j - i + R - 1) / R; i = j; }
+				return g;
+			};
+			auto make_groups = [&](std::vector<item>& items, int R, std::vector<int>& it_out, std::vector<int2>& grp_out, std::vector<int>& slot0_out,
 			                       std::vector<std::vector<int>>& slots_of, int& slot_counter, int& n_grp, int& n_chunk) {
-				std::stable_sort(items.begin(), items.end(), [](const item& a, const item& b) { return a.pid < b.pid; });
 				const int n = (int)items.size(), base = (int)it_out.size();
-				const int R = std::min(255, std::max(1, (n + SSK_LMT_NT - 1) / SSK_LMT_NT));
 				std::vector<int> gkeys;
 				for (int i = 0; i < n;) {
 					int j = i;
@@ -418,8 +425,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 				int n_ent = 0;
 				for (size_t ok = oi; ok < oj; ++ok) {
 					const int l = order[ok], j = (int)(ok - oi);
-					w_tl_slot.push_back(Wn.lm_unknown_slot[l]);
-					w_tl_obs_off.push_back((int)w_tobs_a.size());
+					w_tl_rec.push_back(make_int4(Wn.lm_unknown_slot[l], (int)w_tobs_a.size() - T.obs0, (int)(w_tobs_a.size() + obs_of[l].size()) - T.obs0, 0));
 					for (int o : obs_of[l]) {
 						const int kl = (int)w_tobs_a.size() - T.obs0, pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
 						w_tobs_a.push_back(pack_obs(o, n_ent | (om << 16) | (len << 24)));
@@ -442,8 +448,10 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 							}
 					}
 					for (int m : lm_lmes[ok]) {
-						w_inc_lml[m] = j;
 						for (int k = w_lmep_off[m]; k < w_lmep_off[m + 1]; ++k) w_lmep_loc[k] = path_loc[w_lmep_idx[k]];
+						const int cnt = w_lmep_off[m + 1] - w_lmep_off[m];
+						w_inc_rec[m] = make_int4(j | ((Wn.lm_unknown_slot[l] >= 0 ? 1 : 0) << 15) | (cnt << 16), w_lmep_off[m], 0 /* edge-major slot: below */,
+						                         cnt > 0 ? w_lmep_loc[w_lmep_off[m]] : 0);
 					}
 					if (Wn.lm_unknown_slot[l] >= 0)
 						for (size_t a = 0; a < lm_lmes[ok].size(); ++a)
@@ -454,14 +462,19 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 				}
 				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_a.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0;
 				T.pg0 = (int)w_pgrp.size(); T.pc0 = (int)w_pslot0.size();
-				make_groups(pitems, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
+				// one chunk task per wave: the smallest R whose H_pp + Schur chunks fit one round of the workgroup's waves
+				auto by_pid = [](const item& a, const item& b) { return a.pid < b.pid; };
+				std::stable_sort(pitems.begin(), pitems.end(), by_pid);
+				std::stable_sort(qitems.begin(), qitems.end(), by_pid);
+				int R = 1;
+				while (R < 255 && (count_groups(pitems, R) + 63) / 64 + (count_groups(qitems, R) + 63) / 64 > SSK_LMT_NT / 64) ++R;
+				make_groups(pitems, R, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
 				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size();
-				make_groups(qitems, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
+				make_groups(qitems, R, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
 				w_tiles.push_back(T);
 				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)tile_bytes(T.n_ent, T.n_obs, T.n_inc, T.n_lm));
 				oi = oj;
 			}
-			w_tl_obs_off.push_back((int)w_tobs_a.size());
 			// the observations outside every tile (fixed landmark, no optimised edge on the path) still count in the error
 			for (int o = 0; o < Wn.n_obs && tiled; ++o)
 				if (!in_tile[o]) {
@@ -476,17 +489,21 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 			tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(6 * E + 1) * ((6 * E) | 1) * 8);
 		}
 		if (!tiled) tiled_all = false;
+		if (w == 0 && std::getenv("SSK_LM_DEBUG")) {
+			std::fprintf(stderr, "[ssk lm] window 0: E %d L %d obs %d path %d lme %d tiles %d (region %lld B) pslots %d sslots %d\n", E, L, Wn.n_obs, n_path, n_lme,
+			             tiled ? (int)w_tiles.size() : -1, region_bytes, n_pslots, n_sslots);
+			for (const lm_tile& T : w_tiles)
+				std::fprintf(stderr, "[ssk lm]   tile: lms %d obs %d ent %d inc %d | pgroups %d (chunks %d) sgroups %d (chunks %d)\n", T.n_lm, T.n_obs, T.n_ent, T.n_inc, T.n_pg, T.n_pc, T.n_sg, T.n_sc);
+		}
 		H.n_tiles = tiled ? (int)w_tiles.size() : -1;
-		H.tile0 = (int)tiles.size(); H.tl0 = (int)tl_slot.size(); H.tlo0 = (int)tl_obs_off.size(); H.tobs0 = (int)tobs_a.size();
+		H.tile0 = (int)tiles.size(); H.tl0 = (int)tl_rec.size(); H.tobs0 = (int)tobs_a.size();
 		H.pit0 = (int)pit.size(); H.pg0 = (int)pgrp.size(); H.pcx0 = (int)pslot0.size(); H.ps0 = (int)n_pslots_total; H.pcl0 = (int)pcl_idx.size();
 		H.qit0 = (int)qit.size(); H.sg0 = (int)sgrp.size(); H.scx0 = (int)sslot0.size(); H.ss0 = (int)n_sslots_total; H.scl0 = (int)scl_idx.size();
 		n_pslots_total += (size_t)n_pslots; n_sslots_total += (size_t)n_sslots;
 		tiles.insert(tiles.end(), w_tiles.begin(), w_tiles.end());
-		tl_slot.insert(tl_slot.end(), w_tl_slot.begin(), w_tl_slot.end());
-		tl_obs_off.insert(tl_obs_off.end(), w_tl_obs_off.begin(), w_tl_obs_off.end());
+		tl_rec.insert(tl_rec.end(), w_tl_rec.begin(), w_tl_rec.end());
 		tobs_a.insert(tobs_a.end(), w_tobs_a.begin(), w_tobs_a.end());
 		tobs_px.insert(tobs_px.end(), w_tobs_px.begin(), w_tobs_px.end());
-		inc_lml.insert(inc_lml.end(), w_inc_lml.begin(), w_inc_lml.end());
 		lmep_loc.insert(lmep_loc.end(), w_lmep_loc.begin(), w_lmep_loc.end());
 		pit.insert(pit.end(), w_pit.begin(), w_pit.end()); pgrp.insert(pgrp.end(), w_pgrp.begin(), w_pgrp.end());
 		pslot0.insert(pslot0.end(), w_pslot0.begin(), w_pslot0.end());
@@ -551,6 +568,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		}
 		el_off.push_back(ae);
 		lme_elpos.insert(lme_elpos.end(), w_elpos.begin(), w_elpos.end());
+		for (int m = 0; m < n_lme; ++m) w_inc_rec[m].z = w_elpos[m];
+		inc_rec.insert(inc_rec.end(), w_inc_rec.begin(), w_inc_rec.end());
 	}
 
 	ssk_lm_batch* b = new ssk_lm_batch();
@@ -568,8 +587,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	UP(el_off, el_off); UP(el_idx, el_idx);
 	UP(qp_q, qp_q); UP(pchunk, pchunk); UP(pc_off, pc_off); UP(schunk, schunk); UP(sc_off, sc_off);
 	UP(pose, pose0); UP(lm, lm0);
-	UP(tiles, tile); UP(tl_slot, tl_slot); UP(tl_obs_off, tl_obs_off); UP(tobs_a, tobs_a); UP(tobs_px, tobs_px);
-	UP(inc_lml, inc_lml); UP(lmep_loc, lmep_loc);
+	UP(tiles, tile); UP(tl_rec, tl_rec); UP(tobs_a, tobs_a); UP(tobs_px, tobs_px);
+	UP(inc_rec, inc_rec); UP(lmep_loc, lmep_loc);
 	UP(pit, pit); UP(pgrp, pgrp); UP(pslot0, pslot0); UP(pcl_off, pcl_off); UP(pcl_idx, pcl_idx);
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
 #undef UP

@@ -29,7 +29,8 @@ struct lm_win {
 	int ls0;       // optimised-landmark slots: slot_lm[], Hff x9, Vinv x9, gf x3, df x3
 	int lso0;      // per optimised landmark offset tables (L+1): lmo_off[], lsm_off[]
 	int lmo0;      // lmo_idx[]  (observations of an optimised landmark)
-	int lme0;      // lme entries: lme_edge[], lme_ls[], lme_elpos[], Wb x18, Tb x18, gpe x6
+	int lme0;      // lme entries: lme_edge[], lme_ls[], lme_elpos[], Wb x18, Tb x18, gpe x6; tiled kernel: inc_rec[] =
+	               // (tile-local landmark | optimised << 15 | #path entries << 16, first lmep entry, edge-major slot, first lmep_loc)
 	int lmeo0;     // lmep_off[] (n_lme+1)
 	int lmep0;     // lmep_idx[] path entries of an lme entry
 	int pair0;     // block pairs e<=e': pair_ee[]
@@ -44,7 +45,7 @@ struct lm_win {
 	int trace0;    // trace entries (window * max_iters)
 	// ---- LDS-tiled kernel (ssk_lm_tiled.hip); n_tiles < 0: the window does not fit that kernel ----
 	int n_tiles, tile0;   // tile[]
-	int tl0, tlo0;        // tile landmarks (tile order): tl_slot[]; tl_obs_off[] (n_tl + 1 per window, indices into tobs)
+	int tl0;              // tile landmarks (tile order): tl_rec[] = (optimised slot or -1, first tile-local observation, end, 0)
 	int tobs0;            // packed observation records tobs_a[], tobs_px[]: tile order, then the observations outside every tile (n_obs in all)
 	int pit0, pg0, pcx0, ps0, pcl0;   // H_pp items pit[], lane groups pgrp[], chunk slot bases pslot0[], partial slots Ppart2 x36, pcl_idx[]
 	int qit0, sg0, scx0, ss0, scl0;   // Schur items qit[], lane groups sgrp[], sslot0[], Spart2 x36, scl_idx[]
@@ -71,8 +72,8 @@ struct lm_tile {
 
 struct lm_dev {
 	const lm_win* win;
-	const lm_tile* tile; const int* tl_slot; const int* tl_obs_off; const int4* tobs_a; const float4* tobs_px;
-	const int* inc_lml; const int* lmep_loc;
+	const lm_tile* tile; const int4* tl_rec; const int4* tobs_a; const float4* tobs_px;
+	const int4* inc_rec; const int* lmep_loc;
 	const int* pit; const int2* pgrp; const int* pslot0; const int* pcl_off; const int* pcl_idx;
 	const int* qit; const int2* sgrp; const int* sslot0; const int* scl_off; const int* scl_idx;
 	double* Ppart2; double* Spart2;

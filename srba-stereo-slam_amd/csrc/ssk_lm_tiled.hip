@@ -46,15 +46,20 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 
 // Sum of 36-vectors over the lanes of a wave BY SEGMENT, in lane order.  Lanes are sorted by key; a segment starts
 // at every key change and at lanes 0/16/32/48.  Four passes of 9 values through the wave's LDS scratch (row pitch
-// 9): every lane writes its row, then lanes c < 9 of each 16-lane group walk the 16 rows of their group and store
-// a segment's sum to part[36 * (slot0 + segment)] when the next one starts.
+// 9): every lane writes its row; lanes c < 9 of each 16-lane group turn the 16 rows of their group into running
+// sums that restart at segment heads (in place); the last lane of every segment then holds the segment's sum in
+// its own row and stores it to part[36 * (slot0 + segment)].
 __device__ __forceinline__ void wave_seg_sum36(const double (&acc)[36], int key, double* red, int lane, double* __restrict__ part, int slot0)
 {
 	const int prev = __shfl_up(key, 1, 64);
 	const bool head = (lane & 15) == 0 || key != prev;
 	const unsigned long long hm = __ballot(head);
+	const bool tail = (lane & 15) == 15 || ((hm >> ((lane + 1) & 63)) & 1ull);
+	const int seg = __popcll(hm & ((2ull << lane) - 1ull)) - 1;
+	double* out = part + 36 * (size_t)(slot0 + seg);
 	const int grp = lane >> 4, c = lane & 15;
-	const int seg_base = grp == 0 ? 0 : __popcll(hm & ((1ull << (16 * grp)) - 1ull));
+	const unsigned hrow = (unsigned)(hm >> (16 * grp)) & 0xFFFFu;
+	double* col = red + 16 * grp * RED_P + c;
 #pragma unroll
 	for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -62,20 +67,77 @@ __device__ __forceinline__ void wave_seg_sum36(const double (&acc)[36], int key,
 		WAVE_SYNC();
 		if (c < 9) {
 			double s = 0.0;
-			int seg = seg_base - 1;
 #pragma unroll
 			for (int r = 0; r < 16; ++r) {
-				const int row = 16 * grp + r;
-				const double v = red[row * RED_P + c];
-				if ((hm >> row) & 1ull) {
-					if (r > 0) part[36 * (size_t)(slot0 + seg) + 9 * h + c] = s;
-					s = 0.0; ++seg;
-				}
-				s += v;
+				const double v = col[r * RED_P];
+				s = ((hrow >> r) & 1u) ? v : s + v;
+				col[r * RED_P] = s;
 			}
-			part[36 * (size_t)(slot0 + seg) + 9 * h + c] = s;
 		}
 		WAVE_SYNC();
+		if (tail) {
+#pragma unroll
+			for (int i = 0; i < 9; ++i) out[9 * h + i] = red[lane * RED_P + i];
+		}
+		WAVE_SYNC();
+	}
+}
+
+// H_pp lane group: the 6x6 blocks Je_1^T Je_2 of `cnt` items (pairs of entry records), summed into acc.
+// block = [C, rows(C) x' q2 ; q1 x cols(C), q1 x cols(top right)] with C = A_1^T A_2 and u x' q = q x u
+__device__ __forceinline__ void pp_group(const double* __restrict__ ent, const int* __restrict__ items, int cnt, double (&acc)[36])
+{
+	int nxt = cnt > 0 ? items[0] : 0;
+	for (int k = 0; k < cnt; ++k) {
+		const int itv = nxt;
+		if (k + 1 < cnt) nxt = items[k + 1];              // next item id in flight during this item's arithmetic
+		const double* e1 = ent + ENT_P * (itv & 0xFFFF);
+		const double* e2 = ent + ENT_P * (itv >> 16);
+		double a1[12], a2[12], q1[3], q2[3], C[9], TR[9];
+#pragma unroll
+		for (int i = 0; i < 12; ++i) { a1[i] = e1[i]; a2[i] = e2[i]; }
+#pragma unroll
+		for (int i = 0; i < 3; ++i) { q1[i] = e1[12 + i]; q2[i] = e2[12 + i]; }
+#pragma unroll
+		for (int r = 0; r < 3; ++r)
+#pragma unroll
+			for (int c = 0; c < 3; ++c)
+				C[3 * r + c] = a1[r] * a2[c] + a1[3 + r] * a2[3 + c] + a1[6 + r] * a2[6 + c] + a1[9 + r] * a2[9 + c];
+#pragma unroll
+		for (int r = 0; r < 3; ++r) {
+			cross3(q2, C + 3 * r, TR + 3 * r);
+#pragma unroll
+			for (int c = 0; c < 3; ++c) { acc[6 * r + c] += C[3 * r + c]; acc[6 * r + 3 + c] += TR[3 * r + c]; }
+		}
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const double cc[3] = {C[c], C[3 + c], C[6 + c]}, tc[3] = {TR[c], TR[3 + c], TR[6 + c]};
+			double x[3], y[3];
+			cross3(q1, cc, x);
+			cross3(q1, tc, y);
+#pragma unroll
+			for (int r = 0; r < 3; ++r) { acc[6 * (3 + r) + c] += x[r]; acc[6 * (3 + r) + 3 + c] += y[r]; }
+		}
+	}
+}
+
+// Schur lane group: Y_1 Y_2^T of `cnt` items (pairs of incidence records), summed into acc
+__device__ __forceinline__ void schur_group(const double* __restrict__ Yr, const int* __restrict__ items, int cnt, double (&acc)[36])
+{
+	int nxt = cnt > 0 ? items[0] : 0;
+	for (int k = 0; k < cnt; ++k) {
+		const int itv = nxt;
+		if (k + 1 < cnt) nxt = items[k + 1];
+		const double* Y1 = Yr + Y_P * (itv & 0xFFFF);
+		const double* Y2 = Yr + Y_P * (itv >> 16);
+		double y1[18], y2[18];
+#pragma unroll
+		for (int i = 0; i < 18; ++i) { y1[i] = Y1[i]; y2[i] = Y2[i]; }
+#pragma unroll
+		for (int a = 0; a < 6; ++a)
+#pragma unroll
+			for (int b = 0; b < 6; ++b)
+				acc[6 * a + b] += y1[3 * a] * y2[3 * b] + y1[3 * a + 1] * y2[3 * b + 1] + y1[3 * a + 2] * y2[3 * b + 2];
 	}
 }
 
@@ -212,10 +274,12 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 	__shared__ double s_part[NW];
 	__shared__ double s_lambda, s_nu, s_err;
 	__shared__ int s_accept, s_stop, s_iters, s_accepted;
+	__shared__ int s_lmflag;                           // waves that have published their landmark records, all tiles so far
 
 	const lm_win W = D.win[blockIdx.x];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int n6 = 6 * W.E, np = n6 | 1;
+	int epoch = 0;                                     // tiles started so far
 	double* pose_cur = s_dyn;
 	double* pose_new = s_dyn + 12 * W.n_edges;
 	double* reg = s_dyn + 24 * W.n_edges;
@@ -244,7 +308,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 	__syncthreads();
 	const double e0 = total_error_packed(D, W, P, pose_cur, D.lm, s_part);
 	if (tid == 0) {
-		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0;
+		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_lmflag = 0;
 		ssk_lm_result& R = D.res[blockIdx.x];
 		R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
 	}
@@ -273,74 +337,21 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			double* Yr = obsr + obs_d;
 			double* lmr = Yr + Y_P * T.n_inc;
 			double* red = obsr + wave * RED_WAVE_D;
-			// ---- I1 ----
-			FTICK0();
+			++epoch;
+			// ---- I1: observations ----
 			for (int k = tid; k < T.n_obs; k += NT)
 				linearize_obs_lds(D, W, P, pose_cur, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
-			FTICK(0);
 			__syncthreads();
-			FTICK(1);
 			STAMP(1);
-			FTICK0();
-			// ---- I2 ----
-			double ge[6];
-			bool unk = false;
-			int lml = 0;
-#pragma unroll
-			for (int c = 0; c < 6; ++c) ge[c] = 0.0;
-			if (tid < T.n_inc) {
-				double Wm[18];
-#pragma unroll
-				for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
-				lml = D.inc_lml[W.lme0 + T.inc0 + tid];
-				unk = D.tl_slot[W.tl0 + T.lml0 + lml] >= 0;
-				const int k0 = D.lmep_off[W.lmeo0 + T.inc0 + tid], k1 = D.lmep_off[W.lmeo0 + T.inc0 + tid + 1];
-				for (int k = k0; k < k1; ++k) {
-					const int loc = D.lmep_loc[W.lmep0 + k];
-					const double* er = ent + ENT_P * (loc & 0xFFFF);
-					const double* orr = obsr + OBS_P * (loc >> 16);
-					double a[12], q[3], rr[4], tv[3], x[3];
-#pragma unroll
-					for (int c = 0; c < 12; ++c) a[c] = er[c];
-#pragma unroll
-					for (int c = 0; c < 3; ++c) q[c] = er[12 + c];
-#pragma unroll
-					for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
-#pragma unroll
-					for (int c = 0; c < 3; ++c) tv[c] = a[c] * rr[0] + a[3 + c] * rr[1] + a[6 + c] * rr[2] + a[9 + c] * rr[3];
-					cross3(q, tv, x);
-#pragma unroll
-					for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
-					if (unk) {
-						double jf[12];
-#pragma unroll
-						for (int c = 0; c < 12; ++c) jf[c] = orr[c];
-#pragma unroll
-						for (int b = 0; b < 3; ++b) {
-							double cb[3];
-#pragma unroll
-							for (int c = 0; c < 3; ++c) cb[c] = a[c] * jf[b] + a[3 + c] * jf[3 + b] + a[6 + c] * jf[6 + b] + a[9 + c] * jf[9 + b];
-							cross3(q, cb, x);
-#pragma unroll
-							for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
-						}
-					}
-				}
-				if (unk) {                                 // W waits in the incidence's Y record for L^-1 (next interval)
-					double* yl = Yr + Y_P * tid;
-#pragma unroll
-					for (int c = 0; c < 18; ++c) yl[c] = Wm[c];
-				}
-			}
-			FTICK(2);
+			// ---- I2: landmark lanes (top of the workgroup) first: V, g_f, Cholesky -> lmr; every wave then signals ----
 			{
 				const int j = NT - 1 - tid;
 				if (j < T.n_lm) {
-					const int slot = D.tl_slot[W.tl0 + T.lml0 + j];
+					const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
+					const int slot = lrec.x;
 					if (slot >= 0) {
-						const int o0 = D.tl_obs_off[W.tlo0 + T.lml0 + j] - T.obs0, o1 = D.tl_obs_off[W.tlo0 + T.lml0 + j + 1] - T.obs0;
 						double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
-						for (int k = o0; k < o1; ++k) {
+						for (int k = lrec.y; k < lrec.z; ++k) {
 							const double* orr = obsr + OBS_P * k;
 							double jf[12], rr[4];
 #pragma unroll
@@ -379,29 +390,64 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 					}
 				}
 			}
-			__syncthreads();
-			FTICK(3);
-			STAMP(2);
-			FTICK0();
-			// ---- I3 ----
+			// this wave's landmark records are written (LDS operations of a wave retire in order): release them
+			if (lane == 0) __hip_atomic_fetch_add(&s_lmflag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			// ---- I2: incidence lanes: W and the gradient term in registers, then (once every landmark record of the tile
+			//      is there -- the landmark waves are long done) Y = W L^-T -> LDS, reduced gradient term -> HBM ----
 			if (!pre && tid < T.n_inc) {
-				const int mg = W.lme0 + T.inc0 + tid;
-				double* gr = D.gre + 6 * (size_t)(W.el0 + D.lme_elpos[mg]);
+				const int4 irec = D.inc_rec[W.lme0 + T.inc0 + tid];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
+				const int lml = irec.x & 0x7FFF, cnt = irec.x >> 16;
+				const bool unk = (irec.x >> 15) & 1;
+				double Wm[18], ge[6];
+#pragma unroll
+				for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
+#pragma unroll
+				for (int c = 0; c < 6; ++c) ge[c] = 0.0;
+				int nxt = irec.w;
+				for (int k = 0; k < cnt; ++k) {
+					const int loc = nxt;
+					if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + irec.y + k + 1];
+					const double* er = ent + ENT_P * (loc & 0xFFFF);
+					const double* orr = obsr + OBS_P * (loc >> 16);
+					double a[12], q[3], rr[4], tv[3], x[3];
+#pragma unroll
+					for (int c = 0; c < 12; ++c) a[c] = er[c];
+#pragma unroll
+					for (int c = 0; c < 3; ++c) q[c] = er[12 + c];
+#pragma unroll
+					for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
+#pragma unroll
+					for (int c = 0; c < 3; ++c) tv[c] = a[c] * rr[0] + a[3 + c] * rr[1] + a[6 + c] * rr[2] + a[9 + c] * rr[3];
+					cross3(q, tv, x);
+#pragma unroll
+					for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
+					if (unk) {
+						double jf[12];
+#pragma unroll
+						for (int c = 0; c < 12; ++c) jf[c] = orr[c];
+#pragma unroll
+						for (int b = 0; b < 3; ++b) {
+							double cb[3];
+#pragma unroll
+							for (int c = 0; c < 3; ++c) cb[c] = a[c] * jf[b] + a[3 + c] * jf[3 + b] + a[6 + c] * jf[6 + b] + a[9 + c] * jf[9 + b];
+							cross3(q, cb, x);
+#pragma unroll
+							for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
+						}
+					}
+				}
+				double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
 				if (unk) {
+					while (__hip_atomic_load(&s_lmflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * epoch) __builtin_amdgcn_s_sleep(1);
 					const double* lr = lmr + LMR_P * lml;
 					const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
 					double* yl = Yr + Y_P * tid;
-					double* yg = D.Tb + 18 * (size_t)mg;
-					double Wm[18];
-#pragma unroll
-					for (int c = 0; c < 18; ++c) Wm[c] = yl[c];
 #pragma unroll
 					for (int a = 0; a < 6; ++a) {
 						const double y0 = Wm[3 * a] * i00;
 						const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
 						const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
 						yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
-						yg[3 * a] = y0; yg[3 * a + 1] = y1; yg[3 * a + 2] = y2;
 						gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
 					}
 				} else {
@@ -409,83 +455,34 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 					for (int a = 0; a < 6; ++a) gr[a] = ge[a];
 				}
 			}
-			FTICK(4);
-			for (int c = wave; c < T.n_pc; c += NW) {
-				const int g = 64 * c + lane;
-				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
-				const int cnt = g < T.n_pg ? (rec.y & 255) : 0, key = rec.y >> 8;
+			__syncthreads();
+			STAMP(2);
+			// ---- I3: Y to HBM for the back-substitution (coalesced), then one chunk task per wave and round:
+			//      H_pp chunks read the entry records, Schur chunks the Y records; both reduce through the scratch
+			//      over the (dead) observation records ----
+			if (!pre) {
+				double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
+				for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
+			}
+			const int n_task = T.n_pc + (pre ? 0 : T.n_sc);
+			for (int task = wave; task < n_task; task += NW) {
 				double acc[36];
 #pragma unroll
 				for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-				int nxt = cnt > 0 ? D.pit[W.pit0 + rec.x] : 0;
-				for (int k = 0; k < cnt; ++k) {
-					const int itv = nxt;
-					if (k + 1 < cnt) nxt = D.pit[W.pit0 + rec.x + k + 1];    // next item id in flight during this item's arithmetic
-					const double* e1 = ent + ENT_P * (itv & 0xFFFF);
-					const double* e2 = ent + ENT_P * (itv >> 16);
-					double a1[12], a2[12], q1[3], q2[3], C[9];
-#pragma unroll
-					for (int i = 0; i < 12; ++i) { a1[i] = e1[i]; a2[i] = e2[i]; }
-#pragma unroll
-					for (int i = 0; i < 3; ++i) { q1[i] = e1[12 + i]; q2[i] = e2[12 + i]; }
-#pragma unroll
-					for (int r = 0; r < 3; ++r)
-#pragma unroll
-						for (int s = 0; s < 3; ++s)
-							C[3 * r + s] = a1[r] * a2[s] + a1[3 + r] * a2[3 + s] + a1[6 + r] * a2[6 + s] + a1[9 + r] * a2[9 + s];
-					// block = [C, rows(C) x' q2 ; q1 x cols(C), q1 x (cols of the top right)]  with u x' q = q x u
-					double TR[9];
-#pragma unroll
-					for (int r = 0; r < 3; ++r) {
-						cross3(q2, C + 3 * r, TR + 3 * r);
-#pragma unroll
-						for (int s = 0; s < 3; ++s) { acc[6 * r + s] += C[3 * r + s]; acc[6 * r + 3 + s] += TR[3 * r + s]; }
-					}
-#pragma unroll
-					for (int s = 0; s < 3; ++s) {
-						const double cc[3] = {C[s], C[3 + s], C[6 + s]}, tc[3] = {TR[s], TR[3 + s], TR[6 + s]};
-						double x[3], y[3];
-						cross3(q1, cc, x);
-						cross3(q1, tc, y);
-#pragma unroll
-						for (int r = 0; r < 3; ++r) { acc[6 * (3 + r) + s] += x[r]; acc[6 * (3 + r) + 3 + s] += y[r]; }
-					}
+				if (task < T.n_pc) {
+					const int g = 64 * task + lane;
+					const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
+					pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
+					wave_seg_sum36(acc, rec.y >> 8, red, lane, Pp, D.pslot0[W.pcx0 + T.pc0 + task]);
+				} else {
+					const int c = task - T.n_pc, g = 64 * c + lane;
+					const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
+					schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
+					wave_seg_sum36(acc, rec.y >> 8, red, lane, Sp, D.sslot0[W.scx0 + T.sc0 + c]);
 				}
-				FTICK(5);
-				wave_seg_sum36(acc, key, red, lane, Pp, D.pslot0[W.pcx0 + T.pc0 + c]);
-				FTICK(6);
 			}
 			__syncthreads();
-			FTICK(7);
 			STAMP(3);
-			// ---- I4 ----
-			if (!pre)
-				for (int c = wave; c < T.n_sc; c += NW) {
-					const int g = 64 * c + lane;
-					const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
-					const int cnt = g < T.n_sg ? (rec.y & 255) : 0, key = rec.y >> 8;
-					double acc[36];
-#pragma unroll
-					for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-					int nxt = cnt > 0 ? D.qit[W.qit0 + rec.x] : 0;
-					for (int k = 0; k < cnt; ++k) {
-						const int itv = nxt;
-						if (k + 1 < cnt) nxt = D.qit[W.qit0 + rec.x + k + 1];
-						const double* Y1 = Yr + Y_P * (itv & 0xFFFF);
-						const double* Y2 = Yr + Y_P * (itv >> 16);
-						double y1[18], y2[18];
-#pragma unroll
-						for (int i = 0; i < 18; ++i) { y1[i] = Y1[i]; y2[i] = Y2[i]; }
-#pragma unroll
-						for (int a = 0; a < 6; ++a)
-#pragma unroll
-							for (int b = 0; b < 6; ++b)
-								acc[6 * a + b] += y1[3 * a] * y2[3 * b] + y1[3 * a + 1] * y2[3 * b + 1] + y1[3 * a + 2] * y2[3 * b + 2];
-					}
-					wave_seg_sum36(acc, key, red, lane, Sp, D.sslot0[W.scx0 + T.sc0 + c]);
-				}
-			__syncthreads();
-			STAMP(4);
 		}
 		if (pre) {
 			// lambda0 = tau * max diag(H): the diagonal blocks' slot sums, and the landmark blocks' diagonals
@@ -633,8 +630,6 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			{
 			printf("LMT stamps (cycles, window 0, %d iters, %d tiles): top %llu I1 %llu I2 %llu I3 %llu I4 %llu F2 %llu G %llu H %llu I+dec %llu\n", s_iters, W.n_tiles,
 			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
-			printf("LMT fine (wave 0): I1 work %llu wait %llu | I2 inc %llu lm+wait %llu | I3 Y %llu items %llu segsum %llu wait %llu\n",
-			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[4], s_fine[5], s_fine[6], s_fine[7]);
 			}
 #endif
 	}
