@@ -481,11 +481,15 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 					w_tobs_a.push_back(pack_obs(o, (Wn.obs_path_off[o + 1] - Wn.obs_path_off[o]) << 24));
 					w_tobs_px.push_back(make_float4(Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]));
 				}
+			// final slot ids are block-major, so a block's partial sums are one contiguous run [pcl_off[pid], pcl_off[pid+1]);
+			// pcl_idx / scl_idx map a chunk segment (generation order) to its slot
+			w_pcl_idx.assign((size_t)n_pslots, 0); w_scl_idx.assign((size_t)n_sslots, 0);
+			int np_ = 0, ns_ = 0;
 			for (int p2 = 0; p2 < n_pairs; ++p2) {
-				w_pcl_off[p2] = (int)w_pcl_idx.size(); w_pcl_idx.insert(w_pcl_idx.end(), pslots_of[p2].begin(), pslots_of[p2].end());
-				w_scl_off[p2] = (int)w_scl_idx.size(); w_scl_idx.insert(w_scl_idx.end(), sslots_of[p2].begin(), sslots_of[p2].end());
+				w_pcl_off[p2] = np_; for (int sl : pslots_of[p2]) w_pcl_idx[sl] = np_++;
+				w_scl_off[p2] = ns_; for (int sl : sslots_of[p2]) w_scl_idx[sl] = ns_++;
 			}
-			w_pcl_off[n_pairs] = (int)w_pcl_idx.size(); w_scl_off[n_pairs] = (int)w_scl_idx.size();
+			w_pcl_off[n_pairs] = np_; w_scl_off[n_pairs] = ns_;
 			tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(6 * E + 1) * ((6 * E) | 1) * 8);
 		}
 		if (!tiled) tiled_all = false;

@@ -58,8 +58,8 @@ struct lm_win {
 // 17 per observation (Jf 4x3, w r), 19 per (landmark, edge) incidence (Y = W L^-T 6x3), 9 per landmark (L^-1, c).
 // Reductions over the items of a tile: every lane owns a GROUP of <= R consecutive items of ONE block (items are
 // sorted by block pair id), 64 groups form a chunk (one wave pass), a chunk's segments (runs of equal block id,
-// also cut every 16 lanes) are summed in lane order into consecutive 36-double partial slots starting at
-// pslot0[chunk]; pcl lists the slots of a block in ascending order for the final sum.
+// also cut every 16 lanes) are summed in lane order into 36-double partial slots: segment s of the chunk goes to slot
+// pcl_idx[pslot0[chunk] + s]; slot ids are block-major, block pid owns slots pcl_off[pid] .. pcl_off[pid+1].
 struct lm_tile {
 	int lml0, n_lm;       // tile landmarks tl_*[W.tl0 + lml0 ..)
 	int obs0, n_obs;      // tile observations tobs_*[W.tobs0 + obs0 ..)

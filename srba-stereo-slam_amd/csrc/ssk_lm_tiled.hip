@@ -48,15 +48,15 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 // at every key change and at lanes 0/16/32/48.  Four passes of 9 values through the wave's LDS scratch (row pitch
 // 9): every lane writes its row; lanes c < 9 of each 16-lane group turn the 16 rows of their group into running
 // sums that restart at segment heads (in place); the last lane of every segment then holds the segment's sum in
-// its own row and stores it to part[36 * (slot0 + segment)].
-__device__ __forceinline__ void wave_seg_sum36(const double (&acc)[36], int key, double* red, int lane, double* __restrict__ part, int slot0)
+// its own row and stores it to part[36 * segslot[segment]].
+__device__ __forceinline__ void wave_seg_sum36(const double (&acc)[36], int key, double* red, int lane, double* __restrict__ part, const int* __restrict__ segslot)
 {
 	const int prev = __shfl_up(key, 1, 64);
 	const bool head = (lane & 15) == 0 || key != prev;
 	const unsigned long long hm = __ballot(head);
 	const bool tail = (lane & 15) == 15 || ((hm >> ((lane + 1) & 63)) & 1ull);
 	const int seg = __popcll(hm & ((2ull << lane) - 1ull)) - 1;
-	double* out = part + 36 * (size_t)(slot0 + seg);
+	double* out = part + 36 * (size_t)segslot[seg];
 	const int grp = lane >> 4, c = lane & 15;
 	const unsigned hrow = (unsigned)(hm >> (16 * grp)) & 0xFFFFu;
 	double* col = red + 16 * grp * RED_P + c;
@@ -141,6 +141,37 @@ __device__ __forceinline__ void schur_group(const double* __restrict__ Yr, const
 	}
 }
 
+// 1/sqrt(x), x > 0, to ~1 ulp: hardware estimate + two Newton steps (no IEEE sqrt / divide sequence)
+__device__ __forceinline__ double rsq_f64(double x)
+{
+	double y = __builtin_amdgcn_rsq(x);
+	const double hx = 0.5 * x;
+	y = y * (1.5 - hx * y * y);
+	y = y * (1.5 - hx * y * y);
+	return y;
+}
+
+// One step of the SE(3) chain without a branch on the direction: dir 0: t = R q + tr, dir 1: t = R^T (q - tr).
+// R(i,j) of the step sits at T[si * i + sj * j] with (si, sj) = (4, 1) or (1, 4).
+__device__ __forceinline__ void se3_step(const double* T, int dir, const double* q, double* t)
+{
+	const int si = dir ? 1 : 4, sj = dir ? 4 : 1;
+	const double tr[3] = {T[3], T[7], T[11]};
+	const double d0 = dir ? q[0] - tr[0] : q[0], d1 = dir ? q[1] - tr[1] : q[1], d2 = dir ? q[2] - tr[2] : q[2];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) t[i] = T[si * i] * d0 + T[si * i + sj] * d1 + T[si * i + 2 * sj] * d2 + (dir ? 0.0 : tr[i]);
+}
+
+// stereo projection with the reciprocal depth by Newton iteration
+__device__ __forceinline__ void project_fast(const lm_cam& P, const double* pc, double* h)
+{
+	const double iz = rcp_f64(pc[2]);
+	h[0] = P.cx_l + P.fx_l * pc[0] * iz;
+	h[1] = P.cy_l + P.fy_l * pc[1] * iz;
+	h[2] = P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz;
+	h[3] = P.cy_r + P.fy_r * pc[1] * iz;
+}
+
 // Robustified squared error of a packed observation record (pose: window-relative poses, lm: the window's landmarks)
 __device__ __forceinline__ double obs_error_packed(const lm_cam& P, const double* pose, const double* __restrict__ lm, const int4 rec, const float4 px)
 {
@@ -151,16 +182,17 @@ __device__ __forceinline__ double obs_error_packed(const lm_cam& P, const double
 	q[0] = f[0]; q[1] = f[1]; q[2] = f[2];
 	for (int i = n - 1; i >= 0; --i) {
 		const int c = (int)(codes >> (8 * i)) & 255;
-		const double* T = pose + 12 * (c >> 1);
-		if ((c & 1) == 0) se3_apply(T, q, t); else se3_apply_inv(T, q, t);
+		se3_step(pose + 12 * (c >> 1), c & 1, q, t);
 		q[0] = t[0]; q[1] = t[1]; q[2] = t[2];
 	}
 	double pc[3], h[4];
 	se3_apply_inv(P.S, q, pc);
-	project(P, pc, h);
+	project_fast(P, pc, h);
 	const double r0 = (double)px.x - h[0], r1 = (double)px.y - h[1], r2 = (double)px.z - h[2], r3 = (double)px.w - h[3];
 	const double s2 = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
-	return P.robust ? huber_rho(s2, P.kernel) : s2;
+	if (!P.robust) return s2;
+	const double k2 = P.kernel * P.kernel, u = 1.0 + s2 * rcp_f64(k2);          // rho = 2 k^2 (sqrt(1 + s2/k^2) - 1)
+	return 2.0 * k2 * (u * rsq_f64(u) - 1.0);
 }
 
 __device__ double total_error_packed(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const double* lm, double* s_part)
@@ -170,18 +202,15 @@ __device__ double total_error_packed(const lm_dev& D, const lm_win& W, const lm_
 	return block_sum(e, s_part);
 }
 
-// Sum of component ab over the partial slots idx[k0..k1) in list order; the slot ids and then the values are loaded
-// eight at a time (independent loads in flight), padding adds +0.0.
-__device__ __forceinline__ double slot_sum(const double* __restrict__ part, const int* __restrict__ idx, int k0, int k1, int ab)
+// Sum of component ab over the contiguous partial slots k0..k1-1 in order, eight independent loads in flight;
+// padding adds +0.0.
+__device__ __forceinline__ double slot_sum(const double* __restrict__ part, int k0, int k1, int ab)
 {
 	double s = 0.0;
 	for (int k = k0; k < k1; k += 8) {
-		int id[8];
 		double v[8];
 #pragma unroll
-		for (int u = 0; u < 8; ++u) id[u] = k + u < k1 ? idx[k + u] : -1;
-#pragma unroll
-		for (int u = 0; u < 8; ++u) v[u] = id[u] >= 0 ? part[36 * (size_t)id[u] + ab] : 0.0;
+		for (int u = 0; u < 8; ++u) v[u] = k + u < k1 ? part[36 * (size_t)(k + u) + ab] : 0.0;
 #pragma unroll
 		for (int u = 0; u < 8; ++u) s += v[u];
 	}
@@ -203,32 +232,38 @@ __device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam
 	// dir 0 -> q_i (after the step), dir 1 -> q_{i+1} (before it)
 	for (int i = n - 1; i >= 0; --i) {
 		const int c = (int)(codes >> (8 * i)) & 255;
-		const double* T = pose + 12 * (c >> 1);
-		const bool opt = (om >> i) & 1;
-		double* eq = ent + ENT_P * (e0 + __popc(om & ((1 << i) - 1))) + 12;
-		if ((c & 1) == 0) { se3_apply(T, q, t); if (opt) { eq[0] = t[0]; eq[1] = t[1]; eq[2] = t[2]; } }
-		else { if (opt) { eq[0] = q[0]; eq[1] = q[1]; eq[2] = q[2]; } se3_apply_inv(T, q, t); }
+		const int dir = c & 1;
+		se3_step(pose + 12 * (c >> 1), dir, q, t);
+		if ((om >> i) & 1) {
+			double* eq = ent + ENT_P * (e0 + __popc(om & ((1 << i) - 1))) + 12;
+			eq[0] = dir ? q[0] : t[0]; eq[1] = dir ? q[1] : t[1]; eq[2] = dir ? q[2] : t[2];
+		}
 		q[0] = t[0]; q[1] = t[1]; q[2] = t[2];
 	}
 	double pc[3], h[4], r[4];
 	se3_apply_inv(P.S, q, pc);
-	project(P, pc, h);
+	const double iz = rcp_f64(pc[2]), iz2 = iz * iz;
+	h[0] = P.cx_l + P.fx_l * pc[0] * iz;
+	h[1] = P.cy_l + P.fy_l * pc[1] * iz;
+	h[2] = P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz;
+	h[3] = P.cy_r + P.fy_r * pc[1] * iz;
 	const float z[4] = {px.x, px.y, px.z, px.w};
 	double s2 = 0;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) { r[k] = (double)z[k] - h[k]; s2 += r[k] * r[k]; }
-	const double w = P.robust ? sqrt(1.0 / sqrt(1.0 + s2 / (P.kernel * P.kernel))) : 1.0;
-	const double iz = 1.0 / pc[2], iz2 = iz * iz;
-	const double Dm[12] = {P.fx_l * iz, 0, -P.fx_l * pc[0] * iz2,
-	                       0, P.fy_l * iz, -P.fy_l * pc[1] * iz2,
-	                       P.fx_r * iz, 0, -P.fx_r * (pc[0] - P.baseline) * iz2,
-	                       0, P.fy_r * iz, -P.fy_r * pc[1] * iz2};
-	double M[12];     // D * R_S^T
+	double w = 1.0;                                     // IRLS weight sqrt(rho'(s)/2s) = (1 + s2/k^2)^(-1/4)
+	if (P.robust) { const double rs = rsq_f64(1.0 + s2 * rcp_f64(P.kernel * P.kernel)); w = rs * rsq_f64(rs); }
+	// M = D R_S^T with the structural zeros of the projection Jacobian D (rows: d(u_l, v_l, u_r, v_r)/d(x, y, z))
+	const double dxl = P.fx_l * iz, dzl = -P.fx_l * pc[0] * iz2, dyl = P.fy_l * iz, dwl = -P.fy_l * pc[1] * iz2;
+	const double dxr = P.fx_r * iz, dzr = -P.fx_r * (pc[0] - P.baseline) * iz2, dyr = P.fy_r * iz, dwr = -P.fy_r * pc[1] * iz2;
+	double M[12];
 #pragma unroll
-	for (int i = 0; i < 4; ++i)
-#pragma unroll
-		for (int j = 0; j < 3; ++j)
-			M[3 * i + j] = Dm[3 * i] * P.S[4 * j] + Dm[3 * i + 1] * P.S[4 * j + 1] + Dm[3 * i + 2] * P.S[4 * j + 2];
+	for (int j = 0; j < 3; ++j) {
+		M[j] = dxl * P.S[4 * j] + dzl * P.S[4 * j + 2];
+		M[3 + j] = dyl * P.S[4 * j + 1] + dwl * P.S[4 * j + 2];
+		M[6 + j] = dxr * P.S[4 * j] + dzr * P.S[4 * j + 2];
+		M[9 + j] = dyr * P.S[4 * j + 1] + dwr * P.S[4 * j + 2];
+	}
 #pragma unroll
 	for (int k = 0; k < 4; ++k) orec[12 + k] = w * r[k];
 	// forward pass: RA = product of the step rotations so far
@@ -237,13 +272,16 @@ __device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam
 		const int c = (int)(codes >> (8 * i)) & 255;
 		const int dir = c & 1;
 		const double* T = pose + 12 * (c >> 1);
-		double RN[9];
+		const int sk = dir ? 1 : 4, sb = dir ? 4 : 1;    // (R or R^T)(k,b) = T[sk * k + sb * b]
+		double Rs[9], RN[9];
+#pragma unroll
+		for (int k = 0; k < 3; ++k)
+#pragma unroll
+			for (int b = 0; b < 3; ++b) Rs[3 * k + b] = T[sk * k + sb * b];
 #pragma unroll
 		for (int a = 0; a < 3; ++a)
 #pragma unroll
-			for (int b = 0; b < 3; ++b)
-				RN[3 * a + b] = dir == 0 ? RA[3 * a] * T[b] + RA[3 * a + 1] * T[4 + b] + RA[3 * a + 2] * T[8 + b]
-				                         : RA[3 * a] * T[4 * b] + RA[3 * a + 1] * T[4 * b + 1] + RA[3 * a + 2] * T[4 * b + 2];
+			for (int b = 0; b < 3; ++b) RN[3 * a + b] = RA[3 * a] * Rs[b] + RA[3 * a + 1] * Rs[3 + b] + RA[3 * a + 2] * Rs[6 + b];
 		if ((om >> i) & 1) {
 			const double* RR = dir == 0 ? RA : RN;
 			const double sg = dir == 0 ? w : -w;
@@ -375,11 +413,11 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 							Hm[0] = v00; Hm[1] = v01; Hm[2] = v02; Hm[3] = v01; Hm[4] = v11; Hm[5] = v12; Hm[6] = v02; Hm[7] = v12; Hm[8] = v22;
 							double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
 							gl[0] = g0; gl[1] = g1; gl[2] = g2;
-							const double l00 = sqrt(v00 + lambda), i00 = 1.0 / l00;
+							const double i00 = rsq_f64(v00 + lambda);         // 1 / L_kk straight from the reciprocal square root
 							const double l10 = v01 * i00, l20 = v02 * i00;
-							const double l11 = sqrt(v11 + lambda - l10 * l10), i11 = 1.0 / l11;
+							const double i11 = rsq_f64(v11 + lambda - l10 * l10);
 							const double l21 = (v12 - l20 * l10) * i11;
-							const double l22 = sqrt(v22 + lambda - l20 * l20 - l21 * l21), i22 = 1.0 / l22;
+							const double i22 = rsq_f64(v22 + lambda - l20 * l20 - l21 * l21);
 							const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
 							const double rec[9] = {i00, i10, i11, i20, i21, i22, i00 * g0, i10 * g0 + i11 * g1, i20 * g0 + i21 * g1 + i22 * g2};
 							double* lr = lmr + LMR_P * j;
@@ -473,12 +511,12 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 					const int g = 64 * task + lane;
 					const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
 					pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
-					wave_seg_sum36(acc, rec.y >> 8, red, lane, Pp, D.pslot0[W.pcx0 + T.pc0 + task]);
+					wave_seg_sum36(acc, rec.y >> 8, red, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
 				} else {
 					const int c = task - T.n_pc, g = 64 * c + lane;
 					const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
 					schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
-					wave_seg_sum36(acc, rec.y >> 8, red, lane, Sp, D.sslot0[W.scx0 + T.sc0 + c]);
+					wave_seg_sum36(acc, rec.y >> 8, red, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
 				}
 			}
 			__syncthreads();
@@ -489,7 +527,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			double mx = vmax;
 			for (int it = tid; it < n6; it += NT) {
 				const int e = it / 6, a = it - 6 * e, pid = e * (e + 1) / 2 + e;
-				mx = fmax(mx, slot_sum(Pp, D.pcl_idx + W.pcl0, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], 7 * a));
+				mx = fmax(mx, slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], 7 * a));
 			}
 			mx = block_max(mx, s_part);
 			if (tid == 0) s_lambda = P.tau * mx;
@@ -501,8 +539,8 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
 			const int2 ee = D.pair_ee[W.pair0 + pid];
 			if (ee.x == ee.y && a > b) continue;
-			const double p = slot_sum(Pp, D.pcl_idx + W.pcl0, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], ab);
-			const double sc = slot_sum(Sp, D.scl_idx + W.scl0, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
+			const double p = slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], ab);
+			const double sc = slot_sum(Sp, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
 			double sres = p - sc;
 			if (ee.x == ee.y && a == b) sres += lambda;
 			A[(6 * ee.x + a) * np + 6 * ee.y + b] = sres;
@@ -530,27 +568,38 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 		double dpn = 0, dfn = 0;
 		if (ok) {
 			for (int i = tid; i < n6; i += NT) { D.dp[6 * (size_t)W.us0 + i] = s_b[i]; dpn += s_b[i] * s_b[i]; }
-			// ---- H: landmarks, delta_f = L^-T (c - sum_e Y_e^T delta_e) ----
+			// ---- H: landmarks, delta_f = L^-T (c - sum_e Y_e^T delta_e).  First one lane per incidence (coalesced Y stream,
+			//      3-vector Y_m^T delta_e staged in the window's L2-resident scratch), then one lane per landmark ----
+			for (int m = tid; m < W.n_lme_unknown; m += NT) {
+				const double* Ym = D.Tb + 18 * (size_t)(W.lme0 + m);
+				const int e = D.lme_edge[W.lme0 + m];
+				double y[18], t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+				for (int c = 0; c < 18; ++c) y[c] = Ym[c];
+#pragma unroll
+				for (int a = 0; a < 6; ++a) { const double d = s_b[6 * e + a]; t0 += y[3 * a] * d; t1 += y[3 * a + 1] * d; t2 += y[3 * a + 2] * d; }
+				double* o = D.gpe + 6 * (size_t)(W.lme0 + m);
+				o[0] = t0; o[1] = t1; o[2] = t2;
+			}
+			__syncthreads();
 			for (int l = tid; l < W.L; l += NT) {
 				const double* lg = D.Vinv + 9 * (size_t)(W.ls0 + l);
-				double rhs[3] = {lg[6], lg[7], lg[8]};
+				double li[9];
+#pragma unroll
+				for (int c = 0; c < 9; ++c) li[c] = lg[c];
+				double rhs[3] = {li[6], li[7], li[8]};
 				const int m0 = D.lsm_off[W.lso0 + l], m1 = D.lsm_off[W.lso0 + l + 1];
 				for (int m = m0; m < m1; ++m) {
-					const double* Ym = D.Tb + 18 * (size_t)(W.lme0 + m);
-					const int e = D.lme_edge[W.lme0 + m];
-#pragma unroll
-					for (int a = 0; a < 6; ++a) {
-						const double d = s_b[6 * e + a];
-						rhs[0] -= Ym[3 * a] * d; rhs[1] -= Ym[3 * a + 1] * d; rhs[2] -= Ym[3 * a + 2] * d;
-					}
+					const double* o = D.gpe + 6 * (size_t)(W.lme0 + m);
+					rhs[0] -= o[0]; rhs[1] -= o[1]; rhs[2] -= o[2];
 				}
-				const double d3[3] = {lg[0] * rhs[0] + lg[1] * rhs[1] + lg[3] * rhs[2], lg[2] * rhs[1] + lg[4] * rhs[2], lg[5] * rhs[2]};
-				const int li = D.slot_lm[W.ls0 + l];
+				const double d3[3] = {li[0] * rhs[0] + li[1] * rhs[1] + li[3] * rhs[2], li[2] * rhs[1] + li[4] * rhs[2], li[5] * rhs[2]};
+				const int li_idx = D.slot_lm[W.ls0 + l];
 #pragma unroll
 				for (int a = 0; a < 3; ++a) {
 					D.df[3 * (size_t)(W.ls0 + l) + a] = d3[a];
 					dfn += d3[a] * d3[a];
-					D.lm_new[3 * (size_t)(W.lm0 + li) + a] = D.lm[3 * (size_t)(W.lm0 + li) + a] + d3[a];
+					D.lm_new[3 * (size_t)(W.lm0 + li_idx) + a] = D.lm[3 * (size_t)(W.lm0 + li_idx) + a] + d3[a];
 				}
 			}
 			// ---- H: edges, T_new = exp(eps) (+) T ----
