@@ -48,8 +48,8 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 // at every key change and at lanes 0/16/32/48.  Four passes of 9 values through the wave's LDS scratch (row pitch
 // 9): every lane writes its row; lanes c < 9 of each 16-lane group turn the 16 rows of their group into running
 // sums that restart at segment heads (in place); the last lane of every segment then holds the segment's sum in
-// its own row and stores it to part[36 * segslot[segment]].
-__device__ __forceinline__ void wave_seg_sum36(const double (&acc)[36], int key, double* red, int lane, double* __restrict__ part, const int* __restrict__ segslot)
+// its own row; after the four passes it stores the 36 sums to part[36 * segslot[segment]] in one burst.
+__device__ __forceinline__ void wave_seg_sum36(double (&acc)[36], int key, double* red, int lane, double* __restrict__ part, const int* __restrict__ segslot)
 {
 	const int prev = __shfl_up(key, 1, 64);
 	const bool head = (lane & 15) == 0 || key != prev;
@@ -75,11 +75,13 @@ __device__ __forceinline__ void wave_seg_sum36(const double (&acc)[36], int key,
 			}
 		}
 		WAVE_SYNC();
-		if (tail) {
 #pragma unroll
-			for (int i = 0; i < 9; ++i) out[9 * h + i] = red[lane * RED_P + i];
-		}
+		for (int i = 0; i < 9; ++i) acc[9 * h + i] = red[lane * RED_P + i];     // the lane's running sums (read back in place of its inputs)
 		WAVE_SYNC();
+	}
+	if (tail) {                                            // one burst of stores, nothing waits on it
+#pragma unroll
+		for (int i = 0; i < 36; ++i) out[i] = acc[i];
 	}
 }
 
@@ -330,8 +332,8 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 	__shared__ unsigned long long s_fine[16];
 	unsigned long long f_last = 0;
 	if (tid < 16) s_fine[tid] = 0;
-#define FTICK0() do { if (tid == 0) f_last = __builtin_amdgcn_s_memtime(); } while (0)
-#define FTICK(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_fine[i] += t_ - f_last; f_last = t_; } } while (0)
+#define FTICK0() do { if (tid == 0 || tid == 256) f_last = __builtin_amdgcn_s_memtime(); } while (0)
+#define FTICK(i) do { if (tid == 0 || tid == 256) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_fine[(tid == 0 ? 0 : 8) + i] += t_ - f_last; f_last = t_; } } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #define FTICK0() do {} while (0)
@@ -498,10 +500,12 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			// ---- I3: Y to HBM for the back-substitution (coalesced), then one chunk task per wave and round:
 			//      H_pp chunks read the entry records, Schur chunks the Y records; both reduce through the scratch
 			//      over the (dead) observation records ----
+			FTICK0();
 			if (!pre) {
 				double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
 				for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
 			}
+			FTICK(0);
 			const int n_task = T.n_pc + (pre ? 0 : T.n_sc);
 			for (int task = wave; task < n_task; task += NW) {
 				double acc[36];
@@ -511,15 +515,19 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 					const int g = 64 * task + lane;
 					const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
 					pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
+					FTICK(1);
 					wave_seg_sum36(acc, rec.y >> 8, red, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
 				} else {
 					const int c = task - T.n_pc, g = 64 * c + lane;
 					const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
 					schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
+					FTICK(1);
 					wave_seg_sum36(acc, rec.y >> 8, red, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
 				}
+				FTICK(2);
 			}
 			__syncthreads();
+			FTICK(3);
 			STAMP(3);
 		}
 		if (pre) {
@@ -679,6 +687,8 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			{
 			printf("LMT stamps (cycles, window 0, %d iters, %d tiles): top %llu I1 %llu I2 %llu I3 %llu I4 %llu F2 %llu G %llu H %llu I+dec %llu\n", s_iters, W.n_tiles,
 			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
+			printf("LMT fine I3: wave0 (H_pp task) copy %llu items %llu segsum %llu wait %llu | wave4 (Schur task) copy %llu items %llu segsum %llu wait %llu\n",
+			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[8], s_fine[9], s_fine[10], s_fine[11]);
 			}
 #endif
 	}
