@@ -7,10 +7,11 @@
 //     ALIGNED dword loads (12 per row; the image is L2/MALL resident after the scan kernel);
 //   * moments m10/m01 over the radius-15 disc: lanes own patch rows, wave shuffle reduction, integers;
 //   * angle = degree polynomial in IEEE float; steering (cos,sin) = (m10,m01)/hypot in double;
-//   * the 8.8 fixed-point 7x7 blur is done ONCE per patch and separably inside LDS: horizontal pass with a
-//     sliding window over 13-output row segments (u16 results), vertical pass over 13-output column segments
-//     (u8 results) -- ~75 LDS accesses per lane instead of 392 for blurring each of the 512 samples alone;
-//     no blurred image is ever materialised in HBM;
+//   * the 8.8 fixed-point 7x7 blur is done ONCE per patch and separably inside LDS, on packed data: the horizontal
+//     pass reads 6 dwords per 13-output row segment and forms each output with two v_dot4_u32_u8 (taps packed in
+//     a constant), the vertical pass reads 10 dwords of the transposed u16 tile and uses four v_dot2_u32_u16 per
+//     output (the kernel is VALU-issue bound: 8 keypoint waves per SIMD); no blurred image is ever materialised
+//     in HBM;
 //   * each lane evaluates 4 tests (8 samples), packs 4 bits, lanes exchange nibbles by shuffle, 32 lanes store
 //     one descriptor byte each.
 // Data: 2 KB patch read per keypoint, 32 B + 4 B written.  LDS/VALU bound.
@@ -22,7 +23,11 @@ constexpr int PR = 22;               // patch radius: 19 (rotated |(13,13)| roun
 constexpr int PD = 2 * PR + 1;       // 45
 constexpr int PP = 48;               // raw patch pitch in bytes (12 dwords); pixel c of a row sits at byte shift + c
 constexpr int BD = PD - 6;           // 39: blurred patch side
-constexpr int HP = 40;               // pitch (elements) of the horizontal-pass (u16) and blurred (u8) tiles
+constexpr int HT = 48;               // pitch (u16) of a COLUMN of the transposed horizontal-pass tile (45 rows used, dword aligned)
+constexpr int BT = 40;               // pitch (bytes) of a column of the transposed blurred tile (39 rows used)
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
@@ -54,9 +59,9 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
                      const short2* __restrict__ kp_xy, const int32_t* __restrict__ nkp,
                      const int8_t* __restrict__ pattern, float* __restrict__ kp_angle, uint8_t* __restrict__ desc)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t s_raw[PD * PP];
-	__shared__ uint16_t s_h[PD * HP];          // horizontal pass: rows 0..44, columns 3..41 of the patch
-	__shared__ uint8_t s_b[BD * HP];           // blurred patch: rows/columns 3..41
+	__shared__ __attribute__((aligned(16))) uint8_t s_raw[PD * PP + 16];   // + slack: the dword window of the last segment may run 1 dword past a row
+	__shared__ __attribute__((aligned(16))) uint16_t s_h[BD * HT + 8];     // horizontal pass, transposed: [column 3..41][row 0..44]
+	__shared__ uint8_t s_b[BD * BT];           // blurred patch, transposed: [column 3..41][row 3..41]
 	const int img = img_begin + blockIdx.y;
 	const int k = blockIdx.x;
 	if (k >= nkp[img]) return;
@@ -83,34 +88,54 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 		for (int u = -um; u <= um; ++u) { const int I = p[u]; m10 += u * I; rs += I; }
 		m01 = v * rs;
 	}
-	// horizontal blur pass: item = (row r, segment s of 13 outputs), sliding 7-tap window
+	// horizontal blur pass: item = (row r, segment s of 13 outputs).  The 19 input bytes come in as 6 dwords, are
+	// shifted to byte 0 once (v_alignbyte), and every output is two v_dot4_u32_u8 against the packed taps
+	// (18,34,49,55 | 49,34,18,0) of its realigned window; results (u16, <= 255*257) go out TRANSPOSED
+	// (column-major) so that the vertical pass reads its 19 inputs as contiguous u16 pairs.
 	for (int it = lane; it < PD * 3; it += 64) {
 		const int r = it / 3, s = it - 3 * r;
-		const uint8_t* p = s_raw + r * PP + shift + 13 * s;      // patch columns 13s .. 13s+18
-		uint16_t* o = s_h + r * HP + 13 * s;
-		int w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4], w5 = p[5];
+		const int b0 = shift + 13 * s;                           // first input byte of the segment inside the raw row
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(s_raw + r * PP) + (b0 >> 2);
+		const uint32_t sub = (uint32_t)(b0 & 3);
+		uint32_t D[6], E[5], L[17];
 #pragma unroll
-		for (int j = 0; j < 13; ++j) {
-			const int w6 = p[j + 6];
-			o[j] = (uint16_t)(18 * (w0 + w6) + 34 * (w1 + w5) + 49 * (w2 + w4) + 55 * w3);
-			w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6;
-		}
+		for (int k = 0; k < 6; ++k) D[k] = p[k];
+#pragma unroll
+		for (int k = 0; k < 5; ++k) E[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sub);
+#pragma unroll
+		for (int j = 0; j < 17; ++j) L[j] = (j & 3) == 0 ? E[j >> 2] : __builtin_amdgcn_alignbyte(E[(j >> 2) + 1], E[j >> 2], (uint32_t)(j & 3));
+		uint16_t* o = s_h + (13 * s) * HT + r;
+#pragma unroll
+		for (int j = 0; j < 13; ++j)
+			o[j * HT] = (uint16_t)__builtin_amdgcn_udot4(L[j], 0x37312212u, __builtin_amdgcn_udot4(L[j + 4], 0x00122231u, 0u, false), false);
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
 	__syncthreads();
-	// vertical pass: item = (column j, segment s of 13 outputs)
+	// vertical pass: item = (column j, segment s of 13 outputs): 19 contiguous u16 of the transposed tile as 10 dwords,
+	// shifted to an even start once; an output is four v_dot2_u32_u16 on the pairs of its window.  The blurred patch
+	// is stored transposed too (s_b[column * BT + row]); the tests index it accordingly.
 	for (int it = lane; it < BD * 3; it += 64) {
 		const int s = it / BD, j = it - BD * s;
-		const uint16_t* p = s_h + (13 * s) * HP + j;              // rows 13s .. 13s+18 of column j
-		uint8_t* o = s_b + (13 * s) * HP + j;
-		int w0 = p[0], w1 = p[HP], w2 = p[2 * HP], w3 = p[3 * HP], w4 = p[4 * HP], w5 = p[5 * HP];
+		const int r0 = 13 * s;
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(s_h + j * HT) + (r0 >> 1);
+		const uint32_t sub = (uint32_t)(r0 & 1) * 2u;
+		uint32_t D[10], E[10], Q[19];
+#pragma unroll
+		for (int k = 0; k < 10; ++k) D[k] = p[k];
+#pragma unroll
+		for (int k = 0; k < 9; ++k) E[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sub);
+		E[9] = D[9] >> (8 * sub);
+#pragma unroll
+		for (int i = 0; i < 19; ++i) Q[i] = (i & 1) == 0 ? E[i >> 1] : (i < 18 ? __builtin_amdgcn_alignbyte(E[(i >> 1) + 1], E[i >> 1], 2u) : 0u);
+		uint8_t* o = s_b + j * BT + r0;
 #pragma unroll
 		for (int i = 0; i < 13; ++i) {
-			const int w6 = p[(i + 6) * HP];
-			const int sum = 18 * (w0 + w6) + 34 * (w1 + w5) + 49 * (w2 + w4) + 55 * w3;
-			o[i * HP] = (uint8_t)min((sum + (1 << 15)) >> 16, 255);
-			w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6;
+			uint32_t sum = __builtin_amdgcn_udot2(as_u16x2(Q[i + 6]), as_u16x2(18u), 1u << 15, false);
+			sum = __builtin_amdgcn_udot2(as_u16x2(Q[i + 4]), as_u16x2(49u | (34u << 16)), sum, false);
+			sum = __builtin_amdgcn_udot2(as_u16x2(Q[i + 2]), as_u16x2(49u | (55u << 16)), sum, false);
+			sum = __builtin_amdgcn_udot2(as_u16x2(Q[i]), as_u16x2(18u | (34u << 16)), sum, false);
+			o[i] = (uint8_t)min(sum >> 16, 255u);
 		}
 	}
 
@@ -124,8 +149,8 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 	if (lane == 0) kp_angle[(size_t)img * max_feats + k] = atan2_deg((float)m01, (float)m10);
 	__syncthreads();
 
-	// lane L evaluates tests 4L..4L+3  (bits (4L..4L+3)&7 of byte L/2); blurred(px,py) = s_b[(py-3)*HP + px-3]
-	const uint8_t* bc = s_b + (PR - 3) * HP + (PR - 3);
+	// lane L evaluates tests 4L..4L+3  (bits (4L..4L+3)&7 of byte L/2); blurred(px,py) = s_b[(px-3)*BT + py-3]
+	const uint8_t* bc = s_b + (PR - 3) * BT + (PR - 3);
 	unsigned bits = 0;
 #pragma unroll
 	for (int t = 0; t < 4; ++t) {
@@ -135,8 +160,8 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 		const int iy0 = (int)rintf(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
 		const int ix1 = (int)rintf(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
 		const int iy1 = (int)rintf(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-		const int v0 = bc[iy0 * HP + ix0];
-		const int v1 = bc[iy1 * HP + ix1];
+		const int v0 = bc[ix0 * BT + iy0];
+		const int v1 = bc[ix1 * BT + iy1];
 		bits |= (unsigned)(v0 < v1) << t;
 	}
 	// byte j = tests 8j..8j+7 = lanes 2j (low nibble) and 2j+1 (high nibble)
