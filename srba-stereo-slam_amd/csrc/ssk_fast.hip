@@ -39,32 +39,45 @@ constexpr int SH = TH + 2;                 // score rows Y0-1 .. Y0+TH
 constexpr int SP = IWV;                    // score tile pitch (column index = gx - (X0-4))
 constexpr int NQ = SG * SH * 4;            // pixels in the score region
 
-__device__ __forceinline__ int fast_s(const int (&d)[16])
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// FAST score of a corner from its 16 ring differences, on PACKED 16-bit lanes (v_pk_min/max_i16): A[k] holds
+// (d[2k], d[2k+1]).  lo_n[i] = min of the n ring differences starting at i (doubling), score = max over the 16 arcs
+// of 9 of the arc's min (bright) or of minus the arc's max (dark).  Half the instructions and a third of the live
+// registers of the scalar form -- the scalar form made the whole kernel spill.
+__device__ __forceinline__ int fast_s_packed(const uint32_t (&A)[8])
 {
-	int lo2[16], hi2[16], lo4[16], hi4[16], lo8[16], hi8[16];
+	s16x2 a[8], b[8], lo[8], hi[8];
 #pragma unroll
-	for (int i = 0; i < 16; ++i) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
+	for (int k = 0; k < 8; ++k) a[k] = as_s16x2(A[k]);
 #pragma unroll
-	for (int i = 0; i < 16; ++i) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
+	for (int k = 0; k < 8; ++k) b[k] = as_s16x2(__builtin_amdgcn_alignbyte(A[(k + 1) & 7], A[k], 2u));   // (d[2k+1], d[2k+2])
 #pragma unroll
-	for (int i = 0; i < 16; ++i) { lo8[i] = min(lo4[i], lo4[(i + 4) & 15]); hi8[i] = max(hi4[i], hi4[(i + 4) & 15]); }
-	int sb = 0, hmin = 255;
+	for (int k = 0; k < 8; ++k) { lo[k] = __builtin_elementwise_min(a[k], b[k]); hi[k] = __builtin_elementwise_max(a[k], b[k]); }   // runs of 2
+	s16x2 t[8], u[8];
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		sb = max(sb, min(lo8[i], d[(i + 8) & 15]));       // all 9 of arc i brighter by at least this
-		hmin = min(hmin, max(hi8[i], d[(i + 8) & 15]));   // all 9 of arc i darker by at least -this
-	}
-	return max(sb, -hmin);
+	for (int k = 0; k < 8; ++k) { t[k] = __builtin_elementwise_min(lo[k], lo[(k + 1) & 7]); u[k] = __builtin_elementwise_max(hi[k], hi[(k + 1) & 7]); }   // runs of 4
+#pragma unroll
+	for (int k = 0; k < 8; ++k) { lo[k] = __builtin_elementwise_min(t[k], t[(k + 2) & 7]); hi[k] = __builtin_elementwise_max(u[k], u[(k + 2) & 7]); }     // runs of 8
+#pragma unroll
+	for (int k = 0; k < 8; ++k) { lo[k] = __builtin_elementwise_min(lo[k], a[(k + 4) & 7]); hi[k] = __builtin_elementwise_max(hi[k], a[(k + 4) & 7]); }   // arcs of 9
+	s16x2 sb = lo[0], hm = hi[0];
+#pragma unroll
+	for (int k = 1; k < 8; ++k) { sb = __builtin_elementwise_max(sb, lo[k]); hm = __builtin_elementwise_min(hm, hi[k]); }
+	const int bright = max(max((int)sb.x, (int)sb.y), 0), dark = min(min((int)hm.x, (int)hm.y), 255);
+	return max(bright, -dark);
 }
 
-// the 16 ring pixels around p (LDS, pitch IW) minus the centre, in ring order
-__device__ __forceinline__ void ring_diffs(const uint8_t* p, int (&d)[16])
+// the 16 ring pixels around p (LDS, pitch IW) minus the centre, in ring order, packed in pairs
+__device__ __forceinline__ void ring_diffs_packed(const uint8_t* p, uint32_t (&A)[8])
 {
-	const int c = p[0];
-	d[0] = p[3 * IW] - c;       d[1] = p[3 * IW + 1] - c;   d[2] = p[2 * IW + 2] - c;   d[3] = p[IW + 3] - c;
-	d[4] = p[3] - c;            d[5] = p[-IW + 3] - c;      d[6] = p[-2 * IW + 2] - c;  d[7] = p[-3 * IW + 1] - c;
-	d[8] = p[-3 * IW] - c;      d[9] = p[-3 * IW - 1] - c;  d[10] = p[-2 * IW - 2] - c; d[11] = p[-IW - 3] - c;
-	d[12] = p[-3] - c;          d[13] = p[IW - 3] - c;      d[14] = p[2 * IW - 2] - c;  d[15] = p[3 * IW - 1] - c;
+	const uint32_t c = p[0], cc = c | (c << 16);
+	const uint32_t r[16] = {p[3 * IW], p[3 * IW + 1], p[2 * IW + 2], p[IW + 3], p[3], p[-IW + 3], p[-2 * IW + 2], p[-3 * IW + 1],
+	                        p[-3 * IW], p[-3 * IW - 1], p[-2 * IW - 2], p[-IW - 3], p[-3], p[IW - 3], p[2 * IW - 2], p[3 * IW - 1]};
+#pragma unroll
+	for (int k = 0; k < 8; ++k) A[k] = as_u32(as_s16x2(r[2 * k] | (r[2 * k + 1] << 16)) - as_s16x2(cc));
 }
 
 // append the values of the lanes with pred to an LDS queue: one ds atomic per wave
@@ -223,9 +236,9 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 			const int code = s_q2[q];
 			const int it = code >> 2, k = code & 3;
 			const int sy = it / SG, g = it - sy * SG;
-			int d[16];
-			ring_diffs(s_img + (sy + 3) * IW + 4 * (g + 1) + k, d);
-			const int s = fast_s(d);
+			uint32_t A[8];
+			ring_diffs_packed(s_img + (sy + 3) * IW + 4 * (g + 1) + k, A);
+			const int s = fast_s_packed(A);
 			if (s > threshold) s_sc[sy * SP + 4 * g + k] = (uint8_t)(s - 1);
 		}
 		__syncthreads();
