@@ -9,8 +9,9 @@ is already resident in HBM when the timed region starts:
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), keyframe streams are partitioned one
 batch per GPU (weak scaling) and each step ends with ONE all-gather of the shared-landmark blocks.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant HBM-bound kernel (fast_nms_kernel), measured
-live with HIP events on the stream the kernels run on; `cpu_baseline` is the CPU oracle (the port, not the
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel that dominates the step (the LM solve), `roofline_scan`
+for the front-end's HBM-bound image scan (fast_nms_kernel); both measured live with HIP events on the stream the
+kernels run on; `cpu_baseline` is the CPU oracle (the port, not the
 reference: the reference's path needs OpenCV/MRPT/SRBA/stereo-vo, absent here) timed on the host cores.
 """
 import argparse
@@ -182,19 +183,29 @@ def main():
     tracked = d_tr.cpu().numpy()
 
     if rank == 0:
-        fast_ms, fast_calls = prof["fast_nms"]
-        fast_avg_ms = fast_ms / max(fast_calls, 1)
-        algo_bytes = float(B) * 2 * W * H                       # 933,232 B read per keyframe by the scan
-        achieved = algo_bytes / (fast_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "fast_nms_traffic.json")
+        # PMC traffic per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary
+        # committed under profiles/): bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- KB units, FETCH_SIZE doubled on gfx950
+        # (MI355X_MICROARCH.md "HBM"; re-calibrated in the same run on lm_reset_kernel, which reads exactly what it writes)
+        traffic = {}
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tf):
             try:
                 t = json.load(open(tf))
                 if int(t.get("batch", -1)) == B:
-                    traffic = float(t["hbm_bytes_per_launch"])
+                    traffic = {k: (2.0 * v["fetch_size_kb"] + v["write_size_kb"]) * 1024.0 for k, v in t["kernels"].items()}
             except Exception:
-                traffic = None
+                traffic = {}
+        # dominant kernel by time: the LM solve.  Algorithmic bytes: per LM iteration 56 B per observation
+        # (pixels 16 + ids 16 + landmark 24) + 96 B per edge pose, nothing written when J is fused into the H accumulation
+        lm_ms, lm_calls = prof["lm_solve"]
+        lm_avg_ms = lm_ms / max(lm_calls, 1)
+        lm_algo = float(sum(r.iters * (56 * len(wins[k % len(wins)].obs_lm) + 96 * len(wins[k % len(wins)].edge_unknown_slot)) for k, r in enumerate(res)))
+        lm_ach = lm_algo / (lm_avg_ms * 1e-3) / 1e9
+        # the HBM-bound scan of the front-end (every pixel of both images read once): 933,232 B per keyframe
+        fast_ms, fast_calls = prof["fast_nms"]
+        fast_avg_ms = fast_ms / max(fast_calls, 1)
+        algo_bytes = float(B) * 2 * W * H
+        achieved = algo_bytes / (fast_avg_ms * 1e-3) / 1e9
         stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1] > 0}
         line = {
             "metric": "keyframes/sec (detect+match+LM solve), KITTI-00 stereo",
@@ -221,9 +232,13 @@ def main():
                 "lm_window": {"edges": int(wins[0].E), "landmarks": int(wins[0].L), "observations": int(len(wins[0].obs_lm)),
                               "mean_iters": float(np.mean([r.iters for r in res]))},
             },
-            "roofline": {"kernel": "fast_nms_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_avg_ms},
+            "roofline": {"kernel": "lm_solve_tiled_kernel", "bound": "hbm", "achieved": lm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic.get("lm_solve_tiled_kernel"),
+                         "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
+                         "note": "dominant kernel by time; FP64-issue/LDS bound at 2 waves/SIMD, not bandwidth bound (DESIGN.md 5, 9)"},
+            "roofline_scan": {"kernel": "fast_nms_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("fast_nms_kernel"),
+                              "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_avg_ms},
             "stage_ms_per_launch": stages,
         }
         if world == 1 and args.cpu_sample > 0:
