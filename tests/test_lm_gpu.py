@@ -129,6 +129,26 @@ def test_lm_batch_of_ragged_windows_and_reset(ctx, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("seed,robust", [(1, True), (2, False)])
+def test_lm_general_kernel_same_contract(ctx, oracle, seed, robust, monkeypatch):
+    """the scratch-in-L2 kernel (windows of any size; SSK_LM_KERNEL=l2 forces it) honours the same per-iteration bar
+    as the LDS-tiled kernel the other tests run, on a small and on a multi-tile window."""
+    monkeypatch.setenv("SSK_LM_KERNEL", "l2")
+    win, gt = sl.make_submap_problem(seed, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)
+    check_against_oracle(ctx, oracle, win, sl.make_params(robust=robust, sensor_t=(0.2, -0.05, 0.1)), min_accept=2)
+    win, gt = sl.make_submap_problem(7, n_kf=60, n_lm=1500, submap_size=10, max_tree_depth=4, opt_depth=2, obs_per_kf=250,
+                                     lm_fwd=(3, 20), z_vis=(2.5, 22))
+    check_against_oracle(ctx, oracle, win, sl.make_params(robust=robust), min_accept=2)
+
+
+def test_lm_tiled_kernel_multi_tile_window(ctx, oracle):
+    """a bench-shaped window (~1.4k observations): several LDS tiles, segmented partial sums across tiles."""
+    win, gt = sl.make_submap_problem(7, n_kf=60, n_lm=1500, submap_size=10, max_tree_depth=4, opt_depth=2, obs_per_kf=250,
+                                     lm_fwd=(3, 20), z_vis=(2.5, 22))
+    assert len(win.obs_lm) > 800
+    check_against_oracle(ctx, oracle, win, sl.make_params(), min_accept=2)
+
+
 def test_lm_large_window_global_cholesky(ctx, oracle):
     """a window whose reduced system (6E > 132) does not fit the LDS workspace: L2-resident Cholesky path."""
     win, gt = sl.make_submap_problem(21, n_kf=45, n_lm=900, submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)
