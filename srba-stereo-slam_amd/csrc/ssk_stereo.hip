@@ -5,9 +5,9 @@
 // min_disparity <= xL-xR <= max_disparity, the one with the smallest 256-bit Hamming distance (lowest right
 // index on ties), accepted iff distance <= orb_max_distance.  Matches come out in left-keypoint order.
 //
-// Mapping (gfx950): one 256-thread workgroup per keyframe.  Left keypoints are processed in tiles of 64
+// Mapping (gfx950): one 1024-thread workgroup per keyframe.  Left keypoints are processed in tiles of 64
 // (one per lane, descriptor in 8 VGPRs); right descriptors + coordinates are staged through LDS in tiles of
-// 512 rows; the 4 waves split the right rows (every lane of a wave reads the same LDS row: broadcast).
+// 512 rows (once when they fit one tile); the 16 waves split the right rows (every lane of a wave reads the same LDS row: broadcast).
 // The band test runs first and a wave skips the popcounts of a row no lane accepts (ballot).
 // Argmin = integer min of the packed key (distance<<16 | right index).  The per-left results are then
 // compacted IN ORDER with a workgroup prefix sum, which also writes the gather lists the batched data
@@ -17,8 +17,9 @@
 namespace {
 
 constexpr int TT = 512;
+constexpr int NT = 1024, NW = NT / 64;   // 16 waves: the batch gives one workgroup per CU, so latency is hidden inside it
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(NT)
 void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__ kp_xy, const int32_t* __restrict__ nkp,
                          const uint8_t* __restrict__ desc, float max_y_diff, float min_disp, float max_disp,
                          int orb_max_distance,
@@ -27,9 +28,9 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
 {
 	__shared__ uint4 s_desc[TT * 2];
 	__shared__ short2 s_rxy[TT];
-	__shared__ uint32_t s_part[4][64];
+	__shared__ uint32_t s_part[NW][64];
 	__shared__ uint32_t s_best[SSK_MAX_FEATS];
-	__shared__ int s_scan[256];
+	__shared__ int s_scan[NT];
 
 	const int kf = kf_begin + blockIdx.x;
 	const int il = kf * 2, ir = kf * 2 + 1;
@@ -53,11 +54,13 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
 		uint32_t best = 0xFFFFFFFFu;
 		for (int tile = 0; tile < nr; tile += TT) {
 			const int rows = min(TT, nr - tile);
-			__syncthreads();
-			for (int c = tid; c < rows * 2; c += 256) s_desc[c] = dr[2 * (size_t)tile + c];
-			for (int c = tid; c < rows; c += 256) s_rxy[c] = xr[tile + c];
-			__syncthreads();
-			for (int r = wave; r < rows; r += 4) {
+			if (nr > TT || lbase == 0) {                     // a right side of <= TT rows is staged once for all left tiles
+				__syncthreads();
+				for (int c = tid; c < rows * 2; c += NT) s_desc[c] = dr[2 * (size_t)tile + c];
+				for (int c = tid; c < rows; c += NT) s_rxy[c] = xr[tile + c];
+				__syncthreads();
+			}
+			for (int r = wave; r < rows; r += NW) {
 				const short2 rp = s_rxy[r];
 				const float disp = __fsub_rn(lx, (float)rp.x);
 				const bool cand = ok && !(fabsf(__fsub_rn(ly, (float)rp.y)) > max_y_diff) &&
@@ -72,13 +75,17 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
 		}
 		s_part[wave][lane] = best;
 		__syncthreads();
-		if (wave == 0 && ok)
-			s_best[li] = min(min(s_part[0][lane], s_part[1][lane]), min(s_part[2][lane], s_part[3][lane]));
+		if (wave == 0 && ok) {
+			uint32_t m = s_part[0][lane];
+#pragma unroll
+			for (int w = 1; w < NW; ++w) m = min(m, s_part[w][lane]);
+			s_best[li] = m;
+		}
 		__syncthreads();
 	}
 
-	// ordered compaction: thread t owns left keypoints [t*8, t*8+8)
-	constexpr int PER = SSK_MAX_FEATS / 256;
+	// ordered compaction: thread t owns left keypoints [t*PER, t*PER+PER)
+	constexpr int PER = SSK_MAX_FEATS / NT;
 	int cnt = 0;
 	uint32_t mine[PER];
 #pragma unroll
@@ -92,7 +99,7 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
 	}
 	s_scan[tid] = cnt;
 	__syncthreads();
-	for (int o = 1; o < 256; o <<= 1) {
+	for (int o = 1; o < NT; o <<= 1) {
 		const int v = tid >= o ? s_scan[tid - o] : 0;
 		__syncthreads();
 		s_scan[tid] += v;
@@ -113,7 +120,7 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
 			++pos;
 		}
 	}
-	if (tid == 255) nm[kf] = s_scan[255];
+	if (tid == NT - 1) nm[kf] = s_scan[NT - 1];
 }
 
 }  // namespace
@@ -123,7 +130,7 @@ int ssk_launch_stereo(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, co
 	const int nkf = kf_end - kf_begin;
 	if (nkf <= 0) return SSK_OK;
 	ssk_stage_scope prof(ctx, SSK_STAGE_STEREO);
-	hipLaunchKernelGGL(stereo_match_kernel, dim3(nkf), dim3(256), 0, ctx->stream, kf_begin, b->max_feats, b->kp_xy,
+	hipLaunchKernelGGL(stereo_match_kernel, dim3(nkf), dim3(NT), 0, ctx->stream, kf_begin, b->max_feats, b->kp_xy,
 	                   b->nkp, b->desc, p.max_y_diff, p.min_disparity, p.max_disparity, p.orb_max_distance,
 	                   b->m_q, b->m_t, b->m_d, b->nm, b->m_row, b->m_xy);
 	SSK_LAUNCH_CHECK(ctx, "stereo_match_kernel");
