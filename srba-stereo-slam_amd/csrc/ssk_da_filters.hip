@@ -11,7 +11,8 @@
 //     preimages of the bin edges under the host libm's atanf, ssk_context.hip) -- so no device atanf.
 //   * mode = FIRST maximal bin (strict '>'), survivors = mode-1, mode, mode+1 with wrap.
 //   * the uniqueness scan is order dependent (each accepted match stores ++stage1_counter, which later
-//     comparisons read back), so lane 0 runs it serially in query order out of LDS; M <= 500.
+//     comparisons read back): the wave runs it serially in query order, inputs preloaded 64 at a time and
+//     broadcast by v_readlane, state in LDS; M <= 500.
 // Bound: latency of the serial LDS chain; not a bandwidth kernel (tens of KB per pair).
 #include "ssk_internal.h"
 #include <cfloat>
@@ -88,20 +89,30 @@ void da_filters_kernel(const int32_t* __restrict__ train_idx, const int32_t* __r
 		__syncthreads();
 	}
 
-	if (filter_orb && lane == 0) {
-		// serial, literal order of EST.cpp:1966-2008 (queryIdx == k for BFMatcher output)
+	if (filter_orb) {
+		// serial, literal order of EST.cpp:1966-2008 (queryIdx == k for BFMatcher output).  The whole wave walks the
+		// matches in lock step: 64 matches at a time are loaded one per lane (status, distance, train index -- none of
+		// them is changed by the scan before its turn: the scan only demotes EARLIER matches) and broadcast with
+		// v_readlane, so the dependent chain per match is the two LDS reads of other_matched[t]; lane 0 writes.
 		float counter = 0.f;   // size_t stage1_counter; exact in float for counts < 2^24
-		for (int k = 0; k < n_this; ++k) {
-			if (s_status[k] != SSK_DA_TRACKED) continue;                                      // :1969
-			const float d = (float)dist[o0 + k];
-			const int t = train_idx[o0 + k];
-			if ((double)d > (double)max_orb) { s_status[k] = SSK_DA_REJ_ORB; continue; }       // :1980
-			if (d > s_second[t]) { s_status[k] = SSK_DA_NON_TRACKED; continue; }               // :1988
-			const int prev = s_first[t];
-			if (prev != -1) { s_status[prev] = SSK_DA_NON_TRACKED; counter -= 1.f; }           // :1995-1999
-			s_first[t] = (int16_t)k;                                                           // :2002
-			counter += 1.f;
-			s_second[t] = counter;                                                             // :2003,2007 (Q1)
+		for (int base = 0; base < n_this; base += 64) {
+			const int kl = base + lane;
+			int st_l = -1, d_l = 0, t_l = 0;
+			if (kl < n_this) { st_l = s_status[kl]; d_l = dist[o0 + kl]; t_l = train_idx[o0 + kl]; }
+			const int nk = min(64, n_this - base);
+			for (int l = 0; l < nk; ++l) {
+				if (__builtin_amdgcn_readlane(st_l, l) != SSK_DA_TRACKED) continue;               // :1969
+				const int k = base + l;
+				const float d = (float)__builtin_amdgcn_readlane(d_l, l);
+				const int t = __builtin_amdgcn_readlane(t_l, l);
+				if ((double)d > (double)max_orb) { if (lane == 0) s_status[k] = SSK_DA_REJ_ORB; continue; }       // :1980
+				const float second = s_second[t];
+				const int prev = s_first[t];
+				if (d > second) { if (lane == 0) s_status[k] = SSK_DA_NON_TRACKED; continue; }                    // :1988
+				if (prev != -1) { if (lane == 0) s_status[prev] = SSK_DA_NON_TRACKED; counter -= 1.f; }           // :1995-1999
+				counter += 1.f;
+				if (lane == 0) { s_first[t] = (int16_t)k; s_second[t] = counter; }                                // :2002-2007 (Q1)
+			}
 		}
 	}
 	__syncthreads();
