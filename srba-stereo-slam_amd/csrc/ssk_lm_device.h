@@ -5,7 +5,10 @@
 #ifndef SSK_LM_WAVES
 #define SSK_LM_WAVES 2          // min waves per SIMD the register budget must allow (2 = one 512-thread workgroup per CU)
 #endif
-constexpr int NT = 512;
+#ifndef SSK_LM_NT
+#define SSK_LM_NT 512
+#endif
+constexpr int NT = SSK_LM_NT;
 constexpr int NW = NT / 64;
 
 #define WAVE_SYNC()                                                \

@@ -31,6 +31,7 @@
 
 namespace {
 
+#define SSK_LM_NT SSK_LMT_THREADS
 #include "ssk_lm_device.h"
 
 static_assert(NT == SSK_LMT_NT, "workgroup size of the tiled kernel");
