@@ -116,7 +116,10 @@ def main():
     pkg = ge.load_package()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    rank, world = pkg.dist.init_from_env("nccl")       # one process per GPU, RCCL
+    # SSK_BENCH_EXCHANGE_ALWAYS=1: run the shared-landmark exchange (pack, RCCL all-gather, stitch) on a single rank too
+    exchange = os.environ.get("SSK_BENCH_EXCHANGE_ALWAYS") == "1"
+    rank, world = pkg.dist.init_from_env("nccl", always=exchange)       # one process per GPU, RCCL
+    exchange = exchange or world > 1
     from ssk_amd import capi
     import synth_lm as sl
 
@@ -134,7 +137,7 @@ def main():
     d_tr = torch.empty(B, dtype=torch.int32, device=dev)
     S = args.shared_landmarks
     shared = torch.zeros(S * 12, dtype=torch.float64, device=dev)
-    gathered = torch.zeros(world * S * 12, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros(world * S * 12, dtype=torch.float64, device=dev) if exchange else None
     fused = torch.zeros(S * 3, dtype=torch.float64, device=dev)
 
     prev.run_frontend(fp)          # state: the previous keyframes' features (not part of a step)
@@ -145,7 +148,7 @@ def main():
         ctx.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
         lm.reset()
         lm.run(lp)
-        if world > 1:
+        if exchange:
             # the one exchange step of the path: every submap's shared-landmark blocks to every GPU,
             # fused in rank order (deterministic)
             lm.pack_shared(0, S, shared)
@@ -225,7 +228,7 @@ def main():
                             "(max_y_diff 2, orb_max_distance 60) + KF<->KF Hamming DA with direction/ORB filters + SRBA LM window "
                             "(200-KF/5k-landmark submap, submap_size 10, max_tree_depth 4, window = 10 most recent edges)",
                 "keyframes_per_gpu_per_step": B,
-                "parallelism": "keyframe streams partitioned one batch per GPU" + ("; 1 RCCL all-gather of %d shared-landmark blocks per step" % S if world > 1 else ""),
+                "parallelism": "keyframe streams partitioned one batch per GPU" + ("; 1 RCCL all-gather of %d shared-landmark blocks per step" % S if exchange else ""),
                 "mean_keypoints_per_image": float(nkp.mean()),
                 "mean_stereo_matches": float(nm.mean()),
                 "mean_tracked_vs_prev": float(tracked.mean()),
@@ -247,7 +250,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line))
     lm.close(); cur.close(); prev.close(); ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -4,13 +4,15 @@ except ONE all-gather per step of the shared-landmark blocks."""
 import os
 
 
-def init_from_env(backend):
-    """Rendezvous from the torchrun environment (RANK / WORLD_SIZE / MASTER_*); returns (rank, world)."""
+def init_from_env(backend, always=False):
+    """Rendezvous from the torchrun environment (RANK / WORLD_SIZE / MASTER_*); returns (rank, world).
+    `always` also creates the (single-rank) group when WORLD_SIZE is 1, to exercise the exchange path on one GPU."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or always) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
