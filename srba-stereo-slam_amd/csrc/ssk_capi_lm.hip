@@ -345,7 +345,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		bool tiled = 6 * E <= SSK_LMT_MAX_N6 && Wn.n_edges_total <= 128 && (long long)(6 * E + 1) * ((6 * E) | 1) * 8 <= region_bytes;
 		if (tiled) {
 			auto tile_bytes = [](long long nP, long long nO, long long nM, long long nL) {
-				return 8 * (SSK_LMT_ENT * nP + std::max<long long>(SSK_LMT_OBS * nO, SSK_LMT_RED) + SSK_LMT_Y * nM + SSK_LMT_LMR * nL);
+				return 8 * (SSK_LMT_ENT * nP + SSK_LMT_OBS * nO + SSK_LMT_Y * nM + SSK_LMT_LMR * nL);
 			};
 			std::vector<std::vector<int>> obs_of((size_t)Wn.n_lms_total);
 			for (int o = 0; o < Wn.n_obs; ++o) obs_of[Wn.obs_lm[o]].push_back(o);

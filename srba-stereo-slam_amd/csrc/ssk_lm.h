@@ -112,7 +112,6 @@ int ssk_lm_launch(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows,
 #endif
 constexpr int SSK_LMT_NT = SSK_LMT_THREADS;        // workgroup size
 constexpr int SSK_LMT_ENT = 15, SSK_LMT_OBS = 17, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;   // record pitches (doubles, odd: conflict-free)
-constexpr int SSK_LMT_RED = (SSK_LMT_NT / 64) * 64 * 9;   // doubles of reduction scratch (aliases the observation records)
 constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024 / SSK_LMT_WG_PER_CU;   // gfx950: 160 KB of LDS per CU, shared by the resident workgroups
 constexpr int SSK_LMT_STATIC = 4096;               // reserve for the kernel's static LDS
 constexpr int SSK_LMT_MAX_N6 = 126;

@@ -17,8 +17,8 @@
 //       C = A_i^T A_j (3x3) and two cross products (90 FMA instead of 144) in 36 registers
 //   I4  Schur items (landmark, pair of its incidences): Y_i Y_j^T
 //   Items are sorted by block pair id; a lane owns a group of consecutive items of one block, a wave sums the
-//   lanes of a chunk by segments of equal block id through an LDS transpose (lane order: deterministic, no
-//   floating-point atomics) into partial slots; the final block sum runs over the slot list of the block.
+//   lanes of a chunk by segments of equal block id with a DPP segmented scan (fixed order: deterministic, no
+//   floating-point atomics) into partial slots; the final block sum runs over the slot run of the block.
 // After the tiles: reduced system assembled in LDS over the dead tile buffers, LDL^T + back-substitution in LDS
 // (ssk_lm_device.h), landmark back-substitution from Y, trial state, robust error, lambda schedule: as ssk_lm.hip.
 // A rejected step re-linearises at the same state (bit-identical values) instead of keeping W in HBM.
@@ -36,7 +36,6 @@ namespace {
 
 static_assert(NT == SSK_LMT_NT, "workgroup size of the tiled kernel");
 constexpr int ENT_P = SSK_LMT_ENT, OBS_P = SSK_LMT_OBS, Y_P = SSK_LMT_Y, LMR_P = SSK_LMT_LMR;
-constexpr int RED_P = 9, RED_WAVE_D = 64 * RED_P;
 
 __device__ __forceinline__ void cross3(const double* a, const double* b, double* c)
 {
@@ -46,41 +45,42 @@ __device__ __forceinline__ void cross3(const double* a, const double* b, double*
 }
 
 // Sum of 36-vectors over the lanes of a wave BY SEGMENT, in lane order.  Lanes are sorted by key; a segment starts
-// at every key change and at lanes 0/16/32/48.  Four passes of 9 values through the wave's LDS scratch (row pitch
-// 9): every lane writes its row; lanes c < 9 of each 16-lane group turn the 16 rows of their group into running
-// sums that restart at segment heads (in place); the last lane of every segment then holds the segment's sum in
-// its own row; after the four passes it stores the 36 sums to part[36 * segslot[segment]] in one burst.
-__device__ __forceinline__ void wave_seg_sum36(double (&acc)[36], int key, double* red, int lane, double* __restrict__ part, const int* __restrict__ segslot)
+// at every key change and at lanes 0/16/32/48.  Segmented inclusive scan inside each row of 16 lanes with DPP row
+// shifts (VALU only: the LDS is the contended resource of the chunk tasks, and a transpose through it cost more):
+// step d in {1,2,4,8} adds the value of lane-d when it belongs to the same segment; the fixed shift order makes the
+// result deterministic.  The last lane of every segment then stores its 36 sums to part[36 * segslot[segment]].
+template <int D>
+__device__ __forceinline__ double dpp_shr_f64(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + D, 0xF, 0xF, true);    // row_shr:D, lanes shifted in from outside the row read 0
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + D, 0xF, 0xF, true);
+	return __hiloint2double(hi, lo);
+}
+template <int D>
+__device__ __forceinline__ bool dpp_same_key(int key)
+{
+	return __builtin_amdgcn_update_dpp(-1, key, 0x110 + D, 0xF, 0xF, false) == key;             // outside the row: -1, never a key
+}
+
+__device__ __forceinline__ void wave_seg_sum36(double (&acc)[36], int key, int lane, double* __restrict__ part, const int* __restrict__ segslot)
 {
 	const int prev = __shfl_up(key, 1, 64);
 	const bool head = (lane & 15) == 0 || key != prev;
 	const unsigned long long hm = __ballot(head);
 	const bool tail = (lane & 15) == 15 || ((hm >> ((lane + 1) & 63)) & 1ull);
 	const int seg = __popcll(hm & ((2ull << lane) - 1ull)) - 1;
-	double* out = part + 36 * (size_t)segslot[seg];
-	const int grp = lane >> 4, c = lane & 15;
-	const unsigned hrow = (unsigned)(hm >> (16 * grp)) & 0xFFFFu;
-	double* col = red + 16 * grp * RED_P + c;
+	const bool s1 = dpp_same_key<1>(key), s2 = dpp_same_key<2>(key), s4 = dpp_same_key<4>(key), s8 = dpp_same_key<8>(key);
 #pragma unroll
-	for (int h = 0; h < 4; ++h) {
-#pragma unroll
-		for (int i = 0; i < 9; ++i) red[lane * RED_P + i] = acc[9 * h + i];
-		WAVE_SYNC();
-		if (c < 9) {
-			double s = 0.0;
-#pragma unroll
-			for (int r = 0; r < 16; ++r) {
-				const double v = col[r * RED_P];
-				s = ((hrow >> r) & 1u) ? v : s + v;
-				col[r * RED_P] = s;
-			}
-		}
-		WAVE_SYNC();
-#pragma unroll
-		for (int i = 0; i < 9; ++i) acc[9 * h + i] = red[lane * RED_P + i];     // the lane's running sums (read back in place of its inputs)
-		WAVE_SYNC();
+	for (int i = 0; i < 36; ++i) {
+		double v = acc[i], t;
+		t = dpp_shr_f64<1>(v); v += s1 ? t : 0.0;
+		t = dpp_shr_f64<2>(v); v += s2 ? t : 0.0;
+		t = dpp_shr_f64<4>(v); v += s4 ? t : 0.0;
+		t = dpp_shr_f64<8>(v); v += s8 ? t : 0.0;
+		acc[i] = v;
 	}
 	if (tail) {                                            // one burst of stores, nothing waits on it
+		double* out = part + 36 * (size_t)segslot[seg];
 #pragma unroll
 		for (int i = 0; i < 36; ++i) out[i] = acc[i];
 	}
@@ -374,10 +374,8 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			const lm_tile T = D.tile[W.tile0 + t];
 			double* ent = reg;
 			double* obsr = ent + ENT_P * T.n_ent;
-			const int obs_d = OBS_P * T.n_obs > SSK_LMT_RED ? OBS_P * T.n_obs : SSK_LMT_RED;
-			double* Yr = obsr + obs_d;
+			double* Yr = obsr + OBS_P * T.n_obs;
 			double* lmr = Yr + Y_P * T.n_inc;
-			double* red = obsr + wave * RED_WAVE_D;
 			++epoch;
 			// ---- I1: observations ----
 			for (int k = tid; k < T.n_obs; k += NT)
@@ -517,13 +515,13 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 					const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
 					pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
 					FTICK(1);
-					wave_seg_sum36(acc, rec.y >> 8, red, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
+					wave_seg_sum36(acc, rec.y >> 8, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
 				} else {
 					const int c = task - T.n_pc, g = 64 * c + lane;
 					const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
 					schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
 					FTICK(1);
-					wave_seg_sum36(acc, rec.y >> 8, red, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
+					wave_seg_sum36(acc, rec.y >> 8, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
 				}
 				FTICK(2);
 			}
