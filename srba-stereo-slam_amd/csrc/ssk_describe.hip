@@ -72,20 +72,21 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 
 	// raw patch: aligned dwords covering columns x-22 .. x+22 of rows y-22 .. y+22
 	const int xs = x - PR, xa = xs & ~3, shift = xs - xa;
-	for (int i = lane; i < PD * (PP / 4); i += 64) {
-		const int r = i / (PP / 4), c = i - r * (PP / 4);
-		reinterpret_cast<uint32_t*>(s_raw)[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(y - PR + r) * pitch + xa + 4 * c);
+	for (int i = lane; i < PD * (PP / 16); i += 64) {          // 3 x 16 bytes per row (global dwordx4 only needs dword alignment)
+		const int r = i / (PP / 16), c = i - r * (PP / 16);
+		reinterpret_cast<uint4*>(s_raw)[i] = *reinterpret_cast<const uint4*>(src + (size_t)(y - PR + r) * pitch + xa + 16 * c);
 	}
 	__syncthreads();
 
 	// moments over the radius-15 disc: lane v handles row v-15 (31 rows)
 	int m10 = 0, m01 = 0;
-	if (lane < 31) {
-		const int v = lane - 15;
+	if (lane < 62) {                                           // two lanes per row: u in [-um, -1] and [0, um]
+		const int v = (lane >> 1) - 15;
 		const int um = c_umax[v < 0 ? -v : v];
 		const uint8_t* p = s_raw + (PR + v) * PP + shift + PR;
+		const int u0 = (lane & 1) ? 0 : -um, u1 = (lane & 1) ? um : -1;
 		int rs = 0;
-		for (int u = -um; u <= um; ++u) { const int I = p[u]; m10 += u * I; rs += I; }
+		for (int u = u0; u <= u1; ++u) { const int I = p[u]; m10 += u * I; rs += I; }
 		m01 = v * rs;
 	}
 	// horizontal blur pass: item = (row r, segment s of 13 outputs).  The 19 input bytes come in as 6 dwords, are
@@ -152,9 +153,11 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 	// lane L evaluates tests 4L..4L+3  (bits (4L..4L+3)&7 of byte L/2); blurred(px,py) = s_b[(px-3)*BT + py-3]
 	const uint8_t* bc = s_b + (PR - 3) * BT + (PR - 3);
 	unsigned bits = 0;
+	const uint4 pat4 = reinterpret_cast<const uint4*>(pattern)[lane];   // the lane's four tests (x0,y0,x1,y1 as int8) in one load
+	const uint32_t patw[4] = {pat4.x, pat4.y, pat4.z, pat4.w};
 #pragma unroll
 	for (int t = 0; t < 4; ++t) {
-		const char4 pt = reinterpret_cast<const char4*>(pattern)[4 * lane + t];
+		const char4 pt = __builtin_bit_cast(char4, patw[t]);
 		const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
 		const int ix0 = (int)rintf(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
 		const int iy0 = (int)rintf(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
