@@ -117,9 +117,9 @@ __device__ void so3_exp(const double* w, double* R)
 // G (fast path): the reduced system solved in LDS as a square-root-free LDL^T of the matrix bordered by the
 // right-hand side (row n = g_red^T), right-looking, by the whole workgroup:
 //   A(i,k) -= A(i,j) A(k,j) / d_j   for j < k <= i <= n; column j itself stays unscaled (U_ij = L'_ij d_j), d_j = A(j,j)
-//   when its turn comes.  Blocked by the 6 columns of an edge: the 6x6 diagonal block is factorised in registers by
-//   every thread (no communication), one thread per row finishes the panel, then the whole workgroup applies the
-//   rank-6 update: two barriers per block column.
+//   when its turn comes.  Blocked by the 6 columns of an edge: one wave factorises the 6x6 diagonal block in
+//   registers and finishes the panel (a lane per row), then the whole workgroup applies the rank-6 update: two
+//   barriers per block column.
 // The border row comes out as z = L'^-1 b (forward substitution for free), so only L'^T x = D^-1 z is left: one
 // wavefront keeps x in registers (lane k owns x_k, x_{k+64}), broadcasts x_i with v_readlane and prefetches row
 // i-1 of U while it applies row i, so the dependent chain per step is one readlane + one FMA.
@@ -143,51 +143,59 @@ __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* 
 {
 	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
 	// blocked by the 6 columns of one edge (n = 6E): two barriers per block column instead of one per column
+	__shared__ int s_ldl_bad;
 	for (int c0 = 0; c0 < n; c0 += 6) {
 		__syncthreads();
-		// (1) the 6x6 diagonal block, factorised redundantly in every thread's registers (broadcast reads)
-		double a[21], iv[6];
+		// (1)+(2) by ONE wave (the others would only compete for issue slots with the same serial chain): the 6x6
+		// diagonal block factorised in every lane's registers (broadcast reads), then one lane per row below the block
+		// (the border row included) eliminates inside the block columns
+		if (tid < 64) {
+			double a[21], ivr[6];
 #pragma unroll
-		for (int i = 0; i < 6; ++i)
+			for (int i = 0; i < 6; ++i)
 #pragma unroll
-			for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = A[(c0 + i) * np + c0 + k];
-		bool bad = false;
+				for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = A[(c0 + i) * np + c0 + k];
+			bool bad = false;
 #pragma unroll
-		for (int j = 0; j < 6; ++j) {
-			const double d = a[j * (j + 1) / 2 + j];
-			bad |= !(d > 0.0);
-			iv[j] = rcp_f64(d);
+			for (int j = 0; j < 6; ++j) {
+				const double d = a[j * (j + 1) / 2 + j];
+				bad |= !(d > 0.0);
+				ivr[j] = rcp_f64(d);
 #pragma unroll
-			for (int i = j + 1; i < 6; ++i) {
-				const double t = a[i * (i + 1) / 2 + j] * iv[j];
+				for (int i = j + 1; i < 6; ++i) {
+					const double t = a[i * (i + 1) / 2 + j] * ivr[j];
 #pragma unroll
-				for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+					for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+				}
 			}
-		}
-		if (bad) return false;                            // uniform: every thread factorised the same block
-		// (2) panel: one thread per row below the block (the border row included) eliminates inside the block columns
-		for (int i = c0 + 6 + tid; i <= n; i += NT) {
-			double x[6];
+			for (int i = c0 + 6 + tid; i <= n; i += 64) {
+				double x[6];
 #pragma unroll
-			for (int k = 0; k < 6; ++k) x[k] = A[i * np + c0 + k];
+				for (int k = 0; k < 6; ++k) x[k] = A[i * np + c0 + k];
 #pragma unroll
-			for (int j = 0; j < 5; ++j) {
-				const double t = x[j] * iv[j];
+				for (int j = 0; j < 5; ++j) {
+					const double t = x[j] * ivr[j];
 #pragma unroll
-				for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+					for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+				}
+#pragma unroll
+				for (int k = 1; k < 6; ++k) A[i * np + c0 + k] = x[k];
 			}
+			if (tid == 0) {
+				s_ldl_bad = bad;
 #pragma unroll
-			for (int k = 1; k < 6; ++k) A[i * np + c0 + k] = x[k];
+				for (int i = 0; i < 6; ++i) {
+					inv[c0 + i] = ivr[i];
+#pragma unroll
+					for (int k = 0; k < i; ++k) A[(c0 + i) * np + c0 + k] = a[i * (i + 1) / 2 + k];
+				}
+			}
 		}
 		__syncthreads();
-		if (tid == 0) {
+		if (s_ldl_bad) return false;                      // uniform
+		double iv[6];
 #pragma unroll
-			for (int i = 0; i < 6; ++i) {
-				inv[c0 + i] = iv[i];
-#pragma unroll
-				for (int k = 0; k < i; ++k) A[(c0 + i) * np + c0 + k] = a[i * (i + 1) / 2 + k];
-			}
-		}
+		for (int c = 0; c < 6; ++c) iv[c] = inv[c0 + c];
 		// (3) trailing update A(i,k) -= sum_c U(i,c) U(k,c) / d_c, c0+6 <= k <= min(i, n-1), i <= n: 4 x 2 elements per
 		//     thread and pass, loads before stores
 		const int r0 = c0 + 6;
