@@ -83,6 +83,7 @@ enum {
 	SSK_STAGE_LM_SCHUR,        /* Schur complement */
 	SSK_STAGE_LM_SOLVE,        /* dense Cholesky + back-substitution */
 	SSK_STAGE_LM_UPDATE,       /* state update + error evaluation */
+	SSK_STAGE_CHANGE_IN_POSE,  /* cip_kernel: change-in-pose outlier filter */
 	SSK_STAGE_COUNT
 };
 int ssk_profile_enable(ssk_ctx* ctx, int on);     /* also clears the accumulated sums */
@@ -149,6 +150,50 @@ int ssk_da_filters(ssk_ctx* ctx, const ssk_dmatch* matches, int n_this, int n_ot
                    const float* this_xy, const float* other_xy, const ssk_da_params* params,
                    int32_t* status, int32_t* out_tracked);
 
+/* ---- B2, SURVEY 8(f) row 1: change-in-pose outlier filter -------------------------------------------
+ * Replaces m_detect_outliers_with_change_in_pose (EST.cpp:2113-2177), i.e. the tracked-pair marshalling
+ * (:2120-2133), stereo-vo's  m_voEngine.getChangeInPose(tracked_pairs, pre/cur matches and features,
+ * stereo_camera, odometry_result, initialPoseVector)  (:2139-2146; third-party, absent: a 6-DoF robust
+ * Gauss-Newton on the stereo reprojection error of the tracked pairs in two stages, parameters
+ * [LEAST_SQUARES] KITTI.ini:40-50) and the residual gate  out_residual[k0] > residual_th  (:2164-2176;
+ * residual_th KITTI.ini:119).  Algorithm contract: DESIGN.md "Change-in-pose contract" (P1-P6). */
+typedef struct ssk_cip_params {
+	double fx_l, fy_l, cx_l, cy_l, fx_r, fy_r, cx_r, cy_r, baseline;   /* srba_options.stereo_camera */
+	int32_t initial_max_iters;   /* KITTI.ini:41  iterations of the first stage (all tracked pairs) */
+	int32_t max_iters;           /* KITTI.ini:42  iterations of the refinement stage (first-stage inliers) */
+	int32_t max_incr_cost;       /* KITTI.ini:43  times the cost may grow before a stage stops */
+	int32_t use_robust_kernel;   /* KITTI.ini:49 */
+	double residual_threshold;   /* KITTI.ini:44  inlier gate between the stages (squared pixel norm) */
+	double min_mod_out_vector;   /* KITTI.ini:45  a stage stops when the step norm falls below this */
+	double kernel_param;         /* KITTI.ini:50  pseudo-Huber parameter */
+	int32_t bad_tracking_th;     /* KITTI.ini:47  fewer usable pairs than this: the estimate is invalid */
+	int32_t reserved;
+	double residual_th;          /* KITTI.ini:119 final gate: larger residual -> SSK_DA_REJ_CHANGE_POSE */
+} ssk_cip_params;
+
+typedef struct ssk_cip_result {
+	double pose[12];             /* row-major 3x4 [R|t]: the OTHER (previous) frame seen from THIS one (odometry_result.outPose) */
+	double cost;                 /* robustified cost of the second-stage inliers at the final pose */
+	int32_t valid;               /* odometry_result.valid */
+	int32_t iters_initial, iters_final;   /* odometry_result.num_it, num_it_final */
+	int32_t n_pairs, n_inliers, n_rejected;
+} ssk_cip_result;
+
+/* Host drop-in of m_detect_outliers_with_change_in_pose for one keyframe pair.  da_matches[k].trainIdx is the
+ * OTHER keyframe's match tracked by match k of THIS keyframe (this_matches.m_matches), status is
+ * this_matches.m_status (in/out).  init_pose: [R|t] 3x4 of the previous frame wrt the current one (the caller
+ * converts kf_ini_rel_pose, EST.cpp:2135-2137).  residuals (optional): out_residual per tracked pair, in order. */
+int ssk_da_change_in_pose(ssk_ctx* ctx, const ssk_kf_view* this_kf, const ssk_kf_view* other_kf,
+                          const ssk_dmatch* da_matches, int32_t* status, const double init_pose[12],
+                          const ssk_cip_params* params, double* residuals, ssk_cip_result* out);
+
+/* Known-geometry entry (what the kernel consumes; tests and the batched path use it): per match k of THIS
+ * keyframe the stereo observation this_obs[4k..] = (xl, yl, xr, yr), per match j of the OTHER keyframe
+ * other_obs[4j..]; train_idx / status as above (host arrays). */
+int ssk_cip_filter(ssk_ctx* ctx, const float* this_obs, int n_this, const float* other_obs, int n_other,
+                   const int32_t* train_idx, int32_t* status, const double init_pose[12],
+                   const ssk_cip_params* params, double* residuals, ssk_cip_result* out);
+
 /* ---- B1: stereo front-end ------------------------------------------------------------------------
  * Supplies the definition CStereoSLAMKF::create() lacks (declared KF.h:82-86, defined nowhere) and
  * replaces the live equivalent  m_voEngine.processNewImagePair() + getValues()
@@ -212,6 +257,13 @@ int ssk_kfbatch_debug_candidates(ssk_ctx* ctx, ssk_kfbatch* b, int kf, int eye, 
 int ssk_da_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
                      const ssk_da_params* params, int32_t* d_train_idx, int32_t* d_dist, int32_t* d_status,
                      int32_t* d_tracked);
+
+/* Batched change-in-pose filter on the outputs of ssk_da_run_batch (same pairs, same device arrays): d_status is
+ * updated in place, d_tracked recounted.  init_poses: host [n_pairs*12] or NULL (identity).  d_results: device
+ * array of n_pairs ssk_cip_result or NULL.  Asynchronous on the context stream. */
+int ssk_cip_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
+                      const ssk_cip_params* params, const double* init_poses, const int32_t* d_train_idx,
+                      int32_t* d_status, int32_t* d_tracked, ssk_cip_result* d_results);
 
 /* ---- B3: relative bundle adjustment, Levenberg-Marquardt with Schur complement + dense Cholesky ----
  * Replaces the numerical core of  rba.define_new_keyframe(listObs, newKFInfo, true)  (EST.cpp:782-784):

@@ -58,6 +58,13 @@ int ssko_propagate_ids(int n_matches, int n_sim, const int32_t* tracking_first,
                        const uint64_t* const* other_ids, uint64_t* last_match_id,
                        uint64_t* out_ids, int32_t* out_tracked_per_kf);
 
+/* ---------------- change-in-pose filter (oracle_cip.c): contract P1-P6 in that file ---------------- */
+/* this_obs / other_obs: (xl, yl, xr, yr) per match; train_idx[k] = other match of this match k; status in/out.
+ * residuals (optional): one per tracked pair, in match order.  Returns out->valid. */
+int ssko_change_in_pose(const float* this_obs, int n_this, const float* other_obs, int n_other,
+                        const int32_t* train_idx, int32_t* status, const double init_pose[12],
+                        const ssk_cip_params* P, double* residuals, ssk_cip_result* out);
+
 /* ---------------- landmark initialisation (oracle_geom.c) ---------------- */
 
 typedef struct ssko_stereo_cam {   /* mrpt::utils::TStereoCamera fields the path reads */

@@ -82,6 +82,19 @@ class DaParams(C.Structure):
                 ("rows_offset", C.c_int32), ("max_orb_distance_da", C.c_float)]
 
 
+class CipParams(C.Structure):
+    """ssk_cip_params: change-in-pose filter ([LEAST_SQUARES] and residual_th of the reference ini)."""
+    _fields_ = [(n, C.c_double) for n in ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")] + [
+        ("initial_max_iters", C.c_int32), ("max_iters", C.c_int32), ("max_incr_cost", C.c_int32), ("use_robust_kernel", C.c_int32),
+        ("residual_threshold", C.c_double), ("min_mod_out_vector", C.c_double), ("kernel_param", C.c_double),
+        ("bad_tracking_th", C.c_int32), ("reserved", C.c_int32), ("residual_th", C.c_double)]
+
+
+class CipResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 12), ("cost", C.c_double), ("valid", C.c_int32), ("iters_initial", C.c_int32),
+                ("iters_final", C.c_int32), ("n_pairs", C.c_int32), ("n_inliers", C.c_int32), ("n_rejected", C.c_int32)]
+
+
 class FrontendParams(C.Structure):
     _fields_ = [("n_feats", C.c_int32), ("fast_threshold", C.c_int32), ("n_levels", C.c_int32),
                 ("nms_radius", C.c_int32), ("orb_max_distance", C.c_int32), ("max_y_diff", C.c_float),
@@ -392,6 +405,38 @@ class Context:
         self._chk(self.lib.ssk_da_run_batch(self.h, this_b.h_, other_b.h_, _ptr(pr), len(pr), C.byref(params),
                                             _dev(d_idx), _dev(d_dist), _dev(d_status), _dev(d_tracked)))
 
+    def cip_run_batch(self, this_b, other_b, pairs, params, d_idx, d_status, d_tracked, init_poses=None, d_results=None):
+        pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        ip = None if init_poses is None else np.ascontiguousarray(init_poses, np.float64).reshape(len(pr), 12)
+        self._chk(self.lib.ssk_cip_run_batch(self.h, this_b.h_, other_b.h_, _ptr(pr), len(pr), C.byref(params),
+                                             None if ip is None else _ptr(ip), _dev(d_idx), _dev(d_status), _dev(d_tracked),
+                                             None if d_results is None else _dev(d_results)))
+
+    def cip_filter(self, this_obs, other_obs, train_idx, status, init_pose, params):
+        """ssk_cip_filter on host arrays: returns (status after the filter, residuals of the tracked pairs, CipResult)."""
+        to = np.ascontiguousarray(this_obs, np.float32).reshape(-1, 4)
+        oo = np.ascontiguousarray(other_obs, np.float32).reshape(-1, 4)
+        ti = np.ascontiguousarray(train_idx, np.int32)
+        st = np.ascontiguousarray(status, np.int32).copy()
+        n_trk = int((st == 0).sum())
+        T = np.ascontiguousarray(init_pose, np.float64).reshape(12)
+        res = np.zeros(len(to) + 1)
+        out = CipResult()
+        self._chk(self.lib.ssk_cip_filter(self.h, _ptr(to), len(to), _ptr(oo), len(oo), _ptr(ti), _ptr(st), _ptr(T), C.byref(params),
+                                          _ptr(res), C.byref(out)))
+        return st, res[:n_trk].copy(), out
+
+    def da_change_in_pose(self, this_view, other_view, da_matches, status, init_pose, params):
+        m = np.ascontiguousarray(da_matches, DMATCH_DTYPE)
+        st = np.ascontiguousarray(status, np.int32).copy()
+        n_trk = int((st == 0).sum())
+        T = np.ascontiguousarray(init_pose, np.float64).reshape(12)
+        res = np.zeros(len(m) + 1)
+        out = CipResult()
+        self._chk(self.lib.ssk_da_change_in_pose(self.h, C.byref(this_view), C.byref(other_view), _ptr(m), _ptr(st), _ptr(T),
+                                                 C.byref(params), _ptr(res), C.byref(out)))
+        return st, res[:n_trk].copy(), out
+
     # -- B3 ------------------------------------------------------------------------------------------
     def build_observations(self, kp_left, kp_right, matches, lm_params):
         kl = np.ascontiguousarray(kp_left, KEYPOINT_DTYPE)
@@ -410,7 +455,7 @@ class Context:
         self._chk(self.lib.ssk_profile_enable(self.h, int(on)))
 
     def profile_read(self):
-        n = 10
+        n = 11
         ms = (C.c_double * n)()
         calls = (C.c_int64 * n)()
         self._chk(self.lib.ssk_profile_read(self.h, ms, calls))

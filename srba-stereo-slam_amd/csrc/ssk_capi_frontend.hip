@@ -64,6 +64,7 @@ int batch_create(ssk_ctx* ctx, int n_kf, int w, int h, int max_feats, ssk_kfbatc
 	if (!rc) rc = dev_alloc(ctx, &b->nm, (size_t)n_kf);
 	if (!rc) rc = dev_alloc(ctx, &b->m_row, nk);
 	if (!rc) rc = dev_alloc(ctx, &b->m_xy, nk);
+	if (!rc) rc = dev_alloc(ctx, &b->m_obs, nk);
 	if (rc) { ssk_kfbatch_destroy(b); return rc; }
 	hipError_t e = hipMemsetAsync(b->img, 0, ni * h * b->pitch + 256, ctx->stream);
 	if (e == hipSuccess) e = hipMemsetAsync(b->nkp, 0, ni * 4, ctx->stream);
@@ -116,7 +117,7 @@ void ssk_kfbatch_destroy(ssk_kfbatch* b)
 	if (!b) return;
 	if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
 	void* ptrs[] = {b->img, b->cand, b->ncand, b->kp_xy, b->kp_resp, b->kp_angle, b->kp_cs, b->nkp, b->desc,
-	                b->m_q, b->m_t, b->m_d, b->nm, b->m_row, b->m_xy};
+	                b->m_q, b->m_t, b->m_d, b->nm, b->m_row, b->m_xy, b->m_obs};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
 	delete b;
 }
@@ -282,6 +283,39 @@ int ssk_da_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, co
 	return ssk_launch_da_filters(ctx, d_train_idx, d_dist, o_beg, q_beg, q_end, t_beg, t_end,
 	                             reinterpret_cast<const float*>(this_b->m_xy), reinterpret_cast<const float*>(other_b->m_xy),
 	                             n_pairs, *params, d_status, d_tracked);
+}
+
+int ssk_cip_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
+                      const ssk_cip_params* params, const double* init_poses, const int32_t* d_train_idx,
+                      int32_t* d_status, int32_t* d_tracked, ssk_cip_result* d_results)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!this_b || !other_b || n_pairs < 0 || !params || (n_pairs > 0 && (!pairs || !d_train_idx || !d_status || !d_tracked)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_cip_run_batch: bad argument");
+	if (this_b->max_feats != other_b->max_feats)
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_cip_run_batch: batches differ in max_feats");
+	if (n_pairs == 0) return SSK_OK;
+	for (int p = 0; p < n_pairs; ++p)
+		if (pairs[2 * p] < 0 || pairs[2 * p] >= this_b->n_kf || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= other_b->n_kf)
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_cip_run_batch: pair %d references a keyframe outside its batch", p);
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad((size_t)n_pairs * 8) + ssk_pad((size_t)n_pairs * 20) + ssk_pad((size_t)n_pairs * 96) + 4 * 256))) return rc;
+	ssk_arena_reset(ctx->dev);
+	int32_t* d_pairs = ssk_arena_take<int32_t>(ctx->dev, (size_t)n_pairs * 2);
+	int32_t* d_r = ssk_arena_take<int32_t>(ctx->dev, (size_t)n_pairs * 5);
+	double* d_init = nullptr;
+	SSK_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, ctx->stream));
+	if (init_poses) {
+		d_init = ssk_arena_take<double>(ctx->dev, (size_t)n_pairs * 12);
+		SSK_HIP(ctx, hipMemcpyAsync(d_init, init_poses, sizeof(double) * 12 * (size_t)n_pairs, hipMemcpyHostToDevice, ctx->stream));
+	}
+	const int N = this_b->max_feats;
+	hipLaunchKernelGGL(da_ranges_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, ctx->stream, d_pairs, n_pairs, N,
+	                   this_b->nm, other_b->nm, d_r);
+	SSK_LAUNCH_CHECK(ctx, "da_ranges_kernel");
+	return ssk_launch_cip(ctx, d_train_idx, d_status, d_r + 4 * n_pairs, d_r, d_r + n_pairs, d_r + 2 * n_pairs, this_b->m_obs, other_b->m_obs,
+	                      d_init, n_pairs, N, *params, nullptr, d_results, d_tracked);
 }
 
 }  // extern "C"

@@ -29,9 +29,15 @@ struct ssk_kfbatch {
 	// and its pixel coordinates per L<->R match, written by the stereo kernel
 	int32_t* m_row = nullptr;    // [B][N]   absolute descriptor row of the match's left keypoint
 	float2* m_xy = nullptr;      // [B][N]   left keypoint pixel of the match
+	float4* m_obs = nullptr;     // [B][N]   stereo observation (xl, yl, xr, yr) of the match (change-in-pose filter)
 };
 
 int ssk_launch_fast(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, int threshold);
 int ssk_launch_select(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, const ssk_frontend_params& p);
 int ssk_launch_describe(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, int n_feats);
 int ssk_launch_stereo(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, const ssk_frontend_params& p);
+// change-in-pose filter over pairs (ssk_cip.hip); obs arrays are indexed by match slot (kf * max_feats + k)
+int ssk_launch_cip(ssk_ctx* ctx, const int32_t* d_train_idx, int32_t* d_status, const int32_t* d_out_beg, const int32_t* d_q_beg,
+                   const int32_t* d_q_end, const int32_t* d_t_beg, const float4* d_this_obs, const float4* d_other_obs,
+                   const double* d_init_poses, int n_pairs, int cap, const ssk_cip_params& prm, double* d_residuals, ssk_cip_result* d_results,
+                   int32_t* d_tracked);

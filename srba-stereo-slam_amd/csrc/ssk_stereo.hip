@@ -24,7 +24,7 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
                          const uint8_t* __restrict__ desc, float max_y_diff, float min_disp, float max_disp,
                          int orb_max_distance,
                          int32_t* __restrict__ m_q, int32_t* __restrict__ m_t, int32_t* __restrict__ m_d,
-                         int32_t* __restrict__ nm, int32_t* __restrict__ m_row, float2* __restrict__ m_xy)
+                         int32_t* __restrict__ nm, int32_t* __restrict__ m_row, float2* __restrict__ m_xy, float4* __restrict__ m_obs)
 {
 	__shared__ uint4 s_desc[TT * 2];
 	__shared__ short2 s_rxy[TT];
@@ -117,6 +117,8 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
 			m_row[ob + pos] = il * max_feats + li;
 			const short2 p = xl[li];
 			m_xy[ob + pos] = make_float2((float)p.x, (float)p.y);
+			const short2 pr = xr[mine[e] & 0xFFFFu];
+			m_obs[ob + pos] = make_float4((float)p.x, (float)p.y, (float)pr.x, (float)pr.y);
 			++pos;
 		}
 	}
@@ -132,7 +134,7 @@ int ssk_launch_stereo(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, co
 	ssk_stage_scope prof(ctx, SSK_STAGE_STEREO);
 	hipLaunchKernelGGL(stereo_match_kernel, dim3(nkf), dim3(NT), 0, ctx->stream, kf_begin, b->max_feats, b->kp_xy,
 	                   b->nkp, b->desc, p.max_y_diff, p.min_disparity, p.max_disparity, p.orb_max_distance,
-	                   b->m_q, b->m_t, b->m_d, b->nm, b->m_row, b->m_xy);
+	                   b->m_q, b->m_t, b->m_d, b->nm, b->m_row, b->m_xy, b->m_obs);
 	SSK_LAUNCH_CHECK(ctx, "stereo_match_kernel");
 	return SSK_OK;
 }

@@ -52,6 +52,27 @@ def trim_kf_out(o, arrs):
                 matches=arrs["matches"][:o.n_matches].copy())
 
 
+class CipParams(C.Structure):
+    """ssk_cip_params (include/ssk_capi.h); defaults = [LEAST_SQUARES] / residual_th of demo/config_imgdir_kitti_srba.ini."""
+    _fields_ = [(n, C.c_double) for n in ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")] + [
+        ("initial_max_iters", C.c_int32), ("max_iters", C.c_int32), ("max_incr_cost", C.c_int32), ("use_robust_kernel", C.c_int32),
+        ("residual_threshold", C.c_double), ("min_mod_out_vector", C.c_double), ("kernel_param", C.c_double),
+        ("bad_tracking_th", C.c_int32), ("reserved", C.c_int32), ("residual_th", C.c_double)]
+
+
+class CipResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 12), ("cost", C.c_double), ("valid", C.c_int32), ("iters_initial", C.c_int32),
+                ("iters_final", C.c_int32), ("n_pairs", C.c_int32), ("n_inliers", C.c_int32), ("n_rejected", C.c_int32)]
+
+
+def kitti_cip_params(**over):
+    d = dict(fx_l=707.0912, fy_l=707.0912, cx_l=601.8873, cy_l=183.1104, fx_r=707.0912, fy_r=707.0912, cx_r=601.8873,
+             cy_r=183.1104, baseline=0.54, initial_max_iters=30, max_iters=30, max_incr_cost=3, use_robust_kernel=1,
+             residual_threshold=15.0, min_mod_out_vector=0.001, kernel_param=2.0, bad_tracking_th=5, reserved=0, residual_th=30.0)
+    d.update(over)
+    return CipParams(**d)
+
+
 class StereoCam(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")]
@@ -200,6 +221,19 @@ class Oracle:
         dp = dpc[:n * 6 * win.E].reshape(n, 6 * win.E) if win.E else np.zeros((n, 0))
         df = dfc[:n * 3 * win.L].reshape(n, 3 * win.L) if win.L else np.zeros((n, 0))
         return dict(poses=poses, lms=lms, res=res, trace=list(tr)[:res.iters], dp=dp[:res.iters], df=df[:res.iters])
+
+    def change_in_pose(self, this_obs, other_obs, train_idx, status, init_pose, prm):
+        """Returns (status after the filter, residuals of the tracked pairs, CipResult)."""
+        to = np.ascontiguousarray(this_obs, np.float32).reshape(-1, 4)
+        oo = np.ascontiguousarray(other_obs, np.float32).reshape(-1, 4)
+        ti = np.ascontiguousarray(train_idx, np.int32)
+        st = np.ascontiguousarray(status, np.int32).copy()
+        T = np.ascontiguousarray(init_pose, np.float64).reshape(12)
+        res = np.zeros(len(to) + 1)
+        out = CipResult()
+        self.lib.ssko_change_in_pose.restype = C.c_int
+        self.lib.ssko_change_in_pose(_p(to), len(to), _p(oo), len(oo), _p(ti), _p(st), _p(T), C.byref(prm), _p(res), C.byref(out))
+        return st, res[:out.n_pairs].copy(), out
 
     def project_match_to_3d(self, ul, vl, ur, cam):
         out = (C.c_double * 3)()
