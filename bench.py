@@ -4,7 +4,8 @@
 One "step" = one pass of the whole per-keyframe hot path over a batch of B synthetic KITTI-shaped keyframes that
 is already resident in HBM when the timed region starts:
     stereo front-end (FAST+NMS scan, selection, orientation+BRIEF, L<->R match)          [seam B1]
-  + keyframe<->previous-keyframe data association (Hamming K=1 + direction/ORB filters)  [seam B2]
+  + keyframe<->previous-keyframe data association (Hamming K=1 + direction/ORB filters
+    + change-in-pose filter)                                                            [seam B2]
   + one relative-BA LM solve per keyframe on a BASELINE configs[2]-shaped window         [seam B3]
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), keyframe streams are partitioned one
 batch per GPU (weak scaling) and each step ends with ONE all-gather of the shared-landmark blocks.
@@ -59,7 +60,8 @@ def params(capi, sl):
     da = capi.DaParams(1, 1, H, 60.0)
     lp = capi.LmParams()
     C.memmove(C.byref(lp), C.byref(sl.make_params()), C.sizeof(lp))
-    return fp, da, lp
+    cp = capi.CipParams(**synth.KITTI_CIP)
+    return fp, da, lp, cp
 
 
 def cpu_baseline(sample_kf, wins):
@@ -76,6 +78,8 @@ def cpu_baseline(sample_kf, wins):
     fp = ol.FrontendParams(**synth.KITTI_FRONTEND)
     da = ol.DaParams(1, 1, H, 60.0)
     lp = sl.make_params()
+    cipp = ol.kitti_cip_params()
+    ident = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(12)
     pat = ol.default_pattern()
     base = [synth.synth_stereo_pair(i) for i in range(4)]
     prev_kf = [oracle.frontend(np.roll(l, (2, -3), (0, 1)), np.roll(r, (2, -3), (0, 1)), fp, pat) for l, r in base]
@@ -88,7 +92,13 @@ def cpu_baseline(sample_kf, wins):
         b = time.perf_counter()
         va, _ka = ol.make_kf_view(**kf)
         vb, _kb = ol.make_kf_view(**prev_kf[k % len(base)])
-        oracle.data_association(va, vb, da)
+        _m, st, _n = oracle.data_association(va, vb, da)
+
+        def stereo_obs(k):
+            m = k["matches"]
+            return np.stack([k["kp_left"]["x"][m["queryIdx"]], k["kp_left"]["y"][m["queryIdx"]],
+                             k["kp_right"]["x"][m["trainIdx"]], k["kp_right"]["y"][m["trainIdx"]]], 1)
+        oracle.change_in_pose(stereo_obs(kf), stereo_obs(prev_kf[k % len(base)]), _m["trainIdx"], st, ident, cipp)
         c = time.perf_counter()
         oracle.lm_solve(wins[k % len(wins)], lp, trace=False)
         d = time.perf_counter()
@@ -134,7 +144,7 @@ def main():
     ctx_lm = pkg.Context(local, stream=lm_stream.cuda_stream) if args.overlap else ctx
     B = args.batch
     cur, prev, lm, wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank)
-    fp, da, lp = params(capi, sl)
+    fp, da, lp, cp = params(capi, sl)
     pairs = np.stack([np.arange(B), np.arange(B)], 1).astype(np.int32)
     dev = torch.device("cuda", local)
     N = 512
@@ -153,6 +163,7 @@ def main():
     def step(serial=False):
         cur.run_frontend(fp)
         ctx.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
+        ctx.cip_run_batch(cur, prev, pairs, cp, d_idx, d_st, d_tr)           # change-in-pose outlier filter on the DA verdicts
         if serial:
             torch.cuda.synchronize()      # profile pass: one kernel at a time, clean per-kernel durations
         lm.reset()
@@ -244,7 +255,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]+[2] per keyframe: 1241x376 stereo pair -> ORB(N=500, FAST 20, 1 level) + L<->R "
-                            "(max_y_diff 2, orb_max_distance 60) + KF<->KF Hamming DA with direction/ORB filters + SRBA LM window "
+                            "(max_y_diff 2, orb_max_distance 60) + KF<->KF Hamming DA with direction/ORB/change-in-pose filters + SRBA LM window "
                             "(200-KF/5k-landmark submap, submap_size 10, max_tree_depth 4, window = 10 most recent edges)",
                 "keyframes_per_gpu_per_step": B,
                 "streams": "front-end + DA on one HIP stream, LM solves on a second one" if args.overlap else "one HIP stream",

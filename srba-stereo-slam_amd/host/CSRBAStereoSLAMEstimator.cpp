@@ -50,6 +50,16 @@ void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& 
 	const ssk_kf_view a = this_kf.view(), b = other_kf.view();
 	const ssk_da_params p = srba_options.da();
 	m_ctx.check(ssk_data_association(m_ctx.get(), &a, &b, &p, matches.data(), status.data(), &tracked), "m_internal_data_association");
+	// stage 2 (EST.cpp:1587-1640).  The fundamental-matrix filter (RANSAC) is not built; the change-in-pose filter is
+	// (m_detect_outliers_with_change_in_pose, :2113-2177), started from the identity: keyframe-to-keyframe motion is small
+	// against the scene depth, and the estimator converges from there
+	if (srba_options.da_filter_by_pose_change) {
+		if (tracked < 15) return;                                                        // :1617-1621  "not enough input data": invalid
+		const ssk_cip_params cp = srba_options.cip();
+		const double identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+		ssk_cip_result cr;
+		m_ctx.check(ssk_da_change_in_pose(m_ctx.get(), &a, &b, matches.data(), status.data(), identity, &cp, nullptr, &cr), "m_detect_outliers_with_change_in_pose");
+	}
 	for (size_t k = 0; k < n; ++k)                                                       // :1657-1669
 		if (status[k] == SSK_DA_TRACKED) {
 			out_da.tracking_info[k] = std::make_pair((size_t)matches[k].trainIdx, (double)matches[k].distance);

@@ -32,8 +32,13 @@ struct TSRBAStereoSLAMOptions {                // UTIL.h:221-487
 	// inter-frame match / data association
 	double ransac_fit_prob = 0.95, max_y_diff_epipolar = 1.5, max_orb_distance_da = 60;
 	bool da_filter_by_direction = false, da_filter_by_orb_distance = true;
-	bool da_filter_by_fund_matrix = true, da_filter_by_pose_change = true;   // host-side "next" rows: not run here
+	bool da_filter_by_fund_matrix = true;      // SURVEY 8(f) row 3 (RANSAC, RNG dependent): not built, never run here
+	bool da_filter_by_pose_change = true;      // ssk_da_change_in_pose
 	double residual_th = 50;
+	// stereo-vo [LEAST_SQUARES] section (KITTI.ini:40-50), used by getChangeInPose
+	int ls_initial_max_iters = 10, ls_max_iters = 100, ls_max_incr_cost = 3, ls_bad_tracking_th = 5;
+	double ls_residual_threshold = 1.0, ls_min_mod_out_vector = 0.001, ls_kernel_param = 3.0;
+	bool ls_use_robust_kernel = true;
 	bool use_initial_pose = true;
 	// SRBA
 	double srba_kernel_param = 3.0;
@@ -49,6 +54,8 @@ struct TSRBAStereoSLAMOptions {                // UTIL.h:221-487
 		o.max_y_diff = 2.f; o.orb_max_distance = 60;                                                               // :17,24
 		o.max_orb_distance_da = 60; o.max_y_diff_epipolar = 2.0; o.ransac_fit_prob = 0.95; o.residual_th = 30;      // :119-122
 		o.da_filter_by_direction = true;                                                                           // :124
+		o.ls_initial_max_iters = 30; o.ls_max_iters = 30; o.ls_max_incr_cost = 3; o.ls_residual_threshold = 15;     // :41-44
+		o.ls_min_mod_out_vector = 0.001; o.ls_bad_tracking_th = 5; o.ls_use_robust_kernel = true; o.ls_kernel_param = 2;   // :45-50
 		o.srba_max_tree_depth = 4; o.srba_max_optimize_depth = 5; o.srba_submap_size = 10;                          // :104-106
 		o.srba_use_robust_kernel = true; o.srba_use_robust_kernel_stage1 = true; o.srba_kernel_param = 1.5;         // :107-109
 		o.updated_matches_th = 60; o.use_initial_pose = true;                                                       // :128,133
@@ -74,6 +81,18 @@ struct TSRBAStereoSLAMOptions {                // UTIL.h:221-487
 		ssk_da_params p;
 		p.filter_by_direction = da_filter_by_direction; p.filter_by_orb_distance = da_filter_by_orb_distance;
 		p.rows_offset = stereo_camera.nrows; p.max_orb_distance_da = (float)max_orb_distance_da;
+		return p;
+	}
+	ssk_cip_params cip() const
+	{
+		ssk_cip_params p{};
+		const TStereoCamera& c = stereo_camera;
+		p.fx_l = c.fx_l; p.fy_l = c.fy_l; p.cx_l = c.cx_l; p.cy_l = c.cy_l;
+		p.fx_r = c.fx_r; p.fy_r = c.fy_r; p.cx_r = c.cx_r; p.cy_r = c.cy_r; p.baseline = c.baseline;
+		p.initial_max_iters = ls_initial_max_iters; p.max_iters = ls_max_iters; p.max_incr_cost = ls_max_incr_cost;
+		p.use_robust_kernel = ls_use_robust_kernel; p.residual_threshold = ls_residual_threshold;
+		p.min_mod_out_vector = ls_min_mod_out_vector; p.kernel_param = ls_kernel_param; p.bad_tracking_th = ls_bad_tracking_th;
+		p.residual_th = residual_th;
 		return p;
 	}
 	ssk_lm_params lm(bool robust) const

@@ -66,9 +66,8 @@ class CipResult(C.Structure):
 
 
 def kitti_cip_params(**over):
-    d = dict(fx_l=707.0912, fy_l=707.0912, cx_l=601.8873, cy_l=183.1104, fx_r=707.0912, fy_r=707.0912, cx_r=601.8873,
-             cy_r=183.1104, baseline=0.54, initial_max_iters=30, max_iters=30, max_incr_cost=3, use_robust_kernel=1,
-             residual_threshold=15.0, min_mod_out_vector=0.001, kernel_param=2.0, bad_tracking_th=5, reserved=0, residual_th=30.0)
+    import synth
+    d = dict(synth.KITTI_CIP)
     d.update(over)
     return CipParams(**d)
 

@@ -128,3 +128,9 @@ def synth_translation_sequence(seed, n_frames, w=W, h=H, noise=1.0, d_max=40):
 
 KITTI_FRONTEND = dict(n_feats=500, fast_threshold=20, n_levels=1, nms_radius=2, orb_max_distance=60,
                       max_y_diff=2.0, min_disparity=1.0, max_disparity=128.0, harris_k=0.04)   # disparity 128 = 3 m at fx*b = 382
+
+
+# change-in-pose filter parameters: stereo camera + [LEAST_SQUARES] (KITTI.ini:40-50) + residual_th (KITTI.ini:119)
+KITTI_CIP = dict(fx_l=707.0912, fy_l=707.0912, cx_l=601.8873, cy_l=183.1104, fx_r=707.0912, fy_r=707.0912, cx_r=601.8873,
+                 cy_r=183.1104, baseline=0.54, initial_max_iters=30, max_iters=30, max_incr_cost=3, use_robust_kernel=1,
+                 residual_threshold=15.0, min_mod_out_vector=0.001, kernel_param=2.0, bad_tracking_th=5, reserved=0, residual_th=30.0)
