@@ -42,8 +42,18 @@ def make_lm(oracle):
                         final_poses=out["poses"], final_lms=out["lms"])
 
 
+def make_cip(oracle):
+    import synth_cip as sc
+    c = sc.make_case(11, n_this=240, n_other=260, n_outliers=18)
+    st, res, out = oracle.change_in_pose(c["this_obs"], c["other_obs"], c["train_idx"], c["status"], sc.identity_pose(), ol.kitti_cip_params())
+    np.savez_compressed(os.path.join(HERE, "cip_case0.npz"), this_obs=c["this_obs"], other_obs=c["other_obs"], train_idx=c["train_idx"],
+                        status=c["status"], exp_status=st, exp_residuals=res, exp_pose=np.array(out.pose[:]),
+                        exp_iters=np.array([out.iters_initial, out.iters_final, out.n_inliers, out.n_rejected], np.int32))
+
+
 if __name__ == "__main__":
     o = ol.load()
     make_da(o)
     make_lm(o)
+    make_cip(o)
     print("golden fixtures written to", HERE)

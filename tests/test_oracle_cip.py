@@ -1,10 +1,14 @@
 """CPU: the oracle's change-in-pose filter (oracle/oracle_cip.c, contract P1-P6) against known answers: it recovers a
 known motion, flags the gross outliers and nothing else, leaves already rejected matches alone, and follows the literal
 in-tree rules of EST.cpp:2113-2177 (invalid estimate => every tracked match rejected)."""
+import os
+
 import numpy as np
 
 import oracle_lib as ol
 import synth_cip as sc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def test_recovers_motion_and_flags_outliers(oracle):
@@ -46,3 +50,12 @@ def test_good_initial_pose_needs_fewer_iterations(oracle):
     _, _, warm = oracle.change_in_pose(c["this_obs"], c["other_obs"], c["train_idx"], c["status"], T0, ol.kitti_cip_params())
     assert warm.valid and cold.valid and warm.iters_initial <= cold.iters_initial
     assert np.abs(np.array(warm.pose[:]) - np.array(cold.pose[:])).max() < 1e-3
+
+
+def test_golden_cip(oracle):
+    """committed fixture (tests/golden/make_golden.py): guards the oracle against regressions; not a reference output."""
+    g = np.load(os.path.join(GOLD, "cip_case0.npz"))
+    st, res, out = oracle.change_in_pose(g["this_obs"], g["other_obs"], g["train_idx"], g["status"], sc.identity_pose(), ol.kitti_cip_params())
+    assert np.array_equal(st, g["exp_status"])
+    assert [out.iters_initial, out.iters_final, out.n_inliers, out.n_rejected] == list(g["exp_iters"])
+    assert np.allclose(res, g["exp_residuals"], rtol=1e-9, atol=1e-12) and np.allclose(np.array(out.pose[:]), g["exp_pose"], rtol=0, atol=1e-12)
