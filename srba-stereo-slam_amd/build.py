@@ -77,8 +77,15 @@ def build_host(verbose=True):
     """C++ facade (host/) + its demo driver, linked against libssk_hip.so (rpath: the package directory)."""
     host = os.path.join(HERE, "host")
     out = os.path.join(host, "facade_demo")
-    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp")]
-    deps = srcs + [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")] + [LIB]
+    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp") and not f.endswith("_tool.cpp")]
+    hdrs = [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")]
+    deps = srcs + hdrs + [LIB]
+    # CPU-only driver of the keyframe record I/O (host/ssk_kf_io.h), no GPU library needed
+    tool, tool_src = os.path.join(host, "kf_io_tool"), os.path.join(host, "kf_io_tool.cpp")
+    if not os.path.exists(tool) or os.path.getmtime(tool) < max(os.path.getmtime(d) for d in hdrs + [tool_src]):
+        r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), tool_src, "-o", tool], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("kf_io_tool build failed:\n%s" % r.stderr)
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
         return out
     cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")] + srcs + \

@@ -1,5 +1,7 @@
 // CSRBAStereoSLAMEstimator.cpp -- see the header.  EST.cpp = reference src/CSRBAStereoSLAMEstimator.cpp.
 #include "CSRBAStereoSLAMEstimator.h"
+#include "ssk_kf_io.h"
+#include <fstream>
 #include <algorithm>
 #include <cstdio>
 #include <iostream>
@@ -164,6 +166,28 @@ TNewKeyFrameInfo CSRBAStereoSLAMEstimator::processKeyframe(const StereoImages& s
 		std::cout << "   Created KF #" << newKFInfo.kf_id << " | # kf-to-kf edges created: " << newKFInfo.created_edge_ids.size() << std::endl
 		          << "   Optimization error: " << newKFInfo.optimize_results.total_sqr_error_init << " -> " << newKFInfo.optimize_results.total_sqr_error_final << std::endl;
 	return newKFInfo;
+}
+
+bool CSRBAStereoSLAMEstimator::saveKeyframes(const std::string& path) const
+{
+	std::ofstream f(path, std::ios::binary);
+	if (!f) return false;
+	kfio::put<uint64_t>(f, (uint64_t)m_keyframes.size());                                // EST.cpp:2678-2679
+	for (const CStereoSLAMKF& kf : m_keyframes)
+		if (!kfio::dump_keyframe(f, kf)) return false;
+	return (bool)f;
+}
+
+bool CSRBAStereoSLAMEstimator::loadKeyframes(const std::string& path)
+{
+	std::ifstream f(path, std::ios::binary);
+	uint64_t n = 0;
+	if (!f || !kfio::get(f, n) || n > (1u << 20)) return false;
+	t_vector_kf kfs((size_t)n);
+	for (CStereoSLAMKF& kf : kfs)
+		if (!kfio::load_keyframe(f, kf)) return false;
+	m_keyframes.swap(kfs);
+	return true;
 }
 
 }  // namespace ssk

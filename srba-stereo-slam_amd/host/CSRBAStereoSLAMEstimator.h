@@ -39,10 +39,15 @@ public:
 	TNewKeyFrameInfo processKeyframe(const StereoImages& stImgs, const std::vector<size_t>& similar_kfs = std::vector<size_t>(),
 	                                 const Pose3D& incr_pose = Pose3D());
 
-	// EST.cpp:1341-1411 / 1413-1727 (up to the ORB-distance filter; the fundamental-matrix and change-in-pose
-	// stages are host-side "next" rows and are not run)
+	// EST.cpp:1341-1411 / 1413-1727: Hamming + direction + ORB-distance filters, then the change-in-pose filter
+	// (EST.cpp:2113-2177); the fundamental-matrix stage (RANSAC) is not built and not run
 	void m_data_association(const CStereoSLAMKF& kf, const std::vector<size_t>& similar_kfs, TVectorKfsDaInfo& out_da);
 	void m_internal_data_association(const CStereoSLAMKF& this_kf, const CStereoSLAMKF& other_kf, t_kf_da_info& out_da);
+
+	// the keyframe section of the reference's state file (EST.cpp:2678-2700 / 2311-2346): number of keyframes, then per
+	// keyframe id, camera pose, left features, right features, matches -- byte layout of ssk_kf_io.h
+	bool saveKeyframes(const std::string& path) const;
+	bool loadKeyframes(const std::string& path);
 
 	int currentFASTThreshold() const { return m_fast_th; }
 	int currentORBThreshold() const { return m_orb_th; }

@@ -59,6 +59,15 @@ int main(int argc, char** argv)
 		}
 		std::printf("landmarks %zu edges %zu last_match_id %zu\n", est.rba.get_rba_state().unknown_lms.size(),
 		            est.rba.get_rba_state().k2k_edges.size(), est.lastMatchID());
+		if (g.debug) {                                             // keyframe section of the reference's state file
+			const std::string f = g.out_dir + "/keyframes.kfrec";
+			ssk::CSRBAStereoSLAMEstimator back(ctx, opts, g);
+			if (!est.saveKeyframes(f) || !back.loadKeyframes(f) || back.m_keyframes.size() != est.m_keyframes.size()) {
+				std::fprintf(stderr, "keyframe record round trip failed\n");
+				return 4;
+			}
+			std::printf("saved %zu keyframes to %s\n", est.m_keyframes.size(), f.c_str());
+		}
 	} catch (const std::exception& e) {     // MAIN.cpp:66-75
 		std::fprintf(stderr, "EXCEPTION: %s\n", e.what());
 		return 1;

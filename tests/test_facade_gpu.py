@@ -44,6 +44,8 @@ def test_facade_sequence(tmp_path, oracle):
     pat = ol.default_pattern()
     for k, (l, r) in enumerate(frames):
         exp = oracle.frontend(l, r, prm, pat)
+        if k == 0:
+            exp0 = exp
         assert int(rows[k]["fast_th"]) == 20                      # >= 120 matches: the adaptive loop stays at detect_fast_th
         assert (int(rows[k]["nl"]), int(rows[k]["nr"]), int(rows[k]["matches"])) == (len(exp["kp_left"]), len(exp["kp_right"]), len(exp["matches"]))
         # the reference's debug dump format (KF.cpp:77-91): kf_id match_id xl yl xr yr dist
@@ -63,6 +65,14 @@ def test_facade_sequence(tmp_path, oracle):
     a = np.loadtxt(os.path.join(tmp_path, "da_info_0001.txt"))
     b = np.loadtxt(os.path.join(tmp_path, "info_kf0000.txt"), comments="%")
     assert len(set(a[:, 0]) & set(b[:, 1])) >= 60
+    # keyframes.kfrec = the keyframe section of the reference's state file (EST.cpp:2678-2700), parsed independently
+    import test_kf_io
+    buf = open(os.path.join(tmp_path, "keyframes.kfrec"), "rb").read()
+    assert int(np.frombuffer(buf, "<u8", 1)[0]) == n and "saved %d keyframes" % n in out
+    # the first record holds keyframe 0 exactly as the front-end produced it (checked against the oracle above)
+    off = 8
+    kp_l = np.frombuffer(buf, test_kf_io.KP, int(np.frombuffer(buf, "<u8", 1, off + 8 + 48)[0]), off + 8 + 48 + 8)
+    assert np.array_equal(kp_l["x"], exp0["kp_left"]["x"]) and np.array_equal(kp_l["angle"], exp0["kp_left"]["angle"])
 
 
 def test_facade_too_few_matches_throws(tmp_path):
