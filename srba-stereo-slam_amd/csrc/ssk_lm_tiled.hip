@@ -98,9 +98,20 @@ __device__ __forceinline__ void pp_group(const double* __restrict__ ent, const i
 		const double* e2 = ent + ENT_P * (itv >> 16);
 		double a1[12], a2[12], q1[3], q2[3], C[9], TR[9];
 #pragma unroll
-		for (int i = 0; i < 12; ++i) { a1[i] = e1[i]; a2[i] = e2[i]; }
+		for (int i = 0; i < 12; ++i) a1[i] = e1[i];
 #pragma unroll
-		for (int i = 0; i < 3; ++i) { q1[i] = e1[12 + i]; q2[i] = e2[12 + i]; }
+		for (int i = 0; i < 3; ++i) q1[i] = e1[12 + i];
+		if (e1 != e2) {                                    // items of diagonal blocks pair an entry with itself: the LDS is the
+#pragma unroll
+			for (int i = 0; i < 12; ++i) a2[i] = e2[i];    // contended resource here, so their second record is not read again
+#pragma unroll
+			for (int i = 0; i < 3; ++i) q2[i] = e2[12 + i];
+		} else {
+#pragma unroll
+			for (int i = 0; i < 12; ++i) a2[i] = a1[i];
+#pragma unroll
+			for (int i = 0; i < 3; ++i) q2[i] = q1[i];
+		}
 #pragma unroll
 		for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -135,7 +146,14 @@ __device__ __forceinline__ void schur_group(const double* __restrict__ Yr, const
 		const double* Y2 = Yr + Y_P * (itv >> 16);
 		double y1[18], y2[18];
 #pragma unroll
-		for (int i = 0; i < 18; ++i) { y1[i] = Y1[i]; y2[i] = Y2[i]; }
+		for (int i = 0; i < 18; ++i) y1[i] = Y1[i];
+		if (Y1 != Y2) {
+#pragma unroll
+			for (int i = 0; i < 18; ++i) y2[i] = Y2[i];
+		} else {
+#pragma unroll
+			for (int i = 0; i < 18; ++i) y2[i] = y1[i];
+		}
 #pragma unroll
 		for (int a = 0; a < 6; ++a)
 #pragma unroll
