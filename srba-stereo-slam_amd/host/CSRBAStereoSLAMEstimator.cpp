@@ -1,6 +1,8 @@
 // CSRBAStereoSLAMEstimator.cpp -- see the header.  EST.cpp = reference src/CSRBAStereoSLAMEstimator.cpp.
 #include "CSRBAStereoSLAMEstimator.h"
 #include "ssk_kf_io.h"
+#include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <algorithm>
 #include <cstdio>
@@ -107,7 +109,12 @@ TNewKeyFrameInfo CSRBAStereoSLAMEstimator::processKeyframe(const StereoImages& s
 	m_keyframes.push_back(CStereoSLAMKF());                                              // :84 / :413
 	CStereoSLAMKF& new_kf = m_keyframes.back();
 	new_kf.setKFID(m_last_kf_ID++);
+	static const bool timing = std::getenv("SSK_FACADE_TIMING") != nullptr;   // per-stage wall time of a keyframe on stderr
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	const auto t0 = now();
 	m_frontend(stImgs, new_kf);
+	const auto t1 = now();
 	TNewKeyFrameInfo newKFInfo;
 	new_kf_observations_t listObs;
 	const size_t nMatches = new_kf.m_matches.size();
@@ -125,6 +132,7 @@ TNewKeyFrameInfo CSRBAStereoSLAMEstimator::processKeyframe(const StereoImages& s
 	if (similar.empty()) similar.push_back(m_keyframes.size() - 2);                      // the previous keyframe (:1758)
 	TVectorKfsDaInfo daInfo;
 	m_data_association(new_kf, similar, daInfo);
+	const auto t2 = now();
 	// order by tracked matches, descending (DATrackedSorter, KF.h:117-126; EST.cpp:455-470)
 	std::vector<size_t> sortedIndices(daInfo.size());
 	for (size_t i = 0; i < sortedIndices.size(); ++i) sortedIndices[i] = i;
@@ -161,7 +169,10 @@ TNewKeyFrameInfo CSRBAStereoSLAMEstimator::processKeyframe(const StereoImages& s
 		}
 	}
 	rba.setInitialKFPose(srba_options.use_initial_pose ? incr_pose : Pose3D());          // :772-778
+	const auto t3 = now();
 	rba.define_new_keyframe(listObs, newKFInfo, true);                                   // :782-784
+	if (timing) std::fprintf(stderr, "[facade timing] kf %zu: front-end %.2f ms, data association %.2f ms, ids+observations %.2f ms, define_new_keyframe %.2f ms\n",
+	                         new_kf.m_kf_ID, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
 	if (general_options.verbose_level >= 1)                                              // :846-850
 		std::cout << "   Created KF #" << newKFInfo.kf_id << " | # kf-to-kf edges created: " << newKFInfo.created_edge_ids.size() << std::endl
 		          << "   Optimization error: " << newKFInfo.optimize_results.total_sqr_error_init << " -> " << newKFInfo.optimize_results.total_sqr_error_final << std::endl;
