@@ -4,6 +4,7 @@
 #include "ssk_lm.h"
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,7 +13,10 @@ struct ssk_lm_batch {
 	ssk_ctx* ctx = nullptr;
 	int n_windows = 0, trace = 0, max_iters_alloc = 0, max_n6 = 0;
 	std::vector<lm_win> hdr;
-	std::vector<void*> allocs;
+	void* slab = nullptr;             // ONE device allocation holds every array of the batch
+	size_t slab_bytes = 0;
+	struct req { size_t bytes, copy; const void* src; void** dst; };
+	std::vector<req> reqs;            // filled by upload()/scratch(), resolved by finalize()
 	lm_dev D{};
 	size_t n_pose = 0, n_lm = 0;      // doubles in pose / lm families
 	bool tiled_ok = false;            // every window fits the LDS-tiled kernel
@@ -21,24 +25,59 @@ struct ssk_lm_batch {
 
 namespace {
 
+// upload()/scratch() only RECORD what the batch needs; finalize() makes one slab (reusing the context's cached one when it
+// is large enough), lays the arrays out at 256-byte offsets, moves every host image with a single staged DMA (small
+// batches: the per-keyframe host path) or one copy per array (large batches) and zeroes the scratch part with one memset.
 template <typename T>
 int upload(ssk_lm_batch* b, const std::vector<T>& v, const T** out)
 {
-	T* d = nullptr;
-	SSK_HIP(b->ctx, hipMalloc((void**)&d, sizeof(T) * (v.size() + 4)));
-	b->allocs.push_back(d);
-	if (!v.empty()) SSK_HIP(b->ctx, hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
-	*out = d;
+	b->reqs.push_back({sizeof(T) * (v.size() + 4), sizeof(T) * v.size(), v.empty() ? nullptr : (const void*)v.data(), (void**)out});
 	return SSK_OK;
 }
 template <typename T>
 int scratch(ssk_lm_batch* b, size_t count, T** out)
 {
-	T* d = nullptr;
-	SSK_HIP(b->ctx, hipMalloc((void**)&d, sizeof(T) * (count + 4)));
-	SSK_HIP(b->ctx, hipMemset(d, 0, sizeof(T) * (count + 4)));
-	b->allocs.push_back(d);
-	*out = d;
+	b->reqs.push_back({sizeof(T) * (count + 4), 0, nullptr, (void**)out});
+	return SSK_OK;
+}
+
+int finalize(ssk_lm_batch* b)
+{
+	ssk_ctx* ctx = b->ctx;
+	// uploads first, scratch after: the scratch part is one contiguous range to zero
+	size_t up = 0, total = 0;
+	for (const ssk_lm_batch::req& r : b->reqs) { if (r.copy > 0) up += ssk_pad(r.bytes); total += ssk_pad(r.bytes); }
+	if (total == 0) total = 256;
+	if (ctx->lm_slab && ctx->lm_slab_bytes >= total) { b->slab = ctx->lm_slab; b->slab_bytes = ctx->lm_slab_bytes; ctx->lm_slab = nullptr; ctx->lm_slab_bytes = 0; }
+	else {
+		if (ctx->lm_slab) { SSK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->lm_slab); ctx->lm_slab = nullptr; ctx->lm_slab_bytes = 0; }
+		SSK_HIP(ctx, hipMalloc(&b->slab, total + total / 4));          // head room: the next keyframe's window is a little larger
+		b->slab_bytes = total + total / 4;
+	}
+	const bool staged = up <= (size_t)8 << 20;
+	uint8_t* st = nullptr;
+	if (staged && up) {
+		int rc = ssk_arena_reserve(ctx, ctx->pin, up + 256);
+		if (rc) return rc;
+		ssk_arena_reset(ctx->pin);
+		st = ssk_arena_take<uint8_t>(ctx->pin, up);
+	}
+	size_t off = 0;
+	for (int pass = 0; pass < 2; ++pass)
+		for (const ssk_lm_batch::req& r : b->reqs) {
+			if ((r.copy > 0) != (pass == 0)) continue;
+			uint8_t* d = static_cast<uint8_t*>(b->slab) + off;
+			*r.dst = d;
+			if (pass == 0) {
+				if (staged) { std::memcpy(st + off, r.src, r.copy); std::memset(st + off + r.copy, 0, ssk_pad(r.bytes) - r.copy); }
+				else SSK_HIP(ctx, hipMemcpyAsync(d, r.src, r.copy, hipMemcpyHostToDevice, ctx->stream));
+			}
+			off += ssk_pad(r.bytes);
+		}
+	if (staged && up) SSK_HIP(ctx, hipMemcpyAsync(b->slab, st, up, hipMemcpyHostToDevice, ctx->stream));
+	if (total > up) SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + up, 0, total - up, ctx->stream));
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // host images / pinned staging are free again when create returns
+	b->reqs.clear();
 	return SSK_OK;
 }
 
@@ -180,7 +219,13 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 {
 	if (!b) return;
 	if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
-	for (void* p : b->allocs) (void)hipFree(p);
+	if (b->slab) {
+		ssk_ctx* c = b->ctx;
+		if (c && (!c->lm_slab || c->lm_slab_bytes < b->slab_bytes)) {          // keep the larger slab for the next batch
+			if (c->lm_slab) (void)hipFree(c->lm_slab);
+			c->lm_slab = b->slab; c->lm_slab_bytes = b->slab_bytes;
+		} else (void)hipFree(b->slab);
+	}
 	delete b;
 }
 
@@ -190,6 +235,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	if (!windows || n_windows < 1 || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: bad argument");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	const int MAX_ITERS_ALLOC = 64;
+	static const bool timing = std::getenv("SSK_TIMING") != nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
 	// batch-wide host images of every array family
 	std::vector<int> edge_slot, lm_slot, obs_lm, obs_path_off, path_edge, path_obs, slot_edge, slot_lm;
 	std::vector<int> lmo_off, lmo_idx, lsm_off, lme_edge, lme_ls, lme_elpos, lmep_off, lmep_idx, q_off, q_uend, qo_off, el_off, el_idx;
@@ -576,6 +623,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		inc_rec.insert(inc_rec.end(), w_inc_rec.begin(), w_inc_rec.end());
 	}
 
+	const auto t_sym = std::chrono::steady_clock::now();
 	ssk_lm_batch* b = new ssk_lm_batch();
 	b->ctx = ctx; b->n_windows = n_windows; b->trace = trace; b->max_iters_alloc = MAX_ITERS_ALLOC; b->max_n6 = max_n6;
 	b->hdr = hdr; b->n_pose = pose.size(); b->n_lm = lm.size();
@@ -597,10 +645,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
 #undef UP
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
-	const double *c_pose = nullptr, *c_lm = nullptr;
-	if (!rc) rc = upload(b, pose, &c_pose);
-	if (!rc) rc = upload(b, lm, &c_lm);
-	D.pose = const_cast<double*>(c_pose); D.lm = const_cast<double*>(c_lm);
+	if (!rc) rc = upload(b, pose, const_cast<const double**>(&D.pose));     // working copies of the state (pose0 / lm0 keep the initial one)
+	if (!rc) rc = upload(b, lm, const_cast<const double**>(&D.lm));
 	const size_t n_obs = obs_lm.size(), n_path = path_edge.size(), n_ls = slot_lm.size(), n_us = slot_edge.size();
 	const size_t n_lme = lme_edge.size();
 	if (!rc) rc = scratch(b, pose.size(), &D.pose_new);
@@ -629,7 +675,14 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
 	D.trace_on = trace ? 1 : 0;
+	if (!rc) rc = finalize(b);
 	if (rc) { ssk_lm_batch_destroy(b); return rc; }
+	if (timing) {
+		(void)hipDeviceSynchronize();
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create (%d windows): symbolic %.3f ms, allocate + upload %.3f ms (%zu device arrays)\n",
+		             n_windows, ms(t_begin, t_sym), ms(t_sym, std::chrono::steady_clock::now()), (size_t)1);
+	}
 	*out = b;
 	return SSK_OK;
 }

@@ -33,6 +33,8 @@ struct ssk_ctx {
 	int8_t pattern[1024];              // BRIEF sampling pattern (default: include/ssk_brief_pattern.h)
 	int8_t* d_pattern = nullptr;
 	struct ssk_kfbatch* single = nullptr;   // 1-keyframe batch behind the host drop-in ssk_frontend_run
+	void* lm_slab = nullptr;                // device slab of the last destroyed LM batch, reused by the next one (the host
+	size_t lm_slab_bytes = 0;               // drop-in creates and destroys a batch per keyframe: no hipMalloc in steady state)
 	int n_cu = 256;
 	// per-stage HIP-event profiler (ssk_profile_*): event pairs recorded around kernel launches on the
 	// context stream while enabled; resolved into per-stage sums at ssk_profile_read.
