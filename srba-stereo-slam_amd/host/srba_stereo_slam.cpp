@@ -1,5 +1,8 @@
 // srba_stereo_slam.cpp -- see srba_stereo_slam.h.  SRBA.h = reference src/srba-stereo-slam.h.
 #include "srba_stereo_slam.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <functional>
 #include <limits>
@@ -143,6 +146,10 @@ void mySRBA::edge_creation_policy(TKeyFrameID new_kf_id, const new_kf_observatio
 void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pair<TKeyFrameID, size_t>>& obs_refs,
                     bool optimize_landmarks, bool robust, TOptimizeResults& res)
 {
+	static const bool timing = std::getenv("SSK_FACADE_TIMING") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+	const auto t0 = now();
 	std::map<TKeyFrameID, std::map<TKeyFrameID, step_t>> trees;
 	std::vector<int32_t> obs_lm, obs_path_off(1, 0), path_edge;
 	std::vector<float> obs_px;
@@ -192,14 +199,19 @@ void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pa
 	w.n_lms_total = (int32_t)lm_ids.size(); w.lm_unknown_slot = lm_slot.data(); w.lm_pos = lmpos.data();
 	w.n_obs = (int32_t)obs_lm.size(); w.obs_lm = obs_lm.data(); w.obs_px = obs_px.data();
 	w.obs_path_off = obs_path_off.data(); w.path_edge = path_edge.data();
+	const auto t1 = now();
 	ssk_lm_batch* b = nullptr;
 	m_ctx.check(ssk_lm_batch_create(m_ctx.get(), &w, 1, 0, &b), "ssk_lm_batch_create");
+	const auto t2 = now();
 	const ssk_lm_params prm = m_opts.lm(robust);
 	ssk_lm_result r;
 	int rc = ssk_lm_batch_run(m_ctx.get(), b, &prm);
 	if (rc == SSK_OK) rc = ssk_lm_batch_results(m_ctx.get(), b, &r);
+	const auto t3 = now();
 	if (rc == SSK_OK) rc = ssk_lm_batch_get_state(m_ctx.get(), b, 0, pose.data(), lmpos.data());
 	ssk_lm_batch_destroy(b);
+	if (timing) std::fprintf(stderr, "[facade timing]   run_lm (%d edges opt, %zu obs): window build %.2f ms, batch create %.2f ms, solve %.2f ms (%d iters), state+destroy %.2f ms\n",
+	                         s, obs_lm.size(), ms(t0, t1), ms(t1, t2), ms(t2, t3), (int)r.iters, ms(t3, now()));
 	m_ctx.check(rc, "LM solve");
 	for (size_t i = 0; i < edge_ids.size(); ++i)
 		if (edge_slot[i] >= 0) std::memcpy(m_state.k2k_edges[edge_ids[i]].inv_pose.m, &pose[12 * i], 12 * sizeof(double));
