@@ -388,8 +388,9 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		std::vector<int> w_pit, w_pslot0, w_qit, w_sslot0, w_pcl_off((size_t)n_pairs + 1, 0), w_pcl_idx, w_scl_off((size_t)n_pairs + 1, 0), w_scl_idx;
 		std::vector<int2> w_pgrp, w_sgrp;
 		int n_pslots = 0, n_sslots = 0;
-		const long long region_bytes = (long long)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC - 2LL * 12 * 8 * Wn.n_edges_total;
-		bool tiled = 6 * E <= SSK_LMT_MAX_N6 && Wn.n_edges_total <= 128 && (long long)(6 * E + 1) * ((6 * E) | 1) * 8 <= region_bytes;
+		// LDS of a workgroup: static part, the window's edge poses twice, the solution vector and the pivots, the tile region
+		const long long region_bytes = (long long)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC - 2LL * 12 * 8 * Wn.n_edges_total - 2LL * 8 * ((6 * E + 1) & ~1);
+		bool tiled = 6 * E <= SSK_LM_MAX_N6 && Wn.n_edges_total <= 128 && region_bytes >= 32 * 1024;
 		if (tiled) {
 			auto tile_bytes = [](long long nP, long long nO, long long nM, long long nL) {
 				return 8 * (SSK_LMT_ENT * nP + SSK_LMT_OBS * nO + SSK_LMT_Y * nM + SSK_LMT_LMR * nL);
@@ -519,7 +520,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size();
 				make_groups(qitems, R, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
 				w_tiles.push_back(T);
-				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)tile_bytes(T.n_ent, T.n_obs, T.n_inc, T.n_lm));
+				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (size_t)tile_bytes(T.n_ent, T.n_obs, T.n_inc, T.n_lm));
 				oi = oj;
 			}
 			// the observations outside every tile (fixed landmark, no optimised edge on the path) still count in the error
@@ -537,7 +538,10 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 				w_scl_off[p2] = ns_; for (int sl : sslots_of[p2]) w_scl_idx[sl] = ns_++;
 			}
 			w_pcl_off[n_pairs] = np_; w_scl_off[n_pairs] = ns_;
-			tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(6 * E + 1) * ((6 * E) | 1) * 8);
+			// the reduced system goes to LDS too when it fits beside poses / solution / pivots (else: L2 scratch, Hred)
+			const size_t fixed = (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1));
+			const size_t mat = (size_t)(6 * E + 1) * ((6 * E) | 1) * 8;
+			if (fixed + mat <= (size_t)(SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC)) tiled_dyn = std::max(tiled_dyn, fixed + mat);
 		}
 		if (!tiled) tiled_all = false;
 		if (w == 0 && std::getenv("SSK_LM_DEBUG")) {
@@ -574,7 +578,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		H.qp0 = (int)qp_q.size(); H.pc0 = (int)pchunk.size(); H.sc0 = (int)schunk.size();
 		H.n_pchunk = (int)w_pchunk.size(); H.n_schunk = (int)w_schunk.size();
 		H.trace0 = w * MAX_ITERS_ALLOC; H.h0 = h_total; H.dp_trace0 = dpt; H.df_trace0 = dft;
-		h_total += (long long)36 * E * E;
+		h_total += (long long)(6 * E + 1) * (6 * E + 2);      // Hpair (18 E (E+1)) / the reduced system with its border row
 		if (trace) { dpt += (long long)MAX_ITERS_ALLOC * 6 * E; dft += (long long)MAX_ITERS_ALLOC * 3 * L; }
 		max_n6 = std::max(max_n6, 6 * E);
 

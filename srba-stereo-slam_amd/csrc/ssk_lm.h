@@ -113,7 +113,6 @@ int ssk_lm_launch(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows,
 constexpr int SSK_LMT_NT = SSK_LMT_THREADS;        // workgroup size
 constexpr int SSK_LMT_ENT = 15, SSK_LMT_OBS = 17, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;   // record pitches (doubles, odd: conflict-free)
 constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024 / SSK_LMT_WG_PER_CU;   // gfx950: 160 KB of LDS per CU, shared by the resident workgroups
-constexpr int SSK_LMT_STATIC = 4096;               // reserve for the kernel's static LDS
-constexpr int SSK_LMT_MAX_N6 = 126;
+constexpr int SSK_LMT_STATIC = 1024;               // reserve for the kernel's static LDS (a few scalars and the wave partials)
 int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes);
 int ssk_lm_launch_reset(ssk_ctx* ctx, double* pose, const double* pose0, size_t n_pose, double* lm, const double* lm0, size_t n_lm);

@@ -150,46 +150,6 @@ __device__ __forceinline__ void wave_sum36(const double (&acc)[36], double* red,
 	}
 }
 
-// G (fallback): the same factorisation by the whole workgroup on an L2-resident matrix (6E too large for LDS)
-__device__ bool chol_solve_block(double* A, int n, double* b, int* s_flag, double* s_piv)
-{
-	const int tid = threadIdx.x;
-	for (int j = 0; j < n; ++j) {
-		if (tid == 0) {
-			const double d = A[(size_t)j * n + j];
-			*s_flag = d > 0.0;
-			*s_piv = sqrt(d);
-			if (d > 0.0) A[(size_t)j * n + j] = *s_piv;
-		}
-		__syncthreads();
-		if (!*s_flag) { __syncthreads(); return false; }
-		const double inv = 1.0 / *s_piv;
-		const int m = n - j - 1;
-		for (int i = j + 1 + tid; i < n; i += NT) A[(size_t)i * n + j] = A[(size_t)i * n + j] * inv;
-		__syncthreads();
-		for (int t = tid; t < m * m; t += NT) {
-			const int i = j + 1 + t / m, k = j + 1 + t % m;
-			if (k <= i) A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
-		}
-		__syncthreads();
-	}
-	for (int i = 0; i < n; ++i) {
-		if (tid == 0) b[i] = b[i] / A[(size_t)i * n + i];
-		__syncthreads();
-		const double yi = b[i];
-		for (int k = i + 1 + tid; k < n; k += NT) b[k] -= A[(size_t)k * n + i] * yi;
-		__syncthreads();
-	}
-	for (int i = n - 1; i >= 0; --i) {
-		if (tid == 0) b[i] = b[i] / A[(size_t)i * n + i];
-		__syncthreads();
-		const double xi = b[i];
-		for (int k = tid; k < i; k += NT) b[k] -= A[(size_t)i * n + k] * xi;
-		__syncthreads();
-	}
-	return true;
-}
-
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
 void lm_solve_kernel(lm_dev D, lm_cam P, int lds_n6_cap)
 {

@@ -123,8 +123,8 @@ __device__ void so3_exp(const double* w, double* R)
 // The border row comes out as z = L'^-1 b (forward substitution for free), so only L'^T x = D^-1 z is left: one
 // wavefront keeps x in registers (lane k owns x_k, x_{k+64}), broadcasts x_i with v_readlane and prefetches row
 // i-1 of U while it applies row i, so the dependent chain per step is one readlane + one FMA.
-// A is (n+1) x n with an odd row pitch np (column walks are bank-conflict free), n a multiple of 6.  Every thread
-// returns the same flag.
+// A is (n+1) x n with an odd row pitch np (column walks are bank-conflict free), n a multiple of 6; it may live in LDS
+// or (large systems) in global scratch -- the code only uses plain pointers.  Every thread returns the same flag.
 __device__ __forceinline__ double rcp_f64(double d)
 {
 	double x = __builtin_amdgcn_rcp(d);
@@ -236,6 +236,18 @@ __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* 
 			}
 	}
 	__syncthreads();
+	if (n > 128) {
+		// any size (the matrix then lives in L2 scratch): x <- D^-1 z in LDS, then row i of U updates x_k, k < i, by
+		// the whole workgroup: one barrier per row
+		for (int k = tid; k < n; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
+		__syncthreads();
+		for (int i = n - 1; i > 0; --i) {
+			const double xi = x_out[i];
+			for (int k = tid; k < i; k += NT) x_out[k] -= A[(size_t)i * np + k] * inv[k] * xi;
+			__syncthreads();
+		}
+		return true;
+	}
 	if (tid < 64) {
 		const int k0 = tid, k1 = tid + 64;
 		const double i0 = k0 < n ? inv[k0] : 0.0, i1 = k1 < n ? inv[k1] : 0.0;
@@ -254,3 +266,42 @@ __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* 
 	return true;
 }
 
+// G (fallback): the same factorisation by the whole workgroup on an L2-resident matrix (6E too large for LDS)
+__device__ bool chol_solve_block(double* A, int n, double* b, int* s_flag, double* s_piv)
+{
+	const int tid = threadIdx.x;
+	for (int j = 0; j < n; ++j) {
+		if (tid == 0) {
+			const double d = A[(size_t)j * n + j];
+			*s_flag = d > 0.0;
+			*s_piv = sqrt(d);
+			if (d > 0.0) A[(size_t)j * n + j] = *s_piv;
+		}
+		__syncthreads();
+		if (!*s_flag) { __syncthreads(); return false; }
+		const double inv = 1.0 / *s_piv;
+		const int m = n - j - 1;
+		for (int i = j + 1 + tid; i < n; i += NT) A[(size_t)i * n + j] = A[(size_t)i * n + j] * inv;
+		__syncthreads();
+		for (int t = tid; t < m * m; t += NT) {
+			const int i = j + 1 + t / m, k = j + 1 + t % m;
+			if (k <= i) A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
+		}
+		__syncthreads();
+	}
+	for (int i = 0; i < n; ++i) {
+		if (tid == 0) b[i] = b[i] / A[(size_t)i * n + i];
+		__syncthreads();
+		const double yi = b[i];
+		for (int k = i + 1 + tid; k < n; k += NT) b[k] -= A[(size_t)k * n + i] * yi;
+		__syncthreads();
+	}
+	for (int i = n - 1; i >= 0; --i) {
+		if (tid == 0) b[i] = b[i] / A[(size_t)i * n + i];
+		__syncthreads();
+		const double xi = b[i];
+		for (int k = tid; k < i; k += NT) b[k] -= A[(size_t)i * n + k] * xi;
+		__syncthreads();
+	}
+	return true;
+}

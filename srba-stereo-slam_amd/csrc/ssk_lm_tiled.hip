@@ -324,12 +324,45 @@ __device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam
 			orec[3 * i + j] = w * (M[3 * i] * RA[j] + M[3 * i + 1] * RA[3 + j] + M[3 * i + 2] * RA[6 + j]);
 }
 
-__global__ __launch_bounds__(NT, SSK_LM_WAVES)
-void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
+// F2: H_red block (e,e') = sum of its H_pp slots + lambda I - sum of its Schur slots (slot order), diagonal blocks
+// written from their upper triangle; g_red(e) = sum of its incidences' terms (contiguous, edge-major, 8 lanes per
+// component) into the border row; G: blocked LDL^T + back-substitution (ssk_lm_device.h).  A: (n6 + 1) x np.
+template <typename PtrA>
+__device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win& W, const double* __restrict__ Pp, const double* __restrict__ Sp,
+                                                   double lambda, PtrA A, int np, int n6, double* s_b, double* s_inv)
 {
-	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | tile records / reduced system]
-	__shared__ double s_b[128];
-	__shared__ double s_inv[128];
+	const int tid = threadIdx.x;
+	for (int it = tid; it < W.n_pairs * 36; it += NT) {
+		const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
+		const int2 ee = D.pair_ee[W.pair0 + pid];
+		if (ee.x == ee.y && a > b) continue;
+		const double p = slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], ab);
+		const double sc = slot_sum(Sp, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
+		double sres = p - sc;
+		if (ee.x == ee.y && a == b) sres += lambda;
+		A[(6 * ee.x + a) * np + 6 * ee.y + b] = sres;
+		A[(6 * ee.y + b) * np + 6 * ee.x + a] = sres;
+	}
+	for (int it = tid; it < n6 * 8; it += NT) {
+		const int comp = it >> 3, j = it & 7, e = comp / 6, a = comp - e * 6;
+		const int k0 = D.el_off[W.uso0 + e], k1 = D.el_off[W.uso0 + e + 1];
+		const double* src = D.gre + 6 * (size_t)W.el0 + a;
+		double s0 = 0, s1 = 0;
+		int k = k0 + j;
+		for (; k + 8 < k1; k += 16) { s0 += src[6 * (size_t)k]; s1 += src[6 * (size_t)(k + 8)]; }
+		if (k < k1) s0 += src[6 * (size_t)k];
+		double v = s0 + s1;
+		v += __shfl_down(v, 4, 8); v += __shfl_down(v, 2, 8); v += __shfl_down(v, 1, 8);
+		if (j == 0) A[n6 * np + comp] = v;
+	}
+	__syncthreads();
+	return n6 > 0 ? ldl_solve_lds(A, np, n6, s_b, s_inv) : true;
+}
+
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
+{
+	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | delta | pivots | tile records / reduced system]
 	__shared__ double s_part[NW];
 	__shared__ double s_lambda, s_nu, s_err;
 	__shared__ int s_accept, s_stop, s_iters, s_accepted;
@@ -337,12 +370,17 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 
 	const lm_win W = D.win[blockIdx.x];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int n6 = 6 * W.E, np = n6 | 1;
+	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1;
 	int epoch = 0;                                     // tiles started so far
 	double* pose_cur = s_dyn;
 	double* pose_new = s_dyn + 12 * W.n_edges;
-	double* reg = s_dyn + 24 * W.n_edges;
-	double* A = reg;                                   // reduced system (n6 + 1) x np, over the dead tile records
+	double* s_b = s_dyn + 24 * W.n_edges;               // right-hand side / solution of the reduced system (n6)
+	double* s_inv = s_b + n6p;                         // reciprocal pivots of the LDS solve (n6)
+	double* reg = s_inv + n6p;
+	// the reduced system lives over the dead tile records when (n6 + 1) x (n6 | 1) doubles fit there (E <= ~22),
+	// otherwise in the window's L2-resident scratch (same blocked factorisation through plain pointers)
+	const bool lds_mat = (long long)(n6 + 1) * (n6 | 1) <= (long long)dyn_doubles - (reg - s_dyn);
+	const int np = n6 | 1;
 #ifdef SSK_LM_STAMPS
 	__shared__ unsigned long long s_acc[16];
 	unsigned long long t_last = __builtin_amdgcn_s_memtime();
@@ -558,37 +596,10 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 			if (tid == 0) s_lambda = P.tau * mx;
 			continue;
 		}
-		// ---- F2: H_red block (e,e') = sum of its H_pp slots + lambda I - sum of its Schur slots (slot order); diagonal
-		//      blocks are written from their upper triangle ----
-		for (int it = tid; it < W.n_pairs * 36; it += NT) {
-			const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
-			const int2 ee = D.pair_ee[W.pair0 + pid];
-			if (ee.x == ee.y && a > b) continue;
-			const double p = slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], ab);
-			const double sc = slot_sum(Sp, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
-			double sres = p - sc;
-			if (ee.x == ee.y && a == b) sres += lambda;
-			A[(6 * ee.x + a) * np + 6 * ee.y + b] = sres;
-			A[(6 * ee.y + b) * np + 6 * ee.x + a] = sres;
-		}
-		// g_red(e) = sum of its incidences' terms (contiguous, edge-major): 8 lanes per component
-		for (int it = tid; it < n6 * 8; it += NT) {
-			const int comp = it >> 3, j = it & 7, e = comp / 6, a = comp - e * 6;
-			const int k0 = D.el_off[W.uso0 + e], k1 = D.el_off[W.uso0 + e + 1];
-			const double* src = D.gre + 6 * (size_t)W.el0 + a;
-			double s0 = 0, s1 = 0;
-			int k = k0 + j;
-			for (; k + 8 < k1; k += 16) { s0 += src[6 * (size_t)k]; s1 += src[6 * (size_t)(k + 8)]; }
-			if (k < k1) s0 += src[6 * (size_t)k];
-			double v = s0 + s1;
-			v += __shfl_down(v, 4, 8); v += __shfl_down(v, 2, 8); v += __shfl_down(v, 1, 8);
-			if (j == 0) A[n6 * np + comp] = v;
-		}
-		__syncthreads();
-		STAMP(5);
-		// ---- G ----
-		bool ok = true;
-		if (n6 > 0) ok = ldl_solve_lds(A, np, n6, s_b, s_inv);
+		// ---- F2 + G: assemble and solve the reduced system; instantiated once for the LDS copy and once for the L2 copy so
+		//      that each uses the instructions of its address space (a pointer that may be either compiles to FLAT accesses) ----
+		bool ok = lds_mat ? assemble_and_solve(D, W, Pp, Sp, lambda, reg, np, n6, s_b, s_inv)
+		                  : assemble_and_solve(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv);
 		STAMP(6);
 		double dpn = 0, dfn = 0;
 		if (ok) {
@@ -715,6 +726,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P)
 
 int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes)
 {
+	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
 	static bool attr_set = false;
 	if (!attr_set) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -722,7 +734,7 @@ int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_wi
 		attr_set = true;
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
-	hipLaunchKernelGGL(lm_solve_tiled_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P);
+	hipLaunchKernelGGL(lm_solve_tiled_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
 	SSK_LAUNCH_CHECK(ctx, "lm_solve_tiled_kernel");
 	return SSK_OK;
 }

@@ -149,8 +149,12 @@ def test_lm_tiled_kernel_multi_tile_window(ctx, oracle):
     check_against_oracle(ctx, oracle, win, sl.make_params(), min_accept=2)
 
 
-def test_lm_large_window_global_cholesky(ctx, oracle):
-    """a window whose reduced system (6E > 132) does not fit the LDS workspace: L2-resident Cholesky path."""
+@pytest.mark.parametrize("kernel", ["tiled", "l2"])
+def test_lm_large_window_global_cholesky(ctx, oracle, kernel, monkeypatch):
+    """a window whose reduced system (6E > 132) does not fit LDS: the tiled kernel keeps it in L2 scratch (workgroup-wide
+    Cholesky), as the general kernel does."""
+    if kernel == "l2":
+        monkeypatch.setenv("SSK_LM_KERNEL", "l2")
     win, gt = sl.make_submap_problem(21, n_kf=45, n_lm=900, submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)
     assert 6 * win.E > 140
     check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8))
