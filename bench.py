@@ -5,7 +5,7 @@ One "step" = one pass of the whole per-keyframe hot path over a batch of B synth
 is already resident in HBM when the timed region starts:
     stereo front-end (FAST+NMS scan, selection, orientation+BRIEF, L<->R match)          [seam B1]
   + keyframe<->previous-keyframe data association (Hamming K=1 + direction/ORB filters
-    + change-in-pose filter)                                                            [seam B2]
+    + fundamental-matrix RANSAC + change-in-pose filters)                               [seam B2]
   + one relative-BA LM solve per keyframe on a BASELINE configs[2]-shaped window         [seam B3]
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), keyframe streams are partitioned one
 batch per GPU (weak scaling) and each step ends with ONE all-gather of the shared-landmark blocks.
@@ -45,7 +45,11 @@ def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8):
     ic, ip = cur.image_tensor(), prev.image_tensor()
     for k in range(n_base, B):      # distinct content per keyframe: circular shifts of the base pairs
         ic[k, :, :, :W] = torch.roll(ic[k % n_base, :, :, :W], shifts=5 * (k // n_base), dims=-1)
-    ip[:, :, :, :W] = torch.roll(ic[:, :, :, :W], shifts=(2, -3), dims=(-2, -1))   # previous keyframe: small image motion
+    # previous keyframe: the same scene seen from a camera displaced sideways -- horizontal image motion that differs from
+    # band to band (2..6 px, as strips at different depths), so the pair has a proper epipolar geometry (a uniform image
+    # shift is a degenerate configuration for the fundamental-matrix stage: every 7-point sample is singular)
+    for b0 in range(0, H, 47):
+        ip[:, :, b0:b0 + 47, :W] = torch.roll(ic[:, :, b0:b0 + 47, :W], shifts=-(2 + (b0 // 47) % 5), dims=-1)
     torch.cuda.synchronize()
     wins = [sl.make_submap_problem(100 * rank + s, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2,
                                    obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0] for s in range(n_base)]
@@ -61,7 +65,8 @@ def params(capi, sl):
     lp = capi.LmParams()
     C.memmove(C.byref(lp), C.byref(sl.make_params()), C.sizeof(lp))
     cp = capi.CipParams(**synth.KITTI_CIP)
-    return fp, da, lp, cp
+    fm = capi.FmParams(**synth.KITTI_FM)
+    return fp, da, lp, cp, fm
 
 
 def cpu_baseline(sample_kf, wins):
@@ -82,7 +87,13 @@ def cpu_baseline(sample_kf, wins):
     ident = np.hstack([np.eye(3), np.zeros((3, 1))]).reshape(12)
     pat = ol.default_pattern()
     base = [synth.synth_stereo_pair(i) for i in range(4)]
-    prev_kf = [oracle.frontend(np.roll(l, (2, -3), (0, 1)), np.roll(r, (2, -3), (0, 1)), fp, pat) for l, r in base]
+    def banded(img):
+        out = img.copy()
+        for b0 in range(0, H, 47):
+            out[b0:b0 + 47] = np.roll(img[b0:b0 + 47], -(2 + (b0 // 47) % 5), axis=1)
+        return out
+    prev_kf = [oracle.frontend(banded(l), banded(r), fp, pat) for l, r in base]
+    fmp = ol.kitti_fm_params()
     t0 = time.perf_counter()
     t_fe = t_da = t_lm = 0.0
     for k in range(sample_kf):
@@ -98,7 +109,9 @@ def cpu_baseline(sample_kf, wins):
             m = k["matches"]
             return np.stack([k["kp_left"]["x"][m["queryIdx"]], k["kp_left"]["y"][m["queryIdx"]],
                              k["kp_right"]["x"][m["trainIdx"]], k["kp_right"]["y"][m["trainIdx"]]], 1)
-        oracle.change_in_pose(stereo_obs(kf), stereo_obs(prev_kf[k % len(base)]), _m["trainIdx"], st, ident, cipp)
+        so_a, so_b = stereo_obs(kf), stereo_obs(prev_kf[k % len(base)])
+        st, _r = oracle.fundamental_filter(so_a[:, :2], so_b[:, :2], _m["trainIdx"], st, fmp)
+        oracle.change_in_pose(so_a, so_b, _m["trainIdx"], st, ident, cipp)
         c = time.perf_counter()
         oracle.lm_solve(wins[k % len(wins)], lp, trace=False)
         d = time.perf_counter()
@@ -144,7 +157,7 @@ def main():
     ctx_lm = pkg.Context(local, stream=lm_stream.cuda_stream) if args.overlap else ctx
     B = args.batch
     cur, prev, lm, wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank)
-    fp, da, lp, cp = params(capi, sl)
+    fp, da, lp, cp, fm = params(capi, sl)
     pairs = np.stack([np.arange(B), np.arange(B)], 1).astype(np.int32)
     dev = torch.device("cuda", local)
     N = 512
@@ -163,7 +176,8 @@ def main():
     def step(serial=False):
         cur.run_frontend(fp)
         ctx.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
-        ctx.cip_run_batch(cur, prev, pairs, cp, d_idx, d_st, d_tr)           # change-in-pose outlier filter on the DA verdicts
+        ctx.fm_run_batch(cur, prev, pairs, fm, d_idx, d_st, d_tr)            # stage 2 of the DA (da_stage2_method = 3): fundamental-matrix
+        ctx.cip_run_batch(cur, prev, pairs, cp, d_idx, d_st, d_tr)           # RANSAC filter, then the change-in-pose filter
         if serial:
             torch.cuda.synchronize()      # profile pass: one kernel at a time, clean per-kernel durations
         lm.reset()
@@ -255,7 +269,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]+[2] per keyframe: 1241x376 stereo pair -> ORB(N=500, FAST 20, 1 level) + L<->R "
-                            "(max_y_diff 2, orb_max_distance 60) + KF<->KF Hamming DA with direction/ORB/change-in-pose filters + SRBA LM window "
+                            "(max_y_diff 2, orb_max_distance 60) + KF<->KF Hamming DA with direction/ORB/fundamental-matrix/change-in-pose filters + SRBA LM window "
                             "(200-KF/5k-landmark submap, submap_size 10, max_tree_depth 4, window = 10 most recent edges)",
                 "keyframes_per_gpu_per_step": B,
                 "streams": "front-end + DA on one HIP stream, LM solves on a second one" if args.overlap else "one HIP stream",

@@ -84,6 +84,7 @@ enum {
 	SSK_STAGE_LM_SOLVE,        /* dense Cholesky + back-substitution */
 	SSK_STAGE_LM_UPDATE,       /* state update + error evaluation */
 	SSK_STAGE_CHANGE_IN_POSE,  /* cip_kernel: change-in-pose outlier filter */
+	SSK_STAGE_FUND_MATRIX,     /* fm_kernel: fundamental-matrix RANSAC outlier filter */
 	SSK_STAGE_COUNT
 };
 int ssk_profile_enable(ssk_ctx* ctx, int on);     /* also clears the accumulated sums */
@@ -194,6 +195,36 @@ int ssk_cip_filter(ssk_ctx* ctx, const float* this_obs, int n_this, const float*
                    const int32_t* train_idx, int32_t* status, const double init_pose[12],
                    const ssk_cip_params* params, double* residuals, ssk_cip_result* out);
 
+/* ---- B2, SURVEY 8(f) row 3: fundamental-matrix outlier filter ------------------------------------------
+ * Replaces m_detect_outliers_with_F (EST.cpp:2015-2055): left keypoints of the tracked pairs (:2022-2040),
+ * cv::findFundamentalMat(p_other_left, p_this_left, FM_RANSAC, max_y_diff_epipolar, ransac_fit_prob, mask) (:2044;
+ * OpenCV 2.4, absent: 7-point RANSAC with adaptive iteration count) and the verdict mask 0 => sREJ_FUND_MATRIX
+ * (:2047-2054).  OpenCV samples from its global RNG, so parity with the reference is statistical by construction;
+ * this build's generator is counter based (contract F1-F6, DESIGN.md "Fundamental-matrix contract"). */
+typedef struct ssk_fm_params {
+	double threshold;            /* srba_options.max_y_diff_epipolar (KITTI.ini:121): max distance to the epipolar line, px */
+	double confidence;           /* srba_options.ransac_fit_prob (KITTI.ini:122) */
+	double norm_cx, norm_cy, norm_scale;   /* fixed normalisation of the pixel coordinates inside the 7-point solver */
+	uint64_t seed;               /* of the counter-based sample generator */
+	int32_t max_iters;           /* OpenCV: 2000 */
+	int32_t min_points;          /* 15: below it OpenCV 2.4 would switch to LMedS and the reference does not call (EST.cpp:1590) */
+} ssk_fm_params;
+
+typedef struct ssk_fm_result {
+	double F[9];                 /* row-major, m2^T F m1 = 0 with m1 = other keyframe, unit Frobenius norm */
+	int32_t valid, n_pairs, n_inliers, n_rejected;
+	int32_t hypotheses;          /* samples drawn before the adaptive stop */
+	int32_t best_hypothesis;
+} ssk_fm_result;
+
+/* Host drop-in of m_detect_outliers_with_F for one keyframe pair (arguments as ssk_da_change_in_pose). */
+int ssk_da_fundamental_filter(ssk_ctx* ctx, const ssk_kf_view* this_kf, const ssk_kf_view* other_kf,
+                              const ssk_dmatch* da_matches, int32_t* status, const ssk_fm_params* params, ssk_fm_result* out);
+
+/* Known-geometry entry: this_xy[2k..] / other_xy[2j..] = left keypoint pixel of match k / j (host arrays). */
+int ssk_fm_filter(ssk_ctx* ctx, const float* this_xy, int n_this, const float* other_xy, int n_other,
+                  const int32_t* train_idx, int32_t* status, const ssk_fm_params* params, ssk_fm_result* out);
+
 /* ---- B1: stereo front-end ------------------------------------------------------------------------
  * Supplies the definition CStereoSLAMKF::create() lacks (declared KF.h:82-86, defined nowhere) and
  * replaces the live equivalent  m_voEngine.processNewImagePair() + getValues()
@@ -264,6 +295,12 @@ int ssk_da_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, co
 int ssk_cip_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
                       const ssk_cip_params* params, const double* init_poses, const int32_t* d_train_idx,
                       int32_t* d_status, int32_t* d_tracked, ssk_cip_result* d_results);
+
+/* Batched fundamental-matrix filter on the outputs of ssk_da_run_batch (same conventions as ssk_cip_run_batch);
+ * pair p uses seed params->seed + p. */
+int ssk_fm_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
+                     const ssk_fm_params* params, const int32_t* d_train_idx, int32_t* d_status, int32_t* d_tracked,
+                     ssk_fm_result* d_results);
 
 /* ---- B3: relative bundle adjustment, Levenberg-Marquardt with Schur complement + dense Cholesky ----
  * Replaces the numerical core of  rba.define_new_keyframe(listObs, newKFInfo, true)  (EST.cpp:782-784):

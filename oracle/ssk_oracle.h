@@ -65,6 +65,16 @@ int ssko_change_in_pose(const float* this_obs, int n_this, const float* other_ob
                         const int32_t* train_idx, int32_t* status, const double init_pose[12],
                         const ssk_cip_params* P, double* residuals, ssk_cip_result* out);
 
+/* ---------------- fundamental-matrix filter (oracle_fmat.c): contract F1-F6 in that file ---------------- */
+void ssko_fm_sample(uint64_t seed, int h, int n, int idx[7]);
+int ssko_fm_cubic_roots(double c3, double c2, double c1, double c0, double* roots);
+int ssko_fm_seven_point(const double* m1, const double* m2, const int idx[7], const ssk_fm_params* P, double F[3][9]);
+int ssko_fm_inlier(const double* F, const double* p1, const double* p2, double thr2);
+int ssko_fm_update_iters(double p, int good, int n, int max_iters);
+/* this_xy / other_xy: left keypoint pixel per match; status in/out; returns out->valid */
+int ssko_fundamental_filter(const float* this_xy, int n_this, const float* other_xy, int n_other, const int32_t* train_idx,
+                            int32_t* status, const ssk_fm_params* P, ssk_fm_result* out);
+
 /* ---------------- landmark initialisation (oracle_geom.c) ---------------- */
 
 typedef struct ssko_stereo_cam {   /* mrpt::utils::TStereoCamera fields the path reads */

@@ -95,6 +95,17 @@ class CipResult(C.Structure):
                 ("iters_final", C.c_int32), ("n_pairs", C.c_int32), ("n_inliers", C.c_int32), ("n_rejected", C.c_int32)]
 
 
+class FmParams(C.Structure):
+    """ssk_fm_params: fundamental-matrix RANSAC filter."""
+    _fields_ = [("threshold", C.c_double), ("confidence", C.c_double), ("norm_cx", C.c_double), ("norm_cy", C.c_double),
+                ("norm_scale", C.c_double), ("seed", C.c_uint64), ("max_iters", C.c_int32), ("min_points", C.c_int32)]
+
+
+class FmResult(C.Structure):
+    _fields_ = [("F", C.c_double * 9), ("valid", C.c_int32), ("n_pairs", C.c_int32), ("n_inliers", C.c_int32),
+                ("n_rejected", C.c_int32), ("hypotheses", C.c_int32), ("best_hypothesis", C.c_int32)]
+
+
 class FrontendParams(C.Structure):
     _fields_ = [("n_feats", C.c_int32), ("fast_threshold", C.c_int32), ("n_levels", C.c_int32),
                 ("nms_radius", C.c_int32), ("orb_max_distance", C.c_int32), ("max_y_diff", C.c_float),
@@ -412,6 +423,28 @@ class Context:
                                              None if ip is None else _ptr(ip), _dev(d_idx), _dev(d_status), _dev(d_tracked),
                                              None if d_results is None else _dev(d_results)))
 
+    def fm_run_batch(self, this_b, other_b, pairs, params, d_idx, d_status, d_tracked, d_results=None):
+        pr = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        self._chk(self.lib.ssk_fm_run_batch(self.h, this_b.h_, other_b.h_, _ptr(pr), len(pr), C.byref(params), _dev(d_idx), _dev(d_status),
+                                            _dev(d_tracked), None if d_results is None else _dev(d_results)))
+
+    def fm_filter(self, this_xy, other_xy, train_idx, status, params):
+        """ssk_fm_filter on host arrays: returns (status after the filter, FmResult)."""
+        tx = np.ascontiguousarray(this_xy, np.float32).reshape(-1, 2)
+        ox = np.ascontiguousarray(other_xy, np.float32).reshape(-1, 2)
+        ti = np.ascontiguousarray(train_idx, np.int32)
+        st = np.ascontiguousarray(status, np.int32).copy()
+        out = FmResult()
+        self._chk(self.lib.ssk_fm_filter(self.h, _ptr(tx), len(tx), _ptr(ox), len(ox), _ptr(ti), _ptr(st), C.byref(params), C.byref(out)))
+        return st, out
+
+    def da_fundamental_filter(self, this_view, other_view, da_matches, status, params):
+        m = np.ascontiguousarray(da_matches, DMATCH_DTYPE)
+        st = np.ascontiguousarray(status, np.int32).copy()
+        out = FmResult()
+        self._chk(self.lib.ssk_da_fundamental_filter(self.h, C.byref(this_view), C.byref(other_view), _ptr(m), _ptr(st), C.byref(params), C.byref(out)))
+        return st, out
+
     def cip_filter(self, this_obs, other_obs, train_idx, status, init_pose, params):
         """ssk_cip_filter on host arrays: returns (status after the filter, residuals of the tracked pairs, CipResult)."""
         to = np.ascontiguousarray(this_obs, np.float32).reshape(-1, 4)
@@ -455,7 +488,7 @@ class Context:
         self._chk(self.lib.ssk_profile_enable(self.h, int(on)))
 
     def profile_read(self):
-        n = 11
+        n = 12
         ms = (C.c_double * n)()
         calls = (C.c_int64 * n)()
         self._chk(self.lib.ssk_profile_read(self.h, ms, calls))

@@ -348,4 +348,34 @@ int ssk_cip_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, c
 	                      d_init, n_pairs, N, *params, nullptr, d_results, d_tracked);
 }
 
+int ssk_fm_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
+                     const ssk_fm_params* params, const int32_t* d_train_idx, int32_t* d_status, int32_t* d_tracked,
+                     ssk_fm_result* d_results)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!this_b || !other_b || n_pairs < 0 || !params || (n_pairs > 0 && (!pairs || !d_train_idx || !d_status || !d_tracked)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_fm_run_batch: bad argument");
+	if (this_b->max_feats != other_b->max_feats)
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_fm_run_batch: batches differ in max_feats");
+	if (!(params->threshold > 0) || !(params->norm_scale > 0) || params->max_iters < 1)
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_fm_run_batch: threshold, norm_scale and max_iters must be positive");
+	if (n_pairs == 0) return SSK_OK;
+	for (int p = 0; p < n_pairs; ++p)
+		if (pairs[2 * p] < 0 || pairs[2 * p] >= this_b->n_kf || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= other_b->n_kf)
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_fm_run_batch: pair %d references a keyframe outside its batch", p);
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	int rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad((size_t)n_pairs * 8) + ssk_pad((size_t)n_pairs * 20) + 4 * 256))) return rc;
+	ssk_arena_reset(ctx->dev);
+	int32_t* d_pairs = ssk_arena_take<int32_t>(ctx->dev, (size_t)n_pairs * 2);
+	int32_t* d_r = ssk_arena_take<int32_t>(ctx->dev, (size_t)n_pairs * 5);
+	SSK_HIP(ctx, hipMemcpyAsync(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice, ctx->stream));
+	const int N = this_b->max_feats;
+	hipLaunchKernelGGL(da_ranges_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, ctx->stream, d_pairs, n_pairs, N,
+	                   this_b->nm, other_b->nm, d_r);
+	SSK_LAUNCH_CHECK(ctx, "da_ranges_kernel");
+	return ssk_launch_fm(ctx, d_train_idx, d_status, d_r + 4 * n_pairs, d_r, d_r + n_pairs, d_r + 2 * n_pairs, this_b->m_xy, other_b->m_xy,
+	                     n_pairs, N, *params, d_results, d_tracked);
+}
+
 }  // extern "C"

@@ -41,3 +41,7 @@ int ssk_launch_cip(ssk_ctx* ctx, const int32_t* d_train_idx, int32_t* d_status, 
                    const int32_t* d_q_end, const int32_t* d_t_beg, const float4* d_this_obs, const float4* d_other_obs,
                    const double* d_init_poses, int n_pairs, int cap, const ssk_cip_params& prm, double* d_residuals, ssk_cip_result* d_results,
                    int32_t* d_tracked);
+// fundamental-matrix RANSAC filter over pairs (ssk_fmat.hip); xy arrays are indexed by match slot
+int ssk_launch_fm(ssk_ctx* ctx, const int32_t* d_train_idx, int32_t* d_status, const int32_t* d_out_beg, const int32_t* d_q_beg,
+                  const int32_t* d_q_end, const int32_t* d_t_beg, const float2* d_this_xy, const float2* d_other_xy,
+                  int n_pairs, int cap, const ssk_fm_params& prm, ssk_fm_result* d_results, int32_t* d_tracked);

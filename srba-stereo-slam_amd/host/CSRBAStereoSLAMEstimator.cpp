@@ -54,9 +54,18 @@ void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& 
 	const ssk_kf_view a = this_kf.view(), b = other_kf.view();
 	const ssk_da_params p = srba_options.da();
 	m_ctx.check(ssk_data_association(m_ctx.get(), &a, &b, &p, matches.data(), status.data(), &tracked), "m_internal_data_association");
-	// stage 2 (EST.cpp:1587-1640).  The fundamental-matrix filter (RANSAC) is not built; the change-in-pose filter is
-	// (m_detect_outliers_with_change_in_pose, :2113-2177), started from the identity: keyframe-to-keyframe motion is small
-	// against the scene depth, and the estimator converges from there
+	// stage 2 (EST.cpp:1587-1640): fundamental-matrix filter (m_detect_outliers_with_F, :2015-2055; the RANSAC samples come
+	// from a counter-based generator seeded by the keyframe pair, so a run is reproducible), then the change-in-pose
+	// filter (m_detect_outliers_with_change_in_pose, :2113-2177), started from the identity: keyframe-to-keyframe motion is
+	// small against the scene depth, and the estimator converges from there
+	if (srba_options.da_filter_by_fund_matrix) {
+		if (tracked < 15) return;                                                        // :1590-1594  "not enough input data": invalid
+		const ssk_fm_params fp = srba_options.fm(0x5EED0000ull + ((uint64_t)this_kf.m_kf_ID << 20) + other_kf.m_kf_ID);
+		ssk_fm_result fr;
+		m_ctx.check(ssk_da_fundamental_filter(m_ctx.get(), &a, &b, matches.data(), status.data(), &fp, &fr), "m_detect_outliers_with_F");
+		tracked = 0;
+		for (size_t k = 0; k < n; ++k) tracked += status[k] == SSK_DA_TRACKED;           // filter2_inliers, :1610-1613
+	}
 	if (srba_options.da_filter_by_pose_change) {
 		if (tracked < 15) return;                                                        // :1617-1621  "not enough input data": invalid
 		const ssk_cip_params cp = srba_options.cip();

@@ -39,8 +39,8 @@ public:
 	TNewKeyFrameInfo processKeyframe(const StereoImages& stImgs, const std::vector<size_t>& similar_kfs = std::vector<size_t>(),
 	                                 const Pose3D& incr_pose = Pose3D());
 
-	// EST.cpp:1341-1411 / 1413-1727: Hamming + direction + ORB-distance filters, then the change-in-pose filter
-	// (EST.cpp:2113-2177); the fundamental-matrix stage (RANSAC) is not built and not run
+	// EST.cpp:1341-1411 / 1413-1727: Hamming + direction + ORB-distance filters, then the fundamental-matrix filter
+	// (EST.cpp:2015-2055) and the change-in-pose filter (EST.cpp:2113-2177)
 	void m_data_association(const CStereoSLAMKF& kf, const std::vector<size_t>& similar_kfs, TVectorKfsDaInfo& out_da);
 	void m_internal_data_association(const CStereoSLAMKF& this_kf, const CStereoSLAMKF& other_kf, t_kf_da_info& out_da);
 

@@ -32,7 +32,7 @@ struct TSRBAStereoSLAMOptions {                // UTIL.h:221-487
 	// inter-frame match / data association
 	double ransac_fit_prob = 0.95, max_y_diff_epipolar = 1.5, max_orb_distance_da = 60;
 	bool da_filter_by_direction = false, da_filter_by_orb_distance = true;
-	bool da_filter_by_fund_matrix = true;      // SURVEY 8(f) row 3 (RANSAC, RNG dependent): not built, never run here
+	bool da_filter_by_fund_matrix = true;      // ssk_da_fundamental_filter (counter-based RANSAC)
 	bool da_filter_by_pose_change = true;      // ssk_da_change_in_pose
 	double residual_th = 50;
 	// stereo-vo [LEAST_SQUARES] section (KITTI.ini:40-50), used by getChangeInPose
@@ -81,6 +81,14 @@ struct TSRBAStereoSLAMOptions {                // UTIL.h:221-487
 		ssk_da_params p;
 		p.filter_by_direction = da_filter_by_direction; p.filter_by_orb_distance = da_filter_by_orb_distance;
 		p.rows_offset = stereo_camera.nrows; p.max_orb_distance_da = (float)max_orb_distance_da;
+		return p;
+	}
+	ssk_fm_params fm(uint64_t seed) const
+	{
+		ssk_fm_params p{};
+		p.threshold = max_y_diff_epipolar; p.confidence = ransac_fit_prob;                 // EST.cpp:2044
+		p.norm_cx = 0.5 * stereo_camera.ncols; p.norm_cy = 0.5 * stereo_camera.nrows; p.norm_scale = 2.0 / stereo_camera.ncols;
+		p.seed = seed; p.max_iters = 2000; p.min_points = 15;
 		return p;
 	}
 	ssk_cip_params cip() const

@@ -51,9 +51,19 @@ def make_cip(oracle):
                         exp_iters=np.array([out.iters_initial, out.iters_final, out.n_inliers, out.n_rejected], np.int32))
 
 
+def make_fmat(oracle):
+    import synth_cip as sc
+    c = sc.make_case(12, n_this=240, n_other=260, n_outliers=30)
+    st, out = oracle.fundamental_filter(c["this_obs"][:, :2], c["other_obs"][:, :2], c["train_idx"], c["status"], ol.kitti_fm_params())
+    np.savez_compressed(os.path.join(HERE, "fmat_case0.npz"), this_xy=c["this_obs"][:, :2].copy(), other_xy=c["other_obs"][:, :2].copy(),
+                        train_idx=c["train_idx"], status=c["status"], exp_status=st, exp_F=np.array(out.F[:]),
+                        exp_counts=np.array([out.n_inliers, out.hypotheses, out.best_hypothesis], np.int32))
+
+
 if __name__ == "__main__":
     o = ol.load()
     make_da(o)
     make_lm(o)
     make_cip(o)
+    make_fmat(o)
     print("golden fixtures written to", HERE)

@@ -72,6 +72,24 @@ def kitti_cip_params(**over):
     return CipParams(**d)
 
 
+class FmParams(C.Structure):
+    """ssk_fm_params: fundamental-matrix filter (max_y_diff_epipolar / ransac_fit_prob of the reference ini)."""
+    _fields_ = [("threshold", C.c_double), ("confidence", C.c_double), ("norm_cx", C.c_double), ("norm_cy", C.c_double),
+                ("norm_scale", C.c_double), ("seed", C.c_uint64), ("max_iters", C.c_int32), ("min_points", C.c_int32)]
+
+
+class FmResult(C.Structure):
+    _fields_ = [("F", C.c_double * 9), ("valid", C.c_int32), ("n_pairs", C.c_int32), ("n_inliers", C.c_int32),
+                ("n_rejected", C.c_int32), ("hypotheses", C.c_int32), ("best_hypothesis", C.c_int32)]
+
+
+def kitti_fm_params(**over):
+    import synth
+    d = dict(synth.KITTI_FM)
+    d.update(over)
+    return FmParams(**d)
+
+
 class StereoCam(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")]
@@ -233,6 +251,17 @@ class Oracle:
         self.lib.ssko_change_in_pose.restype = C.c_int
         self.lib.ssko_change_in_pose(_p(to), len(to), _p(oo), len(oo), _p(ti), _p(st), _p(T), C.byref(prm), _p(res), C.byref(out))
         return st, res[:out.n_pairs].copy(), out
+
+    def fundamental_filter(self, this_xy, other_xy, train_idx, status, prm):
+        """Returns (status after the filter, FmResult)."""
+        tx = np.ascontiguousarray(this_xy, np.float32).reshape(-1, 2)
+        ox = np.ascontiguousarray(other_xy, np.float32).reshape(-1, 2)
+        ti = np.ascontiguousarray(train_idx, np.int32)
+        st = np.ascontiguousarray(status, np.int32).copy()
+        out = FmResult()
+        self.lib.ssko_fundamental_filter.restype = C.c_int
+        self.lib.ssko_fundamental_filter(_p(tx), len(tx), _p(ox), len(ox), _p(ti), _p(st), C.byref(prm), C.byref(out))
+        return st, out
 
     def project_match_to_3d(self, ul, vl, ur, cam):
         out = (C.c_double * 3)()

@@ -134,3 +134,8 @@ KITTI_FRONTEND = dict(n_feats=500, fast_threshold=20, n_levels=1, nms_radius=2, 
 KITTI_CIP = dict(fx_l=707.0912, fy_l=707.0912, cx_l=601.8873, cy_l=183.1104, fx_r=707.0912, fy_r=707.0912, cx_r=601.8873,
                  cy_r=183.1104, baseline=0.54, initial_max_iters=30, max_iters=30, max_incr_cost=3, use_robust_kernel=1,
                  residual_threshold=15.0, min_mod_out_vector=0.001, kernel_param=2.0, bad_tracking_th=5, reserved=0, residual_th=30.0)
+
+# fundamental-matrix filter parameters: max_y_diff_epipolar / ransac_fit_prob (KITTI.ini:121-122), OpenCV's 2000 iterations and
+# 15-point minimum; the 7-point solver normalises pixels about the image centre
+KITTI_FM = dict(threshold=2.0, confidence=0.95, norm_cx=620.5, norm_cy=188.0, norm_scale=2.0 / 1241.0, seed=0x5EED0001,
+                max_iters=2000, min_points=15)

@@ -1,0 +1,94 @@
+"""CPU: the oracle's fundamental-matrix RANSAC filter (oracle/oracle_fmat.c, contract F1-F6) against known answers: the
+cubic solver, the 7-point solver on exact data, the sampler, the adaptive iteration count, and the literal in-tree rules
+of EST.cpp:2015-2055."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import oracle_lib as ol
+import synth_cip as sc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def roots_of(oracle, c3, c2, c1, c0):
+    out = (C.c_double * 3)()
+    oracle.lib.ssko_fm_cubic_roots.argtypes = [C.c_double] * 4 + [C.c_void_p]
+    n = oracle.lib.ssko_fm_cubic_roots(c3, c2, c1, c0, out)
+    return list(out[:n])
+
+
+def test_cubic_roots_known_answers(oracle):
+    assert np.allclose(roots_of(oracle, 1, -6, 11, -6), [1, 2, 3], atol=1e-12)            # (x-1)(x-2)(x-3)
+    assert np.allclose(roots_of(oracle, 2, 0, 0, -16), [2.0], atol=1e-12)                  # one real root
+    assert np.allclose(roots_of(oracle, 0, 1, -3, 2), [1, 2], atol=1e-12)                  # degenerate: quadratic
+    assert np.allclose(roots_of(oracle, 0, 0, 4, -2), [0.5], atol=1e-15) and roots_of(oracle, 0, 0, 0, 1) == []
+    r = roots_of(oracle, 1e-3, 5.0, -2.0, -7.0)
+    assert len(r) == 3 and np.allclose(np.polyval([1e-3, 5.0, -2.0, -7.0], r), 0, atol=1e-6) and r == sorted(r)
+
+
+def test_sampler_is_counter_based_and_distinct(oracle):
+    oracle.lib.ssko_fm_sample.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+    seen = set()
+    for h in range(200):
+        idx = (C.c_int * 7)()
+        oracle.lib.ssko_fm_sample(0x5EED0001, h, 9, idx)
+        v = list(idx)
+        assert len(set(v)) == 7 and min(v) >= 0 and max(v) < 9
+        again = (C.c_int * 7)()
+        oracle.lib.ssko_fm_sample(0x5EED0001, h, 9, again)
+        assert list(again) == v                                                              # depends on (seed, h) only
+        seen.add(tuple(v))
+    assert len(seen) > 150
+
+
+def test_update_iters_matches_the_closed_form(oracle):
+    oracle.lib.ssko_fm_update_iters.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int]
+    for good, n in [(270, 300), (150, 300), (60, 300), (300, 300), (7, 300)]:
+        k = oracle.lib.ssko_fm_update_iters(0.95, good, n, 2000)
+        w7 = (good / n) ** 7
+        exact = 1 if w7 >= 1 else min(2000, int(np.ceil(np.log(0.05) / np.log(1 - w7) - 1e-9)))
+        assert k == max(exact, 1) or (good == 7 and k == 2000)
+
+
+def test_seven_point_exact_geometry(oracle):
+    """noise-free pairs of a known motion: every hypothesis' best model has all pairs as inliers."""
+    c = sc.make_case(21, noise=0.0, n_outliers=0, frac_pre_rejected=0.0, n_this=120, n_other=120)
+    # exact pixels on both sides (make_case rounds the other keyframe's pixels)
+    rng = np.random.default_rng(5)
+    P = np.stack([rng.uniform(-9, 9, 120), rng.uniform(-2.5, 2.0, 120), rng.uniform(5, 45, 120)], 1)
+    o = sc.project(P)[:, :2]
+    t = sc.project(P @ c["R"].T + c["t"])[:, :2]
+    st, out = oracle.fundamental_filter(t, o, np.arange(120, dtype=np.int32), np.zeros(120, np.int32), ol.kitti_fm_params(threshold=0.01))
+    assert out.valid == 1 and out.n_inliers == 120 and out.n_rejected == 0 and out.hypotheses <= 2
+    F = np.array(out.F[:]).reshape(3, 3)
+    m1 = np.c_[o, np.ones(120)]; m2 = np.c_[t, np.ones(120)]
+    # (the pixels enter as float32: ~6e-5 px of quantisation is all that is left in the epipolar constraint)
+    assert np.abs(np.einsum("ni,ij,nj->n", m2, F, m1)).max() < 5e-4 and abs(np.linalg.det(F)) < 1e-12
+    assert abs(np.linalg.norm(F) - 1) < 1e-12
+
+
+def test_flags_outliers_and_keeps_earlier_verdicts(oracle):
+    c = sc.make_case(1)
+    st, out = oracle.fundamental_filter(c["this_obs"][:, :2], c["other_obs"][:, :2], c["train_idx"], c["status"], ol.kitti_fm_params())
+    trk = c["status"] == 0
+    assert out.valid == 1 and out.n_pairs == int(trk.sum()) and out.n_inliers + out.n_rejected == out.n_pairs
+    assert np.array_equal(st[~trk], c["status"][~trk])
+    assert (st[trk & c["outlier"]] == 4).mean() > 0.9                        # sREJ_FUND_MATRIX; an outlier may sit on the epipolar line
+    assert (st[trk & ~c["outlier"]] == 4).mean() < 0.1
+    assert out.hypotheses < 60                                               # adaptive stop at ~90 % inliers
+
+
+def test_too_few_pairs_changes_nothing(oracle):
+    c = sc.make_case(3, n_this=30, n_other=40, n_outliers=0)
+    st0 = np.ones(30, np.int32); st0[:14] = 0                                # 14 < min_points = 15 (EST.cpp:1590)
+    st, out = oracle.fundamental_filter(c["this_obs"][:, :2], c["other_obs"][:, :2], c["train_idx"], st0, ol.kitti_fm_params())
+    assert out.valid == 0 and np.array_equal(st, st0) and out.n_pairs == 14
+
+
+def test_golden_fmat(oracle):
+    g = np.load(os.path.join(GOLD, "fmat_case0.npz"))
+    st, out = oracle.fundamental_filter(g["this_xy"], g["other_xy"], g["train_idx"], g["status"], ol.kitti_fm_params())
+    assert np.array_equal(st, g["exp_status"]) and np.array_equal(np.array(out.F[:]), g["exp_F"])
+    assert [out.n_inliers, out.hypotheses, out.best_hypothesis] == list(g["exp_counts"])
