@@ -324,6 +324,162 @@ __device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam
 			orec[3 * i + j] = w * (M[3 * i] * RA[j] + M[3 * i + 1] * RA[3 + j] + M[3 * i + 2] * RA[6 + j]);
 }
 
+// One tile of a window at the pose / landmark state the caller holds: phases I1-I3 of the file header.  `reg`: the
+// workgroup's tile region in LDS; `epoch`: tiles this workgroup has started (the landmark-record flag counts NW per tile);
+// partial sums go to the window's slot arrays Pp / Sp, Y / gradient terms / landmark factors to its HBM scratch.
+__device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* pose_cur,
+                                             double* reg, double lambda, bool pre, int epoch, int* s_lmflag,
+                                             double* __restrict__ Pp, double* __restrict__ Sp, double& vmax)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+		double* ent = reg;
+		double* obsr = ent + ENT_P * T.n_ent;
+		double* Yr = obsr + OBS_P * T.n_obs;
+		double* lmr = Yr + Y_P * T.n_inc;
+		// ---- I1: observations ----
+		for (int k = tid; k < T.n_obs; k += NT)
+			linearize_obs_lds(D, W, P, pose_cur, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
+		__syncthreads();
+		// ---- I2: landmark lanes (top of the workgroup) first: V, g_f, Cholesky -> lmr; every wave then signals ----
+		{
+			const int j = NT - 1 - tid;
+			if (j < T.n_lm) {
+				const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
+				const int slot = lrec.x;
+				if (slot >= 0) {
+					double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
+					for (int k = lrec.y; k < lrec.z; ++k) {
+						const double* orr = obsr + OBS_P * k;
+						double jf[12], rr[4];
+#pragma unroll
+						for (int c = 0; c < 12; ++c) jf[c] = orr[c];
+#pragma unroll
+						for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
+						v00 += jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
+						v01 += jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
+						v02 += jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
+						v11 += jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
+						v12 += jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
+						v22 += jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
+						g0 += jf[0] * rr[0] + jf[3] * rr[1] + jf[6] * rr[2] + jf[9] * rr[3];
+						g1 += jf[1] * rr[0] + jf[4] * rr[1] + jf[7] * rr[2] + jf[10] * rr[3];
+						g2 += jf[2] * rr[0] + jf[5] * rr[1] + jf[8] * rr[2] + jf[11] * rr[3];
+					}
+					if (pre) {
+						vmax = fmax(vmax, fmax(v00, fmax(v11, v22)));
+					} else {
+						double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
+						Hm[0] = v00; Hm[1] = v01; Hm[2] = v02; Hm[3] = v01; Hm[4] = v11; Hm[5] = v12; Hm[6] = v02; Hm[7] = v12; Hm[8] = v22;
+						double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
+						gl[0] = g0; gl[1] = g1; gl[2] = g2;
+						const double i00 = rsq_f64(v00 + lambda);         // 1 / L_kk straight from the reciprocal square root
+						const double l10 = v01 * i00, l20 = v02 * i00;
+						const double i11 = rsq_f64(v11 + lambda - l10 * l10);
+						const double l21 = (v12 - l20 * l10) * i11;
+						const double i22 = rsq_f64(v22 + lambda - l20 * l20 - l21 * l21);
+						const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
+						const double rec[9] = {i00, i10, i11, i20, i21, i22, i00 * g0, i10 * g0 + i11 * g1, i20 * g0 + i21 * g1 + i22 * g2};
+						double* lr = lmr + LMR_P * j;
+						double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
+#pragma unroll
+						for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
+					}
+				}
+			}
+		}
+		// this wave's landmark records are written (LDS operations of a wave retire in order): release them
+		if (lane == 0) __hip_atomic_fetch_add(s_lmflag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		// ---- I2: incidence lanes: W and the gradient term in registers, then (once every landmark record of the tile
+		//      is there -- the landmark waves are long done) Y = W L^-T -> LDS, reduced gradient term -> HBM ----
+		if (!pre && tid < T.n_inc) {
+			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + tid];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
+			const int lml = irec.x & 0x7FFF, cnt = irec.x >> 16;
+			const bool unk = (irec.x >> 15) & 1;
+			double Wm[18], ge[6];
+#pragma unroll
+			for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
+#pragma unroll
+			for (int c = 0; c < 6; ++c) ge[c] = 0.0;
+			int nxt = irec.w;
+			for (int k = 0; k < cnt; ++k) {
+				const int loc = nxt;
+				if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + irec.y + k + 1];
+				const double* er = ent + ENT_P * (loc & 0xFFFF);
+				const double* orr = obsr + OBS_P * (loc >> 16);
+				double a[12], q[3], rr[4], tv[3], x[3];
+#pragma unroll
+				for (int c = 0; c < 12; ++c) a[c] = er[c];
+#pragma unroll
+				for (int c = 0; c < 3; ++c) q[c] = er[12 + c];
+#pragma unroll
+				for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
+#pragma unroll
+				for (int c = 0; c < 3; ++c) tv[c] = a[c] * rr[0] + a[3 + c] * rr[1] + a[6 + c] * rr[2] + a[9 + c] * rr[3];
+				cross3(q, tv, x);
+#pragma unroll
+				for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
+				if (unk) {
+					double jf[12];
+#pragma unroll
+					for (int c = 0; c < 12; ++c) jf[c] = orr[c];
+#pragma unroll
+					for (int b = 0; b < 3; ++b) {
+						double cb[3];
+#pragma unroll
+						for (int c = 0; c < 3; ++c) cb[c] = a[c] * jf[b] + a[3 + c] * jf[3 + b] + a[6 + c] * jf[6 + b] + a[9 + c] * jf[9 + b];
+						cross3(q, cb, x);
+#pragma unroll
+						for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
+					}
+				}
+			}
+			double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
+			if (unk) {
+				while (__hip_atomic_load(s_lmflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * epoch) __builtin_amdgcn_s_sleep(1);
+				const double* lr = lmr + LMR_P * lml;
+				const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
+				double* yl = Yr + Y_P * tid;
+#pragma unroll
+				for (int a = 0; a < 6; ++a) {
+					const double y0 = Wm[3 * a] * i00;
+					const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
+					const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
+					yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
+					gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
+				}
+			} else {
+#pragma unroll
+				for (int a = 0; a < 6; ++a) gr[a] = ge[a];
+			}
+		}
+		__syncthreads();
+		// ---- I3: Y to HBM for the back-substitution (coalesced), then one chunk task per wave and round:
+		//      H_pp chunks read the entry records, Schur chunks the Y records; both reduce through the scratch
+		//      over the (dead) observation records ----
+		if (!pre) {
+			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
+			for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
+		}
+		const int n_task = T.n_pc + (pre ? 0 : T.n_sc);
+		for (int task = wave; task < n_task; task += NW) {
+			double acc[36];
+#pragma unroll
+			for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+			if (task < T.n_pc) {
+				const int g = 64 * task + lane;
+				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
+				pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
+				wave_seg_sum36(acc, rec.y >> 8, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
+			} else {
+				const int c = task - T.n_pc, g = 64 * c + lane;
+				const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
+				schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
+				wave_seg_sum36(acc, rec.y >> 8, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
+			}
+		}
+		__syncthreads();
+}
+
 // F2: H_red block (e,e') = sum of its H_pp slots + lambda I - sum of its Schur slots (slot order), diagonal blocks
 // written from their upper triangle; g_red(e) = sum of its incidences' terms (contiguous, edge-major, 8 lanes per
 // component) into the border row; G: blocked LDL^T + back-substitution (ssk_lm_device.h).  A: (n6 + 1) x np.
@@ -427,163 +583,8 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 		double vmax = 0.0;
 		STAMP(0);
 		for (int t = 0; t < W.n_tiles; ++t) {
-			const lm_tile T = D.tile[W.tile0 + t];
-			double* ent = reg;
-			double* obsr = ent + ENT_P * T.n_ent;
-			double* Yr = obsr + OBS_P * T.n_obs;
-			double* lmr = Yr + Y_P * T.n_inc;
-			++epoch;
-			// ---- I1: observations ----
-			for (int k = tid; k < T.n_obs; k += NT)
-				linearize_obs_lds(D, W, P, pose_cur, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
-			__syncthreads();
+			process_tile(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, ++epoch, &s_lmflag, Pp, Sp, vmax);
 			STAMP(1);
-			// ---- I2: landmark lanes (top of the workgroup) first: V, g_f, Cholesky -> lmr; every wave then signals ----
-			{
-				const int j = NT - 1 - tid;
-				if (j < T.n_lm) {
-					const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
-					const int slot = lrec.x;
-					if (slot >= 0) {
-						double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
-						for (int k = lrec.y; k < lrec.z; ++k) {
-							const double* orr = obsr + OBS_P * k;
-							double jf[12], rr[4];
-#pragma unroll
-							for (int c = 0; c < 12; ++c) jf[c] = orr[c];
-#pragma unroll
-							for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
-							v00 += jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
-							v01 += jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
-							v02 += jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
-							v11 += jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
-							v12 += jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
-							v22 += jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
-							g0 += jf[0] * rr[0] + jf[3] * rr[1] + jf[6] * rr[2] + jf[9] * rr[3];
-							g1 += jf[1] * rr[0] + jf[4] * rr[1] + jf[7] * rr[2] + jf[10] * rr[3];
-							g2 += jf[2] * rr[0] + jf[5] * rr[1] + jf[8] * rr[2] + jf[11] * rr[3];
-						}
-						if (pre) {
-							vmax = fmax(vmax, fmax(v00, fmax(v11, v22)));
-						} else {
-							double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
-							Hm[0] = v00; Hm[1] = v01; Hm[2] = v02; Hm[3] = v01; Hm[4] = v11; Hm[5] = v12; Hm[6] = v02; Hm[7] = v12; Hm[8] = v22;
-							double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
-							gl[0] = g0; gl[1] = g1; gl[2] = g2;
-							const double i00 = rsq_f64(v00 + lambda);         // 1 / L_kk straight from the reciprocal square root
-							const double l10 = v01 * i00, l20 = v02 * i00;
-							const double i11 = rsq_f64(v11 + lambda - l10 * l10);
-							const double l21 = (v12 - l20 * l10) * i11;
-							const double i22 = rsq_f64(v22 + lambda - l20 * l20 - l21 * l21);
-							const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
-							const double rec[9] = {i00, i10, i11, i20, i21, i22, i00 * g0, i10 * g0 + i11 * g1, i20 * g0 + i21 * g1 + i22 * g2};
-							double* lr = lmr + LMR_P * j;
-							double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
-#pragma unroll
-							for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
-						}
-					}
-				}
-			}
-			// this wave's landmark records are written (LDS operations of a wave retire in order): release them
-			if (lane == 0) __hip_atomic_fetch_add(&s_lmflag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-			// ---- I2: incidence lanes: W and the gradient term in registers, then (once every landmark record of the tile
-			//      is there -- the landmark waves are long done) Y = W L^-T -> LDS, reduced gradient term -> HBM ----
-			if (!pre && tid < T.n_inc) {
-				const int4 irec = D.inc_rec[W.lme0 + T.inc0 + tid];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
-				const int lml = irec.x & 0x7FFF, cnt = irec.x >> 16;
-				const bool unk = (irec.x >> 15) & 1;
-				double Wm[18], ge[6];
-#pragma unroll
-				for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
-#pragma unroll
-				for (int c = 0; c < 6; ++c) ge[c] = 0.0;
-				int nxt = irec.w;
-				for (int k = 0; k < cnt; ++k) {
-					const int loc = nxt;
-					if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + irec.y + k + 1];
-					const double* er = ent + ENT_P * (loc & 0xFFFF);
-					const double* orr = obsr + OBS_P * (loc >> 16);
-					double a[12], q[3], rr[4], tv[3], x[3];
-#pragma unroll
-					for (int c = 0; c < 12; ++c) a[c] = er[c];
-#pragma unroll
-					for (int c = 0; c < 3; ++c) q[c] = er[12 + c];
-#pragma unroll
-					for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
-#pragma unroll
-					for (int c = 0; c < 3; ++c) tv[c] = a[c] * rr[0] + a[3 + c] * rr[1] + a[6 + c] * rr[2] + a[9 + c] * rr[3];
-					cross3(q, tv, x);
-#pragma unroll
-					for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
-					if (unk) {
-						double jf[12];
-#pragma unroll
-						for (int c = 0; c < 12; ++c) jf[c] = orr[c];
-#pragma unroll
-						for (int b = 0; b < 3; ++b) {
-							double cb[3];
-#pragma unroll
-							for (int c = 0; c < 3; ++c) cb[c] = a[c] * jf[b] + a[3 + c] * jf[3 + b] + a[6 + c] * jf[6 + b] + a[9 + c] * jf[9 + b];
-							cross3(q, cb, x);
-#pragma unroll
-							for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
-						}
-					}
-				}
-				double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
-				if (unk) {
-					while (__hip_atomic_load(&s_lmflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * epoch) __builtin_amdgcn_s_sleep(1);
-					const double* lr = lmr + LMR_P * lml;
-					const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
-					double* yl = Yr + Y_P * tid;
-#pragma unroll
-					for (int a = 0; a < 6; ++a) {
-						const double y0 = Wm[3 * a] * i00;
-						const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
-						const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
-						yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
-						gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
-					}
-				} else {
-#pragma unroll
-					for (int a = 0; a < 6; ++a) gr[a] = ge[a];
-				}
-			}
-			__syncthreads();
-			STAMP(2);
-			// ---- I3: Y to HBM for the back-substitution (coalesced), then one chunk task per wave and round:
-			//      H_pp chunks read the entry records, Schur chunks the Y records; both reduce through the scratch
-			//      over the (dead) observation records ----
-			FTICK0();
-			if (!pre) {
-				double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
-				for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
-			}
-			FTICK(0);
-			const int n_task = T.n_pc + (pre ? 0 : T.n_sc);
-			for (int task = wave; task < n_task; task += NW) {
-				double acc[36];
-#pragma unroll
-				for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-				if (task < T.n_pc) {
-					const int g = 64 * task + lane;
-					const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
-					pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
-					FTICK(1);
-					wave_seg_sum36(acc, rec.y >> 8, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
-				} else {
-					const int c = task - T.n_pc, g = 64 * c + lane;
-					const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
-					schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
-					FTICK(1);
-					wave_seg_sum36(acc, rec.y >> 8, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
-				}
-				FTICK(2);
-			}
-			__syncthreads();
-			FTICK(3);
-			STAMP(3);
 		}
 		if (pre) {
 			// lambda0 = tau * max diag(H): the diagonal blocks' slot sums, and the landmark blocks' diagonals
