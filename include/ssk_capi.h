@@ -85,6 +85,7 @@ enum {
 	SSK_STAGE_LM_UPDATE,       /* state update + error evaluation */
 	SSK_STAGE_CHANGE_IN_POSE,  /* cip_kernel: change-in-pose outlier filter */
 	SSK_STAGE_FUND_MATRIX,     /* fm_kernel: fundamental-matrix RANSAC outlier filter */
+	SSK_STAGE_BOW,             /* bow_words / bow_vector / bow_score / bow_topk kernels: place recognition */
 	SSK_STAGE_COUNT
 };
 int ssk_profile_enable(ssk_ctx* ctx, int on);     /* also clears the accumulated sums */
@@ -301,6 +302,52 @@ int ssk_cip_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, c
 int ssk_fm_run_batch(ssk_ctx* ctx, ssk_kfbatch* this_b, ssk_kfbatch* other_b, const int32_t* pairs, int n_pairs,
                      const ssk_fm_params* params, const int32_t* d_train_idx, int32_t* d_status, int32_t* d_tracked,
                      ssk_fm_result* d_results);
+
+/* ---- bag-of-words place recognition: CBoWManager (src/CBoWManager.h:59-109) ---------------------------------
+ * Replaces DBoW2 1.0.2's BriefVocabulary::transform and BriefDatabase::add / ::query for the vocabulary the reference
+ * loads (demo/voc.yml.gz: k = 8, L = 5, weightingType 0 = TF_IDF, scoringType 0 = L1_NORM; any k, L and tree shape
+ * are accepted, other weighting / scoring types are refused).  Contract W1-W5: oracle/oracle_bow.c, DESIGN.md.
+ *   m_voc.load(file); m_db.setVocabulary(m_voc, true, 5)  (BOW.h:59-66)  ->  ssk_bow_vocab_create + ssk_bow_db_create
+ *   m_db.add(features)            (BOW.h:71-77, EST.cpp:118,919)         ->  ssk_bow_transform + ssk_bow_db_add
+ *   m_db.query(features, ret, 4)  (BOW.h:84-90, EST.cpp:426)             ->  ssk_bow_transform + ssk_bow_db_query
+ * The file parser (OpenCV FileStorage YAML, gzip) lives in the C++ facade (host/CBoWManager.h); this interface takes the
+ * vocabulary as flat arrays.  Entry ids are 0, 1, 2 ... in insertion order, which the reference reads as keyframe ids. */
+#define SSK_BOW_MAX_RESULTS 16
+typedef struct ssk_bow_vocab ssk_bow_vocab;
+typedef struct ssk_bow_db ssk_bow_db;
+/* n_rec node records IN FILE ORDER (the root, node 0, has no record): node_id > 0, parent_id >= 0, weight, 32-byte
+ * descriptor with bit m + 8k of DBoW2's bitset in bit m of byte k (BOW.h:95-107).  word_node[w] = nodeId of word w. */
+int ssk_bow_vocab_create(ssk_ctx* ctx, int k, int L, int weighting, int scoring, int n_rec, const int32_t* node_id,
+                         const int32_t* parent_id, const double* weight, const uint8_t* desc, int n_words,
+                         const int32_t* word_node, ssk_bow_vocab** out);
+void ssk_bow_vocab_destroy(ssk_bow_vocab* v);
+int ssk_bow_vocab_info(const ssk_bow_vocab* v, int* k, int* L, int* n_nodes, int* n_words);
+/* Host drop-in, one keyframe: n descriptors (rows of m_descriptors_left) -> bag-of-words vector, ascending word ids
+ * and L1-normalised values; words / values have capacity n. */
+int ssk_bow_transform(ssk_ctx* ctx, const ssk_bow_vocab* v, const uint8_t* desc, int n, int32_t* words, double* values,
+                      int* n_words);
+/* Batched, device resident: left descriptors of keyframes [kf_begin, kf_end) of the batch -> the batch's bag-of-words
+ * arrays (asynchronous on the context stream). */
+int ssk_bow_transform_batch(ssk_ctx* ctx, const ssk_bow_vocab* v, ssk_kfbatch* b, int kf_begin, int kf_end);
+int ssk_kfbatch_bow_download(ssk_ctx* ctx, ssk_kfbatch* b, int kf, int32_t* words, double* values, int cap, int* n);
+/* Database of at most capacity_entries vectors of at most max_words_per_entry words each (HBM resident). */
+int ssk_bow_db_create(ssk_ctx* ctx, const ssk_bow_vocab* v, int capacity_entries, int max_words_per_entry, ssk_bow_db** out);
+void ssk_bow_db_destroy(ssk_bow_db* d);
+int ssk_bow_db_size(const ssk_bow_db* d);
+int ssk_bow_db_clear(ssk_ctx* ctx, ssk_bow_db* d);
+int ssk_bow_db_add(ssk_ctx* ctx, ssk_bow_db* d, const int32_t* words, const double* values, int n, int* entry_id);
+int ssk_bow_db_add_from_batch(ssk_ctx* ctx, ssk_bow_db* d, ssk_kfbatch* b, int kf, int* entry_id);   /* device to device */
+/* L1 query: up to max_results (1..SSK_BOW_MAX_RESULTS) entries by descending score, ties by ascending entry id; entries
+ * with id >= max_id are skipped unless max_id == -1; entries without a common word are not reported. */
+int ssk_bow_db_query(ssk_ctx* ctx, ssk_bow_db* d, const int32_t* words, const double* values, int n, int max_results, int max_id,
+                     int32_t* ids, double* scores, int* n_results);
+/* Batched: the bag-of-words vectors of keyframes [kf_begin, kf_end) of the batch against d; max_ids: host array, one per
+ * query, or NULL (-1).  Results stay in the batch (asynchronous); read them with ssk_kfbatch_bow_results, which writes
+ * SSK_BOW_MAX_RESULTS slots per query. */
+int ssk_bow_db_query_batch(ssk_ctx* ctx, ssk_bow_db* d, ssk_kfbatch* b, int kf_begin, int kf_end, int max_results,
+                           const int32_t* max_ids);
+int ssk_kfbatch_bow_results(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, int32_t* ids, double* scores,
+                            int32_t* n_results);
 
 /* ---- B3: relative bundle adjustment, Levenberg-Marquardt with Schur complement + dense Cholesky ----
  * Replaces the numerical core of  rba.define_new_keyframe(listObs, newKFInfo, true)  (EST.cpp:782-784):

@@ -110,6 +110,39 @@ int ssko_lm_solve(const ssk_lm_window* W, const ssk_lm_params* P, double* poses,
 void ssko_build_observations(const ssk_keypoint* kl, const ssk_keypoint* kr, const ssk_dmatch* m, int n,
                              const ssk_lm_params* P, float* obs_px, double* init_pos);
 
+/* ---------------- bag-of-words place recognition (oracle_bow.c; contract W1-W5 there) ---------------- */
+typedef struct ssko_bow_vocab ssko_bow_vocab;
+typedef struct ssko_bow_db ssko_bow_db;
+/* [published: DBoW2 1.0.2 TemplatedVocabulary::load; file demo/voc.yml.gz] records in FILE ORDER (root excluded):
+ * node_id > 0, parent_id >= 0, weight, 32-byte descriptor with bit m + 8k of the DBoW2 bitset in bit m of byte k
+ * (BOW.h:95-107); word_node[w] = nodeId of word w.  NULL on malformed input. */
+ssko_bow_vocab* ssko_bow_vocab_create(int k, int L, int n_rec, const int32_t* node_id, const int32_t* parent_id,
+                                      const double* weight, const uint8_t* desc, int n_words, const int32_t* word_node);
+void ssko_bow_vocab_destroy(ssko_bow_vocab* v);
+/* [published: TemplatedVocabulary::transform(feature, id, weight)] word id of one descriptor (W2) */
+int ssko_bow_word(const ssko_bow_vocab* v, const uint8_t* feat, double* weight);
+/* [published: TemplatedVocabulary::transform(features, BowVector), TF_IDF + L1; call BOW.h:73-76,86-89] (W3) */
+int ssko_bow_transform(const ssko_bow_vocab* v, const uint8_t* feats, int n, int32_t* out_words, double* out_values);
+/* [published: TemplatedDatabase::add / queryL1; calls BOW.h:76,89, EST.cpp:118,426,919] (W4, W5) */
+ssko_bow_db* ssko_bow_db_create(int n_words);
+void ssko_bow_db_destroy(ssko_bow_db* d);
+int ssko_bow_db_size(const ssko_bow_db* d);
+int ssko_bow_db_add(ssko_bow_db* d, const int32_t* words, const double* values, int n);
+int ssko_bow_db_query(const ssko_bow_db* d, const int32_t* words, const double* values, int n, int max_results, int max_id,
+                      int32_t* out_ids, double* out_scores);
+
+/* ---------------- keyframe-insertion / loop-closure policy (oracle_policy.c), all [literal] ---------------- */
+double ssko_update_translation_threshold(double x, double th);     /* UTIL.cpp:153-161 */
+double ssko_update_rotation_threshold(double x, double th);        /* UTIL.cpp:163-171 */
+void ssko_vo_check(double inc_translation_kf, double inc_rotation_kf, double incr_translation, double incr_rotation,
+                   int64_t tracked_feats_from_last_kf, double max_translation_limit, double max_rotation_limit,
+                   double max_translation, double max_rotation, int vo_id_tracking_th, int32_t* out4);   /* EST.cpp:366-392 */
+int ssko_get_similar_kfs(int64_t new_kf_id, int n_q, const int64_t* q_ids, const double* q_scores, const int64_t* topo,
+                         int64_t submap_size, int64_t lc_distance, int64_t* similar, int* n_similar, int64_t* lc_id);   /* EST.cpp:1737-1826 */
+void ssko_kf_decision(int insert_in, int n_da, const int64_t* da_kf_idx, const int64_t* da_tracked, int potential_lc, int64_t lc_id,
+                      int vo_force_new_kf, int64_t updated_matches_th, int64_t up_matches_th_plus, double* th_inout,
+                      int64_t* sorted, int64_t* highest_out, int32_t* flags_out3);   /* EST.cpp:437-548 */
+
 #ifdef __cplusplus
 }
 #endif

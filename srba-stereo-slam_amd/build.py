@@ -80,16 +80,19 @@ def build_host(verbose=True):
     srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp") and not f.endswith("_tool.cpp")]
     hdrs = [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")]
     deps = srcs + hdrs + [LIB]
-    # CPU-only driver of the keyframe record I/O (host/ssk_kf_io.h), no GPU library needed
-    tool, tool_src = os.path.join(host, "kf_io_tool"), os.path.join(host, "kf_io_tool.cpp")
-    if not os.path.exists(tool) or os.path.getmtime(tool) < max(os.path.getmtime(d) for d in hdrs + [tool_src]):
-        r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), tool_src, "-o", tool], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("kf_io_tool build failed:\n%s" % r.stderr)
+    # CPU-only drivers of host-side logic (no GPU library needed): keyframe record I/O (host/ssk_kf_io.h); keyframe policy
+    # (host/ssk_kf_policy.h) + vocabulary file reader (host/ssk_bow_vocab_io.h, zlib)
+    for name, libs in (("kf_io_tool", []), ("policy_tool", ["-lz"])):
+        tool, tool_src = os.path.join(host, name), os.path.join(host, name + ".cpp")
+        if not os.path.exists(tool) or os.path.getmtime(tool) < max(os.path.getmtime(d) for d in hdrs + [tool_src]):
+            r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), tool_src, "-o", tool] + libs,
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("%s build failed:\n%s" % (name, r.stderr))
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
         return out
     cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")] + srcs + \
-          ["-L", HERE, "-lssk_hip", "-Wl,-rpath,$ORIGIN/..", "-o", out]
+          ["-L", HERE, "-lssk_hip", "-lz", "-Wl,-rpath,$ORIGIN/..", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("host facade build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))

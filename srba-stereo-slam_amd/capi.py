@@ -192,12 +192,136 @@ class KfBatch:
         self.ctx._chk(self.ctx.lib.ssk_kfbatch_counts(self.ctx.h, self.h_, _ptr(nkp), _ptr(nm)))
         return nkp.reshape(-1, 2), nm
 
+    # -- bag of words (ssk_bow.hip) --
+    def bow_transform(self, voc, kf_begin=0, kf_end=None):
+        self.ctx._chk(self.ctx.lib.ssk_bow_transform_batch(self.ctx.h, voc.h_, self.h_, int(kf_begin), int(self.n_kf if kf_end is None else kf_end)))
+
+    def bow_download(self, kf):
+        w = np.zeros(self.max_feats, np.int32)
+        v = np.zeros(self.max_feats)
+        n = C.c_int()
+        self.ctx._chk(self.ctx.lib.ssk_kfbatch_bow_download(self.ctx.h, self.h_, int(kf), _ptr(w), _ptr(v), self.max_feats, C.byref(n)))
+        return w[:n.value].copy(), v[:n.value].copy()
+
+    def bow_query(self, db, max_results=4, max_ids=None, kf_begin=0, kf_end=None):
+        kf_end = self.n_kf if kf_end is None else kf_end
+        mi = None if max_ids is None else np.ascontiguousarray(max_ids, np.int32)
+        assert mi is None or len(mi) == kf_end - kf_begin
+        self.ctx._chk(self.ctx.lib.ssk_bow_db_query_batch(self.ctx.h, db.h_, self.h_, int(kf_begin), int(kf_end), int(max_results),
+                                                          None if mi is None else _ptr(mi)))
+
+    def bow_results(self, kf_begin=0, kf_end=None):
+        """[(ids, scores)] of the last bow_query for keyframes [kf_begin, kf_end)."""
+        kf_end = self.n_kf if kf_end is None else kf_end
+        nq = kf_end - kf_begin
+        ids = np.zeros((nq, BOW_MAX_RESULTS), np.int32)
+        sc = np.zeros((nq, BOW_MAX_RESULTS))
+        n = np.zeros(nq, np.int32)
+        self.ctx._chk(self.ctx.lib.ssk_kfbatch_bow_results(self.ctx.h, self.h_, int(kf_begin), int(kf_end), _ptr(ids), _ptr(sc), _ptr(n)))
+        return [(ids[i, :n[i]].copy(), sc[i, :n[i]].copy()) for i in range(nq)]
+
     def debug_candidates(self, kf, eye):
         cap = (self.w // 2 + 1) * (self.h // 2 + 1)
         keys = np.zeros(cap, np.uint32)
         n = C.c_int()
         self.ctx._chk(self.ctx.lib.ssk_kfbatch_debug_candidates(self.ctx.h, self.h_, int(kf), int(eye), _ptr(keys), cap, C.byref(n)))
         return keys[:n.value].copy()
+
+
+BOW_MAX_RESULTS = 16
+
+
+class BowVocab:
+    """ssk_bow_vocab: the vocabulary tree on the device.  v: dict(k, L, weighting, scoring, node_id, parent_id, weight,
+    desc[n,32], word_node) in file order (what host/CBoWManager.h parses from the DBoW2 YAML)."""
+
+    def __init__(self, ctx, v):
+        self.ctx = ctx
+        nid = np.ascontiguousarray(v["node_id"], np.int32); pid = np.ascontiguousarray(v["parent_id"], np.int32)
+        w = np.ascontiguousarray(v["weight"], np.float64); d = np.ascontiguousarray(v["desc"], np.uint8).reshape(-1, 32)
+        wn = np.ascontiguousarray(v["word_node"], np.int32)
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.ssk_bow_vocab_create(ctx.h, int(v["k"]), int(v["L"]), int(v.get("weighting", 0)), int(v.get("scoring", 0)),
+                                              len(nid), _ptr(nid), _ptr(pid), _ptr(w), _ptr(d), len(wn), _ptr(wn), C.byref(h)))
+        self.h_ = h
+        self.n_words = len(wn)
+        _LIVE.add(self)
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.ctx.lib.ssk_bow_vocab_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        k, L, nn, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.ctx._chk(self.ctx.lib.ssk_bow_vocab_info(self.h_, C.byref(k), C.byref(L), C.byref(nn), C.byref(nw)))
+        return k.value, L.value, nn.value, nw.value
+
+    def transform(self, desc):
+        """Host drop-in: descriptors [n, 32] -> (ascending word ids, L1-normalised values)."""
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        w = np.zeros(len(d) + 1, np.int32)
+        v = np.zeros(len(d) + 1)
+        n = C.c_int()
+        self.ctx._chk(self.ctx.lib.ssk_bow_transform(self.ctx.h, self.h_, _ptr(d), len(d), _ptr(w), _ptr(v), C.byref(n)))
+        return w[:n.value].copy(), v[:n.value].copy()
+
+
+class BowDb:
+    """ssk_bow_db: bag-of-words database in HBM (entry ids = insertion order)."""
+
+    def __init__(self, ctx, voc, capacity_entries, max_words_per_entry=512):
+        self.ctx, self.voc = ctx, voc
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.ssk_bow_db_create(ctx.h, voc.h_, int(capacity_entries), int(max_words_per_entry), C.byref(h)))
+        self.h_ = h
+        _LIVE.add(self)
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.ctx.lib.ssk_bow_db_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.ctx.lib.ssk_bow_db_size(self.h_)
+
+    def clear(self):
+        self.ctx._chk(self.ctx.lib.ssk_bow_db_clear(self.ctx.h, self.h_))
+
+    def add(self, words, vals):
+        w = np.ascontiguousarray(words, np.int32); v = np.ascontiguousarray(vals, np.float64)
+        e = C.c_int()
+        self.ctx._chk(self.ctx.lib.ssk_bow_db_add(self.ctx.h, self.h_, _ptr(w), _ptr(v), len(w), C.byref(e)))
+        return e.value
+
+    def add_from_batch(self, batch, kf):
+        e = C.c_int()
+        self.ctx._chk(self.ctx.lib.ssk_bow_db_add_from_batch(self.ctx.h, self.h_, batch.h_, int(kf), C.byref(e)))
+        return e.value
+
+    def query(self, words, vals, max_results=4, max_id=-1):
+        w = np.ascontiguousarray(words, np.int32); v = np.ascontiguousarray(vals, np.float64)
+        ids = np.zeros(BOW_MAX_RESULTS, np.int32); sc = np.zeros(BOW_MAX_RESULTS)
+        n = C.c_int()
+        self.ctx._chk(self.ctx.lib.ssk_bow_db_query(self.ctx.h, self.h_, _ptr(w), _ptr(v), len(w), int(max_results), int(max_id),
+                                                    _ptr(ids), _ptr(sc), C.byref(n)))
+        return ids[:n.value].copy(), sc[:n.value].copy()
 
 
 class LmWindow(C.Structure):
@@ -488,7 +612,7 @@ class Context:
         self._chk(self.lib.ssk_profile_enable(self.h, int(on)))
 
     def profile_read(self):
-        n = 12
+        n = 13
         ms = (C.c_double * n)()
         calls = (C.c_int64 * n)()
         self._chk(self.lib.ssk_profile_read(self.h, ms, calls))

@@ -122,6 +122,7 @@ void ssk_kfbatch_destroy(ssk_kfbatch* b)
 	void* ptrs[] = {b->img, b->cand, b->ncand, b->kp_xy, b->kp_resp, b->kp_angle, b->kp_cs, b->nkp, b->desc,
 	                b->m_q, b->m_t, b->m_d, b->nm, b->m_row, b->m_xy, b->m_obs};
 	for (void* p : ptrs) if (p) (void)hipFree(p);
+	ssk_kfbatch_bow_free(b);
 	delete b;
 }
 

@@ -30,8 +30,16 @@ struct ssk_kfbatch {
 	int32_t* m_row = nullptr;    // [B][N]   absolute descriptor row of the match's left keypoint
 	float2* m_xy = nullptr;      // [B][N]   left keypoint pixel of the match
 	float4* m_obs = nullptr;     // [B][N]   stereo observation (xl, yl, xr, yr) of the match (change-in-pose filter)
+	// bag-of-words place recognition (ssk_bow.hip), allocated by the first transform on the batch
+	int32_t* bow_word = nullptr; // [B][N]   ascending word ids of the left descriptors
+	double* bow_val = nullptr;   // [B][N]   L1-normalised values
+	int32_t* bow_n = nullptr;    // [B]
+	int32_t* q_ids = nullptr;    // [B][SSK_BOW_MAX_RESULTS] last query: entry ids, scores, counts
+	double* q_scores = nullptr;
+	int32_t* q_n = nullptr;
 };
 
+void ssk_kfbatch_bow_free(ssk_kfbatch* b);
 int ssk_launch_fast(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, int threshold);
 int ssk_launch_select(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, const ssk_frontend_params& p);
 int ssk_launch_describe(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, int n_feats);

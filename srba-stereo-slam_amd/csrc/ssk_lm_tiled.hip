@@ -525,7 +525,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 	__shared__ int s_lmflag;                           // waves that have published their landmark records, all tiles so far
 
 	const lm_win W = D.win[blockIdx.x];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x;
 	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1;
 	int epoch = 0;                                     // tiles started so far
 	double* pose_cur = s_dyn;

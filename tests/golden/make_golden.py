@@ -60,10 +60,32 @@ def make_fmat(oracle):
                         exp_counts=np.array([out.n_inliers, out.hypotheses, out.best_hypothesis], np.int32))
 
 
+def make_bow(oracle):
+    import bow_vocab as bv
+    v = bv.synth(k=8, L=3, seed=21)
+    V = oracle.bow_vocab(v)
+    D = oracle.bow_db(V.n_words)
+    rng = np.random.default_rng(22)
+    seq = bv.keyframe_sequence(v, rng, n_kf=10, n=150)
+    seq.append(seq[2].copy())                        # a revisit: keyframe 10 sees what keyframe 2 saw
+    desc_off, bow_off, bw, bx = [0], [0], [], []
+    res_ids = np.zeros((len(seq), 4), np.int32); res_scores = np.zeros((len(seq), 4)); res_n = np.zeros(len(seq), np.int32)
+    for e, f in enumerate(seq):
+        w, x = V.transform(f)
+        ids, sc = D.query(w, x, 4)                   # query before insertion, as EST.cpp:426 / :919
+        res_n[e] = len(ids); res_ids[e, :len(ids)] = ids; res_scores[e, :len(ids)] = sc
+        D.add(w, x)
+        desc_off.append(desc_off[-1] + len(f)); bow_off.append(bow_off[-1] + len(w)); bw.append(w); bx.append(x)
+    np.savez_compressed(os.path.join(HERE, "bow_case0.npz"), n_kf=np.int32(len(seq)), desc=np.concatenate(seq), desc_off=np.array(desc_off, np.int32),
+                        bow_word=np.concatenate(bw), bow_val=np.concatenate(bx), bow_off=np.array(bow_off, np.int32), res_ids=res_ids,
+                        res_scores=res_scores, res_n=res_n, **{"v_" + k: np.asarray(val) for k, val in v.items()})
+
+
 if __name__ == "__main__":
     o = ol.load()
     make_da(o)
     make_lm(o)
     make_cip(o)
     make_fmat(o)
+    make_bow(o)
     print("golden fixtures written to", HERE)

@@ -263,11 +263,81 @@ class Oracle:
         self.lib.ssko_fundamental_filter(_p(tx), len(tx), _p(ox), len(ox), _p(ti), _p(st), C.byref(prm), C.byref(out))
         return st, out
 
+    # ---- bag of words (oracle_bow.c) ----
+    def bow_vocab(self, v):
+        """v: dict from bow_vocab.parse / synth -> OracleBowVocab."""
+        return OracleBowVocab(self.lib, v)
+
+    def bow_db(self, n_words):
+        return OracleBowDb(self.lib, n_words)
+
     def project_match_to_3d(self, ul, vl, ur, cam):
         out = (C.c_double * 3)()
         self.lib.ssko_project_match_to_3d.argtypes = [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         self.lib.ssko_project_match_to_3d(ul, vl, ur, C.byref(cam), out)
         return np.array(out[:])
+
+
+class OracleBowVocab:
+    def __init__(self, lib, v):
+        self.lib = lib
+        self.n_words = len(v["word_node"])
+        nid = np.ascontiguousarray(v["node_id"], np.int32); pid = np.ascontiguousarray(v["parent_id"], np.int32)
+        w = np.ascontiguousarray(v["weight"], np.float64); d = np.ascontiguousarray(v["desc"], np.uint8)
+        wn = np.ascontiguousarray(v["word_node"], np.int32)
+        lib.ssko_bow_vocab_create.restype = C.c_void_p
+        self.h = lib.ssko_bow_vocab_create(int(v["k"]), int(v["L"]), len(nid), _p(nid), _p(pid), _p(w), _p(d), len(wn), _p(wn))
+        if not self.h:
+            raise ValueError("malformed vocabulary")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ssko_bow_vocab_destroy.argtypes = [C.c_void_p]
+            self.lib.ssko_bow_vocab_destroy(self.h)
+            self.h = None
+
+    def word(self, feat):
+        f = np.ascontiguousarray(feat, np.uint8).reshape(32)
+        w = C.c_double()
+        self.lib.ssko_bow_word.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        return self.lib.ssko_bow_word(self.h, _p(f), C.byref(w)), w.value
+
+    def transform(self, feats):
+        f = np.ascontiguousarray(feats, np.uint8).reshape(-1, 32)
+        words = np.zeros(len(f) + 1, np.int32); vals = np.zeros(len(f) + 1)
+        self.lib.ssko_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        n = self.lib.ssko_bow_transform(self.h, _p(f), len(f), _p(words), _p(vals))
+        return words[:n].copy(), vals[:n].copy()
+
+
+class OracleBowDb:
+    def __init__(self, lib, n_words):
+        self.lib = lib
+        lib.ssko_bow_db_create.restype = C.c_void_p
+        self.h = lib.ssko_bow_db_create(int(n_words))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ssko_bow_db_destroy.argtypes = [C.c_void_p]
+            self.lib.ssko_bow_db_destroy(self.h)
+            self.h = None
+
+    def __len__(self):
+        self.lib.ssko_bow_db_size.argtypes = [C.c_void_p]
+        return self.lib.ssko_bow_db_size(self.h)
+
+    def add(self, words, vals):
+        w = np.ascontiguousarray(words, np.int32); v = np.ascontiguousarray(vals, np.float64)
+        self.lib.ssko_bow_db_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        return self.lib.ssko_bow_db_add(self.h, _p(w), _p(v), len(w))
+
+    def query(self, words, vals, max_results=4, max_id=-1):
+        w = np.ascontiguousarray(words, np.int32); v = np.ascontiguousarray(vals, np.float64)
+        cap = max_results if max_results > 0 else max(len(self), 1)
+        ids = np.zeros(cap, np.int32); sc = np.zeros(cap)
+        self.lib.ssko_bow_db_query.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        n = self.lib.ssko_bow_db_query(self.h, _p(w), _p(v), len(w), int(max_results), int(max_id), _p(ids), _p(sc))
+        return ids[:n].copy(), sc[:n].copy()
 
 
 def make_kf_view(kp_left, kp_right, desc_left, desc_right, matches):
