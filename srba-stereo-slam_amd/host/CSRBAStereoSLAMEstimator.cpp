@@ -12,8 +12,10 @@
 namespace ssk {
 
 CSRBAStereoSLAMEstimator::CSRBAStereoSLAMEstimator(Context& ctx, const TSRBAStereoSLAMOptions& opts, const TGeneralOptions& gopts)
-	: srba_options(opts), general_options(gopts), rba(ctx, opts), m_ctx(ctx),
-	  m_fast_th(opts.detect_fast_th), m_orb_th(opts.orb_max_distance) {}
+	: srba_options(opts), general_options(gopts), rba(ctx, opts), m_bow_manager(ctx),
+	  m_max_translation(2 * opts.max_translation), m_max_rotation(2 * opts.max_rotation),                    // EST.cpp:1163-1164
+	  m_max_translation_limit(opts.max_translation), m_max_rotation_limit(opts.max_rotation),
+	  m_ctx(ctx), m_fast_th(opts.detect_fast_th), m_orb_th(opts.orb_max_distance) {}
 
 // EST.cpp:263-315: the do { processNewImagePair } while (repeat) loop with the adaptive FAST / ORB thresholds
 void CSRBAStereoSLAMEstimator::m_frontend(const StereoImages& stImgs, CStereoSLAMKF& kf)
@@ -41,8 +43,10 @@ void CSRBAStereoSLAMEstimator::m_frontend(const StereoImages& stImgs, CStereoSLA
 
 // EST.cpp:1413-1515 + 1647-1669 on the GPU: gather matched-only descriptors (Q3), Hamming K=1, direction filter,
 // ORB-distance + uniqueness filter, tracking_info assembly
-void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& this_kf, const CStereoSLAMKF& other_kf, t_kf_da_info& out_da)
+void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& this_kf, const CStereoSLAMKF& other_kf, t_kf_da_info& out_da,
+                                                           const Pose3D* other_seen_from_this, ssk_cip_result* out_cip)
 {
+	if (out_cip) std::memset(out_cip, 0, sizeof *out_cip);
 	const size_t n = this_kf.m_matches.size();
 	out_da.kf_idx = other_kf.m_kf_ID;                                                    // :1427
 	out_da.tracked_matches = 0;
@@ -56,8 +60,9 @@ void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& 
 	m_ctx.check(ssk_data_association(m_ctx.get(), &a, &b, &p, matches.data(), status.data(), &tracked), "m_internal_data_association");
 	// stage 2 (EST.cpp:1587-1640): fundamental-matrix filter (m_detect_outliers_with_F, :2015-2055; the RANSAC samples come
 	// from a counter-based generator seeded by the keyframe pair, so a run is reproducible), then the change-in-pose
-	// filter (m_detect_outliers_with_change_in_pose, :2113-2177), started from the identity: keyframe-to-keyframe motion is
-	// small against the scene depth, and the estimator converges from there
+	// filter (m_detect_outliers_with_change_in_pose, :2113-2177), started from the caller's estimate of the other camera seen
+	// from this one (similar_kfs_poses, :1828-1862) or, without one, from the identity: keyframe-to-keyframe motion is small
+	// against the scene depth, and the estimator converges from there
 	if (srba_options.da_filter_by_fund_matrix) {
 		if (tracked < 15) return;                                                        // :1590-1594  "not enough input data": invalid
 		const ssk_fm_params fp = srba_options.fm(0x5EED0000ull + ((uint64_t)this_kf.m_kf_ID << 20) + other_kf.m_kf_ID);
@@ -69,9 +74,11 @@ void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& 
 	if (srba_options.da_filter_by_pose_change) {
 		if (tracked < 15) return;                                                        // :1617-1621  "not enough input data": invalid
 		const ssk_cip_params cp = srba_options.cip();
-		const double identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+		const Pose3D identity;
 		ssk_cip_result cr;
-		m_ctx.check(ssk_da_change_in_pose(m_ctx.get(), &a, &b, matches.data(), status.data(), identity, &cp, nullptr, &cr), "m_detect_outliers_with_change_in_pose");
+		m_ctx.check(ssk_da_change_in_pose(m_ctx.get(), &a, &b, matches.data(), status.data(), (other_seen_from_this ? *other_seen_from_this : identity).m,
+		                                  &cp, nullptr, &cr), "m_detect_outliers_with_change_in_pose");
+		if (out_cip) *out_cip = cr;
 	}
 	for (size_t k = 0; k < n; ++k)                                                       // :1657-1669
 		if (status[k] == SSK_DA_TRACKED) {
@@ -87,6 +94,16 @@ void CSRBAStereoSLAMEstimator::m_data_association(const CStereoSLAMKF& kf, const
 	for (size_t k = 0; k < similar_kfs.size(); ++k) {                                    // :1365-1398
 		out_da.push_back(t_kf_da_info());
 		m_internal_data_association(kf, m_keyframes[similar_kfs[k]], out_da.back());
+	}
+}
+
+void CSRBAStereoSLAMEstimator::m_data_association(const CStereoSLAMKF& kf, const TLoopClosureInfo& info, TVectorKfsDaInfo& out_da)
+{
+	out_da.clear();
+	out_da.reserve(info.similar_kfs.size());
+	for (size_t k = 0; k < info.similar_kfs.size(); ++k) {                               // :1365-1398
+		out_da.push_back(t_kf_da_info());
+		m_internal_data_association(kf, m_keyframes[info.similar_kfs[k]], out_da.back(), k < info.similar_kfs_poses.size() ? &info.similar_kfs_poses[k] : nullptr);
 	}
 }
 
@@ -146,6 +163,18 @@ TNewKeyFrameInfo CSRBAStereoSLAMEstimator::processKeyframe(const StereoImages& s
 	std::vector<size_t> sortedIndices(daInfo.size());
 	for (size_t i = 0; i < sortedIndices.size(); ++i) sortedIndices[i] = i;
 	std::stable_sort(sortedIndices.begin(), sortedIndices.end(), [&](size_t a, size_t b) { return daInfo[a].tracked_matches > daInfo[b].tracked_matches; });
+	m_insert_keyframe(new_kf, daInfo, sortedIndices, incr_pose, newKFInfo);
+	if (timing) std::fprintf(stderr, "[facade timing] kf %zu: front-end %.2f ms, data association %.2f ms, insertion (ids, observations, define_new_keyframe) %.2f ms\n",
+	                         new_kf.m_kf_ID, ms(t0, t1), ms(t1, t2), ms(t2, now()));
+	return newKFInfo;
+}
+
+// EST.cpp:560-850 for an accepted candidate: ids from the similar keyframes in `sortedIndices` order, observation list, SRBA
+void CSRBAStereoSLAMEstimator::m_insert_keyframe(CStereoSLAMKF& new_kf, const TVectorKfsDaInfo& daInfo, const std::vector<size_t>& sortedIndices,
+                                                 const Pose3D& incr_pose, TNewKeyFrameInfo& newKFInfo)
+{
+	const size_t nMatches = new_kf.m_matches.size();
+	new_kf_observations_t listObs;
 	// ---- set ids for the current keyframe matches, EST.cpp:572-617 ----
 	new_kf.m_matches_ID.assign(nMatches, 0);
 	std::set<size_t> foundIds;
@@ -178,14 +207,168 @@ TNewKeyFrameInfo CSRBAStereoSLAMEstimator::processKeyframe(const StereoImages& s
 		}
 	}
 	rba.setInitialKFPose(srba_options.use_initial_pose ? incr_pose : Pose3D());          // :772-778
-	const auto t3 = now();
 	rba.define_new_keyframe(listObs, newKFInfo, true);                                   // :782-784
-	if (timing) std::fprintf(stderr, "[facade timing] kf %zu: front-end %.2f ms, data association %.2f ms, ids+observations %.2f ms, define_new_keyframe %.2f ms\n",
-	                         new_kf.m_kf_ID, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
 	if (general_options.verbose_level >= 1)                                              // :846-850
 		std::cout << "   Created KF #" << newKFInfo.kf_id << " | # kf-to-kf edges created: " << newKFInfo.created_edge_ids.size() << std::endl
 		          << "   Optimization error: " << newKFInfo.optimize_results.total_sqr_error_init << " -> " << newKFInfo.optimize_results.total_sqr_error_final << std::endl;
-	return newKFInfo;
+}
+
+// ---- stand-in for rso::CStereoOdometryEstimator (stereo-vo, absent: README.md:16) --------------------------------------
+// What the loop reads of it: the current frame's features (getDataFromVOEngine, KF.h:68), m_odom_result.{valid, outPose,
+// tracked_feats_from_last_frame, tracked_feats_from_last_KF} (EST.cpp:317-378) and resetIds() (EST.cpp:403,622).  Built from
+// this library's stages: front-end with the adaptive thresholds on the new pair, Hamming association with the previous
+// frame + the data-association filters, and the change-in-pose estimate as the incremental pose.  A match keeps its track
+// id while it is re-found from frame to frame; "from last KF" counts the ids that existed at the last resetIds().
+TOdometryResult CSRBAStereoSLAMEstimator::m_vo_process(const StereoImages& stImgs)
+{
+	TOdometryResult r;
+	if (m_vo_has_prev) { std::swap(m_vo_prev, m_vo_cur); m_vo_ids_prev.swap(m_vo_ids_cur); }
+	m_vo_cur = CStereoSLAMKF();
+	m_frontend(stImgs, m_vo_cur);                                                        // EST.cpp:263-315
+	const size_t n = m_vo_cur.m_matches.size();
+	m_vo_ids_cur.assign(n, 0);
+	if (!m_vo_has_prev) {
+		for (size_t k = 0; k < n; ++k) m_vo_ids_cur[k] = m_vo_next_id++;
+		m_vo_kf_max_id = m_vo_next_id;                                                    // ids below this existed at the last reset
+		m_vo_has_prev = true;
+		r.valid = true;                                                                   // first pair: nothing to compare with
+		return r;
+	}
+	t_kf_da_info da;
+	ssk_cip_result cip;
+	m_internal_data_association(m_vo_cur, m_vo_prev, da, nullptr, &cip);
+	for (size_t k = 0; k < n; ++k) {
+		if (da.tracking_info[k].first != INVALID_IDX) {
+			m_vo_ids_cur[k] = m_vo_ids_prev[da.tracking_info[k].first];
+			r.tracked_feats_from_last_frame++;
+			if (m_vo_ids_cur[k] < m_vo_kf_max_id) r.tracked_feats_from_last_KF++;
+		} else {
+			m_vo_ids_cur[k] = m_vo_next_id++;
+		}
+	}
+	r.valid = cip.valid != 0;
+	if (r.valid) {
+		Pose3D prev_seen_from_cur;
+		std::memcpy(prev_seen_from_cur.m, cip.pose, sizeof cip.pose);
+		r.outPose = prev_seen_from_cur.inverse();                                         // this frame seen from the previous one (:324)
+	}
+	return r;
+}
+
+void CSRBAStereoSLAMEstimator::m_vo_reset_ids()
+{
+	// "this will define previous frame as a virtual KF for the visual odometry system so that it can start a new record of
+	// tracked matches from last KF" (EST.cpp:400-403)
+	for (size_t k = 0; k < m_vo_ids_cur.size(); ++k) m_vo_ids_cur[k] = k;
+	m_vo_next_id = m_vo_kf_max_id = m_vo_ids_cur.size();
+}
+
+// EST.cpp:1737-1878
+bool CSRBAStereoSLAMEstimator::m_get_similar_kfs(const size_t newKfId, const QueryResults& dbQueryResults, TLoopClosureInfo& out)
+{
+	if (dbQueryResults.empty())                                                          // :1743-1744
+		throw std::runtime_error("Parameter 'dbQueryResults' is empty. This method should not be called here.");
+	if (dbQueryResults[0].Score < srba_options.query_score_th && general_options.verbose_level >= 1)          // :1748-1751
+		std::cout << "[Warning] Best result in 'dbQueryResults' is below a minimum threshold. Lost camera?" << std::endl;
+	std::vector<policy::TQuery> q(dbQueryResults.size());
+	for (size_t i = 0; i < q.size(); ++i) { q[i].Id = dbQueryResults[i].Id; q[i].Score = dbQueryResults[i].Score; }
+	const size_t SUBMAP_SIZE = rba.parameters.submap_size;                               // :1778
+	const size_t fromIdBase = SUBMAP_SIZE * ((newKfId - 1) / SUBMAP_SIZE);               // :1779
+	const bool found = policy::getSimilarKfs(newKfId, q, SUBMAP_SIZE, srba_options.lc_distance,
+	                                         [&](size_t toId) { return rba.topo_distance(fromIdBase, toId, rba.parameters.max_tree_depth); },
+	                                         out.similar_kfs, out.lc_id);
+	// :1828-1862 initial camera-to-camera poses of the similar keyframes seen from the candidate
+	out.similar_kfs_poses.assign(out.similar_kfs.size(), Pose3D());
+	if (srba_options.da_filter_by_pose_change) {
+		const Pose3D incr_inv = m_incr_pose_from_last_kf.inverse();
+		const Pose3D& cam = srba_options.camera_pose_on_robot_rvt;
+		const Pose3D cam_inv = cam.inverse();
+		for (size_t k = 0; k < out.similar_kfs.size(); ++k) {
+			if (out.similar_kfs[k] == newKfId - 1) { out.similar_kfs_poses[k] = incr_inv; continue; }                // :1846
+			Pose3D rel;                                                                   // similar keyframe seen from the previous one
+			if (rba.get_kf_relative_pose(newKfId - 1, out.similar_kfs[k], rba.parameters.max_tree_depth, rel))          // :1850-1858
+				out.similar_kfs_poses[k] = incr_inv + (cam_inv + rel + cam);
+		}
+	}
+	return found;
+}
+
+// One iteration of the reference's while loop, EST.cpp:44-937
+TFrameReport CSRBAStereoSLAMEstimator::performStereoSLAM(const StereoImages& stImgs)
+{
+	TFrameReport rep;
+	rep.frame = m_frame_count++;
+	if (!m_bow_manager.hasVocabulary()) throw std::runtime_error("performStereoSLAM: no vocabulary loaded (m_bow_manager.loadVocabulary)");
+	rep.odometry = m_vo_process(stImgs);
+	// ---- first iteration, EST.cpp:82-182 ----
+	if (m_keyframes.empty()) {
+		m_keyframes.push_back(m_vo_cur);                                                 // new_kf.getDataFromVOEngine (:112-114)
+		CStereoSLAMKF& new_kf = m_keyframes.back();
+		new_kf.setKFID(m_last_kf_ID++);
+		new_kf.m_matches_ID.clear();
+		new_kf.generateMatchesIDs(0);
+		const size_t nMatches = new_kf.m_matches.size();
+		m_last_match_ID = nMatches ? new_kf.m_matches_ID.back() : 0;                     // :115
+		m_bow_manager.insertIntoDB(new_kf);                                              // :118
+		if (general_options.debug) new_kf.saveInfoToFiles(general_options);
+		new_kf_observations_t listObs;
+		m_build_observations(new_kf, listObs);
+		rba.define_new_keyframe(listObs, rep.kf_info, false);                            // :166-168
+		m_last_kf_pose = new_kf.m_camera_pose;                                           // :182
+		m_vo_reset_ids();
+		rep.checked_for_kf = rep.inserted_kf = true;
+		return rep;
+	}
+	if (!rep.odometry.valid) return rep;                                                 // :318-323 "Not a valid result! Skipping this frame."
+	const Pose3D& incr_pose = rep.odometry.outPose;                                      // :327-330
+	m_current_pose = m_current_pose + incr_pose;
+	m_incr_pose_from_last_kf = m_incr_pose_from_last_kf + incr_pose;
+	m_incr_pose_from_last_check = m_incr_pose_from_last_check + incr_pose;
+	const policy::TVOCheck vo = policy::voCheck(m_incr_pose_from_last_kf.translationNorm(), m_incr_pose_from_last_kf.rotationAngle(),
+	                                            m_incr_pose_from_last_check.translationNorm(), m_incr_pose_from_last_check.rotationAngle(),
+	                                            rep.odometry.tracked_feats_from_last_KF, m_max_translation_limit, m_max_rotation_limit,
+	                                            m_max_translation, m_max_rotation, srba_options.vo_id_tracking_th);        // :366-392
+	rep.vo_force_new_kf = vo.voForceNewKf; rep.vo_force_check_tracking = vo.voForceCheckTracking; rep.vo_force_check_distance = vo.voForceCheckDistance;
+	if (!(vo.voForceNewKf || vo.voForceCheck)) return rep;                               // :394
+	rep.checked_for_kf = true;
+	if (vo.voForceCheckTracking) m_vo_reset_ids();                                       // :398-404
+	m_incr_pose_from_last_check = Pose3D();                                              // :407
+	m_keyframes.push_back(m_vo_cur);                                                     // :413-415 a temporary keyframe
+	CStereoSLAMKF* new_kf = &m_keyframes.back();
+	new_kf->setKFID(m_last_kf_ID);                                                       // :418
+	new_kf->m_matches_ID.clear();
+	m_bow_manager.queryDB(*new_kf, rep.query, 4);                                        // :424-427
+	const bool potentialLoopClosure = m_get_similar_kfs(new_kf->m_kf_ID, rep.query, rep.similar);   // :434-436
+	rep.potential_loop_closure = potentialLoopClosure;
+	const bool insert_in = rep.query[0].Score < 0.05;                                    // :439-441 "result is too low, force the creation of a new KF"
+	TVectorKfsDaInfo daInfo;
+	m_data_association(*new_kf, rep.similar, daInfo);                                    // :446-451
+	std::vector<policy::TDaSummary> das(daInfo.size());
+	for (size_t i = 0; i < das.size(); ++i) { das[i].kf_idx = daInfo[i].kf_idx; das[i].tracked_matches = daInfo[i].tracked_matches; }
+	const policy::TInsertDecision dec = policy::decideInsertion(insert_in, das, potentialLoopClosure, rep.similar.lc_id, vo.voForceNewKf,
+	                                                            srba_options.updated_matches_th, srba_options.up_matches_th_plus,
+	                                                            m_max_translation, m_max_rotation);                        // :455-548
+	rep.highest_tracked = dec.highestNumberTrackedFeats;
+	rep.confirmed_loop_closure = dec.confirmedLoopClosure;
+	m_max_translation = dec.max_translation; m_max_rotation = dec.max_rotation;
+	if (dec.confirmedLoopClosure) { rba.loopClosureDetected(); rba.setLoopClosureOldID(rep.similar.lc_id); }           // :497-498
+	else rba.loopClosureDetected(false);                                                 // :518,546
+	if (!dec.insertNewKf) {                                                              // :558-562 undo the insertion
+		m_keyframes.resize(m_keyframes.size() - 1);
+		return rep;
+	}
+	m_insert_keyframe(*new_kf, daInfo, dec.sortedIndices, m_incr_pose_from_last_kf, rep.kf_info);                     // :564-850
+	m_vo_reset_ids();                                                                    // :620-622
+	m_last_kf_ID++;                                                                      // :657
+	m_max_translation = srba_options.max_translation;                                    // :660-663 as written: the CHECK thresholds restart from
+	m_max_rotation = srba_options.max_rotation;                                          // the limits (the constructor starts them at twice that)
+	Pose3D pose;                                                                         // :909-915 pose of the new keyframe from keyframe 0
+	if (rba.get_kf_relative_pose(0, new_kf->m_kf_ID, rba.parameters.max_tree_depth, pose)) new_kf->m_camera_pose = m_last_kf_pose = pose;
+	m_bow_manager.insertIntoDB(*new_kf);                                                 // :919
+	m_current_pose = m_last_kf_pose + srba_options.camera_pose_on_robot_rvt;             // :922
+	m_incr_pose_from_last_kf = Pose3D();                                                 // :923
+	rep.inserted_kf = true;
+	return rep;
 }
 
 bool CSRBAStereoSLAMEstimator::saveKeyframes(const std::string& path) const

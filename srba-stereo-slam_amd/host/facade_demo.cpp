@@ -3,6 +3,10 @@
 // processKeyframe() each, print one line per keyframe.  Used by tests/test_facade_gpu.py (configs[0] plumbing
 // on synthetic KITTI-shaped pairs) and as the example for INTEGRATION.md.
 //   usage: facade_demo <dir> <n_pairs> <width> <height> [debug_out_dir]
+//          facade_demo stream <voc.yml[.gz]> <dir> <n_pairs> <width> <height> [key=value ...]
+//            the whole frame loop (performStereoSLAM): odometry, keyframe check, bag-of-words query, loop closure; one
+//            line per frame.  keys: submap_size max_tree_depth max_optimize_depth lc_distance max_translation max_rotation
+//            updated_matches_th up_matches_th_plus vo_id_tracking_th
 //   files: <dir>/left_%04d.raw, <dir>/right_%04d.raw   (width*height bytes each)
 #include <cstdio>
 #include <cstdlib>
@@ -19,8 +23,68 @@ static bool read_raw(const std::string& path, std::vector<uint8_t>& buf, size_t 
 	return got == n;
 }
 
+static int stream_main(int argc, char** argv)
+{
+	if (argc < 7) { std::fprintf(stderr, "usage: %s stream <voc> <dir> <n_pairs> <width> <height> [key=value ...]\n", argv[0]); return 2; }
+	const std::string voc = argv[2], dir = argv[3];
+	const int n = std::atoi(argv[4]), w = std::atoi(argv[5]), h = std::atoi(argv[6]);
+	try {
+		ssk::Context ctx(0);
+		ssk::TSRBAStereoSLAMOptions opts = ssk::TSRBAStereoSLAMOptions::kitti();
+		opts.stereo_camera.ncols = w; opts.stereo_camera.nrows = h;
+		for (int i = 7; i < argc; ++i) {
+			const std::string kv = argv[i];
+			const size_t eq = kv.find('=');
+			if (eq == std::string::npos) { std::fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
+			const std::string k = kv.substr(0, eq);
+			const double v = std::atof(kv.c_str() + eq + 1);
+			if (k == "submap_size") opts.srba_submap_size = (size_t)v;
+			else if (k == "max_tree_depth") opts.srba_max_tree_depth = (size_t)v;
+			else if (k == "max_optimize_depth") opts.srba_max_optimize_depth = (size_t)v;
+			else if (k == "lc_distance") opts.lc_distance = (size_t)v;
+			else if (k == "max_translation") opts.max_translation = v;
+			else if (k == "max_rotation") opts.max_rotation = v;
+			else if (k == "updated_matches_th") opts.updated_matches_th = (size_t)v;
+			else if (k == "up_matches_th_plus") opts.up_matches_th_plus = (size_t)v;
+			else if (k == "vo_id_tracking_th") opts.vo_id_tracking_th = (int)v;
+			else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+		}
+		ssk::CSRBAStereoSLAMEstimator est(ctx, opts);
+		est.m_bow_manager.loadVocabulary(voc);                       // EST.cpp:1120 loadVocabularyFromConfigFile
+		std::vector<uint8_t> left, right;
+		for (int k = 0; k < n; ++k) {
+			char a[64], b[64];
+			std::snprintf(a, sizeof a, "/left_%04d.raw", k);
+			std::snprintf(b, sizeof b, "/right_%04d.raw", k);
+			if (!read_raw(dir + a, left, (size_t)w * h) || !read_raw(dir + b, right, (size_t)w * h)) { std::fprintf(stderr, "cannot read pair %d\n", k); return 3; }
+			ssk::StereoImages im;
+			im.left = left.data(); im.right = right.data(); im.width = w; im.height = h; im.stride = w;
+			const ssk::TFrameReport r = est.performStereoSLAM(im);
+			std::printf("FRAME %zu vo_valid %d tracked_frame %zu tracked_kf %zu vo_t %.4f checked %d force_kf %d check_track %d check_dist %d inserted %d pot_lc %d conf_lc %d lc_id %lld highest %zu n_kf %zu",
+			            r.frame, (int)r.odometry.valid, r.odometry.tracked_feats_from_last_frame, r.odometry.tracked_feats_from_last_KF,
+			            r.odometry.outPose.translationNorm(), (int)r.checked_for_kf, (int)r.vo_force_new_kf, (int)r.vo_force_check_tracking,
+			            (int)r.vo_force_check_distance, (int)r.inserted_kf, (int)r.potential_loop_closure, (int)r.confirmed_loop_closure,
+			            r.similar.lc_id == ssk::policy::INVALID_KF_ID ? -1LL : (long long)r.similar.lc_id, r.highest_tracked, est.m_keyframes.size());
+			std::printf(" query");
+			for (const ssk::Result& q : r.query) std::printf(" %u:%.4f", q.Id, q.Score);
+			std::printf(" similar");
+			for (size_t s : r.similar.similar_kfs) std::printf(" %zu", s);
+			if (r.inserted_kf) std::printf(" kf %zu edges %zu err %.4f -> %.4f", r.kf_info.kf_id, r.kf_info.created_edge_ids.size(),
+			                               r.kf_info.optimize_results.total_sqr_error_init, r.kf_info.optimize_results.total_sqr_error_final);
+			std::printf("\n");
+		}
+		std::printf("keyframes %zu landmarks %zu edges %zu db %zu\n", est.m_keyframes.size(), est.rba.get_rba_state().unknown_lms.size(),
+		            est.rba.get_rba_state().k2k_edges.size(), est.m_bow_manager.size());
+	} catch (const std::exception& e) {
+		std::fprintf(stderr, "EXCEPTION: %s\n", e.what());
+		return 1;
+	}
+	return 0;
+}
+
 int main(int argc, char** argv)
 {
+	if (argc > 1 && std::string(argv[1]) == "stream") return stream_main(argc, argv);
 	if (argc < 5) { std::fprintf(stderr, "usage: %s <dir> <n_pairs> <width> <height> [debug_out_dir]\n", argv[0]); return 2; }
 	const std::string dir = argv[1];
 	const int n = std::atoi(argv[2]), w = std::atoi(argv[3]), h = std::atoi(argv[4]);

@@ -55,6 +55,11 @@ public:
 	mySRBA(Context& ctx, const TSRBAStereoSLAMOptions& opts);
 
 	inline void setInitialKFPose(const Pose3D& pose) { m_initial_kf_pose = pose; }  // SRBA.h:95-97
+	void loopClosureDetected(bool _lc = true) { m_lc = _lc; }                       // SRBA.h:85-87 (set by the estimator, read by nobody)
+	void setLoopClosureOldID(size_t _id) { m_lc_old_kf_id = _id; }                  // SRBA.h:90-92
+	// topological distance between two keyframes over the k2k edges; SIZE_MAX when farther than max_depth: what the
+	// estimator reads from spanning_tree.sym.next_edge[from][to].distance (EST.cpp:1803-1812)
+	size_t topo_distance(TKeyFrameID a, TKeyFrameID b, size_t max_depth) const;
 	inline bool isKFLocalmapCenter(TKeyFrameID id) const { return m_localmap_kf_IDs.count(id) != 0; }        // SRBA.h:100-102
 	inline TKeyFrameID getLocalmapCenterID(TKeyFrameID id) const { return *m_kf_localmap_center_ID.at(id).rbegin(); }   // SRBA.h:105-108
 
@@ -78,7 +83,6 @@ private:
 	struct TNewEdgeInfo { size_t id; bool has_approx_init_val; };
 	void edge_creation_policy(TKeyFrameID new_kf_id, const new_kf_observations_t& obs, std::vector<TNewEdgeInfo>& new_k2k_edge_ids);   // SRBA.h:144-308
 	size_t create_kf2kf_edge(TKeyFrameID from, TKeyFrameID to);
-	size_t topo_distance(TKeyFrameID a, TKeyFrameID b, size_t max_depth) const;    // SIZE_MAX when farther than max_depth
 	// breadth-first tree from `root`: for every keyframe within max_depth the step towards the root
 	struct step_t { TKeyFrameID prev; size_t edge; size_t dist; };
 	void bfs(TKeyFrameID root, size_t max_depth, std::map<TKeyFrameID, step_t>& out) const;
@@ -90,6 +94,8 @@ private:
 	rba_state_t m_state;
 	std::vector<std::vector<std::pair<TKeyFrameID, size_t>>> m_adj;                // keyframe -> (neighbour, edge id)
 	Pose3D m_initial_kf_pose;
+	bool m_lc = false;
+	size_t m_lc_old_kf_id = 0;
 	std::deque<std::set<TKeyFrameID>> m_kf_localmap_center_ID;                     // SRBA.h:67
 	std::map<TKeyFrameID, std::set<TKeyFrameID>> m_localmap_kf_IDs;                // SRBA.h:68
 };

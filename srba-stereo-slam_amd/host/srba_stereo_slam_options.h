@@ -44,7 +44,11 @@ struct TSRBAStereoSLAMOptions {                // UTIL.h:221-487
 	double srba_kernel_param = 3.0;
 	bool srba_use_robust_kernel = true, srba_use_robust_kernel_stage1 = true;
 	size_t srba_submap_size = 15, srba_max_tree_depth = 3, srba_max_optimize_depth = 3;
-	size_t updated_matches_th = 50;
+	// keyframe creation ([SRBA_KF_CREATION], UTIL.h:255-280,298-316)
+	size_t updated_matches_th = 50, up_matches_th_plus = 25, lc_distance = 2;
+	double max_rotation = 15., max_translation = 0.30;      // degrees, metres
+	int vo_id_tracking_th = 40;
+	double query_score_th = 0.04;
 
 	static TSRBAStereoSLAMOptions kitti()      // demo/config_imgdir_kitti_srba.ini
 	{
@@ -59,6 +63,7 @@ struct TSRBAStereoSLAMOptions {                // UTIL.h:221-487
 		o.srba_max_tree_depth = 4; o.srba_max_optimize_depth = 5; o.srba_submap_size = 10;                          // :104-106
 		o.srba_use_robust_kernel = true; o.srba_use_robust_kernel_stage1 = true; o.srba_kernel_param = 1.5;         // :107-109
 		o.updated_matches_th = 60; o.use_initial_pose = true;                                                       // :128,133
+		o.max_rotation = 25; o.max_translation = 2.0; o.up_matches_th_plus = 25; o.lc_distance = 10; o.vo_id_tracking_th = 40;   // :126-132
 		// camera_pose_on_robot (0,0,0,0,0,0) (+) (0,0,0,-90deg,0,-90deg): camera z forward, x right, y down (EST.cpp:1105-1112)
 		const double R[9] = {0, 0, 1, -1, 0, 0, 0, -1, 0}, t[3] = {0, 0, 0};
 		o.camera_pose_on_robot_rvt = Pose3D::fromRt(R, t);

@@ -67,6 +67,13 @@ struct Pose3D {                                // SE(3): p_parent = R p + t
 	{
 		for (int i = 0; i < 3; ++i) out[i] = m[4 * i] * p[0] + m[4 * i + 1] * p[1] + m[4 * i + 2] * p[2] + m[4 * i + 3];
 	}
+	double translationNorm() const { return std::sqrt(m[3] * m[3] + m[7] * m[7] + m[11] * m[11]); }    // CPose3DRotVec::m_coords.norm()
+	double rotationAngle() const                                                                          // CPose3DRotVec::m_rotvec.norm()
+	{
+		double c = 0.5 * (m[0] + m[5] + m[10] - 1.0);
+		c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+		return std::acos(c);
+	}
 	double x() const { return m[3]; }
 	double y() const { return m[7]; }
 	double z() const { return m[11]; }

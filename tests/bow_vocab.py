@@ -86,6 +86,59 @@ def synth(k=8, L=3, seed=7, flip=24, ragged=False):
                 weight=weight, desc=np.array(desc, np.uint8), word_node=np.array(word_node, np.int32))
 
 
+def train(images_desc, k=8, L=3, seed=1, iters=4, min_leaf=6):
+    """Hierarchical k-medians on real descriptors (the way DBoW2 builds a vocabulary: Hamming distance, majority-bit
+    centres), idf weights log(N / N_w) over the training images.  images_desc: list of [n_i, 32] uint8 arrays.  The tree
+    is ragged where clusters run empty or small; saved in DBoW2's order."""
+    rng = np.random.default_rng(seed)
+    img_of = np.concatenate([np.full(len(d), i, np.int32) for i, d in enumerate(images_desc)])
+    bits = np.unpackbits(np.concatenate(images_desc), axis=1).astype(np.int32)
+
+    def assign(idx, centres):
+        b = bits[idx]
+        return np.argmin(b @ (1 - centres).T + (1 - b) @ centres.T, axis=1)
+
+    node_id, parent_id, weight, desc, word_node = [], [], [], [], []
+    members = {0: np.arange(len(bits))}
+    depth = {0: 0}
+    next_id = 1
+    stack = [0]
+    while stack:
+        p = stack.pop()
+        idx = members.pop(p)
+        kk = min(k, len(idx))
+        centres = bits[rng.choice(idx, kk, replace=False)].copy()
+        for _ in range(iters):
+            a = assign(idx, centres)
+            for c in range(kk):
+                m = idx[a == c]
+                if len(m):
+                    centres[c] = (2 * bits[m].sum(0) >= len(m)).astype(np.int32)
+        a = assign(idx, centres)
+        kids = []
+        for c in range(kk):
+            m = idx[a == c]
+            if len(m) == 0:
+                continue
+            nid = next_id
+            next_id += 1
+            depth[nid] = depth[p] + 1
+            leaf = depth[nid] == L or len(m) < min_leaf
+            node_id.append(nid); parent_id.append(p)
+            desc.append(np.packbits(centres[c].astype(np.uint8)))
+            if leaf:
+                n_img = len(np.unique(img_of[m]))
+                weight.append(float(np.log(len(images_desc) / n_img)))
+                word_node.append(nid)
+            else:
+                weight.append(0.0)
+                members[nid] = m
+                kids.append(nid)
+        stack.extend(kids)
+    return dict(k=k, L=L, scoring=0, weighting=0, node_id=np.array(node_id, np.int32), parent_id=np.array(parent_id, np.int32),
+                weight=np.array(weight), desc=np.array(desc, np.uint8), word_node=np.array(word_node, np.int32))
+
+
 def write_yaml(v, path):
     """Write `v` in the DBoW2 YAML layout (gzip when the name ends in .gz)."""
     lines = ["%YAML:1.0", "vocabulary:", "   k: %d" % v["k"], "   L: %d" % v["L"], "   scoringType: %d" % v["scoring"],

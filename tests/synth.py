@@ -99,16 +99,18 @@ def synth_stereo_pair(seed, w=W, h=H, noise=2.0):
     return left, right
 
 
-def synth_translation_sequence(seed, n_frames, w=W, h=H, noise=1.0, d_max=40):
+def synth_translation_sequence(seed, n_frames, w=W, h=H, noise=1.0, d_max=40, z_max=80.0, step=1):
     """n_frames rectified stereo pairs of a scene of fronto-parallel strips seen from a camera that moves one baseline
     (0.54 m) to the RIGHT per frame: strip r has integer disparity d_r, so frame k sees it shifted by k*d_r pixels.
+    z_max bounds the depth and `step` is the number of baselines the camera moves per frame: with z_max = 12 m and step = 4
+    every strip moves >= 128 px per frame, so nothing stays in view for more than 10 frames.
     Returns ([(left, right)], strip list [(y0, y1, d_r)])."""
     rng = np.random.default_rng(0x5EED1000 + seed)
-    wide = synth_texture(rng, w + (n_frames + 1) * d_max + 8, h)
+    wide = synth_texture(rng, w + (n_frames * step + 1) * d_max + 8, h)
     strips, y = [], 0
     while y < h:
         bh = int(rng.integers(24, 64))
-        z = rng.uniform(KITTI["fx"] * KITTI["baseline"] / d_max, 80)
+        z = rng.uniform(KITTI["fx"] * KITTI["baseline"] / d_max, z_max)
         d = max(2, min(int(round(KITTI["fx"] * KITTI["baseline"] / z)), d_max))
         strips.append((y, min(h, y + bh), d))
         y += bh
@@ -117,8 +119,8 @@ def synth_translation_sequence(seed, n_frames, w=W, h=H, noise=1.0, d_max=40):
         left = np.empty((h, w), np.uint8)
         right = np.empty((h, w), np.uint8)
         for y0, y1, d in strips:
-            left[y0:y1] = wide[y0:y1, k * d:k * d + w]
-            right[y0:y1] = wide[y0:y1, (k + 1) * d:(k + 1) * d + w]
+            left[y0:y1] = wide[y0:y1, k * step * d:k * step * d + w]
+            right[y0:y1] = wide[y0:y1, (k * step + 1) * d:(k * step + 1) * d + w]
         if noise > 0:
             left = np.clip(np.rint(left + rng.normal(0, noise, left.shape)), 0, 255).astype(np.uint8)
             right = np.clip(np.rint(right + rng.normal(0, noise, right.shape)), 0, 255).astype(np.uint8)
