@@ -57,6 +57,23 @@ def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8):
     return cur, prev, lm, wins
 
 
+BOW_DB_ENTRIES = 200       # place-recognition database: the 200 keyframes of BASELINE configs[2]'s submap
+
+
+def build_place_recognition(capi, ctx, prev):
+    """Vocabulary of the reference's shape (demo/voc.yml.gz: k = 8, L = 5; here a seeded synthetic complete tree, 37 448
+    nodes / 32 768 words) and a database holding the bag-of-words vectors of BOW_DB_ENTRIES earlier keyframes."""
+    import bow_vocab as bv
+    v = bv.synth(k=8, L=5, seed=2024)
+    voc = capi.BowVocab(ctx, v)
+    db = capi.BowDb(ctx, voc, BOW_DB_ENTRIES, 512)
+    prev.bow_transform(voc)
+    for e in range(BOW_DB_ENTRIES):
+        db.add_from_batch(prev, e % prev.n_kf)
+    ctx.synchronize()
+    return v, voc, db
+
+
 def params(capi, sl):
     import ctypes as C
     import synth
@@ -69,9 +86,9 @@ def params(capi, sl):
     return fp, da, lp, cp, fm
 
 
-def cpu_baseline(sample_kf, wins):
+def cpu_baseline(sample_kf, wins, vocab):
     """The oracle (CPU port, 1 thread, -O2 -march=native -ffp-contract=off) on `sample_kf` keyframes of the same
-    workload: front-end + DA vs a shifted previous keyframe + LM solve."""
+    workload: front-end + DA vs a shifted previous keyframe + place-recognition query + LM solve."""
     import oracle_lib as ol
     import synth
     import synth_lm as sl
@@ -94,8 +111,12 @@ def cpu_baseline(sample_kf, wins):
         return out
     prev_kf = [oracle.frontend(banded(l), banded(r), fp, pat) for l, r in base]
     fmp = ol.kitti_fm_params()
+    ovoc = oracle.bow_vocab(vocab)
+    odb = oracle.bow_db(ovoc.n_words)
+    for e in range(BOW_DB_ENTRIES):
+        odb.add(*ovoc.transform(prev_kf[e % len(prev_kf)]["desc_left"]))
     t0 = time.perf_counter()
-    t_fe = t_da = t_lm = 0.0
+    t_fe = t_da = t_lm = t_bow = 0.0
     for k in range(sample_kf):
         l, r = base[k % len(base)]
         a = time.perf_counter()
@@ -112,14 +133,16 @@ def cpu_baseline(sample_kf, wins):
         so_a, so_b = stereo_obs(kf), stereo_obs(prev_kf[k % len(base)])
         st, _r = oracle.fundamental_filter(so_a[:, :2], so_b[:, :2], _m["trainIdx"], st, fmp)
         oracle.change_in_pose(so_a, so_b, _m["trainIdx"], st, ident, cipp)
+        c0 = time.perf_counter()
+        odb.query(*ovoc.transform(kf["desc_left"]), 4)
         c = time.perf_counter()
         oracle.lm_solve(wins[k % len(wins)], lp, trace=False)
         d = time.perf_counter()
-        t_fe += b - a; t_da += c - b; t_lm += d - c
+        t_fe += b - a; t_da += c0 - b; t_bow += c - c0; t_lm += d - c
     dt = time.perf_counter() - t0
     return {"value": sample_kf / dt, "unit": "keyframes/s", "cores": 1, "kind": "port",
-            "sample": "%d keyframes of the same workload (CPU oracle, 1 thread): front-end %.1f ms + DA %.2f ms + LM %.1f ms per keyframe"
-                      % (sample_kf, 1e3 * t_fe / sample_kf, 1e3 * t_da / sample_kf, 1e3 * t_lm / sample_kf),
+            "sample": "%d keyframes of the same workload (CPU oracle, 1 thread): front-end %.1f ms + DA %.2f ms + place recognition %.2f ms + LM %.1f ms per keyframe"
+                      % (sample_kf, 1e3 * t_fe / sample_kf, 1e3 * t_da / sample_kf, 1e3 * t_bow / sample_kf, 1e3 * t_lm / sample_kf),
             "host_cores": os.cpu_count()}
 
 
@@ -172,12 +195,15 @@ def main():
 
     prev.run_frontend(fp)          # state: the previous keyframes' features (not part of a step)
     ctx.synchronize()
+    vocab, voc, db = build_place_recognition(capi, ctx, prev)
 
     def step(serial=False):
         cur.run_frontend(fp)
         ctx.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
         ctx.fm_run_batch(cur, prev, pairs, fm, d_idx, d_st, d_tr)            # stage 2 of the DA (da_stage2_method = 3): fundamental-matrix
         ctx.cip_run_batch(cur, prev, pairs, cp, d_idx, d_st, d_tr)           # RANSAC filter, then the change-in-pose filter
+        cur.bow_transform(voc)                                               # place recognition (queryDB, EST.cpp:426): words of the left
+        cur.bow_query(db, 4)                                                 # descriptors, L1 query of the keyframe database, 4 results
         if serial:
             torch.cuda.synchronize()      # profile pass: one kernel at a time, clean per-kernel durations
         lm.reset()
@@ -269,7 +295,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]+[2] per keyframe: 1241x376 stereo pair -> ORB(N=500, FAST 20, 1 level) + L<->R "
-                            "(max_y_diff 2, orb_max_distance 60) + KF<->KF Hamming DA with direction/ORB/fundamental-matrix/change-in-pose filters + SRBA LM window "
+                            "(max_y_diff 2, orb_max_distance 60) + KF<->KF Hamming DA with direction/ORB/fundamental-matrix/change-in-pose filters + bag-of-words "
+                            "place-recognition query (k=8, L=5 vocabulary, %d-keyframe database, 4 results) + SRBA LM window " % BOW_DB_ENTRIES +
                             "(200-KF/5k-landmark submap, submap_size 10, max_tree_depth 4, window = 10 most recent edges)",
                 "keyframes_per_gpu_per_step": B,
                 "streams": "front-end + DA on one HIP stream, LM solves on a second one" if args.overlap else "one HIP stream",
@@ -290,11 +317,11 @@ def main():
             "stage_ms_per_launch": stages,
         }
         if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, wins)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, wins, vocab)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
-    lm.close(); cur.close(); prev.close()
+    db.close(); voc.close(); lm.close(); cur.close(); prev.close()
     if ctx_lm is not ctx:
         ctx_lm.close()
     ctx.close()

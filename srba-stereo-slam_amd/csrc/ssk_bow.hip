@@ -7,16 +7,17 @@
 //                ndesc uint4[2n] (32-B BRIEF centres, 1.2 MB for the reference's 36 940 nodes: L2 resident),
 //                kids int2[n] (first child, child count), leaf_word i32[n], word_weight f64[n_words]
 //   keyframe     bow_word i32[B][N] ascending word ids, bow_val f64[B][N] L1-normalised values, bow_n i32[B]
-//   database     fixed-stride forward lists: words i32[cap][stride], vals f64[cap][stride], ent_n i32[cap]; an entry is
-//                appended by one device-to-device copy, nothing is re-laid out as the map grows
+//   database     forward lists stored ENTRY-MINOR: words i32[stride][cap], vals f64[stride][cap], ent_n i32[cap]: the query
+//                kernel gives every entry a lane, and the c-th words of 64 consecutive entries are one coalesced row; an
+//                entry is appended by a small scatter kernel, nothing is re-laid out as the map grows
 // Kernels
 //   bow_words_kernel   8 lanes per descriptor, one tree level per step: each lane takes one child (256 coalesced bytes per
 //                      8-child node), popcount of 8 dwords, (distance, child) min over the 8 lanes (first child wins ties)
 //   bow_vector_kernel  one workgroup per keyframe: bitonic sort of the word ids in LDS, run lengths, weight of a run by
 //                      repeated addition (the f64 sequence of W3), serial L1 norm in ascending word order, division
-//   bow_score_kernel   one wave per (query, entry): the entry's words stream through the lanes, a bitmap of the query's
-//                      words in LDS rejects most, the rest binary-search the query; terms are added serially in ascending
-//                      word order so that the f64 sum is the one of W5
+//   bow_score_kernel   one wave per (query, 64 entries), one LANE per entry: the lane walks its entry's ascending words; a bitmap
+//                      of the query's words in LDS rejects most, a per-dword prefix count turns a hit into the query index
+//                      (rank) without a search; the lane adds its terms in word order, which is the f64 sum of W5
 //   bow_topk_kernel    one workgroup per query: max_results rounds of a lexicographic (score, entry id) arg-min
 // Everything is integer work except the two serial f64 sums, which reproduce the reference order bit for bit.
 #include "ssk_frontend.h"
@@ -47,7 +48,7 @@ struct ssk_bow_db {
 namespace {
 
 constexpr int BOW_SORT_MAX = SSK_MAX_FEATS;     // 2048 word ids per keyframe
-constexpr int BOW_BITMAP_WORDS_MAX = 1 << 20;   // query bitmap in LDS up to 1 Mi words (128 KB)
+constexpr int BOW_BITMAP_WORDS_MAX = 1 << 20;   // LDS budget of the query bitmap + its prefix counts: 128 KB (vocabularies up to 512 Ki words)
 
 __device__ __forceinline__ int popc256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1)
 {
@@ -143,9 +144,17 @@ void bow_vector_kernel(const double* __restrict__ word_weight, const int32_t* __
 		s_ow[pos] = w; s_ov[pos] = acc; ++pos;
 	}
 	__syncthreads();
-	if (tid == 0) {
+	if (tid == 0) {                                                    // the serial sum of W3, eight LDS reads in flight
 		double norm = 0;
-		for (int i = 0; i < nw; ++i) norm += fabs(s_ov[i]);
+		int i = 0;
+		for (; i + 8 <= nw; i += 8) {
+			double v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) v[u] = s_ov[i + u];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) norm += fabs(v[u]);
+		}
+		for (; i < nw; ++i) norm += fabs(s_ov[i]);
 		s_norm = norm;
 	}
 	__syncthreads();
@@ -160,60 +169,111 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 	return __hiloint2double(hi, lo);
 }
 
-// W5, raw sums.  grid (n_queries, n_split), 256 threads = 4 waves; wave w of split s takes entries s*4 + w, + 4*n_split, ...
-// Query q = keyframe q_begin + blockIdx.x of the bow_* arrays (stride max_feats).  dynamic LDS: bitmap (bm_words u32).
-__global__ __launch_bounds__(256)
+// W5, raw sums.  grid (n_queries, ceil(n_entries / 64)), 64 threads: lane = entry.  Query q = keyframe q_begin + blockIdx.x of the
+// bow_* arrays (stride q_stride).  Dynamic LDS: s_qv f64[BOW_SORT_MAX] | s_qw i32[BOW_SORT_MAX] | bitmap u32[bm_dwords] | prefix
+// i32[bm_dwords]; bm_dwords == 0 (vocabulary too large for a bitmap): binary search of s_qw instead.
+__global__ __launch_bounds__(64)
 void bow_score_kernel(const int32_t* __restrict__ q_word, const double* __restrict__ q_val, const int32_t* __restrict__ q_n, int q_stride,
                       int q_begin, const int32_t* __restrict__ e_word, const double* __restrict__ e_val, const int32_t* __restrict__ e_n,
-                      int e_stride, int n_entries, const int32_t* __restrict__ max_ids, int bm_dwords, double* __restrict__ scores, int score_stride)
+                      int e_stride, int e_cap, int n_entries, const int32_t* __restrict__ max_ids, int bm_dwords, double* __restrict__ scores,
+                      int score_stride)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-	int* s_qw = reinterpret_cast<int*>(s_raw);                       // [BOW_SORT_MAX]
-	double* s_qv = reinterpret_cast<double*>(s_raw + 4 * BOW_SORT_MAX);   // [BOW_SORT_MAX]
+	double* s_qv = reinterpret_cast<double*>(s_raw);
+	int* s_qw = reinterpret_cast<int*>(s_raw + 8 * BOW_SORT_MAX);
 	unsigned* s_bm = reinterpret_cast<unsigned*>(s_raw + 12 * BOW_SORT_MAX);
-	const int q = blockIdx.x, kf = q_begin + q, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	int* s_pre = reinterpret_cast<int*>(s_raw + 12 * BOW_SORT_MAX) + bm_dwords;
+	const int q = blockIdx.x, kf = q_begin + q, lane = threadIdx.x;
 	const int nq = min(q_n[kf], q_stride);
-	for (int i = tid; i < bm_dwords; i += 256) s_bm[i] = 0;
-	for (int i = tid; i < nq; i += 256) { s_qw[i] = q_word[(size_t)kf * q_stride + i]; s_qv[i] = q_val[(size_t)kf * q_stride + i]; }
+	for (int i = lane; i < bm_dwords; i += 64) s_bm[i] = 0;
+	for (int i = lane; i < nq; i += 64) { s_qw[i] = q_word[(size_t)kf * q_stride + i]; s_qv[i] = q_val[(size_t)kf * q_stride + i]; }
 	__syncthreads();
-	if (bm_dwords > 0)
-		for (int i = tid; i < nq; i += 256) atomicOr(&s_bm[s_qw[i] >> 5], 1u << (s_qw[i] & 31));
-	__syncthreads();
+	if (bm_dwords > 0) {
+		for (int i = lane; i < nq; i += 64) atomicOr(&s_bm[s_qw[i] >> 5], 1u << (s_qw[i] & 31));
+		__syncthreads();
+		// s_pre[d] = number of query words below dword d: every lane counts a contiguous slice, one wave scan joins them
+		const int per = (bm_dwords + 63) / 64, d0 = lane * per, d1 = min(bm_dwords, d0 + per);
+		int cnt = 0;
+		for (int d = d0; d < d1; ++d) cnt += __popc(s_bm[d]);
+		int incl = cnt;
+		for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+		int run = incl - cnt;
+		for (int d = d0; d < d1; ++d) { s_pre[d] = run; run += __popc(s_bm[d]); }
+		__syncthreads();
+	}
 	const int max_id = max_ids ? max_ids[q] : -1;
 	const int e_end = max_id < 0 ? n_entries : min(n_entries, max_id);
-	for (int e = blockIdx.y * 4 + wave; e < n_entries; e += 4 * gridDim.y) {
-		double s = 0;
-		int hits = 0;
-		if (e < e_end) {
-			const int ne = min(e_n[e], e_stride);
-			for (int c0 = 0; c0 < ne; c0 += 64) {
-				const int c = c0 + lane;
-				double term = 0;
-				bool hit = false;
-				if (c < ne) {
-					const int w = e_word[(size_t)e * e_stride + c];
-					bool maybe = bm_dwords > 0 ? ((s_bm[w >> 5] >> (w & 31)) & 1u) != 0 : true;
-					if (maybe) {
-						int lo = 0, hi = nq;                               // first index with s_qw >= w
-						while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_qw[mid] < w) lo = mid + 1; else hi = mid; }
-						if (lo < nq && s_qw[lo] == w) {
-							const double qv = s_qv[lo], dv = e_val[(size_t)e * e_stride + c];
-							term = fabs(qv - dv) - fabs(qv) - fabs(dv);
-							hit = true;
-						}
-					}
-				}
-				unsigned long long m = __ballot(hit);
-				hits += __popcll(m);
-				while (m) {                                            // ascending word order = ascending lane
-					const int l = __ffsll((long long)m) - 1;
-					m &= m - 1;
-					s += readlane_f64(term, l);
-				}
+	const int e = blockIdx.y * 64 + lane;
+	const int ne = e < e_end ? min(e_n[e], e_stride) : 0;
+	int nmax = ne;
+	for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+	double s = 0;
+	int hits = 0;
+	// One wave per SIMD is all the parallelism a (query, 64 entries) pair offers, so the loop is written for latency: U rows per
+	// pass, the next pass's words already in flight, every LDS read of a pass issued back to back (no branch between them: a
+	// miss reads slot 0 and contributes +0.0, which leaves the sum as it is), then the values of the hits, then the U terms are
+	// added in row order.
+	constexpr int U = 32;
+	const int32_t* ew = e_word + e;
+	const double* ev = e_val + e;
+	int wn[U];
+#pragma unroll
+	for (int u = 0; u < U; ++u) wn[u] = u < ne ? ew[(size_t)u * e_cap] : -1;
+	for (int c0 = 0; c0 < nmax; c0 += U) {
+		int w[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) w[u] = wn[u];
+		if (c0 + U < nmax) {
+#pragma unroll
+			for (int u = 0; u < U; ++u) wn[u] = c0 + U + u < ne ? ew[(size_t)(c0 + U + u) * e_cap] : -1;
+		}
+		int qi[U];
+		if (bm_dwords > 0) {
+			unsigned dw[U];
+			int pre[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) { const int d = max(w[u], 0) >> 5; dw[u] = s_bm[d]; pre[u] = s_pre[d]; }
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				const unsigned bit = 1u << (w[u] & 31);
+				qi[u] = (w[u] >= 0 && (dw[u] & bit)) ? pre[u] + __popc(dw[u] & (bit - 1)) : -1;
+			}
+		} else {
+#pragma unroll 1
+			for (int u = 0; u < U; ++u) {
+				qi[u] = -1;
+				if (w[u] < 0) continue;
+				int lo = 0, hi = nq;
+				while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_qw[mid] < w[u]) lo = mid + 1; else hi = mid; }
+				if (lo < nq && s_qw[lo] == w[u]) qi[u] = lo;
 			}
 		}
-		if (lane == 0) scores[(size_t)q * score_stride + e] = hits > 0 ? s : INFINITY;
+		double dv[U], qv[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) dv[u] = qi[u] >= 0 ? ev[(size_t)(c0 + u) * e_cap] : 0.0;
+#pragma unroll
+		for (int u = 0; u < U; ++u) qv[u] = s_qv[max(qi[u], 0)];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const double term = fabs(qv[u] - dv[u]) - fabs(qv[u]) - fabs(dv[u]);
+			s += qi[u] >= 0 ? term : 0.0;                              // ascending word order within the lane's entry
+			hits += qi[u] >= 0;
+		}
 	}
+	if (e < n_entries) scores[(size_t)q * score_stride + e] = hits > 0 ? s : INFINITY;
+}
+
+// entry e of the entry-minor database <- a bag-of-words vector (n from the device when d_n != NULL)
+__global__ __launch_bounds__(256)
+void bow_db_insert_kernel(const int32_t* __restrict__ src_word, const double* __restrict__ src_val, const int32_t* __restrict__ d_n, int n_host,
+                          int e, int e_cap, int e_stride, int32_t* __restrict__ e_word, double* __restrict__ e_val, int32_t* __restrict__ e_n)
+{
+	const int n = min(d_n ? *d_n : n_host, e_stride);
+	for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		e_word[(size_t)c * e_cap + e] = src_word[c];
+		e_val[(size_t)c * e_cap + e] = src_val[c];
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) e_n[e] = n;
 }
 
 // results of query q: up to max_results entries by (raw sum ascending, entry id ascending); score = -s/2
@@ -296,20 +356,16 @@ int launch_query(ssk_ctx* ctx, ssk_bow_db* db, const int32_t* q_word, const doub
 	ssk_stage_scope prof(ctx, SSK_STAGE_BOW);
 	const int ne = db->n_entries;
 	if (ne > 0) {
-		const int bm_dwords = db->voc->n_words <= BOW_BITMAP_WORDS_MAX ? (db->voc->n_words + 31) / 32 : 0;
-		const size_t lds = 12 * (size_t)BOW_SORT_MAX + 4 * (size_t)bm_dwords;
+		const int bm_dwords = db->voc->n_words <= BOW_BITMAP_WORDS_MAX / 2 ? (db->voc->n_words + 31) / 32 : 0;
+		const size_t lds = 12 * (size_t)BOW_SORT_MAX + 8 * (size_t)bm_dwords;
 		static bool attr_set = false;
 		if (!attr_set) {
 			SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(bow_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 			                                 12 * BOW_SORT_MAX + BOW_BITMAP_WORDS_MAX / 8));
 			attr_set = true;
 		}
-		int n_split = (ne + 15) / 16;                                  // ~4 entries per wave
-		const int want = (4 * ctx->n_cu + nq - 1) / nq;                 // but no more workgroups than ~4 per CU need
-		if (n_split > want) n_split = want;
-		if (n_split < 1) n_split = 1;
-		hipLaunchKernelGGL(bow_score_kernel, dim3(nq, n_split), dim3(256), lds, ctx->stream, q_word, q_val, q_n, q_stride, q_begin, db->words,
-		                   db->vals, db->ent_n, db->stride, ne, d_max_ids, bm_dwords, db->scores, db->cap);
+		hipLaunchKernelGGL(bow_score_kernel, dim3(nq, (ne + 63) / 64), dim3(64), lds, ctx->stream, q_word, q_val, q_n, q_stride, q_begin, db->words,
+		                   db->vals, db->ent_n, db->stride, db->cap, ne, d_max_ids, bm_dwords, db->scores, db->cap);
 		SSK_LAUNCH_CHECK(ctx, "bow_score_kernel");
 	}
 	hipLaunchKernelGGL(bow_topk_kernel, dim3(nq), dim3(256), 0, ctx->stream, db->scores, db->cap, ne, max_results, r_stride, q_begin, r_ids,
@@ -522,12 +578,18 @@ int ssk_bow_db_add(ssk_ctx* ctx, ssk_bow_db* d, const int32_t* words, const doub
 			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_bow_db_add: word ids must be ascending and inside the vocabulary (index %d)", i);
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	const int e = d->n_entries;
-	const int32_t hn = n;
+	int rc;
+	const size_t n1 = (size_t)(n > 0 ? n : 1);
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad(n1 * 4) + ssk_pad(n1 * 8) + 2 * 256))) return rc;
+	ssk_arena_reset(ctx->dev);
+	int32_t* d_w = ssk_arena_take<int32_t>(ctx->dev, n1);
+	double* d_v = ssk_arena_take<double>(ctx->dev, n1);
 	if (n > 0) {
-		SSK_HIP(ctx, hipMemcpyAsync(d->words + (size_t)e * d->stride, words, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-		SSK_HIP(ctx, hipMemcpyAsync(d->vals + (size_t)e * d->stride, values, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+		SSK_HIP(ctx, hipMemcpyAsync(d_w, words, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+		SSK_HIP(ctx, hipMemcpyAsync(d_v, values, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
 	}
-	SSK_HIP(ctx, hipMemcpyAsync(d->ent_n + e, &hn, 4, hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(bow_db_insert_kernel, dim3(1), dim3(256), 0, ctx->stream, d_w, d_v, (const int32_t*)nullptr, n, e, d->cap, d->stride, d->words, d->vals, d->ent_n);
+	SSK_LAUNCH_CHECK(ctx, "bow_db_insert_kernel");
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the sources are the caller's (pageable) buffers
 	d->n_entries = e + 1;
 	if (entry_id) *entry_id = e;
@@ -544,9 +606,9 @@ int ssk_bow_db_add_from_batch(ssk_ctx* ctx, ssk_bow_db* d, ssk_kfbatch* b, int k
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	const int e = d->n_entries;
 	const size_t N = (size_t)b->max_feats;
-	SSK_HIP(ctx, hipMemcpyAsync(d->words + (size_t)e * d->stride, b->bow_word + kf * N, N * 4, hipMemcpyDeviceToDevice, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(d->vals + (size_t)e * d->stride, b->bow_val + kf * N, N * 8, hipMemcpyDeviceToDevice, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(d->ent_n + e, b->bow_n + kf, 4, hipMemcpyDeviceToDevice, ctx->stream));
+	hipLaunchKernelGGL(bow_db_insert_kernel, dim3(1), dim3(256), 0, ctx->stream, b->bow_word + kf * N, b->bow_val + kf * N, b->bow_n + kf, 0, e, d->cap,
+	                   d->stride, d->words, d->vals, d->ent_n);
+	SSK_LAUNCH_CHECK(ctx, "bow_db_insert_kernel");
 	d->n_entries = e + 1;
 	if (entry_id) *entry_id = e;
 	return SSK_OK;
