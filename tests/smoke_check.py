@@ -50,6 +50,23 @@ def run():
     assert np.abs(poses - ref["poses"]).max() <= 1e-5 and np.abs(lms - ref["lms"]).max() <= 1e-4
     print("smoke: LM solve on cuda:0 matches the oracle (%d iterations, error %.6g -> %.6g)" % (res.iters, res.err_init, res.err_final))
     batch.close()
+
+    # place recognition: vocabulary-tree transform + L1 database query, bit for bit
+    import bow_vocab as bv
+    v = bv.synth(k=8, L=3, seed=3, ragged=True)
+    G, O = capi.BowVocab(ctx, v), oracle.bow_vocab(v)
+    gdb, odb = capi.BowDb(ctx, G, 16, 256), oracle.bow_db(O.n_words)
+    seq = bv.keyframe_sequence(v, np.random.default_rng(4), n_kf=8, n=200)
+    for f in seq:
+        gw, gx = G.transform(f)
+        ow, ox = O.transform(f)
+        assert np.array_equal(gw, ow) and np.array_equal(gx, ox)
+        gi, gs = gdb.query(gw, gx, 4)
+        oi, os_ = odb.query(ow, ox, 4)
+        assert np.array_equal(gi, oi) and np.array_equal(gs, os_)
+        gdb.add(gw, gx); odb.add(ow, ox)
+    print("smoke: bag-of-words transform + database query on cuda:0 match the oracle bit-exactly (%d words, best score %.4f)" % (len(gw), gs[0]))
+    gdb.close(); G.close()
     ctx.close()
 
 
