@@ -86,6 +86,7 @@ enum {
 	SSK_STAGE_CHANGE_IN_POSE,  /* cip_kernel: change-in-pose outlier filter */
 	SSK_STAGE_FUND_MATRIX,     /* fm_kernel: fundamental-matrix RANSAC outlier filter */
 	SSK_STAGE_BOW,             /* bow_words / bow_vector / bow_score / bow_topk kernels: place recognition */
+	SSK_STAGE_POSE_GRAPH,      /* pg_solve_kernel: global pose-graph optimisation */
 	SSK_STAGE_COUNT
 };
 int ssk_profile_enable(ssk_ctx* ctx, int on);     /* also clears the accumulated sums */
@@ -348,6 +349,29 @@ int ssk_bow_db_query_batch(ssk_ctx* ctx, ssk_bow_db* d, ssk_kfbatch* b, int kf_b
                            const int32_t* max_ids);
 int ssk_kfbatch_bow_results(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, int32_t* ids, double* scores,
                             int32_t* n_results);
+
+/* ---- global pose-graph optimisation after the frame loop (last item) ------------------------
+ * Replaces  rba.get_global_graphslam_problem(poseGraph); mrpt::graphslam::optimize_graph_spa_levmarq(poseGraph, ...)
+ * (EST.cpp:945-957).  Contract G1-G6: oracle/oracle_posegraph.c.  Nodes X_k: pose of keyframe k in the root's frame,
+ * row-major [R|t], in/out; edge e: (i, j) = edge_ij[2e], edge_ij[2e+1] with X_i^-1 X_j = Z_e (edge_z, 12 doubles each; the
+ * k2k edge {from, to, inv_pose} gives i = to, j = from, Z = inv_pose); fixed_node is held (the root).  Levenberg-Marquardt on
+ * e = (t_E, log R_E), E = Z^-1 X_i^-1 X_j, unit information; the step comes from block-Jacobi preconditioned CG. */
+typedef struct ssk_pg_params {
+	int32_t max_iters;                 /* LM attempts; MRPT's default is 100 */
+	int32_t pcg_max_iters;             /* CG iterations per attempt */
+	double tau;                        /* lambda0 = tau * max diag(H); 1e-3 (MRPT's tau) */
+	double max_lambda;                 /* 1e20 */
+	double converged_rel_decrease;     /* stop when an attempt changes the cost by <= this fraction; 1e-9 */
+	double pcg_tol;                    /* CG stops at r.z <= pcg_tol^2 r0.z0; 1e-10 */
+} ssk_pg_params;
+typedef struct ssk_pg_result {
+	int32_t iters, accepted;
+	int32_t stop_reason;               /* 0 max_iters, 1 cost at round-off level, 2 max_lambda, 3 nothing to optimise, 4 converged */
+	int32_t pcg_iters_total;
+	double cost_init, cost_final, lambda_final;
+} ssk_pg_result;
+int ssk_posegraph_optimize(ssk_ctx* ctx, int n_nodes, double* node_poses, int n_edges, const int32_t* edge_ij,
+                           const double* edge_z, int fixed_node, const ssk_pg_params* params, ssk_pg_result* out);
 
 /* ---- B3: relative bundle adjustment, Levenberg-Marquardt with Schur complement + dense Cholesky ----
  * Replaces the numerical core of  rba.define_new_keyframe(listObs, newKFInfo, true)  (EST.cpp:782-784):

@@ -143,6 +143,13 @@ void ssko_kf_decision(int insert_in, int n_da, const int64_t* da_kf_idx, const i
                       int vo_force_new_kf, int64_t updated_matches_th, int64_t up_matches_th_plus, double* th_inout,
                       int64_t* sorted, int64_t* highest_out, int32_t* flags_out3);   /* EST.cpp:437-548 */
 
+/* ---------------- global pose-graph optimisation (oracle_posegraph.c; contract G1-G6 there) ---------------- */
+void ssko_so3_log(const double* T12, double* w3);
+double ssko_pg_cost(int n_edges, const int32_t* edge_ij, const double* edge_z, const double* X);
+/* [published: MRPT optimize_graph_spa_levmarq on rba.get_global_graphslam_problem; call EST.cpp:945-957] */
+int ssko_pg_optimize(int n_nodes, double* X, int n_edges, const int32_t* edge_ij, const double* edge_z, int fixed_node,
+                     const ssk_pg_params* P, ssk_pg_result* out);
+
 #ifdef __cplusplus
 }
 #endif

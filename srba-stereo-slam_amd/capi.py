@@ -324,6 +324,20 @@ class BowDb:
         return ids[:n.value].copy(), sc[:n.value].copy()
 
 
+class PgParams(C.Structure):
+    """ssk_pg_params; defaults: MRPT's 100 iterations / tau 1e-3, CG to 1e-10."""
+    _fields_ = [("max_iters", C.c_int32), ("pcg_max_iters", C.c_int32), ("tau", C.c_double), ("max_lambda", C.c_double),
+                ("converged_rel_decrease", C.c_double), ("pcg_tol", C.c_double)]
+
+    def __init__(self, max_iters=100, pcg_max_iters=400, tau=1e-3, max_lambda=1e20, converged_rel_decrease=1e-9, pcg_tol=1e-10):
+        super().__init__(max_iters, pcg_max_iters, tau, max_lambda, converged_rel_decrease, pcg_tol)
+
+
+class PgResult(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("accepted", C.c_int32), ("stop_reason", C.c_int32), ("pcg_iters_total", C.c_int32),
+                ("cost_init", C.c_double), ("cost_final", C.c_double), ("lambda_final", C.c_double)]
+
+
 class LmWindow(C.Structure):
     _fields_ = [("n_edges_total", C.c_int32), ("edge_unknown_slot", C.c_void_p), ("edge_inv_pose", C.c_void_p),
                 ("n_lms_total", C.c_int32), ("lm_unknown_slot", C.c_void_p), ("lm_pos", C.c_void_p),
@@ -607,12 +621,22 @@ class Context:
     def stitch_shared(self, d_gathered, n_ranks, n_shared, d_fused):
         self._chk(self.lib.ssk_lm_stitch_shared(self.h, _dev(d_gathered), int(n_ranks), int(n_shared), _dev(d_fused)))
 
+    def posegraph_optimize(self, X, edge_ij, edge_z, fixed=0, prm=None):
+        """ssk_posegraph_optimize: returns (optimised node poses [n, 12], PgResult)."""
+        X = np.ascontiguousarray(X, np.float64).reshape(-1, 12).copy()
+        ij = np.ascontiguousarray(edge_ij, np.int32).reshape(-1, 2)
+        z = np.ascontiguousarray(edge_z, np.float64).reshape(-1, 12)
+        prm = prm or PgParams()
+        out = PgResult()
+        self._chk(self.lib.ssk_posegraph_optimize(self.h, len(X), _ptr(X), len(ij), _ptr(ij), _ptr(z), int(fixed), C.byref(prm), C.byref(out)))
+        return X, out
+
     # -- profiling -------------------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self.lib.ssk_profile_enable(self.h, int(on)))
 
     def profile_read(self):
-        n = 13
+        n = 14
         ms = (C.c_double * n)()
         calls = (C.c_int64 * n)()
         self._chk(self.lib.ssk_profile_read(self.h, ms, calls))

@@ -206,7 +206,7 @@ int ssk_profile_read(ssk_ctx* ctx, double* ms, int64_t* calls)
 const char* ssk_stage_name(int stage)
 {
 	static const char* names[SSK_STAGE_COUNT] = {"fast_nms", "select", "describe", "stereo_match", "hamming_match",
-	                                             "da_filters", "lm_linearize", "lm_schur", "lm_solve", "lm_update", "change_in_pose", "fund_matrix", "bow"};
+	                                             "da_filters", "lm_linearize", "lm_schur", "lm_solve", "lm_update", "change_in_pose", "fund_matrix", "bow", "pose_graph"};
 	return stage >= 0 && stage < SSK_STAGE_COUNT ? names[stage] : "?";
 }
 

@@ -2,6 +2,7 @@
 #include "CSRBAStereoSLAMEstimator.h"
 #include "ssk_kf_io.h"
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <fstream>
 #include <algorithm>
@@ -369,6 +370,38 @@ TFrameReport CSRBAStereoSLAMEstimator::performStereoSLAM(const StereoImages& stI
 	m_incr_pose_from_last_kf = Pose3D();                                                 // :923
 	rep.inserted_kf = true;
 	return rep;
+}
+
+// EST.cpp:945-987
+std::vector<Pose3D> CSRBAStereoSLAMEstimator::optimizeGlobalPoseGraph(ssk_pg_result* info, const std::string& path)
+{
+	std::vector<Pose3D> nodes, edge_z;
+	std::vector<int32_t> edge_ij;
+	std::vector<bool> reachable;
+	rba.get_global_graphslam_problem(0, nodes, edge_ij, edge_z, reachable);
+	ssk_pg_result res;
+	std::memset(&res, 0, sizeof res);
+	if (!nodes.empty()) {
+		ssk_pg_params prm;
+		prm.max_iters = 100; prm.tau = 1e-3;                         // mrpt::graphslam defaults (max_iterations, tau)
+		prm.pcg_max_iters = std::max(400, 6 * (int)nodes.size());
+		prm.max_lambda = 1e20; prm.converged_rel_decrease = 1e-9; prm.pcg_tol = 1e-10;
+		static_assert(sizeof(Pose3D) == 12 * sizeof(double), "Pose3D is 12 doubles");
+		m_ctx.check(ssk_posegraph_optimize(m_ctx.get(), (int)nodes.size(), nodes[0].m, (int)edge_z.size(), edge_ij.data(),
+		                                   edge_z.empty() ? nullptr : edge_z[0].m, 0, &prm, &res), "optimize_graph_spa_levmarq");
+	}
+	if (info) *info = res;
+	if (!path.empty()) {
+		if (FILE* f = std::fopen(path.c_str(), "wt")) {                // EST.cpp:976-984
+			for (size_t kf = 0; kf < nodes.size(); ++kf) {
+				const double* m = nodes[kf].m;
+				const double yaw = std::atan2(m[4], m[0]), pitch = std::atan2(-m[8], std::sqrt(m[0] * m[0] + m[4] * m[4])), roll = std::atan2(m[9], m[10]);
+				std::fprintf(f, "%d %.3f %.3f %.3f %.3f %.3f %.3f\n", (int)kf, m[3], m[7], m[11], yaw, pitch, roll);
+			}
+			std::fclose(f);
+		}
+	}
+	return nodes;
 }
 
 bool CSRBAStereoSLAMEstimator::saveKeyframes(const std::string& path) const

@@ -74,6 +74,11 @@ public:
 	// One iteration of the frame loop, EST.cpp:44-937 (first frame: :82-182).  Needs a vocabulary in m_bow_manager.
 	TFrameReport performStereoSLAM(const StereoImages& stImgs);
 
+	// After the loop, EST.cpp:945-987: global pose graph of the relative map, optimised on the device (ssk_posegraph_optimize);
+	// returns the keyframe poses in the frame of keyframe 0 and, when `path` is not empty, writes them as the reference's
+	// out_kf_poses.txt ("kf x y z yaw pitch roll", %.3f, EST.cpp:976-984).
+	std::vector<Pose3D> optimizeGlobalPoseGraph(ssk_pg_result* info = nullptr, const std::string& path = std::string());
+
 	CBoWManager m_bow_manager;                             // EST.h (private there)
 	Pose3D m_current_pose, m_last_kf_pose, m_incr_pose_from_last_kf, m_incr_pose_from_last_check;   // EST.h:150-156
 	double m_max_translation, m_max_rotation, m_max_translation_limit, m_max_rotation_limit;        // EST.cpp:1163-1164

@@ -75,6 +75,12 @@ static int stream_main(int argc, char** argv)
 		}
 		std::printf("keyframes %zu landmarks %zu edges %zu db %zu\n", est.m_keyframes.size(), est.rba.get_rba_state().unknown_lms.size(),
 		            est.rba.get_rba_state().k2k_edges.size(), est.m_bow_manager.size());
+		// after the loop: the global pose graph (EST.cpp:945-987)
+		ssk_pg_result pg;
+		const std::vector<ssk::Pose3D> poses = est.optimizeGlobalPoseGraph(&pg, dir + "/out_kf_poses.txt");
+		std::printf("posegraph nodes %zu iters %d accepted %d stop %d cost %.6g -> %.6g last %.4f %.4f %.4f\n", poses.size(), pg.iters, pg.accepted,
+		            pg.stop_reason, pg.cost_init, pg.cost_final, poses.empty() ? 0.0 : poses.back().x(), poses.empty() ? 0.0 : poses.back().y(),
+		            poses.empty() ? 0.0 : poses.back().z());
 	} catch (const std::exception& e) {
 		std::fprintf(stderr, "EXCEPTION: %s\n", e.what());
 		return 1;

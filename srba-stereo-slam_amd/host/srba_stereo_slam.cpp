@@ -78,6 +78,36 @@ bool mySRBA::get_kf_relative_pose(TKeyFrameID root, TKeyFrameID target, size_t m
 	return true;
 }
 
+void mySRBA::get_global_graphslam_problem(TKeyFrameID root, std::vector<Pose3D>& nodes, std::vector<int32_t>& edge_ij, std::vector<Pose3D>& edge_z,
+                                          std::vector<bool>& reachable) const
+{
+	const size_t n = num_keyframes();
+	nodes.assign(n, Pose3D());
+	reachable.assign(n, false);
+	std::map<TKeyFrameID, step_t> t;
+	bfs(root, std::numeric_limits<size_t>::max(), t);
+	// parents before children: breadth-first distance order
+	std::vector<std::pair<size_t, TKeyFrameID>> order;
+	for (const auto& kv : t) order.push_back(std::make_pair(kv.second.dist, kv.first));
+	std::sort(order.begin(), order.end());
+	for (const auto& o : order) {
+		const TKeyFrameID k = o.second;
+		reachable[k] = true;
+		if (k == root) continue;
+		const step_t& s = t[k];
+		const k2k_edge_t& e = m_state.k2k_edges[s.edge];
+		// pose of k seen from its tree parent: inv_pose is `from` seen from `to`
+		const Pose3D rel = (e.from == k && e.to == s.prev) ? e.inv_pose : e.inv_pose.inverse();
+		nodes[k] = nodes[s.prev] + rel;
+	}
+	edge_ij.clear(); edge_z.clear();
+	for (const k2k_edge_t& e : m_state.k2k_edges) {
+		if (!reachable[e.from] || !reachable[e.to]) continue;
+		edge_ij.push_back((int32_t)e.to); edge_ij.push_back((int32_t)e.from);
+		edge_z.push_back(e.inv_pose);
+	}
+}
+
 // ---- SRBA.h:144-308, restated line by line -------------------------------------------------------------
 void mySRBA::edge_creation_policy(TKeyFrameID new_kf_id, const new_kf_observations_t& obs, std::vector<TNewEdgeInfo>& new_k2k_edge_ids)
 {

@@ -70,6 +70,12 @@ public:
 	// what create_complete_spanning_tree(root, ...)[target] gives the estimator (EST.cpp:909-915).
 	bool get_kf_relative_pose(TKeyFrameID root, TKeyFrameID target, size_t max_depth, Pose3D& out) const;
 
+	// rba.get_global_graphslam_problem(poseGraph) (EST.cpp:946-947): global poses of all keyframes reachable from `root`
+	// (composition of the k2k edges along the breadth-first tree, no depth limit; unreachable keyframes keep the identity and
+	// are reported in `reachable`) and one constraint per k2k edge: X_to^-1 X_from = inv_pose, as (i = to, j = from, Z).
+	void get_global_graphslam_problem(TKeyFrameID root, std::vector<Pose3D>& nodes, std::vector<int32_t>& edge_ij, std::vector<Pose3D>& edge_z,
+	                                  std::vector<bool>& reachable) const;
+
 	struct rba_state_t {
 		std::deque<k2k_edge_t> k2k_edges;
 		std::map<TLandmarkID, landmark_t> unknown_lms;

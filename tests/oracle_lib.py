@@ -90,6 +90,20 @@ def kitti_fm_params(**over):
     return FmParams(**d)
 
 
+class PgParams(C.Structure):
+    """ssk_pg_params; defaults: MRPT's 100 iterations / tau 1e-3, CG to 1e-10."""
+    _fields_ = [("max_iters", C.c_int32), ("pcg_max_iters", C.c_int32), ("tau", C.c_double), ("max_lambda", C.c_double),
+                ("converged_rel_decrease", C.c_double), ("pcg_tol", C.c_double)]
+
+    def __init__(self, max_iters=100, pcg_max_iters=400, tau=1e-3, max_lambda=1e20, converged_rel_decrease=1e-9, pcg_tol=1e-10):
+        super().__init__(max_iters, pcg_max_iters, tau, max_lambda, converged_rel_decrease, pcg_tol)
+
+
+class PgResult(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("accepted", C.c_int32), ("stop_reason", C.c_int32), ("pcg_iters_total", C.c_int32),
+                ("cost_init", C.c_double), ("cost_final", C.c_double), ("lambda_final", C.c_double)]
+
+
 class StereoCam(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")]
@@ -270,6 +284,30 @@ class Oracle:
 
     def bow_db(self, n_words):
         return OracleBowDb(self.lib, n_words)
+
+    # ---- global pose graph (oracle_posegraph.c) ----
+    def pg_cost(self, X, edge_ij, edge_z):
+        X = np.ascontiguousarray(X, np.float64).reshape(-1, 12)
+        ij = np.ascontiguousarray(edge_ij, np.int32).reshape(-1, 2)
+        z = np.ascontiguousarray(edge_z, np.float64).reshape(-1, 12)
+        self.lib.ssko_pg_cost.restype = C.c_double
+        return self.lib.ssko_pg_cost(len(ij), _p(ij), _p(z), _p(X))
+
+    def pg_optimize(self, X, edge_ij, edge_z, fixed=0, prm=None):
+        """Returns (optimised poses [n, 12], PgResult)."""
+        X = np.ascontiguousarray(X, np.float64).reshape(-1, 12).copy()
+        ij = np.ascontiguousarray(edge_ij, np.int32).reshape(-1, 2)
+        z = np.ascontiguousarray(edge_z, np.float64).reshape(-1, 12)
+        prm = prm or PgParams()
+        out = PgResult()
+        self.lib.ssko_pg_optimize(len(X), _p(X), len(ij), _p(ij), _p(z), int(fixed), C.byref(prm), C.byref(out))
+        return X, out
+
+    def so3_log(self, T):
+        T = np.ascontiguousarray(T, np.float64).reshape(12)
+        w = np.zeros(3)
+        self.lib.ssko_so3_log(_p(T), _p(w))
+        return w
 
     def project_match_to_3d(self, ul, vl, ur, cam):
         out = (C.c_double * 3)()

@@ -74,6 +74,17 @@ def test_every_frame_a_keyframe_and_loop_closure(pkg, ctx, tmp_path):
     assert r["pot_lc"] == "1" and r["conf_lc"] == "1" and r["inserted"] == "1" and int(r["lc_id"]) in (0, 1, 2, 4, 5, 6), r
     assert r["similar"][:2] == [n - 1, 3] and int(r["lc_id"]) in r["similar"] and int(r["highest"]) >= 150
     assert "keyframes %d " % (n + 2) in out and "db %d" % (n + 2) in out
+    # after the loop: the global pose graph (EST.cpp:945-987).  The loop-closure keyframe hangs on the old local map only, so
+    # the graph is a tree (cost 0 at the composed poses) and the optimiser has nothing to move; out_kf_poses.txt is written in
+    # the reference's format.  Keyframe k of the first pass sits 4 k baselines to the right of keyframe 0 (robot -y).
+    pg = [l.split() for l in out.splitlines() if l.startswith("posegraph ")][0]
+    assert int(pg[2]) == n + 2 and int(pg[8]) == 1 and float(pg[10]) < 1e-12 and float(pg[12]) < 1e-12, pg
+    poses = np.loadtxt(os.path.join(tmp_path, "out_kf_poses.txt"))
+    assert poses.shape == (n + 2, 7) and np.array_equal(poses[:, 0], np.arange(n + 2))
+    for k in (1, 10, n - 1):
+        assert abs(poses[k, 2] + 2.16 * k) < 0.03 * 2.16 * k + 0.05 and abs(poses[k, 1]) < 0.5 and abs(poses[k, 3]) < 0.5, (k, poses[k])
+    # the revisit keyframes come back to places 3 and 4
+    assert abs(poses[n, 2] + 2.16 * 3) < 0.5 and abs(poses[n + 1, 2] + 2.16 * 4) < 0.5, poses[n:]
 
 
 def test_check_without_insertion(pkg, ctx, tmp_path):
