@@ -146,6 +146,41 @@ def cpu_baseline(sample_kf, wins, vocab):
             "host_cores": os.cpu_count()}
 
 
+def cpu_worker(n_kf):
+    """--cpu-worker: one process of the all-cores CPU baseline; builds its own copy of the workload (2 LM windows, the same
+    vocabulary) and prints {"kf": n, "seconds": t} for its timed section."""
+    import bow_vocab as bv
+    import synth_lm as sl
+    wins = [sl.make_submap_problem(s, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2,
+                                   obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0] for s in range(2)]
+    r = cpu_baseline(n_kf, wins, bv.synth(k=8, L=5, seed=2024))
+    print(json.dumps({"kf": n_kf, "seconds": n_kf / r["value"]}))
+
+
+def cpu_baseline_all_cores(procs, n_kf):
+    """The same CPU oracle, one single-threaded process per keyframe stream on `procs` host cores at once (SURVEY 8(d):
+    "an N-thread run, one KF/submap per thread, for fairness").  Aggregate = sum of the processes' own rates; their timed
+    sections (>= several seconds each) run concurrently."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n_kf)], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(procs)]
+    rate, done = 0.0, 0
+    for p in ps:
+        out, _ = p.communicate()
+        try:
+            r = json.loads(out.strip().splitlines()[-1])
+            rate += r["kf"] / r["seconds"]
+            done += 1
+        except Exception:
+            pass
+    if done == 0:
+        return None
+    return {"value": rate, "unit": "keyframes/s", "cores": done, "kind": "port",
+            "sample": "%d single-threaded oracle processes side by side, %d keyframes each (same per-keyframe work as cpu_baseline)" % (done, n_kf),
+            "host_cores": os.cpu_count()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,10 +188,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="keyframes per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=128, help="keyframes timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="processes of the all-cores CPU baseline (-1: half the host's logical cores, at most 64; 0 = skip)")
+    ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--shared-landmarks", type=int, default=256)
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: LM solves on a second HIP stream beside the front-end / DA kernels (measured: +1 %, the LM workgroups fill every CU)")
     args = ap.parse_args()
+    if args.cpu_worker > 0:
+        cpu_worker(args.cpu_worker)
+        return
 
     import torch
     import torch.distributed as dist
@@ -318,6 +359,9 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, wins, vocab)
+            procs = args.cpu_procs if args.cpu_procs >= 0 else max(1, min(64, (os.cpu_count() or 2) // 2))
+            if procs > 0:
+                line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(procs, max(32, args.cpu_sample // 2))
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

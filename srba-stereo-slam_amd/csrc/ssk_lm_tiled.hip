@@ -483,11 +483,20 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 // F2: H_red block (e,e') = sum of its H_pp slots + lambda I - sum of its Schur slots (slot order), diagonal blocks
 // written from their upper triangle; g_red(e) = sum of its incidences' terms (contiguous, edge-major, 8 lanes per
 // component) into the border row; G: blocked LDL^T + back-substitution (ssk_lm_device.h).  A: (n6 + 1) x np.
+#ifdef SSK_LM_STAMPS
+__device__ unsigned long long g_f2g[4];
+#define F2G_TICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_f2g[i] += t_ - f2g_last; f2g_last = t_; } } while (0)
+#else
+#define F2G_TICK(i) do {} while (0)
+#endif
 template <typename PtrA>
 __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win& W, const double* __restrict__ Pp, const double* __restrict__ Sp,
                                                    double lambda, PtrA A, int np, int n6, double* s_b, double* s_inv)
 {
 	const int tid = threadIdx.x;
+#ifdef SSK_LM_STAMPS
+	unsigned long long f2g_last = __builtin_amdgcn_s_memtime();
+#endif
 	for (int it = tid; it < W.n_pairs * 36; it += NT) {
 		const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
 		const int2 ee = D.pair_ee[W.pair0 + pid];
@@ -499,6 +508,7 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 		A[(6 * ee.x + a) * np + 6 * ee.y + b] = sres;
 		A[(6 * ee.y + b) * np + 6 * ee.x + a] = sres;
 	}
+	F2G_TICK(0);
 	for (int it = tid; it < n6 * 8; it += NT) {
 		const int comp = it >> 3, j = it & 7, e = comp / 6, a = comp - e * 6;
 		const int k0 = D.el_off[W.uso0 + e], k1 = D.el_off[W.uso0 + e + 1];
@@ -512,7 +522,10 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 		if (j == 0) A[n6 * np + comp] = v;
 	}
 	__syncthreads();
-	return n6 > 0 ? ldl_solve_lds(A, np, n6, s_b, s_inv) : true;
+	F2G_TICK(1);
+	const bool ok_ = n6 > 0 ? ldl_solve_lds(A, np, n6, s_b, s_inv) : true;
+	F2G_TICK(2);
+	return ok_;
 }
 
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
@@ -716,6 +729,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 			{
 			printf("LMT stamps (cycles, window 0, %d iters, %d tiles): top %llu I1 %llu I2 %llu I3 %llu I4 %llu F2 %llu G %llu H %llu I+dec %llu\n", s_iters, W.n_tiles,
 			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
+			printf("LMT F2 blocks %llu F2 gradient %llu G %llu (slots: pp %d schur %d)\n", g_f2g[0], g_f2g[1], g_f2g[2], D.pcl_off[W.pairo0 + W.n_pairs] - D.pcl_off[W.pairo0], D.scl_off[W.pairo0 + W.n_pairs] - D.scl_off[W.pairo0]);
 			printf("LMT fine I3: wave0 (H_pp task) copy %llu items %llu segsum %llu wait %llu | wave4 (Schur task) copy %llu items %llu segsum %llu wait %llu\n",
 			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[8], s_fine[9], s_fine[10], s_fine[11]);
 			}
