@@ -29,6 +29,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1241, 376
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # AMD MI355X data sheet: FP64 vector = FP64 matrix (MFMA) 78.6 TFLOP/s (the guide lists no FP64 row)
+
+
+def lm_algorithmic_flops(win):
+    """SURVEY 8(d) per LM iteration of one window: ~1.0 kflop per (observation x edge on its path) for residual, Jacobians
+    and Hessian blocks, 324 flop per landmark x (edges touching it)^2 for the Schur complement, (6E)^3 / 3 for the
+    factorisation of the reduced system."""
+    off = np.asarray(win.obs_path_off)
+    path_len = np.diff(off)
+    unknown = np.asarray(win.edge_unknown_slot) >= 0
+    pe = np.asarray(win.path_edge)
+    lm = np.asarray(win.obs_lm)
+    touch = {}
+    for o in range(len(lm)):
+        es = pe[off[o]:off[o + 1]] >> 1                                   # path entries are edge * 2 + direction
+        touch.setdefault(int(lm[o]), set()).update(int(e) for e in es if unknown[e])
+    schur = sum(len(v) ** 2 for v in touch.values()) * 324.0
+    n6 = 6.0 * int(unknown.sum())
+    return 1000.0 * float(path_len.sum()) + schur + n6 ** 3 / 3.0
+
 
 
 def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8):
@@ -315,6 +335,9 @@ def main():
         lm_avg_ms = lm_ms / max(lm_calls, 1)
         lm_algo = float(sum(r.iters * (56 * len(wins[k % len(wins)].obs_lm) + 96 * len(wins[k % len(wins)].edge_unknown_slot)) for k, r in enumerate(res)))
         lm_ach = lm_algo / (lm_avg_ms * 1e-3) / 1e9
+        per_win_flops = [lm_algorithmic_flops(w) for w in wins]
+        lm_flops = float(sum(r.iters * per_win_flops[k % len(wins)] for k, r in enumerate(res)))
+        lm_tflops = lm_flops / (lm_avg_ms * 1e-3) / 1e12
         # the HBM-bound scan of the front-end (every pixel of both images read once): 933,232 B per keyframe
         fast_ms, fast_calls = prof["fast_nms"]
         fast_avg_ms = fast_ms / max(fast_calls, 1)
@@ -352,6 +375,10 @@ def main():
                          "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic.get("lm_solve_tiled_kernel"),
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
                          "note": "dominant kernel by time; FP64-issue/LDS bound at 2 waves/SIMD, not bandwidth bound (DESIGN.md 5, 9)"},
+            "roofline_fp64": {"kernel": "lm_solve_tiled_kernel", "bound": "mfma", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
+                              "note": "the same launch priced in FP64 flops (SURVEY 8(d) per-unit figures); FP64 MFMA rate = FP64 vector rate on MI355X, "
+                                      "the kernel issues vector FP64 (block-sparse 6x6 / 6x3 products, DESIGN.md 5)"},
             "roofline_scan": {"kernel": "fast_nms_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("fast_nms_kernel"),
                               "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_avg_ms},
