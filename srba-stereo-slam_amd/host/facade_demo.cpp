@@ -8,6 +8,7 @@
 //            line per frame.  keys: submap_size max_tree_depth max_optimize_depth lc_distance max_translation max_rotation
 //            updated_matches_th up_matches_th_plus vo_id_tracking_th
 //   files: <dir>/left_%04d.raw, <dir>/right_%04d.raw   (width*height bytes each)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -52,6 +53,8 @@ static int stream_main(int argc, char** argv)
 		ssk::CSRBAStereoSLAMEstimator est(ctx, opts);
 		est.m_bow_manager.loadVocabulary(voc);                       // EST.cpp:1120 loadVocabularyFromConfigFile
 		std::vector<uint8_t> left, right;
+		double loop_ms = 0, kf_ms = 0;                             // time inside performStereoSLAM (file reads excluded), frame 0 excluded
+		size_t timed_frames = 0, timed_kfs = 0;
 		for (int k = 0; k < n; ++k) {
 			char a[64], b[64];
 			std::snprintf(a, sizeof a, "/left_%04d.raw", k);
@@ -59,7 +62,10 @@ static int stream_main(int argc, char** argv)
 			if (!read_raw(dir + a, left, (size_t)w * h) || !read_raw(dir + b, right, (size_t)w * h)) { std::fprintf(stderr, "cannot read pair %d\n", k); return 3; }
 			ssk::StereoImages im;
 			im.left = left.data(); im.right = right.data(); im.width = w; im.height = h; im.stride = w;
+			const auto t0 = std::chrono::steady_clock::now();
 			const ssk::TFrameReport r = est.performStereoSLAM(im);
+			const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+			if (k > 0) { loop_ms += ms; ++timed_frames; if (r.inserted_kf) { kf_ms += ms; ++timed_kfs; } }
 			std::printf("FRAME %zu vo_valid %d tracked_frame %zu tracked_kf %zu vo_t %.4f checked %d force_kf %d check_track %d check_dist %d inserted %d pot_lc %d conf_lc %d lc_id %lld highest %zu n_kf %zu",
 			            r.frame, (int)r.odometry.valid, r.odometry.tracked_feats_from_last_frame, r.odometry.tracked_feats_from_last_KF,
 			            r.odometry.outPose.translationNorm(), (int)r.checked_for_kf, (int)r.vo_force_new_kf, (int)r.vo_force_check_tracking,
@@ -75,6 +81,9 @@ static int stream_main(int argc, char** argv)
 		}
 		std::printf("keyframes %zu landmarks %zu edges %zu db %zu\n", est.m_keyframes.size(), est.rba.get_rba_state().unknown_lms.size(),
 		            est.rba.get_rba_state().k2k_edges.size(), est.m_bow_manager.size());
+		if (timed_frames)
+			std::printf("timing frames %zu loop_ms %.2f ms_per_frame %.3f frames_per_s %.1f keyframe_frames %zu ms_per_keyframe_frame %.3f\n", timed_frames, loop_ms,
+			            loop_ms / timed_frames, 1e3 * timed_frames / loop_ms, timed_kfs, timed_kfs ? kf_ms / timed_kfs : 0.0);
 		// after the loop: the global pose graph (EST.cpp:945-987)
 		ssk_pg_result pg;
 		const std::vector<ssk::Pose3D> poses = est.optimizeGlobalPoseGraph(&pg, dir + "/out_kf_poses.txt");

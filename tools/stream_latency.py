@@ -14,7 +14,41 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth  # noqa: E402
 
 
+def full_loop(n):
+    """BASELINE configs[3] shape at reduced length: n synthetic frames through the WHOLE frame loop of the facade
+    (performStereoSLAM: odometry stand-in, keyframe policy, place recognition, data association, relative BA) with the
+    reference's KITTI parameters, un-batched, then the global pose graph.  The vocabulary is trained on the sequence."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    import bow_vocab as bv
+    pkg = ge.load_package()
+    from ssk_amd import capi
+    demo = os.path.join(ROOT, "srba-stereo-slam_amd", "host", "facade_demo")
+    frames, _ = synth.synth_translation_sequence(9, n, z_max=30.0)
+    ctx = pkg.Context(0)
+    prm = capi.FrontendParams(**synth.KITTI_FRONTEND)
+    voc = bv.train([ctx.frontend_run(l, r, prm)["desc_left"] for l, r in frames[::max(1, n // 24)]], k=8, L=4, seed=5)
+    ctx.close()
+    with tempfile.TemporaryDirectory() as d:
+        vf = os.path.join(d, "voc.yml.gz")
+        bv.write_yaml(voc, vf)
+        for k, (l, r) in enumerate(frames):
+            l.tofile(os.path.join(d, "left_%04d.raw" % k))
+            r.tofile(os.path.join(d, "right_%04d.raw" % k))
+        env = dict(os.environ, SSK_FACADE_TIMING="1") if os.environ.get("SSK_FACADE_TIMING") else None
+        p = subprocess.run([demo, "stream", vf, d, str(n), str(synth.W), str(synth.H)], capture_output=True, text=True, env=env)
+        assert p.returncode == 0, p.stderr
+        for l in p.stdout.splitlines():
+            if l.startswith(("timing", "keyframes", "posegraph")):
+                print(l)
+        for l in p.stderr.splitlines()[-8:]:
+            if "facade timing" in l:
+                print(l)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "loop":
+        return full_loop(int(sys.argv[2]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     demo = os.path.join(ROOT, "srba-stereo-slam_amd", "host", "facade_demo")
     frames, _ = synth.synth_translation_sequence(3, n)
