@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the all-cores CPU baseline (-1: half the host's logical cores, at most 64; 0 = skip)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--side-stream", type=int, default=0,
+                    help="1: the place-recognition kernels on a second HIP stream beside the data-association chain (both depend only on the front-end)")
     ap.add_argument("--shared-landmarks", type=int, default=256)
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: LM solves on a second HIP stream beside the front-end / DA kernels (measured: +1 %, the LM workgroups fill every CU)")
@@ -257,14 +259,23 @@ def main():
     prev.run_frontend(fp)          # state: the previous keyframes' features (not part of a step)
     ctx.synchronize()
     vocab, voc, db = build_place_recognition(capi, ctx, prev)
+    side = torch.cuda.Stream() if args.side_stream else None
+    ctx_side = pkg.Context(local, stream=side.cuda_stream) if side else None
 
     def step(serial=False):
         cur.run_frontend(fp)
+        if side:
+            side.wait_stream(torch.cuda.current_stream())
+            cur.bow_transform(voc, ctx=ctx_side)
+            cur.bow_query(db, 4, ctx=ctx_side)
         ctx.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
         ctx.fm_run_batch(cur, prev, pairs, fm, d_idx, d_st, d_tr)            # stage 2 of the DA (da_stage2_method = 3): fundamental-matrix
         ctx.cip_run_batch(cur, prev, pairs, cp, d_idx, d_st, d_tr)           # RANSAC filter, then the change-in-pose filter
-        cur.bow_transform(voc)                                               # place recognition (queryDB, EST.cpp:426): words of the left
-        cur.bow_query(db, 4)                                                 # descriptors, L1 query of the keyframe database, 4 results
+        if side:
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            cur.bow_transform(voc)                                           # place recognition (queryDB, EST.cpp:426): words of the left
+            cur.bow_query(db, 4)                                             # descriptors, L1 query of the keyframe database, 4 results
         if serial:
             torch.cuda.synchronize()      # profile pass: one kernel at a time, clean per-kernel durations
         lm.reset()
@@ -393,6 +404,8 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line))
     db.close(); voc.close(); lm.close(); cur.close(); prev.close()
+    if ctx_side:
+        ctx_side.close()
     if ctx_lm is not ctx:
         ctx_lm.close()
     ctx.close()

@@ -193,8 +193,10 @@ class KfBatch:
         return nkp.reshape(-1, 2), nm
 
     # -- bag of words (ssk_bow.hip) --
-    def bow_transform(self, voc, kf_begin=0, kf_end=None):
-        self.ctx._chk(self.ctx.lib.ssk_bow_transform_batch(self.ctx.h, voc.h_, self.h_, int(kf_begin), int(self.n_kf if kf_end is None else kf_end)))
+    def bow_transform(self, voc, kf_begin=0, kf_end=None, ctx=None):
+        """ctx: enqueue on another context's stream (same device) instead of the batch's own."""
+        c = ctx or self.ctx
+        c._chk(c.lib.ssk_bow_transform_batch(c.h, voc.h_, self.h_, int(kf_begin), int(self.n_kf if kf_end is None else kf_end)))
 
     def bow_download(self, kf):
         w = np.zeros(self.max_feats, np.int32)
@@ -203,12 +205,13 @@ class KfBatch:
         self.ctx._chk(self.ctx.lib.ssk_kfbatch_bow_download(self.ctx.h, self.h_, int(kf), _ptr(w), _ptr(v), self.max_feats, C.byref(n)))
         return w[:n.value].copy(), v[:n.value].copy()
 
-    def bow_query(self, db, max_results=4, max_ids=None, kf_begin=0, kf_end=None):
+    def bow_query(self, db, max_results=4, max_ids=None, kf_begin=0, kf_end=None, ctx=None):
         kf_end = self.n_kf if kf_end is None else kf_end
         mi = None if max_ids is None else np.ascontiguousarray(max_ids, np.int32)
         assert mi is None or len(mi) == kf_end - kf_begin
-        self.ctx._chk(self.ctx.lib.ssk_bow_db_query_batch(self.ctx.h, db.h_, self.h_, int(kf_begin), int(kf_end), int(max_results),
-                                                          None if mi is None else _ptr(mi)))
+        c = ctx or self.ctx
+        c._chk(c.lib.ssk_bow_db_query_batch(c.h, db.h_, self.h_, int(kf_begin), int(kf_end), int(max_results),
+                                            None if mi is None else _ptr(mi)))
 
     def bow_results(self, kf_begin=0, kf_end=None):
         """[(ids, scores)] of the last bow_query for keyframes [kf_begin, kf_end)."""
