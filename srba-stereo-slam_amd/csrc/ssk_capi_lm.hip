@@ -20,6 +20,7 @@ struct ssk_lm_batch {
 	lm_dev D{};
 	size_t n_pose = 0, n_lm = 0;      // doubles in pose / lm families
 	bool tiled_ok = false;            // every window fits the LDS-tiled kernel
+	int max_tiles = 0;                // most tiles of a window (cooperative kernel: workgroups per window)
 	size_t tiled_dyn_bytes = 0;       // its dynamic LDS size
 };
 
@@ -649,6 +650,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
 #undef UP
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
+	b->max_tiles = 0;
+	for (const lm_win& hw : b->hdr) b->max_tiles = std::max(b->max_tiles, hw.n_tiles);
 	if (!rc) rc = upload(b, pose, const_cast<const double**>(&D.pose));     // working copies of the state (pose0 / lm0 keep the initial one)
 	if (!rc) rc = upload(b, lm, const_cast<const double**>(&D.lm));
 	const size_t n_obs = obs_lm.size(), n_path = path_edge.size(), n_ls = slot_lm.size(), n_us = slot_edge.size();
@@ -675,6 +678,8 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hred);
 	if (!rc) rc = scratch(b, 6 * n_us, &D.dp);
 	if (!rc) rc = scratch(b, (size_t)n_windows, &D.res);
+	if (!rc) rc = scratch(b, 4 * (size_t)n_windows, &D.coop_i);
+	if (!rc) rc = scratch(b, 128 * (size_t)n_windows, &D.coop_f);
 	if (!rc) rc = scratch(b, trace ? (size_t)n_windows * MAX_ITERS_ALLOC : 1, &D.trace);
 	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
@@ -716,6 +721,13 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	// two kernels, one contract: the LDS-tiled kernel when every window of the batch fits it (SSK_LM_KERNEL=l2 forces
 	// the general scratch-in-L2 kernel, which takes windows of any size)
 	const char* force = std::getenv("SSK_LM_KERNEL");
+	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
+	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
+	if (b->tiled_ok && !b->trace && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
+		int G = std::min(std::min(b->max_tiles, 64), ctx->n_cu / std::max(b->n_windows, 1));
+		const bool want = force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu);
+		if (want) return ssk_lm_launch_coop(ctx, b->D, P, b->n_windows, G, b->tiled_dyn_bytes);
+	}
 	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes);
 	return ssk_lm_launch(ctx, b->D, P, b->n_windows, b->max_n6);
 }

@@ -92,6 +92,8 @@ struct lm_dev {
 	double* Ppart; double* Spart; double* Hpair; double* Hred; double* dp;
 	ssk_lm_result* res; ssk_lm_trace_entry* trace; double* dp_trace; double* df_trace;
 	int trace_on;
+	int* coop_i;      // cooperative kernel, per window: [barrier counter, abort flag, solve ok, -]
+	double* coop_f;   // cooperative kernel, per window: 2 banks x 64 partial values
 };
 
 struct lm_cam {
@@ -115,4 +117,6 @@ constexpr int SSK_LMT_ENT = 15, SSK_LMT_OBS = 17, SSK_LMT_Y = 19, SSK_LMT_LMR = 
 constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024 / SSK_LMT_WG_PER_CU;   // gfx950: 160 KB of LDS per CU, shared by the resident workgroups
 constexpr int SSK_LMT_STATIC = 1024;               // reserve for the kernel's static LDS (a few scalars and the wave partials)
 int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes);
+// G workgroups per window (n_windows * G <= number of CUs, G <= 64): single large windows of the un-batched drop-in path
+int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes);
 int ssk_lm_launch_reset(ssk_ctx* ctx, double* pose, const double* pose0, size_t n_pose, double* lm, const double* lm0, size_t n_lm);

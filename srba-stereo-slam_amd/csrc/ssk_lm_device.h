@@ -266,6 +266,133 @@ __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* 
 	return true;
 }
 
+// G for a system that does not fit LDS (n > ~126: the matrix lives in the window's L2-resident scratch): the same
+// factorisation and the same operation order per element as ldl_solve_lds, organised for global-memory latency:
+//   - every wave factorises the 6x6 diagonal block redundantly, so all 512 threads finish the panel in one pass;
+//   - the finished panel (rows below the block, 6 columns) is staged in LDS: the rank-6 update then costs one global load
+//     and one store per element instead of seven loads;
+//   - back-substitution stages rows of U in LDS in chunks, so its n sequential steps run on LDS instead of one L2 round
+//     trip each.
+// lds: the workgroup's free tile region (lds_doubles doubles).  Every thread returns the same flag.
+__device__ __forceinline__ bool ldl_solve_global(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
+{
+	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+	__shared__ int s_ldl_bad_g;
+	double* Pn = lds;                                  // panel rows r0..n, pitch 7
+	for (int c0 = 0; c0 < n; c0 += 6) {
+		__syncthreads();
+		double a[21], ivr[6];
+#pragma unroll
+		for (int i = 0; i < 6; ++i)
+#pragma unroll
+			for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = A[(size_t)(c0 + i) * np + c0 + k];
+		bool bad = false;
+#pragma unroll
+		for (int j = 0; j < 6; ++j) {
+			const double d = a[j * (j + 1) / 2 + j];
+			bad |= !(d > 0.0);
+			ivr[j] = rcp_f64(d);
+#pragma unroll
+			for (int i = j + 1; i < 6; ++i) {
+				const double t = a[i * (i + 1) / 2 + j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+			}
+		}
+		const int r0 = c0 + 6;
+		for (int i = r0 + tid; i <= n; i += NT) {
+			double x[6];
+#pragma unroll
+			for (int k = 0; k < 6; ++k) x[k] = A[(size_t)i * np + c0 + k];
+#pragma unroll
+			for (int j = 0; j < 5; ++j) {
+				const double t = x[j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+			}
+#pragma unroll
+			for (int k = 1; k < 6; ++k) A[(size_t)i * np + c0 + k] = x[k];
+#pragma unroll
+			for (int k = 0; k < 6; ++k) Pn[(i - r0) * 7 + k] = x[k];
+		}
+		if (tid == 0) {
+			s_ldl_bad_g = bad;
+#pragma unroll
+			for (int i = 0; i < 6; ++i) {
+				inv[c0 + i] = ivr[i];
+#pragma unroll
+				for (int k = 0; k < i; ++k) A[(size_t)(c0 + i) * np + c0 + k] = a[i * (i + 1) / 2 + k];
+			}
+		}
+		__syncthreads();
+		if (s_ldl_bad_g) return false;                    // uniform
+		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
+			for (int kb = r0 + tx; kb < n; kb += 64) {
+				double ui[4][6], uk[2][6], v[8];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int i = ib + (NT / 32) * u;
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] = i <= n ? Pn[(i - r0) * 7 + c] * ivr[c] : 0.0;
+				}
+#pragma unroll
+				for (int w = 0; w < 2; ++w) {
+					const int k = kb + 32 * w;
+#pragma unroll
+					for (int c = 0; c < 6; ++c) uk[w][c] = k < n ? Pn[(k - r0) * 7 + c] : 0.0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						v[2 * u + w] = (i <= n && k < n && k <= i) ? A[(size_t)i * np + k] : 0.0;
+					}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						if (i <= n && k < n && k <= i) {
+							double sacc = 0.0;
+#pragma unroll
+							for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
+							A[(size_t)i * np + k] = v[2 * u + w] - sacc;
+						}
+					}
+			}
+	}
+	__syncthreads();
+	// x <- D^-1 z, then row i of U updates x_k, k < i, from the last row up; rows staged in LDS `cr` at a time
+	for (int k = tid; k < n; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
+	int cr = lds_doubles / (n > 0 ? n : 1);
+	cr = cr > 64 ? 64 : cr;
+	if (cr < 1) {                                      // no room to stage: one L2 round trip per row
+		__syncthreads();
+		for (int i = n - 1; i > 0; --i) {
+			const double xi = x_out[i];
+			for (int k = tid; k < i; k += NT) x_out[k] -= A[(size_t)i * np + k] * inv[k] * xi;
+			__syncthreads();
+		}
+		return true;
+	}
+	for (int hi = n - 1; hi > 0; hi -= cr) {
+		const int lo = hi - cr + 1 > 1 ? hi - cr + 1 : 1;          // rows lo..hi
+		__syncthreads();
+		for (int t = tid; t < (hi - lo + 1) * n; t += NT) {
+			const int r = t / n, k = t - r * n, i = lo + r;
+			lds[r * n + k] = k < i ? A[(size_t)i * np + k] * inv[k] : 0.0;
+		}
+		__syncthreads();
+		for (int i = hi; i >= lo; --i) {
+			const double xi = x_out[i];
+			for (int k = tid; k < i; k += NT) x_out[k] -= lds[(i - lo) * n + k] * xi;
+			__syncthreads();
+		}
+	}
+	return true;
+}
+
 // G (fallback): the same factorisation by the whole workgroup on an L2-resident matrix (6E too large for LDS)
 __device__ bool chol_solve_block(double* A, int n, double* b, int* s_flag, double* s_piv)
 {

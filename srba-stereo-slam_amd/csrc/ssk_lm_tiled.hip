@@ -216,11 +216,55 @@ __device__ __forceinline__ double obs_error_packed(const lm_cam& P, const double
 	return 2.0 * k2 * (u * rsq_f64(u) - 1.0);
 }
 
-__device__ double total_error_packed(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const double* lm, double* s_part)
+// observations k = first, first + step, ... (one workgroup: first = thread id, step = NT)
+__device__ double total_error_packed(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const double* lm, double* s_part,
+                                     int first, int step)
 {
 	double e = 0;
-	for (int k = threadIdx.x; k < W.n_obs; k += NT) e += obs_error_packed(P, pose, lm + 3 * (size_t)W.lm0, D.tobs_a[W.tobs0 + k], D.tobs_px[W.tobs0 + k]);
+	for (int k = first; k < W.n_obs; k += step) e += obs_error_packed(P, pose, lm + 3 * (size_t)W.lm0, D.tobs_a[W.tobs0 + k], D.tobs_px[W.tobs0 + k]);
 	return block_sum(e, s_part);
+}
+
+// ---- cooperative variant: G workgroups share one window (its tiles, incidences, landmarks and observations are dealt out
+// among them; workgroup 0 solves the reduced system).  They meet at barriers in global memory: every thread fences its own
+// stores, thread 0 arrives on a monotonic counter and waits for the G arrivals of this round, every thread fences again
+// before it reads what the others wrote.  All G workgroups are resident (the host launches at most one per CU).  A wait that
+// outlasts COOP_SPIN_LIMIT polls raises the window's abort flag and every workgroup leaves (stop_reason 5).
+constexpr int COOP_SPIN_LIMIT = 1 << 22;
+struct coop_t { int* cnt; int* abort; double* f; int g, G, round, bank; };
+
+__device__ __forceinline__ bool coop_barrier(coop_t& c)
+{
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		++c.round;
+		__hip_atomic_fetch_add(c.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		int spins = 0;
+		while (__hip_atomic_load(c.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < c.round * c.G) {
+			__builtin_amdgcn_s_sleep(8);
+			if (++spins > COOP_SPIN_LIMIT || __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+				__hip_atomic_store(c.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				break;
+			}
+		}
+	}
+	__syncthreads();
+	__threadfence();
+	return __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+// the G workgroups' values v (already reduced inside each workgroup) combined in workgroup order: sum or max
+template <bool MAX>
+__device__ __forceinline__ double coop_combine(coop_t& c, double v, bool& alive)
+{
+	double* slot = c.f + 64 * c.bank;
+	c.bank ^= 1;                                        // two banks: a workgroup is at most one exchange ahead of the slowest
+	if (threadIdx.x == 0) slot[c.g] = v;
+	alive = coop_barrier(c);
+	double r = slot[0];
+	for (int k = 1; k < c.G; ++k) r = MAX ? fmax(r, slot[k]) : r + slot[k];
+	return r;
 }
 
 // Sum of component ab over the contiguous partial slots k0..k1-1 in order, eight independent loads in flight;
@@ -489,15 +533,19 @@ __device__ unsigned long long g_f2g[4];
 #else
 #define F2G_TICK(i) do {} while (0)
 #endif
-template <typename PtrA>
+// `solve` = false: only the share (first, step) of the assembly (cooperative kernel: the workgroups of a window assemble the
+// L2-resident system together, workgroup 0 then factorises it with `assemble` = false)
+template <bool GLOBAL_A, typename PtrA>
 __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win& W, const double* __restrict__ Pp, const double* __restrict__ Sp,
-                                                   double lambda, PtrA A, int np, int n6, double* s_b, double* s_inv)
+                                                   double lambda, PtrA A, int np, int n6, double* s_b, double* s_inv,
+                                                   bool assemble = true, bool solve = true, int first = threadIdx.x, int step = NT,
+                                                   double* lds_free = nullptr, int lds_free_doubles = 0)
 {
-	const int tid = threadIdx.x;
 #ifdef SSK_LM_STAMPS
 	unsigned long long f2g_last = __builtin_amdgcn_s_memtime();
 #endif
-	for (int it = tid; it < W.n_pairs * 36; it += NT) {
+	if (assemble) {
+	for (int it = first; it < W.n_pairs * 36; it += step) {
 		const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
 		const int2 ee = D.pair_ee[W.pair0 + pid];
 		if (ee.x == ee.y && a > b) continue;
@@ -509,7 +557,7 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 		A[(6 * ee.y + b) * np + 6 * ee.x + a] = sres;
 	}
 	F2G_TICK(0);
-	for (int it = tid; it < n6 * 8; it += NT) {
+	for (int it = first; it < n6 * 8; it += step) {
 		const int comp = it >> 3, j = it & 7, e = comp / 6, a = comp - e * 6;
 		const int k0 = D.el_off[W.uso0 + e], k1 = D.el_off[W.uso0 + e + 1];
 		const double* src = D.gre + 6 * (size_t)W.el0 + a;
@@ -521,15 +569,21 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 		v += __shfl_down(v, 4, 8); v += __shfl_down(v, 2, 8); v += __shfl_down(v, 1, 8);
 		if (j == 0) A[n6 * np + comp] = v;
 	}
+	}
 	__syncthreads();
 	F2G_TICK(1);
-	const bool ok_ = n6 > 0 ? ldl_solve_lds(A, np, n6, s_b, s_inv) : true;
+	if (!solve) return true;
+	bool ok_ = true;
+	if (n6 > 0) {
+		if constexpr (GLOBAL_A) ok_ = ldl_solve_global(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
+		else ok_ = ldl_solve_lds(A, np, n6, s_b, s_inv);
+	}
 	F2G_TICK(2);
 	return ok_;
 }
 
-__global__ __launch_bounds__(NT, SSK_LM_WAVES)
-void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
+template <bool COOP>
+__device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, int dyn_doubles, int G)
 {
 	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | delta | pivots | tile records / reduced system]
 	__shared__ double s_part[NW];
@@ -537,10 +591,14 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 	__shared__ int s_accept, s_stop, s_iters, s_accepted;
 	__shared__ int s_lmflag;                           // waves that have published their landmark records, all tiles so far
 
-	const lm_win W = D.win[blockIdx.x];
+	const int wi = COOP ? (int)blockIdx.x / G : (int)blockIdx.x, g = COOP ? (int)blockIdx.x % G : 0, GG = COOP ? G : 1;
+	const lm_win W = D.win[wi];
 	const int tid = threadIdx.x;
 	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1;
 	int epoch = 0;                                     // tiles started so far
+	coop_t co = {COOP ? D.coop_i + 4 * wi : nullptr, COOP ? D.coop_i + 4 * wi + 1 : nullptr, COOP ? D.coop_f + 128 * (size_t)wi : nullptr, g, GG, 0, 0};
+	bool alive = true;
+	(void)alive;
 	double* pose_cur = s_dyn;
 	double* pose_new = s_dyn + 12 * W.n_edges;
 	double* s_b = s_dyn + 24 * W.n_edges;               // right-hand side / solution of the reduced system (n6)
@@ -570,17 +628,20 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 		const double v = D.pose[12 * (size_t)W.edge0 + i];
 		pose_cur[i] = v; pose_new[i] = v;
 	}
-	for (int i = tid; i < 3 * W.n_lms; i += NT) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
+	for (int i = tid + NT * g; i < 3 * W.n_lms; i += NT * GG) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
 	__syncthreads();
-	const double e0 = total_error_packed(D, W, P, pose_cur, D.lm, s_part);
+	double e0 = total_error_packed(D, W, P, pose_cur, D.lm, s_part, tid + NT * g, NT * GG);
+	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
 		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_lmflag = 0;
-		ssk_lm_result& R = D.res[blockIdx.x];
-		R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
+		if (g == 0) {
+			ssk_lm_result& R = D.res[wi];
+			R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
+		}
 	}
 	__syncthreads();
 	if (W.E == 0 && W.L == 0) {
-		if (tid == 0) { ssk_lm_result& R = D.res[blockIdx.x]; R.iters = 0; R.accepted = 0; R.err_final = e0; R.lambda_final = -1.0; }
+		if (tid == 0 && g == 0) { ssk_lm_result& R = D.res[wi]; R.iters = 0; R.accepted = 0; R.err_final = e0; R.lambda_final = -1.0; }
 		return;
 	}
 	double* const Pp = D.Ppart2 + 36 * (size_t)W.ps0;
@@ -588,6 +649,7 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 
 	while (true) {
 		__syncthreads();
+		if (COOP && !alive) { if (tid == 0) s_stop = 5; break; }
 		if (s_iters >= P.max_iters) break;
 		if (W.n_obs > 0 && sqrt(s_err / W.n_obs) < P.stop_rmse) { if (tid == 0) s_stop = 1; break; }
 		const double lambda = s_lambda;
@@ -595,9 +657,14 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 		const int it_idx = s_iters;
 		double vmax = 0.0;
 		STAMP(0);
-		for (int t = 0; t < W.n_tiles; ++t) {
+		for (int t = g; t < W.n_tiles; t += GG) {
 			process_tile(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, ++epoch, &s_lmflag, Pp, Sp, vmax);
 			STAMP(1);
+		}
+		if (COOP) {                                    // every workgroup's slots, Y, gradient terms and landmark factors are out
+			if (pre) vmax = coop_combine<true>(co, block_max(vmax, s_part), alive);
+			else alive = coop_barrier(co);
+			if (!alive) continue;
 		}
 		if (pre) {
 			// lambda0 = tau * max diag(H): the diagonal blocks' slot sums, and the landmark blocks' diagonals
@@ -612,15 +679,36 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 		}
 		// ---- F2 + G: assemble and solve the reduced system; instantiated once for the LDS copy and once for the L2 copy so
 		//      that each uses the instructions of its address space (a pointer that may be either compiles to FLAT accesses) ----
-		bool ok = lds_mat ? assemble_and_solve(D, W, Pp, Sp, lambda, reg, np, n6, s_b, s_inv)
-		                  : assemble_and_solve(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv);
+		bool ok = true;
+		const bool share_f2 = COOP && !lds_mat;         // an L2-resident system is assembled by all the workgroups of the window
+		if (share_f2) {
+			assemble_and_solve<true>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, true, false, tid + NT * g, NT * GG);
+			alive = coop_barrier(co);
+			if (!alive) continue;
+		}
+		if (g == 0) {
+			ok = lds_mat ? assemble_and_solve<false>(D, W, Pp, Sp, lambda, reg, np, n6, s_b, s_inv)
+			             : assemble_and_solve<true>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, !share_f2, true, tid, NT,
+			                                  reg, dyn_doubles - (int)(reg - s_dyn));
+			if (COOP) {
+				if (ok) for (int i = tid; i < n6; i += NT) D.dp[6 * (size_t)W.us0 + i] = s_b[i];
+				if (tid == 0) D.coop_i[4 * wi + 2] = ok;
+			}
+		}
+		if (COOP) {                                    // the step of the edges, to every workgroup
+			alive = coop_barrier(co);
+			if (!alive) continue;
+			ok = D.coop_i[4 * wi + 2] != 0;
+			if (g != 0 && ok) for (int i = tid; i < n6; i += NT) s_b[i] = D.dp[6 * (size_t)W.us0 + i];
+			__syncthreads();
+		}
 		STAMP(6);
 		double dpn = 0, dfn = 0;
 		if (ok) {
-			for (int i = tid; i < n6; i += NT) { D.dp[6 * (size_t)W.us0 + i] = s_b[i]; dpn += s_b[i] * s_b[i]; }
+			for (int i = tid; i < n6; i += NT) { if (!COOP) D.dp[6 * (size_t)W.us0 + i] = s_b[i]; dpn += s_b[i] * s_b[i]; }
 			// ---- H: landmarks, delta_f = L^-T (c - sum_e Y_e^T delta_e).  First one lane per incidence (coalesced Y stream,
 			//      3-vector Y_m^T delta_e staged in the window's L2-resident scratch), then one lane per landmark ----
-			for (int m = tid; m < W.n_lme_unknown; m += NT) {
+			for (int m = tid + NT * g; m < W.n_lme_unknown; m += NT * GG) {
 				const double* Ym = D.Tb + 18 * (size_t)(W.lme0 + m);
 				const int e = D.lme_edge[W.lme0 + m];
 				double y[18], t0 = 0, t1 = 0, t2 = 0;
@@ -631,8 +719,8 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 				double* o = D.gpe + 6 * (size_t)(W.lme0 + m);
 				o[0] = t0; o[1] = t1; o[2] = t2;
 			}
-			__syncthreads();
-			for (int l = tid; l < W.L; l += NT) {
+			if (COOP) alive = coop_barrier(co); else __syncthreads();
+			for (int l = tid + NT * g; l < W.L; l += NT * GG) {
 				const double* lg = D.Vinv + 9 * (size_t)(W.ls0 + l);
 				double li[9];
 #pragma unroll
@@ -678,11 +766,18 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 		STAMP(7);
 		// ---- I ----
 		double err_new = s_err;
-		if (ok) err_new = total_error_packed(D, W, P, pose_new, D.lm_new, s_part);
+		if (COOP && ok) {                              // every workgroup's landmark steps are out
+			__syncthreads();                           // (pose_new of this workgroup complete)
+			alive = coop_barrier(co);
+			const double part = total_error_packed(D, W, P, pose_new, D.lm_new, s_part, tid + NT * g, NT * GG);
+			err_new = coop_combine<false>(co, part, alive);
+			if (!alive) continue;
+		}
+		if (!COOP && ok) err_new = total_error_packed(D, W, P, pose_new, D.lm_new, s_part, tid, NT);
 		__syncthreads();
 		if (tid == 0) {
 			const int accepted = ok && err_new < s_err;
-			if (D.trace_on) {
+			if (D.trace_on && g == 0) {
 				ssk_lm_trace_entry& t = D.trace[W.trace0 + it_idx];
 				t.lambda = lambda; t.err_before = s_err; t.err_after = err_new; t.delta_p_norm = sqrt(dpn);
 				t.delta_f_norm = sqrt(dfn); t.accepted = accepted; t.cholesky_ok = ok;
@@ -706,23 +801,25 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 				const int ei = D.slot_edge[W.us0 + e];
 				for (int c = 0; c < 12; ++c) pose_cur[12 * ei + c] = pose_new[12 * ei + c];
 			}
-			for (int l = tid; l < W.L; l += NT) {
+			for (int l = tid + NT * g; l < W.L; l += NT * GG) {
 				const int li = D.slot_lm[W.ls0 + l];
 				for (int c = 0; c < 3; ++c) D.lm[3 * (size_t)(W.lm0 + li) + c] = D.lm_new[3 * (size_t)(W.lm0 + li) + c];
 			}
+			if (COOP) alive = coop_barrier(co);        // the next pass linearises at the landmarks every workgroup just stored
 		}
 		__syncthreads();
 		STAMP(8);
 		if (s_stop == 2 || s_stop == 4) break;
 	}
 	__syncthreads();
+	if (g != 0) return;
 	// publish the final edge poses (they lived in LDS during the solve)
 	for (int e = tid; e < W.E; e += NT) {
 		const int ei = D.slot_edge[W.us0 + e];
 		for (int c = 0; c < 12; ++c) D.pose[12 * (size_t)(W.edge0 + ei) + c] = pose_cur[12 * ei + c];
 	}
 	if (tid == 0) {
-		ssk_lm_result& R = D.res[blockIdx.x];
+		ssk_lm_result& R = D.res[wi];
 		R.iters = s_iters; R.accepted = s_accepted; R.stop_reason = s_stop; R.err_final = s_err; R.lambda_final = s_lambda;
 #ifdef SSK_LM_STAMPS
 		if (blockIdx.x == 0)
@@ -737,7 +834,36 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 	}
 }
 
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
+{
+	lm_tiled_body<false>(D, P, dyn_doubles, 1);
+}
+
+// G workgroups per window (grid = n_windows * G, all resident)
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_coop_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G)
+{
+	lm_tiled_body<true>(D, P, dyn_doubles, G);
+}
+
 }  // namespace
+
+int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes)
+{
+	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
+	static bool attr_set = false;
+	if (!attr_set) {
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		attr_set = true;
+	}
+	SSK_HIP(ctx, hipMemsetAsync(D.coop_i, 0, sizeof(int) * 4 * (size_t)n_windows, ctx->stream));
+	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
+	hipLaunchKernelGGL(lm_solve_coop_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G);
+	SSK_LAUNCH_CHECK(ctx, "lm_solve_coop_kernel");
+	return SSK_OK;
+}
 
 int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes)
 {
