@@ -160,6 +160,48 @@ def test_lm_large_window_global_cholesky(ctx, oracle, kernel, monkeypatch):
     check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8))
 
 
+def run_plain(ctx, wins, prm):
+    """No trace: (results, [(poses, lms)]) of a batch."""
+    from ssk_amd import capi
+    b = capi.LmBatch(ctx, wins)
+    b.run(to_capi(prm))
+    res = b.results()
+    st = [b.state(i) for i in range(len(wins))]
+    b.close()
+    return res, st
+
+
+@pytest.mark.parametrize("shape", ["bench", "large", "batch3"])
+def test_lm_cooperative_kernel(ctx, oracle, shape, monkeypatch):
+    """lm_solve_coop_kernel (several workgroups per window, barriers in global memory; SSK_LM_KERNEL=coop forces it, the
+    default picks it for few large windows): same contract -- iteration count, stop reason and final error as the oracle
+    within 1e-6, final state as the one-workgroup kernel (the partial error sums are combined in another order, so decisions
+    agree up to the rounding-level coin toss of the last attempt)."""
+    if shape == "bench":
+        wins = [sl.make_submap_problem(7, n_kf=60, n_lm=1500, submap_size=10, max_tree_depth=4, opt_depth=2, obs_per_kf=250,
+                                       lm_fwd=(3, 20), z_vis=(2.5, 22))[0]]
+        prm = sl.make_params()
+    elif shape == "large":
+        wins = [sl.make_submap_problem(21, n_kf=45, n_lm=900, submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)[0]]
+        assert 6 * wins[0].E > 140                       # reduced system in L2 scratch: shared assembly, global-memory LDLT
+        prm = sl.make_params(max_iters=8)
+    else:
+        wins = [sl.make_submap_problem(30 + k, n_kf=40 + 10 * k, n_lm=1000, submap_size=10, max_tree_depth=4, opt_depth=2, obs_per_kf=200,
+                                       lm_fwd=(3, 20), z_vis=(2.5, 22))[0] for k in range(3)]
+        prm = sl.make_params()
+    monkeypatch.setenv("SSK_LM_KERNEL", "tiled")
+    res1, st1 = run_plain(ctx, wins, prm)
+    monkeypatch.setenv("SSK_LM_KERNEL", "coop")
+    resg, stg = run_plain(ctx, wins, prm)
+    for w, (r1, rg) in enumerate(zip(res1, resg)):
+        exp = oracle.lm_solve(wins[w], prm, trace=False)["res"]
+        assert rg.stop_reason == exp.stop_reason != 5 and abs(rg.iters - exp.iters) <= 1 and rg.n_obs == exp.n_obs
+        assert abs(rg.err_init - exp.err_init) <= 1e-10 * exp.err_init and abs(rg.err_final - exp.err_final) <= REL * exp.err_final
+        assert abs(rg.err_final - r1.err_final) <= 1e-9 * r1.err_final and abs(rg.iters - r1.iters) <= 1
+        tol = 1e-5 if rg.stop_reason == 4 else 1e-8
+        assert np.abs(stg[w][0] - st1[w][0]).max() <= tol and np.abs(stg[w][1] - st1[w][1]).max() <= 10 * tol
+
+
 def test_build_observations_bit_exact(ctx, oracle):
     """a10/a11: projectMatchTo3D + camera pose composition (UTIL.h:558-574, EST.cpp:158,698), FP64 bit-exact."""
     import ctypes
