@@ -35,14 +35,14 @@ def full_loop(n):
         for k, (l, r) in enumerate(frames):
             l.tofile(os.path.join(d, "left_%04d.raw" % k))
             r.tofile(os.path.join(d, "right_%04d.raw" % k))
-        env = dict(os.environ, SSK_FACADE_TIMING="1") if os.environ.get("SSK_FACADE_TIMING") else None
+        env = dict(os.environ) if os.environ.get("SSK_FACADE_TIMING") or os.environ.get("SSK_TIMING") else None
         p = subprocess.run([demo, "stream", vf, d, str(n), str(synth.W), str(synth.H)], capture_output=True, text=True, env=env)
         assert p.returncode == 0, p.stderr
         for l in p.stdout.splitlines():
             if l.startswith(("timing", "keyframes", "posegraph")):
                 print(l)
         for l in p.stderr.splitlines()[-8:]:
-            if "facade timing" in l:
+            if "facade timing" in l or "ssk timing" in l:
                 print(l)
 
 
