@@ -355,7 +355,8 @@ int ssk_kfbatch_bow_results(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_e
  * (EST.cpp:945-957).  Contract G1-G6: oracle/oracle_posegraph.c.  Nodes X_k: pose of keyframe k in the root's frame,
  * row-major [R|t], in/out; edge e: (i, j) = edge_ij[2e], edge_ij[2e+1] with X_i^-1 X_j = Z_e (edge_z, 12 doubles each; the
  * k2k edge {from, to, inv_pose} gives i = to, j = from, Z = inv_pose); fixed_node is held (the root).  Levenberg-Marquardt on
- * e = (t_E, log R_E), E = Z^-1 X_i^-1 X_j, unit information; the step comes from block-Jacobi preconditioned CG. */
+ * e = (t_E, log R_E), E = Z^-1 X_i^-1 X_j, unit information, gain-ratio lambda update (as MRPT's optimiser); the step comes
+ * from conjugate gradients preconditioned with the spanning-tree part of the system. */
 typedef struct ssk_pg_params {
 	int32_t max_iters;                 /* LM attempts; MRPT's default is 100 */
 	int32_t pcg_max_iters;             /* CG iterations per attempt */

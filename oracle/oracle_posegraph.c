@@ -14,14 +14,20 @@
  *   G4  Jacobians to first order: with A = Z^-1 X_i^-1, B = X_j:  de/dd_j = J,  de/dd_i = -J,
  *           J = [ R_A   -R_A [t_B]x ;  0   Jr^-1(log R_E) R_B^T ],   Jr^-1(w) = I + [w]x / 2 + c [w]x^2,
  *           c = 1/th^2 - (1 + cos th) / (2 th sin th)   (1/12 below th = 1e-4).
- *   G5  Levenberg-Marquardt with the schedule of L3: H = sum of J^T J blocks, g = sum of +-J^T e;  (H + lambda I) d = -g;
- *       lambda0 = tau * max diag H;  a step is kept iff it lowers the cost: lambda <- lambda / 10, nu <- 2;  otherwise
- *       lambda <- lambda * nu, nu <- 2 nu.  Stop: max_iters attempts, lambda > max_lambda, or an attempt changes the cost by
+ *   G5  Levenberg-Marquardt as MRPT's optimize_graph_spa_levmarq runs it (Madsen-Nielsen-Tingleff): H = sum of J^T J blocks,
+ *       g = sum of +-J^T e;  (H + lambda I) d = -g;  lambda0 = tau * max diag H;  gain ratio rho = (cost - cost_new) /
+ *       (d.(lambda d - g));  a step is kept iff it lowers the cost: lambda <- lambda * max(1/3, 1 - (2 rho - 1)^3), nu <- 2;
+ *       otherwise lambda <- lambda * nu, nu <- 2 nu.  Stop: max_iters attempts, lambda > max_lambda, or an attempt changes the cost by
  *       no more than converged_rel_decrease * cost (either sign), or the cost is at round-off level (<= 1e-22 per edge:
  *       residuals of 1e-11 m / rad; a tree-shaped graph starts there).
- *   G6  the linear system is solved by conjugate gradients preconditioned with the inverse 6x6 diagonal blocks (Cholesky),
- *       from d = 0, until r.z <= pcg_tol^2 * r0.z0 or pcg_max_iters iterations; sums in node order.  (MRPT factorises the
- *       sparse system; to the tolerance used here the step is the same.)
+ *   G6  the linear system is solved by conjugate gradients, from d = 0, until r.z <= pcg_tol^2 * r0.z0 or pcg_max_iters
+ *       iterations; sums in node order.  Preconditioner: the system restricted to a spanning tree -- the full 6x6 diagonal
+ *       blocks (+ lambda I) with the off-diagonal blocks of the TREE edges only, where the tree is the breadth-first tree
+ *       from the fixed node (nodes and their incident edges visited in ascending order; a node the fixed one does not reach
+ *       starts its own tree).  On a tree the block LDL^T factorisation has no fill: children before parents,
+ *       S_k = D_k + lambda I - sum over children c of M_e S_c^-1 M_e, and two sweeps solve it exactly.  What conjugate
+ *       gradients still has to resolve are the loop-closure edges (about six iterations per edge off the tree), not the
+ *       length of the trajectory.  (MRPT factorises the whole sparse system; to the tolerance used here the step is the same.)
  */
 #include "ssk_oracle.h"
 #include <math.h>
@@ -125,6 +131,99 @@ static void chol6_solve(const double* L, const double* b, double* x)
 	for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s / L[6 * i + i]; }
 }
 
+/* G6 tree preconditioner.  order: free nodes, parents before children; par[k] / par_e[k]: tree parent (-1: none or the fixed
+ * node) and the edge to it.  factor: S-factors (Cholesky, 36 per node) into Ls; returns 0 when a block is not positive definite. */
+typedef struct pg_tree { int nf; int32_t* order; int32_t* par; int32_t* par_e; } pg_tree;
+
+static void tree_build(pg_tree* T, int n, int m, const int32_t* edge_ij, int fixed_node)
+{
+	T->order = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+	T->par = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+	T->par_e = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+	int32_t* off = (int32_t*)calloc((size_t)n + 2, sizeof(int32_t));
+	int32_t* inc = (int32_t*)malloc(sizeof(int32_t) * (size_t)(2 * m + 1));
+	for (int k = 0; k < m; ++k) { off[edge_ij[2 * k] + 2]++; off[edge_ij[2 * k + 1] + 2]++; }
+	for (int k = 0; k < n; ++k) off[k + 2] += off[k + 1];
+	for (int k = 0; k < m; ++k) { inc[off[edge_ij[2 * k] + 1]++] = k; inc[off[edge_ij[2 * k + 1] + 1]++] = k; }   /* ascending edge id per node */
+	unsigned char* seen = (unsigned char*)calloc((size_t)n + 1, 1);
+	int32_t* queue = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+	T->nf = 0;
+	for (int k = 0; k < n; ++k) { T->par[k] = -1; T->par_e[k] = -1; }
+	for (int start = -1; start < n; ++start) {              /* the fixed node first, then every node it did not reach */
+		const int root = start < 0 ? fixed_node : start;
+		if (root < 0 || root >= n || seen[root]) continue;
+		int qh = 0, qt = 0;
+		queue[qt++] = root; seen[root] = 1;
+		if (root != fixed_node) T->order[T->nf++] = root;
+		while (qh < qt) {
+			const int u = queue[qh++];
+			for (int t = off[u]; t < off[u + 1]; ++t) {
+				const int ed = inc[t], v = edge_ij[2 * ed] == u ? edge_ij[2 * ed + 1] : edge_ij[2 * ed];
+				if (seen[v]) continue;
+				seen[v] = 1; queue[qt++] = v;
+				T->order[T->nf++] = v;
+				if (u != fixed_node) { T->par[v] = u; T->par_e[v] = ed; }
+			}
+		}
+	}
+	free(off); free(inc); free(seen); free(queue);
+}
+
+static void tree_free(pg_tree* T) { free(T->order); free(T->par); free(T->par_e); }
+
+static void mat6_mul_vec(const double* A, const double* x, double* y)
+{
+	for (int a = 0; a < 6; ++a) { double s = 0; for (int b = 0; b < 6; ++b) s += A[6 * a + b] * x[b]; y[a] = s; }
+}
+
+static int tree_factor(const pg_tree* T, const double* D, const double* M, double lambda, double* S, double* Ls)
+{
+	for (int t = 0; t < T->nf; ++t) {
+		const int k = T->order[t];
+		memcpy(S + 36 * (size_t)k, D + 36 * (size_t)k, 36 * sizeof(double));
+		for (int a = 0; a < 6; ++a) S[36 * (size_t)k + 7 * a] += lambda;
+	}
+	for (int t = T->nf - 1; t >= 0; --t) {                  /* children before parents */
+		const int c = T->order[t];
+		if (!chol6(S + 36 * (size_t)c, Ls + 36 * (size_t)c)) return 0;
+		const int p = T->par[c];
+		if (p < 0) continue;
+		const double* Me = M + 36 * (size_t)T->par_e[c];
+		for (int col = 0; col < 6; ++col) {                  /* S_p -= M_e S_c^-1 M_e, column by column */
+			double m_col[6], x[6], y[6];
+			for (int a = 0; a < 6; ++a) m_col[a] = Me[6 * a + col];
+			chol6_solve(Ls + 36 * (size_t)c, m_col, x);
+			mat6_mul_vec(Me, x, y);
+			for (int a = 0; a < 6; ++a) S[36 * (size_t)p + 6 * a + col] -= y[a];
+		}
+	}
+	return 1;
+}
+
+/* z = M^-1 r on the free nodes (z of the fixed node stays 0); y: work vector */
+static void tree_apply(const pg_tree* T, const double* M, const double* Ls, const double* r, double* y, double* z)
+{
+	for (int t = 0; t < T->nf; ++t) { const int k = T->order[t]; memcpy(y + 6 * (size_t)k, r + 6 * (size_t)k, 6 * sizeof(double)); }
+	for (int t = T->nf - 1; t >= 0; --t) {                  /* forward: t_c = S_c^-1 y_c, y_p += M_e t_c */
+		const int c = T->order[t];
+		double tc[6], u[6];
+		chol6_solve(Ls + 36 * (size_t)c, y + 6 * (size_t)c, tc);
+		memcpy(z + 6 * (size_t)c, tc, sizeof tc);
+		const int p = T->par[c];
+		if (p < 0) continue;
+		mat6_mul_vec(M + 36 * (size_t)T->par_e[c], tc, u);
+		for (int a = 0; a < 6; ++a) y[6 * (size_t)p + a] += u[a];
+	}
+	for (int t = 0; t < T->nf; ++t) {                       /* backward: z_k = t_k + S_k^-1 M_e z_p */
+		const int k = T->order[t], p = T->par[k];
+		if (p < 0) continue;
+		double u[6], v[6];
+		mat6_mul_vec(M + 36 * (size_t)T->par_e[k], z + 6 * (size_t)p, u);
+		chol6_solve(Ls + 36 * (size_t)k, u, v);
+		for (int a = 0; a < 6; ++a) z[6 * (size_t)k + a] += v[a];
+	}
+}
+
 int ssko_pg_optimize(int n_nodes, double* X, int n_edges, const int32_t* edge_ij, const double* edge_z, int fixed_node,
                      const ssk_pg_params* P, ssk_pg_result* out)
 {
@@ -141,6 +240,10 @@ int ssko_pg_optimize(int n_nodes, double* X, int n_edges, const int32_t* edge_ij
 	double* p = (double*)malloc(sizeof(double) * 6 * (n + 1));
 	double* q = (double*)malloc(sizeof(double) * 6 * (n + 1));
 	double* Xn = (double*)malloc(sizeof(double) * 12 * (n + 1));
+	double* S = (double*)malloc(sizeof(double) * 36 * (n + 1));
+	double* yv = (double*)malloc(sizeof(double) * 6 * (n + 1));
+	pg_tree T;
+	tree_build(&T, n_nodes, n_edges, edge_ij, fixed_node);
 	double cost = ssko_pg_cost(n_edges, edge_ij, edge_z, X);
 	out->cost_init = cost;
 	double lambda = -1.0, nu = 2.0;
@@ -173,25 +276,18 @@ int ssko_pg_optimize(int n_nodes, double* X, int n_edges, const int32_t* edge_ij
 			for (size_t k = 0; k < n; ++k) if ((int)k != fixed_node) for (int a = 0; a < 6; ++a) mx = fmax(mx, D[36 * k + 7 * a]);
 			lambda = P->tau * mx;
 		}
-		/* G6: block-Jacobi PCG on (H + lambda I) d = -g, fixed node excluded */
-		int ok = 1;
-		for (size_t k = 0; k < n && ok; ++k) {
-			if ((int)k == fixed_node) continue;
-			double Dk[36];
-			memcpy(Dk, D + 36 * k, sizeof Dk);
-			for (int a = 0; a < 6; ++a) Dk[7 * a] += lambda;
-			ok = chol6(Dk, Lb + 36 * k);
-		}
+		/* G6: tree-preconditioned CG on (H + lambda I) d = -g, fixed node excluded */
+		int ok = tree_factor(&T, D, M, lambda, S, Lb);
 		double dn2 = 0;
 		int cg_it = 0;
 		if (ok) {
 			double rz = 0;
 			for (size_t k = 0; k < n; ++k) {
-				for (int a = 0; a < 6; ++a) { d[6 * k + a] = 0; r[6 * k + a] = (int)k == fixed_node ? 0.0 : -g[6 * k + a]; }
-				if ((int)k == fixed_node) { for (int a = 0; a < 6; ++a) z[6 * k + a] = 0; }
-				else chol6_solve(Lb + 36 * k, r + 6 * k, z + 6 * k);
-				for (int a = 0; a < 6; ++a) { p[6 * k + a] = z[6 * k + a]; rz += r[6 * k + a] * z[6 * k + a]; }
+				for (int a = 0; a < 6; ++a) { d[6 * k + a] = 0; z[6 * k + a] = 0; r[6 * k + a] = (int)k == fixed_node ? 0.0 : -g[6 * k + a]; }
 			}
+			tree_apply(&T, M, Lb, r, yv, z);
+			for (size_t k = 0; k < n; ++k)
+				for (int a = 0; a < 6; ++a) { p[6 * k + a] = z[6 * k + a]; rz += r[6 * k + a] * z[6 * k + a]; }
 			const double rz0 = rz;
 			while (cg_it < P->pcg_max_iters && rz > P->pcg_tol * P->pcg_tol * rz0 && rz > 0) {
 				/* q = (H + lambda I) p */
@@ -216,11 +312,11 @@ int ssko_pg_optimize(int n_nodes, double* X, int n_edges, const int32_t* edge_ij
 				if (!(pq > 0)) break;
 				const double alpha = rz / pq;
 				double rz_new = 0;
-				for (size_t k = 0; k < n; ++k) {
+				for (size_t k = 0; k < n; ++k)
 					for (int a = 0; a < 6; ++a) { d[6 * k + a] += alpha * p[6 * k + a]; r[6 * k + a] -= alpha * q[6 * k + a]; }
-					if ((int)k != fixed_node) chol6_solve(Lb + 36 * k, r + 6 * k, z + 6 * k);
+				tree_apply(&T, M, Lb, r, yv, z);
+				for (size_t k = 0; k < n; ++k)
 					for (int a = 0; a < 6; ++a) rz_new += r[6 * k + a] * z[6 * k + a];
-				}
 				const double beta = rz_new / rz;
 				for (size_t k = 0; k < 6 * n; ++k) p[k] = z[k] + beta * p[k];
 				rz = rz_new;
@@ -233,12 +329,16 @@ int ssko_pg_optimize(int n_nodes, double* X, int n_edges, const int32_t* edge_ij
 		}
 		out->pcg_iters_total += cg_it;
 		const double cost_new = ok ? ssko_pg_cost(n_edges, edge_ij, edge_z, Xn) : cost;
+		double pred = 0;                                     /* d.(lambda d - g): the decrease the linear model predicts */
+		if (ok) for (size_t k = 0; k < 6 * n; ++k) pred += d[k] * (lambda * d[k] - g[k]);
 		const int acc = ok && cost_new < cost;
 		const int converged = ok && P->converged_rel_decrease > 0 && fabs(cost - cost_new) <= P->converged_rel_decrease * cost;
 		++iters;
 		if (acc) {
 			memcpy(X, Xn, sizeof(double) * 12 * n);
-			cost = cost_new; lambda *= 0.1; nu = 2.0; ++accepted;
+			const double rho = pred > 0 ? (cost - cost_new) / pred : 1.0, c3 = 2.0 * rho - 1.0;
+			const double f = 1.0 - c3 * c3 * c3;
+			cost = cost_new; lambda *= f > 1.0 / 3.0 ? f : 1.0 / 3.0; nu = 2.0; ++accepted;
 			if (converged) stop = 4;
 		} else if (converged) {
 			stop = 4;
@@ -249,6 +349,7 @@ int ssko_pg_optimize(int n_nodes, double* X, int n_edges, const int32_t* edge_ij
 		(void)dn2;
 	}
 	out->iters = iters; out->accepted = accepted; out->stop_reason = stop; out->cost_final = cost; out->lambda_final = lambda;
-	free(e); free(M); free(D); free(Lb); free(g); free(d); free(r); free(z); free(p); free(q); free(Xn);
+	free(e); free(M); free(D); free(Lb); free(g); free(d); free(r); free(z); free(p); free(q); free(Xn); free(S); free(yv);
+	tree_free(&T);
 	return 0;
 }

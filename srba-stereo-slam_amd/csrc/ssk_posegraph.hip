@@ -1,7 +1,8 @@
 // ssk_posegraph.hip -- the global pose-graph optimisation the reference runs once after its frame loop:
 //   rba.get_global_graphslam_problem(poseGraph); mrpt::graphslam::optimize_graph_spa_levmarq(poseGraph, ...)   (EST.cpp:945-957)
 // Contract G1-G6: oracle/oracle_posegraph.c.  Levenberg-Marquardt on e = (t_E, log R_E), E = Z^-1 X_i^-1 X_j, unit
-// information; the step comes from conjugate gradients preconditioned with the 6x6 diagonal blocks.
+// information; the step comes from conjugate gradients preconditioned with the spanning-tree part of the system (block LDL^T on a
+// tree has no fill: children before parents, level by level).
 //
 // One persistent 1024-thread workgroup runs the whole optimisation (a keyframe graph has a few thousand nodes and about as
 // many edges; the state, ~1 KB per node, stays in L2): every phase is a loop over edges or over nodes, a node gathers its
@@ -19,6 +20,11 @@ struct pg_dev {
 	int n, m, fixed;
 	double *X, *Xn, *e, *M, *ge, *D, *Lb, *g, *d, *r, *z, *p, *q;
 	const int32_t *edge_ij, *inc_off, *inc;
+	// spanning tree (breadth-first from the fixed node): free nodes by level, parents before children; per node its parent
+	// (-1: none / the fixed node), the edge to it, and its children (descending breadth-first position: the oracle's order)
+	int n_lvl;
+	const int32_t *lvl_off, *order, *par, *par_e, *ch_off, *ch;
+	double *S, *y;
 	const double* Z;
 	ssk_pg_result* res;
 };
@@ -146,6 +152,105 @@ __device__ __forceinline__ void chol6_solve(const double* L, const double* b, do
 	for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s / L[6 * i + i]; }
 }
 
+__device__ __forceinline__ void mat6_vec(const double* __restrict__ A, const double* x, double* y)
+{
+#pragma unroll
+	for (int a = 0; a < 6; ++a) {
+		double s = 0;
+#pragma unroll
+		for (int b = 0; b < 6; ++b) s += A[6 * a + b] * x[b];
+		y[a] = s;
+	}
+}
+
+// G6: S_k = D_k + lambda I - sum over children c of M_e S_c^-1 M_e, Cholesky factors into Lb; levels from the deepest up.
+// Returns through *s_ok (cleared when a block is not positive definite).
+__device__ void tree_factor(const pg_dev& G, double lambda, int* s_ok)
+{
+	for (int lvl = G.n_lvl - 1; lvl >= 0; --lvl) {
+		for (int idx = G.lvl_off[lvl] + threadIdx.x; idx < G.lvl_off[lvl + 1]; idx += PG_NT) {
+			const int k = G.order[idx];
+			double Sk[36];
+#pragma unroll
+			for (int i = 0; i < 36; ++i) Sk[i] = G.D[36 * (size_t)k + i];
+#pragma unroll
+			for (int a = 0; a < 6; ++a) Sk[7 * a] += lambda;
+			for (int t = G.ch_off[k]; t < G.ch_off[k + 1]; ++t) {
+				const int c = G.ch[t];
+				const double* Me = G.M + 36 * (size_t)G.par_e[c];
+				const double* Lc = G.Lb + 36 * (size_t)c;
+				for (int col = 0; col < 6; ++col) {
+					double mc[6], x[6], yv[6];
+#pragma unroll
+					for (int a = 0; a < 6; ++a) mc[a] = Me[6 * a + col];
+					chol6_solve(Lc, mc, x);
+					mat6_vec(Me, x, yv);
+#pragma unroll
+					for (int a = 0; a < 6; ++a) Sk[6 * a + col] -= yv[a];
+				}
+			}
+			bool ok = true;
+#pragma unroll
+			for (int j = 0; j < 6; ++j) {
+				double dj = Sk[6 * j + j];
+				for (int c = 0; c < j; ++c) dj -= Sk[6 * j + c] * Sk[6 * j + c];
+				if (!(dj > 0.0)) { ok = false; dj = 1.0; }
+				const double l = sqrt(dj);
+				Sk[6 * j + j] = l;
+				for (int i = j + 1; i < 6; ++i) {
+					double sv = Sk[6 * i + j];
+					for (int c = 0; c < j; ++c) sv -= Sk[6 * i + c] * Sk[6 * j + c];
+					Sk[6 * i + j] = sv / l;
+				}
+			}
+			if (!ok) *s_ok = 0;
+#pragma unroll
+			for (int i = 0; i < 36; ++i) G.Lb[36 * (size_t)k + i] = Sk[i];
+		}
+		__syncthreads();
+	}
+}
+
+// z = M^-1 r on the free nodes (z of the fixed node must be 0 on entry and stays 0); y: work vector
+__device__ void tree_apply(const pg_dev& G, const double* __restrict__ r, double* __restrict__ z)
+{
+	for (int lvl = G.n_lvl - 1; lvl >= 0; --lvl) {          // forward: y_k = r_k + sum_c M_e t_c, t_k = S_k^-1 y_k
+		for (int idx = G.lvl_off[lvl] + threadIdx.x; idx < G.lvl_off[lvl + 1]; idx += PG_NT) {
+			const int k = G.order[idx];
+			double yk[6], tk[6];
+#pragma unroll
+			for (int a = 0; a < 6; ++a) yk[a] = r[6 * (size_t)k + a];
+			for (int t = G.ch_off[k]; t < G.ch_off[k + 1]; ++t) {
+				const int c = G.ch[t];
+				double tc[6], u[6];
+#pragma unroll
+				for (int a = 0; a < 6; ++a) tc[a] = z[6 * (size_t)c + a];
+				mat6_vec(G.M + 36 * (size_t)G.par_e[c], tc, u);
+#pragma unroll
+				for (int a = 0; a < 6; ++a) yk[a] += u[a];
+			}
+			chol6_solve(G.Lb + 36 * (size_t)k, yk, tk);
+#pragma unroll
+			for (int a = 0; a < 6; ++a) z[6 * (size_t)k + a] = tk[a];
+		}
+		__syncthreads();
+	}
+	for (int lvl = 1; lvl < G.n_lvl; ++lvl) {               // backward: z_k = t_k + S_k^-1 M_e z_p (level 0 has no free parent)
+		for (int idx = G.lvl_off[lvl] + threadIdx.x; idx < G.lvl_off[lvl + 1]; idx += PG_NT) {
+			const int k = G.order[idx], p = G.par[k];
+			if (p < 0) continue;
+			double zp[6], u[6], v[6];
+#pragma unroll
+			for (int a = 0; a < 6; ++a) zp[a] = z[6 * (size_t)p + a];
+			mat6_vec(G.M + 36 * (size_t)G.par_e[k], zp, u);
+			chol6_solve(G.Lb + 36 * (size_t)k, u, v);
+#pragma unroll
+			for (int a = 0; a < 6; ++a) z[6 * (size_t)k + a] += v[a];
+		}
+		__syncthreads();
+	}
+}
+
 __global__ __launch_bounds__(PG_NT)
 void pg_solve_kernel(pg_dev G, ssk_pg_params P)
 {
@@ -210,46 +315,13 @@ void pg_solve_kernel(pg_dev G, ssk_pg_params P)
 		if (tid == 0) { if (s_lambda < 0) s_lambda = P.tau * mx; s_ok = 1; }
 		__syncthreads();
 		const double lambda = s_lambda;
-		// ---- G6: preconditioner, then CG on (H + lambda I) d = -g over the free nodes ----
+		// ---- G6: tree preconditioner, then CG on (H + lambda I) d = -g over the free nodes ----
+		tree_factor(G, lambda, &s_ok);
+		for (int k = tid; k < 6 * G.n; k += PG_NT) { G.d[k] = 0; G.z[k] = 0; G.r[k] = (k / 6 == G.fixed) ? 0.0 : -G.g[k]; }
+		__syncthreads();
+		tree_apply(G, G.r, G.z);
 		double rz_l = 0;
-		for (int k = tid; k < G.n; k += PG_NT) {
-			double r6[6], z6[6] = {0, 0, 0, 0, 0, 0};
-			if (k != G.fixed) {
-				double L[36];
-#pragma unroll
-				for (int i = 0; i < 36; ++i) L[i] = G.D[36 * (size_t)k + i];
-#pragma unroll
-				for (int a = 0; a < 6; ++a) L[7 * a] += lambda;
-				bool ok = true;
-#pragma unroll
-				for (int j = 0; j < 6; ++j) {
-					double dj = L[6 * j + j];
-					for (int c = 0; c < j; ++c) dj -= L[6 * j + c] * L[6 * j + c];
-					if (!(dj > 0.0)) { ok = false; dj = 1.0; }
-					const double l = sqrt(dj);
-					L[6 * j + j] = l;
-					for (int i = j + 1; i < 6; ++i) {
-						double s = L[6 * i + j];
-						for (int c = 0; c < j; ++c) s -= L[6 * i + c] * L[6 * j + c];
-						L[6 * i + j] = s / l;
-					}
-				}
-				if (!ok) s_ok = 0;
-#pragma unroll
-				for (int i = 0; i < 36; ++i) G.Lb[36 * (size_t)k + i] = L[i];
-#pragma unroll
-				for (int a = 0; a < 6; ++a) r6[a] = -G.g[6 * (size_t)k + a];
-				chol6_solve(L, r6, z6);
-			} else {
-#pragma unroll
-				for (int a = 0; a < 6; ++a) r6[a] = 0;
-			}
-#pragma unroll
-			for (int a = 0; a < 6; ++a) {
-				G.d[6 * (size_t)k + a] = 0; G.r[6 * (size_t)k + a] = r6[a]; G.z[6 * (size_t)k + a] = z6[a]; G.p[6 * (size_t)k + a] = z6[a];
-				rz_l += r6[a] * z6[a];
-			}
-		}
+		for (int k = tid; k < 6 * G.n; k += PG_NT) { const double zv = G.z[k]; G.p[k] = zv; rz_l += G.r[k] * zv; }
 		double rz = pg_block_sum(rz_l, s_part);
 		const double rz0 = rz;
 		const bool ok = s_ok != 0;
@@ -294,19 +366,11 @@ void pg_solve_kernel(pg_dev G, ssk_pg_params P)
 				const double pq = pg_block_sum(pq_l, s_part);
 				if (!(pq > 0)) break;
 				const double alpha = rz / pq;
+				for (int k = tid; k < 6 * G.n; k += PG_NT) { G.d[k] += alpha * G.p[k]; G.r[k] -= alpha * G.q[k]; }
+				__syncthreads();
+				tree_apply(G, G.r, G.z);
 				double rzn_l = 0;
-				for (int k = tid; k < G.n; k += PG_NT) {
-					double r6[6], z6[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-					for (int a = 0; a < 6; ++a) {
-						G.d[6 * (size_t)k + a] += alpha * G.p[6 * (size_t)k + a];
-						r6[a] = G.r[6 * (size_t)k + a] - alpha * G.q[6 * (size_t)k + a];
-						G.r[6 * (size_t)k + a] = r6[a];
-					}
-					if (k != G.fixed) chol6_solve(G.Lb + 36 * (size_t)k, r6, z6);
-#pragma unroll
-					for (int a = 0; a < 6; ++a) { G.z[6 * (size_t)k + a] = z6[a]; rzn_l += r6[a] * z6[a]; }
-				}
+				for (int k = tid; k < 6 * G.n; k += PG_NT) rzn_l += G.r[k] * G.z[k];
 				const double rz_new = pg_block_sum(rzn_l, s_part);
 				const double beta = rz_new / rz;
 				for (int k = tid; k < 6 * G.n; k += PG_NT) G.p[k] = G.z[k] + beta * G.p[k];
@@ -331,6 +395,9 @@ void pg_solve_kernel(pg_dev G, ssk_pg_params P)
 			__syncthreads();
 		}
 		const double cost_new = ok ? pg_cost(G, G.Xn, s_part) : s_cost;
+		double pred_l = 0;                                  // d.(lambda d - g): the decrease the linear model predicts
+		if (ok) for (int k = tid; k < 6 * G.n; k += PG_NT) pred_l += G.d[k] * (lambda * G.d[k] - G.g[k]);
+		const double pred = pg_block_sum(pred_l, s_part);
 		__syncthreads();
 		if (tid == 0) {
 			const double cost = s_cost;
@@ -339,7 +406,9 @@ void pg_solve_kernel(pg_dev G, ssk_pg_params P)
 			s_iters += 1; s_cg += cg_it;
 			s_run = acc;
 			if (acc) {
-				s_cost = cost_new; s_lambda = lambda * 0.1; s_nu = 2.0; s_accepted += 1;
+				const double rho = pred > 0 ? (cost - cost_new) / pred : 1.0, c3 = 2.0 * rho - 1.0;
+				const double f = 1.0 - c3 * c3 * c3;
+				s_cost = cost_new; s_lambda = lambda * (f > 1.0 / 3.0 ? f : 1.0 / 3.0); s_nu = 2.0; s_accepted += 1;
 				if (converged) s_stop = 4;
 			} else if (converged) {
 				s_stop = 4;
@@ -391,10 +460,50 @@ extern "C" int ssk_posegraph_optimize(ssk_ctx* ctx, int n_nodes, double* node_po
 			inc[(size_t)cur[(size_t)edge_ij[2 * k + 1]]++] = (int32_t)(k << 1 | 1);
 		}
 	}
+	// breadth-first spanning tree from the fixed node (nodes and incident edges in ascending order); unreached nodes start
+	// their own trees.  Levels: depth in the forest of FREE nodes (children of the fixed node are level 0).
+	std::vector<int32_t> order, lvl_off, par(n, -1), par_e(n, -1), depth(n, -1), ch_off(n + 1, 0), ch;
+	{
+		std::vector<char> seen(n, 0);
+		std::vector<int32_t> queue;
+		queue.reserve(n);
+		for (int start = -1; start < n_nodes; ++start) {
+			const int root = start < 0 ? fixed_node : start;
+			if (seen[(size_t)root]) continue;
+			size_t qh = queue.size();
+			queue.push_back(root); seen[(size_t)root] = 1;
+			if (root != fixed_node) { order.push_back(root); depth[(size_t)root] = 0; }
+			while (qh < queue.size()) {
+				const int u = queue[qh++];
+				for (int t = off[(size_t)u]; t < off[(size_t)u + 1]; ++t) {
+					const int ed = inc[(size_t)t] >> 1, v = edge_ij[2 * ed] == u ? edge_ij[2 * ed + 1] : edge_ij[2 * ed];
+					if (seen[(size_t)v]) continue;
+					seen[(size_t)v] = 1; queue.push_back(v);
+					order.push_back(v);
+					if (u != fixed_node) { par[(size_t)v] = u; par_e[(size_t)v] = ed; depth[(size_t)v] = depth[(size_t)u] + 1; }
+					else depth[(size_t)v] = 0;
+				}
+			}
+		}
+		// several trees interleave depths in `order`: sort by depth, keeping the breadth-first order inside a level
+		std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return depth[(size_t)a] < depth[(size_t)b]; });
+		int n_lvl = 0;
+		for (int32_t k : order) n_lvl = std::max(n_lvl, depth[(size_t)k] + 1);
+		lvl_off.assign((size_t)n_lvl + 1, 0);
+		for (int32_t k : order) lvl_off[(size_t)depth[(size_t)k] + 1]++;
+		for (int l = 0; l < n_lvl; ++l) lvl_off[(size_t)l + 1] += lvl_off[(size_t)l];
+		// children of a node in DESCENDING position of `order` (the oracle walks the order backwards)
+		for (int32_t k : order) if (par[(size_t)k] >= 0) ch_off[(size_t)par[(size_t)k] + 1]++;
+		for (size_t k = 0; k < n; ++k) ch_off[k + 1] += ch_off[k];
+		ch.assign((size_t)ch_off[n] + 1, 0);
+		std::vector<int32_t> cur(ch_off.begin(), ch_off.end() - 1);
+		for (size_t t = order.size(); t-- > 0;) { const int32_t k = order[t]; if (par[(size_t)k] >= 0) ch[(size_t)cur[(size_t)par[(size_t)k]]++] = k; }
+	}
+	const int n_lvl = (int)lvl_off.size() - 1;
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	const size_t m1 = m ? m : 1;
-	const size_t dbl = 12 * n * 2 + 6 * m1 + 36 * m1 + 6 * m1 + 36 * n * 2 + 6 * n * 6 + 12 * m1;
-	const size_t bytes = ssk_pad(dbl * 8) + ssk_pad(2 * m1 * 4) + ssk_pad((n + 1) * 4) + ssk_pad((2 * m + 1) * 4) + ssk_pad(sizeof(ssk_pg_result)) + 16 * 256;
+	const size_t dbl = 12 * n * 2 + 6 * m1 + 36 * m1 + 6 * m1 + 36 * n * 3 + 6 * n * 7 + 12 * m1;
+	const size_t bytes = ssk_pad(dbl * 8) + ssk_pad(2 * m1 * 4) + ssk_pad((n + 1) * 4) * 6 + ssk_pad((2 * m + 1) * 4) + ssk_pad(sizeof(ssk_pg_result)) + 32 * 256;
 	int rc;
 	if ((rc = ssk_arena_reserve(ctx, ctx->dev, bytes))) return rc;
 	ssk_arena_reset(ctx->dev);
@@ -411,6 +520,20 @@ extern "C" int ssk_posegraph_optimize(ssk_ctx* ctx, int n_nodes, double* node_po
 	int32_t* d_inc = ssk_arena_take<int32_t>(ctx->dev, 2 * m + 1);
 	G.res = ssk_arena_take<ssk_pg_result>(ctx->dev, 1);
 	G.Z = d_Z; G.edge_ij = d_ij; G.inc_off = d_off; G.inc = d_inc;
+	G.S = ssk_arena_take<double>(ctx->dev, 36 * n); G.y = ssk_arena_take<double>(ctx->dev, 6 * n);
+	int32_t* d_lvl = ssk_arena_take<int32_t>(ctx->dev, n + 1);
+	int32_t* d_order = ssk_arena_take<int32_t>(ctx->dev, n + 1);
+	int32_t* d_par = ssk_arena_take<int32_t>(ctx->dev, n + 1);
+	int32_t* d_pare = ssk_arena_take<int32_t>(ctx->dev, n + 1);
+	int32_t* d_choff = ssk_arena_take<int32_t>(ctx->dev, n + 1);
+	int32_t* d_ch = ssk_arena_take<int32_t>(ctx->dev, n + 1);
+	G.n_lvl = n_lvl; G.lvl_off = d_lvl; G.order = d_order; G.par = d_par; G.par_e = d_pare; G.ch_off = d_choff; G.ch = d_ch;
+	SSK_HIP(ctx, hipMemcpyAsync(d_lvl, lvl_off.data(), lvl_off.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+	if (!order.empty()) SSK_HIP(ctx, hipMemcpyAsync(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_par, par.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_pare, par_e.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_choff, ch_off.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(d_ch, ch.data(), ch.size() * 4, hipMemcpyHostToDevice, ctx->stream));
 	SSK_HIP(ctx, hipMemcpyAsync(G.X, node_poses, 12 * n * 8, hipMemcpyHostToDevice, ctx->stream));
 	if (m) {
 		SSK_HIP(ctx, hipMemcpyAsync(d_Z, edge_z, 12 * m * 8, hipMemcpyHostToDevice, ctx->stream));
