@@ -21,6 +21,7 @@ struct ssk_lm_batch {
 	size_t n_pose = 0, n_lm = 0;      // doubles in pose / lm families
 	bool tiled_ok = false;            // every window fits the LDS-tiled kernel
 	int max_tiles = 0;                // most tiles of a window (cooperative kernel: workgroups per window)
+	bool has_general = false;         // the general kernel's structures were built too
 	size_t tiled_dyn_bytes = 0;       // its dynamic LDS size
 };
 
@@ -230,7 +231,10 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 	delete b;
 }
 
-int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out)
+// with_general: also build what only the general scratch-in-L2 kernel reads (the q entries with their co-observation lists,
+// the chunk lists, its scratch arrays).  The first attempt leaves them out; a batch with a window the tiler cannot take (or
+// SSK_LM_KERNEL=l2) is built again with them.
+static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out, bool with_general)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!windows || n_windows < 1 || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: bad argument");
@@ -335,6 +339,12 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		const int n_lme = (int)w_lme_edge.size();
 		// q entries: per landmark, pairs of its lme entries (edge slots ascending), then sorted pid-major
 		auto pid_of = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
+		const int n_pairs = E * (E + 1) / 2;
+		int n_q = 0;
+		std::vector<int> w_q_off((size_t)n_pairs + 1, 0), w_qo_off;
+		std::vector<int2> w_q_mm, w_qo;
+		std::vector<int> w_q_uend((size_t)n_pairs + 1, 0);
+		if (with_general) {
 		struct qrec { int pid, lm_order, mi, mj; };
 		std::vector<qrec> qs;
 		for (size_t oi = 0; oi < order.size(); ++oi)
@@ -342,10 +352,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 				for (size_t j = i; j < lm_lmes[oi].size(); ++j)
 					qs.push_back({pid_of(w_lme_edge[lm_lmes[oi][i]], w_lme_edge[lm_lmes[oi][j]]), (int)oi, lm_lmes[oi][i], lm_lmes[oi][j]});
 		std::stable_sort(qs.begin(), qs.end(), [](const qrec& a, const qrec& b) { return a.pid != b.pid ? a.pid < b.pid : a.lm_order < b.lm_order; });
-		const int n_pairs = E * (E + 1) / 2, n_q = (int)qs.size();
-		std::vector<int> w_q_off((size_t)n_pairs + 1, 0), w_qo_off;
-		std::vector<int2> w_q_mm, w_qo;
-		std::vector<int> w_q_uend((size_t)n_pairs + 1, 0);
+		n_q = (int)qs.size();
 		for (const qrec& r : qs) { w_q_off[r.pid + 1]++; if (r.lm_order < L) w_q_uend[r.pid]++; }
 		for (int p = 0; p < n_pairs; ++p) w_q_off[p + 1] += w_q_off[p];
 		for (int p = 0; p < n_pairs; ++p) w_q_uend[p] += w_q_off[p];     // optimised landmarks sort first inside a block
@@ -362,13 +369,14 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 			}
 		}
 		w_qo_off.push_back((int)w_qo.size());
+		} else w_qo_off.push_back(0);
 		std::vector<std::vector<int>> edge_lmes((size_t)E);
 		for (int m = 0; m < n_lme; ++m) edge_lmes[w_lme_edge[m]].push_back(m);
 		// chunks of <= 64 items of one block: H_pp over the q entries with co-observations, Schur over the q
 		// entries of optimised landmarks (which sort first inside a block)
 		std::vector<int> w_qp_q, w_pc_off((size_t)n_pairs + 1, 0), w_sc_off((size_t)n_pairs + 1, 0);
 		std::vector<int3> w_pchunk, w_schunk;
-		for (int p = 0; p < n_pairs; ++p) {
+		for (int p = 0; with_general && p < n_pairs; ++p) {
 			w_pc_off[p] = (int)w_pchunk.size();
 			const int first = (int)w_qp_q.size();
 			for (int q = w_q_off[p]; q < w_q_off[p + 1]; ++q) if (w_qo_off[q + 1] > w_qo_off[q]) w_qp_q.push_back(q);
@@ -628,8 +636,10 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		inc_rec.insert(inc_rec.end(), w_inc_rec.begin(), w_inc_rec.end());
 	}
 
+	if (!tiled_all && !with_general) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, true);
 	const auto t_sym = std::chrono::steady_clock::now();
 	ssk_lm_batch* b = new ssk_lm_batch();
+	b->has_general = with_general;
 	b->ctx = ctx; b->n_windows = n_windows; b->trace = trace; b->max_iters_alloc = MAX_ITERS_ALLOC; b->max_n6 = max_n6;
 	b->hdr = hdr; b->n_pose = pose.size(); b->n_lm = lm.size();
 	lm_dev& D = b->D;
@@ -658,15 +668,15 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	const size_t n_lme = lme_edge.size();
 	if (!rc) rc = scratch(b, pose.size(), &D.pose_new);
 	if (!rc) rc = scratch(b, lm.size(), &D.lm_new);
-	if (!rc) rc = scratch(b, 4 * n_obs, &D.obs_r);
-	if (!rc) rc = scratch(b, 12 * n_obs, &D.obs_Jf);
-	if (!rc) rc = scratch(b, 3 * n_path, &D.path_q);
-	if (!rc) rc = scratch(b, 24 * n_path, &D.path_Je);
-	if (!rc) rc = scratch(b, 9 * n_ls, &D.Hff);
+	if (!rc) rc = scratch(b, with_general ? 4 * n_obs : 0, &D.obs_r);
+	if (!rc) rc = scratch(b, with_general ? 12 * n_obs : 0, &D.obs_Jf);
+	if (!rc) rc = scratch(b, with_general ? 3 * n_path : 0, &D.path_q);
+	if (!rc) rc = scratch(b, with_general ? 24 * n_path : 0, &D.path_Je);
+	if (!rc) rc = scratch(b, 9 * n_ls, &D.Hff);     // (the tiled kernel stores the landmark blocks here for the shared-landmark exchange)
 	if (!rc) rc = scratch(b, 9 * n_ls, &D.Vinv);
 	if (!rc) rc = scratch(b, 3 * n_ls, &D.gf);
 	if (!rc) rc = scratch(b, 3 * n_ls, &D.df);
-	if (!rc) rc = scratch(b, 18 * n_lme, &D.Wb);
+	if (!rc) rc = scratch(b, with_general ? 18 * n_lme : 0, &D.Wb);
 	if (!rc) rc = scratch(b, 18 * n_lme, &D.Tb);
 	if (!rc) rc = scratch(b, 6 * n_lme, &D.gpe);
 	if (!rc) rc = scratch(b, 6 * n_lme, &D.gre);
@@ -674,7 +684,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	if (!rc) rc = scratch(b, 36 * schunk.size(), &D.Spart);
 	if (!rc) rc = scratch(b, 36 * n_pslots_total, &D.Ppart2);
 	if (!rc) rc = scratch(b, 36 * n_sslots_total, &D.Spart2);
-	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hpair);
+	if (!rc) rc = scratch(b, with_general ? (size_t)h_total : 0, &D.Hpair);
 	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hred);
 	if (!rc) rc = scratch(b, 6 * n_us, &D.dp);
 	if (!rc) rc = scratch(b, (size_t)n_windows, &D.res);
@@ -694,6 +704,12 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	}
 	*out = b;
 	return SSK_OK;
+}
+
+int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out)
+{
+	const char* force = std::getenv("SSK_LM_KERNEL");
+	return lm_batch_create_impl(ctx, windows, n_windows, trace, out, force && std::strcmp(force, "l2") == 0);
 }
 
 int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b)
@@ -728,7 +744,8 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 		const bool want = force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu);
 		if (want) return ssk_lm_launch_coop(ctx, b->D, P, b->n_windows, G, b->tiled_dyn_bytes);
 	}
-	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes);
+	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes);
+	if (!b->has_general) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: the batch was built without the general kernel's structures");
 	return ssk_lm_launch(ctx, b->D, P, b->n_windows, b->max_n6);
 }
 
