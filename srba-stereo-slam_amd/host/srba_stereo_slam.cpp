@@ -180,27 +180,47 @@ void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pa
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
 	const auto t0 = now();
-	std::map<TKeyFrameID, std::map<TKeyFrameID, step_t>> trees;
+	// per observing keyframe its depth-limited breadth-first tree, flattened: step towards the observer per keyframe id
+	// (edge == SIZE_MAX: not in the tree); the window is built once per keyframe over ~10^4 observations, so the lookups
+	// are arrays and hashes, not ordered maps
+	const size_t n_kf = num_keyframes();
+	std::map<TKeyFrameID, std::vector<step_t>> trees;
 	std::vector<int32_t> obs_lm, obs_path_off(1, 0), path_edge;
 	std::vector<float> obs_px;
-	std::map<size_t, int> edge_idx;
-	std::map<TLandmarkID, int> lm_idx;
+	std::vector<int> edge_idx(m_state.k2k_edges.size(), -1);
+	std::unordered_map<TLandmarkID, int> lm_idx;
 	std::vector<TLandmarkID> lm_ids;
 	std::vector<size_t> edge_ids;
-	auto edge_index = [&](size_t e) { auto it = edge_idx.find(e); if (it != edge_idx.end()) return it->second; const int i = (int)edge_ids.size(); edge_idx[e] = i; edge_ids.push_back(e); return i; };
+	auto edge_index = [&](size_t e) { if (edge_idx[e] >= 0) return edge_idx[e]; const int i = (int)edge_ids.size(); edge_idx[e] = i; edge_ids.push_back(e); return i; };
 	for (size_t e : opt_edges) edge_index(e);
+	obs_lm.reserve(obs_refs.size()); obs_px.reserve(4 * obs_refs.size()); path_edge.reserve(4 * obs_refs.size());
+	TKeyFrameID tree_kf = (TKeyFrameID)-1;
+	const std::vector<step_t>* tree_p = nullptr;
+	std::vector<int32_t> steps;
 	for (const auto& ref : obs_refs) {
 		const TKeyFrameID kf = ref.first;
 		const kf_observation_t& o = m_state.kf_observations[kf][ref.second];
 		const auto lit = m_state.unknown_lms.find(o.feat_id);
 		if (lit == m_state.unknown_lms.end()) continue;
-		if (!trees.count(kf)) bfs(kf, parameters.max_tree_depth, trees[kf]);
-		const auto& tree = trees[kf];
+		if (kf != tree_kf) {
+			auto it = trees.find(kf);
+			if (it == trees.end()) {
+				std::map<TKeyFrameID, step_t> t;
+				bfs(kf, parameters.max_tree_depth, t);
+				std::vector<step_t>& flat = trees[kf];
+				flat.assign(n_kf, step_t{0, (size_t)-1, 0});
+				for (const auto& kv : t) if (kv.first < n_kf) flat[kv.first] = kv.second;
+				flat[kf].edge = 0;                           // the root is in its own tree
+				it = trees.find(kf);
+			}
+			tree_kf = kf; tree_p = &it->second;
+		}
+		const std::vector<step_t>& tree = *tree_p;
 		const TKeyFrameID base = lit->second.base_kf;
-		if (!tree.count(base)) continue;                    // farther than max_tree_depth: not in the spanning tree
-		std::vector<int32_t> steps;                          // from the base back to the observer
+		if (base >= n_kf || tree[base].edge == (size_t)-1) continue;   // farther than max_tree_depth: not in the spanning tree
+		steps.clear();                                       // from the base back to the observer
 		for (TKeyFrameID cur = base; cur != kf;) {
-			const step_t& s = tree.at(cur);
+			const step_t& s = tree[cur];
 			const k2k_edge_t& e = m_state.k2k_edges[s.edge];
 			// step observer-side keyframe s.prev <- cur: inv_pose applies when cur == from and prev == to
 			steps.push_back(edge_index(s.edge) * 2 + ((e.from == cur && e.to == s.prev) ? 0 : 1));
@@ -209,8 +229,9 @@ void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pa
 		if (steps.size() > 8) continue;
 		path_edge.insert(path_edge.end(), steps.rbegin(), steps.rend());
 		obs_path_off.push_back((int32_t)path_edge.size());
-		if (!lm_idx.count(o.feat_id)) { lm_idx[o.feat_id] = (int)lm_ids.size(); lm_ids.push_back(o.feat_id); }
-		obs_lm.push_back(lm_idx[o.feat_id]);
+		const auto ins = lm_idx.emplace(o.feat_id, (int)lm_ids.size());
+		if (ins.second) lm_ids.push_back(o.feat_id);
+		obs_lm.push_back(ins.first->second);
 		obs_px.insert(obs_px.end(), o.px, o.px + 4);
 	}
 	std::vector<int32_t> edge_slot(edge_ids.size(), -1), lm_slot(lm_ids.size(), -1);

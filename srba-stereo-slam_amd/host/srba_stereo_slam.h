@@ -12,6 +12,7 @@
 #include <deque>
 #include <map>
 #include <set>
+#include <unordered_map>
 #include "srba_stereo_slam_options.h"
 
 namespace ssk {
@@ -78,7 +79,7 @@ public:
 
 	struct rba_state_t {
 		std::deque<k2k_edge_t> k2k_edges;
-		std::map<TLandmarkID, landmark_t> unknown_lms;
+		std::unordered_map<TLandmarkID, landmark_t> unknown_lms;   // looked up per observation: hashed (nothing iterates it in order)
 		std::vector<std::vector<kf_observation_t>> kf_observations;                // per keyframe
 	};
 	rba_state_t& get_rba_state() { return m_state; }
