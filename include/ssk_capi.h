@@ -417,7 +417,8 @@ typedef struct ssk_lm_params {
 typedef struct ssk_lm_result {
 	int32_t iters;                     /* solve attempts made (accepted + rejected) */
 	int32_t accepted;                  /* accepted steps */
-	int32_t stop_reason;               /* 0 max_iters, 1 error threshold, 2 max_lambda, 3 nothing to optimise, 4 converged */
+	int32_t stop_reason;               /* 0 max_iters, 1 error threshold, 2 max_lambda, 3 nothing to optimise, 4 converged,
+	                                      5 cooperative kernel aborted (barrier timeout; ssk_lm_batch_results reports an error) */
 	int32_t n_obs;
 	double err_init, err_final;        /* total (robustified) squared error: optimize_results.total_sqr_error_* (EST.cpp:179) */
 	double lambda_final;

@@ -756,6 +756,10 @@ int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out)
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	SSK_HIP(ctx, hipMemcpy(out, b->D.res, sizeof(ssk_lm_result) * (size_t)b->n_windows, hipMemcpyDeviceToHost));
+	for (int w = 0; w < b->n_windows; ++w)
+		if (out[w].stop_reason == 5)
+			return ssk_set_error(ctx, SSK_ERR_HIP, "ssk_lm_batch_results: window %d: the cooperative kernel's workgroups did not all arrive at a barrier "
+			                     "(not all resident? another kernel holding CUs) -- set SSK_LM_KERNEL=tiled", w);
 	return SSK_OK;
 }
 
