@@ -503,7 +503,7 @@ extern "C" int ssk_posegraph_optimize(ssk_ctx* ctx, int n_nodes, double* node_po
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	const size_t m1 = m ? m : 1;
 	const size_t dbl = 12 * n * 2 + 6 * m1 + 36 * m1 + 6 * m1 + 36 * n * 3 + 6 * n * 7 + 12 * m1;
-	const size_t bytes = ssk_pad(dbl * 8) + ssk_pad(2 * m1 * 4) + ssk_pad((n + 1) * 4) * 6 + ssk_pad((2 * m + 1) * 4) + ssk_pad(sizeof(ssk_pg_result)) + 32 * 256;
+	const size_t bytes = ssk_pad(dbl * 8) + ssk_pad(2 * m1 * 4) + ssk_pad((n + 1) * 4) * 8 + ssk_pad((2 * m + 1) * 4) + ssk_pad(sizeof(ssk_pg_result)) + 32 * 256;
 	int rc;
 	if ((rc = ssk_arena_reserve(ctx, ctx->dev, bytes))) return rc;
 	ssk_arena_reset(ctx->dev);
