@@ -81,6 +81,15 @@ def make_bow(oracle):
                         res_scores=res_scores, res_n=res_n, **{"v_" + k: np.asarray(val) for k, val in v.items()})
 
 
+def make_posegraph(oracle):
+    import synth_pg as sp
+    gph = sp.make_loop(31, n=48, edge_forward=False)
+    X, r = oracle.pg_optimize(gph["init"], gph["edge_ij"], gph["edge_z"])
+    np.savez_compressed(os.path.join(HERE, "posegraph_case0.npz"), init=gph["init"], edge_ij=gph["edge_ij"], edge_z=gph["edge_z"], exp_poses=X,
+                        exp_counts=np.array([r.iters, r.accepted, r.stop_reason, r.pcg_iters_total], np.int32),
+                        exp_cost=np.array([r.cost_init, r.cost_final]))
+
+
 if __name__ == "__main__":
     o = ol.load()
     make_da(o)
@@ -88,4 +97,5 @@ if __name__ == "__main__":
     make_cip(o)
     make_fmat(o)
     make_bow(o)
+    make_posegraph(o)
     print("golden fixtures written to", HERE)

@@ -64,3 +64,12 @@ def test_degenerate_inputs(oracle):
     g = sp.make_loop(4, n=8)
     X, r = oracle.pg_optimize(g["init"], g["edge_ij"], g["edge_z"], prm=ol.PgParams(max_iters=2))
     assert r.iters == 2 and r.stop_reason == 0
+
+
+def test_golden_fixture(oracle):
+    """tests/golden/posegraph_case0.npz (made by tests/golden/make_golden.py from this oracle): a 48-keyframe loop."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "posegraph_case0.npz"))
+    X, r = oracle.pg_optimize(g["init"], g["edge_ij"], g["edge_z"])
+    assert [r.iters, r.accepted, r.stop_reason, r.pcg_iters_total] == g["exp_counts"].tolist()
+    assert np.array_equal(X, g["exp_poses"]) and [r.cost_init, r.cost_final] == g["exp_cost"].tolist()

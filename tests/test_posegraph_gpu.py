@@ -75,3 +75,13 @@ def test_tree_and_degenerate_graphs(ctx, oracle):
     Xa, ra = ctx.posegraph_optimize(g2["init"], g2["edge_ij"], g2["edge_z"], fixed=0)
     Xb, rb = ctx.posegraph_optimize(g2["init"], g2["edge_ij"], g2["edge_z"], fixed=17)
     assert np.array_equal(Xb[17], g2["init"][17]) and abs(ra.cost_final - rb.cost_final) <= 1e-5 * ra.cost_final
+
+
+def test_golden_fixture(ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "posegraph_case0.npz"))
+    X, r = ctx.posegraph_optimize(g["init"], g["edge_ij"], g["edge_z"])
+    it, acc, stop, _cg = g["exp_counts"].tolist()
+    assert abs(r.iters - it) <= 2 and r.stop_reason == stop and abs(r.cost_final - g["exp_cost"][1]) <= 1e-6 * g["exp_cost"][1]
+    assert abs(r.cost_init - g["exp_cost"][0]) <= 1e-9 * g["exp_cost"][0]
+    assert np.abs(X - g["exp_poses"]).max() <= 2e-5 * np.abs(g["exp_poses"]).max()
