@@ -90,6 +90,31 @@ def make_posegraph(oracle):
                         exp_cost=np.array([r.cost_init, r.cost_final]))
 
 
+def make_bow_reference_subtree(oracle):
+    """A part of the vocabulary the reference ships (demo/voc.yml.gz, data): the subtrees of the root's first two children with
+    their real BRIEF centres and idf weights, words renumbered; plus oracle outputs on it.  Only where the file exists."""
+    import bow_vocab as bv
+    if not bv.have_reference_vocabulary():
+        return
+    v = bv.parse(bv.REF_VOC)
+    keep = {1, 2}
+    sel = []
+    for i, (n, p) in enumerate(zip(v["node_id"], v["parent_id"])):          # file order: parents before children
+        if int(n) in keep or int(p) in keep:
+            keep.add(int(n))
+            sel.append(i)
+    sel = np.array(sel)
+    old_words = {int(n): w for w, n in enumerate(v["word_node"])}
+    word_node = np.array([int(v["node_id"][i]) for i in sel if int(v["node_id"][i]) in old_words], np.int32)
+    sub = dict(k=v["k"], L=v["L"], scoring=v["scoring"], weighting=v["weighting"], node_id=v["node_id"][sel], parent_id=v["parent_id"][sel],
+               weight=v["weight"][sel], desc=v["desc"][sel], word_node=word_node)
+    V = oracle.bow_vocab(sub)
+    rng = np.random.default_rng(41)
+    f = bv.keyframe_descriptors(sub, rng, n=400, noise=20)
+    w, x = V.transform(f)
+    np.savez_compressed(os.path.join(HERE, "bow_refvoc_subtree.npz"), desc_in=f, exp_word=w, exp_val=x, **{"v_" + k: np.asarray(val) for k, val in sub.items()})
+
+
 if __name__ == "__main__":
     o = ol.load()
     make_da(o)
@@ -98,4 +123,5 @@ if __name__ == "__main__":
     make_fmat(o)
     make_bow(o)
     make_posegraph(o)
+    make_bow_reference_subtree(o)
     print("golden fixtures written to", HERE)

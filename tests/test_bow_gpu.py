@@ -175,3 +175,24 @@ def test_reference_vocabulary(pkg, ctx, oracle):
     G, O = both(pkg, ctx, oracle, v)
     f = bv.keyframe_descriptors(v, np.random.default_rng(3), n=500, noise=20)
     assert all(np.array_equal(a, b) for a, b in zip(G.transform(f), O.transform(f)))
+
+
+def test_reference_vocabulary_subtree_fixture(pkg, ctx, oracle):
+    """Real DBoW2 centres and idf weights (a part of the reference's vocabulary file, tests/golden/bow_refvoc_subtree.npz): ragged
+    tree (2..8 children), stop words, five levels -- transform and query bit for bit."""
+    from ssk_amd import capi
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_refvoc_subtree.npz"))
+    v = {k[2:]: g[k] for k in g.files if k.startswith("v_")}
+    G, O = both(pkg, ctx, oracle, v)
+    gw, gx = G.transform(g["desc_in"])
+    assert np.array_equal(gw, g["exp_word"]) and np.array_equal(gx, g["exp_val"])
+    rng = np.random.default_rng(9)
+    gdb, odb = capi.BowDb(ctx, G, 16, 512), oracle.bow_db(O.n_words)
+    for f in bv.keyframe_sequence(v, rng, n_kf=12, n=400, noise=20):
+        a, b = G.transform(f)
+        oa, ob = O.transform(f)
+        assert np.array_equal(a, oa) and np.array_equal(b, ob)
+        gi, gs = gdb.query(a, b, 4)
+        oi, os_ = odb.query(oa, ob, 4)
+        assert np.array_equal(gi, oi) and np.array_equal(gs, os_)
+        gdb.add(a, b); odb.add(oa, ob)

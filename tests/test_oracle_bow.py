@@ -165,3 +165,17 @@ def test_reference_vocabulary_file():
     bw, bx = brute_transform(v, f[:60])
     assert np.array_equal(V.transform(f[:60])[0], bw) and np.array_equal(V.transform(f[:60])[1], bx)
     assert 0 < len(w) <= 500 and abs(x.sum() - 1) < 1e-12
+
+
+def test_reference_vocabulary_subtree_fixture():
+    """tests/golden/bow_refvoc_subtree.npz: the subtrees of the first two children of the root of the reference's vocabulary
+    file (real BRIEF centres and idf weights, 9 274 nodes / 8 105 words; data, made by make_golden.py) -- travels to the GPU box."""
+    o = oracle_lib.load()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bow_refvoc_subtree.npz"))
+    v = {k[2:]: g[k] for k in g.files if k.startswith("v_")}
+    assert int(v["k"]) == 8 and int(v["L"]) == 5 and len(v["node_id"]) == 9274
+    V = o.bow_vocab(v)
+    w, x = V.transform(g["desc_in"])
+    assert np.array_equal(w, g["exp_word"]) and np.array_equal(x, g["exp_val"])
+    bw, bx = brute_transform(v, g["desc_in"][:80])
+    assert all(np.array_equal(a, b) for a, b in zip(V.transform(g["desc_in"][:80]), (bw, bx)))
