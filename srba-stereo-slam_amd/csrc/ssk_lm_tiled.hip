@@ -372,7 +372,7 @@ __device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam
 // workgroup's tile region in LDS; `epoch`: tiles this workgroup has started (the landmark-record flag counts NW per tile);
 // partial sums go to the window's slot arrays Pp / Sp, Y / gradient terms / landmark factors to its HBM scratch.
 __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* pose_cur,
-                                             double* reg, double lambda, bool pre, int epoch, int* s_lmflag,
+                                             double* reg, double lambda, bool pre, bool same_state, int epoch, int* s_lmflag,
                                              double* __restrict__ Pp, double* __restrict__ Sp, double& vmax)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -504,8 +504,10 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
 			for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
 		}
+		// same_state: the previous pass linearised at this very state (the lambda0 pass, or a rejected step): its H_pp slots are
+		// still in place and bit-identical, only the lambda-dependent Schur terms are new
 		const int n_task = T.n_pc + (pre ? 0 : T.n_sc);
-		for (int task = wave; task < n_task; task += NW) {
+		for (int task = wave + (same_state ? T.n_pc : 0); task < n_task; task += NW) {
 			double acc[36];
 #pragma unroll
 			for (int i = 0; i < 36; ++i) acc[i] = 0.0;
@@ -590,6 +592,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	__shared__ double s_lambda, s_nu, s_err;
 	__shared__ int s_accept, s_stop, s_iters, s_accepted;
 	__shared__ int s_lmflag;                           // waves that have published their landmark records, all tiles so far
+	__shared__ int s_same;                             // the state has not moved since the previous pass's linearisation
 
 	const int wi = COOP ? (int)blockIdx.x / G : (int)blockIdx.x, g = COOP ? (int)blockIdx.x % G : 0, GG = COOP ? G : 1;
 	const lm_win W = D.win[wi];
@@ -633,7 +636,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	double e0 = total_error_packed(D, W, P, pose_cur, D.lm, s_part, tid + NT * g, NT * GG);
 	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
-		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_lmflag = 0;
+		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_lmflag = 0; s_same = 0;
 		if (g == 0) {
 			ssk_lm_result& R = D.res[wi];
 			R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
@@ -654,11 +657,12 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		if (W.n_obs > 0 && sqrt(s_err / W.n_obs) < P.stop_rmse) { if (tid == 0) s_stop = 1; break; }
 		const double lambda = s_lambda;
 		const bool pre = lambda < 0;                   // first pass of a solve: only the diagonals, for lambda0
+		const bool same_state = !pre && s_same != 0;   // (uniform)
 		const int it_idx = s_iters;
 		double vmax = 0.0;
 		STAMP(0);
 		for (int t = g; t < W.n_tiles; t += GG) {
-			process_tile(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, ++epoch, &s_lmflag, Pp, Sp, vmax);
+			process_tile(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, same_state, ++epoch, &s_lmflag, Pp, Sp, vmax);
 			STAMP(1);
 		}
 		if (COOP) {                                    // every workgroup's slots, Y, gradient terms and landmark factors are out
@@ -674,7 +678,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 				mx = fmax(mx, slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], 7 * a));
 			}
 			mx = block_max(mx, s_part);
-			if (tid == 0) s_lambda = P.tau * mx;
+			if (tid == 0) { s_lambda = P.tau * mx; s_same = 1; }
 			continue;
 		}
 		// ---- F2 + G: assemble and solve the reduced system; instantiated once for the LDS copy and once for the L2 copy so
@@ -784,6 +788,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			}
 			const int converged = ok && P.conv_rel > 0 && fabs(s_err - err_new) <= P.conv_rel * s_err;
 			s_accept = accepted;
+			s_same = !accepted;
 			s_iters = it_idx + 1;
 			if (accepted) {
 				s_err = err_new; s_lambda = lambda * 0.1; s_nu = 2.0; s_accepted += 1;
