@@ -402,7 +402,11 @@ def main():
                 line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(procs, max(32, args.cpu_sample // 2))
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        # RCCL writes its version banner through C stdio, which is flushed at exit when stdout is a pipe: push it out now
+        # so that the JSON line is the last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
     db.close(); voc.close(); lm.close(); cur.close(); prev.close()
     if ctx_side:
         ctx_side.close()
