@@ -36,7 +36,7 @@ def main():
     for k in sorted(set(fe) & set(wr)):
         kernels[k] = {"fetch_size_kb": round(fe[k][0] / fe[k][1], 2), "write_size_kb": round(wr[k][0] / wr[k][1], 2), "dispatches": fe[k][1]}
     cal = kernels.get("lm_reset_kernel")
-    out = {"batch": 256,
+    out = {"batch": int(os.environ.get("SSK_PMC_BATCH", "1024")),
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 (two separate passes), aggregated by tools/pmc_traffic.py",
            "units": "KB per dispatch, average over the dispatches of the run; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 on gfx950",
            "calibration": "lm_reset_kernel reads exactly the bytes it writes (coalesced 8 B/lane copy): FETCH_SIZE/WRITE_SIZE = %.3f, i.e. FETCH_SIZE tallies half the bytes, as MI355X_MICROARCH.md states for gfx950"
