@@ -1,0 +1,78 @@
+/*
+ * ssk_rba.h -- C-ABI of the relative-bundle-adjustment ENGINE behind seam B3: the calls the reference's estimator makes on
+ * its `rba` member (mySRBA : RbaEngine<...>, src/srba-stereo-slam.h:30-310), for callers that cannot include the C++ facade.
+ * Exported by libssk_facade.so (srba-stereo-slam_amd/host, built over libssk_hip.so; same conventions as ssk_capi.h: 0 = SSK_OK,
+ * otherwise an ssk_status code and ssk_rba_last_error has the text).  Graph bookkeeping (keyframes, k2k edges, landmarks, the
+ * fixed-size-submap edge_creation_policy of SRBA.h:144-308, spanning trees) is host code, as in SRBA itself; every
+ * Levenberg-Marquardt solve runs on the MI355X through ssk_lm_batch_* (there is no CPU solver behind this interface).
+ *
+ *   rba.parameters.* = ...                                   (EST.cpp:1149-1160)   ->  ssk_rba_create(options)
+ *   rba.setInitialKFPose(pose)                               (EST.cpp:772-778)     ->  ssk_rba_set_initial_kf_pose
+ *   rba.define_new_keyframe(listObs, newKFInfo, optimize)    (EST.cpp:166,782)     ->  ssk_rba_define_kf
+ *   rba.get_rba_state().k2k_edges[i] / .unknown_lms          (EST.cpp:1779, SRBA.h)->  ssk_rba_get_edge / ssk_rba_get_landmark
+ *   rba.create_complete_spanning_tree(root, tree, depth)     (EST.cpp:909-915)     ->  ssk_rba_spanning_tree_pose
+ *   rba.get_global_graphslam_problem + optimize_graph_spa_levmarq (EST.cpp:945-957)->  ssk_rba_global_poses (+ ssk_posegraph_optimize)
+ */
+#ifndef SSK_RBA_H
+#define SSK_RBA_H
+
+#include "ssk_capi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ssk_rba ssk_rba;
+
+typedef struct ssk_rba_options {
+	/* stereo camera (srba_options.stereo_camera, UTIL.h:366) and camera pose on the robot, row-major [R|t] (EST.cpp:1105-1112) */
+	double fx_l, fy_l, cx_l, cy_l, fx_r, fy_r, cx_r, cy_r, baseline;
+	double sensor_pose[12];
+	/* rba.parameters (EST.cpp:1149-1160; KITTI.ini:104-109) */
+	int32_t max_tree_depth, max_optimize_depth, submap_size;
+	int32_t min_obs_to_loop_closure;       /* SRBA's default 6 (never set by the reference, SRBA.h:166) */
+	int32_t use_robust_kernel, use_robust_kernel_stage1;
+	int32_t reserved;
+	double kernel_param;
+} ssk_rba_options;
+
+/* one entry of mySRBA::new_kf_observations_t (EST.cpp:137-160, 671-699): is_fixed = false, is_unknown_with_init_val = true */
+typedef struct ssk_rba_obs {
+	uint64_t feat_id;
+	float left_x, left_y, right_x, right_y;
+	double rel_pos[3];                     /* landmark in the new keyframe's robot frame (used when the id is new) */
+} ssk_rba_obs;
+
+#define SSK_RBA_MAX_NEW_EDGES 16
+typedef struct ssk_rba_kf_info {           /* TNewKeyFrameInfo, the fields the estimator reads (EST.cpp:178-180, 790, 847-849) */
+	int32_t kf_id, n_created_edges;
+	int32_t created_edge_ids[SSK_RBA_MAX_NEW_EDGES];
+	double total_sqr_error_init, total_sqr_error_final;    /* optimize_results */
+	double stg1_obs_rmse;                                  /* optimize_results_stg1.obs_rmse */
+	int32_t num_observations, num_iters;
+} ssk_rba_kf_info;
+
+int ssk_rba_create(ssk_ctx* ctx, const ssk_rba_options* options, ssk_rba** out);
+void ssk_rba_destroy(ssk_rba* r);
+const char* ssk_rba_last_error(const ssk_rba* r);
+int ssk_rba_set_initial_kf_pose(ssk_rba* r, const double pose[12]);
+/* Throws nothing: an edge-creation failure ("the node becomes isolated", SRBA.h:304) or a solver failure comes back as a code. */
+int ssk_rba_define_kf(ssk_rba* r, const ssk_rba_obs* obs, int n_obs, int run_local_optimization, ssk_rba_kf_info* out);
+int ssk_rba_num_keyframes(const ssk_rba* r);
+int ssk_rba_num_edges(const ssk_rba* r);
+int ssk_rba_num_landmarks(const ssk_rba* r);
+/* k2k edge: inv_pose = pose of keyframe `from` seen from keyframe `to` */
+int ssk_rba_get_edge(const ssk_rba* r, int edge, int32_t* from, int32_t* to, double inv_pose[12]);
+/* SSK_ERR_BAD_ARG when the id is unknown */
+int ssk_rba_get_landmark(const ssk_rba* r, uint64_t feat_id, int32_t* base_kf, double pos[3]);
+/* pose of `target` seen from `root` along the breadth-first tree of depth <= max_depth; *found = 0 when it is farther */
+int ssk_rba_spanning_tree_pose(const ssk_rba* r, int root, int target, int max_depth, double pose[12], int32_t* found);
+/* the global pose-graph problem (EST.cpp:946-947): node poses [n_keyframes][12] from keyframe `root`, one constraint per edge
+ * (edge_ij [n][2] = (to, from), edge_z [n][12] = inv_pose); capacities in, counts out; feed ssk_posegraph_optimize */
+int ssk_rba_global_poses(const ssk_rba* r, int root, double* node_poses, int node_cap, int32_t* edge_ij, double* edge_z, int edge_cap,
+                         int32_t* n_nodes, int32_t* n_edges);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

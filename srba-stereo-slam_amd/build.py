@@ -78,6 +78,9 @@ def build_host(verbose=True):
     host = os.path.join(HERE, "host")
     out = os.path.join(host, "facade_demo")
     srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith(".cpp") and not f.endswith("_tool.cpp")]
+    # libssk_facade.so: the facade classes + the C-ABI of the RBA engine (include/ssk_rba.h), for callers without C++
+    flib = os.path.join(HERE, "libssk_facade.so")
+    lsrcs = [f for f in srcs if not f.endswith("facade_demo.cpp")]
     hdrs = [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")]
     deps = srcs + hdrs + [LIB]
     # CPU-only drivers of host-side logic (no GPU library needed): keyframe record I/O (host/ssk_kf_io.h); keyframe policy
@@ -89,6 +92,14 @@ def build_host(verbose=True):
                                capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("%s build failed:\n%s" % (name, r.stderr))
+    if not os.path.exists(flib) or os.path.getmtime(flib) < max(os.path.getmtime(d) for d in lsrcs + hdrs + [LIB, os.path.join(ROOT, "include", "ssk_rba.h")]):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include")] + lsrcs + \
+              ["-L", HERE, "-lssk_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-o", flib]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("libssk_facade.so build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+        if verbose:
+            print("facade library: %s" % flib)
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
         return out
     cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")] + srcs + \

@@ -341,6 +341,118 @@ class PgResult(C.Structure):
                 ("cost_init", C.c_double), ("cost_final", C.c_double), ("lambda_final", C.c_double)]
 
 
+class RbaOptions(C.Structure):
+    """ssk_rba_options (include/ssk_rba.h); defaults = demo/config_imgdir_kitti_srba.ini."""
+    _fields_ = [(n, C.c_double) for n in ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")] + [
+        ("sensor_pose", C.c_double * 12), ("max_tree_depth", C.c_int32), ("max_optimize_depth", C.c_int32), ("submap_size", C.c_int32),
+        ("min_obs_to_loop_closure", C.c_int32), ("use_robust_kernel", C.c_int32), ("use_robust_kernel_stage1", C.c_int32),
+        ("reserved", C.c_int32), ("kernel_param", C.c_double)]
+
+    @classmethod
+    def kitti(cls, **over):
+        o = cls(707.0912, 707.0912, 601.8873, 183.1104, 707.0912, 707.0912, 601.8873, 183.1104, 0.54)
+        o.sensor_pose = (C.c_double * 12)(0, 0, 1, 0, -1, 0, 0, 0, 0, -1, 0, 0)        # camera z forward, x right, y down
+        o.max_tree_depth, o.max_optimize_depth, o.submap_size, o.min_obs_to_loop_closure = 4, 5, 10, 6
+        o.use_robust_kernel, o.use_robust_kernel_stage1, o.kernel_param = 1, 1, 1.5
+        for k, v in over.items():
+            setattr(o, k, v)
+        return o
+
+
+RBA_OBS_DTYPE = np.dtype([("feat_id", "<u8"), ("left_x", "<f4"), ("left_y", "<f4"), ("right_x", "<f4"), ("right_y", "<f4"), ("rel_pos", "<f8", 3)])
+
+
+class RbaKfInfo(C.Structure):
+    _fields_ = [("kf_id", C.c_int32), ("n_created_edges", C.c_int32), ("created_edge_ids", C.c_int32 * 16),
+                ("total_sqr_error_init", C.c_double), ("total_sqr_error_final", C.c_double), ("stg1_obs_rmse", C.c_double),
+                ("num_observations", C.c_int32), ("num_iters", C.c_int32)]
+
+
+_FLIB = None
+
+
+def load_facade_library():
+    """libssk_facade.so (C++ facade + the C-ABI of include/ssk_rba.h), on top of libssk_hip.so."""
+    global _FLIB
+    if _FLIB is None:
+        load_library()
+        p = os.path.join(HERE, "libssk_facade.so")
+        if not os.path.exists(p):
+            raise ImportError("libssk_facade.so is not built: run `python __graft_entry__.py build`")
+        _FLIB = C.CDLL(p)
+        _FLIB.ssk_rba_last_error.restype = C.c_char_p
+    return _FLIB
+
+
+class Rba:
+    """ssk_rba: the relative-BA engine behind rba.define_new_keyframe (include/ssk_rba.h)."""
+
+    def __init__(self, ctx, options):
+        self.ctx, self.lib = ctx, load_facade_library()
+        h = C.c_void_p()
+        rc = self.lib.ssk_rba_create(ctx.h, C.byref(options), C.byref(h))
+        if rc != 0:
+            raise SskError(rc, "ssk_rba_create failed")
+        self.h_ = h
+        _LIVE.add(self)
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.lib.ssk_rba_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SskError(rc, self.lib.ssk_rba_last_error(self.h_).decode() or self.ctx.lib.ssk_last_error(self.ctx.h).decode())
+
+    def set_initial_kf_pose(self, pose):
+        p = np.ascontiguousarray(pose, np.float64).reshape(12)
+        self._chk(self.lib.ssk_rba_set_initial_kf_pose(self.h_, _ptr(p)))
+
+    def define_kf(self, obs, optimize=True):
+        o = np.ascontiguousarray(obs, RBA_OBS_DTYPE)
+        info = RbaKfInfo()
+        self._chk(self.lib.ssk_rba_define_kf(self.h_, _ptr(o), len(o), int(optimize), C.byref(info)))
+        return info
+
+    def counts(self):
+        return self.lib.ssk_rba_num_keyframes(self.h_), self.lib.ssk_rba_num_edges(self.h_), self.lib.ssk_rba_num_landmarks(self.h_)
+
+    def edge(self, e):
+        f, t = C.c_int32(), C.c_int32()
+        p = np.zeros(12)
+        self._chk(self.lib.ssk_rba_get_edge(self.h_, int(e), C.byref(f), C.byref(t), _ptr(p)))
+        return f.value, t.value, p
+
+    def landmark(self, feat_id):
+        b = C.c_int32()
+        p = np.zeros(3)
+        self.lib.ssk_rba_get_landmark.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        rc = self.lib.ssk_rba_get_landmark(self.h_, int(feat_id), C.byref(b), _ptr(p))
+        return None if rc != 0 else (b.value, p)
+
+    def spanning_tree_pose(self, root, target, max_depth=1000):
+        p = np.zeros(12)
+        found = C.c_int32()
+        self._chk(self.lib.ssk_rba_spanning_tree_pose(self.h_, int(root), int(target), int(max_depth), _ptr(p), C.byref(found)))
+        return p if found.value else None
+
+    def global_poses(self, root=0):
+        nk, ne, _ = self.counts()
+        X = np.zeros((max(nk, 1), 12)); ij = np.zeros((max(ne, 1), 2), np.int32); z = np.zeros((max(ne, 1), 12))
+        nn, nm = C.c_int32(), C.c_int32()
+        self._chk(self.lib.ssk_rba_global_poses(self.h_, int(root), _ptr(X), len(X), _ptr(ij), _ptr(z), len(z), C.byref(nn), C.byref(nm)))
+        return X[:nn.value].copy(), ij[:nm.value].copy(), z[:nm.value].copy()
+
+
 class LmWindow(C.Structure):
     _fields_ = [("n_edges_total", C.c_int32), ("edge_unknown_slot", C.c_void_p), ("edge_inv_pose", C.c_void_p),
                 ("n_lms_total", C.c_int32), ("lm_unknown_slot", C.c_void_p), ("lm_pos", C.c_void_p),

@@ -95,7 +95,12 @@ public:
 		const int rc = ssk_create(&h_, device, hip_stream);
 		if (rc != SSK_OK) throw std::runtime_error(std::string("ssk_create: ") + ssk_last_error(nullptr));
 	}
-	~Context() { ssk_destroy(h_); }
+	// a view of a context somebody else owns (the C-ABI of the facade, include/ssk_rba.h)
+	explicit Context(ssk_ctx* borrowed) : h_(borrowed), owns_(false)
+	{
+		if (!borrowed) throw std::runtime_error("Context: NULL ssk_ctx");
+	}
+	~Context() { if (owns_) ssk_destroy(h_); }
 	Context(const Context&) = delete;
 	Context& operator=(const Context&) = delete;
 	ssk_ctx* get() const { return h_; }
@@ -105,6 +110,7 @@ public:
 	}
 private:
 	ssk_ctx* h_ = nullptr;
+	bool owns_ = true;
 };
 
 }  // namespace ssk
