@@ -453,6 +453,71 @@ class Rba:
         return X[:nn.value].copy(), ij[:nm.value].copy(), z[:nm.value].copy()
 
 
+class SlamFrameReport(C.Structure):
+    _fields_ = [("frame", C.c_int32), ("vo_valid", C.c_int32), ("tracked_from_last_frame", C.c_int32), ("tracked_from_last_kf", C.c_int32),
+                ("vo_pose", C.c_double * 12), ("checked_for_kf", C.c_int32), ("inserted_kf", C.c_int32), ("vo_force_new_kf", C.c_int32),
+                ("vo_force_check_tracking", C.c_int32), ("vo_force_check_distance", C.c_int32), ("potential_loop_closure", C.c_int32),
+                ("confirmed_loop_closure", C.c_int32), ("lc_kf_id", C.c_int32), ("n_query", C.c_int32), ("query_ids", C.c_int32 * 4),
+                ("query_scores", C.c_double * 4), ("n_similar", C.c_int32), ("similar_kfs", C.c_int32 * 8), ("highest_tracked", C.c_int32),
+                ("kf_id", C.c_int32), ("n_created_edges", C.c_int32), ("total_sqr_error_init", C.c_double), ("total_sqr_error_final", C.c_double),
+                ("n_keyframes", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Slam:
+    """ssk_slam: the estimator (include/ssk_slam.h): one call per stereo frame, the reference's whole loop behind it."""
+
+    def __init__(self, ctx, width, height, preset="kitti", **options):
+        self.ctx, self.lib = ctx, load_facade_library()
+        self.lib.ssk_slam_last_error.restype = C.c_char_p
+        self.lib.ssk_slam_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        h = C.c_void_p()
+        rc = self.lib.ssk_slam_create(ctx.h, preset.encode(), int(width), int(height), C.byref(h))
+        if rc != 0:
+            raise SskError(rc, "ssk_slam_create failed")
+        self.h_, self.w, self.hgt = h, width, height
+        _LIVE.add(self)
+        for k, v in options.items():
+            self._chk(self.lib.ssk_slam_set_option(self.h_, k.encode(), float(v)))
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.lib.ssk_slam_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SskError(rc, self.lib.ssk_slam_last_error(self.h_).decode() or self.ctx.lib.ssk_last_error(self.ctx.h).decode())
+
+    def load_vocabulary(self, path):
+        self._chk(self.lib.ssk_slam_load_vocabulary(self.h_, path.encode()))
+
+    def process_frame(self, left, right):
+        l = np.ascontiguousarray(left, np.uint8); r = np.ascontiguousarray(right, np.uint8)
+        assert l.shape == (self.hgt, self.w) and r.shape == (self.hgt, self.w)
+        rep = SlamFrameReport()
+        self._chk(self.lib.ssk_slam_process_frame(self.h_, _ptr(l), _ptr(r), self.w, C.byref(rep)))
+        return rep
+
+    def counts(self):
+        return self.lib.ssk_slam_num_keyframes(self.h_), self.lib.ssk_slam_num_edges(self.h_), self.lib.ssk_slam_num_landmarks(self.h_)
+
+    def optimize_pose_graph(self, path=None):
+        n = max(self.counts()[0], 1)
+        X = np.zeros((n, 12))
+        cnt = C.c_int32()
+        info = PgResult()
+        self._chk(self.lib.ssk_slam_optimize_pose_graph(self.h_, _ptr(X), n, C.byref(cnt), C.byref(info), path.encode() if path else None))
+        return X[:cnt.value].copy(), info
+
+
 class LmWindow(C.Structure):
     _fields_ = [("n_edges_total", C.c_int32), ("edge_unknown_slot", C.c_void_p), ("edge_inv_pose", C.c_void_p),
                 ("n_lms_total", C.c_int32), ("lm_unknown_slot", C.c_void_p), ("lm_pos", C.c_void_p),

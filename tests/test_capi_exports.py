@@ -16,12 +16,14 @@ def test_library_exports_all_declared_symbols(pkg):
 
 
 def test_facade_library_exports_the_rba_engine_abi(pkg):
-    """libssk_facade.so exports every function include/ssk_rba.h declares (loads without a GPU)."""
+    """libssk_facade.so exports every function include/ssk_rba.h and include/ssk_slam.h declare (loads without a GPU)."""
     from ssk_amd import capi
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "ssk_rba.h")).read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(ssk_rba_[a-z0-9_]+)\s*\(", src)))
-    assert len(names) >= 10, names
+    names = []
+    for hdr, pat in (("ssk_rba.h", r"\b(ssk_rba_[a-z0-9_]+)\s*\("), ("ssk_slam.h", r"\b(ssk_slam_[a-z0-9_]+)\s*\(")):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", hdr)).read(), flags=re.S)
+        names += sorted(set(re.findall(pat, src)))
+    assert len(names) >= 20, names
     lib = capi.load_facade_library()
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
