@@ -51,6 +51,7 @@ public:
 		double kernel_param = 3.0;                                                  // EST.cpp:1152
 		double std_noise_observations = 0.5;                                        // EST.cpp:1157 (uniform: cancels in the solve)
 		bool literal_first_edge_init = true;                                        // SRBA.h:194 as written (see .cpp)
+		bool literal_lc_edge_init = false;                                          // SRBA.h:294 as written (see .cpp): off by default
 	} parameters;
 
 	mySRBA(Context& ctx, const TSRBAStereoSLAMOptions& opts);
