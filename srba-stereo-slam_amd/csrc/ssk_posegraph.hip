@@ -4,7 +4,7 @@
 // information; the step comes from conjugate gradients preconditioned with the spanning-tree part of the system (block LDL^T on a
 // tree has no fill: children before parents, level by level).
 //
-// One persistent 1024-thread workgroup runs the whole optimisation (a keyframe graph has a few thousand nodes and about as
+// One persistent 256-thread workgroup runs the whole optimisation (a keyframe graph has a few thousand nodes and about as
 // many edges; the state, ~1 KB per node, stays in L2): every phase is a loop over edges or over nodes, a node gathers its
 // incident edges through a CSR list in ascending edge order -- the order in which the oracle accumulates -- so no atomics
 // and no run-to-run variation; only the three dot products of a CG iteration are tree-reduced (f64, fixed tree).
@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int PG_NT = 1024, PG_NW = PG_NT / 64;
+constexpr int PG_NT = 256, PG_NW = PG_NT / 64;
 
 struct pg_dev {
 	int n, m, fixed;
