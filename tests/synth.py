@@ -128,6 +128,71 @@ def synth_translation_sequence(seed, n_frames, w=W, h=H, noise=1.0, d_max=40, z_
     return frames, strips
 
 
+def synth_forward_sequence(seed, n_frames, step=0.5, w=W, h=H, noise=1.0, half_width=6.0, cam_height=1.65, z_far=120.0, px_per_m=48.0, yaw_per_frame=0.0):
+    """n_frames rectified stereo pairs from a camera driving FORWARD (+z, `step` metres per frame, optionally turning by
+    yaw_per_frame radians about the vertical) through a textured corridor: ground plane, two side walls, a far wall --
+    KITTI-like geometry ("forward motion").  Every pixel is the texture of the first surface its ray
+    hits (bilinear, three octaves so that structure exists at every distance).  Returns ([(left, right)], [camera poses]):
+    pose = (R, t) of the left camera in the world (x right, y down, z forward)."""
+    rng = np.random.default_rng(0x5EED2000 + seed)
+    T = 2048
+    tex = [synth_texture(rng, T, T).astype(np.float32) for _ in range(3)]     # ground, left wall, right wall (tiled)
+    far = synth_texture(rng, T, T).astype(np.float32)
+    fx, fy, cx, cy, b = KITTI["fx"], KITTI["fy"], KITTI["cx"], KITTI["cy"], KITTI["baseline"]
+    uu, vv = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    d_cam = np.stack([(uu - cx) / fx, (vv - cy) / fy, np.ones_like(uu)], -1)       # ray directions in the camera frame
+
+    def sample(t, a, c, foot):
+        """octaves of the tiled texture t at plane coordinates (a, c) in metres; `foot` = metres per image pixel at the hit
+        point: an octave whose texels are smaller than the pixel footprint fades out (it would alias into frame-to-frame noise)"""
+        out = np.full(a.shape, 95.0, np.float32)
+        for o, (sc, wt) in enumerate(((px_per_m, 0.8), (px_per_m / 3, 0.9), (px_per_m / 9, 1.0), (px_per_m / 27, 1.0))):
+            fade = np.clip(1.0 / (sc * foot) - 1.0, 0.0, 1.0).astype(np.float32)
+            if not fade.any():
+                continue
+            x = a * sc + 37.0 * o
+            y = c * sc + 91.0 * o
+            x0 = np.floor(x); y0 = np.floor(y)
+            ax = (x - x0).astype(np.float32); ay = (y - y0).astype(np.float32)
+            i0 = x0.astype(np.int64) % T; j0 = y0.astype(np.int64) % T
+            i1 = (i0 + 1) % T; j1 = (j0 + 1) % T
+            out += wt * fade * ((1 - ax) * (1 - ay) * t[j0, i0] + ax * (1 - ay) * t[j0, i1] + (1 - ax) * ay * t[j1, i0] + ax * ay * t[j1, i1] - 95.0)
+        return out
+
+    def render(R, c):
+        d = d_cam @ R.T                                                          # rays in the world
+        big = 1e9
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = np.where(d[..., 1] > 1e-9, (cam_height - c[1]) / d[..., 1], big)
+            tl = np.where(d[..., 0] < -1e-9, (-half_width - c[0]) / d[..., 0], big)
+            tr = np.where(d[..., 0] > 1e-9, (half_width - c[0]) / d[..., 0], big)
+            tf = np.where(d[..., 2] > 1e-9, (z_far - c[2]) / d[..., 2], big)
+        tg[tg <= 0] = big; tl[tl <= 0] = big; tr[tr <= 0] = big; tf[tf <= 0] = big
+        t = np.minimum(np.minimum(tg, tl), np.minimum(tr, tf))
+        P = c + t[..., None] * d
+        foot = t / fx                                                            # metres per pixel at the surface (the obliquity of the ground is ignored)
+        img = np.where(t == tg, sample(tex[0], P[..., 0], P[..., 2], foot),
+                       np.where(t == tl, sample(tex[1], P[..., 2], P[..., 1], foot),
+                                np.where(t == tr, sample(tex[2], P[..., 2], P[..., 1], foot), sample(far, P[..., 0], P[..., 1], foot))))
+        return img
+
+    frames, poses = [], []
+    c = np.array([0.0, 0.0, 0.0])
+    yaw = 0.0
+    for k in range(n_frames):
+        R = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])   # camera-to-world, yaw about y (down)
+        left = render(R, c)
+        right = render(R, c + R @ np.array([b, 0.0, 0.0]))
+        out = []
+        for im in (left, right):
+            im = im + rng.normal(0, noise, im.shape) if noise > 0 else im
+            out.append(np.clip(np.rint(im), 0, 255).astype(np.uint8))
+        frames.append(tuple(out)); poses.append((R.copy(), c.copy()))
+        c = c + R @ np.array([0.0, 0.0, step])
+        yaw += yaw_per_frame
+    return frames, poses
+
+
 KITTI_FRONTEND = dict(n_feats=500, fast_threshold=20, n_levels=1, nms_radius=2, orb_max_distance=60,
                       max_y_diff=2.0, min_disparity=1.0, max_disparity=128.0, harris_k=0.04)   # disparity 128 = 3 m at fx*b = 382
 
