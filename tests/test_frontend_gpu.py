@@ -51,6 +51,18 @@ def test_config2_single_kf_bit_exact(ctx, oracle, pkg):
     assert_kf_equal(got, exp)
 
 
+def test_rendered_forward_motion_frames_bit_exact(ctx, oracle, pkg):
+    """Ray-cast corridor frames (perspective, scale change, saturated and flat regions side by side): other image statistics
+    than the strip scenes, the same bit-exact bar."""
+    frames, _ = synth.synth_forward_sequence(3, 2, step=0.8, yaw_per_frame=0.01)
+    cp, op = params(pkg)
+    for left, right in frames:
+        got = ctx.frontend_run(left, right, cp)
+        exp = oracle.frontend(left, right, op, ol.default_pattern())
+        assert len(exp["kp_left"]) >= 300 and len(exp["matches"]) >= 100
+        assert_kf_equal(got, exp)
+
+
 @pytest.mark.parametrize("seed,over", [
     (5, dict(n_feats=500, nms_radius=0)),
     (6, dict(n_feats=100, fast_threshold=40)),
