@@ -22,6 +22,7 @@
 // Everything is integer work except the two serial f64 sums, which reproduce the reference order bit for bit.
 #include "ssk_frontend.h"
 #include <climits>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 
@@ -356,7 +357,10 @@ int launch_query(ssk_ctx* ctx, ssk_bow_db* db, const int32_t* q_word, const doub
 	ssk_stage_scope prof(ctx, SSK_STAGE_BOW);
 	const int ne = db->n_entries;
 	if (ne > 0) {
-		const int bm_dwords = db->voc->n_words <= BOW_BITMAP_WORDS_MAX / 2 ? (db->voc->n_words + 31) / 32 : 0;
+		// vocabularies beyond 512 Ki words (bitmap + prefix counts > 128 KB of LDS) binary-search the query instead;
+		// SSK_BOW_NO_BITMAP=1 forces that path (tests)
+		static const bool no_bitmap = std::getenv("SSK_BOW_NO_BITMAP") != nullptr;
+		const int bm_dwords = (!no_bitmap && db->voc->n_words <= BOW_BITMAP_WORDS_MAX / 2) ? (db->voc->n_words + 31) / 32 : 0;
 		const size_t lds = 12 * (size_t)BOW_SORT_MAX + 8 * (size_t)bm_dwords;
 		static bool attr_set = false;
 		if (!attr_set) {

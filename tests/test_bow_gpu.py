@@ -196,3 +196,32 @@ def test_reference_vocabulary_subtree_fixture(pkg, ctx, oracle):
         oi, os_ = odb.query(oa, ob, 4)
         assert np.array_equal(gi, oi) and np.array_equal(gs, os_)
         gdb.add(a, b); odb.add(oa, ob)
+
+
+def test_query_without_bitmap_path(pkg, oracle):
+    """Vocabularies beyond 512 Ki words have no room for the query bitmap in LDS: the score kernel then binary-searches the
+    query.  SSK_BOW_NO_BITMAP=1 (read once per process) forces that path: run it in a process of its own."""
+    import subprocess
+    import sys
+    code = """
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import __graft_entry__ as ge
+import bow_vocab as bv, oracle_lib
+pkg = ge.load_package()
+from ssk_amd import capi
+ctx = pkg.Context(0)
+o = oracle_lib.load()
+v = bv.synth(k=8, L=3, seed=51, ragged=True)
+G, O = capi.BowVocab(ctx, v), o.bow_vocab(v)
+gdb, odb = capi.BowDb(ctx, G, 64, 256), o.bow_db(O.n_words)
+for f in bv.keyframe_sequence(v, np.random.default_rng(52), n_kf=30, n=200):
+    w, x = G.transform(f)
+    gi, gs = gdb.query(w, x, 4); oi, os_ = odb.query(w, x, 4)
+    assert np.array_equal(gi, oi) and np.array_equal(gs, os_)
+    gdb.add(w, x); odb.add(w, x)
+print("OK")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SSK_BOW_NO_BITMAP="1"), timeout=300)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
