@@ -85,3 +85,17 @@ def test_golden_fixture(ctx):
     assert abs(r.iters - it) <= 2 and r.stop_reason == stop and abs(r.cost_final - g["exp_cost"][1]) <= 1e-6 * g["exp_cost"][1]
     assert abs(r.cost_init - g["exp_cost"][0]) <= 1e-9 * g["exp_cost"][0]
     assert np.abs(X - g["exp_poses"]).max() <= 2e-5 * np.abs(g["exp_poses"]).max()
+
+
+def test_disconnected_components(ctx, oracle):
+    """Two loops that share no edge: the second one is not reached from the fixed node and starts its own spanning tree in the
+    preconditioner (its gauge is only held by lambda); both sides take the same attempts."""
+    a, b = sp.make_loop(21, n=20), sp.make_loop(22, n=24)
+    init = np.concatenate([a["init"], b["init"]])
+    ij = np.concatenate([a["edge_ij"], b["edge_ij"] + 20]).astype(np.int32)
+    z = np.concatenate([a["edge_z"], b["edge_z"]])
+    g = dict(init=init, edge_ij=ij, edge_z=z)
+    for it in (1, 3, 6):
+        Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=it)
+        assert (rg.iters, rg.accepted) == (ro.iters, ro.accepted) and abs(rg.cost_final - ro.cost_final) <= 1e-8 * ro.cost_final
+        assert np.abs(Xg - Xo).max() <= 1e-7 * np.abs(Xo).max() and rg.cost_final < rg.cost_init
