@@ -212,7 +212,8 @@ def main():
                     help="processes of the all-cores CPU baseline (-1: half the host's logical cores, at most 64; 0 = skip)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--side-stream", type=int, default=0,
-                    help="1: the place-recognition kernels on a second HIP stream beside the data-association chain (both depend only on the front-end)")
+                    help="1: the place-recognition kernels on a second HIP stream beside the data-association chain (both depend only on the "
+                         "front-end); measured +0.8 % at --batch 256, nothing at 1024")
     ap.add_argument("--shared-landmarks", type=int, default=256)
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: LM solves on a second HIP stream beside the front-end / DA kernels (measured: +1 %, the LM workgroups fill every CU)")
@@ -312,17 +313,18 @@ def main():
     # ---- roofline pass: per-stage kernel time with HIP events on the same stream (all ranks run it, rank 0 reports)
     sync_all()
     ctx.profile_enable(True)
-    if ctx_lm is not ctx:
-        ctx_lm.profile_enable(True)
+    extra_ctx = [c for c in (ctx_lm, ctx_side) if c is not None and c is not ctx]
+    for c in extra_ctx:
+        c.profile_enable(True)
     prof_steps = max(3, min(args.steps, 10))
     for _ in range(prof_steps):
         step(serial=True)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    if ctx_lm is not ctx:
-        for k, v in ctx_lm.profile_read().items():
+    for c in extra_ctx:
+        for k, v in c.profile_read().items():
             prof[k] = (prof[k][0] + v[0], prof[k][1] + v[1]) if k in prof else v
-        ctx_lm.profile_enable(False)
+        c.profile_enable(False)
     res = lm.results()
     nkp, nm = cur.counts()
     tracked = d_tr.cpu().numpy()
@@ -376,7 +378,7 @@ def main():
                             "place-recognition query (k=8, L=5 vocabulary, %d-keyframe database, 4 results) + SRBA LM window " % BOW_DB_ENTRIES +
                             "(200-KF/5k-landmark submap, submap_size 10, max_tree_depth 4, window = 10 most recent edges)",
                 "keyframes_per_gpu_per_step": B,
-                "streams": "front-end + DA on one HIP stream, LM solves on a second one" if args.overlap else "one HIP stream",
+                "streams": ("front-end + DA on one HIP stream, LM solves on a second one" if args.overlap else "one HIP stream") + ("; place recognition on a side stream beside the data-association chain" if args.side_stream else ""),
                 "parallelism": "keyframe streams partitioned one batch per GPU" + ("; 1 RCCL all-gather of %d shared-landmark blocks per step" % S if exchange else ""),
                 "mean_keypoints_per_image": float(nkp.mean()),
                 "mean_stereo_matches": float(nm.mean()),
