@@ -393,6 +393,234 @@ __device__ __forceinline__ bool ldl_solve_global(double* __restrict__ A, int np,
 	return true;
 }
 
+// G for a system in L2 scratch, hybrid: the leading n1 columns are eliminated in global memory (ldl_solve_global's step), then
+// the trailing (n - n1) x (n - n1) block -- the part that fits LDS as a PACKED lower triangle, border row included -- is copied
+// into LDS once and factorised there at LDS latency.  n1 = 0 when the whole triangle fits (6E <= ~186: the LDS residency that the
+// square layout of ldl_solve_lds gives up to 6E = 126).  A global step costs three dependent L2 round trips (~19 us measured), an
+// LDS step ~3 us: a 240-unknown system goes from 40 global steps to 9 global + 31 LDS steps.
+// Same operation order per element as the other two solvers up to the back-substitution, which is done block-wise:
+// x2 (rows >= n1) inside the packed block, then the rows' leading columns (from global memory, staged) onto x1.
+#define SSK_PI(i, k) P[(i) * ((i) + 1) / 2 + (k)]
+__device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
+{
+	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+	__shared__ int s_ldl_bad_h;
+	int n1 = 0;
+	while (n1 < n && (long long)(n - n1 + 1) * (n - n1 + 2) / 2 > lds_doubles) n1 += 6;
+	if (n1 >= n) return ldl_solve_global(A, np, n, x_out, inv, lds, lds_doubles);      // (no room at all: never with the tiler's regions)
+	const int m = n - n1;
+	// ---- phase 1: columns 0 .. n1-1 in global memory, panel staged in LDS (as ldl_solve_global) ----
+	double* Pn = lds;
+	for (int c0 = 0; c0 < n1; c0 += 6) {
+		__syncthreads();
+		double a[21], ivr[6];
+#pragma unroll
+		for (int i = 0; i < 6; ++i)
+#pragma unroll
+			for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = A[(size_t)(c0 + i) * np + c0 + k];
+		bool bad = false;
+#pragma unroll
+		for (int j = 0; j < 6; ++j) {
+			const double d = a[j * (j + 1) / 2 + j];
+			bad |= !(d > 0.0);
+			ivr[j] = rcp_f64(d);
+#pragma unroll
+			for (int i = j + 1; i < 6; ++i) {
+				const double t = a[i * (i + 1) / 2 + j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+			}
+		}
+		const int r0 = c0 + 6;
+		for (int i = r0 + tid; i <= n; i += NT) {
+			double x[6];
+#pragma unroll
+			for (int k = 0; k < 6; ++k) x[k] = A[(size_t)i * np + c0 + k];
+#pragma unroll
+			for (int j = 0; j < 5; ++j) {
+				const double t = x[j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+			}
+#pragma unroll
+			for (int k = 1; k < 6; ++k) A[(size_t)i * np + c0 + k] = x[k];
+#pragma unroll
+			for (int k = 0; k < 6; ++k) Pn[(i - r0) * 7 + k] = x[k];
+		}
+		if (tid == 0) {
+			s_ldl_bad_h = bad;
+#pragma unroll
+			for (int i = 0; i < 6; ++i) {
+				inv[c0 + i] = ivr[i];
+#pragma unroll
+				for (int k = 0; k < i; ++k) A[(size_t)(c0 + i) * np + c0 + k] = a[i * (i + 1) / 2 + k];
+			}
+		}
+		__syncthreads();
+		if (s_ldl_bad_h) return false;                    // uniform
+		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
+			for (int kb = r0 + tx; kb < n; kb += 64) {
+				double ui[4][6], uk[2][6], v[8];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int i = ib + (NT / 32) * u;
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] = i <= n ? Pn[(i - r0) * 7 + c] * ivr[c] : 0.0;
+				}
+#pragma unroll
+				for (int w = 0; w < 2; ++w) {
+					const int k = kb + 32 * w;
+#pragma unroll
+					for (int c = 0; c < 6; ++c) uk[w][c] = k < n ? Pn[(k - r0) * 7 + c] : 0.0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						v[2 * u + w] = (i <= n && k < n && k <= i) ? A[(size_t)i * np + k] : 0.0;
+					}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						if (i <= n && k < n && k <= i) {
+							double sacc = 0.0;
+#pragma unroll
+							for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
+							A[(size_t)i * np + k] = v[2 * u + w] - sacc;
+						}
+					}
+			}
+	}
+	__syncthreads();
+	// ---- phase 2: the trailing block (rows n1 .. n, columns n1 .. row) into LDS, packed ----
+	double* P = lds;
+	for (int r = ty; r <= m; r += NT / 32) {
+		const int cend = r < m ? r : m - 1;
+		for (int c = tx; c <= cend; c += 32) SSK_PI(r, c) = A[(size_t)(n1 + r) * np + n1 + c];
+	}
+	// ---- phase 3: blocked LDL^T of the packed block (the loop of ldl_solve_lds on packed indices) ----
+	for (int c0 = 0; c0 < m; c0 += 6) {
+		__syncthreads();
+		if (tid < 64) {
+			double a[21], ivr[6];
+#pragma unroll
+			for (int i = 0; i < 6; ++i)
+#pragma unroll
+				for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = SSK_PI(c0 + i, c0 + k);
+			bool bad = false;
+#pragma unroll
+			for (int j = 0; j < 6; ++j) {
+				const double d = a[j * (j + 1) / 2 + j];
+				bad |= !(d > 0.0);
+				ivr[j] = rcp_f64(d);
+#pragma unroll
+				for (int i = j + 1; i < 6; ++i) {
+					const double t = a[i * (i + 1) / 2 + j] * ivr[j];
+#pragma unroll
+					for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+				}
+			}
+			for (int i = c0 + 6 + tid; i <= m; i += 64) {
+				double x[6];
+#pragma unroll
+				for (int k = 0; k < 6; ++k) x[k] = SSK_PI(i, c0 + k);
+#pragma unroll
+				for (int j = 0; j < 5; ++j) {
+					const double t = x[j] * ivr[j];
+#pragma unroll
+					for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+				}
+#pragma unroll
+				for (int k = 1; k < 6; ++k) SSK_PI(i, c0 + k) = x[k];
+			}
+			if (tid == 0) {
+				s_ldl_bad_h = bad;
+#pragma unroll
+				for (int i = 0; i < 6; ++i) {
+					inv[n1 + c0 + i] = ivr[i];
+#pragma unroll
+					for (int k = 0; k < i; ++k) SSK_PI(c0 + i, c0 + k) = a[i * (i + 1) / 2 + k];
+				}
+			}
+		}
+		__syncthreads();
+		if (s_ldl_bad_h) return false;                    // uniform
+		double iv[6];
+#pragma unroll
+		for (int c = 0; c < 6; ++c) iv[c] = inv[n1 + c0 + c];
+		const int r0 = c0 + 6;
+		for (int ib = r0 + ty; ib <= m; ib += 4 * (NT / 32))
+			for (int kb = r0 + tx; kb < m; kb += 64) {
+				double ui[4][6], uk[2][6], v[8];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int i = ib + (NT / 32) * u;
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] = i <= m ? SSK_PI(i, c0 + c) * iv[c] : 0.0;
+				}
+#pragma unroll
+				for (int w = 0; w < 2; ++w) {
+					const int k = kb + 32 * w;
+#pragma unroll
+					for (int c = 0; c < 6; ++c) uk[w][c] = k < m ? SSK_PI(k, c0 + c) : 0.0;
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						v[2 * u + w] = (i <= m && k < m && k <= i) ? SSK_PI(i, k) : 0.0;
+					}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						if (i <= m && k < m && k <= i) {
+							double sacc = 0.0;
+#pragma unroll
+							for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
+							SSK_PI(i, k) = v[2 * u + w] - sacc;
+						}
+					}
+			}
+	}
+	__syncthreads();
+	// ---- back-substitution, step A: x2 inside the packed block (rows from the last up; one barrier per row) ----
+	for (int k = tid; k < m; k += NT) x_out[n1 + k] = SSK_PI(m, k) * inv[n1 + k];
+	for (int k = tid; k < n1; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
+	__syncthreads();
+	for (int i = m - 1; i > 0; --i) {
+		const double xi = x_out[n1 + i];
+		for (int k = tid; k < i; k += NT) x_out[n1 + k] -= SSK_PI(i, k) * inv[n1 + k] * xi;
+		__syncthreads();
+	}
+	if (n1 == 0) return true;
+	// ---- step B: every row's leading columns (k < n1) onto x1, rows staged from global memory `cr` at a time ----
+	int cr = lds_doubles / n1;
+	cr = cr > 64 ? 64 : cr;
+	for (int hi = n - 1; hi > 0; hi -= cr) {
+		const int lo = hi - cr + 1 > 1 ? hi - cr + 1 : 1;          // rows lo..hi
+		__syncthreads();
+		for (int t = tid; t < (hi - lo + 1) * n1; t += NT) {
+			const int r = t / n1, k = t - r * n1, i = lo + r;
+			lds[r * n1 + k] = k < i ? A[(size_t)i * np + k] * inv[k] : 0.0;
+		}
+		__syncthreads();
+		for (int i = hi; i >= lo; --i) {
+			const double xi = x_out[i];
+			const int kend = i < n1 ? i : n1;
+			for (int k = tid; k < kend; k += NT) x_out[k] -= lds[(i - lo) * n1 + k] * xi;
+			__syncthreads();
+		}
+	}
+	return true;
+}
+#undef SSK_PI
+
 // G (fallback): the same factorisation by the whole workgroup on an L2-resident matrix (6E too large for LDS)
 __device__ bool chol_solve_block(double* A, int n, double* b, int* s_flag, double* s_piv)
 {

@@ -577,7 +577,7 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 	if (!solve) return true;
 	bool ok_ = true;
 	if (n6 > 0) {
-		if constexpr (GLOBAL_A) ok_ = ldl_solve_global(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
+		if constexpr (GLOBAL_A) ok_ = ldl_solve_hybrid(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
 		else ok_ = ldl_solve_lds(A, np, n6, s_b, s_inv);
 	}
 	F2G_TICK(2);
@@ -690,6 +690,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			alive = coop_barrier(co);
 			if (!alive) continue;
 		}
+		STAMP(5);
 		if (g == 0) {
 			ok = lds_mat ? assemble_and_solve<false>(D, W, Pp, Sp, lambda, reg, np, n6, s_b, s_inv)
 			             : assemble_and_solve<true>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, !share_f2, true, tid, NT,

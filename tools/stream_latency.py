@@ -39,7 +39,7 @@ def full_loop(n):
         p = subprocess.run([demo, "stream", vf, d, str(n), str(synth.W), str(synth.H)], capture_output=True, text=True, env=env)
         assert p.returncode == 0, p.stderr
         for l in p.stdout.splitlines():
-            if l.startswith(("timing", "keyframes", "posegraph")):
+            if l.startswith(("timing", "keyframes", "posegraph", "LMT")):
                 print(l)
         for l in p.stderr.splitlines()[-8:]:
             if "facade timing" in l or "ssk timing" in l:
