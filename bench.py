@@ -215,6 +215,9 @@ def main():
                     help="1: the place-recognition kernels on a second HIP stream beside the data-association chain (both depend only on the "
                          "front-end); measured +0.8 % at --batch 256, nothing at 1024")
     ap.add_argument("--shared-landmarks", type=int, default=256)
+    ap.add_argument("--pcie-steps", type=int, default=5,
+                    help="steps of the PCIe-inclusive pass at N=1 (images uploaded from pinned host memory every step; reported as "
+                         "`pcie_inclusive`, never as `value`; 0 = skip)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: LM solves on a second HIP stream beside the front-end / DA kernels (measured: +1 %, the LM workgroups fill every CU)")
     args = ap.parse_args()
@@ -237,6 +240,8 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = pkg.Context(local, stream=stream)
+    # the stream the context really enqueues on (a null handle above makes it create its own non-blocking stream)
+    main_stream = torch.cuda.ExternalStream(ctx.stream(), device=local)
     # the LM solves of a batch are independent of the same step's front-end / data association (in a keyframe stream:
     # LM of batch k runs beside the front-end of batch k+1), so they go to a second HIP stream: per-window iteration
     # counts differ, and CUs whose window has converged pick up front-end workgroups instead of idling
@@ -263,17 +268,17 @@ def main():
     side = torch.cuda.Stream() if args.side_stream else None
     ctx_side = pkg.Context(local, stream=side.cuda_stream) if side else None
 
-    def step(serial=False):
+    def step(serial=False, cur=cur):
         cur.run_frontend(fp)
         if side:
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(main_stream)
             cur.bow_transform(voc, ctx=ctx_side)
             cur.bow_query(db, 4, ctx=ctx_side)
         ctx.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
         ctx.fm_run_batch(cur, prev, pairs, fm, d_idx, d_st, d_tr)            # stage 2 of the DA (da_stage2_method = 3): fundamental-matrix
         ctx.cip_run_batch(cur, prev, pairs, cp, d_idx, d_st, d_tr)           # RANSAC filter, then the change-in-pose filter
         if side:
-            torch.cuda.current_stream().wait_stream(side)
+            main_stream.wait_stream(side)
         else:
             cur.bow_transform(voc)                                           # place recognition (queryDB, EST.cpp:426): words of the left
             cur.bow_query(db, 4)                                             # descriptors, L1 query of the keyframe database, 4 results
@@ -283,11 +288,11 @@ def main():
         lm.run(lp)
         if exchange:
             # the one exchange step of the path: every submap's shared-landmark blocks to every GPU,
-            # fused in rank order (deterministic); enqueued behind the solve on its stream
-            with torch.cuda.stream(lm_stream):
-                lm.pack_shared(0, S, shared)
-                pkg.dist.exchange_shared(shared, gathered)
-                ctx_lm.stitch_shared(gathered, world, S, fused)
+            # fused in rank order (deterministic); enqueued behind the solve on its stream (RCCL orders the all-gather
+            # against the stream handed over)
+            lm.pack_shared(0, S, shared)
+            pkg.dist.exchange_shared(shared, gathered, stream=ctx_lm.stream())
+            ctx_lm.stitch_shared(gathered, world, S, fused)
         if serial:
             torch.cuda.synchronize()
 
@@ -328,6 +333,62 @@ def main():
     res = lm.results()
     nkp, nm = cur.counts()
     tracked = d_tr.cpu().numpy()
+
+    # ---- PCIe-inclusive pass (reported beside `value`, never as it): the same step when every batch of images arrives from
+    # pinned host memory.  Two resident batches; a copy stream uploads batch k+1 while the step of batch k runs.
+    def pcie_pass():
+        # (a function of its own: the pinned buffer is released while the context's stream still exists -- torch's host
+        # allocator records an event on every stream a pinned block was used on when the block is freed)
+        cur2 = capi.KfBatch(ctx, B, W, H, 512)
+        bufs = [cur, cur2]
+        host = cur.image_tensor().cpu().pin_memory()
+        copy_stream = torch.cuda.Stream()
+        main = main_stream
+        uploaded = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def upload(k):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(consumed[k & 1])
+                bufs[k & 1].image_tensor().copy_(host, non_blocking=True)
+                uploaded[k & 1].record(copy_stream)
+
+        for e in consumed:
+            e.record(main)
+        torch.cuda.synchronize()
+        tp = None
+        n_pcie = args.pcie_steps + 1                      # the first step is the warm-up (its upload is not overlapped)
+        upload(0)
+        for k in range(n_pcie):
+            if k == 1:
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+            upload(k + 1)                                 # (the timed region holds as many uploads as steps: 2 .. n_pcie)
+            main.wait_event(uploaded[k & 1])
+            step(cur=bufs[k & 1])
+            consumed[k & 1].record(main)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - tp
+        # the serial variant: upload, then the step, nothing overlapped
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for k in range(args.pcie_steps):
+            with torch.cuda.stream(main):
+                cur.image_tensor().copy_(host, non_blocking=True)
+            step()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - ts
+        img_bytes = host.numel()
+        pcie = {"value": B * args.pcie_steps / dtp, "unit": "keyframes/s", "ms_per_step": 1e3 * dtp / args.pcie_steps,
+                "steps": args.pcie_steps, "host_bytes_per_step": img_bytes,
+                "serial_value": B * args.pcie_steps / dts, "serial_ms_per_step": 1e3 * dts / args.pcie_steps,
+                "note": "images of every batch uploaded from pinned host memory; value: upload of batch k+1 on a copy stream beside the "
+                        "step of batch k (two resident batches), serial_value: upload then step on one stream"}
+        cur2.close()
+        return pcie
+
+    pcie = pcie_pass() if world == 1 and args.pcie_steps > 0 else None
+    torch.cuda.synchronize()
 
     if rank == 0:
         # PMC traffic per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary
@@ -398,6 +459,7 @@ def main():
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("fast_nms_kernel"),
                               "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_avg_ms},
             "stage_ms_per_launch": stages,
+            "pcie_inclusive": pcie,
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, wins, vocab)

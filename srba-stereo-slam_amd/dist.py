@@ -26,11 +26,20 @@ def partition(n_items, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def exchange_shared(shared, gathered):
+def exchange_shared(shared, gathered, stream=None):
     """The one exchange step: every rank contributes `shared` ([n_shared*12] f64: position 3, g_f 3, upper H_ff 6 per
     landmark) and receives all of them rank-major in `gathered` ([world*n_shared*12]).  A single all-gather: the
     payload is tens of KB, i.e. latency-bound on xGMI, so no ring reduction; the fusion is done locally in rank order
-    (ssk_lm_stitch_shared) and is therefore bit-identical on every rank."""
+    (ssk_lm_stitch_shared) and is therefore bit-identical on every rank.
+
+    stream: the hipStream_t handle (int, `Context.stream()`) the pack and stitch kernels are enqueued on.  RCCL orders
+    a collective against torch's CURRENT stream, and a context that owns its stream is not that one: with `stream`
+    given the all-gather is issued with that stream current, i.e. behind the pack and ahead of the stitch."""
     import torch.distributed as dist
-    dist.all_gather_into_tensor(gathered, shared)
+    if stream is not None and shared.is_cuda:
+        import torch
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=shared.device)):
+            dist.all_gather_into_tensor(gathered, shared)
+    else:
+        dist.all_gather_into_tensor(gathered, shared)
     return gathered

@@ -1,0 +1,72 @@
+"""(e) the one exchange step on the GPU: pack -> RCCL all-gather -> stitch, with a context that OWNS its HIP stream
+(not torch's current stream).  The all-gather has to be ordered behind the pack kernel and ahead of the stitch kernel
+on that stream; a single-rank "nccl" (= RCCL) group is enough to exercise the ordering and the payload layout."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_exchange_is_ordered_on_the_context_stream():
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import synth_lm as sl
+    from test_dist_cpu import fuse_numpy
+    from test_lm_gpu import to_capi
+    pkg = ge.load_package()
+    from ssk_amd import capi
+    if dist.is_initialized():
+        pytest.skip("a process group is already up in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    old = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        torch.cuda.set_device(0)
+        rank, world = pkg.dist.init_from_env("nccl", always=True)
+        assert (rank, world) == (0, 1)
+        ctx = pkg.Context(0)                                     # owns a non-blocking stream
+        assert ctx.stream() not in (0, None)
+        assert ctx.stream() != torch.cuda.current_stream().cuda_stream
+        wins = [sl.make_submap_problem(40 + i, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)[0] for i in range(6)]
+        b = capi.LmBatch(ctx, wins)
+        S = 64
+        dev = torch.device("cuda:0")
+        shared = torch.zeros(S * 12, dtype=torch.float64, device=dev)
+        gathered = torch.zeros(S * 12, dtype=torch.float64, device=dev)
+        fused = torch.zeros(S * 3, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        prm = to_capi(sl.make_params())
+        for rep in range(3):                                     # no host synchronisation between the enqueued pieces
+            b.reset()
+            b.run(prm)
+            b.pack_shared(rep, S, shared)
+            pkg.dist.exchange_shared(shared, gathered, stream=ctx.stream())
+            ctx.stitch_shared(gathered, 1, S, fused)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        g = gathered.cpu().numpy()
+        assert np.array_equal(g, shared.cpu().numpy())
+        assert np.array_equal(g.reshape(S, 12)[:, :3], b.state(2)[1][:S])      # the LAST repetition's window, after its solve
+        exp = fuse_numpy(g, 1, S)
+        assert np.allclose(fused.cpu().numpy().reshape(S, 3), exp, rtol=1e-9, atol=1e-9)
+        b.close()
+        ctx.close()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
