@@ -355,8 +355,12 @@ int ssk_kfbatch_bow_results(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_e
  * (EST.cpp:945-957).  Contract G1-G6: oracle/oracle_posegraph.c.  Nodes X_k: pose of keyframe k in the root's frame,
  * row-major [R|t], in/out; edge e: (i, j) = edge_ij[2e], edge_ij[2e+1] with X_i^-1 X_j = Z_e (edge_z, 12 doubles each; the
  * k2k edge {from, to, inv_pose} gives i = to, j = from, Z = inv_pose); fixed_node is held (the root).  Levenberg-Marquardt on
- * e = (t_E, log R_E), E = Z^-1 X_i^-1 X_j, unit information, gain-ratio lambda update (as MRPT's optimiser); the step comes
- * from conjugate gradients preconditioned with the spanning-tree part of the system. */
+ * e = (t_E, log R_E), E = Z^-1 X_i^-1 X_j, unit information, gain-ratio lambda update (as MRPT's optimiser).  The step
+ * (H + lambda I) d = -g is solved either directly -- block elimination on the spanning tree (no fill) plus a Woodbury
+ * correction of rank 6 per edge off the tree: a keyframe graph is a tree plus a few loop closures -- or, when more than
+ * SSK_PG_DIRECT_MAX_EDGES edges lie off the tree, by conjugate gradients preconditioned with the spanning-tree part (the
+ * oracle's solver; `solver` = 1 forces it). */
+#define SSK_PG_DIRECT_MAX_EDGES 42
 typedef struct ssk_pg_params {
 	int32_t max_iters;                 /* LM attempts; MRPT's default is 100 */
 	int32_t pcg_max_iters;             /* CG iterations per attempt */
@@ -364,11 +368,14 @@ typedef struct ssk_pg_params {
 	double max_lambda;                 /* 1e20 */
 	double converged_rel_decrease;     /* stop when an attempt changes the cost by <= this fraction; 1e-9 */
 	double pcg_tol;                    /* CG stops at r.z <= pcg_tol^2 r0.z0; 1e-10 */
+	int32_t solver;                    /* 0: direct when at most SSK_PG_DIRECT_MAX_EDGES edges lie off the spanning tree, else CG;
+	                                      1: CG always; 2: direct, SSK_ERR_CAPACITY when it does not apply */
+	int32_t reserved;                  /* 0 */
 } ssk_pg_params;
 typedef struct ssk_pg_result {
 	int32_t iters, accepted;
 	int32_t stop_reason;               /* 0 max_iters, 1 cost at round-off level, 2 max_lambda, 3 nothing to optimise, 4 converged */
-	int32_t pcg_iters_total;
+	int32_t pcg_iters_total;           /* 0 when every attempt used the direct solver */
 	double cost_init, cost_final, lambda_final;
 } ssk_pg_result;
 int ssk_posegraph_optimize(ssk_ctx* ctx, int n_nodes, double* node_poses, int n_edges, const int32_t* edge_ij,

@@ -328,12 +328,13 @@ class BowDb:
 
 
 class PgParams(C.Structure):
-    """ssk_pg_params; defaults: MRPT's 100 iterations / tau 1e-3, CG to 1e-10."""
+    """ssk_pg_params; defaults: MRPT's 100 iterations / tau 1e-3, CG to 1e-10; solver 0 = direct (spanning tree + Woodbury)
+    when it applies, 1 = CG always, 2 = direct or an error."""
     _fields_ = [("max_iters", C.c_int32), ("pcg_max_iters", C.c_int32), ("tau", C.c_double), ("max_lambda", C.c_double),
-                ("converged_rel_decrease", C.c_double), ("pcg_tol", C.c_double)]
+                ("converged_rel_decrease", C.c_double), ("pcg_tol", C.c_double), ("solver", C.c_int32), ("reserved", C.c_int32)]
 
-    def __init__(self, max_iters=100, pcg_max_iters=400, tau=1e-3, max_lambda=1e20, converged_rel_decrease=1e-9, pcg_tol=1e-10):
-        super().__init__(max_iters, pcg_max_iters, tau, max_lambda, converged_rel_decrease, pcg_tol)
+    def __init__(self, max_iters=100, pcg_max_iters=400, tau=1e-3, max_lambda=1e20, converged_rel_decrease=1e-9, pcg_tol=1e-10, solver=0):
+        super().__init__(max_iters, pcg_max_iters, tau, max_lambda, converged_rel_decrease, pcg_tol, solver, 0)
 
 
 class PgResult(C.Structure):

@@ -396,6 +396,7 @@ int ssk_bow_vocab_create(ssk_ctx* ctx, int k, int L, int weighting, int scoring,
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!out || n_rec < 0 || n_words < 0 || (n_rec > 0 && (!node_id || !parent_id || !weight || !desc)) || (n_words > 0 && !word_node))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_bow_vocab_create: bad argument");
+	if (k < 1 || L < 1) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_bow_vocab_create: k = %d, L = %d", k, L);
 	if (weighting != 0 || scoring != 0)
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_bow_vocab_create: only weightingType 0 (TF_IDF) with scoringType 0 (L1_NORM) is "
 		                     "implemented (the reference's vocabulary); got %d / %d", weighting, scoring);
@@ -437,7 +438,8 @@ int ssk_bow_vocab_create(ssk_ctx* ctx, int k, int L, int weighting, int scoring,
 	for (int i = 1; i < nn; ++i) std::memcpy(nd.data() + 32 * (size_t)i, desc + 32 * (size_t)rec_of[order[i]], 32);
 	for (int w = 0; w < n_words; ++w) {
 		const int id = word_node[w];
-		if (id <= 0 || id >= n || new_of[id] < 0) continue;
+		if (id <= 0 || id >= n || new_of[id] < 0 || rec_of[id] < 0)
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_bow_vocab_create: word %d names node %d, which is not a node of the tree", w, id);
 		leaf_word[new_of[id]] = w;
 		word_weight[w] = weight[rec_of[id]];
 	}

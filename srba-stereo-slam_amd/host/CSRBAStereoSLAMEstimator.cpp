@@ -383,8 +383,9 @@ std::vector<Pose3D> CSRBAStereoSLAMEstimator::optimizeGlobalPoseGraph(ssk_pg_res
 	std::memset(&res, 0, sizeof res);
 	if (!nodes.empty()) {
 		ssk_pg_params prm;
+		std::memset(&prm, 0, sizeof prm);                              // solver 0: direct (spanning tree + Woodbury) when it applies
 		prm.max_iters = 100; prm.tau = 1e-3;                         // mrpt::graphslam defaults (max_iterations, tau)
-		prm.pcg_max_iters = 1000;                                      // tree-preconditioned: ~6 iterations per edge off the spanning tree
+		prm.pcg_max_iters = 1000;                                      // CG fallback, tree-preconditioned: ~6 iterations per edge off the spanning tree
 		prm.max_lambda = 1e20; prm.converged_rel_decrease = 1e-9; prm.pcg_tol = 1e-10;
 		static_assert(sizeof(Pose3D) == 12 * sizeof(double), "Pose3D is 12 doubles");
 		m_ctx.check(ssk_posegraph_optimize(m_ctx.get(), (int)nodes.size(), nodes[0].m, (int)edge_z.size(), edge_ij.data(),

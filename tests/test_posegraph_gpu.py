@@ -1,7 +1,9 @@
 """GPU parity: global pose-graph optimisation (pg_solve_kernel) vs the CPU oracle through the C-ABI.  Floating point: the
 linearisation follows the oracle's operation order, the three dot products of a CG iteration are tree-reduced, libm differs
 from the device's -- poses and costs are compared within 1e-6 relative (the north star's LM tolerance); the first attempts are
-compared one by one."""
+compared one by one.  Both solvers of the C-ABI are covered: SOLVERS = 0 (direct: spanning-tree elimination + Woodbury, the
+default on keyframe graphs) and 1 (the oracle's tree-preconditioned CG); the direct step is the exact solution of the system
+the oracle's CG solves to 1e-10."""
 import numpy as np
 import pytest
 
@@ -10,19 +12,24 @@ import synth_pg as sp
 pytestmark = pytest.mark.gpu
 
 
+SOLVERS = (0, 1)
+
+
 def both(ctx, oracle, g, init=None, **over):
     from ssk_amd import capi
     import oracle_lib as ol
     init = g["init"] if init is None else init
     Xg, rg = ctx.posegraph_optimize(init, g["edge_ij"], g["edge_z"], prm=capi.PgParams(**over))
+    over.pop("solver", None)                                          # the oracle has the one solver
     Xo, ro = oracle.pg_optimize(init, g["edge_ij"], g["edge_z"], prm=ol.PgParams(**over))
     return Xg, rg, Xo, ro
 
 
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("seed,n,fwd", [(5, 60, True), (6, 90, False), (7, 25, False), (10, 150, True)])
-def test_loop_closure_matches_oracle(ctx, oracle, seed, n, fwd):
+def test_loop_closure_matches_oracle(ctx, oracle, seed, n, fwd, solver):
     g = sp.make_loop(seed, n=n, radius=20.0 * max(1, n / 100), edge_forward=fwd)
-    Xg, rg, Xo, ro = both(ctx, oracle, g, pcg_max_iters=6 * n)      # CG needs O(n) iterations on a chain-like graph
+    Xg, rg, Xo, ro = both(ctx, oracle, g, pcg_max_iters=6 * n, solver=solver)      # CG needs O(n) iterations on a chain-like graph
     # the stop rule (an attempt that changes the cost by <= 1e-9 of it) fires on differences at the rounding level: the two
     # sides may stop an attempt or two apart, at the same optimum
     assert abs(rg.iters - ro.iters) <= 2 and rg.accepted >= rg.iters - 2 and rg.stop_reason == ro.stop_reason == 4
@@ -30,7 +37,7 @@ def test_loop_closure_matches_oracle(ctx, oracle, seed, n, fwd):
     assert rg.cost_final < 0.05 * rg.cost_init
     # states after the same number of attempts (the valley is flat at the 1e-9 stop: a state an attempt further differs by more)
     k = min(rg.iters, ro.iters) - 1
-    Xg, rg, Xo, ro = both(ctx, oracle, g, pcg_max_iters=6 * n, max_iters=k)
+    Xg, rg, Xo, ro = both(ctx, oracle, g, pcg_max_iters=6 * n, max_iters=k, solver=solver)
     assert (rg.iters, rg.accepted) == (ro.iters, ro.accepted) == (k, k)
     # per attempt the two sides agree to 1e-8 (test_single_attempts_match_oracle); over ~15 attempts with lambda falling by 10
     # each time the weakly constrained modes of a long loop amplify the CG-level differences: 2e-5 of the map size at the end
@@ -44,17 +51,44 @@ def test_large_graphs_match_oracle_attempt_by_attempt(ctx, oracle, seed, n):
     attempts are inexact Newton steps -- both sides take the same ones: same decisions, costs within 1e-9, states within 1e-8."""
     g = sp.make_loop(seed, n=n, radius=0.2 * n, edge_forward=False)
     for it in (1, 4):
-        Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=it, pcg_max_iters=300)
+        Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=it, pcg_max_iters=300, solver=1)
         assert (rg.iters, rg.accepted, rg.pcg_iters_total) == (ro.iters, ro.accepted, ro.pcg_iters_total) and rg.accepted == it
         assert abs(rg.cost_final - ro.cost_final) <= 1e-9 * ro.cost_final and rg.cost_final < rg.cost_init
         assert np.abs(Xg - Xo).max() <= 1e-8 * np.abs(Xo).max()
 
 
-def test_single_attempts_match_oracle(ctx, oracle):
+@pytest.mark.parametrize("seed,n,closures", [(8, 400, 3), (14, 1136, 4), (15, 700, 12)])
+def test_direct_solver_on_long_loops(ctx, oracle, seed, n, closures):
+    """The direct solver at keyframe-graph sizes (1136 nodes = the KITTI-00-length run): the oracle's CG is given the budget to
+    converge (1e-10), so both sides take the same Newton steps: same decisions, costs within 1e-8, states within 1e-6 of the map."""
+    g = sp.make_loop(seed, n=n, radius=0.3 * n, noise_t=0.02, noise_r=0.0005, n_closures=closures, edge_forward=False)
+    for it in (1, 5):
+        Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=it, pcg_max_iters=2000, solver=2)
+        assert (rg.iters, rg.accepted) == (ro.iters, ro.accepted) and rg.accepted == it and rg.pcg_iters_total == 0
+        assert abs(rg.cost_final - ro.cost_final) <= 1e-8 * ro.cost_final and rg.cost_final < rg.cost_init
+        assert np.abs(Xg - Xo).max() <= 1e-6 * np.abs(Xo).max()
+    Xg, rg, Xo, ro = both(ctx, oracle, g, pcg_max_iters=2000, solver=2)
+    assert abs(rg.iters - ro.iters) <= 2 and rg.stop_reason == ro.stop_reason and abs(rg.cost_final - ro.cost_final) <= 1e-6 * ro.cost_final
+
+
+def test_direct_solver_capacity_and_fallback(ctx, oracle):
+    """More edges off the tree than the direct solver takes: solver 0 falls back to CG (and still matches), solver 2 says so."""
+    from ssk_amd import capi
+    g = sp.make_loop(16, n=120, n_closures=50, edge_forward=False)
+    Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=2, pcg_max_iters=1000, solver=0)
+    assert rg.pcg_iters_total > 0 and (rg.iters, rg.accepted, rg.pcg_iters_total) == (ro.iters, ro.accepted, ro.pcg_iters_total)
+    with pytest.raises(RuntimeError, match="edges off the spanning tree"):
+        ctx.posegraph_optimize(g["init"], g["edge_ij"], g["edge_z"], prm=capi.PgParams(solver=2))
+    with pytest.raises(RuntimeError, match="solver"):
+        ctx.posegraph_optimize(g["init"], g["edge_ij"], g["edge_z"], prm=capi.PgParams(solver=7))
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_single_attempts_match_oracle(ctx, oracle, solver):
     """Attempt by attempt (max_iters = 1, 2, 3): the same accept / reject decisions and states."""
     g = sp.make_loop(11, n=40, edge_forward=False)
     for it in (1, 2, 3):
-        Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=it)
+        Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=it, solver=solver)
         assert (rg.iters, rg.accepted) == (ro.iters, ro.accepted) and abs(rg.cost_final - ro.cost_final) <= 1e-9 * ro.cost_final
         assert np.abs(Xg - Xo).max() <= 1e-8 * np.abs(Xo).max()
 
@@ -87,7 +121,8 @@ def test_golden_fixture(ctx):
     assert np.abs(X - g["exp_poses"]).max() <= 2e-5 * np.abs(g["exp_poses"]).max()
 
 
-def test_disconnected_components(ctx, oracle):
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_disconnected_components(ctx, oracle, solver):
     """Two loops that share no edge: the second one is not reached from the fixed node and starts its own spanning tree in the
     preconditioner (its gauge is only held by lambda); both sides take the same attempts."""
     a, b = sp.make_loop(21, n=20), sp.make_loop(22, n=24)
@@ -96,6 +131,6 @@ def test_disconnected_components(ctx, oracle):
     z = np.concatenate([a["edge_z"], b["edge_z"]])
     g = dict(init=init, edge_ij=ij, edge_z=z)
     for it in (1, 3, 6):
-        Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=it)
+        Xg, rg, Xo, ro = both(ctx, oracle, g, max_iters=it, solver=solver)
         assert (rg.iters, rg.accepted) == (ro.iters, ro.accepted) and abs(rg.cost_final - ro.cost_final) <= 1e-8 * ro.cost_final
         assert np.abs(Xg - Xo).max() <= 1e-7 * np.abs(Xo).max() and rg.cost_final < rg.cost_init
