@@ -177,6 +177,16 @@ __device__ __forceinline__ void mat6_vec(const double* __restrict__ A, const dou
 	}
 }
 
+// x = (L L^T)^-1 b with the reciprocal diagonal in li (the direct solver's sweeps: no divisions)
+__device__ __forceinline__ void chol6_solve_r(const double* __restrict__ L, const double* __restrict__ li, const double* b, double* x)
+{
+	double y[6];
+#pragma unroll
+	for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k]; y[i] = s * li[i]; }
+#pragma unroll
+	for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s * li[i]; }
+}
+
 // G6: S_k = D_k + lambda I - sum over children c of M_e S_c^-1 M_e, Cholesky factors into Lb; levels from the deepest up.
 // Returns through *s_ok (cleared when a block is not positive definite).
 __device__ void tree_factor(const pg_dev& G, const double* __restrict__ Dsrc, double lambda, int* s_ok)
@@ -197,13 +207,15 @@ __device__ void tree_factor(const pg_dev& G, const double* __restrict__ Dsrc, do
 					double mc[6], x[6], yv[6];
 #pragma unroll
 					for (int a = 0; a < 6; ++a) mc[a] = Me[6 * a + col];
-					chol6_solve(Lc, mc, x);
+					if (G.direct) chol6_solve_r(Lc, G.Li + 6 * (size_t)c, mc, x);      // (the CG path keeps the oracle's divisions)
+					else chol6_solve(Lc, mc, x);
 					mat6_vec(Me, x, yv);
 #pragma unroll
 					for (int a = 0; a < 6; ++a) Sk[6 * a + col] -= yv[a];
 				}
 			}
 			bool ok = true;
+			double li6[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
 			for (int j = 0; j < 6; ++j) {
 				double dj = Sk[6 * j + j];
@@ -211,10 +223,20 @@ __device__ void tree_factor(const pg_dev& G, const double* __restrict__ Dsrc, do
 				if (!(dj > 0.0)) { ok = false; dj = 1.0; }
 				const double l = sqrt(dj);
 				Sk[6 * j + j] = l;
-				for (int i = j + 1; i < 6; ++i) {
-					double sv = Sk[6 * i + j];
-					for (int c = 0; c < j; ++c) sv -= Sk[6 * i + c] * Sk[6 * j + c];
-					Sk[6 * i + j] = sv / l;
+				if (G.direct) {
+					const double rl = 1.0 / l;
+					li6[j] = rl;
+					for (int i = j + 1; i < 6; ++i) {
+						double sv = Sk[6 * i + j];
+						for (int c = 0; c < j; ++c) sv -= Sk[6 * i + c] * Sk[6 * j + c];
+						Sk[6 * i + j] = sv * rl;
+					}
+				} else {
+					for (int i = j + 1; i < 6; ++i) {
+						double sv = Sk[6 * i + j];
+						for (int c = 0; c < j; ++c) sv -= Sk[6 * i + c] * Sk[6 * j + c];
+						Sk[6 * i + j] = sv / l;
+					}
 				}
 			}
 			if (!ok) *s_ok = 0;
@@ -222,21 +244,11 @@ __device__ void tree_factor(const pg_dev& G, const double* __restrict__ Dsrc, do
 			for (int i = 0; i < 36; ++i) G.Lb[36 * (size_t)k + i] = Sk[i];
 			if (G.direct) {
 #pragma unroll
-				for (int a = 0; a < 6; ++a) G.Li[6 * (size_t)k + a] = 1.0 / Sk[7 * a];
+				for (int a = 0; a < 6; ++a) G.Li[6 * (size_t)k + a] = li6[a];
 			}
 		}
 		__syncthreads();
 	}
-}
-
-// x = (L L^T)^-1 b with the reciprocal diagonal in li (the direct solver's sweeps: no divisions)
-__device__ __forceinline__ void chol6_solve_r(const double* __restrict__ L, const double* __restrict__ li, const double* b, double* x)
-{
-	double y[6];
-#pragma unroll
-	for (int i = 0; i < 6; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k]; y[i] = s * li[i]; }
-#pragma unroll
-	for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s * li[i]; }
 }
 
 // W <- T^-1 W for all columns at once: thread `col` owns one column and walks the elimination order by itself -- deepest
