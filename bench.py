@@ -299,7 +299,7 @@ def main():
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -480,7 +480,7 @@ def main():
         ctx_lm.close()
     ctx.close()
     if dist.is_initialized():
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

@@ -84,6 +84,25 @@ def test_direct_solver_capacity_and_fallback(ctx, oracle):
 
 
 @pytest.mark.parametrize("solver", SOLVERS)
+def test_parallel_edges_and_edges_at_the_fixed_node(ctx, oracle, solver):
+    """Two constraints between the same pair of keyframes (one stays off the spanning tree between tree neighbours), closures
+    that end at the fixed node (they only add to a diagonal block) and a fixed node in the middle of the chain."""
+    g = sp.make_loop(17, n=48, n_closures=3, edge_forward=False)
+    rng = np.random.default_rng(3)
+    dup = [5, 20, 33]
+    ij = np.concatenate([g["edge_ij"], g["edge_ij"][dup]]).astype(np.int32)
+    z = np.concatenate([g["edge_z"], [sp.mul(g["edge_z"][k], sp.pose(sp.rotvec(rng.normal(0, 0.002, 3)), rng.normal(0, 0.03, 3))) for k in dup]])
+    from ssk_amd import capi
+    import oracle_lib as ol
+    for fixed in (0, 21):
+        for it in (1, 4):
+            Xg, rg = ctx.posegraph_optimize(g["init"], ij, z, fixed=fixed, prm=capi.PgParams(max_iters=it, solver=solver))
+            Xo, ro = oracle.pg_optimize(g["init"], ij, z, fixed=fixed, prm=ol.PgParams(max_iters=it))
+            assert (rg.iters, rg.accepted) == (ro.iters, ro.accepted) and abs(rg.cost_final - ro.cost_final) <= 1e-8 * ro.cost_final
+            assert np.abs(Xg - Xo).max() <= 1e-7 * np.abs(Xo).max() and np.array_equal(Xg[fixed], g["init"][fixed])
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
 def test_single_attempts_match_oracle(ctx, oracle, solver):
     """Attempt by attempt (max_iters = 1, 2, 3): the same accept / reject decisions and states."""
     g = sp.make_loop(11, n=40, edge_forward=False)
