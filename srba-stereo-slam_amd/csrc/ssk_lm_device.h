@@ -139,101 +139,242 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
 	return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* x_out, double* inv)
+// L'^T x = D^-1 z by ONE wave: lane k owns x_k (and x_{k+64} when TWO: 64 < n <= 128).  The caller has pre-scaled the matrix
+// (A(i,k) <- A(i,k) / d_k below the diagonal, 0 on and above it, border row included), so a row costs its loads -- issued a
+// block of 6 ahead -- plus the dependent chain v_readlane -> FMA; a single in-order wave pays ~9 cycles per dependent
+// instruction, so everything else (scaling, masks, address arithmetic on a runtime pitch) is kept out of this loop.
+template <bool TWO>
+__device__ __forceinline__ void ldl_backsub_wave(const double* A, int np, int n, double* x_out)
 {
-	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-	// blocked by the 6 columns of one edge (n = 6E): two barriers per block column instead of one per column
-	__shared__ int s_ldl_bad;
-	for (int c0 = 0; c0 < n; c0 += 6) {
-		__syncthreads();
-		// (1)+(2) by ONE wave (the others would only compete for issue slots with the same serial chain): the 6x6
-		// diagonal block factorised in every lane's registers (broadcast reads), then one lane per row below the block
-		// (the border row included) eliminates inside the block columns
-		if (tid < 64) {
-			double a[21], ivr[6];
+	const int tid = threadIdx.x;
+	const int k0 = tid, k1 = tid + 64;
+	const int q0 = min(k0, n - 1), q1 = min(k1, n - 1);     // lanes outside the system read a valid column; nobody reads them
+	double y0 = A[n * np + q0], y1 = TWO ? A[n * np + q1] : 0.0;
+	double cur[6][2], nxt[6][2];
+	const int nb = n / 6;
 #pragma unroll
-			for (int i = 0; i < 6; ++i)
-#pragma unroll
-				for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = A[(c0 + i) * np + c0 + k];
-			bool bad = false;
+	for (int j = 0; j < 6; ++j) {
+		const int i = 6 * (nb - 1) + j;
+		cur[j][0] = A[i * np + q0];
+		cur[j][1] = TWO ? A[i * np + q1] : 0.0;
+		nxt[j][0] = nxt[j][1] = 0.0;
+	}
+	for (int b = nb - 1; b >= 0; --b) {
+		if (b > 0) {
+			// the row addresses are rebuilt from b every time (the pitch made opaque): as strength-reduced loop registers
+			// they were spilled to scratch and every block waited for their reloads
+			int npv = np;
+			asm volatile("" : "+v"(npv));
 #pragma unroll
 			for (int j = 0; j < 6; ++j) {
-				const double d = a[j * (j + 1) / 2 + j];
-				bad |= !(d > 0.0);
-				ivr[j] = rcp_f64(d);
-#pragma unroll
-				for (int i = j + 1; i < 6; ++i) {
-					const double t = a[i * (i + 1) / 2 + j] * ivr[j];
-#pragma unroll
-					for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
-				}
+				const int i = 6 * (b - 1) + j;
+				nxt[j][0] = A[i * npv + q0];
+				if (TWO) nxt[j][1] = A[i * npv + q1];
 			}
-			for (int i = c0 + 6 + tid; i <= n; i += 64) {
-				double x[6];
+		}
 #pragma unroll
-				for (int k = 0; k < 6; ++k) x[k] = A[i * np + c0 + k];
+		for (int j = 5; j >= 0; --j) {
+			const int i = 6 * b + j;
+			double xi;
+			if (TWO) xi = i < 64 ? readlane_f64(y0, i) : readlane_f64(y1, i - 64);
+			else xi = readlane_f64(y0, i);
+			y0 -= cur[j][0] * xi;                         // coefficient 0 for k >= i: x_k (k >= i) is already final
+			if (TWO) y1 -= cur[j][1] * xi;
+		}
 #pragma unroll
-				for (int j = 0; j < 5; ++j) {
-					const double t = x[j] * ivr[j];
+		for (int j = 0; j < 6; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+	}
+	if (k0 < n) x_out[k0] = y0;
+	if (TWO && k1 < n) x_out[k1] = y1;
+}
+
+#ifdef SSK_LM_STAMPS
+__device__ unsigned long long g_ldl[4];
+#define LDL_T0() const unsigned long long ldl_t0_ = __builtin_amdgcn_s_memtime()
+#define LDL_ADD(i, who) do { if (threadIdx.x == (who) && blockIdx.x == 0) g_ldl[i] += __builtin_amdgcn_s_memtime() - ldl_t0_; } while (0)
+#else
+#define LDL_T0() do {} while (0)
+#define LDL_ADD(i, who) do {} while (0)
+#endif
+__device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* x_out, double* inv)
+{
+	const int tid = threadIdx.x;
+	// blocked by the 6 columns of one edge (n = 6E), with LOOK-AHEAD: while waves 1.. apply panel c0 to the columns
+	// beyond the next panel, wave 0 applies it to the next panel's 6 columns only, keeps its rows in registers, factorises
+	// the next 6x6 diagonal block (in every lane's registers, handed over by v_readlane) and eliminates inside those
+	// columns -- the serial part of a step runs beside the update instead of after it: ONE barrier per block column.
+	// Every element still receives the same operations in the same order as the step-by-step form.
+	__shared__ int s_ldl_bad;
+	if (tid < 64) {
+		// panel 0: the diagonal block by broadcast reads, then one lane per row below it (the border row included)
+		double a[21], ivr[6];
 #pragma unroll
-					for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+		for (int i = 0; i < 6; ++i)
+#pragma unroll
+			for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = A[i * np + k];
+		bool bad = false;
+#pragma unroll
+		for (int j = 0; j < 6; ++j) {
+			const double d = a[j * (j + 1) / 2 + j];
+			bad |= !(d > 0.0);
+			ivr[j] = rcp_f64(d);
+#pragma unroll
+			for (int i = j + 1; i < 6; ++i) {
+				const double t = a[i * (i + 1) / 2 + j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+			}
+		}
+		for (int i = 6 + tid; i <= n; i += 64) {
+			double x[6];
+#pragma unroll
+			for (int k = 0; k < 6; ++k) x[k] = A[i * np + k];
+#pragma unroll
+			for (int j = 0; j < 5; ++j) {
+				const double t = x[j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+			}
+#pragma unroll
+			for (int k = 1; k < 6; ++k) A[i * np + k] = x[k];
+		}
+		if (tid == 0) {
+			s_ldl_bad = bad;
+#pragma unroll
+			for (int i = 0; i < 6; ++i) {
+				inv[i] = ivr[i];
+#pragma unroll
+				for (int k = 0; k < i; ++k) A[i * np + k] = a[i * (i + 1) / 2 + k];
+			}
+		}
+	}
+	for (int c0 = 0; c0 < n; c0 += 6) {
+		__syncthreads();                                  // panel c0 complete; the update by panel c0 - 6 applied everywhere
+		if (s_ldl_bad) return false;                      // uniform
+		const int r0 = c0 + 6;
+		if (r0 >= n) break;
+		double iv[6];
+#pragma unroll
+		for (int c = 0; c < 6; ++c) iv[c] = inv[c0 + c];
+		LDL_T0();
+		if (tid < 64) {
+			// ---- wave 0: the next panel (columns r0 .. r0+5): update by panel c0, factorise, eliminate ----
+			double uk[6][6];                              // rows r0 .. r0+5 of panel c0 (broadcast reads)
+#pragma unroll
+			for (int k = 0; k < 6; ++k)
+#pragma unroll
+				for (int c = 0; c < 6; ++c) uk[k][c] = A[(r0 + k) * np + c0 + c];
+			double a[21], ivr[6];
+			bool bad = false;
+			for (int i0 = r0; i0 <= n; i0 += 64) {
+				const int i = i0 + tid;
+				const bool row = i <= n;
+				const int ic = row ? i : n;                   // loads are unconditional on a clamped row (a load under a lane
+				double x[6];                                  // condition is compiled as a branch that waits for it at once)
+				{
+					double ui[6], v[6];
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[c] = A[ic * np + c0 + c];
+#pragma unroll
+					for (int k = 0; k < 6; ++k) v[k] = A[ic * np + r0 + k];
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[c] *= iv[c];
+#pragma unroll
+					for (int k = 0; k < 6; ++k) {
+						const bool on = row && r0 + k <= i;          // the lower triangle (r0 + k < n always: no column n)
+						double sacc = 0.0;
+#pragma unroll
+						for (int c = 0; c < 6; ++c) sacc += ui[c] * uk[k][c];
+						x[k] = on ? v[k] - sacc : 0.0;
+					}
 				}
+				if (i0 == r0) {
+					// lanes 0..5 hold the updated rows of the next diagonal block: every lane takes a copy and factorises it
 #pragma unroll
-				for (int k = 1; k < 6; ++k) A[i * np + c0 + k] = x[k];
+					for (int r = 0; r < 6; ++r)
+#pragma unroll
+						for (int k = 0; k <= r; ++k) a[r * (r + 1) / 2 + k] = readlane_f64(x[k], r);
+#pragma unroll
+					for (int j = 0; j < 6; ++j) {
+						const double d = a[j * (j + 1) / 2 + j];
+						bad |= !(d > 0.0);
+						ivr[j] = rcp_f64(d);
+#pragma unroll
+						for (int r = j + 1; r < 6; ++r) {
+							const double t = a[r * (r + 1) / 2 + j] * ivr[j];
+#pragma unroll
+							for (int k = j + 1; k <= r; ++k) a[r * (r + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+						}
+					}
+				}
+				if (row && i >= r0 + 6) {
+#pragma unroll
+					for (int j = 0; j < 5; ++j) {
+						const double t = x[j] * ivr[j];
+#pragma unroll
+						for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+					}
+#pragma unroll
+					for (int k = 0; k < 6; ++k) A[i * np + r0 + k] = x[k];
+				}
 			}
 			if (tid == 0) {
 				s_ldl_bad = bad;
 #pragma unroll
-				for (int i = 0; i < 6; ++i) {
-					inv[c0 + i] = ivr[i];
+				for (int r = 0; r < 6; ++r) {
+					inv[r0 + r] = ivr[r];
 #pragma unroll
-					for (int k = 0; k < i; ++k) A[(c0 + i) * np + c0 + k] = a[i * (i + 1) / 2 + k];
+					for (int k = 0; k <= r; ++k) A[(r0 + r) * np + r0 + k] = a[r * (r + 1) / 2 + k];
 				}
 			}
+			LDL_ADD(0, 0);
+		} else {
+			// ---- waves 1..: A(i,k) -= sum_c U(i,c) U(k,c) / d_c for the columns beyond the next panel, r0+6 <= k <= min(i, n-1),
+			//      i <= n: 4 x 2 elements per thread and pass, loads before stores ----
+			constexpr int NR = (NT - 64) / 32;            // row groups of 32 lanes
+			const int t2 = tid - 64, ty = t2 >> 5, tx = t2 & 31;
+			const int q0 = r0 + 6;
+			for (int ib = q0 + ty; ib <= n; ib += 4 * NR)
+				for (int kb = q0 + tx; kb < n; kb += 64) {
+					// unconditional loads on clamped indices (see above); only the stores are predicated
+					double ui[4][6], uk[2][6], v[8];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const int i = min(ib + NR * u, n);
+#pragma unroll
+						for (int c = 0; c < 6; ++c) ui[u][c] = A[i * np + c0 + c];
+					}
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int k = min(kb + 32 * w, n - 1);
+#pragma unroll
+						for (int c = 0; c < 6; ++c) uk[w][c] = A[k * np + c0 + c];
+					}
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+#pragma unroll
+						for (int w = 0; w < 2; ++w) v[2 * u + w] = A[min(ib + NR * u, n) * np + min(kb + 32 * w, n - 1)];
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+#pragma unroll
+						for (int c = 0; c < 6; ++c) ui[u][c] *= iv[c];
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+#pragma unroll
+						for (int w = 0; w < 2; ++w) {
+							const int i = ib + NR * u, k = kb + 32 * w;
+							if (i <= n && k < n && k <= i) {
+								double sacc = 0.0;
+#pragma unroll
+								for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
+								A[i * np + k] = v[2 * u + w] - sacc;
+							}
+						}
+				}
+			LDL_ADD(1, 64);
 		}
 		__syncthreads();
-		if (s_ldl_bad) return false;                      // uniform
-		double iv[6];
-#pragma unroll
-		for (int c = 0; c < 6; ++c) iv[c] = inv[c0 + c];
-		// (3) trailing update A(i,k) -= sum_c U(i,c) U(k,c) / d_c, c0+6 <= k <= min(i, n-1), i <= n: 4 x 2 elements per
-		//     thread and pass, loads before stores
-		const int r0 = c0 + 6;
-		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
-			for (int kb = r0 + tx; kb < n; kb += 64) {
-				double ui[4][6], uk[2][6], v[8];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const int i = ib + (NT / 32) * u;
-#pragma unroll
-					for (int c = 0; c < 6; ++c) ui[u][c] = i <= n ? A[i * np + c0 + c] * iv[c] : 0.0;
-				}
-#pragma unroll
-				for (int w = 0; w < 2; ++w) {
-					const int k = kb + 32 * w;
-#pragma unroll
-					for (int c = 0; c < 6; ++c) uk[w][c] = k < n ? A[k * np + c0 + c] : 0.0;
-				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u)
-#pragma unroll
-					for (int w = 0; w < 2; ++w) {
-						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
-						v[2 * u + w] = (i <= n && k < n && k <= i) ? A[i * np + k] : 0.0;
-					}
-#pragma unroll
-				for (int u = 0; u < 4; ++u)
-#pragma unroll
-					for (int w = 0; w < 2; ++w) {
-						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
-						if (i <= n && k < n && k <= i) {
-							double sacc = 0.0;
-#pragma unroll
-							for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
-							A[i * np + k] = v[2 * u + w] - sacc;
-						}
-					}
-			}
+		LDL_ADD(2, 0);
 	}
 	__syncthreads();
 	if (n > 128) {
@@ -248,19 +389,17 @@ __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* 
 		}
 		return true;
 	}
+	// pre-scale for the back-substitution, all threads: A(i,k) <- A(i,k) / d_k for k < i (rows 1 .. n, the border row too), 0 elsewhere
+	for (int it = tid; it < (n + 1) * n; it += NT) {
+		const int i = it / n, k = it - i * n;
+		A[i * np + k] = k < i ? A[i * np + k] * inv[k] : 0.0;
+	}
+	__syncthreads();
+	LDL_T0();
 	if (tid < 64) {
-		const int k0 = tid, k1 = tid + 64;
-		const double i0 = k0 < n ? inv[k0] : 0.0, i1 = k1 < n ? inv[k1] : 0.0;
-		double y0 = k0 < n ? A[n * np + k0] * i0 : 0.0, y1 = k1 < n ? A[n * np + k1] * i1 : 0.0;
-		double c0 = k0 < n - 1 ? A[(n - 1) * np + k0] * i0 : 0.0, c1 = k1 < n - 1 ? A[(n - 1) * np + k1] * i1 : 0.0;
-		for (int i = n - 1; i > 0; --i) {
-			const double n0 = k0 < i - 1 ? A[(i - 1) * np + k0] * i0 : 0.0, n1 = k1 < i - 1 ? A[(i - 1) * np + k1] * i1 : 0.0;
-			const double xi = i < 64 ? readlane_f64(y0, i) : readlane_f64(y1, i - 64);
-			y0 -= c0 * xi; y1 -= c1 * xi;                 // c = 0 for k >= i: x_k (k >= i) is already final
-			c0 = n0; c1 = n1;
-		}
-		if (k0 < n) x_out[k0] = y0;
-		if (k1 < n) x_out[k1] = y1;
+		if (n <= 64) ldl_backsub_wave<false>(A, np, n, x_out);
+		else ldl_backsub_wave<true>(A, np, n, x_out);
+		LDL_ADD(3, 0);
 	}
 	__syncthreads();
 	return true;
