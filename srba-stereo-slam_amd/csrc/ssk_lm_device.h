@@ -467,26 +467,29 @@ __device__ __forceinline__ bool ldl_solve_global(double* __restrict__ A, int np,
 		if (s_ldl_bad_g) return false;                    // uniform
 		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
 			for (int kb = r0 + tx; kb < n; kb += 64) {
+				// unconditional loads on clamped indices (a load under a lane condition is compiled as a branch that waits for
+				// it at once); only the stores are predicated
 				double ui[4][6], uk[2][6], v[8];
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const int i = ib + (NT / 32) * u;
+					const int i = min(ib + (NT / 32) * u, n);
 #pragma unroll
-					for (int c = 0; c < 6; ++c) ui[u][c] = i <= n ? Pn[(i - r0) * 7 + c] * ivr[c] : 0.0;
+					for (int c = 0; c < 6; ++c) ui[u][c] = Pn[(i - r0) * 7 + c];
 				}
 #pragma unroll
 				for (int w = 0; w < 2; ++w) {
-					const int k = kb + 32 * w;
+					const int k = min(kb + 32 * w, n - 1);
 #pragma unroll
-					for (int c = 0; c < 6; ++c) uk[w][c] = k < n ? Pn[(k - r0) * 7 + c] : 0.0;
+					for (int c = 0; c < 6; ++c) uk[w][c] = Pn[(k - r0) * 7 + c];
 				}
 #pragma unroll
 				for (int u = 0; u < 4; ++u)
 #pragma unroll
-					for (int w = 0; w < 2; ++w) {
-						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
-						v[2 * u + w] = (i <= n && k < n && k <= i) ? A[(size_t)i * np + k] : 0.0;
-					}
+					for (int w = 0; w < 2; ++w) v[2 * u + w] = A[(size_t)min(ib + (NT / 32) * u, n) * np + min(kb + 32 * w, n - 1)];
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] *= ivr[c];
 #pragma unroll
 				for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -520,7 +523,7 @@ __device__ __forceinline__ bool ldl_solve_global(double* __restrict__ A, int np,
 		__syncthreads();
 		for (int t = tid; t < (hi - lo + 1) * n; t += NT) {
 			const int r = t / n, k = t - r * n, i = lo + r;
-			lds[r * n + k] = k < i ? A[(size_t)i * np + k] * inv[k] : 0.0;
+			{ const double av = A[(size_t)i * np + k] * inv[k]; lds[r * n + k] = k < i ? av : 0.0; }      // (unconditional load)
 		}
 		__syncthreads();
 		for (int i = hi; i >= lo; --i) {
@@ -599,26 +602,29 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 		if (s_ldl_bad_h) return false;                    // uniform
 		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
 			for (int kb = r0 + tx; kb < n; kb += 64) {
+				// unconditional loads on clamped indices (a load under a lane condition is compiled as a branch that waits for
+				// it at once); only the stores are predicated
 				double ui[4][6], uk[2][6], v[8];
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const int i = ib + (NT / 32) * u;
+					const int i = min(ib + (NT / 32) * u, n);
 #pragma unroll
-					for (int c = 0; c < 6; ++c) ui[u][c] = i <= n ? Pn[(i - r0) * 7 + c] * ivr[c] : 0.0;
+					for (int c = 0; c < 6; ++c) ui[u][c] = Pn[(i - r0) * 7 + c];
 				}
 #pragma unroll
 				for (int w = 0; w < 2; ++w) {
-					const int k = kb + 32 * w;
+					const int k = min(kb + 32 * w, n - 1);
 #pragma unroll
-					for (int c = 0; c < 6; ++c) uk[w][c] = k < n ? Pn[(k - r0) * 7 + c] : 0.0;
+					for (int c = 0; c < 6; ++c) uk[w][c] = Pn[(k - r0) * 7 + c];
 				}
 #pragma unroll
 				for (int u = 0; u < 4; ++u)
 #pragma unroll
-					for (int w = 0; w < 2; ++w) {
-						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
-						v[2 * u + w] = (i <= n && k < n && k <= i) ? A[(size_t)i * np + k] : 0.0;
-					}
+					for (int w = 0; w < 2; ++w) v[2 * u + w] = A[(size_t)min(ib + (NT / 32) * u, n) * np + min(kb + 32 * w, n - 1)];
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] *= ivr[c];
 #pragma unroll
 				for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -693,26 +699,32 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 		const int r0 = c0 + 6;
 		for (int ib = r0 + ty; ib <= m; ib += 4 * (NT / 32))
 			for (int kb = r0 + tx; kb < m; kb += 64) {
+				// unconditional loads on clamped indices; an (i, k) above the diagonal reads some other entry of the packed
+				// triangle (inside the allocation) and is never stored
 				double ui[4][6], uk[2][6], v[8];
 #pragma unroll
 				for (int u = 0; u < 4; ++u) {
-					const int i = ib + (NT / 32) * u;
+					const int i = min(ib + (NT / 32) * u, m);
 #pragma unroll
-					for (int c = 0; c < 6; ++c) ui[u][c] = i <= m ? SSK_PI(i, c0 + c) * iv[c] : 0.0;
+					for (int c = 0; c < 6; ++c) ui[u][c] = SSK_PI(i, c0 + c);
 				}
 #pragma unroll
 				for (int w = 0; w < 2; ++w) {
-					const int k = kb + 32 * w;
+					const int k = min(kb + 32 * w, m - 1);
 #pragma unroll
-					for (int c = 0; c < 6; ++c) uk[w][c] = k < m ? SSK_PI(k, c0 + c) : 0.0;
+					for (int c = 0; c < 6; ++c) uk[w][c] = SSK_PI(k, c0 + c);
 				}
 #pragma unroll
 				for (int u = 0; u < 4; ++u)
 #pragma unroll
 					for (int w = 0; w < 2; ++w) {
-						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
-						v[2 * u + w] = (i <= m && k < m && k <= i) ? SSK_PI(i, k) : 0.0;
+						const int i = min(ib + (NT / 32) * u, m), k = min(kb + 32 * w, m - 1);
+						v[2 * u + w] = SSK_PI(i, k);
 					}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] *= iv[c];
 #pragma unroll
 				for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -746,7 +758,7 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 		__syncthreads();
 		for (int t = tid; t < (hi - lo + 1) * n1; t += NT) {
 			const int r = t / n1, k = t - r * n1, i = lo + r;
-			lds[r * n1 + k] = k < i ? A[(size_t)i * np + k] * inv[k] : 0.0;
+			{ const double av = A[(size_t)i * np + k] * inv[k]; lds[r * n1 + k] = k < i ? av : 0.0; }      // (unconditional load)
 		}
 		__syncthreads();
 		for (int i = hi; i >= lo; --i) {
