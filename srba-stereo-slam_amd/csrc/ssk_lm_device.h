@@ -336,6 +336,7 @@ __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* 
 			const int q0 = r0 + 6;
 			for (int ib = q0 + ty; ib <= n; ib += 4 * NR)
 				for (int kb = q0 + tx; kb < n; kb += 64) {
+					if (kb - tx > ib - ty + 4 * NR - 1) break;       // the whole pass lies above the diagonal (uniform)
 					// unconditional loads on clamped indices (see above); only the stores are predicated
 					double ui[4][6], uk[2][6], v[8];
 #pragma unroll
@@ -467,6 +468,7 @@ __device__ __forceinline__ bool ldl_solve_global(double* __restrict__ A, int np,
 		if (s_ldl_bad_g) return false;                    // uniform
 		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
 			for (int kb = r0 + tx; kb < n; kb += 64) {
+				if (kb - tx > ib - ty + 4 * (NT / 32) - 1) break;    // the whole pass lies above the diagonal (uniform)
 				// unconditional loads on clamped indices (a load under a lane condition is compiled as a branch that waits for
 				// it at once); only the stores are predicated
 				double ui[4][6], uk[2][6], v[8];
@@ -602,6 +604,7 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 		if (s_ldl_bad_h) return false;                    // uniform
 		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
 			for (int kb = r0 + tx; kb < n; kb += 64) {
+				if (kb - tx > ib - ty + 4 * (NT / 32) - 1) break;    // the whole pass lies above the diagonal (uniform)
 				// unconditional loads on clamped indices (a load under a lane condition is compiled as a branch that waits for
 				// it at once); only the stores are predicated
 				double ui[4][6], uk[2][6], v[8];
@@ -699,6 +702,7 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 		const int r0 = c0 + 6;
 		for (int ib = r0 + ty; ib <= m; ib += 4 * (NT / 32))
 			for (int kb = r0 + tx; kb < m; kb += 64) {
+				if (kb - tx > ib - ty + 4 * (NT / 32) - 1) break;    // the whole pass lies above the diagonal (uniform)
 				// unconditional loads on clamped indices; an (i, k) above the diagonal reads some other entry of the packed
 				// triangle (inside the allocation) and is never stored
 				double ui[4][6], uk[2][6], v[8];
