@@ -273,11 +273,13 @@ __device__ __forceinline__ double slot_sum(const double* __restrict__ part, int 
 {
 	double s = 0.0;
 	for (int k = k0; k < k1; k += 8) {
+		// unconditional loads on a clamped slot (a load under a lane condition is compiled as a branch that waits for it at
+		// once: the eight loads were serialised L2 round trips), the padding selected afterwards
 		double v[8];
 #pragma unroll
-		for (int u = 0; u < 8; ++u) v[u] = k + u < k1 ? part[36 * (size_t)(k + u) + ab] : 0.0;
+		for (int u = 0; u < 8; ++u) v[u] = part[36 * (size_t)min(k + u, k1 - 1) + ab];
 #pragma unroll
-		for (int u = 0; u < 8; ++u) s += v[u];
+		for (int u = 0; u < 8; ++u) s += k + u < k1 ? v[u] : 0.0;
 	}
 	return s;
 }
@@ -563,10 +565,18 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 		const int comp = it >> 3, j = it & 7, e = comp / 6, a = comp - e * 6;
 		const int k0 = D.el_off[W.uso0 + e], k1 = D.el_off[W.uso0 + e + 1];
 		const double* src = D.gre + 6 * (size_t)W.el0 + a;
+		// s0 takes the elements k0 + j + 16 m, s1 the elements k0 + j + 8 + 16 m (below k1), each in ascending order; four
+		// unconditional loads on clamped indices in flight per turn, the padding selected to +0.0 afterwards
 		double s0 = 0, s1 = 0;
-		int k = k0 + j;
-		for (; k + 8 < k1; k += 16) { s0 += src[6 * (size_t)k]; s1 += src[6 * (size_t)(k + 8)]; }
-		if (k < k1) s0 += src[6 * (size_t)k];
+		for (int k = k0 + j; k < k1; k += 32) {
+			double v[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) v[u] = src[6 * (size_t)min(k + 8 * u, k1 - 1)];
+			s0 += v[0];
+			s1 += k + 8 < k1 ? v[1] : 0.0;
+			s0 += k + 16 < k1 ? v[2] : 0.0;
+			s1 += k + 24 < k1 ? v[3] : 0.0;
+		}
 		double v = s0 + s1;
 		v += __shfl_down(v, 4, 8); v += __shfl_down(v, 2, 8); v += __shfl_down(v, 1, 8);
 		if (j == 0) A[n6 * np + comp] = v;
