@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="keyframes per GPU per step (256: 67.3 k, 512: 70.1 k, 1024: 71.5 k keyframes/s on one MI355X)")
+    ap.add_argument("--batch", type=int, default=1024, help="keyframes per GPU per step (256: 67.3 k, 512: 70.1 k, 1024: 72.7 k keyframes/s on one MI355X)")
     ap.add_argument("--cpu-sample", type=int, default=128, help="keyframes timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the all-cores CPU baseline (-1: half the host's logical cores, at most 64; 0 = skip)")
