@@ -117,9 +117,9 @@ __device__ void so3_exp(const double* w, double* R)
 // G (fast path): the reduced system solved in LDS as a square-root-free LDL^T of the matrix bordered by the
 // right-hand side (row n = g_red^T), right-looking, by the whole workgroup:
 //   A(i,k) -= A(i,j) A(k,j) / d_j   for j < k <= i <= n; column j itself stays unscaled (U_ij = L'_ij d_j), d_j = A(j,j)
-//   when its turn comes.  Blocked by the 6 columns of an edge: one wave factorises the 6x6 diagonal block in
-//   registers and finishes the panel (a lane per row), then the whole workgroup applies the rank-6 update: two
-//   barriers per block column.
+//   when its turn comes.  Blocked by the 6 columns of an edge, with look-ahead: wave 0 applies the current panel to the
+//   next panel's columns, factorises that 6x6 diagonal block in registers and finishes the panel (a lane per row) while
+//   the other waves apply the current panel to the remaining columns: one barrier per block column.
 // The border row comes out as z = L'^-1 b (forward substitution for free), so only L'^T x = D^-1 z is left: one
 // wavefront keeps x in registers (lane k owns x_k, x_{k+64}), broadcasts x_i with v_readlane and prefetches row
 // i-1 of U while it applies row i, so the dependent chain per step is one readlane + one FMA.
