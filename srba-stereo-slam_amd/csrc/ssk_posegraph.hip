@@ -251,6 +251,63 @@ __device__ void tree_factor(const pg_dev& G, const double* __restrict__ Dsrc, do
 	}
 }
 
+// tree_factor for the direct solver (Dt, reciprocal diagonals): EIGHT lanes per node, lane s < 6 owns column s of S_k, so the six
+// triangular solves + products of a child run side by side instead of one after the other in a single thread (a chain-like tree has
+// one or two nodes per level: the serial work per node is what a factorisation costs).  The block is then handed to every lane of
+// the group by shuffles and factorised redundantly; lane 0 stores.  Same operations per entry as tree_factor.
+__device__ void tree_factor_direct(const pg_dev& G, double lambda, int* s_ok)
+{
+	const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3, col = sub < 6 ? sub : 5;
+	for (int lvl = G.n_lvl - 1; lvl >= 0; --lvl) {
+		for (int idx = G.lvl_off[lvl] + grp; idx < G.lvl_off[lvl + 1]; idx += PG_NT / 8) {
+			const int k = G.order[idx];
+			double sc[6];
+#pragma unroll
+			for (int a = 0; a < 6; ++a) sc[a] = G.Dt[36 * (size_t)k + 6 * a + col] + (a == col ? lambda : 0.0);
+			for (int t = G.ch_off[k]; t < G.ch_off[k + 1]; ++t) {
+				const int c = G.ch[t];
+				const double* Me = G.M + 36 * (size_t)G.par_e[c];
+				double mc[6], x[6], yv[6];
+#pragma unroll
+				for (int a = 0; a < 6; ++a) mc[a] = Me[6 * a + col];
+				chol6_solve_r(G.Lb + 36 * (size_t)c, G.Li + 6 * (size_t)c, mc, x);
+				mat6_vec(Me, x, yv);
+#pragma unroll
+				for (int a = 0; a < 6; ++a) sc[a] -= yv[a];
+			}
+			double Sk[36];
+#pragma unroll
+			for (int a = 0; a < 6; ++a)
+#pragma unroll
+				for (int b = 0; b < 6; ++b) Sk[6 * a + b] = __shfl(sc[a], b, 8);
+			bool ok = true;
+			double li6[6];
+#pragma unroll
+			for (int j = 0; j < 6; ++j) {
+				double dj = Sk[6 * j + j];
+				for (int c = 0; c < j; ++c) dj -= Sk[6 * j + c] * Sk[6 * j + c];
+				if (!(dj > 0.0)) { ok = false; dj = 1.0; }
+				const double l = sqrt(dj), rl = 1.0 / l;
+				Sk[6 * j + j] = l;
+				li6[j] = rl;
+				for (int i = j + 1; i < 6; ++i) {
+					double sv = Sk[6 * i + j];
+					for (int c = 0; c < j; ++c) sv -= Sk[6 * i + c] * Sk[6 * j + c];
+					Sk[6 * i + j] = sv * rl;
+				}
+			}
+			if (sub == 0) {
+				if (!ok) *s_ok = 0;
+#pragma unroll
+				for (int i = 0; i < 36; ++i) G.Lb[36 * (size_t)k + i] = Sk[i];
+#pragma unroll
+				for (int a = 0; a < 6; ++a) G.Li[6 * (size_t)k + a] = li6[a];
+			}
+		}
+		__syncthreads();
+	}
+}
+
 // W <- T^-1 W for all columns at once: thread `col` owns one column and walks the elimination order by itself -- deepest
 // nodes first on the way up (t_k = S_k^-1 y_k, y_parent += M_e t_k), parents first on the way down (z_k = t_k + S_k^-1 M_e z_p).
 // No barrier: a column never reads another column.  Rows of the fixed node are never touched (they stay 0).
@@ -293,7 +350,7 @@ __device__ void direct_step(const pg_dev& G, double lambda, int* s_ok)
 {
 	const int tid = threadIdx.x;
 	const int ns = 6 * G.n_nt, nc = G.n_col, n_free = G.lvl_off[G.n_lvl];
-	tree_factor(G, G.Dt, lambda, s_ok);
+	tree_factor_direct(G, lambda, s_ok);
 	if (!*s_ok) return;                                  // uniform: tree_factor ends with a barrier
 	// right-hand sides: column 6 q + a = U_e[:, a] = +J_e[a, :] on node j, -J_e[a, :] on node i (edge e = nt_edge[q]); last = -g
 	for (size_t k = tid; k < (size_t)6 * G.n * nc; k += PG_NT) G.W[k] = 0.0;
