@@ -8,11 +8,14 @@
 //     decide insert_in potential lc_id voForce updated_th up_plus maxT maxR n {kf_idx tracked}*n
 //                                                                                    -> insert confirmed updated highest maxT maxR n sorted...
 //     thr x th                                                                        -> translation rotation
+//   policy_tool options <kitti|default>            the preset of TSRBAStereoSLAMOptions as `key value` lines (tests/test_kitti_ini.py
+//                                                  compares the kitti preset with the reference's demo/config_imgdir_kitti_srba.ini)
 #include <cstdio>
 #include <iostream>
 #include <sstream>
 #include "ssk_bow_vocab_io.h"
 #include "ssk_kf_policy.h"
+#include "srba_stereo_slam_options.h"
 
 using namespace ssk;
 
@@ -79,9 +82,40 @@ static int do_policy()
 	return 0;
 }
 
+static int do_options(const std::string& preset)
+{
+	if (preset != "kitti" && preset != "default") return 1;
+	const TSRBAStereoSLAMOptions o = preset == "kitti" ? TSRBAStereoSLAMOptions::kitti() : TSRBAStereoSLAMOptions();
+#define P(k, v) std::printf("%s %.17g\n", k, (double)(v))
+	P("n_levels", o.n_levels); P("n_feats", o.n_feats); P("detect_fast_th", o.detect_fast_th);
+	P("adaptive_th_min_matches", o.adaptive_th_min_matches); P("orb_adaptive_fast_th", o.orb_adaptive_fast_th);
+	P("non_maximal_suppression", o.non_maximal_suppression); P("nms_min_distance", o.nms_min_distance);
+	P("max_y_diff", o.max_y_diff); P("orb_max_distance", o.orb_max_distance);
+	P("ransac_fit_prob", o.ransac_fit_prob); P("max_y_diff_epipolar", o.max_y_diff_epipolar); P("max_orb_distance_da", o.max_orb_distance_da);
+	P("da_filter_by_direction", o.da_filter_by_direction); P("da_filter_by_orb_distance", o.da_filter_by_orb_distance);
+	P("da_filter_by_fund_matrix", o.da_filter_by_fund_matrix); P("da_filter_by_pose_change", o.da_filter_by_pose_change);
+	P("residual_th", o.residual_th);
+	P("ls_initial_max_iters", o.ls_initial_max_iters); P("ls_max_iters", o.ls_max_iters); P("ls_max_incr_cost", o.ls_max_incr_cost);
+	P("ls_bad_tracking_th", o.ls_bad_tracking_th); P("ls_residual_threshold", o.ls_residual_threshold);
+	P("ls_min_mod_out_vector", o.ls_min_mod_out_vector); P("ls_kernel_param", o.ls_kernel_param); P("ls_use_robust_kernel", o.ls_use_robust_kernel);
+	P("use_initial_pose", o.use_initial_pose);
+	P("srba_kernel_param", o.srba_kernel_param); P("srba_use_robust_kernel", o.srba_use_robust_kernel);
+	P("srba_use_robust_kernel_stage1", o.srba_use_robust_kernel_stage1);
+	P("srba_submap_size", o.srba_submap_size); P("srba_max_tree_depth", o.srba_max_tree_depth); P("srba_max_optimize_depth", o.srba_max_optimize_depth);
+	P("updated_matches_th", o.updated_matches_th); P("up_matches_th_plus", o.up_matches_th_plus); P("lc_distance", o.lc_distance);
+	P("max_rotation", o.max_rotation); P("max_translation", o.max_translation); P("vo_id_tracking_th", o.vo_id_tracking_th);
+	const TStereoCamera& c = o.stereo_camera;
+	P("fx_l", c.fx_l); P("fy_l", c.fy_l); P("cx_l", c.cx_l); P("cy_l", c.cy_l);
+	P("fx_r", c.fx_r); P("fy_r", c.fy_r); P("cx_r", c.cx_r); P("cy_r", c.cy_r); P("baseline", c.baseline); P("ncols", c.ncols); P("nrows", c.nrows);
+	for (int i = 0; i < 12; ++i) { char k[32]; std::snprintf(k, sizeof k, "camera_pose_on_robot_rvt_%d", i); P(k, o.camera_pose_on_robot_rvt.m[i]); }
+#undef P
+	return 0;
+}
+
 int main(int argc, char** argv)
 {
 	try {
+		if (argc == 3 && std::string(argv[1]) == "options") return do_options(argv[2]);
 		if (argc == 4 && std::string(argv[1]) == "vocab") return do_vocab(argv[2], argv[3]);
 		if (argc == 2 && std::string(argv[1]) == "policy") return do_policy();
 	} catch (const std::exception& e) {
