@@ -235,6 +235,9 @@ def main():
     exchange = os.environ.get("SSK_BENCH_EXCHANGE_ALWAYS") == "1"
     rank, world = pkg.dist.init_from_env("nccl", always=exchange)       # one process per GPU, RCCL
     exchange = exchange or world > 1
+    if args.gpus != world:
+        # the driver launches N > 1 through torch.distributed.run with the same --gpus N: a mismatch is a mis-launch
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d (launch N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (args.gpus, world))
     from ssk_amd import capi
     import synth_lm as sl
 

@@ -132,8 +132,8 @@ float ssko_harris_response(const uint8_t* img, int stride, int x, int y, float h
 			c += Ix * Iy;
 		}
 	const float scale = 1.0f / (4.0f * 7.0f * 255.0f);
-	const float s2 = scale * scale;
-	const float s4 = s2 * s2;
+	const float s3 = (scale * scale) * scale;          /* cv::ORB HarrisResponses: scale * scale * scale * scale, left to right */
+	const float s4 = s3 * scale;
 	const float fa = (float)a, fb = (float)b, fc = (float)c;
 	const float t1 = fa * fb;
 	const float t2 = fc * fc;

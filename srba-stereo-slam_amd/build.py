@@ -33,8 +33,11 @@ def _sources():
 def _stamp(src):
     h = hashlib.sha1()
     h.update(" ".join(FLAGS).encode())
-    for f in [src] + sorted(x for x in os.listdir(CSRC) if x.endswith(".h")) + ["../../include/ssk_capi.h"]:
-        with open(os.path.join(CSRC, f), "rb") as fh:
+    inc = os.path.join(ROOT, "include")
+    files = [os.path.join(CSRC, f) for f in [src] + sorted(x for x in os.listdir(CSRC) if x.endswith(".h"))]
+    files += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]     # every public header (ssk_brief_pattern.h too)
+    for f in files:
+        with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
 

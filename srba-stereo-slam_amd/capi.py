@@ -588,9 +588,12 @@ class LmBatch:
     def pack_shared(self, w, n_shared, d_out):
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_pack_shared(self.ctx.h, self.h_, int(w), int(n_shared), _dev(d_out)))
 
-    def results(self):
+    def results(self, check=True):
+        """check=False: the per-window records as the call filled them even when it reports an error (stop_reason 5)."""
         out = (LmResult * self.n)()
-        self.ctx._chk(self.ctx.lib.ssk_lm_batch_results(self.ctx.h, self.h_, out))
+        rc = self.ctx.lib.ssk_lm_batch_results(self.ctx.h, self.h_, out)
+        if check:
+            self.ctx._chk(rc)
         return list(out)
 
     def state(self, w):

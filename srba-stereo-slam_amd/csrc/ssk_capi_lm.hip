@@ -23,6 +23,11 @@ struct ssk_lm_batch {
 	int max_tiles = 0;                // most tiles of a window (cooperative kernel: workgroups per window)
 	bool has_general = false;         // the general kernel's structures were built too
 	size_t tiled_dyn_bytes = 0;       // its dynamic LDS size
+	// cooperative launch in flight: the state it started from (pose_bak / lm_bak) and its parameters, so that a launch whose
+	// workgroups were not all resident (stop_reason 5) is repeated with one workgroup per window by ssk_lm_batch_results
+	bool coop_pending = false;
+	lm_cam coop_P{};
+	double* pose_bak = nullptr; double* lm_bak = nullptr;
 };
 
 namespace {
@@ -693,6 +698,8 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (!rc) rc = scratch(b, trace ? (size_t)n_windows * MAX_ITERS_ALLOC : 1, &D.trace);
 	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
+	if (!rc) rc = scratch(b, pose.size(), &b->pose_bak);
+	if (!rc) rc = scratch(b, lm.size(), &b->lm_bak);
 	D.trace_on = trace ? 1 : 0;
 	if (!rc) rc = finalize(b);
 	if (rc) { ssk_lm_batch_destroy(b); return rc; }
@@ -739,10 +746,23 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	const char* force = std::getenv("SSK_LM_KERNEL");
 	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
 	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
-	if (b->tiled_ok && !b->trace && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
-		int G = std::min(std::min(b->max_tiles, 64), ctx->n_cu / std::max(b->n_windows, 1));
+	b->coop_pending = false;
+	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
+		// the grid barrier of the cooperative kernel needs all n_windows * G workgroups resident: G from what the occupancy
+		// query says one CU holds with this launch's LDS, not from the CU count alone
+		const int per_cu = ssk_lm_coop_blocks_per_cu(ctx, b->tiled_dyn_bytes);
+		int G = std::min(std::min(b->max_tiles, 64), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
 		const bool want = force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu);
-		if (want) return ssk_lm_launch_coop(ctx, b->D, P, b->n_windows, G, b->tiled_dyn_bytes);
+		if (want) {
+			// residency is still not guaranteed (another stream or process may hold CUs): keep the state the launch starts
+			// from, ssk_lm_batch_results repeats a launch that ended in stop_reason 5 with one workgroup per window
+			SSK_HIP(ctx, hipMemcpyAsync(b->pose_bak, b->D.pose, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
+			SSK_HIP(ctx, hipMemcpyAsync(b->lm_bak, b->D.lm, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
+			const bool test_timeout = std::getenv("SSK_LM_COOP_TEST_TIMEOUT") != nullptr;
+			const int rc = ssk_lm_launch_coop(ctx, b->D, P, b->n_windows, G, b->tiled_dyn_bytes, test_timeout);
+			if (rc == SSK_OK) { b->coop_pending = true; b->coop_P = P; }
+			return rc;
+		}
 	}
 	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes);
 	if (!b->has_general) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: the batch was built without the general kernel's structures");
@@ -756,6 +776,23 @@ int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out)
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	SSK_HIP(ctx, hipMemcpy(out, b->D.res, sizeof(ssk_lm_result) * (size_t)b->n_windows, hipMemcpyDeviceToHost));
+	bool timed_out = false;
+	for (int w = 0; w < b->n_windows; ++w) timed_out |= out[w].stop_reason == 5;
+	if (timed_out && b->coop_pending && !std::getenv("SSK_LM_COOP_NO_FALLBACK")) {
+		// a cooperative launch whose workgroups did not all arrive at a barrier: back to the state it started from and the same
+		// solve with one workgroup per window (no cross-workgroup barrier, same contract)
+		b->coop_pending = false;
+		static const bool verbose = std::getenv("SSK_LM_DEBUG") != nullptr;
+		if (verbose) std::fprintf(stderr, "[ssk lm] cooperative launch timed out at a barrier: repeating with one workgroup per window\n");
+		SSK_HIP(ctx, hipMemcpyAsync(b->D.pose, b->pose_bak, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
+		SSK_HIP(ctx, hipMemcpyAsync(b->D.lm, b->lm_bak, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
+		int rc = ssk_lm_launch_tiled(ctx, b->D, b->coop_P, b->n_windows, b->tiled_dyn_bytes);
+		if (rc) return rc;
+		SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		SSK_HIP(ctx, hipMemcpy(out, b->D.res, sizeof(ssk_lm_result) * (size_t)b->n_windows, hipMemcpyDeviceToHost));
+		return SSK_OK;
+	}
+	b->coop_pending = false;
 	for (int w = 0; w < b->n_windows; ++w)
 		if (out[w].stop_reason == 5)
 			return ssk_set_error(ctx, SSK_ERR_HIP, "ssk_lm_batch_results: window %d: the cooperative kernel's workgroups did not all arrive at a barrier "

@@ -118,5 +118,6 @@ constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024 / SSK_LMT_WG_PER_CU;   // gfx950: 1
 constexpr int SSK_LMT_STATIC = 1024;               // reserve for the kernel's static LDS (a few scalars and the wave partials)
 int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes);
 // G workgroups per window (n_windows * G <= number of CUs, G <= 64): single large windows of the un-batched drop-in path
-int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes);
+int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout = false);
+int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes);
 int ssk_lm_launch_reset(ssk_ctx* ctx, double* pose, const double* pose0, size_t n_pose, double* lm, const double* lm0, size_t n_lm);

@@ -231,7 +231,9 @@ __device__ double total_error_packed(const lm_dev& D, const lm_win& W, const lm_
 // before it reads what the others wrote.  All G workgroups are resident (the host launches at most one per CU).  A wait that
 // outlasts COOP_SPIN_LIMIT polls raises the window's abort flag and every workgroup leaves (stop_reason 5).
 constexpr int COOP_SPIN_LIMIT = 1 << 22;
-struct coop_t { int* cnt; int* abort; double* f; int g, G, round, bank; };
+// `expect` = arrivals that complete a barrier round (= G; the forced-timeout test hook of ssk_lm_launch_coop passes G + 1, an
+// arrival that never comes) and `spin_limit` = polls before a waiting workgroup gives up
+struct coop_t { int* cnt; int* abort; double* f; int g, G, round, bank, expect, spin_limit; };
 
 __device__ __forceinline__ bool coop_barrier(coop_t& c)
 {
@@ -241,9 +243,9 @@ __device__ __forceinline__ bool coop_barrier(coop_t& c)
 		++c.round;
 		__hip_atomic_fetch_add(c.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		int spins = 0;
-		while (__hip_atomic_load(c.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < c.round * c.G) {
+		while (__hip_atomic_load(c.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < c.round * c.expect) {
 			__builtin_amdgcn_s_sleep(8);
-			if (++spins > COOP_SPIN_LIMIT || __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+			if (++spins > c.spin_limit || __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
 				__hip_atomic_store(c.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				break;
 			}
@@ -595,7 +597,7 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 }
 
 template <bool COOP>
-__device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, int dyn_doubles, int G)
+__device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, int dyn_doubles, int G, int coop_expect = 1, int coop_spin_limit = COOP_SPIN_LIMIT)
 {
 	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | delta | pivots | tile records / reduced system]
 	__shared__ double s_part[NW];
@@ -609,7 +611,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	const int tid = threadIdx.x;
 	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1;
 	int epoch = 0;                                     // tiles started so far
-	coop_t co = {COOP ? D.coop_i + 4 * wi : nullptr, COOP ? D.coop_i + 4 * wi + 1 : nullptr, COOP ? D.coop_f + 128 * (size_t)wi : nullptr, g, GG, 0, 0};
+	coop_t co = {COOP ? D.coop_i + 4 * wi : nullptr, COOP ? D.coop_i + 4 * wi + 1 : nullptr, COOP ? D.coop_f + 128 * (size_t)wi : nullptr, g, GG, 0, 0, coop_expect, coop_spin_limit};
 	bool alive = true;
 	(void)alive;
 	double* pose_cur = s_dyn;
@@ -751,6 +753,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 #pragma unroll
 				for (int a = 0; a < 3; ++a) {
 					D.df[3 * (size_t)(W.ls0 + l) + a] = d3[a];
+					if (D.trace_on) D.df_trace[W.df_trace0 + (size_t)it_idx * 3 * W.L + 3 * l + a] = d3[a];
 					dfn += d3[a] * d3[a];
 					D.lm_new[3 * (size_t)(W.lm0 + li_idx) + a] = D.lm[3 * (size_t)(W.lm0 + li_idx) + a] + d3[a];
 				}
@@ -771,13 +774,12 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 					O[4 * i + 3] = R[3 * i] * T[3] + R[3 * i + 1] * T[7] + R[3 * i + 2] * T[11] + eps[i];
 				}
 			}
-			if (D.trace_on)
+			if (D.trace_on && g == 0)
 				for (int i = tid; i < n6; i += NT) D.dp_trace[W.dp_trace0 + (size_t)it_idx * n6 + i] = s_b[i];
 		}
 		dpn = block_sum(dpn, s_part);
 		dfn = block_sum(dfn, s_part);
-		if (ok && D.trace_on)
-			for (int i = tid; i < 3 * W.L; i += NT) D.df_trace[W.df_trace0 + (size_t)it_idx * 3 * W.L + i] = D.df[3 * (size_t)W.ls0 + i];
+		if (COOP && D.trace_on) dfn = coop_combine<false>(co, dfn, alive);      // (the trace entry reports the whole step's norm)
 		STAMP(7);
 		// ---- I ----
 		double err_new = s_err;
@@ -859,14 +861,25 @@ void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 
 // G workgroups per window (grid = n_windows * G, all resident)
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
-void lm_solve_coop_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G)
+void lm_solve_coop_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G, int expect, int spin_limit)
 {
-	lm_tiled_body<true>(D, P, dyn_doubles, G);
+	lm_tiled_body<true>(D, P, dyn_doubles, G, expect, spin_limit);
 }
 
 }  // namespace
 
-int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes)
+// How many workgroups of the cooperative kernel one CU can hold with this much dynamic LDS (0 on error): the hand-rolled grid
+// barrier needs every workgroup of a window resident at once, so the caller sizes G from this, not from the CU count alone.
+int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes)
+{
+	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
+	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC);
+	int n = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(lm_solve_coop_kernel), NT, dyn_lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return n;
+}
+
+int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
 	static bool attr_set = false;
@@ -877,7 +890,10 @@ int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_win
 	}
 	SSK_HIP(ctx, hipMemsetAsync(D.coop_i, 0, sizeof(int) * 4 * (size_t)n_windows, ctx->stream));
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
-	hipLaunchKernelGGL(lm_solve_coop_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G);
+	// test_timeout (SSK_LM_COOP_TEST_TIMEOUT=1): every barrier waits for an arrival that never comes and gives up quickly, the
+	// path a workgroup takes when a co-tenant of the GPU keeps one of its partners from being scheduled
+	hipLaunchKernelGGL(lm_solve_coop_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
+	                   test_timeout ? G + 1 : G, test_timeout ? 1 << 10 : COOP_SPIN_LIMIT);
 	SSK_LAUNCH_CHECK(ctx, "lm_solve_coop_kernel");
 	return SSK_OK;
 }

@@ -65,8 +65,8 @@ __device__ float harris_response(const uint8_t* __restrict__ img, int pitch, int
 			a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
 		}
 	const float scale = 1.0f / (4.0f * 7.0f * 255.0f);
-	const float s2 = __fmul_rn(scale, scale);
-	const float s4 = __fmul_rn(s2, s2);
+	// scale_sq_sq = scale * scale * scale * scale, left to right as cv::ORB's HarrisResponses writes it (not (s*s)*(s*s): 1 ulp apart)
+	const float s4 = __fmul_rn(__fmul_rn(__fmul_rn(scale, scale), scale), scale);
 	const float fa = (float)a, fb = (float)b, fc = (float)c;
 	const float t1 = __fmul_rn(fa, fb);
 	const float t2 = __fmul_rn(fc, fc);

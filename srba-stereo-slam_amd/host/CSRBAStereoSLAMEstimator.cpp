@@ -80,6 +80,14 @@ void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& 
 		m_ctx.check(ssk_da_change_in_pose(m_ctx.get(), &a, &b, matches.data(), status.data(), (other_seen_from_this ? *other_seen_from_this : identity).m,
 		                                  &cp, nullptr, &cr), "m_detect_outliers_with_change_in_pose");
 		if (out_cip) *out_cip = cr;
+	} else if (out_cip) {
+		// the odometry stand-in asks for the pose estimate whatever da_stage2_method says (stereo-vo estimates its incremental
+		// pose independently of the SLAM-side filters): the same estimator on a COPY of the statuses, so that it filters nothing
+		std::vector<int32_t> st2(status);
+		const ssk_cip_params cp = srba_options.cip();
+		const Pose3D identity;
+		m_ctx.check(ssk_da_change_in_pose(m_ctx.get(), &a, &b, matches.data(), st2.data(), (other_seen_from_this ? *other_seen_from_this : identity).m,
+		                                  &cp, nullptr, out_cip), "m_vo_process: incremental pose");
 	}
 	for (size_t k = 0; k < n; ++k)                                                       // :1657-1669
 		if (status[k] == SSK_DA_TRACKED) {

@@ -27,7 +27,8 @@ inline bool dump_keypoints(std::ostream& s, const TKeyPointList& kp, const DescM
 		put(s, kp[f].x); put(s, kp[f].y); put(s, kp[f].response); put(s, kp[f].size); put(s, kp[f].angle);
 		put(s, kp[f].octave); put(s, kp[f].class_id);
 	}
-	put<int32_t>(s, desc.rows); put<int32_t>(s, 32); put<int32_t>(s, 0 /* CV_8U */);
+	// descriptors.rows / .cols / .type() of the cv::Mat (EST.cpp:2470-2474): an empty Mat has cols = 0
+	put<int32_t>(s, desc.rows); put<int32_t>(s, desc.rows > 0 ? 32 : 0); put<int32_t>(s, 0 /* CV_8U */);
 	if (!desc.data.empty()) s.write(reinterpret_cast<const char*>(desc.data.data()), (std::streamsize)desc.data.size());
 	return (bool)s;
 }
@@ -42,7 +43,9 @@ inline bool load_keypoints(std::istream& s, TKeyPointList& kp, DescMat& desc)
 		if (!(get(s, kp[f].x) && get(s, kp[f].y) && get(s, kp[f].response) && get(s, kp[f].size) && get(s, kp[f].angle) &&
 		      get(s, kp[f].octave) && get(s, kp[f].class_id))) return false;
 	int32_t rows = 0, cols = 0, type = 0;
-	if (!(get(s, rows) && get(s, cols) && get(s, type)) || rows < 0 || cols != 32 || type != 0) return false;
+	// a side with no keypoints was written from an empty cv::Mat: rows = cols = 0 (and whatever type() an empty Mat reports)
+	if (!(get(s, rows) && get(s, cols) && get(s, type)) || rows < 0) return false;
+	if (rows > 0 ? (cols != 32 || type != 0) : (cols != 0 && cols != 32)) return false;
 	desc.create(rows);
 	if (rows) s.read(reinterpret_cast<char*>(desc.data.data()), (std::streamsize)desc.data.size());
 	return (bool)s;

@@ -27,7 +27,7 @@ def parse(buf):
         n = int(take("<u8")[0])
         rec["kp_" + eye] = take(KP, n).copy()
         rows, cols, typ = take("<i4", 3)
-        assert cols == 32 and typ == 0 and rows == n                             # cv::Mat(N, 32, CV_8U)
+        assert rows == n and typ == 0 and cols == (32 if n else 0)               # cv::Mat(N, 32, CV_8U); an empty Mat has cols = 0
         rec["desc_" + eye] = take("u1", rows * cols).reshape(rows, cols).copy()
     n = int(take("<u8")[0])
     rec["matches"] = take(MATCH, n).copy()
@@ -51,6 +51,9 @@ def test_record_layout_and_roundtrip(tool, tmp_path, nl, nr, nm):
     ra = parse(open(a, "rb").read())
     assert len(ra["kp_left"]) == nl and len(ra["kp_right"]) == nr and len(ra["matches"]) == nm
     assert os.path.getsize(a) == 8 + 48 + 2 * 8 + (nl + nr) * (28 + 32) + 2 * 12 + 8 + nm * 24
+    if nl == 0:
+        # a side without keypoints is an empty cv::Mat on the reference's side: rows = cols = 0 on disk (EST.cpp:2534-2537)
+        assert np.array_equal(np.frombuffer(open(a, "rb").read(), "<i4", 3, 8 + 48 + 8), [0, 0, 0])
     if nm:
         assert np.array_equal(ra["matches"]["id"], 1000 + np.arange(nm))          # generateMatchesIDs (KF.h:75-80)
         assert ra["matches"]["queryIdx"].max() < nl and ra["matches"]["trainIdx"].max() < nr
@@ -70,4 +73,22 @@ def test_truncated_record_is_rejected(tool, tmp_path):
     subprocess.run([tool, "make", a, "20", "20", "10", "3"], check=True)
     data = open(a, "rb").read()
     open(a, "wb").write(data[:len(data) // 2])
+    assert subprocess.run([tool, "roundtrip", a, b], capture_output=True).returncode != 0
+
+
+def test_reference_written_empty_side_loads(tool, tmp_path):
+    """A record as the reference writes it for a keyframe whose right side has no keypoints (descriptors = empty cv::Mat:
+    rows 0, cols 0) must load, and a record that says cols = 32 with rows = 0 (what this build wrote before) too."""
+    a, b = str(tmp_path / "a.kfrec"), str(tmp_path / "b.kfrec")
+    subprocess.run([tool, "make", a, "5", "0", "0", "3"], check=True)
+    data = bytearray(open(a, "rb").read())
+    off = 8 + 48 + 8 + 5 * 28 + 12 + 5 * 32 + 8          # right side: count, then rows / cols / type
+    assert list(np.frombuffer(bytes(data), "<i4", 3, off)) == [0, 0, 0]
+    assert subprocess.run([tool, "roundtrip", a, b], capture_output=True).returncode == 0
+    data[off + 4:off + 8] = np.int32(32).tobytes()
+    open(a, "wb").write(bytes(data))
+    assert subprocess.run([tool, "roundtrip", a, b], capture_output=True).returncode == 0
+    assert list(np.frombuffer(open(b, "rb").read(), "<i4", 3, off)) == [0, 0, 0]
+    data[off + 4:off + 8] = np.int32(7).tobytes()          # any other width is not a descriptor matrix
+    open(a, "wb").write(bytes(data))
     assert subprocess.run([tool, "roundtrip", a, b], capture_output=True).returncode != 0
