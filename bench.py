@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--pcie-steps", type=int, default=5,
                     help="steps of the PCIe-inclusive pass at N=1 (images uploaded from pinned host memory every step; reported as "
                          "`pcie_inclusive`, never as `value`; 0 = skip)")
+    ap.add_argument("--unbatched-frames", type=int, default=401,
+                    help="frames of the un-batched pass at N=1 (the estimator's frame loop, one ssk_slam_process_frame per stereo pair: what a "
+                         "user of performStereoSLAM sees; reported as `unbatched`, never as `value`; 0 = skip)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: LM solves on a second HIP stream beside the front-end / DA kernels (measured: +1 %, the LM workgroups fill every CU)")
     args = ap.parse_args()
@@ -393,6 +396,28 @@ def main():
     pcie = pcie_pass() if world == 1 and args.pcie_steps > 0 else None
     torch.cuda.synchronize()
 
+    # ---- un-batched pass (reported beside `value`, never as it): the reference's loop is sequential -- one stereo pair at a time
+    # through ssk_slam_process_frame (performStereoSLAM, EST.cpp:44-937) with the KITTI parameters: every call pays its own launches,
+    # PCIe copies, host-side window build and symbolic LM set-up; both LM stages per keyframe on the depth-5 local area.
+    def unbatched_pass(n):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import stream_full
+        o = stream_full.run(n, max(8, n // 10), verbose=False)
+        t = o["timing"]
+        kf = max(t["kf_frames"], 1)
+        return {"frames": n, "keyframes": o["keyframes"], "frames_per_s": o["frames_per_s"], "ms_per_frame": o["ms_per_frame"],
+                "ms_per_keyframe_frame": o["ms_per_keyframe_frame"], "worst_frame_ms": o["worst_ms"],
+                "per_frame_ms": {"front_end_odometry": t["vo_ms"] / max(t["frames"], 1)},
+                "per_keyframe_ms": {"place_recognition_query": t["query_ms"] / kf, "data_association": t["da_ms"] / kf,
+                                    "insert_total": t["insert_ms"] / kf, "lm_window_build": t["lm_window_build_ms"] / kf,
+                                    "lm_tiler_and_upload": t["lm_batch_create_ms"] / kf, "lm_solve_stage1_plus_stage2": t["lm_solve_ms"] / kf,
+                                    "lm_readback": t["lm_readback_ms"] / kf},
+                "lm_iters_per_keyframe": t["lm_iters"] / kf, "lm_max_optimised_edges": t["lm_max_opt_edges"], "lm_max_observations": t["lm_max_obs"],
+                "note": "synthetic KITTI-shaped sequence (tests/synth.py), 0.54 m per frame, KITTI.ini parameters (keyframe every 4th frame, submap 10, "
+                        "tree depth 4, optimise depth 5), host clock around each ssk_slam_process_frame call; frame generation excluded"}
+
+    unbatched = unbatched_pass(args.unbatched_frames) if world == 1 and rank == 0 and args.unbatched_frames > 0 else None
+
     if rank == 0:
         # PMC traffic per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary
         # committed under profiles/): bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- KB units, FETCH_SIZE doubled on gfx950
@@ -463,6 +488,7 @@ def main():
                               "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_avg_ms},
             "stage_ms_per_launch": stages,
             "pcie_inclusive": pcie,
+            "unbatched": unbatched,
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, wins, vocab)

@@ -464,6 +464,11 @@ class SlamFrameReport(C.Structure):
                 ("n_keyframes", C.c_int32), ("reserved", C.c_int32)]
 
 
+class SlamTiming(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("vo_ms", "query_ms", "da_ms", "insert_ms", "lm_window_build_ms", "lm_batch_create_ms", "lm_solve_ms", "lm_readback_ms")] + \
+               [(n, C.c_int32) for n in ("frames", "kf_frames", "lm_solves", "lm_iters", "lm_max_opt_edges", "lm_max_obs")]
+
+
 class Slam:
     """ssk_slam: the estimator (include/ssk_slam.h): one call per stereo frame, the reference's whole loop behind it."""
 
@@ -506,6 +511,31 @@ class Slam:
         rep = SlamFrameReport()
         self._chk(self.lib.ssk_slam_process_frame(self.h_, _ptr(l), _ptr(r), self.w, C.byref(rep)))
         return rep
+
+    def timing(self):
+        t = SlamTiming()
+        self._chk(self.lib.ssk_slam_get_timing(self.h_, C.byref(t)))
+        return t
+
+    def set_debug_dir(self, path):
+        self._chk(self.lib.ssk_slam_set_debug_dir(self.h_, str(path).encode()))
+
+    def get_keyframe(self, kf, cap=1024):
+        """(dict as Context.frontend_run returns it, match ids u64[n_matches]) of keyframe `kf`."""
+        o, arrs = alloc_kf_out(cap)
+        ids = np.zeros(cap, np.uint64)
+        self._chk(self.lib.ssk_slam_get_keyframe(self.h_, int(kf), C.byref(o), _ptr(ids)))
+        d = trim_kf_out(o, arrs)
+        return d, ids[:o.n_matches].copy()
+
+    def last_da(self, which, cap=1024):
+        """t_kf_da_info of the last keyframe check against its `which`-th similar keyframe."""
+        other, tracked, pos, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        first = np.zeros(cap, np.int32); dist = np.zeros(cap, np.float64); init = np.zeros(12)
+        self._chk(self.lib.ssk_slam_last_da(self.h_, int(which), C.byref(other), C.byref(tracked), C.byref(pos), _ptr(first), _ptr(dist), cap,
+                                            C.byref(n), _ptr(init)))
+        return dict(other_kf=other.value, tracked=tracked.value, sorted_pos=pos.value, tracking_first=first[:n.value].copy(),
+                    tracking_dist=dist[:n.value].copy(), init_pose=init)
 
     def counts(self):
         return self.lib.ssk_slam_num_keyframes(self.h_), self.lib.ssk_slam_num_edges(self.h_), self.lib.ssk_slam_num_landmarks(self.h_)

@@ -308,7 +308,11 @@ TFrameReport CSRBAStereoSLAMEstimator::performStereoSLAM(const StereoImages& stI
 	TFrameReport rep;
 	rep.frame = m_frame_count++;
 	if (!m_bow_manager.hasVocabulary()) throw std::runtime_error("performStereoSLAM: no vocabulary loaded (m_bow_manager.loadVocabulary)");
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	const auto t_0 = now();
 	rep.odometry = m_vo_process(stImgs);
+	timing.vo_ms += ms(t_0, now()); timing.frames++;
 	// ---- first iteration, EST.cpp:82-182 ----
 	if (m_keyframes.empty()) {
 		m_keyframes.push_back(m_vo_cur);                                                 // new_kf.getDataFromVOEngine (:112-114)
@@ -346,18 +350,23 @@ TFrameReport CSRBAStereoSLAMEstimator::performStereoSLAM(const StereoImages& stI
 	CStereoSLAMKF* new_kf = &m_keyframes.back();
 	new_kf->setKFID(m_last_kf_ID);                                                       // :418
 	new_kf->m_matches_ID.clear();
+	const auto t_q = now();
 	m_bow_manager.queryDB(*new_kf, rep.query, 4);                                        // :424-427
+	timing.query_ms += ms(t_q, now());
 	const bool potentialLoopClosure = m_get_similar_kfs(new_kf->m_kf_ID, rep.query, rep.similar);   // :434-436
 	rep.potential_loop_closure = potentialLoopClosure;
 	const bool insert_in = rep.query[0].Score < 0.05;                                    // :439-441 "result is too low, force the creation of a new KF"
 	TVectorKfsDaInfo daInfo;
+	const auto t_d = now();
 	m_data_association(*new_kf, rep.similar, daInfo);                                    // :446-451
+	timing.da_ms += ms(t_d, now());
 	std::vector<policy::TDaSummary> das(daInfo.size());
 	for (size_t i = 0; i < das.size(); ++i) { das[i].kf_idx = daInfo[i].kf_idx; das[i].tracked_matches = daInfo[i].tracked_matches; }
 	const policy::TInsertDecision dec = policy::decideInsertion(insert_in, das, potentialLoopClosure, rep.similar.lc_id, vo.voForceNewKf,
 	                                                            srba_options.updated_matches_th, srba_options.up_matches_th_plus,
 	                                                            m_max_translation, m_max_rotation);                        // :455-548
 	rep.highest_tracked = dec.highestNumberTrackedFeats;
+	rep.da = daInfo; rep.da_sorted = dec.sortedIndices;
 	rep.confirmed_loop_closure = dec.confirmedLoopClosure;
 	m_max_translation = dec.max_translation; m_max_rotation = dec.max_rotation;
 	if (dec.confirmedLoopClosure) { rba.loopClosureDetected(); rba.setLoopClosureOldID(rep.similar.lc_id); }           // :497-498
@@ -366,7 +375,9 @@ TFrameReport CSRBAStereoSLAMEstimator::performStereoSLAM(const StereoImages& stI
 		m_keyframes.resize(m_keyframes.size() - 1);
 		return rep;
 	}
+	const auto t_i = now();
 	m_insert_keyframe(*new_kf, daInfo, dec.sortedIndices, m_incr_pose_from_last_kf, rep.kf_info);                     // :564-850
+	timing.insert_ms += ms(t_i, now()); timing.kf_frames++;
 	m_vo_reset_ids();                                                                    // :620-622
 	m_last_kf_ID++;                                                                      // :657
 	m_max_translation = srba_options.max_translation;                                    // :660-663 as written: the CHECK thresholds restart from

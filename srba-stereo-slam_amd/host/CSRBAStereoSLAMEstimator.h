@@ -51,12 +51,17 @@ struct TFrameReport {                                      // what one loop iter
 	TLoopClosureInfo similar;
 	size_t highest_tracked = 0;
 	TNewKeyFrameInfo kf_info;
+	TVectorKfsDaInfo da;                                   // data association with rep.similar.similar_kfs, in that order (EST.cpp:446-451)
+	std::vector<size_t> da_sorted;                         // the order the ids were taken from them (DATrackedSorter, EST.cpp:455-470)
 };
 
 class CSRBAStereoSLAMEstimator {
 public:
 	CSRBAStereoSLAMEstimator(Context& ctx, const TSRBAStereoSLAMOptions& opts, const TGeneralOptions& gopts = TGeneralOptions());
 
+	// cumulative host-clock milliseconds per part of performStereoSLAM (the sections the reference instruments with its
+	// profiler: performDA EST.cpp:446-451, define_kf :781-787, plus the front-end / odometry and the place-recognition query)
+	struct TTiming { double vo_ms = 0, query_ms = 0, da_ms = 0, insert_ms = 0; size_t frames = 0, kf_frames = 0; } timing;
 	TSRBAStereoSLAMOptions srba_options;                   // EST.h:48
 	TGeneralOptions general_options;                       // the reference's process-wide global (MAIN.cpp:26)
 	mySRBA rba;                                            // EST.h:54

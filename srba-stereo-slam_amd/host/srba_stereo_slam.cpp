@@ -276,6 +276,10 @@ void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pa
 	const auto t3 = now();
 	if (rc == SSK_OK) rc = ssk_lm_batch_get_state(m_ctx.get(), b, 0, pose.data(), lmpos.data());
 	ssk_lm_batch_destroy(b);
+	const auto t4 = now();
+	this->timing.window_build_ms += ms(t0, t1); this->timing.batch_create_ms += ms(t1, t2); this->timing.solve_ms += ms(t2, t3);
+	this->timing.readback_ms += ms(t3, t4); this->timing.solves++; this->timing.iters += rc == SSK_OK ? (size_t)r.iters : 0;
+	this->timing.max_opt_edges = std::max(this->timing.max_opt_edges, (size_t)s); this->timing.max_obs = std::max(this->timing.max_obs, obs_lm.size());
 	if (timing) std::fprintf(stderr, "[facade timing]   run_lm (%d edges opt, %zu obs): window build %.2f ms, batch create %.2f ms, solve %.2f ms (%d iters), state+destroy %.2f ms\n",
 	                         s, obs_lm.size(), ms(t0, t1), ms(t1, t2), ms(t2, t3), (int)r.iters, ms(t3, now()));
 	m_ctx.check(rc, "LM solve");

@@ -54,6 +54,9 @@ public:
 		bool literal_lc_edge_init = false;                                          // SRBA.h:294 as written (see .cpp): off by default
 	} parameters;
 
+	// cumulative host-clock milliseconds of the four parts of every LM solve (run_lm): what an un-batched caller pays per keyframe
+	struct TTiming { double window_build_ms = 0, batch_create_ms = 0, solve_ms = 0, readback_ms = 0; size_t solves = 0, iters = 0, max_opt_edges = 0, max_obs = 0; } timing;
+
 	mySRBA(Context& ctx, const TSRBAStereoSLAMOptions& opts);
 
 	inline void setInitialKFPose(const Pose3D& pose) { m_initial_kf_pose = pose; }  // SRBA.h:95-97

@@ -10,11 +10,15 @@ struct ssk_slam {
 	ssk::TSRBAStereoSLAMOptions opts;
 	std::unique_ptr<ssk::CSRBAStereoSLAMEstimator> est;     // built at the first use: the options are copied at construction
 	std::string voc, err;
+	ssk::TGeneralOptions gopts;
+	ssk::TVectorKfsDaInfo last_da;
+	std::vector<size_t> last_da_sorted;
+	std::vector<ssk::Pose3D> last_da_init;
 	int w = 0, h = 0;
 	ssk::CSRBAStereoSLAMEstimator& get()
 	{
 		if (!est) {
-			est.reset(new ssk::CSRBAStereoSLAMEstimator(*ctx, opts));
+			est.reset(new ssk::CSRBAStereoSLAMEstimator(*ctx, opts, gopts));
 			if (!voc.empty()) est->m_bow_manager.loadVocabulary(voc);
 		}
 		return *est;
@@ -79,6 +83,52 @@ int ssk_slam_set_option(ssk_slam* s, const char* key, double v)
 	return SSK_OK;
 }
 
+int ssk_slam_set_debug_dir(ssk_slam* s, const char* dir)
+{
+	if (!s || !dir) return SSK_ERR_BAD_ARG;
+	if (s->est) { s->err = "ssk_slam_set_debug_dir: options are fixed once the first frame has been processed"; return SSK_ERR_BAD_ARG; }
+	s->gopts.debug = true; s->gopts.out_dir = dir;
+	return SSK_OK;
+}
+
+int ssk_slam_get_keyframe(const ssk_slam* s, int kf, ssk_kf_out* out, uint64_t* match_ids)
+{
+	if (!s || !out || !s->est || kf < 0 || (size_t)kf >= s->est->m_keyframes.size()) return SSK_ERR_BAD_ARG;
+	const ssk::CStereoSLAMKF& k = s->est->m_keyframes[(size_t)kf];
+	const size_t nl = k.m_keypoints_left.size(), nr = k.m_keypoints_right.size(), nm = k.m_matches.size();
+	if (nl > (size_t)out->capacity || nr > (size_t)out->capacity || nm > (size_t)out->capacity) return SSK_ERR_CAPACITY;
+	if (nl) { std::memcpy(out->kp_left, k.m_keypoints_left.data(), nl * sizeof(ssk_keypoint)); std::memcpy(out->desc_left, k.m_descriptors_left.data.data(), nl * 32); }
+	if (nr) { std::memcpy(out->kp_right, k.m_keypoints_right.data(), nr * sizeof(ssk_keypoint)); std::memcpy(out->desc_right, k.m_descriptors_right.data.data(), nr * 32); }
+	if (nm) std::memcpy(out->matches, k.m_matches.data(), nm * sizeof(ssk_dmatch));
+	out->n_left = (int32_t)nl; out->n_right = (int32_t)nr; out->n_matches = (int32_t)nm;
+	if (match_ids) for (size_t m = 0; m < nm; ++m) match_ids[m] = m < k.m_matches_ID.size() ? (uint64_t)k.m_matches_ID[m] : 0;
+	return SSK_OK;
+}
+
+int ssk_slam_last_da(const ssk_slam* s, int which, int32_t* other_kf, int32_t* tracked, int32_t* sorted_pos,
+                     int32_t* tracking_first, double* tracking_dist, int cap, int32_t* n_matches, double* init_pose)
+{
+	if (!s || which < 0 || (size_t)which >= s->last_da.size() || !n_matches) return SSK_ERR_BAD_ARG;
+	const ssk::t_kf_da_info& d = s->last_da[(size_t)which];
+	if ((size_t)cap < d.tracking_info.size() && (tracking_first || tracking_dist)) return SSK_ERR_CAPACITY;
+	if (other_kf) *other_kf = (int32_t)d.kf_idx;
+	if (tracked) *tracked = (int32_t)d.tracked_matches;
+	if (sorted_pos) {
+		*sorted_pos = -1;
+		for (size_t i = 0; i < s->last_da_sorted.size(); ++i) if (s->last_da_sorted[i] == (size_t)which) *sorted_pos = (int32_t)i;
+	}
+	*n_matches = (int32_t)d.tracking_info.size();
+	if (init_pose) {
+		const ssk::Pose3D identity;
+		std::memcpy(init_pose, ((size_t)which < s->last_da_init.size() ? s->last_da_init[(size_t)which] : identity).m, 12 * sizeof(double));
+	}
+	for (size_t m = 0; m < d.tracking_info.size(); ++m) {
+		if (tracking_first) tracking_first[m] = d.tracking_info[m].first == ssk::INVALID_IDX ? -1 : (int32_t)d.tracking_info[m].first;
+		if (tracking_dist) tracking_dist[m] = d.tracking_info[m].second;
+	}
+	return SSK_OK;
+}
+
 int ssk_slam_load_vocabulary(ssk_slam* s, const char* path)
 {
 	if (!s || !path) return SSK_ERR_BAD_ARG;
@@ -114,7 +164,22 @@ int ssk_slam_process_frame(ssk_slam* s, const uint8_t* left, const uint8_t* righ
 		out->total_sqr_error_init = r.kf_info.optimize_results.total_sqr_error_init;
 		out->total_sqr_error_final = r.kf_info.optimize_results.total_sqr_error_final;
 		out->n_keyframes = (int32_t)s->get().m_keyframes.size();
+		if (r.checked_for_kf) { s->last_da = r.da; s->last_da_sorted = r.da_sorted; s->last_da_init = r.similar.similar_kfs_poses; }
 	});
+}
+
+int ssk_slam_get_timing(const ssk_slam* s, ssk_slam_timing* out)
+{
+	if (!s || !out) return SSK_ERR_BAD_ARG;
+	std::memset(out, 0, sizeof *out);
+	if (!s->est) return SSK_OK;
+	const auto& t = s->est->timing;
+	const auto& l = s->est->rba.timing;
+	out->vo_ms = t.vo_ms; out->query_ms = t.query_ms; out->da_ms = t.da_ms; out->insert_ms = t.insert_ms;
+	out->lm_window_build_ms = l.window_build_ms; out->lm_batch_create_ms = l.batch_create_ms; out->lm_solve_ms = l.solve_ms; out->lm_readback_ms = l.readback_ms;
+	out->frames = (int32_t)t.frames; out->kf_frames = (int32_t)t.kf_frames; out->lm_solves = (int32_t)l.solves; out->lm_iters = (int32_t)l.iters;
+	out->lm_max_opt_edges = (int32_t)l.max_opt_edges; out->lm_max_obs = (int32_t)l.max_obs;
+	return SSK_OK;
 }
 
 int ssk_slam_num_keyframes(const ssk_slam* s) { return s && s->est ? (int)s->est->m_keyframes.size() : 0; }

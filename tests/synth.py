@@ -128,6 +128,44 @@ def synth_translation_sequence(seed, n_frames, w=W, h=H, noise=1.0, d_max=40, z_
     return frames, strips
 
 
+def translation_frame_source(seed, max_pos, w=W, h=H, d_max=40, z_max=60.0, noise=1.0, noise_pool=16):
+    """synth_translation_sequence, lazily and for ANY order of camera positions: get(pos, k) renders the stereo pair seen from
+    `pos` baselines (0.54 m each) to the right of the start, 0 <= pos <= max_pos, with the sensor noise of frame k (drawn from a
+    pool of `noise_pool` pre-generated noise fields: a 4 541-frame run spends its time in the loop under test, not in numpy's
+    normal()).  A camera that comes back to a position sees the same scene under other noise -- what a revisit is."""
+    rng = np.random.default_rng(0x5EED1000 + seed)
+    wide = synth_texture(rng, w + (max_pos + 2) * d_max + 8, h)
+    strips, y = [], 0
+    while y < h:
+        bh = int(rng.integers(24, 64))
+        z = rng.uniform(KITTI["fx"] * KITTI["baseline"] / d_max, z_max)
+        d = max(2, min(int(round(KITTI["fx"] * KITTI["baseline"] / z)), d_max))
+        strips.append((y, min(h, y + bh), d))
+        y += bh
+    pool = [np.rint(np.random.default_rng(seed * 100003 + i).normal(0, noise, (2, h, w))).astype(np.int16) for i in range(noise_pool)] if noise > 0 else None
+
+    def get(pos, k=0):
+        assert 0 <= pos <= max_pos
+        left = np.empty((h, w), np.uint8); right = np.empty((h, w), np.uint8)
+        for y0, y1, d in strips:
+            left[y0:y1] = wide[y0:y1, pos * d:pos * d + w]
+            right[y0:y1] = wide[y0:y1, (pos + 1) * d:(pos + 1) * d + w]
+        if pool is not None:
+            nz = pool[k % noise_pool]
+            left = np.clip(left.astype(np.int16) + nz[0], 0, 255).astype(np.uint8)
+            right = np.clip(right.astype(np.int16) + nz[1], 0, 255).astype(np.uint8)
+        return left, right
+    get.strips = strips
+    return get
+
+
+def out_and_back_positions(n_frames, n_back):
+    """Camera positions (baselines to the right of the start) of an n_frames run: out at one baseline per frame, then the last
+    n_back frames back over the same places -- the revisit that closes a loop."""
+    n_out = n_frames - n_back
+    return [k if k < n_out else 2 * (n_out - 1) - k for k in range(n_frames)]
+
+
 def synth_forward_sequence(seed, n_frames, step=0.5, w=W, h=H, noise=1.0, half_width=6.0, cam_height=1.65, z_far=120.0, px_per_m=48.0, yaw_per_frame=0.0):
     """n_frames rectified stereo pairs from a camera driving FORWARD (+z, `step` metres per frame, optionally turning by
     yaw_per_frame radians about the vertical) through a textured corridor: ground plane, two side walls, a far wall --

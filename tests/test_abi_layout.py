@@ -12,7 +12,7 @@ PAIRS = {                                   # C struct -> ctypes class / numpy d
     "ssk_kf_view": "KfView", "ssk_da_params": "DaParams", "ssk_cip_params": "CipParams", "ssk_cip_result": "CipResult",
     "ssk_fm_params": "FmParams", "ssk_fm_result": "FmResult", "ssk_frontend_params": "FrontendParams", "ssk_kf_out": "KfOut",
     "ssk_pg_params": "PgParams", "ssk_pg_result": "PgResult", "ssk_rba_options": "RbaOptions", "ssk_rba_kf_info": "RbaKfInfo",
-    "ssk_slam_frame_report": "SlamFrameReport", "ssk_lm_window": "LmWindow", "ssk_lm_params": "LmParams",
+    "ssk_slam_frame_report": "SlamFrameReport", "ssk_slam_timing": "SlamTiming", "ssk_lm_window": "LmWindow", "ssk_lm_params": "LmParams",
     "ssk_lm_result": "LmResult", "ssk_lm_trace_entry": "LmTraceEntry",
     "ssk_keypoint": "KEYPOINT_DTYPE", "ssk_dmatch": "DMATCH_DTYPE", "ssk_rba_obs": "RBA_OBS_DTYPE",
 }

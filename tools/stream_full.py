@@ -17,47 +17,27 @@ import bow_vocab as bv  # noqa: E402
 import synth            # noqa: E402
 
 
-def frame_source(seed, n, w=synth.W, h=synth.H, d_max=40, z_max=60.0, noise=1.0):
-    """synth.synth_translation_sequence, lazily: one baseline to the right per frame."""
-    rng = np.random.default_rng(0x5EED1000 + seed)
-    wide = synth.synth_texture(rng, w + (n + 1) * d_max + 8, h)
-    strips, y = [], 0
-    while y < h:
-        bh = int(rng.integers(24, 64))
-        z = rng.uniform(synth.KITTI["fx"] * synth.KITTI["baseline"] / d_max, z_max)
-        d = max(2, min(int(round(synth.KITTI["fx"] * synth.KITTI["baseline"] / z)), d_max))
-        strips.append((y, min(h, y + bh), d))
-        y += bh
-
-    def get(k):
-        left = np.empty((h, w), np.uint8); right = np.empty((h, w), np.uint8)
-        for y0, y1, d in strips:
-            left[y0:y1] = wide[y0:y1, k * d:k * d + w]
-            right[y0:y1] = wide[y0:y1, (k + 1) * d:(k + 1) * d + w]
-        r = np.random.default_rng(seed * 100003 + k)
-        left = np.clip(np.rint(left + r.normal(0, noise, left.shape)), 0, 255).astype(np.uint8)
-        right = np.clip(np.rint(right + r.normal(0, noise, right.shape)), 0, 255).astype(np.uint8)
-        return left, right
-    return get
-
-
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4541
+def run(n, n_back, seed=9, verbose=True, voc_every=None, **options):
+    """The run of tests/test_config3_gpu.py and of bench.py's `unbatched` object: n frames (the last n_back of them back over the
+    places just seen) through ssk_slam_process_frame, then the global pose graph.  Returns a dict of what was observed."""
     import __graft_entry__ as ge
     pkg = ge.load_package()
     from ssk_amd import capi
-    get = frame_source(9, n)
+    pos = synth.out_and_back_positions(n, n_back)
+    get = synth.translation_frame_source(seed, max(pos))
     ctx = pkg.Context(0)
     prm = capi.FrontendParams(**synth.KITTI_FRONTEND)
-    train = [ctx.frontend_run(*get(k), prm)["desc_left"] for k in range(0, n, max(1, n // 32))][:32]
+    step = voc_every or max(1, n // 32)
+    train = [ctx.frontend_run(*get(pos[k], k), prm)["desc_left"] for k in range(0, n, step)][:32]
+    out = dict(frames=n, n_back=n_back, invalid_odometry=[], loop_closures=[], multi_edge_kfs=0, kf_frames=[], kf_pos=[], error_increased=[])
     with tempfile.TemporaryDirectory() as d:
         voc = os.path.join(d, "voc.yml.gz")
         bv.write_yaml(bv.train(train, k=8, L=4, seed=5), voc)
-        slam = capi.Slam(ctx, synth.W, synth.H, "kitti")
+        slam = capi.Slam(ctx, synth.W, synth.H, "kitti", **options)
         slam.load_vocabulary(voc)
-        t_loop, n_kf_frames, t_kf, worst, vo_sum, lc = 0.0, 0, 0.0, 0.0, 0.0, 0
+        t_loop, t_kf, worst = 0.0, 0.0, 0.0
         for k in range(n):
-            l, r = get(k)
+            l, r = get(pos[k], k)
             t0 = time.perf_counter()
             rep = slam.process_frame(l, r)
             dt = time.perf_counter() - t0
@@ -65,23 +45,49 @@ def main():
                 t_loop += dt
                 worst = max(worst, dt)
                 if rep.inserted_kf:
-                    n_kf_frames += 1; t_kf += dt
-            vo_sum += np.array(rep.vo_pose[:]).reshape(3, 4)[0, 3] if rep.vo_valid else 0.0
-            lc += rep.confirmed_loop_closure
-            if rep.inserted_kf and rep.n_created_edges != 1:
-                print("frame %d kf %d: %d edges created, similar %s, err %.1f -> %.1f" % (k, rep.kf_id, rep.n_created_edges, list(rep.similar_kfs[:rep.n_similar]), rep.total_sqr_error_init, rep.total_sqr_error_final))
+                    t_kf += dt
+            if rep.inserted_kf:
+                out["kf_frames"].append(k); out["kf_pos"].append(pos[k])
+                if rep.n_created_edges > 1:
+                    out["multi_edge_kfs"] += 1
+                if k > 0 and not rep.total_sqr_error_final <= rep.total_sqr_error_init:
+                    out["error_increased"].append(k)
+            if rep.confirmed_loop_closure:
+                out["loop_closures"].append((k, int(rep.lc_kf_id), bool(rep.inserted_kf)))
+                if verbose:
+                    print("frame %d: loop closure with keyframe %d (inserted %d, %d edges, err %.1f -> %.1f)" % (k, rep.lc_kf_id, rep.inserted_kf, rep.n_created_edges, rep.total_sqr_error_init, rep.total_sqr_error_final))
             if not rep.vo_valid:
-                print("frame %d: odometry invalid" % k)
+                out["invalid_odometry"].append(k)
+                if verbose:
+                    print("frame %d: odometry invalid" % k)
         nk, ne, nl = slam.counts()
+        tm = slam.timing()
         t0 = time.perf_counter()
         X, info = slam.optimize_pose_graph()
-        t_pg = time.perf_counter() - t0
-        print("frames %d keyframes %d edges %d landmarks %d | loop %.2f s = %.1f frames/s (%.2f ms per frame, %.2f ms on keyframe frames, worst %.1f ms) | "
-              "pose graph %.3f s (stop %d, %d attempts, cost %.4g -> %.4g) | odometry sum %.2f m, loop closures %d | last keyframe y %.2f m for %.2f m of motion"
-              % (n, nk, ne, nl, t_loop, (n - 1) / t_loop, 1e3 * t_loop / (n - 1), 1e3 * t_kf / max(n_kf_frames, 1), 1e3 * worst, t_pg, info.stop_reason, info.iters, info.cost_init, info.cost_final, vo_sum, lc,
-                 X[-1].reshape(3, 4)[1, 3], 0.54 * 4 * (nk - 1)))
+        out.update(keyframes=nk, edges=ne, landmarks=nl, loop_s=t_loop, frames_per_s=(n - 1) / t_loop, ms_per_frame=1e3 * t_loop / (n - 1),
+                   ms_per_keyframe_frame=1e3 * t_kf / max(len(out["kf_frames"]) - 1, 1), worst_ms=1e3 * worst, posegraph_s=time.perf_counter() - t0,
+                   pg_stop=info.stop_reason, pg_iters=info.iters, pg_cost_init=info.cost_init, pg_cost_final=info.cost_final, poses=X,
+                   timing={f: getattr(tm, f) for f, _ in tm._fields_})
         slam.close()
     ctx.close()
+    return out
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4541
+    n_back = int(sys.argv[2]) if len(sys.argv) > 2 else 160
+    o = run(n, n_back)
+    X, kp = o["poses"], np.array(o["kf_pos"])
+    # robot frame: the camera's right is -y (camera_pose_on_robot, EST.cpp:1105-1112); keyframe k sits 0.54 * kf_pos[k] m to the right
+    err = np.abs(X.reshape(-1, 3, 4)[:, 1, 3] + 0.54 * kp)
+    path = 0.54 * (n - 1)
+    print("frames %d keyframes %d edges %d landmarks %d | loop %.2f s = %.1f frames/s (%.2f ms per frame, %.2f ms on keyframe frames, worst %.1f ms) | "
+          "pose graph %.3f s (stop %d, %d attempts, cost %.4g -> %.4g) | loop closures %d, keyframes with > 1 new edge %d, invalid odometry %d | "
+          "position error max %.3f m = %.3f %% of the %.0f m path, last keyframe %.3f m"
+          % (n, o["keyframes"], o["edges"], o["landmarks"], o["loop_s"], o["frames_per_s"], o["ms_per_frame"], o["ms_per_keyframe_frame"], o["worst_ms"],
+             o["posegraph_s"], o["pg_stop"], o["pg_iters"], o["pg_cost_init"], o["pg_cost_final"], len(o["loop_closures"]), o["multi_edge_kfs"],
+             len(o["invalid_odometry"]), err.max(), 100 * err.max() / path, path, err[-1]))
+    print("timing", o["timing"])
 
 
 if __name__ == "__main__":
