@@ -51,7 +51,7 @@ def lm_algorithmic_flops(win):
 
 
 
-def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8):
+def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8, n_lm_distinct=8):
     """B keyframes + B 'previous' keyframes resident in HBM, B LM windows uploaded."""
     import torch
     import synth
@@ -72,8 +72,8 @@ def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8):
         ip[:, :, b0:b0 + 47, :W] = torch.roll(ic[:, :, b0:b0 + 47, :W], shifts=-(2 + (b0 // 47) % 5), dims=-1)
     torch.cuda.synchronize()
     wins = [sl.make_submap_problem(100 * rank + s, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2,
-                                   obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0] for s in range(n_base)]
-    lm = capi.LmBatch(ctx_lm, [wins[k % n_base] for k in range(B)])
+                                   obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0] for s in range(n_lm_distinct)]
+    lm = capi.LmBatch(ctx_lm, [wins[k % n_lm_distinct] for k in range(B)])
     return cur, prev, lm, wins
 
 
@@ -107,14 +107,14 @@ def params(capi, sl):
 
 
 def cpu_baseline(sample_kf, wins, vocab):
-    """The oracle (CPU port, 1 thread, -O2 -march=native -ffp-contract=off) on `sample_kf` keyframes of the same
+    """The oracle (CPU port, 1 thread, -O3 -march=native -ffp-contract=off: the reference builds -O3 -mtune=native, CMakeLists.txt:98-100) on `sample_kf` keyframes of the same
     workload: front-end + DA vs a shifted previous keyframe + place-recognition query + LM solve."""
     import oracle_lib as ol
     import synth
     import synth_lm as sl
     out_dir = os.path.join("/tmp", "ssk_oracle_native_%d" % os.getpid())
     try:
-        oracle = ol.load(march="native", out=out_dir)
+        oracle = ol.load(march="native", out=out_dir, opt="-O3")
     except Exception:
         oracle = ol.load()
     fp = ol.FrontendParams(**synth.KITTI_FRONTEND)
@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--pcie-steps", type=int, default=5,
                     help="steps of the PCIe-inclusive pass at N=1 (images uploaded from pinned host memory every step; reported as "
                          "`pcie_inclusive`, never as `value`; 0 = skip)")
+    ap.add_argument("--lm-distinct", type=int, default=8,
+                    help="distinct LM windows in the batch (the rest are replicas): 8 = the default line; 64 gives ragged iteration counts "
+                         "(64 submaps, seeds 0..63, x16 replicas at --batch 1024)")
     ap.add_argument("--unbatched-frames", type=int, default=401,
                     help="frames of the un-batched pass at N=1 (the estimator's frame loop, one ssk_slam_process_frame per stereo pair: what a "
                          "user of performStereoSLAM sees; reported as `unbatched`, never as `value`; 0 = skip)")
@@ -254,7 +257,7 @@ def main():
     lm_stream = torch.cuda.Stream() if args.overlap else torch.cuda.current_stream()
     ctx_lm = pkg.Context(local, stream=lm_stream.cuda_stream) if args.overlap else ctx
     B = args.batch
-    cur, prev, lm, wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank)
+    cur, prev, lm, wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_lm_distinct=max(1, min(args.lm_distinct, B)))
     fp, da, lp, cp, fm = params(capi, sl)
     pairs = np.stack([np.arange(B), np.arange(B)], 1).astype(np.int32)
     dev = torch.device("cuda", local)
@@ -337,6 +340,11 @@ def main():
             prof[k] = (prof[k][0] + v[0], prof[k][1] + v[1]) if k in prof else v
         c.profile_enable(False)
     res = lm.results()
+    # a number from a run whose solves did not end properly is not a number: every window must have stopped for a contract reason
+    # (1 rmse, 2 lambda, 3 nothing to optimise, 4 converged, 0 iteration limit) below its initial error
+    bad = [(k, r.stop_reason, r.err_init, r.err_final) for k, r in enumerate(res) if r.stop_reason == 5 or not r.err_final <= r.err_init]
+    if bad:
+        sys.exit("bench.py: %d of %d LM windows ended badly (window, stop_reason, err_init, err_final): %s" % (len(bad), len(res), bad[:4]))
     nkp, nm = cur.counts()
     tracked = d_tr.cpu().numpy()
 
@@ -472,6 +480,7 @@ def main():
                 "mean_keypoints_per_image": float(nkp.mean()),
                 "mean_stereo_matches": float(nm.mean()),
                 "mean_tracked_vs_prev": float(tracked.mean()),
+                "lm_distinct_windows": len(wins),
                 "lm_window": {"edges": int(wins[0].E), "landmarks": int(wins[0].L), "observations": int(len(wins[0].obs_lm)),
                               "mean_iters": float(np.mean([r.iters for r in res]))},
             },

@@ -402,11 +402,11 @@ def default_pattern():
 _ORACLE = None
 
 
-def load(march=None, out=None):
+def load(march=None, out=None, opt=None):
     global _ORACLE
-    if march or out:
+    if march or out or opt:
         import __graft_entry__ as ge
-        return Oracle(ge.build_oracle(march=march, out=out))
+        return Oracle(ge.build_oracle(march=march, out=out, opt=opt))
     if _ORACLE is None:
         path = os.path.join(ROOT, "oracle", "_build", "libssk_oracle.so")
         srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
