@@ -20,6 +20,8 @@ struct ssk_lm_batch {
 	lm_dev D{};
 	size_t n_pose = 0, n_lm = 0;      // doubles in pose / lm families
 	bool tiled_ok = false;            // every window fits the LDS-tiled kernel
+	bool acc_ok = false;              // ... and its accumulators fit LDS too: lm_solve_acc_kernel (on-chip accumulation)
+	int schur_mfma = 1;               // acc kernel: Schur complement on the FP64 matrix cores (SSK_LM_SCHUR=mfma, default) or by sparse 6x6 items (=sparse)
 	int max_tiles = 0;                // most tiles of a window (cooperative kernel: workgroups per window)
 	bool has_general = false;         // the general kernel's structures were built too
 	size_t tiled_dyn_bytes = 0;       // its dynamic LDS size
@@ -239,8 +241,21 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 // with_general: also build what only the general scratch-in-L2 kernel reads (the q entries with their co-observation lists,
 // the chunk lists, its scratch arrays).  The first attempt leaves them out; a batch with a window the tiler cannot take (or
 // SSK_LM_KERNEL=l2) is built again with them.
-static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out, bool with_general)
+static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out, bool with_general, bool want_acc)
 {
+	// SSK_LM_SCHUR (read when the batch is built: the two forms lay the tile out differently): mfma = Y panels + v_mfma_f64_16x16x4
+	// into LDS-resident 16x16 tiles, sparse = 6x6 items Y_i Y_j^T as in the slot kernels
+	const char* schur_env = std::getenv("SSK_LM_SCHUR");
+	const int schur_mfma = !(schur_env && std::strcmp(schur_env, "sparse") == 0);
+	const char* force_k = std::getenv("SSK_LM_KERNEL");
+	const bool force_acc = force_k && std::strcmp(force_k, "acc") == 0;
+	if (want_acc && windows && n_windows > 0) {            // cheap look ahead: one window with too many optimised edges rules the acc kernel out
+		for (int w = 0; w < n_windows && want_acc; ++w) {
+			int E = 0;
+			for (int e = 0; e < windows[w].n_edges_total && windows[w].edge_unknown_slot; ++e) if (windows[w].edge_unknown_slot[e] >= 0) ++E;
+			if (E > SSK_LMA_MAX_E) want_acc = false;
+		}
+	}
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!windows || n_windows < 1 || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: bad argument");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
@@ -261,7 +276,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	std::vector<float4> tobs_px;
 	std::vector<int4> tl_rec, inc_rec;
 	std::vector<int> lmep_loc, pit, pslot0, pcl_off, pcl_idx, qit, sslot0, scl_off, scl_idx;
-	std::vector<int2> pgrp, sgrp;
+	std::vector<int2> pgrp, sgrp, tl_pan;
+	std::vector<int> wt_off, wt;
+	bool acc_all = want_acc;
 	size_t n_pslots_total = 0, n_sslots_total = 0, tiled_dyn = 0;
 	bool tiled_all = true;
 	long long h_total = 0, dpt = 0, dft = 0;
@@ -400,15 +417,22 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		std::vector<int4> w_tl_rec, w_inc_rec((size_t)n_lme, make_int4(0, 0, 0, 0));
 		std::vector<int> w_lmep_loc(w_lmep_idx.size(), 0);
 		std::vector<int> w_pit, w_pslot0, w_qit, w_sslot0, w_pcl_off((size_t)n_pairs + 1, 0), w_pcl_idx, w_scl_off((size_t)n_pairs + 1, 0), w_scl_idx;
-		std::vector<int2> w_pgrp, w_sgrp;
+		std::vector<int2> w_pgrp, w_sgrp, w_tl_pan;
+		std::vector<int> w_wt_off, w_wt;
 		int n_pslots = 0, n_sslots = 0;
 		// LDS of a workgroup: static part, the window's edge poses twice, the solution vector and the pivots, the tile region
-		const long long region_bytes = (long long)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC - 2LL * 12 * 8 * Wn.n_edges_total - 2LL * 8 * ((6 * E + 1) & ~1);
+		const bool acc = want_acc && E <= SSK_LMA_MAX_E;
+		const long long region_bytes = (long long)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC - 2LL * 12 * 8 * Wn.n_edges_total - 2LL * 8 * ((6 * E + 1) & ~1) -
+		                               (acc ? 8LL * ssk_lma_acc_doubles(E) : 0);
 		bool tiled = 6 * E <= SSK_LM_MAX_N6 && Wn.n_edges_total <= 128 && region_bytes >= 32 * 1024;
+		if (want_acc && !(acc && tiled)) acc_all = false;
 		if (tiled) {
-			auto tile_bytes = [](long long nP, long long nO, long long nM, long long nL) {
-				return 8 * (SSK_LMT_ENT * nP + SSK_LMT_OBS * nO + SSK_LMT_Y * nM + SSK_LMT_LMR * nL);
+			// Y part of a tile: sparse records (19 doubles per incidence) or, acc + MFMA, panels of [3][16] doubles per (optimised landmark,
+			// 16-row tile of the reduced system it touches); acc: + 7 doubles per incidence for the reduced-gradient terms
+			auto tile_bytes = [](long long nP, long long nO, long long nY, long long nL) {
+				return 8 * (SSK_LMT_ENT * nP + SSK_LMT_OBS * nO + nY + SSK_LMT_LMR * nL);
 			};
+			const bool panels = acc && schur_mfma;
 			std::vector<std::vector<int>> obs_of((size_t)Wn.n_lms_total);
 			for (int o = 0; o < Wn.n_obs; ++o) obs_of[Wn.obs_lm[o]].push_back(o);
 			// packed observation record: everything a lane needs in one coalesced 32-byte load
@@ -427,13 +451,18 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				return om;
 			};
 			// balanced cut: the variable footprint of the window spread evenly over the fewest tiles that fit
-			std::vector<long long> fp_P(order.size()), fp_O(order.size()), fp_M(order.size());
+			std::vector<long long> fp_P(order.size()), fp_O(order.size()), fp_M(order.size()), fp_Y(order.size());
+			std::vector<int> lm_rowmask(order.size(), 0);
 			long long tot = 0;
 			for (size_t oi = 0; oi < order.size(); ++oi) {
 				long long nP = 0;
 				for (int o : obs_of[order[oi]]) nP += __builtin_popcount(opt_mask(o));
 				fp_P[oi] = nP; fp_O[oi] = (long long)obs_of[order[oi]].size(); fp_M[oi] = (long long)lm_lmes[oi].size();
-				tot += 8 * (SSK_LMT_ENT * fp_P[oi] + SSK_LMT_OBS * fp_O[oi] + SSK_LMT_Y * fp_M[oi] + SSK_LMT_LMR);
+				if ((int)oi < L)                                   // rows 6e .. 6e+5 of every incident edge e, as a mask of 16-row tiles
+					for (int m : lm_lmes[oi]) lm_rowmask[oi] |= (1 << ((6 * w_lme_edge[m]) >> 4)) | (1 << ((6 * w_lme_edge[m] + 5) >> 4));
+				fp_Y[oi] = panels ? (long long)SSK_LMA_PANEL * __builtin_popcount(lm_rowmask[oi]) : (long long)SSK_LMT_Y * fp_M[oi];
+				if (acc) fp_Y[oi] += 7 * fp_M[oi];
+				tot += 8 * (SSK_LMT_ENT * fp_P[oi] + SSK_LMT_OBS * fp_O[oi] + fp_Y[oi] + SSK_LMT_LMR);
 			}
 			const long long est_tiles = std::max<long long>(1, (tot + region_bytes * 9 / 10 - 1) / (region_bytes * 9 / 10));
 			const long long target = (tot + est_tiles - 1) / est_tiles;
@@ -473,20 +502,22 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			while (oi < order.size() && tiled) {
 				lm_tile T{};
 				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_a.size(); T.inc0 = lme_cursor;
-				long long nP = 0, nO = 0, nM = 0, nL = 0, var = 0;
+				long long nP = 0, nO = 0, nM = 0, nL = 0, nY = 0, var = 0;
 				size_t oj = oi;
 				for (; oj < order.size(); ++oj) {
-					const long long aP = nP + fp_P[oj], aO = nO + fp_O[oj], aM = nM + fp_M[oj], aL = nL + 1;
-					if (tile_bytes(aP, aO, aM, aL) > region_bytes || aM + aL > SSK_LMT_NT || aP > 65535 || aO > 65535) break;
-					nP = aP; nO = aO; nM = aM; nL = aL;
-					var += 8 * (SSK_LMT_ENT * fp_P[oj] + SSK_LMT_OBS * fp_O[oj] + SSK_LMT_Y * fp_M[oj] + SSK_LMT_LMR);
+					const long long aP = nP + fp_P[oj], aO = nO + fp_O[oj], aM = nM + fp_M[oj], aL = nL + 1, aY = nY + fp_Y[oj];
+					if (tile_bytes(aP, aO, aY, aL) > region_bytes || aM + aL > SSK_LMT_NT || aP > 65535 || aO > 65535 || (panels && aL > 128)) break;
+					nP = aP; nO = aO; nM = aM; nL = aL; nY = aY;
+					var += 8 * (SSK_LMT_ENT * fp_P[oj] + SSK_LMT_OBS * fp_O[oj] + fp_Y[oj] + SSK_LMT_LMR);
 					if (var >= target) { ++oj; break; }
 				}
 				if (oj == oi) { tiled = false; break; }          // one landmark alone does not fit
 				std::vector<item> pitems, qitems;
-				int n_ent = 0;
+				int n_ent = 0, n_pan = 0;
 				for (size_t ok = oi; ok < oj; ++ok) {
 					const int l = order[ok], j = (int)(ok - oi);
+					w_tl_pan.push_back(make_int2(lm_rowmask[ok], n_pan));
+					n_pan += __builtin_popcount(lm_rowmask[ok]);
 					w_tl_rec.push_back(make_int4(Wn.lm_unknown_slot[l], (int)w_tobs_a.size() - T.obs0, (int)(w_tobs_a.size() + obs_of[l].size()) - T.obs0, 0));
 					for (int o : obs_of[l]) {
 						const int kl = (int)w_tobs_a.size() - T.obs0, pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
@@ -522,19 +553,87 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 								                  (lm_lmes[ok][a] - T.inc0) | ((lm_lmes[ok][b2] - T.inc0) << 16)});
 					lme_cursor += (int)lm_lmes[ok].size();
 				}
-				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_a.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0;
+				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_a.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0; T.n_pan = panels ? n_pan : 0;
 				T.pg0 = (int)w_pgrp.size(); T.pc0 = (int)w_pslot0.size();
 				// one chunk task per wave: the smallest R whose H_pp + Schur chunks fit one round of the workgroup's waves
 				auto by_pid = [](const item& a, const item& b) { return a.pid < b.pid; };
 				std::stable_sort(pitems.begin(), pitems.end(), by_pid);
 				std::stable_sort(qitems.begin(), qitems.end(), by_pid);
+				if (!acc) {
 				int R = 1;
 				while (R < 255 && (count_groups(pitems, R) + 63) / 64 + (count_groups(qitems, R) + 63) / 64 > SSK_LMT_NT / 64) ++R;
 				make_groups(pitems, R, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
 				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size();
 				make_groups(qitems, R, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
+				} else {
+				// ---- on-chip accumulation: the last lane of a block's run adds the run's sum to the block's LDS accumulator, so a block
+				// must belong to ONE wave of the tile: chunks (one per wave pass) are cut at block boundaries and padded with empty groups,
+				// and R is at least large enough for the largest block to fit one chunk ----
+				const int NWv = SSK_LMT_NT / 64;
+				auto chunks_acc = [](const std::vector<item>& items, int R) {
+					int n = (int)items.size(), fill = 0, chunks = n ? 1 : 0;
+					for (int i = 0; i < n;) {
+						int j = i; while (j < n && items[j].pid == items[i].pid) ++j;
+						const int g = (j - i + R - 1) / R;
+						if (g > 64) return 1 << 20;
+						if (fill + g > 64) { ++chunks; fill = 0; }
+						fill += g; i = j;
+					}
+					return chunks;
+				};
+				auto make_groups_acc = [&](std::vector<item>& items, int R, std::vector<int>& it_out, std::vector<int2>& grp_out, int& n_grp, int& n_chunk) {
+					const int n = (int)items.size(), base = (int)it_out.size(), g0 = (int)grp_out.size();
+					int fill = 0;
+					for (int i = 0; i < n;) {
+						int j = i; while (j < n && items[j].pid == items[i].pid) ++j;
+						const int g = (j - i + R - 1) / R;
+						if (fill + g > 64) {                         // pad the chunk: empty groups that extend the previous block's run with zeros
+							const int2 last = grp_out.back();
+							for (; fill < 64; ++fill) grp_out.push_back(make_int2(last.x, last.y & ~255));
+							fill = 0;
+						}
+						for (int k = i; k < j; k += R) grp_out.push_back(make_int2(base + k, std::min(R, j - k) | (items[i].pid << 8)));
+						fill += g; i = j;
+					}
+					for (const item& x : items) it_out.push_back(x.packed);
+					n_grp = (int)grp_out.size() - g0; n_chunk = (n_grp + 63) / 64;
+				};
+				int R = 1;
+				if (panels) { while (R < 255 && chunks_acc(pitems, R) > NWv / 2) ++R; }
+				else { while (R < 255 && chunks_acc(pitems, R) + chunks_acc(qitems, R) > NWv) ++R; }
+				make_groups_acc(pitems, R, w_pit, w_pgrp, T.n_pg, T.n_pc);
+				T.sg0 = (int)w_sgrp.size(); T.sc0 = 0; T.n_sg = 0; T.n_sc = 0;
+				if (!panels) make_groups_acc(qitems, R, w_qit, w_sgrp, T.n_sg, T.n_sc);
+				// tasks of the tile's chunk phase, longest first onto the least loaded wave: H_pp chunk c = (0 << 28) | c, sparse Schur chunk
+				// c = (1 << 28) | c, matrix-core Schur tile (I, J) = (2 << 28) | (J << 8) | I
+				struct task { long long cost; int code; };
+				std::vector<task> tasks;
+				for (int c = 0; c < T.n_pc; ++c) tasks.push_back({700 + 380LL * R, c});
+				for (int c = 0; c < T.n_sc; ++c) tasks.push_back({700 + 420LL * R, (1 << 28) | c});
+				if (panels) {
+					const int TR = ssk_lma_row_tiles(E);
+					for (int J = 0; J < TR; ++J)
+						for (int I = 0; I <= J; ++I) {
+							int cover = 0;
+							for (size_t ok = oi; ok < oj; ++ok) cover += (lm_rowmask[ok] >> I) & (lm_rowmask[ok] >> J) & 1;
+							if (cover) tasks.push_back({250 + 80LL * cover, (2 << 28) | (J << 8) | I});
+						}
+				}
+				std::stable_sort(tasks.begin(), tasks.end(), [](const task& a, const task& b) { return a.cost > b.cost; });
+				std::vector<std::vector<int>> per_wave((size_t)NWv);
+				std::vector<long long> load((size_t)NWv, 0);
+				for (const task& t : tasks) {
+					int best = 0;
+					for (int wv = 1; wv < NWv; ++wv) if (load[wv] < load[best]) best = wv;
+					per_wave[best].push_back(t.code); load[best] += t.cost;
+				}
+				T.wt0 = (int)w_wt_off.size();
+				for (int wv = 0; wv < NWv; ++wv) { w_wt_off.push_back((int)w_wt.size()); w_wt.insert(w_wt.end(), per_wave[wv].begin(), per_wave[wv].end()); }
+				w_wt_off.push_back((int)w_wt.size());
+				}
 				w_tiles.push_back(T);
-				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (size_t)tile_bytes(T.n_ent, T.n_obs, T.n_inc, T.n_lm));
+				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (acc ? 8 * (size_t)ssk_lma_acc_doubles(E) : 0) +
+				                                (size_t)tile_bytes(T.n_ent, T.n_obs, nY, T.n_lm));
 				oi = oj;
 			}
 			// the observations outside every tile (fixed landmark, no optimised edge on the path) still count in the error
@@ -564,6 +663,10 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			for (const lm_tile& T : w_tiles)
 				std::fprintf(stderr, "[ssk lm]   tile: lms %d obs %d ent %d inc %d | pgroups %d (chunks %d) sgroups %d (chunks %d)\n", T.n_lm, T.n_obs, T.n_ent, T.n_inc, T.n_pg, T.n_pc, T.n_sg, T.n_sc);
 		}
+		H.acc = acc && tiled ? 1 : 0;
+		H.wt0 = (int)wt.size(); H.wto0 = (int)wt_off.size(); H.pad_acc = 0;
+		wt.insert(wt.end(), w_wt.begin(), w_wt.end()); wt_off.insert(wt_off.end(), w_wt_off.begin(), w_wt_off.end());
+		tl_pan.insert(tl_pan.end(), w_tl_pan.begin(), w_tl_pan.end());
 		H.n_tiles = tiled ? (int)w_tiles.size() : -1;
 		H.tile0 = (int)tiles.size(); H.tl0 = (int)tl_rec.size(); H.tobs0 = (int)tobs_a.size();
 		H.pit0 = (int)pit.size(); H.pg0 = (int)pgrp.size(); H.pcx0 = (int)pslot0.size(); H.ps0 = (int)n_pslots_total; H.pcl0 = (int)pcl_idx.size();
@@ -608,9 +711,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		path_obs.insert(path_obs.end(), p_obs.begin(), p_obs.end());
 		slot_edge.insert(slot_edge.end(), s_edge.begin(), s_edge.end());
 		slot_lm.insert(slot_lm.end(), s_lm.begin(), s_lm.end());
-		int acc = 0;
-		for (int l = 0; l < L; ++l) { lmo_off.push_back(acc); acc += (int)lm_obs[l].size(); lmo_idx.insert(lmo_idx.end(), lm_obs[l].begin(), lm_obs[l].end()); }
-		lmo_off.push_back(acc);
+		int acc_o = 0;
+		for (int l = 0; l < L; ++l) { lmo_off.push_back(acc_o); acc_o += (int)lm_obs[l].size(); lmo_idx.insert(lmo_idx.end(), lm_obs[l].begin(), lm_obs[l].end()); }
+		lmo_off.push_back(acc_o);
 		if (L > 0) lsm_off.insert(lsm_off.end(), w_lsm_off.begin(), w_lsm_off.end()); else lsm_off.push_back(0);
 		lme_edge.insert(lme_edge.end(), w_lme_edge.begin(), w_lme_edge.end());
 		lme_ls.insert(lme_ls.end(), w_lme_ls.begin(), w_lme_ls.end());
@@ -641,7 +744,14 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		inc_rec.insert(inc_rec.end(), w_inc_rec.begin(), w_inc_rec.end());
 	}
 
-	if (!tiled_all && !with_general) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, true);
+	if (want_acc && !acc_all) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, with_general, false);
+	if (want_acc && !force_acc) {
+		// few windows of several tiles each: the cooperative slot kernel spreads a window over CUs, which beats one workgroup per window
+		int mt = 0;
+		for (const lm_win& hw : hdr) mt = std::max(mt, hw.n_tiles);
+		if (mt >= 4 && n_windows * 4 <= ctx->n_cu) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, with_general, false);
+	}
+	if (!tiled_all && !with_general) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, true, false);
 	const auto t_sym = std::chrono::steady_clock::now();
 	ssk_lm_batch* b = new ssk_lm_batch();
 	b->has_general = with_general;
@@ -663,8 +773,11 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(inc_rec, inc_rec); UP(lmep_loc, lmep_loc);
 	UP(pit, pit); UP(pgrp, pgrp); UP(pslot0, pslot0); UP(pcl_off, pcl_off); UP(pcl_idx, pcl_idx);
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
+	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan);
 #undef UP
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
+	b->acc_ok = want_acc && acc_all && tiled_all; b->schur_mfma = schur_mfma;
+	D.store_hff = 0;
 	b->max_tiles = 0;
 	for (const lm_win& hw : b->hdr) b->max_tiles = std::max(b->max_tiles, hw.n_tiles);
 	if (!rc) rc = upload(b, pose, const_cast<const double**>(&D.pose));     // working copies of the state (pose0 / lm0 keep the initial one)
@@ -715,8 +828,12 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 
 int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out)
 {
+	// SSK_LM_KERNEL: l2 = the general scratch-in-L2 kernel, tiled / coop = the slot kernels (one / several workgroups per window),
+	// acc = on-chip accumulation (windows with E <= SSK_LMA_MAX_E; on request: its accumulators cost LDS, i.e. more tiles per pass)
 	const char* force = std::getenv("SSK_LM_KERNEL");
-	return lm_batch_create_impl(ctx, windows, n_windows, trace, out, force && std::strcmp(force, "l2") == 0);
+	const bool l2 = force && std::strcmp(force, "l2") == 0;
+	const bool want_acc = force && std::strcmp(force, "acc") == 0;
+	return lm_batch_create_impl(ctx, windows, n_windows, trace, out, l2, want_acc);
 }
 
 int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b)
@@ -747,6 +864,7 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
 	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
 	b->coop_pending = false;
+	if (b->acc_ok) return ssk_lm_launch_acc(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
 		// the grid barrier of the cooperative kernel needs all n_windows * G workgroups resident: G from what the occupancy
 		// query says one CU holds with this launch's LDS, not from the CU count alone

@@ -49,6 +49,10 @@ struct lm_win {
 	int tobs0;            // packed observation records tobs_a[], tobs_px[]: tile order, then the observations outside every tile (n_obs in all)
 	int pit0, pg0, pcx0, ps0, pcl0;   // H_pp items pit[], lane groups pgrp[], chunk slot bases pslot0[], partial slots Ppart2 x36, pcl_idx[]
 	int qit0, sg0, scx0, ss0, scl0;   // Schur items qit[], lane groups sgrp[], sslot0[], Spart2 x36, scl_idx[]
+	// ---- on-chip accumulation (lm_solve_acc_kernel): acc != 0 when the window's accumulators fit LDS (E <= SSK_LMA_MAX_E) ----
+	int acc;              // 0: partial slots in HBM (kernels above); 1: H_pp blocks, Schur tiles and the reduced gradient accumulate in LDS
+	int wt0, wto0;        // per-wave task lists of the tiles: entries wt[] (base wt0), per tile NW + 1 offsets into them wt_off[] (base wto0)
+	int pad_acc;
 	long long h0;  // Hred (6E)^2 doubles (only used when the matrix does not fit LDS); Hpair 36 x n_pairs
 	long long dp_trace0, df_trace0;
 };
@@ -67,7 +71,8 @@ struct lm_tile {
 	int inc0, n_inc;      // incidences = lme entries W.lme0 + inc0 ..   (n_inc + n_lm <= workgroup size)
 	int pg0, n_pg, pc0, n_pc;   // H_pp lane groups pgrp[W.pg0 + pg0 ..), chunks pslot0[W.pcx0 + pc0 ..)
 	int sg0, n_sg, sc0, n_sc;   // Schur lane groups / chunks
-	int pad;
+	int n_pan;            // acc: Y panels of the tile (a panel = one 16-row tile of the reduced system x one landmark, [3][16] doubles)
+	int wt0, pad0, pad1;  // acc: first entry of the tile's wt_off table (window relative)
 };
 
 struct lm_dev {
@@ -76,6 +81,8 @@ struct lm_dev {
 	const int4* inc_rec; const int* lmep_loc;
 	const int* pit; const int2* pgrp; const int* pslot0; const int* pcl_off; const int* pcl_idx;
 	const int* qit; const int2* sgrp; const int* sslot0; const int* scl_off; const int* scl_idx;
+	const int* wt_off; const int* wt; const int2* tl_pan;   // acc kernel (tl_pan: per tile landmark (row-tile mask, first panel of the tile's panel array))
+	int store_hff;        // 1: the landmark blocks H_ff / g_f of the last linearisation go to HBM (shared-landmark exchange); 0: they stay on chip
 	double* Ppart2; double* Spart2;
 	const int* edge_slot; double* pose; const double* pose0; double* pose_new;
 	const int* lm_slot; double* lm; const double* lm0; double* lm_new;
@@ -120,4 +127,11 @@ int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_wi
 // G workgroups per window (n_windows * G <= number of CUs, G <= 64): single large windows of the un-batched drop-in path
 int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout = false);
 int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes);
+// on-chip accumulation kernel: layout shared by the host tiler and the kernel
+constexpr int SSK_LMA_MAX_E = 12;                  // optimised edges up to which the accumulators live in LDS
+constexpr int SSK_LMA_PANEL = 48;                  // doubles per Y panel: [3 columns][16 rows]
+inline int ssk_lma_row_tiles(int E) { return (6 * E + 15) / 16; }
+// LDS doubles of the accumulators: H_pp blocks (36 per block pair), Schur tiles (256 per upper 16x16 tile), gradient (6E, even)
+inline int ssk_lma_acc_doubles(int E) { const int T = ssk_lma_row_tiles(E); return 36 * (E * (E + 1) / 2) + 256 * (T * (T + 1) / 2) + ((6 * E + 1) & ~1); }
+int ssk_lm_launch_acc(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma);
 int ssk_lm_launch_reset(ssk_ctx* ctx, double* pose, const double* pose0, size_t n_pose, double* lm, const double* lm0, size_t n_lm);

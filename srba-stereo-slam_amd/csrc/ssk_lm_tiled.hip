@@ -530,6 +530,294 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 		__syncthreads();
 }
 
+// ================= on-chip accumulation (lm_solve_acc_kernel) =================
+// Windows with few optimised edges (E <= SSK_LMA_MAX_E): nothing but Y leaves the chip.  LDS holds, beside the tile records,
+//   P_acc  36 doubles per block pair    H_pp blocks, summed over the tiles (kept across a rejected step: same state, same blocks)
+//   S_acc  256 doubles per upper 16x16 tile of the reduced system (matrix-core form), or 36 per block pair (sparse form)
+//   g_acc  6E doubles                   reduced gradient
+// H_pp / sparse Schur: the chunk tasks of the slot kernels, but the last lane of a block's run ADDS the run's sum to the block's
+// accumulator.  The host gives every block of a tile to one wave and one chunk, and runs cut by the 16-lane DPP rows are added
+// row by row, so an accumulator never sees two adds of one instruction and the order of its adds is fixed: deterministic.
+// Matrix-core Schur: S = sum_l Y_l Y_l^T with Y_l (6E x 3) the stacked Y blocks of landmark l.  Y is written as PANELS -- per
+// (landmark, 16-row tile it touches) a [3][16] block, zero where the landmark has no incidence -- and a task (I, J) runs one
+// v_mfma_f64_16x16x4_f64 per landmark that touches both row tiles: A = panel I, B = panel J (k = 3 columns of Y + one zero
+// lane group), the 16x16 accumulator lives in 4 VGPR pairs for the whole task and goes back to LDS once.
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_add_f64(double* p, double v)
+{
+	(void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // ds_add_f64: no wait for a read
+}
+
+// wave_seg_sum36 with the accumulators in LDS: acc36 + 36 * key
+__device__ __forceinline__ void wave_seg_add36(double (&acc)[36], int key, int lane, double* __restrict__ acc36)
+{
+	const int prev = __shfl_up(key, 1, 64);
+	const bool head = (lane & 15) == 0 || key != prev;
+	const unsigned long long hm = __ballot(head);
+	const bool tail = (lane & 15) == 15 || ((hm >> ((lane + 1) & 63)) & 1ull);
+	const bool s1 = dpp_same_key<1>(key), s2 = dpp_same_key<2>(key), s4 = dpp_same_key<4>(key), s8 = dpp_same_key<8>(key);
+#pragma unroll
+	for (int i = 0; i < 36; ++i) {
+		double v = acc[i], t;
+		t = dpp_shr_f64<1>(v); v += s1 ? t : 0.0;
+		t = dpp_shr_f64<2>(v); v += s2 ? t : 0.0;
+		t = dpp_shr_f64<4>(v); v += s4 ? t : 0.0;
+		t = dpp_shr_f64<8>(v); v += s8 ? t : 0.0;
+		acc[i] = v;
+	}
+	double* out = acc36 + 36 * key;
+	for (int r = 0; r < 4; ++r)                            // one DPP row per round: a block's runs in different rows add one after the other
+		if (tail && (lane >> 4) == r) {
+#pragma unroll
+			for (int i = 0; i < 36; ++i) lds_add_f64(out + i, acc[i]);
+		}
+}
+
+// S tile (I, J) += sum over the tile's landmarks that touch row tiles I and J of panel_I panel_J^T.  lmask / lbase: this lane's
+// landmark(s) of the tile (lane, lane + 64): row-tile mask and first panel; pan: the tile's panels.
+__device__ __forceinline__ void schur_mfma_task(const double* __restrict__ pan, int mask0, int base0, int mask1, int base1, int I, int J, int lane,
+                                                double* __restrict__ S_tile)
+{
+	v4d_t c = {S_tile[lane], S_tile[64 + lane], S_tile[128 + lane], S_tile[192 + lane]};
+	const int l48 = lane < 48 ? lane : 47;
+	const bool real = lane < 48;                           // k = 3: the fourth 16-lane group multiplies zeros
+#pragma unroll
+	for (int half = 0; half < 2; ++half) {
+		const int mk = half ? mask1 : mask0, bs = half ? base1 : base0;
+		// this lane's landmark: panels of row tiles I and J (rank of the bit inside the mask)
+		const int pa = bs + __popc(mk & ((1 << I) - 1)), pb = bs + __popc(mk & ((1 << J) - 1));
+		unsigned long long todo = __ballot(((mk >> I) & (mk >> J) & 1) != 0);
+		while (todo) {
+			const int l = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			const int qa = __builtin_amdgcn_readlane(pa, l), qb = __builtin_amdgcn_readlane(pb, l);
+			double a = pan[SSK_LMA_PANEL * qa + l48];
+			double b = pan[SSK_LMA_PANEL * qb + l48];
+			a = real ? a : 0.0; b = real ? b : 0.0;
+			c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+		}
+	}
+	S_tile[lane] = c[0]; S_tile[64 + lane] = c[1]; S_tile[128 + lane] = c[2]; S_tile[192 + lane] = c[3];
+}
+
+#ifdef SSK_LM_STAMPS
+__device__ unsigned long long g_tst[8];
+#define TSTAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_tst[i] += t_ - tst_last; tst_last = t_; } } while (0)
+#else
+#define TSTAMP(i) do {} while (0)
+#endif
+// One tile with on-chip accumulation.  Region: [entries | observation records | Y (records or panels) | landmark records |
+// gradient terms (7 per incidence: 6 values + edge slot)].
+template <bool MFMA>
+__device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* pose_cur,
+                                                 double* reg, double lambda, bool pre, bool same_state, int epoch, int* s_lmflag,
+                                                 double* __restrict__ P_acc, double* __restrict__ S_acc, double* __restrict__ g_acc, double& vmax)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	double* ent = reg;
+	double* obsr = ent + ENT_P * T.n_ent;
+	double* Yr = obsr + OBS_P * T.n_obs;                   // sparse: Y_P per incidence; MFMA: SSK_LMA_PANEL per panel
+	double* lmr = Yr + (MFMA ? SSK_LMA_PANEL * T.n_pan : Y_P * T.n_inc);
+	double* gsc = lmr + LMR_P * T.n_lm;                    // 7 per incidence
+	const int n6 = 6 * W.E;
+#ifdef SSK_LM_STAMPS
+	unsigned long long tst_last = __builtin_amdgcn_s_memtime();
+#endif
+	// ---- I1: observations; the Y panels start from zero ----
+	if (MFMA && !pre) for (int i = tid; i < SSK_LMA_PANEL * T.n_pan; i += NT) Yr[i] = 0.0;
+	for (int k = tid; k < T.n_obs; k += NT)
+		linearize_obs_lds(D, W, P, pose_cur, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
+	__syncthreads();
+	TSTAMP(0);
+	// ---- I2: landmark lanes (top of the workgroup): V, g_f, Cholesky -> lmr ----
+	{
+		const int j = NT - 1 - tid;
+		if (j < T.n_lm) {
+			const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];
+			const int slot = lrec.x;
+			if (slot >= 0) {
+				double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
+				for (int k = lrec.y; k < lrec.z; ++k) {
+					const double* orr = obsr + OBS_P * k;
+					double jf[12], rr[4];
+#pragma unroll
+					for (int c = 0; c < 12; ++c) jf[c] = orr[c];
+#pragma unroll
+					for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
+					v00 += jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
+					v01 += jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
+					v02 += jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
+					v11 += jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
+					v12 += jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
+					v22 += jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
+					g0 += jf[0] * rr[0] + jf[3] * rr[1] + jf[6] * rr[2] + jf[9] * rr[3];
+					g1 += jf[1] * rr[0] + jf[4] * rr[1] + jf[7] * rr[2] + jf[10] * rr[3];
+					g2 += jf[2] * rr[0] + jf[5] * rr[1] + jf[8] * rr[2] + jf[11] * rr[3];
+				}
+				if (pre) {
+					vmax = fmax(vmax, fmax(v00, fmax(v11, v22)));
+				} else {
+					if (D.store_hff) {                         // only the shared-landmark exchange reads the landmark blocks
+						double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
+						Hm[0] = v00; Hm[1] = v01; Hm[2] = v02; Hm[3] = v01; Hm[4] = v11; Hm[5] = v12; Hm[6] = v02; Hm[7] = v12; Hm[8] = v22;
+						double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
+						gl[0] = g0; gl[1] = g1; gl[2] = g2;
+					}
+					const double i00 = rsq_f64(v00 + lambda);
+					const double l10 = v01 * i00, l20 = v02 * i00;
+					const double i11 = rsq_f64(v11 + lambda - l10 * l10);
+					const double l21 = (v12 - l20 * l10) * i11;
+					const double i22 = rsq_f64(v22 + lambda - l20 * l20 - l21 * l21);
+					const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
+					const double rec[9] = {i00, i10, i11, i20, i21, i22, i00 * g0, i10 * g0 + i11 * g1, i20 * g0 + i21 * g1 + i22 * g2};
+					double* lr = lmr + LMR_P * j;
+					double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
+#pragma unroll
+					for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
+				}
+			}
+		}
+	}
+	if (lane == 0) __hip_atomic_fetch_add(s_lmflag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+	// ---- I2: incidence lanes: W, gradient term; Y = W L^-T -> LDS (records or panels) and HBM (back-substitution) ----
+	if (!pre && tid < T.n_inc) {
+		const int4 irec = D.inc_rec[W.lme0 + T.inc0 + tid];
+		const int lml = irec.x & 0x7FFF, cnt = irec.x >> 16;
+		const bool unk = (irec.x >> 15) & 1;
+		const int e_slot = D.lme_edge[W.lme0 + T.inc0 + tid];
+		double Wm[18], ge[6];
+#pragma unroll
+		for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
+#pragma unroll
+		for (int c = 0; c < 6; ++c) ge[c] = 0.0;
+		int nxt = irec.w;
+		for (int k = 0; k < cnt; ++k) {
+			const int loc = nxt;
+			if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + irec.y + k + 1];
+			const double* er = ent + ENT_P * (loc & 0xFFFF);
+			const double* orr = obsr + OBS_P * (loc >> 16);
+			double a[12], q[3], rr[4], tv[3], x[3];
+#pragma unroll
+			for (int c = 0; c < 12; ++c) a[c] = er[c];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) q[c] = er[12 + c];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) tv[c] = a[c] * rr[0] + a[3 + c] * rr[1] + a[6 + c] * rr[2] + a[9 + c] * rr[3];
+			cross3(q, tv, x);
+#pragma unroll
+			for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
+			if (unk) {
+				double jf[12];
+#pragma unroll
+				for (int c = 0; c < 12; ++c) jf[c] = orr[c];
+#pragma unroll
+				for (int b = 0; b < 3; ++b) {
+					double cb[3];
+#pragma unroll
+					for (int c = 0; c < 3; ++c) cb[c] = a[c] * jf[b] + a[3 + c] * jf[3 + b] + a[6 + c] * jf[6 + b] + a[9 + c] * jf[9 + b];
+					cross3(q, cb, x);
+#pragma unroll
+					for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
+				}
+			}
+		}
+		double* gr = gsc + 7 * tid;
+		gr[6] = __hiloint2double(0, e_slot);
+		if (unk) {
+			while (__hip_atomic_load(s_lmflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * epoch) __builtin_amdgcn_s_sleep(1);
+			const double* lr = lmr + LMR_P * lml;
+			const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
+			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0 + tid);
+			int mk = 0, bs = 0;
+			if (MFMA) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lml]; mk = tp.x; bs = tp.y; }
+#pragma unroll
+			for (int a = 0; a < 6; ++a) {
+				const double y0 = Wm[3 * a] * i00;
+				const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
+				const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
+				gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
+				if (MFMA) {
+					const int r = 6 * e_slot + a, rt = r >> 4;
+					double* pp = Yr + SSK_LMA_PANEL * (bs + __popc(mk & ((1 << rt) - 1))) + (r & 15);
+					pp[0] = y0; pp[16] = y1; pp[32] = y2;
+					yg[3 * a] = y0; yg[3 * a + 1] = y1; yg[3 * a + 2] = y2;
+				} else {
+					double* yl = Yr + Y_P * tid;
+					yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
+				}
+			}
+		} else {
+#pragma unroll
+			for (int a = 0; a < 6; ++a) gr[a] = ge[a];
+		}
+	}
+	__syncthreads();
+	TSTAMP(1);
+	// ---- I3 ----
+	if (!pre) {
+		if (!MFMA) {                                       // Y to HBM for the back-substitution (coalesced)
+			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
+			for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
+		}
+		// reduced gradient: component (e, a) by 8 lanes that walk the tile's incidences in order and take those of edge e
+		for (int it = tid; it < n6 * 8; it += NT) {
+			const int comp = it >> 3, j = it & 7, e = comp / 6, a = comp - e * 6;
+			double sacc = 0.0;
+			for (int k = j; k < T.n_inc; k += 8) {
+				const double* gr = gsc + 7 * k;
+				const double v = gr[a];
+				sacc += __double2loint(gr[6]) == e ? v : 0.0;
+			}
+			sacc += __shfl_down(sacc, 4, 8); sacc += __shfl_down(sacc, 2, 8); sacc += __shfl_down(sacc, 1, 8);
+			if (j == 0) g_acc[comp] += sacc;
+		}
+	}
+	TSTAMP(2);
+	{
+		const int* wo = D.wt_off + W.wto0 + T.wt0;
+		const int k0 = wo[wave], k1 = wo[wave + 1];
+		int mask0 = 0, base0 = 0, mask1 = 0, base1 = 0;
+		if (MFMA && !pre) {
+			if (lane < T.n_lm) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lane]; mask0 = tp.x; base0 = tp.y; }
+			if (lane + 64 < T.n_lm) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lane + 64]; mask1 = tp.x; base1 = tp.y; }
+		}
+		for (int k = k0; k < k1; ++k) {
+			const int code = D.wt[W.wt0 + k], kind = code >> 28;
+			if (kind == 0) {
+				if (same_state) continue;                      // the previous pass linearised at this very state: its H_pp blocks stand
+				const int g = 64 * (code & 0xFFFFFF) + lane;
+				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
+				double acc[36];
+#pragma unroll
+				for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+				pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
+				wave_seg_add36(acc, rec.y >> 8, lane, P_acc);
+			} else if (pre) {
+				continue;
+			} else if (kind == 1) {
+				const int g = 64 * (code & 0xFFFFFF) + lane;
+				const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
+				double acc[36];
+#pragma unroll
+				for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+				schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
+				wave_seg_add36(acc, rec.y >> 8, lane, S_acc);
+			} else if (MFMA) {
+				const int I = code & 255, J = (code >> 8) & 255;
+				schur_mfma_task(Yr, mask0, base0, mask1, base1, I, J, lane, S_acc + 256 * (J * (J + 1) / 2 + I));
+			}
+		}
+#ifdef SSK_LM_STAMPS
+		if (threadIdx.x == 0 && blockIdx.x == 0) g_tst[4] += __builtin_amdgcn_s_memtime() - tst_last;      // wave 0's own tasks
+#endif
+	}
+	__syncthreads();
+	TSTAMP(3);
+}
+
 // F2: H_red block (e,e') = sum of its H_pp slots + lambda I - sum of its Schur slots (slot order), diagonal blocks
 // written from their upper triangle; g_red(e) = sum of its incidences' terms (contiguous, edge-major, 8 lanes per
 // component) into the border row; G: blocked LDL^T + back-substitution (ssk_lm_device.h).  A: (n6 + 1) x np.
@@ -596,9 +884,12 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 	return ok_;
 }
 
-template <bool COOP>
+// ACC: 0 = partial slots in HBM, 1 = on-chip accumulation with sparse Schur items, 2 = on-chip accumulation with the Schur
+// complement on the matrix cores
+template <bool COOP, int ACC = 0>
 __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, int dyn_doubles, int G, int coop_expect = 1, int coop_spin_limit = COOP_SPIN_LIMIT)
 {
+	static_assert(!(COOP && ACC), "the accumulators of a window live in one workgroup's LDS");
 	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | delta | pivots | tile records / reduced system]
 	__shared__ double s_part[NW];
 	__shared__ double s_lambda, s_nu, s_err;
@@ -618,7 +909,12 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	double* pose_new = s_dyn + 12 * W.n_edges;
 	double* s_b = s_dyn + 24 * W.n_edges;               // right-hand side / solution of the reduced system (n6)
 	double* s_inv = s_b + n6p;                         // reciprocal pivots of the LDS solve (n6)
-	double* reg = s_inv + n6p;
+	// on-chip accumulators (ACC): H_pp blocks, Schur tiles / blocks, reduced gradient
+	const int n_accP = ACC ? 36 * W.n_pairs : 0, RT = (n6 + 15) >> 4, n_accS = ACC ? 256 * (RT * (RT + 1) / 2) : 0;
+	double* P_acc = s_inv + n6p;
+	double* S_acc = P_acc + n_accP;
+	double* g_acc = S_acc + n_accS;
+	double* reg = ACC ? g_acc + n6p : s_inv + n6p;
 	// the reduced system lives over the dead tile records when (n6 + 1) x (n6 | 1) doubles fit there (E <= ~22),
 	// otherwise in the window's L2-resident scratch (same blocked factorisation through plain pointers)
 	const bool lds_mat = (long long)(n6 + 1) * (n6 | 1) <= (long long)dyn_doubles - (reg - s_dyn);
@@ -673,8 +969,14 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		const int it_idx = s_iters;
 		double vmax = 0.0;
 		STAMP(0);
+		if (ACC) {                                     // the accumulators of this pass start from zero (H_pp: unless the state has not moved)
+			for (int i = tid; i < n_accS + n6p; i += NT) S_acc[i] = 0.0;
+			if (!same_state) for (int i = tid; i < n_accP; i += NT) P_acc[i] = 0.0;
+			__syncthreads();
+		}
 		for (int t = g; t < W.n_tiles; t += GG) {
-			process_tile(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, same_state, ++epoch, &s_lmflag, Pp, Sp, vmax);
+			if (ACC) process_tile_acc<ACC == 2>(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, same_state, ++epoch, &s_lmflag, P_acc, S_acc, g_acc, vmax);
+			else process_tile(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, same_state, ++epoch, &s_lmflag, Pp, Sp, vmax);
 			STAMP(1);
 		}
 		if (COOP) {                                    // every workgroup's slots, Y, gradient terms and landmark factors are out
@@ -687,7 +989,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			double mx = vmax;
 			for (int it = tid; it < n6; it += NT) {
 				const int e = it / 6, a = it - 6 * e, pid = e * (e + 1) / 2 + e;
-				mx = fmax(mx, slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], 7 * a));
+				mx = fmax(mx, ACC ? P_acc[36 * pid + 7 * a] : slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], 7 * a));
 			}
 			mx = block_max(mx, s_part);
 			if (tid == 0) { s_lambda = P.tau * mx; s_same = 1; }
@@ -703,7 +1005,24 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			if (!alive) continue;
 		}
 		STAMP(5);
-		if (g == 0) {
+		if (ACC) {
+			// the reduced system from the accumulators, all in LDS: A = H_pp - S + lambda I over the dead tile records, border row = gradient
+			for (int it = tid; it < W.n_pairs * 36; it += NT) {
+				const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
+				const int2 ee = D.pair_ee[W.pair0 + pid];
+				if (ee.x == ee.y && a > b) continue;
+				const int row = 6 * ee.x + a, col = 6 * ee.y + b;
+				const double sc = ACC == 2 ? S_acc[256 * ((col >> 4) * ((col >> 4) + 1) / 2 + (row >> 4)) + (((row & 15) >> 2) << 6) + ((row & 3) << 4) + (col & 15)]
+				                           : S_acc[it];
+				double sres = P_acc[it] - sc;
+				if (row == col) sres += lambda;
+				reg[row * np + col] = sres;
+				reg[col * np + row] = sres;
+			}
+			for (int i = tid; i < n6; i += NT) reg[n6 * np + i] = g_acc[i];
+			__syncthreads();
+			if (n6 > 0) ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
+		} else if (g == 0) {
 			ok = lds_mat ? assemble_and_solve<false>(D, W, Pp, Sp, lambda, reg, np, n6, s_b, s_inv)
 			             : assemble_and_solve<true>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, !share_f2, true, tid, NT,
 			                                  reg, dyn_doubles - (int)(reg - s_dyn));
@@ -846,6 +1165,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
 			printf("LDL wave0 %llu waves1+ %llu step incl barrier %llu backsub %llu\n", g_ldl[0], g_ldl[1], g_ldl[2], g_ldl[3]);
 			printf("LMT F2 blocks %llu F2 gradient %llu G %llu (slots: pp %d schur %d)\n", g_f2g[0], g_f2g[1], g_f2g[2], D.pcl_off[W.pairo0 + W.n_pairs] - D.pcl_off[W.pairo0], D.scl_off[W.pairo0 + W.n_pairs] - D.scl_off[W.pairo0]);
+			printf("ACC tile phases: I1 %llu I2 %llu gradient %llu tasks (all waves) %llu, of which wave 0 busy %llu\n", g_tst[0], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
 			printf("LMT fine I3: wave0 (H_pp task) copy %llu items %llu segsum %llu wait %llu | wave4 (Schur task) copy %llu items %llu segsum %llu wait %llu\n",
 			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[8], s_fine[9], s_fine[10], s_fine[11]);
 			}
@@ -857,6 +1177,18 @@ __global__ __launch_bounds__(NT, SSK_LM_WAVES)
 void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 {
 	lm_tiled_body<false>(D, P, dyn_doubles, 1);
+}
+
+// on-chip accumulation (E <= SSK_LMA_MAX_E): Schur complement by sparse 6x6 items / on the FP64 matrix cores
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_acc_kernel(lm_dev D, lm_cam P, int dyn_doubles)
+{
+	lm_tiled_body<false, 1>(D, P, dyn_doubles, 1);
+}
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_acc_mfma_kernel(lm_dev D, lm_cam P, int dyn_doubles)
+{
+	lm_tiled_body<false, 2>(D, P, dyn_doubles, 1);
 }
 
 // G workgroups per window (grid = n_windows * G, all resident)
@@ -895,6 +1227,22 @@ int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_win
 	hipLaunchKernelGGL(lm_solve_coop_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
 	                   test_timeout ? G + 1 : G, test_timeout ? 1 << 10 : COOP_SPIN_LIMIT);
 	SSK_LAUNCH_CHECK(ctx, "lm_solve_coop_kernel");
+	return SSK_OK;
+}
+
+int ssk_lm_launch_acc(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma)
+{
+	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
+	static bool attr_set = false;
+	if (!attr_set) {
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_acc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_acc_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		attr_set = true;
+	}
+	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
+	if (schur_mfma) hipLaunchKernelGGL(lm_solve_acc_mfma_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
+	else hipLaunchKernelGGL(lm_solve_acc_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
+	SSK_LAUNCH_CHECK(ctx, schur_mfma ? "lm_solve_acc_mfma_kernel" : "lm_solve_acc_kernel");
 	return SSK_OK;
 }
 

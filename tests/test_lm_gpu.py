@@ -21,8 +21,13 @@ def to_capi(prm):
     return out
 
 
-def rel_err(a, b):
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+def rel_err(a, b, floor=0.0):
+    """|a - b| / max(|b|, floor).  `floor`: the round-off level of the solve.  An LM run ends with attempts whose update is 1e-9 of
+    the first one or less (the stop rule is a 1e-9 relative error decrease): such an update is -H^-1 g with a gradient that has
+    cancelled to round-off, so it differs from kernel to kernel by the summation order of g (1e-5 of a 1e-10 m step was seen between
+    two accumulation orders on the SAME device code).  The 1e-6 bar therefore applies to max(|update|, 1e-6 x the largest update of the
+    run): an absolute 1e-12 of the run's largest step."""
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), floor, 1e-300))
 
 
 def check_against_oracle(ctx, oracle, win, prm, min_accept=1):
@@ -41,6 +46,9 @@ def check_against_oracle(ctx, oracle, win, prm, min_accept=1):
     assert abs(res.accepted - er.accepted) <= (1 if last_free else 0)
     assert res.accepted >= min_accept and res.n_obs == er.n_obs
     assert abs(res.err_init - er.err_init) <= 1e-10 * er.err_init
+    ok_it = [i for i, e in enumerate(exp["trace"]) if e.cholesky_ok]
+    fl_p = 1e-6 * max([np.linalg.norm(exp["dp"][i]) for i in ok_it] + [0.0]) if win.E else 0.0
+    fl_f = 1e-6 * max([np.linalg.norm(exp["df"][i]) for i in ok_it] + [0.0]) if win.L else 0.0
     for i, (g, e) in enumerate(zip(ent, exp["trace"])):
         assert g.cholesky_ok == e.cholesky_ok, i
         if not (last_free and i == res.iters - 1):
@@ -49,9 +57,9 @@ def check_against_oracle(ctx, oracle, win, prm, min_accept=1):
         assert abs(g.err_after - e.err_after) <= REL * abs(e.err_after), (i, g.err_after, e.err_after)
         if e.cholesky_ok:
             if win.E:
-                assert rel_err(dp[i], exp["dp"][i]) <= REL, (i, "edge update", rel_err(dp[i], exp["dp"][i]))
+                assert rel_err(dp[i], exp["dp"][i], fl_p) <= REL, (i, "edge update", rel_err(dp[i], exp["dp"][i]))
             if win.L:
-                assert rel_err(df[i], exp["df"][i]) <= REL, (i, "landmark update", rel_err(df[i], exp["df"][i]))
+                assert rel_err(df[i], exp["df"][i], fl_f) <= REL, (i, "landmark update", rel_err(df[i], exp["df"][i]))
     tol = 1e-5 if last_free else 1e-8
     assert np.abs(poses - exp["poses"]).max() <= tol and np.abs(lms - exp["lms"]).max() <= 10 * tol
     assert abs(res.err_final - er.err_final) <= REL * er.err_final
@@ -267,6 +275,45 @@ def test_lm_bench_windows_against_oracle(ctx, oracle, seed):
     assert win.E == 10 and len(win.obs_lm) > 1000
     res = check_against_oracle(ctx, oracle, win, sl.make_params(), min_accept=2)
     assert res.stop_reason in (1, 4) and res.err_final < res.err_init
+
+
+@pytest.mark.parametrize("schur", ["mfma", "sparse"])
+def test_lm_on_chip_accumulation_kernel(ctx, oracle, schur, monkeypatch):
+    """lm_solve_acc_kernel / lm_solve_acc_mfma_kernel (SSK_LM_KERNEL=acc forces them; the default for batches of windows with
+    E <= 12 optimised edges): H_pp blocks, reduced gradient and the Schur complement accumulate in LDS -- the Schur complement
+    either as sparse 6x6 items (SSK_LM_SCHUR=sparse) or as v_mfma_f64_16x16x4_f64 products of Y panels (=mfma, default).  Same
+    per-iteration bar against the oracle on a one-tile window, a stage-1 window (edges only), bench-shaped multi-tile windows
+    and a window at the E = 12 limit; deterministic run to run."""
+    from ssk_amd import capi
+    monkeypatch.setenv("SSK_LM_KERNEL", "acc")
+    monkeypatch.setenv("SSK_LM_SCHUR", schur)
+    win, gt = sl.make_submap_problem(1, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)
+    check_against_oracle(ctx, oracle, win, sl.make_params(robust=True, sensor_t=(0.2, -0.05, 0.1)), min_accept=2)
+    w1 = sl.Window(np.where(win.edge_unknown_slot == win.E - 1, 0, -1), win.edge_inv_pose,
+                   -np.ones(len(win.lm_pos), np.int32), gt["gt_lm"], win.obs_lm, win.obs_px, win.obs_path_off, win.path_edge)
+    check_against_oracle(ctx, oracle, w1, sl.make_params())
+    for seed in (7, 8):
+        win = sl.make_submap_problem(seed, n_kf=60, n_lm=1500, submap_size=10, max_tree_depth=4, opt_depth=2, obs_per_kf=250,
+                                     lm_fwd=(3, 20), z_vis=(2.5, 22))[0]
+        assert win.E == 10 and len(win.obs_lm) > 800
+        check_against_oracle(ctx, oracle, win, sl.make_params(robust=seed == 7), min_accept=2)
+    win = sl.make_submap_problem(5, n_kf=60, n_lm=1500, submap_size=12, max_tree_depth=4, opt_depth=2, obs_per_kf=200, lm_fwd=(3, 20), z_vis=(2.5, 22))[0]
+    assert win.E == 12, win.E
+    check_against_oracle(ctx, oracle, win, sl.make_params(), min_accept=2)
+    # a batch of ragged windows, twice: bit-identical (fixed order of every accumulator's adds)
+    wins = [sl.make_submap_problem(10 + i, n_kf=8 + 3 * i, n_lm=150 + 60 * i, submap_size=4 + i, obs_per_kf=40 + 10 * i, opt_depth=2)[0] for i in range(5)]
+    assert all(w.E <= 12 for w in wins)
+    b = capi.LmBatch(ctx, wins)
+    b.run(to_capi(sl.make_params()))
+    r1 = b.results(); s1 = [b.state(i) for i in range(len(wins))]
+    b.reset(); b.run(to_capi(sl.make_params()))
+    r2 = b.results()
+    for i, w in enumerate(wins):
+        exp = oracle.lm_solve(w, sl.make_params(), trace=False)
+        assert r1[i].iters == exp["res"].iters and abs(r1[i].err_final - exp["res"].err_final) <= REL * exp["res"].err_final
+        p2, l2 = b.state(i)
+        assert np.array_equal(p2, s1[i][0]) and np.array_equal(l2, s1[i][1]) and r2[i].err_final == r1[i].err_final
+    b.close()
 
 
 def test_build_observations_bit_exact(ctx, oracle):
