@@ -259,6 +259,8 @@ def main():
     B = args.batch
     cur, prev, lm, wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_lm_distinct=max(1, min(args.lm_distinct, B)))
     fp, da, lp, cp, fm = params(capi, sl)
+    if exchange:
+        lm.set_export(True)
     pairs = np.stack([np.arange(B), np.arange(B)], 1).astype(np.int32)
     dev = torch.device("cuda", local)
     N = 512

@@ -462,6 +462,9 @@ int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_en
  * n_ranks GPUs ([n_ranks][n_shared][12], rank-major as all_gather lays them out), summed in rank order so
  * every GPU computes bit-identical fused positions [n_shared*3]. */
 int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, double* d_out);
+/* The landmark blocks H_ff / g_f stay on chip unless somebody will read them: call with on != 0 BEFORE ssk_lm_batch_run to have the
+ * solve leave those of its last linearisation in HBM for ssk_lm_batch_pack_shared (off by default: 96 B per landmark and pass). */
+int ssk_lm_batch_set_export(ssk_ctx* ctx, ssk_lm_batch* b, int on);
 int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double* d_fused);
 
 /* a10/a11: observation marshalling of EST.cpp:142-161,667-704: per match, feat id + pixels + the initial

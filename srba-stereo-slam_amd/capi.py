@@ -615,6 +615,9 @@ class LmBatch:
     def run(self, prm):
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_run(self.ctx.h, self.h_, C.byref(prm)))
 
+    def set_export(self, on=True):
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_set_export(self.ctx.h, self.h_, int(bool(on))))
+
     def pack_shared(self, w, n_shared, d_out):
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_pack_shared(self.ctx.h, self.h_, int(w), int(n_shared), _dev(d_out)))
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 struct ssk_lm_batch {
 	ssk_ctx* ctx = nullptr;
@@ -168,6 +169,14 @@ int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared,
 	return SSK_OK;
 }
 
+int ssk_lm_batch_set_export(ssk_ctx* ctx, ssk_lm_batch* b, int on)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_set_export: batch is NULL");
+	b->D.store_hff = on ? 1 : 0;
+	return SSK_OK;
+}
+
 int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double* d_fused)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
@@ -276,8 +285,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	std::vector<float4> tobs_px;
 	std::vector<int4> tl_rec, inc_rec;
 	std::vector<int> lmep_loc, pit, pslot0, pcl_off, pcl_idx, qit, sslot0, scl_off, scl_idx;
-	std::vector<int2> pgrp, sgrp, tl_pan;
-	std::vector<int> wt_off, wt;
+	std::vector<int2> pgrp, sgrp, tl_pan, suf_rec;
+	std::vector<int> wt_off, wt, tent, tsuf;
+	long long gtab_total = 0;
 	bool acc_all = want_acc;
 	size_t n_pslots_total = 0, n_sslots_total = 0, tiled_dyn = 0;
 	bool tiled_all = true;
@@ -418,12 +428,47 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		std::vector<int> w_lmep_loc(w_lmep_idx.size(), 0);
 		std::vector<int> w_pit, w_pslot0, w_qit, w_sslot0, w_pcl_off((size_t)n_pairs + 1, 0), w_pcl_idx, w_scl_off((size_t)n_pairs + 1, 0), w_scl_idx;
 		std::vector<int2> w_pgrp, w_sgrp, w_tl_pan;
-		std::vector<int> w_wt_off, w_wt;
+		std::vector<int> w_wt_off, w_wt, w_tent, w_tsuf;
+		// ---- path-suffix trie: suffix k of a path = (c_k .. c_{n-1}); a suffix is (first step, shorter suffix), 0 = the empty one ----
+		std::vector<int2> w_suf(1, make_int2(-1, -1));
+		std::vector<int> w_suf_len(1, 0), suf_at((size_t)n_path + 1, 0), obs_suf((size_t)Wn.n_obs, 0);
+		{
+			std::map<std::pair<int, int>, int> ids;
+			for (int o = 0; o < Wn.n_obs; ++o) {
+				int cur = 0;
+				for (int p2 = Wn.obs_path_off[o + 1] - 1; p2 >= Wn.obs_path_off[o]; --p2) {
+					const auto key = std::make_pair(Wn.path_edge[p2], cur);
+					auto it = ids.find(key);
+					if (it == ids.end()) {
+						it = ids.emplace(key, (int)w_suf.size()).first;
+						w_suf.push_back(make_int2(key.first, key.second));
+						w_suf_len.push_back(w_suf_len[cur] + 1);
+					}
+					cur = it->second;
+					suf_at[p2] = cur;
+				}
+				obs_suf[o] = cur;
+			}
+			// ids ascending by length, so that one level only needs the levels before it
+			std::vector<int> perm(w_suf.size()), inv(w_suf.size());
+			for (size_t i = 0; i < perm.size(); ++i) perm[i] = (int)i;
+			std::stable_sort(perm.begin(), perm.end(), [&](int a, int b2) { return w_suf_len[a] < w_suf_len[b2]; });
+			for (size_t i = 0; i < perm.size(); ++i) inv[perm[i]] = (int)i;
+			std::vector<int2> ns(w_suf.size());
+			std::vector<int> nl(w_suf.size());
+			for (size_t i = 0; i < perm.size(); ++i) { ns[i] = make_int2(w_suf[perm[i]].x, w_suf[perm[i]].y < 0 ? -1 : inv[w_suf[perm[i]].y]); nl[i] = w_suf_len[perm[i]]; }
+			w_suf.swap(ns); w_suf_len.swap(nl);
+			for (int& v : suf_at) v = inv[v];
+			for (int& v : obs_suf) v = inv[v];
+		}
+		const int n_suf = (int)w_suf.size();
+		// few suffixes (batched windows): the whole table stays in LDS; many (a local area of tens of keyframes): per-tile copies
+		const bool tab_lds = 96LL * n_suf <= 24 * 1024;
 		int n_pslots = 0, n_sslots = 0;
 		// LDS of a workgroup: static part, the window's edge poses twice, the solution vector and the pivots, the tile region
 		const bool acc = want_acc && E <= SSK_LMA_MAX_E;
 		const long long region_bytes = (long long)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC - 2LL * 12 * 8 * Wn.n_edges_total - 2LL * 8 * ((6 * E + 1) & ~1) -
-		                               (acc ? 8LL * ssk_lma_acc_doubles(E) : 0);
+		                               (acc ? 8LL * ssk_lma_acc_doubles(E) : 0) - (tab_lds ? 96LL * n_suf : 0);
 		bool tiled = 6 * E <= SSK_LM_MAX_N6 && Wn.n_edges_total <= 128 && region_bytes >= 32 * 1024;
 		if (want_acc && !(acc && tiled)) acc_all = false;
 		if (tiled) {
@@ -438,12 +483,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			// packed observation record: everything a lane needs in one coalesced 32-byte load
 			// (x: first local entry | optimised-step mask << 16 | path length << 24, y: landmark, z/w: 8 path codes of 8 bits)
 			std::vector<char> in_tile((size_t)Wn.n_obs, 0);
-			auto pack_obs = [&](int o, int info) {
-				unsigned long long codes = 0;
-				const int pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb;
-				for (int i = 0; i < len; ++i) codes |= (unsigned long long)(Wn.path_edge[pb + i] & 255) << (8 * i);
-				return make_int4(info, Wn.obs_lm[o], (int)(unsigned)(codes & 0xFFFFFFFFull), (int)(unsigned)(codes >> 32));
-			};
+			// (x: first tile-local entry | number of optimised entries << 16, y: landmark, z: suffix id of the whole path as the tile's
+			// table knows it, w: its id in the window's table)
+			auto pack_obs = [&](int o, int info) { return make_int4(info, Wn.obs_lm[o], obs_suf[o], obs_suf[o]); };
 			auto opt_mask = [&](int o) {
 				int om = 0;
 				for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p)
@@ -452,6 +494,13 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			};
 			// balanced cut: the variable footprint of the window spread evenly over the fewest tiles that fit
 			std::vector<long long> fp_P(order.size()), fp_O(order.size()), fp_M(order.size()), fp_Y(order.size());
+			// !tab_lds: the suffixes a landmark's observations use (whole paths + optimised entries), and which tile last took each suffix
+			std::vector<std::vector<int>> lm_sufs(tab_lds ? 0 : order.size());
+			std::vector<int> suf_tile(tab_lds ? 0 : (size_t)n_suf, -1), suf_local(tab_lds ? 0 : (size_t)n_suf, -1);
+			auto entry_suf = [&](int pb, int len, int i) {
+				const int dir = Wn.path_edge[pb + i] & 1;
+				return dir ? suf_at[i + 1 < len ? pb + i + 1 : n_path] : suf_at[pb + i];
+			};
 			std::vector<int> lm_rowmask(order.size(), 0);
 			long long tot = 0;
 			for (size_t oi = 0; oi < order.size(); ++oi) {
@@ -462,6 +511,16 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					for (int m : lm_lmes[oi]) lm_rowmask[oi] |= (1 << ((6 * w_lme_edge[m]) >> 4)) | (1 << ((6 * w_lme_edge[m] + 5) >> 4));
 				fp_Y[oi] = panels ? (long long)SSK_LMA_PANEL * __builtin_popcount(lm_rowmask[oi]) : (long long)SSK_LMT_Y * fp_M[oi];
 				if (acc) fp_Y[oi] += 7 * fp_M[oi];
+				if (!tab_lds) {
+					std::vector<int>& v = lm_sufs[oi];
+					for (int o : obs_of[order[oi]]) {
+						v.push_back(obs_suf[o]);
+						const int pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
+						for (int i = 0; i < len; ++i) if ((om >> i) & 1) v.push_back(entry_suf(pb, len, i));
+					}
+					std::sort(v.begin(), v.end());
+					v.erase(std::unique(v.begin(), v.end()), v.end());
+				}
 				tot += 8 * (SSK_LMT_ENT * fp_P[oi] + SSK_LMT_OBS * fp_O[oi] + fp_Y[oi] + SSK_LMT_LMR);
 			}
 			const long long est_tiles = std::max<long long>(1, (tot + region_bytes * 9 / 10 - 1) / (region_bytes * 9 / 10));
@@ -501,17 +560,30 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			int lme_cursor = 0;
 			while (oi < order.size() && tiled) {
 				lm_tile T{};
-				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_a.size(); T.inc0 = lme_cursor;
-				long long nP = 0, nO = 0, nM = 0, nL = 0, nY = 0, var = 0;
+				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_a.size(); T.inc0 = lme_cursor; T.ent0 = (int)w_tent.size();
+				long long nP = 0, nO = 0, nM = 0, nL = 0, nY = 0, var = 0, nS = 0;
+				const int tile_no = (int)w_tiles.size();
 				size_t oj = oi;
 				for (; oj < order.size(); ++oj) {
-					const long long aP = nP + fp_P[oj], aO = nO + fp_O[oj], aM = nM + fp_M[oj], aL = nL + 1, aY = nY + fp_Y[oj];
-					if (tile_bytes(aP, aO, aY, aL) > region_bytes || aM + aL > SSK_LMT_NT || aP > 65535 || aO > 65535 || (panels && aL > 128)) break;
-					nP = aP; nO = aO; nM = aM; nL = aL; nY = aY;
+					long long aS = nS;
+					if (!tab_lds) for (int sid : lm_sufs[oj]) if (suf_tile[sid] != tile_no) aS += 12;       // the tile's table copy grows with every new suffix
+					const long long aP = nP + fp_P[oj], aO = nO + fp_O[oj], aM = nM + fp_M[oj], aL = nL + 1, aY = nY + fp_Y[oj] + (aS - nS);
+					// one round of lanes per phase: observations, landmarks, incidences each within the workgroup size
+					if (tile_bytes(aP, aO, aY, aL) > region_bytes || aM > SSK_LMT_NT || aL > SSK_LMT_NT || aO > SSK_LMT_NT || aP > 65535 || (panels && aL > 128)) break;
+					nP = aP; nO = aO; nM = aM; nL = aL; nY = aY; nS = aS;
+					if (!tab_lds) for (int sid : lm_sufs[oj]) suf_tile[sid] = tile_no;
 					var += 8 * (SSK_LMT_ENT * fp_P[oj] + SSK_LMT_OBS * fp_O[oj] + fp_Y[oj] + SSK_LMT_LMR);
 					if (var >= target) { ++oj; break; }
 				}
 				if (oj == oi) { tiled = false; break; }          // one landmark alone does not fit
+				// !tab_lds: the tile's suffix list, tile-local id = position
+				T.tsuf0 = (int)w_tsuf.size(); T.n_tsuf = 0;
+				if (!tab_lds)
+					for (size_t ok = oi; ok < oj; ++ok)
+						for (int sid : lm_sufs[ok])
+							if (suf_local[sid] < T.tsuf0) { suf_local[sid] = (int)w_tsuf.size(); w_tsuf.push_back(sid); }
+				T.n_tsuf = (int)w_tsuf.size() - T.tsuf0;
+				auto local_suf = [&](int sid) { return tab_lds ? sid : suf_local[sid] - T.tsuf0; };
 				std::vector<item> pitems, qitems;
 				int n_ent = 0, n_pan = 0;
 				for (size_t ok = oi; ok < oj; ++ok) {
@@ -521,13 +593,15 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					w_tl_rec.push_back(make_int4(Wn.lm_unknown_slot[l], (int)w_tobs_a.size() - T.obs0, (int)(w_tobs_a.size() + obs_of[l].size()) - T.obs0, 0));
 					for (int o : obs_of[l]) {
 						const int kl = (int)w_tobs_a.size() - T.obs0, pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
-						w_tobs_a.push_back(pack_obs(o, n_ent | (om << 16) | (len << 24)));
+						w_tobs_a.push_back(make_int4(n_ent | (__builtin_popcount(om) << 16), Wn.obs_lm[o], local_suf(obs_suf[o]), obs_suf[o]));
 						w_tobs_px.push_back(make_float4(Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]));
 						in_tile[o] = 1;
 						std::vector<std::pair<int, int>> steps;      // (edge slot, local entry)
 						for (int i = 0; i < len; ++i)
 							if ((om >> i) & 1) {
 								const int le = n_ent + __builtin_popcount(om & ((1 << i) - 1));
+								// A = +Jf R^T(suffix i) and q = T(suffix i) f for a forward step, A = -Jf R^T(suffix i+1), q = T(suffix i+1) f for an inverse one
+								w_tent.push_back((local_suf(entry_suf(pb, len, i)) << 1) | (Wn.path_edge[pb + i] & 1));
 								path_loc[pb + i] = le | (kl << 16);
 								steps.push_back(std::make_pair(Wn.edge_unknown_slot[Wn.path_edge[pb + i] >> 1], le));
 							}
@@ -632,14 +706,14 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				w_wt_off.push_back((int)w_wt.size());
 				}
 				w_tiles.push_back(T);
-				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (acc ? 8 * (size_t)ssk_lma_acc_doubles(E) : 0) +
+				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (acc ? 8 * (size_t)ssk_lma_acc_doubles(E) : 0) + (tab_lds ? 96 * (size_t)n_suf : 0) +
 				                                (size_t)tile_bytes(T.n_ent, T.n_obs, nY, T.n_lm));
 				oi = oj;
 			}
 			// the observations outside every tile (fixed landmark, no optimised edge on the path) still count in the error
 			for (int o = 0; o < Wn.n_obs && tiled; ++o)
 				if (!in_tile[o]) {
-					w_tobs_a.push_back(pack_obs(o, (Wn.obs_path_off[o + 1] - Wn.obs_path_off[o]) << 24));
+					w_tobs_a.push_back(pack_obs(o, 0));
 					w_tobs_px.push_back(make_float4(Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]));
 				}
 			// final slot ids are block-major, so a block's partial sums are one contiguous run [pcl_off[pid], pcl_off[pid+1]);
@@ -652,7 +726,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			}
 			w_pcl_off[n_pairs] = np_; w_scl_off[n_pairs] = ns_;
 			// the reduced system goes to LDS too when it fits beside poses / solution / pivots (else: L2 scratch, Hred)
-			const size_t fixed = (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1));
+			const size_t fixed = (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (tab_lds ? 96 * (size_t)n_suf : 0);
 			const size_t mat = (size_t)(6 * E + 1) * ((6 * E) | 1) * 8;
 			if (fixed + mat <= (size_t)(SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC)) tiled_dyn = std::max(tiled_dyn, fixed + mat);
 		}
@@ -663,6 +737,18 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			for (const lm_tile& T : w_tiles)
 				std::fprintf(stderr, "[ssk lm]   tile: lms %d obs %d ent %d inc %d | pgroups %d (chunks %d) sgroups %d (chunks %d)\n", T.n_lm, T.n_obs, T.n_ent, T.n_inc, T.n_pg, T.n_pc, T.n_sg, T.n_sc);
 		}
+		H.n_suf = n_suf; H.suf0 = (int)suf_rec.size(); H.tent0 = (int)tent.size(); H.pad_suf = 0;
+		H.tab_lds = tab_lds ? 1 : 0; H.tsuf0 = (int)tsuf.size(); H.gtab0 = gtab_total;
+		tsuf.insert(tsuf.end(), w_tsuf.begin(), w_tsuf.end());
+		// a table per workgroup that may share the window (cooperative kernel: up to 64)
+		if (!tab_lds) gtab_total += 12LL * n_suf * (n_windows * 4 <= ctx->n_cu ? 64 : 1);
+		for (int k = 0; k <= SSK_LM_MAX_PATH + 1; ++k) {       // suf_lvl[k] = first id of length >= k
+			int first = n_suf;
+			for (int i = 0; i < n_suf; ++i) if (w_suf_len[i] >= k) { first = i; break; }
+			H.suf_lvl[k] = first;
+		}
+		suf_rec.insert(suf_rec.end(), w_suf.begin(), w_suf.end());
+		tent.insert(tent.end(), w_tent.begin(), w_tent.end());
 		H.acc = acc && tiled ? 1 : 0;
 		H.wt0 = (int)wt.size(); H.wto0 = (int)wt_off.size(); H.pad_acc = 0;
 		wt.insert(wt.end(), w_wt.begin(), w_wt.end()); wt_off.insert(wt_off.end(), w_wt_off.begin(), w_wt_off.end());
@@ -773,7 +859,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(inc_rec, inc_rec); UP(lmep_loc, lmep_loc);
 	UP(pit, pit); UP(pgrp, pgrp); UP(pslot0, pslot0); UP(pcl_off, pcl_off); UP(pcl_idx, pcl_idx);
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
-	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan);
+	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan); UP(suf_rec, suf_rec); UP(tent, tent); UP(tsuf, tsuf);
 #undef UP
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
 	b->acc_ok = want_acc && acc_all && tiled_all; b->schur_mfma = schur_mfma;
@@ -811,6 +897,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (!rc) rc = scratch(b, trace ? (size_t)n_windows * MAX_ITERS_ALLOC : 1, &D.trace);
 	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
+	if (!rc) rc = scratch(b, (size_t)gtab_total, &D.suf_tab);
 	if (!rc) rc = scratch(b, pose.size(), &b->pose_bak);
 	if (!rc) rc = scratch(b, lm.size(), &b->lm_bak);
 	D.trace_on = trace ? 1 : 0;

@@ -50,6 +50,15 @@ struct lm_win {
 	int pit0, pg0, pcx0, ps0, pcl0;   // H_pp items pit[], lane groups pgrp[], chunk slot bases pslot0[], partial slots Ppart2 x36, pcl_idx[]
 	int qit0, sg0, scx0, ss0, scl0;   // Schur items qit[], lane groups sgrp[], sslot0[], Spart2 x36, scl_idx[]
 	// ---- on-chip accumulation (lm_solve_acc_kernel): acc != 0 when the window's accumulators fit LDS (E <= SSK_LMA_MAX_E) ----
+	// ---- path-suffix table (tiled kernels): the distinct suffixes (c_k, ..., c_{n-1}) of the observations' spanning-tree paths, id 0 =
+	// the empty one, ids ascending by length; suf_rec[suf0 + id] = (first step code, id of the rest); suf_lvl[k] = first id of length k
+	int n_suf, suf0, tent0;            // tent[tent0 + ..]: per tile entry (suffix id << 1 | direction), tile entry order
+	int tab_lds;                       // 1: the whole table lives in LDS for the pass and records hold global suffix ids; 0 (many suffixes): the table
+	                                   // is built in the window's L2-resident scratch, every tile copies the suffixes it uses (tsuf[]) into LDS and its
+	                                   // records hold tile-local ids
+	int tsuf0, pad_suf;                // tsuf[tsuf0 + ..]: per tile the global ids of the suffixes it uses
+	long long gtab0;                   // suf_tab[gtab0 + ..]: 12 doubles per suffix (x workgroups of the cooperative kernel)
+	int suf_lvl[SSK_LM_MAX_PATH + 2];
 	int acc;              // 0: partial slots in HBM (kernels above); 1: H_pp blocks, Schur tiles and the reduced gradient accumulate in LDS
 	int wt0, wto0;        // per-wave task lists of the tiles: entries wt[] (base wt0), per tile NW + 1 offsets into them wt_off[] (base wto0)
 	int pad_acc;
@@ -72,7 +81,8 @@ struct lm_tile {
 	int pg0, n_pg, pc0, n_pc;   // H_pp lane groups pgrp[W.pg0 + pg0 ..), chunks pslot0[W.pcx0 + pc0 ..)
 	int sg0, n_sg, sc0, n_sc;   // Schur lane groups / chunks
 	int n_pan;            // acc: Y panels of the tile (a panel = one 16-row tile of the reduced system x one landmark, [3][16] doubles)
-	int wt0, pad0, pad1;  // acc: first entry of the tile's wt_off table (window relative)
+	int wt0, ent0, pad1;  // acc: first entry of the tile's wt_off table (window relative); ent0: first tile entry in tent[] (window relative)
+	int tsuf0, n_tsuf, pad2, pad3;   // !tab_lds: the tile's suffixes tsuf[W.tsuf0 + tsuf0 ..) (tile-local id = position)
 };
 
 struct lm_dev {
@@ -81,6 +91,7 @@ struct lm_dev {
 	const int4* inc_rec; const int* lmep_loc;
 	const int* pit; const int2* pgrp; const int* pslot0; const int* pcl_off; const int* pcl_idx;
 	const int* qit; const int2* sgrp; const int* sslot0; const int* scl_off; const int* scl_idx;
+	const int2* suf_rec; const int* tent; const int* tsuf; double* suf_tab;
 	const int* wt_off; const int* wt; const int2* tl_pan;   // acc kernel (tl_pan: per tile landmark (row-tile mask, first panel of the tile's panel array))
 	int store_hff;        // 1: the landmark blocks H_ff / g_f of the last linearisation go to HBM (shared-landmark exchange); 0: they stay on chip
 	double* Ppart2; double* Spart2;
@@ -120,7 +131,10 @@ int ssk_lm_launch(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows,
 #define SSK_LMT_WG_PER_CU 1
 #endif
 constexpr int SSK_LMT_NT = SSK_LMT_THREADS;        // workgroup size
-constexpr int SSK_LMT_ENT = 15, SSK_LMT_OBS = 17, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;   // record pitches (doubles, odd: conflict-free)
+// record pitches (doubles, odd: conflict-free).  Entry: chained point q (3) + packed (suffix id << 1 | direction, tile-local observation);
+// observation: V_o = Jf^T Jf (6) + g_o = Jf^T w r (3) -- the 4x3 blocks A of an optimised path entry are NOT stored: A = +-Jf R_suffix^T
+// with R_suffix from the window's path-suffix table (12 doubles per distinct suffix, rebuilt in LDS at every pass)
+constexpr int SSK_LMT_ENT = 5, SSK_LMT_OBS = 9, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;
 constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024 / SSK_LMT_WG_PER_CU;   // gfx950: 160 KB of LDS per CU, shared by the resident workgroups
 constexpr int SSK_LMT_STATIC = 1024;               // reserve for the kernel's static LDS (a few scalars and the wave partials)
 int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes);

@@ -6,9 +6,14 @@
 // Jacobian blocks and gathers them three times.  Here a window's landmarks are cut (host, ssk_capi_lm.hip) into
 // tiles whose linearisation fits the 160 KB of LDS of a gfx950 CU, and a persistent 512-thread workgroup per
 // window streams the tiles:
-//   I1  lane = observation: SE(3) chain along the spanning-tree path (poses in LDS), stereo projection, IRLS
-//       weight; writes per optimised path entry A = +-w M R (4x3) and the chained point q (the 4x6 block is
-//       [A | q x A], never stored), per observation Jf = w M R_all (4x3) and w r      -> LDS records
+//   T   path-suffix table: the observations of a window share a few dozen spanning-tree paths; every distinct SUFFIX of a
+//       path (host: a trie) gets its composed transform T_s = X_k (+) ... (+) X_{n-1} once per pass, level by level -> LDS
+//   I1  lane = observation: q = T_path f (one transform instead of a chain), stereo projection, IRLS weight,
+//       Jf = w M R_path (4x3); the record keeps only V_o = Jf^T Jf (6) and g_o = Jf^T w r (3), and per optimised path
+//       entry the chained point q_i = T_suffix f.  The 4x3 block A_i = +-w M R_prefix of the entry is NOT stored:
+//       R_path = R_prefix R_suffix, so A_i = +-Jf R_suffix^T and every product the later phases need follows from V_o,
+//       g_o and the table: A_i^T Jf = +-R_s V_o, A_i^T w r = +-R_s g_o, A_i^T A_j = +-R_si V_o R_sj^T.  (A third of the LDS
+//       bytes per observation of the first form: fewer, larger tiles -- a tile phase costs its latency whatever its size)
 //   I2  lane = (landmark, edge) incidence: W = sum Je^T Jf, g_e part, in REGISTERS across the barrier;
 //       lane = landmark: V = sum Jf^T Jf, g_f, Cholesky V + lambda I = L L^T, L^-1, c = L^-1 g_f      -> LDS
 //   I3  incidence lanes: Y = W L^-T (so the Schur term W V^-1 W'^T = Y Y'^T is symmetric by construction),
@@ -86,9 +91,11 @@ __device__ __forceinline__ void wave_seg_sum36(double (&acc)[36], int key, int l
 	}
 }
 
-// H_pp lane group: the 6x6 blocks Je_1^T Je_2 of `cnt` items (pairs of entry records), summed into acc.
-// block = [C, rows(C) x' q2 ; q1 x cols(C), q1 x cols(top right)] with C = A_1^T A_2 and u x' q = q x u
-__device__ __forceinline__ void pp_group(const double* __restrict__ ent, const int* __restrict__ items, int cnt, double (&acc)[36])
+// H_pp lane group: the 6x6 blocks Je_1^T Je_2 of `cnt` items (pairs of entry records of one observation), summed into acc.
+// block = [C, rows(C) x' q2 ; q1 x cols(C), q1 x cols(top right)] with C = A_1^T A_2 = s1 s2 R_1 V_o R_2^T (R_i: rotation of the
+// entry's suffix, V_o = Jf^T Jf of the observation) and u x' q = q x u
+__device__ __forceinline__ void pp_group(const double* __restrict__ ent, const double* __restrict__ obsr, const double* __restrict__ tab,
+                                         const int* __restrict__ items, int cnt, double (&acc)[36])
 {
 	int nxt = cnt > 0 ? items[0] : 0;
 	for (int k = 0; k < cnt; ++k) {
@@ -96,27 +103,28 @@ __device__ __forceinline__ void pp_group(const double* __restrict__ ent, const i
 		if (k + 1 < cnt) nxt = items[k + 1];              // next item id in flight during this item's arithmetic
 		const double* e1 = ent + ENT_P * (itv & 0xFFFF);
 		const double* e2 = ent + ENT_P * (itv >> 16);
-		double a1[12], a2[12], q1[3], q2[3], C[9], TR[9];
+		const double q1[3] = {e1[0], e1[1], e1[2]}, q2[3] = {e2[0], e2[1], e2[2]};
+		const double pk1 = e1[3], pk2 = e2[3];
+		const int c1 = __double2loint(pk1), c2 = __double2loint(pk2);
+		const double* orr = obsr + OBS_P * __double2hiint(pk1);
+		const double* T1 = tab + 12 * (c1 >> 1);
+		const double* T2 = tab + 12 * (c2 >> 1);
+		const double sg = ((c1 ^ c2) & 1) ? -1.0 : 1.0;
+		const double V[6] = {orr[0], orr[1], orr[2], orr[3], orr[4], orr[5]};
+		const double Vm[9] = {V[0], V[1], V[2], V[1], V[3], V[4], V[2], V[4], V[5]};
+		double B[9], C[9], TR[9];
 #pragma unroll
-		for (int i = 0; i < 12; ++i) a1[i] = e1[i];
+		for (int r = 0; r < 3; ++r) {
+			const double r0 = sg * T1[4 * r], r1 = sg * T1[4 * r + 1], r2 = sg * T1[4 * r + 2];
 #pragma unroll
-		for (int i = 0; i < 3; ++i) q1[i] = e1[12 + i];
-		if (e1 != e2) {                                    // items of diagonal blocks pair an entry with itself: the LDS is the
-#pragma unroll
-			for (int i = 0; i < 12; ++i) a2[i] = e2[i];    // contended resource here, so their second record is not read again
-#pragma unroll
-			for (int i = 0; i < 3; ++i) q2[i] = e2[12 + i];
-		} else {
-#pragma unroll
-			for (int i = 0; i < 12; ++i) a2[i] = a1[i];
-#pragma unroll
-			for (int i = 0; i < 3; ++i) q2[i] = q1[i];
+			for (int c = 0; c < 3; ++c) B[3 * r + c] = r0 * Vm[c] + r1 * Vm[3 + c] + r2 * Vm[6 + c];
 		}
 #pragma unroll
-		for (int r = 0; r < 3; ++r)
+		for (int c = 0; c < 3; ++c) {
+			const double t0 = T2[4 * c], t1 = T2[4 * c + 1], t2 = T2[4 * c + 2];
 #pragma unroll
-			for (int c = 0; c < 3; ++c)
-				C[3 * r + c] = a1[r] * a2[c] + a1[3 + r] * a2[3 + c] + a1[6 + r] * a2[6 + c] + a1[9 + r] * a2[9 + c];
+			for (int r = 0; r < 3; ++r) C[3 * r + c] = B[3 * r] * t0 + B[3 * r + 1] * t1 + B[3 * r + 2] * t2;
+		}
 #pragma unroll
 		for (int r = 0; r < 3; ++r) {
 			cross3(q2, C + 3 * r, TR + 3 * r);
@@ -193,20 +201,44 @@ __device__ __forceinline__ void project_fast(const lm_cam& P, const double* pc, 
 	h[3] = P.cy_r + P.fy_r * pc[1] * iz;
 }
 
-// Robustified squared error of a packed observation record (pose: window-relative poses, lm: the window's landmarks)
-__device__ __forceinline__ double obs_error_packed(const lm_cam& P, const double* pose, const double* __restrict__ lm, const int4 rec, const float4 px)
+// Path-suffix table of a window at the poses `pose` (window-relative, LDS): tab[12 * id] = row-major [R | t] of the composed
+// transform of suffix id; id 0 = identity.  Level by level (a suffix = one step (+) a shorter suffix), one barrier per level.
+__device__ void build_suffix_table(const lm_dev& D, const lm_win& W, const double* pose, double* __restrict__ tab)
 {
-	const int n = (rec.x >> 24) & 15;
-	const unsigned long long codes = (unsigned long long)(unsigned)rec.z | ((unsigned long long)(unsigned)rec.w << 32);
-	double q[3], t[3];
-	const double* f = lm + 3 * (size_t)rec.y;
-	q[0] = f[0]; q[1] = f[1]; q[2] = f[2];
-	for (int i = n - 1; i >= 0; --i) {
-		const int c = (int)(codes >> (8 * i)) & 255;
-		se3_step(pose + 12 * (c >> 1), c & 1, q, t);
-		q[0] = t[0]; q[1] = t[1]; q[2] = t[2];
+	const int tid = threadIdx.x;
+	if (tid < 12) tab[tid] = (tid == 0 || tid == 5 || tid == 10) ? 1.0 : 0.0;
+	__syncthreads();
+	for (int lvl = 1; lvl <= SSK_LM_MAX_PATH; ++lvl) {
+		const int i0 = W.suf_lvl[lvl], i1 = W.suf_lvl[lvl + 1];
+		if (i0 >= W.n_suf) break;                          // (uniform)
+		for (int id = i0 + tid; id < i1; id += NT) {
+			const int2 rec = D.suf_rec[W.suf0 + id];
+			const double* X = pose + 12 * (rec.x >> 1);
+			const double* Tn = tab + 12 * rec.y;
+			const int dir = rec.x & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;      // (R or R^T)(i,j) = X[si * i + sj * j]
+			double tn[3] = {Tn[3], Tn[7], Tn[11]};
+			if (dir) { tn[0] -= X[3]; tn[1] -= X[7]; tn[2] -= X[11]; }
+			double* O = tab + 12 * id;
+#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				const double r0 = X[si * i], r1 = X[si * i + sj], r2 = X[si * i + 2 * sj];
+#pragma unroll
+				for (int j = 0; j < 3; ++j) O[4 * i + j] = r0 * Tn[j] + r1 * Tn[4 + j] + r2 * Tn[8 + j];
+				O[4 * i + 3] = r0 * tn[0] + r1 * tn[1] + r2 * tn[2] + (dir ? 0.0 : X[4 * i + 3]);
+			}
+		}
+		__syncthreads();
 	}
-	double pc[3], h[4];
+}
+
+// Robustified squared error of a packed observation record (tab: the suffix table at the state to score, lm: the window's landmarks)
+__device__ __forceinline__ double obs_error_packed(const lm_cam& P, const double* tab, const double* __restrict__ lm, const int4 rec, const float4 px)
+{
+	const double* f = lm + 3 * (size_t)rec.y;
+	const double* T = tab + 12 * rec.w;                    // (w: the id in the window's table; z may be tile-local)
+	double q[3], pc[3], h[4];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) q[i] = T[4 * i] * f[0] + T[4 * i + 1] * f[1] + T[4 * i + 2] * f[2] + T[4 * i + 3];
 	se3_apply_inv(P.S, q, pc);
 	project_fast(P, pc, h);
 	const double r0 = (double)px.x - h[0], r1 = (double)px.y - h[1], r2 = (double)px.z - h[2], r3 = (double)px.w - h[3];
@@ -217,11 +249,11 @@ __device__ __forceinline__ double obs_error_packed(const lm_cam& P, const double
 }
 
 // observations k = first, first + step, ... (one workgroup: first = thread id, step = NT)
-__device__ double total_error_packed(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const double* lm, double* s_part,
+__device__ double total_error_packed(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* tab, const double* lm, double* s_part,
                                      int first, int step)
 {
 	double e = 0;
-	for (int k = first; k < W.n_obs; k += step) e += obs_error_packed(P, pose, lm + 3 * (size_t)W.lm0, D.tobs_a[W.tobs0 + k], D.tobs_px[W.tobs0 + k]);
+	for (int k = first; k < W.n_obs; k += step) e += obs_error_packed(P, tab, lm + 3 * (size_t)W.lm0, D.tobs_a[W.tobs0 + k], D.tobs_px[W.tobs0 + k]);
 	return block_sum(e, s_part);
 }
 
@@ -286,28 +318,25 @@ __device__ __forceinline__ double slot_sum(const double* __restrict__ part, int 
 	return s;
 }
 
-// I1: linearise one observation (packed record: tile-local entry base / optimised-step mask / path codes) into the LDS records
-__device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* pose, const int4 rec, const float4 px,
-                                  double* __restrict__ ent, double* __restrict__ orec)
+// I1: linearise one observation (packed record: first tile-local entry | optimised entries << 16, landmark, suffix id of its path)
+// into the LDS records: V_o = Jf^T Jf, g_o = Jf^T w r; per optimised entry the chained point and (suffix, direction, observation).
+// tent: the tile's entry table (suffix id << 1 | direction); kobs: tile-local index of the observation.
+__device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam& P, const double* tab, const int4 rec, const float4 px,
+                                  const int* __restrict__ tent, int kobs, double* __restrict__ ent, double* __restrict__ orec)
 {
-	const int n = (rec.x >> 24) & 15, e0 = rec.x & 0xFFFF, om = (rec.x >> 16) & 0xFF;
-	const unsigned long long codes = (unsigned long long)(unsigned)rec.z | ((unsigned long long)(unsigned)rec.w << 32);
-	double q[3], t[3];
+	const int e0 = rec.x & 0xFFFF, n_opt = (rec.x >> 16) & 0xFF;
+	double f[3];
 	{
-		const double* f = D.lm + 3 * (size_t)(W.lm0 + rec.y);
-		q[0] = f[0]; q[1] = f[1]; q[2] = f[2];
+		const double* fp = D.lm + 3 * (size_t)(W.lm0 + rec.y);
+		f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
 	}
-	// backward pass: q_i = X_i (+) q_{i+1}; an optimised entry keeps the point its Jacobian needs:
-	// dir 0 -> q_i (after the step), dir 1 -> q_{i+1} (before it)
-	for (int i = n - 1; i >= 0; --i) {
-		const int c = (int)(codes >> (8 * i)) & 255;
-		const int dir = c & 1;
-		se3_step(pose + 12 * (c >> 1), dir, q, t);
-		if ((om >> i) & 1) {
-			double* eq = ent + ENT_P * (e0 + __popc(om & ((1 << i) - 1))) + 12;
-			eq[0] = dir ? q[0] : t[0]; eq[1] = dir ? q[1] : t[1]; eq[2] = dir ? q[2] : t[2];
-		}
-		q[0] = t[0]; q[1] = t[1]; q[2] = t[2];
+	int code = n_opt > 0 ? tent[e0] : 0;
+	const double* T = tab + 12 * rec.z;
+	double R[9], q[3];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		R[3 * i] = T[4 * i]; R[3 * i + 1] = T[4 * i + 1]; R[3 * i + 2] = T[4 * i + 2];
+		q[i] = R[3 * i] * f[0] + R[3 * i + 1] * f[1] + R[3 * i + 2] * f[2] + T[4 * i + 3];
 	}
 	double pc[3], h[4], r[4];
 	se3_apply_inv(P.S, q, pc);
@@ -333,160 +362,166 @@ __device__ void linearize_obs_lds(const lm_dev& D, const lm_win& W, const lm_cam
 		M[6 + j] = dxr * P.S[4 * j] + dzr * P.S[4 * j + 2];
 		M[9 + j] = dyr * P.S[4 * j + 1] + dwr * P.S[4 * j + 2];
 	}
-#pragma unroll
-	for (int k = 0; k < 4; ++k) orec[12 + k] = w * r[k];
-	// forward pass: RA = product of the step rotations so far
-	double RA[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-	for (int i = 0; i < n; ++i) {
-		const int c = (int)(codes >> (8 * i)) & 255;
-		const int dir = c & 1;
-		const double* T = pose + 12 * (c >> 1);
-		const int sk = dir ? 1 : 4, sb = dir ? 4 : 1;    // (R or R^T)(k,b) = T[sk * k + sb * b]
-		double Rs[9], RN[9];
-#pragma unroll
-		for (int k = 0; k < 3; ++k)
-#pragma unroll
-			for (int b = 0; b < 3; ++b) Rs[3 * k + b] = T[sk * k + sb * b];
-#pragma unroll
-		for (int a = 0; a < 3; ++a)
-#pragma unroll
-			for (int b = 0; b < 3; ++b) RN[3 * a + b] = RA[3 * a] * Rs[b] + RA[3 * a + 1] * Rs[3 + b] + RA[3 * a + 2] * Rs[6 + b];
-		if ((om >> i) & 1) {
-			const double* RR = dir == 0 ? RA : RN;
-			const double sg = dir == 0 ? w : -w;
-			double* ea = ent + ENT_P * (e0 + __popc(om & ((1 << i) - 1)));
-#pragma unroll
-			for (int a = 0; a < 4; ++a) {
-				ea[3 * a] = sg * (M[3 * a] * RR[0] + M[3 * a + 1] * RR[3] + M[3 * a + 2] * RR[6]);
-				ea[3 * a + 1] = sg * (M[3 * a] * RR[1] + M[3 * a + 1] * RR[4] + M[3 * a + 2] * RR[7]);
-				ea[3 * a + 2] = sg * (M[3 * a] * RR[2] + M[3 * a + 1] * RR[5] + M[3 * a + 2] * RR[8]);
-			}
-		}
-#pragma unroll
-		for (int a = 0; a < 9; ++a) RA[a] = RN[a];
-	}
+	double jf[12];                                      // Jf = w M R_path
 #pragma unroll
 	for (int i = 0; i < 4; ++i)
 #pragma unroll
 		for (int j = 0; j < 3; ++j)
-			orec[3 * i + j] = w * (M[3 * i] * RA[j] + M[3 * i + 1] * RA[3 + j] + M[3 * i + 2] * RA[6 + j]);
+			jf[3 * i + j] = w * (M[3 * i] * R[j] + M[3 * i + 1] * R[3 + j] + M[3 * i + 2] * R[6 + j]);
+	const double wr[4] = {w * r[0], w * r[1], w * r[2], w * r[3]};
+	orec[0] = jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
+	orec[1] = jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
+	orec[2] = jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
+	orec[3] = jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
+	orec[4] = jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
+	orec[5] = jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
+	orec[6] = jf[0] * wr[0] + jf[3] * wr[1] + jf[6] * wr[2] + jf[9] * wr[3];
+	orec[7] = jf[1] * wr[0] + jf[4] * wr[1] + jf[7] * wr[2] + jf[10] * wr[3];
+	orec[8] = jf[2] * wr[0] + jf[5] * wr[1] + jf[8] * wr[2] + jf[11] * wr[3];
+	for (int k = 0; k < n_opt; ++k) {
+		const int cd = code;
+		if (k + 1 < n_opt) code = tent[e0 + k + 1];         // next entry's code in flight
+		const double* Ts = tab + 12 * (cd >> 1);
+		double* er = ent + ENT_P * (e0 + k);
+#pragma unroll
+		for (int i = 0; i < 3; ++i) er[i] = Ts[4 * i] * f[0] + Ts[4 * i + 1] * f[1] + Ts[4 * i + 2] * f[2] + Ts[4 * i + 3];
+		er[3] = __hiloint2double(kobs, cd);
+	}
+}
+
+// sums of a landmark's observation records k0 .. k1-1: V (6) and g_f (3)
+__device__ __forceinline__ void landmark_sums(const double* __restrict__ obsr, int k0, int k1, double (&v)[9])
+{
+#pragma unroll
+	for (int c = 0; c < 9; ++c) v[c] = 0.0;
+	for (int k = k0; k < k1; ++k) {
+		const double* orr = obsr + OBS_P * k;
+#pragma unroll
+		for (int c = 0; c < 9; ++c) v[c] += orr[c];
+	}
+}
+
+// V + lambda I = L L^T of a landmark (v: V upper 6 + g 3) -> rec = (L^-1 lower 6, c = L^-1 g 3)
+__device__ __forceinline__ void landmark_factor(const double (&v)[9], double lambda, double (&rec)[9])
+{
+	const double i00 = rsq_f64(v[0] + lambda);                 // 1 / L_kk straight from the reciprocal square root
+	const double l10 = v[1] * i00, l20 = v[2] * i00;
+	const double i11 = rsq_f64(v[3] + lambda - l10 * l10);
+	const double l21 = (v[4] - l20 * l10) * i11;
+	const double i22 = rsq_f64(v[5] + lambda - l20 * l20 - l21 * l21);
+	const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
+	rec[0] = i00; rec[1] = i10; rec[2] = i11; rec[3] = i20; rec[4] = i21; rec[5] = i22;
+	rec[6] = i00 * v[6]; rec[7] = i10 * v[6] + i11 * v[7]; rec[8] = i20 * v[6] + i21 * v[7] + i22 * v[8];
+}
+
+// One (landmark, edge) incidence: W = sum over its path entries of Je^T Jf (6x3, only when `unk`: the landmark is optimised) and
+// the gradient term ge = sum Je^T w r, from the entry / observation records and the suffix table:
+//   A^T Jf = s R_s V_o, A^T w r = s R_s g_o (s = +-1), Je = [A | q x A]
+__device__ __forceinline__ void incidence_sums(const lm_dev& D, const lm_win& W, const double* __restrict__ ent, const double* __restrict__ obsr,
+                                               const double* __restrict__ tab, const int4 irec, bool unk, double (&Wm)[18], double (&ge)[6])
+{
+	const int cnt = irec.x >> 16;
+#pragma unroll
+	for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
+#pragma unroll
+	for (int c = 0; c < 6; ++c) ge[c] = 0.0;
+	int nxt = irec.w;
+	for (int k = 0; k < cnt; ++k) {
+		const int loc = nxt;
+		if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + irec.y + k + 1];
+		const double* er = ent + ENT_P * (loc & 0xFFFF);
+		const double* orr = obsr + OBS_P * (loc >> 16);
+		const double q[3] = {er[0], er[1], er[2]};
+		const int cd = __double2loint(er[3]);
+		const double sg = (cd & 1) ? -1.0 : 1.0;
+		const double* Ts = tab + 12 * (cd >> 1);
+		double Rs[9], V[6], g[3], tv[3], x[3];
+#pragma unroll
+		for (int i = 0; i < 3; ++i) { Rs[3 * i] = sg * Ts[4 * i]; Rs[3 * i + 1] = sg * Ts[4 * i + 1]; Rs[3 * i + 2] = sg * Ts[4 * i + 2]; }
+#pragma unroll
+		for (int c = 0; c < 3; ++c) g[c] = orr[6 + c];
+#pragma unroll
+		for (int c = 0; c < 3; ++c) tv[c] = Rs[3 * c] * g[0] + Rs[3 * c + 1] * g[1] + Rs[3 * c + 2] * g[2];
+		cross3(q, tv, x);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
+		if (unk) {
+#pragma unroll
+			for (int c = 0; c < 6; ++c) V[c] = orr[c];
+			const double Vm[9] = {V[0], V[1], V[2], V[1], V[3], V[4], V[2], V[4], V[5]};
+#pragma unroll
+			for (int b = 0; b < 3; ++b) {
+				double cb[3];
+#pragma unroll
+				for (int c = 0; c < 3; ++c) cb[c] = Rs[3 * c] * Vm[b] + Rs[3 * c + 1] * Vm[3 + b] + Rs[3 * c + 2] * Vm[6 + b];
+				cross3(q, cb, x);
+#pragma unroll
+				for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
+			}
+		}
+	}
 }
 
 // One tile of a window at the pose / landmark state the caller holds: phases I1-I3 of the file header.  `reg`: the
-// workgroup's tile region in LDS; `epoch`: tiles this workgroup has started (the landmark-record flag counts NW per tile);
+// workgroup's tile region in LDS; `tab`: the path-suffix table at that state;
 // partial sums go to the window's slot arrays Pp / Sp, Y / gradient terms / landmark factors to its HBM scratch.
-__device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* pose_cur,
-                                             double* reg, double lambda, bool pre, bool same_state, int epoch, int* s_lmflag,
+__device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab,
+                                             double* reg, double lambda, bool pre, bool same_state,
                                              double* __restrict__ Pp, double* __restrict__ Sp, double& vmax)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+		// a window with many suffixes: this tile's part of the table (built in L2 scratch) comes into LDS first, ids in the records are tile-local
+		if (!W.tab_lds) {
+			double* lt = reg;
+			const int* ids = D.tsuf + W.tsuf0 + T.tsuf0;
+			for (int i = tid; i < 12 * T.n_tsuf; i += NT) { const int k = i / 12; lt[i] = tab[12 * (size_t)ids[k] + (i - 12 * k)]; }
+			reg += 12 * T.n_tsuf;
+			tab = lt;
+			__syncthreads();
+		}
 		double* ent = reg;
 		double* obsr = ent + ENT_P * T.n_ent;
 		double* Yr = obsr + OBS_P * T.n_obs;
 		double* lmr = Yr + Y_P * T.n_inc;
 		// ---- I1: observations ----
 		for (int k = tid; k < T.n_obs; k += NT)
-			linearize_obs_lds(D, W, P, pose_cur, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
+			linearize_obs_lds(D, W, P, tab, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], D.tent + W.tent0 + T.ent0, k, ent, obsr + OBS_P * k);
 		__syncthreads();
-		// ---- I2: landmark lanes (top of the workgroup) first: V, g_f, Cholesky -> lmr; every wave then signals ----
-		{
-			const int j = NT - 1 - tid;
-			if (j < T.n_lm) {
-				const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
-				const int slot = lrec.x;
-				if (slot >= 0) {
-					double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
-					for (int k = lrec.y; k < lrec.z; ++k) {
-						const double* orr = obsr + OBS_P * k;
-						double jf[12], rr[4];
-#pragma unroll
-						for (int c = 0; c < 12; ++c) jf[c] = orr[c];
-#pragma unroll
-						for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
-						v00 += jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
-						v01 += jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
-						v02 += jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
-						v11 += jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
-						v12 += jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
-						v22 += jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
-						g0 += jf[0] * rr[0] + jf[3] * rr[1] + jf[6] * rr[2] + jf[9] * rr[3];
-						g1 += jf[1] * rr[0] + jf[4] * rr[1] + jf[7] * rr[2] + jf[10] * rr[3];
-						g2 += jf[2] * rr[0] + jf[5] * rr[1] + jf[8] * rr[2] + jf[11] * rr[3];
-					}
-					if (pre) {
-						vmax = fmax(vmax, fmax(v00, fmax(v11, v22)));
-					} else {
-						double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
-						Hm[0] = v00; Hm[1] = v01; Hm[2] = v02; Hm[3] = v01; Hm[4] = v11; Hm[5] = v12; Hm[6] = v02; Hm[7] = v12; Hm[8] = v22;
-						double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
-						gl[0] = g0; gl[1] = g1; gl[2] = g2;
-						const double i00 = rsq_f64(v00 + lambda);         // 1 / L_kk straight from the reciprocal square root
-						const double l10 = v01 * i00, l20 = v02 * i00;
-						const double i11 = rsq_f64(v11 + lambda - l10 * l10);
-						const double l21 = (v12 - l20 * l10) * i11;
-						const double i22 = rsq_f64(v22 + lambda - l20 * l20 - l21 * l21);
-						const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
-						const double rec[9] = {i00, i10, i11, i20, i21, i22, i00 * g0, i10 * g0 + i11 * g1, i20 * g0 + i21 * g1 + i22 * g2};
-						double* lr = lmr + LMR_P * j;
-						double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
-#pragma unroll
-						for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
-					}
-				}
+		// ---- I2a: a lane per landmark: V, g_f, Cholesky -> lmr (+ HBM for the back-substitution) ----
+		for (int j = tid; j < T.n_lm; j += NT) {
+			const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
+			const int slot = lrec.x;
+			if (slot < 0) continue;
+			double v[9];
+			landmark_sums(obsr, lrec.y, lrec.z, v);
+			if (pre) { vmax = fmax(vmax, fmax(v[0], fmax(v[3], v[5]))); continue; }
+			if (D.store_hff) {                                 // only the shared-landmark exchange reads the landmark blocks
+				double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
+				Hm[0] = v[0]; Hm[1] = v[1]; Hm[2] = v[2]; Hm[3] = v[1]; Hm[4] = v[3]; Hm[5] = v[4]; Hm[6] = v[2]; Hm[7] = v[4]; Hm[8] = v[5];
+				double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
+				gl[0] = v[6]; gl[1] = v[7]; gl[2] = v[8];
 			}
+			double rec[9];
+			landmark_factor(v, lambda, rec);
+			double* lr = lmr + LMR_P * j;
+			double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
+#pragma unroll
+			for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
 		}
-		// this wave's landmark records are written (LDS operations of a wave retire in order): release them
-		if (lane == 0) __hip_atomic_fetch_add(s_lmflag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		// ---- I2: incidence lanes: W and the gradient term in registers, then (once every landmark record of the tile
-		//      is there -- the landmark waves are long done) Y = W L^-T -> LDS, reduced gradient term -> HBM ----
-		if (!pre && tid < T.n_inc) {
-			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + tid];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
-			const int lml = irec.x & 0x7FFF, cnt = irec.x >> 16;
+		if (!pre) __syncthreads();
+		// ---- I2b: a lane per incidence: W and the gradient term, Y = W L^-T -> LDS, reduced gradient term -> HBM ----
+		if (!pre)
+		for (int m = tid; m < T.n_inc; m += NT) {
+			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
+			const int lml = irec.x & 0x7FFF;
 			const bool unk = (irec.x >> 15) & 1;
 			double Wm[18], ge[6];
-#pragma unroll
-			for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
-#pragma unroll
-			for (int c = 0; c < 6; ++c) ge[c] = 0.0;
-			int nxt = irec.w;
-			for (int k = 0; k < cnt; ++k) {
-				const int loc = nxt;
-				if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + irec.y + k + 1];
-				const double* er = ent + ENT_P * (loc & 0xFFFF);
-				const double* orr = obsr + OBS_P * (loc >> 16);
-				double a[12], q[3], rr[4], tv[3], x[3];
-#pragma unroll
-				for (int c = 0; c < 12; ++c) a[c] = er[c];
-#pragma unroll
-				for (int c = 0; c < 3; ++c) q[c] = er[12 + c];
-#pragma unroll
-				for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
-#pragma unroll
-				for (int c = 0; c < 3; ++c) tv[c] = a[c] * rr[0] + a[3 + c] * rr[1] + a[6 + c] * rr[2] + a[9 + c] * rr[3];
-				cross3(q, tv, x);
-#pragma unroll
-				for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
-				if (unk) {
-					double jf[12];
-#pragma unroll
-					for (int c = 0; c < 12; ++c) jf[c] = orr[c];
-#pragma unroll
-					for (int b = 0; b < 3; ++b) {
-						double cb[3];
-#pragma unroll
-						for (int c = 0; c < 3; ++c) cb[c] = a[c] * jf[b] + a[3 + c] * jf[3 + b] + a[6 + c] * jf[6 + b] + a[9 + c] * jf[9 + b];
-						cross3(q, cb, x);
-#pragma unroll
-						for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
-					}
-				}
-			}
+			incidence_sums(D, W, ent, obsr, tab, irec, unk, Wm, ge);
 			double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
 			if (unk) {
-				while (__hip_atomic_load(s_lmflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * epoch) __builtin_amdgcn_s_sleep(1);
 				const double* lr = lmr + LMR_P * lml;
 				const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
-				double* yl = Yr + Y_P * tid;
+				double* yl = Yr + Y_P * m;
 #pragma unroll
 				for (int a = 0; a < 6; ++a) {
 					const double y0 = Wm[3 * a] * i00;
@@ -518,7 +553,7 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 			if (task < T.n_pc) {
 				const int g = 64 * task + lane;
 				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
-				pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
+				pp_group(ent, obsr, tab, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
 				wave_seg_sum36(acc, rec.y >> 8, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
 			} else {
 				const int c = task - T.n_pc, g = 64 * c + lane;
@@ -610,11 +645,19 @@ __device__ unsigned long long g_tst[8];
 // One tile with on-chip accumulation.  Region: [entries | observation records | Y (records or panels) | landmark records |
 // gradient terms (7 per incidence: 6 values + edge slot)].
 template <bool MFMA>
-__device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* pose_cur,
-                                                 double* reg, double lambda, bool pre, bool same_state, int epoch, int* s_lmflag,
+__device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab,
+                                                 double* reg, double lambda, bool pre, bool same_state,
                                                  double* __restrict__ P_acc, double* __restrict__ S_acc, double* __restrict__ g_acc, double& vmax)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	if (!W.tab_lds) {                                      // (as process_tile)
+		double* lt = reg;
+		const int* ids = D.tsuf + W.tsuf0 + T.tsuf0;
+		for (int i = tid; i < 12 * T.n_tsuf; i += NT) { const int k = i / 12; lt[i] = tab[12 * (size_t)ids[k] + (i - 12 * k)]; }
+		reg += 12 * T.n_tsuf;
+		tab = lt;
+		__syncthreads();
+	}
 	double* ent = reg;
 	double* obsr = ent + ENT_P * T.n_ent;
 	double* Yr = obsr + OBS_P * T.n_obs;                   // sparse: Y_P per incidence; MFMA: SSK_LMA_PANEL per panel
@@ -627,110 +670,46 @@ __device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& 
 	// ---- I1: observations; the Y panels start from zero ----
 	if (MFMA && !pre) for (int i = tid; i < SSK_LMA_PANEL * T.n_pan; i += NT) Yr[i] = 0.0;
 	for (int k = tid; k < T.n_obs; k += NT)
-		linearize_obs_lds(D, W, P, pose_cur, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], ent, obsr + OBS_P * k);
+		linearize_obs_lds(D, W, P, tab, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], D.tent + W.tent0 + T.ent0, k, ent, obsr + OBS_P * k);
 	__syncthreads();
 	TSTAMP(0);
-	// ---- I2: landmark lanes (top of the workgroup): V, g_f, Cholesky -> lmr ----
-	{
-		const int j = NT - 1 - tid;
-		if (j < T.n_lm) {
-			const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];
-			const int slot = lrec.x;
-			if (slot >= 0) {
-				double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
-				for (int k = lrec.y; k < lrec.z; ++k) {
-					const double* orr = obsr + OBS_P * k;
-					double jf[12], rr[4];
-#pragma unroll
-					for (int c = 0; c < 12; ++c) jf[c] = orr[c];
-#pragma unroll
-					for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
-					v00 += jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
-					v01 += jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
-					v02 += jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
-					v11 += jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
-					v12 += jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
-					v22 += jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
-					g0 += jf[0] * rr[0] + jf[3] * rr[1] + jf[6] * rr[2] + jf[9] * rr[3];
-					g1 += jf[1] * rr[0] + jf[4] * rr[1] + jf[7] * rr[2] + jf[10] * rr[3];
-					g2 += jf[2] * rr[0] + jf[5] * rr[1] + jf[8] * rr[2] + jf[11] * rr[3];
-				}
-				if (pre) {
-					vmax = fmax(vmax, fmax(v00, fmax(v11, v22)));
-				} else {
-					if (D.store_hff) {                         // only the shared-landmark exchange reads the landmark blocks
-						double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
-						Hm[0] = v00; Hm[1] = v01; Hm[2] = v02; Hm[3] = v01; Hm[4] = v11; Hm[5] = v12; Hm[6] = v02; Hm[7] = v12; Hm[8] = v22;
-						double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
-						gl[0] = g0; gl[1] = g1; gl[2] = g2;
-					}
-					const double i00 = rsq_f64(v00 + lambda);
-					const double l10 = v01 * i00, l20 = v02 * i00;
-					const double i11 = rsq_f64(v11 + lambda - l10 * l10);
-					const double l21 = (v12 - l20 * l10) * i11;
-					const double i22 = rsq_f64(v22 + lambda - l20 * l20 - l21 * l21);
-					const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
-					const double rec[9] = {i00, i10, i11, i20, i21, i22, i00 * g0, i10 * g0 + i11 * g1, i20 * g0 + i21 * g1 + i22 * g2};
-					double* lr = lmr + LMR_P * j;
-					double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
-#pragma unroll
-					for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
-				}
-			}
+	// ---- I2a: a lane per landmark ----
+	for (int j = tid; j < T.n_lm; j += NT) {
+		const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];
+		const int slot = lrec.x;
+		if (slot < 0) continue;
+		double v[9];
+		landmark_sums(obsr, lrec.y, lrec.z, v);
+		if (pre) { vmax = fmax(vmax, fmax(v[0], fmax(v[3], v[5]))); continue; }
+		if (D.store_hff) {
+			double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
+			Hm[0] = v[0]; Hm[1] = v[1]; Hm[2] = v[2]; Hm[3] = v[1]; Hm[4] = v[3]; Hm[5] = v[4]; Hm[6] = v[2]; Hm[7] = v[4]; Hm[8] = v[5];
+			double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
+			gl[0] = v[6]; gl[1] = v[7]; gl[2] = v[8];
 		}
+		double rec[9];
+		landmark_factor(v, lambda, rec);
+		double* lr = lmr + LMR_P * j;
+		double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
+#pragma unroll
+		for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
 	}
-	if (lane == 0) __hip_atomic_fetch_add(s_lmflag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-	// ---- I2: incidence lanes: W, gradient term; Y = W L^-T -> LDS (records or panels) and HBM (back-substitution) ----
-	if (!pre && tid < T.n_inc) {
-		const int4 irec = D.inc_rec[W.lme0 + T.inc0 + tid];
-		const int lml = irec.x & 0x7FFF, cnt = irec.x >> 16;
+	if (!pre) __syncthreads();
+	// ---- I2b: a lane per incidence: W, gradient term; Y = W L^-T -> LDS (records or panels) and HBM (back-substitution) ----
+	if (!pre)
+	for (int m = tid; m < T.n_inc; m += NT) {
+		const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];
+		const int lml = irec.x & 0x7FFF;
 		const bool unk = (irec.x >> 15) & 1;
-		const int e_slot = D.lme_edge[W.lme0 + T.inc0 + tid];
+		const int e_slot = D.lme_edge[W.lme0 + T.inc0 + m];
 		double Wm[18], ge[6];
-#pragma unroll
-		for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
-#pragma unroll
-		for (int c = 0; c < 6; ++c) ge[c] = 0.0;
-		int nxt = irec.w;
-		for (int k = 0; k < cnt; ++k) {
-			const int loc = nxt;
-			if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + irec.y + k + 1];
-			const double* er = ent + ENT_P * (loc & 0xFFFF);
-			const double* orr = obsr + OBS_P * (loc >> 16);
-			double a[12], q[3], rr[4], tv[3], x[3];
-#pragma unroll
-			for (int c = 0; c < 12; ++c) a[c] = er[c];
-#pragma unroll
-			for (int c = 0; c < 3; ++c) q[c] = er[12 + c];
-#pragma unroll
-			for (int c = 0; c < 4; ++c) rr[c] = orr[12 + c];
-#pragma unroll
-			for (int c = 0; c < 3; ++c) tv[c] = a[c] * rr[0] + a[3 + c] * rr[1] + a[6 + c] * rr[2] + a[9 + c] * rr[3];
-			cross3(q, tv, x);
-#pragma unroll
-			for (int c = 0; c < 3; ++c) { ge[c] += tv[c]; ge[3 + c] += x[c]; }
-			if (unk) {
-				double jf[12];
-#pragma unroll
-				for (int c = 0; c < 12; ++c) jf[c] = orr[c];
-#pragma unroll
-				for (int b = 0; b < 3; ++b) {
-					double cb[3];
-#pragma unroll
-					for (int c = 0; c < 3; ++c) cb[c] = a[c] * jf[b] + a[3 + c] * jf[3 + b] + a[6 + c] * jf[6 + b] + a[9 + c] * jf[9 + b];
-					cross3(q, cb, x);
-#pragma unroll
-					for (int c = 0; c < 3; ++c) { Wm[3 * c + b] += cb[c]; Wm[3 * (3 + c) + b] += x[c]; }
-				}
-			}
-		}
-		double* gr = gsc + 7 * tid;
+		incidence_sums(D, W, ent, obsr, tab, irec, unk, Wm, ge);
+		double* gr = gsc + 7 * m;
 		gr[6] = __hiloint2double(0, e_slot);
 		if (unk) {
-			while (__hip_atomic_load(s_lmflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < NW * epoch) __builtin_amdgcn_s_sleep(1);
 			const double* lr = lmr + LMR_P * lml;
 			const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
-			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0 + tid);
+			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0 + m);
 			int mk = 0, bs = 0;
 			if (MFMA) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lml]; mk = tp.x; bs = tp.y; }
 #pragma unroll
@@ -745,7 +724,7 @@ __device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& 
 					pp[0] = y0; pp[16] = y1; pp[32] = y2;
 					yg[3 * a] = y0; yg[3 * a + 1] = y1; yg[3 * a + 2] = y2;
 				} else {
-					double* yl = Yr + Y_P * tid;
+					double* yl = Yr + Y_P * m;
 					yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
 				}
 			}
@@ -793,7 +772,7 @@ __device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& 
 				double acc[36];
 #pragma unroll
 				for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-				pp_group(ent, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
+				pp_group(ent, obsr, tab, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
 				wave_seg_add36(acc, rec.y >> 8, lane, P_acc);
 			} else if (pre) {
 				continue;
@@ -894,14 +873,12 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	__shared__ double s_part[NW];
 	__shared__ double s_lambda, s_nu, s_err;
 	__shared__ int s_accept, s_stop, s_iters, s_accepted;
-	__shared__ int s_lmflag;                           // waves that have published their landmark records, all tiles so far
 	__shared__ int s_same;                             // the state has not moved since the previous pass's linearisation
 
 	const int wi = COOP ? (int)blockIdx.x / G : (int)blockIdx.x, g = COOP ? (int)blockIdx.x % G : 0, GG = COOP ? G : 1;
 	const lm_win W = D.win[wi];
 	const int tid = threadIdx.x;
 	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1;
-	int epoch = 0;                                     // tiles started so far
 	coop_t co = {COOP ? D.coop_i + 4 * wi : nullptr, COOP ? D.coop_i + 4 * wi + 1 : nullptr, COOP ? D.coop_f + 128 * (size_t)wi : nullptr, g, GG, 0, 0, coop_expect, coop_spin_limit};
 	bool alive = true;
 	(void)alive;
@@ -914,7 +891,11 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	double* P_acc = s_inv + n6p;
 	double* S_acc = P_acc + n_accP;
 	double* g_acc = S_acc + n_accS;
-	double* reg = ACC ? g_acc + n6p : s_inv + n6p;
+	// path-suffix table: 12 doubles per distinct suffix, rebuilt for the state of every pass -- in LDS, or (many suffixes) in the window's
+	// L2-resident scratch, one copy per workgroup
+	double* tab_l = ACC ? g_acc + n6p : s_inv + n6p;
+	double* reg = tab_l + (W.tab_lds ? 12 * W.n_suf : 0);
+	double* tab = W.tab_lds ? tab_l : D.suf_tab + W.gtab0 + 12 * (size_t)W.n_suf * g;
 	// the reduced system lives over the dead tile records when (n6 + 1) x (n6 | 1) doubles fit there (E <= ~22),
 	// otherwise in the window's L2-resident scratch (same blocked factorisation through plain pointers)
 	const bool lds_mat = (long long)(n6 + 1) * (n6 | 1) <= (long long)dyn_doubles - (reg - s_dyn);
@@ -941,10 +922,11 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	}
 	for (int i = tid + NT * g; i < 3 * W.n_lms; i += NT * GG) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
 	__syncthreads();
-	double e0 = total_error_packed(D, W, P, pose_cur, D.lm, s_part, tid + NT * g, NT * GG);
+	if (W.tab_lds) build_suffix_table(D, W, pose_cur, tab_l); else build_suffix_table(D, W, pose_cur, tab);
+	double e0 = total_error_packed(D, W, P, tab, D.lm, s_part, tid + NT * g, NT * GG);
 	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
-		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_lmflag = 0; s_same = 0;
+		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_same = 0;
 		if (g == 0) {
 			ssk_lm_result& R = D.res[wi];
 			R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
@@ -968,6 +950,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		const bool same_state = !pre && s_same != 0;   // (uniform)
 		const int it_idx = s_iters;
 		double vmax = 0.0;
+		// (the scoring of the previous attempt left the trial state's table here)
+		if (W.tab_lds) build_suffix_table(D, W, pose_cur, tab_l); else build_suffix_table(D, W, pose_cur, tab);
 		STAMP(0);
 		if (ACC) {                                     // the accumulators of this pass start from zero (H_pp: unless the state has not moved)
 			for (int i = tid; i < n_accS + n6p; i += NT) S_acc[i] = 0.0;
@@ -975,8 +959,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			__syncthreads();
 		}
 		for (int t = g; t < W.n_tiles; t += GG) {
-			if (ACC) process_tile_acc<ACC == 2>(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, same_state, ++epoch, &s_lmflag, P_acc, S_acc, g_acc, vmax);
-			else process_tile(D, W, P, D.tile[W.tile0 + t], pose_cur, reg, lambda, pre, same_state, ++epoch, &s_lmflag, Pp, Sp, vmax);
+			if (ACC) process_tile_acc<ACC == 2>(D, W, P, D.tile[W.tile0 + t], tab, reg, lambda, pre, same_state, P_acc, S_acc, g_acc, vmax);
+			else process_tile(D, W, P, D.tile[W.tile0 + t], tab, reg, lambda, pre, same_state, Pp, Sp, vmax);
 			STAMP(1);
 		}
 		if (COOP) {                                    // every workgroup's slots, Y, gradient terms and landmark factors are out
@@ -1105,11 +1089,16 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		if (COOP && ok) {                              // every workgroup's landmark steps are out
 			__syncthreads();                           // (pose_new of this workgroup complete)
 			alive = coop_barrier(co);
-			const double part = total_error_packed(D, W, P, pose_new, D.lm_new, s_part, tid + NT * g, NT * GG);
+			if (W.tab_lds) build_suffix_table(D, W, pose_new, tab_l); else build_suffix_table(D, W, pose_new, tab);
+			const double part = total_error_packed(D, W, P, tab, D.lm_new, s_part, tid + NT * g, NT * GG);
 			err_new = coop_combine<false>(co, part, alive);
 			if (!alive) continue;
 		}
-		if (!COOP && ok) err_new = total_error_packed(D, W, P, pose_new, D.lm_new, s_part, tid, NT);
+		if (!COOP && ok) {
+			__syncthreads();                               // (pose_new complete)
+			if (W.tab_lds) build_suffix_table(D, W, pose_new, tab_l); else build_suffix_table(D, W, pose_new, tab);
+			err_new = total_error_packed(D, W, P, tab, D.lm_new, s_part, tid, NT);
+		}
 		__syncthreads();
 		if (tid == 0) {
 			const int accepted = ok && err_new < s_err;

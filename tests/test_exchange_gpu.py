@@ -40,6 +40,7 @@ def test_rccl_exchange_is_ordered_on_the_context_stream():
         assert ctx.stream() != torch.cuda.current_stream().cuda_stream
         wins = [sl.make_submap_problem(40 + i, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)[0] for i in range(6)]
         b = capi.LmBatch(ctx, wins)
+        b.set_export(True)
         S = 64
         dev = torch.device("cuda:0")
         shared = torch.zeros(S * 12, dtype=torch.float64, device=dev)

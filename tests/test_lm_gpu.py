@@ -341,6 +341,7 @@ def test_pack_and_stitch_shared_blocks(ctx):
     from test_dist_cpu import fuse_numpy
     wins = [sl.make_submap_problem(30 + i, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)[0] for i in range(2)]
     b = capi.LmBatch(ctx, wins)
+    b.set_export(True)                                  # the landmark blocks of the last linearisation go to HBM only on request
     b.run(to_capi(sl.make_params()))
     S = 32
     dev = torch.device("cuda:0")

@@ -80,6 +80,8 @@ def main():
     X, kp = o["poses"], np.array(o["kf_pos"])
     # robot frame: the camera's right is -y (camera_pose_on_robot, EST.cpp:1105-1112); keyframe k sits 0.54 * kf_pos[k] m to the right
     err = np.abs(X.reshape(-1, 3, 4)[:, 1, 3] + 0.54 * kp)
+    Xr = X.reshape(-1, 3, 4)
+    print("max |x| %.3f max |z| %.3f max rotation deviation %.4f" % (np.abs(Xr[:, 0, 3]).max(), np.abs(Xr[:, 2, 3]).max(), np.abs(Xr[:, :, :3] - np.eye(3)).max()))
     path = 0.54 * (n - 1)
     print("frames %d keyframes %d edges %d landmarks %d | loop %.2f s = %.1f frames/s (%.2f ms per frame, %.2f ms on keyframe frames, worst %.1f ms) | "
           "pose graph %.3f s (stop %d, %d attempts, cost %.4g -> %.4g) | loop closures %d, keyframes with > 1 new edge %d, invalid odometry %d | "
