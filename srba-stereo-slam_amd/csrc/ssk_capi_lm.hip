@@ -254,8 +254,17 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 {
 	// SSK_LM_SCHUR (read when the batch is built: the two forms lay the tile out differently): mfma = Y panels + v_mfma_f64_16x16x4
 	// into LDS-resident 16x16 tiles, sparse = 6x6 items Y_i Y_j^T as in the slot kernels
+	// Default by size (profiles/r02_lm_mfma_vs_sparse.json: the two forms are within 1-7 % of each other at every size measured): matrix
+	// cores where the reduced system is larger than the on-chip accumulation limit (E > 12: the local areas of the un-batched drop-in
+	// path, E ~ 40), sparse items below it (the E = 10 windows of the batched bench: 8.59 ms against 8.72 per 1024 windows).
 	const char* schur_env = std::getenv("SSK_LM_SCHUR");
-	const int schur_mfma = !(schur_env && std::strcmp(schur_env, "sparse") == 0);
+	int max_E = 0;
+	for (int w = 0; windows && w < n_windows; ++w) {
+		int E = 0;
+		for (int e = 0; e < windows[w].n_edges_total && windows[w].edge_unknown_slot; ++e) if (windows[w].edge_unknown_slot[e] >= 0) ++E;
+		max_E = std::max(max_E, E);
+	}
+	const int schur_mfma = schur_env ? (std::strcmp(schur_env, "sparse") != 0) : (max_E > SSK_LMA_MAX_E);
 	const char* force_k = std::getenv("SSK_LM_KERNEL");
 	const bool force_acc = force_k && std::strcmp(force_k, "acc") == 0;
 	if (want_acc && windows && n_windows > 0) {            // cheap look ahead: one window with too many optimised edges rules the acc kernel out
@@ -286,8 +295,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	std::vector<int4> tl_rec, inc_rec;
 	std::vector<int> lmep_loc, pit, pslot0, pcl_off, pcl_idx, qit, sslot0, scl_off, scl_idx;
 	std::vector<int2> pgrp, sgrp, tl_pan, suf_rec;
-	std::vector<int> wt_off, wt, tent, tsuf;
-	long long gtab_total = 0;
+	std::vector<int> wt_off, wt, tent, tsuf, st_off;
+	std::vector<int2> mt;
+	long long gtab_total = 0, n_stile_total = 0;
 	bool acc_all = want_acc;
 	size_t n_pslots_total = 0, n_sslots_total = 0, tiled_dyn = 0;
 	bool tiled_all = true;
@@ -429,6 +439,8 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		std::vector<int> w_pit, w_pslot0, w_qit, w_sslot0, w_pcl_off((size_t)n_pairs + 1, 0), w_pcl_idx, w_scl_off((size_t)n_pairs + 1, 0), w_scl_idx;
 		std::vector<int2> w_pgrp, w_sgrp, w_tl_pan;
 		std::vector<int> w_wt_off, w_wt, w_tent, w_tsuf;
+		std::vector<int2> w_mt;                                // (I | J << 8, partial id in generation order -> final id below)
+		std::vector<std::vector<int>> stile_of;                // per upper 16x16 tile u = J (J + 1) / 2 + I: its partials, tile order
 		// ---- path-suffix trie: suffix k of a path = (c_k .. c_{n-1}); a suffix is (first step, shorter suffix), 0 = the empty one ----
 		std::vector<int2> w_suf(1, make_int2(-1, -1));
 		std::vector<int> w_suf_len(1, 0), suf_at((size_t)n_path + 1, 0), obs_suf((size_t)Wn.n_obs, 0);
@@ -468,7 +480,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		// LDS of a workgroup: static part, the window's edge poses twice, the solution vector and the pivots, the tile region
 		const bool acc = want_acc && E <= SSK_LMA_MAX_E;
 		const long long region_bytes = (long long)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC - 2LL * 12 * 8 * Wn.n_edges_total - 2LL * 8 * ((6 * E + 1) & ~1) -
-		                               (acc ? 8LL * ssk_lma_acc_doubles(E) : 0) - (tab_lds ? 96LL * n_suf : 0);
+		                               (acc ? 8LL * ssk_lma_acc_doubles(E) : 0) - (tab_lds ? 104LL * n_suf : 0);
 		bool tiled = 6 * E <= SSK_LM_MAX_N6 && Wn.n_edges_total <= 128 && region_bytes >= 32 * 1024;
 		if (want_acc && !(acc && tiled)) acc_all = false;
 		if (tiled) {
@@ -477,7 +489,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			auto tile_bytes = [](long long nP, long long nO, long long nY, long long nL) {
 				return 8 * (SSK_LMT_ENT * nP + SSK_LMT_OBS * nO + nY + SSK_LMT_LMR * nL);
 			};
-			const bool panels = acc && schur_mfma;
+			const bool panels = schur_mfma != 0;
+			{ const int TR = ssk_lma_row_tiles(E); stile_of.assign((size_t)(TR * (TR + 1) / 2), std::vector<int>()); }
+			int n_stile = 0;
 			std::vector<std::vector<int>> obs_of((size_t)Wn.n_lms_total);
 			for (int o = 0; o < Wn.n_obs; ++o) obs_of[Wn.obs_lm[o]].push_back(o);
 			// packed observation record: everything a lane needs in one coalesced 32-byte load
@@ -633,7 +647,29 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				auto by_pid = [](const item& a, const item& b) { return a.pid < b.pid; };
 				std::stable_sort(pitems.begin(), pitems.end(), by_pid);
 				std::stable_sort(qitems.begin(), qitems.end(), by_pid);
-				if (!acc) {
+				if (!acc && panels) {
+				// slot kernels, matrix-core Schur: H_pp chunks on half the waves, beside them one task per 16x16 tile of the reduced system
+				// that the tile's landmarks touch, most landmarks first; a task leaves a 256-double partial in HBM
+				int R = 1;
+				while (R < 255 && (count_groups(pitems, R) + 63) / 64 > SSK_LMT_NT / 128) ++R;
+				make_groups(pitems, R, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
+				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size(); T.n_sg = 0; T.n_sc = 0;
+				const int TR = ssk_lma_row_tiles(E);
+				std::vector<std::pair<int, int>> tk;               // (-cover, code)
+				for (int J = 0; J < TR; ++J)
+					for (int I = 0; I <= J; ++I) {
+						int cover = 0;
+						for (size_t ok = oi; ok < oj; ++ok) cover += (lm_rowmask[ok] >> I) & (lm_rowmask[ok] >> J) & 1;
+						if (cover) tk.push_back(std::make_pair(-cover, I | (J << 8)));
+					}
+				std::stable_sort(tk.begin(), tk.end());
+				T.mt0 = (int)w_mt.size(); T.n_mt = (int)tk.size();
+				for (const auto& t : tk) {
+					const int I = t.second & 255, J = t.second >> 8;
+					stile_of[(size_t)(J * (J + 1) / 2 + I)].push_back(n_stile);
+					w_mt.push_back(make_int2(t.second, n_stile++));
+				}
+				} else if (!acc) {
 				int R = 1;
 				while (R < 255 && (count_groups(pitems, R) + 63) / 64 + (count_groups(qitems, R) + 63) / 64 > SSK_LMT_NT / 64) ++R;
 				make_groups(pitems, R, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
@@ -706,7 +742,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				w_wt_off.push_back((int)w_wt.size());
 				}
 				w_tiles.push_back(T);
-				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (acc ? 8 * (size_t)ssk_lma_acc_doubles(E) : 0) + (tab_lds ? 96 * (size_t)n_suf : 0) +
+				tiled_dyn = std::max(tiled_dyn, (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (acc ? 8 * (size_t)ssk_lma_acc_doubles(E) : 0) + (tab_lds ? 104 * (size_t)n_suf : 0) +
 				                                (size_t)tile_bytes(T.n_ent, T.n_obs, nY, T.n_lm));
 				oi = oj;
 			}
@@ -725,8 +761,16 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				w_scl_off[p2] = ns_; for (int sl : sslots_of[p2]) w_scl_idx[sl] = ns_++;
 			}
 			w_pcl_off[n_pairs] = np_; w_scl_off[n_pairs] = ns_;
+			// matrix-core partials: final ids tile-major (u), so that the sum of tile u runs over st_off[u] .. st_off[u + 1]
+			{
+				std::vector<int> fin((size_t)n_stile, 0);
+				int nf = 0;
+				for (size_t u = 0; u < stile_of.size(); ++u) { st_off.push_back(nf); for (int gid : stile_of[u]) fin[gid] = nf++; }
+				st_off.push_back(nf);
+				for (int2& m : w_mt) m.y = fin[m.y];
+			}
 			// the reduced system goes to LDS too when it fits beside poses / solution / pivots (else: L2 scratch, Hred)
-			const size_t fixed = (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (tab_lds ? 96 * (size_t)n_suf : 0);
+			const size_t fixed = (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (tab_lds ? 104 * (size_t)n_suf : 0);
 			const size_t mat = (size_t)(6 * E + 1) * ((6 * E) | 1) * 8;
 			if (fixed + mat <= (size_t)(SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC)) tiled_dyn = std::max(tiled_dyn, fixed + mat);
 		}
@@ -737,8 +781,12 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			for (const lm_tile& T : w_tiles)
 				std::fprintf(stderr, "[ssk lm]   tile: lms %d obs %d ent %d inc %d | pgroups %d (chunks %d) sgroups %d (chunks %d)\n", T.n_lm, T.n_obs, T.n_ent, T.n_inc, T.n_pg, T.n_pc, T.n_sg, T.n_sc);
 		}
-		H.n_suf = n_suf; H.suf0 = (int)suf_rec.size(); H.tent0 = (int)tent.size(); H.pad_suf = 0;
+		H.n_suf = n_suf; H.suf0 = (int)suf_rec.size(); H.tent0 = (int)tent.size();
 		H.tab_lds = tab_lds ? 1 : 0; H.tsuf0 = (int)tsuf.size(); H.gtab0 = gtab_total;
+		H.schur_mfma = schur_mfma; H.mt0 = (int)mt.size(); H.st0 = (int)n_stile_total; H.pad_mt = 0;
+		H.sto0 = (int)st_off.size() - (tiled ? (int)stile_of.size() + 1 : 0);
+		mt.insert(mt.end(), w_mt.begin(), w_mt.end());
+		for (const auto& v : stile_of) n_stile_total += (long long)v.size();
 		tsuf.insert(tsuf.end(), w_tsuf.begin(), w_tsuf.end());
 		// a table per workgroup that may share the window (cooperative kernel: up to 64)
 		if (!tab_lds) gtab_total += 12LL * n_suf * (n_windows * 4 <= ctx->n_cu ? 64 : 1);
@@ -859,7 +907,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(inc_rec, inc_rec); UP(lmep_loc, lmep_loc);
 	UP(pit, pit); UP(pgrp, pgrp); UP(pslot0, pslot0); UP(pcl_off, pcl_off); UP(pcl_idx, pcl_idx);
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
-	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan); UP(suf_rec, suf_rec); UP(tent, tent); UP(tsuf, tsuf);
+	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan); UP(suf_rec, suf_rec); UP(tent, tent); UP(tsuf, tsuf); UP(mt, mt); UP(st_off, st_off);
 #undef UP
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
 	b->acc_ok = want_acc && acc_all && tiled_all; b->schur_mfma = schur_mfma;
@@ -898,6 +946,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
 	if (!rc) rc = scratch(b, (size_t)gtab_total, &D.suf_tab);
+	if (!rc) rc = scratch(b, 256 * (size_t)n_stile_total, &D.Stile);
 	if (!rc) rc = scratch(b, pose.size(), &b->pose_bak);
 	if (!rc) rc = scratch(b, lm.size(), &b->lm_bak);
 	D.trace_on = trace ? 1 : 0;
@@ -955,7 +1004,7 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
 		// the grid barrier of the cooperative kernel needs all n_windows * G workgroups resident: G from what the occupancy
 		// query says one CU holds with this launch's LDS, not from the CU count alone
-		const int per_cu = ssk_lm_coop_blocks_per_cu(ctx, b->tiled_dyn_bytes);
+		const int per_cu = ssk_lm_coop_blocks_per_cu(ctx, b->tiled_dyn_bytes, b->schur_mfma);
 		int G = std::min(std::min(b->max_tiles, 64), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
 		const bool want = force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu);
 		if (want) {
@@ -964,12 +1013,12 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 			SSK_HIP(ctx, hipMemcpyAsync(b->pose_bak, b->D.pose, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
 			SSK_HIP(ctx, hipMemcpyAsync(b->lm_bak, b->D.lm, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
 			const bool test_timeout = std::getenv("SSK_LM_COOP_TEST_TIMEOUT") != nullptr;
-			const int rc = ssk_lm_launch_coop(ctx, b->D, P, b->n_windows, G, b->tiled_dyn_bytes, test_timeout);
+			const int rc = ssk_lm_launch_coop(ctx, b->D, P, b->n_windows, G, b->tiled_dyn_bytes, test_timeout, b->schur_mfma);
 			if (rc == SSK_OK) { b->coop_pending = true; b->coop_P = P; }
 			return rc;
 		}
 	}
-	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes);
+	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 	if (!b->has_general) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: the batch was built without the general kernel's structures");
 	return ssk_lm_launch(ctx, b->D, P, b->n_windows, b->max_n6);
 }
@@ -991,7 +1040,7 @@ int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out)
 		if (verbose) std::fprintf(stderr, "[ssk lm] cooperative launch timed out at a barrier: repeating with one workgroup per window\n");
 		SSK_HIP(ctx, hipMemcpyAsync(b->D.pose, b->pose_bak, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
 		SSK_HIP(ctx, hipMemcpyAsync(b->D.lm, b->lm_bak, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
-		int rc = ssk_lm_launch_tiled(ctx, b->D, b->coop_P, b->n_windows, b->tiled_dyn_bytes);
+		int rc = ssk_lm_launch_tiled(ctx, b->D, b->coop_P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 		if (rc) return rc;
 		SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		SSK_HIP(ctx, hipMemcpy(out, b->D.res, sizeof(ssk_lm_result) * (size_t)b->n_windows, hipMemcpyDeviceToHost));

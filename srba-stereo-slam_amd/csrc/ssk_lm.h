@@ -56,7 +56,10 @@ struct lm_win {
 	int tab_lds;                       // 1: the whole table lives in LDS for the pass and records hold global suffix ids; 0 (many suffixes): the table
 	                                   // is built in the window's L2-resident scratch, every tile copies the suffixes it uses (tsuf[]) into LDS and its
 	                                   // records hold tile-local ids
-	int tsuf0, pad_suf;                // tsuf[tsuf0 + ..]: per tile the global ids of the suffixes it uses
+	int tsuf0;                         // tsuf[tsuf0 + ..]: per tile the global ids of the suffixes it uses
+	int schur_mfma;                    // slot kernels: 1 = Schur complement on the matrix cores (Y panels; per (tile, 16x16 tile of the reduced
+	                                   // system) a 256-double partial in HBM: Stile[], summed in tile order), 0 = sparse 6x6 items
+	int mt0, st0, sto0, pad_mt;        // mt[mt0 + ..]: (I | J << 8, partial id) per task; Stile[256 * (st0 + id)]; st_off[sto0 + u]: partials of tile u
 	long long gtab0;                   // suf_tab[gtab0 + ..]: 12 doubles per suffix (x workgroups of the cooperative kernel)
 	int suf_lvl[SSK_LM_MAX_PATH + 2];
 	int acc;              // 0: partial slots in HBM (kernels above); 1: H_pp blocks, Schur tiles and the reduced gradient accumulate in LDS
@@ -82,7 +85,8 @@ struct lm_tile {
 	int sg0, n_sg, sc0, n_sc;   // Schur lane groups / chunks
 	int n_pan;            // acc: Y panels of the tile (a panel = one 16-row tile of the reduced system x one landmark, [3][16] doubles)
 	int wt0, ent0, pad1;  // acc: first entry of the tile's wt_off table (window relative); ent0: first tile entry in tent[] (window relative)
-	int tsuf0, n_tsuf, pad2, pad3;   // !tab_lds: the tile's suffixes tsuf[W.tsuf0 + tsuf0 ..) (tile-local id = position)
+	int tsuf0, n_tsuf;    // !tab_lds: the tile's suffixes tsuf[W.tsuf0 + tsuf0 ..) (tile-local id = position)
+	int mt0, n_mt;        // slot kernels, matrix-core Schur: the tile's tasks mt[W.mt0 + mt0 ..)
 };
 
 struct lm_dev {
@@ -92,6 +96,7 @@ struct lm_dev {
 	const int* pit; const int2* pgrp; const int* pslot0; const int* pcl_off; const int* pcl_idx;
 	const int* qit; const int2* sgrp; const int* sslot0; const int* scl_off; const int* scl_idx;
 	const int2* suf_rec; const int* tent; const int* tsuf; double* suf_tab;
+	const int2* mt; const int* st_off; double* Stile;
 	const int* wt_off; const int* wt; const int2* tl_pan;   // acc kernel (tl_pan: per tile landmark (row-tile mask, first panel of the tile's panel array))
 	int store_hff;        // 1: the landmark blocks H_ff / g_f of the last linearisation go to HBM (shared-landmark exchange); 0: they stay on chip
 	double* Ppart2; double* Spart2;
@@ -137,10 +142,10 @@ constexpr int SSK_LMT_NT = SSK_LMT_THREADS;        // workgroup size
 constexpr int SSK_LMT_ENT = 5, SSK_LMT_OBS = 9, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;
 constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024 / SSK_LMT_WG_PER_CU;   // gfx950: 160 KB of LDS per CU, shared by the resident workgroups
 constexpr int SSK_LMT_STATIC = 1024;               // reserve for the kernel's static LDS (a few scalars and the wave partials)
-int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes);
+int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma);
 // G workgroups per window (n_windows * G <= number of CUs, G <= 64): single large windows of the un-batched drop-in path
-int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout = false);
-int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes);
+int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout, int schur_mfma);
+int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes, int schur_mfma);
 // on-chip accumulation kernel: layout shared by the host tiler and the kernel
 constexpr int SSK_LMA_MAX_E = 12;                  // optimised edges up to which the accumulators live in LDS
 constexpr int SSK_LMA_PANEL = 48;                  // doubles per Y panel: [3 columns][16 rows]

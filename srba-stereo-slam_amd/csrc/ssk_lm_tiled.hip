@@ -203,7 +203,25 @@ __device__ __forceinline__ void project_fast(const lm_cam& P, const double* pc, 
 
 // Path-suffix table of a window at the poses `pose` (window-relative, LDS): tab[12 * id] = row-major [R | t] of the composed
 // transform of suffix id; id 0 = identity.  Level by level (a suffix = one step (+) a shorter suffix), one barrier per level.
-__device__ void build_suffix_table(const lm_dev& D, const lm_win& W, const double* pose, double* __restrict__ tab)
+// recs: the (first step, rest) records -- an LDS copy made once per solve when the table itself lives in LDS (the table is rebuilt
+// twice per LM attempt and every level would otherwise start with an L2 round trip), else the array in HBM.
+__device__ __forceinline__ void suffix_compose(const double* pose, double* __restrict__ tab, int id, const int2 rec)
+{
+	const double* X = pose + 12 * (rec.x >> 1);
+	const double* Tn = tab + 12 * rec.y;
+	const int dir = rec.x & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;      // (R or R^T)(i,j) = X[si * i + sj * j]
+	double tn[3] = {Tn[3], Tn[7], Tn[11]};
+	if (dir) { tn[0] -= X[3]; tn[1] -= X[7]; tn[2] -= X[11]; }
+	double* O = tab + 12 * id;
+#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		const double r0 = X[si * i], r1 = X[si * i + sj], r2 = X[si * i + 2 * sj];
+#pragma unroll
+		for (int j = 0; j < 3; ++j) O[4 * i + j] = r0 * Tn[j] + r1 * Tn[4 + j] + r2 * Tn[8 + j];
+		O[4 * i + 3] = r0 * tn[0] + r1 * tn[1] + r2 * tn[2] + (dir ? 0.0 : X[4 * i + 3]);
+	}
+}
+__device__ void build_suffix_table(const lm_win& W, const double* pose, double* __restrict__ tab, const int2* __restrict__ recs)
 {
 	const int tid = threadIdx.x;
 	if (tid < 12) tab[tid] = (tid == 0 || tid == 5 || tid == 10) ? 1.0 : 0.0;
@@ -211,22 +229,7 @@ __device__ void build_suffix_table(const lm_dev& D, const lm_win& W, const doubl
 	for (int lvl = 1; lvl <= SSK_LM_MAX_PATH; ++lvl) {
 		const int i0 = W.suf_lvl[lvl], i1 = W.suf_lvl[lvl + 1];
 		if (i0 >= W.n_suf) break;                          // (uniform)
-		for (int id = i0 + tid; id < i1; id += NT) {
-			const int2 rec = D.suf_rec[W.suf0 + id];
-			const double* X = pose + 12 * (rec.x >> 1);
-			const double* Tn = tab + 12 * rec.y;
-			const int dir = rec.x & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;      // (R or R^T)(i,j) = X[si * i + sj * j]
-			double tn[3] = {Tn[3], Tn[7], Tn[11]};
-			if (dir) { tn[0] -= X[3]; tn[1] -= X[7]; tn[2] -= X[11]; }
-			double* O = tab + 12 * id;
-#pragma unroll
-			for (int i = 0; i < 3; ++i) {
-				const double r0 = X[si * i], r1 = X[si * i + sj], r2 = X[si * i + 2 * sj];
-#pragma unroll
-				for (int j = 0; j < 3; ++j) O[4 * i + j] = r0 * Tn[j] + r1 * Tn[4 + j] + r2 * Tn[8 + j];
-				O[4 * i + 3] = r0 * tn[0] + r1 * tn[1] + r2 * tn[2] + (dir ? 0.0 : X[4 * i + 3]);
-			}
-		}
+		for (int id = i0 + tid; id < i1; id += NT) suffix_compose(pose, tab, id, recs[id]);
 		__syncthreads();
 	}
 }
@@ -303,6 +306,7 @@ __device__ __forceinline__ double coop_combine(coop_t& c, double v, bool& alive)
 
 // Sum of component ab over the contiguous partial slots k0..k1-1 in order, eight independent loads in flight;
 // padding adds +0.0.
+template <int PITCH = 36>
 __device__ __forceinline__ double slot_sum(const double* __restrict__ part, int k0, int k1, int ab)
 {
 	double s = 0.0;
@@ -311,7 +315,7 @@ __device__ __forceinline__ double slot_sum(const double* __restrict__ part, int 
 		// once: the eight loads were serialised L2 round trips), the padding selected afterwards
 		double v[8];
 #pragma unroll
-		for (int u = 0; u < 8; ++u) v[u] = part[36 * (size_t)min(k + u, k1 - 1) + ab];
+		for (int u = 0; u < 8; ++u) v[u] = part[PITCH * (size_t)min(k + u, k1 - 1) + ab];
 #pragma unroll
 		for (int u = 0; u < 8; ++u) s += k + u < k1 ? v[u] : 0.0;
 	}
@@ -462,121 +466,6 @@ __device__ __forceinline__ void incidence_sums(const lm_dev& D, const lm_win& W,
 	}
 }
 
-// One tile of a window at the pose / landmark state the caller holds: phases I1-I3 of the file header.  `reg`: the
-// workgroup's tile region in LDS; `tab`: the path-suffix table at that state;
-// partial sums go to the window's slot arrays Pp / Sp, Y / gradient terms / landmark factors to its HBM scratch.
-__device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab,
-                                             double* reg, double lambda, bool pre, bool same_state,
-                                             double* __restrict__ Pp, double* __restrict__ Sp, double& vmax)
-{
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-		// a window with many suffixes: this tile's part of the table (built in L2 scratch) comes into LDS first, ids in the records are tile-local
-		if (!W.tab_lds) {
-			double* lt = reg;
-			const int* ids = D.tsuf + W.tsuf0 + T.tsuf0;
-			for (int i = tid; i < 12 * T.n_tsuf; i += NT) { const int k = i / 12; lt[i] = tab[12 * (size_t)ids[k] + (i - 12 * k)]; }
-			reg += 12 * T.n_tsuf;
-			tab = lt;
-			__syncthreads();
-		}
-		double* ent = reg;
-		double* obsr = ent + ENT_P * T.n_ent;
-		double* Yr = obsr + OBS_P * T.n_obs;
-		double* lmr = Yr + Y_P * T.n_inc;
-		// ---- I1: observations ----
-		for (int k = tid; k < T.n_obs; k += NT)
-			linearize_obs_lds(D, W, P, tab, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], D.tent + W.tent0 + T.ent0, k, ent, obsr + OBS_P * k);
-		__syncthreads();
-		// ---- I2a: a lane per landmark: V, g_f, Cholesky -> lmr (+ HBM for the back-substitution) ----
-		for (int j = tid; j < T.n_lm; j += NT) {
-			const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
-			const int slot = lrec.x;
-			if (slot < 0) continue;
-			double v[9];
-			landmark_sums(obsr, lrec.y, lrec.z, v);
-			if (pre) { vmax = fmax(vmax, fmax(v[0], fmax(v[3], v[5]))); continue; }
-			if (D.store_hff) {                                 // only the shared-landmark exchange reads the landmark blocks
-				double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
-				Hm[0] = v[0]; Hm[1] = v[1]; Hm[2] = v[2]; Hm[3] = v[1]; Hm[4] = v[3]; Hm[5] = v[4]; Hm[6] = v[2]; Hm[7] = v[4]; Hm[8] = v[5];
-				double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
-				gl[0] = v[6]; gl[1] = v[7]; gl[2] = v[8];
-			}
-			double rec[9];
-			landmark_factor(v, lambda, rec);
-			double* lr = lmr + LMR_P * j;
-			double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
-#pragma unroll
-			for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
-		}
-		if (!pre) __syncthreads();
-		// ---- I2b: a lane per incidence: W and the gradient term, Y = W L^-T -> LDS, reduced gradient term -> HBM ----
-		if (!pre)
-		for (int m = tid; m < T.n_inc; m += NT) {
-			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
-			const int lml = irec.x & 0x7FFF;
-			const bool unk = (irec.x >> 15) & 1;
-			double Wm[18], ge[6];
-			incidence_sums(D, W, ent, obsr, tab, irec, unk, Wm, ge);
-			double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
-			if (unk) {
-				const double* lr = lmr + LMR_P * lml;
-				const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
-				double* yl = Yr + Y_P * m;
-#pragma unroll
-				for (int a = 0; a < 6; ++a) {
-					const double y0 = Wm[3 * a] * i00;
-					const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
-					const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
-					yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
-					gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
-				}
-			} else {
-#pragma unroll
-				for (int a = 0; a < 6; ++a) gr[a] = ge[a];
-			}
-		}
-		__syncthreads();
-		// ---- I3: Y to HBM for the back-substitution (coalesced), then one chunk task per wave and round:
-		//      H_pp chunks read the entry records, Schur chunks the Y records; both reduce through the scratch
-		//      over the (dead) observation records ----
-		if (!pre) {
-			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
-			for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
-		}
-		// same_state: the previous pass linearised at this very state (the lambda0 pass, or a rejected step): its H_pp slots are
-		// still in place and bit-identical, only the lambda-dependent Schur terms are new
-		const int n_task = T.n_pc + (pre ? 0 : T.n_sc);
-		for (int task = wave + (same_state ? T.n_pc : 0); task < n_task; task += NW) {
-			double acc[36];
-#pragma unroll
-			for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-			if (task < T.n_pc) {
-				const int g = 64 * task + lane;
-				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
-				pp_group(ent, obsr, tab, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
-				wave_seg_sum36(acc, rec.y >> 8, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
-			} else {
-				const int c = task - T.n_pc, g = 64 * c + lane;
-				const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
-				schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
-				wave_seg_sum36(acc, rec.y >> 8, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
-			}
-		}
-		__syncthreads();
-}
-
-// ================= on-chip accumulation (lm_solve_acc_kernel) =================
-// Windows with few optimised edges (E <= SSK_LMA_MAX_E): nothing but Y leaves the chip.  LDS holds, beside the tile records,
-//   P_acc  36 doubles per block pair    H_pp blocks, summed over the tiles (kept across a rejected step: same state, same blocks)
-//   S_acc  256 doubles per upper 16x16 tile of the reduced system (matrix-core form), or 36 per block pair (sparse form)
-//   g_acc  6E doubles                   reduced gradient
-// H_pp / sparse Schur: the chunk tasks of the slot kernels, but the last lane of a block's run ADDS the run's sum to the block's
-// accumulator.  The host gives every block of a tile to one wave and one chunk, and runs cut by the 16-lane DPP rows are added
-// row by row, so an accumulator never sees two adds of one instruction and the order of its adds is fixed: deterministic.
-// Matrix-core Schur: S = sum_l Y_l Y_l^T with Y_l (6E x 3) the stacked Y blocks of landmark l.  Y is written as PANELS -- per
-// (landmark, 16-row tile it touches) a [3][16] block, zero where the landmark has no incidence -- and a task (I, J) runs one
-// v_mfma_f64_16x16x4_f64 per landmark that touches both row tiles: A = panel I, B = panel J (k = 3 columns of Y + one zero
-// lane group), the 16x16 accumulator lives in 4 VGPR pairs for the whole task and goes back to LDS once.
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void lds_add_f64(double* p, double v)
@@ -611,10 +500,12 @@ __device__ __forceinline__ void wave_seg_add36(double (&acc)[36], int key, int l
 
 // S tile (I, J) += sum over the tile's landmarks that touch row tiles I and J of panel_I panel_J^T.  lmask / lbase: this lane's
 // landmark(s) of the tile (lane, lane + 64): row-tile mask and first panel; pan: the tile's panels.
+template <bool RMW>
 __device__ __forceinline__ void schur_mfma_task(const double* __restrict__ pan, int mask0, int base0, int mask1, int base1, int I, int J, int lane,
                                                 double* __restrict__ S_tile)
 {
-	v4d_t c = {S_tile[lane], S_tile[64 + lane], S_tile[128 + lane], S_tile[192 + lane]};
+	v4d_t c = {0.0, 0.0, 0.0, 0.0};
+	if (RMW) { c[0] = S_tile[lane]; c[1] = S_tile[64 + lane]; c[2] = S_tile[128 + lane]; c[3] = S_tile[192 + lane]; }
 	const int l48 = lane < 48 ? lane : 47;
 	const bool real = lane < 48;                           // k = 3: the fourth 16-lane group multiplies zeros
 #pragma unroll
@@ -642,6 +533,151 @@ __device__ unsigned long long g_tst[8];
 #else
 #define TSTAMP(i) do {} while (0)
 #endif
+// One tile of a window at the pose / landmark state the caller holds: phases I1-I3 of the file header.  `reg`: the
+// workgroup's tile region in LDS; `tab`: the path-suffix table at that state;
+// partial sums go to the window's slot arrays Pp / Sp, Y / gradient terms / landmark factors to its HBM scratch.
+template <bool MFMA>
+__device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab,
+                                             double* reg, double lambda, bool pre, bool same_state,
+                                             double* __restrict__ Pp, double* __restrict__ Sp, double& vmax)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SSK_LM_STAMPS
+		unsigned long long tst_last = __builtin_amdgcn_s_memtime();
+#endif
+		// a window with many suffixes: this tile's part of the table (built in L2 scratch) comes into LDS first, ids in the records are tile-local
+		if (!W.tab_lds) {
+			double* lt = reg;
+			const int* ids = D.tsuf + W.tsuf0 + T.tsuf0;
+			for (int i = tid; i < 12 * T.n_tsuf; i += NT) { const int k = i / 12; lt[i] = tab[12 * (size_t)ids[k] + (i - 12 * k)]; }
+			reg += 12 * T.n_tsuf;
+			tab = lt;
+			__syncthreads();
+		}
+		double* ent = reg;
+		double* obsr = ent + ENT_P * T.n_ent;
+		double* Yr = obsr + OBS_P * T.n_obs;               // sparse: Y_P per incidence; matrix cores: SSK_LMA_PANEL per panel
+		double* lmr = Yr + (MFMA ? SSK_LMA_PANEL * T.n_pan : Y_P * T.n_inc);
+		// ---- I1: observations (the Y panels start from zero) ----
+		if (MFMA && !pre) for (int i = tid; i < SSK_LMA_PANEL * T.n_pan; i += NT) Yr[i] = 0.0;
+		for (int k = tid; k < T.n_obs; k += NT)
+			linearize_obs_lds(D, W, P, tab, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], D.tent + W.tent0 + T.ent0, k, ent, obsr + OBS_P * k);
+		__syncthreads();
+		TSTAMP(0);
+		// ---- I2a: a lane per landmark: V, g_f, Cholesky -> lmr (+ HBM for the back-substitution) ----
+		for (int j = tid; j < T.n_lm; j += NT) {
+			const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
+			const int slot = lrec.x;
+			if (slot < 0) continue;
+			double v[9];
+			landmark_sums(obsr, lrec.y, lrec.z, v);
+			if (pre) { vmax = fmax(vmax, fmax(v[0], fmax(v[3], v[5]))); continue; }
+			if (D.store_hff) {                                 // only the shared-landmark exchange reads the landmark blocks
+				double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
+				Hm[0] = v[0]; Hm[1] = v[1]; Hm[2] = v[2]; Hm[3] = v[1]; Hm[4] = v[3]; Hm[5] = v[4]; Hm[6] = v[2]; Hm[7] = v[4]; Hm[8] = v[5];
+				double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
+				gl[0] = v[6]; gl[1] = v[7]; gl[2] = v[8];
+			}
+			double rec[9];
+			landmark_factor(v, lambda, rec);
+			double* lr = lmr + LMR_P * j;
+			double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
+#pragma unroll
+			for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
+		}
+		if (!pre) __syncthreads();
+		TSTAMP(5);
+		// ---- I2b: a lane per incidence: W and the gradient term, Y = W L^-T -> LDS, reduced gradient term -> HBM ----
+		if (!pre)
+		for (int m = tid; m < T.n_inc; m += NT) {
+			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
+			const int lml = irec.x & 0x7FFF;
+			const bool unk = (irec.x >> 15) & 1;
+			double Wm[18], ge[6];
+			incidence_sums(D, W, ent, obsr, tab, irec, unk, Wm, ge);
+			double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
+			if (unk) {
+				const double* lr = lmr + LMR_P * lml;
+				const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
+				double* yl = Yr + Y_P * m;
+				double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0 + m);
+				int mk = 0, bs = 0, e_slot = 0;
+				if (MFMA) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lml]; mk = tp.x; bs = tp.y; e_slot = D.lme_edge[W.lme0 + T.inc0 + m]; }
+#pragma unroll
+				for (int a = 0; a < 6; ++a) {
+					const double y0 = Wm[3 * a] * i00;
+					const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
+					const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
+					if (MFMA) {                                    // rows 6e .. 6e+5 of the landmark's panels, and HBM for the back-substitution
+						const int r = 6 * e_slot + a, rt = r >> 4;
+						double* pp = Yr + SSK_LMA_PANEL * (bs + __popc(mk & ((1 << rt) - 1))) + (r & 15);
+						pp[0] = y0; pp[16] = y1; pp[32] = y2;
+						yg[3 * a] = y0; yg[3 * a + 1] = y1; yg[3 * a + 2] = y2;
+					} else {
+						yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
+					}
+					gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
+				}
+			} else {
+#pragma unroll
+				for (int a = 0; a < 6; ++a) gr[a] = ge[a];
+			}
+		}
+		__syncthreads();
+		TSTAMP(1);
+		// ---- I3: Y to HBM for the back-substitution (coalesced), then one chunk task per wave and round:
+		//      H_pp chunks read the entry records, Schur chunks the Y records; both reduce through the scratch
+		//      over the (dead) observation records ----
+		if (!pre && !MFMA) {
+			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
+			for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
+		}
+		// same_state: the previous pass linearised at this very state (the lambda0 pass, or a rejected step): its H_pp slots are
+		// still in place and bit-identical, only the lambda-dependent Schur terms are new
+		const int n_task = T.n_pc + (pre ? 0 : (MFMA ? T.n_mt : T.n_sc));
+		int mask0 = 0, base0 = 0, mask1 = 0, base1 = 0;
+		if (MFMA && !pre) {                                  // this lane's landmark(s) of the tile: row-tile mask and first panel
+			if (lane < T.n_lm) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lane]; mask0 = tp.x; base0 = tp.y; }
+			if (lane + 64 < T.n_lm) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lane + 64]; mask1 = tp.x; base1 = tp.y; }
+		}
+		for (int task = wave + (same_state ? T.n_pc : 0); task < n_task; task += NW) {
+			if (MFMA && task >= T.n_pc) {
+				// Schur tile (I, J) of this tile's landmarks on the matrix cores -> its 256-double partial in HBM (coalesced)
+				const int2 mrec = D.mt[W.mt0 + T.mt0 + task - T.n_pc];
+				schur_mfma_task<false>(Yr, mask0, base0, mask1, base1, mrec.x & 255, mrec.x >> 8, lane, D.Stile + 256 * (size_t)(W.st0 + mrec.y));
+				continue;
+			}
+			double acc[36];
+#pragma unroll
+			for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+			if (task < T.n_pc) {
+				const int g = 64 * task + lane;
+				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
+				pp_group(ent, obsr, tab, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
+				wave_seg_sum36(acc, rec.y >> 8, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
+			} else {
+				const int c = task - T.n_pc, g = 64 * c + lane;
+				const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
+				schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
+				wave_seg_sum36(acc, rec.y >> 8, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
+			}
+		}
+		__syncthreads();
+		TSTAMP(3);
+}
+
+// ================= on-chip accumulation (lm_solve_acc_kernel) =================
+// Windows with few optimised edges (E <= SSK_LMA_MAX_E): nothing but Y leaves the chip.  LDS holds, beside the tile records,
+//   P_acc  36 doubles per block pair    H_pp blocks, summed over the tiles (kept across a rejected step: same state, same blocks)
+//   S_acc  256 doubles per upper 16x16 tile of the reduced system (matrix-core form), or 36 per block pair (sparse form)
+//   g_acc  6E doubles                   reduced gradient
+// H_pp / sparse Schur: the chunk tasks of the slot kernels, but the last lane of a block's run ADDS the run's sum to the block's
+// accumulator.  The host gives every block of a tile to one wave and one chunk, and runs cut by the 16-lane DPP rows are added
+// row by row, so an accumulator never sees two adds of one instruction and the order of its adds is fixed: deterministic.
+// Matrix-core Schur: S = sum_l Y_l Y_l^T with Y_l (6E x 3) the stacked Y blocks of landmark l.  Y is written as PANELS -- per
+// (landmark, 16-row tile it touches) a [3][16] block, zero where the landmark has no incidence -- and a task (I, J) runs one
+// v_mfma_f64_16x16x4_f64 per landmark that touches both row tiles: A = panel I, B = panel J (k = 3 columns of Y + one zero
+// lane group), the 16x16 accumulator lives in 4 VGPR pairs for the whole task and goes back to LDS once.
 // One tile with on-chip accumulation.  Region: [entries | observation records | Y (records or panels) | landmark records |
 // gradient terms (7 per incidence: 6 values + edge slot)].
 template <bool MFMA>
@@ -786,7 +822,7 @@ __device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& 
 				wave_seg_add36(acc, rec.y >> 8, lane, S_acc);
 			} else if (MFMA) {
 				const int I = code & 255, J = (code >> 8) & 255;
-				schur_mfma_task(Yr, mask0, base0, mask1, base1, I, J, lane, S_acc + 256 * (J * (J + 1) / 2 + I));
+				schur_mfma_task<true>(Yr, mask0, base0, mask1, base1, I, J, lane, S_acc + 256 * (J * (J + 1) / 2 + I));
 			}
 		}
 #ifdef SSK_LM_STAMPS
@@ -808,7 +844,7 @@ __device__ unsigned long long g_f2g[4];
 #endif
 // `solve` = false: only the share (first, step) of the assembly (cooperative kernel: the workgroups of a window assemble the
 // L2-resident system together, workgroup 0 then factorises it with `assemble` = false)
-template <bool GLOBAL_A, typename PtrA>
+template <bool GLOBAL_A, bool SMF = false, typename PtrA>
 __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win& W, const double* __restrict__ Pp, const double* __restrict__ Sp,
                                                    double lambda, PtrA A, int np, int n6, double* s_b, double* s_inv,
                                                    bool assemble = true, bool solve = true, int first = threadIdx.x, int step = NT,
@@ -823,7 +859,11 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 		const int2 ee = D.pair_ee[W.pair0 + pid];
 		if (ee.x == ee.y && a > b) continue;
 		const double p = slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], ab);
-		const double sc = slot_sum(Sp, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
+		double sc;
+		if (SMF) {                                         // matrix-core Schur: the partials of the 16x16 tile that holds (row, col), tile order
+			const int row = 6 * ee.x + a, col = 6 * ee.y + b, u = (col >> 4) * ((col >> 4) + 1) / 2 + (row >> 4);
+			sc = slot_sum<256>(D.Stile + 256 * (size_t)W.st0, D.st_off[W.sto0 + u], D.st_off[W.sto0 + u + 1], (((row & 15) >> 2) << 6) + ((row & 3) << 4) + (col & 15));
+		} else sc = slot_sum(Sp, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
 		double sres = p - sc;
 		if (ee.x == ee.y && a == b) sres += lambda;
 		A[(6 * ee.x + a) * np + 6 * ee.y + b] = sres;
@@ -865,7 +905,7 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 
 // ACC: 0 = partial slots in HBM, 1 = on-chip accumulation with sparse Schur items, 2 = on-chip accumulation with the Schur
 // complement on the matrix cores
-template <bool COOP, int ACC = 0>
+template <bool COOP, int ACC = 0, bool SMF = false>
 __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, int dyn_doubles, int G, int coop_expect = 1, int coop_spin_limit = COOP_SPIN_LIMIT)
 {
 	static_assert(!(COOP && ACC), "the accumulators of a window live in one workgroup's LDS");
@@ -894,7 +934,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	// path-suffix table: 12 doubles per distinct suffix, rebuilt for the state of every pass -- in LDS, or (many suffixes) in the window's
 	// L2-resident scratch, one copy per workgroup
 	double* tab_l = ACC ? g_acc + n6p : s_inv + n6p;
-	double* reg = tab_l + (W.tab_lds ? 12 * W.n_suf : 0);
+	int2* recs_l = reinterpret_cast<int2*>(tab_l + (W.tab_lds ? 12 * W.n_suf : 0));
+	double* reg = tab_l + (W.tab_lds ? 13 * W.n_suf : 0);
 	double* tab = W.tab_lds ? tab_l : D.suf_tab + W.gtab0 + 12 * (size_t)W.n_suf * g;
 	// the reduced system lives over the dead tile records when (n6 + 1) x (n6 | 1) doubles fit there (E <= ~22),
 	// otherwise in the window's L2-resident scratch (same blocked factorisation through plain pointers)
@@ -922,7 +963,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	}
 	for (int i = tid + NT * g; i < 3 * W.n_lms; i += NT * GG) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
 	__syncthreads();
-	if (W.tab_lds) build_suffix_table(D, W, pose_cur, tab_l); else build_suffix_table(D, W, pose_cur, tab);
+	if (W.tab_lds) for (int i = tid; i < W.n_suf; i += NT) recs_l[i] = D.suf_rec[W.suf0 + i];      // (the build's first barrier covers it)
+	if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, tab, D.suf_rec + W.suf0);
 	double e0 = total_error_packed(D, W, P, tab, D.lm, s_part, tid + NT * g, NT * GG);
 	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
@@ -951,7 +993,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		const int it_idx = s_iters;
 		double vmax = 0.0;
 		// (the scoring of the previous attempt left the trial state's table here)
-		if (W.tab_lds) build_suffix_table(D, W, pose_cur, tab_l); else build_suffix_table(D, W, pose_cur, tab);
+		if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, tab, D.suf_rec + W.suf0);
 		STAMP(0);
 		if (ACC) {                                     // the accumulators of this pass start from zero (H_pp: unless the state has not moved)
 			for (int i = tid; i < n_accS + n6p; i += NT) S_acc[i] = 0.0;
@@ -960,7 +1002,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		}
 		for (int t = g; t < W.n_tiles; t += GG) {
 			if (ACC) process_tile_acc<ACC == 2>(D, W, P, D.tile[W.tile0 + t], tab, reg, lambda, pre, same_state, P_acc, S_acc, g_acc, vmax);
-			else process_tile(D, W, P, D.tile[W.tile0 + t], tab, reg, lambda, pre, same_state, Pp, Sp, vmax);
+			else process_tile<SMF>(D, W, P, D.tile[W.tile0 + t], tab, reg, lambda, pre, same_state, Pp, Sp, vmax);
 			STAMP(1);
 		}
 		if (COOP) {                                    // every workgroup's slots, Y, gradient terms and landmark factors are out
@@ -984,7 +1026,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		bool ok = true;
 		const bool share_f2 = COOP && !lds_mat;         // an L2-resident system is assembled by all the workgroups of the window
 		if (share_f2) {
-			assemble_and_solve<true>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, true, false, tid + NT * g, NT * GG);
+			assemble_and_solve<true, SMF>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, true, false, tid + NT * g, NT * GG);
 			alive = coop_barrier(co);
 			if (!alive) continue;
 		}
@@ -1007,8 +1049,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			__syncthreads();
 			if (n6 > 0) ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
 		} else if (g == 0) {
-			ok = lds_mat ? assemble_and_solve<false>(D, W, Pp, Sp, lambda, reg, np, n6, s_b, s_inv)
-			             : assemble_and_solve<true>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, !share_f2, true, tid, NT,
+			ok = lds_mat ? assemble_and_solve<false, SMF>(D, W, Pp, Sp, lambda, reg, np, n6, s_b, s_inv)
+			             : assemble_and_solve<true, SMF>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, !share_f2, true, tid, NT,
 			                                  reg, dyn_doubles - (int)(reg - s_dyn));
 			if (COOP) {
 				if (ok) for (int i = tid; i < n6; i += NT) D.dp[6 * (size_t)W.us0 + i] = s_b[i];
@@ -1089,14 +1131,14 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		if (COOP && ok) {                              // every workgroup's landmark steps are out
 			__syncthreads();                           // (pose_new of this workgroup complete)
 			alive = coop_barrier(co);
-			if (W.tab_lds) build_suffix_table(D, W, pose_new, tab_l); else build_suffix_table(D, W, pose_new, tab);
+			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, tab, D.suf_rec + W.suf0);
 			const double part = total_error_packed(D, W, P, tab, D.lm_new, s_part, tid + NT * g, NT * GG);
 			err_new = coop_combine<false>(co, part, alive);
 			if (!alive) continue;
 		}
 		if (!COOP && ok) {
 			__syncthreads();                               // (pose_new complete)
-			if (W.tab_lds) build_suffix_table(D, W, pose_new, tab_l); else build_suffix_table(D, W, pose_new, tab);
+			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, tab, D.suf_rec + W.suf0);
 			err_new = total_error_packed(D, W, P, tab, D.lm_new, s_part, tid, NT);
 		}
 		__syncthreads();
@@ -1154,7 +1196,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
 			printf("LDL wave0 %llu waves1+ %llu step incl barrier %llu backsub %llu\n", g_ldl[0], g_ldl[1], g_ldl[2], g_ldl[3]);
 			printf("LMT F2 blocks %llu F2 gradient %llu G %llu (slots: pp %d schur %d)\n", g_f2g[0], g_f2g[1], g_f2g[2], D.pcl_off[W.pairo0 + W.n_pairs] - D.pcl_off[W.pairo0], D.scl_off[W.pairo0 + W.n_pairs] - D.scl_off[W.pairo0]);
-			printf("ACC tile phases: I1 %llu I2 %llu gradient %llu tasks (all waves) %llu, of which wave 0 busy %llu\n", g_tst[0], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
+			printf("tile phases: I1 %llu I2a (landmarks) %llu I2b (incidences) %llu gradient (acc) %llu chunk tasks (all waves) %llu, of which wave 0 busy (acc) %llu\n", g_tst[0], g_tst[5], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
 			printf("LMT fine I3: wave0 (H_pp task) copy %llu items %llu segsum %llu wait %llu | wave4 (Schur task) copy %llu items %llu segsum %llu wait %llu\n",
 			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[8], s_fine[9], s_fine[10], s_fine[11]);
 			}
@@ -1166,6 +1208,17 @@ __global__ __launch_bounds__(NT, SSK_LM_WAVES)
 void lm_solve_tiled_kernel(lm_dev D, lm_cam P, int dyn_doubles)
 {
 	lm_tiled_body<false>(D, P, dyn_doubles, 1);
+}
+// ... with the Schur complement on the FP64 matrix cores (v_mfma_f64_16x16x4_f64 on Y panels, 256-double partials per tile)
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_tiled_mfma_kernel(lm_dev D, lm_cam P, int dyn_doubles)
+{
+	lm_tiled_body<false, 0, true>(D, P, dyn_doubles, 1);
+}
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_coop_mfma_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G, int expect, int spin_limit)
+{
+	lm_tiled_body<true, 0, true>(D, P, dyn_doubles, G, expect, spin_limit);
 }
 
 // on-chip accumulation (E <= SSK_LMA_MAX_E): Schur complement by sparse 6x6 items / on the FP64 matrix cores
@@ -1191,21 +1244,24 @@ void lm_solve_coop_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G, int expect
 
 // How many workgroups of the cooperative kernel one CU can hold with this much dynamic LDS (0 on error): the hand-rolled grid
 // barrier needs every workgroup of a window resident at once, so the caller sizes G from this, not from the CU count alone.
-int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes)
+int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes, int schur_mfma)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
-	(void)hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC);
+	const void* fn = schur_mfma ? reinterpret_cast<const void*>(lm_solve_coop_mfma_kernel) : reinterpret_cast<const void*>(lm_solve_coop_kernel);
+	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC);
 	int n = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(lm_solve_coop_kernel), NT, dyn_lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, NT, dyn_lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	return n;
 }
 
-int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout)
+int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout, int schur_mfma)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
 	static bool attr_set = false;
 	if (!attr_set) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		attr_set = true;
 	}
@@ -1213,8 +1269,10 @@ int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_win
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	// test_timeout (SSK_LM_COOP_TEST_TIMEOUT=1): every barrier waits for an arrival that never comes and gives up quickly, the
 	// path a workgroup takes when a co-tenant of the GPU keeps one of its partners from being scheduled
-	hipLaunchKernelGGL(lm_solve_coop_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
-	                   test_timeout ? G + 1 : G, test_timeout ? 1 << 10 : COOP_SPIN_LIMIT);
+	if (schur_mfma) hipLaunchKernelGGL(lm_solve_coop_mfma_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
+	                                   test_timeout ? G + 1 : G, test_timeout ? 1 << 10 : COOP_SPIN_LIMIT);
+	else hipLaunchKernelGGL(lm_solve_coop_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
+	                        test_timeout ? G + 1 : G, test_timeout ? 1 << 10 : COOP_SPIN_LIMIT);
 	SSK_LAUNCH_CHECK(ctx, "lm_solve_coop_kernel");
 	return SSK_OK;
 }
@@ -1235,17 +1293,20 @@ int ssk_lm_launch_acc(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_wind
 	return SSK_OK;
 }
 
-int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes)
+int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
 	static bool attr_set = false;
 	if (!attr_set) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		attr_set = true;
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
-	hipLaunchKernelGGL(lm_solve_tiled_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
+	if (schur_mfma) hipLaunchKernelGGL(lm_solve_tiled_mfma_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
+	else hipLaunchKernelGGL(lm_solve_tiled_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
 	SSK_LAUNCH_CHECK(ctx, "lm_solve_tiled_kernel");
 	return SSK_OK;
 }

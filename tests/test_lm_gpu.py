@@ -277,6 +277,19 @@ def test_lm_bench_windows_against_oracle(ctx, oracle, seed):
     assert res.stop_reason in (1, 4) and res.err_final < res.err_init
 
 
+@pytest.mark.parametrize("kernel", ["tiled", "coop"])
+def test_lm_sparse_schur_form(ctx, oracle, kernel, monkeypatch):
+    """SSK_LM_SCHUR=sparse: the Schur complement as sparse 6x6 items Y_i Y_j^T with segmented lane sums (the form every other test
+    runs with the matrix cores: v_mfma_f64_16x16x4_f64 on Y panels) -- same per-iteration bar, one workgroup per window and the
+    cooperative kernel, on a bench-shaped window and on one whose reduced system lives in L2 scratch."""
+    monkeypatch.setenv("SSK_LM_SCHUR", "sparse")
+    monkeypatch.setenv("SSK_LM_KERNEL", kernel)
+    for shape in ("bench", "large"):
+        wins, prm = coop_cases(shape)
+        res = check_against_oracle(ctx, oracle, wins[0], prm)
+        assert res.stop_reason != 5
+
+
 @pytest.mark.parametrize("schur", ["mfma", "sparse"])
 def test_lm_on_chip_accumulation_kernel(ctx, oracle, schur, monkeypatch):
     """lm_solve_acc_kernel / lm_solve_acc_mfma_kernel (SSK_LM_KERNEL=acc forces them; the default for batches of windows with
