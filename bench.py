@@ -51,7 +51,7 @@ def lm_algorithmic_flops(win):
 
 
 
-def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8, n_lm_distinct=8):
+def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8, n_lm_distinct=8, shared=None):
     """B keyframes + B 'previous' keyframes resident in HBM, B LM windows uploaded."""
     import torch
     import synth
@@ -73,8 +73,18 @@ def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8, n_lm_distinct=8):
     torch.cuda.synchronize()
     wins = [sl.make_submap_problem(100 * rank + s, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2,
                                    obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0] for s in range(n_lm_distinct)]
-    lm = capi.LmBatch(ctx_lm, [wins[k % n_lm_distinct] for k in range(B)])
-    return cur, prev, lm, wins
+    batch = [wins[k % n_lm_distinct] for k in range(B)]
+    shared_idx = None
+    if shared is not None:
+        # BASELINE configs[4]: window 0 of every rank is ITS submap of the shared set (8 config-3-shaped submaps, seeds 50.., + 256 landmarks
+        # of one identity each, observed from two of the submaps): the window the exchange packs; the rest of the batch as before
+        n_sub, n_shared = shared
+        sw, si, _ = sl.make_shared_submaps(n_sub=n_sub, n_shared=n_shared, seed0=50, only={rank % n_sub}, n_kf=200, n_lm=5000, submap_size=10,
+                                           max_tree_depth=4, opt_depth=2, obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))
+        batch[0] = sw[0]
+        shared_idx = si[0]
+    lm = capi.LmBatch(ctx_lm, batch)
+    return cur, prev, lm, wins, shared_idx, batch
 
 
 BOW_DB_ENTRIES = 200       # place-recognition database: the 200 keyframes of BASELINE configs[2]'s submap
@@ -257,10 +267,10 @@ def main():
     lm_stream = torch.cuda.Stream() if args.overlap else torch.cuda.current_stream()
     ctx_lm = pkg.Context(local, stream=lm_stream.cuda_stream) if args.overlap else ctx
     B = args.batch
-    cur, prev, lm, wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_lm_distinct=max(1, min(args.lm_distinct, B)))
+    S = args.shared_landmarks
+    cur, prev, lm, wins, shared_idx, lm_batch_wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_lm_distinct=max(1, min(args.lm_distinct, B)),
+                                                                    shared=(max(world, 2), S) if exchange else None)
     fp, da, lp, cp, fm = params(capi, sl)
-    if exchange:
-        lm.set_export(True)
     pairs = np.stack([np.arange(B), np.arange(B)], 1).astype(np.int32)
     dev = torch.device("cuda", local)
     N = 512
@@ -268,10 +278,14 @@ def main():
     d_dist = torch.empty(B * N, dtype=torch.int32, device=dev)
     d_st = torch.empty(B * N, dtype=torch.int32, device=dev)
     d_tr = torch.empty(B, dtype=torch.int32, device=dev)
-    S = args.shared_landmarks
     shared = torch.zeros(S * 12, dtype=torch.float64, device=dev)
     gathered = torch.zeros(world * S * 12, dtype=torch.float64, device=dev) if exchange else None
-    fused = torch.zeros(S * 3, dtype=torch.float64, device=dev)
+    if exchange:
+        # the consensus positions of the shared landmarks (identical on every rank: the same seeded set) and, per shared landmark, its
+        # index in this rank's window 0 (-1: this submap does not observe it)
+        _, _, sh = sl.make_shared_submaps(n_sub=max(world, 2), n_shared=S, seed0=50, only=set())
+        shared_pos = torch.from_numpy(sh["init"].reshape(-1).copy()).to(dev)
+        d_shared_idx = torch.from_numpy(shared_idx.astype(np.int32)).to(dev)
 
     prev.run_frontend(fp)          # state: the previous keyframes' features (not part of a step)
     ctx.synchronize()
@@ -298,12 +312,14 @@ def main():
         lm.reset()
         lm.run(lp)
         if exchange:
-            # the one exchange step of the path: every submap's shared-landmark blocks to every GPU,
-            # fused in rank order (deterministic); enqueued behind the solve on its stream (RCCL orders the all-gather
-            # against the stream handed over)
-            lm.pack_shared(0, S, shared)
+            # the one exchange step of the path (BASELINE configs[4]): every submap's g / H blocks of the shared landmarks at its solved
+            # state to every GPU, summed in rank order (deterministic), Gauss-Newton step of the shared landmarks, written back: one round of
+            # the block-coordinate descent on the joint problem; enqueued behind the solve on its stream (RCCL orders the all-gather against
+            # the stream handed over)
+            lm.pack_shared(0, d_shared_idx, lp, shared)
             pkg.dist.exchange_shared(shared, gathered, stream=ctx_lm.stream())
-            ctx_lm.stitch_shared(gathered, world, S, fused)
+            ctx_lm.stitch_shared(gathered, world, S, shared_pos)
+            lm.set_shared(0, d_shared_idx, shared_pos)
         if serial:
             torch.cuda.synchronize()
 
@@ -447,10 +463,11 @@ def main():
         # (pixels 16 + ids 16 + landmark 24) + 96 B per edge pose, nothing written when J is fused into the H accumulation
         lm_ms, lm_calls = prof["lm_solve"]
         lm_avg_ms = lm_ms / max(lm_calls, 1)
-        lm_algo = float(sum(r.iters * (56 * len(wins[k % len(wins)].obs_lm) + 96 * len(wins[k % len(wins)].edge_unknown_slot)) for k, r in enumerate(res)))
+        lm_algo = float(sum(r.iters * (56 * len(lm_batch_wins[k].obs_lm) + 96 * len(lm_batch_wins[k].edge_unknown_slot)) for k, r in enumerate(res)))
         lm_ach = lm_algo / (lm_avg_ms * 1e-3) / 1e9
         per_win_flops = [lm_algorithmic_flops(w) for w in wins]
-        lm_flops = float(sum(r.iters * per_win_flops[k % len(wins)] for k, r in enumerate(res)))
+        lm_flops = float(sum(r.iters * (per_win_flops[k % len(wins)] if lm_batch_wins[k] is wins[k % len(wins)] else lm_algorithmic_flops(lm_batch_wins[k]))
+                             for k, r in enumerate(res)))
         lm_tflops = lm_flops / (lm_avg_ms * 1e-3) / 1e12
         # the HBM-bound scan of the front-end (every pixel of both images read once): 933,232 B per keyframe
         fast_ms, fast_calls = prof["fast_nms"]
@@ -478,7 +495,8 @@ def main():
                             "(200-KF/5k-landmark submap, submap_size 10, max_tree_depth 4, window = 10 most recent edges)",
                 "keyframes_per_gpu_per_step": B,
                 "streams": ("front-end + DA on one HIP stream, LM solves on a second one" if args.overlap else "one HIP stream") + ("; place recognition on a side stream beside the data-association chain" if args.side_stream else ""),
-                "parallelism": "keyframe streams partitioned one batch per GPU" + ("; 1 RCCL all-gather of %d shared-landmark blocks per step" % S if exchange else ""),
+                "parallelism": "keyframe streams partitioned one batch per GPU" + ("; configs[4]: every rank's window 0 is its submap of the shared set (%d landmarks of one identity "
+                               "observed from 2 of the %d submaps), 1 RCCL all-gather of their g/H blocks per step + Gauss-Newton update" % (S, max(world, 2)) if exchange else ""),
                 "mean_keypoints_per_image": float(nkp.mean()),
                 "mean_stereo_matches": float(nm.mean()),
                 "mean_tracked_vs_prev": float(tracked.mean()),

@@ -453,19 +453,25 @@ int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_in
 int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_entry* entries, int cap,
                            double* delta_p, double* delta_f, int* n_entries);
 
-/* Multi-GPU exchange (no reference counterpart, the reference is single-process): submaps are
- * partitioned one per GPU and stitched through landmarks observed from more than one submap.
- * pack: the first n_shared optimised landmarks of window w as 12 doubles each -- position (3), gradient g_f
- * (3), upper triangle of H_ff (6) as left by the last linearisation -- into a device buffer: the payload of
- * the ONE all-gather per step (RCCL, issued by the host layer on the same stream).
- * stitch: information-weighted fusion x = (sum_r H_r + eps I)^-1 sum_r H_r x_r of the gathered blocks of
- * n_ranks GPUs ([n_ranks][n_shared][12], rank-major as all_gather lays them out), summed in rank order so
- * every GPU computes bit-identical fused positions [n_shared*3]. */
-int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, double* d_out);
-/* The landmark blocks H_ff / g_f stay on chip unless somebody will read them: call with on != 0 BEFORE ssk_lm_batch_run to have the
- * solve leave those of its last linearisation in HBM for ssk_lm_batch_pack_shared (off by default: 96 B per landmark and pass). */
+/* Multi-GPU exchange (BASELINE configs[4]; no reference counterpart, the reference is single-process): submaps are
+ * partitioned one per GPU and stitched through landmarks of ONE identity observed from more than one submap.  Such a landmark is
+ * based at a keyframe several submaps reach and is optimised by NO window (lm_unknown_slot -1); the exchange moves it:
+ * pack   : per shared landmark s (d_lm_idx[s] = its index in window w, or -1 when this window does not observe it) 12 doubles:
+ *          position (3), g = sum Jf^T w r (3), upper triangle of H = sum Jf^T Jf (6) over the window's observations of it at the
+ *          window's CURRENT state (after ssk_lm_batch_run: the solved state) -- the payload of the ONE all-gather per step (RCCL,
+ *          issued by the host layer on the same stream).
+ * stitch : the gathered blocks of n_ranks GPUs ([n_ranks][n_shared][12], rank-major as all_gather lays them out) summed in rank order,
+ *          so every GPU computes bit-identical results; Gauss-Newton step of every landmark with the cameras held,
+ *          d_pos[s] += (sum_r H_r + lambda I)^-1 sum_r g_r  (d_pos: [n_shared*3], the consensus positions every rank holds).
+ * set    : d_pos back into window w (current AND initial state, so that ssk_lm_batch_reset keeps them).
+ * Alternated with the windows' own solves this is block-coordinate descent on the joint problem of all submaps: it converges to the
+ * solution a single process would compute for their union (tests/test_shared_gpu.py, tests/test_dist_cpu.py). */
+int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, const int32_t* d_lm_idx, const ssk_lm_params* p, double* d_out);
+int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double lambda, double* d_pos);
+int ssk_lm_batch_set_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, const int32_t* d_lm_idx, const double* d_pos);
+/* The blocks H_ff / g_f of the landmarks a window DOES optimise stay on chip; on != 0 before ssk_lm_batch_run leaves those of the last
+ * linearisation in HBM (diagnostics). */
 int ssk_lm_batch_set_export(ssk_ctx* ctx, ssk_lm_batch* b, int on);
-int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double* d_fused);
 
 /* a10/a11: observation marshalling of EST.cpp:142-161,667-704: per match, feat id + pixels + the initial
  * landmark position  camera_pose_on_robot (+) projectMatchTo3D(xl,yl,xr)  (UTIL.h:558-574). Host arrays. */

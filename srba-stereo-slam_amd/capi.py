@@ -618,8 +618,13 @@ class LmBatch:
     def set_export(self, on=True):
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_set_export(self.ctx.h, self.h_, int(bool(on))))
 
-    def pack_shared(self, w, n_shared, d_out):
-        self.ctx._chk(self.ctx.lib.ssk_lm_batch_pack_shared(self.ctx.h, self.h_, int(w), int(n_shared), _dev(d_out)))
+    def pack_shared(self, w, d_lm_idx, prm, d_out):
+        """window w's blocks (position 3, g 3, upper H 6) of the shared landmarks d_lm_idx (device int32: landmark index in the window or -1)
+        at the window's current state -> d_out (device f64 [n_shared * 12])."""
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_pack_shared(self.ctx.h, self.h_, int(w), int(d_lm_idx.numel()), _dev(d_lm_idx), C.byref(prm), _dev(d_out)))
+
+    def set_shared(self, w, d_lm_idx, d_pos):
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_set_shared(self.ctx.h, self.h_, int(w), int(d_lm_idx.numel()), _dev(d_lm_idx), _dev(d_pos)))
 
     def results(self, check=True):
         """check=False: the per-window records as the call filled them even when it reports an error (stop_reason 5)."""
@@ -835,8 +840,10 @@ class Context:
         self._chk(self.lib.ssk_build_observations(self.h, _ptr(kl), _ptr(kr), _ptr(m), len(m), C.byref(lm_params), _ptr(px), _ptr(pos)))
         return px, pos
 
-    def stitch_shared(self, d_gathered, n_ranks, n_shared, d_fused):
-        self._chk(self.lib.ssk_lm_stitch_shared(self.h, _dev(d_gathered), int(n_ranks), int(n_shared), _dev(d_fused)))
+    def stitch_shared(self, d_gathered, n_ranks, n_shared, d_pos, lam=0.0):
+        """d_pos [n_shared * 3] += (sum_r H_r + lam I)^-1 sum_r g_r over the gathered blocks, rank order."""
+        self.lib.ssk_lm_stitch_shared.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        self._chk(self.lib.ssk_lm_stitch_shared(self.h, _dev(d_gathered), int(n_ranks), int(n_shared), float(lam), _dev(d_pos)))
 
     def posegraph_optimize(self, X, edge_ij, edge_z, fixed=0, prm=None):
         """ssk_posegraph_optimize: returns (optimised node poses [n, 12], PgResult)."""

@@ -111,61 +111,140 @@ __global__ void build_obs_kernel(const ssk_keypoint* __restrict__ kl, const ssk_
 		init_pos[3 * i + r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P.S[4 * r], X), __dmul_rn(P.S[4 * r + 1], Y)), __dmul_rn(P.S[4 * r + 2], Z)), P.S[4 * r + 3]);
 }
 
-// (e) multi-GPU exchange payload: per shared landmark 12 doubles = position (3), g_f (3), upper H_ff (6)
-__global__ void pack_shared_kernel(lm_dev D, int w, int n_shared, double* __restrict__ out)
+// (e) multi-GPU exchange (BASELINE configs[4]).  A shared landmark is based at a keyframe that several submaps reach;
+// no window optimises it (lm_unknown_slot -1), the exchange moves it:
+//   pack     per shared landmark what THIS window's observations say at its current state: 12 doubles = position (3), g = sum Jf^T w r
+//            (3), upper triangle of H = sum Jf^T Jf (6) -- observation model and IRLS weight of the LM contract.  A thread per shared
+//            landmark walks the window's observations in order (fixed order: deterministic, no atomics).
+//   stitch   after the ONE all-gather: g and H summed in RANK ORDER (bitwise identical on every GPU), Gauss-Newton step of the
+//            landmark with every camera held: x <- x + (sum H + lambda I)^-1 sum g.
+//   set      the new positions back into the window (state and initial state).
+// Alternating this with the windows' own LM solves is block-coordinate descent on the JOINT problem of all submaps: its fixed point is
+// the joint optimum (tests/test_shared_gpu.py, tests/test_dist_cpu.py: equal to a single-process solve of the union).
+__global__ void pack_shared_kernel(lm_dev D, lm_cam P, int w, int n_shared, const int* __restrict__ lm_idx, double* __restrict__ out)
 {
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n_shared) return;
 	const lm_win W = D.win[w];
 	double* o = out + 12 * (size_t)s;
-	if (s >= W.L) { for (int c = 0; c < 12; ++c) o[c] = 0.0; return; }
-	const int li = D.slot_lm[W.ls0 + s];
-	const double* x = D.lm + 3 * (size_t)(W.lm0 + li);
-	const double* g = D.gf + 3 * (size_t)(W.ls0 + s);
-	const double* Hm = D.Hff + 9 * (size_t)(W.ls0 + s);
-	o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = g[0]; o[4] = g[1]; o[5] = g[2];
-	o[6] = Hm[0]; o[7] = Hm[1]; o[8] = Hm[2]; o[9] = Hm[4]; o[10] = Hm[5]; o[11] = Hm[8];
+	const int li = lm_idx[s];
+	double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // g (3), H upper (6)
+	double f[3] = {0, 0, 0};
+	if (li >= 0 && li < W.n_lms) {
+		const double* fp = D.lm + 3 * (size_t)(W.lm0 + li);
+		f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
+		const double* pose = D.pose + 12 * (size_t)W.edge0;
+		for (int ob = 0; ob < W.n_obs; ++ob) {
+			if (D.obs_lm[W.obs0 + ob] != li) continue;
+			double q[3] = {f[0], f[1], f[2]}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+			const int pb = D.obs_path_off[W.opo0 + ob], pe = D.obs_path_off[W.opo0 + ob + 1];
+			for (int i = pe - 1; i >= pb; --i) {
+				const int c = D.path_edge[W.path0 + i];
+				const double* T = pose + 12 * (c >> 1);
+				const int dir = c & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;
+				const double d0 = dir ? q[0] - T[3] : q[0], d1 = dir ? q[1] - T[7] : q[1], d2 = dir ? q[2] - T[11] : q[2];
+				double t[3], Rn[9];
+				for (int a = 0; a < 3; ++a) {
+					const double r0 = T[si * a], r1 = T[si * a + sj], r2 = T[si * a + 2 * sj];
+					t[a] = r0 * d0 + r1 * d1 + r2 * d2 + (dir ? 0.0 : T[4 * a + 3]);
+					for (int b = 0; b < 3; ++b) Rn[3 * a + b] = r0 * R[b] + r1 * R[3 + b] + r2 * R[6 + b];
+				}
+				for (int a = 0; a < 3; ++a) q[a] = t[a];
+				for (int a = 0; a < 9; ++a) R[a] = Rn[a];
+			}
+			const double e0 = q[0] - P.S[3], e1 = q[1] - P.S[7], e2 = q[2] - P.S[11];
+			double pc[3];
+			for (int a = 0; a < 3; ++a) pc[a] = P.S[a] * e0 + P.S[4 + a] * e1 + P.S[8 + a] * e2;
+			const double iz = 1.0 / pc[2], iz2 = iz * iz;
+			const float* z = D.obs_px + 4 * (size_t)(W.obs0 + ob);
+			const double r[4] = {(double)z[0] - (P.cx_l + P.fx_l * pc[0] * iz), (double)z[1] - (P.cy_l + P.fy_l * pc[1] * iz),
+			                     (double)z[2] - (P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz), (double)z[3] - (P.cy_r + P.fy_r * pc[1] * iz)};
+			const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+			const double wgt = P.robust ? 1.0 / sqrt(sqrt(1.0 + s2 / (P.kernel * P.kernel))) : 1.0;
+			const double Dm[12] = {P.fx_l * iz, 0, -P.fx_l * pc[0] * iz2, 0, P.fy_l * iz, -P.fy_l * pc[1] * iz2,
+			                       P.fx_r * iz, 0, -P.fx_r * (pc[0] - P.baseline) * iz2, 0, P.fy_r * iz, -P.fy_r * pc[1] * iz2};
+			double M[12], Jf[12];                               // M = D R_S^T, Jf = w M R
+			for (int a = 0; a < 4; ++a)
+				for (int b = 0; b < 3; ++b) M[3 * a + b] = Dm[3 * a] * P.S[4 * b] + Dm[3 * a + 1] * P.S[4 * b + 1] + Dm[3 * a + 2] * P.S[4 * b + 2];
+			for (int a = 0; a < 4; ++a)
+				for (int b = 0; b < 3; ++b) Jf[3 * a + b] = wgt * (M[3 * a] * R[b] + M[3 * a + 1] * R[3 + b] + M[3 * a + 2] * R[6 + b]);
+			for (int b = 0; b < 3; ++b) acc[b] += wgt * (Jf[b] * r[0] + Jf[3 + b] * r[1] + Jf[6 + b] * r[2] + Jf[9 + b] * r[3]);
+			int k = 3;
+			for (int a = 0; a < 3; ++a)
+				for (int b = a; b < 3; ++b) acc[k++] += Jf[a] * Jf[b] + Jf[3 + a] * Jf[3 + b] + Jf[6 + a] * Jf[6 + b] + Jf[9 + a] * Jf[9 + b];
+		}
+	}
+	o[0] = f[0]; o[1] = f[1]; o[2] = f[2];
+	for (int c = 0; c < 9; ++c) o[3 + c] = acc[c];
 }
 
-// fuse the gathered blocks in RANK ORDER (fixed summation order => bitwise identical on every GPU):
-// x = (sum_r H_r + eps I)^-1 (sum_r H_r x_r)
-__global__ void stitch_shared_kernel(const double* __restrict__ g, int n_ranks, int n_shared, double* __restrict__ fused)
+__global__ void stitch_shared_kernel(const double* __restrict__ g, int n_ranks, int n_shared, double lambda, double* __restrict__ pos)
 {
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n_shared) return;
 	double A[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-	for (int r = 0; r < n_ranks; ++r) {
+	for (int r = 0; r < n_ranks; ++r) {                    // rank order: the same sums, bit for bit, on every GPU
 		const double* p = g + 12 * ((size_t)r * n_shared + s);
-		const double h00 = p[6], h01 = p[7], h02 = p[8], h11 = p[9], h12 = p[10], h22 = p[11];
-		A[0] += h00; A[1] += h01; A[2] += h02; A[3] += h11; A[4] += h12; A[5] += h22;
-		b[0] += h00 * p[0] + h01 * p[1] + h02 * p[2];
-		b[1] += h01 * p[0] + h11 * p[1] + h12 * p[2];
-		b[2] += h02 * p[0] + h12 * p[1] + h22 * p[2];
+		b[0] += p[3]; b[1] += p[4]; b[2] += p[5];
+		for (int c = 0; c < 6; ++c) A[c] += p[6 + c];
 	}
-	const double eps = 1e-9;
-	const double a = A[0] + eps, bb = A[1], c = A[2], d = A[3] + eps, e = A[4], f = A[5] + eps;
+	if (!(A[0] + A[3] + A[5] > 0.0)) return;               // nobody observes it: it stays where it is
+	const double a = A[0] + lambda, bb = A[1], c = A[2], d = A[3] + lambda, e = A[4], f = A[5] + lambda;
 	const double c00 = d * f - e * e, c01 = c * e - bb * f, c02 = bb * e - c * d;
 	const double det = a * c00 + bb * c01 + c * c02;
 	const double id = 1.0 / det;
 	const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = (a * f - c * c) * id, i12 = (bb * c - a * e) * id, i22 = (a * d - bb * bb) * id;
-	fused[3 * s] = i00 * b[0] + i01 * b[1] + i02 * b[2];
-	fused[3 * s + 1] = i01 * b[0] + i11 * b[1] + i12 * b[2];
-	fused[3 * s + 2] = i02 * b[0] + i12 * b[1] + i22 * b[2];
+	pos[3 * s] += i00 * b[0] + i01 * b[1] + i02 * b[2];
+	pos[3 * s + 1] += i01 * b[0] + i11 * b[1] + i12 * b[2];
+	pos[3 * s + 2] += i02 * b[0] + i12 * b[1] + i22 * b[2];
+}
+
+__global__ void set_shared_kernel(lm_dev D, double* __restrict__ lm0, int w, int n_shared, const int* __restrict__ lm_idx, const double* __restrict__ pos)
+{
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_shared) return;
+	const lm_win W = D.win[w];
+	const int li = lm_idx[s];
+	if (li < 0 || li >= W.n_lms) return;
+	for (int c = 0; c < 3; ++c) { D.lm[3 * (size_t)(W.lm0 + li) + c] = pos[3 * s + c]; lm0[3 * (size_t)(W.lm0 + li) + c] = pos[3 * s + c]; }
 }
 
 }  // namespace
 
 extern "C" {
 
-int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, double* d_out)
+static lm_cam cam_of(const ssk_lm_params* p)
+{
+	lm_cam P{};
+	P.fx_l = p->fx_l; P.fy_l = p->fy_l; P.cx_l = p->cx_l; P.cy_l = p->cy_l;
+	P.fx_r = p->fx_r; P.fy_r = p->fy_r; P.cx_r = p->cx_r; P.cy_r = p->cy_r; P.baseline = p->baseline;
+	for (int i = 0; i < 12; ++i) P.S[i] = p->sensor_pose[i];
+	P.max_iters = p->max_iters; P.robust = p->use_robust_kernel; P.kernel = p->kernel_param; P.tau = p->tau;
+	P.max_lambda = p->max_lambda; P.stop_rmse = p->max_error_per_obs_to_stop; P.conv_rel = p->converged_rel_decrease;
+	return P;
+}
+
+int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, const int32_t* d_lm_idx, const ssk_lm_params* p, double* d_out)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
-	if (!b || w < 0 || w >= b->n_windows || n_shared < 0 || (n_shared > 0 && !d_out))
+	if (!b || w < 0 || w >= b->n_windows || n_shared < 0 || !p || (n_shared > 0 && (!d_out || !d_lm_idx)))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_pack_shared: bad argument");
 	if (n_shared == 0) return SSK_OK;
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
-	hipLaunchKernelGGL(pack_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, b->D, w, n_shared, d_out);
+	hipLaunchKernelGGL(pack_shared_kernel, dim3((n_shared + 63) / 64), dim3(64), 0, ctx->stream, b->D, cam_of(p), w, n_shared, d_lm_idx, d_out);
 	SSK_LAUNCH_CHECK(ctx, "pack_shared_kernel");
+	return SSK_OK;
+}
+
+int ssk_lm_batch_set_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, const int32_t* d_lm_idx, const double* d_pos)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || w < 0 || w >= b->n_windows || n_shared < 0 || (n_shared > 0 && (!d_pos || !d_lm_idx)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_set_shared: bad argument");
+	if (n_shared == 0) return SSK_OK;
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(set_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, b->D, const_cast<double*>(b->D.lm0), w, n_shared, d_lm_idx, d_pos);
+	SSK_LAUNCH_CHECK(ctx, "set_shared_kernel");
 	return SSK_OK;
 }
 
@@ -177,14 +256,14 @@ int ssk_lm_batch_set_export(ssk_ctx* ctx, ssk_lm_batch* b, int on)
 	return SSK_OK;
 }
 
-int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double* d_fused)
+int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double lambda, double* d_pos)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
-	if (n_ranks < 1 || n_shared < 0 || (n_shared > 0 && (!d_gathered || !d_fused)))
+	if (n_ranks < 1 || n_shared < 0 || !(lambda >= 0.0) || (n_shared > 0 && (!d_gathered || !d_pos)))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_stitch_shared: bad argument");
 	if (n_shared == 0) return SSK_OK;
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
-	hipLaunchKernelGGL(stitch_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, d_gathered, n_ranks, n_shared, d_fused);
+	hipLaunchKernelGGL(stitch_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, d_gathered, n_ranks, n_shared, lambda, d_pos);
 	SSK_LAUNCH_CHECK(ctx, "stitch_shared_kernel");
 	return SSK_OK;
 }

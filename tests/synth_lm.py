@@ -89,8 +89,13 @@ class Window:
 
 
 def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=4, opt_depth=5, obs_per_kf=250,
-                        px_noise=0.5, edge_noise=(0.05, 0.01), lm_noise=0.05, root=None, lm_fwd=(4.0, 45.0), z_vis=(3.0, 60.0)):
-    """Returns (Window with a perturbed initial state, dict with ground truth)."""
+                        px_noise=0.5, edge_noise=(0.05, 0.01), lm_noise=0.05, root=None, lm_fwd=(4.0, 45.0), z_vis=(3.0, 60.0), shared=None):
+    """Returns (Window with a perturbed initial state, dict with ground truth).
+    shared (BASELINE configs[4]): dict(points (n, 3) in the frame of a common ANCHOR keyframe, init (n, 3) their initial estimates,
+    G 4x4 = the anchor seen from this submap's root keyframe, use (n,) bool: which of them this submap observes).  The anchor hangs on
+    the root by a FIXED edge at its true value; the landmarks are based at the anchor, observed from the keyframes of the local area
+    that see them, and come last in the window's landmark list, NOT optimised (lm_unknown_slot -1): gt["shared_idx"][s] = index of
+    shared landmark s in this window, or -1."""
     rng = np.random.default_rng(0xBA5E0000 + seed)
     k = KITTI_CAM
     # ---- trajectory: ~1 m per keyframe, gentle yaw; robot x forward, z up ----
@@ -188,6 +193,30 @@ def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=
         if len(steps) > max_tree_depth:
             continue
         win_obs.append((kf, l, p, steps))
+    # ---- shared landmarks: based at the anchor keyframe n_kf, reached over the fixed edge (anchor -> root) ----
+    shared_lm0 = n_lm
+    if shared is not None:
+        G = np.asarray(shared["G"], float)
+        anchor_edge = len(edges)
+        edges.append((n_kf, root))
+        inv_pose_gt.append(G)                                  # pose of `from` (the anchor) seen from `to` (the root)
+        pts = np.asarray(shared["points"], float)
+        for s_i in np.flatnonzero(shared["use"]):
+            pw = Tw[root] @ G @ np.append(pts[s_i], 1.0)
+            n_seen = 0
+            for kf in sorted(area):
+                pc = (np.linalg.inv(Tw[kf] @ S) @ pw)[:3]
+                if not (z_vis[0] <= pc[2] <= z_vis[1]):
+                    continue
+                u, v, ur = k["cx"] + k["fx"] * pc[0] / pc[2], k["cy"] + k["fy"] * pc[1] / pc[2], k["cx"] + k["fx"] * (pc[0] - k["baseline"]) / pc[2]
+                if not (0 <= u < k["w"] and 0 <= ur < k["w"] and 0 <= v < k["h"]):
+                    continue
+                steps = path(kf, root) + [(anchor_edge, root, n_kf)]
+                if len(steps) > max_tree_depth:
+                    continue
+                px = np.array([u, v, ur, v])
+                win_obs.append((kf, shared_lm0 + int(s_i), px + rng.normal(0, px_noise, 4) if px_noise > 0 else px, steps))
+                n_seen += 1
     used_edges = sorted({e for _, _, _, st in win_obs for e, _, _ in st} | set(opt_edges))
     eidx = {e: i for i, e in enumerate(used_edges)}
     used_lms = sorted({l for _, l, _, _ in win_obs})
@@ -196,8 +225,12 @@ def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=
     for s, e in enumerate(opt_edges):
         edge_slot[eidx[e]] = s
     lm_slot = np.arange(len(used_lms), dtype=np.int32)       # every landmark of the area is optimised
+    if shared is not None:
+        lm_slot[[i for i, l in enumerate(used_lms) if l >= shared_lm0]] = -1      # ... but the shared ones: moved by the exchange, not by this window
+        lm_slot[lm_slot >= 0] = np.arange(int((lm_slot >= 0).sum()))
     gt_pose = np.array([inv_pose_gt[e][:3, :].reshape(-1) for e in used_edges])
-    gt_lm = np.array([(np.linalg.inv(Tw[base_of[l]]) @ np.append(lm_world[l], 1.0))[:3] for l in used_lms]).reshape(-1, 3)
+    gt_lm = np.array([(np.linalg.inv(Tw[base_of[l]]) @ np.append(lm_world[l], 1.0))[:3] if l < shared_lm0 else np.asarray(shared["points"], float)[l - shared_lm0]
+                      for l in used_lms]).reshape(-1, 3)
     obs_lm = np.array([lidx[l] for _, l, _, _ in win_obs], np.int32)
     obs_px = np.array([p for _, _, p, _ in win_obs], np.float32).reshape(-1, 4)
     off, pe = [0], []
@@ -215,5 +248,71 @@ def make_submap_problem(seed, n_kf=30, n_lm=800, submap_size=10, max_tree_depth=
             dT = se3(so3_exp(rng.normal(0, edge_noise[1], 3)), rng.normal(0, edge_noise[0], 3))
             init_pose[i] = (dT @ T)[:3, :].reshape(-1)
     init_lm = gt_lm + rng.normal(0, lm_noise, gt_lm.shape) * (1 + np.abs(gt_lm[:, :1]) / 10.0)
+    out = dict(gt_pose=gt_pose, gt_lm=gt_lm, n_kf=n_kf, edges=[edges[e] for e in used_edges], area=sorted(area))
+    if shared is not None:
+        idx = -np.ones(len(shared["points"]), np.int32)
+        for i, l in enumerate(used_lms):
+            if l >= shared_lm0:
+                idx[l - shared_lm0] = i
+                init_lm[i] = np.asarray(shared["init"], float)[l - shared_lm0]      # every submap starts from the same estimate
+        out["shared_idx"] = idx
     win = Window(edge_slot, init_pose, lm_slot, init_lm, obs_lm, obs_px, off, pe)
-    return win, dict(gt_pose=gt_pose, gt_lm=gt_lm, n_kf=n_kf, edges=[edges[e] for e in used_edges], area=sorted(area))
+    return win, out
+
+
+def make_shared_submaps(n_sub=8, n_shared=256, seed0=50, per_landmark=2, only=None, **kw):
+    """BASELINE configs[4]: n_sub independent config-3-shaped submaps (seeds seed0 ..) + n_shared landmarks of ONE identity each,
+    observed from `per_landmark` >= 2 of the submaps (landmark s from submaps s, s+1, .. mod n_sub): the submaps' newest keyframes stand
+    around a common anchor keyframe (known, fixed relative poses) and the shared landmarks lie in front of it.
+    only: build just these submaps (every rank of a multi-GPU run builds its own; the shared set is the same for all).
+    Returns ([Window], [shared_idx arrays], dict(points, init))."""
+    rng = np.random.default_rng(0x5AAE0000 + seed0)
+    x = rng.uniform(5.0, 14.0, n_shared)
+    pts = np.column_stack([x, rng.uniform(-0.35, 0.35, n_shared) * x, rng.uniform(-0.12, 0.2, n_shared) * x])
+    init = pts + rng.normal(0, 0.05, pts.shape) * (1 + x[:, None] / 10.0)
+    wins, idxs = [], []
+    for r in range(n_sub):
+        use = np.array([(r - s) % n_sub < per_landmark for s in range(n_shared)])
+        G = se3(rot_z(rng.normal(0, 0.05)), [rng.normal(0, 0.3), rng.normal(0, 0.3), 0.0])      # the anchor seen from this submap's root
+        if only is not None and r not in only:
+            continue
+        w, gt = make_submap_problem(seed0 + r, shared=dict(points=pts, init=init, G=G, use=use), **kw)
+        wins.append(w); idxs.append(gt["shared_idx"])
+    return wins, idxs, dict(points=pts, init=init)
+
+
+def join_windows(wins, idxs):
+    """The union of the submaps as ONE window: edges and private landmarks side by side, every shared landmark once and OPTIMISED --
+    what a single process would solve.  Returns (Window, per-submap edge offsets, per-submap landmark index maps, joint index of
+    every shared landmark)."""
+    n_shared = len(idxs[0])
+    e_off, slots, poses, lm_map, lm_pos, lm_slot = [], [], [], [], [], []
+    ne = 0
+    E = 0
+    shared_joint = -np.ones(n_shared, np.int64)
+    for w, idx in zip(wins, idxs):
+        e_off.append(ne)
+        sl = w.edge_unknown_slot.copy()
+        sl[sl >= 0] += E
+        E += w.E
+        slots.append(sl); poses.append(w.edge_inv_pose); ne += len(sl)
+        inv = {int(li): s for s, li in enumerate(idx) if li >= 0}
+        m = np.zeros(len(w.lm_pos), np.int64)
+        for li in range(len(w.lm_pos)):
+            if li in inv and shared_joint[inv[li]] >= 0:
+                m[li] = shared_joint[inv[li]]
+                continue
+            m[li] = len(lm_pos)
+            lm_pos.append(w.lm_pos[li]); lm_slot.append(1)
+            if li in inv:
+                shared_joint[inv[li]] = m[li]
+        lm_map.append(m)
+    lm_slot = np.arange(len(lm_pos), dtype=np.int32)
+    obs_lm = np.concatenate([m[w.obs_lm] for w, m in zip(wins, lm_map)]).astype(np.int32)
+    obs_px = np.concatenate([w.obs_px for w in wins])
+    off, pe = [0], []
+    for w, eo in zip(wins, e_off):
+        for o in range(len(w.obs_lm)):
+            pe.extend(int(c) + 2 * eo for c in w.path_edge[w.obs_path_off[o]:w.obs_path_off[o + 1]])
+            off.append(len(pe))
+    return Window(np.concatenate(slots), np.concatenate(poses), lm_slot, np.array(lm_pos), obs_lm, obs_px, off, pe), e_off, lm_map, shared_joint

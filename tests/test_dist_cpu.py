@@ -1,6 +1,9 @@
-"""CPU (gloo, world size 2): the N>1 plumbing of the path -- partitioning and the single all-gather of the
-shared-landmark blocks with its rank-major layout; the fusion (numpy restatement of ssk_lm_stitch_shared's formula,
-test infrastructure) must be bit-identical on both ranks because it sums in rank order."""
+"""CPU (gloo, world size 2): the N > 1 path of BASELINE configs[4] / SURVEY 8(e) -- partitioning, the single all-gather of the
+shared-landmark blocks with its rank-major layout, and what the exchange MEANS: two ranks, one submap each, 24 landmarks of one
+identity observed from both.  Per round every rank solves its own window (the CPU oracle stands in for the GPU solve: test
+infrastructure), contributes its g / H blocks of the shared landmarks (tests/shared_ref.py, the numpy restatement of
+ssk_lm_batch_pack_shared), ONE all-gather, the rank-ordered Gauss-Newton update (restatement of ssk_lm_stitch_shared).  The rounds
+must converge to the JOINT single-process solve of the union of the two submaps, bit-identically on both ranks."""
 import os
 import socket
 import sys
@@ -12,55 +15,52 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def fuse_numpy(g, n_ranks, n_shared):
-    """x = (sum_r H_r + eps I)^-1 sum_r H_r x_r, summed in rank order (what stitch_shared_kernel computes)."""
-    g = g.reshape(n_ranks, n_shared, 12)
-    out = np.zeros((n_shared, 3))
-    for s in range(n_shared):
-        A = np.zeros((3, 3))
-        b = np.zeros(3)
-        for r in range(n_ranks):
-            p = g[r, s]
-            Hm = np.array([[p[6], p[7], p[8]], [p[7], p[9], p[10]], [p[8], p[10], p[11]]])
-            A = A + Hm
-            b = b + Hm @ p[:3]
-        out[s] = np.linalg.solve(A + 1e-9 * np.eye(3), b)
-    return out
+N_SHARED, ROUNDS = 24, 70
+KW = dict(n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60, opt_depth=2)
 
 
 def worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    import __graft_entry__ as ge
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import importlib.util
     spec = importlib.util.spec_from_file_location("ssk_dist", os.path.join(ROOT, "srba-stereo-slam_amd", "dist.py"))
     d = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(d)
+    import oracle_lib as ol
+    import shared_ref as sr
+    import synth_lm as sl
     r, w = d.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    n_shared = 16
-    rng = np.random.default_rng(100 + rank)
-    blocks = np.zeros((n_shared, 12))
-    blocks[:, :3] = rng.normal(0, 5, (n_shared, 3)) + np.arange(n_shared)[:, None]
-    for s in range(n_shared):
-        J = rng.normal(0, 1, (4, 3))
-        Hm = J.T @ J + 0.1 * np.eye(3)
-        blocks[s, 6:] = [Hm[0, 0], Hm[0, 1], Hm[0, 2], Hm[1, 1], Hm[1, 2], Hm[2, 2]]
-    shared = torch.from_numpy(blocks.reshape(-1).copy())
-    gathered = torch.zeros(world * n_shared * 12, dtype=torch.float64)
-    d.exchange_shared(shared, gathered)
-    g = gathered.numpy().reshape(world, n_shared, 12)
-    assert np.array_equal(g[rank], blocks)                       # rank-major layout
-    fused = fuse_numpy(gathered.numpy(), world, n_shared)
+    oracle = ol.load()
+    wins, idxs, sh = sl.make_shared_submaps(n_sub=world, n_shared=N_SHARED, seed0=50, only={rank}, **KW)
+    win, idx = wins[0], idxs[0]
+    prm = sl.make_params(max_iters=50, conv=1e-14)
+    pos = sh["init"].copy()
+    errs, first = [], None
+    for rnd in range(ROUNDS):
+        win.lm_pos[idx[idx >= 0]] = pos[idx >= 0]
+        out = oracle.lm_solve(win, prm, trace=False)
+        win = sl.Window(win.edge_unknown_slot, out["poses"], win.lm_unknown_slot, out["lms"], win.obs_lm, win.obs_px, win.obs_path_off, win.path_edge)
+        blocks = sr.blocks(win, prm, out["poses"], out["lms"], idx)
+        shared = torch.from_numpy(blocks.reshape(-1).copy())
+        gathered = torch.zeros(world * N_SHARED * 12, dtype=torch.float64)
+        d.exchange_shared(shared, gathered)                      # the ONE collective of a round
+        g = gathered.numpy().reshape(world, N_SHARED, 12)
+        assert np.array_equal(g[rank], blocks)                   # rank-major layout
+        if rnd == 0:
+            first = g[1 - rank][:, 3:6].tobytes()                # the OTHER rank's gradient blocks really arrived
+        pos = sr.consensus(g, pos)
+        t = torch.tensor([out["res"].err_final], dtype=torch.float64)
+        dist.all_reduce(t)                                       # (test bookkeeping only: the joint cost)
+        errs.append(float(t.item()))
     parts = [d.partition(11, k, world) for k in range(world)]
-    q.put((rank, fused.tobytes(), g[1 - rank][:, :3].tobytes(), parts))
+    q.put((rank, pos.tobytes(), win.edge_inv_pose.tobytes(), win.lm_pos.tobytes(), errs, first, parts))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gloo_world2_exchange_is_rank_ordered_and_deterministic():
+def test_gloo_world2_exchange_rounds_equal_the_joint_solve():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -72,14 +72,31 @@ def test_gloo_world2_exchange_is_rank_ordered_and_deterministic():
         p.start()
     res = {}
     for _ in range(2):
-        r = q.get(timeout=120)
+        r = q.get(timeout=300)
         res[r[0]] = r
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res[0][1] == res[1][1]                                # fused landmarks bit-identical on both ranks
-    assert res[0][3] == [(0, 6), (6, 11)]                        # contiguous partition, remainder to the low ranks
-    # each rank really received the OTHER rank's positions
-    a = np.frombuffer(res[0][2]).reshape(-1, 3)
-    b = np.frombuffer(res[1][2]).reshape(-1, 3)
-    assert not np.array_equal(a, b)
+    assert res[0][1] == res[1][1]                                # consensus positions bit-identical on both ranks (rank-ordered sums)
+    assert res[0][6] == [(0, 6), (6, 11)]                        # contiguous partition, remainder to the low ranks
+    assert res[0][5] != res[1][5]                                # each rank received the other's blocks, not its own twice
+    # ---- against the joint single-process solve of the union ----
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    import synth_lm as sl
+    wins, idxs, sh = sl.make_shared_submaps(n_sub=2, n_shared=N_SHARED, seed0=50, **KW)
+    joint, e_off, lm_map, sj = sl.join_windows(wins, idxs)
+    J = ol.load().lm_solve(joint, sl.make_params(max_iters=50, conv=1e-14), trace=False)
+    shared = np.frombuffer(res[0][1]).reshape(N_SHARED, 3)
+    assert np.abs(shared - J["lms"][sj]).max() <= 1e-6
+    errs = res[0][4]
+    assert errs[-1] < errs[0] and abs(errs[-1] - J["res"].err_final) <= 1e-9 * J["res"].err_final
+    for r in range(2):
+        poses = np.frombuffer(res[r][2]).reshape(-1, 12)
+        lms = np.frombuffer(res[r][3]).reshape(-1, 3)
+        assert np.abs(poses - J["poses"][e_off[r]:e_off[r] + len(poses)]).max() <= 1e-6, r
+        private = idxs[r][idxs[r] >= 0]
+        keep = np.ones(len(lms), bool)
+        keep[private] = False                                    # (the window's own copy of the shared ones is one round behind)
+        ref = J["lms"][lm_map[r]][keep]                          # 1e-6 RELATIVE: a landmark 40 m away is known to its depth's share of that
+        assert (np.abs(lms[keep] - ref) <= 1e-6 * np.maximum(1.0, np.linalg.norm(ref, axis=1))[:, None]).all(), r

@@ -19,7 +19,6 @@ def test_rccl_exchange_is_ordered_on_the_context_stream():
     import torch.distributed as dist
     import __graft_entry__ as ge
     import synth_lm as sl
-    from test_dist_cpu import fuse_numpy
     from test_lm_gpu import to_capi
     pkg = ge.load_package()
     from ssk_amd import capi
@@ -38,29 +37,36 @@ def test_rccl_exchange_is_ordered_on_the_context_stream():
         ctx = pkg.Context(0)                                     # owns a non-blocking stream
         assert ctx.stream() not in (0, None)
         assert ctx.stream() != torch.cuda.current_stream().cuda_stream
-        wins = [sl.make_submap_problem(40 + i, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)[0] for i in range(6)]
-        b = capi.LmBatch(ctx, wins)
-        b.set_export(True)
         S = 64
+        wins, idxs, sh = sl.make_shared_submaps(n_sub=3, n_shared=S, seed0=40, per_landmark=3, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60, opt_depth=2)
+        b = capi.LmBatch(ctx, wins)
         dev = torch.device("cuda:0")
         shared = torch.zeros(S * 12, dtype=torch.float64, device=dev)
         gathered = torch.zeros(S * 12, dtype=torch.float64, device=dev)
-        fused = torch.zeros(S * 3, dtype=torch.float64, device=dev)
+        pos = torch.from_numpy(sh["init"].reshape(-1).copy()).to(dev)
+        d_idx = [torch.from_numpy(i.astype(np.int32)).to(dev) for i in idxs]
         torch.cuda.synchronize()
         prm = to_capi(sl.make_params())
+        before = None
         for rep in range(3):                                     # no host synchronisation between the enqueued pieces
             b.reset()
             b.run(prm)
-            b.pack_shared(rep, S, shared)
+            if rep == 2:                                         # (a copy ordered on the CONTEXT's stream, like everything else here)
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(ctx.stream()), device=dev)):
+                    before = pos.clone()
+            b.pack_shared(rep, d_idx[rep], prm, shared)
             pkg.dist.exchange_shared(shared, gathered, stream=ctx.stream())
-            ctx.stitch_shared(gathered, 1, S, fused)
+            ctx.stitch_shared(gathered, 1, S, pos)
+            b.set_shared(rep, d_idx[rep], pos)
         ctx.synchronize()
         torch.cuda.synchronize()
         g = gathered.cpu().numpy()
         assert np.array_equal(g, shared.cpu().numpy())
-        assert np.array_equal(g.reshape(S, 12)[:, :3], b.state(2)[1][:S])      # the LAST repetition's window, after its solve
-        exp = fuse_numpy(g, 1, S)
-        assert np.allclose(fused.cpu().numpy().reshape(S, 3), exp, rtol=1e-9, atol=1e-9)
+        # the LAST repetition's window, after its solve: its own copy of the shared landmarks, then the update written back
+        import shared_ref as sr
+        exp = sr.consensus(g.reshape(1, S, 12), before.cpu().numpy().reshape(S, 3))
+        assert np.allclose(pos.cpu().numpy().reshape(S, 3), exp, rtol=1e-10, atol=1e-12)
+        assert np.array_equal(b.state(2)[1][idxs[2]], pos.cpu().numpy().reshape(S, 3))
         b.close()
         ctx.close()
     finally:

@@ -344,31 +344,3 @@ def test_build_observations_bit_exact(ctx, oracle):
     oracle.lib.ssko_build_observations(ctypes.c_void_p(kl.ctypes.data), ctypes.c_void_p(kr.ctypes.data), ctypes.c_void_p(m.ctypes.data),
                                        len(m), ctypes.byref(prm), ctypes.c_void_p(epx.ctypes.data), ctypes.c_void_p(epos.ctypes.data))
     assert np.array_equal(px, epx) and np.array_equal(pos, epos)
-
-
-def test_pack_and_stitch_shared_blocks(ctx):
-    """(e) multi-GPU exchange payload and fusion on one GPU: pack the first landmarks of two windows, lay them out
-    as an all-gather would (rank-major) and compare the kernel's fusion with the numpy formula."""
-    import torch
-    from ssk_amd import capi
-    from test_dist_cpu import fuse_numpy
-    wins = [sl.make_submap_problem(30 + i, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)[0] for i in range(2)]
-    b = capi.LmBatch(ctx, wins)
-    b.set_export(True)                                  # the landmark blocks of the last linearisation go to HBM only on request
-    b.run(to_capi(sl.make_params()))
-    S = 32
-    dev = torch.device("cuda:0")
-    gathered = torch.zeros(2 * S * 12, dtype=torch.float64, device=dev)
-    for r in range(2):
-        b.pack_shared(r, S, gathered[r * S * 12:(r + 1) * S * 12])
-    fused = torch.zeros(S * 3, dtype=torch.float64, device=dev)
-    ctx.stitch_shared(gathered, 2, S, fused)
-    ctx.synchronize()
-    g = gathered.cpu().numpy()
-    for r in range(2):
-        lms = b.state(r)[1]
-        assert np.array_equal(g.reshape(2, S, 12)[r, :, :3], lms[:S])          # positions of the first S optimised landmarks
-        assert np.all(g.reshape(2, S, 12)[r, :, 6] > 0)                           # H_ff diagonal from the last linearisation
-    exp = fuse_numpy(g, 2, S)
-    assert np.allclose(fused.cpu().numpy().reshape(S, 3), exp, rtol=1e-9, atol=1e-9)
-    b.close()

@@ -1,0 +1,101 @@
+"""GPU: the shared-landmark exchange of BASELINE configs[4] with its real meaning.  Two config-3-shaped submaps observe 24
+landmarks of one identity each (tests/synth_lm.make_shared_submaps); neither window optimises them.  One exchange round = both
+windows' LM solves, ssk_lm_batch_pack_shared (every window's g / H blocks of the shared landmarks at its solved state), the all-gather
+(here: the two windows of one batch laid out rank-major), ssk_lm_stitch_shared (rank-ordered sums, Gauss-Newton step of the landmarks),
+ssk_lm_batch_set_shared.  Checked:
+  * the packed blocks and the update against the numpy restatement tests/shared_ref.py,
+  * the rounds converge -- block-coordinate descent on the joint problem -- to the JOINT single-process solve of the union (the
+    CPU oracle on tests/synth_lm.join_windows): edge poses, private and shared landmarks within 1e-6."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import shared_ref as sr
+import synth_lm as sl
+
+pytestmark = pytest.mark.gpu
+
+
+def to_capi(prm):
+    from ssk_amd import capi
+    out = capi.LmParams()
+    C.memmove(C.byref(out), C.byref(prm), C.sizeof(out))
+    return out
+
+
+def test_exchange_rounds_converge_to_the_joint_solve(ctx, oracle):
+    import torch
+    from ssk_amd import capi
+    S = 24
+    wins, idxs, sh = sl.make_shared_submaps(n_sub=2, n_shared=S, seed0=50, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60, opt_depth=2)
+    assert all(int((i >= 0).sum()) == S for i in idxs) and all(w.E >= 3 for w in wins)
+    prm = sl.make_params(max_iters=50, conv=1e-14)
+    joint, e_off, lm_map, sj = sl.join_windows(wins, idxs)
+    J = oracle.lm_solve(joint, prm, trace=False)
+    assert J["res"].err_final < 0.02 * J["res"].err_init
+    dev = torch.device("cuda:0")
+    b = capi.LmBatch(ctx, wins)
+    cp = to_capi(prm)
+    d_idx = [torch.from_numpy(i.astype(np.int32)).to(dev) for i in idxs]
+    gathered = torch.zeros(2 * S * 12, dtype=torch.float64, device=dev)
+    pos = torch.from_numpy(sh["init"].reshape(-1).copy()).to(dev)
+    errs = []
+    for rnd in range(70):
+        b.run(cp)                                           # (continues from the state of the previous round)
+        res = b.results()
+        errs.append(sum(r.err_final for r in res))
+        for r in range(2):
+            b.pack_shared(r, d_idx[r], cp, gathered[r * S * 12:(r + 1) * S * 12])
+        if rnd == 0:                                        # the device blocks and the update against the numpy restatement
+            ctx.synchronize()
+            g = gathered.cpu().numpy().reshape(2, S, 12)
+            for r in range(2):
+                p_r, l_r = b.state(r)
+                exp = sr.blocks(wins[r], prm, p_r, l_r, idxs[r])
+                assert np.allclose(g[r], exp, rtol=1e-9, atol=1e-9 * np.abs(exp).max()), r
+                assert np.all(g[r][:, 6] > 0) and np.all(g[r][:, 9] > 0) and np.all(g[r][:, 11] > 0)
+            exp_pos = sr.consensus(g, sh["init"])
+        ctx.stitch_shared(gathered, 2, S, pos)
+        if rnd == 0:
+            ctx.synchronize()
+            assert np.allclose(pos.cpu().numpy().reshape(S, 3), exp_pos, rtol=1e-10, atol=1e-12)
+        for r in range(2):
+            b.set_shared(r, d_idx[r], pos)
+    ctx.synchronize()
+    assert errs[-1] < errs[0] and abs(errs[-1] - J["res"].err_final) <= 1e-9 * J["res"].err_final, (errs[0], errs[-1], J["res"].err_final)
+    shared = pos.cpu().numpy().reshape(S, 3)
+    assert np.abs(shared - J["lms"][sj]).max() <= 1e-6
+    for r in range(2):
+        p_r, l_r = b.state(r)
+        assert np.abs(p_r - J["poses"][e_off[r]:e_off[r] + len(p_r)]).max() <= 1e-6, r
+        ref = J["lms"][lm_map[r]]                           # 1e-6 RELATIVE: a landmark 40 m away is known to its depth's share of that
+        assert (np.abs(l_r - ref) <= 1e-6 * np.maximum(1.0, np.linalg.norm(ref, axis=1))[:, None]).all(), r
+        assert np.array_equal(l_r[idxs[r]], shared)         # every window holds the consensus positions
+    # ssk_lm_batch_reset keeps the consensus positions (they are part of the initial state now)
+    b.reset()
+    assert np.array_equal(b.state(0)[1][idxs[0]], shared)
+    b.close()
+
+
+def test_pack_of_a_landmark_nobody_observes_and_bad_arguments(ctx):
+    import torch
+    from ssk_amd import capi
+    wins, idxs, sh = sl.make_shared_submaps(n_sub=2, n_shared=8, seed0=60, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60, opt_depth=2)
+    b = capi.LmBatch(ctx, wins[:1])
+    dev = torch.device("cuda:0")
+    idx = idxs[0].astype(np.int32).copy()
+    idx[3] = -1                                             # not in this window: a zero block, and the stitch leaves it where it is
+    d_idx = torch.from_numpy(idx).to(dev)
+    out = torch.full((8 * 12,), 7.0, dtype=torch.float64, device=dev)
+    b.pack_shared(0, d_idx, to_capi(sl.make_params()), out)
+    pos = torch.from_numpy(sh["init"].reshape(-1).copy()).to(dev)
+    ctx.stitch_shared(out, 1, 8, pos)
+    ctx.synchronize()
+    o = out.cpu().numpy().reshape(8, 12)
+    assert np.all(o[3] == 0) and np.all(o[[0, 1, 2, 4, 5, 6, 7], 6] > 0)
+    p = pos.cpu().numpy().reshape(8, 3)
+    assert np.array_equal(p[3], sh["init"][3]) and not np.array_equal(p[0], sh["init"][0])
+    with pytest.raises(capi.SskError):
+        b.pack_shared(1, d_idx, to_capi(sl.make_params()), out)       # no such window
+    b.close()
