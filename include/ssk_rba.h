@@ -32,7 +32,8 @@ typedef struct ssk_rba_options {
 	int32_t max_tree_depth, max_optimize_depth, submap_size;
 	int32_t min_obs_to_loop_closure;       /* SRBA's default 6 (never set by the reference, SRBA.h:166) */
 	int32_t use_robust_kernel, use_robust_kernel_stage1;
-	int32_t reserved;
+	int32_t reserved;                      /* flags.  bit 0: an extra edge to a far local-map centre starts from the previous edge's value, SRBA.h:294
+	                                        * as written (default 0: from the composed current estimates -- the literal value diverges) */
 	double kernel_param;
 } ssk_rba_options;
 
@@ -61,6 +62,10 @@ int ssk_rba_define_kf(ssk_rba* r, const ssk_rba_obs* obs, int n_obs, int run_loc
 int ssk_rba_num_keyframes(const ssk_rba* r);
 int ssk_rba_num_edges(const ssk_rba* r);
 int ssk_rba_num_landmarks(const ssk_rba* r);
+/* the local-map bookkeeping of mySRBA::edge_creation_policy (SRBA.h:67-68, 100-108): the centres keyframe `kf` belongs to, ascending
+ * (the last one is getLocalmapCenterID), and the keyframes of the local map centred at `center` (*n = -1 when it is not a centre) */
+int ssk_rba_localmap_centers(const ssk_rba* r, int kf, int32_t* out, int cap, int32_t* n);
+int ssk_rba_localmap_kfs(const ssk_rba* r, int center, int32_t* out, int cap, int32_t* n);
 /* k2k edge: inv_pose = pose of keyframe `from` seen from keyframe `to` */
 int ssk_rba_get_edge(const ssk_rba* r, int edge, int32_t* from, int32_t* to, double inv_pose[12]);
 /* SSK_ERR_BAD_ARG when the id is unknown */

@@ -49,7 +49,8 @@ int ssk_slam_create(ssk_ctx* ctx, const char* preset, int width, int height, ssk
 void ssk_slam_destroy(ssk_slam* s);
 const char* ssk_slam_last_error(const ssk_slam* s);
 /* before the first frame.  keys: submap_size max_tree_depth max_optimize_depth lc_distance max_translation max_rotation
- * updated_matches_th up_matches_th_plus vo_id_tracking_th n_feats detect_fast_th residual_th use_initial_pose */
+ * updated_matches_th up_matches_th_plus vo_id_tracking_th n_feats detect_fast_th residual_th use_initial_pose
+ * literal_lc_edge_init (1 = SRBA.h:294 as written; default 0: the literal value diverges) */
 int ssk_slam_set_option(ssk_slam* s, const char* key, double value);
 /* before the first frame: general_options.debug = true, out_dir = dir ([APP_OPTIONS] debug / out_dir, KITTI.ini:71-72): every inserted
  * keyframe writes info_kf%04d.txt / info_feats_kf%04d.txt (KF.cpp:60-110) and da_info_%04d.txt (EST.cpp:751-763) there */

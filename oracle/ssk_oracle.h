@@ -153,4 +153,16 @@ int ssko_pg_optimize(int n_nodes, double* X, int n_edges, const int32_t* edge_ij
 #ifdef __cplusplus
 }
 #endif
+/* ---- oracle_edge_policy.c: mySRBA::edge_creation_policy, SRBA.h:144-308 ---- */
+typedef struct ssko_ecp ssko_ecp;
+ssko_ecp* ssko_ecp_create(int submap_size, int min_obs_to_loop_closure, int max_tree_depth, int max_optimize_depth);
+void ssko_ecp_destroy(ssko_ecp* s);
+void ssko_ecp_set_initial_kf_pose(ssko_ecp* s, const double* pose12);
+void ssko_ecp_set_edge_pose(ssko_ecp* s, int e, const double* pose12);
+int ssko_ecp_num_edges(const ssko_ecp* s);
+int ssko_ecp_get_edge(const ssko_ecp* s, int e, int* from, int* to, double* pose12);
+int ssko_ecp_kf_centers(const ssko_ecp* s, int kf, int* out8);
+int ssko_ecp_localmap_kfs(const ssko_ecp* s, int center, int* out64);
+int ssko_ecp_define_kf(ssko_ecp* s, const uint64_t* feat_ids, int n_obs);
+
 #endif

@@ -427,6 +427,17 @@ class Rba:
     def counts(self):
         return self.lib.ssk_rba_num_keyframes(self.h_), self.lib.ssk_rba_num_edges(self.h_), self.lib.ssk_rba_num_landmarks(self.h_)
 
+    def localmap_centers(self, kf):
+        out = np.zeros(16, np.int32); n = C.c_int32()
+        self._chk(self.lib.ssk_rba_localmap_centers(self.h_, int(kf), _ptr(out), 16, C.byref(n)))
+        return [int(v) for v in out[:n.value]]
+
+    def localmap_kfs(self, center):
+        """keyframes of the local map centred at `center`, or None when it is not a centre."""
+        out = np.zeros(256, np.int32); n = C.c_int32()
+        self._chk(self.lib.ssk_rba_localmap_kfs(self.h_, int(center), _ptr(out), 256, C.byref(n)))
+        return None if n.value < 0 else [int(v) for v in out[:n.value]]
+
     def edge(self, e):
         f, t = C.c_int32(), C.c_int32()
         p = np.zeros(12)

@@ -20,6 +20,7 @@ mySRBA::mySRBA(Context& ctx, const TSRBAStereoSLAMOptions& o) : m_ctx(ctx), m_op
 	parameters.max_optimize_depth = o.srba_max_optimize_depth;
 	parameters.submap_size = o.srba_submap_size;
 	parameters.std_noise_observations = 0.5;
+	parameters.literal_lc_edge_init = o.srba_literal_lc_edge_init;
 }
 
 size_t mySRBA::create_kf2kf_edge(TKeyFrameID from, TKeyFrameID to)
@@ -164,9 +165,10 @@ void mySRBA::edge_creation_policy(TKeyFrameID new_kf_id, const new_kf_observatio
 					m_localmap_kf_IDs[central_kf_id].insert(new_kf_id);                                        // :293
 					// :294 as written copies the value of the previously created edge.  For the edge to the new keyframe's own local
 					// map that is a neighbouring pose; for a further edge to a far local map (a loop-closing link) it is off by the
-					// whole distance between the two maps, and the robust LM does not recover from that (measured on a 4 541-frame
-					// sequence: a pose-graph cost of 1.1e4).  Unless literal_lc_edge_init is set, such an edge starts from the
-					// composition of the current estimates along the graph (the new keyframe is already linked by its first edge).
+					// distance between the two maps, and the robust LM of this build does not recover from that (reproduction:
+					// tests/test_config3_gpu.py::test_literal_loop_closing_edge_init_diverges).  Unless literal_lc_edge_init is set, such
+					// an edge starts from the composition of the current estimates along the graph (the new keyframe is already
+					// linked by its first edge).
 					Pose3D init = nei.id == 0 ? Pose3D() : m_state.k2k_edges[nei.id - 1].inv_pose;
 					if (!parameters.literal_lc_edge_init && new_k2k_edge_ids.size() > 1) {
 						Pose3D rel;

@@ -51,7 +51,7 @@ public:
 		double kernel_param = 3.0;                                                  // EST.cpp:1152
 		double std_noise_observations = 0.5;                                        // EST.cpp:1157 (uniform: cancels in the solve)
 		bool literal_first_edge_init = true;                                        // SRBA.h:194 as written (see .cpp)
-		bool literal_lc_edge_init = false;                                          // SRBA.h:294 as written (see .cpp): off by default
+		bool literal_lc_edge_init = false;                                          // true = SRBA.h:294 as written (see .cpp: it diverges here)
 	} parameters;
 
 	// cumulative host-clock milliseconds of the four parts of every LM solve (run_lm): what an un-batched caller pays per keyframe
@@ -67,6 +67,10 @@ public:
 	size_t topo_distance(TKeyFrameID a, TKeyFrameID b, size_t max_depth) const;
 	inline bool isKFLocalmapCenter(TKeyFrameID id) const { return m_localmap_kf_IDs.count(id) != 0; }        // SRBA.h:100-102
 	inline TKeyFrameID getLocalmapCenterID(TKeyFrameID id) const { return *m_kf_localmap_center_ID.at(id).rbegin(); }   // SRBA.h:105-108
+
+	// the local-map bookkeeping of edge_creation_policy (SRBA.h:67-68), for inspection
+	const std::set<TKeyFrameID>& localmap_centers_of(TKeyFrameID id) const { return m_kf_localmap_center_ID.at(id); }
+	const std::set<TKeyFrameID>* localmap_kfs(TKeyFrameID center) const { const auto it = m_localmap_kf_IDs.find(center); return it == m_localmap_kf_IDs.end() ? nullptr : &it->second; }
 
 	// EST.cpp:166,782
 	void define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameInfo& out_new_kf_info, bool run_local_optimization);

@@ -44,6 +44,12 @@ struct TSRBAStereoSLAMOptions {                // UTIL.h:221-487
 	double srba_kernel_param = 3.0;
 	bool srba_use_robust_kernel = true, srba_use_robust_kernel_stage1 = true;
 	size_t srba_submap_size = 15, srba_max_tree_depth = 3, srba_max_optimize_depth = 3;
+	// SRBA.h:294 as written gives an extra edge to a FAR local-map centre (a loop-closing link) the value of the previously created edge
+	// as its initial pose: off by the distance between the two maps, and this build's LM does not recover from it
+	// (tests/test_config3_gpu.py::test_literal_loop_closing_edge_init_diverges: 97 % position error on the revisit sequence against
+	// 0.1 %).  false (default): start it from the composition of the current estimates along the graph.  true: as written.
+	// Not a reference parameter.
+	bool srba_literal_lc_edge_init = false;
 	// keyframe creation ([SRBA_KF_CREATION], UTIL.h:255-280,298-316)
 	size_t updated_matches_th = 50, up_matches_th_plus = 25, lc_distance = 2;
 	double max_rotation = 15., max_translation = 0.30;      // degrees, metres

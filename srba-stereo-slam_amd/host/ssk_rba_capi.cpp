@@ -39,6 +39,7 @@ int ssk_rba_create(ssk_ctx* ctx, const ssk_rba_options* o, ssk_rba** out)
 		opts.srba_submap_size = (size_t)o->submap_size;
 		opts.srba_use_robust_kernel = o->use_robust_kernel != 0; opts.srba_use_robust_kernel_stage1 = o->use_robust_kernel_stage1 != 0;
 		opts.srba_kernel_param = o->kernel_param;
+		opts.srba_literal_lc_edge_init = (o->reserved & 1) != 0;    // flags bit 0: SRBA.h:294 as written
 		r->rba.reset(new ssk::mySRBA(*r->ctx, opts));
 		if (o->min_obs_to_loop_closure > 0) r->rba->parameters.min_obs_to_loop_closure = (size_t)o->min_obs_to_loop_closure;
 	});
@@ -88,6 +89,30 @@ int ssk_rba_define_kf(ssk_rba* r, const ssk_rba_obs* obs, int n_obs, int run_loc
 int ssk_rba_num_keyframes(const ssk_rba* r) { return r ? (int)r->rba->num_keyframes() : 0; }
 int ssk_rba_num_edges(const ssk_rba* r) { return r ? (int)r->rba->get_rba_state().k2k_edges.size() : 0; }
 int ssk_rba_num_landmarks(const ssk_rba* r) { return r ? (int)r->rba->get_rba_state().unknown_lms.size() : 0; }
+
+int ssk_rba_localmap_centers(const ssk_rba* r, int kf, int32_t* out, int cap, int32_t* n)
+{
+	if (!r || !n || kf < 0 || kf >= ssk_rba_num_keyframes(r)) return SSK_ERR_BAD_ARG;
+	if (kf == 0 && ssk_rba_num_keyframes(r) == 1) { *n = 0; return SSK_OK; }      // (keyframe 0 gets its entry when keyframe 1 arrives, SRBA.h:153-158)
+	const std::set<ssk::TKeyFrameID>& c = r->rba->localmap_centers_of((size_t)kf);
+	*n = (int32_t)c.size();
+	if ((int)c.size() > cap) return SSK_ERR_CAPACITY;
+	int i = 0;
+	for (ssk::TKeyFrameID v : c) out[i++] = (int32_t)v;
+	return SSK_OK;
+}
+
+int ssk_rba_localmap_kfs(const ssk_rba* r, int center, int32_t* out, int cap, int32_t* n)
+{
+	if (!r || !n || center < 0) return SSK_ERR_BAD_ARG;
+	const std::set<ssk::TKeyFrameID>* m = r->rba->localmap_kfs((size_t)center);
+	if (!m) { *n = -1; return SSK_OK; }
+	*n = (int32_t)m->size();
+	if ((int)m->size() > cap) return SSK_ERR_CAPACITY;
+	int i = 0;
+	for (ssk::TKeyFrameID v : *m) out[i++] = (int32_t)v;
+	return SSK_OK;
+}
 
 int ssk_rba_get_edge(const ssk_rba* r, int edge, int32_t* from, int32_t* to, double inv_pose[12])
 {

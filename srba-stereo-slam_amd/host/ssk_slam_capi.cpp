@@ -79,6 +79,7 @@ int ssk_slam_set_option(ssk_slam* s, const char* key, double v)
 	else if (k == "detect_fast_th") o.detect_fast_th = (int)v;
 	else if (k == "residual_th") o.residual_th = v;
 	else if (k == "use_initial_pose") o.use_initial_pose = v != 0;
+	else if (k == "literal_lc_edge_init") o.srba_literal_lc_edge_init = v != 0;
 	else { s->err = "ssk_slam_set_option: unknown key " + k; return SSK_ERR_BAD_ARG; }
 	return SSK_OK;
 }

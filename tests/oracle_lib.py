@@ -378,6 +378,55 @@ class OracleBowDb:
         return ids[:n].copy(), sc[:n].copy()
 
 
+class OracleEdgePolicy:
+    """oracle/oracle_edge_policy.c: mySRBA::edge_creation_policy (SRBA.h:144-308) and its local-map bookkeeping."""
+
+    def __init__(self, lib, submap_size, min_obs_lc, max_tree_depth, max_optimize_depth):
+        self.lib = lib
+        lib.ssko_ecp_create.restype = C.c_void_p
+        lib.ssko_ecp_create.argtypes = [C.c_int] * 4
+        for f in ("ssko_ecp_destroy", "ssko_ecp_set_initial_kf_pose", "ssko_ecp_set_edge_pose", "ssko_ecp_num_edges", "ssko_ecp_get_edge",
+                  "ssko_ecp_kf_centers", "ssko_ecp_localmap_kfs", "ssko_ecp_define_kf"):
+            getattr(lib, f).argtypes = None
+        self.h = C.c_void_p(lib.ssko_ecp_create(submap_size, min_obs_lc, max_tree_depth, max_optimize_depth))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ssko_ecp_destroy(self.h)
+            self.h = None
+
+    def set_initial_kf_pose(self, pose):
+        p = np.ascontiguousarray(pose, np.float64).reshape(12)
+        self.lib.ssko_ecp_set_initial_kf_pose(self.h, _p(p))
+
+    def set_edge_pose(self, e, pose):
+        p = np.ascontiguousarray(pose, np.float64).reshape(12)
+        self.lib.ssko_ecp_set_edge_pose(self.h, C.c_int(e), _p(p))
+
+    def define_kf(self, feat_ids):
+        ids = np.ascontiguousarray(feat_ids, np.uint64)
+        return self.lib.ssko_ecp_define_kf(self.h, _p(ids), C.c_int(len(ids)))
+
+    def num_edges(self):
+        return self.lib.ssko_ecp_num_edges(self.h)
+
+    def edge(self, e):
+        f, t = C.c_int(), C.c_int()
+        p = np.zeros(12)
+        assert self.lib.ssko_ecp_get_edge(self.h, C.c_int(e), C.byref(f), C.byref(t), _p(p)) == 0
+        return f.value, t.value, p
+
+    def kf_centers(self, kf):
+        out = np.zeros(8, np.int32)
+        n = self.lib.ssko_ecp_kf_centers(self.h, C.c_int(kf), _p(out))
+        return [int(v) for v in out[:n]]
+
+    def localmap_kfs(self, c):
+        out = np.zeros(64, np.int32)
+        n = self.lib.ssko_ecp_localmap_kfs(self.h, C.c_int(c), _p(out))
+        return None if n < 0 else [int(v) for v in out[:n]]
+
+
 def make_kf_view(kp_left, kp_right, desc_left, desc_right, matches):
     kp_left = np.ascontiguousarray(kp_left, dtype=KEYPOINT_DTYPE)
     kp_right = np.ascontiguousarray(kp_right, dtype=KEYPOINT_DTYPE)

@@ -55,3 +55,20 @@ def test_config3_full_length_stream(pkg):
           "keyframes linked to an old local map %d; max position error %.3f m (along track %.3f m) over %.0f m; pose graph %.4g -> %.4g"
           % (N_FRAMES, o["keyframes"], o["edges"], o["frames_per_s"], o["ms_per_keyframe_frame"], len(o["loop_closures"]), o["multi_edge_kfs"],
              err.max(), along.max(), path, o["pg_cost_init"], o["pg_cost_final"]))
+
+
+def test_literal_loop_closing_edge_init_diverges(pkg):
+    """Why `literal_lc_edge_init` is NOT the default: the same 4 541-frame sequence with SRBA.h:294 as written -- an
+    extra edge from a new local-map centre to a FAR centre starts from a copy of the edge created just before, i.e. off by the
+    distance between the two maps.  The topology is identical (tests/test_edge_policy_gpu.py compares it with the literal oracle);
+    the robust LM of this build does not pull such an edge back: the keyframes of the way back end hundreds of metres from their
+    places and the pose graph starts from a cost four orders of magnitude higher.  With the default (initial value composed from the
+    current estimates along the graph) the same run is test_config3_full_length_stream above."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stream_full
+    o = stream_full.run(N_FRAMES, N_BACK, verbose=False, literal_lc_edge_init=1.0)
+    assert o["invalid_odometry"] == [] and o["multi_edge_kfs"] >= 1          # the same revisit, the same extra edges
+    X = o["poses"].reshape(-1, 3, 4)
+    along = np.abs(X[:, 1, 3] + 0.54 * np.array(o["kf_pos"]))
+    path = 0.54 * (N_FRAMES - 1)
+    assert along.max() > 0.1 * path and o["pg_cost_init"] > 1e3, (along.max(), o["pg_cost_init"])

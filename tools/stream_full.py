@@ -76,7 +76,8 @@ def run(n, n_back, seed=9, verbose=True, voc_every=None, **options):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4541
     n_back = int(sys.argv[2]) if len(sys.argv) > 2 else 160
-    o = run(n, n_back)
+    opts = dict(kv.split("=") for kv in sys.argv[3:])
+    o = run(n, n_back, **{k: float(v) for k, v in opts.items()})
     X, kp = o["poses"], np.array(o["kf_pos"])
     # robot frame: the camera's right is -y (camera_pose_on_robot, EST.cpp:1105-1112); keyframe k sits 0.54 * kf_pos[k] m to the right
     err = np.abs(X.reshape(-1, 3, 4)[:, 1, 3] + 0.54 * kp)
