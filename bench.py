@@ -231,6 +231,9 @@ def main():
     ap.add_argument("--lm-distinct", type=int, default=8,
                     help="distinct LM windows in the batch (the rest are replicas): 8 = the default line; 64 gives ragged iteration counts "
                          "(64 submaps, seeds 0..63, x16 replicas at --batch 1024)")
+    ap.add_argument("--lm-depth5", type=int, default=64,
+                    help="windows of the `lm_depth5` pass at N=1: the reference's real per-keyframe LM load (KITTI.ini:104-106: optimise depth 5 => a "
+                         "local area of ~40 edges) as stage 1 + stage 2 per keyframe, batched and one keyframe at a time; 0 = skip")
     ap.add_argument("--unbatched-frames", type=int, default=401,
                     help="frames of the un-batched pass at N=1 (the estimator's frame loop, one ssk_slam_process_frame per stereo pair: what a "
                          "user of performStereoSLAM sees; reported as `unbatched`, never as `value`; 0 = skip)")
@@ -444,6 +447,47 @@ def main():
 
     unbatched = unbatched_pass(args.unbatched_frames) if world == 1 and rank == 0 and args.unbatched_frames > 0 else None
 
+    # ---- the reference's real per-keyframe LM load (reported beside `value`): define_new_keyframe does TWO solves per keyframe
+    # (EST.cpp:782-784): stage 1 = optimize_edges on the new edge with the landmarks held, stage 2 = optimize_local_area with
+    # srba_max_optimize_depth = 5 (KITTI.ini:105): ~40 edges.  The headline's window is BASELINE configs[2]'s "window = 10".
+    def lm_depth5_pass(n):
+        wins5 = [sl.make_submap_problem(s, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=5, obs_per_kf=250, lm_fwd=(3, 20),
+                                        z_vis=(2.5, 22))[0] for s in range(4)]
+        def stage1(w):
+            newest = int(np.flatnonzero(w.edge_unknown_slot == w.E - 1)[0])
+            keep = [o for o in range(len(w.obs_lm)) if w.obs_path_off[o + 1] > w.obs_path_off[o] and (w.path_edge[w.obs_path_off[o]] >> 1) == newest]
+            off, pe = [0], []
+            for o in keep:
+                pe.extend(w.path_edge[w.obs_path_off[o]:w.obs_path_off[o + 1]]); off.append(len(pe))
+            return sl.Window(np.where(w.edge_unknown_slot == w.E - 1, 0, -1), w.edge_inv_pose, -np.ones(len(w.lm_pos), np.int32), w.lm_pos,
+                             w.obs_lm[keep], w.obs_px[keep], off, pe)
+        st1 = [stage1(w) for w in wins5]
+        out = {"window": {"stage2_edges": int(wins5[0].E), "stage2_observations": int(len(wins5[0].obs_lm)), "stage2_landmarks": int(wins5[0].L),
+                          "stage1_observations": int(len(st1[0].obs_lm))}}
+        def timed(batch_wins, reps):
+            b = capi.LmBatch(ctx, batch_wins)
+            b.run(lp); b.results()                       # warm-up (code objects, slab)
+            t = 0.0
+            for _ in range(reps):
+                b.reset(); ctx.synchronize()
+                t0 = time.perf_counter()
+                b.run(lp); r = b.results()
+                t += time.perf_counter() - t0
+            assert all(x.stop_reason != 5 and x.err_final <= x.err_init for x in r)
+            it = float(np.mean([x.iters for x in r]))
+            b.close()
+            return 1e3 * t / reps, it
+        ms1, it1 = timed([st1[k % 4] for k in range(n)], 3)
+        ms2, it2 = timed([wins5[k % 4] for k in range(n)], 3)
+        out["batched"] = {"windows": n, "stage1_ms": ms1, "stage2_ms": ms2, "keyframes_per_s": n / ((ms1 + ms2) * 1e-3), "stage1_iters": it1, "stage2_iters": it2}
+        l1, _ = timed([st1[0]], 10)
+        l2, _ = timed([wins5[0]], 10)
+        out["one_keyframe"] = {"stage1_ms": l1, "stage2_ms": l2, "note": "one window per launch: stage 2 on the cooperative kernel (its tiles dealt out over up to 64 "
+                               "workgroups), host clock around ssk_lm_batch_run + results, structures already built"}
+        return out
+
+    lm_depth5 = lm_depth5_pass(args.lm_depth5) if world == 1 and rank == 0 and args.lm_depth5 > 0 else None
+
     if rank == 0:
         # PMC traffic per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary
         # committed under profiles/): bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- KB units, FETCH_SIZE doubled on gfx950
@@ -518,6 +562,7 @@ def main():
             "stage_ms_per_launch": stages,
             "pcie_inclusive": pcie,
             "unbatched": unbatched,
+            "lm_depth5": lm_depth5,
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, wins, vocab)

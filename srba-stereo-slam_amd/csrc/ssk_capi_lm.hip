@@ -991,6 +991,10 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
 	b->acc_ok = want_acc && acc_all && tiled_all; b->schur_mfma = schur_mfma;
 	D.store_hff = 0;
+	// SSK_LM_LDL=mfma (needs the matrix-core Schur form): the kernels whose L2-resident reduced systems are factorised in 16-column panels
+	// with the trailing update on the matrix cores (lm_solve_*_ldlm_kernel); default: the six-column VALU solver -- measured faster,
+	// profiles/r02_lm_ldl_mfma_vs_valu.json
+	{ const char* ldl = std::getenv("SSK_LM_LDL"); D.ldl_mfma = ldl && std::strcmp(ldl, "mfma") == 0 && schur_mfma; if (D.ldl_mfma) b->schur_mfma = 2; }
 	b->max_tiles = 0;
 	for (const lm_win& hw : b->hdr) b->max_tiles = std::max(b->max_tiles, hw.n_tiles);
 	if (!rc) rc = upload(b, pose, const_cast<const double**>(&D.pose));     // working copies of the state (pose0 / lm0 keep the initial one)

@@ -98,6 +98,7 @@ struct lm_dev {
 	const int2* suf_rec; const int* tent; const int* tsuf; double* suf_tab;
 	const int2* mt; const int* st_off; double* Stile;
 	const int* wt_off; const int* wt; const int2* tl_pan;   // acc kernel (tl_pan: per tile landmark (row-tile mask, first panel of the tile's panel array))
+	int ldl_mfma;         // reduced systems in L2 scratch: 1 = 16-column LDL^T panels with the trailing update on the FP64 matrix cores (default), 0 = 6-column VALU solver (SSK_LM_LDL=valu)
 	int store_hff;        // 1: the landmark blocks H_ff / g_f of the last linearisation go to HBM (shared-landmark exchange); 0: they stay on chip
 	double* Ppart2; double* Spart2;
 	const int* edge_slot; double* pose; const double* pose0; double* pose_new;

@@ -776,6 +776,152 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 }
 #undef SSK_PI
 
+// G for a system in L2 scratch on the FP64 MATRIX CORES: the same right-looking LDL^T (U = L' D unscaled, border row = right-hand side)
+// blocked by 16 columns.  Per panel: the panel's columns of all rows below come into LDS once (pitch 17); one wave factorises the
+// 16 x 16 diagonal block in registers (a lane per row, columns exchanged by shuffles: no workgroup barrier inside the block); a lane
+// per row eliminates the panel below it; then the trailing matrix takes its rank-16 update as 16 x 16 tiles, a wave per tile:
+// four v_mfma_f64_16x16x4_f64 with A = -(U inv) rows, B = U rows from the LDS panel, the accumulator loaded from and stored to the
+// matrix.  15 panels for a 240-unknown local area instead of 40 six-column steps, and the update -- 4.6 Mflop of the 4.7 -- runs on
+// the matrix pipe.  Back-substitution by 16-row blocks from the bottom: inside a block by one wave (shuffles), then every earlier
+// unknown takes the block's 16 terms at once (coalesced rows).  Same operations per element as the other solvers up to the order of
+// the 16 terms of an update, which the matrix core fixes (k ascending).
+// lds: the workgroup's free tile region; falls back to ldl_solve_hybrid when a panel (n + 1 rows x 17) does not fit.
+typedef double ldl_v4d_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles);
+__device__ __forceinline__ bool ldl_solve_mfma16(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
+{
+	if ((long long)(n + 1) * 17 > lds_doubles) return ldl_solve_hybrid(A, np, n, x_out, inv, lds, lds_doubles);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	__shared__ int s_ldl_bad_m;
+	double* Pn = lds;                                  // panel: rows c .. n, 16 columns, pitch 17
+	if (tid == 0) s_ldl_bad_m = 0;
+	for (int c = 0; c < n; c += 16) {
+		const int pw = n - c < 16 ? n - c : 16;
+		__syncthreads();                                   // the previous panel's update is in the matrix
+		if (s_ldl_bad_m) return false;
+		// ---- the panel's columns of rows c .. n into LDS (unused columns of a narrow last panel: zero) ----
+		for (int i = c + tid; i <= n; i += NT) {
+			double* pr = Pn + (i - c) * 17;
+#pragma unroll
+			for (int j = 0; j < 16; ++j) pr[j] = j < pw ? A[(size_t)i * np + c + (j < pw ? j : 0)] : 0.0;
+		}
+		__syncthreads();
+		// ---- diagonal block: lane r of wave 0 = row c + r; column j of the rows below it by shuffle ----
+		if (wave == 0) {
+			double x[16];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) x[k] = Pn[(lane < pw ? lane : 0) * 17 + k];
+			bool bad = false;
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				const double d = readlane_f64(x[j], j);
+				if (j < pw) bad |= !(d > 0.0);
+				const double ivj = j < pw ? rcp_f64(d) : 0.0;
+				const double t = x[j] * ivj;
+#pragma unroll
+				for (int k = j + 1; k < 16; ++k) {
+					const double akj = readlane_f64(x[j], k);       // U(c + k, c + j): a scalar broadcast
+					if (lane > j && k <= lane) x[k] -= t * akj;
+				}
+				if (lane == j && j < pw) inv[c + j] = ivj;
+			}
+			if (lane < pw) {
+				double* pr = Pn + lane * 17;
+#pragma unroll
+				for (int k = 0; k < 16; ++k) { pr[k] = x[k]; if (k <= lane && k < pw) A[(size_t)(c + lane) * np + c + k] = x[k]; }
+			}
+			if (lane == 0 && bad) s_ldl_bad_m = 1;
+		}
+		__syncthreads();
+		if (s_ldl_bad_m) return false;
+		double ivr[16];
+#pragma unroll
+		for (int j = 0; j < 16; ++j) ivr[j] = j < pw ? inv[c + j] : 0.0;
+		// ---- rows below the block: eliminate inside the panel (block entries by broadcast reads) ----
+		for (int i = c + pw + tid; i <= n; i += NT) {
+			double* pr = Pn + (i - c) * 17;
+			double x[16];
+#pragma unroll
+			for (int k = 0; k < 16; ++k) x[k] = pr[k];
+#pragma unroll
+			for (int j = 0; j < 15; ++j) {
+				const double t = x[j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k < 16; ++k) x[k] -= t * Pn[k * 17 + j];
+			}
+#pragma unroll
+			for (int k = 0; k < 16; ++k) { pr[k] = x[k]; if (k < pw) A[(size_t)i * np + c + k] = x[k]; }
+		}
+		__syncthreads();
+		// ---- trailing update: tile (a, b), b <= a, rows r0 + 16 a .., columns r0 + 16 b .., a wave per tile ----
+		const int r0 = c + pw;
+		if (r0 < n) {
+			const int nr = (n + 1 - r0 + 15) >> 4, nc = (n - r0 + 15) >> 4;
+			const int m = lane & 15, kk = lane >> 4;
+			int idx = 0;
+			for (int a = 0; a < nr; ++a)
+				for (int b = 0; b <= a && b < nc; ++b, ++idx) {
+					if (idx % NW != wave) continue;
+					const int i0 = r0 + 16 * a, k0 = r0 + 16 * b;
+					ldl_v4d_t acc;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const int row = i0 + kk + 4 * r, col = k0 + m;
+						const double v = A[(size_t)(row <= n ? row : n) * np + (col < n ? col : n - 1)];
+						acc[r] = (row <= n && col < n) ? v : 0.0;
+					}
+					const double* pa = Pn + ((i0 + m <= n ? i0 + m : n) - c) * 17;
+					const double* pb = Pn + ((k0 + m <= n ? k0 + m : n) - c) * 17;
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						// (the pivot reciprocal of column 4 q + kk straight from LDS: a lane-dependent index into a register array would go through scratch)
+						const int jc = c + 4 * q + kk;
+						const double av = -(pa[4 * q + kk] * inv[jc < n ? jc : n - 1]);
+						acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, pb[4 * q + kk], acc, 0, 0, 0);
+					}
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const int row = i0 + kk + 4 * r, col = k0 + m;
+						if (row <= n && col < n && col <= row) A[(size_t)row * np + col] = acc[r];
+					}
+				}
+		}
+	}
+	__syncthreads();
+	if (s_ldl_bad_m) return false;
+	// ---- back-substitution: x = D^-1 z, then L'^T x: 16-row blocks from the bottom ----
+	for (int k = tid; k < n; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
+	__syncthreads();
+	for (int c = ((n - 1) >> 4) << 4; c >= 0; c -= 16) {
+		const int pw = n - c < 16 ? n - c : 16;
+		if (wave == 0) {
+			// lane k (< pw): column c + k of the block's rows, scaled; x of the block from the last row up
+			const int k = lane < pw ? lane : 0;
+			double u[16];
+			const double ivk = inv[c + k];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) u[i] = (i < pw && i > k) ? A[(size_t)(c + i) * np + c + k] * ivk : 0.0;
+			double xv = x_out[c + k];
+#pragma unroll
+			for (int i = 15; i >= 1; --i) {
+				const double xi = readlane_f64(xv, i);
+				if (i < pw) xv -= u[i] * xi;                    // (u[i] = 0 for k >= i)
+			}
+			if (lane < pw) x_out[c + lane] = xv;
+		}
+		__syncthreads();
+		for (int k = tid; k < c; k += NT) {
+			const double ivk = inv[k];
+			double sacc = 0.0;
+#pragma unroll
+			for (int i = 0; i < 16; ++i) sacc += i < pw ? A[(size_t)(c + (i < pw ? i : 0)) * np + k] * x_out[c + (i < pw ? i : 0)] : 0.0;
+			x_out[k] -= sacc * ivk;
+		}
+		__syncthreads();
+	}
+	return true;
+}
+
 // G (fallback): the same factorisation by the whole workgroup on an L2-resident matrix (6E too large for LDS)
 __device__ bool chol_solve_block(double* A, int n, double* b, int* s_flag, double* s_piv)
 {

@@ -844,7 +844,7 @@ __device__ unsigned long long g_f2g[4];
 #endif
 // `solve` = false: only the share (first, step) of the assembly (cooperative kernel: the workgroups of a window assemble the
 // L2-resident system together, workgroup 0 then factorises it with `assemble` = false)
-template <bool GLOBAL_A, bool SMF = false, typename PtrA>
+template <bool GLOBAL_A, bool SMF = false, bool LDLM = false, typename PtrA>
 __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win& W, const double* __restrict__ Pp, const double* __restrict__ Sp,
                                                    double lambda, PtrA A, int np, int n6, double* s_b, double* s_inv,
                                                    bool assemble = true, bool solve = true, int first = threadIdx.x, int step = NT,
@@ -896,7 +896,11 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 	if (!solve) return true;
 	bool ok_ = true;
 	if (n6 > 0) {
-		if constexpr (GLOBAL_A) ok_ = ldl_solve_hybrid(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
+		if constexpr (GLOBAL_A) {
+			// LDLM (kernels lm_solve_*_ldlm_kernel, SSK_LM_LDL=mfma): 16-column panels with the trailing update on the matrix cores
+			if constexpr (LDLM) ok_ = ldl_solve_mfma16(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
+			else ok_ = ldl_solve_hybrid(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
+		}
 		else ok_ = ldl_solve_lds(A, np, n6, s_b, s_inv);
 	}
 	F2G_TICK(2);
@@ -905,7 +909,7 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 
 // ACC: 0 = partial slots in HBM, 1 = on-chip accumulation with sparse Schur items, 2 = on-chip accumulation with the Schur
 // complement on the matrix cores
-template <bool COOP, int ACC = 0, bool SMF = false>
+template <bool COOP, int ACC = 0, bool SMF = false, bool LDLM = false>
 __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, int dyn_doubles, int G, int coop_expect = 1, int coop_spin_limit = COOP_SPIN_LIMIT)
 {
 	static_assert(!(COOP && ACC), "the accumulators of a window live in one workgroup's LDS");
@@ -1050,7 +1054,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			if (n6 > 0) ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
 		} else if (g == 0) {
 			ok = lds_mat ? assemble_and_solve<false, SMF>(D, W, Pp, Sp, lambda, reg, np, n6, s_b, s_inv)
-			             : assemble_and_solve<true, SMF>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, !share_f2, true, tid, NT,
+			             : assemble_and_solve<true, SMF, LDLM>(D, W, Pp, Sp, lambda, D.Hred + W.h0, np, n6, s_b, s_inv, !share_f2, true, tid, NT,
 			                                  reg, dyn_doubles - (int)(reg - s_dyn));
 			if (COOP) {
 				if (ok) for (int i = tid; i < n6; i += NT) D.dp[6 * (size_t)W.us0 + i] = s_b[i];
@@ -1220,6 +1224,17 @@ void lm_solve_coop_mfma_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G, int e
 {
 	lm_tiled_body<true, 0, true>(D, P, dyn_doubles, G, expect, spin_limit);
 }
+// ... and the factorisation of an L2-resident reduced system in 16-column panels on the matrix cores (SSK_LM_LDL=mfma)
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_tiled_ldlm_kernel(lm_dev D, lm_cam P, int dyn_doubles)
+{
+	lm_tiled_body<false, 0, true, true>(D, P, dyn_doubles, 1);
+}
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_coop_ldlm_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G, int expect, int spin_limit)
+{
+	lm_tiled_body<true, 0, true, true>(D, P, dyn_doubles, G, expect, spin_limit);
+}
 
 // on-chip accumulation (E <= SSK_LMA_MAX_E): Schur complement by sparse 6x6 items / on the FP64 matrix cores
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
@@ -1247,7 +1262,8 @@ void lm_solve_coop_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G, int expect
 int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes, int schur_mfma)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
-	const void* fn = schur_mfma ? reinterpret_cast<const void*>(lm_solve_coop_mfma_kernel) : reinterpret_cast<const void*>(lm_solve_coop_kernel);
+	const void* fn = schur_mfma == 2 ? reinterpret_cast<const void*>(lm_solve_coop_ldlm_kernel)
+	               : schur_mfma ? reinterpret_cast<const void*>(lm_solve_coop_mfma_kernel) : reinterpret_cast<const void*>(lm_solve_coop_kernel);
 	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC);
 	int n = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, NT, dyn_lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -1263,13 +1279,17 @@ int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_win
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_ldlm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		attr_set = true;
 	}
 	SSK_HIP(ctx, hipMemsetAsync(D.coop_i, 0, sizeof(int) * 4 * (size_t)n_windows, ctx->stream));
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	// test_timeout (SSK_LM_COOP_TEST_TIMEOUT=1): every barrier waits for an arrival that never comes and gives up quickly, the
 	// path a workgroup takes when a co-tenant of the GPU keeps one of its partners from being scheduled
-	if (schur_mfma) hipLaunchKernelGGL(lm_solve_coop_mfma_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
+	if (schur_mfma == 2) hipLaunchKernelGGL(lm_solve_coop_ldlm_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
+	                                        test_timeout ? G + 1 : G, test_timeout ? 1 << 10 : COOP_SPIN_LIMIT);
+	else if (schur_mfma) hipLaunchKernelGGL(lm_solve_coop_mfma_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
 	                                   test_timeout ? G + 1 : G, test_timeout ? 1 << 10 : COOP_SPIN_LIMIT);
 	else hipLaunchKernelGGL(lm_solve_coop_kernel, dim3(n_windows * G), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8), G,
 	                        test_timeout ? G + 1 : G, test_timeout ? 1 << 10 : COOP_SPIN_LIMIT);
@@ -1302,10 +1322,13 @@ int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_wi
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_ldlm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		attr_set = true;
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
-	if (schur_mfma) hipLaunchKernelGGL(lm_solve_tiled_mfma_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
+	if (schur_mfma == 2) hipLaunchKernelGGL(lm_solve_tiled_ldlm_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
+	else if (schur_mfma) hipLaunchKernelGGL(lm_solve_tiled_mfma_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
 	else hipLaunchKernelGGL(lm_solve_tiled_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
 	SSK_LAUNCH_CHECK(ctx, "lm_solve_tiled_kernel");
 	return SSK_OK;
