@@ -537,7 +537,7 @@ __device__ unsigned long long g_tst[8];
 // workgroup's tile region in LDS; `tab`: the path-suffix table at that state;
 // partial sums go to the window's slot arrays Pp / Sp, Y / gradient terms / landmark factors to its HBM scratch.
 template <bool MFMA>
-__device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab,
+__device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab_l, const double* __restrict__ gtab,
                                              double* reg, double lambda, bool pre, bool same_state,
                                              double* __restrict__ Pp, double* __restrict__ Sp, double& vmax)
 {
@@ -545,15 +545,16 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 #ifdef SSK_LM_STAMPS
 		unsigned long long tst_last = __builtin_amdgcn_s_memtime();
 #endif
-		// a window with many suffixes: this tile's part of the table (built in L2 scratch) comes into LDS first, ids in the records are tile-local
+		// a window with many suffixes: this tile's part of the table (built in L2 scratch) comes into LDS first, ids in the records are
+		// tile-local.  Either way `tab` is an LDS pointer (a pointer that might be global would turn every table read into a FLAT load)
+		double* lt = reg;
 		if (!W.tab_lds) {
-			double* lt = reg;
 			const int* ids = D.tsuf + W.tsuf0 + T.tsuf0;
-			for (int i = tid; i < 12 * T.n_tsuf; i += NT) { const int k = i / 12; lt[i] = tab[12 * (size_t)ids[k] + (i - 12 * k)]; }
+			for (int i = tid; i < 12 * T.n_tsuf; i += NT) { const int k = i / 12; lt[i] = gtab[12 * (size_t)ids[k] + (i - 12 * k)]; }
 			reg += 12 * T.n_tsuf;
-			tab = lt;
 			__syncthreads();
 		}
+		const double* tab = W.tab_lds ? tab_l : lt;
 		double* ent = reg;
 		double* obsr = ent + ENT_P * T.n_ent;
 		double* Yr = obsr + OBS_P * T.n_obs;               // sparse: Y_P per incidence; matrix cores: SSK_LMA_PANEL per panel
@@ -681,19 +682,19 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 // One tile with on-chip accumulation.  Region: [entries | observation records | Y (records or panels) | landmark records |
 // gradient terms (7 per incidence: 6 values + edge slot)].
 template <bool MFMA>
-__device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab,
+__device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab_l, const double* __restrict__ gtab,
                                                  double* reg, double lambda, bool pre, bool same_state,
                                                  double* __restrict__ P_acc, double* __restrict__ S_acc, double* __restrict__ g_acc, double& vmax)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	if (!W.tab_lds) {                                      // (as process_tile)
-		double* lt = reg;
+	double* lt = reg;                                      // (as process_tile)
+	if (!W.tab_lds) {
 		const int* ids = D.tsuf + W.tsuf0 + T.tsuf0;
-		for (int i = tid; i < 12 * T.n_tsuf; i += NT) { const int k = i / 12; lt[i] = tab[12 * (size_t)ids[k] + (i - 12 * k)]; }
+		for (int i = tid; i < 12 * T.n_tsuf; i += NT) { const int k = i / 12; lt[i] = gtab[12 * (size_t)ids[k] + (i - 12 * k)]; }
 		reg += 12 * T.n_tsuf;
-		tab = lt;
 		__syncthreads();
 	}
+	const double* tab = W.tab_lds ? tab_l : lt;
 	double* ent = reg;
 	double* obsr = ent + ENT_P * T.n_ent;
 	double* Yr = obsr + OBS_P * T.n_obs;                   // sparse: Y_P per incidence; MFMA: SSK_LMA_PANEL per panel
@@ -940,7 +941,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	double* tab_l = ACC ? g_acc + n6p : s_inv + n6p;
 	int2* recs_l = reinterpret_cast<int2*>(tab_l + (W.tab_lds ? 12 * W.n_suf : 0));
 	double* reg = tab_l + (W.tab_lds ? 13 * W.n_suf : 0);
-	double* tab = W.tab_lds ? tab_l : D.suf_tab + W.gtab0 + 12 * (size_t)W.n_suf * g;
+	double* gtab = D.suf_tab + W.gtab0 + (W.tab_lds ? 0 : 12 * (size_t)W.n_suf * g);
 	// the reduced system lives over the dead tile records when (n6 + 1) x (n6 | 1) doubles fit there (E <= ~22),
 	// otherwise in the window's L2-resident scratch (same blocked factorisation through plain pointers)
 	const bool lds_mat = (long long)(n6 + 1) * (n6 | 1) <= (long long)dyn_doubles - (reg - s_dyn);
@@ -968,8 +969,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	for (int i = tid + NT * g; i < 3 * W.n_lms; i += NT * GG) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
 	__syncthreads();
 	if (W.tab_lds) for (int i = tid; i < W.n_suf; i += NT) recs_l[i] = D.suf_rec[W.suf0 + i];      // (the build's first barrier covers it)
-	if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, tab, D.suf_rec + W.suf0);
-	double e0 = total_error_packed(D, W, P, tab, D.lm, s_part, tid + NT * g, NT * GG);
+	if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
+	double e0 = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm, s_part, tid + NT * g, NT * GG) : total_error_packed(D, W, P, gtab, D.lm, s_part, tid + NT * g, NT * GG);
 	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
 		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_same = 0;
@@ -997,7 +998,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		const int it_idx = s_iters;
 		double vmax = 0.0;
 		// (the scoring of the previous attempt left the trial state's table here)
-		if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, tab, D.suf_rec + W.suf0);
+		if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
 		STAMP(0);
 		if (ACC) {                                     // the accumulators of this pass start from zero (H_pp: unless the state has not moved)
 			for (int i = tid; i < n_accS + n6p; i += NT) S_acc[i] = 0.0;
@@ -1005,8 +1006,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			__syncthreads();
 		}
 		for (int t = g; t < W.n_tiles; t += GG) {
-			if (ACC) process_tile_acc<ACC == 2>(D, W, P, D.tile[W.tile0 + t], tab, reg, lambda, pre, same_state, P_acc, S_acc, g_acc, vmax);
-			else process_tile<SMF>(D, W, P, D.tile[W.tile0 + t], tab, reg, lambda, pre, same_state, Pp, Sp, vmax);
+			if (ACC) process_tile_acc<ACC == 2>(D, W, P, D.tile[W.tile0 + t], tab_l, gtab, reg, lambda, pre, same_state, P_acc, S_acc, g_acc, vmax);
+			else process_tile<SMF>(D, W, P, D.tile[W.tile0 + t], tab_l, gtab, reg, lambda, pre, same_state, Pp, Sp, vmax);
 			STAMP(1);
 		}
 		if (COOP) {                                    // every workgroup's slots, Y, gradient terms and landmark factors are out
@@ -1135,15 +1136,16 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		if (COOP && ok) {                              // every workgroup's landmark steps are out
 			__syncthreads();                           // (pose_new of this workgroup complete)
 			alive = coop_barrier(co);
-			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, tab, D.suf_rec + W.suf0);
-			const double part = total_error_packed(D, W, P, tab, D.lm_new, s_part, tid + NT * g, NT * GG);
+			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
+			const double part = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm_new, s_part, tid + NT * g, NT * GG)
+			                              : total_error_packed(D, W, P, gtab, D.lm_new, s_part, tid + NT * g, NT * GG);
 			err_new = coop_combine<false>(co, part, alive);
 			if (!alive) continue;
 		}
 		if (!COOP && ok) {
 			__syncthreads();                               // (pose_new complete)
-			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, tab, D.suf_rec + W.suf0);
-			err_new = total_error_packed(D, W, P, tab, D.lm_new, s_part, tid, NT);
+			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
+			err_new = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm_new, s_part, tid, NT) : total_error_packed(D, W, P, gtab, D.lm_new, s_part, tid, NT);
 		}
 		__syncthreads();
 		if (tid == 0) {
