@@ -919,6 +919,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	__shared__ double s_lambda, s_nu, s_err;
 	__shared__ int s_accept, s_stop, s_iters, s_accepted;
 	__shared__ int s_same;                             // the state has not moved since the previous pass's linearisation
+	__shared__ int s_tabcur;                           // the suffix table in place is the current state's (an accepted step's scoring left exactly that)
 
 	const int wi = COOP ? (int)blockIdx.x / G : (int)blockIdx.x, g = COOP ? (int)blockIdx.x % G : 0, GG = COOP ? G : 1;
 	const lm_win W = D.win[wi];
@@ -973,7 +974,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	double e0 = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm, s_part, tid + NT * g, NT * GG) : total_error_packed(D, W, P, gtab, D.lm, s_part, tid + NT * g, NT * GG);
 	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
-		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_same = 0;
+		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_same = 0; s_tabcur = 1;
 		if (g == 0) {
 			ssk_lm_result& R = D.res[wi];
 			R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
@@ -997,8 +998,11 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		const bool same_state = !pre && s_same != 0;   // (uniform)
 		const int it_idx = s_iters;
 		double vmax = 0.0;
-		// (the scoring of the previous attempt left the trial state's table here)
-		if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
+		// the scoring of a REJECTED attempt left the trial state's table here; an accepted one's is the new current state's own
+		if (!s_tabcur) {                                   // (uniform)
+			if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
+			if (tid == 0) s_tabcur = 1;
+		}
 		STAMP(0);
 		if (ACC) {                                     // the accumulators of this pass start from zero (H_pp: unless the state has not moved)
 			for (int i = tid; i < n_accS + n6p; i += NT) S_acc[i] = 0.0;
@@ -1158,6 +1162,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			const int converged = ok && P.conv_rel > 0 && fabs(s_err - err_new) <= P.conv_rel * s_err;
 			s_accept = accepted;
 			s_same = !accepted;
+			if (ok) s_tabcur = accepted;
 			s_iters = it_idx + 1;
 			if (accepted) {
 				s_err = err_new; s_lambda = lambda * 0.1; s_nu = 2.0; s_accepted += 1;
