@@ -376,6 +376,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	std::vector<int2> pgrp, sgrp, tl_pan, suf_rec;
 	std::vector<int> wt_off, wt, tent, tsuf, st_off;
 	std::vector<int2> mt;
+	std::vector<int4> ilane;
 	long long gtab_total = 0, n_stile_total = 0;
 	bool acc_all = want_acc;
 	size_t n_pslots_total = 0, n_sslots_total = 0, tiled_dyn = 0;
@@ -519,6 +520,8 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		std::vector<int2> w_pgrp, w_sgrp, w_tl_pan;
 		std::vector<int> w_wt_off, w_wt, w_tent, w_tsuf;
 		std::vector<int2> w_mt;                                // (I | J << 8, partial id in generation order -> final id below)
+		std::vector<int4> w_ilane;                             // incidence lanes, tile by tile
+		auto inc_lanes = [](int cnt) { const int ns = (cnt + SSK_LMT_INC_CAP - 1) / SSK_LMT_INC_CAP; return ns < 1 ? 1 : (ns > 8 ? 8 : ns); };
 		std::vector<std::vector<int>> stile_of;                // per upper 16x16 tile u = J (J + 1) / 2 + I: its partials, tile order
 		// ---- path-suffix trie: suffix k of a path = (c_k .. c_{n-1}); a suffix is (first step, shorter suffix), 0 = the empty one ----
 		std::vector<int2> w_suf(1, make_int2(-1, -1));
@@ -653,17 +656,23 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			int lme_cursor = 0;
 			while (oi < order.size() && tiled) {
 				lm_tile T{};
-				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_a.size(); T.inc0 = lme_cursor; T.ent0 = (int)w_tent.size();
-				long long nP = 0, nO = 0, nM = 0, nL = 0, nY = 0, var = 0, nS = 0;
+				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_a.size(); T.inc0 = lme_cursor; T.ent0 = (int)w_tent.size(); T.il0 = (int)w_ilane.size();
+				long long nP = 0, nO = 0, nM = 0, nL = 0, nY = 0, var = 0, nS = 0, nIL = 0;
 				const int tile_no = (int)w_tiles.size();
 				size_t oj = oi;
 				for (; oj < order.size(); ++oj) {
 					long long aS = nS;
 					if (!tab_lds) for (int sid : lm_sufs[oj]) if (suf_tile[sid] != tile_no) aS += 12;       // the tile's table copy grows with every new suffix
 					const long long aP = nP + fp_P[oj], aO = nO + fp_O[oj], aM = nM + fp_M[oj], aL = nL + 1, aY = nY + fp_Y[oj] + (aS - nS);
+					long long aIL = nIL;                           // incidence lanes: the lanes of one incidence stay inside one wavefront
+					for (int m : lm_lmes[oj]) {
+						const int ns = inc_lanes(w_lmep_off[m + 1] - w_lmep_off[m]);
+						if ((aIL & 63) + ns > 64) aIL = (aIL + 63) & ~63LL;
+						aIL += ns;
+					}
 					// one round of lanes per phase: observations, landmarks, incidences each within the workgroup size
-					if (tile_bytes(aP, aO, aY, aL) > region_bytes || aM > SSK_LMT_NT || aL > SSK_LMT_NT || aO > SSK_LMT_NT || aP > 65535 || (panels && aL > 128)) break;
-					nP = aP; nO = aO; nM = aM; nL = aL; nY = aY; nS = aS;
+					if (tile_bytes(aP, aO, aY, aL) > region_bytes || aIL > SSK_LMT_NT || aL > SSK_LMT_NT || aO > SSK_LMT_NT || aP > 65535 || (panels && aL > 128)) break;
+					nP = aP; nO = aO; nM = aM; nL = aL; nY = aY; nS = aS; nIL = aIL;
 					if (!tab_lds) for (int sid : lm_sufs[oj]) suf_tile[sid] = tile_no;
 					var += 8 * (SSK_LMT_ENT * fp_P[oj] + SSK_LMT_OBS * fp_O[oj] + fp_Y[oj] + SSK_LMT_LMR);
 					if (var >= target) { ++oj; break; }
@@ -712,6 +721,16 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 						const int cnt = w_lmep_off[m + 1] - w_lmep_off[m];
 						w_inc_rec[m] = make_int4(j | ((Wn.lm_unknown_slot[l] >= 0 ? 1 : 0) << 15) | (cnt << 16), w_lmep_off[m], 0 /* edge-major slot: below */,
 						                         cnt > 0 ? w_lmep_loc[w_lmep_off[m]] : 0);
+						// the incidence's lanes: its path entries dealt out SSK_LMT_INC_CAP at a time (a tile phase lasts as long as its longest
+						// lane: 84 % of the incidences have one entry, the tail has ten and more), all lanes of one incidence in one wavefront
+						const int ns = inc_lanes(cnt), per = (cnt + ns - 1) / ns;
+						int pos = (int)w_ilane.size() - T.il0;
+						if ((pos & 63) + ns > 64)
+							for (; pos & 63; ++pos) w_ilane.push_back(make_int4(0, 0, 0, 0));       // (padding: lanes of no incidence)
+						for (int sub = 0; sub < ns; ++sub) {
+							const int k0 = std::min(cnt, sub * per), k1 = std::min(cnt, k0 + per);
+							w_ilane.push_back(make_int4((m - T.inc0) | (sub << 16) | (ns << 20), w_lmep_off[m] + k0, k1 - k0, k1 > k0 ? w_lmep_loc[w_lmep_off[m] + k0] : 0));
+						}
 					}
 					if (Wn.lm_unknown_slot[l] >= 0)
 						for (size_t a = 0; a < lm_lmes[ok].size(); ++a)
@@ -721,6 +740,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					lme_cursor += (int)lm_lmes[ok].size();
 				}
 				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_a.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0; T.n_pan = panels ? n_pan : 0;
+				T.n_il = (int)w_ilane.size() - T.il0;
 				T.pg0 = (int)w_pgrp.size(); T.pc0 = (int)w_pslot0.size();
 				// one chunk task per wave: the smallest R whose H_pp + Schur chunks fit one round of the workgroup's waves
 				auto by_pid = [](const item& a, const item& b) { return a.pid < b.pid; };
@@ -862,6 +882,8 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		}
 		H.n_suf = n_suf; H.suf0 = (int)suf_rec.size(); H.tent0 = (int)tent.size();
 		H.tab_lds = tab_lds ? 1 : 0; H.tsuf0 = (int)tsuf.size(); H.gtab0 = gtab_total;
+		H.il0 = (int)ilane.size();
+		ilane.insert(ilane.end(), w_ilane.begin(), w_ilane.end());
 		H.schur_mfma = schur_mfma; H.mt0 = (int)mt.size(); H.st0 = (int)n_stile_total; H.pad_mt = 0;
 		H.sto0 = (int)st_off.size() - (tiled ? (int)stile_of.size() + 1 : 0);
 		mt.insert(mt.end(), w_mt.begin(), w_mt.end());
@@ -986,7 +1008,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(inc_rec, inc_rec); UP(lmep_loc, lmep_loc);
 	UP(pit, pit); UP(pgrp, pgrp); UP(pslot0, pslot0); UP(pcl_off, pcl_off); UP(pcl_idx, pcl_idx);
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
-	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan); UP(suf_rec, suf_rec); UP(tent, tent); UP(tsuf, tsuf); UP(mt, mt); UP(st_off, st_off);
+	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan); UP(suf_rec, suf_rec); UP(tent, tent); UP(tsuf, tsuf); UP(mt, mt); UP(st_off, st_off); UP(ilane, ilane);
 #undef UP
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
 	b->acc_ok = want_acc && acc_all && tiled_all; b->schur_mfma = schur_mfma;

@@ -59,6 +59,7 @@ struct lm_win {
 	int tsuf0;                         // tsuf[tsuf0 + ..]: per tile the global ids of the suffixes it uses
 	int schur_mfma;                    // slot kernels: 1 = Schur complement on the matrix cores (Y panels; per (tile, 16x16 tile of the reduced
 	                                   // system) a 256-double partial in HBM: Stile[], summed in tile order), 0 = sparse 6x6 items
+	int il0;                           // ilane[il0 + ..]: incidence lanes of the tiles: (local incidence | sub-lane << 16 | lanes of the incidence << 20, first lmep entry, entries, first entry location)
 	int mt0, st0, sto0, pad_mt;        // mt[mt0 + ..]: (I | J << 8, partial id) per task; Stile[256 * (st0 + id)]; st_off[sto0 + u]: partials of tile u
 	long long gtab0;                   // suf_tab[gtab0 + ..]: 12 doubles per suffix (x workgroups of the cooperative kernel)
 	int suf_lvl[SSK_LM_MAX_PATH + 2];
@@ -87,6 +88,7 @@ struct lm_tile {
 	int wt0, ent0, pad1;  // acc: first entry of the tile's wt_off table (window relative); ent0: first tile entry in tent[] (window relative)
 	int tsuf0, n_tsuf;    // !tab_lds: the tile's suffixes tsuf[W.tsuf0 + tsuf0 ..) (tile-local id = position)
 	int mt0, n_mt;        // slot kernels, matrix-core Schur: the tile's tasks mt[W.mt0 + mt0 ..)
+	int il0, n_il, pad4, pad5;   // incidence LANES of the tile: ilane[W.il0 + il0 ..) -- an incidence with many path entries is shared by up to 8 lanes
 };
 
 struct lm_dev {
@@ -97,6 +99,7 @@ struct lm_dev {
 	const int* qit; const int2* sgrp; const int* sslot0; const int* scl_off; const int* scl_idx;
 	const int2* suf_rec; const int* tent; const int* tsuf; double* suf_tab;
 	const int2* mt; const int* st_off; double* Stile;
+	const int4* ilane;
 	const int* wt_off; const int* wt; const int2* tl_pan;   // acc kernel (tl_pan: per tile landmark (row-tile mask, first panel of the tile's panel array))
 	int ldl_mfma;         // reduced systems in L2 scratch: 1 = 16-column LDL^T panels with the trailing update on the FP64 matrix cores (default), 0 = 6-column VALU solver (SSK_LM_LDL=valu)
 	int store_hff;        // 1: the landmark blocks H_ff / g_f of the last linearisation go to HBM (shared-landmark exchange); 0: they stay on chip
@@ -140,6 +143,10 @@ constexpr int SSK_LMT_NT = SSK_LMT_THREADS;        // workgroup size
 // record pitches (doubles, odd: conflict-free).  Entry: chained point q (3) + packed (suffix id << 1 | direction, tile-local observation);
 // observation: V_o = Jf^T Jf (6) + g_o = Jf^T w r (3) -- the 4x3 blocks A of an optimised path entry are NOT stored: A = +-Jf R_suffix^T
 // with R_suffix from the window's path-suffix table (12 doubles per distinct suffix, rebuilt in LDS at every pass)
+#ifndef SSK_LMT_INC_CAP_V
+#define SSK_LMT_INC_CAP_V 2
+#endif
+constexpr int SSK_LMT_INC_CAP = SSK_LMT_INC_CAP_V;  // path entries per incidence lane (an incidence with more is split, at most 8 lanes)
 constexpr int SSK_LMT_ENT = 5, SSK_LMT_OBS = 9, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;
 constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024 / SSK_LMT_WG_PER_CU;   // gfx950: 160 KB of LDS per CU, shared by the resident workgroups
 constexpr int SSK_LMT_STATIC = 1024;               // reserve for the kernel's static LDS (a few scalars and the wave partials)

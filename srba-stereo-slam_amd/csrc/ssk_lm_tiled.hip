@@ -421,18 +421,19 @@ __device__ __forceinline__ void landmark_factor(const double (&v)[9], double lam
 // One (landmark, edge) incidence: W = sum over its path entries of Je^T Jf (6x3, only when `unk`: the landmark is optimised) and
 // the gradient term ge = sum Je^T w r, from the entry / observation records and the suffix table:
 //   A^T Jf = s R_s V_o, A^T w r = s R_s g_o (s = +-1), Je = [A | q x A]
+// lrec: the LANE's share of the incidence (ilane record: -, first lmep entry, entries, first entry location)
 __device__ __forceinline__ void incidence_sums(const lm_dev& D, const lm_win& W, const double* __restrict__ ent, const double* __restrict__ obsr,
-                                               const double* __restrict__ tab, const int4 irec, bool unk, double (&Wm)[18], double (&ge)[6])
+                                               const double* __restrict__ tab, const int4 lrec, bool unk, double (&Wm)[18], double (&ge)[6])
 {
-	const int cnt = irec.x >> 16;
+	const int cnt = lrec.z;
 #pragma unroll
 	for (int c = 0; c < 18; ++c) Wm[c] = 0.0;
 #pragma unroll
 	for (int c = 0; c < 6; ++c) ge[c] = 0.0;
-	int nxt = irec.w;
+	int nxt = lrec.w;
 	for (int k = 0; k < cnt; ++k) {
 		const int loc = nxt;
-		if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + irec.y + k + 1];
+		if (k + 1 < cnt) nxt = D.lmep_loc[W.lmep0 + lrec.y + k + 1];
 		const double* er = ent + ENT_P * (loc & 0xFFFF);
 		const double* orr = obsr + OBS_P * (loc >> 16);
 		const double q[3] = {er[0], er[1], er[2]};
@@ -533,6 +534,21 @@ __device__ unsigned long long g_tst[8];
 #else
 #define TSTAMP(i) do {} while (0)
 #endif
+// The lanes of one incidence (sub-lane s of ns, consecutive lanes of one wavefront) add their shares up into sub-lane 0: a fixed
+// binary tree of wave shuffles (s + 2^k into s), executed by the whole wavefront.
+__device__ __forceinline__ void incidence_combine(double (&Wm)[18], double (&ge)[6], int sub, int ns)
+{
+	int ns_max = 1;                                     // largest lane count of an incidence in this wavefront (uniform)
+	for (int v = 8; v >= 2; --v) if (__ballot(ns >= v) != 0ull) { ns_max = v; break; }
+	for (int d = 1; d < ns_max; d <<= 1) {
+		const bool take = (sub & (2 * d - 1)) == 0 && sub + d < ns;
+#pragma unroll
+		for (int c = 0; c < 18; ++c) { const double v = __shfl_down(Wm[c], d, 64); Wm[c] += take ? v : 0.0; }
+#pragma unroll
+		for (int c = 0; c < 6; ++c) { const double v = __shfl_down(ge[c], d, 64); ge[c] += take ? v : 0.0; }
+	}
+}
+
 // One tile of a window at the pose / landmark state the caller holds: phases I1-I3 of the file header.  `reg`: the
 // workgroup's tile region in LDS; `tab`: the path-suffix table at that state;
 // partial sums go to the window's slot arrays Pp / Sp, Y / gradient terms / landmark factors to its HBM scratch.
@@ -590,12 +606,16 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 		TSTAMP(5);
 		// ---- I2b: a lane per incidence: W and the gradient term, Y = W L^-T -> LDS, reduced gradient term -> HBM ----
 		if (!pre)
-		for (int m = tid; m < T.n_inc; m += NT) {
+		for (int il = tid; il < ((T.n_il + 63) & ~63); il += NT) {          // (whole wavefronts: the lanes of an incidence meet in shuffles)
+			const int4 lrec = il < T.n_il ? D.ilane[W.il0 + T.il0 + il] : make_int4(0, 0, 0, 0);
+			const int ns = (lrec.x >> 20) & 15, sub = (lrec.x >> 16) & 15, m = lrec.x & 0xFFFF;
 			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
 			const int lml = irec.x & 0x7FFF;
 			const bool unk = (irec.x >> 15) & 1;
 			double Wm[18], ge[6];
-			incidence_sums(D, W, ent, obsr, tab, irec, unk, Wm, ge);
+			incidence_sums(D, W, ent, obsr, tab, lrec, unk, Wm, ge);
+			incidence_combine(Wm, ge, sub, ns);
+			if (ns == 0 || sub != 0) continue;                 // the incidence's first lane carries on with the sums
 			double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
 			if (unk) {
 				const double* lr = lmr + LMR_P * lml;
@@ -734,13 +754,17 @@ __device__ __forceinline__ void process_tile_acc(const lm_dev& D, const lm_win& 
 	if (!pre) __syncthreads();
 	// ---- I2b: a lane per incidence: W, gradient term; Y = W L^-T -> LDS (records or panels) and HBM (back-substitution) ----
 	if (!pre)
-	for (int m = tid; m < T.n_inc; m += NT) {
+	for (int il = tid; il < ((T.n_il + 63) & ~63); il += NT) {
+		const int4 lrec = il < T.n_il ? D.ilane[W.il0 + T.il0 + il] : make_int4(0, 0, 0, 0);
+		const int ns = (lrec.x >> 20) & 15, sub = (lrec.x >> 16) & 15, m = lrec.x & 0xFFFF;
 		const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];
 		const int lml = irec.x & 0x7FFF;
 		const bool unk = (irec.x >> 15) & 1;
 		const int e_slot = D.lme_edge[W.lme0 + T.inc0 + m];
 		double Wm[18], ge[6];
-		incidence_sums(D, W, ent, obsr, tab, irec, unk, Wm, ge);
+		incidence_sums(D, W, ent, obsr, tab, lrec, unk, Wm, ge);
+		incidence_combine(Wm, ge, sub, ns);
+		if (ns == 0 || sub != 0) continue;
 		double* gr = gsc + 7 * m;
 		gr[6] = __hiloint2double(0, e_slot);
 		if (unk) {
