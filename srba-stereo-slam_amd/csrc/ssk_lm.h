@@ -144,7 +144,7 @@ constexpr int SSK_LMT_NT = SSK_LMT_THREADS;        // workgroup size
 // observation: V_o = Jf^T Jf (6) + g_o = Jf^T w r (3) -- the 4x3 blocks A of an optimised path entry are NOT stored: A = +-Jf R_suffix^T
 // with R_suffix from the window's path-suffix table (12 doubles per distinct suffix, rebuilt in LDS at every pass)
 #ifndef SSK_LMT_INC_CAP_V
-#define SSK_LMT_INC_CAP_V 2
+#define SSK_LMT_INC_CAP_V 3
 #endif
 constexpr int SSK_LMT_INC_CAP = SSK_LMT_INC_CAP_V;  // path entries per incidence lane (an incidence with more is split, at most 8 lanes)
 constexpr int SSK_LMT_ENT = 5, SSK_LMT_OBS = 9, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;
