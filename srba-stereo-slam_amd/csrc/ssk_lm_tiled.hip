@@ -74,14 +74,16 @@ __device__ __forceinline__ void wave_seg_sum36(double (&acc)[36], int key, int l
 	const unsigned long long hm = __ballot(head);
 	const bool tail = (lane & 15) == 15 || ((hm >> ((lane + 1) & 63)) & 1ull);
 	const int seg = __popcll(hm & ((2ull << lane) - 1ull)) - 1;
-	const bool s1 = dpp_same_key<1>(key), s2 = dpp_same_key<2>(key), s4 = dpp_same_key<4>(key), s8 = dpp_same_key<8>(key);
+	// "add the value d lanes below when it belongs to the same run" as ONE fma on a 0 / 1 mask (the select form costs two v_cndmask and
+	// an add per step: 36 values x 4 steps); a lane shifted in from outside the row reads 0, so t * 0 is exact
+	const double s1 = dpp_same_key<1>(key) ? 1.0 : 0.0, s2 = dpp_same_key<2>(key) ? 1.0 : 0.0, s4 = dpp_same_key<4>(key) ? 1.0 : 0.0, s8 = dpp_same_key<8>(key) ? 1.0 : 0.0;
 #pragma unroll
 	for (int i = 0; i < 36; ++i) {
-		double v = acc[i], t;
-		t = dpp_shr_f64<1>(v); v += s1 ? t : 0.0;
-		t = dpp_shr_f64<2>(v); v += s2 ? t : 0.0;
-		t = dpp_shr_f64<4>(v); v += s4 ? t : 0.0;
-		t = dpp_shr_f64<8>(v); v += s8 ? t : 0.0;
+		double v = acc[i];
+		v = fma(dpp_shr_f64<1>(v), s1, v);
+		v = fma(dpp_shr_f64<2>(v), s2, v);
+		v = fma(dpp_shr_f64<4>(v), s4, v);
+		v = fma(dpp_shr_f64<8>(v), s8, v);
 		acc[i] = v;
 	}
 	if (tail) {                                            // one burst of stores, nothing waits on it
@@ -103,11 +105,15 @@ __device__ __forceinline__ void pp_group(const double* __restrict__ ent, const d
 		if (k + 1 < cnt) nxt = items[k + 1];              // next item id in flight during this item's arithmetic
 		const double* e1 = ent + ENT_P * (itv & 0xFFFF);
 		const double* e2 = ent + ENT_P * (itv >> 16);
-		const double q1[3] = {e1[0], e1[1], e1[2]}, q2[3] = {e2[0], e2[1], e2[2]};
-		const double pk1 = e1[3], pk2 = e2[3];
-		const int c1 = __double2loint(pk1), c2 = __double2loint(pk2);
+		const bool diag = e1 == e2;                        // an entry paired with itself (diagonal blocks): one record, one rotation
+		const double q1[3] = {e1[0], e1[1], e1[2]};
+		const double pk1 = e1[3];
+		const int c1 = __double2loint(pk1);
 		const double* orr = obsr + OBS_P * __double2hiint(pk1);
 		const double* T1 = tab + 12 * (c1 >> 1);
+		double q2[3] = {q1[0], q1[1], q1[2]};
+		int c2 = c1;
+		if (!diag) { q2[0] = e2[0]; q2[1] = e2[1]; q2[2] = e2[2]; c2 = __double2loint(e2[3]); }
 		const double* T2 = tab + 12 * (c2 >> 1);
 		const double sg = ((c1 ^ c2) & 1) ? -1.0 : 1.0;
 		const double V[6] = {orr[0], orr[1], orr[2], orr[3], orr[4], orr[5]};
@@ -119,9 +125,13 @@ __device__ __forceinline__ void pp_group(const double* __restrict__ ent, const d
 #pragma unroll
 			for (int c = 0; c < 3; ++c) B[3 * r + c] = r0 * Vm[c] + r1 * Vm[3 + c] + r2 * Vm[6 + c];
 		}
+		double R1[9];                                       // (kept for the diagonal case: R2 = R1 without a second read)
+#pragma unroll
+		for (int r = 0; r < 3; ++r) { R1[3 * r] = T1[4 * r]; R1[3 * r + 1] = T1[4 * r + 1]; R1[3 * r + 2] = T1[4 * r + 2]; }
 #pragma unroll
 		for (int c = 0; c < 3; ++c) {
-			const double t0 = T2[4 * c], t1 = T2[4 * c + 1], t2 = T2[4 * c + 2];
+			double t0 = R1[3 * c], t1 = R1[3 * c + 1], t2 = R1[3 * c + 2];
+			if (!diag) { t0 = T2[4 * c]; t1 = T2[4 * c + 1]; t2 = T2[4 * c + 2]; }
 #pragma unroll
 			for (int r = 0; r < 3; ++r) C[3 * r + c] = B[3 * r] * t0 + B[3 * r + 1] * t1 + B[3 * r + 2] * t2;
 		}
@@ -481,14 +491,16 @@ __device__ __forceinline__ void wave_seg_add36(double (&acc)[36], int key, int l
 	const bool head = (lane & 15) == 0 || key != prev;
 	const unsigned long long hm = __ballot(head);
 	const bool tail = (lane & 15) == 15 || ((hm >> ((lane + 1) & 63)) & 1ull);
-	const bool s1 = dpp_same_key<1>(key), s2 = dpp_same_key<2>(key), s4 = dpp_same_key<4>(key), s8 = dpp_same_key<8>(key);
+	// "add the value d lanes below when it belongs to the same run" as ONE fma on a 0 / 1 mask (the select form costs two v_cndmask and
+	// an add per step: 36 values x 4 steps); a lane shifted in from outside the row reads 0, so t * 0 is exact
+	const double s1 = dpp_same_key<1>(key) ? 1.0 : 0.0, s2 = dpp_same_key<2>(key) ? 1.0 : 0.0, s4 = dpp_same_key<4>(key) ? 1.0 : 0.0, s8 = dpp_same_key<8>(key) ? 1.0 : 0.0;
 #pragma unroll
 	for (int i = 0; i < 36; ++i) {
-		double v = acc[i], t;
-		t = dpp_shr_f64<1>(v); v += s1 ? t : 0.0;
-		t = dpp_shr_f64<2>(v); v += s2 ? t : 0.0;
-		t = dpp_shr_f64<4>(v); v += s4 ? t : 0.0;
-		t = dpp_shr_f64<8>(v); v += s8 ? t : 0.0;
+		double v = acc[i];
+		v = fma(dpp_shr_f64<1>(v), s1, v);
+		v = fma(dpp_shr_f64<2>(v), s2, v);
+		v = fma(dpp_shr_f64<4>(v), s4, v);
+		v = fma(dpp_shr_f64<8>(v), s8, v);
 		acc[i] = v;
 	}
 	double* out = acc36 + 36 * key;
