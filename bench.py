@@ -493,7 +493,7 @@ def main():
         # committed under profiles/): bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- KB units, FETCH_SIZE doubled on gfx950
         # (MI355X_MICROARCH.md "HBM"; re-calibrated in the same run on lm_reset_kernel, which reads exactly what it writes)
         traffic = {}
-        for tf in ("r01_pmc_traffic.json", "r01_pmc_traffic_b256.json"):          # the summary collected at this batch size
+        for tf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json", "r01_pmc_traffic_b256.json"):          # the summary collected at this batch size
             tf = os.path.join(ROOT, "profiles", tf)
             if traffic or not os.path.exists(tf):
                 continue
@@ -518,6 +518,12 @@ def main():
         fast_avg_ms = fast_ms / max(fast_calls, 1)
         algo_bytes = float(B) * 2 * W * H
         achieved = algo_bytes / (fast_avg_ms * 1e-3) / 1e9
+        # the orientation + BRIEF kernel: per keypoint a 45 x 48 B patch read (2160 B; the aligned-dword window of the 45 x 45 patch), 32 B of
+        # descriptor + 4 B of angle written
+        desc_ms, desc_calls = prof["describe"]
+        desc_avg_ms = desc_ms / max(desc_calls, 1)
+        desc_algo = float(nkp.sum()) * (45 * 48 + 36)
+        desc_ach = desc_algo / (desc_avg_ms * 1e-3) / 1e9
         stages = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items() if v[1] > 0}
         line = {
             "metric": "keyframes/sec (detect+match+LM solve), KITTI-00 stereo",
@@ -551,7 +557,7 @@ def main():
             "roofline": {"kernel": "lm_solve_tiled_kernel", "bound": "hbm", "achieved": lm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic.get("lm_solve_tiled_kernel"),
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
-                         "note": "dominant kernel by time; FP64-issue/LDS bound at 2 waves/SIMD, not bandwidth bound (DESIGN.md 5, 9)"},
+                         "note": "dominant kernel by time; latency bound at 2 waves/SIMD (profiles/r02_pmc_sq.json: waves wait 64 % of their time), not bandwidth bound (DESIGN.md 5, 9)"},
             "roofline_fp64": {"kernel": "lm_solve_tiled_kernel", "bound": "mfma", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
                               "note": "the same launch priced in FP64 flops (SURVEY 8(d) per-unit figures); FP64 MFMA rate = FP64 vector rate on MI355X, "
@@ -559,6 +565,11 @@ def main():
             "roofline_scan": {"kernel": "fast_nms_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("fast_nms_kernel"),
                               "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_avg_ms},
+            "roofline_describe": {"kernel": "describe_kernel", "bound": "hbm", "achieved": desc_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": desc_ach / HBM_PEAK_GBS, "traffic": traffic.get("describe_kernel"),
+                                  "algorithmic_bytes_per_launch": desc_algo, "avg_launch_ms": desc_avg_ms,
+                                  "note": "VALU-issue bound (profiles/r02_pmc_sq.json: every resident wave issues VALU 17 % of its time at ~5 waves per SIMD; "
+                                          "3 LDS bank-conflict cycles per LDS instruction in the transposed blur tiles); patches of neighbouring keypoints overlap in L2"},
             "stage_ms_per_launch": stages,
             "pcie_inclusive": pcie,
             "unbatched": unbatched,

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Aggregate two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate passes, as the TCC block cannot hold both) of
-`python3 bench.py --steps 3 --warmup 1 --cpu-sample 0` into profiles/r01_pmc_traffic.json (per-kernel averages, KB per
+`python3 bench.py --steps 3 --warmup 1 --cpu-sample 0` into profiles/r02_pmc_traffic.json (per-kernel averages, KB per
 dispatch).  Usage on the GPU box, from the repo root:
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0
-    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/r01_pmc_traffic.json
+    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_pmc_traffic.json
 bench.py turns the numbers into bytes: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (KB units; FETCH_SIZE tallies half the bytes of
 a wide coalesced read on gfx950, MI355X_MICROARCH.md; re-checked here on lm_reset_kernel, which reads what it writes)."""
 import csv
