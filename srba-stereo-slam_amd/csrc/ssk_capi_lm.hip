@@ -359,6 +359,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	const int MAX_ITERS_ALLOC = 64;
 	static const bool timing = std::getenv("SSK_TIMING") != nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
+	double t_ph[5] = {0, 0, 0, 0, 0};                      // per window: validation + incidences, suffix trie, tile loop, concatenation
+	auto tnow = [] { return std::chrono::steady_clock::now(); };
+	auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
 	// batch-wide host images of every array family
 	std::vector<int> edge_slot, lm_slot, obs_lm, obs_path_off, path_edge, path_obs, slot_edge, slot_lm;
 	std::vector<int> lmo_off, lmo_idx, lsm_off, lme_edge, lme_ls, lme_elpos, lmep_off, lmep_idx, q_off, q_uend, qo_off, el_off, el_idx;
@@ -384,6 +387,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	long long h_total = 0, dpt = 0, dft = 0;
 	int max_n6 = 0;
 	for (int w = 0; w < n_windows; ++w) {
+		const auto tp0 = tnow();
 		const ssk_lm_window& Wn = windows[w];
 		lm_win& H = hdr[w];
 		if (Wn.n_edges_total < 0 || Wn.n_lms_total < 0 || Wn.n_obs < 0 ||
@@ -523,6 +527,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		std::vector<int4> w_ilane;                             // incidence lanes, tile by tile
 		auto inc_lanes = [](int cnt) { const int ns = (cnt + SSK_LMT_INC_CAP - 1) / SSK_LMT_INC_CAP; return ns < 1 ? 1 : (ns > 8 ? 8 : ns); };
 		std::vector<std::vector<int>> stile_of;                // per upper 16x16 tile u = J (J + 1) / 2 + I: its partials, tile order
+		const auto tp1 = tnow();
 		// ---- path-suffix trie: suffix k of a path = (c_k .. c_{n-1}); a suffix is (first step, shorter suffix), 0 = the empty one ----
 		std::vector<int2> w_suf(1, make_int2(-1, -1));
 		std::vector<int> w_suf_len(1, 0), suf_at((size_t)n_path + 1, 0), obs_suf((size_t)Wn.n_obs, 0);
@@ -556,6 +561,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			for (int& v : obs_suf) v = inv[v];
 		}
 		const int n_suf = (int)w_suf.size();
+		const auto tp2 = tnow();
 		// few suffixes (batched windows): the whole table stays in LDS; many (a local area of tens of keyframes): per-tile copies
 		const bool tab_lds = 96LL * n_suf <= 24 * 1024;
 		int n_pslots = 0, n_sslots = 0;
@@ -732,7 +738,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 							w_ilane.push_back(make_int4((m - T.inc0) | (sub << 16) | (ns << 20), w_lmep_off[m] + k0, k1 - k0, k1 > k0 ? w_lmep_loc[w_lmep_off[m] + k0] : 0));
 						}
 					}
-					if (Wn.lm_unknown_slot[l] >= 0)
+					if (Wn.lm_unknown_slot[l] >= 0 && !panels)          // (the matrix-core form has no Schur items: 50 k of them in a 40-edge local area)
 						for (size_t a = 0; a < lm_lmes[ok].size(); ++a)
 							for (size_t b2 = a; b2 < lm_lmes[ok].size(); ++b2)
 								qitems.push_back({pid_of(w_lme_edge[lm_lmes[ok][a]], w_lme_edge[lm_lmes[ok][b2]]),
@@ -755,12 +761,20 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size(); T.n_sg = 0; T.n_sc = 0;
 				const int TR = ssk_lma_row_tiles(E);
 				std::vector<std::pair<int, int>> tk;               // (-cover, code)
-				for (int J = 0; J < TR; ++J)
-					for (int I = 0; I <= J; ++I) {
-						int cover = 0;
-						for (size_t ok = oi; ok < oj; ++ok) cover += (lm_rowmask[ok] >> I) & (lm_rowmask[ok] >> J) & 1;
-						if (cover) tk.push_back(std::make_pair(-cover, I | (J << 8)));
+				{
+					// landmarks per (I, J): a landmark touches 3-4 row tiles, so walk its bit pairs instead of all T (T + 1) / 2 tiles per landmark
+					std::vector<int> cover((size_t)(TR * (TR + 1) / 2), 0);
+					for (size_t ok = oi; ok < oj; ++ok) {
+						const int mk = lm_rowmask[ok];
+						for (int mj = mk; mj; mj &= mj - 1) {
+							const int J = __builtin_ctz(mj);
+							for (int mi = mk & ((2 << J) - 1); mi; mi &= mi - 1) cover[(size_t)(J * (J + 1) / 2 + __builtin_ctz(mi))]++;
+						}
 					}
+					for (int J = 0; J < TR; ++J)
+						for (int I = 0; I <= J; ++I)
+							if (cover[(size_t)(J * (J + 1) / 2 + I)]) tk.push_back(std::make_pair(-cover[(size_t)(J * (J + 1) / 2 + I)], I | (J << 8)));
+				}
 				std::stable_sort(tk.begin(), tk.end());
 				T.mt0 = (int)w_mt.size(); T.n_mt = (int)tk.size();
 				for (const auto& t : tk) {
@@ -874,6 +888,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			if (fixed + mat <= (size_t)(SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC)) tiled_dyn = std::max(tiled_dyn, fixed + mat);
 		}
 		if (!tiled) tiled_all = false;
+		const auto tp3 = tnow();
 		if (w == 0 && std::getenv("SSK_LM_DEBUG")) {
 			std::fprintf(stderr, "[ssk lm] window 0: E %d L %d obs %d path %d lme %d tiles %d (region %lld B) pslots %d sslots %d\n", E, L, Wn.n_obs, n_path, n_lme,
 			             tiled ? (int)w_tiles.size() : -1, region_bytes, n_pslots, n_sslots);
@@ -977,6 +992,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		lme_elpos.insert(lme_elpos.end(), w_elpos.begin(), w_elpos.end());
 		for (int m = 0; m < n_lme; ++m) w_inc_rec[m].z = w_elpos[m];
 		inc_rec.insert(inc_rec.end(), w_inc_rec.begin(), w_inc_rec.end());
+		t_ph[0] += tms(tp0, tp1); t_ph[1] += tms(tp1, tp2); t_ph[2] += tms(tp2, tp3); t_ph[3] += tms(tp3, tnow());
 	}
 
 	if (want_acc && !acc_all) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, with_general, false);
@@ -1060,8 +1076,8 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (timing) {
 		(void)hipDeviceSynchronize();
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create (%d windows): symbolic %.3f ms, allocate + upload %.3f ms (%zu device arrays)\n",
-		             n_windows, ms(t_begin, t_sym), ms(t_sym, std::chrono::steady_clock::now()), (size_t)1);
+		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create (%d windows): symbolic %.3f ms (incidences %.3f, suffix trie %.3f, tiles %.3f, concatenation %.3f), allocate + upload %.3f ms\n",
+		             n_windows, ms(t_begin, t_sym), t_ph[0], t_ph[1], t_ph[2], t_ph[3], ms(t_sym, std::chrono::steady_clock::now()));
 	}
 	*out = b;
 	return SSK_OK;
