@@ -1055,8 +1055,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (!rc) rc = scratch(b, 6 * n_lme, &D.gre);
 	if (!rc) rc = scratch(b, 36 * pchunk.size(), &D.Ppart);
 	if (!rc) rc = scratch(b, 36 * schunk.size(), &D.Spart);
-	if (!rc) rc = scratch(b, 36 * n_pslots_total, &D.Ppart2);
-	if (!rc) rc = scratch(b, 36 * n_sslots_total, &D.Spart2);
+	// (+ one record: the assembly's clamped loads of an EMPTY run read the slot at the run's start, which for the last run is one past the end)
+	if (!rc) rc = scratch(b, 36 * n_pslots_total + 36, &D.Ppart2);
+	if (!rc) rc = scratch(b, 36 * n_sslots_total + 36, &D.Spart2);
 	if (!rc) rc = scratch(b, with_general ? (size_t)h_total : 0, &D.Hpair);
 	if (!rc) rc = scratch(b, (size_t)h_total, &D.Hred);
 	if (!rc) rc = scratch(b, 6 * n_us, &D.dp);
@@ -1067,7 +1068,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
 	if (!rc) rc = scratch(b, (size_t)gtab_total, &D.suf_tab);
-	if (!rc) rc = scratch(b, 256 * (size_t)n_stile_total, &D.Stile);
+	if (!rc) rc = scratch(b, 256 * (size_t)n_stile_total + 256, &D.Stile);
 	if (!rc) rc = scratch(b, pose.size(), &b->pose_bak);
 	if (!rc) rc = scratch(b, lm.size(), &b->lm_bak);
 	D.trace_on = trace ? 1 : 0;

@@ -332,6 +332,26 @@ __device__ __forceinline__ double slot_sum(const double* __restrict__ part, int 
 	return s;
 }
 
+// p - s of one component: the H_pp slots k in [p0, p1) (pitch 36, component ab) and the Schur slots / matrix-core partials k in [s0, s1)
+// (pitch SP, component sb), each summed in slot order; the loads of both runs are issued together, four and four per turn
+template <int SP>
+__device__ __forceinline__ double slot_diff(const double* __restrict__ Pp, int p0, int p1, int ab, const double* __restrict__ Sp, int s0, int s1, int sb)
+{
+	double p = 0.0, sc = 0.0;
+	for (int kp = p0, ks = s0; kp < p1 || ks < s1; kp += 4, ks += 4) {
+		double v[4], u[4];
+#pragma unroll
+		for (int t = 0; t < 4; ++t) v[t] = Pp[36 * (size_t)max(min(kp + t, p1 - 1), p0) + ab];
+#pragma unroll
+		for (int t = 0; t < 4; ++t) u[t] = Sp[SP * (size_t)max(min(ks + t, s1 - 1), s0) + sb];
+#pragma unroll
+		for (int t = 0; t < 4; ++t) p += kp + t < p1 ? v[t] : 0.0;
+#pragma unroll
+		for (int t = 0; t < 4; ++t) sc += ks + t < s1 ? u[t] : 0.0;
+	}
+	return p - sc;
+}
+
 // I1: linearise one observation (packed record: first tile-local entry | optimised entries << 16, landmark, suffix id of its path)
 // into the LDS records: V_o = Jf^T Jf, g_o = Jf^T w r; per optimised entry the chained point and (suffix, direction, observation).
 // tent: the tile's entry table (suffix id << 1 | direction); kobs: tile-local index of the observation.
@@ -895,13 +915,14 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 		const int pid = it / 36, ab = it - pid * 36, a = ab / 6, b = ab - a * 6;
 		const int2 ee = D.pair_ee[W.pair0 + pid];
 		if (ee.x == ee.y && a > b) continue;
-		const double p = slot_sum(Pp, D.pcl_off[W.pairo0 + pid], D.pcl_off[W.pairo0 + pid + 1], ab);
-		double sc;
+		// (empty runs: p1 == p0 reads slot p0 - clamped inside the window's arrays - and adds nothing)
+		double sres;
+		const int p0 = D.pcl_off[W.pairo0 + pid], p1 = D.pcl_off[W.pairo0 + pid + 1];
 		if (SMF) {                                         // matrix-core Schur: the partials of the 16x16 tile that holds (row, col), tile order
 			const int row = 6 * ee.x + a, col = 6 * ee.y + b, u = (col >> 4) * ((col >> 4) + 1) / 2 + (row >> 4);
-			sc = slot_sum<256>(D.Stile + 256 * (size_t)W.st0, D.st_off[W.sto0 + u], D.st_off[W.sto0 + u + 1], (((row & 15) >> 2) << 6) + ((row & 3) << 4) + (col & 15));
-		} else sc = slot_sum(Sp, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
-		double sres = p - sc;
+			sres = slot_diff<256>(Pp, p0, p1, ab, D.Stile + 256 * (size_t)W.st0, D.st_off[W.sto0 + u], D.st_off[W.sto0 + u + 1],
+			                      (((row & 15) >> 2) << 6) + ((row & 3) << 4) + (col & 15));
+		} else sres = slot_diff<36>(Pp, p0, p1, ab, Sp, D.scl_off[W.pairo0 + pid], D.scl_off[W.pairo0 + pid + 1], ab);
 		if (ee.x == ee.y && a == b) sres += lambda;
 		A[(6 * ee.x + a) * np + 6 * ee.y + b] = sres;
 		A[(6 * ee.y + b) * np + 6 * ee.x + a] = sres;
