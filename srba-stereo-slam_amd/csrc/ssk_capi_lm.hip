@@ -784,7 +784,8 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				}
 				} else if (!acc) {
 				int R = 1;
-				while (R < 255 && (count_groups(pitems, R) + 63) / 64 + (count_groups(qitems, R) + 63) / 64 > SSK_LMT_NT / 64) ++R;
+				while (R < 255 && (count_groups(pitems, R) + 63) / 64 + (count_groups(qitems, R) + 63) / 64 > SSK_LMT_NT / 64) ++R;      // one chunk task per wavefront (two rounds of smaller tasks measured 5 % slower)
+				if (w == 0 && std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm]   tile %d: H_pp items %zu Schur items %zu, <= %d items per lane\n", tile_no, pitems.size(), qitems.size(), R);
 				make_groups(pitems, R, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
 				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size();
 				make_groups(qitems, R, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
