@@ -26,6 +26,7 @@ struct ssk_lm_batch {
 	int max_tiles = 0;                // most tiles of a window (cooperative kernel: workgroups per window)
 	bool has_general = false;         // the general kernel's structures were built too
 	size_t tiled_dyn_bytes = 0;       // its dynamic LDS size
+	bool lds_sys = false;             // every window's reduced system fits LDS: the kernel variant without the L2-resident solver
 	// cooperative launch in flight: the state it started from (pose_bak / lm_bak) and its parameters, so that a launch whose
 	// workgroups were not all resident (stop_reason 5) is repeated with one workgroup per window by ssk_lm_batch_results
 	bool coop_pending = false;
@@ -383,6 +384,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	long long gtab_total = 0, n_stile_total = 0;
 	bool acc_all = want_acc;
 	size_t n_pslots_total = 0, n_sslots_total = 0, tiled_dyn = 0;
+	bool lds_sys_all = true;
 	bool tiled_all = true;
 	long long h_total = 0, dpt = 0, dft = 0;
 	int max_n6 = 0;
@@ -887,6 +889,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			const size_t fixed = (size_t)(2 * 12 * 8 * Wn.n_edges_total) + (size_t)(2 * 8 * ((6 * E + 1) & ~1)) + (tab_lds ? 104 * (size_t)n_suf : 0);
 			const size_t mat = (size_t)(6 * E + 1) * ((6 * E) | 1) * 8;
 			if (fixed + mat <= (size_t)(SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC)) tiled_dyn = std::max(tiled_dyn, fixed + mat);
+			else lds_sys_all = false;
 		}
 		if (!tiled) tiled_all = false;
 		const auto tp3 = tnow();
@@ -1027,7 +1030,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
 	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan); UP(suf_rec, suf_rec); UP(tent, tent); UP(tsuf, tsuf); UP(mt, mt); UP(st_off, st_off); UP(ilane, ilane);
 #undef UP
-	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn;
+	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn; b->lds_sys = tiled_all && lds_sys_all;
 	b->acc_ok = want_acc && acc_all && tiled_all; b->schur_mfma = schur_mfma;
 	D.store_hff = 0;
 	// SSK_LM_LDL=mfma (needs the matrix-core Schur form): the kernels whose L2-resident reduced systems are factorised in 16-column panels
@@ -1130,6 +1133,8 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 		const int per_cu = ssk_lm_coop_blocks_per_cu(ctx, b->tiled_dyn_bytes, b->schur_mfma);
 		int G = std::min(std::min(b->max_tiles, 64), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
 		const bool want = force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu);
+		if (std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm] run: %d windows, max tiles %d, %d workgroups per CU -> %s, G %d, max 6E %d, Schur %s\n", b->n_windows, b->max_tiles, per_cu,
+		                                              want ? "cooperative" : "one workgroup per window", G, b->max_n6, b->schur_mfma ? "mfma" : "sparse");
 		if (want) {
 			// residency is still not guaranteed (another stream or process may hold CUs): keep the state the launch starts
 			// from, ssk_lm_batch_results repeats a launch that ended in stop_reason 5 with one workgroup per window
@@ -1141,7 +1146,7 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 			return rc;
 		}
 	}
-	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
+	if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) return ssk_lm_launch_tiled(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma, b->lds_sys);
 	if (!b->has_general) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: the batch was built without the general kernel's structures");
 	return ssk_lm_launch(ctx, b->D, P, b->n_windows, b->max_n6);
 }
@@ -1163,7 +1168,7 @@ int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out)
 		if (verbose) std::fprintf(stderr, "[ssk lm] cooperative launch timed out at a barrier: repeating with one workgroup per window\n");
 		SSK_HIP(ctx, hipMemcpyAsync(b->D.pose, b->pose_bak, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
 		SSK_HIP(ctx, hipMemcpyAsync(b->D.lm, b->lm_bak, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
-		int rc = ssk_lm_launch_tiled(ctx, b->D, b->coop_P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
+		int rc = ssk_lm_launch_tiled(ctx, b->D, b->coop_P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma, b->lds_sys);
 		if (rc) return rc;
 		SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		SSK_HIP(ctx, hipMemcpy(out, b->D.res, sizeof(ssk_lm_result) * (size_t)b->n_windows, hipMemcpyDeviceToHost));

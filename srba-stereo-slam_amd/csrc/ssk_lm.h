@@ -150,7 +150,7 @@ constexpr int SSK_LMT_INC_CAP = SSK_LMT_INC_CAP_V;  // path entries per incidenc
 constexpr int SSK_LMT_ENT = 5, SSK_LMT_OBS = 9, SSK_LMT_Y = 19, SSK_LMT_LMR = 9;
 constexpr int SSK_LMT_LDS_TOTAL = 160 * 1024 / SSK_LMT_WG_PER_CU;   // gfx950: 160 KB of LDS per CU, shared by the resident workgroups
 constexpr int SSK_LMT_STATIC = 1024;               // reserve for the kernel's static LDS (a few scalars and the wave partials)
-int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma);
+int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma, bool lds_sys);
 // G workgroups per window (n_windows * G <= number of CUs, G <= 64): single large windows of the un-batched drop-in path
 int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout, int schur_mfma);
 int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes, int schur_mfma);

@@ -196,6 +196,191 @@ __device__ unsigned long long g_ldl[4];
 #define LDL_T0() do {} while (0)
 #define LDL_ADD(i, who) do {} while (0)
 #endif
+// index map of the in-LDS factorisation of a packed lower triangle (row i at i (i + 1) / 2)
+struct ldl_ix_packed { __device__ __forceinline__ int operator()(int i, int k) const { return i * (i + 1) / 2 + k; } };
+
+// The factorisation proper, L' D L'^T of rows 0 .. n (row n = right-hand side) in LDS under an index map: see ldl_solve_lds.
+// (ix(i, k) of an element above the diagonal must stay inside the allocation: it is read, never used or stored.)
+template <typename IX>
+__device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int n, double* inv)
+{
+	const int tid = threadIdx.x;
+	__shared__ int s_ldl_bad_p;
+	if (tid < 64) {
+		// panel 0: the diagonal block by broadcast reads, then one lane per row below it (the border row included)
+		double a[21], ivr[6];
+#pragma unroll
+		for (int i = 0; i < 6; ++i)
+#pragma unroll
+			for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = A[ix(i, k)];
+		bool bad = false;
+#pragma unroll
+		for (int j = 0; j < 6; ++j) {
+			const double d = a[j * (j + 1) / 2 + j];
+			bad |= !(d > 0.0);
+			ivr[j] = rcp_f64(d);
+#pragma unroll
+			for (int i = j + 1; i < 6; ++i) {
+				const double t = a[i * (i + 1) / 2 + j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+			}
+		}
+		for (int i = 6 + tid; i <= n; i += 64) {
+			double x[6];
+#pragma unroll
+			for (int k = 0; k < 6; ++k) x[k] = A[ix(i, k)];
+#pragma unroll
+			for (int j = 0; j < 5; ++j) {
+				const double t = x[j] * ivr[j];
+#pragma unroll
+				for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+			}
+#pragma unroll
+			for (int k = 1; k < 6; ++k) A[ix(i, k)] = x[k];
+		}
+		if (tid == 0) {
+			s_ldl_bad_p = bad;
+#pragma unroll
+			for (int i = 0; i < 6; ++i) {
+				inv[i] = ivr[i];
+#pragma unroll
+				for (int k = 0; k < i; ++k) A[ix(i, k)] = a[i * (i + 1) / 2 + k];
+			}
+		}
+	}
+	for (int c0 = 0; c0 < n; c0 += 6) {
+		__syncthreads();                                  // panel c0 complete; the update by panel c0 - 6 applied everywhere
+		if (s_ldl_bad_p) return false;                      // uniform
+		const int r0 = c0 + 6;
+		if (r0 >= n) break;
+		double iv[6];
+#pragma unroll
+		for (int c = 0; c < 6; ++c) iv[c] = inv[c0 + c];
+		
+		if (tid < 64) {
+			// ---- wave 0: the next panel (columns r0 .. r0+5): update by panel c0, factorise, eliminate ----
+			double uk[6][6];                              // rows r0 .. r0+5 of panel c0 (broadcast reads)
+#pragma unroll
+			for (int k = 0; k < 6; ++k)
+#pragma unroll
+				for (int c = 0; c < 6; ++c) uk[k][c] = A[ix((r0 + k), c0 + c)];
+			double a[21], ivr[6];
+			bool bad = false;
+			for (int i0 = r0; i0 <= n; i0 += 64) {
+				const int i = i0 + tid;
+				const bool row = i <= n;
+				const int ic = row ? i : n;                   // loads are unconditional on a clamped row (a load under a lane
+				double x[6];                                  // condition is compiled as a branch that waits for it at once)
+				{
+					double ui[6], v[6];
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[c] = A[ix(ic, c0 + c)];
+#pragma unroll
+					for (int k = 0; k < 6; ++k) v[k] = A[ix(ic, r0 + k)];
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[c] *= iv[c];
+#pragma unroll
+					for (int k = 0; k < 6; ++k) {
+						const bool on = row && r0 + k <= i;          // the lower triangle (r0 + k < n always: no column n)
+						double sacc = 0.0;
+#pragma unroll
+						for (int c = 0; c < 6; ++c) sacc += ui[c] * uk[k][c];
+						x[k] = on ? v[k] - sacc : 0.0;
+					}
+				}
+				if (i0 == r0) {
+					// lanes 0..5 hold the updated rows of the next diagonal block: every lane takes a copy and factorises it
+#pragma unroll
+					for (int r = 0; r < 6; ++r)
+#pragma unroll
+						for (int k = 0; k <= r; ++k) a[r * (r + 1) / 2 + k] = readlane_f64(x[k], r);
+#pragma unroll
+					for (int j = 0; j < 6; ++j) {
+						const double d = a[j * (j + 1) / 2 + j];
+						bad |= !(d > 0.0);
+						ivr[j] = rcp_f64(d);
+#pragma unroll
+						for (int r = j + 1; r < 6; ++r) {
+							const double t = a[r * (r + 1) / 2 + j] * ivr[j];
+#pragma unroll
+							for (int k = j + 1; k <= r; ++k) a[r * (r + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
+						}
+					}
+				}
+				if (row && i >= r0 + 6) {
+#pragma unroll
+					for (int j = 0; j < 5; ++j) {
+						const double t = x[j] * ivr[j];
+#pragma unroll
+						for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
+					}
+#pragma unroll
+					for (int k = 0; k < 6; ++k) A[ix(i, r0 + k)] = x[k];
+				}
+			}
+			if (tid == 0) {
+				s_ldl_bad_p = bad;
+#pragma unroll
+				for (int r = 0; r < 6; ++r) {
+					inv[r0 + r] = ivr[r];
+#pragma unroll
+					for (int k = 0; k <= r; ++k) A[ix((r0 + r), r0 + k)] = a[r * (r + 1) / 2 + k];
+				}
+			}
+			
+		} else {
+			// ---- waves 1..: A(i,k) -= sum_c U(i,c) U(k,c) / d_c for the columns beyond the next panel, r0+6 <= k <= min(i, n-1),
+			//      i <= n: 4 x 2 elements per thread and pass, loads before stores ----
+			constexpr int NR = (NT - 64) / 32;            // row groups of 32 lanes
+			const int t2 = tid - 64, ty = t2 >> 5, tx = t2 & 31;
+			const int q0 = r0 + 6;
+			for (int ib = q0 + ty; ib <= n; ib += 4 * NR)
+				for (int kb = q0 + tx; kb < n; kb += 64) {
+					if (kb - tx > ib - ty + 4 * NR - 1) break;       // the whole pass lies above the diagonal (uniform)
+					// unconditional loads on clamped indices (see above); only the stores are predicated
+					double ui[4][6], uk[2][6], v[8];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const int i = min(ib + NR * u, n);
+#pragma unroll
+						for (int c = 0; c < 6; ++c) ui[u][c] = A[ix(i, c0 + c)];
+					}
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int k = min(kb + 32 * w, n - 1);
+#pragma unroll
+						for (int c = 0; c < 6; ++c) uk[w][c] = A[ix(k, c0 + c)];
+					}
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+#pragma unroll
+						for (int w = 0; w < 2; ++w) v[2 * u + w] = A[ix(min(ib + NR * u, n), min(kb + 32 * w, n - 1))];
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+#pragma unroll
+						for (int c = 0; c < 6; ++c) ui[u][c] *= iv[c];
+#pragma unroll
+					for (int u = 0; u < 4; ++u)
+#pragma unroll
+						for (int w = 0; w < 2; ++w) {
+							const int i = ib + NR * u, k = kb + 32 * w;
+							if (i <= n && k < n && k <= i) {
+								double sacc = 0.0;
+#pragma unroll
+								for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
+								A[ix(i, k)] = v[2 * u + w] - sacc;
+							}
+						}
+				}
+			
+		}
+		__syncthreads();
+		
+	}
+	return true;
+}
+
 __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* x_out, double* inv)
 {
 	const int tid = threadIdx.x;
@@ -649,128 +834,83 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 		const int cend = r < m ? r : m - 1;
 		for (int c = tx; c <= cend; c += 32) SSK_PI(r, c) = A[(size_t)(n1 + r) * np + n1 + c];
 	}
-	// ---- phase 3: blocked LDL^T of the packed block (the loop of ldl_solve_lds on packed indices) ----
-	for (int c0 = 0; c0 < m; c0 += 6) {
-		__syncthreads();
-		if (tid < 64) {
-			double a[21], ivr[6];
-#pragma unroll
-			for (int i = 0; i < 6; ++i)
-#pragma unroll
-				for (int k = 0; k <= i; ++k) a[i * (i + 1) / 2 + k] = SSK_PI(c0 + i, c0 + k);
-			bool bad = false;
-#pragma unroll
-			for (int j = 0; j < 6; ++j) {
-				const double d = a[j * (j + 1) / 2 + j];
-				bad |= !(d > 0.0);
-				ivr[j] = rcp_f64(d);
-#pragma unroll
-				for (int i = j + 1; i < 6; ++i) {
-					const double t = a[i * (i + 1) / 2 + j] * ivr[j];
-#pragma unroll
-					for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
-				}
-			}
-			for (int i = c0 + 6 + tid; i <= m; i += 64) {
-				double x[6];
-#pragma unroll
-				for (int k = 0; k < 6; ++k) x[k] = SSK_PI(i, c0 + k);
-#pragma unroll
-				for (int j = 0; j < 5; ++j) {
-					const double t = x[j] * ivr[j];
-#pragma unroll
-					for (int k = j + 1; k < 6; ++k) x[k] -= t * a[k * (k + 1) / 2 + j];
-				}
-#pragma unroll
-				for (int k = 1; k < 6; ++k) SSK_PI(i, c0 + k) = x[k];
-			}
-			if (tid == 0) {
-				s_ldl_bad_h = bad;
-#pragma unroll
-				for (int i = 0; i < 6; ++i) {
-					inv[n1 + c0 + i] = ivr[i];
-#pragma unroll
-					for (int k = 0; k < i; ++k) SSK_PI(c0 + i, c0 + k) = a[i * (i + 1) / 2 + k];
-				}
-			}
-		}
-		__syncthreads();
-		if (s_ldl_bad_h) return false;                    // uniform
-		double iv[6];
-#pragma unroll
-		for (int c = 0; c < 6; ++c) iv[c] = inv[n1 + c0 + c];
-		const int r0 = c0 + 6;
-		for (int ib = r0 + ty; ib <= m; ib += 4 * (NT / 32))
-			for (int kb = r0 + tx; kb < m; kb += 64) {
-				if (kb - tx > ib - ty + 4 * (NT / 32) - 1) break;    // the whole pass lies above the diagonal (uniform)
-				// unconditional loads on clamped indices; an (i, k) above the diagonal reads some other entry of the packed
-				// triangle (inside the allocation) and is never stored
-				double ui[4][6], uk[2][6], v[8];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const int i = min(ib + (NT / 32) * u, m);
-#pragma unroll
-					for (int c = 0; c < 6; ++c) ui[u][c] = SSK_PI(i, c0 + c);
-				}
-#pragma unroll
-				for (int w = 0; w < 2; ++w) {
-					const int k = min(kb + 32 * w, m - 1);
-#pragma unroll
-					for (int c = 0; c < 6; ++c) uk[w][c] = SSK_PI(k, c0 + c);
-				}
-#pragma unroll
-				for (int u = 0; u < 4; ++u)
-#pragma unroll
-					for (int w = 0; w < 2; ++w) {
-						const int i = min(ib + (NT / 32) * u, m), k = min(kb + 32 * w, m - 1);
-						v[2 * u + w] = SSK_PI(i, k);
-					}
-#pragma unroll
-				for (int u = 0; u < 4; ++u)
-#pragma unroll
-					for (int c = 0; c < 6; ++c) ui[u][c] *= iv[c];
-#pragma unroll
-				for (int u = 0; u < 4; ++u)
-#pragma unroll
-					for (int w = 0; w < 2; ++w) {
-						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
-						if (i <= m && k < m && k <= i) {
-							double sacc = 0.0;
-#pragma unroll
-							for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
-							SSK_PI(i, k) = v[2 * u + w] - sacc;
-						}
-					}
-			}
-	}
+	// ---- phase 3: blocked LDL^T of the packed block with look-ahead (ldl_solve_lds's factorisation on packed indices) ----
 	__syncthreads();
-	// ---- back-substitution, step A: x2 inside the packed block (rows from the last up; one barrier per row) ----
+	if (!ldl_factor_lookahead(P, ldl_ix_packed{}, m, inv + n1)) return false;
+	__syncthreads();
+	// ---- back-substitution x = D^-1 z - L'^T x by 16-row blocks from the bottom (two barriers per block, not one per row): inside a
+	//      block one wavefront (a lane per column, x of the rows above by readlane), then every earlier unknown takes the block's
+	//      16 terms at once.  Step A: x2 inside the packed block ----
+	const int lane = tid & 63, wave = tid >> 6;
 	for (int k = tid; k < m; k += NT) x_out[n1 + k] = SSK_PI(m, k) * inv[n1 + k];
 	for (int k = tid; k < n1; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
 	__syncthreads();
-	for (int i = m - 1; i > 0; --i) {
-		const double xi = x_out[n1 + i];
-		for (int k = tid; k < i; k += NT) x_out[n1 + k] -= SSK_PI(i, k) * inv[n1 + k] * xi;
+	for (int c = ((m - 1) >> 4) << 4; c >= 0; c -= 16) {
+		const int pw = m - c < 16 ? m - c : 16;
+		if (wave == 0) {
+			const int k = lane < pw ? lane : 0;
+			const double ivk = inv[n1 + c + k];
+			double u[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) u[i] = (i < pw && i > k) ? SSK_PI(c + i, c + k) * ivk : 0.0;
+			double xv = x_out[n1 + c + k];
+#pragma unroll
+			for (int i = 15; i >= 1; --i) {
+				const double xi = readlane_f64(xv, i);
+				if (i < pw) xv -= u[i] * xi;                    // (u[i] = 0 for k >= i)
+			}
+			if (lane < pw) x_out[n1 + c + lane] = xv;
+		}
+		__syncthreads();
+		for (int k = tid; k < c; k += NT) {
+			double sacc = 0.0;
+#pragma unroll
+			for (int i = 0; i < 16; ++i) { const int ii = c + (i < pw ? i : 0); sacc += i < pw ? SSK_PI(ii, k) * x_out[n1 + ii] : 0.0; }
+			x_out[n1 + k] -= sacc * inv[n1 + k];
+		}
 		__syncthreads();
 	}
 	if (n1 == 0) return true;
-	// ---- step B: every row's leading columns (k < n1) onto x1, rows staged from global memory `cr` at a time ----
-	int cr = lds_doubles / n1;
-	cr = cr > 64 ? 64 : cr;
-	for (int hi = n - 1; hi > 0; hi -= cr) {
-		const int lo = hi - cr + 1 > 1 ? hi - cr + 1 : 1;          // rows lo..hi
+	// ---- step B: the leading unknowns.  Rows >= n1 are final: their terms are one matrix-vector product (column k by lanes k of the
+	//      8 wavefronts, a row subset each, partial sums through LDS -- the packed block is dead); then the leading triangle by blocks ----
+	for (int kc = 0; kc < n1; kc += 64) {
+		const int k = kc + lane;
+		double sacc = 0.0;
+		if (k < n1) for (int i = n1 + wave; i < n; i += NW) sacc += A[(size_t)i * np + k] * x_out[i];
+		lds[tid] = sacc;
 		__syncthreads();
-		for (int t = tid; t < (hi - lo + 1) * n1; t += NT) {
-			const int r = t / n1, k = t - r * n1, i = lo + r;
-			{ const double av = A[(size_t)i * np + k] * inv[k]; lds[r * n1 + k] = k < i ? av : 0.0; }      // (unconditional load)
+		if (wave == 0 && k < n1) {
+			double t = 0.0;
+#pragma unroll
+			for (int q = 0; q < NW; ++q) t += lds[64 * q + lane];
+			x_out[k] -= t * inv[k];
 		}
 		__syncthreads();
-		for (int i = hi; i >= lo; --i) {
-			const double xi = x_out[i];
-			const int kend = i < n1 ? i : n1;
-			for (int k = tid; k < kend; k += NT) x_out[k] -= lds[(i - lo) * n1 + k] * xi;
-			__syncthreads();
+	}
+	for (int c = ((n1 - 1) >> 4) << 4; c >= 0; c -= 16) {
+		const int pw = n1 - c < 16 ? n1 - c : 16;
+		if (wave == 0) {
+			const int k = lane < pw ? lane : 0;
+			const double ivk = inv[c + k];
+			double u[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) u[i] = (i < pw && i > k) ? A[(size_t)(c + i) * np + c + k] * ivk : 0.0;
+			double xv = x_out[c + k];
+#pragma unroll
+			for (int i = 15; i >= 1; --i) {
+				const double xi = readlane_f64(xv, i);
+				if (i < pw) xv -= u[i] * xi;
+			}
+			if (lane < pw) x_out[c + lane] = xv;
 		}
+		__syncthreads();
+		for (int k = tid; k < c; k += NT) {
+			double sacc = 0.0;
+#pragma unroll
+			for (int i = 0; i < 16; ++i) { const int ii = c + (i < pw ? i : 0); sacc += i < pw ? A[(size_t)ii * np + k] * x_out[ii] : 0.0; }
+			x_out[k] -= sacc * inv[k];
+		}
+		__syncthreads();
 	}
 	return true;
 }

@@ -967,7 +967,7 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 
 // ACC: 0 = partial slots in HBM, 1 = on-chip accumulation with sparse Schur items, 2 = on-chip accumulation with the Schur
 // complement on the matrix cores
-template <bool COOP, int ACC = 0, bool SMF = false, bool LDLM = false>
+template <bool COOP, int ACC = 0, bool SMF = false, bool LDLM = false, bool LDSYS = false>
 __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, int dyn_doubles, int G, int coop_expect = 1, int coop_spin_limit = COOP_SPIN_LIMIT)
 {
 	static_assert(!(COOP && ACC), "the accumulators of a window live in one workgroup's LDS");
@@ -1002,7 +1002,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	double* gtab = D.suf_tab + W.gtab0 + (W.tab_lds ? 0 : 12 * (size_t)W.n_suf * g);
 	// the reduced system lives over the dead tile records when (n6 + 1) x (n6 | 1) doubles fit there (E <= ~22),
 	// otherwise in the window's L2-resident scratch (same blocked factorisation through plain pointers)
-	const bool lds_mat = (long long)(n6 + 1) * (n6 | 1) <= (long long)dyn_doubles - (reg - s_dyn);
+	// (LDSYS: the host found that every window's system fits: the L2-resident solver is compiled out)
+	const bool lds_mat = LDSYS || (long long)(n6 + 1) * (n6 | 1) <= (long long)dyn_doubles - (reg - s_dyn);
 	const int np = n6 | 1;
 #ifdef SSK_LM_STAMPS
 	__shared__ unsigned long long s_acc[16];
@@ -1288,6 +1289,12 @@ void lm_solve_coop_mfma_kernel(lm_dev D, lm_cam P, int dyn_doubles, int G, int e
 {
 	lm_tiled_body<true, 0, true>(D, P, dyn_doubles, G, expect, spin_limit);
 }
+// every reduced system of the batch fits LDS (E <= ~21: the batched per-keyframe windows): without the L2-resident solver
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_tiled_lds_kernel(lm_dev D, lm_cam P, int dyn_doubles)
+{
+	lm_tiled_body<false, 0, false, false, true>(D, P, dyn_doubles, 1);
+}
 // ... and the factorisation of an L2-resident reduced system in 16-column panels on the matrix cores (SSK_LM_LDL=mfma)
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
 void lm_solve_tiled_ldlm_kernel(lm_dev D, lm_cam P, int dyn_doubles)
@@ -1377,7 +1384,7 @@ int ssk_lm_launch_acc(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_wind
 	return SSK_OK;
 }
 
-int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma)
+int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma, bool lds_sys)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
 	static bool attr_set = false;
@@ -1388,11 +1395,14 @@ int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_wi
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_ldlm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		attr_set = true;
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	if (schur_mfma == 2) hipLaunchKernelGGL(lm_solve_tiled_ldlm_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
 	else if (schur_mfma) hipLaunchKernelGGL(lm_solve_tiled_mfma_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
+	else if (lds_sys) hipLaunchKernelGGL(lm_solve_tiled_lds_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
 	else hipLaunchKernelGGL(lm_solve_tiled_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
 	SSK_LAUNCH_CHECK(ctx, "lm_solve_tiled_kernel");
 	return SSK_OK;
