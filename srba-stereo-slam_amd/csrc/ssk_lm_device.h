@@ -196,6 +196,13 @@ __device__ unsigned long long g_ldl[4];
 #define LDL_T0() do {} while (0)
 #define LDL_ADD(i, who) do {} while (0)
 #endif
+#ifdef SSK_LM_STAMPS
+#define LDLH_T() unsigned long long ldlh_t_ = __builtin_amdgcn_s_memtime()
+#define LDLH_ADD(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_ldl[i] += t_ - ldlh_t_; ldlh_t_ = t_; } } while (0)
+#else
+#define LDLH_T() do {} while (0)
+#define LDLH_ADD(i) do {} while (0)
+#endif
 // index map of the in-LDS factorisation of a packed lower triangle (row i at i (i + 1) / 2)
 struct ldl_ix_packed { __device__ __forceinline__ int operator()(int i, int k) const { return i * (i + 1) / 2 + k; } };
 
@@ -734,12 +741,22 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 {
 	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
 	__shared__ int s_ldl_bad_h;
+	// LDS: [panel of a leading step: rows x 7 | packed trailing block]; the panel area is only needed when there are leading columns
 	int n1 = 0;
-	while (n1 < n && (long long)(n - n1 + 1) * (n - n1 + 2) / 2 > lds_doubles) n1 += 6;
+	while (n1 < n && (long long)(n - n1 + 1) * (n - n1 + 2) / 2 + (n1 ? 7 * (n + 1) : 0) > lds_doubles) n1 += 6;
 	if (n1 >= n) return ldl_solve_global(A, np, n, x_out, inv, lds, lds_doubles);      // (no room at all: never with the tiler's regions)
 	const int m = n - n1;
-	// ---- phase 1: columns 0 .. n1-1 in global memory, panel staged in LDS (as ldl_solve_global) ----
 	double* Pn = lds;
+	double* P = lds + (n1 ? 7 * (n + 1) : 0);
+	LDLH_T();
+	// ---- phase 1: the trailing block (rows n1 .. n, columns n1 .. row) into LDS, packed: it takes the updates of the leading
+	//      steps there, at LDS latency (in global memory a step's update of the whole matrix cost ~19 us, 2/3 of it this block) ----
+	for (int r = ty; r <= m; r += NT / 32) {
+		const int cend = r < m ? r : m - 1;
+		for (int c = tx; c <= cend; c += 32) SSK_PI(r, c) = A[(size_t)(n1 + r) * np + n1 + c];
+	}
+	LDLH_ADD(0);
+	// ---- phase 2: columns 0 .. n1-1 in global memory, six at a time, panel staged in LDS (as ldl_solve_global) ----
 	for (int c0 = 0; c0 < n1; c0 += 6) {
 		__syncthreads();
 		double a[21], ivr[6];
@@ -787,8 +804,10 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 		}
 		__syncthreads();
 		if (s_ldl_bad_h) return false;                    // uniform
+		// (a) the leading columns still to come, r0 <= k < n1, in global memory: 4 x 2 elements per thread and pass
+		if (r0 < n1)
 		for (int ib = r0 + ty; ib <= n; ib += 4 * (NT / 32))
-			for (int kb = r0 + tx; kb < n; kb += 64) {
+			for (int kb = r0 + tx; kb < n1; kb += 64) {
 				if (kb - tx > ib - ty + 4 * (NT / 32) - 1) break;    // the whole pass lies above the diagonal (uniform)
 				// unconditional loads on clamped indices (a load under a lane condition is compiled as a branch that waits for
 				// it at once); only the stores are predicated
@@ -801,14 +820,14 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 				}
 #pragma unroll
 				for (int w = 0; w < 2; ++w) {
-					const int k = min(kb + 32 * w, n - 1);
+					const int k = min(kb + 32 * w, n1 - 1);
 #pragma unroll
 					for (int c = 0; c < 6; ++c) uk[w][c] = Pn[(k - r0) * 7 + c];
 				}
 #pragma unroll
 				for (int u = 0; u < 4; ++u)
 #pragma unroll
-					for (int w = 0; w < 2; ++w) v[2 * u + w] = A[(size_t)min(ib + (NT / 32) * u, n) * np + min(kb + 32 * w, n - 1)];
+					for (int w = 0; w < 2; ++w) v[2 * u + w] = A[(size_t)min(ib + (NT / 32) * u, n) * np + min(kb + 32 * w, n1 - 1)];
 #pragma unroll
 				for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -818,7 +837,7 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 #pragma unroll
 					for (int w = 0; w < 2; ++w) {
 						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
-						if (i <= n && k < n && k <= i) {
+						if (i <= n && k < n1 && k <= i) {
 							double sacc = 0.0;
 #pragma unroll
 							for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
@@ -826,18 +845,56 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 						}
 					}
 			}
-	}
-	__syncthreads();
-	// ---- phase 2: the trailing block (rows n1 .. n, columns n1 .. row) into LDS, packed ----
-	double* P = lds;
-	for (int r = ty; r <= m; r += NT / 32) {
-		const int cend = r < m ? r : m - 1;
-		for (int c = tx; c <= cend; c += 32) SSK_PI(r, c) = A[(size_t)(n1 + r) * np + n1 + c];
+		// (b) the trailing block in LDS: rows n1 + ii, columns n1 + kk, kk <= min(ii, m - 1); panel row of matrix row i: i - r0
+		const int po = n1 - r0;
+		for (int ib = ty; ib <= m; ib += 4 * (NT / 32))
+			for (int kb = tx; kb < m; kb += 64) {
+				if (kb - tx > ib - ty + 4 * (NT / 32) - 1) break;    // the whole pass lies above the diagonal (uniform)
+				// an (ii, kk) above the diagonal reads some other entry of the packed triangle (inside the allocation), never stored
+				double ui[4][6], uk[2][6], v[8];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int i = min(ib + (NT / 32) * u, m);
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] = Pn[(i + po) * 7 + c];
+				}
+#pragma unroll
+				for (int w = 0; w < 2; ++w) {
+					const int k = min(kb + 32 * w, m - 1);
+#pragma unroll
+					for (int c = 0; c < 6; ++c) uk[w][c] = Pn[(k + po) * 7 + c];
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = min(ib + (NT / 32) * u, m), k = min(kb + 32 * w, m - 1);
+						v[2 * u + w] = SSK_PI(i, k);
+					}
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ui[u][c] *= ivr[c];
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+#pragma unroll
+					for (int w = 0; w < 2; ++w) {
+						const int i = ib + (NT / 32) * u, k = kb + 32 * w;
+						if (i <= m && k < m && k <= i) {
+							double sacc = 0.0;
+#pragma unroll
+							for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
+							SSK_PI(i, k) = v[2 * u + w] - sacc;
+						}
+					}
+			}
 	}
 	// ---- phase 3: blocked LDL^T of the packed block with look-ahead (ldl_solve_lds's factorisation on packed indices) ----
 	__syncthreads();
+	LDLH_ADD(1);
 	if (!ldl_factor_lookahead(P, ldl_ix_packed{}, m, inv + n1)) return false;
 	__syncthreads();
+	LDLH_ADD(2);
 	// ---- back-substitution x = D^-1 z - L'^T x by 16-row blocks from the bottom (two barriers per block, not one per row): inside a
 	//      block one wavefront (a lane per column, x of the rows above by readlane), then every earlier unknown takes the block's
 	//      16 terms at once.  Step A: x2 inside the packed block ----
@@ -870,48 +927,60 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 		}
 		__syncthreads();
 	}
-	if (n1 == 0) return true;
-	// ---- step B: the leading unknowns.  Rows >= n1 are final: their terms are one matrix-vector product (column k by lanes k of the
-	//      8 wavefronts, a row subset each, partial sums through LDS -- the packed block is dead); then the leading triangle by blocks ----
-	for (int kc = 0; kc < n1; kc += 64) {
-		const int k = kc + lane;
-		double sacc = 0.0;
-		if (k < n1) for (int i = n1 + wave; i < n; i += NW) sacc += A[(size_t)i * np + k] * x_out[i];
-		lds[tid] = sacc;
+	if (n1 == 0) { LDLH_ADD(3); return true; }
+	// ---- step B: the leading unknowns.  The leading columns of the rows come into LDS (the packed block is dead), scaled by the
+	//      pivots and zero from the diagonal on, as many rows at a time as fit (all of them up to ~45 edges), from the last row up.
+	//      Rows >= n1 are final: unknown k < n1 takes their terms in one pass (a lane per k); the leading triangle goes by 16-row
+	//      blocks as above ----
+	const int cr = lds_doubles / n1 < n ? lds_doubles / n1 : n;
+	for (int hi = n - 1; hi >= 1;) {
+		const int lo = hi - cr + 1 > 1 ? hi - cr + 1 : 1;
 		__syncthreads();
-		if (wave == 0 && k < n1) {
-			double t = 0.0;
-#pragma unroll
-			for (int q = 0; q < NW; ++q) t += lds[64 * q + lane];
-			x_out[k] -= t * inv[k];
+		for (int t = tid; t < (hi - lo + 1) * n1; t += NT) {
+			const int r = t / n1, k = t - r * n1, i = lo + r;
+			const double av = A[(size_t)i * np + k] * inv[k];      // (unconditional load)
+			lds[t] = k < i ? av : 0.0;
 		}
 		__syncthreads();
-	}
-	for (int c = ((n1 - 1) >> 4) << 4; c >= 0; c -= 16) {
-		const int pw = n1 - c < 16 ? n1 - c : 16;
-		if (wave == 0) {
-			const int k = lane < pw ? lane : 0;
-			const double ivk = inv[c + k];
-			double u[16];
-#pragma unroll
-			for (int i = 0; i < 16; ++i) u[i] = (i < pw && i > k) ? A[(size_t)(c + i) * np + c + k] * ivk : 0.0;
-			double xv = x_out[c + k];
-#pragma unroll
-			for (int i = 15; i >= 1; --i) {
-				const double xi = readlane_f64(xv, i);
-				if (i < pw) xv -= u[i] * xi;
+		const int ilo = lo > n1 ? lo : n1;
+		if (hi >= ilo) {
+			for (int k = tid; k < n1; k += NT) {
+				double s0 = 0.0, s1 = 0.0;
+				int i = ilo;
+				for (; i + 1 <= hi; i += 2) { s0 += lds[(i - lo) * n1 + k] * x_out[i]; s1 += lds[(i + 1 - lo) * n1 + k] * x_out[i + 1]; }
+				if (i <= hi) s0 += lds[(i - lo) * n1 + k] * x_out[i];
+				x_out[k] -= s0 + s1;
 			}
-			if (lane < pw) x_out[c + lane] = xv;
+			__syncthreads();
 		}
-		__syncthreads();
-		for (int k = tid; k < c; k += NT) {
-			double sacc = 0.0;
+		for (int bh = hi < n1 - 1 ? hi : n1 - 1; bh >= lo;) {
+			const int bl = bh - 15 > lo ? bh - 15 : lo, pw = bh - bl + 1;
+			if (wave == 0) {
+				const int k = lane < pw ? lane : 0;
+				double u[16];
 #pragma unroll
-			for (int i = 0; i < 16; ++i) { const int ii = c + (i < pw ? i : 0); sacc += i < pw ? A[(size_t)ii * np + k] * x_out[ii] : 0.0; }
-			x_out[k] -= sacc * inv[k];
+				for (int i = 0; i < 16; ++i) u[i] = i < pw ? lds[(bl + i - lo) * n1 + bl + k] : 0.0;      // (zero for k >= i)
+				double xv = x_out[bl + k];
+#pragma unroll
+				for (int i = 15; i >= 1; --i) {
+					const double xi = readlane_f64(xv, i);
+					if (i < pw) xv -= u[i] * xi;
+				}
+				if (lane < pw) x_out[bl + lane] = xv;
+			}
+			__syncthreads();
+			for (int k = tid; k < bl; k += NT) {
+				double sacc = 0.0;
+#pragma unroll
+				for (int i = 0; i < 16; ++i) sacc += i < pw ? lds[(bl + (i < pw ? i : 0) - lo) * n1 + k] * x_out[bl + (i < pw ? i : 0)] : 0.0;
+				x_out[k] -= sacc;
+			}
+			__syncthreads();
+			bh = bl - 1;
 		}
-		__syncthreads();
+		hi = lo - 1;
 	}
+	LDLH_ADD(3);
 	return true;
 }
 #undef SSK_PI
