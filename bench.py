@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1241, 376
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LM_KERNEL = "lm_solve_tiled_lds_kernel"      # the bench windows (E = 10): every reduced system fits LDS, the variant without the L2-resident solver
 FP64_PEAK_TFLOPS = 78.6    # AMD MI355X data sheet: FP64 vector = FP64 matrix (MFMA) 78.6 TFLOP/s (the guide lists no FP64 row)
 
 
@@ -554,11 +555,11 @@ def main():
                 "lm_window": {"edges": int(wins[0].E), "landmarks": int(wins[0].L), "observations": int(len(wins[0].obs_lm)),
                               "mean_iters": float(np.mean([r.iters for r in res]))},
             },
-            "roofline": {"kernel": "lm_solve_tiled_kernel", "bound": "hbm", "achieved": lm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic.get("lm_solve_tiled_kernel"),
+            "roofline": {"kernel": LM_KERNEL, "bound": "hbm", "achieved": lm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic.get(LM_KERNEL),
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
                          "note": "dominant kernel by time; latency bound at 2 waves/SIMD (profiles/r02_pmc_sq.json: waves wait 64 % of their time), not bandwidth bound (DESIGN.md 5, 9)"},
-            "roofline_fp64": {"kernel": "lm_solve_tiled_kernel", "bound": "mfma", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline_fp64": {"kernel": LM_KERNEL, "bound": "mfma", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
                               "note": "the same launch priced in FP64 flops (SURVEY 8(d) per-unit figures); FP64 MFMA rate = FP64 vector rate on MI355X, "
                                       "the kernel issues vector FP64 (block-sparse 6x6 / 6x3 products, DESIGN.md 5)"},

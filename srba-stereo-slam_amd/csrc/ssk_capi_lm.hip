@@ -360,6 +360,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	const int MAX_ITERS_ALLOC = 64;
 	static const bool timing = std::getenv("SSK_TIMING") != nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
+	double t_sub[4] = {0, 0, 0, 0};                        // inside the tile loop: footprints, cut, records (rest: groups and tasks)
 	double t_ph[5] = {0, 0, 0, 0, 0};                      // per window: validation + incidences, suffix trie, tile loop, concatenation
 	auto tnow = [] { return std::chrono::steady_clock::now(); };
 	auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
@@ -627,6 +628,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				}
 				tot += 8 * (SSK_LMT_ENT * fp_P[oi] + SSK_LMT_OBS * fp_O[oi] + fp_Y[oi] + SSK_LMT_LMR);
 			}
+			const auto ts_pre = tnow(); t_sub[0] += tms(tp2, ts_pre);
 			const long long est_tiles = std::max<long long>(1, (tot + region_bytes * 9 / 10 - 1) / (region_bytes * 9 / 10));
 			const long long target = (tot + est_tiles - 1) / est_tiles;
 			std::vector<int> path_loc((size_t)n_path, -1);
@@ -660,9 +662,23 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					}
 				}
 			};
+			// the items of a tile by block pair id, stable: a counting sort (a tile has a few hundred items over <= E (E + 1) / 2 ids)
+			std::vector<item> pitems, qitems, sort_tmp;
+			std::vector<int> sort_cnt((size_t)n_pairs + 1);
+			auto sort_by_pid = [&](std::vector<item>& items) {
+				if (items.size() < 2) return;
+				std::fill(sort_cnt.begin(), sort_cnt.end(), 0);
+				for (const item& x : items) ++sort_cnt[(size_t)x.pid + 1];
+				for (int i = 0; i < n_pairs; ++i) sort_cnt[(size_t)i + 1] += sort_cnt[(size_t)i];
+				sort_tmp.resize(items.size());
+				for (const item& x : items) sort_tmp[(size_t)sort_cnt[(size_t)x.pid]++] = x;
+				items.swap(sort_tmp);
+			};
+			std::vector<std::pair<int, int>> steps;
 			size_t oi = 0;
 			int lme_cursor = 0;
 			while (oi < order.size() && tiled) {
+				const auto ts_a = tnow();
 				lm_tile T{};
 				T.lml0 = (int)oi; T.obs0 = (int)w_tobs_a.size(); T.inc0 = lme_cursor; T.ent0 = (int)w_tent.size(); T.il0 = (int)w_ilane.size();
 				long long nP = 0, nO = 0, nM = 0, nL = 0, nY = 0, var = 0, nS = 0, nIL = 0;
@@ -686,6 +702,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					if (var >= target) { ++oj; break; }
 				}
 				if (oj == oi) { tiled = false; break; }          // one landmark alone does not fit
+				const auto ts_b = tnow(); t_sub[1] += tms(ts_a, ts_b);
 				// !tab_lds: the tile's suffix list, tile-local id = position
 				T.tsuf0 = (int)w_tsuf.size(); T.n_tsuf = 0;
 				if (!tab_lds)
@@ -694,7 +711,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 							if (suf_local[sid] < T.tsuf0) { suf_local[sid] = (int)w_tsuf.size(); w_tsuf.push_back(sid); }
 				T.n_tsuf = (int)w_tsuf.size() - T.tsuf0;
 				auto local_suf = [&](int sid) { return tab_lds ? sid : suf_local[sid] - T.tsuf0; };
-				std::vector<item> pitems, qitems;
+				pitems.clear(); qitems.clear();
 				int n_ent = 0, n_pan = 0;
 				for (size_t ok = oi; ok < oj; ++ok) {
 					const int l = order[ok], j = (int)(ok - oi);
@@ -706,7 +723,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 						w_tobs_a.push_back(make_int4(n_ent | (__builtin_popcount(om) << 16), Wn.obs_lm[o], local_suf(obs_suf[o]), obs_suf[o]));
 						w_tobs_px.push_back(make_float4(Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]));
 						in_tile[o] = 1;
-						std::vector<std::pair<int, int>> steps;      // (edge slot, local entry)
+						steps.clear();                               // (edge slot, local entry)
 						for (int i = 0; i < len; ++i)
 							if ((om >> i) & 1) {
 								const int le = n_ent + __builtin_popcount(om & ((1 << i) - 1));
@@ -747,13 +764,13 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 								                  (lm_lmes[ok][a] - T.inc0) | ((lm_lmes[ok][b2] - T.inc0) << 16)});
 					lme_cursor += (int)lm_lmes[ok].size();
 				}
+				const auto ts_c = tnow(); t_sub[2] += tms(ts_b, ts_c);
 				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_a.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0; T.n_pan = panels ? n_pan : 0;
 				T.n_il = (int)w_ilane.size() - T.il0;
 				T.pg0 = (int)w_pgrp.size(); T.pc0 = (int)w_pslot0.size();
 				// one chunk task per wave: the smallest R whose H_pp + Schur chunks fit one round of the workgroup's waves
-				auto by_pid = [](const item& a, const item& b) { return a.pid < b.pid; };
-				std::stable_sort(pitems.begin(), pitems.end(), by_pid);
-				std::stable_sort(qitems.begin(), qitems.end(), by_pid);
+				sort_by_pid(pitems);
+				sort_by_pid(qitems);
 				if (!acc && panels) {
 				// slot kernels, matrix-core Schur: H_pp chunks on half the waves, beside them one task per 16x16 tile of the reduced system
 				// that the tile's landmarks touch, most landmarks first; a task leaves a 256-double partial in HBM
@@ -1083,6 +1100,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
 		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create (%d windows): symbolic %.3f ms (incidences %.3f, suffix trie %.3f, tiles %.3f, concatenation %.3f), allocate + upload %.3f ms\n",
 		             n_windows, ms(t_begin, t_sym), t_ph[0], t_ph[1], t_ph[2], t_ph[3], ms(t_sym, std::chrono::steady_clock::now()));
+		std::fprintf(stderr, "[ssk timing]   tiles: footprints %.3f ms, cut %.3f, records %.3f\n", t_sub[0], t_sub[1], t_sub[2]);
 	}
 	*out = b;
 	return SSK_OK;
