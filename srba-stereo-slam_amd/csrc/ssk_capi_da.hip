@@ -138,31 +138,29 @@ int ssk_data_association(ssk_ctx* ctx, const ssk_kf_view* a, const ssk_kf_view* 
 	int rc;
 	const size_t sa = (size_t)na, sb = (size_t)(nb > 0 ? nb : 1);
 	const size_t nLa = (size_t)a->n_left, nLb = (size_t)(b->n_left > 0 ? b->n_left : 1);
-	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad(nLa * 32) + ssk_pad(nLb * 32) + 4 * ssk_pad(sa * 4) + ssk_pad(sb * 4) +
-	                                               ssk_pad(sa * 8) + ssk_pad(sb * 8) + 12 * 256))) return rc;
-	if ((rc = ssk_arena_reserve(ctx, ctx->pin, 4 * ssk_pad(sa * 4) + ssk_pad(sb * 4) + ssk_pad(sa * 8) + ssk_pad(sb * 8) + 10 * 256))) return rc;
+	const size_t in_bytes = ssk_pad(nLa * 32) + ssk_pad(nLb * 32) + ssk_pad(sa * 4) + ssk_pad(sb * 4) + ssk_pad(sa * 8) + ssk_pad(sb * 8) + ssk_pad(16);
+	const size_t out_bytes = 3 * ssk_pad(sa * 4) + ssk_pad(4);
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, in_bytes + out_bytes + 4 * 256))) return rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->pin, in_bytes + out_bytes + 4 * 256))) return rc;
 	ssk_arena_reset(ctx->dev); ssk_arena_reset(ctx->pin);
 	// device: whole left descriptor blocks of both KFs + gather lists (match -> left keypoint row), so the
-	// "matched-only" matrices curLDesc / preLDesc (EST.cpp:1351-1358,1432-1439) are never built.
-	uint8_t* d_da = ssk_arena_take<uint8_t>(ctx->dev, nLa * 32);
-	uint8_t* d_db = ssk_arena_take<uint8_t>(ctx->dev, nLb * 32);
-	int32_t* d_ga = ssk_arena_take<int32_t>(ctx->dev, sa);
-	int32_t* d_gb = ssk_arena_take<int32_t>(ctx->dev, sb);
-	int32_t* d_idx = ssk_arena_take<int32_t>(ctx->dev, sa);
-	int32_t* d_dist = ssk_arena_take<int32_t>(ctx->dev, sa);
-	int32_t* d_status = ssk_arena_take<int32_t>(ctx->dev, sa);
-	float* d_axy = ssk_arena_take<float>(ctx->dev, 2 * sa);
-	float* d_bxy = ssk_arena_take<float>(ctx->dev, 2 * sb);
-	int32_t* d_off = ssk_arena_take<int32_t>(ctx->dev, 4);
-	int32_t* d_tracked = ssk_arena_take<int32_t>(ctx->dev, 1);
-	int32_t* h_ga = ssk_arena_take<int32_t>(ctx->pin, sa);
-	int32_t* h_gb = ssk_arena_take<int32_t>(ctx->pin, sb);
-	float* h_axy = ssk_arena_take<float>(ctx->pin, 2 * sa);
-	float* h_bxy = ssk_arena_take<float>(ctx->pin, 2 * sb);
-	int32_t* h_idx = ssk_arena_take<int32_t>(ctx->pin, sa);
-	int32_t* h_dist = ssk_arena_take<int32_t>(ctx->pin, sa);
-	int32_t* h_status = ssk_arena_take<int32_t>(ctx->pin, sa);
-	int32_t* h_tracked = ssk_arena_take<int32_t>(ctx->pin, 1);
+	// "matched-only" matrices curLDesc / preLDesc (EST.cpp:1351-1358,1432-1439) are never built.  One transfer in, one out.
+	ssk_xfer_pack in; in.begin(ctx, in_bytes + out_bytes);
+	int32_t *h_ga, *h_gb, *h_off, *h_idx, *h_dist, *h_status, *h_tracked;
+	float *h_axy, *h_bxy;
+	const uint8_t* d_da = in.put(a->desc_left, nLa * 32);
+	const uint8_t* d_db = in.put(b->desc_left, b->n_left > 0 ? (size_t)b->n_left * 32 : 0);
+	in.off = ssk_pad(nLa * 32) + ssk_pad(nLb * 32);          // (an empty other keyframe still owns its padded slot)
+	int32_t* d_ga = in.slot<int32_t>(sa, &h_ga);
+	int32_t* d_gb = in.slot<int32_t>(sb, &h_gb);
+	float* d_axy = in.slot<float>(2 * sa, &h_axy);
+	float* d_bxy = in.slot<float>(2 * sb, &h_bxy);
+	int32_t* d_off = in.slot<int32_t>(4, &h_off);
+	const size_t in_end = in.off;
+	int32_t* d_idx = in.slot<int32_t>(sa, &h_idx);
+	int32_t* d_dist = in.slot<int32_t>(sa, &h_dist);
+	int32_t* d_status = in.slot<int32_t>(sa, &h_status);
+	int32_t* d_tracked = in.slot<int32_t>(1, &h_tracked);
 	for (int k = 0; k < na; ++k) {
 		const int i = a->matches[k].queryIdx;
 		h_ga[k] = i; h_axy[2 * k] = a->kp_left[i].x; h_axy[2 * k + 1] = a->kp_left[i].y;
@@ -171,20 +169,11 @@ int ssk_data_association(ssk_ctx* ctx, const ssk_kf_view* a, const ssk_kf_view* 
 		const int i = b->matches[k].queryIdx;
 		h_gb[k] = i; h_bxy[2 * k] = b->kp_left[i].x; h_bxy[2 * k + 1] = b->kp_left[i].y;
 	}
-	const int32_t off[4] = {0, na, 0, nb};
-	SSK_HIP(ctx, hipMemcpyAsync(d_da, a->desc_left, nLa * 32, hipMemcpyHostToDevice, ctx->stream));
-	if (b->n_left > 0) SSK_HIP(ctx, hipMemcpyAsync(d_db, b->desc_left, (size_t)b->n_left * 32, hipMemcpyHostToDevice, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(d_ga, h_ga, sa * 4, hipMemcpyHostToDevice, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(d_axy, h_axy, sa * 8, hipMemcpyHostToDevice, ctx->stream));
-	if (nb > 0) {
-		SSK_HIP(ctx, hipMemcpyAsync(d_gb, h_gb, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream));
-		SSK_HIP(ctx, hipMemcpyAsync(d_bxy, h_bxy, (size_t)nb * 8, hipMemcpyHostToDevice, ctx->stream));
-	}
-	SSK_HIP(ctx, hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
+	h_off[0] = 0; h_off[1] = na; h_off[2] = 0; h_off[3] = nb;
+	SSK_HIP(ctx, in.upload(ctx->stream, 0, in_end));
 	if ((rc = ssk_launch_hamming(ctx, d_da, d_off, d_off + 1, d_ga, d_db, d_off + 2, d_off + 3, d_gb, nullptr, 1, na, d_idx, d_dist))) return rc;
-	if ((rc = run_filters_and_fetch(ctx, d_idx, d_dist, d_off, d_axy, d_bxy, params, na, d_status, d_tracked, h_status, h_tracked))) return rc;
-	SSK_HIP(ctx, hipMemcpyAsync(h_idx, d_idx, sa * 4, hipMemcpyDeviceToHost, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(h_dist, d_dist, sa * 4, hipMemcpyDeviceToHost, ctx->stream));
+	if ((rc = ssk_launch_da_filters(ctx, d_idx, d_dist, nullptr, d_off, d_off + 1, d_off + 2, d_off + 3, d_axy, d_bxy, 1, *params, d_status, d_tracked))) return rc;
+	SSK_HIP(ctx, in.download(ctx->stream, in_end, in.off));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	for (int k = 0; k < na; ++k) {
 		out_matches[k].queryIdx = k; out_matches[k].trainIdx = h_idx[k]; out_matches[k].imgIdx = 0;

@@ -195,26 +195,36 @@ int ssk_kfbatch_download(ssk_ctx* ctx, ssk_kfbatch* b, int kf, ssk_kf_out* out)
 	if (!b || !out || kf < 0 || kf >= b->n_kf || !out->kp_left || !out->kp_right || !out->desc_left || !out->desc_right || !out->matches)
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_kfbatch_download: bad argument");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
-	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	// every array of the keyframe into the pinned arena behind one synchronisation (ten blocking copies cost 0.15 ms per frame)
 	const int N = b->max_feats;
-	int32_t cnt[3];
-	SSK_HIP(ctx, hipMemcpy(cnt, b->nkp + 2 * kf, 8, hipMemcpyDeviceToHost));
-	SSK_HIP(ctx, hipMemcpy(cnt + 2, b->nm + kf, 4, hipMemcpyDeviceToHost));
+	int rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->pin, ssk_pad(16) + ssk_pad(sizeof(short2) * 2 * N) + 2 * ssk_pad(sizeof(float) * 2 * N) + ssk_pad((size_t)2 * N * 32) +
+	                                               3 * ssk_pad(sizeof(int32_t) * N) + 2 * 256))) return rc;
+	ssk_arena_reset(ctx->pin);
+	int32_t* cnt = ssk_arena_take<int32_t>(ctx->pin, 4);
+	short2* xy = ssk_arena_take<short2>(ctx->pin, (size_t)2 * N);
+	float* resp = ssk_arena_take<float>(ctx->pin, (size_t)2 * N);
+	float* ang = ssk_arena_take<float>(ctx->pin, (size_t)2 * N);
+	uint8_t* desc = ssk_arena_take<uint8_t>(ctx->pin, (size_t)2 * N * 32);
+	int32_t* mq = ssk_arena_take<int32_t>(ctx->pin, N);
+	int32_t* mt = ssk_arena_take<int32_t>(ctx->pin, N);
+	int32_t* md = ssk_arena_take<int32_t>(ctx->pin, N);
+	const size_t o = (size_t)kf * 2 * N;
+	SSK_HIP(ctx, hipMemcpyAsync(cnt, b->nkp + 2 * kf, 8, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(cnt + 2, b->nm + kf, 4, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(xy, b->kp_xy + o, sizeof(short2) * 2 * N, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(resp, b->kp_resp + o, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(ang, b->kp_angle + o, sizeof(float) * 2 * N, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(desc, b->desc + o * 32, (size_t)2 * N * 32, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(mq, b->m_q + (size_t)kf * N, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(mt, b->m_t + (size_t)kf * N, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(md, b->m_d + (size_t)kf * N, sizeof(int32_t) * N, hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	const int nl = cnt[0], nr = cnt[1], nmm = cnt[2];
 	if (nl > out->capacity || nr > out->capacity || nmm > out->capacity)
 		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_kfbatch_download: capacity %d < %d/%d/%d", out->capacity, nl, nr, nmm);
-	std::vector<short2> xy((size_t)2 * N);
-	std::vector<float> resp((size_t)2 * N), ang((size_t)2 * N);
-	std::vector<int32_t> mq(N), mt(N), md(N);
-	const size_t o = (size_t)kf * 2 * N;
-	SSK_HIP(ctx, hipMemcpy(xy.data(), b->kp_xy + o, sizeof(short2) * 2 * N, hipMemcpyDeviceToHost));
-	SSK_HIP(ctx, hipMemcpy(resp.data(), b->kp_resp + o, sizeof(float) * 2 * N, hipMemcpyDeviceToHost));
-	SSK_HIP(ctx, hipMemcpy(ang.data(), b->kp_angle + o, sizeof(float) * 2 * N, hipMemcpyDeviceToHost));
-	if (nl) SSK_HIP(ctx, hipMemcpy(out->desc_left, b->desc + o * 32, (size_t)nl * 32, hipMemcpyDeviceToHost));
-	if (nr) SSK_HIP(ctx, hipMemcpy(out->desc_right, b->desc + (o + N) * 32, (size_t)nr * 32, hipMemcpyDeviceToHost));
-	SSK_HIP(ctx, hipMemcpy(mq.data(), b->m_q + (size_t)kf * N, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
-	SSK_HIP(ctx, hipMemcpy(mt.data(), b->m_t + (size_t)kf * N, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
-	SSK_HIP(ctx, hipMemcpy(md.data(), b->m_d + (size_t)kf * N, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+	if (nl) std::memcpy(out->desc_left, desc, (size_t)nl * 32);
+	if (nr) std::memcpy(out->desc_right, desc + (size_t)N * 32, (size_t)nr * 32);
 	for (int e = 0; e < 2; ++e) {
 		ssk_keypoint* kp = e ? out->kp_right : out->kp_left;
 		const int n = e ? nr : nl;

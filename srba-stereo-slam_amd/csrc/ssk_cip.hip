@@ -327,36 +327,34 @@ int ssk_cip_filter(ssk_ctx* ctx, const float* this_obs, int n_this, const float*
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	const size_t nt = (size_t)(n_this > 0 ? n_this : 1), no = (size_t)(n_other > 0 ? n_other : 1);
 	int rc;
-	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad(16 * nt) + ssk_pad(16 * no) + 2 * ssk_pad(4 * nt) + ssk_pad(8 * nt) + ssk_pad(96) +
-	                                               ssk_pad(sizeof(ssk_cip_result)) + ssk_pad(64) + 10 * 256))) return rc;
-	if ((rc = ssk_arena_reserve(ctx, ctx->pin, ssk_pad(4 * nt) + ssk_pad(8 * nt) + ssk_pad(sizeof(ssk_cip_result)) + 4 * 256))) return rc;
+	const size_t total = ssk_pad(16 * nt) + ssk_pad(16 * no) + 2 * ssk_pad(4 * nt) + ssk_pad(8 * nt) + ssk_pad(96) + ssk_pad(sizeof(ssk_cip_result)) + ssk_pad(16);
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, total + 2 * 256))) return rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->pin, total + 2 * 256))) return rc;
 	ssk_arena_reset(ctx->dev); ssk_arena_reset(ctx->pin);
-	float4* d_to = ssk_arena_take<float4>(ctx->dev, nt);
-	float4* d_oo = ssk_arena_take<float4>(ctx->dev, no);
-	int32_t* d_ti = ssk_arena_take<int32_t>(ctx->dev, nt);
-	int32_t* d_st = ssk_arena_take<int32_t>(ctx->dev, nt);
-	double* d_res = ssk_arena_take<double>(ctx->dev, nt);
-	double* d_T = ssk_arena_take<double>(ctx->dev, 12);
-	ssk_cip_result* d_out = ssk_arena_take<ssk_cip_result>(ctx->dev, 1);
-	int32_t* d_rng = ssk_arena_take<int32_t>(ctx->dev, 4);
-	int32_t* h_st = ssk_arena_take<int32_t>(ctx->pin, nt);
-	double* h_res = ssk_arena_take<double>(ctx->pin, nt);
-	ssk_cip_result* h_out = ssk_arena_take<ssk_cip_result>(ctx->pin, 1);
-	const int32_t rng[4] = {0, n_this, 0, 0};              // q_beg, q_end, t_beg, out_beg
-	if (n_this) {
-		SSK_HIP(ctx, hipMemcpyAsync(d_to, this_obs, 16 * (size_t)n_this, hipMemcpyHostToDevice, ctx->stream));
-		SSK_HIP(ctx, hipMemcpyAsync(d_ti, train_idx, 4 * (size_t)n_this, hipMemcpyHostToDevice, ctx->stream));
-		SSK_HIP(ctx, hipMemcpyAsync(d_st, status, 4 * (size_t)n_this, hipMemcpyHostToDevice, ctx->stream));
-	}
-	if (n_other) SSK_HIP(ctx, hipMemcpyAsync(d_oo, other_obs, 16 * (size_t)n_other, hipMemcpyHostToDevice, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(d_T, init_pose, 96, hipMemcpyHostToDevice, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(d_rng, rng, sizeof rng, hipMemcpyHostToDevice, ctx->stream));
+	// one transfer in (observations, train indices, start pose, ranges, statuses), one out (statuses, residuals, result)
+	ssk_xfer_pack pk; pk.begin(ctx, total);
+	int32_t* h_rng;
+	double* h_res;
+	ssk_cip_result* h_out;
+	float4* d_to = pk.put(reinterpret_cast<const float4*>(this_obs), (size_t)n_this);
+	pk.off = ssk_pad(16 * nt);
+	float4* d_oo = pk.put(reinterpret_cast<const float4*>(other_obs), (size_t)n_other);
+	pk.off = ssk_pad(16 * nt) + ssk_pad(16 * no);
+	int32_t* d_ti = pk.put(train_idx, (size_t)n_this);
+	pk.off = ssk_pad(16 * nt) + ssk_pad(16 * no) + ssk_pad(4 * nt);
+	double* d_T = pk.put(init_pose, 12);
+	int32_t* d_rng = pk.slot<int32_t>(4, &h_rng);
+	h_rng[0] = 0; h_rng[1] = n_this; h_rng[2] = 0; h_rng[3] = 0;      // q_beg, q_end, t_beg, out_beg
+	const size_t st_begin = pk.off;
+	int32_t* d_st = pk.put(status, (size_t)n_this);
+	pk.off = st_begin + ssk_pad(4 * nt);
+	const int32_t* h_st = reinterpret_cast<const int32_t*>(pk.h + st_begin);
+	const size_t in_end = pk.off;
+	double* d_res = pk.slot<double>(nt, &h_res);
+	ssk_cip_result* d_out = pk.slot<ssk_cip_result>(1, &h_out);
+	SSK_HIP(ctx, pk.upload(ctx->stream, 0, in_end));
 	if ((rc = ssk_launch_cip(ctx, d_ti, d_st, d_rng + 3, d_rng, d_rng + 1, d_rng + 2, d_to, d_oo, d_T, 1, n_this, *params, d_res, d_out, nullptr))) return rc;
-	if (n_this) {
-		SSK_HIP(ctx, hipMemcpyAsync(h_st, d_st, 4 * (size_t)n_this, hipMemcpyDeviceToHost, ctx->stream));
-		SSK_HIP(ctx, hipMemcpyAsync(h_res, d_res, 8 * (size_t)n_this, hipMemcpyDeviceToHost, ctx->stream));
-	}
-	SSK_HIP(ctx, hipMemcpyAsync(h_out, d_out, sizeof(ssk_cip_result), hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, pk.download(ctx->stream, st_begin, pk.off));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	int j = 0;
 	for (int k = 0; k < n_this; ++k) {

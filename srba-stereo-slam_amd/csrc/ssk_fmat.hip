@@ -356,28 +356,31 @@ int ssk_fm_filter(ssk_ctx* ctx, const float* this_xy, int n_this, const float* o
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	const size_t nt = (size_t)(n_this > 0 ? n_this : 1), no = (size_t)(n_other > 0 ? n_other : 1);
 	int rc;
-	if ((rc = ssk_arena_reserve(ctx, ctx->dev, ssk_pad(8 * nt) + ssk_pad(8 * no) + 2 * ssk_pad(4 * nt) + ssk_pad(sizeof(ssk_fm_result)) + ssk_pad(64) + 8 * 256))) return rc;
-	if ((rc = ssk_arena_reserve(ctx, ctx->pin, ssk_pad(4 * nt) + ssk_pad(sizeof(ssk_fm_result)) + 4 * 256))) return rc;
+	const size_t total = ssk_pad(8 * nt) + ssk_pad(8 * no) + 2 * ssk_pad(4 * nt) + ssk_pad(sizeof(ssk_fm_result)) + ssk_pad(16);
+	if ((rc = ssk_arena_reserve(ctx, ctx->dev, total + 2 * 256))) return rc;
+	if ((rc = ssk_arena_reserve(ctx, ctx->pin, total + 2 * 256))) return rc;
 	ssk_arena_reset(ctx->dev); ssk_arena_reset(ctx->pin);
-	float2* d_tx = ssk_arena_take<float2>(ctx->dev, nt);
-	float2* d_ox = ssk_arena_take<float2>(ctx->dev, no);
-	int32_t* d_ti = ssk_arena_take<int32_t>(ctx->dev, nt);
-	int32_t* d_st = ssk_arena_take<int32_t>(ctx->dev, nt);
-	ssk_fm_result* d_out = ssk_arena_take<ssk_fm_result>(ctx->dev, 1);
-	int32_t* d_rng = ssk_arena_take<int32_t>(ctx->dev, 4);
-	int32_t* h_st = ssk_arena_take<int32_t>(ctx->pin, nt);
-	ssk_fm_result* h_out = ssk_arena_take<ssk_fm_result>(ctx->pin, 1);
-	const int32_t rng[4] = {0, n_this, 0, 0};
-	if (n_this) {
-		SSK_HIP(ctx, hipMemcpyAsync(d_tx, this_xy, 8 * (size_t)n_this, hipMemcpyHostToDevice, ctx->stream));
-		SSK_HIP(ctx, hipMemcpyAsync(d_ti, train_idx, 4 * (size_t)n_this, hipMemcpyHostToDevice, ctx->stream));
-		SSK_HIP(ctx, hipMemcpyAsync(d_st, status, 4 * (size_t)n_this, hipMemcpyHostToDevice, ctx->stream));
-	}
-	if (n_other) SSK_HIP(ctx, hipMemcpyAsync(d_ox, other_xy, 8 * (size_t)n_other, hipMemcpyHostToDevice, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(d_rng, rng, sizeof rng, hipMemcpyHostToDevice, ctx->stream));
+	// one transfer in (coordinates, train indices, ranges, statuses), one out (statuses, result)
+	ssk_xfer_pack pk; pk.begin(ctx, total);
+	int32_t *h_st, *h_rng;
+	ssk_fm_result* h_out;
+	float2* d_tx = pk.put(reinterpret_cast<const float2*>(this_xy), (size_t)n_this);
+	pk.off = ssk_pad(8 * nt);
+	float2* d_ox = pk.put(reinterpret_cast<const float2*>(other_xy), (size_t)n_other);
+	pk.off = ssk_pad(8 * nt) + ssk_pad(8 * no);
+	int32_t* d_ti = pk.put(train_idx, (size_t)n_this);
+	pk.off = ssk_pad(8 * nt) + ssk_pad(8 * no) + ssk_pad(4 * nt);
+	int32_t* d_rng = pk.slot<int32_t>(4, &h_rng);
+	h_rng[0] = 0; h_rng[1] = n_this; h_rng[2] = 0; h_rng[3] = 0;
+	const size_t st_begin = pk.off;
+	int32_t* d_st = pk.put(status, (size_t)n_this);
+	pk.off = st_begin + ssk_pad(4 * nt);
+	h_st = reinterpret_cast<int32_t*>(pk.h + st_begin);
+	const size_t in_end = pk.off;
+	ssk_fm_result* d_out = pk.slot<ssk_fm_result>(1, &h_out);
+	SSK_HIP(ctx, pk.upload(ctx->stream, 0, in_end));
 	if ((rc = ssk_launch_fm(ctx, d_ti, d_st, d_rng + 3, d_rng, d_rng + 1, d_rng + 2, d_tx, d_ox, 1, n_this, *params, d_out, nullptr))) return rc;
-	if (n_this) SSK_HIP(ctx, hipMemcpyAsync(h_st, d_st, 4 * (size_t)n_this, hipMemcpyDeviceToHost, ctx->stream));
-	SSK_HIP(ctx, hipMemcpyAsync(h_out, d_out, sizeof(ssk_fm_result), hipMemcpyDeviceToHost, ctx->stream));
+	SSK_HIP(ctx, pk.download(ctx->stream, st_begin, pk.off));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	for (int k = 0; k < n_this; ++k) status[k] = h_st[k];
 	*out = *h_out;

@@ -93,6 +93,30 @@ inline T* ssk_arena_take(ssk_arena& a, size_t count)
 }
 inline size_t ssk_pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
+// One transfer per direction for a host entry point (a small hipMemcpyAsync costs ~8 us of host time, a keyframe pair's data
+// association used 26 of them): the inputs are laid out back to back in the pinned arena and go to the same layout in the
+// device arena with one copy; the outputs are carved from one device block that comes back with one copy.
+// Pieces that go both ways (a status array a filter updates in place) sit between the inputs and the outputs.
+// Reserve both arenas for the total first (ssk_pad per piece).
+struct ssk_xfer_pack {
+	uint8_t *h = nullptr, *d = nullptr;
+	size_t off = 0;
+	void begin(ssk_ctx* ctx, size_t cap) { h = ssk_arena_take<uint8_t>(ctx->pin, cap); d = ssk_arena_take<uint8_t>(ctx->dev, cap); off = 0; }
+	template <typename T>
+	T* slot(size_t count, T** host)                    // device address of a piece; *host = its mirror in the pinned block
+	{
+		*host = reinterpret_cast<T*>(h + off);
+		T* r = reinterpret_cast<T*>(d + off);
+		off += ssk_pad(count * sizeof(T));
+		return r;
+	}
+	template <typename T>
+	T* put(const T* src, size_t count) { T* hv; T* r = slot<T>(count, &hv); if (count) std::memcpy(hv, src, count * sizeof(T)); return r; }
+	// bytes [from, to) of the block, host -> device / device -> host
+	hipError_t upload(hipStream_t s, size_t from, size_t to) const { return to > from ? hipMemcpyAsync(d + from, h + from, to - from, hipMemcpyHostToDevice, s) : hipSuccess; }
+	hipError_t download(hipStream_t s, size_t from, size_t to) const { return to > from ? hipMemcpyAsync(h + from, d + from, to - from, hipMemcpyDeviceToHost, s) : hipSuccess; }
+};
+
 // kernels' host-side launchers shared between translation units.  Pair p works on virtual rows
 // [beg[p], end[p]) of each side; out_beg[p] (NULL = q_beg) is the output row of its first query.
 int ssk_launch_hamming(ssk_ctx* ctx, const uint8_t* d_q, const int32_t* d_q_beg, const int32_t* d_q_end,
