@@ -227,6 +227,21 @@ int ssk_da_fundamental_filter(ssk_ctx* ctx, const ssk_kf_view* this_kf, const ss
 int ssk_fm_filter(ssk_ctx* ctx, const float* this_xy, int n_this, const float* other_xy, int n_other,
                   const int32_t* train_idx, int32_t* status, const ssk_fm_params* params, ssk_fm_result* out);
 
+/* The three stages of m_internal_data_association for one keyframe pair behind ONE upload, one synchronisation and one
+ * download: ssk_data_association, then (fm_params != NULL) the fundamental-matrix filter, then (cip_params != NULL) the
+ * change-in-pose filter from init_pose (NULL: identity), each on the statuses the previous one left.  The host gates between
+ * the stages ("not enough input data", EST.cpp:1590-1594, 1617-1621) are NOT applied: all requested stages run, and `out`
+ * carries the number of tracked matches after each so that the caller applies the gates as the reference does (a stage run
+ * on fewer than its minimum leaves the statuses alone).  Same kernels, same inputs, same results as the three calls. */
+typedef struct ssk_da_staged_out {
+	int32_t tracked_da, tracked_fm, tracked_final, reserved;   /* SSK_DA_TRACKED count after each stage (a skipped stage repeats the previous) */
+	ssk_fm_result fm;
+	ssk_cip_result cip;
+} ssk_da_staged_out;
+int ssk_data_association_staged(ssk_ctx* ctx, const ssk_kf_view* this_kf, const ssk_kf_view* other_kf, const ssk_da_params* da_params,
+                                const ssk_fm_params* fm_params, const ssk_cip_params* cip_params, const double* init_pose,
+                                ssk_dmatch* out_matches, int32_t* out_status, ssk_da_staged_out* out);
+
 /* ---- B1: stereo front-end ------------------------------------------------------------------------
  * Supplies the definition CStereoSLAMKF::create() lacks (declared KF.h:82-86, defined nowhere) and
  * replaces the live equivalent  m_voEngine.processNewImagePair() + getValues()

@@ -106,6 +106,12 @@ class FmResult(C.Structure):
                 ("n_rejected", C.c_int32), ("hypotheses", C.c_int32), ("best_hypothesis", C.c_int32)]
 
 
+class DaStagedOut(C.Structure):
+    """ssk_da_staged_out: tracked counts after each stage of ssk_data_association_staged, and the two filters' results."""
+    _fields_ = [("tracked_da", C.c_int32), ("tracked_fm", C.c_int32), ("tracked_final", C.c_int32), ("reserved", C.c_int32),
+                ("fm", FmResult), ("cip", CipResult)]
+
+
 class FrontendParams(C.Structure):
     _fields_ = [("n_feats", C.c_int32), ("fast_threshold", C.c_int32), ("n_levels", C.c_int32),
                 ("nms_radius", C.c_int32), ("orb_max_distance", C.c_int32), ("max_y_diff", C.c_float),
@@ -808,6 +814,21 @@ class Context:
         out = FmResult()
         self._chk(self.lib.ssk_fm_filter(self.h, _ptr(tx), len(tx), _ptr(ox), len(ox), _ptr(ti), _ptr(st), C.byref(params), C.byref(out)))
         return st, out
+
+    def data_association_staged(self, this_view, other_view, params, fm_params=None, cip_params=None, init_pose=None):
+        """ssk_data_association_staged: association + (optional) fundamental-matrix + (optional) change-in-pose filters of one pair
+        in one call.  Returns (matches, status after the last stage, DaStagedOut)."""
+        n = this_view.n_matches
+        m = np.zeros(n, DMATCH_DTYPE)
+        st = np.zeros(n, np.int32)
+        out = DaStagedOut()
+        T = None if init_pose is None else np.ascontiguousarray(init_pose, np.float64).reshape(12)
+        self.lib.ssk_data_association_staged.argtypes = [C.c_void_p] * 10
+        self._chk(self.lib.ssk_data_association_staged(self.h, C.byref(this_view), C.byref(other_view), C.byref(params),
+                                                       None if fm_params is None else C.byref(fm_params),
+                                                       None if cip_params is None else C.byref(cip_params),
+                                                       None if T is None else _ptr(T), _ptr(m), _ptr(st), C.byref(out)))
+        return m, st, out
 
     def da_fundamental_filter(self, this_view, other_view, da_matches, status, params):
         m = np.ascontiguousarray(da_matches, DMATCH_DTYPE)

@@ -55,39 +55,31 @@ void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& 
 	if (n == 0) return;
 	std::vector<DMatch> matches(n);
 	std::vector<int32_t> status(n);
-	int32_t tracked = 0;
 	const ssk_kf_view a = this_kf.view(), b = other_kf.view();
 	const ssk_da_params p = srba_options.da();
-	m_ctx.check(ssk_data_association(m_ctx.get(), &a, &b, &p, matches.data(), status.data(), &tracked), "m_internal_data_association");
-	// stage 2 (EST.cpp:1587-1640): fundamental-matrix filter (m_detect_outliers_with_F, :2015-2055; the RANSAC samples come
-	// from a counter-based generator seeded by the keyframe pair, so a run is reproducible), then the change-in-pose
+	// the association, then stage 2 (EST.cpp:1587-1640): fundamental-matrix filter (m_detect_outliers_with_F, :2015-2055; the RANSAC
+	// samples come from a counter-based generator seeded by the keyframe pair, so a run is reproducible), then the change-in-pose
 	// filter (m_detect_outliers_with_change_in_pose, :2113-2177), started from the caller's estimate of the other camera seen
 	// from this one (similar_kfs_poses, :1828-1862) or, without one, from the identity: keyframe-to-keyframe motion is small
-	// against the scene depth, and the estimator converges from there
-	if (srba_options.da_filter_by_fund_matrix) {
-		if (tracked < 15) return;                                                        // :1590-1594  "not enough input data": invalid
-		const ssk_fm_params fp = srba_options.fm(0x5EED0000ull + ((uint64_t)this_kf.m_kf_ID << 20) + other_kf.m_kf_ID);
-		ssk_fm_result fr;
-		m_ctx.check(ssk_da_fundamental_filter(m_ctx.get(), &a, &b, matches.data(), status.data(), &fp, &fr), "m_detect_outliers_with_F");
-		tracked = 0;
-		for (size_t k = 0; k < n; ++k) tracked += status[k] == SSK_DA_TRACKED;           // filter2_inliers, :1610-1613
-	}
-	if (srba_options.da_filter_by_pose_change) {
-		if (tracked < 15) return;                                                        // :1617-1621  "not enough input data": invalid
-		const ssk_cip_params cp = srba_options.cip();
-		const Pose3D identity;
-		ssk_cip_result cr;
-		m_ctx.check(ssk_da_change_in_pose(m_ctx.get(), &a, &b, matches.data(), status.data(), (other_seen_from_this ? *other_seen_from_this : identity).m,
-		                                  &cp, nullptr, &cr), "m_detect_outliers_with_change_in_pose");
-		if (out_cip) *out_cip = cr;
+	// against the scene depth, and the estimator converges from there.  One call: the stages run back to back on the device
+	// (one upload, one synchronisation), the reference's gates between them are applied here on the counts it returns.
+	const bool fm_on = srba_options.da_filter_by_fund_matrix, cip_on = srba_options.da_filter_by_pose_change;
+	const ssk_fm_params fp = srba_options.fm(0x5EED0000ull + ((uint64_t)this_kf.m_kf_ID << 20) + other_kf.m_kf_ID);
+	const ssk_cip_params cp = srba_options.cip();
+	const Pose3D identity;
+	const double* init = (other_seen_from_this ? *other_seen_from_this : identity).m;
+	ssk_da_staged_out so;
+	m_ctx.check(ssk_data_association_staged(m_ctx.get(), &a, &b, &p, fm_on ? &fp : nullptr, cip_on ? &cp : nullptr, init,
+	                                        matches.data(), status.data(), &so), "m_internal_data_association");
+	if (fm_on && so.tracked_da < 15) return;                                             // :1590-1594  "not enough input data": invalid
+	if (cip_on && so.tracked_fm < 15) return;                                            // :1617-1621  (filter2_inliers, :1610-1613)
+	if (cip_on) {
+		if (out_cip) *out_cip = so.cip;
 	} else if (out_cip) {
 		// the odometry stand-in asks for the pose estimate whatever da_stage2_method says (stereo-vo estimates its incremental
 		// pose independently of the SLAM-side filters): the same estimator on a COPY of the statuses, so that it filters nothing
 		std::vector<int32_t> st2(status);
-		const ssk_cip_params cp = srba_options.cip();
-		const Pose3D identity;
-		m_ctx.check(ssk_da_change_in_pose(m_ctx.get(), &a, &b, matches.data(), st2.data(), (other_seen_from_this ? *other_seen_from_this : identity).m,
-		                                  &cp, nullptr, out_cip), "m_vo_process: incremental pose");
+		m_ctx.check(ssk_da_change_in_pose(m_ctx.get(), &a, &b, matches.data(), st2.data(), init, &cp, nullptr, out_cip), "m_vo_process: incremental pose");
 	}
 	for (size_t k = 0; k < n; ++k)                                                       // :1657-1669
 		if (status[k] == SSK_DA_TRACKED) {

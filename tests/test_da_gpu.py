@@ -189,3 +189,51 @@ def test_golden_da_gpu(ctx, pkg):
         out, st, tracked = ctx.data_association(va, vb, prm)
         assert np.array_equal(out["trainIdx"], g["exp_trainIdx"]) and np.array_equal(out["distance"], g["exp_distance"])
         assert np.array_equal(st, g["exp_status"]) and tracked == int(g["exp_tracked"])
+
+
+def test_data_association_staged_equals_the_three_calls(ctx):
+    """ssk_data_association_staged (one upload, one synchronisation) against ssk_data_association + ssk_da_fundamental_filter +
+    ssk_da_change_in_pose on the same keyframes: identical matches, statuses, counts and results, with every combination of
+    the two optional stages, from the identity and from a given start pose, and for an empty other keyframe."""
+    import ctypes as C
+    from ssk_amd import capi
+    fp = capi.FrontendParams(**synth.KITTI_FRONTEND)
+    frames, _ = synth.synth_translation_sequence(3, 2)          # 0.54 m of motion between the two pairs (a pure image shift is degenerate for F)
+    a = ctx.frontend_run(frames[1][0], frames[1][1], fp)
+    b = ctx.frontend_run(frames[0][0], frames[0][1], fp)
+    va, _ka = capi.make_kf_view(**a)
+    vb, _kb = capi.make_kf_view(**b)
+    dap = capi.DaParams(1, 1, synth.H, 60.0)
+    fmp, cpp = capi.FmParams(), capi.CipParams()
+    o = ol.kitti_fm_params(seed=0x5EED0123, norm_cx=0.5 * synth.W, norm_cy=0.5 * synth.H, norm_scale=2.0 / synth.W)
+    C.memmove(C.byref(fmp), C.byref(o), C.sizeof(fmp))
+    o = ol.kitti_cip_params()
+    C.memmove(C.byref(cpp), C.byref(o), C.sizeof(cpp))
+    ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    start = ident.copy(); start[3] = 0.05; start[11] = -0.1
+    m0, st0, tr0 = ctx.data_association(va, vb, dap)
+    assert tr0 >= 100
+    for use_fm in (False, True):
+        for use_cip in (False, True):
+            for init in (None, start):
+                st, trs = st0.copy(), [tr0]
+                fr = cr = None
+                if use_fm:
+                    st, fr = ctx.da_fundamental_filter(va, vb, m0, st, fmp)
+                trs.append(int((st == 0).sum()))
+                if use_cip:
+                    st, _res, cr = ctx.da_change_in_pose(va, vb, m0, st, ident if init is None else init, cpp)
+                trs.append(int((st == 0).sum()))
+                m1, st1, so = ctx.data_association_staged(va, vb, dap, fmp if use_fm else None, cpp if use_cip else None, init)
+                assert np.array_equal(m1, m0) and np.array_equal(st1, st), (use_fm, use_cip)
+                assert [so.tracked_da, so.tracked_fm, so.tracked_final] == trs
+                if use_fm:
+                    assert bytes(so.fm) == bytes(fr) and so.fm.valid == 1
+                if use_cip:
+                    assert bytes(so.cip) == bytes(cr) and so.cip.valid == 1
+    # an other keyframe without matches: nothing tracked, the later stages leave the statuses alone
+    e = {k: v[:0] for k, v in b.items()}
+    ve, _ke = capi.make_kf_view(**e)
+    m2, st2, tr2 = ctx.data_association(va, ve, dap)
+    m3, st3, so = ctx.data_association_staged(va, ve, dap, fmp, cpp, None)
+    assert tr2 == 0 and np.array_equal(st3, st2) and np.array_equal(m3["trainIdx"], m2["trainIdx"]) and so.tracked_final == 0
