@@ -241,6 +241,14 @@ typedef struct ssk_da_staged_out {
 int ssk_data_association_staged(ssk_ctx* ctx, const ssk_kf_view* this_kf, const ssk_kf_view* other_kf, const ssk_da_params* da_params,
                                 const ssk_fm_params* fm_params, const ssk_cip_params* cip_params, const double* init_pose,
                                 ssk_dmatch* out_matches, int32_t* out_status, ssk_da_staged_out* out);
+/* The same for ONE keyframe against n_others keyframes (m_data_association, EST.cpp:1341-1411: the candidate against every
+ * similar keyframe) in one upload, one launch per stage and one synchronisation.  Pair p = (this_kf, others[p]); fm_seeds:
+ * RANSAC seed per pair or NULL (fm_params->seed + p); init_poses: n_others x 12 or NULL (identity);
+ * out_matches / out_status: n_others rows of this_kf->n_matches entries; outs: n_others records. */
+int ssk_data_association_staged_multi(ssk_ctx* ctx, const ssk_kf_view* this_kf, const ssk_kf_view* others, int n_others,
+                                      const ssk_da_params* da_params, const ssk_fm_params* fm_params, const uint64_t* fm_seeds,
+                                      const ssk_cip_params* cip_params, const double* init_poses,
+                                      ssk_dmatch* out_matches, int32_t* out_status, ssk_da_staged_out* outs);
 
 /* ---- B1: stereo front-end ------------------------------------------------------------------------
  * Supplies the definition CStereoSLAMKF::create() lacks (declared KF.h:82-86, defined nowhere) and

@@ -830,6 +830,23 @@ class Context:
                                                        None if T is None else _ptr(T), _ptr(m), _ptr(st), C.byref(out)))
         return m, st, out
 
+    def data_association_staged_multi(self, this_view, other_views, params, fm_params=None, fm_seeds=None, cip_params=None, init_poses=None):
+        """ssk_data_association_staged_multi: this keyframe against every keyframe of other_views in one call.
+        Returns (matches [S, n], statuses [S, n], list of DaStagedOut)."""
+        S, n = len(other_views), this_view.n_matches
+        views = (KfView * S)(*other_views)
+        m = np.zeros((S, n), DMATCH_DTYPE)
+        st = np.zeros((S, n), np.int32)
+        outs = (DaStagedOut * S)()
+        seeds = None if fm_seeds is None else np.ascontiguousarray(fm_seeds, np.uint64)
+        T = None if init_poses is None else np.ascontiguousarray(init_poses, np.float64).reshape(S, 12)
+        self.lib.ssk_data_association_staged_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        self._chk(self.lib.ssk_data_association_staged_multi(self.h, C.byref(this_view), views, S, C.byref(params),
+                                                             None if fm_params is None else C.byref(fm_params), None if seeds is None else _ptr(seeds),
+                                                             None if cip_params is None else C.byref(cip_params), None if T is None else _ptr(T),
+                                                             _ptr(m), _ptr(st), outs))
+        return m, st, list(outs)
+
     def da_fundamental_filter(self, this_view, other_view, da_matches, status, params):
         m = np.ascontiguousarray(da_matches, DMATCH_DTYPE)
         st = np.ascontiguousarray(status, np.int32).copy()

@@ -185,98 +185,127 @@ int ssk_data_association(ssk_ctx* ctx, const ssk_kf_view* a, const ssk_kf_view* 
 	return SSK_OK;
 }
 
-int ssk_data_association_staged(ssk_ctx* ctx, const ssk_kf_view* a, const ssk_kf_view* b, const ssk_da_params* params,
-                                const ssk_fm_params* fmp, const ssk_cip_params* cpp, const double* init_pose,
-                                ssk_dmatch* out_matches, int32_t* out_status, ssk_da_staged_out* out)
+int ssk_data_association_staged_multi(ssk_ctx* ctx, const ssk_kf_view* a, const ssk_kf_view* others, int n_others, const ssk_da_params* params,
+                                      const ssk_fm_params* fmp, const uint64_t* fm_seeds, const ssk_cip_params* cpp, const double* init_poses,
+                                      ssk_dmatch* out_matches, int32_t* out_status, ssk_da_staged_out* outs)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
-	if (!a || !b || !params || !out || a->n_matches < 0 || b->n_matches < 0 ||
-	    (a->n_matches > 0 && (!out_matches || !out_status || !a->matches || !a->desc_left || !a->kp_left || !a->kp_right)) ||
-	    (b->n_matches > 0 && (!b->matches || !b->desc_left || !b->kp_left || !b->kp_right)))
+	if (!a || n_others < 0 || (n_others > 0 && (!others || !outs)) || !params || a->n_matches < 0 ||
+	    (a->n_matches > 0 && n_others > 0 && (!out_matches || !out_status || !a->matches || !a->desc_left || !a->kp_left || !a->kp_right)))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association_staged: bad argument");
 	if (fmp && (!(fmp->threshold > 0) || !(fmp->norm_scale > 0) || fmp->max_iters < 1))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association_staged: threshold, norm_scale and max_iters must be positive");
 	if (cpp && cpp->use_robust_kernel && !(cpp->kernel_param > 0)) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association_staged: kernel_param must be > 0");
-	std::memset(out, 0, sizeof *out);
-	const int na = a->n_matches, nb = b->n_matches;
+	if (n_others == 0) return SSK_OK;
+	std::memset(outs, 0, sizeof(ssk_da_staged_out) * (size_t)n_others);
+	const int na = a->n_matches, S = n_others;
 	if (na == 0) return SSK_OK;
-	if (na > ssk_da_max_matches() || nb > ssk_da_max_matches())
-		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_data_association_staged: more than %d matches per keyframe", ssk_da_max_matches());
-	for (int pass = 0; pass < 2; ++pass) {
-		const ssk_kf_view* kf = pass ? b : a;
+	size_t nb_tot = 0, nLb_tot = 0;
+	for (int p = -1; p < S; ++p) {
+		const ssk_kf_view* kf = p < 0 ? a : others + p;
+		if (kf->n_matches < 0 || (kf->n_matches > 0 && (!kf->matches || !kf->desc_left || !kf->kp_left || !kf->kp_right)))
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association_staged: keyframe %d: bad view", p);
+		if (kf->n_matches > ssk_da_max_matches())
+			return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_data_association_staged: more than %d matches per keyframe", ssk_da_max_matches());
 		for (int k = 0; k < kf->n_matches; ++k)
 			if (kf->matches[k].queryIdx < 0 || kf->matches[k].queryIdx >= kf->n_left || kf->matches[k].trainIdx < 0 || kf->matches[k].trainIdx >= kf->n_right)
-				return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association_staged: %s match %d outside the keypoint lists", pass ? "other_kf" : "this_kf", k);
+				return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association_staged: keyframe %d: match %d outside the keypoint lists", p, k);
+		if (p >= 0) { nb_tot += (size_t)kf->n_matches; nLb_tot += (size_t)(kf->n_matches > 0 ? kf->n_left : 0); }
 	}
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	int rc;
-	const size_t sa = (size_t)na, sb = (size_t)(nb > 0 ? nb : 1);
-	const size_t nLa = (size_t)a->n_left, nLb = (size_t)(b->n_left > 0 ? b->n_left : 1);
+	const size_t sa = (size_t)na, sb = nb_tot > 0 ? nb_tot : 1, nLa = (size_t)a->n_left, nLb = nLb_tot > 0 ? nLb_tot : 1, sS = (size_t)S;
 	const size_t total = ssk_pad(nLa * 32) + ssk_pad(nLb * 32) + ssk_pad(sa * 4) + ssk_pad(sb * 4) + ssk_pad(sa * 8) + ssk_pad(sb * 8) +
-	                     ssk_pad(sa * 16) + ssk_pad(sb * 16) + ssk_pad(96) + ssk_pad(16) +
-	                     3 * ssk_pad(sa * 4) + ssk_pad(16) + ssk_pad(sizeof(ssk_fm_result)) + ssk_pad(sizeof(ssk_cip_result));
+	                     ssk_pad(sa * 16) + ssk_pad(sb * 16) + ssk_pad(96 * sS) + ssk_pad(8 * sS) + ssk_pad(20 * sS) +
+	                     3 * ssk_pad(sS * sa * 4) + ssk_pad(12 * sS) + ssk_pad(sizeof(ssk_fm_result) * sS) + ssk_pad(sizeof(ssk_cip_result) * sS);
 	if ((rc = ssk_arena_reserve(ctx, ctx->dev, total + 2 * 256))) return rc;
 	if ((rc = ssk_arena_reserve(ctx, ctx->pin, total + 2 * 256))) return rc;
 	ssk_arena_reset(ctx->dev); ssk_arena_reset(ctx->pin);
+	// pair p: query rows [0, na) of this keyframe, train rows [t_beg[p], t_end[p]) of the others laid end to end, output row p * na
 	ssk_xfer_pack pk; pk.begin(ctx, total);
-	int32_t *h_ga, *h_gb, *h_off, *h_idx, *h_dist, *h_status, *h_tr;
+	uint8_t *h_da, *h_db;
+	int32_t *h_ga, *h_gb, *h_rng, *h_idx, *h_dist, *h_status, *h_tr;
 	float *h_axy, *h_bxy, *h_aobs, *h_bobs;
 	double* h_T;
+	unsigned long long* h_seed;
 	ssk_fm_result* h_fm;
 	ssk_cip_result* h_cip;
-	const uint8_t* d_da = pk.put(a->desc_left, nLa * 32);
-	const uint8_t* d_db = pk.put(b->desc_left, b->n_left > 0 ? (size_t)b->n_left * 32 : 0);
-	pk.off = ssk_pad(nLa * 32) + ssk_pad(nLb * 32);
+	const uint8_t* d_da = pk.slot<uint8_t>(nLa * 32, &h_da);
+	const uint8_t* d_db = pk.slot<uint8_t>(nLb * 32, &h_db);
 	int32_t* d_ga = pk.slot<int32_t>(sa, &h_ga);
 	int32_t* d_gb = pk.slot<int32_t>(sb, &h_gb);
 	float* d_axy = pk.slot<float>(2 * sa, &h_axy);
 	float* d_bxy = pk.slot<float>(2 * sb, &h_bxy);
 	float* d_aobs = pk.slot<float>(4 * sa, &h_aobs);
 	float* d_bobs = pk.slot<float>(4 * sb, &h_bobs);
-	double* d_T = pk.slot<double>(12, &h_T);
-	int32_t* d_off = pk.slot<int32_t>(4, &h_off);
+	double* d_T = pk.slot<double>(12 * sS, &h_T);
+	unsigned long long* d_seed = pk.slot<unsigned long long>(sS, &h_seed);
+	int32_t* d_rng = pk.slot<int32_t>(5 * sS, &h_rng);           // q_beg | q_end | t_beg | t_end | out_beg
 	const size_t in_end = pk.off;
-	int32_t* d_idx = pk.slot<int32_t>(sa, &h_idx);
-	int32_t* d_dist = pk.slot<int32_t>(sa, &h_dist);
-	int32_t* d_status = pk.slot<int32_t>(sa, &h_status);
-	int32_t* d_tr = pk.slot<int32_t>(4, &h_tr);
-	ssk_fm_result* d_fm = pk.slot<ssk_fm_result>(1, &h_fm);
-	ssk_cip_result* d_cip = pk.slot<ssk_cip_result>(1, &h_cip);
-	for (int pass = 0; pass < 2; ++pass) {
-		const ssk_kf_view* kf = pass ? b : a;
-		int32_t* g = pass ? h_gb : h_ga;
-		float* xy = pass ? h_bxy : h_axy;
-		float* ob = pass ? h_bobs : h_aobs;
+	int32_t* d_idx = pk.slot<int32_t>(sS * sa, &h_idx);
+	int32_t* d_dist = pk.slot<int32_t>(sS * sa, &h_dist);
+	int32_t* d_status = pk.slot<int32_t>(sS * sa, &h_status);
+	int32_t* d_tr = pk.slot<int32_t>(3 * sS, &h_tr);
+	ssk_fm_result* d_fm = pk.slot<ssk_fm_result>(sS, &h_fm);
+	ssk_cip_result* d_cip = pk.slot<ssk_cip_result>(sS, &h_cip);
+	auto fill = [](const ssk_kf_view* kf, int row0, int32_t* g, float* xy, float* ob) {
 		for (int k = 0; k < kf->n_matches; ++k) {
 			const int l = kf->matches[k].queryIdx, r = kf->matches[k].trainIdx;
-			g[k] = l;
+			g[k] = row0 + l;
 			xy[2 * k] = kf->kp_left[l].x; xy[2 * k + 1] = kf->kp_left[l].y;
 			ob[4 * k] = kf->kp_left[l].x; ob[4 * k + 1] = kf->kp_left[l].y; ob[4 * k + 2] = kf->kp_right[r].x; ob[4 * k + 3] = kf->kp_right[r].y;
 		}
-	}
+	};
+	std::memcpy(h_da, a->desc_left, nLa * 32);
+	fill(a, 0, h_ga, h_axy, h_aobs);
 	static const double identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-	std::memcpy(h_T, init_pose ? init_pose : identity, sizeof identity);
-	h_off[0] = 0; h_off[1] = na; h_off[2] = 0; h_off[3] = nb;     // q_beg, q_end, t_beg, t_end; out_beg = q_beg = 0
+	size_t row = 0, m0 = 0;
+	for (int p = 0; p < S; ++p) {
+		const ssk_kf_view* kf = others + p;
+		if (kf->n_matches > 0) {
+			std::memcpy(h_db + row * 32, kf->desc_left, (size_t)kf->n_left * 32);
+			fill(kf, (int)row, h_gb + m0, h_bxy + 2 * m0, h_bobs + 4 * m0);
+		}
+		h_rng[p] = 0; h_rng[S + p] = na; h_rng[2 * S + p] = (int32_t)m0; h_rng[3 * S + p] = (int32_t)(m0 + (size_t)kf->n_matches); h_rng[4 * S + p] = p * na;
+		std::memcpy(h_T + 12 * p, init_poses ? init_poses + 12 * p : identity, sizeof identity);
+		h_seed[p] = fm_seeds ? fm_seeds[p] : (fmp ? fmp->seed + (uint64_t)p : 0);
+		if (kf->n_matches > 0) { row += (size_t)kf->n_left; m0 += (size_t)kf->n_matches; }
+	}
+	const int32_t *q_beg = d_rng, *q_end = d_rng + S, *t_beg = d_rng + 2 * S, *t_end = d_rng + 3 * S, *o_beg = d_rng + 4 * S;
 	SSK_HIP(ctx, pk.upload(ctx->stream, 0, in_end));
-	if ((rc = ssk_launch_hamming(ctx, d_da, d_off, d_off + 1, d_ga, d_db, d_off + 2, d_off + 3, d_gb, nullptr, 1, na, d_idx, d_dist))) return rc;
-	if ((rc = ssk_launch_da_filters(ctx, d_idx, d_dist, nullptr, d_off, d_off + 1, d_off + 2, d_off + 3, d_axy, d_bxy, 1, *params, d_status, d_tr))) return rc;
-	if (fmp && (rc = ssk_launch_fm(ctx, d_idx, d_status, d_off, d_off, d_off + 1, d_off + 2, reinterpret_cast<const float2*>(d_axy),
-	                               reinterpret_cast<const float2*>(d_bxy), 1, na, *fmp, d_fm, d_tr + 1))) return rc;
-	if (cpp && (rc = ssk_launch_cip(ctx, d_idx, d_status, d_off, d_off, d_off + 1, d_off + 2, reinterpret_cast<const float4*>(d_aobs),
-	                                reinterpret_cast<const float4*>(d_bobs), d_T, 1, na, *cpp, nullptr, d_cip, d_tr + 2))) return rc;
+	if ((rc = ssk_launch_hamming(ctx, d_da, q_beg, q_end, d_ga, d_db, t_beg, t_end, d_gb, o_beg, S, na, d_idx, d_dist))) return rc;
+	if ((rc = ssk_launch_da_filters(ctx, d_idx, d_dist, o_beg, q_beg, q_end, t_beg, t_end, d_axy, d_bxy, S, *params, d_status, d_tr))) return rc;
+	if (fmp && (rc = ssk_launch_fm(ctx, d_idx, d_status, o_beg, q_beg, q_end, t_beg, reinterpret_cast<const float2*>(d_axy),
+	                               reinterpret_cast<const float2*>(d_bxy), S, na, *fmp, d_fm, d_tr + S, d_seed))) return rc;
+	if (cpp && (rc = ssk_launch_cip(ctx, d_idx, d_status, o_beg, q_beg, q_end, t_beg, reinterpret_cast<const float4*>(d_aobs),
+	                                reinterpret_cast<const float4*>(d_bobs), d_T, S, na, *cpp, nullptr, d_cip, d_tr + 2 * S))) return rc;
 	SSK_HIP(ctx, pk.download(ctx->stream, in_end, pk.off));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	for (int k = 0; k < na; ++k) {
-		out_matches[k].queryIdx = k; out_matches[k].trainIdx = h_idx[k]; out_matches[k].imgIdx = 0;
-		out_matches[k].distance = nb > 0 ? (float)h_dist[k] : 3.402823466e+38f;
-		out_status[k] = h_status[k];
+	for (int p = 0; p < S; ++p) {
+		const int nb = others[p].n_matches;
+		for (int k = 0; k < na; ++k) {
+			ssk_dmatch& m = out_matches[(size_t)p * sa + k];
+			m.queryIdx = k; m.trainIdx = h_idx[(size_t)p * sa + k]; m.imgIdx = 0;
+			m.distance = nb > 0 ? (float)h_dist[(size_t)p * sa + k] : 3.402823466e+38f;
+			out_status[(size_t)p * sa + k] = h_status[(size_t)p * sa + k];
+		}
+		ssk_da_staged_out& o = outs[p];
+		o.tracked_da = h_tr[p];
+		o.tracked_fm = fmp ? h_tr[S + p] : o.tracked_da;
+		o.tracked_final = cpp ? h_tr[2 * S + p] : o.tracked_fm;
+		if (fmp) o.fm = h_fm[p];
+		if (cpp) o.cip = h_cip[p];
 	}
-	out->tracked_da = h_tr[0];
-	out->tracked_fm = fmp ? h_tr[1] : h_tr[0];
-	out->tracked_final = cpp ? h_tr[2] : out->tracked_fm;
-	if (fmp) out->fm = *h_fm;
-	if (cpp) out->cip = *h_cip;
 	return SSK_OK;
+}
+
+int ssk_data_association_staged(ssk_ctx* ctx, const ssk_kf_view* a, const ssk_kf_view* b, const ssk_da_params* params,
+                                const ssk_fm_params* fmp, const ssk_cip_params* cpp, const double* init_pose,
+                                ssk_dmatch* out_matches, int32_t* out_status, ssk_da_staged_out* out)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_data_association_staged: bad argument");
+	return ssk_data_association_staged_multi(ctx, a, b, 1, params, fmp, nullptr, cpp, init_pose, out_matches, out_status, out);
 }
 
 }  // extern "C"

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NT)
 void fm_kernel(const int32_t* __restrict__ train_idx, int32_t* __restrict__ status, const int32_t* __restrict__ out_beg,
                const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end, const int32_t* __restrict__ t_beg,
                const float2* __restrict__ this_xy, const float2* __restrict__ other_xy, ssk_fm_params P, int cap,
-               ssk_fm_result* __restrict__ results, int32_t* __restrict__ tracked_out)
+               ssk_fm_result* __restrict__ results, int32_t* __restrict__ tracked_out, const unsigned long long* __restrict__ seeds)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];   // [m1 double2 x cap | m2 double2 x cap | idx_of int x cap]
 	double2* s_m1 = reinterpret_cast<double2*>(s_dyn);
@@ -250,7 +250,7 @@ void fm_kernel(const int32_t* __restrict__ train_idx, int32_t* __restrict__ stat
 
 	const bool run = n >= P.min_points && n >= 7;                        // F1 (uniform)
 	const double thr2 = P.threshold * P.threshold;
-	const uint64_t seed = P.seed + (uint64_t)pair;
+	const uint64_t seed = seeds ? (uint64_t)seeds[pair] : P.seed + (uint64_t)pair;      // (per-pair seeds: the un-batched caller seeds by keyframe ids)
 	if (run) {
 		const int hl = tid & (HR - 1), quarter = tid / HR;
 		for (int r = 0; HR * r < s_niters; ++r) {                        // (s_niters only changes between the barriers below)
@@ -321,7 +321,7 @@ void fm_kernel(const int32_t* __restrict__ train_idx, int32_t* __restrict__ stat
 
 int ssk_launch_fm(ssk_ctx* ctx, const int32_t* d_train_idx, int32_t* d_status, const int32_t* d_out_beg, const int32_t* d_q_beg,
                   const int32_t* d_q_end, const int32_t* d_t_beg, const float2* d_this_xy, const float2* d_other_xy,
-                  int n_pairs, int cap, const ssk_fm_params& prm, ssk_fm_result* d_results, int32_t* d_tracked)
+                  int n_pairs, int cap, const ssk_fm_params& prm, ssk_fm_result* d_results, int32_t* d_tracked, const unsigned long long* d_seeds)
 {
 	if (n_pairs <= 0) return SSK_OK;
 	if (cap < 1) cap = 1;
@@ -334,7 +334,7 @@ int ssk_launch_fm(ssk_ctx* ctx, const int32_t* d_train_idx, int32_t* d_status, c
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_FUND_MATRIX);
 	hipLaunchKernelGGL(fm_kernel, dim3(n_pairs), dim3(NT), 36 * (size_t)cap, ctx->stream, d_train_idx, d_status, d_out_beg, d_q_beg, d_q_end, d_t_beg,
-	                   d_this_xy, d_other_xy, prm, cap, d_results, d_tracked);
+	                   d_this_xy, d_other_xy, prm, cap, d_results, d_tracked, d_seeds);
 	SSK_LAUNCH_CHECK(ctx, "fm_kernel");
 	return SSK_OK;
 }

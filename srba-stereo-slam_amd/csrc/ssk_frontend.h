@@ -52,4 +52,5 @@ int ssk_launch_cip(ssk_ctx* ctx, const int32_t* d_train_idx, int32_t* d_status, 
 // fundamental-matrix RANSAC filter over pairs (ssk_fmat.hip); xy arrays are indexed by match slot
 int ssk_launch_fm(ssk_ctx* ctx, const int32_t* d_train_idx, int32_t* d_status, const int32_t* d_out_beg, const int32_t* d_q_beg,
                   const int32_t* d_q_end, const int32_t* d_t_beg, const float2* d_this_xy, const float2* d_other_xy,
-                  int n_pairs, int cap, const ssk_fm_params& prm, ssk_fm_result* d_results, int32_t* d_tracked);
+                  int n_pairs, int cap, const ssk_fm_params& prm, ssk_fm_result* d_results, int32_t* d_tracked,
+                  const unsigned long long* d_seeds = nullptr);   // d_seeds: per-pair RANSAC seeds (NULL: prm.seed + pair)

@@ -88,24 +88,59 @@ void CSRBAStereoSLAMEstimator::m_internal_data_association(const CStereoSLAMKF& 
 		}
 }
 
+// The candidate against every similar keyframe (EST.cpp:1341-1411): the reference loops over m_internal_data_association; here
+// the S pairs go to the device together (ssk_data_association_staged_multi: one upload, one launch per stage, one synchronisation)
+// and the per-pair logic of m_internal_data_association -- gates and tracking_info assembly -- runs on what comes back.
+void CSRBAStereoSLAMEstimator::m_data_association_pairs(const CStereoSLAMKF& kf, const std::vector<size_t>& others, const std::vector<Pose3D>* poses,
+                                                        TVectorKfsDaInfo& out_da)
+{
+	const size_t S = others.size(), n = kf.m_matches.size();
+	out_da.assign(S, t_kf_da_info());                                                    // :1346-1347
+	for (size_t k = 0; k < S; ++k) {
+		out_da[k].kf_idx = m_keyframes[others[k]].m_kf_ID;                               // :1427
+		out_da[k].tracked_matches = 0;
+		out_da[k].tracking_info.assign(n, std::make_pair(INVALID_IDX, 0.0));             // :1429
+	}
+	if (S == 0 || n == 0) return;
+	const bool fm_on = srba_options.da_filter_by_fund_matrix, cip_on = srba_options.da_filter_by_pose_change;
+	const ssk_kf_view a = kf.view();
+	std::vector<ssk_kf_view> views(S);
+	std::vector<uint64_t> seeds(S);
+	std::vector<double> init(12 * S);
+	const Pose3D identity;
+	for (size_t k = 0; k < S; ++k) {
+		const CStereoSLAMKF& o = m_keyframes[others[k]];
+		views[k] = o.view();
+		seeds[k] = 0x5EED0000ull + ((uint64_t)kf.m_kf_ID << 20) + o.m_kf_ID;
+		std::memcpy(&init[12 * k], (poses && k < poses->size() ? (*poses)[k] : identity).m, 12 * sizeof(double));
+	}
+	const ssk_da_params p = srba_options.da();
+	const ssk_fm_params fp = srba_options.fm(0);
+	const ssk_cip_params cp = srba_options.cip();
+	std::vector<DMatch> matches(S * n);
+	std::vector<int32_t> status(S * n);
+	std::vector<ssk_da_staged_out> so(S);
+	m_ctx.check(ssk_data_association_staged_multi(m_ctx.get(), &a, views.data(), (int)S, &p, fm_on ? &fp : nullptr, seeds.data(), cip_on ? &cp : nullptr,
+	                                              init.data(), matches.data(), status.data(), so.data()), "m_data_association");
+	for (size_t k = 0; k < S; ++k) {
+		if (fm_on && so[k].tracked_da < 15) continue;                                    // :1590-1594  "not enough input data": invalid
+		if (cip_on && so[k].tracked_fm < 15) continue;                                   // :1617-1621
+		for (size_t m = 0; m < n; ++m)                                                   // :1657-1669
+			if (status[k * n + m] == SSK_DA_TRACKED) {
+				out_da[k].tracking_info[m] = std::make_pair((size_t)matches[k * n + m].trainIdx, (double)matches[k * n + m].distance);
+				out_da[k].tracked_matches++;
+			}
+	}
+}
+
 void CSRBAStereoSLAMEstimator::m_data_association(const CStereoSLAMKF& kf, const std::vector<size_t>& similar_kfs, TVectorKfsDaInfo& out_da)
 {
-	out_da.clear();
-	out_da.reserve(similar_kfs.size());                                                  // :1346-1347
-	for (size_t k = 0; k < similar_kfs.size(); ++k) {                                    // :1365-1398
-		out_da.push_back(t_kf_da_info());
-		m_internal_data_association(kf, m_keyframes[similar_kfs[k]], out_da.back());
-	}
+	m_data_association_pairs(kf, similar_kfs, nullptr, out_da);                         // :1365-1398
 }
 
 void CSRBAStereoSLAMEstimator::m_data_association(const CStereoSLAMKF& kf, const TLoopClosureInfo& info, TVectorKfsDaInfo& out_da)
 {
-	out_da.clear();
-	out_da.reserve(info.similar_kfs.size());
-	for (size_t k = 0; k < info.similar_kfs.size(); ++k) {                               // :1365-1398
-		out_da.push_back(t_kf_da_info());
-		m_internal_data_association(kf, m_keyframes[info.similar_kfs[k]], out_da.back(), k < info.similar_kfs_poses.size() ? &info.similar_kfs_poses[k] : nullptr);
-	}
+	m_data_association_pairs(kf, info.similar_kfs, &info.similar_kfs_poses, out_da);    // :1365-1398
 }
 
 // EST.cpp:142-161 / 667-704: observation list; the pixel + initial-position arithmetic (projectMatchTo3D and the

@@ -95,6 +95,7 @@ public:
 
 	// EST.cpp:1341-1411 / 1413-1727: Hamming + direction + ORB-distance filters, then the fundamental-matrix filter
 	// (EST.cpp:2015-2055) and the change-in-pose filter (EST.cpp:2113-2177)
+	void m_data_association_pairs(const CStereoSLAMKF& kf, const std::vector<size_t>& others, const std::vector<Pose3D>* poses, TVectorKfsDaInfo& out_da);
 	void m_data_association(const CStereoSLAMKF& kf, const std::vector<size_t>& similar_kfs, TVectorKfsDaInfo& out_da);
 	void m_internal_data_association(const CStereoSLAMKF& this_kf, const CStereoSLAMKF& other_kf, t_kf_da_info& out_da,
 	                                 const Pose3D* other_seen_from_this = nullptr, ssk_cip_result* out_cip = nullptr);

@@ -237,3 +237,36 @@ def test_data_association_staged_equals_the_three_calls(ctx):
     m2, st2, tr2 = ctx.data_association(va, ve, dap)
     m3, st3, so = ctx.data_association_staged(va, ve, dap, fmp, cpp, None)
     assert tr2 == 0 and np.array_equal(st3, st2) and np.array_equal(m3["trainIdx"], m2["trainIdx"]) and so.tracked_final == 0
+
+
+def test_data_association_staged_multi_equals_pair_by_pair(ctx):
+    """One keyframe against three others (one of them empty) in ONE call = the pairs one at a time: per-pair RANSAC seeds and
+    start poses reach their pair, rows do not leak into each other."""
+    import ctypes as C
+    from ssk_amd import capi
+    fp = capi.FrontendParams(**synth.KITTI_FRONTEND)
+    frames, _ = synth.synth_translation_sequence(3, 4)
+    kfs = [ctx.frontend_run(l, r, fp) for l, r in frames]
+    va, _ka = capi.make_kf_view(**kfs[3])
+    others = [kfs[2], {k: v[:0] for k, v in kfs[0].items()}, kfs[1]]
+    keep = [capi.make_kf_view(**o) for o in others]
+    views = [k[0] for k in keep]
+    dap = capi.DaParams(1, 1, synth.H, 60.0)
+    cpp = capi.CipParams()
+    o = ol.kitti_cip_params()
+    C.memmove(C.byref(cpp), C.byref(o), C.sizeof(cpp))
+    seeds = [0x5EED0000 + (3 << 20) + 2, 77, 0x5EED0000 + (3 << 20) + 1]
+    ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+    poses = np.stack([ident, ident, ident]); poses[2, 11] = -0.5
+    fmp = capi.FmParams()
+    fo = ol.kitti_fm_params(seed=0, norm_cx=0.5 * synth.W, norm_cy=0.5 * synth.H, norm_scale=2.0 / synth.W)
+    C.memmove(C.byref(fmp), C.byref(fo), C.sizeof(fmp))
+    m, st, outs = ctx.data_association_staged_multi(va, views, dap, fmp, seeds, cpp, poses)
+    for p in range(3):
+        one = capi.FmParams()
+        fo = ol.kitti_fm_params(seed=seeds[p], norm_cx=0.5 * synth.W, norm_cy=0.5 * synth.H, norm_scale=2.0 / synth.W)
+        C.memmove(C.byref(one), C.byref(fo), C.sizeof(one))
+        m1, st1, o1 = ctx.data_association_staged(va, views[p], dap, one, cpp, poses[p])
+        assert np.array_equal(m[p], m1) and np.array_equal(st[p], st1), p
+        assert bytes(outs[p]) == bytes(o1), p
+    assert outs[0].tracked_final >= 60 and outs[2].tracked_final >= 60 and outs[1].tracked_final == 0
