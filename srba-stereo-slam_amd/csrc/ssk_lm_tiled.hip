@@ -289,7 +289,7 @@ __device__ __forceinline__ bool coop_barrier(coop_t& c)
 		__hip_atomic_fetch_add(c.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		int spins = 0;
 		while (__hip_atomic_load(c.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < c.round * c.expect) {
-			__builtin_amdgcn_s_sleep(8);
+			__builtin_amdgcn_s_sleep(1);
 			if (++spins > c.spin_limit || __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
 				__hip_atomic_store(c.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				break;
