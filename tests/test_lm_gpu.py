@@ -168,6 +168,19 @@ def test_lm_large_window_global_cholesky(ctx, oracle, kernel, monkeypatch):
     check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8))
 
 
+@pytest.mark.parametrize("n_kf", [24, 27, 41, 59])
+@pytest.mark.parametrize("kernel", ["tiled", "coop"])
+def test_lm_dense_solver_beyond_lds_sizes(ctx, oracle, n_kf, kernel, monkeypatch):
+    """ldl_solve_hybrid at the sizes where its paths change (6E = 138, 156: the whole packed triangle in LDS, no leading columns; 240: eleven leading
+    six-column steps in L2 scratch beside the LDS block; 348: more leading columns than LDS rows, the back-substitution stages the rows in several
+    chunks): every attempt against the oracle on one workgroup and on the cooperative kernel."""
+    monkeypatch.setenv("SSK_LM_KERNEL", kernel)
+    win, gt = sl.make_submap_problem(21, n_kf=n_kf, n_lm=20 * n_kf, submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)
+    assert win.E == n_kf - 1 and 6 * win.E > 132
+    res = check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8))
+    assert res.stop_reason != 5
+
+
 def run_plain(ctx, wins, prm):
     """No trace: (results, [(poses, lms)]) of a batch."""
     from ssk_amd import capi
