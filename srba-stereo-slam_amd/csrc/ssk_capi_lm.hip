@@ -767,6 +767,8 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				const auto ts_c = tnow(); t_sub[2] += tms(ts_b, ts_c);
 				T.n_lm = (int)(oj - oi); T.n_obs = (int)w_tobs_a.size() - T.obs0; T.n_ent = n_ent; T.n_inc = lme_cursor - T.inc0; T.n_pan = panels ? n_pan : 0;
 				T.n_il = (int)w_ilane.size() - T.il0;
+				T.slot0 = 0; T.n_slot = 0;                        // the tile's optimised landmarks: a run of slots (they lead the tile order, in slot order)
+				for (size_t ok = oi; ok < oj; ++ok) { const int sl = Wn.lm_unknown_slot[order[ok]]; if (sl >= 0) { if (!T.n_slot) T.slot0 = sl; ++T.n_slot; } }
 				T.pg0 = (int)w_pgrp.size(); T.pc0 = (int)w_pslot0.size();
 				// one chunk task per wave: the smallest R whose H_pp + Schur chunks fit one round of the workgroup's waves
 				sort_by_pid(pitems);

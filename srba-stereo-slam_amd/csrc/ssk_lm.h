@@ -88,7 +88,7 @@ struct lm_tile {
 	int wt0, ent0, pad1;  // acc: first entry of the tile's wt_off table (window relative); ent0: first tile entry in tent[] (window relative)
 	int tsuf0, n_tsuf;    // !tab_lds: the tile's suffixes tsuf[W.tsuf0 + tsuf0 ..) (tile-local id = position)
 	int mt0, n_mt;        // slot kernels, matrix-core Schur: the tile's tasks mt[W.mt0 + mt0 ..)
-	int il0, n_il, pad4, pad5;   // incidence LANES of the tile: ilane[W.il0 + il0 ..) -- an incidence with many path entries is shared by up to 8 lanes
+	int il0, n_il, slot0, n_slot;   // slot0 / n_slot: the tile's optimised landmarks are the slots slot0 .. slot0 + n_slot - 1 (tile order = slot order); incidence LANES of the tile: ilane[W.il0 + il0 ..) -- an incidence with many path entries is shared by up to 8 lanes
 };
 
 struct lm_dev {

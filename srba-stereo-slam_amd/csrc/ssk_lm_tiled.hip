@@ -1137,7 +1137,17 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			for (int i = tid; i < n6; i += NT) { if (!COOP) D.dp[6 * (size_t)W.us0 + i] = s_b[i]; dpn += s_b[i] * s_b[i]; }
 			// ---- H: landmarks, delta_f = L^-T (c - sum_e Y_e^T delta_e).  First one lane per incidence (coalesced Y stream,
 			//      3-vector Y_m^T delta_e staged in the window's L2-resident scratch), then one lane per landmark ----
-			for (int m = tid + NT * g; m < W.n_lme_unknown; m += NT * GG) {
+			// COOP: a workgroup takes the incidences and the landmarks of ITS tiles (a tile's optimised landmarks are a run of slots, their incidences a
+			// run of the landmark-major list), so this phase, the scoring and the state copy below need no barrier between workgroups
+			const int n_own = COOP ? (W.n_tiles - g + GG - 1) / GG : 1;
+			for (int own = 0; own < n_own; ++own) {
+				int m_lo = 0, m_hi = W.n_lme_unknown, l_lo = 0, l_hi = W.L;
+				if (COOP) {
+					const lm_tile& To = D.tile[W.tile0 + g + own * GG];
+					l_lo = To.slot0; l_hi = To.slot0 + To.n_slot;
+					m_lo = D.lsm_off[W.lso0 + l_lo]; m_hi = D.lsm_off[W.lso0 + l_hi];
+				}
+			for (int m = m_lo + tid; m < m_hi; m += NT) {
 				const double* Ym = D.Tb + 18 * (size_t)(W.lme0 + m);
 				const int e = D.lme_edge[W.lme0 + m];
 				double y[18], t0 = 0, t1 = 0, t2 = 0;
@@ -1148,8 +1158,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 				double* o = D.gpe + 6 * (size_t)(W.lme0 + m);
 				o[0] = t0; o[1] = t1; o[2] = t2;
 			}
-			if (COOP) alive = coop_barrier(co); else __syncthreads();
-			for (int l = tid + NT * g; l < W.L; l += NT * GG) {
+			__syncthreads();
+			for (int l = l_lo + tid; l < l_hi; l += NT) {
 				const double* lg = D.Vinv + 9 * (size_t)(W.ls0 + l);
 				double li[9];
 #pragma unroll
@@ -1169,6 +1179,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 					dfn += d3[a] * d3[a];
 					D.lm_new[3 * (size_t)(W.lm0 + li_idx) + a] = D.lm[3 * (size_t)(W.lm0 + li_idx) + a] + d3[a];
 				}
+			}
 			}
 			// ---- H: edges, T_new = exp(eps) (+) T ----
 			for (int e = tid; e < W.E; e += NT) {
@@ -1195,13 +1206,23 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		STAMP(7);
 		// ---- I ----
 		double err_new = s_err;
-		if (COOP && ok) {                              // every workgroup's landmark steps are out
-			__syncthreads();                           // (pose_new of this workgroup complete)
-			alive = coop_barrier(co);
+		if (COOP && ok) {
+			// the observations of this workgroup's tiles see only its own landmarks' steps (no barrier between workgroups); the
+			// observations outside every tile (fixed landmark, fixed path) are dealt out over all workgroups
+			__syncthreads();                           // (pose_new and the landmark steps of this workgroup complete)
 			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
-			const double part = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm_new, s_part, tid + NT * g, NT * GG)
-			                              : total_error_packed(D, W, P, gtab, D.lm_new, s_part, tid + NT * g, NT * GG);
-			err_new = coop_combine<false>(co, part, alive);
+			const double* tabn = W.tab_lds ? tab_l : gtab;
+			const lm_tile& Tl = D.tile[W.tile0 + W.n_tiles - 1];
+			const int n_tiled = Tl.obs0 + Tl.n_obs;
+			double e = 0;
+			for (int t = g; t < W.n_tiles; t += GG) {
+				const lm_tile& To = D.tile[W.tile0 + t];
+				for (int k = To.obs0 + tid; k < To.obs0 + To.n_obs; k += NT)
+					e += obs_error_packed(P, tabn, D.lm_new + 3 * (size_t)W.lm0, D.tobs_a[W.tobs0 + k], D.tobs_px[W.tobs0 + k]);
+			}
+			for (int k = n_tiled + tid + NT * g; k < W.n_obs; k += NT * GG)
+				e += obs_error_packed(P, tabn, D.lm_new + 3 * (size_t)W.lm0, D.tobs_a[W.tobs0 + k], D.tobs_px[W.tobs0 + k]);
+			err_new = coop_combine<false>(co, block_sum(e, s_part), alive);
 			if (!alive) continue;
 		}
 		if (!COOP && ok) {
@@ -1238,11 +1259,16 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 				const int ei = D.slot_edge[W.us0 + e];
 				for (int c = 0; c < 12; ++c) pose_cur[12 * ei + c] = pose_new[12 * ei + c];
 			}
-			for (int l = tid + NT * g; l < W.L; l += NT * GG) {
-				const int li = D.slot_lm[W.ls0 + l];
-				for (int c = 0; c < 3; ++c) D.lm[3 * (size_t)(W.lm0 + li) + c] = D.lm_new[3 * (size_t)(W.lm0 + li) + c];
+			// (COOP: the landmarks of this workgroup's tiles -- the next pass linearises them here, no barrier between workgroups)
+			const int n_own = COOP ? (W.n_tiles - g + GG - 1) / GG : 1;
+			for (int own = 0; own < n_own; ++own) {
+				int l_lo = 0, l_hi = W.L;
+				if (COOP) { const lm_tile& To = D.tile[W.tile0 + g + own * GG]; l_lo = To.slot0; l_hi = To.slot0 + To.n_slot; }
+				for (int l = l_lo + tid; l < l_hi; l += NT) {
+					const int li = D.slot_lm[W.ls0 + l];
+					for (int c = 0; c < 3; ++c) D.lm[3 * (size_t)(W.lm0 + li) + c] = D.lm_new[3 * (size_t)(W.lm0 + li) + c];
+				}
 			}
-			if (COOP) alive = coop_barrier(co);        // the next pass linearises at the landmarks every workgroup just stored
 		}
 		__syncthreads();
 		STAMP(8);
