@@ -1151,7 +1151,11 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 		// the grid barrier of the cooperative kernel needs all n_windows * G workgroups resident: G from what the occupancy
 		// query says one CU holds with this launch's LDS, not from the CU count alone
 		const int per_cu = ssk_lm_coop_blocks_per_cu(ctx, b->tiled_dyn_bytes, b->schur_mfma);
-		int G = std::min(std::min(b->max_tiles, 64), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
+		// at most 32 workgroups per window: beyond that the barriers (seven, then four per attempt) cost more than the shorter tile phase
+		// gives back (measured on 50- and 120-tile local areas: 32 beats 64 by 3 %, 16 loses 7 %); SSK_LM_COOP_G overrides
+		int gmax = 32;
+		if (const char* gcap = std::getenv("SSK_LM_COOP_G")) gmax = std::max(1, std::min(64, std::atoi(gcap)));
+		int G = std::min(std::min(b->max_tiles, gmax), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
 		const bool want = force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu);
 		if (std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm] run: %d windows, max tiles %d, %d workgroups per CU -> %s, G %d, max 6E %d, Schur %s\n", b->n_windows, b->max_tiles, per_cu,
 		                                              want ? "cooperative" : "one workgroup per window", G, b->max_n6, b->schur_mfma ? "mfma" : "sparse");
