@@ -1212,8 +1212,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			__syncthreads();                           // (pose_new and the landmark steps of this workgroup complete)
 			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
 			const double* tabn = W.tab_lds ? tab_l : gtab;
-			const lm_tile& Tl = D.tile[W.tile0 + W.n_tiles - 1];
-			const int n_tiled = Tl.obs0 + Tl.n_obs;
+			int n_tiled = 0;
+			if (W.n_tiles > 0) { const lm_tile& Tl = D.tile[W.tile0 + W.n_tiles - 1]; n_tiled = Tl.obs0 + Tl.n_obs; }
 			double e = 0;
 			for (int t = g; t < W.n_tiles; t += GG) {
 				const lm_tile& To = D.tile[W.tile0 + t];
