@@ -2,6 +2,7 @@
 // batch of optimisation windows on the host (graph bookkeeping, as SRBA does symbolically on the CPU),
 // uploads state + structure to HBM once, and runs the persistent LM kernel of ssk_lm.hip on it.
 #include "ssk_lm.h"
+#include <memory_resource>
 #include <algorithm>
 #include <cmath>
 #include <chrono>
@@ -427,8 +428,13 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		// ---- symbolic structure ----
 		// per landmark index: its (edge slot -> path entries) incidences
 		std::vector<int> p_obs((size_t)n_path);
-		std::vector<std::vector<std::pair<int, int>>> inc((size_t)Wn.n_lms_total);   // (edge slot, path entry)
-		std::vector<std::vector<int>> lm_obs((size_t)L);
+		// the per-landmark / per-block lists below are tens of thousands of small vectors for a 15 k-observation local area: they come
+		// from one monotonic arena per window (malloc / free per list was a third of the symbolic time)
+		std::pmr::monotonic_buffer_resource pool(size_t(1) << 20);
+		using ivec = std::pmr::vector<int>;
+		using ivecs = std::pmr::vector<ivec>;
+		std::pmr::vector<std::pmr::vector<std::pair<int, int>>> inc((size_t)Wn.n_lms_total, &pool);   // (edge slot, path entry)
+		ivecs lm_obs((size_t)L, &pool);
 		for (int o = 0; o < Wn.n_obs; ++o) {
 			const int li = Wn.obs_lm[o];
 			const int ls = Wn.lm_unknown_slot[li];
@@ -445,7 +451,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		for (int l = 0; l < Wn.n_lms_total; ++l) if (Wn.lm_unknown_slot[l] < 0 && !inc[l].empty()) order.push_back(l);
 		std::vector<int> w_lme_edge, w_lme_ls, w_lmep_off, w_lmep_idx, w_lsm_off;
 		std::vector<int> path_to_lme((size_t)n_path, -1);
-		std::vector<std::vector<int>> lm_lmes((size_t)order.size());
+		ivecs lm_lmes((size_t)order.size(), &pool);
 		int n_lme_unknown = 0;
 		for (size_t oi = 0; oi < order.size(); ++oi) {
 			const int l = order[oi];
@@ -499,7 +505,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		}
 		w_qo_off.push_back((int)w_qo.size());
 		} else w_qo_off.push_back(0);
-		std::vector<std::vector<int>> edge_lmes((size_t)E);
+		ivecs edge_lmes((size_t)E, &pool);
 		for (int m = 0; m < n_lme; ++m) edge_lmes[w_lme_edge[m]].push_back(m);
 		// chunks of <= 64 items of one block: H_pp over the q entries with co-observations, Schur over the q
 		// entries of optimised landmarks (which sort first inside a block)
@@ -583,7 +589,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			const bool panels = schur_mfma != 0;
 			{ const int TR = ssk_lma_row_tiles(E); stile_of.assign((size_t)(TR * (TR + 1) / 2), std::vector<int>()); }
 			int n_stile = 0;
-			std::vector<std::vector<int>> obs_of((size_t)Wn.n_lms_total);
+			ivecs obs_of((size_t)Wn.n_lms_total, &pool);
 			for (int o = 0; o < Wn.n_obs; ++o) obs_of[Wn.obs_lm[o]].push_back(o);
 			// packed observation record: everything a lane needs in one coalesced 32-byte load
 			// (x: first local entry | optimised-step mask << 16 | path length << 24, y: landmark, z/w: 8 path codes of 8 bits)
@@ -600,7 +606,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			// balanced cut: the variable footprint of the window spread evenly over the fewest tiles that fit
 			std::vector<long long> fp_P(order.size()), fp_O(order.size()), fp_M(order.size()), fp_Y(order.size());
 			// !tab_lds: the suffixes a landmark's observations use (whole paths + optimised entries), and which tile last took each suffix
-			std::vector<std::vector<int>> lm_sufs(tab_lds ? 0 : order.size());
+			ivecs lm_sufs(tab_lds ? 0 : order.size(), &pool);
 			std::vector<int> suf_tile(tab_lds ? 0 : (size_t)n_suf, -1), suf_local(tab_lds ? 0 : (size_t)n_suf, -1);
 			auto entry_suf = [&](int pb, int len, int i) {
 				const int dir = Wn.path_edge[pb + i] & 1;
@@ -617,7 +623,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				fp_Y[oi] = panels ? (long long)SSK_LMA_PANEL * __builtin_popcount(lm_rowmask[oi]) : (long long)SSK_LMT_Y * fp_M[oi];
 				if (acc) fp_Y[oi] += 7 * fp_M[oi];
 				if (!tab_lds) {
-					std::vector<int>& v = lm_sufs[oi];
+					ivec& v = lm_sufs[oi];
 					for (int o : obs_of[order[oi]]) {
 						v.push_back(obs_suf[o]);
 						const int pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
@@ -632,7 +638,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			const long long est_tiles = std::max<long long>(1, (tot + region_bytes * 9 / 10 - 1) / (region_bytes * 9 / 10));
 			const long long target = (tot + est_tiles - 1) / est_tiles;
 			std::vector<int> path_loc((size_t)n_path, -1);
-			std::vector<std::vector<int>> pslots_of((size_t)n_pairs), sslots_of((size_t)n_pairs);
+			ivecs pslots_of((size_t)n_pairs, &pool), sslots_of((size_t)n_pairs, &pool);
 			struct item { int pid, packed; };
 			// lane groups of <= R consecutive items of one block; n_groups(R) for a sorted item list
 			auto count_groups = [](const std::vector<item>& items, int R) {
@@ -641,7 +647,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				return g;
 			};
 			auto make_groups = [&](std::vector<item>& items, int R, std::vector<int>& it_out, std::vector<int2>& grp_out, std::vector<int>& slot0_out,
-			                       std::vector<std::vector<int>>& slots_of, int& slot_counter, int& n_grp, int& n_chunk) {
+			                       ivecs& slots_of, int& slot_counter, int& n_grp, int& n_chunk) {
 				const int n = (int)items.size(), base = (int)it_out.size();
 				std::vector<int> gkeys;
 				for (int i = 0; i < n;) {
