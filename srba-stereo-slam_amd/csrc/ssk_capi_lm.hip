@@ -3,6 +3,7 @@
 // uploads state + structure to HBM once, and runs the persistent LM kernel of ssk_lm.hip on it.
 #include "ssk_lm.h"
 #include <memory_resource>
+#include <unordered_map>
 #include <algorithm>
 #include <cmath>
 #include <chrono>
@@ -541,15 +542,16 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		std::vector<int2> w_suf(1, make_int2(-1, -1));
 		std::vector<int> w_suf_len(1, 0), suf_at((size_t)n_path + 1, 0), obs_suf((size_t)Wn.n_obs, 0);
 		{
-			std::map<std::pair<int, int>, int> ids;
+			std::pmr::unordered_map<uint64_t, int> ids(&pool);      // (first step, shorter suffix) -> id
+			ids.reserve(4096);
 			for (int o = 0; o < Wn.n_obs; ++o) {
 				int cur = 0;
 				for (int p2 = Wn.obs_path_off[o + 1] - 1; p2 >= Wn.obs_path_off[o]; --p2) {
-					const auto key = std::make_pair(Wn.path_edge[p2], cur);
+					const uint64_t key = ((uint64_t)(uint32_t)Wn.path_edge[p2] << 32) | (uint32_t)cur;
 					auto it = ids.find(key);
 					if (it == ids.end()) {
 						it = ids.emplace(key, (int)w_suf.size()).first;
-						w_suf.push_back(make_int2(key.first, key.second));
+						w_suf.push_back(make_int2(Wn.path_edge[p2], cur));
 						w_suf_len.push_back(w_suf_len[cur] + 1);
 					}
 					cur = it->second;
@@ -597,17 +599,16 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			// (x: first tile-local entry | number of optimised entries << 16, y: landmark, z: suffix id of the whole path as the tile's
 			// table knows it, w: its id in the window's table)
 			auto pack_obs = [&](int o, int info) { return make_int4(info, Wn.obs_lm[o], obs_suf[o], obs_suf[o]); };
-			auto opt_mask = [&](int o) {
-				int om = 0;
+			std::vector<int> omask((size_t)Wn.n_obs, 0);           // bit i: step i of the observation's path is an optimised edge
+			for (int o = 0; o < Wn.n_obs; ++o)
 				for (int p = Wn.obs_path_off[o]; p < Wn.obs_path_off[o + 1]; ++p)
-					if (Wn.edge_unknown_slot[Wn.path_edge[p] >> 1] >= 0) om |= 1 << (p - Wn.obs_path_off[o]);
-				return om;
-			};
+					if (Wn.edge_unknown_slot[Wn.path_edge[p] >> 1] >= 0) omask[o] |= 1 << (p - Wn.obs_path_off[o]);
+			auto opt_mask = [&](int o) { return omask[o]; };
 			// balanced cut: the variable footprint of the window spread evenly over the fewest tiles that fit
 			std::vector<long long> fp_P(order.size()), fp_O(order.size()), fp_M(order.size()), fp_Y(order.size());
 			// !tab_lds: the suffixes a landmark's observations use (whole paths + optimised entries), and which tile last took each suffix
 			ivecs lm_sufs(tab_lds ? 0 : order.size(), &pool);
-			std::vector<int> suf_tile(tab_lds ? 0 : (size_t)n_suf, -1), suf_local(tab_lds ? 0 : (size_t)n_suf, -1);
+			std::vector<int> suf_tile(tab_lds ? 0 : (size_t)n_suf, -1), suf_local(tab_lds ? 0 : (size_t)n_suf, -1), suf_stamp(tab_lds ? 0 : (size_t)n_suf, -1);
 			auto entry_suf = [&](int pb, int len, int i) {
 				const int dir = Wn.path_edge[pb + i] & 1;
 				return dir ? suf_at[i + 1 < len ? pb + i + 1 : n_path] : suf_at[pb + i];
@@ -623,14 +624,14 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				fp_Y[oi] = panels ? (long long)SSK_LMA_PANEL * __builtin_popcount(lm_rowmask[oi]) : (long long)SSK_LMT_Y * fp_M[oi];
 				if (acc) fp_Y[oi] += 7 * fp_M[oi];
 				if (!tab_lds) {
-					ivec& v = lm_sufs[oi];
+					ivec& v = lm_sufs[oi];                          // each suffix once (stamped), ascending
+					auto take = [&](int sid) { if (suf_stamp[(size_t)sid] != (int)oi) { suf_stamp[(size_t)sid] = (int)oi; v.push_back(sid); } };
 					for (int o : obs_of[order[oi]]) {
-						v.push_back(obs_suf[o]);
+						take(obs_suf[o]);
 						const int pb = Wn.obs_path_off[o], len = Wn.obs_path_off[o + 1] - pb, om = opt_mask(o);
-						for (int i = 0; i < len; ++i) if ((om >> i) & 1) v.push_back(entry_suf(pb, len, i));
+						for (int i = 0; i < len; ++i) if ((om >> i) & 1) take(entry_suf(pb, len, i));
 					}
 					std::sort(v.begin(), v.end());
-					v.erase(std::unique(v.begin(), v.end()), v.end());
 				}
 				tot += 8 * (SSK_LMT_ENT * fp_P[oi] + SSK_LMT_OBS * fp_O[oi] + fp_Y[oi] + SSK_LMT_LMR);
 			}
