@@ -282,22 +282,36 @@ struct coop_t { int* cnt; int* abort; double* f; int g, G, round, bank, expect, 
 
 __device__ __forceinline__ bool coop_barrier(coop_t& c)
 {
+#ifdef SSK_COOP_ALL_FENCE
 	__threadfence();
 	__syncthreads();
+#else
+	// every thread's stores are out of the CU (workgroup-scope release + the barrier); ONE thread then publishes for the workgroup:
+	// the agent-scope release writes the XCD's dirty L2 lines back once, not once per wavefront
+	// (a workgroup-scope release alone does not wait for the stores: s_waitcnt vmcnt(0) -- acknowledged by L2 -- is spelt out)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0) expcnt(7) lgkmcnt(15)
+	__syncthreads();
+#endif
 	if (threadIdx.x == 0) {
 		++c.round;
 		__hip_atomic_fetch_add(c.cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		int spins = 0;
-		while (__hip_atomic_load(c.cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < c.round * c.expect) {
+		while (__hip_atomic_load(c.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.round * c.expect) {
 			__builtin_amdgcn_s_sleep(1);
 			if (++spins > c.spin_limit || __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
 				__hip_atomic_store(c.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				break;
 			}
 		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (one invalidation of the CU's L1 / the XCD's non-local L2 lines for the workgroup)
 	}
 	__syncthreads();
+#ifdef SSK_COOP_ALL_FENCE
 	__threadfence();
+#else
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
 	return __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
