@@ -1161,28 +1161,35 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 					l_lo = To.slot0; l_hi = To.slot0 + To.n_slot;
 					m_lo = D.lsm_off[W.lso0 + l_lo]; m_hi = D.lsm_off[W.lso0 + l_hi];
 				}
-			for (int m = m_lo + tid; m < m_hi; m += NT) {
-				const double* Ym = D.Tb + 18 * (size_t)(W.lme0 + m);
-				const int e = D.lme_edge[W.lme0 + m];
-				double y[18], t0 = 0, t1 = 0, t2 = 0;
-#pragma unroll
-				for (int c = 0; c < 18; ++c) y[c] = Ym[c];
-#pragma unroll
-				for (int a = 0; a < 6; ++a) { const double d = s_b[6 * e + a]; t0 += y[3 * a] * d; t1 += y[3 * a + 1] * d; t2 += y[3 * a + 2] * d; }
-				double* o = D.gpe + 6 * (size_t)(W.lme0 + m);
-				o[0] = t0; o[1] = t1; o[2] = t2;
-			}
-			__syncthreads();
+			// one pass, a lane per landmark: its incidences' Y blocks are one contiguous run of the landmark-major list (neighbouring lanes read
+			// neighbouring runs); the two-pass form -- a lane per incidence, 3-vectors staged in L2 scratch, a barrier, then a lane per landmark --
+			// paid three dependent L2 round trips for the same sums (same operations per landmark, same order)
+			(void)m_lo; (void)m_hi;
 			for (int l = l_lo + tid; l < l_hi; l += NT) {
 				const double* lg = D.Vinv + 9 * (size_t)(W.ls0 + l);
+				const int m0 = D.lsm_off[W.lso0 + l], m1 = D.lsm_off[W.lso0 + l + 1];
 				double li[9];
 #pragma unroll
 				for (int c = 0; c < 9; ++c) li[c] = lg[c];
 				double rhs[3] = {li[6], li[7], li[8]};
-				const int m0 = D.lsm_off[W.lso0 + l], m1 = D.lsm_off[W.lso0 + l + 1];
-				for (int m = m0; m < m1; ++m) {
-					const double* o = D.gpe + 6 * (size_t)(W.lme0 + m);
-					rhs[0] -= o[0]; rhs[1] -= o[1]; rhs[2] -= o[2];
+				for (int m = m0; m < m1; m += 2) {
+					// two incidences per turn, loads first (the second on a clamped index, masked afterwards)
+					const int mb = m + 1 < m1 ? m + 1 : m;
+					const double* Ya = D.Tb + 18 * (size_t)(W.lme0 + m);
+					const double* Yb = D.Tb + 18 * (size_t)(W.lme0 + mb);
+					const int ea = D.lme_edge[W.lme0 + m], eb = D.lme_edge[W.lme0 + mb];
+					double ya[18], yb[18];
+#pragma unroll
+					for (int c = 0; c < 18; ++c) { ya[c] = Ya[c]; yb[c] = Yb[c]; }
+					double t0 = 0, t1 = 0, t2 = 0, u0 = 0, u1 = 0, u2 = 0;
+#pragma unroll
+					for (int a = 0; a < 6; ++a) {
+						const double da = s_b[6 * ea + a], db = s_b[6 * eb + a];
+						t0 += ya[3 * a] * da; t1 += ya[3 * a + 1] * da; t2 += ya[3 * a + 2] * da;
+						u0 += yb[3 * a] * db; u1 += yb[3 * a + 1] * db; u2 += yb[3 * a + 2] * db;
+					}
+					rhs[0] -= t0; rhs[1] -= t1; rhs[2] -= t2;
+					if (m + 1 < m1) { rhs[0] -= u0; rhs[1] -= u1; rhs[2] -= u2; }
 				}
 				const double d3[3] = {li[0] * rhs[0] + li[1] * rhs[1] + li[3] * rhs[2], li[2] * rhs[1] + li[4] * rhs[2], li[5] * rhs[2]};
 				const int li_idx = D.slot_lm[W.ls0 + l];
