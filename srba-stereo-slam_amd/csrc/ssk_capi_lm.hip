@@ -811,12 +811,23 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					w_mt.push_back(make_int2(t.second, n_stile++));
 				}
 				} else if (!acc) {
-				int R = 1;
-				while (R < 255 && (count_groups(pitems, R) + 63) / 64 + (count_groups(qitems, R) + 63) / 64 > SSK_LMT_NT / 64) ++R;      // one chunk task per wavefront (two rounds of smaller tasks measured 5 % slower)
-				if (w == 0 && std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm]   tile %d: H_pp items %zu Schur items %zu, <= %d items per lane\n", tile_no, pitems.size(), qitems.size(), R);
-				make_groups(pitems, R, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
+				// the kernel runs the H_pp chunk tasks on the wavefronts the landmark / incidence phases leave idle (NW - max(ceil(n_lm / 64),
+				// ceil(n_il / 64))) and the Schur chunk tasks afterwards on all of them: one task per wavefront in each (two rounds of
+				// smaller tasks measured 5 % slower), so each kind gets the smallest lane-group size whose chunks fit its wavefronts
+				const int NWt = SSK_LMT_NT / 64;
+				const int busy = std::max((T.n_lm + 63) / 64, (T.n_il + 63) / 64), idle = std::max(NWt - busy, 0);
+				int Rp = 1, Rs = 1;
+				if (idle >= 1) {
+					while (Rp < 255 && (count_groups(pitems, Rp) + 63) / 64 > idle) ++Rp;
+					while (Rs < 255 && (count_groups(qitems, Rs) + 63) / 64 > NWt) ++Rs;
+				} else {
+					while (Rp < 255 && (count_groups(pitems, Rp) + 63) / 64 + (count_groups(qitems, Rp) + 63) / 64 > NWt) ++Rp;
+					Rs = Rp;
+				}
+				if (w == 0 && std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm]   tile %d: H_pp items %zu (<= %d per lane), Schur items %zu (<= %d per lane), %d idle wavefronts\n", tile_no, pitems.size(), Rp, qitems.size(), Rs, idle);
+				make_groups(pitems, Rp, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
 				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size();
-				make_groups(qitems, R, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
+				make_groups(qitems, Rs, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
 				} else {
 				// ---- on-chip accumulation: the last lane of a block's run adds the run's sum to the block's LDS accumulator, so a block
 				// must belong to ONE wave of the tile: chunks (one per wave pass) are cut at block boundaries and padded with empty groups,

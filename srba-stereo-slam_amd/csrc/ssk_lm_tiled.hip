@@ -601,7 +601,7 @@ __device__ __forceinline__ void incidence_combine(double (&Wm)[18], double (&ge)
 template <bool MFMA>
 __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, const lm_cam& P, const lm_tile& T, const double* tab_l, const double* __restrict__ gtab,
                                              double* reg, double lambda, bool pre, bool same_state,
-                                             double* __restrict__ Pp, double* __restrict__ Sp, double& vmax)
+                                             double* __restrict__ Pp, double* __restrict__ Sp, double& vmax, int* s_i2a, int& i2a_target)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef SSK_LM_STAMPS
@@ -627,92 +627,22 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 			linearize_obs_lds(D, W, P, tab, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], D.tent + W.tent0 + T.ent0, k, ent, obsr + OBS_P * k);
 		__syncthreads();
 		TSTAMP(0);
-		// ---- I2a: a lane per landmark: V, g_f, Cholesky -> lmr (+ HBM for the back-substitution) ----
-		for (int j = tid; j < T.n_lm; j += NT) {
-			const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
-			const int slot = lrec.x;
-			if (slot < 0) continue;
-			double v[9];
-			landmark_sums(obsr, lrec.y, lrec.z, v);
-			if (pre) { vmax = fmax(vmax, fmax(v[0], fmax(v[3], v[5]))); continue; }
-			if (D.store_hff) {                                 // only the shared-landmark exchange reads the landmark blocks
-				double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
-				Hm[0] = v[0]; Hm[1] = v[1]; Hm[2] = v[2]; Hm[3] = v[1]; Hm[4] = v[3]; Hm[5] = v[4]; Hm[6] = v[2]; Hm[7] = v[4]; Hm[8] = v[5];
-				double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
-				gl[0] = v[6]; gl[1] = v[7]; gl[2] = v[8];
-			}
-			double rec[9];
-			landmark_factor(v, lambda, rec);
-			double* lr = lmr + LMR_P * j;
-			double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
-#pragma unroll
-			for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
-		}
-		if (!pre) __syncthreads();
-		TSTAMP(5);
-		// ---- I2b: a lane per incidence: W and the gradient term, Y = W L^-T -> LDS, reduced gradient term -> HBM ----
-		if (!pre)
-		for (int il = tid; il < ((T.n_il + 63) & ~63); il += NT) {          // (whole wavefronts: the lanes of an incidence meet in shuffles)
-			const int4 lrec = il < T.n_il ? D.ilane[W.il0 + T.il0 + il] : make_int4(0, 0, 0, 0);
-			const int ns = (lrec.x >> 20) & 15, sub = (lrec.x >> 16) & 15, m = lrec.x & 0xFFFF;
-			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
-			const int lml = irec.x & 0x7FFF;
-			const bool unk = (irec.x >> 15) & 1;
-			double Wm[18], ge[6];
-			incidence_sums(D, W, ent, obsr, tab, lrec, unk, Wm, ge);
-			incidence_combine(Wm, ge, sub, ns);
-			if (ns == 0 || sub != 0) continue;                 // the incidence's first lane carries on with the sums
-			double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
-			if (unk) {
-				const double* lr = lmr + LMR_P * lml;
-				const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
-				double* yl = Yr + Y_P * m;
-				double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0 + m);
-				int mk = 0, bs = 0, e_slot = 0;
-				if (MFMA) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lml]; mk = tp.x; bs = tp.y; e_slot = D.lme_edge[W.lme0 + T.inc0 + m]; }
-#pragma unroll
-				for (int a = 0; a < 6; ++a) {
-					const double y0 = Wm[3 * a] * i00;
-					const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
-					const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
-					if (MFMA) {                                    // rows 6e .. 6e+5 of the landmark's panels, and HBM for the back-substitution
-						const int r = 6 * e_slot + a, rt = r >> 4;
-						double* pp = Yr + SSK_LMA_PANEL * (bs + __popc(mk & ((1 << rt) - 1))) + (r & 15);
-						pp[0] = y0; pp[16] = y1; pp[32] = y2;
-						yg[3 * a] = y0; yg[3 * a + 1] = y1; yg[3 * a + 2] = y2;
-					} else {
-						yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
-					}
-					gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
-				}
-			} else {
-#pragma unroll
-				for (int a = 0; a < 6; ++a) gr[a] = ge[a];
-			}
-		}
-		__syncthreads();
-		TSTAMP(1);
-		// ---- I3: Y to HBM for the back-substitution (coalesced), then one chunk task per wave and round:
-		//      H_pp chunks read the entry records, Schur chunks the Y records; both reduce through the scratch
-		//      over the (dead) observation records ----
-		if (!pre && !MFMA) {
-			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
-			for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
-		}
-		// same_state: the previous pass linearised at this very state (the lambda0 pass, or a rejected step): its H_pp slots are
-		// still in place and bit-identical, only the lambda-dependent Schur terms are new
-		const int n_task = T.n_pc + (pre ? 0 : (MFMA ? T.n_mt : T.n_sc));
+		// The H_pp chunk tasks read only what I1 wrote.  The wavefronts that I2a (a lane per landmark: 2 of 8 on the bench window) and I2b (a lane per
+		// incidence lane: 5) leave without work run them meanwhile, THROUGH both phases: the I2a -> I2b hand-over is a counter in LDS between the
+		// wavefronts concerned, not a workgroup barrier (a barrier there made the early tasks -- longer than I2a -- lengthen the phase: 8.19 vs 7.73 ms).
+		// same_state: the previous pass linearised at this very state (the lambda0 pass, or a rejected step): its H_pp slots are still in place
+		// and bit-identical, only the lambda-dependent Schur terms are new.
+		const int n_pc = same_state ? 0 : T.n_pc;
+		const int w_a = (T.n_lm + 63) >> 6, w_b = pre ? 0 : (T.n_il + 63) >> 6, w_ab = w_a > w_b ? w_a : w_b;
+		const int n_early = min(n_pc, max(NW - w_ab, 0));
+		if (!pre) i2a_target += w_a;                       // (uniform: every wavefront keeps the running count of I2a arrivals)
 		int mask0 = 0, base0 = 0, mask1 = 0, base1 = 0;
-		if (MFMA && !pre) {                                  // this lane's landmark(s) of the tile: row-tile mask and first panel
-			if (lane < T.n_lm) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lane]; mask0 = tp.x; base0 = tp.y; }
-			if (lane + 64 < T.n_lm) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lane + 64]; mask1 = tp.x; base1 = tp.y; }
-		}
-		for (int task = wave + (same_state ? T.n_pc : 0); task < n_task; task += NW) {
+		auto run_task = [&](int task) {
 			if (MFMA && task >= T.n_pc) {
 				// Schur tile (I, J) of this tile's landmarks on the matrix cores -> its 256-double partial in HBM (coalesced)
 				const int2 mrec = D.mt[W.mt0 + T.mt0 + task - T.n_pc];
 				schur_mfma_task<false>(Yr, mask0, base0, mask1, base1, mrec.x & 255, mrec.x >> 8, lane, D.Stile + 256 * (size_t)(W.st0 + mrec.y));
-				continue;
+				return;
 			}
 			double acc[36];
 #pragma unroll
@@ -728,7 +658,96 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 				schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
 				wave_seg_sum36(acc, rec.y >> 8, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
 			}
+		};
+		if (wave >= w_ab) {
+			if (wave - w_ab < n_early) run_task(wave - w_ab);
+		} else {
+			// ---- I2a: a lane per landmark: V, g_f, Cholesky -> lmr (+ HBM for the back-substitution) ----
+			for (int j = tid; j < T.n_lm; j += NT) {
+				const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
+				const int slot = lrec.x;
+				if (slot < 0) continue;
+				double v[9];
+				landmark_sums(obsr, lrec.y, lrec.z, v);
+				if (pre) { vmax = fmax(vmax, fmax(v[0], fmax(v[3], v[5]))); continue; }
+				if (D.store_hff) {                                 // only the shared-landmark exchange reads the landmark blocks
+					double* Hm = D.Hff + 9 * (size_t)(W.ls0 + slot);
+					Hm[0] = v[0]; Hm[1] = v[1]; Hm[2] = v[2]; Hm[3] = v[1]; Hm[4] = v[3]; Hm[5] = v[4]; Hm[6] = v[2]; Hm[7] = v[4]; Hm[8] = v[5];
+					double* gl = D.gf + 3 * (size_t)(W.ls0 + slot);
+					gl[0] = v[6]; gl[1] = v[7]; gl[2] = v[8];
+				}
+				double rec[9];
+				landmark_factor(v, lambda, rec);
+				double* lr = lmr + LMR_P * j;
+				double* lg = D.Vinv + 9 * (size_t)(W.ls0 + slot);
+	#pragma unroll
+				for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
+			}
+			if (!pre) {
+				if (wave < w_a) {                              // this wavefront's landmark records are in LDS: arrive
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					if (lane == 0) __hip_atomic_fetch_add(s_i2a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+				if (wave < w_b) {                              // the incidence lanes read every landmark record of the tile: wait for the w_a arrivals
+					while (__hip_atomic_load(s_i2a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i2a_target) __builtin_amdgcn_s_sleep(1);
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				}
+			}
+			// ---- I2b: a lane per incidence: W and the gradient term, Y = W L^-T -> LDS, reduced gradient term -> HBM ----
+			if (!pre)
+			for (int il = tid; il < ((T.n_il + 63) & ~63); il += NT) {          // (whole wavefronts: the lanes of an incidence meet in shuffles)
+				const int4 lrec = il < T.n_il ? D.ilane[W.il0 + T.il0 + il] : make_int4(0, 0, 0, 0);
+				const int ns = (lrec.x >> 20) & 15, sub = (lrec.x >> 16) & 15, m = lrec.x & 0xFFFF;
+				const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
+				const int lml = irec.x & 0x7FFF;
+				const bool unk = (irec.x >> 15) & 1;
+				double Wm[18], ge[6];
+				incidence_sums(D, W, ent, obsr, tab, lrec, unk, Wm, ge);
+				incidence_combine(Wm, ge, sub, ns);
+				if (ns == 0 || sub != 0) continue;                 // the incidence's first lane carries on with the sums
+				double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
+				if (unk) {
+					const double* lr = lmr + LMR_P * lml;
+					const double i00 = lr[0], i10 = lr[1], i11 = lr[2], i20 = lr[3], i21 = lr[4], i22 = lr[5], c0 = lr[6], c1 = lr[7], c2 = lr[8];
+					double* yl = Yr + Y_P * m;
+					double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0 + m);
+					int mk = 0, bs = 0, e_slot = 0;
+					if (MFMA) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lml]; mk = tp.x; bs = tp.y; e_slot = D.lme_edge[W.lme0 + T.inc0 + m]; }
+	#pragma unroll
+					for (int a = 0; a < 6; ++a) {
+						const double y0 = Wm[3 * a] * i00;
+						const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
+						const double y2 = Wm[3 * a] * i20 + Wm[3 * a + 1] * i21 + Wm[3 * a + 2] * i22;
+						if (MFMA) {                                    // rows 6e .. 6e+5 of the landmark's panels, and HBM for the back-substitution
+							const int r = 6 * e_slot + a, rt = r >> 4;
+							double* pp = Yr + SSK_LMA_PANEL * (bs + __popc(mk & ((1 << rt) - 1))) + (r & 15);
+							pp[0] = y0; pp[16] = y1; pp[32] = y2;
+							yg[3 * a] = y0; yg[3 * a + 1] = y1; yg[3 * a + 2] = y2;
+						} else {
+							yl[3 * a] = y0; yl[3 * a + 1] = y1; yl[3 * a + 2] = y2;
+						}
+						gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
+					}
+				} else {
+	#pragma unroll
+					for (int a = 0; a < 6; ++a) gr[a] = ge[a];
+				}
+			}
 		}
+		__syncthreads();
+		TSTAMP(1);
+		// ---- I3: Y to HBM for the back-substitution (coalesced), then one chunk task per wave and round: the H_pp chunks the idle wavefronts
+		//      did not take, then the Schur chunks (they read the Y records) ----
+		if (!pre && !MFMA) {
+			double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0);
+			for (int i = tid; i < 18 * T.n_inc; i += NT) { const int m = i / 18; yg[i] = Yr[m * Y_P + (i - 18 * m)]; }
+		}
+		if (MFMA && !pre) {                                  // this lane's landmark(s) of the tile: row-tile mask and first panel
+			if (lane < T.n_lm) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lane]; mask0 = tp.x; base0 = tp.y; }
+			if (lane + 64 < T.n_lm) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lane + 64]; mask1 = tp.x; base1 = tp.y; }
+		}
+		const int n_task = T.n_pc + (pre ? 0 : (MFMA ? T.n_mt : T.n_sc));
+		for (int task = n_early + (same_state ? T.n_pc : 0) + wave; task < n_task; task += NW) run_task(task);
 		__syncthreads();
 		TSTAMP(3);
 }
@@ -991,6 +1010,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	__shared__ int s_accept, s_stop, s_iters, s_accepted;
 	__shared__ int s_same;                             // the state has not moved since the previous pass's linearisation
 	__shared__ int s_tabcur;                           // the suffix table in place is the current state's (an accepted step's scoring left exactly that)
+	__shared__ int s_i2a;                              // arrivals of the landmark wavefronts (I2a) of every tile pass so far: process_tile
+	int i2a_target = 0;
 
 	const int wi = COOP ? (int)blockIdx.x / G : (int)blockIdx.x, g = COOP ? (int)blockIdx.x % G : 0, GG = COOP ? G : 1;
 	const lm_win W = D.win[wi];
@@ -1046,7 +1067,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 	double e0 = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm, s_part, tid + NT * g, NT * GG) : total_error_packed(D, W, P, gtab, D.lm, s_part, tid + NT * g, NT * GG);
 	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
-		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_same = 0; s_tabcur = 1;
+		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_same = 0; s_tabcur = 1; s_i2a = 0;
 		if (g == 0) {
 			ssk_lm_result& R = D.res[wi];
 			R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
@@ -1083,7 +1104,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 		}
 		for (int t = g; t < W.n_tiles; t += GG) {
 			if (ACC) process_tile_acc<ACC == 2>(D, W, P, D.tile[W.tile0 + t], tab_l, gtab, reg, lambda, pre, same_state, P_acc, S_acc, g_acc, vmax);
-			else process_tile<SMF>(D, W, P, D.tile[W.tile0 + t], tab_l, gtab, reg, lambda, pre, same_state, Pp, Sp, vmax);
+			else process_tile<SMF>(D, W, P, D.tile[W.tile0 + t], tab_l, gtab, reg, lambda, pre, same_state, Pp, Sp, vmax, &s_i2a, i2a_target);
 			STAMP(1);
 		}
 		if (COOP) {                                    // every workgroup's slots, Y, gradient terms and landmark factors are out
