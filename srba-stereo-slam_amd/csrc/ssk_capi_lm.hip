@@ -811,18 +811,29 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					w_mt.push_back(make_int2(t.second, n_stile++));
 				}
 				} else if (!acc) {
-				// the kernel runs the H_pp chunk tasks on the wavefronts the landmark / incidence phases leave idle (NW - max(ceil(n_lm / 64),
-				// ceil(n_il / 64))) and the Schur chunk tasks afterwards on all of them: one task per wavefront in each (two rounds of
-				// smaller tasks measured 5 % slower), so each kind gets the smallest lane-group size whose chunks fit its wavefronts
+				// the kernel gives the landmark phase the last ceil(n_lm / 64) wavefronts and the incidence phase the first ceil(n_il / 64); the
+				// wavefronts between them (`idle`) take one H_pp chunk task each meanwhile, and after the barrier the H_pp tasks left and the
+				// Schur tasks share all NW wavefronts, one task each (two rounds of smaller tasks measured 5 % slower).  Lane-group sizes (Rp, Rs):
+				// the pair whose longest task is shortest under that constraint (a task costs ~250 instructions per H_pp item, ~155 per
+				// Schur item, ~650 for the segmented scan)
 				const int NWt = SSK_LMT_NT / 64;
-				const int busy = std::max((T.n_lm + 63) / 64, (T.n_il + 63) / 64), idle = std::max(NWt - busy, 0);
+				const int idle = std::max(NWt - (T.n_lm + 63) / 64 - (T.n_il + 63) / 64, 0);
 				int Rp = 1, Rs = 1;
-				if (idle >= 1) {
-					while (Rp < 255 && (count_groups(pitems, Rp) + 63) / 64 > idle) ++Rp;
-					while (Rs < 255 && (count_groups(qitems, Rs) + 63) / 64 > NWt) ++Rs;
-				} else {
-					while (Rp < 255 && (count_groups(pitems, Rp) + 63) / 64 + (count_groups(qitems, Rp) + 63) / 64 > NWt) ++Rp;
-					Rs = Rp;
+				{
+					long long best = -1;
+					for (int rp = 1; rp <= 48; ++rp) {
+						const int cp = (count_groups(pitems, rp) + 63) / 64, room = NWt - std::max(cp - idle, 0);
+						if (room < 1 && !qitems.empty()) continue;
+						if (room < 0) continue;
+						int rs = 1;
+						while (rs < 255 && !qitems.empty() && (count_groups(qitems, rs) + 63) / 64 > room) ++rs;
+						const long long cost = std::max(pitems.empty() ? 0LL : 250LL * rp + 650, qitems.empty() ? 0LL : 155LL * rs + 650);
+						if (best < 0 || cost < best) { best = cost; Rp = rp; Rs = rs; }
+					}
+					if (best < 0) {                                  // (never with the tile limits: fall back to one common size)
+						while (Rp < 255 && (count_groups(pitems, Rp) + 63) / 64 + (count_groups(qitems, Rp) + 63) / 64 > NWt) ++Rp;
+						Rs = Rp;
+					}
 				}
 				if (w == 0 && std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm]   tile %d: H_pp items %zu (<= %d per lane), Schur items %zu (<= %d per lane), %d idle wavefronts\n", tile_no, pitems.size(), Rp, qitems.size(), Rs, idle);
 				make_groups(pitems, Rp, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);

@@ -627,14 +627,21 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 			linearize_obs_lds(D, W, P, tab, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], D.tent + W.tent0 + T.ent0, k, ent, obsr + OBS_P * k);
 		__syncthreads();
 		TSTAMP(0);
-		// The H_pp chunk tasks read only what I1 wrote.  The wavefronts that I2a (a lane per landmark: 2 of 8 on the bench window) and I2b (a lane per
-		// incidence lane: 5) leave without work run them meanwhile, THROUGH both phases: the I2a -> I2b hand-over is a counter in LDS between the
-		// wavefronts concerned, not a workgroup barrier (a barrier there made the early tasks -- longer than I2a -- lengthen the phase: 8.19 vs 7.73 ms).
+		// After I1 the wavefronts have ROLES, not common phases:
+		//   landmark wavefronts (the LAST ceil(n_lm / 64): 2 of 8 on the bench window)  I2a: V, g_f, Cholesky -> landmark records, then they arrive
+		//                                                                              on a counter in LDS
+		//   incidence wavefronts (the FIRST ceil(n_il / 64): 5)                        I2b: W and the gradient term of their incidence lanes from
+		//                                                                              what I1 wrote; then they wait for the landmark records;
+		//                                                                              then Y = W L^-T
+		//   the wavefronts between them                                                 one H_pp chunk task each (H_pp reads only what I1 wrote)
+		// and one workgroup barrier later the H_pp tasks left and the Schur tasks (they read Y) take all wavefronts.  The tiler sizes the lane groups
+		// of the two task kinds for exactly this (ssk_capi_lm.hip).  A wavefront with both roles (a tile of many incidence lanes) does I2a first.
 		// same_state: the previous pass linearised at this very state (the lambda0 pass, or a rejected step): its H_pp slots are still in place
 		// and bit-identical, only the lambda-dependent Schur terms are new.
 		const int n_pc = same_state ? 0 : T.n_pc;
-		const int w_a = (T.n_lm + 63) >> 6, w_b = pre ? 0 : (T.n_il + 63) >> 6, w_ab = w_a > w_b ? w_a : w_b;
-		const int n_early = min(n_pc, max(NW - w_ab, 0));
+		const int w_a = (T.n_lm + 63) >> 6, w_b = pre ? 0 : (T.n_il + 63) >> 6;
+		const int wa0 = NW - w_a;                          // first landmark wavefront (n_lm <= NT: w_a <= NW)
+		const int n_early = min(n_pc, max(wa0 - w_b, 0));
 		if (!pre) i2a_target += w_a;                       // (uniform: every wavefront keeps the running count of I2a arrivals)
 		int mask0 = 0, base0 = 0, mask1 = 0, base1 = 0;
 		auto run_task = [&](int task) {
@@ -659,11 +666,9 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 				wave_seg_sum36(acc, rec.y >> 8, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
 			}
 		};
-		if (wave >= w_ab) {
-			if (wave - w_ab < n_early) run_task(wave - w_ab);
-		} else {
+		if (wave >= wa0) {
 			// ---- I2a: a lane per landmark: V, g_f, Cholesky -> lmr (+ HBM for the back-substitution) ----
-			for (int j = tid; j < T.n_lm; j += NT) {
+			for (int j = tid - 64 * wa0; j < T.n_lm; j += NT) {
 				const int4 lrec = D.tl_rec[W.tl0 + T.lml0 + j];   // (slot, first local observation, end)
 				const int slot = lrec.x;
 				if (slot < 0) continue;
@@ -683,28 +688,26 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 	#pragma unroll
 				for (int c = 0; c < 9; ++c) { lr[c] = rec[c]; lg[c] = rec[c]; }
 			}
-			if (!pre) {
-				if (wave < w_a) {                              // this wavefront's landmark records are in LDS: arrive
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					if (lane == 0) __hip_atomic_fetch_add(s_i2a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				}
-				if (wave < w_b) {                              // the incidence lanes read every landmark record of the tile: wait for the w_a arrivals
-					while (__hip_atomic_load(s_i2a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i2a_target) __builtin_amdgcn_s_sleep(1);
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				}
+			if (!pre) {                                        // this wavefront's landmark records are in LDS: arrive
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				if (lane == 0) __hip_atomic_fetch_add(s_i2a, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
-			// ---- I2b: a lane per incidence: W and the gradient term, Y = W L^-T -> LDS, reduced gradient term -> HBM ----
-			if (!pre)
-			for (int il = tid; il < ((T.n_il + 63) & ~63); il += NT) {          // (whole wavefronts: the lanes of an incidence meet in shuffles)
-				const int4 lrec = il < T.n_il ? D.ilane[W.il0 + T.il0 + il] : make_int4(0, 0, 0, 0);
-				const int ns = (lrec.x >> 20) & 15, sub = (lrec.x >> 16) & 15, m = lrec.x & 0xFFFF;
-				const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
-				const int lml = irec.x & 0x7FFF;
-				const bool unk = (irec.x >> 15) & 1;
-				double Wm[18], ge[6];
-				incidence_sums(D, W, ent, obsr, tab, lrec, unk, Wm, ge);
-				incidence_combine(Wm, ge, sub, ns);
-				if (ns == 0 || sub != 0) continue;                 // the incidence's first lane carries on with the sums
+		}
+		if (wave < w_b) {
+			// ---- I2b: a lane per incidence lane (n_il <= NT: one each; whole wavefronts, the lanes of an incidence meet in shuffles) ----
+			const int il = tid;
+			const int4 lrec = il < T.n_il ? D.ilane[W.il0 + T.il0 + il] : make_int4(0, 0, 0, 0);
+			const int ns = (lrec.x >> 20) & 15, sub = (lrec.x >> 16) & 15, m = lrec.x & 0xFFFF;
+			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
+			const int lml = irec.x & 0x7FFF;
+			const bool unk = (irec.x >> 15) & 1;
+			double Wm[18], ge[6];
+			incidence_sums(D, W, ent, obsr, tab, lrec, unk, Wm, ge);
+			incidence_combine(Wm, ge, sub, ns);
+			// the landmark records: wait for the w_a arrivals of this tile pass
+			while (__hip_atomic_load(s_i2a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i2a_target) __builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			if (ns != 0 && sub == 0) {                         // the incidence's first lane carries on with the sums
 				double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
 				if (unk) {
 					const double* lr = lmr + LMR_P * lml;
@@ -713,7 +716,7 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 					double* yg = D.Tb + 18 * (size_t)(W.lme0 + T.inc0 + m);
 					int mk = 0, bs = 0, e_slot = 0;
 					if (MFMA) { const int2 tp = D.tl_pan[W.tl0 + T.lml0 + lml]; mk = tp.x; bs = tp.y; e_slot = D.lme_edge[W.lme0 + T.inc0 + m]; }
-	#pragma unroll
+#pragma unroll
 					for (int a = 0; a < 6; ++a) {
 						const double y0 = Wm[3 * a] * i00;
 						const double y1 = Wm[3 * a] * i10 + Wm[3 * a + 1] * i11;
@@ -729,10 +732,12 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 						gr[a] = ge[a] - (y0 * c0 + y1 * c1 + y2 * c2);
 					}
 				} else {
-	#pragma unroll
+#pragma unroll
 					for (int a = 0; a < 6; ++a) gr[a] = ge[a];
 				}
 			}
+		} else if (wave < wa0) {
+			if (wave - w_b < n_early) run_task(wave - w_b);
 		}
 		__syncthreads();
 		TSTAMP(1);
