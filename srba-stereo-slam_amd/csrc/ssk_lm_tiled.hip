@@ -621,6 +621,10 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 		double* obsr = ent + ENT_P * T.n_ent;
 		double* Yr = obsr + OBS_P * T.n_obs;               // sparse: Y_P per incidence; matrix cores: SSK_LMA_PANEL per panel
 		double* lmr = Yr + (MFMA ? SSK_LMA_PANEL * T.n_pan : Y_P * T.n_inc);
+		// the incidence lane's two records are asked for before I1: the incidence phase is the critical path behind it and starts with them
+		const bool inc_wave = !pre && (tid >> 6) < ((T.n_il + 63) >> 6);
+		const int4 lrec_i = (inc_wave && tid < T.n_il) ? D.ilane[W.il0 + T.il0 + tid] : make_int4(0, 0, 0, 0);
+		const int4 irec_i = inc_wave ? D.inc_rec[W.lme0 + T.inc0 + (lrec_i.x & 0xFFFF)] : make_int4(0, 0, 0, 0);
 		// ---- I1: observations (the Y panels start from zero) ----
 		if (MFMA && !pre) for (int i = tid; i < SSK_LMA_PANEL * T.n_pan; i += NT) Yr[i] = 0.0;
 		for (int k = tid; k < T.n_obs; k += NT)
@@ -695,10 +699,9 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 		}
 		if (wave < w_b) {
 			// ---- I2b: a lane per incidence lane (n_il <= NT: one each; whole wavefronts, the lanes of an incidence meet in shuffles) ----
-			const int il = tid;
-			const int4 lrec = il < T.n_il ? D.ilane[W.il0 + T.il0 + il] : make_int4(0, 0, 0, 0);
+			const int4 lrec = lrec_i;
 			const int ns = (lrec.x >> 20) & 15, sub = (lrec.x >> 16) & 15, m = lrec.x & 0xFFFF;
-			const int4 irec = D.inc_rec[W.lme0 + T.inc0 + m];   // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
+			const int4 irec = irec_i;                          // (local landmark | optimised << 15 | #entries << 16, first lmep, edge-major slot, first entry)
 			const int lml = irec.x & 0x7FFF;
 			const bool unk = (irec.x >> 15) & 1;
 			double Wm[18], ge[6];
