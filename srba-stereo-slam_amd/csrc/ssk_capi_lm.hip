@@ -945,7 +945,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			std::fprintf(stderr, "[ssk lm] window 0: E %d L %d obs %d path %d lme %d tiles %d (region %lld B) pslots %d sslots %d\n", E, L, Wn.n_obs, n_path, n_lme,
 			             tiled ? (int)w_tiles.size() : -1, region_bytes, n_pslots, n_sslots);
 			for (const lm_tile& T : w_tiles)
-				std::fprintf(stderr, "[ssk lm]   tile: lms %d obs %d ent %d inc %d | pgroups %d (chunks %d) sgroups %d (chunks %d)\n", T.n_lm, T.n_obs, T.n_ent, T.n_inc, T.n_pg, T.n_pc, T.n_sg, T.n_sc);
+				std::fprintf(stderr, "[ssk lm]   tile: lms %d obs %d ent %d inc %d (lanes %d) | pgroups %d (chunks %d) sgroups %d (chunks %d) matrix-core tasks %d\n", T.n_lm, T.n_obs, T.n_ent, T.n_inc, T.n_il, T.n_pg, T.n_pc, T.n_sg, T.n_sc, T.n_mt);
 		}
 		H.n_suf = n_suf; H.suf0 = (int)suf_rec.size(); H.tent0 = (int)tent.size();
 		H.tab_lds = tab_lds ? 1 : 0; H.tsuf0 = (int)tsuf.size(); H.gtab0 = gtab_total;
