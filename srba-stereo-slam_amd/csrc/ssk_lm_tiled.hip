@@ -705,11 +705,23 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 			const int lml = irec.x & 0x7FFF;
 			const bool unk = (irec.x >> 15) & 1;
 			double Wm[18], ge[6];
+#ifdef SSK_LM_STAMPS
+			const unsigned long long rt0 = __builtin_amdgcn_s_memtime();
+#endif
 			incidence_sums(D, W, ent, obsr, tab, lrec, unk, Wm, ge);
+#ifdef SSK_LM_STAMPS
+			const unsigned long long rt1 = __builtin_amdgcn_s_memtime();
+#endif
 			incidence_combine(Wm, ge, sub, ns);
+#ifdef SSK_LM_STAMPS
+			const unsigned long long rt2 = __builtin_amdgcn_s_memtime();
+#endif
 			// the landmark records: wait for the w_a arrivals of this tile pass
 			while (__hip_atomic_load(s_i2a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i2a_target) __builtin_amdgcn_s_sleep(1);
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef SSK_LM_STAMPS
+			if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long rt3 = __builtin_amdgcn_s_memtime(); g_tst[4] += rt1 - rt0; g_tst[6] += rt2 - rt1; g_tst[7] += rt3 - rt2; }
+#endif
 			if (ns != 0 && sub == 0) {                         // the incidence's first lane carries on with the sums
 				double* gr = D.gre + 6 * (size_t)(W.el0 + irec.z);
 				if (unk) {
@@ -1342,6 +1354,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			printf("LDL wave0 %llu waves1+ %llu step incl barrier %llu backsub %llu\n", g_ldl[0], g_ldl[1], g_ldl[2], g_ldl[3]);
 			printf("LMT F2 blocks %llu F2 gradient %llu G %llu (slots: pp %d schur %d)\n", g_f2g[0], g_f2g[1], g_f2g[2], D.pcl_off[W.pairo0 + W.n_pairs] - D.pcl_off[W.pairo0], D.scl_off[W.pairo0 + W.n_pairs] - D.scl_off[W.pairo0]);
 			printf("tile phases: I1 %llu I2a (landmarks) %llu I2b (incidences) %llu gradient (acc) %llu chunk tasks (all waves) %llu, of which wave 0 busy (acc) %llu\n", g_tst[0], g_tst[5], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
+			printf("incidence role, wavefront 0: sums %llu, lane combine %llu, wait for the landmark records %llu\n", g_tst[4], g_tst[6], g_tst[7]);
 			printf("LMT fine I3: wave0 (H_pp task) copy %llu items %llu segsum %llu wait %llu | wave4 (Schur task) copy %llu items %llu segsum %llu wait %llu\n",
 			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[8], s_fine[9], s_fine[10], s_fine[11]);
 			}
