@@ -698,7 +698,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					long long aIL = nIL;                           // incidence lanes: the lanes of one incidence stay inside one wavefront
 					for (int m : lm_lmes[oj]) {
 						const int ns = inc_lanes(w_lmep_off[m + 1] - w_lmep_off[m]);
-						if ((aIL & 63) + ns > 64) aIL = (aIL + 63) & ~63LL;
+						if ((aIL & 15) + ns > 16) aIL = (aIL + 15) & ~15LL;      // (the lanes of an incidence inside one 16-lane row: DPP combine)
 						aIL += ns;
 					}
 					// one round of lanes per phase: observations, landmarks, incidences each within the workgroup size
@@ -754,11 +754,11 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 						w_inc_rec[m] = make_int4(j | ((Wn.lm_unknown_slot[l] >= 0 ? 1 : 0) << 15) | (cnt << 16), w_lmep_off[m], 0 /* edge-major slot: below */,
 						                         cnt > 0 ? w_lmep_loc[w_lmep_off[m]] : 0);
 						// the incidence's lanes: its path entries dealt out SSK_LMT_INC_CAP at a time (a tile phase lasts as long as its longest
-						// lane: 84 % of the incidences have one entry, the tail has ten and more), all lanes of one incidence in one wavefront
+						// lane: 84 % of the incidences have one entry, the tail has ten and more), all lanes of one incidence in one 16-lane row of a wavefront
 						const int ns = inc_lanes(cnt), per = (cnt + ns - 1) / ns;
 						int pos = (int)w_ilane.size() - T.il0;
-						if ((pos & 63) + ns > 64)
-							for (; pos & 63; ++pos) w_ilane.push_back(make_int4(0, 0, 0, 0));       // (padding: lanes of no incidence)
+						if ((pos & 15) + ns > 16)
+							for (; pos & 15; ++pos) w_ilane.push_back(make_int4(0, 0, 0, 0));       // (padding: lanes of no incidence)
 						for (int sub = 0; sub < ns; ++sub) {
 							const int k0 = std::min(cnt, sub * per), k1 = std::min(cnt, k0 + per);
 							w_ilane.push_back(make_int4((m - T.inc0) | (sub << 16) | (ns << 20), w_lmep_off[m] + k0, k1 - k0, k1 > k0 ? w_lmep_loc[w_lmep_off[m] + k0] : 0));

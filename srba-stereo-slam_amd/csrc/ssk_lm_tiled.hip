@@ -62,6 +62,13 @@ __device__ __forceinline__ double dpp_shr_f64(double v)
 	return __hiloint2double(hi, lo);
 }
 template <int D>
+__device__ __forceinline__ double dpp_shl_f64(double v)      // the value D lanes up inside the 16-lane row (0 from outside it)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + D, 0xF, 0xF, true);    // row_shl:D
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + D, 0xF, 0xF, true);
+	return __hiloint2double(hi, lo);
+}
+template <int D>
 __device__ __forceinline__ bool dpp_same_key(int key)
 {
 	return __builtin_amdgcn_update_dpp(-1, key, 0x110 + D, 0xF, 0xF, false) == key;             // outside the row: -1, never a key
@@ -586,12 +593,28 @@ __device__ __forceinline__ void incidence_combine(double (&Wm)[18], double (&ge)
 {
 	int ns_max = 1;                                     // largest lane count of an incidence in this wavefront (uniform)
 	for (int v = 8; v >= 2; --v) if (__ballot(ns >= v) != 0ull) { ns_max = v; break; }
-	for (int d = 1; d < ns_max; d <<= 1) {
-		const bool take = (sub & (2 * d - 1)) == 0 && sub + d < ns;
+	// the lanes of an incidence sit inside one 16-lane row (the tiler pads), so "the value d lanes up" is a DPP row shift -- a VALU move per
+	// half -- not a ds_bpermute through the LDS pipeline (the combine was 4.2 k cycles of the incidence role's 12 k, more than its sums)
+	if (ns_max > 1) {
+		const bool take = (sub & 1) == 0 && sub + 1 < ns;
 #pragma unroll
-		for (int c = 0; c < 18; ++c) { const double v = __shfl_down(Wm[c], d, 64); Wm[c] += take ? v : 0.0; }
+		for (int c = 0; c < 18; ++c) { const double v = dpp_shl_f64<1>(Wm[c]); Wm[c] += take ? v : 0.0; }
 #pragma unroll
-		for (int c = 0; c < 6; ++c) { const double v = __shfl_down(ge[c], d, 64); ge[c] += take ? v : 0.0; }
+		for (int c = 0; c < 6; ++c) { const double v = dpp_shl_f64<1>(ge[c]); ge[c] += take ? v : 0.0; }
+	}
+	if (ns_max > 2) {
+		const bool take = (sub & 3) == 0 && sub + 2 < ns;
+#pragma unroll
+		for (int c = 0; c < 18; ++c) { const double v = dpp_shl_f64<2>(Wm[c]); Wm[c] += take ? v : 0.0; }
+#pragma unroll
+		for (int c = 0; c < 6; ++c) { const double v = dpp_shl_f64<2>(ge[c]); ge[c] += take ? v : 0.0; }
+	}
+	if (ns_max > 4) {
+		const bool take = (sub & 7) == 0 && sub + 4 < ns;
+#pragma unroll
+		for (int c = 0; c < 18; ++c) { const double v = dpp_shl_f64<4>(Wm[c]); Wm[c] += take ? v : 0.0; }
+#pragma unroll
+		for (int c = 0; c < 6; ++c) { const double v = dpp_shl_f64<4>(ge[c]); ge[c] += take ? v : 0.0; }
 	}
 }
 
