@@ -583,6 +583,7 @@ __device__ __forceinline__ void schur_mfma_task(const double* __restrict__ pan, 
 
 #ifdef SSK_LM_STAMPS
 __device__ unsigned long long g_tst[8];
+__device__ unsigned long long g_fine[8];      // chunk tasks of wavefront 0 / 4 of workgroup 0: lane-group items, segmented sum + stores, tasks
 #define TSTAMP(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_tst[i] += t_ - tst_last; tst_last = t_; } } while (0)
 #else
 #define TSTAMP(i) do {} while (0)
@@ -681,17 +682,33 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 			double acc[36];
 #pragma unroll
 			for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#ifdef SSK_LM_STAMPS
+			const unsigned long long ft0 = __builtin_amdgcn_s_memtime();
+			unsigned long long ft1;
+#endif
 			if (task < T.n_pc) {
 				const int g = 64 * task + lane;
 				const int2 rec = D.pgrp[W.pg0 + T.pg0 + (g < T.n_pg ? g : T.n_pg - 1)];
 				pp_group(ent, obsr, tab, D.pit + W.pit0 + rec.x, g < T.n_pg ? (rec.y & 255) : 0, acc);
+#ifdef SSK_LM_STAMPS
+				ft1 = __builtin_amdgcn_s_memtime();
+#endif
 				wave_seg_sum36(acc, rec.y >> 8, lane, Pp, D.pcl_idx + W.pcl0 + D.pslot0[W.pcx0 + T.pc0 + task]);
 			} else {
 				const int c = task - T.n_pc, g = 64 * c + lane;
 				const int2 rec = D.sgrp[W.sg0 + T.sg0 + (g < T.n_sg ? g : T.n_sg - 1)];
 				schur_group(Yr, D.qit + W.qit0 + rec.x, g < T.n_sg ? (rec.y & 255) : 0, acc);
+#ifdef SSK_LM_STAMPS
+				ft1 = __builtin_amdgcn_s_memtime();
+#endif
 				wave_seg_sum36(acc, rec.y >> 8, lane, Sp, D.scl_idx + W.scl0 + D.sslot0[W.scx0 + T.sc0 + c]);
 			}
+#ifdef SSK_LM_STAMPS
+			if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4)) {
+				const unsigned long long ft2 = __builtin_amdgcn_s_memtime();
+				g_fine[(wave == 0 ? 0 : 4) + 0] += ft1 - ft0; g_fine[(wave == 0 ? 0 : 4) + 1] += ft2 - ft1; g_fine[(wave == 0 ? 0 : 4) + 2] += 1;
+			}
+#endif
 		};
 		if (wave >= wa0) {
 			// ---- I2a: a lane per landmark: V, g_f, Cholesky -> lmr (+ HBM for the back-substitution) ----
@@ -1377,6 +1394,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, 
 			printf("LDL wave0 %llu waves1+ %llu step incl barrier %llu backsub %llu\n", g_ldl[0], g_ldl[1], g_ldl[2], g_ldl[3]);
 			printf("LMT F2 blocks %llu F2 gradient %llu G %llu (slots: pp %d schur %d)\n", g_f2g[0], g_f2g[1], g_f2g[2], D.pcl_off[W.pairo0 + W.n_pairs] - D.pcl_off[W.pairo0], D.scl_off[W.pairo0 + W.n_pairs] - D.scl_off[W.pairo0]);
 			printf("tile phases: I1 %llu I2a (landmarks) %llu I2b (incidences) %llu gradient (acc) %llu chunk tasks (all waves) %llu, of which wave 0 busy (acc) %llu\n", g_tst[0], g_tst[5], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
+			printf("chunk tasks after the barrier: wavefront 0 %llu tasks: items %llu, segmented sum + stores %llu | wavefront 4 %llu tasks: items %llu, sum + stores %llu\n", g_fine[2], g_fine[0], g_fine[1], g_fine[6], g_fine[4], g_fine[5]);
 			printf("incidence role, wavefront 0: sums %llu, lane combine %llu, wait for the landmark records %llu\n", g_tst[4], g_tst[6], g_tst[7]);
 			printf("LMT fine I3: wave0 (H_pp task) copy %llu items %llu segsum %llu wait %llu | wave4 (Schur task) copy %llu items %llu segsum %llu wait %llu\n",
 			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[8], s_fine[9], s_fine[10], s_fine[11]);
