@@ -1061,9 +1061,15 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 // ACC: 0 = partial slots in HBM, 1 = on-chip accumulation with sparse Schur items, 2 = on-chip accumulation with the Schur
 // complement on the matrix cores
 template <bool COOP, int ACC = 0, bool SMF = false, bool LDLM = false, bool LDSYS = false>
-__device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P, int dyn_doubles, int G, int coop_expect = 1, int coop_spin_limit = COOP_SPIN_LIMIT)
+__device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_arg, int dyn_doubles, int G, int coop_expect = 1, int coop_spin_limit = COOP_SPIN_LIMIT)
 {
 	static_assert(!(COOP && ACC), "the accumulators of a window live in one workgroup's LDS");
+	// the camera / schedule parameters (29 doubles) from LDS, not from 60 scalar registers held for the whole kernel: the kernel's ~45 array
+	// bases and the window header already overflow the scalar file (spilled scalars come back through v_readlane, a VALU slot each)
+	__shared__ lm_cam s_P;
+	if (threadIdx.x == 0) s_P = P_arg;
+	__syncthreads();
+	const lm_cam& P = s_P;
 	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | delta | pivots | tile records / reduced system]
 	__shared__ double s_part[NW];
 	__shared__ double s_lambda, s_nu, s_err;
