@@ -558,7 +558,7 @@ def main():
             "roofline": {"kernel": LM_KERNEL, "bound": "hbm", "achieved": lm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic.get(LM_KERNEL),
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
-                         "note": "dominant kernel by time; latency bound at 2 waves/SIMD (profiles/r02_pmc_sq.json: waves wait 59 % of their time), not bandwidth bound (DESIGN.md 5, 9)"},
+                         "note": "dominant kernel by time; latency bound at 2 waves/SIMD (profiles/r02_pmc_sq.json: waves wait 58 % of their time), not bandwidth bound (DESIGN.md 5, 9)"},
             "roofline_fp64": {"kernel": LM_KERNEL, "bound": "mfma", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
                               "note": "the same launch priced in FP64 flops (SURVEY 8(d) per-unit figures); FP64 MFMA rate = FP64 vector rate on MI355X, "
