@@ -238,6 +238,48 @@ __device__ __forceinline__ void suffix_compose(const double* pose, double* __res
 		O[4 * i + 3] = r0 * tn[0] + r1 * tn[1] + r2 * tn[2] + (dir ? 0.0 : X[4 * i + 3]);
 	}
 }
+// The table in LDS (few suffixes: the batched windows): a lane per suffix walks its own chain of steps -- first the codes from the suffix down to
+// the empty one, then the transforms from the innermost step outwards, in registers: the same operations in the same order as the level
+// scheme below (bit-identical), the shared prefixes recomputed, and ONE barrier instead of one per level (8.5 k -> ~2.5 k cycles per build
+// on the bench window: a level was a chain of dependent LDS reads on two of the eight wavefronts)
+__device__ void build_suffix_table_walk(const lm_win& W, const double* pose, double* __restrict__ tab, const int2* __restrict__ recs)
+{
+	const int tid = threadIdx.x;
+	__syncthreads();                                   // (the caller's writes of the step records, once per solve, and of the poses)
+	if (tid < 12) tab[tid] = (tid == 0 || tid == 5 || tid == 10) ? 1.0 : 0.0;
+	for (int id = 1 + tid; id < W.n_suf; id += NT) {
+		int code[SSK_LM_MAX_PATH], n = 0, cur = id;
+#pragma unroll
+		for (int k = 0; k < SSK_LM_MAX_PATH; ++k) {
+			code[k] = 0;
+			if (cur != 0) { const int2 r = recs[cur]; code[k] = r.x; cur = r.y; n = k + 1; }
+		}
+		double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+#pragma unroll
+		for (int k = SSK_LM_MAX_PATH - 1; k >= 0; --k) {
+			if (k >= n) continue;
+			const double* X = pose + 12 * (code[k] >> 1);
+			const int dir = code[k] & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;      // (R or R^T)(i,j) = X[si * i + sj * j]
+			double tn[3] = {T[3], T[7], T[11]};
+			if (dir) { tn[0] -= X[3]; tn[1] -= X[7]; tn[2] -= X[11]; }
+			double O[12];
+#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				const double r0 = X[si * i], r1 = X[si * i + sj], r2 = X[si * i + 2 * sj];
+#pragma unroll
+				for (int j = 0; j < 3; ++j) O[4 * i + j] = r0 * T[j] + r1 * T[4 + j] + r2 * T[8 + j];
+				O[4 * i + 3] = r0 * tn[0] + r1 * tn[1] + r2 * tn[2] + (dir ? 0.0 : X[4 * i + 3]);
+			}
+#pragma unroll
+			for (int i = 0; i < 12; ++i) T[i] = O[i];
+		}
+		double* o = tab + 12 * id;
+#pragma unroll
+		for (int i = 0; i < 12; ++i) o[i] = T[i];
+	}
+	__syncthreads();
+}
+
 __device__ void build_suffix_table(const lm_win& W, const double* pose, double* __restrict__ tab, const int2* __restrict__ recs)
 {
 	const int tid = threadIdx.x;
@@ -1129,7 +1171,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 	for (int i = tid + NT * g; i < 3 * W.n_lms; i += NT * GG) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
 	__syncthreads();
 	if (W.tab_lds) for (int i = tid; i < W.n_suf; i += NT) recs_l[i] = D.suf_rec[W.suf0 + i];      // (the build's first barrier covers it)
-	if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
+	if (W.tab_lds) build_suffix_table_walk(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
 	double e0 = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm, s_part, tid + NT * g, NT * GG) : total_error_packed(D, W, P, gtab, D.lm, s_part, tid + NT * g, NT * GG);
 	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
@@ -1159,7 +1201,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 		double vmax = 0.0;
 		// the scoring of a REJECTED attempt left the trial state's table here; an accepted one's is the new current state's own
 		if (!s_tabcur) {                                   // (uniform)
-			if (W.tab_lds) build_suffix_table(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
+			if (W.tab_lds) build_suffix_table_walk(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
 			if (tid == 0) s_tabcur = 1;
 		}
 		STAMP(0);
@@ -1233,6 +1275,9 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 			__syncthreads();
 		}
 		STAMP(6);
+#ifdef SSK_LM_STAMPS
+		f_last = __builtin_amdgcn_s_memtime();
+#endif
 		double dpn = 0, dfn = 0;
 		if (ok) {
 			for (int i = tid; i < n6; i += NT) { if (!COOP) D.dp[6 * (size_t)W.us0 + i] = s_b[i]; dpn += s_b[i] * s_b[i]; }
@@ -1259,24 +1304,28 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 #pragma unroll
 				for (int c = 0; c < 9; ++c) li[c] = lg[c];
 				double rhs[3] = {li[6], li[7], li[8]};
-				for (int m = m0; m < m1; m += 2) {
-					// two incidences per turn, loads first (the second on a clamped index, masked afterwards)
-					const int mb = m + 1 < m1 ? m + 1 : m;
+				for (int m = m0; m < m1; m += 3) {
+					// three incidences per turn (85 % of the landmarks have no more), all loads first (clamped indices, masked afterwards): one
+					// round trip to memory per turn -- the Y blocks come from beyond the L2
+					const int mb = m + 1 < m1 ? m + 1 : m, mc = m + 2 < m1 ? m + 2 : m;
 					const double* Ya = D.Tb + 18 * (size_t)(W.lme0 + m);
 					const double* Yb = D.Tb + 18 * (size_t)(W.lme0 + mb);
-					const int ea = D.lme_edge[W.lme0 + m], eb = D.lme_edge[W.lme0 + mb];
-					double ya[18], yb[18];
+					const double* Yc = D.Tb + 18 * (size_t)(W.lme0 + mc);
+					const int ea = D.lme_edge[W.lme0 + m], eb = D.lme_edge[W.lme0 + mb], ec = D.lme_edge[W.lme0 + mc];
+					double ya[18], yb[18], yc[18];
 #pragma unroll
-					for (int c = 0; c < 18; ++c) { ya[c] = Ya[c]; yb[c] = Yb[c]; }
-					double t0 = 0, t1 = 0, t2 = 0, u0 = 0, u1 = 0, u2 = 0;
+					for (int c = 0; c < 18; ++c) { ya[c] = Ya[c]; yb[c] = Yb[c]; yc[c] = Yc[c]; }
+					double t0 = 0, t1 = 0, t2 = 0, u0 = 0, u1 = 0, u2 = 0, v0 = 0, v1 = 0, v2 = 0;
 #pragma unroll
 					for (int a = 0; a < 6; ++a) {
-						const double da = s_b[6 * ea + a], db = s_b[6 * eb + a];
+						const double da = s_b[6 * ea + a], db = s_b[6 * eb + a], dc = s_b[6 * ec + a];
 						t0 += ya[3 * a] * da; t1 += ya[3 * a + 1] * da; t2 += ya[3 * a + 2] * da;
 						u0 += yb[3 * a] * db; u1 += yb[3 * a + 1] * db; u2 += yb[3 * a + 2] * db;
+						v0 += yc[3 * a] * dc; v1 += yc[3 * a + 1] * dc; v2 += yc[3 * a + 2] * dc;
 					}
 					rhs[0] -= t0; rhs[1] -= t1; rhs[2] -= t2;
 					if (m + 1 < m1) { rhs[0] -= u0; rhs[1] -= u1; rhs[2] -= u2; }
+					if (m + 2 < m1) { rhs[0] -= v0; rhs[1] -= v1; rhs[2] -= v2; }
 				}
 				const double d3[3] = {li[0] * rhs[0] + li[1] * rhs[1] + li[3] * rhs[2], li[2] * rhs[1] + li[4] * rhs[2], li[5] * rhs[2]};
 				const int li_idx = D.slot_lm[W.ls0 + l];
@@ -1289,6 +1338,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 				}
 			}
 			}
+			FTICK(0);
 			// ---- H: edges, T_new = exp(eps) (+) T ----
 			for (int e = tid; e < W.E; e += NT) {
 				const int ei = D.slot_edge[W.us0 + e];
@@ -1308,8 +1358,10 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 			if (D.trace_on && g == 0)
 				for (int i = tid; i < n6; i += NT) D.dp_trace[W.dp_trace0 + (size_t)it_idx * n6 + i] = s_b[i];
 		}
+		FTICK(1);
 		dpn = block_sum(dpn, s_part);
 		dfn = block_sum(dfn, s_part);
+		FTICK(2);
 		if (COOP && D.trace_on) dfn = coop_combine<false>(co, dfn, alive);      // (the trace entry reports the whole step's norm)
 		STAMP(7);
 		// ---- I ----
@@ -1318,7 +1370,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 			// the observations of this workgroup's tiles see only its own landmarks' steps (no barrier between workgroups); the
 			// observations outside every tile (fixed landmark, fixed path) are dealt out over all workgroups
 			__syncthreads();                           // (pose_new and the landmark steps of this workgroup complete)
-			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
+			if (W.tab_lds) build_suffix_table_walk(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
 			const double* tabn = W.tab_lds ? tab_l : gtab;
 			int n_tiled = 0;
 			if (W.n_tiles > 0) { const lm_tile& Tl = D.tile[W.tile0 + W.n_tiles - 1]; n_tiled = Tl.obs0 + Tl.n_obs; }
@@ -1335,9 +1387,12 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 		}
 		if (!COOP && ok) {
 			__syncthreads();                               // (pose_new complete)
-			if (W.tab_lds) build_suffix_table(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
+			FTICK(3);
+			if (W.tab_lds) build_suffix_table_walk(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
+			FTICK(4);
 			err_new = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm_new, s_part, tid, NT) : total_error_packed(D, W, P, gtab, D.lm_new, s_part, tid, NT);
 		}
+		FTICK(5);
 		__syncthreads();
 		if (tid == 0) {
 			const int accepted = ok && err_new < s_err;
@@ -1402,8 +1457,8 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 			printf("tile phases: I1 %llu I2a (landmarks) %llu I2b (incidences) %llu gradient (acc) %llu chunk tasks (all waves) %llu, of which wave 0 busy (acc) %llu\n", g_tst[0], g_tst[5], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
 			printf("chunk tasks after the barrier: wavefront 0 %llu tasks: items %llu, segmented sum + stores %llu | wavefront 4 %llu tasks: items %llu, sum + stores %llu\n", g_fine[2], g_fine[0], g_fine[1], g_fine[6], g_fine[4], g_fine[5]);
 			printf("incidence role, wavefront 0: sums %llu, lane combine %llu, wait for the landmark records %llu\n", g_tst[4], g_tst[6], g_tst[7]);
-			printf("LMT fine I3: wave0 (H_pp task) copy %llu items %llu segsum %llu wait %llu | wave4 (Schur task) copy %llu items %llu segsum %llu wait %llu\n",
-			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[8], s_fine[9], s_fine[10], s_fine[11]);
+			printf("H / I fine (thread 0): landmark back-substitution %llu, edges %llu, norms %llu, sync %llu, table at the trial state %llu, error %llu\n",
+			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[4], s_fine[5]);
 			}
 #endif
 	}
