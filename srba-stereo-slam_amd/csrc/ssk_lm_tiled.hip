@@ -1304,28 +1304,24 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 #pragma unroll
 				for (int c = 0; c < 9; ++c) li[c] = lg[c];
 				double rhs[3] = {li[6], li[7], li[8]};
-				for (int m = m0; m < m1; m += 3) {
-					// three incidences per turn (85 % of the landmarks have no more), all loads first (clamped indices, masked afterwards): one
-					// round trip to memory per turn -- the Y blocks come from beyond the L2
-					const int mb = m + 1 < m1 ? m + 1 : m, mc = m + 2 < m1 ? m + 2 : m;
+				for (int m = m0; m < m1; m += 2) {
+					// two incidences per turn, loads first (the second on a clamped index, masked afterwards)
+					const int mb = m + 1 < m1 ? m + 1 : m;
 					const double* Ya = D.Tb + 18 * (size_t)(W.lme0 + m);
 					const double* Yb = D.Tb + 18 * (size_t)(W.lme0 + mb);
-					const double* Yc = D.Tb + 18 * (size_t)(W.lme0 + mc);
-					const int ea = D.lme_edge[W.lme0 + m], eb = D.lme_edge[W.lme0 + mb], ec = D.lme_edge[W.lme0 + mc];
-					double ya[18], yb[18], yc[18];
+					const int ea = D.lme_edge[W.lme0 + m], eb = D.lme_edge[W.lme0 + mb];
+					double ya[18], yb[18];
 #pragma unroll
-					for (int c = 0; c < 18; ++c) { ya[c] = Ya[c]; yb[c] = Yb[c]; yc[c] = Yc[c]; }
-					double t0 = 0, t1 = 0, t2 = 0, u0 = 0, u1 = 0, u2 = 0, v0 = 0, v1 = 0, v2 = 0;
+					for (int c = 0; c < 18; ++c) { ya[c] = Ya[c]; yb[c] = Yb[c]; }
+					double t0 = 0, t1 = 0, t2 = 0, u0 = 0, u1 = 0, u2 = 0;
 #pragma unroll
 					for (int a = 0; a < 6; ++a) {
-						const double da = s_b[6 * ea + a], db = s_b[6 * eb + a], dc = s_b[6 * ec + a];
+						const double da = s_b[6 * ea + a], db = s_b[6 * eb + a];
 						t0 += ya[3 * a] * da; t1 += ya[3 * a + 1] * da; t2 += ya[3 * a + 2] * da;
 						u0 += yb[3 * a] * db; u1 += yb[3 * a + 1] * db; u2 += yb[3 * a + 2] * db;
-						v0 += yc[3 * a] * dc; v1 += yc[3 * a + 1] * dc; v2 += yc[3 * a + 2] * dc;
 					}
 					rhs[0] -= t0; rhs[1] -= t1; rhs[2] -= t2;
 					if (m + 1 < m1) { rhs[0] -= u0; rhs[1] -= u1; rhs[2] -= u2; }
-					if (m + 2 < m1) { rhs[0] -= v0; rhs[1] -= v1; rhs[2] -= v2; }
 				}
 				const double d3[3] = {li[0] * rhs[0] + li[1] * rhs[1] + li[3] * rhs[2], li[2] * rhs[1] + li[4] * rhs[2], li[5] * rhs[2]};
 				const int li_idx = D.slot_lm[W.ls0 + l];
