@@ -693,8 +693,14 @@ __device__ __forceinline__ void process_tile(const lm_dev& D, const lm_win& W, c
 		const int4 irec_i = inc_wave ? D.inc_rec[W.lme0 + T.inc0 + (lrec_i.x & 0xFFFF)] : make_int4(0, 0, 0, 0);
 		// ---- I1: observations (the Y panels start from zero) ----
 		if (MFMA && !pre) for (int i = tid; i < SSK_LMA_PANEL * T.n_pan; i += NT) Yr[i] = 0.0;
+#ifdef SSK_LM_STAMPS
+		const unsigned long long i1t0 = __builtin_amdgcn_s_memtime();
+#endif
 		for (int k = tid; k < T.n_obs; k += NT)
 			linearize_obs_lds(D, W, P, tab, D.tobs_a[W.tobs0 + T.obs0 + k], D.tobs_px[W.tobs0 + T.obs0 + k], D.tent + W.tent0 + T.ent0, k, ent, obsr + OBS_P * k);
+#ifdef SSK_LM_STAMPS
+		if (threadIdx.x == 0 && blockIdx.x == 0) g_fine[3] += __builtin_amdgcn_s_memtime() - i1t0;      // wavefront 0's own I1 work (without the barrier)
+#endif
 		__syncthreads();
 		TSTAMP(0);
 		// After I1 the wavefronts have ROLES, not common phases:
@@ -1452,6 +1458,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 			printf("LMT F2 blocks %llu F2 gradient %llu G %llu (slots: pp %d schur %d)\n", g_f2g[0], g_f2g[1], g_f2g[2], D.pcl_off[W.pairo0 + W.n_pairs] - D.pcl_off[W.pairo0], D.scl_off[W.pairo0 + W.n_pairs] - D.scl_off[W.pairo0]);
 			printf("tile phases: I1 %llu I2a (landmarks) %llu I2b (incidences) %llu gradient (acc) %llu chunk tasks (all waves) %llu, of which wave 0 busy (acc) %llu\n", g_tst[0], g_tst[5], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
 			printf("chunk tasks after the barrier: wavefront 0 %llu tasks: items %llu, segmented sum + stores %llu | wavefront 4 %llu tasks: items %llu, sum + stores %llu\n", g_fine[2], g_fine[0], g_fine[1], g_fine[6], g_fine[4], g_fine[5]);
+			printf("I1, wavefront 0 without the barrier: %llu\n", g_fine[3]);
 			printf("incidence role, wavefront 0: sums %llu, lane combine %llu, wait for the landmark records %llu\n", g_tst[4], g_tst[6], g_tst[7]);
 			printf("H / I fine (thread 0): landmark back-substitution %llu, edges %llu, norms %llu, sync %llu, table at the trial state %llu, error %llu\n",
 			       s_fine[0], s_fine[1], s_fine[2], s_fine[3], s_fine[4], s_fine[5]);
