@@ -1149,6 +1149,17 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 	int2* recs_l = reinterpret_cast<int2*>(tab_l + (W.tab_lds ? 12 * W.n_suf : 0));
 	double* reg = tab_l + (W.tab_lds ? 13 * W.n_suf : 0);
 	double* gtab = D.suf_tab + W.gtab0 + (W.tab_lds ? 0 : 12 * (size_t)W.n_suf * g);
+	// the suffix table at a state.  The kernel variant of the batches whose systems all fit LDS (LDSYS: the batched per-keyframe windows, few
+	// suffixes of few steps) builds an LDS table by a chain walk per suffix: one barrier instead of one per level.  The other variants keep the
+	// level scheme and do not even contain the walk: with a few hundred suffixes of up to eight steps it does not pay, and its mere presence
+	// moved their register allocation (+4 % on a 40-edge local area)
+	auto build_table = [&](const double* pose) {
+		if constexpr (LDSYS) {
+			if (W.tab_lds) build_suffix_table_walk(W, pose, tab_l, recs_l); else build_suffix_table(W, pose, gtab, D.suf_rec + W.suf0);
+		} else {
+			if (W.tab_lds) build_suffix_table(W, pose, tab_l, recs_l); else build_suffix_table(W, pose, gtab, D.suf_rec + W.suf0);
+		}
+	};
 	// the reduced system lives over the dead tile records when (n6 + 1) x (n6 | 1) doubles fit there (E <= ~22),
 	// otherwise in the window's L2-resident scratch (same blocked factorisation through plain pointers)
 	// (LDSYS: the host found that every window's system fits: the L2-resident solver is compiled out)
@@ -1177,7 +1188,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 	for (int i = tid + NT * g; i < 3 * W.n_lms; i += NT * GG) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
 	__syncthreads();
 	if (W.tab_lds) for (int i = tid; i < W.n_suf; i += NT) recs_l[i] = D.suf_rec[W.suf0 + i];      // (the build's first barrier covers it)
-	if (W.tab_lds) build_suffix_table_walk(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
+	build_table(pose_cur);
 	double e0 = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm, s_part, tid + NT * g, NT * GG) : total_error_packed(D, W, P, gtab, D.lm, s_part, tid + NT * g, NT * GG);
 	if (COOP) e0 = coop_combine<false>(co, e0, alive);
 	if (tid == 0) {
@@ -1207,7 +1218,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 		double vmax = 0.0;
 		// the scoring of a REJECTED attempt left the trial state's table here; an accepted one's is the new current state's own
 		if (!s_tabcur) {                                   // (uniform)
-			if (W.tab_lds) build_suffix_table_walk(W, pose_cur, tab_l, recs_l); else build_suffix_table(W, pose_cur, gtab, D.suf_rec + W.suf0);
+			build_table(pose_cur);
 			if (tid == 0) s_tabcur = 1;
 		}
 		STAMP(0);
@@ -1372,7 +1383,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 			// the observations of this workgroup's tiles see only its own landmarks' steps (no barrier between workgroups); the
 			// observations outside every tile (fixed landmark, fixed path) are dealt out over all workgroups
 			__syncthreads();                           // (pose_new and the landmark steps of this workgroup complete)
-			if (W.tab_lds) build_suffix_table_walk(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
+			build_table(pose_new);
 			const double* tabn = W.tab_lds ? tab_l : gtab;
 			int n_tiled = 0;
 			if (W.n_tiles > 0) { const lm_tile& Tl = D.tile[W.tile0 + W.n_tiles - 1]; n_tiled = Tl.obs0 + Tl.n_obs; }
@@ -1390,7 +1401,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 		if (!COOP && ok) {
 			__syncthreads();                               // (pose_new complete)
 			FTICK(3);
-			if (W.tab_lds) build_suffix_table_walk(W, pose_new, tab_l, recs_l); else build_suffix_table(W, pose_new, gtab, D.suf_rec + W.suf0);
+			build_table(pose_new);
 			FTICK(4);
 			err_new = W.tab_lds ? total_error_packed(D, W, P, tab_l, D.lm_new, s_part, tid, NT) : total_error_packed(D, W, P, gtab, D.lm_new, s_part, tid, NT);
 		}
