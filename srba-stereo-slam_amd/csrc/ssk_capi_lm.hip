@@ -2,6 +2,7 @@
 // batch of optimisation windows on the host (graph bookkeeping, as SRBA does symbolically on the CPU),
 // uploads state + structure to HBM once, and runs the persistent LM kernel of ssk_lm.hip on it.
 #include "ssk_lm.h"
+#include "ssk_lm_node_build.h"
 #include <memory_resource>
 #include <unordered_map>
 #include <algorithm>
@@ -31,6 +32,10 @@ struct ssk_lm_batch {
 	bool lds_sys = false;             // every window's reduced system fits LDS: the kernel variant without the L2-resident solver
 	// cooperative launch in flight: the state it started from (pose_bak / lm_bak) and its parameters, so that a launch whose
 	// workgroups were not all resident (stop_reason 5) is repeated with one workgroup per window by ssk_lm_batch_results
+	// node form (ssk_lm_node.hip): built when every window of the batch fits it (reduced system + a tile of node records in LDS)
+	bool node_ok = false;
+	nd_dev N{};
+	size_t node_dyn_bytes = 0;
 	bool coop_pending = false;
 	lm_cam coop_P{};
 	double* pose_bak = nullptr; double* lm_bak = nullptr;
@@ -1047,6 +1052,19 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		t_ph[0] += tms(tp0, tp1); t_ph[1] += tms(tp1, tp2); t_ph[2] += tms(tp2, tp3); t_ph[3] += tms(tp3, tnow());
 	}
 
+	// ---- node form: the default for batches whose windows all fit it (SSK_LM_KERNEL=node|tiled|coop|l2|acc picks a kernel) ----
+	nd_host NH;
+	bool node_all = !force_k || std::strcmp(force_k, "node") == 0;
+	const size_t node_lds_limit = (size_t)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC;
+	for (int w = 0; w < n_windows && node_all; ++w) {
+		const lm_win& Hw = hdr[w];
+		if (8 * nd_lds_doubles(Hw.n_edges, Hw.E, 4, 0) > node_lds_limit) { node_all = false; break; }
+		nd_win nw{};
+		nw.edge0 = Hw.edge0; nw.lm0 = Hw.lm0; nw.us0 = Hw.us0; nw.ls0 = Hw.ls0; nw.trace0 = Hw.trace0; nw.dp_trace0 = Hw.dp_trace0; nw.df_trace0 = Hw.df_trace0;
+		if (!nd_build_window(windows[w], 4, NH, nw) || 8 * NH.lds_doubles > node_lds_limit) node_all = false;
+	}
+	if (force_k && std::strcmp(force_k, "node") == 0 && !node_all)
+		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: SSK_LM_KERNEL=node, but a window of the batch does not fit the node kernel");
 	if (want_acc && !acc_all) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, with_general, false);
 	if (want_acc && !force_acc) {
 		// few windows of several tiles each: the cooperative slot kernel spreads a window over CUs, which beats one workgroup per window
@@ -1078,6 +1096,17 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
 	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan); UP(suf_rec, suf_rec); UP(tent, tent); UP(tsuf, tsuf); UP(mt, mt); UP(st_off, st_off); UP(ilane, ilane);
 #undef UP
+	b->node_ok = node_all;
+	if (node_all) {
+#define UPN(vec, field) if (!rc) rc = upload(b, NH.vec, &b->N.field)
+		UPN(win, win); UPN(tile, tile); UPN(group, group); UPN(suf, suf); UPN(obs, obs); UPN(px, px); UPN(lane, lane);
+		UPN(item, item); UPN(qs, qs); UPN(gitem, gitem); UPN(gqs, gqs);
+#undef UPN
+		b->node_dyn_bytes = 8 * NH.lds_doubles;
+		if (std::getenv("SSK_LM_DEBUG"))
+			std::fprintf(stderr, "[ssk lm] node form: %d windows, window 0: %d tiles, %d suffixes; dynamic LDS %zu B, longest item run of a lane %d\n", n_windows,
+			             NH.win[0].n_tiles, NH.win[0].n_suf, b->node_dyn_bytes, NH.max_items_per_lane);
+	}
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn; b->lds_sys = tiled_all && lds_sys_all;
 	b->acc_ok = want_acc && acc_all && tiled_all; b->schur_mfma = schur_mfma;
 	D.store_hff = 0;
@@ -1121,6 +1150,10 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
 	if (!rc) rc = scratch(b, (size_t)gtab_total, &D.suf_tab);
 	if (!rc) rc = scratch(b, 256 * (size_t)n_stile_total + 256, &D.Stile);
+	if (node_all) {
+		if (!rc) rc = scratch(b, (size_t)NH.tab_doubles, &b->N.tab);
+		if (!rc) rc = scratch(b, (size_t)SSK_ND_SCR * NH.lane.size(), &b->N.scr);
+	}
 	if (!rc) rc = scratch(b, pose.size(), &b->pose_bak);
 	if (!rc) rc = scratch(b, lm.size(), &b->lm_bak);
 	D.trace_on = trace ? 1 : 0;
@@ -1175,6 +1208,7 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
 	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
 	b->coop_pending = false;
+	if (b->node_ok) return ssk_lm_launch_node(ctx, b->D, b->N, P, b->n_windows, b->node_dyn_bytes);
 	if (b->acc_ok) return ssk_lm_launch_acc(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
 		// the grid barrier of the cooperative kernel needs all n_windows * G workgroups resident: G from what the occupancy

@@ -1,6 +1,7 @@
 // ssk_lm.h -- device data model of a batch of relative-BA windows (see ssk_lm.hip for the kernel).
 #pragma once
 #include "ssk_internal.h"
+#include "ssk_lm_node.h"
 
 constexpr int SSK_LM_MAX_PATH = 8;     // spanning-tree path length limit (reference max_tree_depth = 4, KITTI.ini:104)
 constexpr int SSK_LM_MAX_N6 = 768;     // reduced system limit: 6E <= 768 (E <= 128 optimised edges per window)
@@ -161,4 +162,6 @@ inline int ssk_lma_row_tiles(int E) { return (6 * E + 15) / 16; }
 // LDS doubles of the accumulators: H_pp blocks (36 per block pair), Schur tiles (256 per upper 16x16 tile), gradient (6E, even)
 inline int ssk_lma_acc_doubles(int E) { const int T = ssk_lma_row_tiles(E); return 36 * (E * (E + 1) / 2) + 256 * (T * (T + 1) / 2) + ((6 * E + 1) & ~1); }
 int ssk_lm_launch_acc(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma);
+// node form (ssk_lm_node.hip): one 256-thread workgroup per window, dynamic LDS sized for the largest window of the batch
+int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes);
 int ssk_lm_launch_reset(ssk_ctx* ctx, double* pose, const double* pose0, size_t n_pose, double* lm, const double* lm0, size_t n_lm);

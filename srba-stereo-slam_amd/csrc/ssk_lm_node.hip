@@ -1,0 +1,629 @@
+// ssk_lm_node.hip -- relative-BA Levenberg-Marquardt solve in the NODE form (data model and algebra: ssk_lm_node.h; contract L1-L5 of
+// oracle/oracle_lm.c; reference: rba.define_new_keyframe EST.cpp:782-784, solver_LM_schur_dense_cholesky SRBA.h:34).
+// One persistent 256-thread workgroup per window, several workgroups per CU; wave-private landmark groups, block-major pair phase with
+// register accumulators, dense LDL^T in LDS.  No float atomics: every sum has one owner and a fixed order.
+#include "ssk_lm.h"
+#include "ssk_lm_node.h"
+
+// LM parity is a 1e-6 relative tolerance (contract L5), not bit-exactness: let the compiler fuse multiply-adds here
+#pragma clang fp contract(fast)
+
+namespace {
+
+#define SSK_LM_NT 256
+#undef SSK_LM_WAVES
+#define SSK_LM_WAVES 2
+#include "ssk_lm_device.h"
+
+constexpr int NDW = NW;                 // wavefronts per workgroup = groups per tile
+constexpr int NQ = NT / 4;              // quads per workgroup
+constexpr int REC = SSK_ND_REC, STG = SSK_ND_STAGE, LREC = SSK_ND_LREC, SCR = SSK_ND_SCR;
+// node record in LDS (doubles): Zh 0..8, q 9..11, Ph 12..20, vh 21..23
+constexpr int R_Q = 9, R_P = 12, R_V = 21;
+
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double nd_rsq(double x)       // 1/sqrt(x), x > 0: hardware estimate + two Newton steps
+{
+	double y = __builtin_amdgcn_rsq(x);
+	const double hx = 0.5 * x;
+	y = y * (1.5 - hx * y * y);
+	y = y * (1.5 - hx * y * y);
+	return y;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+	return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void nd_cross(const double* a, const double* b, double* c)
+{
+	c[0] = a[1] * b[2] - a[2] * b[1];
+	c[1] = a[2] * b[0] - a[0] * b[2];
+	c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// 12 doubles of a suffix transform / scratch record from global memory as six 16-byte loads
+__device__ __forceinline__ void nd_load12(const double* __restrict__ p, double (&o)[12])
+{
+	const v2d_t* v = reinterpret_cast<const v2d_t*>(p);
+#pragma unroll
+	for (int i = 0; i < 6; ++i) { const v2d_t x = v[i]; o[2 * i] = x.x; o[2 * i + 1] = x.y; }
+}
+__device__ __forceinline__ void nd_store12(double* __restrict__ p, const double (&o)[12])
+{
+	v2d_t* v = reinterpret_cast<v2d_t*>(p);
+#pragma unroll
+	for (int i = 0; i < 6; ++i) { v2d_t x; x.x = o[2 * i]; x.y = o[2 * i + 1]; v[i] = x; }
+}
+
+// Suffix table of the window at the poses `pose` (LDS) -> tab (HBM, 12 doubles per suffix, id 0 = identity): a lane per suffix walks its
+// own chain -- the codes from the suffix down to the empty one, then the transforms from the innermost step outwards.
+__device__ void nd_build_table(const nd_win& W, const nd_i2* suf /* LDS copy */, const double* pose, double* __restrict__ tab)
+{
+	for (int id = threadIdx.x; id < W.n_suf; id += NT) {
+		int code[SSK_LM_MAX_PATH], n = 0, cur = id;
+#pragma unroll
+		for (int k = 0; k < SSK_LM_MAX_PATH; ++k) {
+			code[k] = 0;
+			if (cur != 0) { const nd_i2 r = suf[cur]; code[k] = r.x; cur = r.y; n = k + 1; }
+		}
+		double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+#pragma unroll
+		for (int k = SSK_LM_MAX_PATH - 1; k >= 0; --k) {
+			if (k >= n) continue;
+			const double* X = pose + 12 * (code[k] >> 1);
+			const int dir = code[k] & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;      // (R or R^T)(i,j) = X[si * i + sj * j]
+			double tn[3] = {T[3], T[7], T[11]};
+			if (dir) { tn[0] -= X[3]; tn[1] -= X[7]; tn[2] -= X[11]; }
+			double O[12];
+#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				const double r0 = X[si * i], r1 = X[si * i + sj], r2 = X[si * i + 2 * sj];
+#pragma unroll
+				for (int j = 0; j < 3; ++j) O[4 * i + j] = r0 * T[j] + r1 * T[4 + j] + r2 * T[8 + j];
+				O[4 * i + 3] = r0 * tn[0] + r1 * tn[1] + r2 * tn[2] + (dir ? 0.0 : X[4 * i + 3]);
+			}
+#pragma unroll
+			for (int i = 0; i < 12; ++i) T[i] = O[i];
+		}
+		nd_store12(tab + 12 * (size_t)id, T);
+	}
+}
+
+// camera-frame point and stereo prediction of a landmark f under the path transform T; returns the residual r = z - h
+__device__ __forceinline__ void nd_residual(const lm_cam& P, const double (&T)[12], const double* f, const nd_f4 px, double (&pc)[3], double& iz, double (&r)[4])
+{
+	double q[3];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) q[i] = T[4 * i] * f[0] + T[4 * i + 1] * f[1] + T[4 * i + 2] * f[2] + T[4 * i + 3];
+	const double d0 = q[0] - P.S[3], d1 = q[1] - P.S[7], d2 = q[2] - P.S[11];
+#pragma unroll
+	for (int i = 0; i < 3; ++i) pc[i] = P.S[i] * d0 + P.S[4 + i] * d1 + P.S[8 + i] * d2;
+	iz = rcp_f64(pc[2]);
+	r[0] = (double)px.x - (P.cx_l + P.fx_l * pc[0] * iz);
+	r[1] = (double)px.y - (P.cy_l + P.fy_l * pc[1] * iz);
+	r[2] = (double)px.z - (P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz);
+	r[3] = (double)px.w - (P.cy_r + P.fy_r * pc[1] * iz);
+}
+
+// ---- group phase: one wavefront linearises one landmark group; leaves the node records in `stage` (the wavefront's part of the record
+// region: lane i's record at stage + REC * i), the back-substitution records in HBM ----
+__device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G,
+                                                   const double* __restrict__ tab, double* __restrict__ stage, double lambda, bool pre, int lane, double& vmax)
+{
+	const int oi = W.obs0 + G.obs0 + min(lane, G.n_obs - 1);       // loads are unconditional on clamped indices
+	const int li = W.lane0 + G.lane0 + min(lane, G.n_lanes - 1);
+	const nd_i2 orec = N.obs[oi];
+	const nd_f4 px = N.px[oi];
+	nd_i4 lrec = N.lane[li];
+	if (lane >= G.n_lanes) lrec.w = 0;                             // idle lane
+	const int kind = lrec.w & 0xFF, root_lane = (lrec.w >> 8) & 0xFF;
+	const bool is_node = kind == 2, is_root = kind == 1;
+	// the node's transform and landmark (needed last: in flight behind everything else)
+	double Tn[12], fn[3];
+	nd_load12(tab + 12 * (size_t)(is_node ? (lrec.z & 0xFFFF) : 0), Tn);
+	{
+		const double* fp = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
+		fn[0] = fp[0]; fn[1] = fp[1]; fn[2] = fp[2];
+	}
+	// ---- lane = observation: V_o = Jf^T Jf (6), g_o = Jf^T w r (3) -> staging ----
+	{
+		double T[12], f[3], pc[3], iz, r[4];
+		nd_load12(tab + 12 * (size_t)(orec.y & 0xFFFF), T);
+		const double* fp = D.lm + 3 * (size_t)(W.lm0 + orec.x);
+		f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
+		nd_residual(P, T, f, px, pc, iz, r);
+		const double iz2 = iz * iz;
+		const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+		double w = 1.0;                                            // IRLS weight sqrt(rho'(s)/2s) = (1 + s2/k^2)^(-1/4)
+		if (P.robust) { const double rs = nd_rsq(1.0 + s2 * rcp_f64(P.kernel * P.kernel)); w = rs * nd_rsq(rs); }
+		// M = D_proj R_S^T with the structural zeros of the projection Jacobian
+		const double dxl = P.fx_l * iz, dzl = -P.fx_l * pc[0] * iz2, dyl = P.fy_l * iz, dwl = -P.fy_l * pc[1] * iz2;
+		const double dxr = P.fx_r * iz, dzr = -P.fx_r * (pc[0] - P.baseline) * iz2, dyr = P.fy_r * iz, dwr = -P.fy_r * pc[1] * iz2;
+		double M[12];
+#pragma unroll
+		for (int j = 0; j < 3; ++j) {
+			M[j] = dxl * P.S[4 * j] + dzl * P.S[4 * j + 2];
+			M[3 + j] = dyl * P.S[4 * j + 1] + dwl * P.S[4 * j + 2];
+			M[6 + j] = dxr * P.S[4 * j] + dzr * P.S[4 * j + 2];
+			M[9 + j] = dyr * P.S[4 * j + 1] + dwr * P.S[4 * j + 2];
+		}
+		double jf[12];                                             // Jf = w M R_path
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+#pragma unroll
+			for (int j = 0; j < 3; ++j) jf[3 * i + j] = w * (M[3 * i] * T[j] + M[3 * i + 1] * T[4 + j] + M[3 * i + 2] * T[8 + j]);
+		const double wr[4] = {w * r[0], w * r[1], w * r[2], w * r[3]};
+		double* o = stage + STG * lane;
+		o[0] = jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
+		o[1] = jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
+		o[2] = jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
+		o[3] = jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
+		o[4] = jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
+		o[5] = jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
+		o[6] = jf[0] * wr[0] + jf[3] * wr[1] + jf[6] * wr[2] + jf[9] * wr[3];
+		o[7] = jf[1] * wr[0] + jf[4] * wr[1] + jf[7] * wr[2] + jf[10] * wr[3];
+		o[8] = jf[2] * wr[0] + jf[5] * wr[1] + jf[8] * wr[2] + jf[11] * wr[3];
+	}
+	WAVE_SYNC();
+	// ---- lane = root / node: sums over its run of the staging (a landmark's observations are sorted so that a trie subtree is a run) ----
+	double vs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	{
+		const int a = lrec.y & 0xFF, n = kind ? (lrec.y >> 8) : 0;
+		for (int i = 0; i < n; ++i) {
+			const double* o = stage + STG * (a + i);
+#pragma unroll
+			for (int c = 0; c < 9; ++c) vs[c] += o[c];
+		}
+	}
+	WAVE_SYNC();
+	// ---- roots: V + lambda I = L L^T -> (L, L^-1, c = L^-1 g, fixed flag) for the landmark's nodes; L^-1, c to HBM for the landmark step ----
+	if (is_root) {
+		const bool opt = lrec.z >= 0;
+		double rec[16];
+		if (opt && !pre) {
+			const double a00 = vs[0] + lambda, i00 = nd_rsq(a00);
+			const double l10 = vs[1] * i00, l20 = vs[2] * i00;
+			const double a11 = vs[3] + lambda - l10 * l10, i11 = nd_rsq(a11);
+			const double l21 = (vs[4] - l20 * l10) * i11;
+			const double a22 = vs[5] + lambda - l20 * l20 - l21 * l21, i22 = nd_rsq(a22);
+			const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
+			rec[0] = a00 * i00; rec[1] = l10; rec[2] = a11 * i11; rec[3] = l20; rec[4] = l21; rec[5] = a22 * i22;
+			rec[6] = i00; rec[7] = i10; rec[8] = i11; rec[9] = i20; rec[10] = i21; rec[11] = i22;
+			rec[12] = i00 * vs[6]; rec[13] = i10 * vs[6] + i11 * vs[7]; rec[14] = i20 * vs[6] + i21 * vs[7] + i22 * vs[8];
+			rec[15] = 0.0;
+		} else {
+			rec[0] = 1; rec[1] = 0; rec[2] = 1; rec[3] = 0; rec[4] = 0; rec[5] = 1;
+			rec[6] = 1; rec[7] = 0; rec[8] = 1; rec[9] = 0; rec[10] = 0; rec[11] = 1;
+			rec[12] = 0; rec[13] = 0; rec[14] = 0; rec[15] = 1.0;
+		}
+		if (pre && opt) vmax = fmax(vmax, fmax(vs[0], fmax(vs[3], vs[5])));
+		double* o = stage + LREC * lane;
+#pragma unroll
+		for (int c = 0; c < 16; ++c) o[c] = rec[c];
+		if (!pre) {
+			double sc[12];
+#pragma unroll
+			for (int c = 0; c < 9; ++c) sc[c] = opt ? rec[6 + c] : 0.0;
+			sc[9] = sc[10] = sc[11] = 0.0;
+			nd_store12(N.scr + SCR * (size_t)li, sc);
+			if (D.store_hff && opt) {                              // diagnostics: the landmark blocks of the last linearisation
+				double* Hm = D.Hff + 9 * (size_t)(W.ls0 + lrec.z);
+				Hm[0] = vs[0]; Hm[1] = vs[1]; Hm[2] = vs[2]; Hm[3] = vs[1]; Hm[4] = vs[3]; Hm[5] = vs[4]; Hm[6] = vs[2]; Hm[7] = vs[4]; Hm[8] = vs[5];
+				double* gl = D.gf + 3 * (size_t)(W.ls0 + lrec.z);
+				gl[0] = vs[6]; gl[1] = vs[7]; gl[2] = vs[8];
+			}
+		}
+	}
+	WAVE_SYNC();
+	// ---- nodes: Z = Vs L^-T, Pm = L - Z, v = gs - Z c, rotated into the edge's frame ----
+	double out[24];
+	if (is_node) {
+		const double* lr = stage + LREC * root_lane;
+		double Lm[6], Li[6], cc[3];
+#pragma unroll
+		for (int c = 0; c < 6; ++c) { Lm[c] = lr[c]; Li[c] = lr[6 + c]; }
+		cc[0] = lr[12]; cc[1] = lr[13]; cc[2] = lr[14];
+		const bool fixed = lr[15] != 0.0;
+		const double V[9] = {vs[0], vs[1], vs[2], vs[1], vs[3], vs[4], vs[2], vs[4], vs[5]};
+		double Z[9], Pm[9], v[3];
+#pragma unroll
+		for (int i = 0; i < 3; ++i) {
+			// Z(i,j) = sum_{k <= j} V(i,k) Li(j,k)      (Li lower triangular, packed 00 10 11 20 21 22)
+			Z[3 * i] = V[3 * i] * Li[0];
+			Z[3 * i + 1] = V[3 * i] * Li[1] + V[3 * i + 1] * Li[2];
+			Z[3 * i + 2] = V[3 * i] * Li[3] + V[3 * i + 1] * Li[4] + V[3 * i + 2] * Li[5];
+			v[i] = vs[6 + i] - (Z[3 * i] * cc[0] + Z[3 * i + 1] * cc[1] + Z[3 * i + 2] * cc[2]);
+		}
+		const double Lf[9] = {Lm[0], 0, 0, Lm[1], Lm[2], 0, Lm[3], Lm[4], Lm[5]};
+#pragma unroll
+		for (int c = 0; c < 9; ++c) Pm[c] = fixed ? ((c == 0 || c == 4 || c == 8) ? 1.0 : 0.0) : Lf[c] - Z[c];
+		const double sg = ((lrec.z >> 24) & 1) ? -1.0 : 1.0;
+#pragma unroll
+		for (int i = 0; i < 3; ++i) {
+			const double r0 = sg * Tn[4 * i], r1 = sg * Tn[4 * i + 1], r2 = sg * Tn[4 * i + 2];
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				out[3 * i + j] = r0 * Z[j] + r1 * Z[3 + j] + r2 * Z[6 + j];
+				out[R_P + 3 * i + j] = r0 * Pm[j] + r1 * Pm[3 + j] + r2 * Pm[6 + j];
+			}
+			out[R_V + i] = r0 * v[0] + r1 * v[1] + r2 * v[2];
+			out[R_Q + i] = Tn[4 * i] * fn[0] + Tn[4 * i + 1] * fn[1] + Tn[4 * i + 2] * fn[2] + Tn[4 * i + 3];
+		}
+	}
+	WAVE_SYNC();
+	if (is_node) {
+		v2d_t* o = reinterpret_cast<v2d_t*>(stage + REC * lane);
+#pragma unroll
+		for (int c = 0; c < 12; ++c) { v2d_t x; x.x = out[2 * c]; x.y = out[2 * c + 1]; o[c] = x; }
+		if (!pre) {
+			const double sc[12] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], out[8], out[R_Q], out[R_Q + 1], out[R_Q + 2]};
+			nd_store12(N.scr + SCR * (size_t)li, sc);
+		}
+	}
+}
+
+// ---- pair phase: the items of one 6x6 block dealt out among the 4 lanes of a quad; 36 sums in registers ----
+// item: record X = slot | P-part << 9 (row node), record Y = slot << 10 | P-part << 19 (column node), bit 20: not nested (D = -Zh Zh^T)
+// block(r, c) = [I; [q_r]x] D [I | -[q_c]x],  D = +-X Y^T
+__device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, const int* __restrict__ items, int n, int ql, bool pre, double (&acc)[36])
+{
+	int it_next = n > ql ? items[ql] : 0;
+	for (int i = ql; i < n; i += 4) {
+		const int it = it_next;
+		if (i + 4 < n) it_next = items[i + 4];
+		const double* xr = rec + REC * (it & 511);
+		const double* yc = rec + REC * ((it >> 10) & 511);
+		const v2d_t* Xv = reinterpret_cast<const v2d_t*>(xr + R_P * ((it >> 9) & 1));
+		const v2d_t* Yv = reinterpret_cast<const v2d_t*>(yc + R_P * ((it >> 19) & 1));
+		double X[10], Y[10];
+#pragma unroll
+		for (int c = 0; c < 5; ++c) { const v2d_t a = Xv[c], b = Yv[c]; X[2 * c] = a.x; X[2 * c + 1] = a.y; Y[2 * c] = b.x; Y[2 * c + 1] = b.y; }
+		const double qr[3] = {xr[R_Q], xr[R_Q + 1], xr[R_Q + 2]}, qc[3] = {yc[R_Q], yc[R_Q + 1], yc[R_Q + 2]};
+		const double sg = ((it >> 20) & 1) ? (pre ? 0.0 : -1.0) : 1.0;
+		double Dm[9], U[9];
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			const double x0 = sg * X[3 * a], x1 = sg * X[3 * a + 1], x2 = sg * X[3 * a + 2];
+#pragma unroll
+			for (int b = 0; b < 3; ++b) Dm[3 * a + b] = x0 * Y[3 * b] + x1 * Y[3 * b + 1] + x2 * Y[3 * b + 2];
+			nd_cross(qc, Dm + 3 * a, U + 3 * a);                   // row a of -D [q_c]x = q_c x (row a of D)
+#pragma unroll
+			for (int b = 0; b < 3; ++b) { acc[6 * a + b] += Dm[3 * a + b]; acc[6 * a + 3 + b] += U[3 * a + b]; }
+		}
+#pragma unroll
+		for (int b = 0; b < 3; ++b) {                              // columns of [q_r]x D and [q_r]x U
+			const double cd[3] = {Dm[b], Dm[3 + b], Dm[6 + b]}, cu[3] = {U[b], U[3 + b], U[6 + b]};
+			double xd[3], xu[3];
+			nd_cross(qr, cd, xd);
+			nd_cross(qr, cu, xu);
+#pragma unroll
+			for (int a = 0; a < 3; ++a) { acc[6 * (3 + a) + b] += xd[a]; acc[6 * (3 + a) + 3 + b] += xu[a]; }
+		}
+	}
+}
+
+// the four lanes' sums of a quad, in the fixed order (l0 + l1) + (l2 + l3): every lane ends with the total
+__device__ __forceinline__ void nd_quad_sum36(double (&acc)[36])
+{
+#pragma unroll
+	for (int c = 0; c < 36; ++c) acc[c] += dpp_f64<0xB1>(acc[c]);      // quad_perm [1,0,3,2]
+#pragma unroll
+	for (int c = 0; c < 36; ++c) acc[c] += dpp_f64<0x4E>(acc[c]);      // quad_perm [2,3,0,1]
+}
+
+// ---- trial state: landmark steps and robust error of one group by one wavefront ----
+// backsub: node lanes t_n = Zh_n^T (dt_e + dw_e x q_n) -> root lane delta_f = L^-T (c - sum t_n), f_new = f + delta_f -> the landmark's
+// observation lanes; !backsub: the error at the current landmarks (the solve's first pass)
+__device__ __forceinline__ void nd_score_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G,
+                                               const double* __restrict__ tab, double* __restrict__ stage, const double* s_b, bool backsub, int it_idx,
+                                               int lane, double& err, double& dfn)
+{
+	const int oi = W.obs0 + G.obs0 + min(lane, G.n_obs - 1);
+	const int li = W.lane0 + G.lane0 + min(lane, G.n_lanes - 1);
+	const nd_i2 orec = N.obs[oi];
+	const nd_f4 px = N.px[oi];
+	double T[12];
+	nd_load12(tab + 12 * (size_t)(orec.y & 0xFFFF), T);
+	double f[3];
+	if (backsub) {
+		nd_i4 lrec = N.lane[li];
+		if (lane >= G.n_lanes) lrec.w = 0;
+		const int kind = lrec.w & 0xFF;
+		double sc[12], fl[3];
+		nd_load12(N.scr + SCR * (size_t)li, sc);
+		{
+			const double* fp = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
+			fl[0] = fp[0]; fl[1] = fp[1]; fl[2] = fp[2];
+		}
+		if (kind == 2) {
+			const double* d6 = s_b + 6 * ((lrec.z >> 16) & 0xFF);
+			const double dw[3] = {d6[3], d6[4], d6[5]};
+			double x[3];
+			nd_cross(dw, sc + 9, x);
+			const double a0 = d6[0] + x[0], a1 = d6[1] + x[1], a2 = d6[2] + x[2];
+			double* o = stage + 3 * lane;
+#pragma unroll
+			for (int j = 0; j < 3; ++j) o[j] = sc[j] * a0 + sc[3 + j] * a1 + sc[6 + j] * a2;
+		}
+		WAVE_SYNC();
+		double fnew[3] = {fl[0], fl[1], fl[2]};
+		if (kind == 1 && lrec.z >= 0) {
+			const int nn = (lrec.w >> 16) & 0xFF;
+			double rhs[3] = {sc[6], sc[7], sc[8]};
+			for (int i = 1; i <= nn; ++i) {
+				const double* o = stage + 3 * (lane + i);
+				rhs[0] -= o[0]; rhs[1] -= o[1]; rhs[2] -= o[2];
+			}
+			// delta_f = L^-T rhs   (sc[0..5] = L^-1 lower triangle packed 00 10 11 20 21 22)
+			const double d3[3] = {sc[0] * rhs[0] + sc[1] * rhs[1] + sc[3] * rhs[2], sc[2] * rhs[1] + sc[4] * rhs[2], sc[5] * rhs[2]};
+#pragma unroll
+			for (int a = 0; a < 3; ++a) {
+				fnew[a] = fl[a] + d3[a];
+				dfn += d3[a] * d3[a];
+				D.lm_new[3 * (size_t)(W.lm0 + lrec.x) + a] = fnew[a];
+				if (D.trace_on) D.df_trace[W.df_trace0 + (size_t)it_idx * 3 * W.L + 3 * lrec.z + a] = d3[a];
+			}
+		}
+		WAVE_SYNC();
+		if (kind == 1) { double* o = stage + 3 * lane; o[0] = fnew[0]; o[1] = fnew[1]; o[2] = fnew[2]; }
+		WAVE_SYNC();
+		const double* fo = stage + 3 * ((orec.y >> 16) & 0xFF);
+		f[0] = fo[0]; f[1] = fo[1]; f[2] = fo[2];
+		WAVE_SYNC();                                               // (the next group of this wavefront overwrites the staging)
+	} else {
+		const double* fp = D.lm + 3 * (size_t)(W.lm0 + orec.x);
+		f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
+	}
+	double pc[3], iz, r[4];
+	nd_residual(P, T, f, px, pc, iz, r);
+	const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+	double rho = s2;
+	if (P.robust) { const double k2 = P.kernel * P.kernel, u = 1.0 + s2 * rcp_f64(k2); rho = 2.0 * k2 * (u * nd_rsq(u) - 1.0); }
+	if (lane < G.n_obs) err += rho;
+}
+
+__device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const lm_cam& P_arg, int dyn_doubles)
+{
+	__shared__ lm_cam s_P;
+	if (threadIdx.x == 0) s_P = P_arg;
+	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | delta | pivots | block accumulators | gradient | records / reduced system]
+	__shared__ double s_part[NW];
+	__shared__ double s_lambda, s_nu, s_err;
+	__shared__ int s_accept, s_stop, s_iters, s_accepted, s_cur;
+	__syncthreads();
+	const lm_cam& P = s_P;
+	const int wi = (int)blockIdx.x;
+	const nd_win W = N.win[wi];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, quad = tid >> 2, ql = tid & 3;
+	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1, np = n6 | 1, n_pairs = W.E * (W.E + 1) / 2;
+	double* pose_cur = s_dyn;
+	double* pose_new = s_dyn + 12 * W.n_edges;
+	double* s_b = s_dyn + 24 * W.n_edges;
+	double* s_inv = s_b + n6p;
+	double* Hb = s_inv + n6p;                          // 36 doubles per block pair (e <= e2): H(6e + a, 6e2 + b) at 36 pid + 6a + b
+	double* g_acc = Hb + 36 * n_pairs;
+	nd_i2* s_suf = reinterpret_cast<nd_i2*>(g_acc + n6p);    // the trie's (first step, rest) records: the table builds walk them
+	double* reg = g_acc + n6p + ((W.n_suf + 1) & ~1);  // node records of a tile (wave w: reg + 64 REC w), later the dense bordered system
+	(void)dyn_doubles;
+	double* stage = reg + 64 * REC * wave;
+	const nd_group* groups = N.group + W.grp0;
+	int n_groups = 0;
+	if (W.n_tiles > 0) { const nd_tile Tl = N.tile[W.tile0 + W.n_tiles - 1]; n_groups = Tl.grp0 + Tl.n_grp; }
+	double* tabs[2] = {N.tab + W.tab0, N.tab + W.tab0 + 12 * (size_t)W.n_suf};
+
+	for (int i = tid; i < 12 * W.n_edges; i += NT) {
+		const double v = D.pose[12 * (size_t)W.edge0 + i];
+		pose_cur[i] = v; pose_new[i] = v;
+	}
+	for (int i = tid; i < W.n_suf; i += NT) s_suf[i] = N.suf[W.suf0 + i];
+	// (a landmark nobody observes has no root lane: its trial position is its position)
+	for (int i = tid; i < 3 * W.n_lms; i += NT) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
+	__syncthreads();
+	nd_build_table(W, s_suf, pose_cur, tabs[0]);
+	__syncthreads();
+	double e0 = 0.0, dummy = 0.0;
+	for (int g = wave; g < n_groups; g += NDW) nd_score_group(D, N, W, P, groups[g], tabs[0], stage, s_b, false, 0, lane, e0, dummy);
+	e0 = block_sum(e0, s_part);
+	if (tid == 0) {
+		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_cur = 0;
+		ssk_lm_result& R = D.res[wi];
+		R.err_init = e0; R.n_obs = W.n_obs; R.stop_reason = (W.E == 0 && W.L == 0) ? 3 : 0;
+	}
+	__syncthreads();
+	if (W.E == 0 && W.L == 0) {
+		if (tid == 0) { ssk_lm_result& R = D.res[wi]; R.iters = 0; R.accepted = 0; R.err_final = e0; R.lambda_final = -1.0; }
+		return;
+	}
+
+	while (true) {
+		__syncthreads();
+		if (s_iters >= P.max_iters) break;
+		if (W.n_obs > 0 && sqrt(s_err / W.n_obs) < P.stop_rmse) { if (tid == 0) s_stop = 1; break; }
+		const double lambda = s_lambda;
+		const bool pre = lambda < 0;                   // first pass of a solve: only diag(H_pp) and diag(V), for lambda_0
+		const int it_idx = s_iters, cur = s_cur;
+		const double* tab_cur = tabs[cur];
+		double vmax = 0.0;
+		for (int i = tid; i < 36 * n_pairs + n6p; i += NT) Hb[i] = 0.0;      // (block accumulators and gradient are contiguous)
+		__syncthreads();
+		// ---- linearisation: tile by tile ----
+		for (int t = 0; t < W.n_tiles; ++t) {
+			const nd_tile T = N.tile[W.tile0 + t];
+			nd_i2 q0 = nd_i2{0, 0};                    // (round 0's slot in flight behind the group phase)
+			if (T.n_rounds > 0) q0 = N.qs[W.qs0 + T.qs0 + quad];
+			if (wave < T.n_grp) nd_linearise_group(D, N, W, P, groups[T.grp0 + wave], tab_cur, stage, lambda, pre, lane, vmax);
+			__syncthreads();
+			for (int r = 0; r < T.n_rounds; ++r) {
+				const nd_i2 q = r == 0 ? q0 : N.qs[W.qs0 + T.qs0 + r * NQ + quad];
+				const int pid = q.x & 0xFFFF, n = (q.x >> 16) & 0xFFFF;
+				double acc[36];
+#pragma unroll
+				for (int c = 0; c < 36; ++c) acc[c] = 0.0;
+				nd_pair_items(reg, N.item + W.item0 + q.y, n, ql, pre, acc);
+				nd_quad_sum36(acc);
+				if (ql == 0 && n > 0) {
+					v2d_t* hb = reinterpret_cast<v2d_t*>(Hb + 36 * pid);
+#pragma unroll
+					for (int c = 0; c < 18; ++c) { v2d_t x = hb[c]; x.x += acc[2 * c]; x.y += acc[2 * c + 1]; hb[c] = x; }
+				}
+			}
+			if (!pre)
+				for (int k = quad; k < T.n_gqs; k += NQ) {
+					// reduced gradient of one edge: sum over the tile's nodes on it of [vh; q x vh]
+					const nd_i2 q = N.gqs[W.gqs0 + T.gqs0 + k];
+					const int e = q.x & 0xFFFF, n = (q.x >> 16) & 0xFFFF;
+					const int* items = N.gitem + W.gitem0 + q.y;
+					double ga[6] = {0, 0, 0, 0, 0, 0};
+					for (int i = ql; i < n; i += 4) {
+						const double* rc = reg + REC * items[i];
+						const double vh[3] = {rc[R_V], rc[R_V + 1], rc[R_V + 2]}, qq[3] = {rc[R_Q], rc[R_Q + 1], rc[R_Q + 2]};
+						double x[3];
+						nd_cross(qq, vh, x);
+#pragma unroll
+						for (int c = 0; c < 3; ++c) { ga[c] += vh[c]; ga[3 + c] += x[c]; }
+					}
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ga[c] += dpp_f64<0xB1>(ga[c]);
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ga[c] += dpp_f64<0x4E>(ga[c]);
+					if (ql == 0) {
+#pragma unroll
+						for (int c = 0; c < 6; ++c) g_acc[6 * e + c] += ga[c];
+					}
+				}
+			__syncthreads();
+		}
+		if (pre) {
+			// lambda0 = tau * max diag(H): the diagonal blocks of H_pp and the landmark blocks' diagonals
+			double mx = vmax;
+			for (int it = tid; it < n6; it += NT) {
+				const int e = it / 6, a = it - 6 * e;
+				mx = fmax(mx, Hb[36 * (e * (e + 1) / 2 + e) + 7 * a]);
+			}
+			mx = block_max(mx, s_part);
+			if (tid == 0) s_lambda = P.tau * mx;
+			continue;
+		}
+		// ---- the reduced system: A = H_pp - S + lambda I over the dead records, border row = reduced gradient; LDL^T ----
+		for (int it = tid; it < 36 * n_pairs; it += NT) {
+			const int pid = it / 36, ab = it - 36 * pid, a = ab / 6, b = ab - 6 * a;
+			int e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
+			while ((e2 + 1) * (e2 + 2) / 2 <= pid) ++e2;
+			while (e2 * (e2 + 1) / 2 > pid) --e2;
+			const int e = pid - e2 * (e2 + 1) / 2;
+			if (e == e2 && a > b) continue;
+			const int row = 6 * e + a, col = 6 * e2 + b;
+			double v = Hb[it];
+			if (row == col) v += lambda;
+			reg[row * np + col] = v;
+			reg[col * np + row] = v;
+		}
+		for (int i = tid; i < n6; i += NT) reg[n6 * np + i] = g_acc[i];
+		__syncthreads();
+		bool ok = true;
+		if (n6 > 0) ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
+		double dpn = 0, dfn = 0, err_new = s_err;
+		if (ok) {
+			for (int i = tid; i < n6; i += NT) {
+				dpn += s_b[i] * s_b[i];
+				if (D.trace_on) D.dp_trace[W.dp_trace0 + (size_t)it_idx * n6 + i] = s_b[i];
+			}
+			// edges: T_new = exp(eps) (+) T
+			for (int e = tid; e < W.E; e += NT) {
+				const int ei = D.slot_edge[W.us0 + e];
+				const double* T = pose_cur + 12 * ei;
+				double* O = pose_new + 12 * ei;
+				double eps[6], R[9];
+#pragma unroll
+				for (int a = 0; a < 6; ++a) eps[a] = s_b[6 * e + a];
+				so3_exp(eps + 3, R);
+#pragma unroll
+				for (int i = 0; i < 3; ++i) {
+#pragma unroll
+					for (int j = 0; j < 3; ++j) O[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+					O[4 * i + 3] = R[3 * i] * T[3] + R[3 * i + 1] * T[7] + R[3 * i + 2] * T[11] + eps[i];
+				}
+			}
+			__syncthreads();
+			nd_build_table(W, s_suf, pose_new, tabs[cur ^ 1]);
+			__syncthreads();
+			double e = 0.0;
+			for (int g = wave; g < n_groups; g += NDW) nd_score_group(D, N, W, P, groups[g], tabs[cur ^ 1], stage, s_b, true, it_idx, lane, e, dfn);
+			err_new = block_sum(e, s_part);
+		}
+		dpn = block_sum(dpn, s_part);
+		dfn = block_sum(dfn, s_part);
+		__syncthreads();
+		if (tid == 0) {
+			const int accepted = ok && err_new < s_err;
+			if (D.trace_on) {
+				ssk_lm_trace_entry& t = D.trace[W.trace0 + it_idx];
+				t.lambda = lambda; t.err_before = s_err; t.err_after = err_new; t.delta_p_norm = sqrt(dpn);
+				t.delta_f_norm = sqrt(dfn); t.accepted = accepted; t.cholesky_ok = ok;
+			}
+			const int converged = ok && P.conv_rel > 0 && fabs(s_err - err_new) <= P.conv_rel * s_err;
+			s_accept = accepted;
+			s_iters = it_idx + 1;
+			if (accepted) {
+				s_err = err_new; s_lambda = lambda * 0.1; s_nu = 2.0; s_accepted += 1; s_cur = cur ^ 1;
+				if (converged) s_stop = 4;
+			} else if (converged) {
+				s_stop = 4;
+			} else {
+				s_lambda = lambda * s_nu; s_nu *= 2.0;
+				if (s_lambda > P.max_lambda) s_stop = 2;
+			}
+		}
+		__syncthreads();
+		if (s_accept) {
+			for (int e = tid; e < W.E; e += NT) {
+				const int ei = D.slot_edge[W.us0 + e];
+				for (int c = 0; c < 12; ++c) pose_cur[12 * ei + c] = pose_new[12 * ei + c];
+			}
+			for (int l = tid; l < W.L; l += NT) {
+				const int li = D.slot_lm[W.ls0 + l];
+				for (int c = 0; c < 3; ++c) D.lm[3 * (size_t)(W.lm0 + li) + c] = D.lm_new[3 * (size_t)(W.lm0 + li) + c];
+			}
+		}
+		__syncthreads();
+		if (s_stop == 2 || s_stop == 4) break;
+	}
+	__syncthreads();
+	// publish the final edge poses (they lived in LDS during the solve)
+	for (int e = tid; e < W.E; e += NT) {
+		const int ei = D.slot_edge[W.us0 + e];
+		for (int c = 0; c < 12; ++c) D.pose[12 * (size_t)(W.edge0 + ei) + c] = pose_cur[12 * ei + c];
+	}
+	if (tid == 0) {
+		ssk_lm_result& R = D.res[wi];
+		R.iters = s_iters; R.accepted = s_accepted; R.stop_reason = s_stop; R.err_final = s_err; R.lambda_final = s_lambda;
+	}
+}
+
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_node_kernel(lm_dev D, nd_dev N, lm_cam P, int dyn_doubles)
+{
+	nd_body(D, N, P, dyn_doubles);
+}
+
+}  // namespace
+
+int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes)
+{
+	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
+	static bool attr_set = false;
+	if (!attr_set) {
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_node_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		attr_set = true;
+	}
+	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
+	hipLaunchKernelGGL(lm_solve_node_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, N, P, (int)(dyn_lds_bytes / 8));
+	SSK_LAUNCH_CHECK(ctx, "lm_solve_node_kernel");
+	return SSK_OK;
+}

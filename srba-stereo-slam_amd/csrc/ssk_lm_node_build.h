@@ -1,0 +1,239 @@
+// ssk_lm_node_build.h -- host side of the NODE form (ssk_lm_node.h): the symbolic structure of one window -- suffix trie, nodes,
+// landmark groups, tiles, block-sorted items -- as SRBA does its graph bookkeeping on the CPU.  HIP free (plain C++17): the
+// library (ssk_capi_lm.hip) and the CPU emulation of the kernel's data flow (tools/lm_node_emu.cpp, tests/test_lm_node_form.py)
+// compile the same code.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+#include "../../include/ssk_capi.h"
+#include "ssk_lm_node.h"
+
+struct nd_host {
+	std::vector<nd_win> win;
+	std::vector<nd_tile> tile;
+	std::vector<nd_group> group;
+	std::vector<nd_i2> suf, obs, qs, gqs;
+	std::vector<nd_f4> px;
+	std::vector<nd_i4> lane;
+	std::vector<int> item, gitem;
+	long long tab_doubles = 0;          // suffix tables of all windows
+	size_t lds_doubles = 0;             // largest dynamic LDS need of a window (doubles)
+	int max_items_per_lane = 0;         // (diagnostic: the longest item run of a quad lane)
+};
+
+// dynamic LDS of a window, doubles: edge poses twice, solution + pivots, block accumulators, gradient accumulator, the trie records, then the region the
+// node records of a tile (waves x 64 x SSK_ND_REC) share with the dense bordered system ((6E + 1) x (6E | 1))
+inline size_t nd_lds_doubles(int n_edges, int E, int waves, int n_suf)
+{
+	const size_t n6 = 6 * (size_t)E, n6p = (n6 + 1) & ~(size_t)1;
+	const size_t region = std::max((size_t)waves * 64 * SSK_ND_REC, (n6 + 1) * (n6 | 1));
+	return 24 * (size_t)n_edges + 2 * n6p + 36 * ((size_t)E * (E + 1) / 2) + n6p + (((size_t)n_suf + 1) & ~(size_t)1) + region;
+}
+
+// Appends window Wn to H (bases edge0 / lm0 / us0 / ls0 / trace offsets are the caller's: the families are shared with the other
+// kernels' structures).  Returns false -- and leaves H untouched -- when the window does not fit the node kernel:
+// more than 128 optimised edges, a landmark with more than 64 observations or more than 63 nodes, more than 65535 suffixes.
+inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */)
+{
+	const int n_obs = Wn.n_obs, n_lms = Wn.n_lms_total;
+	int E = 0, L = 0;
+	for (int e = 0; e < Wn.n_edges_total; ++e) if (Wn.edge_unknown_slot[e] >= 0) ++E;
+	for (int l = 0; l < n_lms; ++l) if (Wn.lm_unknown_slot[l] >= 0) ++L;
+	if (E > 128 || waves < 1 || waves > SSK_ND_MAX_WAVES) return false;
+	// ---- suffix trie (ids in creation order: the rest of a suffix always has a smaller id) ----
+	std::vector<nd_i2> suf(1, nd_i2{-1, -1});
+	std::vector<int> obs_suf((size_t)n_obs, 0);
+	{
+		std::unordered_map<uint64_t, int> ids;
+		ids.reserve(1024);
+		for (int o = 0; o < n_obs; ++o) {
+			int cur = 0;
+			for (int p = Wn.obs_path_off[o + 1] - 1; p >= Wn.obs_path_off[o]; --p) {
+				const uint64_t key = ((uint64_t)(uint32_t)Wn.path_edge[p] << 32) | (uint32_t)cur;
+				auto it = ids.find(key);
+				if (it == ids.end()) { it = ids.emplace(key, (int)suf.size()).first; suf.push_back(nd_i2{Wn.path_edge[p], cur}); }
+				cur = it->second;
+			}
+			obs_suf[o] = cur;
+		}
+	}
+	const int n_suf = (int)suf.size();
+	if (n_suf > 65535) return false;
+	// ---- landmarks: observations sorted so that every trie subtree is a run; nodes ----
+	std::vector<std::vector<int>> lm_obs((size_t)n_lms);
+	for (int o = 0; o < n_obs; ++o) lm_obs[(size_t)Wn.obs_lm[o]].push_back(o);
+	struct node { int key, a, n; };                       // key suffix, run of the landmark's sorted observations
+	struct lmk { int l, obs_first; std::vector<int> obs; std::vector<node> nodes; };
+	std::vector<lmk> lms;
+	auto optimised = [&](int sid) { return Wn.edge_unknown_slot[suf[(size_t)sid].x >> 1] >= 0; };
+	std::vector<std::vector<int>> chains;                 // per observation of the current landmark: suffix ids from the shortest to the whole path
+	for (int l = 0; l < n_lms; ++l) {
+		const std::vector<int>& ob = lm_obs[(size_t)l];
+		if (ob.empty()) continue;                         // never observed: nothing to linearise, nothing moves it
+		if (ob.size() > 64) return false;
+		chains.assign(ob.size(), std::vector<int>());
+		for (size_t k = 0; k < ob.size(); ++k) {
+			for (int s = obs_suf[(size_t)ob[k]]; s != 0; s = suf[(size_t)s].y) chains[k].push_back(s);
+			std::reverse(chains[k].begin(), chains[k].end());
+		}
+		std::vector<int> ord(ob.size());
+		for (size_t k = 0; k < ord.size(); ++k) ord[k] = (int)k;
+		std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return chains[(size_t)a] < chains[(size_t)b]; });
+		lmk M;
+		M.l = l; M.obs_first = 0;
+		for (int k : ord) M.obs.push_back(ob[(size_t)k]);
+		// nodes in the order of their first observation (depth first): a node's observations are the run of those whose chain holds its key
+		for (size_t k = 0; k < ord.size(); ++k)
+			for (int s : chains[(size_t)ord[k]]) {
+				if (!optimised(s)) continue;
+				bool seen = false;
+				for (node& nd : M.nodes) if (nd.key == s) { nd.n = (int)k + 1 - nd.a; seen = true; break; }
+				if (!seen) M.nodes.push_back(node{s, (int)k, 1});
+			}
+		if (M.nodes.size() > 63) return false;
+		lms.push_back(std::move(M));
+	}
+	// optimised landmarks first, in slot order (the landmark trace is by slot), then the fixed ones
+	std::stable_sort(lms.begin(), lms.end(), [&](const lmk& a, const lmk& b) {
+		const int sa = Wn.lm_unknown_slot[a.l], sb = Wn.lm_unknown_slot[b.l];
+		if ((sa >= 0) != (sb >= 0)) return sa >= 0;
+		return sa >= 0 ? sa < sb : a.l < b.l;
+	});
+	// ---- groups: greedy runs of landmarks with <= 64 observations and <= 64 lanes ----
+	const size_t win_i = H.win.size();
+	(void)win_i;
+	hdr.n_edges = Wn.n_edges_total; hdr.E = E; hdr.n_lms = n_lms; hdr.L = L; hdr.n_obs = n_obs; hdr.n_suf = n_suf;
+	hdr.suf0 = (int)H.suf.size(); hdr.tile0 = (int)H.tile.size(); hdr.grp0 = (int)H.group.size();
+	hdr.obs0 = (int)H.obs.size(); hdr.lane0 = (int)H.lane.size();
+	hdr.item0 = (int)H.item.size(); hdr.qs0 = (int)H.qs.size(); hdr.gitem0 = (int)H.gitem.size(); hdr.gqs0 = (int)H.gqs.size();
+	hdr.tab0 = H.tab_doubles; hdr.pad0 = 0;
+	std::vector<nd_group> groups;
+	std::vector<nd_i2> w_obs;
+	std::vector<nd_f4> w_px;
+	std::vector<nd_i4> w_lane;
+	struct gnode { int lmk, node, slot_lane; };            // per lane of a group: which landmark / node (-1 = root)
+	std::vector<std::vector<gnode>> glanes;
+	{
+		nd_group G{0, 0, 0, 0};
+		std::vector<gnode> gl;
+		auto flush = [&] {
+			if (G.n_lanes == 0) return;
+			groups.push_back(G); glanes.push_back(gl);
+			G.obs0 += G.n_obs; G.lane0 += G.n_lanes; G.n_obs = 0; G.n_lanes = 0; gl.clear();
+		};
+		for (size_t m = 0; m < lms.size(); ++m) {
+			const lmk& M = lms[m];
+			const int no = (int)M.obs.size(), nl = 1 + (int)M.nodes.size();
+			if (G.n_obs + no > 64 || G.n_lanes + nl > 64) flush();
+			const int root_lane = G.n_lanes, obs_a = G.n_obs;
+			for (int o : M.obs) {
+				w_obs.push_back(nd_i2{M.l, obs_suf[(size_t)o] | (root_lane << 16)});
+				w_px.push_back(nd_f4{Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]});
+			}
+			w_lane.push_back(nd_i4{M.l, obs_a | (no << 8), Wn.lm_unknown_slot[M.l], 1 | (root_lane << 8) | ((int)M.nodes.size() << 16)});
+			gl.push_back(gnode{(int)m, -1, root_lane});
+			for (size_t k = 0; k < M.nodes.size(); ++k) {
+				const node& nd = M.nodes[k];
+				const int code = suf[(size_t)nd.key].x, inv = code & 1;
+				const int tsuf = inv ? suf[(size_t)nd.key].y : nd.key;
+				const int es = Wn.edge_unknown_slot[code >> 1];
+				w_lane.push_back(nd_i4{M.l, (obs_a + nd.a) | (nd.n << 8), tsuf | (es << 16) | (inv << 24), 2 | (root_lane << 8)});
+				gl.push_back(gnode{(int)m, (int)k, root_lane + 1 + (int)k});
+			}
+			G.n_obs += no; G.n_lanes += nl;
+		}
+		flush();
+	}
+	// ---- tiles: `waves` groups each; items of a tile sorted by block; a quad of lanes per block and round ----
+	const int NQ = waves * 16;
+	const int n_pairs = E * (E + 1) / 2;
+	auto pid_of = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
+	std::vector<nd_tile> tiles;
+	std::vector<int> w_item, w_gitem;
+	std::vector<nd_i2> w_qs, w_gqs;
+	std::vector<std::vector<int>> by_pid((size_t)n_pairs), by_edge((size_t)E);
+	std::vector<int> used_pid;
+	int max_per_lane = 0;
+	for (size_t g0 = 0; g0 < groups.size(); g0 += (size_t)waves) {
+		nd_tile T{};
+		T.grp0 = (int)g0; T.n_grp = (int)std::min(groups.size() - g0, (size_t)waves);
+		used_pid.clear();
+		for (int wv = 0; wv < T.n_grp; ++wv) {
+			const std::vector<gnode>& gl = glanes[g0 + (size_t)wv];
+			for (size_t a = 0; a < gl.size(); ++a) {
+				if (gl[a].node < 0) continue;
+				const lmk& M = lms[(size_t)gl[a].lmk];
+				const bool opt = Wn.lm_unknown_slot[M.l] >= 0;
+				const int ka = M.nodes[(size_t)gl[a].node].key, ea = Wn.edge_unknown_slot[suf[(size_t)ka].x >> 1];
+				const int slot_a = 64 * wv + gl[a].slot_lane;
+				by_edge[(size_t)ea].push_back(slot_a);
+				// partners: the later nodes of the same landmark (they follow in the lane order) and the node itself
+				for (size_t b = a; b < gl.size() && gl[b].lmk == gl[a].lmk; ++b) {
+					const int kb = M.nodes[(size_t)gl[b].node].key, eb = Wn.edge_unknown_slot[suf[(size_t)kb].x >> 1];
+					const int slot_b = 64 * wv + gl[b].slot_lane;
+					// nested: one key is a suffix of the other (walk the longer one's rests)
+					auto is_suffix_of = [&](int shorter, int longer) { for (int s = longer; s != 0; s = suf[(size_t)s].y) if (s == shorter) return true; return false; };
+					int far = 0;                                   // 1: a far (b's key is a suffix of a's), 2: b far, 0: not nested
+					if (is_suffix_of(kb, ka)) far = 1; else if (is_suffix_of(ka, kb)) far = 2;
+					if (far == 0 && !opt) continue;
+					// item (row r, column c): X = far == row ? Zh_r : (nested ? Ph_r : Zh_r), Y likewise
+					auto emit = [&](int slot_r, int slot_c, bool r_far, bool c_far, int pid) {
+						const int xp = (far != 0 && !r_far) ? 1 : 0, yp = (far != 0 && !c_far) ? 1 : 0;
+						if (by_pid[(size_t)pid].empty()) used_pid.push_back(pid);
+						by_pid[(size_t)pid].push_back(slot_r | (xp << 9) | (slot_c << 10) | (yp << 19) | ((far == 0 ? 1 : 0) << 20));
+					};
+					if (a == b) emit(slot_a, slot_a, true, false, pid_of(ea, ea));
+					else if (ea < eb) emit(slot_a, slot_b, far == 1, far == 2, pid_of(ea, eb));
+					else if (eb < ea) emit(slot_b, slot_a, far == 2, far == 1, pid_of(eb, ea));
+					else {                                         // two nodes of one landmark on the same edge: both orders go to the diagonal block
+						emit(slot_a, slot_b, far == 1, far == 2, pid_of(ea, ea));
+						emit(slot_b, slot_a, far == 2, far == 1, pid_of(ea, ea));
+					}
+				}
+			}
+		}
+		// most items first: the 16 quads of a wavefront run in lockstep, so blocks of similar size share one
+		std::stable_sort(used_pid.begin(), used_pid.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
+		T.qs0 = (int)w_qs.size();
+		T.n_rounds = ((int)used_pid.size() + NQ - 1) / NQ;
+		for (size_t k = 0; k < (size_t)T.n_rounds * NQ; ++k) {
+			if (k < used_pid.size()) {
+				std::vector<int>& v = by_pid[(size_t)used_pid[k]];
+				if (v.size() > 65535) return false;
+				w_qs.push_back(nd_i2{used_pid[k] | ((int)v.size() << 16), (int)w_item.size()});
+				w_item.insert(w_item.end(), v.begin(), v.end());
+				max_per_lane = std::max(max_per_lane, ((int)v.size() + 3) / 4);
+				v.clear();
+			} else w_qs.push_back(nd_i2{0, 0});
+		}
+		T.gqs0 = (int)w_gqs.size(); T.n_gqs = 0;
+		for (int e = 0; e < E; ++e) {
+			std::vector<int>& v = by_edge[(size_t)e];
+			if (v.empty()) continue;
+			w_gqs.push_back(nd_i2{e | ((int)v.size() << 16), (int)w_gitem.size()});
+			w_gitem.insert(w_gitem.end(), v.begin(), v.end());
+			++T.n_gqs;
+			v.clear();
+		}
+		tiles.push_back(T);
+	}
+	hdr.n_tiles = (int)tiles.size();
+	// ---- commit ----
+	H.suf.insert(H.suf.end(), suf.begin(), suf.end());
+	H.tile.insert(H.tile.end(), tiles.begin(), tiles.end());
+	H.group.insert(H.group.end(), groups.begin(), groups.end());
+	H.obs.insert(H.obs.end(), w_obs.begin(), w_obs.end());
+	H.px.insert(H.px.end(), w_px.begin(), w_px.end());
+	H.lane.insert(H.lane.end(), w_lane.begin(), w_lane.end());
+	H.item.insert(H.item.end(), w_item.begin(), w_item.end());
+	H.qs.insert(H.qs.end(), w_qs.begin(), w_qs.end());
+	H.gitem.insert(H.gitem.end(), w_gitem.begin(), w_gitem.end());
+	H.gqs.insert(H.gqs.end(), w_gqs.begin(), w_gqs.end());
+	H.tab_doubles += 2LL * 12 * n_suf;
+	H.lds_doubles = std::max(H.lds_doubles, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf));
+	H.max_items_per_lane = std::max(H.max_items_per_lane, max_per_lane);
+	H.win.push_back(hdr);
+	return true;
+}

@@ -1,0 +1,256 @@
+// lm_node_emu.cpp -- CPU emulation of the DATA FLOW of lm_solve_node_kernel (srba-stereo-slam_amd/csrc/ssk_lm_node.hip) on the tables
+// the library's own host builder produces (ssk_lm_node_build.h): groups, staging runs, root / node lanes, node records, block-sorted
+// items, gradient items, the landmark step.  Test infrastructure (tests/test_lm_node_form.py compares its reduced system with the dense
+// textbook form): it checks the symbolic structure and the bit fields without a GPU; the kernel's lane mechanics (DPP sums, LDS
+// overlays) are not modelled.  Build: g++ -O2 -shared -fPIC tools/lm_node_emu.cpp -o <out>/liblm_node_emu.so
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "../srba-stereo-slam_amd/csrc/ssk_lm_node_build.h"
+
+namespace {
+
+void cross(const double* a, const double* b, double* c)
+{
+	c[0] = a[1] * b[2] - a[2] * b[1];
+	c[1] = a[2] * b[0] - a[0] * b[2];
+	c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+void build_table(const nd_host& H, const nd_win& W, const double* pose, std::vector<double>& tab)
+{
+	tab.assign(12 * (size_t)W.n_suf, 0.0);
+	for (int id = 0; id < W.n_suf; ++id) {
+		int code[8], n = 0, cur = id;
+		while (cur != 0) { const nd_i2 r = H.suf[(size_t)W.suf0 + cur]; code[n++] = r.x; cur = r.y; }
+		double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+		for (int k = n - 1; k >= 0; --k) {
+			const double* X = pose + 12 * (code[k] >> 1);
+			const int dir = code[k] & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;
+			double tn[3] = {T[3], T[7], T[11]};
+			if (dir) { tn[0] -= X[3]; tn[1] -= X[7]; tn[2] -= X[11]; }
+			double O[12];
+			for (int i = 0; i < 3; ++i) {
+				const double r0 = X[si * i], r1 = X[si * i + sj], r2 = X[si * i + 2 * sj];
+				for (int j = 0; j < 3; ++j) O[4 * i + j] = r0 * T[j] + r1 * T[4 + j] + r2 * T[8 + j];
+				O[4 * i + 3] = r0 * tn[0] + r1 * tn[1] + r2 * tn[2] + (dir ? 0.0 : X[4 * i + 3]);
+			}
+			std::memcpy(T, O, sizeof T);
+		}
+		std::memcpy(&tab[12 * (size_t)id], T, sizeof T);
+	}
+}
+
+}  // namespace
+
+extern "C" {
+
+// Linearisation at the window's state: Hred (n6 x n6, row major, both triangles, lambda on the diagonal) and the reduced gradient g.
+// dp != NULL: also the landmark step df (3 per optimised slot) for the given edge step.  pre != 0: the lambda_0 pass (diag blocks of
+// H_pp only, vmax = largest diagonal of an optimised landmark's block).  Returns 0, or -1 when the window does not fit the node form.
+int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lambda, int pre, int waves, double* Hred, double* g, const double* dp, double* df,
+                     double* vmax_out, int* stats /* tiles, groups, items, max items per lane */)
+{
+	nd_host H;
+	nd_win hdr{};
+	if (!nd_build_window(*Wn, waves, H, hdr)) return -1;
+	const nd_win& W = H.win[0];
+	const int n6 = 6 * W.E;
+	std::vector<double> tab;
+	build_table(H, W, Wn->edge_inv_pose, tab);
+	const int n_pairs = W.E * (W.E + 1) / 2;
+	std::vector<double> Hb(36 * (size_t)n_pairs, 0.0), gacc((size_t)n6 + 1, 0.0);
+	std::vector<double> scr(12 * H.lane.size(), 0.0);
+	double vmax = 0.0;
+	const double* S = P->sensor_pose;
+	int n_groups = 0;
+	for (int t = 0; t < W.n_tiles; ++t) {
+		const nd_tile& T = H.tile[(size_t)W.tile0 + t];
+		std::vector<double> rec((size_t)waves * 64 * SSK_ND_REC, 0.0);
+		for (int wv = 0; wv < T.n_grp; ++wv) {
+			const nd_group& G = H.group[(size_t)W.grp0 + T.grp0 + wv];
+			++n_groups;
+			double stage[64 * 9];
+			for (int lane = 0; lane < G.n_obs; ++lane) {
+				const nd_i2 orec = H.obs[(size_t)W.obs0 + G.obs0 + lane];
+				const nd_f4 px = H.px[(size_t)W.obs0 + G.obs0 + lane];
+				const double* Tp = &tab[12 * (size_t)(orec.y & 0xFFFF)];
+				const double* f = Wn->lm_pos + 3 * orec.x;
+				double q[3], pc[3];
+				for (int i = 0; i < 3; ++i) q[i] = Tp[4 * i] * f[0] + Tp[4 * i + 1] * f[1] + Tp[4 * i + 2] * f[2] + Tp[4 * i + 3];
+				const double d0 = q[0] - S[3], d1 = q[1] - S[7], d2 = q[2] - S[11];
+				for (int i = 0; i < 3; ++i) pc[i] = S[i] * d0 + S[4 + i] * d1 + S[8 + i] * d2;
+				const double iz = 1.0 / pc[2], iz2 = iz * iz;
+				const double r[4] = {(double)px.x - (P->cx_l + P->fx_l * pc[0] * iz), (double)px.y - (P->cy_l + P->fy_l * pc[1] * iz),
+				                     (double)px.z - (P->cx_r + P->fx_r * (pc[0] - P->baseline) * iz), (double)px.w - (P->cy_r + P->fy_r * pc[1] * iz)};
+				const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+				const double w = P->use_robust_kernel ? std::sqrt(1.0 / std::sqrt(1.0 + s2 / (P->kernel_param * P->kernel_param))) : 1.0;
+				const double Dm[12] = {P->fx_l * iz, 0, -P->fx_l * pc[0] * iz2, 0, P->fy_l * iz, -P->fy_l * pc[1] * iz2,
+				                       P->fx_r * iz, 0, -P->fx_r * (pc[0] - P->baseline) * iz2, 0, P->fy_r * iz, -P->fy_r * pc[1] * iz2};
+				double M[12], jf[12];
+				for (int a = 0; a < 4; ++a)
+					for (int b = 0; b < 3; ++b) M[3 * a + b] = Dm[3 * a] * S[4 * b] + Dm[3 * a + 1] * S[4 * b + 1] + Dm[3 * a + 2] * S[4 * b + 2];
+				for (int a = 0; a < 4; ++a)
+					for (int b = 0; b < 3; ++b) jf[3 * a + b] = w * (M[3 * a] * Tp[b] + M[3 * a + 1] * Tp[4 + b] + M[3 * a + 2] * Tp[8 + b]);
+				double* o = stage + 9 * lane;
+				int k = 0;
+				for (int a = 0; a < 3; ++a)
+					for (int b = a; b < 3; ++b) o[k++] = jf[a] * jf[b] + jf[3 + a] * jf[3 + b] + jf[6 + a] * jf[6 + b] + jf[9 + a] * jf[9 + b];
+				for (int b = 0; b < 3; ++b) o[6 + b] = w * (jf[b] * r[0] + jf[3 + b] * r[1] + jf[6 + b] * r[2] + jf[9 + b] * r[3]);
+			}
+			double vs[64][9], lrec[64][16];
+			for (int lane = 0; lane < G.n_lanes; ++lane) {
+				const nd_i4 lr = H.lane[(size_t)W.lane0 + G.lane0 + lane];
+				const int a = lr.y & 0xFF, n = lr.y >> 8;
+				for (int c = 0; c < 9; ++c) vs[lane][c] = 0.0;
+				for (int i = 0; i < n; ++i)
+					for (int c = 0; c < 9; ++c) vs[lane][c] += stage[9 * (a + i) + c];
+			}
+			for (int lane = 0; lane < G.n_lanes; ++lane) {
+				const nd_i4 lr = H.lane[(size_t)W.lane0 + G.lane0 + lane];
+				if ((lr.w & 0xFF) != 1) continue;
+				const bool opt = lr.z >= 0;
+				double* rc = lrec[lane];
+				const double* v = vs[lane];
+				if (opt && !pre) {
+					const double a00 = v[0] + lambda, l00 = std::sqrt(a00), i00 = 1.0 / l00;
+					const double l10 = v[1] * i00, l20 = v[2] * i00;
+					const double a11 = v[3] + lambda - l10 * l10, l11 = std::sqrt(a11), i11 = 1.0 / l11;
+					const double l21 = (v[4] - l20 * l10) * i11;
+					const double a22 = v[5] + lambda - l20 * l20 - l21 * l21, l22 = std::sqrt(a22), i22 = 1.0 / l22;
+					const double i10 = -i11 * l10 * i00, i21 = -i22 * l21 * i11, i20 = -(i21 * l10 + i22 * l20) * i00;
+					const double R16[16] = {l00, l10, l11, l20, l21, l22, i00, i10, i11, i20, i21, i22,
+					                        i00 * v[6], i10 * v[6] + i11 * v[7], i20 * v[6] + i21 * v[7] + i22 * v[8], 0.0};
+					std::memcpy(rc, R16, sizeof R16);
+				} else {
+					const double R16[16] = {1, 0, 1, 0, 0, 1, 1, 0, 1, 0, 0, 1, 0, 0, 0, 1.0};
+					std::memcpy(rc, R16, sizeof R16);
+				}
+				if (pre && opt) vmax = std::fmax(vmax, std::fmax(v[0], std::fmax(v[3], v[5])));
+				double* sc = &scr[12 * ((size_t)G.lane0 + lane)];
+				for (int c = 0; c < 9; ++c) sc[c] = opt && !pre ? rc[6 + c] : 0.0;
+			}
+			for (int lane = 0; lane < G.n_lanes; ++lane) {
+				const nd_i4 lr = H.lane[(size_t)W.lane0 + G.lane0 + lane];
+				if ((lr.w & 0xFF) != 2) continue;
+				const double* rc = lrec[(lr.w >> 8) & 0xFF];
+				const double* Lm = rc, *Li = rc + 6, *cc = rc + 12;
+				const bool fixed = rc[15] != 0.0;
+				const double* v9 = vs[lane];
+				const double V[9] = {v9[0], v9[1], v9[2], v9[1], v9[3], v9[4], v9[2], v9[4], v9[5]};
+				double Z[9], Pm[9], v[3];
+				for (int i = 0; i < 3; ++i) {
+					Z[3 * i] = V[3 * i] * Li[0];
+					Z[3 * i + 1] = V[3 * i] * Li[1] + V[3 * i + 1] * Li[2];
+					Z[3 * i + 2] = V[3 * i] * Li[3] + V[3 * i + 1] * Li[4] + V[3 * i + 2] * Li[5];
+					v[i] = v9[6 + i] - (Z[3 * i] * cc[0] + Z[3 * i + 1] * cc[1] + Z[3 * i + 2] * cc[2]);
+				}
+				const double Lf[9] = {Lm[0], 0, 0, Lm[1], Lm[2], 0, Lm[3], Lm[4], Lm[5]};
+				for (int c = 0; c < 9; ++c) Pm[c] = fixed ? ((c == 0 || c == 4 || c == 8) ? 1.0 : 0.0) : Lf[c] - Z[c];
+				const double* Tn = &tab[12 * (size_t)(lr.z & 0xFFFF)];
+				const double sg = ((lr.z >> 24) & 1) ? -1.0 : 1.0;
+				const double* f = Wn->lm_pos + 3 * lr.x;
+				double* out = &rec[(size_t)SSK_ND_REC * (64 * wv + lane)];
+				for (int i = 0; i < 3; ++i) {
+					const double r0 = sg * Tn[4 * i], r1 = sg * Tn[4 * i + 1], r2 = sg * Tn[4 * i + 2];
+					for (int j = 0; j < 3; ++j) {
+						out[3 * i + j] = r0 * Z[j] + r1 * Z[3 + j] + r2 * Z[6 + j];
+						out[12 + 3 * i + j] = r0 * Pm[j] + r1 * Pm[3 + j] + r2 * Pm[6 + j];
+					}
+					out[21 + i] = r0 * v[0] + r1 * v[1] + r2 * v[2];
+					out[9 + i] = Tn[4 * i] * f[0] + Tn[4 * i + 1] * f[1] + Tn[4 * i + 2] * f[2] + Tn[4 * i + 3];
+				}
+				double* sc = &scr[12 * ((size_t)G.lane0 + lane)];
+				for (int c = 0; c < 9; ++c) sc[c] = out[c];
+				for (int c = 0; c < 3; ++c) sc[9 + c] = out[9 + c];
+			}
+		}
+		const int NQ = waves * 16;
+		for (int r = 0; r < T.n_rounds; ++r)
+			for (int quad = 0; quad < NQ; ++quad) {
+				const nd_i2 q = H.qs[(size_t)W.qs0 + T.qs0 + r * NQ + quad];
+				const int pid = q.x & 0xFFFF, n = (q.x >> 16) & 0xFFFF;
+				for (int i = 0; i < n; ++i) {
+					const int it = H.item[(size_t)W.item0 + q.y + i];
+					const double* xr = &rec[(size_t)SSK_ND_REC * (it & 511)];
+					const double* yc = &rec[(size_t)SSK_ND_REC * ((it >> 10) & 511)];
+					const double* X = xr + 12 * ((it >> 9) & 1);
+					const double* Y = yc + 12 * ((it >> 19) & 1);
+					const double* qr = xr + 9, *qc = yc + 9;
+					const double sg = ((it >> 20) & 1) ? (pre ? 0.0 : -1.0) : 1.0;
+					double Dm[9], U[9];
+					double* acc = &Hb[36 * (size_t)pid];
+					for (int a = 0; a < 3; ++a) {
+						for (int b = 0; b < 3; ++b) Dm[3 * a + b] = sg * (X[3 * a] * Y[3 * b] + X[3 * a + 1] * Y[3 * b + 1] + X[3 * a + 2] * Y[3 * b + 2]);
+						cross(qc, Dm + 3 * a, U + 3 * a);
+						for (int b = 0; b < 3; ++b) { acc[6 * a + b] += Dm[3 * a + b]; acc[6 * a + 3 + b] += U[3 * a + b]; }
+					}
+					for (int b = 0; b < 3; ++b) {
+						const double cd[3] = {Dm[b], Dm[3 + b], Dm[6 + b]}, cu[3] = {U[b], U[3 + b], U[6 + b]};
+						double xd[3], xu[3];
+						cross(qr, cd, xd); cross(qr, cu, xu);
+						for (int a = 0; a < 3; ++a) { acc[6 * (3 + a) + b] += xd[a]; acc[6 * (3 + a) + 3 + b] += xu[a]; }
+					}
+				}
+			}
+		if (!pre)
+			for (int k = 0; k < T.n_gqs; ++k) {
+				const nd_i2 q = H.gqs[(size_t)W.gqs0 + T.gqs0 + k];
+				const int e = q.x & 0xFFFF, n = (q.x >> 16) & 0xFFFF;
+				for (int i = 0; i < n; ++i) {
+					const double* rc = &rec[(size_t)SSK_ND_REC * H.gitem[(size_t)W.gitem0 + q.y + i]];
+					double x[3];
+					cross(rc + 9, rc + 21, x);
+					for (int c = 0; c < 3; ++c) { gacc[6 * e + c] += rc[21 + c]; gacc[6 * e + 3 + c] += x[c]; }
+				}
+			}
+	}
+	const int np = n6;
+	for (int i = 0; i < n6 * n6; ++i) Hred[i] = 0.0;
+	for (int pid = 0; pid < n_pairs; ++pid) {
+		int e2 = 0;
+		while ((e2 + 1) * (e2 + 2) / 2 <= pid) ++e2;
+		const int e = pid - e2 * (e2 + 1) / 2;
+		for (int a = 0; a < 6; ++a)
+			for (int b = 0; b < 6; ++b) {
+				if (e == e2 && a > b) continue;
+				const int row = 6 * e + a, col = 6 * e2 + b;
+				double v = Hb[36 * (size_t)pid + 6 * a + b];
+				if (row == col) v += lambda;
+				Hred[row * np + col] = v; Hred[col * np + row] = v;
+			}
+	}
+	for (int i = 0; i < n6; ++i) g[i] = gacc[i];
+	if (vmax_out) *vmax_out = vmax;
+	if (stats) { stats[0] = W.n_tiles; stats[1] = n_groups; stats[2] = (int)H.item.size(); stats[3] = H.max_items_per_lane; }
+	if (dp && df) {
+		for (int gi = 0; gi < n_groups; ++gi) {
+			const nd_group& G = H.group[(size_t)W.grp0 + gi];
+			double t3[64][3];
+			for (int lane = 0; lane < G.n_lanes; ++lane) {
+				const nd_i4 lr = H.lane[(size_t)W.lane0 + G.lane0 + lane];
+				if ((lr.w & 0xFF) != 2) continue;
+				const double* sc = &scr[12 * ((size_t)G.lane0 + lane)];
+				const double* d6 = dp + 6 * ((lr.z >> 16) & 0xFF);
+				double x[3];
+				cross(d6 + 3, sc + 9, x);
+				const double a0 = d6[0] + x[0], a1 = d6[1] + x[1], a2 = d6[2] + x[2];
+				for (int j = 0; j < 3; ++j) t3[lane][j] = sc[j] * a0 + sc[3 + j] * a1 + sc[6 + j] * a2;
+			}
+			for (int lane = 0; lane < G.n_lanes; ++lane) {
+				const nd_i4 lr = H.lane[(size_t)W.lane0 + G.lane0 + lane];
+				if ((lr.w & 0xFF) != 1 || lr.z < 0) continue;
+				const double* sc = &scr[12 * ((size_t)G.lane0 + lane)];
+				const int nn = (lr.w >> 16) & 0xFF;
+				double rhs[3] = {sc[6], sc[7], sc[8]};
+				for (int i = 1; i <= nn; ++i) for (int c = 0; c < 3; ++c) rhs[c] -= t3[lane + i][c];
+				df[3 * lr.z] = sc[0] * rhs[0] + sc[1] * rhs[1] + sc[3] * rhs[2];
+				df[3 * lr.z + 1] = sc[2] * rhs[1] + sc[4] * rhs[2];
+				df[3 * lr.z + 2] = sc[5] * rhs[2];
+			}
+		}
+	}
+	return 0;
+}
+
+}  // extern "C"
