@@ -26,7 +26,8 @@ class SskError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libssk_hip.so")
+    # SSK_LIB: another build of the same library (same-box A/B timing of kernel variants, tools/lm_ab.py); default: the in-tree build
+    return os.environ.get("SSK_LIB") or os.path.join(HERE, "libssk_hip.so")
 
 
 def declared_symbols():

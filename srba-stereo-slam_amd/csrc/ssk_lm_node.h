@@ -41,6 +41,10 @@ constexpr int SSK_ND_STAGE = 9;         // doubles per observation in the wave-p
 constexpr int SSK_ND_LREC = 16;         // doubles per root record in the staging: L (6), L^-1 (6), c (3), fixed flag
 constexpr int SSK_ND_SCR = 12;          // doubles per lane in the window's HBM scratch: node (Zh 9, q 3) / root (L^-1 6, c 3)
 constexpr int SSK_ND_MAX_WAVES = 8;
+#ifndef SSK_ND_LANE_RUNS
+#define SSK_ND_LANE_RUNS 0              // pair phase: 0 = a quad of lanes per block, DPP sums, one ds_add_f64 per component and quad (default);
+#endif                                  // 1 = a LANE owns a run of <= 8 items of one block and adds its 36 sums itself (perfectly balanced turns, but 256 lanes x 36
+                                        // conflicting LDS atomics per tile: measured 5.41 ms against 4.18 ms per 1024 bench windows, same box)
 
 // plain mirrors of the HIP vector types (the host builder is HIP free: tools/lm_node_emu.cpp compiles it with g++)
 struct alignas(8) nd_i2 { int x, y; };
@@ -52,11 +56,13 @@ struct nd_win {
 	int edge0, lm0, us0, ls0;           // bases into the batch-wide pose / landmark / slot_edge / slot_lm families (shared with the other kernels)
 	int suf0;                           // nd_suf[suf0 + id] = (first step code, id of the rest)
 	int n_tiles, tile0;                 // nd_tile[tile0 ..)
+	int n_groups;
 	int grp0;                           // nd_group[grp0 ..)
 	int obs0;                           // nd_obs / nd_px [obs0 + group.obs0 + lane]
 	int lane0;                          // nd_lane[lane0 + group.lane0 + lane]; scratch nd_scr[SSK_ND_SCR * (lane0 + ...)]
 	int item0, qs0, gitem0, gqs0;       // nd_item / nd_qs / nd_gitem / nd_gqs bases
-	int trace0, pad0;
+	int trace0;
+	int n_rounds, max_parts;            // (diagnostics: most rounds of quad slots of a tile, parts of a block)
 	long long tab0;                     // nd_tab[tab0 ..): two suffix tables (current / trial state), 12 doubles per suffix each
 	long long dp_trace0, df_trace0;
 };
@@ -79,7 +85,8 @@ struct nd_group {
 //   w  kind (0 idle, 1 root, 2 node) | lane of the landmark's root << 8 | root: number of node lanes that follow << 16
 // observation record (int2): x landmark, y suffix of the whole path | lane of the landmark's root << 16
 // item (int): record X: slot | P-part << 9;  record Y: slot << 10 | P-part << 19;  bit 20: not nested (D = -Zh Zh^T)
-// quad slot (int2): x block pair id | items << 16, y first item (tile relative is folded in: window relative)
+// quad slot (int2): x block pair id (0xFFFF: none) | items << 16, y first item (window relative) | part of the block << 28 |
+//   block cut in two << 30 | this wavefront holds such blocks << 31
 
 struct nd_dev {
 	const nd_win* win; const nd_tile* tile; const nd_group* group;

@@ -23,6 +23,15 @@ constexpr int R_Q = 9, R_P = 12, R_V = 21;
 
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 
+#ifdef SSK_LM_STAMPS
+__device__ unsigned long long g_nd_fine[16];
+#define FINE0() unsigned long long f_t_ = __builtin_amdgcn_s_memtime()
+#define FINE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_nd_fine[i] += t_ - f_t_; f_t_ = t_; } } while (0)
+#else
+#define FINE0() do {} while (0)
+#define FINE(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ double nd_rsq(double x)       // 1/sqrt(x), x > 0: hardware estimate + two Newton steps
 {
 	double y = __builtin_amdgcn_rsq(x);
@@ -113,14 +122,24 @@ __device__ __forceinline__ void nd_residual(const lm_cam& P, const double (&T)[1
 
 // ---- group phase: one wavefront linearises one landmark group; leaves the node records in `stage` (the wavefront's part of the record
 // region: lane i's record at stage + REC * i), the back-substitution records in HBM ----
-__device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G,
+// the static records of a lane for one group (observation record + pixels, root / node record): fetched a tile (a group) ahead
+struct nd_recs { nd_i2 orec; nd_f4 px; nd_i4 lrec; };
+__device__ __forceinline__ nd_recs nd_fetch_recs(const nd_dev& N, const nd_win& W, const nd_group G, int lane)
+{
+	const int oi = W.obs0 + G.obs0 + min(lane, max(G.n_obs - 1, 0));      // loads are unconditional on clamped indices
+	const int li = W.lane0 + G.lane0 + min(lane, max(G.n_lanes - 1, 0));
+	nd_recs r;
+	r.orec = N.obs[oi]; r.px = N.px[oi]; r.lrec = N.lane[li];
+	return r;
+}
+
+__device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G, const nd_recs rc,
                                                    const double* __restrict__ tab, double* __restrict__ stage, double lambda, bool pre, int lane, double& vmax)
 {
-	const int oi = W.obs0 + G.obs0 + min(lane, G.n_obs - 1);       // loads are unconditional on clamped indices
 	const int li = W.lane0 + G.lane0 + min(lane, G.n_lanes - 1);
-	const nd_i2 orec = N.obs[oi];
-	const nd_f4 px = N.px[oi];
-	nd_i4 lrec = N.lane[li];
+	const nd_i2 orec = rc.orec;
+	const nd_f4 px = rc.px;
+	nd_i4 lrec = rc.lrec;
 	if (lane >= G.n_lanes) lrec.w = 0;                             // idle lane
 	const int kind = lrec.w & 0xFF, root_lane = (lrec.w >> 8) & 0xFF;
 	const bool is_node = kind == 2, is_root = kind == 1;
@@ -131,6 +150,7 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 		const double* fp = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
 		fn[0] = fp[0]; fn[1] = fp[1]; fn[2] = fp[2];
 	}
+	FINE0();
 	// ---- lane = observation: V_o = Jf^T Jf (6), g_o = Jf^T w r (3) -> staging ----
 	{
 		double T[12], f[3], pc[3], iz, r[4];
@@ -171,17 +191,39 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 		o[8] = jf[2] * wr[0] + jf[5] * wr[1] + jf[8] * wr[2] + jf[11] * wr[3];
 	}
 	WAVE_SYNC();
+	FINE(0);
 	// ---- lane = root / node: sums over its run of the staging (a landmark's observations are sorted so that a trie subtree is a run) ----
 	double vs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	{
 		const int a = lrec.y & 0xFF, n = kind ? (lrec.y >> 8) : 0;
+#if ND_SUM4
+		// four rows per turn, loads first (rows past the run: the run's last row, weight 0); the order of the adds is the rows' order
+		for (int i = 0; i < n; i += 4) {
+			double v[4][9];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const double* o = stage + STG * (a + min(i + u, n - 1));
+#pragma unroll
+				for (int c = 0; c < 9; ++c) v[u][c] = o[c];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const double wgt = i + u < n ? 1.0 : 0.0;
+#pragma unroll
+				for (int c = 0; c < 9; ++c) vs[c] = fma(wgt, v[u][c], vs[c]);
+			}
+		}
+	}
+#else
 		for (int i = 0; i < n; ++i) {
 			const double* o = stage + STG * (a + i);
 #pragma unroll
 			for (int c = 0; c < 9; ++c) vs[c] += o[c];
 		}
 	}
+#endif
 	WAVE_SYNC();
+	FINE(1);
 	// ---- roots: V + lambda I = L L^T -> (L, L^-1, c = L^-1 g, fixed flag) for the landmark's nodes; L^-1, c to HBM for the landmark step ----
 	if (is_root) {
 		const bool opt = lrec.z >= 0;
@@ -221,6 +263,7 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 		}
 	}
 	WAVE_SYNC();
+	FINE(2);
 	// ---- nodes: Z = Vs L^-T, Pm = L - Z, v = gs - Z c, rotated into the edge's frame ----
 	double out[24];
 	if (is_node) {
@@ -257,6 +300,7 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 		}
 	}
 	WAVE_SYNC();
+	FINE(3);
 	if (is_node) {
 		v2d_t* o = reinterpret_cast<v2d_t*>(stage + REC * lane);
 #pragma unroll
@@ -266,45 +310,104 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 			nd_store12(N.scr + SCR * (size_t)li, sc);
 		}
 	}
+	FINE(4);
+}
+
+struct nd_item_ops { double X[10], Y[10], qr[3], qc[3]; };
+__device__ __forceinline__ void nd_item_load(const double* __restrict__ rec, int it, nd_item_ops& o)
+{
+	const double* xr = rec + REC * (it & 511);
+	const double* yc = rec + REC * ((it >> 10) & 511);
+	const v2d_t* Xv = reinterpret_cast<const v2d_t*>(xr + R_P * ((it >> 9) & 1));
+	const v2d_t* Yv = reinterpret_cast<const v2d_t*>(yc + R_P * ((it >> 19) & 1));
+#pragma unroll
+	for (int c = 0; c < 5; ++c) { const v2d_t a = Xv[c], b = Yv[c]; o.X[2 * c] = a.x; o.X[2 * c + 1] = a.y; o.Y[2 * c] = b.x; o.Y[2 * c + 1] = b.y; }
+#pragma unroll
+	for (int c = 0; c < 3; ++c) { o.qr[c] = xr[R_Q + c]; o.qc[c] = yc[R_Q + c]; }
+}
+// acc += sg [I; [q_r]x] (X Y^T) [I | -[q_c]x]
+__device__ __forceinline__ void nd_item_apply(const nd_item_ops& o, double sg, double (&acc)[36])
+{
+	const double sqc[3] = {sg * o.qc[0], sg * o.qc[1], sg * o.qc[2]}, sqr[3] = {sg * o.qr[0], sg * o.qr[1], sg * o.qr[2]};
+	double Dm[9], U[9];
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {
+#pragma unroll
+		for (int b = 0; b < 3; ++b) Dm[3 * a + b] = o.X[3 * a] * o.Y[3 * b] + o.X[3 * a + 1] * o.Y[3 * b + 1] + o.X[3 * a + 2] * o.Y[3 * b + 2];
+		nd_cross(sqc, Dm + 3 * a, U + 3 * a);                      // row a of -sg D [q_c]x = (sg q_c) x (row a of D)
+#pragma unroll
+		for (int b = 0; b < 3; ++b) { acc[6 * a + b] = fma(sg, Dm[3 * a + b], acc[6 * a + b]); acc[6 * a + 3 + b] += U[3 * a + b]; }
+	}
+#pragma unroll
+	for (int b = 0; b < 3; ++b) {                                  // columns of sg [q_r]x D and of [q_r]x U, added component by component
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			const int a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+			acc[6 * (3 + a) + b] = fma(-sqr[a2], Dm[3 * a1 + b], fma(sqr[a1], Dm[3 * a2 + b], acc[6 * (3 + a) + b]));
+			acc[6 * (3 + a) + 3 + b] = fma(-o.qr[a2], U[3 * a1 + b], fma(o.qr[a1], U[3 * a2 + b], acc[6 * (3 + a) + 3 + b]));
+		}
+	}
 }
 
 // ---- pair phase: the items of one 6x6 block dealt out among the 4 lanes of a quad; 36 sums in registers ----
 // item: record X = slot | P-part << 9 (row node), record Y = slot << 10 | P-part << 19 (column node), bit 20: not nested (D = -Zh Zh^T)
-// block(r, c) = [I; [q_r]x] D [I | -[q_c]x],  D = +-X Y^T
-__device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, const int* __restrict__ items, int n, int ql, bool pre, double (&acc)[36])
+// block(r, c) = [I; [q_r]x] D [I | -[q_c]x],  D = +-X Y^T.
+// A lane's first ND_ITEMS_REG item codes come from HBM in ONE burst of independent loads (nd_items_fetch, issued in front of the tile's
+// barrier) -- a load per loop turn put an HBM round trip into every item.
+#ifndef ND_PIPE
+#define ND_PIPE 0                       // 1: software-pipelined item turns (loads of item k + 1 in front of the products of item k)
+#endif
+#ifndef ND_SUM4
+#define ND_SUM4 1                       // 1: four staging rows per turn in the run sums
+#endif
+constexpr int ND_ITEMS_REG = 8;
+struct nd_items { int it[ND_ITEMS_REG]; };
+// the lane's items are items[first], items[first + step], ...
+__device__ __forceinline__ nd_items nd_items_fetch(const int* __restrict__ items, int n, int first, int step)
 {
-	int it_next = n > ql ? items[ql] : 0;
-	for (int i = ql; i < n; i += 4) {
-		const int it = it_next;
-		if (i + 4 < n) it_next = items[i + 4];
-		const double* xr = rec + REC * (it & 511);
-		const double* yc = rec + REC * ((it >> 10) & 511);
-		const v2d_t* Xv = reinterpret_cast<const v2d_t*>(xr + R_P * ((it >> 9) & 1));
-		const v2d_t* Yv = reinterpret_cast<const v2d_t*>(yc + R_P * ((it >> 19) & 1));
-		double X[10], Y[10];
+	nd_items r;
 #pragma unroll
-		for (int c = 0; c < 5; ++c) { const v2d_t a = Xv[c], b = Yv[c]; X[2 * c] = a.x; X[2 * c + 1] = a.y; Y[2 * c] = b.x; Y[2 * c + 1] = b.y; }
-		const double qr[3] = {xr[R_Q], xr[R_Q + 1], xr[R_Q + 2]}, qc[3] = {yc[R_Q], yc[R_Q + 1], yc[R_Q + 2]};
-		const double sg = ((it >> 20) & 1) ? (pre ? 0.0 : -1.0) : 1.0;
-		double Dm[9], U[9];
+	for (int k = 0; k < ND_ITEMS_REG; ++k) r.it[k] = items[min(first + step * k, max(n - 1, 0))];      // unconditional, clamped
+	return r;
+}
+__device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, const int* __restrict__ items, const nd_items& pre_it, int n, int ql, int step, bool pre, double (&acc)[36])
+{
+	const double neg = pre ? 0.0 : -1.0;
+#if ND_PIPE
+	// the wavefront's lanes run in lockstep: every lane takes as many turns as the longest run among them (a lane past its run repeats its
+	// last item with weight 0), so the turns need no lane branches and the loads of item k + 1 are issued in front of the products of item k
+	const int mine = n > ql ? (n - ql + step - 1) / step : 0;
+	int turns = mine;
 #pragma unroll
-		for (int a = 0; a < 3; ++a) {
-			const double x0 = sg * X[3 * a], x1 = sg * X[3 * a + 1], x2 = sg * X[3 * a + 2];
+	for (int o = 32; o > 0; o >>= 1) turns = max(turns, __shfl_xor(turns, o, 64));
+	turns = __builtin_amdgcn_readfirstlane(turns);
+	nd_item_ops cur, nxt;
+	nd_item_load(rec, pre_it.it[0], cur);
 #pragma unroll
-			for (int b = 0; b < 3; ++b) Dm[3 * a + b] = x0 * Y[3 * b] + x1 * Y[3 * b + 1] + x2 * Y[3 * b + 2];
-			nd_cross(qc, Dm + 3 * a, U + 3 * a);                   // row a of -D [q_c]x = q_c x (row a of D)
-#pragma unroll
-			for (int b = 0; b < 3; ++b) { acc[6 * a + b] += Dm[3 * a + b]; acc[6 * a + 3 + b] += U[3 * a + b]; }
+	for (int k = 0; k < ND_ITEMS_REG; ++k) {
+		if (k < turns) {                                           // (uniform)
+			const int it = pre_it.it[k];
+			if (k + 1 < ND_ITEMS_REG && k + 1 < turns) nd_item_load(rec, pre_it.it[k + 1], nxt);
+			nd_item_apply(cur, k < mine ? (((it >> 20) & 1) ? neg : 1.0) : 0.0, acc);
+			cur = nxt;
 		}
+	}
+#else
 #pragma unroll
-		for (int b = 0; b < 3; ++b) {                              // columns of [q_r]x D and [q_r]x U
-			const double cd[3] = {Dm[b], Dm[3 + b], Dm[6 + b]}, cu[3] = {U[b], U[3 + b], U[6 + b]};
-			double xd[3], xu[3];
-			nd_cross(qr, cd, xd);
-			nd_cross(qr, cu, xu);
-#pragma unroll
-			for (int a = 0; a < 3; ++a) { acc[6 * (3 + a) + b] += xd[a]; acc[6 * (3 + a) + 3 + b] += xu[a]; }
+	for (int k = 0; k < ND_ITEMS_REG; ++k) {
+		if (ql + step * k < n) {
+			const int it = pre_it.it[k];
+			nd_item_ops o;
+			nd_item_load(rec, it, o);
+			nd_item_apply(o, ((it >> 20) & 1) ? neg : 1.0, acc);
 		}
+	}
+#endif
+	for (int i = ql + step * ND_ITEMS_REG; i < n; i += step) {     // (long runs: the large windows)
+		const int it = items[i];
+		nd_item_ops o;
+		nd_item_load(rec, it, o);
+		nd_item_apply(o, ((it >> 20) & 1) ? neg : 1.0, acc);
 	}
 }
 
@@ -320,19 +423,18 @@ __device__ __forceinline__ void nd_quad_sum36(double (&acc)[36])
 // ---- trial state: landmark steps and robust error of one group by one wavefront ----
 // backsub: node lanes t_n = Zh_n^T (dt_e + dw_e x q_n) -> root lane delta_f = L^-T (c - sum t_n), f_new = f + delta_f -> the landmark's
 // observation lanes; !backsub: the error at the current landmarks (the solve's first pass)
-__device__ __forceinline__ void nd_score_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G,
+__device__ __forceinline__ void nd_score_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G, const nd_recs rc,
                                                const double* __restrict__ tab, double* __restrict__ stage, const double* s_b, bool backsub, int it_idx,
                                                int lane, double& err, double& dfn)
 {
-	const int oi = W.obs0 + G.obs0 + min(lane, G.n_obs - 1);
 	const int li = W.lane0 + G.lane0 + min(lane, G.n_lanes - 1);
-	const nd_i2 orec = N.obs[oi];
-	const nd_f4 px = N.px[oi];
+	const nd_i2 orec = rc.orec;
+	const nd_f4 px = rc.px;
 	double T[12];
 	nd_load12(tab + 12 * (size_t)(orec.y & 0xFFFF), T);
 	double f[3];
 	if (backsub) {
-		nd_i4 lrec = N.lane[li];
+		nd_i4 lrec = rc.lrec;
 		if (lane >= G.n_lanes) lrec.w = 0;
 		const int kind = lrec.w & 0xFF;
 		double sc[12], fl[3];
@@ -409,26 +511,45 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 	double* Hb = s_inv + n6p;                          // 36 doubles per block pair (e <= e2): H(6e + a, 6e2 + b) at 36 pid + 6a + b
 	double* g_acc = Hb + 36 * n_pairs;
 	nd_i2* s_suf = reinterpret_cast<nd_i2*>(g_acc + n6p);    // the trie's (first step, rest) records: the table builds walk them
-	double* reg = g_acc + n6p + ((W.n_suf + 1) & ~1);  // node records of a tile (wave w: reg + 64 REC w), later the dense bordered system
+	// the window's tile and group descriptors (a few hundred bytes): every phase starts from them
+	nd_tile* s_tile = reinterpret_cast<nd_tile*>(g_acc + n6p + ((W.n_suf + 1) & ~1));
+	nd_group* groups = reinterpret_cast<nd_group*>(s_tile + W.n_tiles);
+	const int n_groups = W.n_groups;
+	double* reg = reinterpret_cast<double*>(groups + n_groups + (W.n_tiles & 1));      // node records of a tile (wave w: reg + 64 REC w), later the dense bordered system
 	(void)dyn_doubles;
 	double* stage = reg + 64 * REC * wave;
-	const nd_group* groups = N.group + W.grp0;
-	int n_groups = 0;
-	if (W.n_tiles > 0) { const nd_tile Tl = N.tile[W.tile0 + W.n_tiles - 1]; n_groups = Tl.grp0 + Tl.n_grp; }
 	double* tabs[2] = {N.tab + W.tab0, N.tab + W.tab0 + 12 * (size_t)W.n_suf};
+#ifdef SSK_LM_STAMPS
+	// per-phase cycle stamps of window 0 (thread 0, after the phase's barrier): diagnostics build only
+	__shared__ unsigned long long s_acc[16];
+	unsigned long long t_last = __builtin_amdgcn_s_memtime();
+	if (tid < 16) s_acc[tid] = 0;
+#define STAMP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_acc[i] += t_ - t_last; t_last = t_; } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 	for (int i = tid; i < 12 * W.n_edges; i += NT) {
 		const double v = D.pose[12 * (size_t)W.edge0 + i];
 		pose_cur[i] = v; pose_new[i] = v;
 	}
 	for (int i = tid; i < W.n_suf; i += NT) s_suf[i] = N.suf[W.suf0 + i];
+	for (int i = tid; i < W.n_tiles; i += NT) s_tile[i] = N.tile[W.tile0 + i];
+	for (int i = tid; i < n_groups; i += NT) groups[i] = N.group[W.grp0 + i];
 	// (a landmark nobody observes has no root lane: its trial position is its position)
 	for (int i = tid; i < 3 * W.n_lms; i += NT) D.lm_new[3 * (size_t)W.lm0 + i] = D.lm[3 * (size_t)W.lm0 + i];
 	__syncthreads();
 	nd_build_table(W, s_suf, pose_cur, tabs[0]);
 	__syncthreads();
 	double e0 = 0.0, dummy = 0.0;
-	for (int g = wave; g < n_groups; g += NDW) nd_score_group(D, N, W, P, groups[g], tabs[0], stage, s_b, false, 0, lane, e0, dummy);
+	{
+		nd_recs nx = nd_fetch_recs(N, W, groups[min(wave, max(n_groups - 1, 0))], lane);
+		for (int g = wave; g < n_groups; g += NDW) {
+			const nd_recs rc = nx;
+			if (g + NDW < n_groups) nx = nd_fetch_recs(N, W, groups[g + NDW], lane);
+			nd_score_group(D, N, W, P, groups[g], rc, tabs[0], stage, s_b, false, 0, lane, e0, dummy);
+		}
+	}
 	e0 = block_sum(e0, s_part);
 	if (tid == 0) {
 		s_lambda = -1.0; s_nu = 2.0; s_err = e0; s_iters = 0; s_accepted = 0; s_stop = 0; s_cur = 0;
@@ -450,29 +571,78 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 		const int it_idx = s_iters, cur = s_cur;
 		const double* tab_cur = tabs[cur];
 		double vmax = 0.0;
+		STAMP(0);
 		for (int i = tid; i < 36 * n_pairs + n6p; i += NT) Hb[i] = 0.0;      // (block accumulators and gradient are contiguous)
 		__syncthreads();
+		STAMP(1);
 		// ---- linearisation: tile by tile ----
+		nd_recs nx = nd_fetch_recs(N, W, groups[min(wave, max(n_groups - 1, 0))], lane);
 		for (int t = 0; t < W.n_tiles; ++t) {
-			const nd_tile T = N.tile[W.tile0 + t];
-			nd_i2 q0 = nd_i2{0, 0};                    // (round 0's slot in flight behind the group phase)
+			const nd_tile T = s_tile[t];
+			nd_i2 q0 = nd_i2{0xFFFF, 0};               // (round 0's slot in flight behind the group phase)
+#if SSK_ND_LANE_RUNS
+			if (T.n_rounds > 0) q0 = N.qs[W.qs0 + T.qs0 + tid];
+#else
 			if (T.n_rounds > 0) q0 = N.qs[W.qs0 + T.qs0 + quad];
-			if (wave < T.n_grp) nd_linearise_group(D, N, W, P, groups[T.grp0 + wave], tab_cur, stage, lambda, pre, lane, vmax);
+#endif
+			const nd_recs rc = nx;
+			if (t + 1 < W.n_tiles) nx = nd_fetch_recs(N, W, groups[min(s_tile[t + 1].grp0 + wave, n_groups - 1)], lane);      // the next tile's records: in flight during this one
+			if (wave < T.n_grp) nd_linearise_group(D, N, W, P, groups[T.grp0 + wave], rc, tab_cur, stage, lambda, pre, lane, vmax);
+#if SSK_ND_LANE_RUNS
+			nd_items its = nd_items_fetch(N.item + W.item0 + q0.y, (q0.x >> 16) & 0x7FFF, 0, 1);      // (in flight across the barrier)
+			STAMP(2);
 			__syncthreads();
+			STAMP(3);
 			for (int r = 0; r < T.n_rounds; ++r) {
-				const nd_i2 q = r == 0 ? q0 : N.qs[W.qs0 + T.qs0 + r * NQ + quad];
-				const int pid = q.x & 0xFFFF, n = (q.x >> 16) & 0xFFFF;
+				// a lane = a run of consecutive items of one block; its 36 sums go straight to the block's accumulator (ds_add_f64, no return)
+				const nd_i2 q = r == 0 ? q0 : N.qs[W.qs0 + T.qs0 + r * NT + tid];
+				const int pid = q.x & 0xFFFF, n = (q.x >> 16) & 0x7FFF;
+				if (r > 0) its = nd_items_fetch(N.item + W.item0 + q.y, n, 0, 1);
 				double acc[36];
 #pragma unroll
 				for (int c = 0; c < 36; ++c) acc[c] = 0.0;
-				nd_pair_items(reg, N.item + W.item0 + q.y, n, ql, pre, acc);
-				nd_quad_sum36(acc);
-				if (ql == 0 && n > 0) {
-					v2d_t* hb = reinterpret_cast<v2d_t*>(Hb + 36 * pid);
+				FINE0();
+				nd_pair_items(reg, N.item + W.item0 + q.y, its, n, 0, 1, pre, acc);
+				FINE(5);
+				if (pid != 0xFFFF) {
+					double* hb = Hb + 36 * pid;
 #pragma unroll
-					for (int c = 0; c < 18; ++c) { v2d_t x = hb[c]; x.x += acc[2 * c]; x.y += acc[2 * c + 1]; hb[c] = x; }
+					for (int c = 0; c < 36; ++c) (void)__hip_atomic_fetch_add(hb + c, acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
+				FINE(6);
 			}
+#else
+			nd_items its = nd_items_fetch(N.item + W.item0 + (q0.y & 0x0FFFFFFF), (q0.x >> 16) & 0x7FFF, ql, 4);      // (in flight across the barrier)
+			STAMP(2);
+			__syncthreads();
+			STAMP(3);
+			for (int r = 0; r < T.n_rounds; ++r) {
+				const nd_i2 q = r == 0 ? q0 : N.qs[W.qs0 + T.qs0 + r * NQ + quad];
+				const int pid = q.x & 0xFFFF, n = (q.x >> 16) & 0x7FFF;
+				if (r > 0) its = nd_items_fetch(N.item + W.item0 + (q.y & 0x0FFFFFFF), n, ql, 4);
+				double acc[36];
+#pragma unroll
+				for (int c = 0; c < 36; ++c) acc[c] = 0.0;
+				FINE0();
+				nd_pair_items(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc);
+				FINE(5);
+				nd_quad_sum36(acc);
+				// a block cut in two parts sits in the two quads of one aligned lane octet: the second quad's sums come over by a mirror step
+				// (only in the wavefronts that hold such blocks: bit 31 of y is set in all their slots)
+				if (__builtin_amdgcn_readfirstlane(q.y) < 0) {
+					const double on = ((q.y >> 30) & 1) ? 1.0 : 0.0;
+#pragma unroll
+					for (int c = 0; c < 36; ++c) acc[c] += on * dpp_f64<0x141>(acc[c]);      // row_half_mirror: lane i <-> 7 - i of its octet
+				}
+				if (ql == 0 && pid != 0xFFFF && ((q.y >> 28) & 3) == 0) {
+					// one owner per block and tile: ds_add_f64 without a return is a plain read-modify-write in the LDS unit (no wait for a read)
+					double* hb = Hb + 36 * pid;
+#pragma unroll
+					for (int c = 0; c < 36; ++c) (void)__hip_atomic_fetch_add(hb + c, acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+				FINE(6);
+			}
+#endif
 			if (!pre)
 				for (int k = quad; k < T.n_gqs; k += NQ) {
 					// reduced gradient of one edge: sum over the tile's nodes on it of [vh; q x vh]
@@ -480,9 +650,22 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 					const int e = q.x & 0xFFFF, n = (q.x >> 16) & 0xFFFF;
 					const int* items = N.gitem + W.gitem0 + q.y;
 					double ga[6] = {0, 0, 0, 0, 0, 0};
-					for (int i = ql; i < n; i += 4) {
-						const double* rc = reg + REC * items[i];
-						const double vh[3] = {rc[R_V], rc[R_V + 1], rc[R_V + 2]}, qq[3] = {rc[R_Q], rc[R_Q + 1], rc[R_Q + 2]};
+					int gi[ND_ITEMS_REG];
+#pragma unroll
+					for (int k2 = 0; k2 < ND_ITEMS_REG; ++k2) gi[k2] = items[min(ql + 4 * k2, n - 1)];
+#pragma unroll
+					for (int k2 = 0; k2 < ND_ITEMS_REG; ++k2)
+						if (ql + 4 * k2 < n) {
+							const double* rcd = reg + REC * gi[k2];
+							const double vh[3] = {rcd[R_V], rcd[R_V + 1], rcd[R_V + 2]}, qq[3] = {rcd[R_Q], rcd[R_Q + 1], rcd[R_Q + 2]};
+							double x[3];
+							nd_cross(qq, vh, x);
+#pragma unroll
+							for (int c = 0; c < 3; ++c) { ga[c] += vh[c]; ga[3 + c] += x[c]; }
+						}
+					for (int i = ql + 4 * ND_ITEMS_REG; i < n; i += 4) {
+						const double* rcd = reg + REC * items[i];
+						const double vh[3] = {rcd[R_V], rcd[R_V + 1], rcd[R_V + 2]}, qq[3] = {rcd[R_Q], rcd[R_Q + 1], rcd[R_Q + 2]};
 						double x[3];
 						nd_cross(qq, vh, x);
 #pragma unroll
@@ -494,10 +677,12 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 					for (int c = 0; c < 6; ++c) ga[c] += dpp_f64<0x4E>(ga[c]);
 					if (ql == 0) {
 #pragma unroll
-						for (int c = 0; c < 6; ++c) g_acc[6 * e + c] += ga[c];
+						for (int c = 0; c < 6; ++c) (void)__hip_atomic_fetch_add(g_acc + 6 * e + c, ga[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
+			STAMP(4);
 			__syncthreads();
+			STAMP(5);
 		}
 		if (pre) {
 			// lambda0 = tau * max diag(H): the diagonal blocks of H_pp and the landmark blocks' diagonals
@@ -526,8 +711,10 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 		}
 		for (int i = tid; i < n6; i += NT) reg[n6 * np + i] = g_acc[i];
 		__syncthreads();
+		STAMP(6);
 		bool ok = true;
 		if (n6 > 0) ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
+		STAMP(7);
 		double dpn = 0, dfn = 0, err_new = s_err;
 		if (ok) {
 			for (int i = tid; i < n6; i += NT) {
@@ -553,9 +740,18 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 			__syncthreads();
 			nd_build_table(W, s_suf, pose_new, tabs[cur ^ 1]);
 			__syncthreads();
+			STAMP(8);
 			double e = 0.0;
-			for (int g = wave; g < n_groups; g += NDW) nd_score_group(D, N, W, P, groups[g], tabs[cur ^ 1], stage, s_b, true, it_idx, lane, e, dfn);
+			{
+				nd_recs nx = nd_fetch_recs(N, W, groups[min(wave, max(n_groups - 1, 0))], lane);
+				for (int g = wave; g < n_groups; g += NDW) {
+					const nd_recs rc = nx;
+					if (g + NDW < n_groups) nx = nd_fetch_recs(N, W, groups[g + NDW], lane);
+					nd_score_group(D, N, W, P, groups[g], rc, tabs[cur ^ 1], stage, s_b, true, it_idx, lane, e, dfn);
+				}
+			}
 			err_new = block_sum(e, s_part);
+			STAMP(9);
 		}
 		dpn = block_sum(dpn, s_part);
 		dfn = block_sum(dfn, s_part);
@@ -592,6 +788,7 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 			}
 		}
 		__syncthreads();
+		STAMP(10);
 		if (s_stop == 2 || s_stop == 4) break;
 	}
 	__syncthreads();
@@ -603,6 +800,14 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 	if (tid == 0) {
 		ssk_lm_result& R = D.res[wi];
 		R.iters = s_iters; R.accepted = s_accepted; R.stop_reason = s_stop; R.err_final = s_err; R.lambda_final = s_lambda;
+#ifdef SSK_LM_STAMPS
+		if (blockIdx.x == 0)
+			printf("node stamps (cycles, window 0, %d iters, %d tiles): loop top %llu zero %llu | groups: own %llu + barrier %llu, pairs: own %llu + barrier %llu | assemble %llu solve %llu "
+			       "edges + table %llu score %llu decision + copy %llu\n", s_iters, W.n_tiles, s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8], s_acc[9], s_acc[10]);
+		if (blockIdx.x == 0)
+			printf("node fine (thread 0, cumulative over launches): group: loads + observation %llu, run sums %llu, roots %llu, nodes %llu, record stores %llu | pairs: items %llu, quad sum + adds %llu\n",
+			       g_nd_fine[0], g_nd_fine[1], g_nd_fine[2], g_nd_fine[3], g_nd_fine[4], g_nd_fine[5], g_nd_fine[6]);
+#endif
 	}
 }
 

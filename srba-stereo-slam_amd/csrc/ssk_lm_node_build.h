@@ -25,11 +25,12 @@ struct nd_host {
 
 // dynamic LDS of a window, doubles: edge poses twice, solution + pivots, block accumulators, gradient accumulator, the trie records, then the region the
 // node records of a tile (waves x 64 x SSK_ND_REC) share with the dense bordered system ((6E + 1) x (6E | 1))
-inline size_t nd_lds_doubles(int n_edges, int E, int waves, int n_suf)
+inline size_t nd_lds_doubles(int n_edges, int E, int waves, int n_suf, int n_tiles = 0, int n_groups = 0)
 {
 	const size_t n6 = 6 * (size_t)E, n6p = (n6 + 1) & ~(size_t)1;
 	const size_t region = std::max((size_t)waves * 64 * SSK_ND_REC, (n6 + 1) * (n6 | 1));
-	return 24 * (size_t)n_edges + 2 * n6p + 36 * ((size_t)E * (E + 1) / 2) + n6p + (((size_t)n_suf + 1) & ~(size_t)1) + region;
+	return 24 * (size_t)n_edges + 2 * n6p + 36 * ((size_t)E * (E + 1) / 2) + n6p + (((size_t)n_suf + 1) & ~(size_t)1) +
+	       3 * (size_t)n_tiles + 2 * (size_t)n_groups + ((size_t)n_tiles & 1) + region;      // (+ the tile / group descriptors: 24 and 16 bytes each)
 }
 
 // Appends window Wn to H (bases edge0 / lm0 / us0 / ls0 / trace offsets are the caller's: the families are shared with the other
@@ -108,7 +109,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	hdr.suf0 = (int)H.suf.size(); hdr.tile0 = (int)H.tile.size(); hdr.grp0 = (int)H.group.size();
 	hdr.obs0 = (int)H.obs.size(); hdr.lane0 = (int)H.lane.size();
 	hdr.item0 = (int)H.item.size(); hdr.qs0 = (int)H.qs.size(); hdr.gitem0 = (int)H.gitem.size(); hdr.gqs0 = (int)H.gqs.size();
-	hdr.tab0 = H.tab_doubles; hdr.pad0 = 0;
+	hdr.tab0 = H.tab_doubles;
 	std::vector<nd_group> groups;
 	std::vector<nd_i2> w_obs;
 	std::vector<nd_f4> w_px;
@@ -146,21 +147,21 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		}
 		flush();
 	}
-	// ---- tiles: `waves` groups each; items of a tile sorted by block; a quad of lanes per block and round ----
+	// ---- tiles: `waves` groups each; the items of a tile sorted by 6x6 block ----
 	const int NQ = waves * 16;
+	(void)NQ;
 	const int n_pairs = E * (E + 1) / 2;
 	auto pid_of = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
 	std::vector<nd_tile> tiles;
 	std::vector<int> w_item, w_gitem;
 	std::vector<nd_i2> w_qs, w_gqs;
-	std::vector<std::vector<int>> by_pid((size_t)n_pairs), by_edge((size_t)E);
-	std::vector<int> used_pid;
-	int max_per_lane = 0;
-	for (size_t g0 = 0; g0 < groups.size(); g0 += (size_t)waves) {
-		nd_tile T{};
-		T.grp0 = (int)g0; T.n_grp = (int)std::min(groups.size() - g0, (size_t)waves);
-		used_pid.clear();
-		for (int wv = 0; wv < T.n_grp; ++wv) {
+	const size_t n_tiles = (groups.size() + (size_t)waves - 1) / (size_t)waves;
+	std::vector<std::vector<std::pair<int, int>>> tile_items(n_tiles);       // (block, item) per tile, generation order
+	std::vector<std::vector<std::vector<int>>> tile_edge(n_tiles, std::vector<std::vector<int>>((size_t)E));
+	for (size_t t = 0; t < n_tiles; ++t) {
+		const size_t g0 = t * (size_t)waves;
+		const int n_grp = (int)std::min(groups.size() - g0, (size_t)waves);
+		for (int wv = 0; wv < n_grp; ++wv) {
 			const std::vector<gnode>& gl = glanes[g0 + (size_t)wv];
 			for (size_t a = 0; a < gl.size(); ++a) {
 				if (gl[a].node < 0) continue;
@@ -168,7 +169,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 				const bool opt = Wn.lm_unknown_slot[M.l] >= 0;
 				const int ka = M.nodes[(size_t)gl[a].node].key, ea = Wn.edge_unknown_slot[suf[(size_t)ka].x >> 1];
 				const int slot_a = 64 * wv + gl[a].slot_lane;
-				by_edge[(size_t)ea].push_back(slot_a);
+				tile_edge[t][(size_t)ea].push_back(slot_a);
 				// partners: the later nodes of the same landmark (they follow in the lane order) and the node itself
 				for (size_t b = a; b < gl.size() && gl[b].lmk == gl[a].lmk; ++b) {
 					const int kb = M.nodes[(size_t)gl[b].node].key, eb = Wn.edge_unknown_slot[suf[(size_t)kb].x >> 1];
@@ -178,11 +179,10 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 					int far = 0;                                   // 1: a far (b's key is a suffix of a's), 2: b far, 0: not nested
 					if (is_suffix_of(kb, ka)) far = 1; else if (is_suffix_of(ka, kb)) far = 2;
 					if (far == 0 && !opt) continue;
-					// item (row r, column c): X = far == row ? Zh_r : (nested ? Ph_r : Zh_r), Y likewise
+					// item (row r, column c): the far node of a nested pair gives Zh, the near one Ph; not nested: Zh, Zh and the sign bit
 					auto emit = [&](int slot_r, int slot_c, bool r_far, bool c_far, int pid) {
 						const int xp = (far != 0 && !r_far) ? 1 : 0, yp = (far != 0 && !c_far) ? 1 : 0;
-						if (by_pid[(size_t)pid].empty()) used_pid.push_back(pid);
-						by_pid[(size_t)pid].push_back(slot_r | (xp << 9) | (slot_c << 10) | (yp << 19) | ((far == 0 ? 1 : 0) << 20));
+						tile_items[t].push_back(std::make_pair(pid, slot_r | (xp << 9) | (slot_c << 10) | (yp << 19) | ((far == 0 ? 1 : 0) << 20)));
 					};
 					if (a == b) emit(slot_a, slot_a, true, false, pid_of(ea, ea));
 					else if (ea < eb) emit(slot_a, slot_b, far == 1, far == 2, pid_of(ea, eb));
@@ -194,32 +194,113 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 				}
 			}
 		}
-		// most items first: the 16 quads of a wavefront run in lockstep, so blocks of similar size share one
-		std::stable_sort(used_pid.begin(), used_pid.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
+	}
+#if SSK_ND_LANE_RUNS
+	// lane slots of a tile: the items of a block dealt out in runs of R consecutive items, a lane per run; R = the shortest run length
+	// whose lanes fit the workgroup (one round); the lanes of one block stay inside one wavefront (their sums meet in ONE ds_add_f64 per
+	// component: the order of the adds is the LDS unit's lane order, the same in every launch)
+	int max_per_lane = 0, max_rounds = 0;
+	const int NT_ = waves * 64;
+	std::vector<std::vector<int>> by_pid((size_t)n_pairs);
+	std::vector<int> used;
+	for (size_t t = 0; t < n_tiles; ++t) {
+		nd_tile T{};
+		T.grp0 = (int)(t * (size_t)waves); T.n_grp = (int)std::min(groups.size() - t * (size_t)waves, (size_t)waves);
+		used.clear();
+		for (const auto& it : tile_items[t]) { if (by_pid[(size_t)it.first].empty()) used.push_back(it.first); by_pid[(size_t)it.first].push_back(it.second); }
+		std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
+		auto lanes_for = [&](int R) {
+			long long pos = 0;
+			for (int p2 : used) {
+				const long long g = ((long long)by_pid[(size_t)p2].size() + R - 1) / R;
+				if (g > 64) return (long long)1 << 40;
+				if ((pos & 63) + g > 64) pos = (pos + 63) & ~63LL;
+				pos += g;
+			}
+			return pos;
+		};
+		int R = 1;
+		while (R < 8 && lanes_for(R) > NT_) ++R;
+		if (lanes_for(R) >= ((long long)1 << 40)) return false;
 		T.qs0 = (int)w_qs.size();
-		T.n_rounds = ((int)used_pid.size() + NQ - 1) / NQ;
-		for (size_t k = 0; k < (size_t)T.n_rounds * NQ; ++k) {
-			if (k < used_pid.size()) {
-				std::vector<int>& v = by_pid[(size_t)used_pid[k]];
-				if (v.size() > 65535) return false;
-				w_qs.push_back(nd_i2{used_pid[k] | ((int)v.size() << 16), (int)w_item.size()});
-				w_item.insert(w_item.end(), v.begin(), v.end());
-				max_per_lane = std::max(max_per_lane, ((int)v.size() + 3) / 4);
-				v.clear();
-			} else w_qs.push_back(nd_i2{0, 0});
+		long long pos = 0;
+		for (int p2 : used) {
+			const std::vector<int>& v = by_pid[(size_t)p2];
+			const long long g = ((long long)v.size() + R - 1) / R;
+			if ((pos & 63) + g > 64) for (; pos & 63; ++pos) w_qs.push_back(nd_i2{0xFFFF, 0});
+			for (long long k = 0; k < g; ++k) {
+				const int first = (int)w_item.size(), n = (int)std::min<long long>(R, (long long)v.size() - k * R);
+				w_item.insert(w_item.end(), v.begin() + k * R, v.begin() + k * R + n);
+				w_qs.push_back(nd_i2{p2 | (n << 16), first});
+				++pos;
+			}
+			max_per_lane = std::max(max_per_lane, std::min(R, (int)v.size()));
 		}
+		for (; pos % NT_; ++pos) w_qs.push_back(nd_i2{0xFFFF, 0});
+		T.n_rounds = (int)(pos / NT_);
+		max_rounds = std::max(max_rounds, T.n_rounds);
+		for (int p2 : used) by_pid[(size_t)p2].clear();
 		T.gqs0 = (int)w_gqs.size(); T.n_gqs = 0;
 		for (int e = 0; e < E; ++e) {
-			std::vector<int>& v = by_edge[(size_t)e];
+			const std::vector<int>& v = tile_edge[t][(size_t)e];
 			if (v.empty()) continue;
 			w_gqs.push_back(nd_i2{e | ((int)v.size() << 16), (int)w_gitem.size()});
 			w_gitem.insert(w_gitem.end(), v.begin(), v.end());
 			++T.n_gqs;
-			v.clear();
 		}
 		tiles.push_back(T);
 	}
-	hdr.n_tiles = (int)tiles.size();
+#else
+	// quad slots of a tile: a block per quad, heaviest first (the 16 quads of a wavefront run in lockstep: similar loads share one); with quads
+	// to spare the heaviest blocks are cut in two parts (items dealt out alternately) that sit in the two quads of an aligned lane octet
+	// and are added up by a DPP mirror step before the block's accumulator takes them
+	int max_per_lane = 0, max_rounds = 0;
+	std::vector<std::vector<int>> by_pid((size_t)n_pairs);
+	std::vector<int> used;
+	for (size_t t = 0; t < n_tiles; ++t) {
+		nd_tile T{};
+		T.grp0 = (int)(t * (size_t)waves); T.n_grp = (int)std::min(groups.size() - t * (size_t)waves, (size_t)waves);
+		used.clear();
+		for (const auto& it : tile_items[t]) { if (by_pid[(size_t)it.first].empty()) used.push_back(it.first); by_pid[(size_t)it.first].push_back(it.second); }
+		std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
+		int n_split = 0;
+		if ((int)used.size() < NQ) {
+			n_split = std::min((NQ - (int)used.size()), (int)used.size());
+			while (n_split > 0 && by_pid[(size_t)used[(size_t)n_split - 1]].size() < 8) --n_split;       // (a short run is not worth a second quad)
+		}
+		struct qslot { int pid, part, parts; };
+		std::vector<qslot> slots;
+		for (int k = 0; k < n_split; ++k) { slots.push_back(qslot{used[(size_t)k], 0, 2}); slots.push_back(qslot{used[(size_t)k], 1, 2}); }
+		for (size_t k = (size_t)n_split; k < used.size(); ++k) slots.push_back(qslot{used[k], 0, 1});
+		T.qs0 = (int)w_qs.size();
+		T.n_rounds = ((int)slots.size() + NQ - 1) / NQ;
+		max_rounds = std::max(max_rounds, T.n_rounds);
+		for (size_t k = 0; k < (size_t)T.n_rounds * NQ; ++k) {
+			const int wave_flag = (k / 16) * 16 < (size_t)(2 * n_split) ? (int)0x80000000u : 0;      // this wavefront holds blocks cut in two
+			if (k >= slots.size()) { w_qs.push_back(nd_i2{0xFFFF, wave_flag}); continue; }
+			const qslot& q = slots[k];
+			const std::vector<int>& v = by_pid[(size_t)q.pid];
+			const int first = (int)w_item.size();
+			for (size_t i = (size_t)q.part; i < v.size(); i += (size_t)q.parts) w_item.push_back(v[i]);
+			const int n = (int)w_item.size() - first;
+			if (n > 32767 || first >= (1 << 28)) return false;
+			w_qs.push_back(nd_i2{q.pid | (n << 16), first | (q.part << 28) | (q.parts == 2 ? 1 << 30 : 0) | wave_flag});
+			max_per_lane = std::max(max_per_lane, (n + 3) / 4);
+		}
+		for (int p : used) by_pid[(size_t)p].clear();
+		T.gqs0 = (int)w_gqs.size(); T.n_gqs = 0;
+		for (int e = 0; e < E; ++e) {
+			const std::vector<int>& v = tile_edge[t][(size_t)e];
+			if (v.empty()) continue;
+			w_gqs.push_back(nd_i2{e | ((int)v.size() << 16), (int)w_gitem.size()});
+			w_gitem.insert(w_gitem.end(), v.begin(), v.end());
+			++T.n_gqs;
+		}
+		tiles.push_back(T);
+	}
+#endif
+	hdr.n_rounds = max_rounds; hdr.max_parts = 2;
+	hdr.n_tiles = (int)tiles.size(); hdr.n_groups = (int)groups.size();
 	// ---- commit ----
 	H.suf.insert(H.suf.end(), suf.begin(), suf.end());
 	H.tile.insert(H.tile.end(), tiles.begin(), tiles.end());
@@ -232,7 +313,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	H.gitem.insert(H.gitem.end(), w_gitem.begin(), w_gitem.end());
 	H.gqs.insert(H.gqs.end(), w_gqs.begin(), w_gqs.end());
 	H.tab_doubles += 2LL * 12 * n_suf;
-	H.lds_doubles = std::max(H.lds_doubles, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf));
+	H.lds_doubles = std::max(H.lds_doubles, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)tiles.size(), (int)groups.size()));
 	H.max_items_per_lane = std::max(H.max_items_per_lane, max_per_lane);
 	H.win.push_back(hdr);
 	return true;

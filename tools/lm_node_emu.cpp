@@ -165,13 +165,14 @@ int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lam
 				for (int c = 0; c < 3; ++c) sc[9 + c] = out[9 + c];
 			}
 		}
-		const int NQ = waves * 16;
+		const int NQ = SSK_ND_LANE_RUNS ? waves * 64 : waves * 16;      // slots per round
 		for (int r = 0; r < T.n_rounds; ++r)
 			for (int quad = 0; quad < NQ; ++quad) {
 				const nd_i2 q = H.qs[(size_t)W.qs0 + T.qs0 + r * NQ + quad];
-				const int pid = q.x & 0xFFFF, n = (q.x >> 16) & 0xFFFF;
+				const int pid = q.x & 0xFFFF, n = (q.x >> 16) & 0x7FFF;
+				if (pid == 0xFFFF) continue;                      // (a quad without a block)
 				for (int i = 0; i < n; ++i) {
-					const int it = H.item[(size_t)W.item0 + q.y + i];
+					const int it = H.item[(size_t)W.item0 + (q.y & 0x0FFFFFFF) + i];
 					const double* xr = &rec[(size_t)SSK_ND_REC * (it & 511)];
 					const double* yc = &rec[(size_t)SSK_ND_REC * ((it >> 10) & 511)];
 					const double* X = xr + 12 * ((it >> 9) & 1);
