@@ -272,47 +272,38 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		__syncthreads();
 
 		FSTAMP(3);
-		// ---- phase C: strict 3x3 NMS inside the emit region [31,W-31) x [31,H-31), 4 pixels per lane ----
-		for (int base = 0; base < (TW / 4) * TH; base += 256) {
-			const int it = base + tid;
-			bool pr[4] = {false, false, false, false};
-			uint32_t key[4] = {0, 0, 0, 0};
-			if (it < (TW / 4) * TH) {
-				const int ly = it / (TW / 4), g = it - ly * (TW / 4);
-				const int gy = Y0 + ly, gx0 = X0 + 4 * g;
-				const uint32_t* sd = reinterpret_cast<const uint32_t*>(s_sc + (ly + 1) * SP + 4 * (g + 1));
-				const uint32_t own = sd[0];
-				if (own != 0u && gy < h - SSK_EDGE) {
-					// strict maximum over the 8 neighbours for the four pixels at once: 9 dword reads, the shifted rows by
-					// v_alignbyte, bytes widened to packed 16-bit pairs, neighbour maximum by v_pk_max_u16, "centre > max"
-					// as a non-zero saturating difference (a byte-by-byte walk of the 32 neighbours was a third of the kernel)
-					constexpr int SPD = SP / 4;
-					const uint32_t uL = sd[-SPD - 1], uC = sd[-SPD], uR = sd[-SPD + 1];
-					const uint32_t mL = sd[-1], mR = sd[1];
-					const uint32_t dL = sd[SPD - 1], dC = sd[SPD], dR = sd[SPD + 1];
-					const uint32_t nb[8] = {__builtin_amdgcn_alignbyte(uC, uL, 3u), uC, __builtin_amdgcn_alignbyte(uR, uC, 1u),
-					                        __builtin_amdgcn_alignbyte(own, mL, 3u), __builtin_amdgcn_alignbyte(mR, own, 1u),
-					                        __builtin_amdgcn_alignbyte(dC, dL, 3u), dC, __builtin_amdgcn_alignbyte(dR, dC, 1u)};
-					uint32_t win[2];
-#pragma unroll
-					for (int hsel = 0; hsel < 2; ++hsel) {
-						const uint32_t sel = hsel ? 0x0c030c02u : 0x0c010c00u;
-						u16x2 m = as_u16x2(__builtin_amdgcn_perm(0u, nb[0], sel));
-#pragma unroll
-						for (int j = 1; j < 8; ++j) m = __builtin_elementwise_max(m, as_u16x2(__builtin_amdgcn_perm(0u, nb[j], sel)));
-						win[hsel] = as_u32x(__builtin_elementwise_sub_sat(as_u16x2(__builtin_amdgcn_perm(0u, own, sel)), m));
-					}
-#pragma unroll
-					for (int k = 0; k < 4; ++k) {
-						const int gx = gx0 + k;
-						if (((win[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) != 0u && gx >= SSK_EDGE && gx < w - SSK_EDGE) {
-							pr[k] = true;
-							key[k] = (((own >> (8 * k)) & 255u) << 24) | ((uint32_t)(4095 - gy) << 12) | (uint32_t)(4095 - gx);
-						}
+		// ---- phase C: strict 3x3 NMS inside the emit region [31,W-31) x [31,H-31): a lane per CORNER (the second queue again: a few % of the
+		// pixels), its 8 neighbours' scores by byte reads.  (A sweep of all 1024 pixel groups of the tile ran every wavefront through the
+		// whole test with an eighth of its lanes holding a corner: ~350 of the kernel's ~1550 instructions per thread.) ----
+		for (int base = 0; base < q2n; base += 256) {
+			const int q = base + tid;
+			bool pr = false;
+			uint32_t key = 0;
+			if (q < q2n) {
+				const int code = s_q2[q];
+				const int it = code >> 2, k = code & 3;
+				const int sy = it / SG, g = it - sy * SG;
+				const int col = 4 * g + k;                               // score tile column: gx - (X0 - 4)
+				const int gy = Y0 - 1 + sy, gx = X0 - 4 + col;
+				const uint8_t* sc = s_sc + sy * SP + col;
+				const int own = sc[0];
+				if (own != 0 && sy >= 1 && sy <= TH && col >= 4 && col < TW + 4 && gy < h - SSK_EDGE && gx >= SSK_EDGE && gx < w - SSK_EDGE) {
+					const int m0 = max(max((int)sc[-SP - 1], (int)sc[-SP]), max((int)sc[-SP + 1], (int)sc[-1]));
+					const int m1 = max(max((int)sc[1], (int)sc[SP - 1]), max((int)sc[SP], (int)sc[SP + 1]));
+					if (own > max(m0, m1)) {
+						pr = true;
+						key = ((uint32_t)own << 24) | ((uint32_t)(4095 - gy) << 12) | (uint32_t)(4095 - gx);
 					}
 				}
 			}
-			wave_push4(pr, key, s_out, &s_on);
+			const unsigned long long m = __ballot(pr);
+			if (m != 0ull) {                                             // (wave uniform)
+				const int lane = tid & 63;
+				int b0 = 0;
+				if (lane == 0) b0 = atomicAdd(&s_on, __popcll(m));
+				b0 = __shfl(b0, 0, 64);
+				if (pr) s_out[b0 + __popcll(m & ((1ull << lane) - 1ull))] = key;
+			}
 		}
 		__syncthreads();
 		const int on = s_on;

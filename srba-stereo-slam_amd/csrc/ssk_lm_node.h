@@ -38,7 +38,7 @@
 
 constexpr int SSK_ND_REC = 26;          // doubles per node record in LDS (24 used; 26: a 16-byte aligned pitch whose b128 gathers spread over all banks)
 constexpr int SSK_ND_STAGE = 9;         // doubles per observation in the wave-private staging
-constexpr int SSK_ND_LREC = 16;         // doubles per root record in the staging: L (6), L^-1 (6), c (3), fixed flag
+constexpr int SSK_ND_LREC = 17;         // doubles per root record in the staging: L (6), L^-1 (6), c (3), fixed flag (17: an odd pitch, no bank conflicts between roots)
 constexpr int SSK_ND_SCR = 12;          // doubles per lane in the window's HBM scratch: node (Zh 9, q 3) / root (L^-1 6, c 3)
 constexpr int SSK_ND_MAX_WAVES = 8;
 #ifndef SSK_ND_LANE_RUNS

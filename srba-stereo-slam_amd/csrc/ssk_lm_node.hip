@@ -198,16 +198,16 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 		const int a = lrec.y & 0xFF, n = kind ? (lrec.y >> 8) : 0;
 #if ND_SUM4
 		// four rows per turn, loads first (rows past the run: the run's last row, weight 0); the order of the adds is the rows' order
-		for (int i = 0; i < n; i += 4) {
-			double v[4][9];
+		for (int i = 0; i < n; i += ND_SUMROWS) {
+			double v[ND_SUMROWS][9];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
+			for (int u = 0; u < ND_SUMROWS; ++u) {
 				const double* o = stage + STG * (a + min(i + u, n - 1));
 #pragma unroll
 				for (int c = 0; c < 9; ++c) v[u][c] = o[c];
 			}
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
+			for (int u = 0; u < ND_SUMROWS; ++u) {
 				const double wgt = i + u < n ? 1.0 : 0.0;
 #pragma unroll
 				for (int c = 0; c < 9; ++c) vs[c] = fma(wgt, v[u][c], vs[c]);
@@ -358,7 +358,13 @@ __device__ __forceinline__ void nd_item_apply(const nd_item_ops& o, double sg, d
 #define ND_PIPE 0                       // 1: software-pipelined item turns (loads of item k + 1 in front of the products of item k)
 #endif
 #ifndef ND_SUM4
-#define ND_SUM4 1                       // 1: four staging rows per turn in the run sums
+#define ND_SUM4 1                       // 1: ND_SUMROWS staging rows per turn in the run sums
+#endif
+#ifndef ND_SUMROWS
+#define ND_SUMROWS 4
+#endif
+#ifndef ND_HB_ATOMIC
+#define ND_HB_ATOMIC 1                  // block accumulators: 1 = ds_add_f64 per component, 0 = 16-byte loads, adds, 16-byte stores
 #endif
 constexpr int ND_ITEMS_REG = 8;
 struct nd_items { int it[ND_ITEMS_REG]; };
@@ -635,10 +641,19 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 					for (int c = 0; c < 36; ++c) acc[c] += on * dpp_f64<0x141>(acc[c]);      // row_half_mirror: lane i <-> 7 - i of its octet
 				}
 				if (ql == 0 && pid != 0xFFFF && ((q.y >> 28) & 3) == 0) {
+#if ND_HB_ATOMIC
 					// one owner per block and tile: ds_add_f64 without a return is a plain read-modify-write in the LDS unit (no wait for a read)
 					double* hb = Hb + 36 * pid;
 #pragma unroll
 					for (int c = 0; c < 36; ++c) (void)__hip_atomic_fetch_add(hb + c, acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+					v2d_t* hb = reinterpret_cast<v2d_t*>(Hb + 36 * pid);
+					v2d_t old[18];
+#pragma unroll
+					for (int c = 0; c < 18; ++c) old[c] = hb[c];
+#pragma unroll
+					for (int c = 0; c < 18; ++c) { v2d_t x = old[c]; x.x += acc[2 * c]; x.y += acc[2 * c + 1]; hb[c] = x; }
+#endif
 				}
 				FINE(6);
 			}
