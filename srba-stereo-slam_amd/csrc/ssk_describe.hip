@@ -78,15 +78,32 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 	}
 	__syncthreads();
 
-	// moments over the radius-15 disc: lane v handles row v-15 (31 rows)
+	// moments over the radius-15 disc: two lanes per row v (u in [-16, -1] and [0, 15]; the disc's |u| <= umax(v) by a byte mask), the
+	// 16 pixels as 4 realigned dwords, sums by v_dot4_u32_u8 against packed |u| weights (a byte-by-byte loop was a sixth of the kernel)
 	int m10 = 0, m01 = 0;
-	if (lane < 62) {                                           // two lanes per row: u in [-um, -1] and [0, um]
-		const int v = (lane >> 1) - 15;
+	if (lane < 62) {
+		const int v = (lane >> 1) - 15, half = lane & 1;
 		const int um = c_umax[v < 0 ? -v : v];
-		const uint8_t* p = s_raw + (PR + v) * PP + shift + PR;
-		const int u0 = (lane & 1) ? 0 : -um, u1 = (lane & 1) ? um : -1;
-		int rs = 0;
-		for (int u = u0; u <= u1; ++u) { const int I = p[u]; m10 += u * I; rs += I; }
+		const int b = (PR + v) * PP + shift + PR - (half ? 0 : 16);
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(s_raw) + (b >> 2);
+		const uint32_t sub = (uint32_t)(b & 3);
+		uint32_t D[5];
+#pragma unroll
+		for (int k = 0; k < 5; ++k) D[k] = p[k];
+		int rs = 0, mu = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t I = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sub);
+			// bytes inside the disc: upper half u = 4k + i <= um; lower half u = -16 + 4k + i >= -um
+			const int nlo = half ? min(max(um + 1 - 4 * k, 0), 4) : min(max(16 - um - 4 * k, 0), 4);      // upper: valid low bytes; lower: invalid low bytes
+			const uint32_t lowmask = nlo >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nlo)) - 1u);
+			const uint32_t Im = I & (half ? lowmask : ~lowmask);
+			const uint32_t wu = 0x03020100u + 0x04040404u * (uint32_t)k;                                   // u = 4k + (0, 1, 2, 3)
+			const uint32_t wl = 0x0D0E0F10u - 0x04040404u * (uint32_t)k;                                   // |u| = 16 - 4k - (0, 1, 2, 3)
+			mu = (int)__builtin_amdgcn_udot4(Im, half ? wu : wl, (uint32_t)mu, false);
+			rs = (int)__builtin_amdgcn_udot4(Im, 0x01010101u, (uint32_t)rs, false);
+		}
+		m10 = half ? mu : -mu;
 		m01 = v * rs;
 	}
 	// horizontal blur pass: item = (row r, segment s of 13 outputs).  The 19 input bytes come in as 6 dwords, are
@@ -98,17 +115,24 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 		const int b0 = shift + 13 * s;                           // first input byte of the segment inside the raw row
 		const uint32_t* p = reinterpret_cast<const uint32_t*>(s_raw + r * PP) + (b0 >> 2);
 		const uint32_t sub = (uint32_t)(b0 & 3);
-		uint32_t D[6], E[5], L[17];
+		uint32_t D[6], E[5];
 #pragma unroll
 		for (int k = 0; k < 6; ++k) D[k] = p[k];
 #pragma unroll
 		for (int k = 0; k < 5; ++k) E[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sub);
-#pragma unroll
-		for (int j = 0; j < 17; ++j) L[j] = (j & 3) == 0 ? E[j >> 2] : __builtin_amdgcn_alignbyte(E[(j >> 2) + 1], E[j >> 2], (uint32_t)(j & 3));
 		uint16_t* o = s_h + (13 * s) * HT + r;
+		// output j = sum_t tap[t] byte[j + t], taps (18,34,49,55,49,34,18): the window of output 4q + ph starts at byte ph of E[q]; instead
+		// of shifting the window to a dword start (12 v_alignbyte per segment) the TAPS are packed at the byte phase: 2 or 3 v_dot4
 #pragma unroll
-		for (int j = 0; j < 13; ++j)
-			o[j * HT] = (uint16_t)__builtin_amdgcn_udot4(L[j], 0x37312212u, __builtin_amdgcn_udot4(L[j + 4], 0x00122231u, 0u, false), false);
+		for (int j = 0; j < 13; ++j) {
+			const int q = j >> 2, ph = j & 3;
+			uint32_t sum;
+			if (ph == 0) sum = __builtin_amdgcn_udot4(E[q], 0x37312212u, __builtin_amdgcn_udot4(E[q + 1], 0x00122231u, 0u, false), false);
+			else if (ph == 1) sum = __builtin_amdgcn_udot4(E[q], 0x31221200u, __builtin_amdgcn_udot4(E[q + 1], 0x12223137u, 0u, false), false);
+			else if (ph == 2) sum = __builtin_amdgcn_udot4(E[q], 0x22120000u, __builtin_amdgcn_udot4(E[q + 1], 0x22313731u, __builtin_amdgcn_udot4(E[q + 2], 0x00000012u, 0u, false), false), false);
+			else sum = __builtin_amdgcn_udot4(E[q], 0x12000000u, __builtin_amdgcn_udot4(E[q + 1], 0x31373122u, __builtin_amdgcn_udot4(E[q + 2], 0x00001222u, 0u, false), false), false);
+			o[j * HT] = (uint16_t)sum;
+		}
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
@@ -121,21 +145,30 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 		const int r0 = 13 * s;
 		const uint32_t* p = reinterpret_cast<const uint32_t*>(s_h + j * HT) + (r0 >> 1);
 		const uint32_t sub = (uint32_t)(r0 & 1) * 2u;
-		uint32_t D[10], E[10], Q[19];
+		uint32_t D[10], E[10];
 #pragma unroll
 		for (int k = 0; k < 10; ++k) D[k] = p[k];
 #pragma unroll
 		for (int k = 0; k < 9; ++k) E[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sub);
 		E[9] = D[9] >> (8 * sub);
-#pragma unroll
-		for (int i = 0; i < 19; ++i) Q[i] = (i & 1) == 0 ? E[i >> 1] : (i < 18 ? __builtin_amdgcn_alignbyte(E[(i >> 1) + 1], E[i >> 1], 2u) : 0u);
 		uint8_t* o = s_b + j * BT + r0;
+		// E[m] = (in[2m], in[2m+1]); output i = sum_t tap[t] in[i + t]: an even i starts on a pair, an odd one in the middle of one -- the taps
+		// are paired accordingly instead of realigning the window (9 v_alignbyte per segment)
 #pragma unroll
 		for (int i = 0; i < 13; ++i) {
-			uint32_t sum = __builtin_amdgcn_udot2(as_u16x2(Q[i + 6]), as_u16x2(18u), 1u << 15, false);
-			sum = __builtin_amdgcn_udot2(as_u16x2(Q[i + 4]), as_u16x2(49u | (34u << 16)), sum, false);
-			sum = __builtin_amdgcn_udot2(as_u16x2(Q[i + 2]), as_u16x2(49u | (55u << 16)), sum, false);
-			sum = __builtin_amdgcn_udot2(as_u16x2(Q[i]), as_u16x2(18u | (34u << 16)), sum, false);
+			const int a = i >> 1;
+			uint32_t sum = 1u << 15;
+			if ((i & 1) == 0) {
+				sum = __builtin_amdgcn_udot2(as_u16x2(E[a + 3]), as_u16x2(18u), sum, false);
+				sum = __builtin_amdgcn_udot2(as_u16x2(E[a + 2]), as_u16x2(49u | (34u << 16)), sum, false);
+				sum = __builtin_amdgcn_udot2(as_u16x2(E[a + 1]), as_u16x2(49u | (55u << 16)), sum, false);
+				sum = __builtin_amdgcn_udot2(as_u16x2(E[a]), as_u16x2(18u | (34u << 16)), sum, false);
+			} else {
+				sum = __builtin_amdgcn_udot2(as_u16x2(E[a + 3]), as_u16x2(34u | (18u << 16)), sum, false);
+				sum = __builtin_amdgcn_udot2(as_u16x2(E[a + 2]), as_u16x2(55u | (49u << 16)), sum, false);
+				sum = __builtin_amdgcn_udot2(as_u16x2(E[a + 1]), as_u16x2(34u | (49u << 16)), sum, false);
+				sum = __builtin_amdgcn_udot2(as_u16x2(E[a]), as_u16x2(18u << 16), sum, false);
+			}
 			o[i] = (uint8_t)min(sum >> 16, 255u);
 		}
 	}
