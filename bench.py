@@ -29,7 +29,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1241, 376
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-LM_KERNEL = "lm_solve_tiled_lds_kernel"      # the bench windows (E = 10): every reduced system fits LDS, the variant without the L2-resident solver
 FP64_PEAK_TFLOPS = 78.6    # AMD MI355X data sheet: FP64 vector = FP64 matrix (MFMA) 78.6 TFLOP/s (the guide lists no FP64 row)
 
 
@@ -52,15 +51,23 @@ def lm_algorithmic_flops(win):
 
 
 
-def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=8, n_lm_distinct=8, shared=None):
-    """B keyframes + B 'previous' keyframes resident in HBM, B LM windows uploaded."""
-    import torch
+def _synth_pair(seed):
     import synth
+    return synth.synth_stereo_pair(seed)
+
+
+def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=64, n_lm_distinct=64, shared=None):
+    """B keyframes + B 'previous' keyframes resident in HBM, B LM windows uploaded."""
+    import multiprocessing as mp
+    import torch
     import synth_lm as sl
     cur = capi.KfBatch(ctx, B, W, H, 512)
     prev = capi.KfBatch(ctx, B, W, H, 512)
-    for i in range(min(n_base, B)):
-        l, r = synth.synth_stereo_pair(1000 * rank + i)
+    n_base = min(n_base, B)
+    # the distinct base pairs are rendered on the host cores side by side (~2 s each on one core)
+    with mp.get_context("spawn").Pool(max(1, min(16, os.cpu_count() or 1, n_base))) as pool:
+        pairs_lr = pool.map(_synth_pair, [1000 * rank + i for i in range(n_base)])
+    for i, (l, r) in enumerate(pairs_lr):
         cur.upload(i, l, r)
     ctx.synchronize()
     ic, ip = cur.image_tensor(), prev.image_tensor()
@@ -229,10 +236,11 @@ def main():
     ap.add_argument("--pcie-steps", type=int, default=5,
                     help="steps of the PCIe-inclusive pass at N=1 (images uploaded from pinned host memory every step; reported as "
                          "`pcie_inclusive`, never as `value`; 0 = skip)")
-    ap.add_argument("--lm-distinct", type=int, default=8,
-                    help="distinct LM windows in the batch (the rest are replicas): 8 = the default line; 64 gives ragged iteration counts "
-                         "(64 submaps, seeds 0..63, x16 replicas at --batch 1024)")
-    ap.add_argument("--lm-depth5", type=int, default=64,
+    ap.add_argument("--lm-distinct", type=int, default=64,
+                    help="distinct LM windows in the batch (the rest are replicas): 64 submaps (seeds 0..63, x16 replicas at --batch 1024) give ragged "
+                         "iteration counts; rounds 1-2 quoted 8")
+    ap.add_argument("--base-images", type=int, default=64, help="distinct rendered stereo pairs (the rest of the batch: circular shifts of them)")
+    ap.add_argument("--lm-depth5", type=int, default=1024,
                     help="windows of the `lm_depth5` pass at N=1: the reference's real per-keyframe LM load (KITTI.ini:104-106: optimise depth 5 => a "
                          "local area of ~40 edges) as stage 1 + stage 2 per keyframe, batched and one keyframe at a time; 0 = skip")
     ap.add_argument("--unbatched-frames", type=int, default=401,
@@ -272,7 +280,7 @@ def main():
     ctx_lm = pkg.Context(local, stream=lm_stream.cuda_stream) if args.overlap else ctx
     B = args.batch
     S = args.shared_landmarks
-    cur, prev, lm, wins, shared_idx, lm_batch_wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_lm_distinct=max(1, min(args.lm_distinct, B)),
+    cur, prev, lm, wins, shared_idx, lm_batch_wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=max(1, args.base_images), n_lm_distinct=max(1, min(args.lm_distinct, B)),
                                                                     shared=(max(world, 2), S) if exchange else None)
     fp, da, lp, cp, fm = params(capi, sl)
     pairs = np.stack([np.arange(B), np.arange(B)], 1).astype(np.int32)
@@ -478,13 +486,34 @@ def main():
             it = float(np.mean([x.iters for x in r]))
             b.close()
             return 1e3 * t / reps, it
-        ms1, it1 = timed([st1[k % 4] for k in range(n)], 3)
-        ms2, it2 = timed([wins5[k % 4] for k in range(n)], 3)
-        out["batched"] = {"windows": n, "stage1_ms": ms1, "stage2_ms": ms2, "keyframes_per_s": n / ((ms1 + ms2) * 1e-3), "stage1_iters": it1, "stage2_iters": it2}
-        l1, _ = timed([st1[0]], 10)
-        l2, _ = timed([wins5[0]], 10)
-        out["one_keyframe"] = {"stage1_ms": l1, "stage2_ms": l2, "note": "one window per launch: stage 2 on the cooperative kernel (its tiles dealt out over up to 32 "
-                               "workgroups), host clock around ssk_lm_batch_run + results, structures already built"}
+        def timed_named(batch_wins, reps):
+            b = capi.LmBatch(ctx, batch_wins)
+            name = b.kernel_name()
+            b.close()
+            ms, it = timed(batch_wins, reps)
+            return ms, it, name
+        ms1, it1, k1 = timed_named([st1[k % 4] for k in range(n)], 3)
+        ms2, it2, k2 = timed_named([wins5[k % 4] for k in range(n)], 3)
+        out["batched"] = {"windows": n, "stage1_ms": ms1, "stage2_ms": ms2, "keyframes_per_s": n / ((ms1 + ms2) * 1e-3), "stage1_iters": it1, "stage2_iters": it2,
+                          "stage1_kernel": k1, "stage2_kernel": k2}
+        # the stage-2 launch priced in FP64 flops (SURVEY 8(d) per-unit figures, as roofline_fp64): the kernel that carries the reference's real load
+        fl = float(np.mean([lm_algorithmic_flops(w) for w in wins5])) * it2 * n
+        out["roofline_depth5"] = {"kernel": k2, "bound": "mfma", "achieved": fl / (ms2 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": fl / (ms2 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl, "avg_launch_ms": ms2,
+                                  "note": "host clock around ssk_lm_batch_run + results of %d windows (one workgroup per window); kernel-trace and PMC summaries: profiles/r03_lm_depth5*" % n}
+        l1, _, kk1 = timed_named([st1[0]], 10)
+        l2, _, kk2 = timed_named([wins5[0]], 10)
+        out["one_keyframe"] = {"stage1_ms": l1, "stage2_ms": l2, "stage1_kernel": kk1, "stage2_kernel": kk2,
+                               "note": "one window per launch (stage 2: its tiles dealt out over up to 32 workgroups), host clock around ssk_lm_batch_run + results, structures already built"}
+        # the CPU oracle on the same stage-2 window (1 thread)
+        try:
+            import oracle_lib
+            orc = oracle_lib.load()
+            t0 = time.perf_counter()
+            orc.lm_solve(wins5[0], sl.make_params(), trace=False)
+            out["cpu_ms"] = {"stage2_ms": 1e3 * (time.perf_counter() - t0), "cores": 1, "kind": "port", "sample": "one stage-2 window (the CPU oracle, 1 thread)"}
+        except Exception as e:       # the oracle is test infrastructure: its absence does not stop the bench
+            out["cpu_ms"] = {"error": str(e)}
         return out
 
     lm_depth5 = lm_depth5_pass(args.lm_depth5) if world == 1 and rank == 0 and args.lm_depth5 > 0 else None
@@ -493,17 +522,38 @@ def main():
         # PMC traffic per launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, summary
         # committed under profiles/): bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- KB units, FETCH_SIZE doubled on gfx950
         # (MI355X_MICROARCH.md "HBM"; re-calibrated in the same run on lm_reset_kernel, which reads exactly what it writes)
-        traffic = {}
-        for tf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json", "r01_pmc_traffic_b256.json"):          # the summary collected at this batch size
-            tf = os.path.join(ROOT, "profiles", tf)
-            if traffic or not os.path.exists(tf):
+        LM_KERNEL = lm.kernel_name()
+        traffic, traffic_src, pmc_ms = {}, None, {}
+        for tf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # the newest summary collected at this batch size
+            tfp = os.path.join(ROOT, "profiles", tf)
+            if traffic or not os.path.exists(tfp):
                 continue
             try:
-                t = json.load(open(tf))
+                t = json.load(open(tfp))
                 if int(t.get("batch", -1)) == B:
                     traffic = {k: (2.0 * v["fetch_size_kb"] + v["write_size_kb"]) * 1024.0 for k, v in t["kernels"].items()}
+                    pmc_ms = {k: v.get("avg_ms") for k, v in t["kernels"].items()}
+                    traffic_src = {"file": "profiles/" + tf, "git_head": t.get("git_head")}
             except Exception:
                 traffic = {}
+
+        def traffic_of(kernel, live_ms):
+            """PMC traffic of a kernel, or None when the summary does not belong to this build: the kernel's average duration in the
+            profiled run (stamped into the summary by tools/pmc_traffic.py) must agree with the live one within 5 %."""
+            if kernel not in traffic:
+                return None
+            ref = pmc_ms.get(kernel)
+            if ref is None or not live_ms or abs(ref / live_ms - 1.0) > 0.05:
+                return None
+            return traffic[kernel]
+        # executed FP64 flops from the PMC pass of the same command (tools/pmc_lm.sh: SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)
+        pmc_flop = None
+        pl = os.path.join(ROOT, "profiles", "r03_pmc_lm_wave_time.json")
+        if os.path.exists(pl):
+            try:
+                pmc_flop = json.load(open(pl)).get(LM_KERNEL, {}).get("derived", {}).get("f64_flop")
+            except Exception:
+                pmc_flop = None
         # dominant kernel by time: the LM solve.  Algorithmic bytes (SURVEY 8(d)): per LM iteration 56 B per observation
         # (pixels 16 + ids 16 + landmark 24) + 96 B per edge pose, nothing written when J is fused into the H accumulation
         lm_ms, lm_calls = prof["lm_solve"]
@@ -556,21 +606,23 @@ def main():
                               "mean_iters": float(np.mean([r.iters for r in res]))},
             },
             "roofline": {"kernel": LM_KERNEL, "bound": "hbm", "achieved": lm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic.get(LM_KERNEL),
+                         "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic_of(LM_KERNEL, lm_avg_ms), "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
-                         "note": "dominant kernel by time; latency bound at 2 waves/SIMD (profiles/r02_pmc_sq.json: waves wait 58 % of their time), not bandwidth bound (DESIGN.md 5, 9)"},
+                         "note": "dominant kernel by time; not bandwidth bound: two persistent workgroups per CU, waves wait on LDS / FP64 dependencies "
+                                 "(profiles/r03_pmc_lm_wave_time.json, DESIGN.md 5); traffic is null when the committed PMC summary's kernel time differs from the live one by more than 5 %"},
             "roofline_fp64": {"kernel": LM_KERNEL, "bound": "mfma", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
-                              "note": "the same launch priced in FP64 flops (SURVEY 8(d) per-unit figures); FP64 MFMA rate = FP64 vector rate on MI355X, "
-                                      "the kernel issues vector FP64 (block-sparse 6x6 / 6x3 products, DESIGN.md 5)"},
+                              "executed_flops_per_launch_pmc": pmc_flop,
+                              "executed_frac_pmc": (pmc_flop / (lm_avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc_flop else None,
+                              "note": "the same launch priced in FP64 flops: `achieved` from SURVEY 8(d)'s per-unit figures (an upper estimate of the work: the node form "
+                                      "executes less), `executed_*_pmc` from the SQ_INSTS_VALU_*_F64 counters of the committed PMC pass; FP64 MFMA rate = FP64 vector rate on MI355X"},
             "roofline_scan": {"kernel": "fast_nms_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("fast_nms_kernel"),
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_of("fast_nms_kernel", fast_avg_ms),
                               "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_avg_ms},
             "roofline_describe": {"kernel": "describe_kernel", "bound": "hbm", "achieved": desc_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": desc_ach / HBM_PEAK_GBS, "traffic": traffic.get("describe_kernel"),
+                                  "frac": desc_ach / HBM_PEAK_GBS, "traffic": traffic_of("describe_kernel", desc_avg_ms),
                                   "algorithmic_bytes_per_launch": desc_algo, "avg_launch_ms": desc_avg_ms,
-                                  "note": "VALU-issue bound (profiles/r02_pmc_sq.json: every resident wave issues VALU 17 % of its time at ~5 waves per SIMD; "
-                                          "3 LDS bank-conflict cycles per LDS instruction in the transposed blur tiles); patches of neighbouring keypoints overlap in L2"},
+                                  "note": "VALU-issue bound (one wavefront per keypoint, ~700 vector instructions each); patches of neighbouring keypoints overlap in L2"},
             "stage_ms_per_launch": stages,
             "pcie_inclusive": pcie,
             "unbatched": unbatched,

@@ -470,6 +470,8 @@ int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b);
 /* Runs the LM loop of every window of the batch (one launch, asynchronous on the context stream). */
 int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* params);
 int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out /* n_windows */);
+/* Name of the kernel ssk_lm_batch_run launches for this batch (diagnostics: the profile summaries under profiles/ are keyed by it). */
+int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap);
 /* Current state of window w: edge_inv_pose [n_edges_total*12], lm_pos [n_lms_total*3]. */
 int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_inv_pose, double* lm_pos);
 /* Trace of window w: entries [max_iters]; delta_p [max_iters][6E], delta_f [max_iters][3L] (may be NULL). */

@@ -633,6 +633,11 @@ class LmBatch:
     def run(self, prm):
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_run(self.ctx.h, self.h_, C.byref(prm)))
 
+    def kernel_name(self):
+        buf = C.create_string_buffer(64)
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_kernel_name(self.ctx.h, self.h_, buf, 64))
+        return buf.value.decode()
+
     def set_export(self, on=True):
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_set_export(self.ctx.h, self.h_, int(bool(on))))
 
@@ -890,7 +895,7 @@ class Context:
         self._chk(self.lib.ssk_build_observations(self.h, _ptr(kl), _ptr(kr), _ptr(m), len(m), C.byref(lm_params), _ptr(px), _ptr(pos)))
         return px, pos
 
-    def stitch_shared(self, d_gathered, n_ranks, n_shared, d_pos, lam=0.0):
+    def stitch_shared(self, d_gathered, n_ranks, n_shared, d_pos, lam=1e-9):
         """d_pos [n_shared * 3] += (sum_r H_r + lam I)^-1 sum_r g_r over the gathered blocks, rank order."""
         self.lib.ssk_lm_stitch_shared.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
         self._chk(self.lib.ssk_lm_stitch_shared(self.h, _dev(d_gathered), int(n_ranks), int(n_shared), float(lam), _dev(d_pos)))

@@ -33,6 +33,7 @@ struct ssk_lm_batch {
 	// cooperative launch in flight: the state it started from (pose_bak / lm_bak) and its parameters, so that a launch whose
 	// workgroups were not all resident (stop_reason 5) is repeated with one workgroup per window by ssk_lm_batch_results
 	// node form (ssk_lm_node.hip): built when every window of the batch fits it (reduced system + a tile of node records in LDS)
+	bool gtab_multi = false;          // the per-workgroup suffix tables of the windows whose table lives in L2 scratch were sized for the cooperative kernel (64 copies)
 	bool node_ok = false;
 	nd_dev N{};
 	size_t node_dyn_bytes = 0;
@@ -200,6 +201,10 @@ __global__ void stitch_shared_kernel(const double* __restrict__ g, int n_ranks, 
 	const double a = A[0] + lambda, bb = A[1], c = A[2], d = A[3] + lambda, e = A[4], f = A[5] + lambda;
 	const double c00 = d * f - e * e, c01 = c * e - bb * f, c02 = bb * e - c * d;
 	const double det = a * c00 + bb * c01 + c * c02;
+	// a (near) singular block -- one far observation, depth barely observable, lambda 0 -- would put inf / NaN into the consensus position,
+	// from where it reaches the window's initial state too: such a landmark stays where it is this round
+	const double tr = a + d + f;
+	if (!(det > 1e-12 * tr * tr * tr)) return;
 	const double id = 1.0 / det;
 	const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = (a * f - c * c) * id, i12 = (bb * c - a * e) * id, i22 = (a * d - bb * bb) * id;
 	pos[3 * s] += i00 * b[0] + i01 * b[1] + i02 * b[2];
@@ -221,6 +226,8 @@ __global__ void set_shared_kernel(lm_dev D, double* __restrict__ lm0, int w, int
 
 extern "C" {
 
+static int lm_batch_settle(ssk_ctx* ctx, ssk_lm_batch* b);
+
 static lm_cam cam_of(const ssk_lm_params* p)
 {
 	lm_cam P{};
@@ -239,6 +246,7 @@ int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared,
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_pack_shared: bad argument");
 	if (n_shared == 0) return SSK_OK;
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	hipLaunchKernelGGL(pack_shared_kernel, dim3((n_shared + 63) / 64), dim3(64), 0, ctx->stream, b->D, cam_of(p), w, n_shared, d_lm_idx, d_out);
 	SSK_LAUNCH_CHECK(ctx, "pack_shared_kernel");
 	return SSK_OK;
@@ -351,7 +359,12 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		for (int e = 0; e < windows[w].n_edges_total && windows[w].edge_unknown_slot; ++e) if (windows[w].edge_unknown_slot[e] >= 0) ++E;
 		max_E = std::max(max_E, E);
 	}
-	const int schur_mfma = schur_env ? (std::strcmp(schur_env, "sparse") != 0) : (max_E > SSK_LMA_MAX_E);
+	// (a batch of many large windows runs one workgroup per window: there the sparse items win -- 91 ms against 130 ms per 1024 depth-5
+	// local areas of 40 edges, profiles/r03_lm_depth5.json; the matrix cores keep the few-large-windows case of the cooperative kernel)
+	const int schur_mfma_default = max_E > SSK_LMA_MAX_E && ctx && n_windows * 4 <= ctx->n_cu;
+	// the matrix-core form keeps a landmark's 16-row-tile set in a 32-bit mask: 6E + 15 <= 16 * 31, i.e. E <= 80
+	const bool mfma_fits = ssk_lma_row_tiles(max_E) <= 31;
+	const int schur_mfma = mfma_fits && (schur_env ? (std::strcmp(schur_env, "sparse") != 0) : schur_mfma_default);
 	const char* force_k = std::getenv("SSK_LM_KERNEL");
 	const bool force_acc = force_k && std::strcmp(force_k, "acc") == 0;
 	if (want_acc && windows && n_windows > 0) {            // cheap look ahead: one window with too many optimised edges rules the acc kernel out
@@ -1066,12 +1079,6 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (force_k && std::strcmp(force_k, "node") == 0 && !node_all)
 		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: SSK_LM_KERNEL=node, but a window of the batch does not fit the node kernel");
 	if (want_acc && !acc_all) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, with_general, false);
-	if (want_acc && !force_acc) {
-		// few windows of several tiles each: the cooperative slot kernel spreads a window over CUs, which beats one workgroup per window
-		int mt = 0;
-		for (const lm_win& hw : hdr) mt = std::max(mt, hw.n_tiles);
-		if (mt >= 4 && n_windows * 4 <= ctx->n_cu) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, with_general, false);
-	}
 	if (!tiled_all && !with_general) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, true, false);
 	const auto t_sym = std::chrono::steady_clock::now();
 	ssk_lm_batch* b = new ssk_lm_batch();
@@ -1096,6 +1103,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(qit, qit); UP(sgrp, sgrp); UP(sslot0, sslot0); UP(scl_off, scl_off); UP(scl_idx, scl_idx);
 	UP(wt_off, wt_off); UP(wt, wt); UP(tl_pan, tl_pan); UP(suf_rec, suf_rec); UP(tent, tent); UP(tsuf, tsuf); UP(mt, mt); UP(st_off, st_off); UP(ilane, ilane);
 #undef UP
+	b->gtab_multi = n_windows * 4 <= ctx->n_cu;
 	b->node_ok = node_all;
 	if (node_all) {
 #define UPN(vec, field) if (!rc) rc = upload(b, NH.vec, &b->N.field)
@@ -1180,11 +1188,32 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	return lm_batch_create_impl(ctx, windows, n_windows, trace, out, l2, want_acc);
 }
 
+// A cooperative launch whose workgroups did not all arrive at a barrier (stop_reason 5) leaves a half-updated state: whoever reads the
+// batch next -- results, state, trace, the shared-landmark pack, another run or a reset -- first goes back to the state the launch
+// started from and repeats the solve with one workgroup per window (no cross-workgroup barrier, same contract).
+static int lm_batch_settle(ssk_ctx* ctx, ssk_lm_batch* b)
+{
+	if (!b->coop_pending) return SSK_OK;
+	b->coop_pending = false;
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	std::vector<ssk_lm_result> r((size_t)b->n_windows);
+	SSK_HIP(ctx, hipMemcpy(r.data(), b->D.res, sizeof(ssk_lm_result) * r.size(), hipMemcpyDeviceToHost));
+	bool timed_out = false;
+	for (const ssk_lm_result& x : r) timed_out |= x.stop_reason == 5;
+	if (!timed_out || std::getenv("SSK_LM_COOP_NO_FALLBACK")) return SSK_OK;
+	static const bool verbose = std::getenv("SSK_LM_DEBUG") != nullptr;
+	if (verbose) std::fprintf(stderr, "[ssk lm] cooperative launch timed out at a barrier: repeating with one workgroup per window\n");
+	SSK_HIP(ctx, hipMemcpyAsync(b->D.pose, b->pose_bak, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
+	SSK_HIP(ctx, hipMemcpyAsync(b->D.lm, b->lm_bak, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
+	return ssk_lm_launch_tiled(ctx, b->D, b->coop_P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma, b->lds_sys);
+}
+
 int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_reset: batch is NULL");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	b->coop_pending = false;                          // (the state is overwritten: a timed-out launch needs no repair)
 	return ssk_lm_launch_reset(ctx, b->D.pose, b->D.pose0, b->n_pose, b->D.lm, b->D.lm0, b->n_lm);
 }
 
@@ -1207,7 +1236,7 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	const char* force = std::getenv("SSK_LM_KERNEL");
 	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
 	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
-	b->coop_pending = false;
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a run on top of a timed-out cooperative launch continues from the repaired state)
 	if (b->node_ok) return ssk_lm_launch_node(ctx, b->D, b->N, P, b->n_windows, b->node_dyn_bytes);
 	if (b->acc_ok) return ssk_lm_launch_acc(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
@@ -1219,7 +1248,8 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 		int gmax = 32;
 		if (const char* gcap = std::getenv("SSK_LM_COOP_G")) gmax = std::max(1, std::min(64, std::atoi(gcap)));
 		int G = std::min(std::min(b->max_tiles, gmax), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
-		const bool want = force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu);
+		// (windows whose suffix table lives in L2 scratch need one table per workgroup: sized for it only when the batch is small enough)
+		const bool want = b->gtab_multi && (force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu));
 		if (std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm] run: %d windows, max tiles %d, %d workgroups per CU -> %s, G %d, max 6E %d, Schur %s\n", b->n_windows, b->max_tiles, per_cu,
 		                                              want ? "cooperative" : "one workgroup per window", G, b->max_n6, b->schur_mfma ? "mfma" : "sparse");
 		if (want) {
@@ -1238,29 +1268,39 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	return ssk_lm_launch(ctx, b->D, P, b->n_windows, b->max_n6);
 }
 
+int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || !out || cap < 1) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_kernel_name: bad argument");
+	// the same decisions as ssk_lm_batch_run
+	const char* force = std::getenv("SSK_LM_KERNEL");
+	const char* name = "lm_solve_kernel";
+	if (b->node_ok) name = "lm_solve_node_kernel";
+	else if (b->acc_ok) name = b->schur_mfma ? "lm_solve_acc_mfma_kernel" : "lm_solve_acc_kernel";
+	else if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) {
+		bool coop = false;
+		if (!(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
+			const int per_cu = ssk_lm_coop_blocks_per_cu(ctx, b->tiled_dyn_bytes, b->schur_mfma);
+			int gmax = 32;
+			if (const char* gcap = std::getenv("SSK_LM_COOP_G")) gmax = std::max(1, std::min(64, std::atoi(gcap)));
+			const int G = std::min(std::min(b->max_tiles, gmax), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
+			coop = b->gtab_multi && (force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu));
+		}
+		if (coop) name = b->schur_mfma == 2 ? "lm_solve_coop_ldlm_kernel" : b->schur_mfma ? "lm_solve_coop_mfma_kernel" : "lm_solve_coop_kernel";
+		else name = b->schur_mfma == 2 ? "lm_solve_tiled_ldlm_kernel" : b->schur_mfma ? "lm_solve_tiled_mfma_kernel" : b->lds_sys ? "lm_solve_tiled_lds_kernel" : "lm_solve_tiled_kernel";
+	}
+	std::snprintf(out, (size_t)cap, "%s", name);
+	return SSK_OK;
+}
+
 int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_results: NULL argument");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	SSK_HIP(ctx, hipMemcpy(out, b->D.res, sizeof(ssk_lm_result) * (size_t)b->n_windows, hipMemcpyDeviceToHost));
-	bool timed_out = false;
-	for (int w = 0; w < b->n_windows; ++w) timed_out |= out[w].stop_reason == 5;
-	if (timed_out && b->coop_pending && !std::getenv("SSK_LM_COOP_NO_FALLBACK")) {
-		// a cooperative launch whose workgroups did not all arrive at a barrier: back to the state it started from and the same
-		// solve with one workgroup per window (no cross-workgroup barrier, same contract)
-		b->coop_pending = false;
-		static const bool verbose = std::getenv("SSK_LM_DEBUG") != nullptr;
-		if (verbose) std::fprintf(stderr, "[ssk lm] cooperative launch timed out at a barrier: repeating with one workgroup per window\n");
-		SSK_HIP(ctx, hipMemcpyAsync(b->D.pose, b->pose_bak, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
-		SSK_HIP(ctx, hipMemcpyAsync(b->D.lm, b->lm_bak, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
-		int rc = ssk_lm_launch_tiled(ctx, b->D, b->coop_P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma, b->lds_sys);
-		if (rc) return rc;
-		SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		SSK_HIP(ctx, hipMemcpy(out, b->D.res, sizeof(ssk_lm_result) * (size_t)b->n_windows, hipMemcpyDeviceToHost));
-		return SSK_OK;
-	}
 	b->coop_pending = false;
 	for (int w = 0; w < b->n_windows; ++w)
 		if (out[w].stop_reason == 5)
@@ -1274,6 +1314,7 @@ int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_in
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || w < 0 || w >= b->n_windows) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_state: bad argument");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	const lm_win& H = b->hdr[w];
 	if (edge_inv_pose && H.n_edges) SSK_HIP(ctx, hipMemcpy(edge_inv_pose, b->D.pose + 12 * (size_t)H.edge0, sizeof(double) * 12 * (size_t)H.n_edges, hipMemcpyDeviceToHost));
@@ -1288,6 +1329,7 @@ int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_en
 	if (!b || w < 0 || w >= b->n_windows || !entries || !n_entries) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_trace: bad argument");
 	if (!b->trace) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_trace: the batch was created without trace");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	ssk_lm_result r;
 	SSK_HIP(ctx, hipMemcpy(&r, b->D.res + w, sizeof r, hipMemcpyDeviceToHost));

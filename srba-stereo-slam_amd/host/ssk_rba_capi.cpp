@@ -94,11 +94,18 @@ int ssk_rba_localmap_centers(const ssk_rba* r, int kf, int32_t* out, int cap, in
 {
 	if (!r || !n || kf < 0 || kf >= ssk_rba_num_keyframes(r)) return SSK_ERR_BAD_ARG;
 	if (kf == 0 && ssk_rba_num_keyframes(r) == 1) { *n = 0; return SSK_OK; }      // (keyframe 0 gets its entry when keyframe 1 arrives, SRBA.h:153-158)
-	const std::set<ssk::TKeyFrameID>& c = r->rba->localmap_centers_of((size_t)kf);
-	*n = (int32_t)c.size();
-	if ((int)c.size() > cap) return SSK_ERR_CAPACITY;
-	int i = 0;
-	for (ssk::TKeyFrameID v : c) out[i++] = (int32_t)v;
+	// (a keyframe without an entry makes the map's at() throw: nothing may unwind across the C boundary)
+	try {
+		const std::set<ssk::TKeyFrameID>& c = r->rba->localmap_centers_of((size_t)kf);
+		*n = (int32_t)c.size();
+		if ((int)c.size() > cap) return SSK_ERR_CAPACITY;
+		if (!c.empty() && !out) return SSK_ERR_BAD_ARG;
+		int i = 0;
+		for (ssk::TKeyFrameID v : c) out[i++] = (int32_t)v;
+	} catch (const std::exception&) {
+		*n = 0;
+		return SSK_ERR_BAD_ARG;
+	}
 	return SSK_OK;
 }
 

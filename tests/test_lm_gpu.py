@@ -181,6 +181,37 @@ def test_lm_dense_solver_beyond_lds_sizes(ctx, oracle, n_kf, kernel, monkeypatch
     assert res.stop_reason != 5
 
 
+@pytest.mark.parametrize("kernel", ["tiled", "coop"])
+def test_lm_window_beyond_the_matrix_core_mask(ctx, oracle, kernel, monkeypatch):
+    """E = 90 optimised edges: 6E / 16 = 34 row tiles of the reduced system, more than the 32-bit tile mask of the matrix-core Schur form holds --
+    the library must fall back to the sparse form there (and say which kernel it runs), with the usual per-iteration bar."""
+    from ssk_amd import capi
+    monkeypatch.setenv("SSK_LM_KERNEL", kernel)
+    win, gt = sl.make_submap_problem(23, n_kf=91, n_lm=1500, submap_size=3, max_tree_depth=6, opt_depth=90, obs_per_kf=40)
+    assert win.E == 90
+    b = capi.LmBatch(ctx, [win])
+    assert "mfma" not in b.kernel_name() and b.kernel_name().startswith("lm_solve_" + kernel)
+    b.close()
+    res = check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=5))
+    assert res.stop_reason != 5
+
+
+def test_lm_kernel_name_follows_the_batch(ctx, monkeypatch):
+    """ssk_lm_batch_kernel_name: the node form for windows whose reduced system fits LDS, the tiled / cooperative kernels beyond, the forced ones."""
+    from ssk_amd import capi
+    small = sl.make_submap_problem(1, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)[0]
+    large = sl.make_submap_problem(21, n_kf=45, n_lm=900, submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)[0]
+    for wins, env, expect in (([small], None, "lm_solve_node_kernel"), ([small], "tiled", "lm_solve_tiled"), ([large], None, "lm_solve_coop"),
+                              ([large] * 128, None, "lm_solve_tiled_kernel"), ([small], "l2", "lm_solve_kernel")):
+        if env:
+            monkeypatch.setenv("SSK_LM_KERNEL", env)
+        else:
+            monkeypatch.delenv("SSK_LM_KERNEL", raising=False)
+        b = capi.LmBatch(ctx, wins)
+        assert b.kernel_name().startswith(expect), (env, b.kernel_name())
+        b.close()
+
+
 def run_plain(ctx, wins, prm):
     """No trace: (results, [(poses, lms)]) of a batch."""
     from ssk_amd import capi

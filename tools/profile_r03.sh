@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-3 profile artefacts (run on the GPU box from the repo root: SSK_GIT_HEAD=<head> bash tools/profile_r03.sh), summarised into profiles/:
+#   r03_kernel_stats_bench_b1024.csv   rocprofv3 --kernel-trace --stats of the default bench command (per-kernel time)
+#   r03_pmc_traffic.json               separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/pmc_traffic.py), stamped with the kernels'
+#                                      average duration in the un-counted stats pass and the git head
+#   r03_pmc_sq.json                    one --pmc pass of SQ counters: VALU / LDS activity of every kernel (tools/pmc_sq.py)
+#   r03_pmc_lm_wave_time.json          where the LM kernel's wave time goes (tools/pmc_lm.sh: four --pmc passes)
+set -u
+export TMPDIR=/tmp
+ROOTD=$PWD
+OUT=$ROOTD/gpurun_out/r03prof
+rm -rf $OUT; mkdir -p $OUT
+B="--steps 10 --warmup 2 --cpu-sample 0 --cpu-procs 0 --pcie-steps 0 --unbatched-frames 0 --lm-depth5 0"
+BS="--steps 3 --warmup 1 --cpu-sample 0 --cpu-procs 0 --pcie-steps 0 --unbatched-frames 0 --lm-depth5 0"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $ROOTD/bench.py $B > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $ROOTD/bench.py $BS > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $ROOTD/bench.py $BS > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -o q -- python3 $ROOTD/bench.py $BS > $OUT/sq.log 2>&1
+cd $ROOTD
+python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/r03_pmc_traffic.json $OUT/stats
+python3 tools/pmc_sq.py $OUT/pmc_sq $OUT/r03_pmc_sq.json > /dev/null 2>&1 || true
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/r03_kernel_stats_bench_b1024.csv
+tail -1 $OUT/stats.log | cut -c1-400
+bash tools/pmc_lm.sh r03 > $OUT/pmc_lm.log 2>&1
+cp gpurun_out/pmc_lm_r03/summary.json $OUT/r03_pmc_lm_wave_time.json
+ls -la $OUT/*.json $OUT/*.csv
