@@ -58,14 +58,16 @@ def _synth_pair(seed):
 
 def build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=64, n_lm_distinct=64, shared=None):
     """B keyframes + B 'previous' keyframes resident in HBM, B LM windows uploaded."""
-    import multiprocessing as mp
+    from multiprocessing.pool import ThreadPool
     import torch
     import synth_lm as sl
     cur = capi.KfBatch(ctx, B, W, H, 512)
     prev = capi.KfBatch(ctx, B, W, H, 512)
     n_base = min(n_base, B)
-    # the distinct base pairs are rendered on the host cores side by side (~2 s each on one core)
-    with mp.get_context("spawn").Pool(max(1, min(16, os.cpu_count() or 1, n_base))) as pool:
+    # the distinct base pairs are rendered on the host cores side by side (~2 s each on one core; numpy / scipy release the interpreter
+    # lock).  THREADS, not processes: under rocprofv3 the process has initialised the GPU before main() runs, and a fork / exec from
+    # such a process is what the GPU boxes of this pool refuse (a spawn pool hung a profiled run for 40 minutes)
+    with ThreadPool(max(1, min(16, os.cpu_count() or 1, n_base))) as pool:
         pairs_lr = pool.map(_synth_pair, [1000 * rank + i for i in range(n_base)])
     for i, (l, r) in enumerate(pairs_lr):
         cur.upload(i, l, r)
