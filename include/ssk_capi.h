@@ -281,6 +281,12 @@ typedef struct ssk_kf_out {
 /* BRIEF sampling pattern: 256 tests x (x0,y0,x1,y1) int8, |v| <= 13.  Default: include/ssk_brief_pattern.h. */
 int ssk_set_brief_pattern(ssk_ctx* ctx, const int8_t* pattern1024);
 int ssk_get_brief_pattern(ssk_ctx* ctx, int8_t* pattern1024);
+/* A context starts with the pattern in the 1024-byte file named by the environment variable SSK_BRIEF_PATTERN_FILE when it is set (e.g.
+ * OpenCV's learned bit_pattern_31_, which this repository cannot ship: needed for descriptors that match a DBoW2 vocabulary trained on
+ * cv::ORB); a file that cannot be read, is short or holds a coordinate beyond +-13 fails ssk_create. */
+/* Steering of the BRIEF tests (front-end contract C7): 1 (default) = as cv::ORB -- (float)cos / (float)sin of the fastAtan2 angle times
+ * (float)(CV_PI/180.f), include/ssk_sincos.h; 0 = the exact direction of the intensity centroid (the form of rounds 1-2). */
+int ssk_set_orb_steering(ssk_ctx* ctx, int mode);
 
 /* Host drop-in, one stereo pair (8-bit gray, `stride` bytes between rows):
  * detect + describe both images, match L<->R, fill `out`.  Does NOT throw on few matches: the

@@ -18,8 +18,10 @@
  *       (OpenCV's nth_element order / keep-all-ties is implementation defined; the total order is not).
  *   C6  orientation: intensity centroid over the radius-15 disc (u_max table), integer moments;
  *       KeyPoint.angle = the degree polynomial of OpenCV 2.4 fastAtan2 in IEEE float, no contraction.
- *   C7  steering uses (cos,sin) = (m10,m01)/sqrt(m10^2+m01^2) evaluated in double and rounded to float
- *       -- the exact direction of the centroid -- not libm cos/sin of the polynomial angle, so the result
+ *   C7  steering (default, mode 1): as cv::ORB -- the fastAtan2 degree angle times (float)(CV_PI/180.f), then (float)cos / (float)sin of
+ *       that float, evaluated by the shared include/ssk_sincos.h (equal to the host libm's double cos / sin rounded to float for every
+ *       float angle in [0, 360]: tools/sincos_check.c).  Mode 0 (rounds 1-2): (cos,sin) = (m10,m01)/sqrt(m10^2+m01^2) in double
+ *       -- the exact direction of the centroid -- not cos/sin of the polynomial angle, so the result
  *       needs only correctly-rounded IEEE sqrt/div (bit-reproducible on CPU and GPU).
  *   C8  7x7 sigma=2 Gaussian blur in 8.8 fixed point, taps {18,34,49,55,49,34,18}, result
  *       min(255,(sum + 2^15) >> 16); samples never reach the image border (C4), so no border rule.
@@ -30,6 +32,7 @@
  *       matches are emitted in left-keypoint order; 1-to-1 is not enforced (KITTI.ini:18).
  */
 #include "ssk_oracle.h"
+#include "../include/ssk_sincos.h"
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -189,6 +192,9 @@ static int blur_at(const uint8_t* img, int stride, int x, int y)
 	return v > 255 ? 255 : v;
 }
 
+static int g_orb_steering = 1;          /* C7: 1 = cv::ORB's (float)cos / (float)sin of the fastAtan2 angle, 0 = exact centroid direction */
+void ssko_set_orb_steering(int mode) { g_orb_steering = mode ? 1 : 0; }
+
 /* C6/C7/C9 for one keypoint: angle (deg), descriptor (32 B). */
 void ssko_orient_describe(const uint8_t* img, int stride, int x, int y, const int8_t* pattern,
                           float* angle_deg, uint8_t* desc)
@@ -203,7 +209,8 @@ void ssko_orient_describe(const uint8_t* img, int stride, int x, int y, const in
 	}
 	*angle_deg = ssko_atan2_deg((float)m01, (float)m10);
 	float ca = 1.f, sa = 0.f;
-	if (m01 != 0 || m10 != 0) {
+	if (g_orb_steering) ssk_orb_sincos_deg(*angle_deg, &ca, &sa);
+	else if (m01 != 0 || m10 != 0) {
 		const double dx = (double)m10, dy = (double)m01;
 		const double r = sqrt(dx * dx + dy * dy);
 		ca = (float)(dx / r);

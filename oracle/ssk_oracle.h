@@ -91,6 +91,8 @@ void ssko_fast_score_map(const uint8_t* img, int w, int h, int stride, int thres
 int ssko_fast_candidates(const uint8_t* img, int w, int h, int stride, int threshold, uint32_t* keys, int cap);
 float ssko_harris_response(const uint8_t* img, int stride, int x, int y, float harris_k);
 float ssko_atan2_deg(float y, float x);
+/* C7 steering of the descriptors: 1 (default) = cv::ORB's cos / sin of the angle (include/ssk_sincos.h), 0 = exact centroid direction */
+void ssko_set_orb_steering(int mode);
 void ssko_orient_describe(const uint8_t* img, int stride, int x, int y, const int8_t* pattern,
                           float* angle_deg, uint8_t* desc32);
 int ssko_orb_detect(const uint8_t* img, int w, int h, int stride, const ssk_frontend_params* prm,

@@ -781,6 +781,10 @@ class Context:
         p = np.ascontiguousarray(pattern, np.int8).reshape(1024)
         self._chk(self.lib.ssk_set_brief_pattern(self.h, _ptr(p)))
 
+    def set_orb_steering(self, mode):
+        """C7: 1 (default) = cv::ORB's cos / sin of the fastAtan2 angle (include/ssk_sincos.h), 0 = exact centroid direction."""
+        self._chk(self.lib.ssk_set_orb_steering(self.h, int(mode)))
+
     def get_brief_pattern(self):
         p = np.zeros(1024, np.int8)
         self._chk(self.lib.ssk_get_brief_pattern(self.h, _ptr(p)))

@@ -97,6 +97,14 @@ int ssk_set_brief_pattern(ssk_ctx* ctx, const int8_t* pattern1024)
 	return SSK_OK;
 }
 
+int ssk_set_orb_steering(ssk_ctx* ctx, int mode)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (mode != 0 && mode != 1) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_set_orb_steering: mode %d (0 = centroid direction, 1 = cv::ORB)", mode);
+	ctx->orb_steering = mode;
+	return SSK_OK;
+}
+
 int ssk_get_brief_pattern(ssk_ctx* ctx, int8_t* pattern1024)
 {
 	if (!ctx || !pattern1024) return SSK_ERR_BAD_ARG;

@@ -1,5 +1,6 @@
 // ssk_context.hip -- context, error text, arenas, stream + HIP-event timer of libssk_hip.so.
 #include "ssk_internal.h"
+#include <cstdlib>
 #include <cmath>
 #include "../../include/ssk_brief_pattern.h"
 
@@ -126,6 +127,21 @@ int ssk_create(ssk_ctx** out, int device, void* hip_stream)
 	CREATE_HIP(hipMalloc((void**)&ctx->d_dir_thresh, sizeof ctx->dir_thresh));
 	CREATE_HIP(hipMemcpy(ctx->d_dir_thresh, ctx->dir_thresh, sizeof ctx->dir_thresh, hipMemcpyHostToDevice));
 	std::memcpy(ctx->pattern, ssk_default_brief_pattern, sizeof ctx->pattern);
+	if (const char* pf = std::getenv("SSK_BRIEF_PATTERN_FILE")) {
+		// an external 256 x (x0, y0, x1, y1) int8 table, e.g. OpenCV's bit_pattern_31_ (DBoW2 vocabularies are trained on it)
+		std::FILE* f = std::fopen(pf, "rb");
+		int8_t buf[1024];
+		const size_t got = f ? std::fread(buf, 1, sizeof buf, f) : 0;
+		if (f) std::fclose(f);
+		bool ok = got == sizeof buf;
+		for (size_t i = 0; ok && i < sizeof buf; ++i) ok = buf[i] >= -13 && buf[i] <= 13;
+		if (!ok) {
+			const int rc = ssk_set_error(nullptr, SSK_ERR_BAD_ARG, "ssk_create: SSK_BRIEF_PATTERN_FILE=%s is not a readable 1024-byte table of coordinates within +-13", pf);
+			ssk_destroy(ctx);
+			return rc;
+		}
+		std::memcpy(ctx->pattern, buf, sizeof buf);
+	}
 	CREATE_HIP(hipMalloc((void**)&ctx->d_pattern, sizeof ctx->pattern));
 	CREATE_HIP(hipMemcpy(ctx->d_pattern, ctx->pattern, sizeof ctx->pattern, hipMemcpyHostToDevice));
 #undef CREATE_HIP

@@ -6,7 +6,7 @@
 //   * the 45x45 raw patch (radius 19 of rotated samples + 3 of blur support) is staged in LDS once with
 //     ALIGNED dword loads (12 per row; the image is L2/MALL resident after the scan kernel);
 //   * moments m10/m01 over the radius-15 disc: lanes own patch rows, wave shuffle reduction, integers;
-//   * angle = degree polynomial in IEEE float; steering (cos,sin) = (m10,m01)/hypot in double;
+//   * angle = degree polynomial in IEEE float; steering (cos,sin) = cv::ORB's (float)cos / (float)sin of that angle (ssk_sincos.h);
 //   * the 8.8 fixed-point 7x7 blur is done ONCE per patch and separably inside LDS, on packed data: the horizontal
 //     pass reads 6 dwords per 13-output row segment and forms each output with two v_dot4_u32_u8 (taps packed in
 //     a constant), the vertical pass reads 10 dwords of the transposed u16 tile and uses four v_dot2_u32_u16 per
@@ -16,6 +16,7 @@
 //     one descriptor byte each.
 // Data: 2 KB patch read per keypoint, 32 B + 4 B written.  LDS/VALU bound.
 #include "ssk_frontend.h"
+#include "../../include/ssk_sincos.h"
 
 namespace {
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ float atan2_deg(float y, float x)
 __global__ __launch_bounds__(64)
 void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int img_begin, int max_feats,
                      const short2* __restrict__ kp_xy, const int32_t* __restrict__ nkp,
-                     const int8_t* __restrict__ pattern, float* __restrict__ kp_angle, uint8_t* __restrict__ desc)
+                     const int8_t* __restrict__ pattern, int steering, float* __restrict__ kp_angle, uint8_t* __restrict__ desc)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_raw[PD * PP + 16];   // + slack: the dword window of the last segment may run 1 dword past a row
 	__shared__ __attribute__((aligned(16))) uint16_t s_h[BD * HT + 8];     // horizontal pass, transposed: [column 3..41][row 0..44]
@@ -173,14 +174,18 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 		}
 	}
 
+	// C7 steering: cv::ORB's (float)cos / (float)sin of the degree angle (shared with the oracle: include/ssk_sincos.h), or (steering 0,
+	// rounds 1-2) the exact direction of the centroid
+	const float ang = atan2_deg((float)m01, (float)m10);
 	float ca = 1.f, sa = 0.f;
-	if (m01 != 0 || m10 != 0) {
+	if (steering) ssk_orb_sincos_deg(ang, &ca, &sa);
+	else if (m01 != 0 || m10 != 0) {
 		const double dx = (double)m10, dy = (double)m01;
 		const double r = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
 		ca = (float)(dx / r);
 		sa = (float)(dy / r);
 	}
-	if (lane == 0) kp_angle[(size_t)img * max_feats + k] = atan2_deg((float)m01, (float)m10);
+	if (lane == 0) kp_angle[(size_t)img * max_feats + k] = ang;
 	__syncthreads();
 
 	// lane L evaluates tests 4L..4L+3  (bits (4L..4L+3)&7 of byte L/2); blurred(px,py) = s_b[(px-3)*BT + py-3]
@@ -214,7 +219,7 @@ int ssk_launch_describe(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end
 	if (nimg <= 0 || n_feats <= 0) return SSK_OK;
 	ssk_stage_scope prof(ctx, SSK_STAGE_DESCRIBE);
 	hipLaunchKernelGGL(describe_kernel, dim3(n_feats, nimg), dim3(64), 0, ctx->stream, b->img, b->h, b->pitch,
-	                   img_begin, b->max_feats, b->kp_xy, b->nkp, ctx->d_pattern, b->kp_angle, b->desc);
+	                   img_begin, b->max_feats, b->kp_xy, b->nkp, ctx->d_pattern, ctx->orb_steering, b->kp_angle, b->desc);
 	SSK_LAUNCH_CHECK(ctx, "describe_kernel");
 	return SSK_OK;
 }

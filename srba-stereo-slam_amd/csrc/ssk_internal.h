@@ -32,6 +32,7 @@ struct ssk_ctx {
 	float* d_dir_thresh = nullptr;
 	int8_t pattern[1024];              // BRIEF sampling pattern (default: include/ssk_brief_pattern.h)
 	int8_t* d_pattern = nullptr;
+	int orb_steering = 1;              // C7: 1 = cv::ORB's (float)cos / (float)sin of the fastAtan2 angle (include/ssk_sincos.h), 0 = exact centroid direction
 	struct ssk_kfbatch* single = nullptr;   // 1-keyframe batch behind the host drop-in ssk_frontend_run
 	void* lm_slab = nullptr;                // device slab of the last destroyed LM batch, reused by the next one (the host
 	size_t lm_slab_bytes = 0;               // drop-in creates and destroys a batch per keyframe: no hipMalloc in steady state)

@@ -180,6 +180,10 @@ class Oracle:
         n = self.lib.ssko_fast_candidates(_p(img), w, h, w, int(threshold), _p(keys), len(keys))
         return keys[:n].copy()
 
+    def set_orb_steering(self, mode):
+        """C7 of the front-end contract: 1 (default) = cv::ORB's cos / sin of the angle, 0 = exact centroid direction (rounds 1-2)."""
+        self.lib.ssko_set_orb_steering(int(mode))
+
     def orb_detect(self, img, prm, pattern):
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape

@@ -116,6 +116,38 @@ def test_custom_brief_pattern(ctx, oracle, pkg):
         ctx.set_brief_pattern(old)
 
 
+def test_steering_modes_and_external_pattern_file(ctx, oracle, pkg, tmp_path, monkeypatch):
+    """C7: the default steering is cv::ORB's -- (float)cos / (float)sin of the fastAtan2 angle through include/ssk_sincos.h, the same
+    function on both sides -- and the centroid-direction form of rounds 1-2 stays selectable; the two give different descriptors.  A
+    context created with SSK_BRIEF_PATTERN_FILE set starts from that 1024-byte table (the way a third party drops in OpenCV's
+    bit_pattern_31_); a bad file fails the creation."""
+    left, right = synth.synth_stereo_pair(12)
+    cp, op = params(pkg, n_feats=200)
+    new = ctx.frontend_run(left, right, cp)
+    assert_kf_equal(new, oracle.frontend(left, right, op, ol.default_pattern()))
+    ctx.set_orb_steering(0); oracle.set_orb_steering(0)
+    try:
+        old = ctx.frontend_run(left, right, cp)
+        assert_kf_equal(old, oracle.frontend(left, right, op, ol.default_pattern()))
+    finally:
+        ctx.set_orb_steering(1); oracle.set_orb_steering(1)
+    assert np.array_equal(old["kp_left"]["angle"], new["kp_left"]["angle"]) and not np.array_equal(old["desc_left"], new["desc_left"])
+    pat = np.random.default_rng(78).integers(-13, 14, 1024).astype(np.int8)
+    f = tmp_path / "pattern.bin"
+    f.write_bytes(pat.tobytes())
+    monkeypatch.setenv("SSK_BRIEF_PATTERN_FILE", str(f))
+    c2 = pkg.Context(0)
+    try:
+        assert np.array_equal(c2.get_brief_pattern(), pat)
+        assert_kf_equal(c2.frontend_run(left, right, cp), oracle.frontend(left, right, op, pat))
+    finally:
+        c2.close()
+    (tmp_path / "short.bin").write_bytes(pat.tobytes()[:1000])
+    monkeypatch.setenv("SSK_BRIEF_PATTERN_FILE", str(tmp_path / "short.bin"))
+    with pytest.raises(Exception):
+        pkg.Context(0)
+
+
 def test_batch_equals_single_and_da_batch(ctx, oracle, pkg):
     """A batch of keyframes gives, per keyframe, exactly the single-keyframe result; batched DA on the
     HBM-resident features equals the oracle's data association on the downloaded keyframes."""
