@@ -127,6 +127,7 @@ int ssk_create(ssk_ctx** out, int device, void* hip_stream)
 	CREATE_HIP(hipMalloc((void**)&ctx->d_dir_thresh, sizeof ctx->dir_thresh));
 	CREATE_HIP(hipMemcpy(ctx->d_dir_thresh, ctx->dir_thresh, sizeof ctx->dir_thresh, hipMemcpyHostToDevice));
 	std::memcpy(ctx->pattern, ssk_default_brief_pattern, sizeof ctx->pattern);
+	if (const char* sm = std::getenv("SSK_ORB_STEERING")) ctx->orb_steering = std::atoi(sm) ? 1 : 0;      // (0: the centroid-direction steering of rounds 1-2)
 	if (const char* pf = std::getenv("SSK_BRIEF_PATTERN_FILE")) {
 		// an external 256 x (x0, y0, x1, y1) int8 table, e.g. OpenCV's bit_pattern_31_ (DBoW2 vocabularies are trained on it)
 		std::FILE* f = std::fopen(pf, "rb");

@@ -330,11 +330,17 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 	}
 	// stage 2: optimize_local_area(root = new KF, depth = max_optimize_depth)
 	{
+		// (the device solver's reduced system holds 128 edges, include/ssk_capi.h: a local area beyond that -- a revisit that ties several
+		// old local maps to the new one within the depth -- is optimised to the largest depth that fits.  SRBA has no such limit.)
 		std::map<TKeyFrameID, step_t> area;
-		bfs(new_kf_id, parameters.max_optimize_depth, area);
 		std::set<size_t> opt;
-		for (size_t e = 0; e < m_state.k2k_edges.size(); ++e)
-			if (area.count(m_state.k2k_edges[e].from) && area.count(m_state.k2k_edges[e].to)) opt.insert(e);
+		for (size_t depth = parameters.max_optimize_depth; ; --depth) {
+			area.clear(); opt.clear();
+			bfs(new_kf_id, depth, area);
+			for (size_t e = 0; e < m_state.k2k_edges.size(); ++e)
+				if (area.count(m_state.k2k_edges[e].from) && area.count(m_state.k2k_edges[e].to)) opt.insert(e);
+			if (opt.size() <= 128 || depth <= 1) break;
+		}
 		std::vector<std::pair<TKeyFrameID, size_t>> refs;
 		for (const auto& kv : area)
 			for (size_t i = 0; i < m_state.kf_observations[kv.first].size(); ++i) refs.push_back(std::make_pair(kv.first, i));

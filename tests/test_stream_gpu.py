@@ -53,7 +53,10 @@ def test_every_frame_a_keyframe_and_loop_closure(pkg, ctx, tmp_path):
     assert os.path.exists(DEMO), "host facade not built: python __graft_entry__.py build"
     n = 44
     frames, _ = synth.synth_translation_sequence(5, n, z_max=12.0, step=4)
-    again, _ = synth.synth_translation_sequence(5, n, z_max=12.0, step=4, noise=4.0)     # the same places under other sensor noise
+    # the same places under other (stronger) sensor noise.  (sigma 2: at sigma 4 the scores of the keyframes around the revisited place
+    # tie within 0.003 -- 0.5095 / 0.5067 -- and a one-bit change of a few descriptors decides whether the potential loop closure is the
+    # neighbouring place, confirmed by its tracked features, or one two places away, which shares too little to be confirmed)
+    again, _ = synth.synth_translation_sequence(5, n, z_max=12.0, step=4, noise=2.0)
     seq = frames + [again[2], again[3], again[4]]
     rows, out = run_stream(ctx, tmp_path, seq, dict(max_translation=0.3, submap_size=4, max_tree_depth=3, max_optimize_depth=3, lc_distance=3),
                            train_on=frames[::4])
