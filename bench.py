@@ -371,6 +371,28 @@ def main():
         for k, v in c.profile_read().items():
             prof[k] = (prof[k][0] + v[0], prof[k][1] + v[1]) if k in prof else v
         c.profile_enable(False)
+    # ---- configs[4]: how many exchange rounds the joint problem needs from here (after the timed steps; N > 1 or SSK_BENCH_EXCHANGE_ALWAYS):
+    # Anderson-mixed rounds (pkg.dist.SharedLandmarkAccelerator: the same host arithmetic on every rank) until the consensus positions
+    # move by less than 1e-6 m; plain rounds converge linearly (factor ~0.7) and need about three times as many
+    exchange_rounds = None
+    if exchange:
+        acc = pkg.dist.SharedLandmarkAccelerator(m=5)
+        for rnd in range(40):
+            lm.run(lp)
+            lm.pack_shared(0, d_shared_idx, lp, shared)
+            pkg.dist.exchange_shared(shared, gathered, stream=ctx_lm.stream())
+            x = shared_pos.cpu().numpy().copy()
+            ctx_lm.stitch_shared(gathered, world, S, shared_pos)
+            ctx_lm.synchronize()
+            nxt = acc.step(x, shared_pos.cpu().numpy())
+            shared_pos.copy_(torch.from_numpy(nxt))
+            lm.set_shared(0, d_shared_idx, shared_pos)
+            if float(np.abs(nxt - x).max()) < 1e-6:
+                exchange_rounds = rnd + 1
+                break
+        sync_all()
+        lm.reset()
+        lm.run(lp)
     res = lm.results()
     # a number from a run whose solves did not end properly is not a number: every window must have stopped for a contract reason
     # (1 rmse, 2 lambda, 3 nothing to optimise, 4 converged, 0 iteration limit) below its initial error
@@ -603,6 +625,7 @@ def main():
                 "mean_keypoints_per_image": float(nkp.mean()),
                 "mean_stereo_matches": float(nm.mean()),
                 "mean_tracked_vs_prev": float(tracked.mean()),
+                "exchange_rounds_to_1e-6": exchange_rounds,
                 "lm_distinct_windows": len(wins),
                 "lm_window": {"edges": int(wins[0].E), "landmarks": int(wins[0].L), "observations": int(len(wins[0].obs_lm)),
                               "mean_iters": float(np.mean([r.iters for r in res]))},

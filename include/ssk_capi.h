@@ -499,6 +499,10 @@ int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_en
  * solution a single process would compute for their union (tests/test_shared_gpu.py, tests/test_dist_cpu.py). */
 int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, const int32_t* d_lm_idx, const ssk_lm_params* p, double* d_out);
 int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, int n_shared, double lambda, double* d_pos);
+/* exchange: the all-gather itself for callers that hold an RCCL communicator (ncclComm_t, passed as void*) instead of torch.distributed:
+ *          ncclAllGather of this rank's n_shared x 12 doubles (d_shared, from pack) into d_gathered ([n_ranks][n_shared][12]) on the context's
+ *          stream -- behind the pack kernel, ahead of the stitch kernel, no host synchronisation.  RCCL is resolved at run time (dlopen). */
+int ssk_lm_exchange_shared(ssk_ctx* ctx, void* nccl_comm, const double* d_shared, double* d_gathered, int n_shared);
 int ssk_lm_batch_set_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, const int32_t* d_lm_idx, const double* d_pos);
 /* The blocks H_ff / g_f of the landmarks a window DOES optimise stay on chip; on != 0 before ssk_lm_batch_run leaves those of the last
  * linearisation in HBM (diagnostics). */

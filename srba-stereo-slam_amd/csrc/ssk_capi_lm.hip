@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <dlfcn.h>
 
 struct ssk_lm_batch {
 	ssk_ctx* ctx = nullptr;
@@ -281,6 +282,30 @@ int ssk_lm_stitch_shared(ssk_ctx* ctx, const double* d_gathered, int n_ranks, in
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	hipLaunchKernelGGL(stitch_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, d_gathered, n_ranks, n_shared, lambda, d_pos);
 	SSK_LAUNCH_CHECK(ctx, "stitch_shared_kernel");
+	return SSK_OK;
+}
+
+// The ONE collective of the path for callers without torch.distributed -- the C++ facade of a multi-GPU deployment:
+// ncclAllGather (RCCL) of every rank's packed blocks on the context's stream, behind the pack kernel and ahead of the stitch kernel.
+// RCCL is looked up at run time (dlopen: the copy the process already holds -- PyTorch ships one -- or librccl.so.1 of the ROCm
+// installation), so libssk_hip.so carries no link-time dependency on it and a process never ends up with two RCCL instances.
+int ssk_lm_exchange_shared(ssk_ctx* ctx, void* nccl_comm, const double* d_shared, double* d_gathered, int n_shared)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!nccl_comm || n_shared < 0 || (n_shared > 0 && (!d_shared || !d_gathered)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_exchange_shared: bad argument");
+	if (n_shared == 0) return SSK_OK;
+	typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+	static allgather_fn fn = [] {
+		void* h = nullptr;
+		for (const char* name : {"librccl.so", "librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break;      // already in the process?
+		if (!h) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+		return h ? reinterpret_cast<allgather_fn>(dlsym(h, "ncclAllGather")) : nullptr;
+	}();
+	if (!fn) return ssk_set_error(ctx, SSK_ERR_HIP, "ssk_lm_exchange_shared: RCCL (librccl.so) is not available: %s", dlerror());
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	const int rc = fn(d_shared, d_gathered, (size_t)12 * (size_t)n_shared, 8 /* ncclFloat64 */, nccl_comm, ctx->stream);
+	if (rc != 0) return ssk_set_error(ctx, SSK_ERR_HIP, "ssk_lm_exchange_shared: ncclAllGather failed (ncclResult_t %d)", rc);
 	return SSK_OK;
 }
 

@@ -43,3 +43,42 @@ def exchange_shared(shared, gathered, stream=None):
     else:
         dist.all_gather_into_tensor(gathered, shared)
     return gathered
+
+
+class SharedLandmarkAccelerator:
+    """Anderson acceleration of the exchange rounds (BASELINE configs[4]).
+
+    One round is a fixed-point map x -> G(x) on the consensus positions x of the shared landmarks: every rank solves its window with
+    the shared landmarks held at x, the blocks are gathered, G(x) = x + (sum H)^-1 sum g.  Plain iteration x <- G(x) is block-coordinate
+    descent on the joint problem: linear convergence (factor ~0.7 per round on the test problems, 70 rounds to 1e-6).  Anderson mixing
+    over the last `m` rounds -- x_next = G(x_k) - dG gamma, gamma = argmin |f_k - dF gamma|, f = G(x) - x -- reaches the same fixed point
+    (the joint optimum) in a fraction of the rounds.  Host arithmetic on 3 n_shared doubles in float64, the same on every rank (every
+    rank holds the same gathered blocks), so the consensus stays bit-identical across ranks.
+
+    usage per round:  x_next = acc.step(x, gx)   with x the positions the round started from and gx the stitched positions G(x)."""
+
+    def __init__(self, m=5, restart_ratio=4.0):
+        self.m, self.restart_ratio = int(m), float(restart_ratio)
+        self.X, self.GX = [], []
+
+    def reset(self):
+        self.X, self.GX = [], []
+
+    def step(self, x, gx):
+        import numpy as np
+        x = np.asarray(x, np.float64).reshape(-1)
+        gx = np.asarray(gx, np.float64).reshape(-1)
+        f = gx - x
+        # a residual that grew by a large factor: the history no longer describes the map near here (an LM solve took another branch)
+        if self.X and np.linalg.norm(f) > self.restart_ratio * np.linalg.norm(self.GX[-1] - self.X[-1]):
+            self.reset()
+        self.X.append(x.copy()); self.GX.append(gx.copy())
+        if len(self.X) > self.m + 1:
+            self.X.pop(0); self.GX.pop(0)
+        if len(self.X) < 2:
+            return gx.copy()
+        F = [g - y for g, y in zip(self.GX, self.X)]
+        dF = np.stack([F[i + 1] - F[i] for i in range(len(F) - 1)], 1)
+        dG = np.stack([self.GX[i + 1] - self.GX[i] for i in range(len(F) - 1)], 1)
+        gamma, *_ = np.linalg.lstsq(dF, f, rcond=1e-10)
+        return gx - dG @ gamma

@@ -19,7 +19,7 @@ N_SHARED, ROUNDS = 24, 70
 KW = dict(n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60, opt_depth=2)
 
 
-def worker(rank, world, port, q):
+def worker(rank, world, port, q, rounds=ROUNDS, accelerate=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -38,7 +38,8 @@ def worker(rank, world, port, q):
     prm = sl.make_params(max_iters=50, conv=1e-14)
     pos = sh["init"].copy()
     errs, first = [], None
-    for rnd in range(ROUNDS):
+    acc = d.SharedLandmarkAccelerator(m=5) if accelerate else None
+    for rnd in range(rounds):
         win.lm_pos[idx[idx >= 0]] = pos[idx >= 0]
         out = oracle.lm_solve(win, prm, trace=False)
         win = sl.Window(win.edge_unknown_slot, out["poses"], win.lm_unknown_slot, out["lms"], win.obs_lm, win.obs_px, win.obs_path_off, win.path_edge)
@@ -49,8 +50,9 @@ def worker(rank, world, port, q):
         g = gathered.numpy().reshape(world, N_SHARED, 12)
         assert np.array_equal(g[rank], blocks)                   # rank-major layout
         if rnd == 0:
-            first = g[1 - rank][:, 3:6].tobytes()                # the OTHER rank's gradient blocks really arrived
-        pos = sr.consensus(g, pos)
+            first = g[(rank + 1) % world][:, 3:6].tobytes()      # ANOTHER rank's gradient blocks really arrived
+        gx = sr.consensus(g, pos)
+        pos = acc.step(pos, gx).reshape(N_SHARED, 3) if acc else gx      # (Anderson mixing of the rounds: the same arithmetic on every rank)
         t = torch.tensor([out["res"].err_final], dtype=torch.float64)
         dist.all_reduce(t)                                       # (test bookkeeping only: the joint cost)
         errs.append(float(t.item()))
@@ -100,3 +102,38 @@ def test_gloo_world2_exchange_rounds_equal_the_joint_solve():
         keep[private] = False                                    # (the window's own copy of the shared ones is one round behind)
         ref = J["lms"][lm_map[r]][keep]                          # 1e-6 RELATIVE: a landmark 40 m away is known to its depth's share of that
         assert (np.abs(lms[keep] - ref) <= 1e-6 * np.maximum(1.0, np.linalg.norm(ref, axis=1))[:, None]).all(), r
+
+
+def test_gloo_world4_accelerated_rounds_equal_the_joint_solve():
+    """World size 4 (every shared landmark seen from two of the four submaps) with the Anderson-accelerated rounds of
+    srba-stereo-slam_amd/dist.py (SharedLandmarkAccelerator): 20 rounds instead of 70 reach the joint solve of the union of the four
+    submaps within 1e-6, bit-identically on all ranks."""
+    world, rounds = 4, 20
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, rounds, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=600)
+        res[r[0]] = r
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(res[r][1] == res[0][1] for r in range(world))     # consensus positions bit-identical on every rank
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    import synth_lm as sl
+    wins, idxs, sh = sl.make_shared_submaps(n_sub=world, n_shared=N_SHARED, seed0=50, **KW)
+    joint, e_off, lm_map, sj = sl.join_windows(wins, idxs)
+    J = ol.load().lm_solve(joint, sl.make_params(max_iters=50, conv=1e-14), trace=False)
+    shared = np.frombuffer(res[0][1]).reshape(N_SHARED, 3)
+    assert np.abs(shared - J["lms"][sj]).max() <= 1e-6
+    for r in range(world):
+        poses = np.frombuffer(res[r][2]).reshape(-1, 12)
+        assert np.abs(poses - J["poses"][e_off[r]:e_off[r] + len(poses)]).max() <= 1e-6, r

@@ -77,3 +77,35 @@ def test_rccl_exchange_is_ordered_on_the_context_stream():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_c_abi_exchange_on_a_single_rank_communicator(pkg, ctx):
+    """ssk_lm_exchange_shared: the all-gather through the C-ABI with an RCCL communicator created outside torch.distributed (ncclGetUniqueId +
+    ncclCommInitRank, world size 1, through ctypes on the RCCL the process already holds): what the C++ facade of a multi-GPU deployment
+    calls.  One rank: the gathered buffer is the rank's own blocks; the call is enqueued on the context's stream."""
+    import ctypes as C
+    import os
+    import torch
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        S = 256
+        dev = torch.device("cuda:0")
+        shared = torch.arange(S * 12, dtype=torch.float64, device=dev) * 0.5
+        gathered = torch.zeros(S * 12, dtype=torch.float64, device=dev)
+        lib = ctx.lib
+        lib.ssk_lm_exchange_shared.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        ctx._chk(lib.ssk_lm_exchange_shared(ctx.h, comm, C.c_void_p(shared.data_ptr()), C.c_void_p(gathered.data_ptr()), S))
+        ctx.synchronize()
+        assert torch.equal(gathered, shared)
+        assert lib.ssk_lm_exchange_shared(ctx.h, None, C.c_void_p(shared.data_ptr()), C.c_void_p(gathered.data_ptr()), S) != 0      # no communicator
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -78,6 +78,57 @@ def test_exchange_rounds_converge_to_the_joint_solve(ctx, oracle):
     b.close()
 
 
+def test_configs4_at_its_stated_size_accelerated_rounds(ctx, oracle, pkg):
+    """BASELINE configs[4] at its stated size: 8 config-3-shaped submaps (200 keyframes / 5 000 landmarks, window = the 10 most recent
+    edges, seeds 50..57) + 256 landmarks of one identity each, every one observed from two of the eight submaps.  The 8 windows of one
+    batch stand for the 8 ranks (rank-major gathered buffer); the rounds are mixed by SharedLandmarkAccelerator (Anderson, m = 5) and
+    stop when the consensus moves by less than 1e-8; the result is the oracle's JOINT solve of the union -- 80 edges, ~3 000 landmarks --
+    within 1e-6, in a fraction of the 70 plain rounds."""
+    import torch
+    from ssk_amd import capi
+    n_sub, S = 8, 256
+    wins, idxs, sh = sl.make_shared_submaps(n_sub=n_sub, n_shared=S, seed0=50, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2,
+                                            obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))
+    assert all(w.E == 10 for w in wins) and all(int((i >= 0).sum()) >= 16 for i in idxs)
+    prm = sl.make_params(max_iters=50, conv=1e-14)
+    joint, e_off, lm_map, sj = sl.join_windows(wins, idxs)
+    seen = sj >= 0                                          # (a shared landmark no submap happens to see stays where it started)
+    J = oracle.lm_solve(joint, prm, trace=False)
+    dev = torch.device("cuda:0")
+    b = capi.LmBatch(ctx, wins)
+    assert b.kernel_name() == "lm_solve_node_kernel"
+    cp = to_capi(prm)
+    d_idx = [torch.from_numpy(i.astype(np.int32)).to(dev) for i in idxs]
+    gathered = torch.zeros(n_sub * S * 12, dtype=torch.float64, device=dev)
+    pos = torch.from_numpy(sh["init"].reshape(-1).copy()).to(dev)
+    acc = pkg.dist.SharedLandmarkAccelerator(m=5)
+    rounds = 0
+    for rnd in range(40):
+        b.run(cp); b.results()
+        for r in range(n_sub):
+            b.pack_shared(r, d_idx[r], cp, gathered[r * S * 12:(r + 1) * S * 12])
+        x = pos.cpu().numpy().copy()
+        ctx.stitch_shared(gathered, n_sub, S, pos)
+        ctx.synchronize()
+        nxt = acc.step(x, pos.cpu().numpy())
+        pos.copy_(torch.from_numpy(nxt))
+        for r in range(n_sub):
+            b.set_shared(r, d_idx[r], pos)
+        rounds = rnd + 1
+        if np.abs(nxt - x).max() < 1e-8:
+            break
+    ctx.synchronize()
+    shared = pos.cpu().numpy().reshape(S, 3)
+    assert rounds <= 25, rounds
+    assert np.abs(shared[seen] - J["lms"][sj[seen]]).max() <= 1e-6, (rounds, np.abs(shared[seen] - J["lms"][sj[seen]]).max())
+    b.run(cp); b.results()                                  # the windows at the final consensus
+    for r in range(n_sub):
+        p_r, l_r = b.state(r)
+        assert np.abs(p_r - J["poses"][e_off[r]:e_off[r] + len(p_r)]).max() <= 1e-6, r
+    print("configs[4] at size: %d accelerated rounds to a consensus step below 1e-8" % rounds)
+    b.close()
+
+
 def test_pack_of_a_landmark_nobody_observes_and_bad_arguments(ctx):
     import torch
     from ssk_amd import capi
