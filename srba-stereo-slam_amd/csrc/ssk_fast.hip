@@ -125,10 +125,11 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_img[IH * IW];
 	__shared__ __attribute__((aligned(16))) uint8_t s_sc[SH * SP];
+	__shared__ uint16_t s_qg[SG * SH];         // phase A: 4-pixel groups with a survivor, (group << 4) | 4-bit mask
 	__shared__ uint16_t s_q1[NQ];
 	__shared__ uint16_t s_q2[NQ];
 	__shared__ uint32_t s_out[TW * TH / 4 + 64];
-	__shared__ int s_q1n, s_q2n, s_on, s_base;
+	__shared__ int s_qgn, s_q1n, s_q2n, s_on, s_base;
 
 	const int tid = threadIdx.x;
 #ifdef SSK_FAST_STAMPS
@@ -144,8 +145,9 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 	const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, stride = gridDim.x >> 3;
 	const int per_x = (n_tiles + 7) >> 3;
 	const int t_end = min(n_tiles, (xcd + 1) * per_x);
-	constexpr int NLD = (IH * (IW / 4) + 255) / 256;        // dwords of a tile per thread (6)
-	uint32_t pre[NLD];
+	constexpr int NCH = IH * (IWV / 16);                    // 16-byte chunks of a tile: 9 per row (144 B), 360 in all
+	constexpr int NLD = (NCH + 255) / 256;                  // per thread (2)
+	uint4 pre[NLD];
 
 	auto issue_loads = [&](int t) {
 		const int im = div_magic(t, magic_img), r = t - im * tiles_img, by = div_magic(r, magic_x), bx = r - by * tiles_x;
@@ -154,12 +156,18 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 #pragma unroll
 		for (int u = 0; u < NLD; ++u) {
 			const int i = tid + 256 * u;
-			uint32_t v = 0;
-			if (i < IH * (IW / 4)) {
-				const int row = i / (IW / 4), c = i - row * (IW / 4);
+			uint4 v = make_uint4(0u, 0u, 0u, 0u);
+			if (i < NCH) {
+				const int row = i / 9, c = i - row * 9;
 				const int gy = min(max(Y0 - 4 + row, 0), h - 1);
-				const int gx = X0 - 8 + 4 * c;
-				if (gx + 4 <= pitch) v = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * pitch + gx);
+				const int gx = X0 - 8 + 16 * c;                   // a multiple of 4: global dwordx4 loads only need dword alignment
+				const uint8_t* p = src + (size_t)gy * pitch + gx;
+				if (gx + 16 <= pitch) v = *reinterpret_cast<const uint4*>(p);
+				else {                                            // the last tile column runs past the row pitch: dword by dword, zero beyond
+					if (gx + 4 <= pitch) v.x = *reinterpret_cast<const uint32_t*>(p);
+					if (gx + 8 <= pitch) v.y = *reinterpret_cast<const uint32_t*>(p + 4);
+					if (gx + 12 <= pitch) v.z = *reinterpret_cast<const uint32_t*>(p + 8);
+				}
 			}
 			pre[u] = v;
 		}
@@ -172,10 +180,14 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 #pragma unroll
 		for (int u = 0; u < NLD; ++u) {
 			const int i = tid + 256 * u;
-			if (i < IH * (IW / 4)) reinterpret_cast<uint32_t*>(s_img)[i] = pre[u];
+			if (i < NCH) {
+				const int row = i / 9, c = i - row * 9;
+				uint32_t* d = reinterpret_cast<uint32_t*>(s_img) + row * (IW / 4) + 4 * c;      // (row pitch 37 dwords: not 16-byte aligned)
+				d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
+			}
 		}
 		for (int i = tid; i < SH * SP / 4; i += 256) reinterpret_cast<uint32_t*>(s_sc)[i] = 0u;
-		if (tid == 0) { s_q1n = 0; s_q2n = 0; s_on = 0; }
+		if (tid == 0) { s_qgn = 0; s_q1n = 0; s_q2n = 0; s_on = 0; }
 		__syncthreads();
 		if (t + stride < t_end) issue_loads(t + stride);
 		FSTAMP(0);
@@ -220,8 +232,32 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 						pr[k] = ((res[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) != 0u && k < w - 3 - gx0;
 				}
 			}
-			const uint16_t codes[4] = {(uint16_t)(it * 4), (uint16_t)(it * 4 + 1), (uint16_t)(it * 4 + 2), (uint16_t)(it * 4 + 3)};
-			wave_push4(pr, codes, s_q1, &s_q1n);
+			// ONE queue entry per group with a survivor (one ballot, one store): four entries per group -- four ballots, four conditional
+			// stores in every one of the five rounds -- were a quarter of the kernel; the groups are expanded to pixels below
+			const unsigned m4 = (unsigned)pr[0] | ((unsigned)pr[1] << 1) | ((unsigned)pr[2] << 2) | ((unsigned)pr[3] << 3);
+			wave_push(m4 != 0u, (uint16_t)((it << 4) | m4), s_qg, &s_qgn);
+		}
+		__syncthreads();
+		// ---- phase A2: the queued groups' survivors as a dense pixel queue (code = 4 * group + pixel) ----
+		const int qgn = s_qgn;
+		for (int base = 0; base < qgn; base += 256) {
+			const int q = base + tid;
+			const unsigned e = q < qgn ? s_qg[q] : 0u;
+			const unsigned m4 = e & 15u, cnt = __popc(m4);
+			// exclusive prefix of the lanes' counts (0..4) from the ballots of their three bits
+			const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+			const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+			if (total == 0) continue;                            // (wave uniform)
+			const int lane = tid & 63;
+			const unsigned long long lt = (1ull << lane) - 1ull;
+			const int before = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+			int qb = 0;
+			if (lane == 0) qb = atomicAdd(&s_q1n, total);
+			qb = __shfl(qb, 0, 64) + before;
+			const unsigned code0 = (e >> 4) << 2;
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				if (m4 & (1u << k)) s_q1[qb + __popc(m4 & ((1u << k) - 1u))] = (uint16_t)(code0 + k);
 		}
 		__syncthreads();
 
