@@ -73,9 +73,11 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 
 	// raw patch: aligned dwords covering columns x-22 .. x+22 of rows y-22 .. y+22
 	const int xs = x - PR, xa = xs & ~3, shift = xs - xa;
-	for (int i = lane; i < PD * (PP / 16); i += 64) {          // 3 x 16 bytes per row (global dwordx4 only needs dword alignment)
-		const int r = i / (PP / 16), c = i - r * (PP / 16);
-		reinterpret_cast<uint4*>(s_raw)[i] = *reinterpret_cast<const uint4*>(src + (size_t)(y - PR + r) * pitch + xa + 16 * c);
+	if (lane < PD) {                                           // a lane per patch row: 3 x 16 bytes (global dwordx4 only needs dword alignment);
+		const uint4* g = reinterpret_cast<const uint4*>(src + (size_t)(y - PR + lane) * pitch + xa);      // (a chunk per lane and turn cost 3 x the address arithmetic)
+		const uint4 v0 = g[0], v1 = g[1], v2 = g[2];
+		uint4* d = reinterpret_cast<uint4*>(s_raw) + lane * (PP / 16);
+		d[0] = v0; d[1] = v1; d[2] = v2;
 	}
 	__syncthreads();
 
