@@ -35,7 +35,7 @@ struct ssk_lm_batch {
 	// workgroups were not all resident (stop_reason 5) is repeated with one workgroup per window by ssk_lm_batch_results
 	// node form (ssk_lm_node.hip): built when every window of the batch fits it (reduced system + a tile of node records in LDS)
 	bool gtab_multi = false;          // the per-workgroup suffix tables of the windows whose table lives in L2 scratch were sized for the cooperative kernel (64 copies)
-	bool node_ok = false;
+	bool node_ok = false, node_big = false;
 	nd_dev N{};
 	size_t node_dyn_bytes = 0;
 	bool coop_pending = false;
@@ -1094,12 +1094,19 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	nd_host NH;
 	bool node_all = !force_k || std::strcmp(force_k, "node") == 0;
 	const size_t node_lds_limit = (size_t)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC;
+	// (a window whose reduced system does not fit LDS: the BIG form -- accumulators and system in HBM / L2, ssk_lm_node.hip -- only on request
+	//  (SSK_LM_KERNEL=node): measured 360 ms per 1024 depth-5 windows (E = 40) against 94 ms of the tiled kernel, 84 % of it the
+	//  global_atomic_add_f64 stream of the pair phase -- 640 k adds per window and pass, the chip's L2 atomic rate)
+	const bool node_big_default = false;
+	bool node_big = false;
 	for (int w = 0; w < n_windows && node_all; ++w) {
 		const lm_win& Hw = hdr[w];
-		if (8 * nd_lds_doubles(Hw.n_edges, Hw.E, 4, 0) > node_lds_limit) { node_all = false; break; }
 		nd_win nw{};
 		nw.edge0 = Hw.edge0; nw.lm0 = Hw.lm0; nw.us0 = Hw.us0; nw.ls0 = Hw.ls0; nw.trace0 = Hw.trace0; nw.dp_trace0 = Hw.dp_trace0; nw.df_trace0 = Hw.df_trace0;
-		if (!nd_build_window(windows[w], 4, NH, nw) || 8 * NH.lds_doubles > node_lds_limit) node_all = false;
+		nw.h0 = Hw.h0;
+		if (!nd_build_window(windows[w], 4, NH, nw, node_lds_limit / 8)) { node_all = false; break; }
+		if (8 * NH.lds_doubles > node_lds_limit) node_big = true;
+		if (node_big && (8 * NH.lds_doubles_big > node_lds_limit || (!force_k && !node_big_default))) node_all = false;
 	}
 	if (force_k && std::strcmp(force_k, "node") == 0 && !node_all)
 		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: SSK_LM_KERNEL=node, but a window of the batch does not fit the node kernel");
@@ -1135,10 +1142,15 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		UPN(win, win); UPN(tile, tile); UPN(group, group); UPN(suf, suf); UPN(obs, obs); UPN(px, px); UPN(lane, lane);
 		UPN(item, item); UPN(qs, qs); UPN(gitem, gitem); UPN(gqs, gqs);
 #undef UPN
-		b->node_dyn_bytes = 8 * NH.lds_doubles;
+		b->node_big = node_big;
+		b->node_dyn_bytes = 8 * (node_big ? NH.lds_doubles_big : NH.lds_doubles);
 		if (std::getenv("SSK_LM_DEBUG"))
-			std::fprintf(stderr, "[ssk lm] node form: %d windows, window 0: %d tiles, %d suffixes; dynamic LDS %zu B, longest item run of a lane %d\n", n_windows,
-			             NH.win[0].n_tiles, NH.win[0].n_suf, b->node_dyn_bytes, NH.max_items_per_lane);
+		{
+			long long rounds = 0;
+			for (int t = 0; t < NH.win[0].n_tiles; ++t) rounds += NH.tile[NH.win[0].tile0 + t].n_rounds;
+			std::fprintf(stderr, "[ssk lm] node form%s: %d windows, window 0: %d tiles, %d groups, %d suffixes, %lld pair rounds, %zu items (all windows); dynamic LDS %zu B, longest item run of a lane %d\n",
+			             node_big ? " (BIG)" : "", n_windows, NH.win[0].n_tiles, NH.win[0].n_groups, NH.win[0].n_suf, rounds, NH.item.size(), b->node_dyn_bytes, NH.max_items_per_lane);
+		}
 	}
 	b->tiled_ok = tiled_all; b->tiled_dyn_bytes = tiled_dyn; b->lds_sys = tiled_all && lds_sys_all;
 	b->acc_ok = want_acc && acc_all && tiled_all; b->schur_mfma = schur_mfma;
@@ -1186,6 +1198,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (node_all) {
 		if (!rc) rc = scratch(b, (size_t)NH.tab_doubles, &b->N.tab);
 		if (!rc) rc = scratch(b, (size_t)SSK_ND_SCR * NH.lane.size(), &b->N.scr);
+		if (!rc) rc = scratch(b, node_big ? (size_t)NH.hb_doubles : 0, &b->N.hb);
 	}
 	if (!rc) rc = scratch(b, pose.size(), &b->pose_bak);
 	if (!rc) rc = scratch(b, lm.size(), &b->lm_bak);
@@ -1262,7 +1275,7 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
 	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a run on top of a timed-out cooperative launch continues from the repaired state)
-	if (b->node_ok) return ssk_lm_launch_node(ctx, b->D, b->N, P, b->n_windows, b->node_dyn_bytes);
+	if (b->node_ok) return ssk_lm_launch_node(ctx, b->D, b->N, P, b->n_windows, b->node_dyn_bytes, b->node_big);
 	if (b->acc_ok) return ssk_lm_launch_acc(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
 		// the grid barrier of the cooperative kernel needs all n_windows * G workgroups resident: G from what the occupancy
@@ -1300,7 +1313,7 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 	// the same decisions as ssk_lm_batch_run
 	const char* force = std::getenv("SSK_LM_KERNEL");
 	const char* name = "lm_solve_kernel";
-	if (b->node_ok) name = "lm_solve_node_kernel";
+	if (b->node_ok) name = b->node_big ? "lm_solve_node_big_kernel" : "lm_solve_node_kernel";
 	else if (b->acc_ok) name = b->schur_mfma ? "lm_solve_acc_mfma_kernel" : "lm_solve_acc_kernel";
 	else if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) {
 		bool coop = false;

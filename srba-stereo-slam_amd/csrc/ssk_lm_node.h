@@ -65,6 +65,8 @@ struct nd_win {
 	int n_rounds, max_parts;            // (diagnostics: most rounds of quad slots of a tile, parts of a block)
 	long long tab0;                     // nd_tab[tab0 ..): two suffix tables (current / trial state), 12 doubles per suffix each
 	long long dp_trace0, df_trace0;
+	long long hb0, h0;                  // BIG form (reduced system larger than LDS): block accumulators nd_dev::hb[hb0 ..) (36 doubles per block pair) and
+	                                    // the dense bordered system lm_dev::Hred[h0 ..), both in HBM / L2
 };
 
 struct nd_tile {
@@ -92,5 +94,5 @@ struct nd_dev {
 	const nd_win* win; const nd_tile* tile; const nd_group* group;
 	const nd_i2* suf; const nd_i2* obs; const nd_f4* px; const nd_i4* lane;
 	const int* item; const nd_i2* qs; const int* gitem; const nd_i2* gqs;
-	double* tab; double* scr;
+	double* tab; double* scr; double* hb;
 };

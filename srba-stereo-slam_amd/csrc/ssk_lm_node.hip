@@ -496,6 +496,10 @@ __device__ __forceinline__ void nd_score_group(const lm_dev& D, const nd_dev& N,
 	if (lane < G.n_obs) err += rho;
 }
 
+// BIG: the reduced system does not fit LDS: block accumulators (global_atomic_add_f64, still one owner per block and tile, the tiles' barriers
+// order the adds: bit-reproducible) and the dense bordered system in HBM / L2, factorised by ldl_solve_hybrid with the node records' LDS
+// region (and everything behind it) as its staging
+template <bool BIG>
 __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const lm_cam& P_arg, int dyn_doubles)
 {
 	__shared__ lm_cam s_P;
@@ -514,15 +518,16 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 	double* pose_new = s_dyn + 12 * W.n_edges;
 	double* s_b = s_dyn + 24 * W.n_edges;
 	double* s_inv = s_b + n6p;
-	double* Hb = s_inv + n6p;                          // 36 doubles per block pair (e <= e2): H(6e + a, 6e2 + b) at 36 pid + 6a + b
-	double* g_acc = Hb + 36 * n_pairs;
+	double* Hb = BIG ? N.hb + W.hb0 : s_inv + n6p;     // 36 doubles per block pair (e <= e2): H(6e + a, 6e2 + b) at 36 pid + 6a + b
+	double* g_acc = BIG ? s_inv + n6p : Hb + 36 * n_pairs;
 	nd_i2* s_suf = reinterpret_cast<nd_i2*>(g_acc + n6p);    // the trie's (first step, rest) records: the table builds walk them
 	// the window's tile and group descriptors (a few hundred bytes): every phase starts from them
 	nd_tile* s_tile = reinterpret_cast<nd_tile*>(g_acc + n6p + ((W.n_suf + 1) & ~1));
 	nd_group* groups = reinterpret_cast<nd_group*>(s_tile + W.n_tiles);
 	const int n_groups = W.n_groups;
 	double* reg = reinterpret_cast<double*>(groups + n_groups + (W.n_tiles & 1));      // node records of a tile (wave w: reg + 64 REC w), later the dense bordered system
-	(void)dyn_doubles;
+	const int reg_doubles = dyn_doubles - (int)(reg - s_dyn);
+	(void)reg_doubles;
 	double* stage = reg + 64 * REC * wave;
 	double* tabs[2] = {N.tab + W.tab0, N.tab + W.tab0 + 12 * (size_t)W.n_suf};
 #ifdef SSK_LM_STAMPS
@@ -578,7 +583,11 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 		const double* tab_cur = tabs[cur];
 		double vmax = 0.0;
 		STAMP(0);
-		for (int i = tid; i < 36 * n_pairs + n6p; i += NT) Hb[i] = 0.0;      // (block accumulators and gradient are contiguous)
+		if (BIG) {
+			for (int i = tid; i < 36 * n_pairs; i += NT) __hip_atomic_store(Hb + i, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for (int i = tid; i < n6p; i += NT) g_acc[i] = 0.0;
+		} else
+			for (int i = tid; i < 36 * n_pairs + n6p; i += NT) Hb[i] = 0.0;      // (block accumulators and gradient are contiguous)
 		__syncthreads();
 		STAMP(1);
 		// ---- linearisation: tile by tile ----
@@ -644,8 +653,13 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 #if ND_HB_ATOMIC
 					// one owner per block and tile: ds_add_f64 without a return is a plain read-modify-write in the LDS unit (no wait for a read)
 					double* hb = Hb + 36 * pid;
+					if (BIG) {
 #pragma unroll
-					for (int c = 0; c < 36; ++c) (void)__hip_atomic_fetch_add(hb + c, acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						for (int c = 0; c < 36; ++c) (void)unsafeAtomicAdd(hb + c, acc[c]);
+					} else {
+#pragma unroll
+						for (int c = 0; c < 36; ++c) (void)__hip_atomic_fetch_add(hb + c, acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
 #else
 					v2d_t* hb = reinterpret_cast<v2d_t*>(Hb + 36 * pid);
 					v2d_t old[18];
@@ -704,13 +718,15 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 			double mx = vmax;
 			for (int it = tid; it < n6; it += NT) {
 				const int e = it / 6, a = it - 6 * e;
-				mx = fmax(mx, Hb[36 * (e * (e + 1) / 2 + e) + 7 * a]);
+				const double* hd = Hb + 36 * (e * (e + 1) / 2 + e) + 7 * a;
+				mx = fmax(mx, BIG ? __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *hd);
 			}
 			mx = block_max(mx, s_part);
 			if (tid == 0) s_lambda = P.tau * mx;
 			continue;
 		}
 		// ---- the reduced system: A = H_pp - S + lambda I over the dead records, border row = reduced gradient; LDL^T ----
+		double* Asys = BIG ? D.Hred + W.h0 : reg;
 		for (int it = tid; it < 36 * n_pairs; it += NT) {
 			const int pid = it / 36, ab = it - 36 * pid, a = ab / 6, b = ab - 6 * a;
 			int e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
@@ -719,16 +735,19 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 			const int e = pid - e2 * (e2 + 1) / 2;
 			if (e == e2 && a > b) continue;
 			const int row = 6 * e + a, col = 6 * e2 + b;
-			double v = Hb[it];
+			double v = BIG ? __hip_atomic_load(Hb + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Hb[it];
 			if (row == col) v += lambda;
-			reg[row * np + col] = v;
-			reg[col * np + row] = v;
+			Asys[(size_t)row * np + col] = v;
+			Asys[(size_t)col * np + row] = v;
 		}
-		for (int i = tid; i < n6; i += NT) reg[n6 * np + i] = g_acc[i];
+		for (int i = tid; i < n6; i += NT) Asys[(size_t)n6 * np + i] = g_acc[i];
 		__syncthreads();
 		STAMP(6);
 		bool ok = true;
-		if (n6 > 0) ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
+		if (n6 > 0) {
+			if constexpr (BIG) ok = ldl_solve_hybrid(Asys, np, n6, s_b, s_inv, reg, reg_doubles);
+			else ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
+		}
 		STAMP(7);
 		double dpn = 0, dfn = 0, err_new = s_err;
 		if (ok) {
@@ -829,21 +848,29 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
 void lm_solve_node_kernel(lm_dev D, nd_dev N, lm_cam P, int dyn_doubles)
 {
-	nd_body(D, N, P, dyn_doubles);
+	nd_body<false>(D, N, P, dyn_doubles);
+}
+
+__global__ __launch_bounds__(NT, 1)
+void lm_solve_node_big_kernel(lm_dev D, nd_dev N, lm_cam P, int dyn_doubles)
+{
+	nd_body<true>(D, N, P, dyn_doubles);
 }
 
 }  // namespace
 
-int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes)
+int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, bool big)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
 	static bool attr_set = false;
 	if (!attr_set) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_node_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_node_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
 		attr_set = true;
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
-	hipLaunchKernelGGL(lm_solve_node_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, N, P, (int)(dyn_lds_bytes / 8));
-	SSK_LAUNCH_CHECK(ctx, "lm_solve_node_kernel");
+	if (big) hipLaunchKernelGGL(lm_solve_node_big_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, N, P, (int)(dyn_lds_bytes / 8));
+	else hipLaunchKernelGGL(lm_solve_node_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, N, P, (int)(dyn_lds_bytes / 8));
+	SSK_LAUNCH_CHECK(ctx, big ? "lm_solve_node_big_kernel" : "lm_solve_node_kernel");
 	return SSK_OK;
 }

@@ -20,23 +20,30 @@ struct nd_host {
 	std::vector<int> item, gitem;
 	long long tab_doubles = 0;          // suffix tables of all windows
 	size_t lds_doubles = 0;             // largest dynamic LDS need of a window (doubles)
+	size_t lds_doubles_big = 0;         // ... in the BIG form (accumulators and system in HBM / L2)
+	long long hb_doubles = 0;           // BIG form: block accumulators of all windows
 	int max_items_per_lane = 0;         // (diagnostic: the longest item run of a quad lane)
 };
 
 // dynamic LDS of a window, doubles: edge poses twice, solution + pivots, block accumulators, gradient accumulator, the trie records, then the region the
 // node records of a tile (waves x 64 x SSK_ND_REC) share with the dense bordered system ((6E + 1) x (6E | 1))
-inline size_t nd_lds_doubles(int n_edges, int E, int waves, int n_suf, int n_tiles = 0, int n_groups = 0)
+// BIG form (big = true): accumulators and system live in HBM / L2; the region holds the node records, later whatever the hybrid solver
+// (ldl_solve_hybrid) can use of the packed trailing triangle -- up to `limit` doubles in all.
+inline size_t nd_lds_doubles(int n_edges, int E, int waves, int n_suf, int n_tiles = 0, int n_groups = 0, bool big = false, size_t limit = 0)
 {
 	const size_t n6 = 6 * (size_t)E, n6p = (n6 + 1) & ~(size_t)1;
-	const size_t region = std::max((size_t)waves * 64 * SSK_ND_REC, (n6 + 1) * (n6 | 1));
-	return 24 * (size_t)n_edges + 2 * n6p + 36 * ((size_t)E * (E + 1) / 2) + n6p + (((size_t)n_suf + 1) & ~(size_t)1) +
-	       3 * (size_t)n_tiles + 2 * (size_t)n_groups + ((size_t)n_tiles & 1) + region;      // (+ the tile / group descriptors: 24 and 16 bytes each)
+	const size_t fixed = 24 * (size_t)n_edges + 2 * n6p + n6p + (((size_t)n_suf + 1) & ~(size_t)1) +
+	                     3 * (size_t)n_tiles + 2 * (size_t)n_groups + ((size_t)n_tiles & 1);      // (+ the tile / group descriptors: 24 and 16 bytes each)
+	const size_t recs = (size_t)waves * 64 * SSK_ND_REC;
+	if (!big) return fixed + 36 * ((size_t)E * (E + 1) / 2) + std::max(recs, (n6 + 1) * (n6 | 1));
+	const size_t want = fixed + std::max(recs, (n6 + 1) * (n6 + 2) / 2);
+	return std::max(fixed + recs, std::min(want, limit));
 }
 
 // Appends window Wn to H (bases edge0 / lm0 / us0 / ls0 / trace offsets are the caller's: the families are shared with the other
 // kernels' structures).  Returns false -- and leaves H untouched -- when the window does not fit the node kernel:
 // more than 128 optimised edges, a landmark with more than 64 observations or more than 63 nodes, more than 65535 suffixes.
-inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */)
+inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */, size_t lds_limit_doubles = 20352)
 {
 	const int n_obs = Wn.n_obs, n_lms = Wn.n_lms_total;
 	int E = 0, L = 0;
@@ -110,6 +117,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	hdr.obs0 = (int)H.obs.size(); hdr.lane0 = (int)H.lane.size();
 	hdr.item0 = (int)H.item.size(); hdr.qs0 = (int)H.qs.size(); hdr.gitem0 = (int)H.gitem.size(); hdr.gqs0 = (int)H.gqs.size();
 	hdr.tab0 = H.tab_doubles;
+	hdr.hb0 = H.hb_doubles;
 	std::vector<nd_group> groups;
 	std::vector<nd_i2> w_obs;
 	std::vector<nd_f4> w_px;
@@ -313,7 +321,9 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	H.gitem.insert(H.gitem.end(), w_gitem.begin(), w_gitem.end());
 	H.gqs.insert(H.gqs.end(), w_gqs.begin(), w_gqs.end());
 	H.tab_doubles += 2LL * 12 * n_suf;
+	H.hb_doubles += 36LL * E * (E + 1) / 2;
 	H.lds_doubles = std::max(H.lds_doubles, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)tiles.size(), (int)groups.size()));
+	H.lds_doubles_big = std::max(H.lds_doubles_big, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)tiles.size(), (int)groups.size(), true, lds_limit_doubles));
 	H.max_items_per_lane = std::max(H.max_items_per_lane, max_per_lane);
 	H.win.push_back(hdr);
 	return true;

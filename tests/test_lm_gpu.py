@@ -157,19 +157,19 @@ def test_lm_tiled_kernel_multi_tile_window(ctx, oracle):
     check_against_oracle(ctx, oracle, win, sl.make_params(), min_accept=2)
 
 
-@pytest.mark.parametrize("kernel", ["tiled", "l2"])
+@pytest.mark.parametrize("kernel", ["tiled", "l2", "node"])
 def test_lm_large_window_global_cholesky(ctx, oracle, kernel, monkeypatch):
     """a window whose reduced system (6E > 132) does not fit LDS: the tiled kernel keeps it in L2 scratch (workgroup-wide
-    Cholesky), as the general kernel does."""
-    if kernel == "l2":
-        monkeypatch.setenv("SSK_LM_KERNEL", "l2")
+    Cholesky), as the general kernel and the BIG form of the node kernel do."""
+    if kernel != "tiled":
+        monkeypatch.setenv("SSK_LM_KERNEL", kernel)
     win, gt = sl.make_submap_problem(21, n_kf=45, n_lm=900, submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)
     assert 6 * win.E > 140
     check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8))
 
 
 @pytest.mark.parametrize("n_kf", [24, 27, 41, 59])
-@pytest.mark.parametrize("kernel", ["tiled", "coop"])
+@pytest.mark.parametrize("kernel", ["tiled", "coop", "node"])
 def test_lm_dense_solver_beyond_lds_sizes(ctx, oracle, n_kf, kernel, monkeypatch):
     """ldl_solve_hybrid at the sizes where its paths change (6E = 138, 156: the whole packed triangle in LDS, no leading columns; 240: eleven leading
     six-column steps in L2 scratch beside the LDS block; 348: more leading columns than LDS rows, the back-substitution stages the rows in several
@@ -181,7 +181,7 @@ def test_lm_dense_solver_beyond_lds_sizes(ctx, oracle, n_kf, kernel, monkeypatch
     assert res.stop_reason != 5
 
 
-@pytest.mark.parametrize("kernel", ["tiled", "coop"])
+@pytest.mark.parametrize("kernel", ["tiled", "coop", "node"])
 def test_lm_window_beyond_the_matrix_core_mask(ctx, oracle, kernel, monkeypatch):
     """E = 90 optimised edges: 6E / 16 = 34 row tiles of the reduced system, more than the 32-bit tile mask of the matrix-core Schur form holds --
     the library must fall back to the sparse form there (and say which kernel it runs), with the usual per-iteration bar."""
@@ -202,7 +202,8 @@ def test_lm_kernel_name_follows_the_batch(ctx, monkeypatch):
     small = sl.make_submap_problem(1, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)[0]
     large = sl.make_submap_problem(21, n_kf=45, n_lm=900, submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)[0]
     for wins, env, expect in (([small], None, "lm_solve_node_kernel"), ([small], "tiled", "lm_solve_tiled"), ([large], None, "lm_solve_coop"),
-                              ([large] * 128, None, "lm_solve_tiled_kernel"), ([small], "l2", "lm_solve_kernel")):
+                              ([large] * 128, None, "lm_solve_tiled_kernel"), ([large], "node", "lm_solve_node_big_kernel"),
+                              ([small], "l2", "lm_solve_kernel")):
         if env:
             monkeypatch.setenv("SSK_LM_KERNEL", env)
         else:
