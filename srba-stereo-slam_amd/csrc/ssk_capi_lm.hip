@@ -1092,6 +1092,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 
 	// ---- node form: the default for batches whose windows all fit it (SSK_LM_KERNEL=node|tiled|coop|l2|acc picks a kernel) ----
 	nd_host NH;
+	std::vector<int> node_order;
 	bool node_all = !force_k || std::strcmp(force_k, "node") == 0;
 	const size_t node_lds_limit = (size_t)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC;
 	// (a window whose reduced system does not fit LDS: the BIG form -- accumulators and system in HBM / L2, ssk_lm_node.hip -- only on request
@@ -1101,6 +1102,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	bool node_big = false;
 	for (int w = 0; w < n_windows && node_all; ++w) {
 		const lm_win& Hw = hdr[w];
+		if (!force_k && !node_big_default && 8 * nd_lds_doubles(Hw.n_edges, Hw.E, 4, 0) > node_lds_limit) { node_all = false; break; }      // (before the symbolic work)
 		nd_win nw{};
 		nw.edge0 = Hw.edge0; nw.lm0 = Hw.lm0; nw.us0 = Hw.us0; nw.ls0 = Hw.ls0; nw.trace0 = Hw.trace0; nw.dp_trace0 = Hw.dp_trace0; nw.df_trace0 = Hw.df_trace0;
 		nw.h0 = Hw.h0;
@@ -1141,6 +1143,16 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 #define UPN(vec, field) if (!rc) rc = upload(b, NH.vec, &b->N.field)
 		UPN(win, win); UPN(tile, tile); UPN(group, group); UPN(suf, suf); UPN(obs, obs); UPN(px, px); UPN(lane, lane);
 		UPN(item, item); UPN(qs, qs); UPN(gitem, gitem); UPN(gqs, gqs);
+		{
+			// launch order: windows by observations x optimised edges, largest first (SSK_LM_ORDER=0: as given)
+			node_order.resize((size_t)n_windows);
+			std::vector<int>& ord = node_order;       // (lives until finalize() copies it)
+			for (int w = 0; w < n_windows; ++w) ord[(size_t)w] = w;
+			const char* oe = std::getenv("SSK_LM_ORDER");
+			if (!oe || std::atoi(oe) != 0)
+				std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return (long long)NH.win[a].n_obs * (NH.win[a].E + 4) > (long long)NH.win[c].n_obs * (NH.win[c].E + 4); });
+			if (!rc) rc = upload(b, ord, &b->N.order);
+		}
 #undef UPN
 		b->node_big = node_big;
 		b->node_dyn_bytes = 8 * (node_big ? NH.lds_doubles_big : NH.lds_doubles);

@@ -95,4 +95,5 @@ struct nd_dev {
 	const nd_i2* suf; const nd_i2* obs; const nd_f4* px; const nd_i4* lane;
 	const int* item; const nd_i2* qs; const int* gitem; const nd_i2* gqs;
 	double* tab; double* scr; double* hb;
+	const int* order;                   // launch order: workgroup b solves window order[b] (largest first: the last workgroups to start are the short ones)
 };

@@ -510,7 +510,7 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 	__shared__ int s_accept, s_stop, s_iters, s_accepted, s_cur;
 	__syncthreads();
 	const lm_cam& P = s_P;
-	const int wi = (int)blockIdx.x;
+	const int wi = N.order[blockIdx.x];
 	const nd_win W = N.win[wi];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, quad = tid >> 2, ql = tid & 3;
 	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1, np = n6 | 1, n_pairs = W.E * (W.E + 1) / 2;
@@ -835,10 +835,10 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 		ssk_lm_result& R = D.res[wi];
 		R.iters = s_iters; R.accepted = s_accepted; R.stop_reason = s_stop; R.err_final = s_err; R.lambda_final = s_lambda;
 #ifdef SSK_LM_STAMPS
-		if (blockIdx.x == 0)
+		if (wi == 0)
 			printf("node stamps (cycles, window 0, %d iters, %d tiles): loop top %llu zero %llu | groups: own %llu + barrier %llu, pairs: own %llu + barrier %llu | assemble %llu solve %llu "
 			       "edges + table %llu score %llu decision + copy %llu\n", s_iters, W.n_tiles, s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8], s_acc[9], s_acc[10]);
-		if (blockIdx.x == 0)
+		if (wi == 0)
 			printf("node fine (thread 0, cumulative over launches): group: loads + observation %llu, run sums %llu, roots %llu, nodes %llu, record stores %llu | pairs: items %llu, quad sum + adds %llu\n",
 			       g_nd_fine[0], g_nd_fine[1], g_nd_fine[2], g_nd_fine[3], g_nd_fine[4], g_nd_fine[5], g_nd_fine[6]);
 #endif
