@@ -189,7 +189,7 @@ __device__ __forceinline__ void ldl_backsub_wave(const double* A, int np, int n,
 }
 
 #ifdef SSK_LM_STAMPS
-__device__ unsigned long long g_ldl[4];
+__device__ unsigned long long g_ldl[8];
 #define LDL_T0() const unsigned long long ldl_t0_ = __builtin_amdgcn_s_memtime()
 #define LDL_ADD(i, who) do { if (threadIdx.x == (who) && blockIdx.x == 0) g_ldl[i] += __builtin_amdgcn_s_memtime() - ldl_t0_; } while (0)
 #else
@@ -208,8 +208,10 @@ struct ldl_ix_packed { __device__ __forceinline__ int operator()(int i, int k) c
 
 // The factorisation proper, L' D L'^T of rows 0 .. n (row n = right-hand side) in LDS under an index map: see ldl_solve_lds.
 // (ix(i, k) of an element above the diagonal must stay inside the allocation: it is read, never used or stored.)
+// nr >= n: the last row.  nr = n is the square system with its border row; nr > n a block COLUMN of a larger system (n columns
+// factorised, the rows below eliminated on the way: ldl_solve_blocked).
 template <typename IX>
-__device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int n, double* inv)
+__device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int n, double* inv, int nr)
 {
 	const int tid = threadIdx.x;
 	__shared__ int s_ldl_bad_p;
@@ -233,7 +235,7 @@ __device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int
 				for (int k = j + 1; k <= i; ++k) a[i * (i + 1) / 2 + k] -= t * a[k * (k + 1) / 2 + j];
 			}
 		}
-		for (int i = 6 + tid; i <= n; i += 64) {
+		for (int i = 6 + tid; i <= nr; i += 64) {
 			double x[6];
 #pragma unroll
 			for (int k = 0; k < 6; ++k) x[k] = A[ix(i, k)];
@@ -274,10 +276,10 @@ __device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int
 				for (int c = 0; c < 6; ++c) uk[k][c] = A[ix((r0 + k), c0 + c)];
 			double a[21], ivr[6];
 			bool bad = false;
-			for (int i0 = r0; i0 <= n; i0 += 64) {
+			for (int i0 = r0; i0 <= nr; i0 += 64) {
 				const int i = i0 + tid;
-				const bool row = i <= n;
-				const int ic = row ? i : n;                   // loads are unconditional on a clamped row (a load under a lane
+				const bool row = i <= nr;
+				const int ic = row ? i : nr;                  // loads are unconditional on a clamped row (a load under a lane
 				double x[6];                                  // condition is compiled as a branch that waits for it at once)
 				{
 					double ui[6], v[6];
@@ -342,14 +344,14 @@ __device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int
 			constexpr int NR = (NT - 64) / 32;            // row groups of 32 lanes
 			const int t2 = tid - 64, ty = t2 >> 5, tx = t2 & 31;
 			const int q0 = r0 + 6;
-			for (int ib = q0 + ty; ib <= n; ib += 4 * NR)
+			for (int ib = q0 + ty; ib <= nr; ib += 4 * NR)
 				for (int kb = q0 + tx; kb < n; kb += 64) {
 					if (kb - tx > ib - ty + 4 * NR - 1) break;       // the whole pass lies above the diagonal (uniform)
 					// unconditional loads on clamped indices (see above); only the stores are predicated
 					double ui[4][6], uk[2][6], v[8];
 #pragma unroll
 					for (int u = 0; u < 4; ++u) {
-						const int i = min(ib + NR * u, n);
+						const int i = min(ib + NR * u, nr);
 #pragma unroll
 						for (int c = 0; c < 6; ++c) ui[u][c] = A[ix(i, c0 + c)];
 					}
@@ -362,7 +364,7 @@ __device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int
 #pragma unroll
 					for (int u = 0; u < 4; ++u)
 #pragma unroll
-						for (int w = 0; w < 2; ++w) v[2 * u + w] = A[ix(min(ib + NR * u, n), min(kb + 32 * w, n - 1))];
+						for (int w = 0; w < 2; ++w) v[2 * u + w] = A[ix(min(ib + NR * u, nr), min(kb + 32 * w, n - 1))];
 #pragma unroll
 					for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -372,7 +374,7 @@ __device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int
 #pragma unroll
 						for (int w = 0; w < 2; ++w) {
 							const int i = ib + NR * u, k = kb + 32 * w;
-							if (i <= n && k < n && k <= i) {
+							if (i <= nr && k < n && k <= i) {
 								double sacc = 0.0;
 #pragma unroll
 								for (int c = 0; c < 6; ++c) sacc += ui[u][c] * uk[w][c];
@@ -737,6 +739,111 @@ __device__ __forceinline__ bool ldl_solve_global(double* __restrict__ A, int np,
 // Same operation order per element as the other two solvers up to the back-substitution, which is done block-wise:
 // x2 (rows >= n1) inside the packed block, then the rows' leading columns (from global memory, staged) onto x1.
 #define SSK_PI(i, k) P[(i) * ((i) + 1) / 2 + (k)]
+// Back-substitution, the n1 leading unknowns of a system whose trailing unknowns x_out[n1 .. n) are final and whose leading ones hold
+// z_k / d_k: the rows' leading columns come from the matrix in global memory, staged in `lds`.
+__device__ __forceinline__ bool ldl_backsub_leading(double* __restrict__ A, int np, int n, int n1, double* x_out, double* inv, double* lds, int lds_doubles)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	// ---- step B: the leading unknowns.  The leading columns of the rows come into LDS (the packed block is dead), scaled by the
+	//      pivots and zero from the diagonal on, as many rows at a time as fit (all of them up to ~45 edges), from the last row up.
+	//      Rows >= n1 are final: unknown k < n1 takes their terms in one pass (a lane per k); the leading triangle goes by 16-row
+	//      blocks as above ----
+	const int cr = lds_doubles / n1 < n ? lds_doubles / n1 : n;
+	for (int hi = n - 1; hi >= 1;) {
+		const int lo = hi - cr + 1 > 1 ? hi - cr + 1 : 1;
+		__syncthreads();
+		for (int t = tid; t < (hi - lo + 1) * n1; t += NT) {
+			const int r = t / n1, k = t - r * n1, i = lo + r;
+			const double av = A[(size_t)i * np + k] * inv[k];      // (unconditional load)
+			lds[t] = k < i ? av : 0.0;
+		}
+		__syncthreads();
+		const int ilo = lo > n1 ? lo : n1;
+		if (hi >= ilo) {
+			for (int k = tid; k < n1; k += NT) {
+				double s0 = 0.0, s1 = 0.0;
+				int i = ilo;
+				for (; i + 1 <= hi; i += 2) { s0 += lds[(i - lo) * n1 + k] * x_out[i]; s1 += lds[(i + 1 - lo) * n1 + k] * x_out[i + 1]; }
+				if (i <= hi) s0 += lds[(i - lo) * n1 + k] * x_out[i];
+				x_out[k] -= s0 + s1;
+			}
+			__syncthreads();
+		}
+		for (int bh = hi < n1 - 1 ? hi : n1 - 1; bh >= lo;) {
+			const int bl = bh - 15 > lo ? bh - 15 : lo, pw = bh - bl + 1;
+			if (wave == 0) {
+				const int k = lane < pw ? lane : 0;
+				double u[16];
+#pragma unroll
+				for (int i = 0; i < 16; ++i) u[i] = i < pw ? lds[(bl + i - lo) * n1 + bl + k] : 0.0;      // (zero for k >= i)
+				double xv = x_out[bl + k];
+#pragma unroll
+				for (int i = 15; i >= 1; --i) {
+					const double xi = readlane_f64(xv, i);
+					if (i < pw) xv -= u[i] * xi;
+				}
+				if (lane < pw) x_out[bl + lane] = xv;
+			}
+			__syncthreads();
+			for (int k = tid; k < bl; k += NT) {
+				double sacc = 0.0;
+#pragma unroll
+				for (int i = 0; i < 16; ++i) sacc += i < pw ? lds[(bl + (i < pw ? i : 0) - lo) * n1 + k] * x_out[bl + (i < pw ? i : 0)] : 0.0;
+				x_out[k] -= sacc;
+			}
+			__syncthreads();
+			bh = bl - 1;
+		}
+		hi = lo - 1;
+	}
+	return true;
+}
+
+// Back-substitution shared by ldl_solve_hybrid and ldl_solve_blocked: the trailing m unknowns inside the packed LDS block P (border row
+// = row m), then the n1 leading ones from the matrix in global memory (rows' leading columns staged in `lds`; P is dead by then).
+__device__ __forceinline__ bool ldl_backsub_blocks(double* __restrict__ A, int np, int n, int n1, int m, double* P, double* x_out, double* inv, double* lds, int lds_doubles)
+{
+	const int tid = threadIdx.x;
+#ifdef SSK_LM_STAMPS
+	LDLH_T();
+#endif
+	// ---- back-substitution x = D^-1 z - L'^T x by 16-row blocks from the bottom (two barriers per block, not one per row): inside a
+	//      block one wavefront (a lane per column, x of the rows above by readlane), then every earlier unknown takes the block's
+	//      16 terms at once.  Step A: x2 inside the packed block ----
+	const int lane = tid & 63, wave = tid >> 6;
+	for (int k = tid; k < m; k += NT) x_out[n1 + k] = SSK_PI(m, k) * inv[n1 + k];
+	for (int k = tid; k < n1; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
+	__syncthreads();
+	for (int c = ((m - 1) >> 4) << 4; c >= 0; c -= 16) {
+		const int pw = m - c < 16 ? m - c : 16;
+		if (wave == 0) {
+			const int k = lane < pw ? lane : 0;
+			const double ivk = inv[n1 + c + k];
+			double u[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) u[i] = (i < pw && i > k) ? SSK_PI(c + i, c + k) * ivk : 0.0;
+			double xv = x_out[n1 + c + k];
+#pragma unroll
+			for (int i = 15; i >= 1; --i) {
+				const double xi = readlane_f64(xv, i);
+				if (i < pw) xv -= u[i] * xi;                    // (u[i] = 0 for k >= i)
+			}
+			if (lane < pw) x_out[n1 + c + lane] = xv;
+		}
+		__syncthreads();
+		for (int k = tid; k < c; k += NT) {
+			double sacc = 0.0;
+#pragma unroll
+			for (int i = 0; i < 16; ++i) { const int ii = c + (i < pw ? i : 0); sacc += i < pw ? SSK_PI(ii, k) * x_out[n1 + ii] : 0.0; }
+			x_out[n1 + k] -= sacc * inv[n1 + k];
+		}
+		__syncthreads();
+	}
+	if (n1 == 0) { LDLH_ADD(3); return true; }
+	const bool ok_ = ldl_backsub_leading(A, np, n, n1, x_out, inv, lds, lds_doubles);
+	LDLH_ADD(3);
+	return ok_;
+}
 __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
 {
 	const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
@@ -892,98 +999,386 @@ __device__ __forceinline__ bool ldl_solve_hybrid(double* __restrict__ A, int np,
 	// ---- phase 3: blocked LDL^T of the packed block with look-ahead (ldl_solve_lds's factorisation on packed indices) ----
 	__syncthreads();
 	LDLH_ADD(1);
-	if (!ldl_factor_lookahead(P, ldl_ix_packed{}, m, inv + n1)) return false;
+	if (!ldl_factor_lookahead(P, ldl_ix_packed{}, m, inv + n1, m)) return false;
 	__syncthreads();
 	LDLH_ADD(2);
-	// ---- back-substitution x = D^-1 z - L'^T x by 16-row blocks from the bottom (two barriers per block, not one per row): inside a
-	//      block one wavefront (a lane per column, x of the rows above by readlane), then every earlier unknown takes the block's
-	//      16 terms at once.  Step A: x2 inside the packed block ----
-	const int lane = tid & 63, wave = tid >> 6;
-	for (int k = tid; k < m; k += NT) x_out[n1 + k] = SSK_PI(m, k) * inv[n1 + k];
+	return ldl_backsub_blocks(A, np, n, n1, m, P, x_out, inv, lds, lds_doubles);
+}
+
+// index map of a block column in LDS: rows x (w columns), odd pitch
+struct ldl_ix_rect { int pitch; __device__ __forceinline__ int operator()(int i, int k) const { return i * pitch + k; } };
+
+// C(i, k) -= sum_q S(i, q) inv[q] S(k, q) over a staged chunk of CW finished columns (S: rows of the target, pitch CW + 1; row k of S
+// is the matrix row of target column k), for the target's lower part k <= i, k < ncol, i <= nr.  A wavefront takes a column pair,
+// its lanes the rows: the S(k, .) reads are broadcasts, S(i, .) and C(i, k) conflict free (odd pitches / triangular offsets).
+template <int CW, typename IX>
+__device__ __forceinline__ void ldl_chunk_update(double* C, const IX ix, int ncol, int nr, const double* S, const double* ivq, int nq)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int k0 = 2 * wave; k0 < ncol; k0 += 2 * (NT / 64)) {
+		const int k1 = k0 + 1 < ncol ? k0 + 1 : k0;
+		double sk0[CW], sk1[CW];
+#pragma unroll
+		for (int q = 0; q < CW; ++q) {
+			const double iv = q < nq ? ivq[q] : 0.0;      // (a last chunk of fewer columns: its staging holds zeros there)
+			sk0[q] = S[k0 * (CW + 1) + q] * iv; sk1[q] = S[k1 * (CW + 1) + q] * iv;
+		}
+		for (int ib = (k0 >> 6) << 6; ib <= nr; ib += 64) {
+			const int i0 = min(ib + lane, nr);
+			double a0[CW];
+#pragma unroll
+			for (int q = 0; q < CW; ++q) a0[q] = S[i0 * (CW + 1) + q];
+			const double c00 = C[ix(i0, k0)], c01 = C[ix(i0, k1)];
+			double s00 = 0, s01 = 0;
+#pragma unroll
+			for (int q = 0; q < CW; ++q) { s00 += a0[q] * sk0[q]; s01 += a0[q] * sk1[q]; }
+			const bool r0 = ib + lane <= nr;
+			if (r0 && i0 >= k0) C[ix(i0, k0)] = c00 - s00;
+			if (r0 && i0 >= k1 && k1 != k0) C[ix(i0, k1)] = c01 - s01;
+		}
+	}
+}
+
+// The updates of a target in LDS (rows r0 .. n of the matrix, ncol columns under the index map) by the finished columns 0 .. c - 1,
+// from CW-column chunks staged through S (rows x (CW + 1)): one parallel load per chunk, the next chunk in flight in registers
+// during the update.
+template <int CW, typename IX>
+__device__ __forceinline__ void ldl_apply_leading(const double* __restrict__ A, int np, int n, const double* inv, const IX ixf, double* C, int ncol, int r0, int c, double* S)
+{
+	constexpr int SR = 8;                              // elements per thread and leg (rows x CW <= 8 NT: 340 rows at 512 threads, 170 at 256; more: further legs)
+	const int tid = threadIdx.x, nr = n - r0, cnt = (nr + 1) * CW, legs = (cnt + SR * NT - 1) / (SR * NT);
+	auto chunk_load = [&](int p0, int leg, double (&v)[SR]) {
+#pragma unroll
+		for (int j = 0; j < SR; ++j) {
+			const int e = min(tid + NT * (j + SR * leg), cnt - 1), r = e / CW, q = e - r * CW;
+			v[j] = A[(size_t)(r0 + r) * np + p0 + q];
+		}
+	};
+	auto chunk_store = [&](int nq, int leg, const double (&v)[SR]) {
+#pragma unroll
+		for (int j = 0; j < SR; ++j) {
+			const int e = tid + NT * (j + SR * leg), r = e / CW, q = e - r * CW;
+			if (e < cnt) S[r * (CW + 1) + q] = q < nq ? v[j] : 0.0;
+		}
+	};
+	double v[SR];
+	if (c > 0) chunk_load(0, 0, v);
+	for (int p0 = 0; p0 < c; p0 += CW) {
+		__syncthreads();                               // the staging is free (and, first turn, the target is in LDS)
+		const int nq = c - p0 < CW ? c - p0 : CW;
+		chunk_store(nq, 0, v);
+		for (int leg = 1; leg < legs; ++leg) { chunk_load(p0, leg, v); chunk_store(nq, leg, v); }
+		if (p0 + CW < c) chunk_load(p0 + CW, 0, v);
+		__syncthreads();
+		ldl_chunk_update<CW>(C, ixf, ncol, nr, S, inv + p0, nq);
+	}
+	__syncthreads();
+}
+
+// The leading n1 columns of a system in L2 scratch, left-looking by block columns: a block column (rows c .. n, as many columns as
+// fit LDS beside the staging) is loaded ONCE, takes the updates of the columns before it (ldl_apply_leading), is factorised at LDS
+// latency (ldl_factor_lookahead on the rectangle) and is stored once.  0: done, 1: a pivot <= 0, 2: a block column does not fit.
+template <int CW>
+__device__ __forceinline__ int ldl_leading_panels(double* __restrict__ A, int np, int n, int n1, double* inv, double* lds, int lds_doubles)
+{
+	const int tid = threadIdx.x;
+	for (int c = 0; c < n1;) {
+		const int R = n - c + 1;
+		const int stage = c ? (CW + 1) * R : 0;
+		int w = ((lds_doubles - stage) / R - 1) / 6 * 6;
+		if (w > n1 - c) w = n1 - c;
+		if (w < 6) return 2;                               // (a system far beyond the tiler's sizes; nothing is modified when c == 0)
+		const ldl_ix_rect ix{w + 1};
+		double* Pn = lds;
+		double* S = lds + (size_t)R * (w + 1);
+		__syncthreads();
+		for (int e0 = 0; e0 < R * w; e0 += 8 * NT) {       // (eight loads in flight per thread)
+			double v[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) { const int e = min(e0 + tid + NT * j, R * w - 1), r = e / w, k = e - r * w; v[j] = A[(size_t)(c + r) * np + c + k]; }
+#pragma unroll
+			for (int j = 0; j < 8; ++j) { const int e = e0 + tid + NT * j, r = e / w, k = e - r * w; if (e < R * w) Pn[r * (w + 1) + k] = v[j]; }
+		}
+		ldl_apply_leading<CW>(A, np, n, inv, ix, Pn, w, c, c, S);
+		__syncthreads();
+		if (!ldl_factor_lookahead(Pn, ix, w, inv + c, R - 1)) return 1;
+		__syncthreads();
+		for (int e = tid; e < R * w; e += NT) { const int r = e / w, k = e - r * w; if (k <= r) A[(size_t)(c + r) * np + c + k] = Pn[r * (w + 1) + k]; }
+		c += w;
+	}
+	__syncthreads();                                   // (the last block column's stores are issued; its LDS copy is dead)
+	return 0;
+}
+
+// G for a system in L2 scratch, BLOCKED: like ldl_solve_hybrid the trailing block is factorised in LDS as a packed triangle, but the
+// leading n1 columns no longer cost one global-memory step per six columns (three dependent L2 round trips and two barriers each):
+// ldl_leading_panels; the packed trailing block then takes the updates of ALL leading columns the same way and is factorised in place.
+// Per element the same operations as the other solvers; the order of the update terms is by column (ascending) as there.
+// (Measured equal to ldl_solve_hybrid on a 240-unknown system -- the in-LDS factorisation is bound by LDS bandwidth, 6.5 accesses per
+// element and six-column step -- which is why the default is ldl_solve_regtile.)
+__device__ __forceinline__ bool ldl_solve_blocked(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
+{
+	constexpr int CW = 12;
+	const int tid = threadIdx.x;
+	int m = n;
+	while (m > 0 && (long long)(m + 1) * (m + 2) / 2 + (m < n ? (long long)(CW + 1) * (m + 1) : 0) > lds_doubles) m -= 6;
+	const int n1 = n - m;
+	if (m <= 0) return ldl_solve_hybrid(A, np, n, x_out, inv, lds, lds_doubles);
+	LDLH_T();
+	const int lead = ldl_leading_panels<CW>(A, np, n, n1, inv, lds, lds_doubles);
+	if (lead == 1) return false;
+	if (lead == 2) return ldl_solve_hybrid(A, np, n, x_out, inv, lds, lds_doubles);
+	LDLH_ADD(0);
+	// ---- the trailing block: packed in LDS, the leading columns' updates, the factorisation in place ----
+	double* P = lds;
+	double* S = lds + (size_t)(m + 1) * (m + 2) / 2;
+	for (int r = tid >> 5; r <= m; r += NT / 32) {
+		const int cend = r < m ? r : m - 1;
+		for (int k = tid & 31; k <= cend; k += 32) SSK_PI(r, k) = A[(size_t)(n1 + r) * np + n1 + k];
+	}
+	if (n1 > 0) ldl_apply_leading<CW>(A, np, n, inv, ldl_ix_packed{}, P, m, n1, n1, S);
+	__syncthreads();
+	LDLH_ADD(1);
+	if (!ldl_factor_lookahead(P, ldl_ix_packed{}, m, inv + n1, m)) return false;
+	__syncthreads();
+	LDLH_ADD(2);
+	return ldl_backsub_blocks(A, np, n, n1, m, P, x_out, inv, lds, lds_doubles);
+}
+
+// G for a system in L2 scratch, the trailing block in REGISTERS: the lower triangle of the last m <= 246 unknowns is cut into 8 x 8
+// tiles, one per thread (31 x 32 / 2 = 496 tiles at 512 threads; column-major thread order, so that whole wavefronts retire as the
+// factorisation advances), 64 doubles each.  A step eliminates the 8 columns of one tile column:
+//   A  the thread of the diagonal tile factorises it (L' D L'^T in its registers), eliminates the right-hand side's 8 entries (it owns
+//      them) and publishes the factor;                                                      -- barrier
+//   B  the threads of the tiles below eliminate their 8 rows against it and publish them, tile-major (lane = tile row: no conflicts);
+//                                                                                            -- barrier
+//   C  every thread right of the column: tile -= U_I D^-1 U_J^T, 512 multiply-adds against 128 LDS reads (the LDS-resident
+//      factorisation pays 6.5 LDS accesses per 6 multiply-adds and is bound by them); double buffers: no third barrier.
+// The leading n - m columns (systems beyond 41 edges) go by ldl_leading_panels, their updates reach the tiles through staged chunks.
+// Back-substitution from the registers: per tile row one 8 x 8 triangle by the diagonal thread, then the row's tiles hand their
+// 8-term partial sums to the diagonal threads of their columns (fixed order: bit-reproducible).
+// Same operations per element as the other solvers up to the order of an update's terms (term by term here, not a 6-term sum first).
+__device__ __forceinline__ bool ldl_solve_regtile(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
+{
+	constexpr int CW = 12, TP = 33;
+	constexpr int TMAX = NT >= 496 ? 31 : (NT >= 253 ? 22 : (NT >= 120 ? 15 : 10));      // T (T + 1) / 2 <= NT
+	constexpr int L_S2 = 8 * CW * TP, L_SZ = 16, L_PN = 64 * TP, L_DG = 72, L_ZP = 8, L_XS = 8 * 32, L_PART = 8 * 32;
+	constexpr int L_TOTAL = L_S2 + L_SZ + 2 * L_PN + 2 * L_DG + 2 * L_ZP + L_XS + L_PART;
+	if (lds_doubles < L_TOTAL) return ldl_solve_blocked(A, np, n, x_out, inv, lds, lds_doubles);
+	const int tid = threadIdx.x;
+	const int m = n < 8 * TMAX / 6 * 6 ? n : 8 * TMAX / 6 * 6, n1 = n - m, T = (m + 7) >> 3;
+	__shared__ int s_ldl_bad_r;
+	LDLH_T();
+	if (n1 > 0) {
+		const int lead = ldl_leading_panels<CW>(A, np, n, n1, inv, lds, lds_doubles);
+		if (lead == 1) return false;
+		if (lead == 2) return ldl_solve_blocked(A, np, n, x_out, inv, lds, lds_doubles);
+	}
+	LDLH_ADD(0);
+	double* S2 = lds;                                  // staged chunk of leading columns, tile-major: [(row in tile) * CW + q][tile row]
+	double* Sz = S2 + L_S2;                            // ... of the right-hand side
+	double* Pn2 = Sz + L_SZ;                           // the eliminated tile column: [buffer][(row in tile) * 8 + c][tile row]
+	double* dg = Pn2 + 2 * L_PN;                       // [buffer]: the diagonal tile's factor (64) and 1 / pivots (8)
+	double* Zp = dg + 2 * L_DG;                        // [buffer]: the right-hand side's eliminated entries of the column
+	double* xs = Zp + 2 * L_ZP;                        // the solution of the trailing block
+	double* part = xs + L_XS;                          // partial sums of the back-substitution, one 8-vector per tile column
+	// thread -> tile (I, J), I >= J, column-major
+	int J = 0, I = 0;
+	{ int idx = tid; while (J < T && idx >= T - J) { idx -= T - J; ++J; } I = J + idx; }
+	const bool active = J < T;
+	if (!active) { I = 0; J = 0; }
+	const bool diag = active && I == J;
+	double t[8][8], z[8];
+#pragma unroll
+	for (int a = 0; a < 8; ++a)
+#pragma unroll
+		for (int b = 0; b < 8; ++b) {
+			const int r = 8 * I + a, k = 8 * J + b;
+			const double v = A[(size_t)(n1 + min(r, m - 1)) * np + n1 + min(k, m - 1)];      // (unconditional loads on clamped indices)
+			t[a][b] = (r < m && k < m) ? v : (r == k ? 1.0 : 0.0);                             // the padding of the last tile row: identity
+		}
+#pragma unroll
+	for (int b = 0; b < 8; ++b) { const int k = 8 * J + b; const double v = A[(size_t)n * np + n1 + min(k, m - 1)]; z[b] = k < m ? v : 0.0; }
+	if (tid == 0) s_ldl_bad_r = 0;
+	if (n1 > 0) {
+		// ---- the leading columns' updates: chunks of CW columns, rows n1 .. n staged tile-major ----
+		for (int e = tid; e < L_S2; e += NT) S2[e] = 0.0;      // (the padding rows stay zero)
+		const int cnt = (m + 1) * CW;
+		for (int p0 = 0; p0 < n1; p0 += CW) {
+			const int nq = n1 - p0 < CW ? n1 - p0 : CW;
+			__syncthreads();
+			for (int e0 = 0; e0 < cnt; e0 += 8 * NT) {
+				double v[8];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) { const int e = min(e0 + tid + NT * j, cnt - 1), r = e / CW, q = e - r * CW; v[j] = A[(size_t)(n1 + r) * np + p0 + q]; }
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const int e = e0 + tid + NT * j, r = e / CW, q = e - r * CW;
+					const double x = q < nq ? v[j] : 0.0;
+					if (e < cnt) { if (r < m) S2[((r & 7) * CW + q) * TP + (r >> 3)] = x; else Sz[q] = x; }
+				}
+			}
+			__syncthreads();
+			if (active) {
+#pragma unroll 1
+				for (int q = 0; q < CW; ++q) {
+					const double ivq = q < nq ? inv[p0 + q] : 0.0;
+					double ui[8], uj[8];
+#pragma unroll
+					for (int a = 0; a < 8; ++a) { ui[a] = S2[(a * CW + q) * TP + I] * ivq; uj[a] = S2[(a * CW + q) * TP + J]; }
+#pragma unroll
+					for (int a = 0; a < 8; ++a)
+#pragma unroll
+						for (int b = 0; b < 8; ++b) t[a][b] -= ui[a] * uj[b];
+					if (diag) {
+						const double uz = Sz[q] * ivq;
+#pragma unroll
+						for (int b = 0; b < 8; ++b) z[b] -= uz * uj[b];
+					}
+				}
+			}
+		}
+	}
+	__syncthreads();
+	LDLH_ADD(1);
+	// ---- the factorisation, a tile column per step ----
+	for (int J0 = 0; J0 < T; ++J0) {
+		const int buf = J0 & 1;
+		double* dgb = dg + buf * L_DG;
+		double* pnb = Pn2 + buf * L_PN;
+		double* zpb = Zp + buf * L_ZP;
+		if (diag && J == J0) {
+			double iv[8];
+			bool bad = false;
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const double d = t[j][j];
+				bad |= !(d > 0.0);
+				iv[j] = rcp_f64(d);
+#pragma unroll
+				for (int i = j + 1; i < 8; ++i) {
+					const double f = t[i][j] * iv[j];
+#pragma unroll
+					for (int k = j + 1; k <= i; ++k) t[i][k] -= f * t[k][j];
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 7; ++j) {
+				const double f = z[j] * iv[j];
+#pragma unroll
+				for (int k = j + 1; k < 8; ++k) z[k] -= f * t[k][j];
+			}
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+#pragma unroll
+				for (int j = 0; j < i; ++j) dgb[8 * i + j] = t[i][j];
+				dgb[64 + i] = iv[i];
+				zpb[i] = z[i];
+				if (8 * J0 + i < m) inv[n1 + 8 * J0 + i] = iv[i];
+			}
+			if (bad) s_ldl_bad_r = 1;
+		}
+		__syncthreads();
+		LDLH_ADD(4);
+		if (s_ldl_bad_r) return false;                     // uniform
+		if (active && J == J0 && I > J0) {
+			double iv[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) iv[j] = dgb[64 + j];
+#pragma unroll
+			for (int j = 0; j < 7; ++j) {
+				double ud[8];
+#pragma unroll
+				for (int k = j + 1; k < 8; ++k) ud[k] = dgb[8 * k + j];
+#pragma unroll
+				for (int a = 0; a < 8; ++a) {
+					const double f = t[a][j] * iv[j];
+#pragma unroll
+					for (int k = j + 1; k < 8; ++k) t[a][k] -= f * ud[k];
+				}
+			}
+#pragma unroll
+			for (int a = 0; a < 8; ++a)
+#pragma unroll
+				for (int c = 0; c < 8; ++c) pnb[(8 * a + c) * TP + I] = t[a][c];
+		}
+		__syncthreads();
+		LDLH_ADD(5);
+		if (active && J > J0) {
+#pragma unroll 1
+			for (int c = 0; c < 8; ++c) {
+				const double ivc = dgb[64 + c];
+				double ui[8], uj[8];
+#pragma unroll
+				for (int a = 0; a < 8; ++a) { ui[a] = pnb[(8 * a + c) * TP + I] * ivc; uj[a] = pnb[(8 * a + c) * TP + J]; }
+#pragma unroll
+				for (int a = 0; a < 8; ++a)
+#pragma unroll
+					for (int b = 0; b < 8; ++b) t[a][b] -= ui[a] * uj[b];
+				if (diag) {
+					const double uz = zpb[c] * ivc;
+#pragma unroll
+					for (int b = 0; b < 8; ++b) z[b] -= uz * uj[b];
+				}
+			}
+		}
+	}
+	LDLH_ADD(6);
+	// ---- back-substitution x = D^-1 z - L'^T x, a tile row per step from the bottom ----
+	double acc[8];
+#pragma unroll
+	for (int b = 0; b < 8; ++b) acc[b] = 0.0;
+	for (int J0 = T - 1; J0 >= 0; --J0) {
+		if (diag && J == J0) {
+			double x[8];
+#pragma unroll
+			for (int b = 7; b >= 0; --b) {
+				double sacc = z[b] - acc[b];
+#pragma unroll
+				for (int a = b + 1; a < 8; ++a) sacc -= t[a][b] * x[a];
+				x[b] = sacc * (8 * J0 + b < m ? inv[n1 + 8 * J0 + b] : 1.0);
+				xs[8 * J0 + b] = x[b];
+			}
+		}
+		__syncthreads();
+		if (active && I == J0 && J < J0) {
+			double xa[8];
+#pragma unroll
+			for (int a = 0; a < 8; ++a) xa[a] = xs[8 * J0 + a];
+#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				double p = 0.0;
+#pragma unroll
+				for (int a = 0; a < 8; ++a) p += t[a][b] * xa[a];
+				part[8 * J + b] = p;
+			}
+		}
+		__syncthreads();
+		if (diag && J < J0) {
+#pragma unroll
+			for (int b = 0; b < 8; ++b) acc[b] += part[8 * J + b];
+		}
+	}
+	__syncthreads();
+	for (int k = tid; k < m; k += NT) x_out[n1 + k] = xs[k];
 	for (int k = tid; k < n1; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
 	__syncthreads();
-	for (int c = ((m - 1) >> 4) << 4; c >= 0; c -= 16) {
-		const int pw = m - c < 16 ? m - c : 16;
-		if (wave == 0) {
-			const int k = lane < pw ? lane : 0;
-			const double ivk = inv[n1 + c + k];
-			double u[16];
-#pragma unroll
-			for (int i = 0; i < 16; ++i) u[i] = (i < pw && i > k) ? SSK_PI(c + i, c + k) * ivk : 0.0;
-			double xv = x_out[n1 + c + k];
-#pragma unroll
-			for (int i = 15; i >= 1; --i) {
-				const double xi = readlane_f64(xv, i);
-				if (i < pw) xv -= u[i] * xi;                    // (u[i] = 0 for k >= i)
-			}
-			if (lane < pw) x_out[n1 + c + lane] = xv;
-		}
-		__syncthreads();
-		for (int k = tid; k < c; k += NT) {
-			double sacc = 0.0;
-#pragma unroll
-			for (int i = 0; i < 16; ++i) { const int ii = c + (i < pw ? i : 0); sacc += i < pw ? SSK_PI(ii, k) * x_out[n1 + ii] : 0.0; }
-			x_out[n1 + k] -= sacc * inv[n1 + k];
-		}
-		__syncthreads();
-	}
-	if (n1 == 0) { LDLH_ADD(3); return true; }
-	// ---- step B: the leading unknowns.  The leading columns of the rows come into LDS (the packed block is dead), scaled by the
-	//      pivots and zero from the diagonal on, as many rows at a time as fit (all of them up to ~45 edges), from the last row up.
-	//      Rows >= n1 are final: unknown k < n1 takes their terms in one pass (a lane per k); the leading triangle goes by 16-row
-	//      blocks as above ----
-	const int cr = lds_doubles / n1 < n ? lds_doubles / n1 : n;
-	for (int hi = n - 1; hi >= 1;) {
-		const int lo = hi - cr + 1 > 1 ? hi - cr + 1 : 1;
-		__syncthreads();
-		for (int t = tid; t < (hi - lo + 1) * n1; t += NT) {
-			const int r = t / n1, k = t - r * n1, i = lo + r;
-			const double av = A[(size_t)i * np + k] * inv[k];      // (unconditional load)
-			lds[t] = k < i ? av : 0.0;
-		}
-		__syncthreads();
-		const int ilo = lo > n1 ? lo : n1;
-		if (hi >= ilo) {
-			for (int k = tid; k < n1; k += NT) {
-				double s0 = 0.0, s1 = 0.0;
-				int i = ilo;
-				for (; i + 1 <= hi; i += 2) { s0 += lds[(i - lo) * n1 + k] * x_out[i]; s1 += lds[(i + 1 - lo) * n1 + k] * x_out[i + 1]; }
-				if (i <= hi) s0 += lds[(i - lo) * n1 + k] * x_out[i];
-				x_out[k] -= s0 + s1;
-			}
-			__syncthreads();
-		}
-		for (int bh = hi < n1 - 1 ? hi : n1 - 1; bh >= lo;) {
-			const int bl = bh - 15 > lo ? bh - 15 : lo, pw = bh - bl + 1;
-			if (wave == 0) {
-				const int k = lane < pw ? lane : 0;
-				double u[16];
-#pragma unroll
-				for (int i = 0; i < 16; ++i) u[i] = i < pw ? lds[(bl + i - lo) * n1 + bl + k] : 0.0;      // (zero for k >= i)
-				double xv = x_out[bl + k];
-#pragma unroll
-				for (int i = 15; i >= 1; --i) {
-					const double xi = readlane_f64(xv, i);
-					if (i < pw) xv -= u[i] * xi;
-				}
-				if (lane < pw) x_out[bl + lane] = xv;
-			}
-			__syncthreads();
-			for (int k = tid; k < bl; k += NT) {
-				double sacc = 0.0;
-#pragma unroll
-				for (int i = 0; i < 16; ++i) sacc += i < pw ? lds[(bl + (i < pw ? i : 0) - lo) * n1 + k] * x_out[bl + (i < pw ? i : 0)] : 0.0;
-				x_out[k] -= sacc;
-			}
-			__syncthreads();
-			bh = bl - 1;
-		}
-		hi = lo - 1;
-	}
+	bool ok_ = true;
+	if (n1 > 0) ok_ = ldl_backsub_leading(A, np, n, n1, x_out, inv, lds, lds_doubles);
 	LDLH_ADD(3);
-	return true;
+	return ok_;
 }
 #undef SSK_PI
+#ifndef SSK_LDL_BLOCKED
+#define SSK_LDL_BLOCKED 2               // the solver of systems in L2 scratch: 2 ldl_solve_regtile (default), 1 ldl_solve_blocked, 0 ldl_solve_hybrid (same-box A/B: tools/lm_variant.sh)
+#endif
+#if SSK_LDL_BLOCKED == 2
+#define SSK_LDL_BIG ldl_solve_regtile
+#elif SSK_LDL_BLOCKED == 1
+#define SSK_LDL_BIG ldl_solve_blocked
+#else
+#define SSK_LDL_BIG ldl_solve_hybrid
+#endif
 
 // G for a system in L2 scratch on the FP64 MATRIX CORES: the same right-looking LDL^T (U = L' D unscaled, border row = right-hand side)
 // blocked by 16 columns.  Per panel: the panel's columns of all rows below come into LDS once (pitch 17); one wave factorises the

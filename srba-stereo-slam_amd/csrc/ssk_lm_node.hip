@@ -745,7 +745,7 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 		STAMP(6);
 		bool ok = true;
 		if (n6 > 0) {
-			if constexpr (BIG) ok = ldl_solve_hybrid(Asys, np, n6, s_b, s_inv, reg, reg_doubles);
+			if constexpr (BIG) ok = SSK_LDL_BIG(Asys, np, n6, s_b, s_inv, reg, reg_doubles);
 			else ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
 		}
 		STAMP(7);

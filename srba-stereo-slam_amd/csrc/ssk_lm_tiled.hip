@@ -1098,7 +1098,7 @@ __device__ __forceinline__ bool assemble_and_solve(const lm_dev& D, const lm_win
 		if constexpr (GLOBAL_A) {
 			// LDLM (kernels lm_solve_*_ldlm_kernel, SSK_LM_LDL=mfma): 16-column panels with the trailing update on the matrix cores
 			if constexpr (LDLM) ok_ = ldl_solve_mfma16(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
-			else ok_ = ldl_solve_hybrid(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
+			else ok_ = SSK_LDL_BIG(A, np, n6, s_b, s_inv, lds_free, lds_free_doubles);
 		}
 		else ok_ = ldl_solve_lds(A, np, n6, s_b, s_inv);
 	}
@@ -1465,7 +1465,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 			{
 			printf("LMT stamps (cycles, window 0, %d iters, %d tiles): top %llu I1 %llu I2 %llu I3 %llu I4 %llu F2 %llu G %llu H %llu I+dec %llu\n", s_iters, W.n_tiles,
 			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
-			printf("LDL wave0 %llu waves1+ %llu step incl barrier %llu backsub %llu\n", g_ldl[0], g_ldl[1], g_ldl[2], g_ldl[3]);
+			printf("LDL wave0 %llu waves1+ %llu step incl barrier %llu backsub %llu | register tiles (thread 0 = tile (0, 0)): A + barrier %llu, B + barrier %llu, C of the last step %llu\n", g_ldl[0], g_ldl[1], g_ldl[2], g_ldl[3], g_ldl[4], g_ldl[5], g_ldl[6]);
 			printf("LMT F2 blocks %llu F2 gradient %llu G %llu (slots: pp %d schur %d)\n", g_f2g[0], g_f2g[1], g_f2g[2], D.pcl_off[W.pairo0 + W.n_pairs] - D.pcl_off[W.pairo0], D.scl_off[W.pairo0 + W.n_pairs] - D.scl_off[W.pairo0]);
 			printf("tile phases: I1 %llu I2a (landmarks) %llu I2b (incidences) %llu gradient (acc) %llu chunk tasks (all waves) %llu, of which wave 0 busy (acc) %llu\n", g_tst[0], g_tst[5], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
 			printf("chunk tasks after the barrier: wavefront 0 %llu tasks: items %llu, segmented sum + stores %llu | wavefront 4 %llu tasks: items %llu, sum + stores %llu\n", g_fine[2], g_fine[0], g_fine[1], g_fine[6], g_fine[4], g_fine[5]);
