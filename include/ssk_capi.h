@@ -480,6 +480,10 @@ int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out /* n_
 int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap);
 /* Current state of window w: edge_inv_pose [n_edges_total*12], lm_pos [n_lms_total*3]. */
 int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_inv_pose, double* lm_pos);
+/* Replaces the state of window w (either pointer may be NULL: that part is kept) -- the structure of a window can be built before its
+   initial values are final: the estimator's facade builds the local-area window of a keyframe beside the solve of its new edges
+   (the reference runs the two solves back to back on one set of structures: rba.define_new_keyframe, EST.cpp:782-784).  Synchronous. */
+int ssk_lm_batch_set_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, const double* edge_inv_pose, const double* lm_pos);
 /* Trace of window w: entries [max_iters]; delta_p [max_iters][6E], delta_f [max_iters][3L] (may be NULL). */
 int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_entry* entries, int cap,
                            double* delta_p, double* delta_f, int* n_entries);

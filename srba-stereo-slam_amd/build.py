@@ -97,7 +97,7 @@ def build_host(verbose=True):
                 raise RuntimeError("%s build failed:\n%s" % (name, r.stderr))
     if not os.path.exists(flib) or os.path.getmtime(flib) < max(os.path.getmtime(d) for d in lsrcs + hdrs + [LIB, os.path.join(ROOT, "include", "ssk_rba.h")]):
         cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include")] + lsrcs + \
-              ["-L", HERE, "-lssk_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-o", flib]
+              ["-L", HERE, "-lssk_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN", "-o", flib]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("libssk_facade.so build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
@@ -106,7 +106,7 @@ def build_host(verbose=True):
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
         return out
     cmd = [HIPCC, "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I", os.path.join(ROOT, "include")] + srcs + \
-          ["-L", HERE, "-lssk_hip", "-lz", "-Wl,-rpath,$ORIGIN/..", "-o", out]
+          ["-L", HERE, "-lssk_hip", "-lz", "-pthread", "-Wl,-rpath,$ORIGIN/..", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("host facade build failed:\n%s\n%s" % (" ".join(cmd), r.stderr))

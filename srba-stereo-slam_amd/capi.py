@@ -664,6 +664,12 @@ class LmBatch:
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_get_state(self.ctx.h, self.h_, int(w), _ptr(poses), _ptr(lms)))
         return poses, lms
 
+    def set_state(self, w, poses=None, lms=None):
+        """ssk_lm_batch_set_state: replaces the edge poses [n_edges, 12] and / or landmark positions [n_lms, 3] of window w (None: kept)."""
+        p = None if poses is None else np.ascontiguousarray(poses, dtype=np.float64)
+        l = None if lms is None else np.ascontiguousarray(lms, dtype=np.float64)
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_set_state(self.ctx.h, self.h_, int(w), _ptr(p) if p is not None else None, _ptr(l) if l is not None else None))
+
     def trace(self, w, cap=64):
         win = self.windows[w]
         E = int((np.asarray(win.edge_unknown_slot) >= 0).sum())

@@ -1372,6 +1372,28 @@ int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_in
 	return SSK_OK;
 }
 
+int ssk_lm_batch_set_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, const double* edge_inv_pose, const double* lm_pos)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || w < 0 || w >= b->n_windows) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_set_state: bad argument");
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const lm_win& H = b->hdr[w];
+	// both copies: the working state and the one ssk_lm_batch_reset restores
+	if (edge_inv_pose && H.n_edges) {
+		const size_t off = 12 * (size_t)H.edge0, bytes = sizeof(double) * 12 * (size_t)H.n_edges;
+		SSK_HIP(ctx, hipMemcpy(b->D.pose + off, edge_inv_pose, bytes, hipMemcpyHostToDevice));
+		SSK_HIP(ctx, hipMemcpy(const_cast<double*>(b->D.pose0) + off, edge_inv_pose, bytes, hipMemcpyHostToDevice));
+	}
+	if (lm_pos && H.n_lms) {
+		const size_t off = 3 * (size_t)H.lm0, bytes = sizeof(double) * 3 * (size_t)H.n_lms;
+		SSK_HIP(ctx, hipMemcpy(b->D.lm + off, lm_pos, bytes, hipMemcpyHostToDevice));
+		SSK_HIP(ctx, hipMemcpy(const_cast<double*>(b->D.lm0) + off, lm_pos, bytes, hipMemcpyHostToDevice));
+	}
+	return SSK_OK;
+}
+
 int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_entry* entries, int cap,
                            double* delta_p, double* delta_f, int* n_entries)
 {

@@ -7,6 +7,12 @@
 #include <functional>
 #include <limits>
 #include <queue>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <exception>
+#include <cstring>
+#include <cmath>
 
 namespace ssk {
 
@@ -189,25 +195,68 @@ void mySRBA::edge_creation_policy(TKeyFrameID new_kf_id, const new_kf_observatio
 	}
 }
 
-// one LM solve on the MI355X: window = opt_edges + everything the referenced observations' paths touch
-void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pair<TKeyFrameID, size_t>>& obs_refs,
-                    bool optimize_landmarks, bool robust, TOptimizeResults& res)
+struct mySRBA::worker_t {
+	std::mutex mu;
+	std::condition_variable cv;
+	std::function<void()> job;
+	bool busy = false, quit = false;
+	std::thread th;
+	worker_t() : th([this]() {
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			cv.wait(lk, [this]() { return quit || (busy && job); });
+			if (quit) return;
+			std::function<void()> f; f.swap(job);
+			lk.unlock(); f(); lk.lock();
+			busy = false;
+			cv.notify_all();
+		}
+	}) {}
+	void start(std::function<void()> f) { std::unique_lock<std::mutex> lk(mu); job = std::move(f); busy = true; cv.notify_all(); }
+	void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this]() { return !busy; }); }
+	~worker_t() { { std::unique_lock<std::mutex> lk(mu); quit = true; cv.notify_all(); } th.join(); }
+};
+
+// one LM solve on the MI355X, in two halves: lm_prepare builds the window (opt_edges + everything the referenced observations' paths
+// touch) and its device structures -- it only READS the map, so the local-area window of a keyframe can be prepared on a second
+// thread beside the solve of its new edges --, lm_finish solves and writes the result back.
+struct mySRBA::lm_job {
+	std::vector<int32_t> obs_lm, obs_path_off, path_edge, edge_slot, lm_slot;
+	std::vector<float> obs_px;
+	std::vector<double> pose, lmpos;
+	std::vector<TLandmarkID> lm_ids;
+	std::vector<size_t> edge_ids;
+	ssk_lm_window w{};
+	ssk_lm_batch* b = nullptr;
+	bool optimize_landmarks = false;
+	int n_opt = 0, rc = 0;
+	double build_ms = 0, create_ms = 0;
+	std::chrono::steady_clock::time_point t_launch;
+	~lm_job() { if (b) ssk_lm_batch_destroy(b); }
+};
+
+namespace {
+inline std::chrono::steady_clock::time_point lm_now() { return std::chrono::steady_clock::now(); }
+inline double lm_ms(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); }
+}
+
+mySRBA::~mySRBA() { delete m_worker; }
+
+void mySRBA::lm_prepare(lm_job& j, const std::set<size_t>& opt_edges, const std::vector<std::pair<TKeyFrameID, size_t>>& obs_refs, bool optimize_landmarks, bool create) const
 {
-	static const bool timing = std::getenv("SSK_FACADE_TIMING") != nullptr;
-	auto now = [] { return std::chrono::steady_clock::now(); };
-	auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-	const auto t0 = now();
+	const auto t0 = lm_now();
 	// per observing keyframe its depth-limited breadth-first tree, flattened: step towards the observer per keyframe id
 	// (edge == SIZE_MAX: not in the tree); the window is built once per keyframe over ~10^4 observations, so the lookups
 	// are arrays and hashes, not ordered maps
 	const size_t n_kf = num_keyframes();
 	std::map<TKeyFrameID, std::vector<step_t>> trees;
-	std::vector<int32_t> obs_lm, obs_path_off(1, 0), path_edge;
-	std::vector<float> obs_px;
+	std::vector<int32_t>& obs_lm = j.obs_lm; std::vector<int32_t>& obs_path_off = j.obs_path_off; std::vector<int32_t>& path_edge = j.path_edge;
+	std::vector<float>& obs_px = j.obs_px;
+	obs_path_off.assign(1, 0);
 	std::vector<int> edge_idx(m_state.k2k_edges.size(), -1);
 	std::unordered_map<TLandmarkID, int> lm_idx;
-	std::vector<TLandmarkID> lm_ids;
-	std::vector<size_t> edge_ids;
+	std::vector<TLandmarkID>& lm_ids = j.lm_ids;
+	std::vector<size_t>& edge_ids = j.edge_ids;
 	auto edge_index = [&](size_t e) { if (edge_idx[e] >= 0) return edge_idx[e]; const int i = (int)edge_ids.size(); edge_idx[e] = i; edge_ids.push_back(e); return i; };
 	for (size_t e : opt_edges) edge_index(e);
 	obs_lm.reserve(obs_refs.size()); obs_px.reserve(4 * obs_refs.size()); path_edge.reserve(4 * obs_refs.size());
@@ -237,11 +286,11 @@ void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pa
 		if (base >= n_kf || tree[base].edge == (size_t)-1) continue;   // farther than max_tree_depth: not in the spanning tree
 		steps.clear();                                       // from the base back to the observer
 		for (TKeyFrameID cur = base; cur != kf;) {
-			const step_t& s = tree[cur];
-			const k2k_edge_t& e = m_state.k2k_edges[s.edge];
-			// step observer-side keyframe s.prev <- cur: inv_pose applies when cur == from and prev == to
-			steps.push_back(edge_index(s.edge) * 2 + ((e.from == cur && e.to == s.prev) ? 0 : 1));
-			cur = s.prev;
+			const step_t& st = tree[cur];
+			const k2k_edge_t& e = m_state.k2k_edges[st.edge];
+			// step observer-side keyframe st.prev <- cur: inv_pose applies when cur == from and prev == to
+			steps.push_back(edge_index(st.edge) * 2 + ((e.from == cur && e.to == st.prev) ? 0 : 1));
+			cur = st.prev;
 		}
 		if (steps.size() > 8) continue;
 		path_edge.insert(path_edge.end(), steps.rbegin(), steps.rend());
@@ -251,44 +300,74 @@ void mySRBA::run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pa
 		obs_lm.push_back(ins.first->second);
 		obs_px.insert(obs_px.end(), o.px, o.px + 4);
 	}
-	std::vector<int32_t> edge_slot(edge_ids.size(), -1), lm_slot(lm_ids.size(), -1);
-	std::vector<double> pose(12 * edge_ids.size()), lmpos(3 * lm_ids.size());
+	j.edge_slot.assign(edge_ids.size(), -1); j.lm_slot.assign(lm_ids.size(), -1);
+	j.pose.resize(12 * edge_ids.size()); j.lmpos.resize(3 * lm_ids.size());
+	j.optimize_landmarks = optimize_landmarks;
 	int s = 0;
 	for (size_t i = 0; i < edge_ids.size(); ++i) {
-		if (opt_edges.count(edge_ids[i])) edge_slot[i] = s++;
-		std::memcpy(&pose[12 * i], m_state.k2k_edges[edge_ids[i]].inv_pose.m, 12 * sizeof(double));
+		if (opt_edges.count(edge_ids[i])) j.edge_slot[i] = s++;
+		std::memcpy(&j.pose[12 * i], m_state.k2k_edges[edge_ids[i]].inv_pose.m, 12 * sizeof(double));
 	}
+	j.n_opt = s;
 	for (size_t i = 0; i < lm_ids.size(); ++i) {
-		if (optimize_landmarks) lm_slot[i] = (int32_t)i;
-		std::memcpy(&lmpos[3 * i], m_state.unknown_lms[lm_ids[i]].pos, 3 * sizeof(double));
+		if (optimize_landmarks) j.lm_slot[i] = (int32_t)i;
+		std::memcpy(&j.lmpos[3 * i], m_state.unknown_lms.find(lm_ids[i])->second.pos, 3 * sizeof(double));
 	}
 	ssk_lm_window w;
-	w.n_edges_total = (int32_t)edge_ids.size(); w.edge_unknown_slot = edge_slot.data(); w.edge_inv_pose = pose.data();
-	w.n_lms_total = (int32_t)lm_ids.size(); w.lm_unknown_slot = lm_slot.data(); w.lm_pos = lmpos.data();
+	w.n_edges_total = (int32_t)edge_ids.size(); w.edge_unknown_slot = j.edge_slot.data(); w.edge_inv_pose = j.pose.data();
+	w.n_lms_total = (int32_t)lm_ids.size(); w.lm_unknown_slot = j.lm_slot.data(); w.lm_pos = j.lmpos.data();
 	w.n_obs = (int32_t)obs_lm.size(); w.obs_lm = obs_lm.data(); w.obs_px = obs_px.data();
 	w.obs_path_off = obs_path_off.data(); w.path_edge = path_edge.data();
-	const auto t1 = now();
-	ssk_lm_batch* b = nullptr;
-	m_ctx.check(ssk_lm_batch_create(m_ctx.get(), &w, 1, 0, &b), "ssk_lm_batch_create");
-	const auto t2 = now();
+	j.w = w;
+	j.build_ms = lm_ms(t0, lm_now());
+	if (create) lm_create(j);
+}
+
+// the device structures of a built window (HIP calls: kept on the caller's thread -- allocation and uploads from a second thread
+// beside a running solve measured slower than one after the other)
+void mySRBA::lm_create(lm_job& j) const
+{
+	const auto t1 = lm_now();
+	m_ctx.check(ssk_lm_batch_create(m_ctx.get(), &j.w, 1, 0, &j.b), "ssk_lm_batch_create");
+	j.create_ms = lm_ms(t1, lm_now());
+}
+
+// launches the solve.  refresh: the job was prepared before the map took its latest values (the solve of the new edges): upload the
+// current ones first
+void mySRBA::lm_launch(lm_job& j, bool robust, bool refresh)
+{
+	j.t_launch = lm_now();
+	int rc = SSK_OK;
+	if (refresh) {
+		for (size_t i = 0; i < j.edge_ids.size(); ++i) std::memcpy(&j.pose[12 * i], m_state.k2k_edges[j.edge_ids[i]].inv_pose.m, 12 * sizeof(double));
+		rc = ssk_lm_batch_set_state(m_ctx.get(), j.b, 0, j.pose.data(), nullptr);      // (the solve of the new edges holds the landmarks)
+	}
 	const ssk_lm_params prm = m_opts.lm(robust);
-	ssk_lm_result r;
-	int rc = ssk_lm_batch_run(m_ctx.get(), b, &prm);
-	if (rc == SSK_OK) rc = ssk_lm_batch_results(m_ctx.get(), b, &r);
-	const auto t3 = now();
-	if (rc == SSK_OK) rc = ssk_lm_batch_get_state(m_ctx.get(), b, 0, pose.data(), lmpos.data());
-	ssk_lm_batch_destroy(b);
-	const auto t4 = now();
-	this->timing.window_build_ms += ms(t0, t1); this->timing.batch_create_ms += ms(t1, t2); this->timing.solve_ms += ms(t2, t3);
-	this->timing.readback_ms += ms(t3, t4); this->timing.solves++; this->timing.iters += rc == SSK_OK ? (size_t)r.iters : 0;
-	this->timing.max_opt_edges = std::max(this->timing.max_opt_edges, (size_t)s); this->timing.max_obs = std::max(this->timing.max_obs, obs_lm.size());
+	if (rc == SSK_OK) rc = ssk_lm_batch_run(m_ctx.get(), j.b, &prm);
+	j.rc = rc;
+}
+
+// waits for the solve and writes its result to the map
+void mySRBA::lm_collect(lm_job& j, TOptimizeResults& res)
+{
+	static const bool timing = std::getenv("SSK_FACADE_TIMING") != nullptr;
+	int rc = j.rc;
+	ssk_lm_result r{};
+	if (rc == SSK_OK) rc = ssk_lm_batch_results(m_ctx.get(), j.b, &r);
+	const auto t3 = lm_now();
+	if (rc == SSK_OK) rc = ssk_lm_batch_get_state(m_ctx.get(), j.b, 0, j.pose.data(), j.lmpos.data());
+	ssk_lm_batch_destroy(j.b); j.b = nullptr;
+	const auto t4 = lm_now();
+	this->timing.window_build_ms += j.build_ms; this->timing.batch_create_ms += j.create_ms; this->timing.solve_ms += lm_ms(j.t_launch, t3);
+	this->timing.readback_ms += lm_ms(t3, t4); this->timing.solves++; this->timing.iters += rc == SSK_OK ? (size_t)r.iters : 0;
+	this->timing.max_opt_edges = std::max(this->timing.max_opt_edges, (size_t)j.n_opt); this->timing.max_obs = std::max(this->timing.max_obs, j.obs_lm.size());
 	if (timing) std::fprintf(stderr, "[facade timing]   run_lm (%d edges opt, %zu obs): window build %.2f ms, batch create %.2f ms, solve %.2f ms (%d iters), state+destroy %.2f ms\n",
-	                         s, obs_lm.size(), ms(t0, t1), ms(t1, t2), ms(t2, t3), (int)r.iters, ms(t3, now()));
+	                         j.n_opt, j.obs_lm.size(), j.build_ms, j.create_ms, lm_ms(j.t_launch, t3), (int)r.iters, lm_ms(t3, lm_now()));
 	m_ctx.check(rc, "LM solve");
-	for (size_t i = 0; i < edge_ids.size(); ++i)
-		if (edge_slot[i] >= 0) std::memcpy(m_state.k2k_edges[edge_ids[i]].inv_pose.m, &pose[12 * i], 12 * sizeof(double));
-	if (optimize_landmarks)
-		for (size_t i = 0; i < lm_ids.size(); ++i) std::memcpy(m_state.unknown_lms[lm_ids[i]].pos, &lmpos[3 * i], 3 * sizeof(double));
+	for (size_t i = 0; i < j.edge_ids.size(); ++i)
+		if (j.edge_slot[i] >= 0) std::memcpy(m_state.k2k_edges[j.edge_ids[i]].inv_pose.m, &j.pose[12 * i], 12 * sizeof(double));
+	if (j.optimize_landmarks)
+		for (size_t i = 0; i < j.lm_ids.size(); ++i) std::memcpy(m_state.unknown_lms[j.lm_ids[i]].pos, &j.lmpos[3 * i], 3 * sizeof(double));
 	res.total_sqr_error_init = r.err_init; res.total_sqr_error_final = r.err_final;
 	res.num_observations = (size_t)r.n_obs; res.num_iters = (size_t)r.iters;
 	res.obs_rmse = r.n_obs ? std::sqrt(r.err_final / r.n_obs) : 0.0;
@@ -321,15 +400,15 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 	}
 	if (!run_local_optimization || new_edges.empty()) return;
 	// stage 1: optimize_edges on the new edges only, with the new keyframe's observations, landmarks held
-	{
-		std::set<size_t> opt;
-		for (const auto& e : new_edges) opt.insert(e.id);
-		std::vector<std::pair<TKeyFrameID, size_t>> refs;
-		for (size_t i = 0; i < m_state.kf_observations[new_kf_id].size(); ++i) refs.push_back(std::make_pair(new_kf_id, i));
-		run_lm(opt, refs, false, parameters.use_robust_kernel_stage1, out.optimize_results_stg1);
-	}
 	// stage 2: optimize_local_area(root = new KF, depth = max_optimize_depth)
-	{
+	// The local-area window (~10^4 observations, ~0.6 ms of host work) is collected on a second thread while stage 1 is prepared and
+	// solved; it reads the map only, stage 1's result is written to the map after the join and uploaded to the prepared window
+	// -- on request (SSK_FACADE_OVERLAP=1).  Measured on one box, 401 frames, ms per keyframe frame: one after the other 8.53 / 8.54, overlapped
+	// 8.30 / 8.98 (the hand-over costs what it saves); with the batch creation on the second thread too: 9.13 (allocation and uploads beside a
+	// running solve serialise in the runtime).  Default: one after the other.
+	static const bool overlap = std::getenv("SSK_FACADE_OVERLAP") && std::atoi(std::getenv("SSK_FACADE_OVERLAP")) != 0;
+	lm_job j2;
+	auto prepare_stage2 = [&]() {
 		// (the device solver's reduced system holds 128 edges, include/ssk_capi.h: a local area beyond that -- a revisit that ties several
 		// old local maps to the new one within the depth -- is optimised to the largest depth that fits.  SRBA has no such limit.)
 		std::map<TKeyFrameID, step_t> area;
@@ -344,8 +423,29 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 		std::vector<std::pair<TKeyFrameID, size_t>> refs;
 		for (const auto& kv : area)
 			for (size_t i = 0; i < m_state.kf_observations[kv.first].size(); ++i) refs.push_back(std::make_pair(kv.first, i));
-		run_lm(opt, refs, true, parameters.use_robust_kernel, out.optimize_results);
+		lm_prepare(j2, opt, refs, true, !overlap);
+	};
+	std::exception_ptr worker_error;
+	if (overlap && !m_worker) m_worker = new worker_t();
+	if (overlap) m_worker->start([&]() { try { prepare_stage2(); } catch (...) { worker_error = std::current_exception(); } });
+	struct joiner { worker_t* w; ~joiner() { if (w) w->wait(); } } join_on_exit{overlap ? m_worker : nullptr};
+	{
+		std::set<size_t> opt;
+		for (const auto& e : new_edges) opt.insert(e.id);
+		std::vector<std::pair<TKeyFrameID, size_t>> refs;
+		for (size_t i = 0; i < m_state.kf_observations[new_kf_id].size(); ++i) refs.push_back(std::make_pair(new_kf_id, i));
+		lm_job j1;
+		lm_prepare(j1, opt, refs, false, true);
+		lm_launch(j1, parameters.use_robust_kernel_stage1, false);
+		// (lm_collect writes the new edges' poses to the map: only after the worker has stopped reading it)
+		if (overlap) m_worker->wait();
+		if (worker_error) std::rethrow_exception(worker_error);
+		lm_collect(j1, out.optimize_results_stg1);
 	}
+	if (!overlap) prepare_stage2();
+	else lm_create(j2);
+	lm_launch(j2, parameters.use_robust_kernel, overlap);
+	lm_collect(j2, out.optimize_results);
 }
 
 }  // namespace ssk

@@ -58,6 +58,9 @@ public:
 	struct TTiming { double window_build_ms = 0, batch_create_ms = 0, solve_ms = 0, readback_ms = 0; size_t solves = 0, iters = 0, max_opt_edges = 0, max_obs = 0; } timing;
 
 	mySRBA(Context& ctx, const TSRBAStereoSLAMOptions& opts);
+	~mySRBA();
+	mySRBA(const mySRBA&) = delete;
+	mySRBA& operator=(const mySRBA&) = delete;
 
 	inline void setInitialKFPose(const Pose3D& pose) { m_initial_kf_pose = pose; }  // SRBA.h:95-97
 	void loopClosureDetected(bool _lc = true) { m_lc = _lc; }                       // SRBA.h:85-87 (set by the estimator, read by nobody)
@@ -101,8 +104,14 @@ private:
 	// breadth-first tree from `root`: for every keyframe within max_depth the step towards the root
 	struct step_t { TKeyFrameID prev; size_t edge; size_t dist; };
 	void bfs(TKeyFrameID root, size_t max_depth, std::map<TKeyFrameID, step_t>& out) const;
-	void run_lm(const std::set<size_t>& opt_edges, const std::vector<std::pair<TKeyFrameID, size_t>>& obs_refs,
-	            bool optimize_landmarks, bool robust, TOptimizeResults& res);
+	struct lm_job;
+	// one persistent helper thread (a thread's first HIP call costs about a millisecond: not one thread per keyframe)
+	struct worker_t;
+	worker_t* m_worker = nullptr;
+	void lm_prepare(lm_job& j, const std::set<size_t>& opt_edges, const std::vector<std::pair<TKeyFrameID, size_t>>& obs_refs, bool optimize_landmarks, bool create) const;
+	void lm_create(lm_job& j) const;
+	void lm_launch(lm_job& j, bool robust, bool refresh);
+	void lm_collect(lm_job& j, TOptimizeResults& res);
 
 	Context& m_ctx;
 	TSRBAStereoSLAMOptions m_opts;

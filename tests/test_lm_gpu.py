@@ -213,6 +213,31 @@ def test_lm_kernel_name_follows_the_batch(ctx, monkeypatch):
         b.close()
 
 
+def test_lm_set_state_equals_a_batch_built_on_that_state(ctx):
+    """ssk_lm_batch_set_state: a batch whose structures were built on other initial values (the facade prepares the local-area window
+    beside the solve of the new edges) and then given the final ones solves bit for bit like a batch built on them -- also after a reset."""
+    import copy
+    from ssk_amd import capi
+    win, gt = sl.make_submap_problem(4, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)
+    prm = to_capi(sl.make_params())
+    ref = capi.LmBatch(ctx, [win]); ref.run(prm); r0 = ref.results()[0]; p0, l0 = ref.state(0); ref.close()
+    stale = copy.copy(win)
+    poses = np.array(win.edge_inv_pose, dtype=np.float64).reshape(-1, 12)
+    lms = np.array(win.lm_pos, dtype=np.float64).reshape(-1, 3)
+    stale.edge_inv_pose = (poses + 0.05).reshape(np.shape(win.edge_inv_pose))
+    stale.lm_pos = (lms * 1.1).reshape(np.shape(win.lm_pos))
+    b = capi.LmBatch(ctx, [stale])
+    b.set_state(0, poses, lms)
+    for _ in range(2):
+        b.run(prm)
+        r = b.results()[0]
+        p, l = b.state(0)
+        assert (r.iters, r.accepted, r.err_init, r.err_final) == (r0.iters, r0.accepted, r0.err_init, r0.err_final)
+        assert np.array_equal(p, p0) and np.array_equal(l, l0)
+        b.reset()
+    b.close()
+
+
 def run_plain(ctx, wins, prm):
     """No trace: (results, [(poses, lms)]) of a batch."""
     from ssk_amd import capi
