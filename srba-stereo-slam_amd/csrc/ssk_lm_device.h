@@ -190,6 +190,7 @@ __device__ __forceinline__ void ldl_backsub_wave(const double* A, int np, int n,
 
 #ifdef SSK_LM_STAMPS
 __device__ unsigned long long g_ldl[8];
+__device__ unsigned long long g_ldl_w[8][4];      // register-tile solver, per wavefront: cycles inside A, B, C, at the two barriers
 #define LDL_T0() const unsigned long long ldl_t0_ = __builtin_amdgcn_s_memtime()
 #define LDL_ADD(i, who) do { if (threadIdx.x == (who) && blockIdx.x == 0) g_ldl[i] += __builtin_amdgcn_s_memtime() - ldl_t0_; } while (0)
 #else
@@ -198,9 +199,13 @@ __device__ unsigned long long g_ldl[8];
 #endif
 #ifdef SSK_LM_STAMPS
 #define LDLH_T() unsigned long long ldlh_t_ = __builtin_amdgcn_s_memtime()
+#define LDLW_T() unsigned long long ldlw_t_ = __builtin_amdgcn_s_memtime()
+#define LDLW_ADD(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_ldl_w[threadIdx.x >> 6][i] += t_ - ldlw_t_; ldlw_t_ = t_; } while (0)
 #define LDLH_ADD(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_ldl[i] += t_ - ldlh_t_; ldlh_t_ = t_; } } while (0)
 #else
 #define LDLH_T() do {} while (0)
+#define LDLW_T() do {} while (0)
+#define LDLW_ADD(i) do {} while (0)
 #define LDLH_ADD(i) do {} while (0)
 #endif
 // index map of the in-LDS factorisation of a packed lower triangle (row i at i (i + 1) / 2)
@@ -1242,6 +1247,7 @@ __device__ __forceinline__ bool ldl_solve_regtile(double* __restrict__ A, int np
 	__syncthreads();
 	LDLH_ADD(1);
 	// ---- the factorisation, a tile column per step ----
+	LDLW_T();
 	for (int J0 = 0; J0 < T; ++J0) {
 		const int buf = J0 & 1;
 		double* dgb = dg + buf * L_DG;
@@ -1278,7 +1284,9 @@ __device__ __forceinline__ bool ldl_solve_regtile(double* __restrict__ A, int np
 			}
 			if (bad) s_ldl_bad_r = 1;
 		}
+		LDLW_ADD(0);
 		__syncthreads();
+		LDLW_ADD(3);
 		LDLH_ADD(4);
 		if (s_ldl_bad_r) return false;                     // uniform
 		if (active && J == J0 && I > J0) {
@@ -1302,9 +1310,14 @@ __device__ __forceinline__ bool ldl_solve_regtile(double* __restrict__ A, int np
 #pragma unroll
 				for (int c = 0; c < 8; ++c) pnb[(8 * a + c) * TP + I] = t[a][c];
 		}
+		LDLW_ADD(1);
 		__syncthreads();
+		LDLW_ADD(3);
 		LDLH_ADD(5);
 		if (active && J > J0) {
+			// (not software-pipelined: with the operands of column c + 1 in flight beside the 64 multiply-adds of column c the tile, the
+			//  right-hand side and two operand sets exceed the 256 registers of two waves per SIMD -- the compiler spills z inside the loop,
+			//  7.7 ms against 4.05 ms for one depth-5 window)
 #pragma unroll 1
 			for (int c = 0; c < 8; ++c) {
 				const double ivc = dgb[64 + c];
@@ -1322,6 +1335,7 @@ __device__ __forceinline__ bool ldl_solve_regtile(double* __restrict__ A, int np
 				}
 			}
 		}
+		LDLW_ADD(2);
 	}
 	LDLH_ADD(6);
 	// ---- back-substitution x = D^-1 z - L'^T x, a tile row per step from the bottom ----

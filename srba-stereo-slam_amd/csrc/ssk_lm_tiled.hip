@@ -1465,6 +1465,7 @@ __device__ __forceinline__ void lm_tiled_body(const lm_dev& D, const lm_cam& P_a
 			{
 			printf("LMT stamps (cycles, window 0, %d iters, %d tiles): top %llu I1 %llu I2 %llu I3 %llu I4 %llu F2 %llu G %llu H %llu I+dec %llu\n", s_iters, W.n_tiles,
 			       s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8]);
+			for (int w_ = 0; w_ < 8; ++w_) printf("register tiles, wavefront %d: A %llu B %llu C %llu barriers %llu\n", w_, g_ldl_w[w_][0], g_ldl_w[w_][1], g_ldl_w[w_][2], g_ldl_w[w_][3]);
 			printf("LDL wave0 %llu waves1+ %llu step incl barrier %llu backsub %llu | register tiles (thread 0 = tile (0, 0)): A + barrier %llu, B + barrier %llu, C of the last step %llu\n", g_ldl[0], g_ldl[1], g_ldl[2], g_ldl[3], g_ldl[4], g_ldl[5], g_ldl[6]);
 			printf("LMT F2 blocks %llu F2 gradient %llu G %llu (slots: pp %d schur %d)\n", g_f2g[0], g_f2g[1], g_f2g[2], D.pcl_off[W.pairo0 + W.n_pairs] - D.pcl_off[W.pairo0], D.scl_off[W.pairo0 + W.n_pairs] - D.scl_off[W.pairo0]);
 			printf("tile phases: I1 %llu I2a (landmarks) %llu I2b (incidences) %llu gradient (acc) %llu chunk tasks (all waves) %llu, of which wave 0 busy (acc) %llu\n", g_tst[0], g_tst[5], g_tst[1], g_tst[2], g_tst[3], g_tst[4]);
