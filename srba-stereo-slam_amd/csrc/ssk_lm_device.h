@@ -1382,6 +1382,159 @@ __device__ __forceinline__ bool ldl_solve_regtile(double* __restrict__ A, int np
 	LDLH_ADD(3);
 	return ok_;
 }
+// The register-tile factorisation for a reduced system whose block accumulators are in LDS (the node kernel, E <= 14): 4 x 4 tiles, one
+// per thread (T (T + 1) / 2 <= NT tiles, T = ceil(6E / 4) <= 22 at 256 threads), loaded STRAIGHT from the 6 x 6 block accumulators Hb
+// (H(6e + a, 6e2 + b), e <= e2, at 36 pid + 6a + b; lambda added on the diagonal; right-hand side g) -- no dense copy of the system.
+// Steps A / B / C and the back-substitution as in ldl_solve_regtile; a step costs ~1.8 k cycles against ~7 k of the in-LDS six-column
+// step (whose rank-6 update is bound by LDS bandwidth).  lds: 2 x (16 T' + 24) + 8 T' doubles, T' = 23.
+__device__ __forceinline__ bool ldl_solve_tiles4_lds(const double* Hb, const double* g, double lambda, int n, double* x_out, double* lds)
+{
+	constexpr int TP = 23;
+	constexpr int L_PN = 16 * TP, L_DG = 20, L_ZP = 4;
+	const int tid = threadIdx.x, T = (n + 3) >> 2;
+	__shared__ int s_ldl_bad_t;
+	double* Pn2 = lds;                                 // [buffer][(row in tile) * 4 + c][tile row]
+	double* dg = Pn2 + 2 * L_PN;                       // [buffer]: the diagonal tile's factor (16) and 1 / pivots (4)
+	double* Zp = dg + 2 * L_DG;                        // [buffer]: the right-hand side's eliminated entries of the column
+	double* xs = Zp + 2 * L_ZP;                        // the solution (4 T)
+	double* part = xs + 4 * TP;                        // partial sums of the back-substitution, one 4-vector per tile column
+	int J = 0, I = 0;
+	{ int idx = tid; while (J < T && idx >= T - J) { idx -= T - J; ++J; } I = J + idx; }
+	const bool active = J < T;
+	if (!active) { I = 0; J = 0; }
+	const bool diag = active && I == J;
+	double t[4][4], z[4], ivd[4];
+#pragma unroll
+	for (int a = 0; a < 4; ++a)
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int r0 = 4 * I + a, c0 = 4 * J + b;
+			const int r = min(max(r0, c0), n - 1), c = min(min(r0, c0), n - 1);      // the stored triangle: H(c, r), c <= r
+			const int er = r / 6, ec = c / 6;
+			const double v = Hb[36 * (er * (er + 1) / 2 + ec) + 6 * (c - 6 * ec) + (r - 6 * er)];
+			t[a][b] = (r0 < n && c0 < n) ? (r0 == c0 ? v + lambda : v) : (r0 == c0 ? 1.0 : 0.0);
+		}
+#pragma unroll
+	for (int b = 0; b < 4; ++b) { const int c0 = 4 * J + b; const double v = g[min(c0, n - 1)]; z[b] = c0 < n ? v : 0.0; ivd[b] = 1.0; }
+	if (tid == 0) s_ldl_bad_t = 0;
+	__syncthreads();
+	for (int J0 = 0; J0 < T; ++J0) {
+		const int buf = J0 & 1;
+		double* dgb = dg + buf * L_DG;
+		double* pnb = Pn2 + buf * L_PN;
+		double* zpb = Zp + buf * L_ZP;
+		if (diag && J == J0) {
+			bool bad = false;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const double d = t[j][j];
+				bad |= !(d > 0.0);
+				ivd[j] = rcp_f64(d);
+#pragma unroll
+				for (int i = j + 1; i < 4; ++i) {
+					const double f = t[i][j] * ivd[j];
+#pragma unroll
+					for (int k = j + 1; k <= i; ++k) t[i][k] -= f * t[k][j];
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				const double f = z[j] * ivd[j];
+#pragma unroll
+				for (int k = j + 1; k < 4; ++k) z[k] -= f * t[k][j];
+			}
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+#pragma unroll
+				for (int j = 0; j < i; ++j) dgb[4 * i + j] = t[i][j];
+				dgb[16 + i] = ivd[i];
+				zpb[i] = z[i];
+			}
+			if (bad) s_ldl_bad_t = 1;
+		}
+		__syncthreads();
+		if (s_ldl_bad_t) return false;                     // uniform
+		if (active && J == J0 && I > J0) {
+			double iv[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) iv[j] = dgb[16 + j];
+#pragma unroll
+			for (int j = 0; j < 3; ++j) {
+				double ud[4];
+#pragma unroll
+				for (int k = j + 1; k < 4; ++k) ud[k] = dgb[4 * k + j];
+#pragma unroll
+				for (int a = 0; a < 4; ++a) {
+					const double f = t[a][j] * iv[j];
+#pragma unroll
+					for (int k = j + 1; k < 4; ++k) t[a][k] -= f * ud[k];
+				}
+			}
+#pragma unroll
+			for (int a = 0; a < 4; ++a)
+#pragma unroll
+				for (int c = 0; c < 4; ++c) pnb[(4 * a + c) * TP + I] = t[a][c];
+		}
+		__syncthreads();
+		if (active && J > J0) {
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const double ivc = dgb[16 + c];
+				double ui[4], uj[4];
+#pragma unroll
+				for (int a = 0; a < 4; ++a) { ui[a] = pnb[(4 * a + c) * TP + I] * ivc; uj[a] = pnb[(4 * a + c) * TP + J]; }
+#pragma unroll
+				for (int a = 0; a < 4; ++a)
+#pragma unroll
+					for (int b = 0; b < 4; ++b) t[a][b] -= ui[a] * uj[b];
+				if (diag) {
+					const double uz = zpb[c] * ivc;
+#pragma unroll
+					for (int b = 0; b < 4; ++b) z[b] -= uz * uj[b];
+				}
+			}
+		}
+	}
+	// ---- back-substitution x = D^-1 z - L'^T x, a tile row per step from the bottom ----
+	double acc[4];
+#pragma unroll
+	for (int b = 0; b < 4; ++b) acc[b] = 0.0;
+	for (int J0 = T - 1; J0 >= 0; --J0) {
+		if (diag && J == J0) {
+			double x[4];
+#pragma unroll
+			for (int b = 3; b >= 0; --b) {
+				double sacc = z[b] - acc[b];
+#pragma unroll
+				for (int a = b + 1; a < 4; ++a) sacc -= t[a][b] * x[a];
+				x[b] = sacc * ivd[b];
+				xs[4 * J0 + b] = x[b];
+			}
+		}
+		__syncthreads();
+		if (active && I == J0 && J < J0) {
+			double xa[4];
+#pragma unroll
+			for (int a = 0; a < 4; ++a) xa[a] = xs[4 * J0 + a];
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				double p = 0.0;
+#pragma unroll
+				for (int a = 0; a < 4; ++a) p += t[a][b] * xa[a];
+				part[4 * J + b] = p;
+			}
+		}
+		__syncthreads();
+		if (diag && J < J0) {
+#pragma unroll
+			for (int b = 0; b < 4; ++b) acc[b] += part[4 * J + b];
+		}
+	}
+	__syncthreads();
+	for (int k = tid; k < n; k += NT) x_out[k] = xs[k];
+	__syncthreads();
+	return true;
+}
 #undef SSK_PI
 #ifndef SSK_LDL_BLOCKED
 #define SSK_LDL_BLOCKED 2               // the solver of systems in L2 scratch: 2 ldl_solve_regtile (default), 1 ldl_solve_blocked, 0 ldl_solve_hybrid (same-box A/B: tools/lm_variant.sh)

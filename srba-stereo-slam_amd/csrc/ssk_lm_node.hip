@@ -363,6 +363,9 @@ __device__ __forceinline__ void nd_item_apply(const nd_item_ops& o, double sg, d
 #ifndef ND_SUMROWS
 #define ND_SUMROWS 4
 #endif
+#ifndef ND_TILES4
+#define ND_TILES4 1                     // the reduced system of windows with E <= 14 as 4 x 4 register tiles (0: dense copy + ldl_solve_lds)
+#endif
 #ifndef ND_HB_ATOMIC
 #define ND_HB_ATOMIC 1                  // block accumulators: 1 = ds_add_f64 per component, 0 = 16-byte loads, adds, 16-byte stores
 #endif
@@ -725,28 +728,34 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 			if (tid == 0) s_lambda = P.tau * mx;
 			continue;
 		}
-		// ---- the reduced system: A = H_pp - S + lambda I over the dead records, border row = reduced gradient; LDL^T ----
-		double* Asys = BIG ? D.Hred + W.h0 : reg;
-		for (int it = tid; it < 36 * n_pairs; it += NT) {
-			const int pid = it / 36, ab = it - 36 * pid, a = ab / 6, b = ab - 6 * a;
-			int e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
-			while ((e2 + 1) * (e2 + 2) / 2 <= pid) ++e2;
-			while (e2 * (e2 + 1) / 2 > pid) --e2;
-			const int e = pid - e2 * (e2 + 1) / 2;
-			if (e == e2 && a > b) continue;
-			const int row = 6 * e + a, col = 6 * e2 + b;
-			double v = BIG ? __hip_atomic_load(Hb + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Hb[it];
-			if (row == col) v += lambda;
-			Asys[(size_t)row * np + col] = v;
-			Asys[(size_t)col * np + row] = v;
-		}
-		for (int i = tid; i < n6; i += NT) Asys[(size_t)n6 * np + i] = g_acc[i];
-		__syncthreads();
-		STAMP(6);
+		// ---- the reduced system: A = H_pp - S + lambda I, border row = reduced gradient; LDL^T ----
 		bool ok = true;
-		if (n6 > 0) {
-			if constexpr (BIG) ok = SSK_LDL_BIG(Asys, np, n6, s_b, s_inv, reg, reg_doubles);
-			else ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
+		if (!BIG && ND_TILES4 && 2 * ((n6 + 3) >> 2) * (((n6 + 3) >> 2) + 1) <= 4 * NT) {
+			// register tiles straight from the block accumulators (no dense copy)
+			STAMP(6);
+			if (n6 > 0) ok = ldl_solve_tiles4_lds(Hb, g_acc, lambda, n6, s_b, reg);
+		} else {
+			double* Asys = BIG ? D.Hred + W.h0 : reg;
+			for (int it = tid; it < 36 * n_pairs; it += NT) {
+				const int pid = it / 36, ab = it - 36 * pid, a = ab / 6, b = ab - 6 * a;
+				int e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
+				while ((e2 + 1) * (e2 + 2) / 2 <= pid) ++e2;
+				while (e2 * (e2 + 1) / 2 > pid) --e2;
+				const int e = pid - e2 * (e2 + 1) / 2;
+				if (e == e2 && a > b) continue;
+				const int row = 6 * e + a, col = 6 * e2 + b;
+				double v = BIG ? __hip_atomic_load(Hb + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : Hb[it];
+				if (row == col) v += lambda;
+				Asys[(size_t)row * np + col] = v;
+				Asys[(size_t)col * np + row] = v;
+			}
+			for (int i = tid; i < n6; i += NT) Asys[(size_t)n6 * np + i] = g_acc[i];
+			__syncthreads();
+			STAMP(6);
+			if (n6 > 0) {
+				if constexpr (BIG) ok = SSK_LDL_BIG(Asys, np, n6, s_b, s_inv, reg, reg_doubles);
+				else ok = ldl_solve_lds(reg, np, n6, s_b, s_inv);
+			}
 		}
 		STAMP(7);
 		double dpn = 0, dfn = 0, err_new = s_err;
