@@ -5,6 +5,7 @@
 #                                      average duration in the un-counted stats pass and the git head
 #   r03_pmc_sq.json                    one --pmc pass of SQ counters: VALU / LDS activity of every kernel (tools/pmc_sq.py)
 #   r03_pmc_lm_wave_time.json          where the LM kernel's wave time goes (tools/pmc_lm.sh: four --pmc passes)
+#   r03_lm_depth5_kernel_stats.csv / r03_lm_depth5_pmc.json   the depth-5 LM batch (tools/lm_depth5_run.py): --stats pass, FP64 / wave counter pass
 set -u
 export TMPDIR=/tmp
 ROOTD=$PWD
@@ -24,4 +25,12 @@ cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/r03_kernel_stats_
 tail -1 $OUT/stats.log | cut -c1-400
 bash tools/pmc_lm.sh r03 > $OUT/pmc_lm.log 2>&1
 cp gpurun_out/pmc_lm_r03/summary.json $OUT/r03_pmc_lm_wave_time.json
+# the depth-5 LM batch (bench.py's lm_depth5 object): per-kernel time and executed FP64 work
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d5_stats -o s -- python3 $ROOTD/tools/lm_depth5_run.py > $OUT/d5_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "lm_solve" --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/d5_pmc -o p -- python3 $ROOTD/tools/lm_depth5_run.py > $OUT/d5_pmc.log 2>&1
+cd $ROOTD
+cp $(find $OUT/d5_stats -name "*kernel_stats.csv" | head -1) $OUT/r03_lm_depth5_kernel_stats.csv
+python3 tools/lm_depth5_run.py $OUT/d5_pmc > $OUT/r03_lm_depth5_pmc.json
+tail -1 $OUT/d5_stats.log | cut -c1-300
 ls -la $OUT/*.json $OUT/*.csv
