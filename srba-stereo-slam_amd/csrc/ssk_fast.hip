@@ -11,10 +11,9 @@
 //            test on the 4 compass ring pixels of all four (a 9-arc holds two adjacent compass points); survivors
 //            are appended to an LDS queue with ONE ds atomic per wave (ballot + lane prefix), so the later
 //            phases run on dense lanes;
-//   phase B1 queued pixels: 16-bit brighter / darker ring masks, exact "9 contiguous" test by mask doubling
-//            and shifts (~80 ops) -> second queue of real corners (a few % of the pixels);
-//   phase B  corners only: exact score s-1 (max over the 16 arcs of 9 of the min signed difference, by
-//            min/max doubling) -> 8-bit score tile in LDS;
+//   phase B  queued pixels: exact score s-1 (max over the 16 arcs of 9 of the min signed difference, by min/max doubling on packed
+//            16-bit pairs); score > threshold is the corner test (round 3: the separate 16-bit ring-mask test in front of it cost as
+//            much per pixel as the score) -> 8-bit score tile in LDS + second queue of real corners (a few % of the pixels);
 //   phase C  strict 3x3 NMS, 4 pixels per lane behind one dword read of their scores (all-zero groups skip),
 //            survivors packed score<<24|(4095-y)<<12|(4095-x) into an LDS list; ONE global atomicAdd per
 //            workgroup reserves the output range in the image's candidate list.
@@ -262,7 +261,9 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		__syncthreads();
 
 		FSTAMP(1);
-		// ---- phase B1: exact corner test by ring masks ----
+		// ---- phase B: the exact score of every queued pixel; a corner is a pixel whose score exceeds the threshold (an arc of 9 all brighter
+		//      than c + t or all darker than c - t  <=>  max over the arcs of the arc's min |difference| > t).  The separate corner test by 16-bit
+		//      ring masks that used to stand in front of the score (round 2) cost as much per pixel as the packed score itself. ----
 		const int q1n = s_q1n;
 		for (int base = 0; base < q1n; base += 256) {
 			const int q = base + tid;
@@ -272,41 +273,18 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 				code = s_q1[q];
 				const int it = code >> 2, k = code & 3;
 				const int sy = it / SG, g = it - sy * SG;
-				const uint8_t* p = s_img + (sy + 3) * IW + 4 * (g + 1) + k;
-				const int c = p[0], hi = c + threshold, lo = c - threshold;
-				const int r0 = p[3 * IW], r1 = p[3 * IW + 1], r2 = p[2 * IW + 2], r3 = p[IW + 3], r4 = p[3], r5 = p[-IW + 3];
-				const int r6 = p[-2 * IW + 2], r7 = p[-3 * IW + 1], r8 = p[-3 * IW], r9 = p[-3 * IW - 1], r10 = p[-2 * IW - 2];
-				const int r11 = p[-IW - 3], r12 = p[-3], r13 = p[IW - 3], r14 = p[2 * IW - 2], r15 = p[3 * IW - 1];
-				unsigned mb = 0, md = 0;
-#define SSK_RB(i, r) mb |= (unsigned)((r) > hi) << (i); md |= (unsigned)((r) < lo) << (i);
-				SSK_RB(0, r0) SSK_RB(1, r1) SSK_RB(2, r2) SSK_RB(3, r3) SSK_RB(4, r4) SSK_RB(5, r5) SSK_RB(6, r6) SSK_RB(7, r7)
-				SSK_RB(8, r8) SSK_RB(9, r9) SSK_RB(10, r10) SSK_RB(11, r11) SSK_RB(12, r12) SSK_RB(13, r13) SSK_RB(14, r14) SSK_RB(15, r15)
-#undef SSK_RB
-				unsigned xb = mb | (mb << 16), xd = md | (md << 16);
-				unsigned tb = xb & (xb >> 1), td = xd & (xd >> 1);
-				tb &= tb >> 2; td &= td >> 2;
-				tb &= tb >> 4; td &= td >> 4;
-				tb &= xb >> 8; td &= xd >> 8;
-				corner = ((tb | td) & 0xFFFFu) != 0u;
+				uint32_t A[8];
+				ring_diffs_packed(s_img + (sy + 3) * IW + 4 * (g + 1) + k, A);
+				const int sc = fast_s_packed(A);
+				corner = sc > threshold;
+				if (corner) s_sc[sy * SP + 4 * g + k] = (uint8_t)(sc - 1);
 			}
 			wave_push(corner, code, s_q2, &s_q2n);
 		}
 		__syncthreads();
+		const int q2n = s_q2n;
 
 		FSTAMP(2);
-		// ---- phase B: exact score of the corners ----
-		const int q2n = s_q2n;
-		for (int q = tid; q < q2n; q += 256) {
-			const int code = s_q2[q];
-			const int it = code >> 2, k = code & 3;
-			const int sy = it / SG, g = it - sy * SG;
-			uint32_t A[8];
-			ring_diffs_packed(s_img + (sy + 3) * IW + 4 * (g + 1) + k, A);
-			const int s = fast_s_packed(A);
-			if (s > threshold) s_sc[sy * SP + 4 * g + k] = (uint8_t)(s - 1);
-		}
-		__syncthreads();
-
 		FSTAMP(3);
 		// ---- phase C: strict 3x3 NMS inside the emit region [31,W-31) x [31,H-31): a lane per CORNER (the second queue again: a few % of the
 		// pixels), its 8 neighbours' scores by byte reads.  (A sweep of all 1024 pixel groups of the tile ran every wavefront through the

@@ -1087,12 +1087,19 @@ template <int CW>
 __device__ __forceinline__ int ldl_leading_panels(double* __restrict__ A, int np, int n, int n1, double* inv, double* lds, int lds_doubles)
 {
 	const int tid = threadIdx.x;
+	// (every block column must fit before the first one is touched: a caller falls back to another solver on 2)
+	for (int c = 0; c < n1;) {
+		const int R = n - c + 1;
+		int w = ((lds_doubles - (c ? (CW + 1) * R : 0)) / R - 1) / 6 * 6;
+		if (w > n1 - c) w = n1 - c;
+		if (w < 6) return 2;                               // (a system far beyond the tiler's sizes)
+		c += w;
+	}
 	for (int c = 0; c < n1;) {
 		const int R = n - c + 1;
 		const int stage = c ? (CW + 1) * R : 0;
 		int w = ((lds_doubles - stage) / R - 1) / 6 * 6;
 		if (w > n1 - c) w = n1 - c;
-		if (w < 6) return 2;                               // (a system far beyond the tiler's sizes; nothing is modified when c == 0)
 		const ldl_ix_rect ix{w + 1};
 		double* Pn = lds;
 		double* S = lds + (size_t)R * (w + 1);
