@@ -5,6 +5,9 @@
 #ifndef SSK_LM_WAVES
 #define SSK_LM_WAVES 2          // min waves per SIMD the register budget must allow (2 = one 512-thread workgroup per CU)
 #endif
+#ifndef SSK_RT_UNROLL
+#define SSK_RT_UNROLL 1                 // unroll factor of the register-tile update's column loop (ldl_solve_regtile)
+#endif
 #ifndef SSK_LM_NT
 #define SSK_LM_NT 512
 #endif
@@ -1325,7 +1328,7 @@ __device__ __forceinline__ bool ldl_solve_regtile(double* __restrict__ A, int np
 			// (not software-pipelined: with the operands of column c + 1 in flight beside the 64 multiply-adds of column c the tile, the
 			//  right-hand side and two operand sets exceed the 256 registers of two waves per SIMD -- the compiler spills z inside the loop,
 			//  7.7 ms against 4.05 ms for one depth-5 window)
-#pragma unroll 1
+#pragma unroll SSK_RT_UNROLL
 			for (int c = 0; c < 8; ++c) {
 				const double ivc = dgb[64 + c];
 				double ui[8], uj[8];
