@@ -198,7 +198,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		// ---- phase A: compass test, 4 pixels per lane ----
 		for (int base = 0; base < SG * SH; base += 256) {
 			const int it = base + tid;
-			bool pr[4] = {false, false, false, false};
+			unsigned m4 = 0u;                                      // bit k: pixel k of the group passes the compass test
 			if (it < SG * SH) {
 				const int sy = it / SG, g = it - sy * SG;
 				const int gy = Y0 - 1 + sy, gx0 = X0 - 4 + 4 * g;
@@ -226,14 +226,18 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 						const u16x2 dh = as_u16x2(as_u32x(__builtin_elementwise_sub_sat(lo, a4)) | as_u32x(__builtin_elementwise_sub_sat(lo, a12)));
 						res[hsel] = as_u32x(__builtin_elementwise_min(bv, bh)) | as_u32x(__builtin_elementwise_min(dv, dh));
 					}
-#pragma unroll
-					for (int k = 0; k < 4; ++k)      // gx0 >= X_ORG - 4 >= 3 always; only the last tile column can pass w - 3
-						pr[k] = ((res[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) != 0u && k < w - 3 - gx0;
+					// non-zero 16-bit lanes -> bits: min(x, 1) per lane, then (lo | hi >> 15) of each pair; gx0 >= X_ORG - 4 >= 3 always, only the last
+					// tile column can pass w - 3: the pixels k < w - 3 - gx0 as one mask
+					const uint32_t one2 = 0x00010001u;
+					const uint32_t n0 = as_u32x(__builtin_elementwise_min(as_u16x2(res[0]), as_u16x2(one2)));
+					const uint32_t n1 = as_u32x(__builtin_elementwise_min(as_u16x2(res[1]), as_u16x2(one2)));
+					const unsigned bits = ((n0 | (n0 >> 15)) & 3u) | (((n1 | (n1 >> 15)) & 3u) << 2);
+					const int room = min(max(w - 3 - gx0, 0), 4);
+					m4 = bits & ((1u << room) - 1u);
 				}
 			}
 			// ONE queue entry per group with a survivor (one ballot, one store): four entries per group -- four ballots, four conditional
 			// stores in every one of the five rounds -- were a quarter of the kernel; the groups are expanded to pixels below
-			const unsigned m4 = (unsigned)pr[0] | ((unsigned)pr[1] << 1) | ((unsigned)pr[2] << 2) | ((unsigned)pr[3] << 3);
 			wave_push(m4 != 0u, (uint16_t)((it << 4) | m4), s_qg, &s_qgn);
 		}
 		__syncthreads();
