@@ -113,28 +113,30 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 	// shifted to byte 0 once (v_alignbyte), and every output is two v_dot4_u32_u8 against the packed taps
 	// (18,34,49,55 | 49,34,18,0) of its realigned window; results (u16, <= 255*257) go out TRANSPOSED
 	// (column-major) so that the vertical pass reads its 19 inputs as contiguous u16 pairs.
-	for (int it = lane; it < PD * 3; it += 64) {
-		const int r = it / 3, s = it - 3 * r;
-		const int b0 = shift + 13 * s;                           // first input byte of the segment inside the raw row
+	// (segments of 10 outputs, 4 per row: 180 items fill the wavefront's three turns to 64 + 64 + 52 lanes; 135 items of 13 outputs left
+	//  the third turn 7 lanes of the longer body)
+	for (int it = lane; it < PD * 4; it += 64) {
+		const int r = it >> 2, s = it & 3;
+		const int b0 = shift + 10 * s;                           // first input byte of the segment inside the raw row
 		const uint32_t* p = reinterpret_cast<const uint32_t*>(s_raw + r * PP) + (b0 >> 2);
 		const uint32_t sub = (uint32_t)(b0 & 3);
-		uint32_t D[6], E[5];
+		uint32_t D[5], E[4];
 #pragma unroll
-		for (int k = 0; k < 6; ++k) D[k] = p[k];
+		for (int k = 0; k < 5; ++k) D[k] = p[k];
 #pragma unroll
-		for (int k = 0; k < 5; ++k) E[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sub);
-		uint16_t* o = s_h + (13 * s) * HT + r;
+		for (int k = 0; k < 4; ++k) E[k] = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sub);
+		uint16_t* o = s_h + (10 * s) * HT + r;
 		// output j = sum_t tap[t] byte[j + t], taps (18,34,49,55,49,34,18): the window of output 4q + ph starts at byte ph of E[q]; instead
 		// of shifting the window to a dword start (12 v_alignbyte per segment) the TAPS are packed at the byte phase: 2 or 3 v_dot4
 #pragma unroll
-		for (int j = 0; j < 13; ++j) {
+		for (int j = 0; j < 10; ++j) {
 			const int q = j >> 2, ph = j & 3;
 			uint32_t sum;
 			if (ph == 0) sum = __builtin_amdgcn_udot4(E[q], 0x37312212u, __builtin_amdgcn_udot4(E[q + 1], 0x00122231u, 0u, false), false);
 			else if (ph == 1) sum = __builtin_amdgcn_udot4(E[q], 0x31221200u, __builtin_amdgcn_udot4(E[q + 1], 0x12223137u, 0u, false), false);
 			else if (ph == 2) sum = __builtin_amdgcn_udot4(E[q], 0x22120000u, __builtin_amdgcn_udot4(E[q + 1], 0x22313731u, __builtin_amdgcn_udot4(E[q + 2], 0x00000012u, 0u, false), false), false);
 			else sum = __builtin_amdgcn_udot4(E[q], 0x12000000u, __builtin_amdgcn_udot4(E[q + 1], 0x31373122u, __builtin_amdgcn_udot4(E[q + 2], 0x00001222u, 0u, false), false), false);
-			o[j * HT] = (uint16_t)sum;
+			if (j < 9 || s < 3) o[j * HT] = (uint16_t)sum;       // (39 = 10 + 10 + 10 + 9 columns)
 		}
 	}
 #pragma unroll
