@@ -8,9 +8,9 @@
 //   phase 0  the (128+16) x (32+8) pixel tile (ring + NMS halo, 4-byte aligned columns) is staged in LDS with
 //            aligned dword loads, 144 B per row coalesced (neighbouring tiles re-read the halo from L2);
 //   phase A  item = 4 horizontally adjacent pixels: FIVE dword LDS reads (rows y-3, y, y+3) feed the necessary
-//            test on the 4 compass ring pixels of all four (a 9-arc holds two adjacent compass points); survivors
-//            are appended to an LDS queue with ONE ds atomic per wave (ballot + lane prefix), so the later
-//            phases run on dense lanes;
+//            test on the 4 compass ring pixels of all four (a 9-arc holds two adjacent compass points); a lane keeps
+//            the survivor bits of its five items and the wave appends them all to an LDS pixel queue in ONE step
+//            (five ballots of the counts, one ds atomic), so the later phases run on dense lanes;
 //   phase B  queued pixels: exact score s-1 (max over the 16 arcs of 9 of the min signed difference, by min/max doubling on packed
 //            16-bit pairs); score > threshold is the corner test (round 3: the separate 16-bit ring-mask test in front of it cost as
 //            much per pixel as the score) -> 8-bit score tile in LDS + second queue of real corners (a few % of the pixels);
@@ -124,11 +124,10 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_img[IH * IW];
 	__shared__ __attribute__((aligned(16))) uint8_t s_sc[SH * SP];
-	__shared__ uint16_t s_qg[SG * SH];         // phase A: 4-pixel groups with a survivor, (group << 4) | 4-bit mask
 	__shared__ uint16_t s_q1[NQ];
 	__shared__ uint16_t s_q2[NQ];
 	__shared__ uint32_t s_out[TW * TH / 4 + 64];
-	__shared__ int s_qgn, s_q1n, s_q2n, s_on, s_base;
+	__shared__ int s_q1n, s_q2n, s_on, s_base;
 
 	const int tid = threadIdx.x;
 #ifdef SSK_FAST_STAMPS
@@ -186,7 +185,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 			}
 		}
 		for (int i = tid; i < SH * SP / 4; i += 256) reinterpret_cast<uint32_t*>(s_sc)[i] = 0u;
-		if (tid == 0) { s_qgn = 0; s_q1n = 0; s_q2n = 0; s_on = 0; }
+		if (tid == 0) { s_q1n = 0; s_q2n = 0; s_on = 0; }
 		__syncthreads();
 		if (t + stride < t_end) issue_loads(t + stride);
 		FSTAMP(0);
@@ -195,9 +194,15 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		const int img = img_begin + im;
 		const int X0 = X_ORG + bx * TW, Y0 = SSK_EDGE + by * TH;
 
-		// ---- phase A: compass test, 4 pixels per lane ----
-		for (int base = 0; base < SG * SH; base += 256) {
-			const int it = base + tid;
+		// ---- phase A: compass test, 4 pixels per lane; the lane keeps the survivor bits of its five groups (4 bits each) and the wavefront
+		//      appends all of them to the pixel queue in ONE step (five ballots of the lanes' counts, one ds atomic): a push per round plus a
+		//      second pass that expanded queued groups to pixels were a fifth of the kernel ----
+		constexpr int NRA = (SG * SH + 255) / 256;
+		static_assert(4 * NRA <= 32, "survivor bits of a lane");
+		unsigned all = 0u;
+#pragma unroll
+		for (int ra = 0; ra < NRA; ++ra) {
+			const int it = 256 * ra + tid;
 			unsigned m4 = 0u;                                      // bit k: pixel k of the group passes the compass test
 			if (it < SG * SH) {
 				const int sy = it / SG, g = it - sy * SG;
@@ -236,31 +241,29 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 					m4 = bits & ((1u << room) - 1u);
 				}
 			}
-			// ONE queue entry per group with a survivor (one ballot, one store): four entries per group -- four ballots, four conditional
-			// stores in every one of the five rounds -- were a quarter of the kernel; the groups are expanded to pixels below
-			wave_push(m4 != 0u, (uint16_t)((it << 4) | m4), s_qg, &s_qgn);
+			all |= m4 << (4 * ra);
 		}
-		__syncthreads();
-		// ---- phase A2: the queued groups' survivors as a dense pixel queue (code = 4 * group + pixel) ----
-		const int qgn = s_qgn;
-		for (int base = 0; base < qgn; base += 256) {
-			const int q = base + tid;
-			const unsigned e = q < qgn ? s_qg[q] : 0u;
-			const unsigned m4 = e & 15u, cnt = __popc(m4);
-			// exclusive prefix of the lanes' counts (0..4) from the ballots of their three bits
-			const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
-			const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-			if (total == 0) continue;                            // (wave uniform)
-			const int lane = tid & 63;
-			const unsigned long long lt = (1ull << lane) - 1ull;
-			const int before = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
-			int qb = 0;
-			if (lane == 0) qb = atomicAdd(&s_q1n, total);
-			qb = __shfl(qb, 0, 64) + before;
-			const unsigned code0 = (e >> 4) << 2;
+		{
+			const unsigned cnt = __popc(all);                        // 0 .. 20
+			const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u), b3 = __ballot(cnt & 8u), b4 = __ballot(cnt & 16u);
+			const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3) + 16 * __popcll(b4);
+			if (total != 0) {                                      // (wave uniform)
+				const int lane = tid & 63;
+				const unsigned long long lt = (1ull << lane) - 1ull;
+				const int before = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt) + 8 * __popcll(b3 & lt) + 16 * __popcll(b4 & lt);
+				int qb = 0;
+				if (lane == 0) qb = atomicAdd(&s_q1n, total);
+				qb = __shfl(qb, 0, 64) + before;
 #pragma unroll
-			for (int k = 0; k < 4; ++k)
-				if (m4 & (1u << k)) s_q1[qb + __popc(m4 & ((1u << k) - 1u))] = (uint16_t)(code0 + k);
+				for (int ra = 0; ra < NRA; ++ra) {
+					const unsigned m4 = (all >> (4 * ra)) & 15u;
+					const unsigned code0 = (unsigned)(256 * ra + tid) << 2;      // code = 4 * group + pixel
+#pragma unroll
+					for (int k = 0; k < 4; ++k)
+						if (m4 & (1u << k)) s_q1[qb + __popc(m4 & ((1u << k) - 1u))] = (uint16_t)(code0 + k);
+					qb += __popc(m4);
+				}
+			}
 		}
 		__syncthreads();
 
