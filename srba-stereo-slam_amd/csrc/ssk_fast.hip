@@ -233,9 +233,12 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 					}
 					// non-zero 16-bit lanes -> bits: min(x, 1) per lane, then (lo | hi >> 15) of each pair; gx0 >= X_ORG - 4 >= 3 always, only the last
 					// tile column can pass w - 3: the pixels k < w - 3 - gx0 as one mask
+					// (v_pk_min_u16 by name: the compiler rewrites min(x, 1) as x != 0 and spends four compares, four selects and two
+					//  permutes on it)
 					const uint32_t one2 = 0x00010001u;
-					const uint32_t n0 = as_u32x(__builtin_elementwise_min(as_u16x2(res[0]), as_u16x2(one2)));
-					const uint32_t n1 = as_u32x(__builtin_elementwise_min(as_u16x2(res[1]), as_u16x2(one2)));
+					uint32_t n0, n1;
+					asm("v_pk_min_u16 %0, %1, %2" : "=v"(n0) : "v"(res[0]), "v"(one2));
+					asm("v_pk_min_u16 %0, %1, %2" : "=v"(n1) : "v"(res[1]), "v"(one2));
 					const unsigned bits = ((n0 | (n0 >> 15)) & 3u) | (((n1 | (n1 >> 15)) & 3u) << 2);
 					const int room = min(max(w - 3 - gx0, 0), 4);
 					m4 = bits & ((1u << room) - 1u);
