@@ -225,6 +225,7 @@ struct mySRBA::lm_job {
 	std::vector<float> obs_px;
 	std::vector<double> pose, lmpos;
 	std::vector<TLandmarkID> lm_ids;
+	std::vector<landmark_t*> lm_ptr;
 	std::vector<size_t> edge_ids;
 	ssk_lm_window w{};
 	ssk_lm_batch* b = nullptr;
@@ -249,13 +250,19 @@ void mySRBA::lm_prepare(lm_job& j, const std::set<size_t>& opt_edges, const std:
 	// (edge == SIZE_MAX: not in the tree); the window is built once per keyframe over ~10^4 observations, so the lookups
 	// are arrays and hashes, not ordered maps
 	const size_t n_kf = num_keyframes();
-	std::map<TKeyFrameID, std::vector<step_t>> trees;
+	std::unordered_map<TKeyFrameID, std::vector<step_t>>& trees = m_tree_cache[optimize_landmarks ? 1 : 0];      // (kept across keyframes: see the header)
 	std::vector<int32_t>& obs_lm = j.obs_lm; std::vector<int32_t>& obs_path_off = j.obs_path_off; std::vector<int32_t>& path_edge = j.path_edge;
 	std::vector<float>& obs_px = j.obs_px;
 	obs_path_off.assign(1, 0);
 	std::vector<int> edge_idx(m_state.k2k_edges.size(), -1);
-	std::unordered_map<TLandmarkID, int> lm_idx;
+	const int slot = optimize_landmarks ? 1 : 0;
+	std::vector<uint32_t>& stamp = m_lm_stamp[slot];
+	std::vector<int32_t>& local = m_lm_local[slot];
+	if (stamp.size() < m_n_lm_seq) { stamp.resize(m_n_lm_seq + m_n_lm_seq / 2 + 1024, 0u); local.resize(stamp.size(), -1); }
+	if (++m_lm_gen[slot] == 0u) { std::fill(stamp.begin(), stamp.end(), 0u); m_lm_gen[slot] = 1u; }
+	const uint32_t gen = m_lm_gen[slot];
 	std::vector<TLandmarkID>& lm_ids = j.lm_ids;
+	std::vector<landmark_t*>& lm_ptr = j.lm_ptr;
 	std::vector<size_t>& edge_ids = j.edge_ids;
 	auto edge_index = [&](size_t e) { if (edge_idx[e] >= 0) return edge_idx[e]; const int i = (int)edge_ids.size(); edge_idx[e] = i; edge_ids.push_back(e); return i; };
 	for (size_t e : opt_edges) edge_index(e);
@@ -266,8 +273,8 @@ void mySRBA::lm_prepare(lm_job& j, const std::set<size_t>& opt_edges, const std:
 	for (const auto& ref : obs_refs) {
 		const TKeyFrameID kf = ref.first;
 		const kf_observation_t& o = m_state.kf_observations[kf][ref.second];
-		const auto lit = m_state.unknown_lms.find(o.feat_id);
-		if (lit == m_state.unknown_lms.end()) continue;
+		landmark_t* const lmk = o.lm;
+		if (!lmk) continue;
 		if (kf != tree_kf) {
 			auto it = trees.find(kf);
 			if (it == trees.end()) {
@@ -282,8 +289,9 @@ void mySRBA::lm_prepare(lm_job& j, const std::set<size_t>& opt_edges, const std:
 			tree_kf = kf; tree_p = &it->second;
 		}
 		const std::vector<step_t>& tree = *tree_p;
-		const TKeyFrameID base = lit->second.base_kf;
-		if (base >= n_kf || tree[base].edge == (size_t)-1) continue;   // farther than max_tree_depth: not in the spanning tree
+		const TKeyFrameID base = lmk->base_kf;
+		if (base >= tree.size() || tree[base].edge == (size_t)-1) continue;   // farther than max_tree_depth: not in the spanning tree (a cached
+		                                                                       // tree is as long as the map was when it was built: bases are older)
 		steps.clear();                                       // from the base back to the observer
 		for (TKeyFrameID cur = base; cur != kf;) {
 			const step_t& st = tree[cur];
@@ -295,9 +303,8 @@ void mySRBA::lm_prepare(lm_job& j, const std::set<size_t>& opt_edges, const std:
 		if (steps.size() > 8) continue;
 		path_edge.insert(path_edge.end(), steps.rbegin(), steps.rend());
 		obs_path_off.push_back((int32_t)path_edge.size());
-		const auto ins = lm_idx.emplace(o.feat_id, (int)lm_ids.size());
-		if (ins.second) lm_ids.push_back(o.feat_id);
-		obs_lm.push_back(ins.first->second);
+		if (stamp[lmk->seq] != gen) { stamp[lmk->seq] = gen; local[lmk->seq] = (int32_t)lm_ids.size(); lm_ids.push_back(o.feat_id); lm_ptr.push_back(lmk); }
+		obs_lm.push_back(local[lmk->seq]);
 		obs_px.insert(obs_px.end(), o.px, o.px + 4);
 	}
 	j.edge_slot.assign(edge_ids.size(), -1); j.lm_slot.assign(lm_ids.size(), -1);
@@ -311,7 +318,7 @@ void mySRBA::lm_prepare(lm_job& j, const std::set<size_t>& opt_edges, const std:
 	j.n_opt = s;
 	for (size_t i = 0; i < lm_ids.size(); ++i) {
 		if (optimize_landmarks) j.lm_slot[i] = (int32_t)i;
-		std::memcpy(&j.lmpos[3 * i], m_state.unknown_lms.find(lm_ids[i])->second.pos, 3 * sizeof(double));
+		std::memcpy(&j.lmpos[3 * i], lm_ptr[i]->pos, 3 * sizeof(double));
 	}
 	ssk_lm_window w;
 	w.n_edges_total = (int32_t)edge_ids.size(); w.edge_unknown_slot = j.edge_slot.data(); w.edge_inv_pose = j.pose.data();
@@ -367,7 +374,7 @@ void mySRBA::lm_collect(lm_job& j, TOptimizeResults& res)
 	for (size_t i = 0; i < j.edge_ids.size(); ++i)
 		if (j.edge_slot[i] >= 0) std::memcpy(m_state.k2k_edges[j.edge_ids[i]].inv_pose.m, &j.pose[12 * i], 12 * sizeof(double));
 	if (j.optimize_landmarks)
-		for (size_t i = 0; i < j.lm_ids.size(); ++i) std::memcpy(m_state.unknown_lms[j.lm_ids[i]].pos, &j.lmpos[3 * i], 3 * sizeof(double));
+		for (size_t i = 0; i < j.lm_ids.size(); ++i) std::memcpy(j.lm_ptr[i]->pos, &j.lmpos[3 * i], 3 * sizeof(double));
 	res.total_sqr_error_init = r.err_init; res.total_sqr_error_final = r.err_final;
 	res.num_observations = (size_t)r.n_obs; res.num_iters = (size_t)r.iters;
 	res.obs_rmse = r.n_obs ? std::sqrt(r.err_final / r.n_obs) : 0.0;
@@ -383,16 +390,22 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 	std::vector<TNewEdgeInfo> new_edges;
 	if (new_kf_id >= 1) edge_creation_policy(new_kf_id, obs, new_edges);        // virtual edge_creation_policy
 	for (const auto& e : new_edges) out.created_edge_ids.push_back(e.id);
+	// (a keyframe with one new edge is a leaf: no path between older keyframes changes; with several it may open shorter ones)
+	if (new_edges.size() != 1) { m_tree_cache[0].clear(); m_tree_cache[1].clear(); }
+	for (auto& c : m_tree_cache) if (c.size() > 256) c.clear();      // (a local area holds a few dozen observers: the rest is left behind)
 	// add_observation: a feature id seen for the first time becomes a landmark based at this keyframe with the given
 	// relative position (is_unknown_with_init_val, EST.cpp:143-158)
 	for (const auto& o : obs) {
-		if (!m_state.unknown_lms.count(o.obs.feat_id)) {
+		auto lit = m_state.unknown_lms.find(o.obs.feat_id);
+		if (lit == m_state.unknown_lms.end()) {
 			landmark_t lm;
 			lm.base_kf = new_kf_id;
 			lm.pos[0] = o.rel_pos[0]; lm.pos[1] = o.rel_pos[1]; lm.pos[2] = o.rel_pos[2];
-			m_state.unknown_lms[o.obs.feat_id] = lm;
+			lm.seq = m_n_lm_seq++;
+			lit = m_state.unknown_lms.emplace(o.obs.feat_id, lm).first;
 		}
 		kf_observation_t k;
+		k.lm = &lit->second;
 		k.feat_id = o.obs.feat_id;
 		k.px[0] = o.obs.obs_data.left_px.x; k.px[1] = o.obs.obs_data.left_px.y;
 		k.px[2] = o.obs.obs_data.right_px.x; k.px[3] = o.obs.obs_data.right_px.y;

@@ -39,8 +39,8 @@ struct TNewKeyFrameInfo {                      // EST.cpp:178-180,790,847-849
 };
 
 struct k2k_edge_t { TKeyFrameID from, to; Pose3D inv_pose; };   // inv_pose: `from` as seen from `to`
-struct landmark_t { TKeyFrameID base_kf; double pos[3]; };
-struct kf_observation_t { TLandmarkID feat_id; float px[4]; };
+struct landmark_t { TKeyFrameID base_kf; double pos[3]; uint32_t seq = 0; };      // seq: creation order (index of the per-window scratch of the LM window builder)
+struct kf_observation_t { TLandmarkID feat_id; float px[4]; landmark_t* lm = nullptr; };      // lm: the map node (stable: nodes of an unordered_map do not move)
 
 class mySRBA {
 public:
@@ -105,6 +105,16 @@ private:
 	struct step_t { TKeyFrameID prev; size_t edge; size_t dist; };
 	void bfs(TKeyFrameID root, size_t max_depth, std::map<TKeyFrameID, step_t>& out) const;
 	struct lm_job;
+	// window-local landmark index per landmark sequence number, valid where the stamp equals the job's generation (no hash per observation,
+	// no clearing); two slots: the new-edges window and the local-area window may be built at the same time
+	mutable std::vector<uint32_t> m_lm_stamp[2];
+	mutable std::vector<int32_t> m_lm_local[2];
+	mutable uint32_t m_lm_gen[2] = {0, 0};
+	uint32_t m_n_lm_seq = 0;
+	// depth-limited spanning trees per observing keyframe, flattened (step towards the observer per keyframe id), kept across keyframes:
+	// every new edge joins the NEW keyframe to an older one, so the paths from an observer to the (older) base keyframes of its landmarks
+	// only change when a keyframe arrives with several edges -- then the cache is dropped.  Per slot as the landmark scratch.
+	mutable std::unordered_map<TKeyFrameID, std::vector<step_t>> m_tree_cache[2];
 	// one persistent helper thread (a thread's first HIP call costs about a millisecond: not one thread per keyframe)
 	struct worker_t;
 	worker_t* m_worker = nullptr;
