@@ -90,6 +90,17 @@ struct nd_group {
 // quad slot (int2): x block pair id (0xFFFF: none) | items << 16, y first item (window relative) | part of the block << 28 |
 //   block cut in two << 30 | this wavefront holds such blocks << 31
 
+// phase-split form (ssk_lm_split.hip): per window, beside its nd_win (whose tile[].qs0 / n_rounds then mean: first (tile, block) slot of the
+// tile in sqs[], number of such slots)
+struct nd_split {
+	int sqs0;                           // nd_dev::sqs[sqs0 + tile.qs0 + k]: x block pair id, y items, z first item (window relative), w partial slot
+	int poff0, goff0, gslot0;           // sp_dev::poff[poff0 + pid] .. [pid + 1]: the block's partial slots; goff[goff0 + e]: the edge's gradient slots; gslot[gslot0 + tile.gqs0 + k]
+	int n_part, n_gpart;
+	int gtile0;                         // the window's first tile in the batch-wide tile numbering (per-tile error / vmax partials)
+	int pad;
+	long long part0, gpart0;            // Hpart[36 * (part0 + slot)], gpart[6 * (gpart0 + slot)]
+};
+
 struct nd_dev {
 	const nd_win* win; const nd_tile* tile; const nd_group* group;
 	const nd_i2* suf; const nd_i2* obs; const nd_f4* px; const nd_i4* lane;

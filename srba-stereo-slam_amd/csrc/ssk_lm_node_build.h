@@ -23,6 +23,12 @@ struct nd_host {
 	size_t lds_doubles_big = 0;         // ... in the BIG form (accumulators and system in HBM / L2)
 	long long hb_doubles = 0;           // BIG form: block accumulators of all windows
 	int max_items_per_lane = 0;         // (diagnostic: the longest item run of a quad lane)
+	// ---- phase-split form (ssk_lm_split.hip): one nd_split per window beside its nd_win ----
+	std::vector<nd_split> swin;
+	std::vector<nd_i4> sqs;             // (tile, block) slots: x block pair id, y items, z first item (window relative), w partial slot (window relative)
+	std::vector<int> poff, goff, gslot; // poff: per window n_pairs + 1 (partial slots of a block, block-major); goff: E + 1; gslot: per gqs entry its gradient partial slot
+	long long part_slots = 0, gpart_slots = 0;   // 36-double / 6-double partial slots of all windows
+	int max_tile_blocks = 0;
 };
 
 // dynamic LDS of a window, doubles: edge poses twice, solution + pivots, block accumulators, gradient accumulator, the trie records, then the region the
@@ -43,7 +49,10 @@ inline size_t nd_lds_doubles(int n_edges, int E, int waves, int n_suf, int n_til
 // Appends window Wn to H (bases edge0 / lm0 / us0 / ls0 / trace offsets are the caller's: the families are shared with the other
 // kernels' structures).  Returns false -- and leaves H untouched -- when the window does not fit the node kernel:
 // more than 128 optimised edges, a landmark with more than 64 observations or more than 63 nodes, more than 65535 suffixes.
-inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */, size_t lds_limit_doubles = 20352)
+// split = true: the tables of the PHASE-SPLIT form (ssk_lm_split.hip): landmarks ordered by the set of optimised edges their nodes touch (so that
+// the landmarks of a tile share 6x6 blocks: 3x fewer (tile, block) pairs on a depth-5 local area), one quad slot per (tile, block) with a
+// partial-sum slot in HBM (block-major numbering: the slots of a block are contiguous, tile order), gradient slots per (tile, edge) likewise.
+inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */, size_t lds_limit_doubles = 20352, bool split = false)
 {
 	const int n_obs = Wn.n_obs, n_lms = Wn.n_lms_total;
 	int E = 0, L = 0;
@@ -103,12 +112,29 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		if (M.nodes.size() > 63) return false;
 		lms.push_back(std::move(M));
 	}
-	// optimised landmarks first, in slot order (the landmark trace is by slot), then the fixed ones
-	std::stable_sort(lms.begin(), lms.end(), [&](const lmk& a, const lmk& b) {
-		const int sa = Wn.lm_unknown_slot[a.l], sb = Wn.lm_unknown_slot[b.l];
-		if ((sa >= 0) != (sb >= 0)) return sa >= 0;
-		return sa >= 0 ? sa < sb : a.l < b.l;
-	});
+	if (!split) {
+		// optimised landmarks first, in slot order, then the fixed ones
+		std::stable_sort(lms.begin(), lms.end(), [&](const lmk& a, const lmk& b) {
+			const int sa = Wn.lm_unknown_slot[a.l], sb = Wn.lm_unknown_slot[b.l];
+			if ((sa >= 0) != (sb >= 0)) return sa >= 0;
+			return sa >= 0 ? sa < sb : a.l < b.l;
+		});
+	} else {
+		// by the sorted set of optimised edge slots of the landmark's nodes, lexicographically (ties: landmark index)
+		std::vector<std::vector<int>> eset(lms.size());
+		for (size_t m = 0; m < lms.size(); ++m) {
+			for (const node& nd : lms[m].nodes) eset[m].push_back(Wn.edge_unknown_slot[suf[(size_t)nd.key].x >> 1]);
+			std::sort(eset[m].begin(), eset[m].end());
+			eset[m].erase(std::unique(eset[m].begin(), eset[m].end()), eset[m].end());
+		}
+		std::vector<int> ord(lms.size());
+		for (size_t m = 0; m < ord.size(); ++m) ord[m] = (int)m;
+		std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return eset[(size_t)a] != eset[(size_t)b] ? eset[(size_t)a] < eset[(size_t)b] : lms[(size_t)a].l < lms[(size_t)b].l; });
+		std::vector<lmk> sorted;
+		sorted.reserve(lms.size());
+		for (int m : ord) sorted.push_back(std::move(lms[(size_t)m]));
+		lms.swap(sorted);
+	}
 	// ---- groups: greedy runs of landmarks with <= 64 observations and <= 64 lanes ----
 	const size_t win_i = H.win.size();
 	(void)win_i;
@@ -203,6 +229,56 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			}
 		}
 	}
+	std::vector<nd_i4> w_sqs;
+	std::vector<int> w_poff, w_goff, w_gslot;
+	int n_part = 0, n_gpart = 0, max_tile_blocks = 0;
+	if (split) {
+		std::vector<std::vector<int>> by_pid((size_t)n_pairs);
+		std::vector<int> used;
+		for (size_t t = 0; t < n_tiles; ++t) {
+			nd_tile T{};
+			T.grp0 = (int)(t * (size_t)waves); T.n_grp = (int)std::min(groups.size() - t * (size_t)waves, (size_t)waves);
+			used.clear();
+			for (const auto& it : tile_items[t]) { if (by_pid[(size_t)it.first].empty()) used.push_back(it.first); by_pid[(size_t)it.first].push_back(it.second); }
+			// heaviest first: the 16 quads of a wavefront run in lockstep
+			std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
+			T.qs0 = (int)w_sqs.size(); T.n_rounds = (int)used.size();      // (split form: n_rounds = number of (tile, block) slots)
+			max_tile_blocks = std::max(max_tile_blocks, (int)used.size());
+			for (int p2 : used) {
+				const std::vector<int>& v = by_pid[(size_t)p2];
+				w_sqs.push_back(nd_i4{p2, (int)v.size(), (int)w_item.size(), -1});
+				w_item.insert(w_item.end(), v.begin(), v.end());
+			}
+			for (int p2 : used) by_pid[(size_t)p2].clear();
+			T.gqs0 = (int)w_gqs.size(); T.n_gqs = 0;
+			for (int e = 0; e < E; ++e) {
+				const std::vector<int>& v = tile_edge[t][(size_t)e];
+				if (v.empty()) continue;
+				w_gqs.push_back(nd_i2{e | ((int)v.size() << 16), (int)w_gitem.size()});
+				w_gitem.insert(w_gitem.end(), v.begin(), v.end());
+				++T.n_gqs;
+			}
+			tiles.push_back(T);
+		}
+		// partial slots, block-major (a block's slots are contiguous, in tile order); gradient slots, edge-major
+		w_poff.assign((size_t)n_pairs + 1, 0);
+		for (const nd_i4& q : w_sqs) w_poff[(size_t)q.x + 1]++;
+		for (int p2 = 0; p2 < n_pairs; ++p2) w_poff[(size_t)p2 + 1] += w_poff[(size_t)p2];
+		{
+			std::vector<int> next(w_poff.begin(), w_poff.end() - 1);
+			for (nd_i4& q : w_sqs) q.w = next[(size_t)q.x]++;
+		}
+		n_part = (int)w_sqs.size();
+		w_goff.assign((size_t)E + 1, 0);
+		for (const nd_i2& q : w_gqs) w_goff[(size_t)(q.x & 0xFFFF) + 1]++;
+		for (int e = 0; e < E; ++e) w_goff[(size_t)e + 1] += w_goff[(size_t)e];
+		{
+			std::vector<int> next(w_goff.begin(), w_goff.end() - 1);
+			w_gslot.resize(w_gqs.size());
+			for (size_t k = 0; k < w_gqs.size(); ++k) w_gslot[k] = next[(size_t)(w_gqs[k].x & 0xFFFF)]++;
+		}
+		n_gpart = (int)w_gqs.size();
+	} else {
 #if SSK_ND_LANE_RUNS
 	// lane slots of a tile: the items of a block dealt out in runs of R consecutive items, a lane per run; R = the shortest run length
 	// whose lanes fit the workgroup (one round); the lanes of one block stay inside one wavefront (their sums meet in ONE ds_add_f64 per
@@ -308,6 +384,8 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	}
 #endif
 	hdr.n_rounds = max_rounds; hdr.max_parts = 2;
+	H.max_items_per_lane = std::max(H.max_items_per_lane, max_per_lane);
+	}
 	hdr.n_tiles = (int)tiles.size(); hdr.n_groups = (int)groups.size();
 	// ---- commit ----
 	H.suf.insert(H.suf.end(), suf.begin(), suf.end());
@@ -324,7 +402,19 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	H.hb_doubles += 36LL * E * (E + 1) / 2;
 	H.lds_doubles = std::max(H.lds_doubles, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)tiles.size(), (int)groups.size()));
 	H.lds_doubles_big = std::max(H.lds_doubles_big, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)tiles.size(), (int)groups.size(), true, lds_limit_doubles));
-	H.max_items_per_lane = std::max(H.max_items_per_lane, max_per_lane);
+	if (split) {
+		nd_split S{};
+		S.sqs0 = (int)H.sqs.size(); S.poff0 = (int)H.poff.size(); S.goff0 = (int)H.goff.size(); S.gslot0 = (int)H.gslot.size();
+		S.n_part = n_part; S.n_gpart = n_gpart; S.part0 = H.part_slots; S.gpart0 = H.gpart_slots;
+		S.gtile0 = (int)H.tile.size() - (int)tiles.size();
+		H.sqs.insert(H.sqs.end(), w_sqs.begin(), w_sqs.end());
+		H.poff.insert(H.poff.end(), w_poff.begin(), w_poff.end());
+		H.goff.insert(H.goff.end(), w_goff.begin(), w_goff.end());
+		H.gslot.insert(H.gslot.end(), w_gslot.begin(), w_gslot.end());
+		H.part_slots += n_part; H.gpart_slots += n_gpart;
+		H.max_tile_blocks = std::max(H.max_tile_blocks, max_tile_blocks);
+		H.swin.push_back(S);
+	}
 	H.win.push_back(hdr);
 	return true;
 }

@@ -90,20 +90,29 @@ def dense(win, prm, lam):
     return Hred, gred, dp, df, Hpp, Hff
 
 
-def run_emu(emu, win, prm, lam, pre=False, dp=None, waves=4):
+def run_emu(emu, win, prm, lam, pre=False, dp=None, waves=4, form=0):
     n = 6 * win.E
-    H = np.zeros((n, n)); g = np.zeros(n + 1); df = np.zeros((max(win.L, 1), 3)); vmax = C.c_double(0); stats = (C.c_int * 4)()
+    H = np.zeros((n, n)); g = np.zeros(n + 1); df = np.zeros((max(win.L, 1), 3)); vmax = C.c_double(0); stats = (C.c_int * 5)()
     wc = win.c()
-    rc = emu.nd_emu_linearise(C.byref(wc), C.byref(prm), C.c_double(lam), int(pre), waves, H.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
-                              dp.ctypes.data_as(C.c_void_p) if dp is not None else None, df.ctypes.data_as(C.c_void_p) if dp is not None else None,
-                              C.byref(vmax), stats)
+    rc = emu.nd_emu_linearise_form(C.byref(wc), C.byref(prm), C.c_double(lam), int(pre), waves, H.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p),
+                                   dp.ctypes.data_as(C.c_void_p) if dp is not None else None, df.ctypes.data_as(C.c_void_p) if dp is not None else None,
+                                   C.byref(vmax), stats, form)
     assert rc == 0
     return H, g[:n], df[:win.L], vmax.value, list(stats)
 
 
-def check(emu, win, prm, lam=0.37, waves=4):
-    H1, g1, dp1, df1, Hpp, Hff = dense(win, prm, lam)
-    H2, g2, df2, _, stats = run_emu(emu, win, prm, lam, dp=np.ascontiguousarray(dp1), waves=waves)
+def check(emu, win, prm, lam=0.37, waves=4, forms=(0, 1)):
+    """form 0: the tables of the persistent node kernel; form 1: those of the phase-split kernels (landmarks clustered by edge set, one
+    partial-sum slot per (tile, block), block-major reduction)"""
+    ref = dense(win, prm, lam)
+    for form in forms:
+        stats = check_form(emu, win, prm, lam, waves, form, ref)
+    return stats
+
+
+def check_form(emu, win, prm, lam, waves, form, ref):
+    H1, g1, dp1, df1, Hpp, Hff = ref
+    H2, g2, df2, _, stats = run_emu(emu, win, prm, lam, dp=np.ascontiguousarray(dp1), waves=waves, form=form)
     if win.E:
         sc = np.abs(H1).max()
         assert np.abs(H1 - H2).max() <= 1e-12 * sc, np.abs(H1 - H2).max() / sc
@@ -111,7 +120,7 @@ def check(emu, win, prm, lam=0.37, waves=4):
     if win.L:
         assert np.abs(df1 - df2).max() <= 1e-9 * max(np.abs(df1).max(), 1e-300)
     # the lambda_0 pass: diagonal blocks of H_pp alone, largest diagonal entry of an optimised landmark's block
-    H3, _, _, vmax, _ = run_emu(emu, win, prm, 0.0, pre=True, waves=waves)
+    H3, _, _, vmax, _ = run_emu(emu, win, prm, 0.0, pre=True, waves=waves, form=form)
     for e in range(win.E):
         blk = slice(6 * e, 6 * e + 6)
         assert np.abs(np.triu(H3[blk, blk]) - np.triu(Hpp[blk, blk])).max() <= 1e-12 * np.abs(Hpp).max()
@@ -143,6 +152,15 @@ def test_node_form_bench_window_and_wave_counts(emu):
     for waves in (4, 8):
         stats = check(emu, win, sl.make_params(), waves=waves)
         assert stats[0] == (stats[1] + waves - 1) // waves and stats[2] > 4000
+
+
+def test_split_form_depth5_window(emu):
+    """The reference's real per-keyframe load (KITTI.ini:104-106: optimise depth 5 -> 40 edges, 8.3 k observations): the tables of the phase-split
+    form against the dense textbook system; the clustering by edge set must cut the (tile, block) pairs well below the slot order's ~16 k."""
+    win = sl.make_submap_problem(0, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=5, obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0]
+    assert win.E == 40 and len(win.obs_lm) > 8000
+    stats = check(emu, win, sl.make_params(), forms=(1,))
+    assert stats[2] > 40000 and stats[4] < 7000, stats
 
 
 def test_node_form_two_nodes_of_a_landmark_on_one_edge(emu):

@@ -48,12 +48,13 @@ extern "C" {
 // Linearisation at the window's state: Hred (n6 x n6, row major, both triangles, lambda on the diagonal) and the reduced gradient g.
 // dp != NULL: also the landmark step df (3 per optimised slot) for the given edge step.  pre != 0: the lambda_0 pass (diag blocks of
 // H_pp only, vmax = largest diagonal of an optimised landmark's block).  Returns 0, or -1 when the window does not fit the node form.
-int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lambda, int pre, int waves, double* Hred, double* g, const double* dp, double* df,
-                     double* vmax_out, int* stats /* tiles, groups, items, max items per lane */)
+// form 1: the tables of the phase-split form (ssk_lm_split.hip): (tile, block) slots -> partial sums in "HBM" -> block-major reduction
+int nd_emu_linearise_form(const ssk_lm_window* Wn, const ssk_lm_params* P, double lambda, int pre, int waves, double* Hred, double* g, const double* dp, double* df,
+                          double* vmax_out, int* stats /* tiles, groups, items, max items per lane (split: most blocks of a tile), partial slots */, int form)
 {
 	nd_host H;
 	nd_win hdr{};
-	if (!nd_build_window(*Wn, waves, H, hdr)) return -1;
+	if (!nd_build_window(*Wn, waves, H, hdr, 20352, form == 1)) return -1;
 	const nd_win& W = H.win[0];
 	const int n6 = 6 * W.E;
 	std::vector<double> tab;
@@ -61,6 +62,7 @@ int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lam
 	const int n_pairs = W.E * (W.E + 1) / 2;
 	std::vector<double> Hb(36 * (size_t)n_pairs, 0.0), gacc((size_t)n6 + 1, 0.0);
 	std::vector<double> scr(12 * H.lane.size(), 0.0);
+	std::vector<double> part(36 * (size_t)(form == 1 ? H.part_slots : 0) + 36, 0.0), gpart(6 * (size_t)(form == 1 ? H.gpart_slots : 0) + 6, 0.0);
 	double vmax = 0.0;
 	const double* S = P->sensor_pose;
 	int n_groups = 0;
@@ -166,13 +168,23 @@ int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lam
 			}
 		}
 		const int NQ = SSK_ND_LANE_RUNS ? waves * 64 : waves * 16;      // slots per round
-		for (int r = 0; r < T.n_rounds; ++r)
-			for (int quad = 0; quad < NQ; ++quad) {
-				const nd_i2 q = H.qs[(size_t)W.qs0 + T.qs0 + r * NQ + quad];
-				const int pid = q.x & 0xFFFF, n = (q.x >> 16) & 0x7FFF;
-				if (pid == 0xFFFF) continue;                      // (a quad without a block)
+		const int n_slots = form == 1 ? T.n_rounds : T.n_rounds * NQ;
+		for (int sl = 0; sl < n_slots; ++sl) {
+			{
+				int pid, n, first;
+				double* acc;
+				if (form == 1) {
+					const nd_i4 q = H.sqs[(size_t)H.swin[0].sqs0 + T.qs0 + sl];
+					pid = q.x; n = q.y; first = q.z;
+					acc = &part[36 * (size_t)q.w];
+				} else {
+					const nd_i2 q = H.qs[(size_t)W.qs0 + T.qs0 + sl];
+					pid = q.x & 0xFFFF; n = (q.x >> 16) & 0x7FFF; first = q.y & 0x0FFFFFFF;
+					if (pid == 0xFFFF) continue;                      // (a quad without a block)
+					acc = &Hb[36 * (size_t)pid];
+				}
 				for (int i = 0; i < n; ++i) {
-					const int it = H.item[(size_t)W.item0 + (q.y & 0x0FFFFFFF) + i];
+					const int it = H.item[(size_t)W.item0 + first + i];
 					const double* xr = &rec[(size_t)SSK_ND_REC * (it & 511)];
 					const double* yc = &rec[(size_t)SSK_ND_REC * ((it >> 10) & 511)];
 					const double* X = xr + 12 * ((it >> 9) & 1);
@@ -180,7 +192,6 @@ int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lam
 					const double* qr = xr + 9, *qc = yc + 9;
 					const double sg = ((it >> 20) & 1) ? (pre ? 0.0 : -1.0) : 1.0;
 					double Dm[9], U[9];
-					double* acc = &Hb[36 * (size_t)pid];
 					for (int a = 0; a < 3; ++a) {
 						for (int b = 0; b < 3; ++b) Dm[3 * a + b] = sg * (X[3 * a] * Y[3 * b] + X[3 * a + 1] * Y[3 * b + 1] + X[3 * a + 2] * Y[3 * b + 2]);
 						cross(qc, Dm + 3 * a, U + 3 * a);
@@ -194,17 +205,29 @@ int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lam
 					}
 				}
 			}
+		}
 		if (!pre)
 			for (int k = 0; k < T.n_gqs; ++k) {
 				const nd_i2 q = H.gqs[(size_t)W.gqs0 + T.gqs0 + k];
 				const int e = q.x & 0xFFFF, n = (q.x >> 16) & 0xFFFF;
+				double* ga = form == 1 ? &gpart[6 * (size_t)H.gslot[(size_t)H.swin[0].gslot0 + T.gqs0 + k]] : &gacc[6 * (size_t)e];
 				for (int i = 0; i < n; ++i) {
 					const double* rc = &rec[(size_t)SSK_ND_REC * H.gitem[(size_t)W.gitem0 + q.y + i]];
 					double x[3];
 					cross(rc + 9, rc + 21, x);
-					for (int c = 0; c < 3; ++c) { gacc[6 * e + c] += rc[21 + c]; gacc[6 * e + 3 + c] += x[c]; }
+					for (int c = 0; c < 3; ++c) { ga[c] += rc[21 + c]; ga[3 + c] += x[c]; }
 				}
 			}
+	}
+	if (form == 1) {
+		// the reduction kernel: a block's partial slots are contiguous (tile order), an edge's gradient slots likewise
+		const nd_split& S = H.swin[0];
+		for (int pid = 0; pid < n_pairs; ++pid)
+			for (int s2 = H.poff[(size_t)S.poff0 + pid]; s2 < H.poff[(size_t)S.poff0 + pid + 1]; ++s2)
+				for (int c = 0; c < 36; ++c) Hb[36 * (size_t)pid + c] += part[36 * (size_t)s2 + c];
+		for (int e = 0; e < W.E; ++e)
+			for (int s2 = H.goff[(size_t)S.goff0 + e]; s2 < H.goff[(size_t)S.goff0 + e + 1]; ++s2)
+				for (int c = 0; c < 6; ++c) gacc[6 * (size_t)e + c] += gpart[6 * (size_t)s2 + c];
 	}
 	const int np = n6;
 	for (int i = 0; i < n6 * n6; ++i) Hred[i] = 0.0;
@@ -223,7 +246,7 @@ int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lam
 	}
 	for (int i = 0; i < n6; ++i) g[i] = gacc[i];
 	if (vmax_out) *vmax_out = vmax;
-	if (stats) { stats[0] = W.n_tiles; stats[1] = n_groups; stats[2] = (int)H.item.size(); stats[3] = H.max_items_per_lane; }
+	if (stats) { stats[0] = W.n_tiles; stats[1] = n_groups; stats[2] = (int)H.item.size(); stats[3] = form == 1 ? H.max_tile_blocks : H.max_items_per_lane; if (form == 1) stats[4] = (int)H.part_slots; }
 	if (dp && df) {
 		for (int gi = 0; gi < n_groups; ++gi) {
 			const nd_group& G = H.group[(size_t)W.grp0 + gi];
@@ -252,6 +275,12 @@ int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lam
 		}
 	}
 	return 0;
+}
+
+int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lambda, int pre, int waves, double* Hred, double* g, const double* dp, double* df,
+                     double* vmax_out, int* stats /* tiles, groups, items, max items per lane */)
+{
+	return nd_emu_linearise_form(Wn, P, lambda, pre, waves, Hred, g, dp, df, vmax_out, stats, 0);
 }
 
 }  // extern "C"
