@@ -3,6 +3,7 @@
 // uploads state + structure to HBM once, and runs the persistent LM kernel of ssk_lm.hip on it.
 #include "ssk_lm.h"
 #include "ssk_lm_node_build.h"
+#include "ssk_lm_split.h"
 #include <memory_resource>
 #include <unordered_map>
 #include <algorithm>
@@ -38,6 +39,11 @@ struct ssk_lm_batch {
 	bool node_ok = false, node_big = false;
 	nd_dev N{};
 	size_t node_dyn_bytes = 0;
+	// phase-split node form (ssk_lm_split.hip): windows whose reduced system does not fit LDS (the depth-5 local areas) -- and lean batches:
+	// built from the node tables alone, the tiled / general families are never constructed
+	bool split_ok = false, lean = false;
+	sp_dev S{};
+	size_t split_solve_dyn_bytes = 0, split_init_dyn_bytes = 0;
 	bool coop_pending = false;
 	lm_cam coop_P{};
 	double* pose_bak = nullptr; double* lm_bak = nullptr;
@@ -367,6 +373,214 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 	delete b;
 }
 
+// argument checks of one window; E / L = optimised edges / landmarks, s_edge / s_lm = the slot -> index maps, n_path = path entries
+static int lm_validate_window(ssk_ctx* ctx, const ssk_lm_window& Wn, int w, int& E, int& L, std::vector<int>& s_edge, std::vector<int>& s_lm, int& n_path)
+{
+	if (Wn.n_edges_total < 0 || Wn.n_lms_total < 0 || Wn.n_obs < 0 ||
+	    (Wn.n_edges_total > 0 && (!Wn.edge_unknown_slot || !Wn.edge_inv_pose)) ||
+	    (Wn.n_lms_total > 0 && (!Wn.lm_unknown_slot || !Wn.lm_pos)) ||
+	    (Wn.n_obs > 0 && (!Wn.obs_lm || !Wn.obs_px || !Wn.obs_path_off)))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d has NULL arrays", w);
+	E = 0; L = 0;
+	for (int e = 0; e < Wn.n_edges_total; ++e) if (Wn.edge_unknown_slot[e] >= 0) ++E;
+	for (int l = 0; l < Wn.n_lms_total; ++l) if (Wn.lm_unknown_slot[l] >= 0) ++L;
+	if (6 * E > SSK_LM_MAX_N6) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: window %d optimises %d edges (> %d)", w, E, SSK_LM_MAX_N6 / 6);
+	s_edge.assign((size_t)E, -1); s_lm.assign((size_t)L, -1);
+	for (int e = 0; e < Wn.n_edges_total; ++e) {
+		const int s = Wn.edge_unknown_slot[e];
+		if (s >= E || (s >= 0 && s_edge[s] != -1)) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d edge slots are not a permutation of 0..E-1", w);
+		if (s >= 0) s_edge[s] = e;
+	}
+	for (int l = 0; l < Wn.n_lms_total; ++l) {
+		const int s = Wn.lm_unknown_slot[l];
+		if (s >= L || (s >= 0 && s_lm[s] != -1)) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d landmark slots are not a permutation of 0..L-1", w);
+		if (s >= 0) s_lm[s] = l;
+	}
+	n_path = Wn.n_obs ? Wn.obs_path_off[Wn.n_obs] : 0;
+	if (Wn.n_obs && Wn.obs_path_off[0] != 0) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d obs_path_off[0] != 0", w);
+	for (int o = 0; o < Wn.n_obs; ++o) {
+		const int len = Wn.obs_path_off[o + 1] - Wn.obs_path_off[o];
+		if (len < 0 || len > SSK_LM_MAX_PATH) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d observation %d path length %d outside [0,%d]", w, o, len, SSK_LM_MAX_PATH);
+		if (Wn.obs_lm[o] < 0 || Wn.obs_lm[o] >= Wn.n_lms_total) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d observation %d landmark out of range", w, o);
+	}
+	for (int p = 0; p < n_path; ++p)
+		if (!Wn.path_edge || Wn.path_edge[p] < 0 || (Wn.path_edge[p] >> 1) >= Wn.n_edges_total)
+			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d path entry %d out of range", w, p);
+
+	return SSK_OK;
+}
+
+// ---- lean batch: node tables only ----
+// A batch whose windows all fit the node builder (ssk_lm_node_build.h: <= 128 optimised edges, <= 64 observations and <= 63 nodes per landmark)
+// needs none of the tiled / general structures: every window small enough for lm_solve_node_kernel (reduced system + a tile of records in LDS)
+// -> the persistent node kernel; otherwise -> the phase-split kernels (ssk_lm_split.h), whatever the windows' sizes.  Returns 1 when the
+// batch does not qualify (the caller falls back to the full builder), 0 with *out set, or an error code.
+static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out, bool want_split)
+{
+	const int MAX_ITERS_ALLOC = 64;
+	static const bool timing = std::getenv("SSK_TIMING") != nullptr;
+	const auto t_begin = std::chrono::steady_clock::now();
+	const size_t node_lds_limit = (size_t)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC;
+	std::vector<int> edge_slot, lm_slot, obs_lm, obs_path_off, path_edge, slot_edge, slot_lm;
+	std::vector<double> pose, lm;
+	std::vector<float> obs_px;
+	std::vector<lm_win> hdr((size_t)n_windows);
+	long long h_total = 0, dpt = 0, dft = 0;
+	int max_n6 = 0;
+	bool split = want_split;
+	for (int w = 0; w < n_windows; ++w) {
+		const ssk_lm_window& Wn = windows[w];
+		lm_win& H = hdr[w];
+		int E = 0, L = 0, n_path = 0;
+		std::vector<int> s_edge, s_lm;
+		{ const int rcv = lm_validate_window(ctx, Wn, w, E, L, s_edge, s_lm, n_path); if (rcv) return rcv; }
+		std::memset(&H, 0, sizeof H);
+		H.n_edges = Wn.n_edges_total; H.E = E; H.n_lms = Wn.n_lms_total; H.L = L; H.n_obs = Wn.n_obs; H.n_path = n_path;
+		H.n_pairs = E * (E + 1) / 2; H.n_tiles = -1;
+		H.edge0 = (int)edge_slot.size(); H.lm0 = (int)lm_slot.size(); H.obs0 = (int)obs_lm.size();
+		H.opo0 = (int)obs_path_off.size(); H.path0 = (int)path_edge.size();
+		H.us0 = (int)slot_edge.size(); H.ls0 = (int)slot_lm.size();
+		H.trace0 = w * MAX_ITERS_ALLOC; H.h0 = h_total; H.dp_trace0 = dpt; H.df_trace0 = dft;
+		h_total += (long long)(6 * E + 1) * (6 * E + 2);
+		if (trace) { dpt += (long long)MAX_ITERS_ALLOC * 6 * E; dft += (long long)MAX_ITERS_ALLOC * 3 * L; }
+		max_n6 = std::max(max_n6, 6 * E);
+		if (8 * nd_lds_doubles(Wn.n_edges_total, E, 4, 0) > node_lds_limit) split = true;
+		edge_slot.insert(edge_slot.end(), Wn.edge_unknown_slot, Wn.edge_unknown_slot + Wn.n_edges_total);
+		pose.insert(pose.end(), Wn.edge_inv_pose, Wn.edge_inv_pose + 12 * (size_t)Wn.n_edges_total);
+		lm_slot.insert(lm_slot.end(), Wn.lm_unknown_slot, Wn.lm_unknown_slot + Wn.n_lms_total);
+		lm.insert(lm.end(), Wn.lm_pos, Wn.lm_pos + 3 * (size_t)Wn.n_lms_total);
+		obs_lm.insert(obs_lm.end(), Wn.obs_lm, Wn.obs_lm + Wn.n_obs);
+		obs_px.insert(obs_px.end(), Wn.obs_px, Wn.obs_px + 4 * (size_t)Wn.n_obs);
+		if (Wn.n_obs) obs_path_off.insert(obs_path_off.end(), Wn.obs_path_off, Wn.obs_path_off + Wn.n_obs + 1);
+		else obs_path_off.push_back(0);
+		if (n_path) path_edge.insert(path_edge.end(), Wn.path_edge, Wn.path_edge + n_path);
+		slot_edge.insert(slot_edge.end(), s_edge.begin(), s_edge.end());
+		slot_lm.insert(slot_lm.end(), s_lm.begin(), s_lm.end());
+	}
+	// ---- the node tables, in the form the kernel family wants (a batch that turns out too large for the node kernel's LDS is re-built split) ----
+	nd_host NH;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		NH = nd_host();
+		bool fits = true;
+		for (int w = 0; w < n_windows && fits; ++w) {
+			const lm_win& Hw = hdr[w];
+			nd_win nw{};
+			nw.edge0 = Hw.edge0; nw.lm0 = Hw.lm0; nw.us0 = Hw.us0; nw.ls0 = Hw.ls0; nw.trace0 = Hw.trace0; nw.dp_trace0 = Hw.dp_trace0; nw.df_trace0 = Hw.df_trace0;
+			nw.h0 = Hw.h0;
+			fits = nd_build_window(windows[w], SSK_SP_WAVES, NH, nw, node_lds_limit / 8, split);
+		}
+		if (!fits) return 1;
+		if (split || 8 * NH.lds_doubles <= node_lds_limit) break;
+		split = true;
+	}
+	const auto t_sym = std::chrono::steady_clock::now();
+	ssk_lm_batch* b = new ssk_lm_batch();
+	b->ctx = ctx; b->n_windows = n_windows; b->trace = trace; b->max_iters_alloc = MAX_ITERS_ALLOC; b->max_n6 = max_n6;
+	b->hdr = hdr; b->n_pose = pose.size(); b->n_lm = lm.size();
+	b->lean = true; b->node_ok = !split; b->split_ok = split;
+	lm_dev& D = b->D;
+	int rc = SSK_OK;
+#define UP(vec, field) if (!rc) rc = upload(b, vec, &D.field)
+	UP(hdr, win);
+	UP(edge_slot, edge_slot); UP(lm_slot, lm_slot); UP(obs_lm, obs_lm); UP(obs_px, obs_px); UP(obs_path_off, obs_path_off);
+	UP(path_edge, path_edge); UP(slot_edge, slot_edge); UP(slot_lm, slot_lm);
+	UP(pose, pose0); UP(lm, lm0);
+#undef UP
+#define UPN(vec, field) if (!rc) rc = upload(b, NH.vec, &b->N.field)
+	UPN(win, win); UPN(tile, tile); UPN(group, group); UPN(suf, suf); UPN(obs, obs); UPN(px, px); UPN(lane, lane);
+	UPN(item, item); UPN(gitem, gitem); UPN(gqs, gqs);
+	if (!split) { UPN(qs, qs); }
+#undef UPN
+	// launch order / XCD placement: windows by observations x optimised edges, largest first
+	std::vector<int> ord((size_t)n_windows);
+	for (int w = 0; w < n_windows; ++w) ord[(size_t)w] = w;
+	{
+		const char* oe = std::getenv("SSK_LM_ORDER");
+		if (!oe || std::atoi(oe) != 0)
+			std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return (long long)NH.win[a].n_obs * (NH.win[a].E + 4) > (long long)NH.win[c].n_obs * (NH.win[c].E + 4); });
+	}
+	std::vector<nd_i2> tile_map;
+	std::vector<int> win_map;
+	if (!split) {
+		if (!rc) rc = upload(b, ord, &b->N.order);
+		b->node_dyn_bytes = 8 * NH.lds_doubles;
+	} else {
+		// a window's workgroups all go to ONE XCD (workgroup i runs on XCD i mod 8): its suffix table, landmarks and scratch stay in that L2
+		constexpr int NX = 8;
+		std::vector<std::vector<nd_i2>> tl(NX);
+		std::vector<std::vector<int>> wl(NX);
+		std::vector<long long> load(NX, 0);
+		for (int w : ord) {
+			int x = 0;
+			for (int k = 1; k < NX; ++k) if (load[k] < load[x]) x = k;
+			for (int t = 0; t < NH.win[(size_t)w].n_tiles; ++t) tl[x].push_back(nd_i2{w, t});
+			wl[x].push_back(w);
+			load[x] += NH.win[(size_t)w].n_tiles;
+		}
+		size_t mt = 0, mw = 0;
+		for (int x = 0; x < NX; ++x) { mt = std::max(mt, tl[x].size()); mw = std::max(mw, wl[x].size()); }
+		tile_map.assign(mt * NX, nd_i2{-1, 0});
+		win_map.assign(mw * NX, -1);
+		for (int x = 0; x < NX; ++x) {
+			for (size_t k = 0; k < tl[x].size(); ++k) tile_map[k * NX + x] = tl[x][k];
+			for (size_t k = 0; k < wl[x].size(); ++k) win_map[k * NX + x] = wl[x][k];
+		}
+		b->S.n_tile_wgs = (int)tile_map.size(); b->S.n_win_wgs = (int)win_map.size();
+		if (!rc) rc = upload(b, NH.swin, &b->S.sw);
+		if (!rc) rc = upload(b, NH.sqs, &b->S.sqs);
+		if (!rc) rc = upload(b, NH.poff, &b->S.poff);
+		if (!rc) rc = upload(b, NH.goff, &b->S.goff);
+		if (!rc) rc = upload(b, NH.gslot, &b->S.gslot);
+		if (!rc) rc = upload(b, tile_map, &b->S.tile_map);
+		if (!rc) rc = upload(b, win_map, &b->S.win_map);
+		size_t sd = 0, id = 0;
+		for (const nd_win& nw : NH.win) {
+			sd = std::max(sd, ssk_sp_solve_lds_doubles(nw.n_edges, nw.n_suf, nw.E));
+			id = std::max(id, 12 * (size_t)nw.n_edges + (size_t)nw.n_suf + 2);
+		}
+		b->split_solve_dyn_bytes = 8 * sd; b->split_init_dyn_bytes = 8 * id;
+		if (b->split_solve_dyn_bytes > node_lds_limit || b->split_init_dyn_bytes > node_lds_limit) { delete b; return 1; }
+	}
+	D.store_hff = 0;
+	if (!rc) rc = upload(b, pose, const_cast<const double**>(&D.pose));
+	if (!rc) rc = upload(b, lm, const_cast<const double**>(&D.lm));
+	const size_t n_ls = slot_lm.size(), n_us = slot_edge.size();
+	if (!rc) rc = scratch(b, pose.size(), &D.pose_new);
+	if (!rc) rc = scratch(b, lm.size(), &D.lm_new);
+	if (!rc) rc = scratch(b, 9 * n_ls, &D.Hff);
+	if (!rc) rc = scratch(b, 3 * n_ls, &D.gf);
+	if (!rc) rc = scratch(b, split ? (size_t)h_total : 0, &D.Hred);
+	if (!rc) rc = scratch(b, 6 * n_us, &D.dp);
+	if (!rc) rc = scratch(b, (size_t)n_windows, &D.res);
+	if (!rc) rc = scratch(b, trace ? (size_t)n_windows * MAX_ITERS_ALLOC : 1, &D.trace);
+	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
+	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
+	if (!rc) rc = scratch(b, (size_t)NH.tab_doubles, &b->N.tab);
+	if (!rc) rc = scratch(b, (size_t)SSK_ND_SCR * NH.lane.size(), &b->N.scr);
+	if (split) {
+		if (!rc) rc = scratch(b, 36 * (size_t)NH.part_slots + 36, &b->S.Hpart);
+		if (!rc) rc = scratch(b, 6 * (size_t)NH.gpart_slots + 6, &b->S.gpart);
+		if (!rc) rc = scratch(b, NH.tile.size(), &b->S.vpart);
+		if (!rc) rc = scratch(b, NH.tile.size(), &b->S.epart);
+		if (!rc) rc = scratch(b, NH.tile.size(), &b->S.fpart);
+		if (!rc) rc = scratch(b, (size_t)n_windows, &b->S.ctl);
+	}
+	D.trace_on = trace ? 1 : 0;
+	if (!rc) rc = finalize(b);
+	if (rc) { ssk_lm_batch_destroy(b); return rc; }
+	if (std::getenv("SSK_LM_DEBUG"))
+		std::fprintf(stderr, "[ssk lm] lean batch, %s form: %d windows, window 0: %d tiles, %d groups, %d suffixes; %zu items, %lld partial slots (all windows), most blocks of a tile %d\n",
+		             split ? "phase-split" : "node", n_windows, NH.win[0].n_tiles, NH.win[0].n_groups, NH.win[0].n_suf, NH.item.size(), NH.part_slots, NH.max_tile_blocks);
+	if (timing) {
+		(void)hipDeviceSynchronize();
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create, lean (%d windows, %s): symbolic %.3f ms, allocate + upload %.3f ms\n", n_windows, split ? "split" : "node",
+		             ms(t_begin, t_sym), ms(t_sym, std::chrono::steady_clock::now()));
+	}
+	*out = b;
+	return SSK_OK;
+}
+
 // with_general: also build what only the general scratch-in-L2 kernel reads (the q entries with their co-observation lists,
 // the chunk lists, its scratch arrays).  The first attempt leaves them out; a batch with a window the tiler cannot take (or
 // SSK_LM_KERNEL=l2) is built again with them.
@@ -438,37 +652,9 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		const auto tp0 = tnow();
 		const ssk_lm_window& Wn = windows[w];
 		lm_win& H = hdr[w];
-		if (Wn.n_edges_total < 0 || Wn.n_lms_total < 0 || Wn.n_obs < 0 ||
-		    (Wn.n_edges_total > 0 && (!Wn.edge_unknown_slot || !Wn.edge_inv_pose)) ||
-		    (Wn.n_lms_total > 0 && (!Wn.lm_unknown_slot || !Wn.lm_pos)) ||
-		    (Wn.n_obs > 0 && (!Wn.obs_lm || !Wn.obs_px || !Wn.obs_path_off)))
-			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d has NULL arrays", w);
-		int E = 0, L = 0;
-		for (int e = 0; e < Wn.n_edges_total; ++e) if (Wn.edge_unknown_slot[e] >= 0) ++E;
-		for (int l = 0; l < Wn.n_lms_total; ++l) if (Wn.lm_unknown_slot[l] >= 0) ++L;
-		if (6 * E > SSK_LM_MAX_N6) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: window %d optimises %d edges (> %d)", w, E, SSK_LM_MAX_N6 / 6);
-		std::vector<int> s_edge((size_t)E, -1), s_lm((size_t)L, -1);
-		for (int e = 0; e < Wn.n_edges_total; ++e) {
-			const int s = Wn.edge_unknown_slot[e];
-			if (s >= E || (s >= 0 && s_edge[s] != -1)) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d edge slots are not a permutation of 0..E-1", w);
-			if (s >= 0) s_edge[s] = e;
-		}
-		for (int l = 0; l < Wn.n_lms_total; ++l) {
-			const int s = Wn.lm_unknown_slot[l];
-			if (s >= L || (s >= 0 && s_lm[s] != -1)) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d landmark slots are not a permutation of 0..L-1", w);
-			if (s >= 0) s_lm[s] = l;
-		}
-		const int n_path = Wn.n_obs ? Wn.obs_path_off[Wn.n_obs] : 0;
-		if (Wn.n_obs && Wn.obs_path_off[0] != 0) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d obs_path_off[0] != 0", w);
-		for (int o = 0; o < Wn.n_obs; ++o) {
-			const int len = Wn.obs_path_off[o + 1] - Wn.obs_path_off[o];
-			if (len < 0 || len > SSK_LM_MAX_PATH) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d observation %d path length %d outside [0,%d]", w, o, len, SSK_LM_MAX_PATH);
-			if (Wn.obs_lm[o] < 0 || Wn.obs_lm[o] >= Wn.n_lms_total) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d observation %d landmark out of range", w, o);
-		}
-		for (int p = 0; p < n_path; ++p)
-			if (!Wn.path_edge || Wn.path_edge[p] < 0 || (Wn.path_edge[p] >> 1) >= Wn.n_edges_total)
-				return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d path entry %d out of range", w, p);
-
+		int E = 0, L = 0, n_path = 0;
+		std::vector<int> s_edge, s_lm;
+		{ const int rcv = lm_validate_window(ctx, Wn, w, E, L, s_edge, s_lm, n_path); if (rcv) return rcv; }
 		// ---- symbolic structure ----
 		// per landmark index: its (edge slot -> path entries) incidences
 		std::vector<int> p_obs((size_t)n_path);
@@ -1235,6 +1421,16 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 	const char* force = std::getenv("SSK_LM_KERNEL");
 	const bool l2 = force && std::strcmp(force, "l2") == 0;
 	const bool want_acc = force && std::strcmp(force, "acc") == 0;
+	// the default: node tables only (node kernel for windows whose reduced system fits LDS, the phase-split kernels otherwise; =split forces
+	// the latter); a batch the node builder cannot take, or a forced kernel of rounds 1-3, goes through the full builder
+	if (!force || std::strcmp(force, "split") == 0) {
+		if (!ctx) return SSK_ERR_BAD_ARG;
+		if (!windows || n_windows < 1 || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: bad argument");
+		SSK_HIP(ctx, hipSetDevice(ctx->device));
+		const int rc = lm_batch_create_lean(ctx, windows, n_windows, trace, out, force != nullptr);
+		if (rc != 1) return rc;
+		if (force) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: SSK_LM_KERNEL=split, but a window of the batch does not fit the node builder");
+	}
 	return lm_batch_create_impl(ctx, windows, n_windows, trace, out, l2, want_acc);
 }
 
@@ -1287,6 +1483,7 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
 	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a run on top of a timed-out cooperative launch continues from the repaired state)
+	if (b->split_ok) return ssk_lm_launch_split(ctx, b->D, b->N, b->S, P, b->n_windows, b->split_solve_dyn_bytes, b->split_init_dyn_bytes);
 	if (b->node_ok) return ssk_lm_launch_node(ctx, b->D, b->N, P, b->n_windows, b->node_dyn_bytes, b->node_big);
 	if (b->acc_ok) return ssk_lm_launch_acc(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
@@ -1325,7 +1522,8 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 	// the same decisions as ssk_lm_batch_run
 	const char* force = std::getenv("SSK_LM_KERNEL");
 	const char* name = "lm_solve_kernel";
-	if (b->node_ok) name = b->node_big ? "lm_solve_node_big_kernel" : "lm_solve_node_kernel";
+	if (b->split_ok) name = "lm_split_linearise_kernel";      // (the heaviest of the four kernels of a pass)
+	else if (b->node_ok) name = b->node_big ? "lm_solve_node_big_kernel" : "lm_solve_node_kernel";
 	else if (b->acc_ok) name = b->schur_mfma ? "lm_solve_acc_mfma_kernel" : "lm_solve_acc_kernel";
 	else if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) {
 		bool coop = false;

@@ -234,6 +234,8 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	int n_part = 0, n_gpart = 0, max_tile_blocks = 0;
 	if (split) {
 		std::vector<std::vector<int>> by_pid((size_t)n_pairs);
+		std::vector<char> is_diag((size_t)n_pairs, 0);         // block (e, e): the only ones the lambda_0 pass needs (bit 30 of the slot's x)
+		for (int e = 0; e < E; ++e) is_diag[(size_t)pid_of(e, e)] = 1;
 		std::vector<int> used;
 		for (size_t t = 0; t < n_tiles; ++t) {
 			nd_tile T{};
@@ -246,7 +248,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			max_tile_blocks = std::max(max_tile_blocks, (int)used.size());
 			for (int p2 : used) {
 				const std::vector<int>& v = by_pid[(size_t)p2];
-				w_sqs.push_back(nd_i4{p2, (int)v.size(), (int)w_item.size(), -1});
+				w_sqs.push_back(nd_i4{p2 | (is_diag[(size_t)p2] ? 1 << 30 : 0), (int)v.size(), (int)w_item.size(), -1});
 				w_item.insert(w_item.end(), v.begin(), v.end());
 			}
 			for (int p2 : used) by_pid[(size_t)p2].clear();
@@ -262,11 +264,11 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		}
 		// partial slots, block-major (a block's slots are contiguous, in tile order); gradient slots, edge-major
 		w_poff.assign((size_t)n_pairs + 1, 0);
-		for (const nd_i4& q : w_sqs) w_poff[(size_t)q.x + 1]++;
+		for (const nd_i4& q : w_sqs) w_poff[(size_t)(q.x & 0xFFFF) + 1]++;
 		for (int p2 = 0; p2 < n_pairs; ++p2) w_poff[(size_t)p2 + 1] += w_poff[(size_t)p2];
 		{
 			std::vector<int> next(w_poff.begin(), w_poff.end() - 1);
-			for (nd_i4& q : w_sqs) q.w = next[(size_t)q.x]++;
+			for (nd_i4& q : w_sqs) q.w = next[(size_t)(q.x & 0xFFFF)]++;
 		}
 		n_part = (int)w_sqs.size();
 		w_goff.assign((size_t)E + 1, 0);

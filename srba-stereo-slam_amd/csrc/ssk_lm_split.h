@@ -1,0 +1,49 @@
+// ssk_lm_split.h -- the PHASE-SPLIT node form of the relative-BA Levenberg-Marquardt solve (kernels: ssk_lm_split.hip,
+// ssk_lm_split_solve.hip; host tables: ssk_lm_node_build.h with split = true).  Reference: rba.define_new_keyframe EST.cpp:782-784 with
+// srba_max_optimize_depth = 5 (KITTI.ini:104-106: local areas of ~40 edges / 8 k observations), solver type SRBA.h:34.
+//
+// Why.  A window whose reduced system (6E x 6E doubles) does not fit LDS cannot keep its block accumulators on one CU: the persistent
+// one-workgroup-per-window kernels of rounds 1-3 walked 39 tiles serially per LM pass at two waves per SIMD (91.6 ms per 1 024 depth-5
+// windows, 279 spilled VGPRs).  Here one LM pass of the WHOLE BATCH is four launches, each with its own shape and register budget:
+//   K1  lm_split_linearise_kernel   grid = all tiles of all windows (4 landmark groups = 4 wavefronts each, ~40 k workgroups): group phase
+//       (observations -> run sums -> roots -> node records in LDS) and pair phase of ssk_lm_node.h; a quad of lanes per (tile, block) sums its
+//       items in registers and stores ONE 36-double partial to its own slot in HBM (no atomics; slots are numbered block-major by the host),
+//       reduced-gradient partials per (tile, edge) likewise.
+//   K2  lm_split_solve_kernel       grid = windows, 512 threads: sums a block's partial slots in slot (= tile) order into the dense bordered
+//       system, LDL^T by the register-tile solver (ldl_solve_regtile: the solver in a kernel of its own), edge update exp(eps) (+) T, the
+//       trial state's suffix table.  The lambda_0 pass ends after the diagonal blocks.
+//   K3  lm_split_score_kernel       grid = tiles: landmark steps + robust error of the trial state group by group (nd_score_group), one error /
+//       |delta_f|^2 partial per tile.
+//   K4  lm_split_decide_kernel      grid = windows: partials summed in tile order, accept / reject, lambda schedule (contract L5 of
+//       oracle/oracle_lm.c), trace, state copy, stop flags.  A stopped window's workgroups leave at once in every later launch.
+// Every sum has one owner and a fixed order: results are bit-reproducible run to run and independent of the batch around a window.
+#pragma once
+#include "ssk_lm.h"
+#include "ssk_lm_node.h"
+
+struct sp_ctl {                         // LM loop state of one window (device)
+	double lambda, nu, err, dpn;
+	int iters, accepted, stop, cur;     // cur: which of the two suffix tables holds the current state's transforms
+	int active;                         // 1 while the window's loop runs
+	int ok;                             // the attempt's factorisation succeeded (K2 -> K3 / K4)
+	int pre;                            // 1: the next linearisation is the lambda_0 pass (every window's first: K2 ends it; the host launches no K3 / K4 behind it)
+	int pad;
+};
+
+struct sp_dev {
+	const nd_split* sw; const nd_i4* sqs; const int* poff; const int* goff; const int* gslot;
+	double* Hpart; double* gpart;       // 36 / 6 doubles per partial slot
+	double* vpart; double* epart; double* fpart;      // per tile of the batch: largest landmark-block diagonal (lambda_0 pass), robust error, |delta_f|^2
+	sp_ctl* ctl;
+	const nd_i2* tile_map;              // K1 / K3: workgroup -> (window, tile of the window) or (-1, -): a window's tiles share an XCD (its L2 holds the window's suffix table)
+	const int* win_map;                 // K2 / K4: workgroup -> window or -1, the same XCD as its tiles
+	int n_tile_wgs, n_win_wgs;
+};
+
+constexpr int SSK_SP_WAVES = 4;         // wavefronts per K1 / K3 workgroup = landmark groups per tile
+// K2: dynamic LDS of the solve kernel (doubles): the register-tile solver's staging + the window's edge poses and trie records
+size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E);
+
+int ssk_lm_launch_split(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp_dev& S, const lm_cam& P, int n_windows, size_t solve_dyn_bytes, size_t init_dyn_bytes);
+// (ssk_lm_split_solve.hip)
+int ssk_lm_launch_split_solve(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp_dev& S, const lm_cam& P, size_t dyn_bytes);

@@ -175,7 +175,8 @@ int nd_emu_linearise_form(const ssk_lm_window* Wn, const ssk_lm_params* P, doubl
 				double* acc;
 				if (form == 1) {
 					const nd_i4 q = H.sqs[(size_t)H.swin[0].sqs0 + T.qs0 + sl];
-					pid = q.x; n = q.y; first = q.z;
+					pid = q.x & 0xFFFF; n = q.y; first = q.z;
+					if (pre && !((q.x >> 30) & 1)) continue;     // (the lambda_0 pass: diagonal blocks only)
 					acc = &part[36 * (size_t)q.w];
 				} else {
 					const nd_i2 q = H.qs[(size_t)W.qs0 + T.qs0 + sl];
