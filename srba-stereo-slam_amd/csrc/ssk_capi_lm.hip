@@ -499,7 +499,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		if (!oe || std::atoi(oe) != 0)
 			std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return (long long)NH.win[a].n_obs * (NH.win[a].E + 4) > (long long)NH.win[c].n_obs * (NH.win[c].E + 4); });
 	}
-	std::vector<nd_i2> tile_map;
+	std::vector<sp_tile> tile_map;
 	std::vector<int> win_map;
 	if (!split) {
 		if (!rc) rc = upload(b, ord, &b->N.order);
@@ -519,13 +519,27 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		}
 		size_t mt = 0, mw = 0;
 		for (int x = 0; x < NX; ++x) { mt = std::max(mt, tl[x].size()); mw = std::max(mw, wl[x].size()); }
-		tile_map.assign(mt * NX, nd_i2{-1, 0});
+		sp_tile none{};
+		none.wi = -1;
+		tile_map.assign(mt * NX, none);
 		win_map.assign(mw * NX, -1);
 		for (int x = 0; x < NX; ++x) {
-			for (size_t k = 0; k < tl[x].size(); ++k) tile_map[k * NX + x] = tl[x][k];
+			for (size_t k = 0; k < tl[x].size(); ++k) {
+				const nd_i2 wt = tl[x][k];
+				const nd_win& nw = NH.win[(size_t)wt.x];
+				const nd_split& sw = NH.swin[(size_t)wt.x];
+				const nd_tile& T = NH.tile[(size_t)nw.tile0 + wt.y];
+				sp_tile d{};
+				d.wi = wt.x; d.tile = wt.y; d.grp = nw.grp0 + T.grp0; d.n_grp = T.n_grp; d.sqs = sw.sqs0 + T.qs0; d.n_slots = T.n_rounds;
+				d.gqs = nw.gqs0 + T.gqs0; d.n_gqs = T.n_gqs; d.gslot = sw.gslot0 + T.gqs0; d.gtile = sw.gtile0 + wt.y;
+				d.item0 = nw.item0; d.gitem0 = nw.gitem0;
+				tile_map[k * NX + x] = d;
+			}
 			for (size_t k = 0; k < wl[x].size(); ++k) win_map[k * NX + x] = wl[x][k];
 		}
 		b->S.n_tile_wgs = (int)tile_map.size(); b->S.n_win_wgs = (int)win_map.size();
+		b->S.max_pairs = 0;
+		for (const nd_win& nw : NH.win) b->S.max_pairs = std::max(b->S.max_pairs, nw.E * (nw.E + 1) / 2);
 		if (!rc) rc = upload(b, NH.swin, &b->S.sw);
 		if (!rc) rc = upload(b, NH.sqs, &b->S.sqs);
 		if (!rc) rc = upload(b, NH.poff, &b->S.poff);

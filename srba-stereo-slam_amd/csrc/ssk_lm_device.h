@@ -117,6 +117,25 @@ __device__ void so3_exp(const double* w, double* R)
 	R[0] += 1; R[4] += 1; R[8] += 1;
 }
 
+// (the same, always inlined: a call passes w and R through scratch memory)
+__device__ __forceinline__ void so3_exp_inl(const double* w, double* R)
+{
+	const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+	const double th = sqrt(th2);
+	double a, b;
+	if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; }
+	else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+	const double K[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+	double K2[9];
+#pragma unroll
+	for (int i = 0; i < 3; ++i)
+#pragma unroll
+		for (int j = 0; j < 3; ++j) K2[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+#pragma unroll
+	for (int i = 0; i < 9; ++i) R[i] = a * K[i] + b * K2[i];
+	R[0] += 1; R[4] += 1; R[8] += 1;
+}
+
 // G (fast path): the reduced system solved in LDS as a square-root-free LDL^T of the matrix bordered by the
 // right-hand side (row n = g_red^T), right-looking, by the whole workgroup:
 //   A(i,k) -= A(i,j) A(k,j) / d_j   for j < k <= i <= n; column j itself stays unscaled (U_ij = L'_ij d_j), d_j = A(j,j)

@@ -93,7 +93,8 @@ struct nd_group {
 // phase-split form (ssk_lm_split.hip): per window, beside its nd_win (whose tile[].qs0 / n_rounds then mean: first (tile, block) slot of the
 // tile in sqs[], number of such slots)
 struct nd_split {
-	int sqs0;                           // nd_dev::sqs[sqs0 + tile.qs0 + k]: x block pair id, y items, z first item (window relative), w partial slot
+	int sqs0;                           // sp_dev::sqs[sqs0 + tile.qs0 + k], a LANE slot: x block pair id | several-lane blocks in this wavefront << 29 | diagonal block << 30,
+	                                    // y items of the block | log2(lanes of the block) << 16 | this lane's rank << 20, z first item (window relative), w partial slot
 	int poff0, goff0, gslot0;           // sp_dev::poff[poff0 + pid] .. [pid + 1]: the block's partial slots; goff[goff0 + e]: the edge's gradient slots; gslot[gslot0 + tile.gqs0 + k]
 	int n_part, n_gpart;
 	int gtile0;                         // the window's first tile in the batch-wide tile numbering (per-tile error / vmax partials)

@@ -244,12 +244,34 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			for (const auto& it : tile_items[t]) { if (by_pid[(size_t)it.first].empty()) used.push_back(it.first); by_pid[(size_t)it.first].push_back(it.second); }
 			// heaviest first: the 16 quads of a wavefront run in lockstep
 			std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
-			T.qs0 = (int)w_sqs.size(); T.n_rounds = (int)used.size();      // (split form: n_rounds = number of (tile, block) slots)
+			// LANE slots: a block gets 1, 2 or 4 lanes (its items dealt out among them, the lanes' sums joined by one or two DPP steps), the fewest
+			// that keep a lane's run <= R items; R = the shortest run length whose lanes fit the fewest rounds of the workgroup.  Heaviest blocks first,
+			// so the 4-lane blocks come first, then the 2-lane ones: every group is aligned and a wavefront's lanes walk runs of similar length.
+			const int NT_ = waves * 64;
+			const int rounds_min = std::max(1, ((int)used.size() + NT_ - 1) / NT_);
+			auto lanes_of = [](int c, int R) { return c <= R ? 1 : (c <= 2 * R ? 2 : 4); };
+			int R = 1;
+			for (;; ++R) {
+				long long lanes = 0;
+				for (int p2 : used) lanes += lanes_of((int)by_pid[(size_t)p2].size(), R);
+				if (lanes <= (long long)NT_ * rounds_min) break;
+			}
+			T.qs0 = (int)w_sqs.size();
 			max_tile_blocks = std::max(max_tile_blocks, (int)used.size());
 			for (int p2 : used) {
 				const std::vector<int>& v = by_pid[(size_t)p2];
-				w_sqs.push_back(nd_i4{p2 | (is_diag[(size_t)p2] ? 1 << 30 : 0), (int)v.size(), (int)w_item.size(), -1});
+				const int k = lanes_of((int)v.size(), R), kc = k == 4 ? 2 : (k == 2 ? 1 : 0);
+				if ((int)v.size() > 0xFFFF) return false;
+				for (int r = 0; r < k; ++r)
+					w_sqs.push_back(nd_i4{p2 | (is_diag[(size_t)p2] ? 1 << 30 : 0), (int)v.size() | (kc << 16) | (r << 20), (int)w_item.size(), -1});
 				w_item.insert(w_item.end(), v.begin(), v.end());
+			}
+			T.n_rounds = (int)w_sqs.size() - T.qs0;               // (split form: n_rounds = number of lane slots of the tile)
+			// bit 29: this wavefront (64 consecutive lane slots) holds blocks of several lanes
+			for (int w0 = T.qs0; w0 < (int)w_sqs.size(); w0 += 64) {
+				bool multi = false;
+				for (int i = w0; i < std::min(w0 + 64, (int)w_sqs.size()); ++i) multi |= ((w_sqs[(size_t)i].y >> 16) & 3) != 0;
+				if (multi) for (int i = w0; i < std::min(w0 + 64, (int)w_sqs.size()); ++i) w_sqs[(size_t)i].x |= 1 << 29;
 			}
 			for (int p2 : used) by_pid[(size_t)p2].clear();
 			T.gqs0 = (int)w_gqs.size(); T.n_gqs = 0;
@@ -264,13 +286,13 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		}
 		// partial slots, block-major (a block's slots are contiguous, in tile order); gradient slots, edge-major
 		w_poff.assign((size_t)n_pairs + 1, 0);
-		for (const nd_i4& q : w_sqs) w_poff[(size_t)(q.x & 0xFFFF) + 1]++;
+		for (const nd_i4& q : w_sqs) if (((q.y >> 20) & 3) == 0) w_poff[(size_t)(q.x & 0xFFFF) + 1]++;
 		for (int p2 = 0; p2 < n_pairs; ++p2) w_poff[(size_t)p2 + 1] += w_poff[(size_t)p2];
 		{
 			std::vector<int> next(w_poff.begin(), w_poff.end() - 1);
-			for (nd_i4& q : w_sqs) q.w = next[(size_t)(q.x & 0xFFFF)]++;
+			for (nd_i4& q : w_sqs) q.w = ((q.y >> 20) & 3) == 0 ? next[(size_t)(q.x & 0xFFFF)]++ : next[(size_t)(q.x & 0xFFFF)] - 1;      // (the lanes of a block follow its first one)
 		}
-		n_part = (int)w_sqs.size();
+		n_part = w_poff[(size_t)n_pairs];
 		w_goff.assign((size_t)E + 1, 0);
 		for (const nd_i2& q : w_gqs) w_goff[(size_t)(q.x & 0xFFFF) + 1]++;
 		for (int e = 0; e < E; ++e) w_goff[(size_t)e + 1] += w_goff[(size_t)e];

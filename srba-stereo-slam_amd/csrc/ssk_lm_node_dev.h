@@ -115,6 +115,9 @@ __device__ __forceinline__ nd_recs nd_fetch_recs(const nd_dev& N, const nd_win& 
 	return r;
 }
 
+// LATE_TN: the node lanes' transform and landmark are loaded behind the observation phase instead of in front of it (30 VGPRs fewer at the
+// function's pressure peak: the phase-split kernel runs three wavefronts per SIMD on 168 registers; the load then flies behind the run sums)
+template <bool LATE_TN = false>
 __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G, const nd_recs rc,
                                                    const double* __restrict__ tab, double* __restrict__ stage, double lambda, bool pre, int lane, double& vmax)
 {
@@ -127,8 +130,8 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 	const bool is_node = kind == 2, is_root = kind == 1;
 	// the node's transform and landmark (needed last: in flight behind everything else)
 	double Tn[12], fn[3];
-	nd_load12(tab + 12 * (size_t)(is_node ? (lrec.z & 0xFFFF) : 0), Tn);
-	{
+	if (!LATE_TN) {
+		nd_load12(tab + 12 * (size_t)(is_node ? (lrec.z & 0xFFFF) : 0), Tn);
 		const double* fp = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
 		fn[0] = fp[0]; fn[1] = fp[1]; fn[2] = fp[2];
 	}
@@ -174,6 +177,11 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 	}
 	WAVE_SYNC();
 	FINE(0);
+	if (LATE_TN) {
+		nd_load12(tab + 12 * (size_t)(is_node ? (lrec.z & 0xFFFF) : 0), Tn);
+		const double* fp = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
+		fn[0] = fp[0]; fn[1] = fp[1]; fn[2] = fp[2];
+	}
 	// ---- lane = root / node: sums over its run of the staging (a landmark's observations are sorted so that a trie subtree is a run) ----
 	double vs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	{

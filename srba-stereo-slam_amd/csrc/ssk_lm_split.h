@@ -9,8 +9,9 @@
 //       (observations -> run sums -> roots -> node records in LDS) and pair phase of ssk_lm_node.h; a quad of lanes per (tile, block) sums its
 //       items in registers and stores ONE 36-double partial to its own slot in HBM (no atomics; slots are numbered block-major by the host),
 //       reduced-gradient partials per (tile, edge) likewise.
-//   K2  lm_split_solve_kernel       grid = windows, 512 threads: sums a block's partial slots in slot (= tile) order into the dense bordered
-//       system, LDL^T by the register-tile solver (ldl_solve_regtile: the solver in a kernel of its own), edge update exp(eps) (+) T, the
+//   K2a lm_split_reduce_kernel      grid = windows x chunks of 7 blocks: sums a block's partial slots in slot (= tile) order into the dense bordered
+//       system (a kernel of its own: the sums are latency-bound loads that want every CU's full occupancy, not the solver's 8 wavefronts)
+//   K2  lm_split_solve_kernel       grid = windows, 512 threads: LDL^T by the register-tile solver (ldl_solve_regtile: the solver in a kernel of its own), edge update exp(eps) (+) T, the
 //       trial state's suffix table.  The lambda_0 pass ends after the diagonal blocks.
 //   K3  lm_split_score_kernel       grid = tiles: landmark steps + robust error of the trial state group by group (nd_score_group), one error /
 //       |delta_f|^2 partial per tile.
@@ -30,14 +31,25 @@ struct sp_ctl {                         // LM loop state of one window (device)
 	int pad;
 };
 
+// K1 / K3: one workgroup's tile with absolute indices, so that the tile's groups and slots load beside the window's headers instead of behind them
+struct alignas(16) sp_tile {
+	int wi, tile;                       // window (-1: none), tile of the window
+	int grp, n_grp;                     // nd_dev::group[grp ..)
+	int sqs, n_slots;                   // sp_dev::sqs[sqs ..): lane slots
+	int gqs, n_gqs, gslot;              // nd_dev::gqs[gqs ..), sp_dev::gslot[gslot ..)
+	int gtile;                          // the tile's number in the batch (vpart / epart / fpart)
+	int item0, gitem0;                  // the window's bases into nd_dev::item / gitem
+};
+
 struct sp_dev {
 	const nd_split* sw; const nd_i4* sqs; const int* poff; const int* goff; const int* gslot;
 	double* Hpart; double* gpart;       // 36 / 6 doubles per partial slot
 	double* vpart; double* epart; double* fpart;      // per tile of the batch: largest landmark-block diagonal (lambda_0 pass), robust error, |delta_f|^2
 	sp_ctl* ctl;
-	const nd_i2* tile_map;              // K1 / K3: workgroup -> (window, tile of the window) or (-1, -): a window's tiles share an XCD (its L2 holds the window's suffix table)
+	const sp_tile* tile_map;            // K1 / K3: workgroup -> tile (wi -1: none): a window's tiles share an XCD (its L2 holds the window's suffix table)
 	const int* win_map;                 // K2 / K4: workgroup -> window or -1, the same XCD as its tiles
 	int n_tile_wgs, n_win_wgs;
+	int max_pairs;                      // most 6x6 blocks of a window's reduced system (K2a's grid)
 };
 
 constexpr int SSK_SP_WAVES = 4;         // wavefronts per K1 / K3 workgroup = landmark groups per tile

@@ -2,6 +2,8 @@
 // kernel and the launch sequence.  Overview, data model: ssk_lm_split.h; algebra: ssk_lm_node.h; contract L1-L5: oracle/oracle_lm.c;
 // reference: rba.define_new_keyframe EST.cpp:782-784 (optimise depth 5, KITTI.ini:104-106), solver_LM_schur_dense_cholesky SRBA.h:34.
 #include "ssk_lm_split.h"
+#include <algorithm>
+#include <cstdlib>
 
 // LM parity is a 1e-6 relative tolerance (contract L5), not bit-exactness: let the compiler fuse multiply-adds here
 #pragma clang fp contract(fast)
@@ -20,6 +22,16 @@ constexpr int R_Q = 9, R_P = 12, R_V = 21;
 static_assert(NDW == SSK_SP_WAVES, "tile = SSK_SP_WAVES groups");
 
 #include "ssk_lm_node_dev.h"
+
+#ifdef SSK_LM_STAMPS
+// per-phase clock sums over all K1 workgroups of the non-lambda_0 passes (thread 0 of each): diagnostics build only (tools/split_stamps.py)
+__device__ unsigned long long g_sp_t[16];
+#define SP_T0() unsigned long long sp_t_ = __builtin_amdgcn_s_memtime()
+#define SP_T(i) do { if (threadIdx.x == 0 && !pre) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_sp_t[i], t_ - sp_t_); sp_t_ = t_; } } while (0)
+#else
+#define SP_T0() do {} while (0)
+#define SP_T(i) do {} while (0)
+#endif
 
 // ---- K0: per window: loop state, trial buffers = state, suffix table of the initial state ----
 __global__ __launch_bounds__(NT)
@@ -49,66 +61,92 @@ void lm_split_init_kernel(lm_dev D, nd_dev N, sp_dev S)
 }
 
 // ---- K1: one tile (NDW landmark groups) of one window: group phase, pair phase -> partial slots ----
+// Pair phase: LANE slots (host: ssk_lm_node_build.h): a block has 1, 2 or 4 lanes, its items dealt out among them, so that every lane of the
+// workgroup walks a run of about the same length (a lane per block made the first wavefront walk 30-item runs while the others idled; a quad per
+// block paid a 216-instruction DPP sum for every one-item block); the lanes of a block are joined by one or two DPP steps, its first lane stores.
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
-void lm_split_linearise_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P_arg)
+void lm_split_linearise_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P)
 {
-	__shared__ lm_cam s_P;
 	__shared__ double s_part[NW];
 	extern __shared__ __attribute__((aligned(16))) double s_dyn[];      // node records of the tile: wave w at s_dyn + 64 REC w
-	const nd_i2 tm = S.tile_map[blockIdx.x];
-	if (tm.x < 0) return;
-	const int wi = tm.x;
+	SP_T0();
+	const sp_tile T = S.tile_map[blockIdx.x];
+	if (T.wi < 0) return;
+	const int wi = T.wi;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, quad = tid >> 2, ql = tid & 3;
+	// one level of loads behind the tile record: loop state, window headers, the wavefront's group, the first lane slot, the quad's gradient slot
 	const sp_ctl c = S.ctl[wi];
-	if (!c.active) return;
-	if (threadIdx.x == 0) s_P = P_arg;
 	const nd_win W = N.win[wi];
 	const nd_split SW = S.sw[wi];
-	const nd_tile T = N.tile[W.tile0 + tm.y];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, quad = tid >> 2, ql = tid & 3;
+	const nd_group G = N.group[T.grp + min(wave, max(T.n_grp - 1, 0))];
+	nd_i4 q0 = nd_i4{0, 0, 0, 0};
+	if (tid < T.n_slots) q0 = S.sqs[T.sqs + tid];
+	if (!c.active) return;
 	const bool pre = c.pre != 0;
+	SP_T(0);
 	const double lambda = c.lambda;
 	const double* tab_cur = N.tab + W.tab0 + (c.cur ? 12 * (size_t)W.n_suf : 0);
 	double* reg = s_dyn;
 	double* stage = reg + 64 * REC * wave;
-	// the first round's slot and item codes: in flight behind the group phase
-	nd_i4 q0 = nd_i4{0, 0, 0, 0};
-	if (quad < T.n_rounds) q0 = S.sqs[SW.sqs0 + T.qs0 + quad];
-	__syncthreads();
-	const lm_cam& P = s_P;
 	double vmax = 0.0;
 	if (wave < T.n_grp) {
-		const nd_group G = N.group[W.grp0 + T.grp0 + wave];
 		const nd_recs rc = nd_fetch_recs(N, W, G, lane);
-		nd_linearise_group(D, N, W, P, G, rc, tab_cur, stage, lambda, pre, lane, vmax);
+#ifdef SSK_LM_STAMPS
+		if (tid == 0 && !pre) { (void)__builtin_amdgcn_readfirstlane(rc.lrec.x + rc.orec.x); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_sp_t[2], t_ - sp_t_); sp_t_ = t_; }
+#endif
+		nd_linearise_group<true>(D, N, W, P, G, rc, tab_cur, stage, lambda, pre, lane, vmax);
 	}
-	nd_items its = nd_items_fetch(N.item + W.item0 + q0.z, q0.y, ql, 4);
+	if (pre) {
+		// (the lambda_0 pass) the wavefront's largest landmark-block diagonal: into LDS now, a register held to the kernel's end was spilled
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) vmax = fmax(vmax, __shfl_down(vmax, o, 64));
+		if (lane == 0) s_part[wave] = vmax;
+	}
+	SP_T(3);
+	// item codes of the first lane slot and of the quad's gradient slot: in flight across the barrier
+	nd_i2 gq = nd_i2{0, 0};
+	int gs = 0;
+	if (quad < T.n_gqs) { gq = N.gqs[T.gqs + quad]; gs = S.gslot[T.gslot + quad]; }
+	const int* items = N.item + T.item0;
+	nd_items its = nd_items_fetch(items + q0.z, q0.y & 0xFFFF, (q0.y >> 20) & 3, 1 << ((q0.y >> 16) & 3));
+	const int gn = (gq.x >> 16) & 0xFFFF;
+	const int* gitems = N.gitem + T.gitem0 + gq.y;
+	int gi[ND_ITEMS_REG];
+#pragma unroll
+	for (int k2 = 0; k2 < ND_ITEMS_REG; ++k2) gi[k2] = gitems[min(ql + 4 * k2, max(gn - 1, 0))];
 	__syncthreads();
-	for (int k = quad; k < T.n_rounds; k += NQ) {
-		const nd_i4 q = k == quad ? q0 : S.sqs[SW.sqs0 + T.qs0 + k];
-		const int n = q.y;
-		if (k != quad) its = nd_items_fetch(N.item + W.item0 + q.z, n, ql, 4);
-		// the lambda_0 pass only needs the diagonal blocks (bit 30 of x)
-		if (pre && !((q.x >> 30) & 1)) continue;
-		double acc[36];
+	SP_T(4);
+	if (pre && tid == 0) {
+		double mx = s_part[0];
 #pragma unroll
-		for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-		nd_pair_items(reg, N.item + W.item0 + q.z, its, n, ql, 4, pre, acc);
-		nd_quad_sum36(acc);
-		if (ql == 0) {
-			v2d_t* o = reinterpret_cast<v2d_t*>(S.Hpart + 36 * (size_t)(SW.part0 + q.w));
-#pragma unroll
-			for (int i = 0; i < 18; ++i) { v2d_t x; x.x = acc[2 * i]; x.y = acc[2 * i + 1]; o[i] = x; }
-		}
+		for (int w = 1; w < NW; ++w) mx = fmax(mx, s_part[w]);
+		S.vpart[T.gtile] = mx;
 	}
 	if (!pre)
 		for (int k = quad; k < T.n_gqs; k += NQ) {
 			// reduced gradient of one edge: sum over the tile's nodes on it of [vh; q x vh]
-			const nd_i2 q = N.gqs[W.gqs0 + T.gqs0 + k];
-			const int n = (q.x >> 16) & 0xFFFF;
-			const int* items = N.gitem + W.gitem0 + q.y;
+			if (k != quad) {
+				gq = N.gqs[T.gqs + k]; gs = S.gslot[T.gslot + k];
+			}
+			const int n = (gq.x >> 16) & 0xFFFF;
+			const int* gis = N.gitem + T.gitem0 + gq.y;
+			if (k != quad) {
+#pragma unroll
+				for (int k2 = 0; k2 < ND_ITEMS_REG; ++k2) gi[k2] = gis[min(ql + 4 * k2, n - 1)];
+			}
 			double ga[6] = {0, 0, 0, 0, 0, 0};
-			for (int i = ql; i < n; i += 4) {
-				const double* rcd = reg + REC * items[i];
+#pragma unroll
+			for (int k2 = 0; k2 < ND_ITEMS_REG; ++k2)
+				if (ql + 4 * k2 < n) {
+					const double* rcd = reg + REC * gi[k2];
+					const double vh[3] = {rcd[R_V], rcd[R_V + 1], rcd[R_V + 2]}, qq[3] = {rcd[R_Q], rcd[R_Q + 1], rcd[R_Q + 2]};
+					double x[3];
+					nd_cross(qq, vh, x);
+#pragma unroll
+					for (int i2 = 0; i2 < 3; ++i2) { ga[i2] += vh[i2]; ga[3 + i2] += x[i2]; }
+				}
+			for (int i = ql + 4 * ND_ITEMS_REG; i < n; i += 4) {
+				const double* rcd = reg + REC * gis[i];
 				const double vh[3] = {rcd[R_V], rcd[R_V + 1], rcd[R_V + 2]}, qq[3] = {rcd[R_Q], rcd[R_Q + 1], rcd[R_Q + 2]};
 				double x[3];
 				nd_cross(qq, vh, x);
@@ -120,14 +158,101 @@ void lm_split_linearise_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P_arg)
 #pragma unroll
 			for (int i = 0; i < 6; ++i) ga[i] += dpp_f64<0x4E>(ga[i]);
 			if (ql == 0) {
-				double* o = S.gpart + 6 * (size_t)(SW.gpart0 + S.gslot[SW.gslot0 + T.gqs0 + k]);
+				double* o = S.gpart + 6 * (size_t)(SW.gpart0 + gs);
 #pragma unroll
 				for (int i = 0; i < 6; ++i) o[i] = ga[i];
 			}
 		}
-	if (pre) {
-		const double mx = block_max(vmax, s_part);
-		if (tid == 0) S.vpart[SW.gtile0 + tm.y] = mx;
+	SP_T(5);
+	for (int k = tid; k < T.n_slots; k += NT) {
+		const nd_i4 q = k == tid ? q0 : S.sqs[T.sqs + k];
+		const int n = q.y & 0xFFFF, kc = (q.y >> 16) & 3, rank = (q.y >> 20) & 3, step = 1 << kc;
+		if (k != tid) its = nd_items_fetch(items + q.z, n, rank, step);
+		// the lambda_0 pass only needs the diagonal blocks (bit 30 of x)
+		if (pre && !((q.x >> 30) & 1)) continue;
+		double acc[36];
+#pragma unroll
+		for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+		nd_pair_items(reg, items + q.z, its, n, rank, step, pre, acc);
+		if ((__builtin_amdgcn_readfirstlane(q.x) >> 29) & 1) {
+			// the lanes of a block: (l0 + l1) + (l2 + l3), a fixed order; lanes of one-lane blocks add 0
+			const double m1 = kc >= 1 ? 1.0 : 0.0, m2 = kc == 2 ? 1.0 : 0.0;
+#pragma unroll
+			for (int i = 0; i < 36; ++i) acc[i] = fma(m1, dpp_f64<0xB1>(acc[i]), acc[i]);      // quad_perm [1,0,3,2]
+#pragma unroll
+			for (int i = 0; i < 36; ++i) acc[i] = fma(m2, dpp_f64<0x4E>(acc[i]), acc[i]);      // quad_perm [2,3,0,1]
+		}
+		if (rank == 0) {
+			v2d_t* o = reinterpret_cast<v2d_t*>(S.Hpart + 36 * (size_t)(SW.part0 + q.w));
+#pragma unroll
+			for (int i = 0; i < 18; ++i) { v2d_t x; x.x = acc[2 * i]; x.y = acc[2 * i + 1]; o[i] = x; }
+		}
+	}
+	SP_T(6);
+#ifdef SSK_LM_STAMPS
+	if (tid == 0 && !pre) atomicAdd(&g_sp_t[15], 1ULL);
+#endif
+}
+
+// sum of the 36-double (6-double) partial slots [a, b) at component c: eight loads in flight, adds in slot order
+template <int PITCH>
+__device__ __forceinline__ double sp_slot_sum(const double* __restrict__ p, int a, int b, int c)
+{
+	double s = 0.0;
+	int k = a;
+	for (; k + 8 <= b; k += 8) {
+		double v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) v[u] = p[(size_t)PITCH * (k + u) + c];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) s += v[u];
+	}
+	if (k < b) {
+		double v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) v[u] = p[(size_t)PITCH * min(k + u, b - 1) + c];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) s += k + u < b ? v[u] : 0.0;
+	}
+	return s;
+}
+
+// ---- K2a: the reduced system from its partial slots: workgroup (window, chunk of SP_RB blocks); a block's slots are contiguous and summed in slot
+// (= tile) order; A = H_pp - S + lambda I, both triangles, border row = reduced gradient ----
+constexpr int SP_RB = 7;                // blocks per workgroup: 7 x 36 = 252 of 256 threads
+__global__ __launch_bounds__(NT)
+void lm_split_reduce_kernel(lm_dev D, nd_dev N, sp_dev S)
+{
+	const int wi = S.win_map[blockIdx.x];
+	if (wi < 0) return;
+	const sp_ctl c = S.ctl[wi];
+	if (!c.active || c.pre != 0) return;
+	const nd_win W = N.win[wi];
+	const int n_pairs = W.E * (W.E + 1) / 2;
+	if ((int)blockIdx.y * SP_RB >= n_pairs && blockIdx.y != 0) return;
+	const nd_split SW = S.sw[wi];
+	const int tid = threadIdx.x;
+	const int n6 = 6 * W.E, np = n6 | 1;
+	double* A = D.Hred + W.h0;
+	const int b = tid / 36, ab = tid - 36 * b, pid = (int)blockIdx.y * SP_RB + b;
+	if (b < SP_RB && pid < n_pairs) {
+		const int* poff = S.poff + SW.poff0;
+		double v = sp_slot_sum<36>(S.Hpart + 36 * (size_t)SW.part0, poff[pid], poff[pid + 1], ab);
+		int e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
+		while ((e2 + 1) * (e2 + 2) / 2 <= pid) ++e2;
+		while (e2 * (e2 + 1) / 2 > pid) --e2;
+		const int e = pid - e2 * (e2 + 1) / 2, a = ab / 6, bb = ab - 6 * a;
+		if (!(e == e2 && a > bb)) {
+			const int row = 6 * e + a, col = 6 * e2 + bb;
+			if (row == col) v += c.lambda;
+			A[(size_t)row * np + col] = v;
+			A[(size_t)col * np + row] = v;
+		}
+	}
+	if (blockIdx.y == 0) {
+		const double* gp = S.gpart + 6 * (size_t)SW.gpart0;
+		const int* goff = S.goff + SW.goff0;
+		for (int i = tid; i < n6; i += NT) { const int e = i / 6; A[(size_t)n6 * np + i] = sp_slot_sum<6>(gp, goff[e], goff[e + 1], i - 6 * e); }
 	}
 }
 
@@ -139,17 +264,16 @@ void lm_split_score_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P_arg, int init)
 	__shared__ double s_part[NW];
 	__shared__ double s_stage[NW * 64 * 3];
 	extern __shared__ __attribute__((aligned(16))) double s_dyn[];      // the edge step (6E)
-	const nd_i2 tm = S.tile_map[blockIdx.x];
-	if (tm.x < 0) return;
-	const int wi = tm.x;
+	const sp_tile T = S.tile_map[blockIdx.x];
+	if (T.wi < 0) return;
+	const int wi = T.wi;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const sp_ctl c = S.ctl[wi];
+	const nd_win W = N.win[wi];
+	const nd_group G = N.group[T.grp + min(wave, max(T.n_grp - 1, 0))];
 	if (!c.active) return;
 	if (!init && !c.ok) return;
 	if (threadIdx.x == 0) s_P = P_arg;
-	const nd_win W = N.win[wi];
-	const nd_split SW = S.sw[wi];
-	const nd_tile T = N.tile[W.tile0 + tm.y];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	double* s_b = s_dyn;
 	if (!init)
 		for (int i = tid; i < 6 * W.E; i += NT) s_b[i] = D.dp[6 * (size_t)W.us0 + i];
@@ -158,13 +282,12 @@ void lm_split_score_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P_arg, int init)
 	const double* tab = N.tab + W.tab0 + ((init ? c.cur : (c.cur ^ 1)) ? 12 * (size_t)W.n_suf : 0);
 	double e = 0.0, dfn = 0.0;
 	if (wave < T.n_grp) {
-		const nd_group G = N.group[W.grp0 + T.grp0 + wave];
 		const nd_recs rc = nd_fetch_recs(N, W, G, lane);
 		nd_score_group(D, N, W, P, G, rc, tab, s_stage + 64 * 3 * wave, s_b, !init, c.iters, lane, e, dfn);
 	}
 	e = block_sum(e, s_part);
 	dfn = block_sum(dfn, s_part);
-	if (tid == 0) { S.epart[SW.gtile0 + tm.y] = e; S.fpart[SW.gtile0 + tm.y] = dfn; }
+	if (tid == 0) { S.epart[T.gtile] = e; S.fpart[T.gtile] = dfn; }
 }
 
 // ---- K4: per window: the attempt's verdict (contract L5), trace, state copy, stop flags ----
@@ -239,6 +362,15 @@ void lm_split_decide_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int init)
 
 }  // namespace
 
+#ifdef SSK_LM_STAMPS
+extern "C" int ssk_lm_split_stamps(unsigned long long* out16, int reset)
+{
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sp_t), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+	if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sp_t), z, sizeof z) != hipSuccess) return 1; }
+	return 0;
+}
+#endif
+
 int ssk_lm_launch_split(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp_dev& S, const lm_cam& P, int n_windows, size_t solve_dyn_bytes, size_t init_dyn_bytes)
 {
 	(void)n_windows;
@@ -258,6 +390,7 @@ int ssk_lm_launch_split(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp
 	SSK_LAUNCH_CHECK(ctx, "lm_split_init/score/decide");
 	for (int pass = 0; pass <= P.max_iters; ++pass) {
 		hipLaunchKernelGGL(lm_split_linearise_kernel, gt, bt, lin_lds, ctx->stream, D, N, S, P);
+		if (pass > 0) hipLaunchKernelGGL(lm_split_reduce_kernel, dim3((unsigned)S.n_win_wgs, (unsigned)std::max(1, (S.max_pairs + SP_RB - 1) / SP_RB)), bt, 0, ctx->stream, D, N, S);
 		const int rc = ssk_lm_launch_split_solve(ctx, D, N, S, P, solve_dyn_bytes);
 		if (rc) return rc;
 		if (pass == 0) continue;                           // every window's first pass is its lambda_0 pass: no attempt to score

@@ -17,14 +17,6 @@ constexpr int REC = SSK_ND_REC, STG = SSK_ND_STAGE, LREC = SSK_ND_LREC, SCR = SS
 constexpr int R_Q = 9, R_P = 12, R_V = 21;
 #include "ssk_lm_node_dev.h"
 
-__device__ __forceinline__ void pid_decode(int pid, int& e, int& e2)
-{
-	e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
-	while ((e2 + 1) * (e2 + 2) / 2 <= pid) ++e2;
-	while (e2 * (e2 + 1) / 2 > pid) --e2;
-	e = pid - e2 * (e2 + 1) / 2;
-}
-
 // sum of the 36-double (6-double) partial slots [a, b) at component c: eight loads in flight, adds in slot order
 template <int PITCH>
 __device__ __forceinline__ double slot_sum(const double* __restrict__ p, int a, int b, int c)
@@ -60,7 +52,7 @@ void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubl
 	const nd_win W = N.win[wi];
 	const nd_split SW = S.sw[wi];
 	const int tid = threadIdx.x;
-	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1, np = n6 | 1, n_pairs = W.E * (W.E + 1) / 2;
+	const int n6 = 6 * W.E, n6p = (n6 + 1) & ~1, np = n6 | 1;
 	const double* Hp = S.Hpart + 36 * (size_t)SW.part0;
 	const int* poff = S.poff + SW.poff0;
 	if (c.pre != 0) {
@@ -83,25 +75,8 @@ void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubl
 	const int lds_doubles = dyn_doubles - (int)(lds - s_dyn);
 	for (int i = tid; i < 12 * W.n_edges; i += NT) pose[i] = D.pose[12 * (size_t)W.edge0 + i];
 	for (int i = tid; i < W.n_suf; i += NT) s_suf[i] = N.suf[W.suf0 + i];
-	// ---- the reduced system: A = H_pp - S + lambda I, border row = reduced gradient ----
+	// (the reduced system was assembled by lm_split_reduce_kernel: A = H_pp - S + lambda I, both triangles, border row = reduced gradient)
 	double* A = D.Hred + W.h0;
-	const double lambda = c.lambda;
-	for (int it = tid; it < 36 * n_pairs; it += NT) {
-		const int pid = it / 36, ab = it - 36 * pid, a = ab / 6, b = ab - 6 * a;
-		int e, e2;
-		pid_decode(pid, e, e2);
-		double v = slot_sum<36>(Hp, poff[pid], poff[pid + 1], ab);
-		if (e == e2 && a > b) continue;
-		const int row = 6 * e + a, col = 6 * e2 + b;
-		if (row == col) v += lambda;
-		A[(size_t)row * np + col] = v;
-		A[(size_t)col * np + row] = v;
-	}
-	{
-		const double* gp = S.gpart + 6 * (size_t)SW.gpart0;
-		const int* goff = S.goff + SW.goff0;
-		for (int i = tid; i < n6; i += NT) { const int e = i / 6; A[(size_t)n6 * np + i] = slot_sum<6>(gp, goff[e], goff[e + 1], i - 6 * e); }
-	}
 	__syncthreads();
 	bool ok = true;
 	if (n6 > 0) ok = SSK_LDL_BIG(A, np, n6, s_b, s_inv, lds, lds_doubles);
@@ -119,7 +94,7 @@ void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubl
 			double eps[6], R[9], O[12];
 #pragma unroll
 			for (int a = 0; a < 6; ++a) eps[a] = s_b[6 * e + a];
-			so3_exp(eps + 3, R);
+			so3_exp_inl(eps + 3, R);
 #pragma unroll
 			for (int i = 0; i < 3; ++i) {
 #pragma unroll

@@ -62,7 +62,7 @@ def check_against_oracle(ctx, oracle, win, prm, min_accept=1):
                 assert rel_err(df[i], exp["df"][i], fl_f) <= REL, (i, "landmark update", rel_err(df[i], exp["df"][i]))
     tol = 1e-5 if last_free else 1e-8
     # (absolute, except for a landmark the solve sends away -- depth unobservable, |f| ~ 1e7 --: relative to its size beyond 1 km)
-    assert np.abs(poses - exp["poses"]).max() <= tol and (np.abs(lms - exp["lms"]) / np.maximum(1.0, np.abs(exp["lms"]) * 1e-3)).max() <= 10 * tol
+    assert np.abs(poses - exp["poses"]).max() <= tol and (np.abs(lms - exp["lms"]) / np.where(np.abs(exp["lms"]) > 1e3, np.abs(exp["lms"]), 1.0)).max() <= 10 * tol
     assert abs(res.err_final - er.err_final) <= REL * er.err_final
     b.close()
     return res

@@ -19,7 +19,7 @@ def summarise(src):
     for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0]
-            if "lm_solve" not in name:
+            if "lm_solve" not in name and "lm_split" not in name:
                 continue
             s = acc.setdefault(name, {}).setdefault(r["Counter_Name"], [0.0, 0])
             s[0] += float(r["Counter_Value"]); s[1] += 1
@@ -35,6 +35,10 @@ def summarise(src):
         if wc:
             rec["valu_active"] = rec.get("SQ_ACTIVE_INST_VALU", 0) / wc
             rec["waiting"] = rec.get("SQ_WAIT_ANY", 0) / wc
+            if "SQ_ACTIVE_INST_LDS" in rec:
+                rec["lds_active"] = rec["SQ_ACTIVE_INST_LDS"] / wc
+        if rec.get("SQ_INSTS_LDS"):
+            rec["lds_conflict_cycles_per_inst"] = rec.get("SQ_LDS_BANK_CONFLICT", 0) / rec["SQ_INSTS_LDS"]
         out["kernels"][name] = rec
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 

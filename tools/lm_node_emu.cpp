@@ -171,11 +171,12 @@ int nd_emu_linearise_form(const ssk_lm_window* Wn, const ssk_lm_params* P, doubl
 		const int n_slots = form == 1 ? T.n_rounds : T.n_rounds * NQ;
 		for (int sl = 0; sl < n_slots; ++sl) {
 			{
-				int pid, n, first;
+				int pid, n, first, i0 = 0, istep = 1;
 				double* acc;
 				if (form == 1) {
 					const nd_i4 q = H.sqs[(size_t)H.swin[0].sqs0 + T.qs0 + sl];
-					pid = q.x & 0xFFFF; n = q.y; first = q.z;
+					pid = q.x & 0xFFFF; n = q.y & 0xFFFF; first = q.z;
+					i0 = (q.y >> 20) & 3; istep = 1 << ((q.y >> 16) & 3);      // a lane slot: every lanes-th item from the lane's rank on
 					if (pre && !((q.x >> 30) & 1)) continue;     // (the lambda_0 pass: diagonal blocks only)
 					acc = &part[36 * (size_t)q.w];
 				} else {
@@ -184,7 +185,7 @@ int nd_emu_linearise_form(const ssk_lm_window* Wn, const ssk_lm_params* P, doubl
 					if (pid == 0xFFFF) continue;                      // (a quad without a block)
 					acc = &Hb[36 * (size_t)pid];
 				}
-				for (int i = 0; i < n; ++i) {
+				for (int i = i0; i < n; i += istep) {
 					const int it = H.item[(size_t)W.item0 + first + i];
 					const double* xr = &rec[(size_t)SSK_ND_REC * (it & 511)];
 					const double* yc = &rec[(size_t)SSK_ND_REC * ((it >> 10) & 511)];
