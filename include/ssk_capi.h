@@ -478,6 +478,9 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* params)
 int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out /* n_windows */);
 /* Name of the kernel ssk_lm_batch_run launches for this batch (diagnostics: the profile summaries under profiles/ are keyed by it). */
 int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap);
+/* Host time ssk_lm_batch_create spent on the batch's symbolic structure (suffix tries, landmark groups, block-sorted items: what SRBA's
+ * define_new_keyframe does on the CPU before it optimises, EST.cpp:782-784), milliseconds, and the host threads it used.  Either may be NULL. */
+int ssk_lm_batch_symbolic_ms(ssk_ctx* ctx, ssk_lm_batch* b, double* ms, int* threads);
 /* Current state of window w: edge_inv_pose [n_edges_total*12], lm_pos [n_lms_total*3]. */
 int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_inv_pose, double* lm_pos);
 /* Replaces the state of window w (either pointer may be NULL: that part is kept) -- the structure of a window can be built before its

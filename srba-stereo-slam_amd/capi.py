@@ -638,6 +638,12 @@ class LmBatch:
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_kernel_name(self.ctx.h, self.h_, buf, 64))
         return buf.value.decode()
 
+    def symbolic_ms(self):
+        """(host milliseconds of the symbolic build in ssk_lm_batch_create, host threads used)"""
+        ms, thr = C.c_double(0), C.c_int(0)
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_symbolic_ms(self.ctx.h, self.h_, C.byref(ms), C.byref(thr)))
+        return ms.value, thr.value
+
     def set_export(self, on=True):
         self.ctx._chk(self.ctx.lib.ssk_lm_batch_set_export(self.ctx.h, self.h_, int(bool(on))))
 

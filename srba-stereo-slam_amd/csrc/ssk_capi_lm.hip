@@ -7,6 +7,8 @@
 #include <memory_resource>
 #include <unordered_map>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
@@ -43,6 +45,10 @@ struct ssk_lm_batch {
 	// built from the node tables alone, the tiled / general families are never constructed
 	bool split_ok = false, lean = false;
 	sp_dev S{};
+	nd_dev N2{};                      // the phase-split windows' node tables (N: the node kernel's); both families' win[] are indexed by the batch's window number
+	int node_n = 0, split_n = 0;      // windows per family (a mixed batch runs both)
+	double symbolic_ms = 0.0;         // host time of the symbolic build (ssk_lm_batch_symbolic_ms)
+	int symbolic_threads = 1;
 	size_t split_solve_dyn_bytes = 0, split_init_dyn_bytes = 0;
 	bool coop_pending = false;
 	lm_cam coop_P{};
@@ -427,7 +433,6 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	std::vector<lm_win> hdr((size_t)n_windows);
 	long long h_total = 0, dpt = 0, dft = 0;
 	int max_n6 = 0;
-	bool split = want_split;
 	for (int w = 0; w < n_windows; ++w) {
 		const ssk_lm_window& Wn = windows[w];
 		lm_win& H = hdr[w];
@@ -444,7 +449,6 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		h_total += (long long)(6 * E + 1) * (6 * E + 2);
 		if (trace) { dpt += (long long)MAX_ITERS_ALLOC * 6 * E; dft += (long long)MAX_ITERS_ALLOC * 3 * L; }
 		max_n6 = std::max(max_n6, 6 * E);
-		if (8 * nd_lds_doubles(Wn.n_edges_total, E, 4, 0) > node_lds_limit) split = true;
 		edge_slot.insert(edge_slot.end(), Wn.edge_unknown_slot, Wn.edge_unknown_slot + Wn.n_edges_total);
 		pose.insert(pose.end(), Wn.edge_inv_pose, Wn.edge_inv_pose + 12 * (size_t)Wn.n_edges_total);
 		lm_slot.insert(lm_slot.end(), Wn.lm_unknown_slot, Wn.lm_unknown_slot + Wn.n_lms_total);
@@ -457,27 +461,50 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		slot_edge.insert(slot_edge.end(), s_edge.begin(), s_edge.end());
 		slot_lm.insert(slot_lm.end(), s_lm.begin(), s_lm.end());
 	}
-	// ---- the node tables, in the form the kernel family wants (a batch that turns out too large for the node kernel's LDS is re-built split) ----
-	nd_host NH;
-	for (int attempt = 0; attempt < 2; ++attempt) {
-		NH = nd_host();
-		bool fits = true;
-		for (int w = 0; w < n_windows && fits; ++w) {
+	// ---- the node tables, per window in the form of ITS kernel family: the persistent node kernel when the reduced system and a tile of records fit
+	// LDS, the phase-split kernels otherwise (or for every window: SSK_LM_KERNEL=split) -- no all-or-nothing choice for a mixed batch.  Windows are
+	// built side by side (a thread each), then appended in window order. ----
+	std::vector<nd_host> one((size_t)n_windows);
+	std::vector<char> w_split((size_t)n_windows, 0), w_bad((size_t)n_windows, 0);
+	int n_thr_used = 1;
+	{
+		auto build = [&](int w) {
 			const lm_win& Hw = hdr[w];
 			nd_win nw{};
 			nw.edge0 = Hw.edge0; nw.lm0 = Hw.lm0; nw.us0 = Hw.us0; nw.ls0 = Hw.ls0; nw.trace0 = Hw.trace0; nw.dp_trace0 = Hw.dp_trace0; nw.df_trace0 = Hw.df_trace0;
 			nw.h0 = Hw.h0;
-			fits = nd_build_window(windows[w], SSK_SP_WAVES, NH, nw, node_lds_limit / 8, split);
-		}
-		if (!fits) return 1;
-		if (split || 8 * NH.lds_doubles <= node_lds_limit) break;
-		split = true;
+			bool sp = want_split || 8 * nd_lds_doubles(Hw.n_edges, Hw.E, 4, 0) > node_lds_limit;
+			if (!sp) {
+				if (!nd_build_window(windows[w], SSK_SP_WAVES, one[(size_t)w], nw, node_lds_limit / 8, false)) { w_bad[(size_t)w] = 1; return; }
+				if (8 * one[(size_t)w].lds_doubles > node_lds_limit) { sp = true; one[(size_t)w] = nd_host(); }
+			}
+			if (sp && !nd_build_window(windows[w], SSK_SP_WAVES, one[(size_t)w], nw, node_lds_limit / 8, true)) { w_bad[(size_t)w] = 1; return; }
+			w_split[(size_t)w] = sp;
+		};
+		static const int n_thr_max = [] { const char* e = std::getenv("SSK_LM_BUILD_THREADS"); const int hc = (int)std::thread::hardware_concurrency(); return e ? std::max(1, std::atoi(e)) : std::max(1, std::min(hc, 16)); }();
+		const int n_thr = std::min(n_thr_max, n_windows / 8);      // (a thread is worth it from a handful of windows on)
+		n_thr_used = std::max(n_thr, 1);
+		if (n_thr > 1) {
+			std::vector<std::thread> pool;
+			std::atomic<int> next{0};
+			for (int t = 0; t < n_thr; ++t) pool.emplace_back([&] { for (int w = next++; w < n_windows; w = next++) build(w); });
+			for (std::thread& th : pool) th.join();
+		} else
+			for (int w = 0; w < n_windows; ++w) build(w);
+	}
+	int n_node = 0, n_split = 0;
+	for (int w = 0; w < n_windows; ++w) { if (w_bad[(size_t)w]) return 1; if (w_split[(size_t)w]) ++n_split; else ++n_node; }
+	nd_host NHn, NHs;                                      // the two families' tables; win[] (and swin[]) of both are indexed by the batch's window number
+	for (int w = 0; w < n_windows; ++w) {
+		if (w_split[(size_t)w]) { nd_append(NHs, one[(size_t)w]); if (n_node) nd_append_placeholder(NHn, false); }
+		else { nd_append(NHn, one[(size_t)w]); if (n_split) nd_append_placeholder(NHs, true); }
+		one[(size_t)w] = nd_host();
 	}
 	const auto t_sym = std::chrono::steady_clock::now();
 	ssk_lm_batch* b = new ssk_lm_batch();
 	b->ctx = ctx; b->n_windows = n_windows; b->trace = trace; b->max_iters_alloc = MAX_ITERS_ALLOC; b->max_n6 = max_n6;
 	b->hdr = hdr; b->n_pose = pose.size(); b->n_lm = lm.size();
-	b->lean = true; b->node_ok = !split; b->split_ok = split;
+	b->lean = true; b->node_ok = n_node > 0; b->split_ok = n_split > 0; b->node_n = n_node; b->split_n = n_split;
 	lm_dev& D = b->D;
 	int rc = SSK_OK;
 #define UP(vec, field) if (!rc) rc = upload(b, vec, &D.field)
@@ -486,25 +513,32 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(path_edge, path_edge); UP(slot_edge, slot_edge); UP(slot_lm, slot_lm);
 	UP(pose, pose0); UP(lm, lm0);
 #undef UP
-#define UPN(vec, field) if (!rc) rc = upload(b, NH.vec, &b->N.field)
-	UPN(win, win); UPN(tile, tile); UPN(group, group); UPN(suf, suf); UPN(obs, obs); UPN(px, px); UPN(lane, lane);
-	UPN(item, item); UPN(gitem, gitem); UPN(gqs, gqs);
-	if (!split) { UPN(qs, qs); }
-#undef UPN
 	// launch order / XCD placement: windows by observations x optimised edges, largest first
-	std::vector<int> ord((size_t)n_windows);
-	for (int w = 0; w < n_windows; ++w) ord[(size_t)w] = w;
-	{
-		const char* oe = std::getenv("SSK_LM_ORDER");
-		if (!oe || std::atoi(oe) != 0)
-			std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return (long long)NH.win[a].n_obs * (NH.win[a].E + 4) > (long long)NH.win[c].n_obs * (NH.win[c].E + 4); });
-	}
+	const bool by_size = [] { const char* oe = std::getenv("SSK_LM_ORDER"); return !oe || std::atoi(oe) != 0; }();
+	auto ordered = [&](const nd_host& NH, bool sp) {
+		std::vector<int> ord;
+		for (int w = 0; w < n_windows; ++w) if ((bool)w_split[(size_t)w] == sp) ord.push_back(w);
+		if (by_size)
+			std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return (long long)NH.win[(size_t)a].n_obs * (NH.win[(size_t)a].E + 4) > (long long)NH.win[(size_t)c].n_obs * (NH.win[(size_t)c].E + 4); });
+		return ord;
+	};
+	std::vector<int> ord_n, win_map;
 	std::vector<sp_tile> tile_map;
-	std::vector<int> win_map;
-	if (!split) {
-		if (!rc) rc = upload(b, ord, &b->N.order);
-		b->node_dyn_bytes = 8 * NH.lds_doubles;
-	} else {
+	if (n_node) {
+#define UPN(vec, field) if (!rc) rc = upload(b, NHn.vec, &b->N.field)
+		UPN(win, win); UPN(tile, tile); UPN(group, group); UPN(suf, suf); UPN(obs, obs); UPN(px, px); UPN(lane, lane);
+		UPN(item, item); UPN(gitem, gitem); UPN(gqs, gqs); UPN(qs, qs);
+#undef UPN
+		ord_n = ordered(NHn, false);
+		if (!rc) rc = upload(b, ord_n, &b->N.order);
+		b->node_dyn_bytes = 8 * NHn.lds_doubles;
+	}
+	if (n_split) {
+#define UPN(vec, field) if (!rc) rc = upload(b, NHs.vec, &b->N2.field)
+		UPN(win, win); UPN(tile, tile); UPN(group, group); UPN(suf, suf); UPN(obs, obs); UPN(px, px); UPN(lane, lane);
+		UPN(item, item); UPN(gitem, gitem); UPN(gqs, gqs);
+#undef UPN
+		const std::vector<int> ord = ordered(NHs, true);
 		// a window's workgroups all go to ONE XCD (workgroup i runs on XCD i mod 8): its suffix table, landmarks and scratch stay in that L2
 		constexpr int NX = 8;
 		std::vector<std::vector<nd_i2>> tl(NX);
@@ -513,9 +547,9 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		for (int w : ord) {
 			int x = 0;
 			for (int k = 1; k < NX; ++k) if (load[k] < load[x]) x = k;
-			for (int t = 0; t < NH.win[(size_t)w].n_tiles; ++t) tl[x].push_back(nd_i2{w, t});
+			for (int t = 0; t < NHs.win[(size_t)w].n_tiles; ++t) tl[x].push_back(nd_i2{w, t});
 			wl[x].push_back(w);
-			load[x] += NH.win[(size_t)w].n_tiles;
+			load[x] += NHs.win[(size_t)w].n_tiles;
 		}
 		size_t mt = 0, mw = 0;
 		for (int x = 0; x < NX; ++x) { mt = std::max(mt, tl[x].size()); mw = std::max(mw, wl[x].size()); }
@@ -526,9 +560,9 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		for (int x = 0; x < NX; ++x) {
 			for (size_t k = 0; k < tl[x].size(); ++k) {
 				const nd_i2 wt = tl[x][k];
-				const nd_win& nw = NH.win[(size_t)wt.x];
-				const nd_split& sw = NH.swin[(size_t)wt.x];
-				const nd_tile& T = NH.tile[(size_t)nw.tile0 + wt.y];
+				const nd_win& nw = NHs.win[(size_t)wt.x];
+				const nd_split& sw = NHs.swin[(size_t)wt.x];
+				const nd_tile& T = NHs.tile[(size_t)nw.tile0 + wt.y];
 				sp_tile d{};
 				d.wi = wt.x; d.tile = wt.y; d.grp = nw.grp0 + T.grp0; d.n_grp = T.n_grp; d.sqs = sw.sqs0 + T.qs0; d.n_slots = T.n_rounds;
 				d.gqs = nw.gqs0 + T.gqs0; d.n_gqs = T.n_gqs; d.gslot = sw.gslot0 + T.gqs0; d.gtile = sw.gtile0 + wt.y;
@@ -539,16 +573,16 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		}
 		b->S.n_tile_wgs = (int)tile_map.size(); b->S.n_win_wgs = (int)win_map.size();
 		b->S.max_pairs = 0;
-		for (const nd_win& nw : NH.win) b->S.max_pairs = std::max(b->S.max_pairs, nw.E * (nw.E + 1) / 2);
-		if (!rc) rc = upload(b, NH.swin, &b->S.sw);
-		if (!rc) rc = upload(b, NH.sqs, &b->S.sqs);
-		if (!rc) rc = upload(b, NH.poff, &b->S.poff);
-		if (!rc) rc = upload(b, NH.goff, &b->S.goff);
-		if (!rc) rc = upload(b, NH.gslot, &b->S.gslot);
+		for (const nd_win& nw : NHs.win) b->S.max_pairs = std::max(b->S.max_pairs, nw.E * (nw.E + 1) / 2);
+		if (!rc) rc = upload(b, NHs.swin, &b->S.sw);
+		if (!rc) rc = upload(b, NHs.sqs, &b->S.sqs);
+		if (!rc) rc = upload(b, NHs.poff, &b->S.poff);
+		if (!rc) rc = upload(b, NHs.goff, &b->S.goff);
+		if (!rc) rc = upload(b, NHs.gslot, &b->S.gslot);
 		if (!rc) rc = upload(b, tile_map, &b->S.tile_map);
 		if (!rc) rc = upload(b, win_map, &b->S.win_map);
 		size_t sd = 0, id = 0;
-		for (const nd_win& nw : NH.win) {
+		for (const nd_win& nw : NHs.win) {
 			sd = std::max(sd, ssk_sp_solve_lds_doubles(nw.n_edges, nw.n_suf, nw.E));
 			id = std::max(id, 12 * (size_t)nw.n_edges + (size_t)nw.n_suf + 2);
 		}
@@ -563,32 +597,38 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (!rc) rc = scratch(b, lm.size(), &D.lm_new);
 	if (!rc) rc = scratch(b, 9 * n_ls, &D.Hff);
 	if (!rc) rc = scratch(b, 3 * n_ls, &D.gf);
-	if (!rc) rc = scratch(b, split ? (size_t)h_total : 0, &D.Hred);
+	if (!rc) rc = scratch(b, n_split ? (size_t)h_total : 0, &D.Hred);
 	if (!rc) rc = scratch(b, 6 * n_us, &D.dp);
 	if (!rc) rc = scratch(b, (size_t)n_windows, &D.res);
 	if (!rc) rc = scratch(b, trace ? (size_t)n_windows * MAX_ITERS_ALLOC : 1, &D.trace);
 	if (!rc) rc = scratch(b, (size_t)dpt, &D.dp_trace);
 	if (!rc) rc = scratch(b, (size_t)dft, &D.df_trace);
-	if (!rc) rc = scratch(b, (size_t)NH.tab_doubles, &b->N.tab);
-	if (!rc) rc = scratch(b, (size_t)SSK_ND_SCR * NH.lane.size(), &b->N.scr);
-	if (split) {
-		if (!rc) rc = scratch(b, 36 * (size_t)NH.part_slots + 36, &b->S.Hpart);
-		if (!rc) rc = scratch(b, 6 * (size_t)NH.gpart_slots + 6, &b->S.gpart);
-		if (!rc) rc = scratch(b, NH.tile.size(), &b->S.vpart);
-		if (!rc) rc = scratch(b, NH.tile.size(), &b->S.epart);
-		if (!rc) rc = scratch(b, NH.tile.size(), &b->S.fpart);
+	if (n_node) {
+		if (!rc) rc = scratch(b, (size_t)NHn.tab_doubles, &b->N.tab);
+		if (!rc) rc = scratch(b, (size_t)SSK_ND_SCR * NHn.lane.size(), &b->N.scr);
+	}
+	if (n_split) {
+		if (!rc) rc = scratch(b, (size_t)NHs.tab_doubles, &b->N2.tab);
+		if (!rc) rc = scratch(b, (size_t)SSK_ND_SCR * NHs.lane.size(), &b->N2.scr);
+		if (!rc) rc = scratch(b, 36 * (size_t)NHs.part_slots + 36, &b->S.Hpart);
+		if (!rc) rc = scratch(b, 6 * (size_t)NHs.gpart_slots + 6, &b->S.gpart);
+		if (!rc) rc = scratch(b, NHs.tile.size(), &b->S.vpart);
+		if (!rc) rc = scratch(b, NHs.tile.size(), &b->S.epart);
+		if (!rc) rc = scratch(b, NHs.tile.size(), &b->S.fpart);
 		if (!rc) rc = scratch(b, (size_t)n_windows, &b->S.ctl);
 	}
 	D.trace_on = trace ? 1 : 0;
 	if (!rc) rc = finalize(b);
 	if (rc) { ssk_lm_batch_destroy(b); return rc; }
 	if (std::getenv("SSK_LM_DEBUG"))
-		std::fprintf(stderr, "[ssk lm] lean batch, %s form: %d windows, window 0: %d tiles, %d groups, %d suffixes; %zu items, %lld partial slots (all windows), most blocks of a tile %d\n",
-		             split ? "phase-split" : "node", n_windows, NH.win[0].n_tiles, NH.win[0].n_groups, NH.win[0].n_suf, NH.item.size(), NH.part_slots, NH.max_tile_blocks);
+		std::fprintf(stderr, "[ssk lm] lean batch: %d windows for the node kernel, %d for the phase-split kernels (%zu tiles, %zu items, %lld partial slots, most blocks of a tile %d)\n",
+		             n_node, n_split, NHs.tile.size(), NHs.item.size(), NHs.part_slots, NHs.max_tile_blocks);
+	b->symbolic_ms = std::chrono::duration<double, std::milli>(t_sym - t_begin).count();
+	b->symbolic_threads = n_thr_used;
 	if (timing) {
 		(void)hipDeviceSynchronize();
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create, lean (%d windows, %s): symbolic %.3f ms, allocate + upload %.3f ms\n", n_windows, split ? "split" : "node",
+		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create, lean (%d windows: %d node, %d split): symbolic %.3f ms, allocate + upload %.3f ms\n", n_windows, n_node, n_split,
 		             ms(t_begin, t_sym), ms(t_sym, std::chrono::steady_clock::now()));
 	}
 	*out = b;
@@ -1316,6 +1356,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (!tiled_all && !with_general) return lm_batch_create_impl(ctx, windows, n_windows, trace, out, true, false);
 	const auto t_sym = std::chrono::steady_clock::now();
 	ssk_lm_batch* b = new ssk_lm_batch();
+	b->symbolic_ms = std::chrono::duration<double, std::milli>(t_sym - t_begin).count();
 	b->has_general = with_general;
 	b->ctx = ctx; b->n_windows = n_windows; b->trace = trace; b->max_iters_alloc = MAX_ITERS_ALLOC; b->max_n6 = max_n6;
 	b->hdr = hdr; b->n_pose = pose.size(); b->n_lm = lm.size();
@@ -1497,7 +1538,12 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
 	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a run on top of a timed-out cooperative launch continues from the repaired state)
-	if (b->split_ok) return ssk_lm_launch_split(ctx, b->D, b->N, b->S, P, b->n_windows, b->split_solve_dyn_bytes, b->split_init_dyn_bytes);
+	if (b->lean) {
+		// a mixed batch: the small windows on the persistent node kernel, the others on the phase-split kernels, one after the other on the stream
+		if (b->node_n) { const int rc1 = ssk_lm_launch_node(ctx, b->D, b->N, P, b->node_n, b->node_dyn_bytes, false); if (rc1) return rc1; }
+		if (b->split_n) return ssk_lm_launch_split(ctx, b->D, b->N2, b->S, P, b->split_n, b->split_solve_dyn_bytes, b->split_init_dyn_bytes);
+		return SSK_OK;
+	}
 	if (b->node_ok) return ssk_lm_launch_node(ctx, b->D, b->N, P, b->n_windows, b->node_dyn_bytes, b->node_big);
 	if (b->acc_ok) return ssk_lm_launch_acc(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
@@ -1536,7 +1582,7 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 	// the same decisions as ssk_lm_batch_run
 	const char* force = std::getenv("SSK_LM_KERNEL");
 	const char* name = "lm_solve_kernel";
-	if (b->split_ok) name = "lm_split_linearise_kernel";      // (the heaviest of the four kernels of a pass)
+	if (b->split_ok) name = "lm_split_linearise_kernel";      // (the heaviest kernel of a pass; a mixed batch also runs lm_solve_node_kernel on its small windows)
 	else if (b->node_ok) name = b->node_big ? "lm_solve_node_big_kernel" : "lm_solve_node_kernel";
 	else if (b->acc_ok) name = b->schur_mfma ? "lm_solve_acc_mfma_kernel" : "lm_solve_acc_kernel";
 	else if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) {
@@ -1552,6 +1598,15 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 		else name = b->schur_mfma == 2 ? "lm_solve_tiled_ldlm_kernel" : b->schur_mfma ? "lm_solve_tiled_mfma_kernel" : b->lds_sys ? "lm_solve_tiled_lds_kernel" : "lm_solve_tiled_kernel";
 	}
 	std::snprintf(out, (size_t)cap, "%s", name);
+	return SSK_OK;
+}
+
+int ssk_lm_batch_symbolic_ms(ssk_ctx* ctx, ssk_lm_batch* b, double* ms, int* threads)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_symbolic_ms: batch is NULL");
+	if (ms) *ms = b->symbolic_ms;
+	if (threads) *threads = b->symbolic_threads;
 	return SSK_OK;
 }
 

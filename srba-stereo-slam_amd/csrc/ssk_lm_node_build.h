@@ -5,7 +5,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
-#include <unordered_map>
+#include <cstring>
 #include <vector>
 #include "../../include/ssk_capi.h"
 #include "ssk_lm_node.h"
@@ -50,8 +50,60 @@ inline size_t nd_lds_doubles(int n_edges, int E, int waves, int n_suf, int n_til
 // kernels' structures).  Returns false -- and leaves H untouched -- when the window does not fit the node kernel:
 // more than 128 optimised edges, a landmark with more than 64 observations or more than 63 nodes, more than 65535 suffixes.
 // split = true: the tables of the PHASE-SPLIT form (ssk_lm_split.hip): landmarks ordered by the set of optimised edges their nodes touch (so that
-// the landmarks of a tile share 6x6 blocks: 3x fewer (tile, block) pairs on a depth-5 local area), one quad slot per (tile, block) with a
-// partial-sum slot in HBM (block-major numbering: the slots of a block are contiguous, tile order), gradient slots per (tile, edge) likewise.
+// the landmarks of a tile share 6x6 blocks: 3x fewer (tile, block) pairs on a depth-5 local area), LANE slots (a block has 1, 2 or 4 lanes) with a
+// partial-sum slot in HBM per (tile, block) (block-major numbering: the slots of a block are contiguous, tile order), gradient slots per
+// (tile, edge) likewise.
+// Round 4: flat arrays and counting sorts instead of a vector per landmark / tile / block (3.4 ms -> see DESIGN.md for a depth-5 local area: this
+// runs on the per-keyframe host path of the facade and in front of every batch).
+static_assert(SSK_ND_LANE_RUNS == 0, "the host builder emits quad slots (SSK_ND_LANE_RUNS = 0)");
+
+namespace nd_detail {
+// open-addressing map (suffix record -> id) of the trie: keys (first step code << 32 | rest id), linear probing, power-of-two capacity
+struct suf_map {
+	std::vector<uint64_t> key;
+	std::vector<int> val;
+	size_t mask = 0, used = 0;
+	void init(size_t cap) { size_t c = 64; while (c < cap) c <<= 1; key.assign(c, ~(uint64_t)0); val.assign(c, 0); mask = c - 1; used = 0; }
+	static size_t hash(uint64_t k) { k ^= k >> 29; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 32; return (size_t)k; }
+	void grow()
+	{
+		std::vector<uint64_t> ok; std::vector<int> ov;
+		ok.swap(key); ov.swap(val);
+		init(2 * (mask + 1));
+		for (size_t i = 0; i < ok.size(); ++i) if (ok[i] != ~(uint64_t)0) { size_t h = hash(ok[i]) & mask; while (key[h] != ~(uint64_t)0) h = (h + 1) & mask; key[h] = ok[i]; val[h] = ov[i]; ++used; }
+	}
+	// returns the id of k, inserting `fresh` when absent (inserted = true)
+	int get(uint64_t k, int fresh, bool& inserted)
+	{
+		size_t h = hash(k) & mask;
+		while (key[h] != ~(uint64_t)0) { if (key[h] == k) { inserted = false; return val[h]; } h = (h + 1) & mask; }
+		key[h] = k; val[h] = fresh; inserted = true;
+		if (++used * 2 > mask) grow();
+		return fresh;
+	}
+};
+// set of optimised edge slots (<= 128) in the order of the sorted vector of its elements, lexicographically
+struct eset { uint64_t lo = 0, hi = 0; };
+inline bool eset_less(const eset& a, const eset& b)
+{
+	const uint64_t dlo = a.lo ^ b.lo, dhi = a.hi ^ b.hi;
+	if (!dlo && !dhi) return false;
+	// the lowest element in which they differ: the set that holds it is smaller, unless the other has nothing at or above it (a prefix: shorter, smaller)
+	if (dlo) {
+		const int i = __builtin_ctzll(dlo);
+		const bool a_has = (a.lo >> i) & 1;
+		const eset& other = a_has ? b : a;
+		const bool other_ends = (i == 63 ? 0 : (other.lo >> (i + 1))) == 0 && other.hi == 0;
+		return a_has ? !other_ends : other_ends;
+	}
+	const int i = __builtin_ctzll(dhi);
+	const bool a_has = (a.hi >> i) & 1;
+	const eset& other = a_has ? b : a;
+	const bool other_ends = (i == 63 ? 0 : (other.hi >> (i + 1))) == 0;
+	return a_has ? !other_ends : other_ends;
+}
+}  // namespace nd_detail
+
 inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */, size_t lds_limit_doubles = 20352, bool split = false)
 {
 	const int n_obs = Wn.n_obs, n_lms = Wn.n_lms_total;
@@ -59,164 +111,221 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	for (int e = 0; e < Wn.n_edges_total; ++e) if (Wn.edge_unknown_slot[e] >= 0) ++E;
 	for (int l = 0; l < n_lms; ++l) if (Wn.lm_unknown_slot[l] >= 0) ++L;
 	if (E > 128 || waves < 1 || waves > SSK_ND_MAX_WAVES) return false;
-	// ---- suffix trie (ids in creation order: the rest of a suffix always has a smaller id) ----
+	// ---- suffix trie (ids in creation order: the rest of a suffix always has a smaller id); chain[id][k] = the suffix of length k + 1 on id's
+	// chain of rests (chain[id][len - 1] = id) ----
+	constexpr int MAXP = 8;                                // (SSK_LM_MAX_PATH)
 	std::vector<nd_i2> suf(1, nd_i2{-1, -1});
+	std::vector<int> suf_len(1, 0);
 	std::vector<int> obs_suf((size_t)n_obs, 0);
 	{
-		std::unordered_map<uint64_t, int> ids;
-		ids.reserve(1024);
+		nd_detail::suf_map ids;
+		ids.init(2048);
+		const int* prev = nullptr;
+		int prev_n = -1, prev_id = 0;
 		for (int o = 0; o < n_obs; ++o) {
+			const int p0 = Wn.obs_path_off[o], pn = Wn.obs_path_off[o + 1] - p0;
+			if (pn > MAXP) return false;
+			// the observations of one keyframe pair follow each other and share their path
+			if (pn == prev_n && (pn == 0 || std::memcmp(prev, Wn.path_edge + p0, sizeof(int) * (size_t)pn) == 0)) { obs_suf[o] = prev_id; continue; }
 			int cur = 0;
-			for (int p = Wn.obs_path_off[o + 1] - 1; p >= Wn.obs_path_off[o]; --p) {
+			for (int p = p0 + pn - 1; p >= p0; --p) {
 				const uint64_t key = ((uint64_t)(uint32_t)Wn.path_edge[p] << 32) | (uint32_t)cur;
-				auto it = ids.find(key);
-				if (it == ids.end()) { it = ids.emplace(key, (int)suf.size()).first; suf.push_back(nd_i2{Wn.path_edge[p], cur}); }
-				cur = it->second;
+				bool ins;
+				const int id = ids.get(key, (int)suf.size(), ins);
+				if (ins) { suf.push_back(nd_i2{Wn.path_edge[p], cur}); suf_len.push_back(suf_len[(size_t)cur] + 1); }
+				cur = id;
 			}
 			obs_suf[o] = cur;
+			prev = Wn.path_edge + p0; prev_n = pn; prev_id = cur;
 		}
 	}
 	const int n_suf = (int)suf.size();
 	if (n_suf > 65535) return false;
-	// ---- landmarks: observations sorted so that every trie subtree is a run; nodes ----
-	std::vector<std::vector<int>> lm_obs((size_t)n_lms);
-	for (int o = 0; o < n_obs; ++o) lm_obs[(size_t)Wn.obs_lm[o]].push_back(o);
-	struct node { int key, a, n; };                       // key suffix, run of the landmark's sorted observations
-	struct lmk { int l, obs_first; std::vector<int> obs; std::vector<node> nodes; };
-	std::vector<lmk> lms;
-	auto optimised = [&](int sid) { return Wn.edge_unknown_slot[suf[(size_t)sid].x >> 1] >= 0; };
-	std::vector<std::vector<int>> chains;                 // per observation of the current landmark: suffix ids from the shortest to the whole path
-	for (int l = 0; l < n_lms; ++l) {
-		const std::vector<int>& ob = lm_obs[(size_t)l];
-		if (ob.empty()) continue;                         // never observed: nothing to linearise, nothing moves it
-		if (ob.size() > 64) return false;
-		chains.assign(ob.size(), std::vector<int>());
-		for (size_t k = 0; k < ob.size(); ++k) {
-			for (int s = obs_suf[(size_t)ob[k]]; s != 0; s = suf[(size_t)s].y) chains[k].push_back(s);
-			std::reverse(chains[k].begin(), chains[k].end());
-		}
-		std::vector<int> ord(ob.size());
-		for (size_t k = 0; k < ord.size(); ++k) ord[k] = (int)k;
-		std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return chains[(size_t)a] < chains[(size_t)b]; });
-		lmk M;
-		M.l = l; M.obs_first = 0;
-		for (int k : ord) M.obs.push_back(ob[(size_t)k]);
-		// nodes in the order of their first observation (depth first): a node's observations are the run of those whose chain holds its key
-		for (size_t k = 0; k < ord.size(); ++k)
-			for (int s : chains[(size_t)ord[k]]) {
-				if (!optimised(s)) continue;
-				bool seen = false;
-				for (node& nd : M.nodes) if (nd.key == s) { nd.n = (int)k + 1 - nd.a; seen = true; break; }
-				if (!seen) M.nodes.push_back(node{s, (int)k, 1});
-			}
-		if (M.nodes.size() > 63) return false;
-		lms.push_back(std::move(M));
+	std::vector<int> chain((size_t)n_suf * MAXP, 0);
+	std::vector<char> suf_opt((size_t)n_suf, 0);           // the suffix starts at an optimised edge
+	std::vector<int> suf_es((size_t)n_suf, -1);            // ... its slot
+	for (int id = 1; id < n_suf; ++id) {
+		const int len = suf_len[(size_t)id], rest = suf[(size_t)id].y;
+		for (int k = 0; k + 1 < len; ++k) chain[(size_t)id * MAXP + k] = chain[(size_t)rest * MAXP + k];
+		chain[(size_t)id * MAXP + len - 1] = id;
+		suf_es[(size_t)id] = Wn.edge_unknown_slot[suf[(size_t)id].x >> 1];
+		suf_opt[(size_t)id] = suf_es[(size_t)id] >= 0;
 	}
-	if (!split) {
-		// optimised landmarks first, in slot order, then the fixed ones
-		std::stable_sort(lms.begin(), lms.end(), [&](const lmk& a, const lmk& b) {
-			const int sa = Wn.lm_unknown_slot[a.l], sb = Wn.lm_unknown_slot[b.l];
-			if ((sa >= 0) != (sb >= 0)) return sa >= 0;
-			return sa >= 0 ? sa < sb : a.l < b.l;
-		});
-	} else {
-		// by the sorted set of optimised edge slots of the landmark's nodes, lexicographically (ties: landmark index)
-		std::vector<std::vector<int>> eset(lms.size());
-		for (size_t m = 0; m < lms.size(); ++m) {
-			for (const node& nd : lms[m].nodes) eset[m].push_back(Wn.edge_unknown_slot[suf[(size_t)nd.key].x >> 1]);
-			std::sort(eset[m].begin(), eset[m].end());
-			eset[m].erase(std::unique(eset[m].begin(), eset[m].end()), eset[m].end());
+	// a is a suffix of b (or b itself)
+	auto is_suffix_of = [&](int a, int b) { const int la = suf_len[(size_t)a]; return la <= suf_len[(size_t)b] && (la == 0 || chain[(size_t)b * MAXP + la - 1] == a); };
+	// ---- landmarks: observations by landmark (counting sort), then per landmark sorted so that every trie subtree is a run; nodes ----
+	std::vector<int> lo_off((size_t)n_lms + 1, 0), lo_idx((size_t)n_obs);
+	for (int o = 0; o < n_obs; ++o) lo_off[(size_t)Wn.obs_lm[o] + 1]++;
+	for (int l = 0; l < n_lms; ++l) lo_off[(size_t)l + 1] += lo_off[(size_t)l];
+	{
+		std::vector<int> next(lo_off.begin(), lo_off.end() - 1);
+		for (int o = 0; o < n_obs; ++o) lo_idx[(size_t)next[(size_t)Wn.obs_lm[o]]++] = o;
+	}
+	struct node { int key, a, n; };                       // key suffix, run of the landmark's sorted observations
+	struct lmk { int l, obs0, n_obs, node0, n_nodes; };   // observations lm_sorted[obs0 ..), nodes nodes[node0 ..)
+	std::vector<lmk> lms;
+	lms.reserve((size_t)n_lms);
+	std::vector<int> lm_sorted((size_t)n_obs);             // per landmark its observations, sorted
+	std::vector<node> nodes;
+	nodes.reserve((size_t)n_obs * 2);
+	int n_sorted = 0;
+	for (int l = 0; l < n_lms; ++l) {
+		const int o0 = lo_off[(size_t)l], no = lo_off[(size_t)l + 1] - o0;
+		if (no == 0) continue;                            // never observed: nothing to linearise, nothing moves it
+		if (no > 64) return false;
+		// stable insertion sort by chain (the sequence of suffix ids from the shortest to the whole path), lexicographically
+		int ord[64];
+		auto chain_less = [&](int oa, int ob) {
+			const int sa = obs_suf[(size_t)oa], sb = obs_suf[(size_t)ob];
+			if (sa == sb) return false;
+			const int la = suf_len[(size_t)sa], lb = suf_len[(size_t)sb], lm = la < lb ? la : lb;
+			const int* ca = &chain[(size_t)sa * MAXP]; const int* cb = &chain[(size_t)sb * MAXP];
+			for (int k = 0; k < lm; ++k) if (ca[k] != cb[k]) return ca[k] < cb[k];
+			return la < lb;
+		};
+		for (int k = 0; k < no; ++k) {
+			const int o = lo_idx[(size_t)o0 + k];
+			int j = k;
+			while (j > 0 && chain_less(o, ord[j - 1])) { ord[j] = ord[j - 1]; --j; }
+			ord[j] = o;
 		}
+		lmk M{l, n_sorted, no, (int)nodes.size(), 0};
+		for (int k = 0; k < no; ++k) lm_sorted[(size_t)n_sorted + k] = ord[k];
+		n_sorted += no;
+		// nodes in the order of their first observation (depth first): a node's observations are the run of those whose chain holds its key
+		for (int k = 0; k < no; ++k) {
+			const int sid = obs_suf[(size_t)ord[k]], len = suf_len[(size_t)sid];
+			for (int c = 0; c < len; ++c) {
+				const int s2 = chain[(size_t)sid * MAXP + c];
+				if (!suf_opt[(size_t)s2]) continue;
+				bool seen = false;
+				for (int i = M.node0; i < (int)nodes.size(); ++i) if (nodes[(size_t)i].key == s2) { nodes[(size_t)i].n = k + 1 - nodes[(size_t)i].a; seen = true; break; }
+				if (!seen) nodes.push_back(node{s2, k, 1});
+			}
+		}
+		M.n_nodes = (int)nodes.size() - M.node0;
+		if (M.n_nodes > 63) return false;
+		lms.push_back(M);
+	}
+	{
 		std::vector<int> ord(lms.size());
 		for (size_t m = 0; m < ord.size(); ++m) ord[m] = (int)m;
-		std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return eset[(size_t)a] != eset[(size_t)b] ? eset[(size_t)a] < eset[(size_t)b] : lms[(size_t)a].l < lms[(size_t)b].l; });
-		std::vector<lmk> sorted;
-		sorted.reserve(lms.size());
-		for (int m : ord) sorted.push_back(std::move(lms[(size_t)m]));
+		if (!split) {
+			// optimised landmarks first, in slot order, then the fixed ones
+			std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+				const int sa = Wn.lm_unknown_slot[lms[(size_t)a].l], sb = Wn.lm_unknown_slot[lms[(size_t)b].l];
+				if ((sa >= 0) != (sb >= 0)) return sa >= 0;
+				return sa >= 0 ? sa < sb : lms[(size_t)a].l < lms[(size_t)b].l;
+			});
+		} else {
+			// by the sorted set of optimised edge slots of the landmark's nodes, lexicographically (ties: landmark index)
+			std::vector<nd_detail::eset> es(lms.size());
+			for (size_t m = 0; m < lms.size(); ++m)
+				for (int i = 0; i < lms[m].n_nodes; ++i) {
+					const int e = suf_es[(size_t)nodes[(size_t)lms[m].node0 + i].key];
+					if (e < 64) es[m].lo |= (uint64_t)1 << e; else es[m].hi |= (uint64_t)1 << (e - 64);
+				}
+			std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+				if (nd_detail::eset_less(es[(size_t)a], es[(size_t)b])) return true;
+				if (nd_detail::eset_less(es[(size_t)b], es[(size_t)a])) return false;
+				return lms[(size_t)a].l < lms[(size_t)b].l;
+			});
+		}
+		std::vector<lmk> sorted(lms.size());
+		for (size_t m = 0; m < ord.size(); ++m) sorted[m] = lms[(size_t)ord[m]];
 		lms.swap(sorted);
 	}
 	// ---- groups: greedy runs of landmarks with <= 64 observations and <= 64 lanes ----
-	const size_t win_i = H.win.size();
-	(void)win_i;
 	hdr.n_edges = Wn.n_edges_total; hdr.E = E; hdr.n_lms = n_lms; hdr.L = L; hdr.n_obs = n_obs; hdr.n_suf = n_suf;
 	hdr.suf0 = (int)H.suf.size(); hdr.tile0 = (int)H.tile.size(); hdr.grp0 = (int)H.group.size();
 	hdr.obs0 = (int)H.obs.size(); hdr.lane0 = (int)H.lane.size();
 	hdr.item0 = (int)H.item.size(); hdr.qs0 = (int)H.qs.size(); hdr.gitem0 = (int)H.gitem.size(); hdr.gqs0 = (int)H.gqs.size();
 	hdr.tab0 = H.tab_doubles;
 	hdr.hb0 = H.hb_doubles;
-	std::vector<nd_group> groups;
-	std::vector<nd_i2> w_obs;
-	std::vector<nd_f4> w_px;
-	std::vector<nd_i4> w_lane;
+	// (everything is appended to H directly; a window that turns out not to fit is rolled back)
+	const size_t r_suf = H.suf.size(), r_tile = H.tile.size(), r_group = H.group.size(), r_obs = H.obs.size(), r_px = H.px.size(), r_lane = H.lane.size(),
+	             r_item = H.item.size(), r_qs = H.qs.size(), r_gitem = H.gitem.size(), r_gqs = H.gqs.size(), r_sqs = H.sqs.size(), r_poff = H.poff.size(),
+	             r_goff = H.goff.size(), r_gslot = H.gslot.size();
+	auto rollback = [&] {
+		H.suf.resize(r_suf); H.tile.resize(r_tile); H.group.resize(r_group); H.obs.resize(r_obs); H.px.resize(r_px); H.lane.resize(r_lane);
+		H.item.resize(r_item); H.qs.resize(r_qs); H.gitem.resize(r_gitem); H.gqs.resize(r_gqs); H.sqs.resize(r_sqs); H.poff.resize(r_poff);
+		H.goff.resize(r_goff); H.gslot.resize(r_gslot);
+		return false;
+	};
 	struct gnode { int lmk, node, slot_lane; };            // per lane of a group: which landmark / node (-1 = root)
-	std::vector<std::vector<gnode>> glanes;
+	std::vector<gnode> glanes;                             // all groups' lanes, group after group (H.group[...].lane0 / n_lanes index it)
+	glanes.reserve(nodes.size() + lms.size());
 	{
 		nd_group G{0, 0, 0, 0};
-		std::vector<gnode> gl;
 		auto flush = [&] {
 			if (G.n_lanes == 0) return;
-			groups.push_back(G); glanes.push_back(gl);
-			G.obs0 += G.n_obs; G.lane0 += G.n_lanes; G.n_obs = 0; G.n_lanes = 0; gl.clear();
+			H.group.push_back(G);
+			G.obs0 += G.n_obs; G.lane0 += G.n_lanes; G.n_obs = 0; G.n_lanes = 0;
 		};
 		for (size_t m = 0; m < lms.size(); ++m) {
 			const lmk& M = lms[m];
-			const int no = (int)M.obs.size(), nl = 1 + (int)M.nodes.size();
+			const int no = M.n_obs, nl = 1 + M.n_nodes;
 			if (G.n_obs + no > 64 || G.n_lanes + nl > 64) flush();
 			const int root_lane = G.n_lanes, obs_a = G.n_obs;
-			for (int o : M.obs) {
-				w_obs.push_back(nd_i2{M.l, obs_suf[(size_t)o] | (root_lane << 16)});
-				w_px.push_back(nd_f4{Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]});
+			for (int k = 0; k < no; ++k) {
+				const int o = lm_sorted[(size_t)M.obs0 + k];
+				H.obs.push_back(nd_i2{M.l, obs_suf[(size_t)o] | (root_lane << 16)});
+				H.px.push_back(nd_f4{Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]});
 			}
-			w_lane.push_back(nd_i4{M.l, obs_a | (no << 8), Wn.lm_unknown_slot[M.l], 1 | (root_lane << 8) | ((int)M.nodes.size() << 16)});
-			gl.push_back(gnode{(int)m, -1, root_lane});
-			for (size_t k = 0; k < M.nodes.size(); ++k) {
-				const node& nd = M.nodes[k];
+			H.lane.push_back(nd_i4{M.l, obs_a | (no << 8), Wn.lm_unknown_slot[M.l], 1 | (root_lane << 8) | (M.n_nodes << 16)});
+			glanes.push_back(gnode{(int)m, -1, root_lane});
+			for (int k = 0; k < M.n_nodes; ++k) {
+				const node& nd = nodes[(size_t)M.node0 + k];
 				const int code = suf[(size_t)nd.key].x, inv = code & 1;
 				const int tsuf = inv ? suf[(size_t)nd.key].y : nd.key;
-				const int es = Wn.edge_unknown_slot[code >> 1];
-				w_lane.push_back(nd_i4{M.l, (obs_a + nd.a) | (nd.n << 8), tsuf | (es << 16) | (inv << 24), 2 | (root_lane << 8)});
-				gl.push_back(gnode{(int)m, (int)k, root_lane + 1 + (int)k});
+				const int es = suf_es[(size_t)nd.key];
+				H.lane.push_back(nd_i4{M.l, (obs_a + nd.a) | (nd.n << 8), tsuf | (es << 16) | (inv << 24), 2 | (root_lane << 8)});
+				glanes.push_back(gnode{(int)m, k, root_lane + 1 + k});
 			}
 			G.n_obs += no; G.n_lanes += nl;
 		}
 		flush();
 	}
-	// ---- tiles: `waves` groups each; the items of a tile sorted by 6x6 block ----
+	const size_t n_groups = H.group.size() - r_group;
+	// ---- tiles: `waves` groups each; the items of a tile sorted by 6x6 block (counting sort over the blocks the tile touches) ----
 	const int NQ = waves * 16;
-	(void)NQ;
 	const int n_pairs = E * (E + 1) / 2;
 	auto pid_of = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
-	std::vector<nd_tile> tiles;
-	std::vector<int> w_item, w_gitem;
-	std::vector<nd_i2> w_qs, w_gqs;
-	const size_t n_tiles = (groups.size() + (size_t)waves - 1) / (size_t)waves;
-	std::vector<std::vector<std::pair<int, int>>> tile_items(n_tiles);       // (block, item) per tile, generation order
-	std::vector<std::vector<std::vector<int>>> tile_edge(n_tiles, std::vector<std::vector<int>>((size_t)E));
+	const size_t n_tiles = (n_groups + (size_t)waves - 1) / (size_t)waves;
+	std::vector<int> t_pid, t_code;                        // the current tile's items, generation order
+	std::vector<int> cnt((size_t)n_pairs + 1, 0), start((size_t)n_pairs + 1, 0), used, sorted_code;
+	std::vector<int> e_cnt((size_t)E + 1, 0), e_start((size_t)E + 1, 0), e_slot, e_of;      // the tile's node slots by edge
+	std::vector<char> is_diag((size_t)n_pairs, 0);         // block (e, e): the only ones the lambda_0 pass needs (bit 30 of a lane slot's x)
+	for (int e = 0; e < E; ++e) is_diag[(size_t)pid_of(e, e)] = 1;
+	int max_per_lane = 0, max_rounds = 0, max_tile_blocks = 0;
 	for (size_t t = 0; t < n_tiles; ++t) {
 		const size_t g0 = t * (size_t)waves;
-		const int n_grp = (int)std::min(groups.size() - g0, (size_t)waves);
+		const int n_grp = (int)std::min(n_groups - g0, (size_t)waves);
+		t_pid.clear(); t_code.clear(); e_slot.clear(); e_of.clear(); used.clear();
 		for (int wv = 0; wv < n_grp; ++wv) {
-			const std::vector<gnode>& gl = glanes[g0 + (size_t)wv];
-			for (size_t a = 0; a < gl.size(); ++a) {
+			const nd_group& Gr = H.group[r_group + g0 + (size_t)wv];
+			const gnode* gl = &glanes[(size_t)Gr.lane0];
+			const int nl = Gr.n_lanes;
+			for (int a = 0; a < nl; ++a) {
 				if (gl[a].node < 0) continue;
 				const lmk& M = lms[(size_t)gl[a].lmk];
 				const bool opt = Wn.lm_unknown_slot[M.l] >= 0;
-				const int ka = M.nodes[(size_t)gl[a].node].key, ea = Wn.edge_unknown_slot[suf[(size_t)ka].x >> 1];
+				const int ka = nodes[(size_t)M.node0 + gl[a].node].key, ea = suf_es[(size_t)ka];
 				const int slot_a = 64 * wv + gl[a].slot_lane;
-				tile_edge[t][(size_t)ea].push_back(slot_a);
+				e_slot.push_back(slot_a); e_of.push_back(ea);
 				// partners: the later nodes of the same landmark (they follow in the lane order) and the node itself
-				for (size_t b = a; b < gl.size() && gl[b].lmk == gl[a].lmk; ++b) {
-					const int kb = M.nodes[(size_t)gl[b].node].key, eb = Wn.edge_unknown_slot[suf[(size_t)kb].x >> 1];
+				for (int b = a; b < nl && gl[b].lmk == gl[a].lmk; ++b) {
+					const int kb = nodes[(size_t)M.node0 + gl[b].node].key, eb = suf_es[(size_t)kb];
 					const int slot_b = 64 * wv + gl[b].slot_lane;
-					// nested: one key is a suffix of the other (walk the longer one's rests)
-					auto is_suffix_of = [&](int shorter, int longer) { for (int s = longer; s != 0; s = suf[(size_t)s].y) if (s == shorter) return true; return false; };
 					int far = 0;                                   // 1: a far (b's key is a suffix of a's), 2: b far, 0: not nested
 					if (is_suffix_of(kb, ka)) far = 1; else if (is_suffix_of(ka, kb)) far = 2;
 					if (far == 0 && !opt) continue;
 					// item (row r, column c): the far node of a nested pair gives Zh, the near one Ph; not nested: Zh, Zh and the sign bit
 					auto emit = [&](int slot_r, int slot_c, bool r_far, bool c_far, int pid) {
 						const int xp = (far != 0 && !r_far) ? 1 : 0, yp = (far != 0 && !c_far) ? 1 : 0;
-						tile_items[t].push_back(std::make_pair(pid, slot_r | (xp << 9) | (slot_c << 10) | (yp << 19) | ((far == 0 ? 1 : 0) << 20)));
+						if (cnt[(size_t)pid]++ == 0) used.push_back(pid);
+						t_pid.push_back(pid);
+						t_code.push_back(slot_r | (xp << 9) | (slot_c << 10) | (yp << 19) | ((far == 0 ? 1 : 0) << 20));
 					};
 					if (a == b) emit(slot_a, slot_a, true, false, pid_of(ea, ea));
 					else if (ea < eb) emit(slot_a, slot_b, far == 1, far == 2, pid_of(ea, eb));
@@ -228,22 +337,20 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 				}
 			}
 		}
-	}
-	std::vector<nd_i4> w_sqs;
-	std::vector<int> w_poff, w_goff, w_gslot;
-	int n_part = 0, n_gpart = 0, max_tile_blocks = 0;
-	if (split) {
-		std::vector<std::vector<int>> by_pid((size_t)n_pairs);
-		std::vector<char> is_diag((size_t)n_pairs, 0);         // block (e, e): the only ones the lambda_0 pass needs (bit 30 of the slot's x)
-		for (int e = 0; e < E; ++e) is_diag[(size_t)pid_of(e, e)] = 1;
-		std::vector<int> used;
-		for (size_t t = 0; t < n_tiles; ++t) {
-			nd_tile T{};
-			T.grp0 = (int)(t * (size_t)waves); T.n_grp = (int)std::min(groups.size() - t * (size_t)waves, (size_t)waves);
-			used.clear();
-			for (const auto& it : tile_items[t]) { if (by_pid[(size_t)it.first].empty()) used.push_back(it.first); by_pid[(size_t)it.first].push_back(it.second); }
-			// heaviest first: the 16 quads of a wavefront run in lockstep
-			std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
+		// heaviest block first (ties: first appearance): the lanes of a wavefront run in lockstep
+		std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
+		{
+			int pos = 0;
+			for (int p2 : used) { start[(size_t)p2] = pos; pos += cnt[(size_t)p2]; }
+			sorted_code.resize(t_code.size());
+			std::vector<int>& fill = e_start;               // (scratch: the blocks' fill positions)
+			fill.assign((size_t)std::max(n_pairs, E) + 1, 0);
+			for (size_t i = 0; i < t_pid.size(); ++i) sorted_code[(size_t)(start[(size_t)t_pid[i]] + fill[(size_t)t_pid[i]]++)] = t_code[i];
+		}
+		nd_tile T{};
+		T.grp0 = (int)g0; T.n_grp = n_grp;
+		const int item_base = (int)(H.item.size() - r_item);
+		if (split) {
 			// LANE slots: a block gets 1, 2 or 4 lanes (its items dealt out among them, the lanes' sums joined by one or two DPP steps), the fewest
 			// that keep a lane's run <= R items; R = the shortest run length whose lanes fit the fewest rounds of the workgroup.  Heaviest blocks first,
 			// so the 4-lane blocks come first, then the 2-lane ones: every group is aligned and a wavefront's lanes walk runs of similar length.
@@ -253,192 +360,152 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			int R = 1;
 			for (;; ++R) {
 				long long lanes = 0;
-				for (int p2 : used) lanes += lanes_of((int)by_pid[(size_t)p2].size(), R);
+				for (int p2 : used) lanes += lanes_of(cnt[(size_t)p2], R);
 				if (lanes <= (long long)NT_ * rounds_min) break;
 			}
-			T.qs0 = (int)w_sqs.size();
+			T.qs0 = (int)(H.sqs.size() - r_sqs);
 			max_tile_blocks = std::max(max_tile_blocks, (int)used.size());
 			for (int p2 : used) {
-				const std::vector<int>& v = by_pid[(size_t)p2];
-				const int k = lanes_of((int)v.size(), R), kc = k == 4 ? 2 : (k == 2 ? 1 : 0);
-				if ((int)v.size() > 0xFFFF) return false;
+				const int c = cnt[(size_t)p2];
+				const int k = lanes_of(c, R), kc = k == 4 ? 2 : (k == 2 ? 1 : 0);
+				if (c > 0xFFFF) return rollback();
 				for (int r = 0; r < k; ++r)
-					w_sqs.push_back(nd_i4{p2 | (is_diag[(size_t)p2] ? 1 << 30 : 0), (int)v.size() | (kc << 16) | (r << 20), (int)w_item.size(), -1});
-				w_item.insert(w_item.end(), v.begin(), v.end());
+					H.sqs.push_back(nd_i4{p2 | (is_diag[(size_t)p2] ? 1 << 30 : 0), c | (kc << 16) | (r << 20), item_base + start[(size_t)p2], -1});
 			}
-			T.n_rounds = (int)w_sqs.size() - T.qs0;               // (split form: n_rounds = number of lane slots of the tile)
+			H.item.insert(H.item.end(), sorted_code.begin(), sorted_code.end());
+			T.n_rounds = (int)(H.sqs.size() - r_sqs) - T.qs0;     // (split form: n_rounds = number of lane slots of the tile)
 			// bit 29: this wavefront (64 consecutive lane slots) holds blocks of several lanes
-			for (int w0 = T.qs0; w0 < (int)w_sqs.size(); w0 += 64) {
+			for (size_t w0 = r_sqs + (size_t)T.qs0; w0 < H.sqs.size(); w0 += 64) {
+				const size_t w1 = std::min(w0 + 64, H.sqs.size());
 				bool multi = false;
-				for (int i = w0; i < std::min(w0 + 64, (int)w_sqs.size()); ++i) multi |= ((w_sqs[(size_t)i].y >> 16) & 3) != 0;
-				if (multi) for (int i = w0; i < std::min(w0 + 64, (int)w_sqs.size()); ++i) w_sqs[(size_t)i].x |= 1 << 29;
+				for (size_t i = w0; i < w1; ++i) multi |= ((H.sqs[i].y >> 16) & 3) != 0;
+				if (multi) for (size_t i = w0; i < w1; ++i) H.sqs[i].x |= 1 << 29;
 			}
-			for (int p2 : used) by_pid[(size_t)p2].clear();
-			T.gqs0 = (int)w_gqs.size(); T.n_gqs = 0;
+		} else {
+			// quad slots of a tile: a block per quad, heaviest first (the 16 quads of a wavefront run in lockstep: similar loads share one); with quads
+			// to spare the heaviest blocks are cut in two parts (items dealt out alternately) that sit in the two quads of an aligned lane octet
+			// and are added up by a DPP mirror step before the block's accumulator takes them
+			int n_split = 0;
+			if ((int)used.size() < NQ) {
+				n_split = std::min((NQ - (int)used.size()), (int)used.size());
+				while (n_split > 0 && cnt[(size_t)used[(size_t)n_split - 1]] < 8) --n_split;       // (a short run is not worth a second quad)
+			}
+			const int n_slots = (int)used.size() + n_split;
+			T.qs0 = (int)(H.qs.size() - r_qs);
+			T.n_rounds = (n_slots + NQ - 1) / NQ;
+			max_rounds = std::max(max_rounds, T.n_rounds);
+			for (int k = 0; k < T.n_rounds * NQ; ++k) {
+				const int wave_flag = (k / 16) * 16 < 2 * n_split ? (int)0x80000000u : 0;      // this wavefront holds blocks cut in two
+				if (k >= n_slots) { H.qs.push_back(nd_i2{0xFFFF, wave_flag}); continue; }
+				const int pid = k < 2 * n_split ? used[(size_t)(k >> 1)] : used[(size_t)(k - n_split)];
+				const int part = k < 2 * n_split ? (k & 1) : 0, parts = k < 2 * n_split ? 2 : 1;
+				const int first = (int)(H.item.size() - r_item);
+				const int* v = &sorted_code[(size_t)start[(size_t)pid]];
+				const int c = cnt[(size_t)pid];
+				for (int i = part; i < c; i += parts) H.item.push_back(v[i]);
+				const int n = (int)(H.item.size() - r_item) - first;
+				if (n > 32767 || first >= (1 << 28)) return rollback();
+				H.qs.push_back(nd_i2{pid | (n << 16), first | (part << 28) | (parts == 2 ? 1 << 30 : 0) | wave_flag});
+				max_per_lane = std::max(max_per_lane, (n + 3) / 4);
+			}
+		}
+		for (int p2 : used) cnt[(size_t)p2] = 0;
+		// gradient slots: the tile's node slots by edge (edge order; inside an edge the lane order)
+		T.gqs0 = (int)(H.gqs.size() - r_gqs); T.n_gqs = 0;
+		{
+			std::fill(e_cnt.begin(), e_cnt.end(), 0);
+			for (int e : e_of) e_cnt[(size_t)e]++;
+			int pos = (int)(H.gitem.size() - r_gitem);
+			const size_t base = H.gitem.size();
+			H.gitem.resize(base + e_slot.size());
+			std::vector<int>& fill = e_start;
+			fill.assign((size_t)std::max(n_pairs, E) + 1, 0);
 			for (int e = 0; e < E; ++e) {
-				const std::vector<int>& v = tile_edge[t][(size_t)e];
-				if (v.empty()) continue;
-				w_gqs.push_back(nd_i2{e | ((int)v.size() << 16), (int)w_gitem.size()});
-				w_gitem.insert(w_gitem.end(), v.begin(), v.end());
+				if (e_cnt[(size_t)e] == 0) continue;
+				H.gqs.push_back(nd_i2{e | (e_cnt[(size_t)e] << 16), pos});
+				fill[(size_t)e] = pos - (int)(base - r_gitem);      // (position inside this tile's part)
+				pos += e_cnt[(size_t)e];
 				++T.n_gqs;
 			}
-			tiles.push_back(T);
+			for (size_t i = 0; i < e_slot.size(); ++i) H.gitem[base + (size_t)fill[(size_t)e_of[i]]++] = e_slot[i];
 		}
+		H.tile.push_back(T);
+	}
+	int n_part = 0, n_gpart = 0;
+	if (split) {
 		// partial slots, block-major (a block's slots are contiguous, in tile order); gradient slots, edge-major
-		w_poff.assign((size_t)n_pairs + 1, 0);
-		for (const nd_i4& q : w_sqs) if (((q.y >> 20) & 3) == 0) w_poff[(size_t)(q.x & 0xFFFF) + 1]++;
+		const size_t p0 = H.poff.size(), g0 = H.goff.size();
+		H.poff.resize(p0 + (size_t)n_pairs + 1, 0);
+		int* w_poff = &H.poff[p0];
+		for (size_t i = r_sqs; i < H.sqs.size(); ++i) if (((H.sqs[i].y >> 20) & 3) == 0) w_poff[(size_t)(H.sqs[i].x & 0xFFFF) + 1]++;
 		for (int p2 = 0; p2 < n_pairs; ++p2) w_poff[(size_t)p2 + 1] += w_poff[(size_t)p2];
 		{
-			std::vector<int> next(w_poff.begin(), w_poff.end() - 1);
-			for (nd_i4& q : w_sqs) q.w = ((q.y >> 20) & 3) == 0 ? next[(size_t)(q.x & 0xFFFF)]++ : next[(size_t)(q.x & 0xFFFF)] - 1;      // (the lanes of a block follow its first one)
+			std::vector<int> next(w_poff, w_poff + n_pairs);
+			for (size_t i = r_sqs; i < H.sqs.size(); ++i) {
+				nd_i4& q = H.sqs[i];
+				q.w = ((q.y >> 20) & 3) == 0 ? next[(size_t)(q.x & 0xFFFF)]++ : next[(size_t)(q.x & 0xFFFF)] - 1;      // (the lanes of a block follow its first one)
+			}
 		}
 		n_part = w_poff[(size_t)n_pairs];
-		w_goff.assign((size_t)E + 1, 0);
-		for (const nd_i2& q : w_gqs) w_goff[(size_t)(q.x & 0xFFFF) + 1]++;
+		H.goff.resize(g0 + (size_t)E + 1, 0);
+		int* w_goff = &H.goff[g0];
+		for (size_t i = r_gqs; i < H.gqs.size(); ++i) w_goff[(size_t)(H.gqs[i].x & 0xFFFF) + 1]++;
 		for (int e = 0; e < E; ++e) w_goff[(size_t)e + 1] += w_goff[(size_t)e];
 		{
-			std::vector<int> next(w_goff.begin(), w_goff.end() - 1);
-			w_gslot.resize(w_gqs.size());
-			for (size_t k = 0; k < w_gqs.size(); ++k) w_gslot[k] = next[(size_t)(w_gqs[k].x & 0xFFFF)]++;
+			std::vector<int> next(w_goff, w_goff + E);
+			H.gslot.resize(r_gslot + (H.gqs.size() - r_gqs));
+			for (size_t k = r_gqs; k < H.gqs.size(); ++k) H.gslot[r_gslot + (k - r_gqs)] = next[(size_t)(H.gqs[k].x & 0xFFFF)]++;
 		}
-		n_gpart = (int)w_gqs.size();
-	} else {
-#if SSK_ND_LANE_RUNS
-	// lane slots of a tile: the items of a block dealt out in runs of R consecutive items, a lane per run; R = the shortest run length
-	// whose lanes fit the workgroup (one round); the lanes of one block stay inside one wavefront (their sums meet in ONE ds_add_f64 per
-	// component: the order of the adds is the LDS unit's lane order, the same in every launch)
-	int max_per_lane = 0, max_rounds = 0;
-	const int NT_ = waves * 64;
-	std::vector<std::vector<int>> by_pid((size_t)n_pairs);
-	std::vector<int> used;
-	for (size_t t = 0; t < n_tiles; ++t) {
-		nd_tile T{};
-		T.grp0 = (int)(t * (size_t)waves); T.n_grp = (int)std::min(groups.size() - t * (size_t)waves, (size_t)waves);
-		used.clear();
-		for (const auto& it : tile_items[t]) { if (by_pid[(size_t)it.first].empty()) used.push_back(it.first); by_pid[(size_t)it.first].push_back(it.second); }
-		std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
-		auto lanes_for = [&](int R) {
-			long long pos = 0;
-			for (int p2 : used) {
-				const long long g = ((long long)by_pid[(size_t)p2].size() + R - 1) / R;
-				if (g > 64) return (long long)1 << 40;
-				if ((pos & 63) + g > 64) pos = (pos + 63) & ~63LL;
-				pos += g;
-			}
-			return pos;
-		};
-		int R = 1;
-		while (R < 8 && lanes_for(R) > NT_) ++R;
-		if (lanes_for(R) >= ((long long)1 << 40)) return false;
-		T.qs0 = (int)w_qs.size();
-		long long pos = 0;
-		for (int p2 : used) {
-			const std::vector<int>& v = by_pid[(size_t)p2];
-			const long long g = ((long long)v.size() + R - 1) / R;
-			if ((pos & 63) + g > 64) for (; pos & 63; ++pos) w_qs.push_back(nd_i2{0xFFFF, 0});
-			for (long long k = 0; k < g; ++k) {
-				const int first = (int)w_item.size(), n = (int)std::min<long long>(R, (long long)v.size() - k * R);
-				w_item.insert(w_item.end(), v.begin() + k * R, v.begin() + k * R + n);
-				w_qs.push_back(nd_i2{p2 | (n << 16), first});
-				++pos;
-			}
-			max_per_lane = std::max(max_per_lane, std::min(R, (int)v.size()));
-		}
-		for (; pos % NT_; ++pos) w_qs.push_back(nd_i2{0xFFFF, 0});
-		T.n_rounds = (int)(pos / NT_);
-		max_rounds = std::max(max_rounds, T.n_rounds);
-		for (int p2 : used) by_pid[(size_t)p2].clear();
-		T.gqs0 = (int)w_gqs.size(); T.n_gqs = 0;
-		for (int e = 0; e < E; ++e) {
-			const std::vector<int>& v = tile_edge[t][(size_t)e];
-			if (v.empty()) continue;
-			w_gqs.push_back(nd_i2{e | ((int)v.size() << 16), (int)w_gitem.size()});
-			w_gitem.insert(w_gitem.end(), v.begin(), v.end());
-			++T.n_gqs;
-		}
-		tiles.push_back(T);
+		n_gpart = (int)(H.gqs.size() - r_gqs);
 	}
-#else
-	// quad slots of a tile: a block per quad, heaviest first (the 16 quads of a wavefront run in lockstep: similar loads share one); with quads
-	// to spare the heaviest blocks are cut in two parts (items dealt out alternately) that sit in the two quads of an aligned lane octet
-	// and are added up by a DPP mirror step before the block's accumulator takes them
-	int max_per_lane = 0, max_rounds = 0;
-	std::vector<std::vector<int>> by_pid((size_t)n_pairs);
-	std::vector<int> used;
-	for (size_t t = 0; t < n_tiles; ++t) {
-		nd_tile T{};
-		T.grp0 = (int)(t * (size_t)waves); T.n_grp = (int)std::min(groups.size() - t * (size_t)waves, (size_t)waves);
-		used.clear();
-		for (const auto& it : tile_items[t]) { if (by_pid[(size_t)it.first].empty()) used.push_back(it.first); by_pid[(size_t)it.first].push_back(it.second); }
-		std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return by_pid[(size_t)a].size() > by_pid[(size_t)b].size(); });
-		int n_split = 0;
-		if ((int)used.size() < NQ) {
-			n_split = std::min((NQ - (int)used.size()), (int)used.size());
-			while (n_split > 0 && by_pid[(size_t)used[(size_t)n_split - 1]].size() < 8) --n_split;       // (a short run is not worth a second quad)
-		}
-		struct qslot { int pid, part, parts; };
-		std::vector<qslot> slots;
-		for (int k = 0; k < n_split; ++k) { slots.push_back(qslot{used[(size_t)k], 0, 2}); slots.push_back(qslot{used[(size_t)k], 1, 2}); }
-		for (size_t k = (size_t)n_split; k < used.size(); ++k) slots.push_back(qslot{used[k], 0, 1});
-		T.qs0 = (int)w_qs.size();
-		T.n_rounds = ((int)slots.size() + NQ - 1) / NQ;
-		max_rounds = std::max(max_rounds, T.n_rounds);
-		for (size_t k = 0; k < (size_t)T.n_rounds * NQ; ++k) {
-			const int wave_flag = (k / 16) * 16 < (size_t)(2 * n_split) ? (int)0x80000000u : 0;      // this wavefront holds blocks cut in two
-			if (k >= slots.size()) { w_qs.push_back(nd_i2{0xFFFF, wave_flag}); continue; }
-			const qslot& q = slots[k];
-			const std::vector<int>& v = by_pid[(size_t)q.pid];
-			const int first = (int)w_item.size();
-			for (size_t i = (size_t)q.part; i < v.size(); i += (size_t)q.parts) w_item.push_back(v[i]);
-			const int n = (int)w_item.size() - first;
-			if (n > 32767 || first >= (1 << 28)) return false;
-			w_qs.push_back(nd_i2{q.pid | (n << 16), first | (q.part << 28) | (q.parts == 2 ? 1 << 30 : 0) | wave_flag});
-			max_per_lane = std::max(max_per_lane, (n + 3) / 4);
-		}
-		for (int p : used) by_pid[(size_t)p].clear();
-		T.gqs0 = (int)w_gqs.size(); T.n_gqs = 0;
-		for (int e = 0; e < E; ++e) {
-			const std::vector<int>& v = tile_edge[t][(size_t)e];
-			if (v.empty()) continue;
-			w_gqs.push_back(nd_i2{e | ((int)v.size() << 16), (int)w_gitem.size()});
-			w_gitem.insert(w_gitem.end(), v.begin(), v.end());
-			++T.n_gqs;
-		}
-		tiles.push_back(T);
-	}
-#endif
 	hdr.n_rounds = max_rounds; hdr.max_parts = 2;
-	H.max_items_per_lane = std::max(H.max_items_per_lane, max_per_lane);
-	}
-	hdr.n_tiles = (int)tiles.size(); hdr.n_groups = (int)groups.size();
+	hdr.n_tiles = (int)n_tiles; hdr.n_groups = (int)n_groups;
 	// ---- commit ----
 	H.suf.insert(H.suf.end(), suf.begin(), suf.end());
-	H.tile.insert(H.tile.end(), tiles.begin(), tiles.end());
-	H.group.insert(H.group.end(), groups.begin(), groups.end());
-	H.obs.insert(H.obs.end(), w_obs.begin(), w_obs.end());
-	H.px.insert(H.px.end(), w_px.begin(), w_px.end());
-	H.lane.insert(H.lane.end(), w_lane.begin(), w_lane.end());
-	H.item.insert(H.item.end(), w_item.begin(), w_item.end());
-	H.qs.insert(H.qs.end(), w_qs.begin(), w_qs.end());
-	H.gitem.insert(H.gitem.end(), w_gitem.begin(), w_gitem.end());
-	H.gqs.insert(H.gqs.end(), w_gqs.begin(), w_gqs.end());
 	H.tab_doubles += 2LL * 12 * n_suf;
 	H.hb_doubles += 36LL * E * (E + 1) / 2;
-	H.lds_doubles = std::max(H.lds_doubles, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)tiles.size(), (int)groups.size()));
-	H.lds_doubles_big = std::max(H.lds_doubles_big, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)tiles.size(), (int)groups.size(), true, lds_limit_doubles));
+	H.lds_doubles = std::max(H.lds_doubles, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)n_tiles, (int)n_groups));
+	H.lds_doubles_big = std::max(H.lds_doubles_big, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)n_tiles, (int)n_groups, true, lds_limit_doubles));
+	H.max_items_per_lane = std::max(H.max_items_per_lane, max_per_lane);
 	if (split) {
 		nd_split S{};
-		S.sqs0 = (int)H.sqs.size(); S.poff0 = (int)H.poff.size(); S.goff0 = (int)H.goff.size(); S.gslot0 = (int)H.gslot.size();
+		S.sqs0 = (int)r_sqs; S.poff0 = (int)r_poff; S.goff0 = (int)r_goff; S.gslot0 = (int)r_gslot;
 		S.n_part = n_part; S.n_gpart = n_gpart; S.part0 = H.part_slots; S.gpart0 = H.gpart_slots;
-		S.gtile0 = (int)H.tile.size() - (int)tiles.size();
-		H.sqs.insert(H.sqs.end(), w_sqs.begin(), w_sqs.end());
-		H.poff.insert(H.poff.end(), w_poff.begin(), w_poff.end());
-		H.goff.insert(H.goff.end(), w_goff.begin(), w_goff.end());
-		H.gslot.insert(H.gslot.end(), w_gslot.begin(), w_gslot.end());
+		S.gtile0 = (int)r_tile;
 		H.part_slots += n_part; H.gpart_slots += n_gpart;
 		H.max_tile_blocks = std::max(H.max_tile_blocks, max_tile_blocks);
 		H.swin.push_back(S);
 	}
 	H.win.push_back(hdr);
 	return true;
+}
+
+// Appends the tables of ONE window (built into a fresh nd_host by nd_build_window with zero bases) to a batch's tables: every window-level base moves
+// by the batch's sizes; indices stored inside the tables are window relative and stay.  Windows can so be built side by side (one thread each).
+inline void nd_append(nd_host& D, const nd_host& W1)
+{
+	nd_win w = W1.win[0];
+	w.suf0 += (int)D.suf.size(); w.tile0 += (int)D.tile.size(); w.grp0 += (int)D.group.size(); w.obs0 += (int)D.obs.size(); w.lane0 += (int)D.lane.size();
+	w.item0 += (int)D.item.size(); w.qs0 += (int)D.qs.size(); w.gitem0 += (int)D.gitem.size(); w.gqs0 += (int)D.gqs.size();
+	w.tab0 += D.tab_doubles; w.hb0 += D.hb_doubles;
+	if (!W1.swin.empty()) {
+		nd_split s = W1.swin[0];
+		s.sqs0 += (int)D.sqs.size(); s.poff0 += (int)D.poff.size(); s.goff0 += (int)D.goff.size(); s.gslot0 += (int)D.gslot.size();
+		s.part0 += D.part_slots; s.gpart0 += D.gpart_slots; s.gtile0 += (int)D.tile.size();
+		D.swin.push_back(s);
+	}
+	D.win.push_back(w);
+#define ND_APP(v) D.v.insert(D.v.end(), W1.v.begin(), W1.v.end())
+	ND_APP(suf); ND_APP(tile); ND_APP(group); ND_APP(obs); ND_APP(px); ND_APP(lane); ND_APP(item); ND_APP(qs); ND_APP(gitem); ND_APP(gqs);
+	ND_APP(sqs); ND_APP(poff); ND_APP(goff); ND_APP(gslot);
+#undef ND_APP
+	D.tab_doubles += W1.tab_doubles; D.hb_doubles += W1.hb_doubles; D.part_slots += W1.part_slots; D.gpart_slots += W1.gpart_slots;
+	D.lds_doubles = std::max(D.lds_doubles, W1.lds_doubles); D.lds_doubles_big = std::max(D.lds_doubles_big, W1.lds_doubles_big);
+	D.max_items_per_lane = std::max(D.max_items_per_lane, W1.max_items_per_lane); D.max_tile_blocks = std::max(D.max_tile_blocks, W1.max_tile_blocks);
+}
+// a window of the batch that another kernel family solves: an empty header keeps the family's window arrays indexed by the batch's window number
+inline void nd_append_placeholder(nd_host& D, bool split)
+{
+	D.win.push_back(nd_win{});
+	if (split) D.swin.push_back(nd_split{});
 }

@@ -3,6 +3,7 @@
 // items, gradient items, the landmark step.  Test infrastructure (tests/test_lm_node_form.py compares its reduced system with the dense
 // textbook form): it checks the symbolic structure and the bit fields without a GPU; the kernel's lane mechanics (DPP sums, LDS
 // overlays) are not modelled.  Build: g++ -O2 -shared -fPIC tools/lm_node_emu.cpp -o <out>/liblm_node_emu.so
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -277,6 +278,37 @@ int nd_emu_linearise_form(const ssk_lm_window* Wn, const ssk_lm_params* P, doubl
 		}
 	}
 	return 0;
+}
+
+// FNV-1a hashes of every table the host builder emits for the window (tests: two builds of the library must agree; tools: refactors of the builder)
+static unsigned long long nd_fnv(const void* p, size_t n, unsigned long long h = 1469598103934665603ull)
+{
+	const unsigned char* b = (const unsigned char*)p;
+	for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+	return h;
+}
+int nd_emu_tables_hash(const ssk_lm_window* Wn, int waves, int split, unsigned long long* out /* 16 */)
+{
+	nd_host H;
+	nd_win hdr{};
+	if (!nd_build_window(*Wn, waves, H, hdr, 20352, split != 0)) return -1;
+#define HV(i, v) out[i] = nd_fnv(H.v.data(), sizeof(H.v[0]) * H.v.size()) ^ (unsigned long long)H.v.size()
+	HV(0, win); HV(1, tile); HV(2, group); HV(3, suf); HV(4, obs); HV(5, px); HV(6, lane); HV(7, item); HV(8, qs); HV(9, gitem); HV(10, gqs);
+	HV(11, swin); HV(12, sqs); HV(13, poff); HV(14, goff); HV(15, gslot);
+#undef HV
+	return 0;
+}
+
+// host builder alone, `reps` times: milliseconds per build (tools: profiling the symbolic stage without a GPU)
+double nd_emu_build_ms(const ssk_lm_window* Wn, int waves, int split, int reps)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	for (int r = 0; r < reps; ++r) {
+		nd_host H;
+		nd_win hdr{};
+		if (!nd_build_window(*Wn, waves, H, hdr, 20352, split != 0)) return -1.0;
+	}
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 
 int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lambda, int pre, int waves, double* Hred, double* g, const double* dp, double* df,
