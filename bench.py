@@ -280,6 +280,7 @@ def main():
     # counts differ, and CUs whose window has converged pick up front-end workgroups instead of idling
     lm_stream = torch.cuda.Stream() if args.overlap else torch.cuda.current_stream()
     ctx_lm = pkg.Context(local, stream=lm_stream.cuda_stream) if args.overlap else ctx
+    lm_ext_stream = torch.cuda.ExternalStream(ctx_lm.stream(), device=local)      # the stream the LM context really enqueues on
     B = args.batch
     S = args.shared_landmarks
     cur, prev, lm, wins, shared_idx, lm_batch_wins = build_workload(pkg, capi, ctx, ctx_lm, B, rank, n_base=max(1, args.base_images), n_lm_distinct=max(1, min(args.lm_distinct, B)),
@@ -307,7 +308,9 @@ def main():
     side = torch.cuda.Stream() if args.side_stream else None
     ctx_side = pkg.Context(local, stream=side.cuda_stream) if side else None
 
-    def step(serial=False, cur=cur):
+    exch_events = []                 # (start, end) HIP events around the exchange of a step, on the LM stream
+
+    def step(serial=False, cur=cur, lm=lm, lm_ctx=None):
         cur.run_frontend(fp)
         if side:
             side.wait_stream(main_stream)
@@ -323,17 +326,21 @@ def main():
             cur.bow_query(db, 4)                                             # descriptors, L1 query of the keyframe database, 4 results
         if serial:
             torch.cuda.synchronize()      # profile pass: one kernel at a time, clean per-kernel durations
-        lm.reset()
-        lm.run(lp)
+        lm.reset(ctx=lm_ctx)
+        lm.run(lp, ctx=lm_ctx)
         if exchange:
             # the one exchange step of the path (BASELINE configs[4]): every submap's g / H blocks of the shared landmarks at its solved
             # state to every GPU, summed in rank order (deterministic), Gauss-Newton step of the shared landmarks, written back: one round of
             # the block-coordinate descent on the joint problem; enqueued behind the solve on its stream (RCCL orders the all-gather against
             # the stream handed over)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(lm_ext_stream)
             lm.pack_shared(0, d_shared_idx, lp, shared)
             pkg.dist.exchange_shared(shared, gathered, stream=ctx_lm.stream())
             ctx_lm.stitch_shared(gathered, world, S, shared_pos)
             lm.set_shared(0, d_shared_idx, shared_pos)
+            ev[1].record(lm_ext_stream)
+            exch_events.append(ev)
         if serial:
             torch.cuda.synchronize()
 
@@ -346,11 +353,19 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    exch_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     dt = time.perf_counter() - t0
+    # the exchange of the timed steps on this rank (pack + RCCL all-gather + stitch + write-back, HIP events on the LM stream): every rank's mean
+    # goes into the line, so that the first multi-GPU run is diagnosable
+    exchange_ms = float(np.mean([a.elapsed_time(b) for a, b in exch_events])) if exch_events else None
+    exchange_ms_all = [exchange_ms]
+    if world > 1:
+        exchange_ms_all = [None] * world
+        dist.all_gather_object(exchange_ms_all, exchange_ms)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -480,6 +495,42 @@ def main():
 
     unbatched = unbatched_pass(args.unbatched_frames) if world == 1 and rank == 0 and args.unbatched_frames > 0 else None
 
+    # ---- the symbolic build inside the loop (reported beside `value`): in the reference the LM window is built from the keyframe's own data and
+    # define_new_keyframe does its symbolic update before it optimises (EST.cpp:666-704, 782-784); `value` re-solves windows whose tables were
+    # built once.  Here every step solves a batch whose ssk_lm_batch_create (symbolic build on the host's threads + allocation + upload, through
+    # a context of its own) ran beside the previous step: two batches alive, a creator thread, the same step otherwise.
+    def symbolic_pass(n):
+        import threading
+        ctx_c = pkg.Context(local)
+        made = {}
+        mar = capi.LmBatch.marshal(lm_batch_wins)       # (the C view of the windows, once: the creator thread then spends its time inside the library)
+        def create(k):
+            made[k] = capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar)
+        create(0); create(1)                              # (slab allocations, code objects)
+        made.pop(1).close()
+        sym_ms, sym_thr = made[0].symbolic_ms()
+        torch.cuda.synchronize()
+        t_create = []
+        t0s = time.perf_counter()
+        for k in range(n):
+            th = threading.Thread(target=create, args=(k + 1,))
+            th.start()
+            step(lm=made[k], lm_ctx=ctx_lm)
+            torch.cuda.synchronize()
+            th.join()
+            t_create.append(made[k + 1].create_ms)
+            made.pop(k).close()
+        dts = time.perf_counter() - t0s
+        made.pop(n).close()
+        ctx_c.close()
+        return {"value_incl_symbolic": B * n / dts, "ms_per_step": 1e3 * dts / n, "steps": n,
+                "lm_symbolic_ms_per_window": sym_ms / B, "lm_symbolic_ms_per_batch": sym_ms, "host_threads": sym_thr,
+                "lm_batch_create_ms": float(np.mean(t_create)),
+                "note": "every step solves an LM batch created (ssk_lm_batch_create: symbolic build on `host_threads` threads, allocation, upload) beside "
+                        "the previous step by a second host thread; lm_symbolic_ms_per_window: host time of the symbolic part / windows of the batch"}
+
+    symbolic = symbolic_pass(max(3, min(args.steps, 8))) if world == 1 and rank == 0 and not exchange else None
+
     # ---- the reference's real per-keyframe LM load (reported beside `value`): define_new_keyframe does TWO solves per keyframe
     # (EST.cpp:782-784): stage 1 = optimize_edges on the new edge with the landmarks held, stage 2 = optimize_local_area with
     # srba_max_optimize_depth = 5 (KITTI.ini:105): ~40 edges.  The headline's window is BASELINE configs[2]'s "window = 10".
@@ -522,9 +573,9 @@ def main():
                           "stage1_kernel": k1, "stage2_kernel": k2}
         # the stage-2 launch priced in FP64 flops (SURVEY 8(d) per-unit figures, as roofline_fp64): the kernel that carries the reference's real load
         fl = float(np.mean([lm_algorithmic_flops(w) for w in wins5])) * it2 * n
-        out["roofline_depth5"] = {"kernel": k2, "bound": "mfma", "achieved": fl / (ms2 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        out["roofline_depth5"] = {"kernel": k2, "bound": "fp64", "achieved": fl / (ms2 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": fl / (ms2 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl, "avg_launch_ms": ms2,
-                                  "note": "host clock around ssk_lm_batch_run + results of %d windows (one workgroup per window); kernel-trace and PMC summaries: profiles/r03_lm_depth5*" % n}
+                                  "note": "host clock around ssk_lm_batch_run + results of %d windows (phase-split kernels: linearise / reduce / solve / score / decide per LM pass, ssk_lm_split.h); no MFMA is issued (FP64 matrix rate = vector rate on MI355X); kernel-trace and PMC summaries: profiles/r04_lm_depth5*" % n}
         l1, _, kk1 = timed_named([st1[0]], 10)
         l2, _, kk2 = timed_named([wins5[0]], 10)
         out["one_keyframe"] = {"stage1_ms": l1, "stage2_ms": l2, "stage1_kernel": kk1, "stage2_kernel": kk2,
@@ -548,7 +599,7 @@ def main():
         # (MI355X_MICROARCH.md "HBM"; re-calibrated in the same run on lm_reset_kernel, which reads exactly what it writes)
         LM_KERNEL = lm.kernel_name()
         traffic, traffic_src, pmc_ms = {}, None, {}
-        for tf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # the newest summary collected at this batch size
+        for tf in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # the newest summary collected at this batch size
             tfp = os.path.join(ROOT, "profiles", tf)
             if traffic or not os.path.exists(tfp):
                 continue
@@ -626,6 +677,7 @@ def main():
                 "mean_stereo_matches": float(nm.mean()),
                 "mean_tracked_vs_prev": float(tracked.mean()),
                 "exchange_rounds_to_1e-6": exchange_rounds,
+                "rccl_world": world if exchange else None,
                 "lm_distinct_windows": len(wins),
                 "lm_window": {"edges": int(wins[0].E), "landmarks": int(wins[0].L), "observations": int(len(wins[0].obs_lm)),
                               "mean_iters": float(np.mean([r.iters for r in res]))},
@@ -635,7 +687,7 @@ def main():
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
                          "note": "dominant kernel by time; not bandwidth bound: two persistent workgroups per CU, waves wait on LDS / FP64 dependencies "
                                  "(profiles/r03_pmc_lm_wave_time.json, DESIGN.md 5); traffic is null when the committed PMC summary's kernel time differs from the live one by more than 5 %"},
-            "roofline_fp64": {"kernel": LM_KERNEL, "bound": "mfma", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline_fp64": {"kernel": LM_KERNEL, "bound": "fp64", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
                               "executed_flops_per_launch_pmc": pmc_flop,
                               "executed_frac_pmc": (pmc_flop / (lm_avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc_flop else None,
@@ -649,6 +701,10 @@ def main():
                                   "algorithmic_bytes_per_launch": desc_algo, "avg_launch_ms": desc_avg_ms,
                                   "note": "VALU-issue bound (one wavefront per keypoint, ~700 vector instructions each); patches of neighbouring keypoints overlap in L2"},
             "stage_ms_per_launch": stages,
+            "value_incl_symbolic": symbolic["value_incl_symbolic"] if symbolic else None,
+            "lm_symbolic_ms_per_window": symbolic["lm_symbolic_ms_per_window"] if symbolic else None,
+            "lm_symbolic": symbolic,
+            "exchange_ms_per_rank": exchange_ms_all if exchange else None,
             "pcie_inclusive": pcie,
             "unbatched": unbatched,
             "lm_depth5": lm_depth5,

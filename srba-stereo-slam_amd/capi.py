@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import sys
+import time
 import weakref
 
 import numpy as np
@@ -596,21 +597,30 @@ class LmBatch:
     """ssk_lm_batch wrapper.  `windows`: objects with the ssk_lm_window arrays as numpy attributes
     (edge_unknown_slot, edge_inv_pose, lm_unknown_slot, lm_pos, obs_lm, obs_px, obs_path_off, path_edge)."""
 
-    def __init__(self, ctx, windows, trace=False):
-        self.ctx, self.windows = ctx, list(windows)
-        n = len(self.windows)
-        arr = (LmWindow * n)()
-        self._keep = []
-        for i, w in enumerate(self.windows):
+    @staticmethod
+    def marshal(windows):
+        """(ssk_lm_window array, the numpy arrays it points into): the C view of a list of windows, reusable for several batches"""
+        windows = list(windows)
+        arr = (LmWindow * len(windows))()
+        keep = []
+        for i, w in enumerate(windows):
             a = [np.ascontiguousarray(w.edge_unknown_slot, np.int32), np.ascontiguousarray(w.edge_inv_pose, np.float64),
                  np.ascontiguousarray(w.lm_unknown_slot, np.int32), np.ascontiguousarray(w.lm_pos, np.float64),
                  np.ascontiguousarray(w.obs_lm, np.int32), np.ascontiguousarray(w.obs_px, np.float32),
                  np.ascontiguousarray(w.obs_path_off, np.int32), np.ascontiguousarray(w.path_edge, np.int32)]
-            self._keep.append(a)
+            keep.append(a)
             p = lambda x: x.ctypes.data if x.size else 0
             arr[i] = LmWindow(len(a[0]), p(a[0]), p(a[1]), len(a[2]), p(a[2]), p(a[3]), len(a[4]), p(a[4]), p(a[5]), p(a[6]), p(a[7]))
+        return arr, keep
+
+    def __init__(self, ctx, windows, trace=False, marshalled=None):
+        self.ctx, self.windows = ctx, list(windows)
+        n = len(self.windows)
+        arr, self._keep = marshalled if marshalled is not None else LmBatch.marshal(self.windows)
         h = C.c_void_p()
+        t0 = time.perf_counter()
         ctx._chk(ctx.lib.ssk_lm_batch_create(ctx.h, arr, n, int(bool(trace)), C.byref(h)))
+        self.create_ms = 1e3 * (time.perf_counter() - t0)      # the C call alone: symbolic build + allocation + upload (no Python marshalling)
         self.h_, self.n = h, n
         _LIVE.add(self)
 
@@ -627,11 +637,14 @@ class LmBatch:
         except Exception:
             pass
 
-    def reset(self):
-        self.ctx._chk(self.ctx.lib.ssk_lm_batch_reset(self.ctx.h, self.h_))
+    def reset(self, ctx=None):
+        """`ctx`: the context (stream) to enqueue on; default: the one the batch was created with"""
+        c = ctx or self.ctx
+        c._chk(c.lib.ssk_lm_batch_reset(c.h, self.h_))
 
-    def run(self, prm):
-        self.ctx._chk(self.ctx.lib.ssk_lm_batch_run(self.ctx.h, self.h_, C.byref(prm)))
+    def run(self, prm, ctx=None):
+        c = ctx or self.ctx
+        c._chk(c.lib.ssk_lm_batch_run(c.h, self.h_, C.byref(prm)))
 
     def kernel_name(self):
         buf = C.create_string_buffer(64)

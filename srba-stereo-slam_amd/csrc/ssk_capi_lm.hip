@@ -60,8 +60,8 @@ namespace {
 // upload()/scratch() only RECORD what the batch needs; finalize() makes one slab (reusing the context's cached one when it
 // is large enough), lays the arrays out at 256-byte offsets, moves every host image with a single staged DMA (small
 // batches: the per-keyframe host path) or one copy per array (large batches) and zeroes the scratch part with one memset.
-template <typename T>
-int upload(ssk_lm_batch* b, const std::vector<T>& v, const T** out)
+template <typename T, typename A>
+int upload(ssk_lm_batch* b, const std::vector<T, A>& v, const T** out)
 {
 	b->reqs.push_back({sizeof(T) * (v.size() + 4), sizeof(T) * v.size(), v.empty() ? nullptr : (const void*)v.data(), (void**)out});
 	return SSK_OK;
@@ -382,6 +382,8 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 // argument checks of one window; E / L = optimised edges / landmarks, s_edge / s_lm = the slot -> index maps, n_path = path entries
 static int lm_validate_window(ssk_ctx* ctx, const ssk_lm_window& Wn, int w, int& E, int& L, std::vector<int>& s_edge, std::vector<int>& s_lm, int& n_path)
 {
+	// (ctx == nullptr: no message, just the code -- the builder's threads check their windows side by side)
+#define ssk_set_error(c, code, ...) ((c) ? ssk_set_error((c), (code), __VA_ARGS__) : (code))
 	if (Wn.n_edges_total < 0 || Wn.n_lms_total < 0 || Wn.n_obs < 0 ||
 	    (Wn.n_edges_total > 0 && (!Wn.edge_unknown_slot || !Wn.edge_inv_pose)) ||
 	    (Wn.n_lms_total > 0 && (!Wn.lm_unknown_slot || !Wn.lm_pos)) ||
@@ -412,7 +414,7 @@ static int lm_validate_window(ssk_ctx* ctx, const ssk_lm_window& Wn, int w, int&
 	for (int p = 0; p < n_path; ++p)
 		if (!Wn.path_edge || Wn.path_edge[p] < 0 || (Wn.path_edge[p] >> 1) >= Wn.n_edges_total)
 			return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: window %d path entry %d out of range", w, p);
-
+#undef ssk_set_error
 	return SSK_OK;
 }
 
@@ -427,79 +429,104 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	static const bool timing = std::getenv("SSK_TIMING") != nullptr;
 	const auto t_begin = std::chrono::steady_clock::now();
 	const size_t node_lds_limit = (size_t)SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC;
-	std::vector<int> edge_slot, lm_slot, obs_lm, obs_path_off, path_edge, slot_edge, slot_lm;
-	std::vector<double> pose, lm;
-	std::vector<float> obs_px;
+	// Three phases: (1) every window validated and its node tables built, side by side (a thread per window in turn); (2) prefix sums of all sizes;
+	// (3) the batch-wide host images and tables filled, side by side again.  Nothing heavy is serial.
+	struct lean_win { int E = 0, L = 0, n_path = 0; std::vector<int> s_edge, s_lm; nd_host nh; nd_sizes off; char split = 0, bad = 0; };
+	std::vector<lean_win> lw((size_t)n_windows);
+	static const int n_thr_max = [] { const char* e = std::getenv("SSK_LM_BUILD_THREADS"); const int hc = (int)std::thread::hardware_concurrency(); return e ? std::max(1, std::atoi(e)) : std::max(1, std::min(hc / 2, 32)); }();
+	const int n_thr_used = std::max(1, std::min(n_thr_max, n_windows / 8));      // (a thread is worth it from a handful of windows on)
+	auto parallel = [&](auto&& fn) {
+		if (n_thr_used > 1) {
+			std::vector<std::thread> pool;
+			std::atomic<int> next{0};
+			for (int t = 0; t < n_thr_used; ++t) pool.emplace_back([&] { for (int w = next++; w < n_windows; w = next++) fn(w); });
+			for (std::thread& th : pool) th.join();
+		} else
+			for (int w = 0; w < n_windows; ++w) fn(w);
+	};
+	// ---- (1) per window: checks; its kernel family -- the persistent node kernel when the reduced system and a tile of records fit LDS, the
+	// phase-split kernels otherwise (or for every window: SSK_LM_KERNEL=split): no all-or-nothing choice for a mixed batch --; its node tables ----
+	parallel([&](int w) {
+		const ssk_lm_window& Wn = windows[w];
+		lean_win& X = lw[(size_t)w];
+		if (lm_validate_window(nullptr, Wn, w, X.E, X.L, X.s_edge, X.s_lm, X.n_path)) { X.bad = 2; return; }
+		bool sp = want_split || 8 * nd_lds_doubles(Wn.n_edges_total, X.E, 4, 0) > node_lds_limit;
+		if (!sp) {
+			if (!nd_build_window(Wn, SSK_SP_WAVES, X.nh, nd_win{}, node_lds_limit / 8, false)) { X.bad = 1; return; }
+			if (8 * X.nh.lds_doubles > node_lds_limit) { sp = true; X.nh = nd_host(); }
+		}
+		if (sp && !nd_build_window(Wn, SSK_SP_WAVES, X.nh, nd_win{}, node_lds_limit / 8, true)) { X.bad = 1; return; }
+		X.split = sp;
+	});
+	for (int w = 0; w < n_windows; ++w) {
+		if (lw[(size_t)w].bad == 2) { int E, L, np; std::vector<int> a, c; return lm_validate_window(ctx, windows[w], w, E, L, a, c, np); }      // (again, for the message)
+		if (lw[(size_t)w].bad) return 1;
+	}
+	// ---- (2) bases ----
 	std::vector<lm_win> hdr((size_t)n_windows);
 	long long h_total = 0, dpt = 0, dft = 0;
-	int max_n6 = 0;
+	int max_n6 = 0, n_node = 0, n_split = 0;
+	size_t n_edge_t = 0, n_lm_t = 0, n_obs_t = 0, n_opo_t = 0, n_path_t = 0, n_us_t = 0, n_ls_t = 0;
+	nd_sizes zn, zs;
 	for (int w = 0; w < n_windows; ++w) {
 		const ssk_lm_window& Wn = windows[w];
+		lean_win& X = lw[(size_t)w];
 		lm_win& H = hdr[w];
-		int E = 0, L = 0, n_path = 0;
-		std::vector<int> s_edge, s_lm;
-		{ const int rcv = lm_validate_window(ctx, Wn, w, E, L, s_edge, s_lm, n_path); if (rcv) return rcv; }
 		std::memset(&H, 0, sizeof H);
-		H.n_edges = Wn.n_edges_total; H.E = E; H.n_lms = Wn.n_lms_total; H.L = L; H.n_obs = Wn.n_obs; H.n_path = n_path;
+		const int E = X.E, L = X.L;
+		H.n_edges = Wn.n_edges_total; H.E = E; H.n_lms = Wn.n_lms_total; H.L = L; H.n_obs = Wn.n_obs; H.n_path = X.n_path;
 		H.n_pairs = E * (E + 1) / 2; H.n_tiles = -1;
-		H.edge0 = (int)edge_slot.size(); H.lm0 = (int)lm_slot.size(); H.obs0 = (int)obs_lm.size();
-		H.opo0 = (int)obs_path_off.size(); H.path0 = (int)path_edge.size();
-		H.us0 = (int)slot_edge.size(); H.ls0 = (int)slot_lm.size();
+		H.edge0 = (int)n_edge_t; H.lm0 = (int)n_lm_t; H.obs0 = (int)n_obs_t; H.opo0 = (int)n_opo_t; H.path0 = (int)n_path_t;
+		H.us0 = (int)n_us_t; H.ls0 = (int)n_ls_t;
 		H.trace0 = w * MAX_ITERS_ALLOC; H.h0 = h_total; H.dp_trace0 = dpt; H.df_trace0 = dft;
 		h_total += (long long)(6 * E + 1) * (6 * E + 2);
 		if (trace) { dpt += (long long)MAX_ITERS_ALLOC * 6 * E; dft += (long long)MAX_ITERS_ALLOC * 3 * L; }
 		max_n6 = std::max(max_n6, 6 * E);
-		edge_slot.insert(edge_slot.end(), Wn.edge_unknown_slot, Wn.edge_unknown_slot + Wn.n_edges_total);
-		pose.insert(pose.end(), Wn.edge_inv_pose, Wn.edge_inv_pose + 12 * (size_t)Wn.n_edges_total);
-		lm_slot.insert(lm_slot.end(), Wn.lm_unknown_slot, Wn.lm_unknown_slot + Wn.n_lms_total);
-		lm.insert(lm.end(), Wn.lm_pos, Wn.lm_pos + 3 * (size_t)Wn.n_lms_total);
-		obs_lm.insert(obs_lm.end(), Wn.obs_lm, Wn.obs_lm + Wn.n_obs);
-		obs_px.insert(obs_px.end(), Wn.obs_px, Wn.obs_px + 4 * (size_t)Wn.n_obs);
-		if (Wn.n_obs) obs_path_off.insert(obs_path_off.end(), Wn.obs_path_off, Wn.obs_path_off + Wn.n_obs + 1);
-		else obs_path_off.push_back(0);
-		if (n_path) path_edge.insert(path_edge.end(), Wn.path_edge, Wn.path_edge + n_path);
-		slot_edge.insert(slot_edge.end(), s_edge.begin(), s_edge.end());
-		slot_lm.insert(slot_lm.end(), s_lm.begin(), s_lm.end());
+		n_edge_t += (size_t)Wn.n_edges_total; n_lm_t += (size_t)Wn.n_lms_total; n_obs_t += (size_t)Wn.n_obs; n_opo_t += (size_t)Wn.n_obs + 1;
+		n_path_t += (size_t)X.n_path; n_us_t += (size_t)E; n_ls_t += (size_t)L;
+		nd_sizes& z = X.split ? zs : zn;
+		X.off = z;
+		nd_sizes_add(z, nd_sizes_of(X.nh));
+		if (X.split) ++n_split; else ++n_node;
 	}
-	// ---- the node tables, per window in the form of ITS kernel family: the persistent node kernel when the reduced system and a tile of records fit
-	// LDS, the phase-split kernels otherwise (or for every window: SSK_LM_KERNEL=split) -- no all-or-nothing choice for a mixed batch.  Windows are
-	// built side by side (a thread each), then appended in window order. ----
-	std::vector<nd_host> one((size_t)n_windows);
-	std::vector<char> w_split((size_t)n_windows, 0), w_bad((size_t)n_windows, 0);
-	int n_thr_used = 1;
-	{
-		auto build = [&](int w) {
-			const lm_win& Hw = hdr[w];
-			nd_win nw{};
-			nw.edge0 = Hw.edge0; nw.lm0 = Hw.lm0; nw.us0 = Hw.us0; nw.ls0 = Hw.ls0; nw.trace0 = Hw.trace0; nw.dp_trace0 = Hw.dp_trace0; nw.df_trace0 = Hw.df_trace0;
-			nw.h0 = Hw.h0;
-			bool sp = want_split || 8 * nd_lds_doubles(Hw.n_edges, Hw.E, 4, 0) > node_lds_limit;
-			if (!sp) {
-				if (!nd_build_window(windows[w], SSK_SP_WAVES, one[(size_t)w], nw, node_lds_limit / 8, false)) { w_bad[(size_t)w] = 1; return; }
-				if (8 * one[(size_t)w].lds_doubles > node_lds_limit) { sp = true; one[(size_t)w] = nd_host(); }
-			}
-			if (sp && !nd_build_window(windows[w], SSK_SP_WAVES, one[(size_t)w], nw, node_lds_limit / 8, true)) { w_bad[(size_t)w] = 1; return; }
-			w_split[(size_t)w] = sp;
-		};
-		static const int n_thr_max = [] { const char* e = std::getenv("SSK_LM_BUILD_THREADS"); const int hc = (int)std::thread::hardware_concurrency(); return e ? std::max(1, std::atoi(e)) : std::max(1, std::min(hc, 16)); }();
-		const int n_thr = std::min(n_thr_max, n_windows / 8);      // (a thread is worth it from a handful of windows on)
-		n_thr_used = std::max(n_thr, 1);
-		if (n_thr > 1) {
-			std::vector<std::thread> pool;
-			std::atomic<int> next{0};
-			for (int t = 0; t < n_thr; ++t) pool.emplace_back([&] { for (int w = next++; w < n_windows; w = next++) build(w); });
-			for (std::thread& th : pool) th.join();
-		} else
-			for (int w = 0; w < n_windows; ++w) build(w);
-	}
-	int n_node = 0, n_split = 0;
-	for (int w = 0; w < n_windows; ++w) { if (w_bad[(size_t)w]) return 1; if (w_split[(size_t)w]) ++n_split; else ++n_node; }
+	if (n_edge_t > 0x7FFFFFFF || n_obs_t > 0x7FFFFFFF || n_path_t > 0x7FFFFFFF || zn.item > 0x7FFFFFFF || zs.item > 0x7FFFFFFF)
+		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: the batch's tables exceed 2^31 entries");
+	nd_vec<int> edge_slot(n_edge_t), lm_slot(n_lm_t), obs_lm(n_obs_t), obs_path_off(n_opo_t), path_edge(n_path_t), slot_edge(n_us_t), slot_lm(n_ls_t);
+	nd_vec<double> pose(12 * n_edge_t), lm(3 * n_lm_t);
+	nd_vec<float> obs_px(4 * n_obs_t);
 	nd_host NHn, NHs;                                      // the two families' tables; win[] (and swin[]) of both are indexed by the batch's window number
+	if (n_node) nd_resize(NHn, zn, (size_t)n_windows, false);
+	if (n_split) nd_resize(NHs, zs, (size_t)n_windows, true);
+	std::vector<char> w_split((size_t)n_windows, 0);
+	// ---- (3) placement ----
+	parallel([&](int w) {
+		const ssk_lm_window& Wn = windows[w];
+		lean_win& X = lw[(size_t)w];
+		const lm_win& H = hdr[w];
+		auto put = [](auto* dst, const auto* src, size_t n) { if (n) std::memcpy(dst, src, sizeof(*src) * n); };
+		put(&edge_slot[0] + H.edge0, Wn.edge_unknown_slot, (size_t)Wn.n_edges_total);
+		put(&pose[0] + 12 * (size_t)H.edge0, Wn.edge_inv_pose, 12 * (size_t)Wn.n_edges_total);
+		put(&lm_slot[0] + H.lm0, Wn.lm_unknown_slot, (size_t)Wn.n_lms_total);
+		put(&lm[0] + 3 * (size_t)H.lm0, Wn.lm_pos, 3 * (size_t)Wn.n_lms_total);
+		put(&obs_lm[0] + H.obs0, Wn.obs_lm, (size_t)Wn.n_obs);
+		put(&obs_px[0] + 4 * (size_t)H.obs0, Wn.obs_px, 4 * (size_t)Wn.n_obs);
+		if (Wn.n_obs) put(&obs_path_off[0] + H.opo0, Wn.obs_path_off, (size_t)Wn.n_obs + 1); else obs_path_off[(size_t)H.opo0] = 0;
+		put(&path_edge[0] + H.path0, Wn.path_edge, (size_t)X.n_path);
+		put(&slot_edge[0] + H.us0, X.s_edge.data(), X.s_edge.size());
+		put(&slot_lm[0] + H.ls0, X.s_lm.data(), X.s_lm.size());
+		nd_win& nw = X.nh.win[0];
+		nw.edge0 = H.edge0; nw.lm0 = H.lm0; nw.us0 = H.us0; nw.ls0 = H.ls0; nw.trace0 = H.trace0; nw.dp_trace0 = H.dp_trace0; nw.df_trace0 = H.df_trace0;
+		nw.h0 = H.h0;
+		nd_place(X.split ? NHs : NHn, (size_t)w, X.off, X.nh);
+		w_split[(size_t)w] = X.split;
+	});
 	for (int w = 0; w < n_windows; ++w) {
-		if (w_split[(size_t)w]) { nd_append(NHs, one[(size_t)w]); if (n_node) nd_append_placeholder(NHn, false); }
-		else { nd_append(NHn, one[(size_t)w]); if (n_split) nd_append_placeholder(NHs, true); }
-		one[(size_t)w] = nd_host();
+		nd_host& Dh = lw[(size_t)w].split ? NHs : NHn;
+		const nd_host& W1 = lw[(size_t)w].nh;
+		Dh.lds_doubles = std::max(Dh.lds_doubles, W1.lds_doubles); Dh.lds_doubles_big = std::max(Dh.lds_doubles_big, W1.lds_doubles_big);
+		Dh.max_items_per_lane = std::max(Dh.max_items_per_lane, W1.max_items_per_lane); Dh.max_tile_blocks = std::max(Dh.max_tile_blocks, W1.max_tile_blocks);
 	}
+	lw.clear();
 	const auto t_sym = std::chrono::steady_clock::now();
 	ssk_lm_batch* b = new ssk_lm_batch();
 	b->ctx = ctx; b->n_windows = n_windows; b->trace = trace; b->max_iters_alloc = MAX_ITERS_ALLOC; b->max_n6 = max_n6;

@@ -6,18 +6,32 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <utility>
 #include <vector>
 #include "../../include/ssk_capi.h"
 #include "ssk_lm_node.h"
 
+// vectors whose resize() leaves new elements uninitialised: the batch-wide tables are sized by prefix sums and then filled by the builder's
+// threads -- a value-initialising resize wrote 100 MB of zeros on one thread first
+template <typename T>
+struct nd_noinit : std::allocator<T> {
+	template <typename U> struct rebind { using other = nd_noinit<U>; };
+	nd_noinit() = default;
+	template <typename U> nd_noinit(const nd_noinit<U>&) {}
+	template <typename U> void construct(U* p) { ::new ((void*)p) U; }
+	template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <typename T> using nd_vec = std::vector<T, nd_noinit<T>>;
+
 struct nd_host {
 	std::vector<nd_win> win;
-	std::vector<nd_tile> tile;
-	std::vector<nd_group> group;
-	std::vector<nd_i2> suf, obs, qs, gqs;
-	std::vector<nd_f4> px;
-	std::vector<nd_i4> lane;
-	std::vector<int> item, gitem;
+	nd_vec<nd_tile> tile;
+	nd_vec<nd_group> group;
+	nd_vec<nd_i2> suf, obs, qs, gqs;
+	nd_vec<nd_f4> px;
+	nd_vec<nd_i4> lane;
+	nd_vec<int> item, gitem;
 	long long tab_doubles = 0;          // suffix tables of all windows
 	size_t lds_doubles = 0;             // largest dynamic LDS need of a window (doubles)
 	size_t lds_doubles_big = 0;         // ... in the BIG form (accumulators and system in HBM / L2)
@@ -25,8 +39,8 @@ struct nd_host {
 	int max_items_per_lane = 0;         // (diagnostic: the longest item run of a quad lane)
 	// ---- phase-split form (ssk_lm_split.hip): one nd_split per window beside its nd_win ----
 	std::vector<nd_split> swin;
-	std::vector<nd_i4> sqs;             // (tile, block) slots: x block pair id, y items, z first item (window relative), w partial slot (window relative)
-	std::vector<int> poff, goff, gslot; // poff: per window n_pairs + 1 (partial slots of a block, block-major); goff: E + 1; gslot: per gqs entry its gradient partial slot
+	nd_vec<nd_i4> sqs;                  // (tile, block) slots: x block pair id, y items, z first item (window relative), w partial slot (window relative)
+	nd_vec<int> poff, goff, gslot;      // poff: per window n_pairs + 1 (partial slots of a block, block-major); goff: E + 1; gslot: per gqs entry its gradient partial slot
 	long long part_slots = 0, gpart_slots = 0;   // 36-double / 6-double partial slots of all windows
 	int max_tile_blocks = 0;
 };
@@ -508,4 +522,48 @@ inline void nd_append_placeholder(nd_host& D, bool split)
 {
 	D.win.push_back(nd_win{});
 	if (split) D.swin.push_back(nd_split{});
+}
+
+// Sizes of a one-window nd_host, and its placement into pre-sized batch tables at given offsets (the parallel form of nd_append: every window of
+// a batch can be placed by its own thread once the offsets -- prefix sums of the sizes -- are known).
+struct nd_sizes { size_t suf = 0, tile = 0, group = 0, obs = 0, lane = 0, item = 0, qs = 0, gitem = 0, gqs = 0, sqs = 0, poff = 0, goff = 0, gslot = 0; long long tab = 0, hb = 0, part = 0, gpart = 0; };
+inline nd_sizes nd_sizes_of(const nd_host& W1)
+{
+	nd_sizes z;
+	z.suf = W1.suf.size(); z.tile = W1.tile.size(); z.group = W1.group.size(); z.obs = W1.obs.size(); z.lane = W1.lane.size(); z.item = W1.item.size();
+	z.qs = W1.qs.size(); z.gitem = W1.gitem.size(); z.gqs = W1.gqs.size(); z.sqs = W1.sqs.size(); z.poff = W1.poff.size(); z.goff = W1.goff.size();
+	z.gslot = W1.gslot.size(); z.tab = W1.tab_doubles; z.hb = W1.hb_doubles; z.part = W1.part_slots; z.gpart = W1.gpart_slots;
+	return z;
+}
+inline void nd_sizes_add(nd_sizes& a, const nd_sizes& b)
+{
+	a.suf += b.suf; a.tile += b.tile; a.group += b.group; a.obs += b.obs; a.lane += b.lane; a.item += b.item; a.qs += b.qs; a.gitem += b.gitem; a.gqs += b.gqs;
+	a.sqs += b.sqs; a.poff += b.poff; a.goff += b.goff; a.gslot += b.gslot; a.tab += b.tab; a.hb += b.hb; a.part += b.part; a.gpart += b.gpart;
+}
+inline void nd_resize(nd_host& D, const nd_sizes& z, size_t n_windows, bool split)
+{
+	D.win.assign(n_windows, nd_win{});
+	if (split) D.swin.assign(n_windows, nd_split{});
+	D.suf.resize(z.suf); D.tile.resize(z.tile); D.group.resize(z.group); D.obs.resize(z.obs); D.px.resize(z.obs); D.lane.resize(z.lane); D.item.resize(z.item);
+	D.qs.resize(z.qs); D.gitem.resize(z.gitem); D.gqs.resize(z.gqs); D.sqs.resize(z.sqs); D.poff.resize(z.poff); D.goff.resize(z.goff); D.gslot.resize(z.gslot);
+	D.tab_doubles = z.tab; D.hb_doubles = z.hb; D.part_slots = z.part; D.gpart_slots = z.gpart;
+}
+// window `wi` of the batch: tables of W1 to the offsets `o` of D (thread safe for distinct windows; D's running maxima are the caller's)
+inline void nd_place(nd_host& D, size_t wi, const nd_sizes& o, const nd_host& W1)
+{
+	nd_win w = W1.win[0];
+	w.suf0 += (int)o.suf; w.tile0 += (int)o.tile; w.grp0 += (int)o.group; w.obs0 += (int)o.obs; w.lane0 += (int)o.lane;
+	w.item0 += (int)o.item; w.qs0 += (int)o.qs; w.gitem0 += (int)o.gitem; w.gqs0 += (int)o.gqs;
+	w.tab0 += o.tab; w.hb0 += o.hb;
+	if (!W1.swin.empty()) {
+		nd_split s = W1.swin[0];
+		s.sqs0 += (int)o.sqs; s.poff0 += (int)o.poff; s.goff0 += (int)o.goff; s.gslot0 += (int)o.gslot;
+		s.part0 += o.part; s.gpart0 += o.gpart; s.gtile0 += (int)o.tile;
+		D.swin[wi] = s;
+	}
+	D.win[wi] = w;
+#define ND_PUT(v, off) if (!W1.v.empty()) std::memcpy(&D.v[off], W1.v.data(), sizeof(W1.v[0]) * W1.v.size())
+	ND_PUT(suf, o.suf); ND_PUT(tile, o.tile); ND_PUT(group, o.group); ND_PUT(obs, o.obs); ND_PUT(px, o.obs); ND_PUT(lane, o.lane); ND_PUT(item, o.item);
+	ND_PUT(qs, o.qs); ND_PUT(gitem, o.gitem); ND_PUT(gqs, o.gqs); ND_PUT(sqs, o.sqs); ND_PUT(poff, o.poff); ND_PUT(goff, o.goff); ND_PUT(gslot, o.gslot);
+#undef ND_PUT
 }
