@@ -643,6 +643,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		if (!rc) rc = scratch(b, NHs.tile.size(), &b->S.epart);
 		if (!rc) rc = scratch(b, NHs.tile.size(), &b->S.fpart);
 		if (!rc) rc = scratch(b, (size_t)n_windows, &b->S.ctl);
+		if (!rc) rc = scratch(b, 4, &b->S.n_active);
 	}
 	D.trace_on = trace ? 1 : 0;
 	if (!rc) rc = finalize(b);

@@ -46,6 +46,7 @@ struct sp_dev {
 	double* Hpart; double* gpart;       // 36 / 6 doubles per partial slot
 	double* vpart; double* epart; double* fpart;      // per tile of the batch: largest landmark-block diagonal (lambda_0 pass), robust error, |delta_f|^2
 	sp_ctl* ctl;
+	int* n_active;                      // windows whose loop still runs (K0 counts them in, K4 counts a stopped one out): the host polls it between groups of passes of a small batch
 	const sp_tile* tile_map;            // K1 / K3: workgroup -> tile (wi -1: none): a window's tiles share an XCD (its L2 holds the window's suffix table)
 	const int* win_map;                 // K2 / K4: workgroup -> window or -1, the same XCD as its tiles
 	int n_tile_wgs, n_win_wgs;

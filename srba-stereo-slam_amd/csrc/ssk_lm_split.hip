@@ -55,6 +55,7 @@ void lm_split_init_kernel(lm_dev D, nd_dev N, sp_dev S)
 		c.lambda = -1.0; c.nu = 2.0; c.err = 0.0; c.dpn = 0.0;
 		c.iters = 0; c.accepted = 0; c.stop = 0; c.cur = 0; c.active = 1; c.ok = 0; c.pre = 1;
 		S.ctl[wi] = c;
+		atomicAdd(S.n_active, 1);
 	}
 	__syncthreads();
 	nd_build_table(W, s_suf, pose, N.tab + W.tab0);
@@ -340,7 +341,7 @@ void lm_split_decide_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int init)
 			if (c.iters >= P.max_iters) c.active = 0;
 			else if (W.n_obs > 0 && sqrt(c.err / W.n_obs) < P.stop_rmse) { c.stop = 1; c.active = 0; }
 		}
-		if (!c.active) { R.iters = c.iters; R.accepted = c.accepted; R.stop_reason = c.stop; R.err_final = c.err; R.lambda_final = c.lambda; }
+		if (!c.active) { R.iters = c.iters; R.accepted = c.accepted; R.stop_reason = c.stop; R.err_final = c.err; R.lambda_final = c.lambda; atomicSub(S.n_active, 1); }
 		S.ctl[wi] = c;
 		s_copy = copy;
 	}
@@ -384,18 +385,32 @@ int ssk_lm_launch_split(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp
 	const size_t lin_lds = sizeof(double) * (size_t)NDW * 64 * REC;
 	const size_t small_lds = (init_dyn_bytes + 15) & ~(size_t)15;      // K0: the window's poses and trie records
 	const dim3 gt((unsigned)S.n_tile_wgs), gw((unsigned)S.n_win_wgs), bt(NT);
+	SSK_HIP(ctx, hipMemsetAsync(S.n_active, 0, sizeof(int), ctx->stream));
 	hipLaunchKernelGGL(lm_split_init_kernel, gw, bt, small_lds, ctx->stream, D, N, S);
 	hipLaunchKernelGGL(lm_split_score_kernel, gt, bt, 0, ctx->stream, D, N, S, P, 1);
 	hipLaunchKernelGGL(lm_split_decide_kernel, gw, bt, 0, ctx->stream, D, N, S, P, 1);
 	SSK_LAUNCH_CHECK(ctx, "lm_split_init/score/decide");
+	// A small batch (the un-batched drop-in: one local area per keyframe) is latency bound: after the passes a solve usually takes the host asks
+	// how many windows still run and stops enqueueing when none does (a window's workgroups leave at once in a pass it does not need, but five
+	// launches per pass are not free).  A large batch is enqueued whole: ssk_lm_batch_run stays asynchronous there.
+	const bool poll = n_windows <= 8 && !std::getenv("SSK_SP_NO_POLL");
+	int* h_poll = nullptr;
+	if (poll) { if (ssk_arena_reserve(ctx, ctx->pin, 256)) return SSK_ERR_HIP; h_poll = reinterpret_cast<int*>(ctx->pin.base); }
+	int next_poll = 10;
 	for (int pass = 0; pass <= P.max_iters; ++pass) {
 		hipLaunchKernelGGL(lm_split_linearise_kernel, gt, bt, lin_lds, ctx->stream, D, N, S, P);
 		if (pass > 0) hipLaunchKernelGGL(lm_split_reduce_kernel, dim3((unsigned)S.n_win_wgs, (unsigned)std::max(1, (S.max_pairs + SP_RB - 1) / SP_RB)), bt, 0, ctx->stream, D, N, S);
 		const int rc = ssk_lm_launch_split_solve(ctx, D, N, S, P, solve_dyn_bytes);
 		if (rc) return rc;
 		if (pass == 0) continue;                           // every window's first pass is its lambda_0 pass: no attempt to score
-		hipLaunchKernelGGL(lm_split_score_kernel, gt, bt, sizeof(double) * 6 * 128, ctx->stream, D, N, S, P, 0);
+		hipLaunchKernelGGL(lm_split_score_kernel, gt, bt, sizeof(double) * 6 * 128, ctx->stream, D, N, S, P, 0);      // (dynamic LDS: the edge step, 6E doubles)
 		hipLaunchKernelGGL(lm_split_decide_kernel, gw, bt, 0, ctx->stream, D, N, S, P, 0);
+		if (poll && pass >= next_poll && pass < P.max_iters) {
+			SSK_HIP(ctx, hipMemcpyAsync(h_poll, S.n_active, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+			SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			if (*h_poll <= 0) break;
+			next_poll = pass + 2;
+		}
 	}
 	SSK_LAUNCH_CHECK(ctx, "lm_split kernels");
 	return SSK_OK;
