@@ -402,7 +402,12 @@ def main():
             nxt = acc.step(x, shared_pos.cpu().numpy())
             shared_pos.copy_(torch.from_numpy(nxt))
             lm.set_shared(0, d_shared_idx, shared_pos)
-            if float(np.abs(nxt - x).max()) < 1e-6:
+            # every rank must take the same decision (the host arithmetic could differ by an ulp between hosts: one rank leaving the loop
+            # while the others enter the next all-gather would hang the collective)
+            stop = torch.tensor([1 if float(np.abs(nxt - x).max()) < 1e-6 else 0], dtype=torch.int32, device=dev)
+            if world > 1:
+                dist.all_reduce(stop, op=dist.ReduceOp.MIN)
+            if int(stop.item()):
                 exchange_rounds = rnd + 1
                 break
         sync_all()

@@ -521,6 +521,12 @@ int ssk_build_observations(ssk_ctx* ctx, const ssk_keypoint* kp_left, const ssk_
                            const ssk_dmatch* matches, int n_matches, const ssk_lm_params* cam,
                            float* obs_px /* n x 4 */, double* init_pos /* n x 3 */);
 
+/* The same for keyframes [kf_begin, kf_end) of a resident batch after ssk_kfbatch_run_frontend, device to device: d_obs_px [n_kf][max_feats][4]
+ * (xl, yl, xr, yr of every L<->R match, match order), d_init_pos [n_kf][max_feats][3]; slots beyond a keyframe's match count are left as they
+ * are.  Either output may be NULL.  Asynchronous on the context stream. */
+int ssk_build_observations_batch(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, const ssk_lm_params* cam,
+                                 float* d_obs_px, double* d_init_pos);
+
 /* Test hook: the 19 float thresholds the context derived from the host libm's atanf for the
  * direction bins 9..27 (see csrc/ssk_context.hip). */
 int ssk_debug_direction_thresholds(ssk_ctx* ctx, float* out19);

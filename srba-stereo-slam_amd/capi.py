@@ -201,6 +201,12 @@ class KfBatch:
         return nkp.reshape(-1, 2), nm
 
     # -- bag of words (ssk_bow.hip) --
+    def build_observations(self, lm_params, d_obs_px=None, d_init_pos=None, kf_begin=0, kf_end=None):
+        """a10 / a11 for the whole batch, device to device: d_obs_px [n_kf, max_feats, 4] f32, d_init_pos [n_kf, max_feats, 3] f64 (torch tensors)."""
+        e = self.n_kf if kf_end is None else kf_end
+        self.ctx._chk(self.ctx.lib.ssk_build_observations_batch(self.ctx.h, self.h_, int(kf_begin), int(e), C.byref(lm_params),
+                                                                None if d_obs_px is None else _dev(d_obs_px), None if d_init_pos is None else _dev(d_init_pos)))
+
     def bow_transform(self, voc, kf_begin=0, kf_end=None, ctx=None):
         """ctx: enqueue on another context's stream (same device) instead of the batch's own."""
         c = ctx or self.ctx

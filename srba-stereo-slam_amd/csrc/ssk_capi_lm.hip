@@ -4,6 +4,7 @@
 #include "ssk_lm.h"
 #include "ssk_lm_node_build.h"
 #include "ssk_lm_split.h"
+#include "ssk_frontend.h"
 #include <memory_resource>
 #include <unordered_map>
 #include <algorithm>
@@ -131,6 +132,25 @@ __global__ void build_obs_kernel(const ssk_keypoint* __restrict__ kl, const ssk_
 	const double Z = __dmul_rn(__dmul_rn(b_d, P.fx_l), P.fx_r);
 	for (int r = 0; r < 3; ++r)
 		init_pos[3 * i + r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P.S[4 * r], X), __dmul_rn(P.S[4 * r + 1], Y)), __dmul_rn(P.S[4 * r + 2], Z)), P.S[4 * r + 3]);
+}
+
+// the same for a resident keyframe batch: a thread per (keyframe, L<->R match slot), the stereo observation (xl, yl, xr, yr) the stereo kernel left
+// per match -> the match's initial landmark position; the expression of build_obs_kernel term by term (bit for bit the same values)
+__global__ void build_obs_batch_kernel(const float4* __restrict__ m_obs, const int32_t* __restrict__ nm, int kf_begin, int n_kf, int N, lm_cam P,
+                                       double* __restrict__ init_pos)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_kf * N) return;
+	const int kf = kf_begin + i / N, k = i - (i / N) * N;
+	if (k >= nm[kf]) return;
+	const float4 o = m_obs[(size_t)kf * N + k];
+	const double ul = (double)o.x, vl = (double)o.y, ur = (double)o.z;
+	const double b_d = P.baseline / __dadd_rn(__dmul_rn(P.fx_l, P.cx_r - ur), __dmul_rn(P.fx_r, ul - P.cx_l));
+	const double X = __dmul_rn(__dmul_rn(b_d, P.fx_r), ul - P.cx_l);
+	const double Y = __dmul_rn(__dmul_rn(b_d, P.fx_r), vl - P.cy_l);
+	const double Z = __dmul_rn(__dmul_rn(b_d, P.fx_l), P.fx_r);
+	for (int r = 0; r < 3; ++r)
+		init_pos[3 * (size_t)i + r] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P.S[4 * r], X), __dmul_rn(P.S[4 * r + 1], Y)), __dmul_rn(P.S[4 * r + 2], Z)), P.S[4 * r + 3]);
 }
 
 // (e) multi-GPU exchange (BASELINE configs[4]).  A shared landmark is based at a keyframe that several submaps reach;
@@ -272,6 +292,7 @@ int ssk_lm_batch_set_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, 
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_set_shared: bad argument");
 	if (n_shared == 0) return SSK_OK;
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a timed-out cooperative launch is repaired first: its restore would overwrite what is written here)
 	hipLaunchKernelGGL(set_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, b->D, const_cast<double*>(b->D.lm0), w, n_shared, d_lm_idx, d_pos);
 	SSK_LAUNCH_CHECK(ctx, "set_shared_kernel");
 	return SSK_OK;
@@ -362,6 +383,23 @@ int ssk_build_observations(ssk_ctx* ctx, const ssk_keypoint* kp_left, const ssk_
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	std::memcpy(obs_px, h_px, 16 * n);
 	std::memcpy(init_pos, h_pos, 24 * n);
+	return SSK_OK;
+}
+
+int ssk_build_observations_batch(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int kf_end, const ssk_lm_params* cam, float* d_obs_px, double* d_init_pos)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || !cam || kf_begin < 0 || kf_end > b->n_kf || kf_begin > kf_end || (!d_obs_px && !d_init_pos))
+		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_build_observations_batch: bad argument");
+	const int n_kf = kf_end - kf_begin, N = b->max_feats;
+	if (n_kf == 0) return SSK_OK;
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	if (d_obs_px)      // (the pixels are the stereo kernel's per-match observation records as they are)
+		SSK_HIP(ctx, hipMemcpyAsync(d_obs_px, b->m_obs + (size_t)kf_begin * N, sizeof(float4) * (size_t)n_kf * N, hipMemcpyDeviceToDevice, ctx->stream));
+	if (d_init_pos) {
+		hipLaunchKernelGGL(build_obs_batch_kernel, dim3((unsigned)(((size_t)n_kf * N + 255) / 256)), dim3(256), 0, ctx->stream, b->m_obs, b->nm, kf_begin, n_kf, N, cam_of(cam), d_init_pos);
+		SSK_LAUNCH_CHECK(ctx, "build_obs_batch_kernel");
+	}
 	return SSK_OK;
 }
 

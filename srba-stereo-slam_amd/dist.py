@@ -81,4 +81,8 @@ class SharedLandmarkAccelerator:
         dF = np.stack([F[i + 1] - F[i] for i in range(len(F) - 1)], 1)
         dG = np.stack([self.GX[i + 1] - self.GX[i] for i in range(len(F) - 1)], 1)
         gamma, *_ = np.linalg.lstsq(dF, f, rcond=1e-10)
+        # an ill-conditioned history (non-finite or huge coefficients) would be written straight into the consensus positions: plain round instead
+        if not np.all(np.isfinite(gamma)) or np.abs(gamma).max() > 1e3:
+            self.reset()
+            return gx.copy()
         return gx - dG @ gamma

@@ -13,12 +13,11 @@ sequence; the checks are properties of the domain:
     reference's narrower notion (a query result BELOW 0.8 x the best score that is topologically far, EST.cpp:1794-1826) and
     is only counted,
   * drift after the global pose graph.  The graph of this trajectory is a CHAIN of 1 135 keyframes: the revisit at the far end ties the
-    last 86 m to themselves, nothing ties the far end to the start, so what is checked is dead reckoning.  Per edge (2.16 m, ~100
-    landmarks at integer keypoint coordinates: a disparity of ~20 px known to +-0.5 px) the along-track error is a few millimetres and
-    the heading error ~2 mrad; summed as a random walk over 1 135 edges: ~0.1-0.3 % of the path along the track (two builds whose
-    descriptors differ in one bit per hundred keypoints measured 0.09 % and 0.25 %: the bound is 0.5 %), and sqrt(1135) x 2 mrad = 0.07 rad
-    of heading (1 sigma), whose integral along the line is ~4 % of the path sideways (the same two builds: 2.8 % and 6.1 %; the bounds are
-    3 sigma: 0.25 rad, 12 %).  That a revisit of the START does pull the ends together is the next test,
+    last 86 m to themselves, nothing ties the far end to the start, so what is checked is dead reckoning: a random walk whose size depends
+    on the frame source's seed.  Round 4 measured the DISTRIBUTION (tools/drift_sweep.py, profiles/r04_drift_sweep.json: five seeds, both
+    ORB steering forms): along track 0.008-0.25 %, 3-D 0.15-6.1 % of the path, seed 9 -- the only seed of rounds 1-3 -- the outlier in both
+    forms (6.1 % / 3.3 %); the medians are 0.011 % and 0.47 %.  The test runs seeds 9, 10, 11 and asserts the MEDIAN against the bounds of
+    rounds 1-2 (0.2 % along track, 3.5 % in 3-D, 0.1 rad of heading) and every single run against the 3 sigma bounds (0.5 %, 12 %, 0.25 rad),
   * the pose-graph optimisation lowers its cost.
 Runs tools/stream_full.py's run(); the same function feeds bench.py's `unbatched` object."""
 import os
@@ -32,33 +31,49 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_FRAMES, N_BACK = 4541, 160
 
 
+def drift_of(o):
+    """(along-track, 3-D, heading) drift after the global pose graph: fractions of the path, largest rotation-matrix deviation"""
+    X = o["poses"].reshape(-1, 3, 4)
+    kf = np.array(o["kf_frames"])
+    truth = np.zeros((len(kf), 3)); truth[:, 1] = -0.54 * np.array(o["kf_pos"])      # robot frame, the camera's right is -y (EST.cpp:1105-1112)
+    path = 0.54 * (N_FRAMES - 1)
+    err = np.linalg.norm(X[:, :, 3] - truth, axis=1)
+    along = np.abs(X[:, 1, 3] - truth[:, 1])
+    return along.max() / path, err.max() / path, float(np.abs(X[:, :, :3] - np.eye(3)).max())
+
+
 def test_config3_full_length_stream(pkg):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import stream_full
-    o = stream_full.run(N_FRAMES, N_BACK, verbose=False)
-    assert o["frames"] == N_FRAMES and o["invalid_odometry"] == [] and o["error_increased"] == []
-    kf = np.array(o["kf_frames"])
-    assert o["keyframes"] == len(kf) == 1 + (N_FRAMES - 1) // 4 and np.all(np.diff(kf) == 4)
-    assert o["edges"] >= o["keyframes"] - 1 + 1 and o["multi_edge_kfs"] >= 1          # loop-closing edges beyond the chain
-    assert o["landmarks"] > 100 * 1000
-    # drift after the global pose graph: robot frame, the camera's right is -y (camera_pose_on_robot, EST.cpp:1105-1112)
-    X = o["poses"].reshape(-1, 3, 4)
-    truth = np.zeros((len(kf), 3)); truth[:, 1] = -0.54 * np.array(o["kf_pos"])
-    err = np.linalg.norm(X[:, :, 3] - truth, axis=1)
-    path = 0.54 * (N_FRAMES - 1)
-    along = np.abs(X[:, 1, 3] - truth[:, 1])
-    assert along.max() < 0.005 * path, (along.max(), path)
-    assert err.max() < 0.12 * path, (err.max(), path)
-    assert np.abs(X[:, :, :3] - np.eye(3)).max() < 0.25                                   # pure translation: the heading only drifts
-    # the keyframes of the way back sit on the places of the way out
-    assert abs(X[-1, 1, 3] + 0.54 * o["kf_pos"][-1]) < 0.005 * path
-    assert o["pg_iters"] >= 1 and o["pg_cost_final"] < o["pg_cost_init"] and o["pg_cost_final"] < 0.1 * o["pg_cost_init"]
-    t = o["timing"]
-    assert t["frames"] == N_FRAMES and t["kf_frames"] == o["keyframes"] - 1 and t["lm_solves"] == 2 * t["kf_frames"]       # stage 1 + stage 2 per keyframe
-    print("configs[3]: %d frames, %d keyframes, %d edges, %.1f frames/s un-batched, %.2f ms per keyframe frame; confirmed_loop_closure flags %d, "
-          "keyframes linked to an old local map %d; max position error %.3f m (along track %.3f m) over %.0f m; pose graph %.4g -> %.4g"
-          % (N_FRAMES, o["keyframes"], o["edges"], o["frames_per_s"], o["ms_per_keyframe_frame"], len(o["loop_closures"]), o["multi_edge_kfs"],
-             err.max(), along.max(), path, o["pg_cost_init"], o["pg_cost_final"]))
+    drifts = []
+    for seed in (9, 10, 11):
+        o = stream_full.run(N_FRAMES, N_BACK, seed=seed, verbose=False)
+        assert o["frames"] == N_FRAMES and o["invalid_odometry"] == [] and o["error_increased"] == [], seed
+        kf = np.array(o["kf_frames"])
+        assert o["keyframes"] == len(kf) == 1 + (N_FRAMES - 1) // 4 and np.all(np.diff(kf) == 4)
+        assert o["landmarks"] > 100 * 1000
+        along, err3, heading = drift_of(o)
+        drifts.append((along, err3, heading))
+        # every run: the 3 sigma bounds of the random walk (module header)
+        assert along < 0.005 and err3 < 0.12 and heading < 0.25, (seed, along, err3, heading)
+        path = 0.54 * (N_FRAMES - 1)
+        X = o["poses"].reshape(-1, 3, 4)
+        # the keyframes of the way back sit on the places of the way out
+        assert abs(X[-1, 1, 3] + 0.54 * o["kf_pos"][-1]) < 0.005 * path
+        if o["multi_edge_kfs"] >= 1:            # (a chain without loop-closing edges is a tree: the pose graph has nothing to move)
+            assert o["pg_iters"] >= 1 and o["pg_cost_final"] < o["pg_cost_init"]
+        t = o["timing"]
+        assert t["frames"] == N_FRAMES and t["kf_frames"] == o["keyframes"] - 1 and t["lm_solves"] == 2 * t["kf_frames"]       # stage 1 + stage 2 per keyframe
+        if seed == 9:
+            assert o["edges"] >= o["keyframes"] - 1 + 1 and o["multi_edge_kfs"] >= 1      # loop-closing edges beyond the chain
+            assert o["pg_cost_final"] < 0.1 * o["pg_cost_init"]
+        print("configs[3] seed %d: %d frames, %d keyframes, %d edges, %.1f frames/s un-batched, %.2f ms per keyframe frame; confirmed_loop_closure flags %d, "
+              "keyframes linked to an old local map %d; drift along track %.3f %%, 3-D %.2f %%, heading %.3f; pose graph %.4g -> %.4g"
+              % (seed, N_FRAMES, o["keyframes"], o["edges"], o["frames_per_s"], o["ms_per_keyframe_frame"], len(o["loop_closures"]), o["multi_edge_kfs"],
+                 100 * along, 100 * err3, heading, o["pg_cost_init"], o["pg_cost_final"]))
+    # the distribution: medians against the bounds of rounds 1-2 (a regression of the LM, the data association or the facade moves every seed)
+    med = np.median(np.array(drifts), axis=0)
+    assert med[0] < 0.002 and med[1] < 0.035 and med[2] < 0.1, med
 
 
 def test_revisit_of_the_start_closes_the_loop(pkg):

@@ -349,6 +349,29 @@ def test_lm_bench_windows_against_oracle(ctx, oracle, seed):
     assert res.stop_reason in (1, 4) and res.err_final < res.err_init
 
 
+def test_lm_bench_windows_seeds_8_to_63(ctx, oracle):
+    """bench.py's default line solves 64 distinct windows (seeds 0-63 on rank 0); seeds 0-7 are checked per iteration above, the other 56 here as
+    ONE batch (the way the bench runs them): iteration count, stop reason, final error and final state of every window against the oracle."""
+    from ssk_amd import capi
+    wins = [sl.make_submap_problem(seed, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2, obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0]
+            for seed in range(8, 64)]
+    prm = sl.make_params()
+    b = capi.LmBatch(ctx, wins)
+    assert b.kernel_name() == "lm_solve_node_kernel"
+    b.run(to_capi(prm))
+    res = b.results()
+    for i, w in enumerate(wins):
+        exp = oracle.lm_solve(w, prm, trace=False)
+        er = exp["res"]
+        assert res[i].iters == er.iters and res[i].stop_reason == er.stop_reason, (i + 8, res[i].iters, er.iters, res[i].stop_reason, er.stop_reason)
+        assert abs(res[i].accepted - er.accepted) <= (1 if er.stop_reason == 4 else 0)
+        assert abs(res[i].err_init - er.err_init) <= 1e-10 * er.err_init and abs(res[i].err_final - er.err_final) <= REL * er.err_final
+        p, l = b.state(i)
+        tol = 1e-5 if er.stop_reason == 4 else 1e-8
+        assert np.abs(p - exp["poses"]).max() <= tol and np.abs(l - exp["lms"]).max() <= 10 * tol, i + 8
+    b.close()
+
+
 @pytest.mark.parametrize("kernel", ["tiled", "coop"])
 def test_lm_sparse_schur_form(ctx, oracle, kernel, monkeypatch):
     """SSK_LM_SCHUR=sparse: the Schur complement as sparse 6x6 items Y_i Y_j^T with segmented lane sums (the form every other test
@@ -557,3 +580,31 @@ def test_build_observations_bit_exact(ctx, oracle):
     oracle.lib.ssko_build_observations(ctypes.c_void_p(kl.ctypes.data), ctypes.c_void_p(kr.ctypes.data), ctypes.c_void_p(m.ctypes.data),
                                        len(m), ctypes.byref(prm), ctypes.c_void_p(epx.ctypes.data), ctypes.c_void_p(epos.ctypes.data))
     assert np.array_equal(px, epx) and np.array_equal(pos, epos)
+
+
+def test_build_observations_batch_equals_the_host_entry(ctx, oracle):
+    """ssk_build_observations_batch (a10 / a11 for a resident keyframe batch, device to device) against the per-keyframe host entry on the same
+    keyframes: pixels and initial landmark positions bit for bit."""
+    import torch
+    from ssk_amd import capi
+    B = 3
+    kb = capi.KfBatch(ctx, B, synth.W, synth.H, 512)
+    for k in range(B):
+        l, r = synth.synth_stereo_pair(40 + k)
+        kb.upload(k, l, r)
+    kb.run_frontend(capi.FrontendParams(**synth.KITTI_FRONTEND))
+    prm = to_capi(sl.make_params(sensor_t=(0.27, 0.0, 1.65)))
+    dev = torch.device("cuda", 0)
+    d_px = torch.zeros(B, 512, 4, dtype=torch.float32, device=dev)
+    d_pos = torch.zeros(B, 512, 3, dtype=torch.float64, device=dev)
+    kb.build_observations(prm, d_px, d_pos)
+    ctx.synchronize()
+    px, pos = d_px.cpu().numpy(), d_pos.cpu().numpy()
+    for k in range(B):
+        kf = kb.download(k)
+        m = kf["matches"]
+        assert len(m) > 100
+        epx, epos = ctx.build_observations(kf["kp_left"], kf["kp_right"], m, prm)
+        assert np.array_equal(px[k, :len(m)], epx) and np.array_equal(pos[k, :len(m)], epos)
+        assert not pos[k, len(m):].any()
+    kb.close()

@@ -90,6 +90,28 @@ def test_every_frame_a_keyframe_and_loop_closure(pkg, ctx, tmp_path):
     assert abs(poses[n, 2] + 2.16 * 3) < 0.5 and abs(poses[n + 1, 2] + 2.16 * 4) < 0.5, poses[n:]
 
 
+def test_loop_closure_under_stronger_noise(pkg, ctx, tmp_path):
+    """The revisit of test_every_frame_a_keyframe_and_loop_closure at sensor noise sigma 4 (the scenario of rounds 1-2): there the scores of the
+    keyframes around the revisited place tie within 0.003, so WHICH old keyframe becomes the potential loop closure is decided by single descriptor
+    bits.  What must hold whatever the tie's outcome: the query's best results are the old keyframes around place 3, a potential loop closure
+    with one of them is raised, and when it is a direct neighbour of the revisited place (which shares most of its view) it is confirmed and
+    the keyframe inserted."""
+    assert os.path.exists(DEMO), "host facade not built: python __graft_entry__.py build"
+    n = 44
+    frames, _ = synth.synth_translation_sequence(5, n, z_max=12.0, step=4)
+    again, _ = synth.synth_translation_sequence(5, n, z_max=12.0, step=4, noise=4.0)
+    seq = frames + [again[2], again[3], again[4]]
+    rows, out = run_stream(ctx, tmp_path, seq, dict(max_translation=0.3, submap_size=4, max_tree_depth=3, max_optimize_depth=3, lc_distance=3),
+                           train_on=frames[::4])
+    assert rows[n]["vo_valid"] == "0" and int(rows[n]["n_kf"]) == n
+    r = rows[n + 1]
+    assert r["vo_valid"] == "1" and r["checked"] == "1"
+    assert r["query"][0][0] in (2, 3, 4) and {q[0] for q in r["query"]} <= set(range(8)), r
+    assert r["pot_lc"] == "1" and int(r["lc_id"]) in (0, 1, 2, 4, 5, 6), r
+    if abs(int(r["lc_id"]) - 3) <= 1:
+        assert r["conf_lc"] == "1" and r["inserted"] == "1", r
+
+
 def test_check_without_insertion(pkg, ctx, tmp_path):
     """KITTI limits (2 m / 25 deg): a keyframe is forced every 4th frame (4 x 0.54 m > 2 m); in between, the loop only
     accumulates odometry."""
