@@ -536,6 +536,76 @@ def main():
 
     symbolic = symbolic_pass(max(3, min(args.steps, 8))) if world == 1 and rank == 0 and not exchange else None
 
+    # ---- end-to-end pass (reported beside `value`): the LM windows of a step built FROM THE STEP'S OWN front-end output, as the reference does per
+    # keyframe (EST.cpp:666-704 -> 782-784): stereo matches -> a10 / a11 (ssk_build_observations_batch: pixels + projectMatchTo3D (+) camera pose)
+    # -> the matches tracked against the previous keyframe -> stage 1 of define_new_keyframe for every keyframe of the batch (the new edge
+    # previous -> current optimised, the tracked landmarks held at the previous keyframe's triangulation) -> ssk_lm_batch_create (symbolic
+    # build) -> solve.  Everything between the images and the solved edges is inside the timed region: downloads, host assembly, create, solve.
+    def e2e_pass(n):
+        import ctypes as C
+        Nf = 512
+        d_px_c = torch.zeros(B, Nf, 4, dtype=torch.float32, device=dev)
+        d_pos_p = torch.zeros(B, Nf, 3, dtype=torch.float64, device=dev)
+        prev.build_observations(lp, None, d_pos_p)             # state, like the previous keyframes' features
+        ctx.synchronize()
+        pos_p = d_pos_p.cpu().numpy()
+        es = np.zeros(1, np.int32); ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64)
+        ar = np.arange(Nf + 1, dtype=np.int32); pe = np.zeros(Nf, np.int32)
+        TRACKED = 0                                            # EST.h:102
+        t_ph = np.zeros(5)
+        stats = []
+        def one(timed):
+            t0 = time.perf_counter()
+            cur.run_frontend(fp)
+            ctx.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
+            ctx.fm_run_batch(cur, prev, pairs, fm, d_idx, d_st, d_tr)
+            ctx.cip_run_batch(cur, prev, pairs, cp, d_idx, d_st, d_tr)
+            cur.bow_transform(voc); cur.bow_query(db, 4)
+            cur.build_observations(lp, d_px_c, None)
+            idx = d_idx.view(B, N).cpu().numpy(); st = d_st.view(B, N).cpu().numpy(); px = d_px_c.cpu().numpy()      # (synchronises)
+            _, nm_c = cur.counts()
+            t1 = time.perf_counter()
+            mask = (st == TRACKED) & (np.arange(N)[None, :] < nm_c[:, None]) & (idx >= 0)
+            cnt = mask.sum(1).astype(np.int64)
+            off = np.concatenate([[0], np.cumsum(cnt)])
+            bb, ii = np.nonzero(mask)
+            jj = idx[bb, ii]
+            obs_px = np.ascontiguousarray(px[bb, ii])                          # the current keyframe's stereo pixels of the tracked matches
+            lm_pos = np.ascontiguousarray(pos_p[bb, jj])                       # the landmarks: the previous keyframe's triangulation of its matches
+            obs_lm = (np.arange(len(bb)) - off[bb]).astype(np.int32)
+            lm_slot = -np.ones(len(bb), np.int32)
+            arr = (capi.LmWindow * B)()
+            p_es, p_id, p_ar, p_pe = es.ctypes.data, ident.ctypes.data, ar.ctypes.data, pe.ctypes.data
+            p_ls, p_lp, p_ol, p_px = lm_slot.ctypes.data, lm_pos.ctypes.data, obs_lm.ctypes.data, obs_px.ctypes.data
+            for b_ in range(B):
+                o_, c_ = int(off[b_]), int(cnt[b_])
+                arr[b_] = capi.LmWindow(1, p_es, p_id, c_, p_ls + 4 * o_, p_lp + 24 * o_, c_, p_ol + 4 * o_, p_px + 16 * o_, p_ar, p_pe)
+            t2 = time.perf_counter()
+            lb = capi.LmBatch(ctx, [None] * B, marshalled=(arr, [es, ident, ar, pe, lm_slot, lm_pos, obs_lm, obs_px]))
+            t3 = time.perf_counter()
+            lb.run(lp)
+            r = lb.results()
+            t4 = time.perf_counter()
+            if timed:
+                t_ph[:] += [t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0]
+                stats.append((float(cnt.mean()), float(np.mean([x.iters for x in r])), float(np.mean([x.err_final <= x.err_init for x in r])), lb.symbolic_ms()[0]))
+            lb.close()
+        one(False)
+        for _ in range(n):
+            one(True)
+        t_ph /= n
+        st_ = np.mean(np.array(stats), 0)
+        return {"value": B / t_ph[4], "unit": "keyframes/s", "ms_per_step": 1e3 * t_ph[4], "steps": n,
+                "ms": {"front_end_da_a10_a11_and_downloads": 1e3 * t_ph[0], "host_window_assembly": 1e3 * t_ph[1], "lm_batch_create": 1e3 * t_ph[2],
+                       "lm_solve_and_results": 1e3 * t_ph[3]},
+                "lm_symbolic_ms_per_window": st_[3] / B, "mean_tracked_observations": st_[0], "mean_lm_iters": st_[1], "windows_with_error_not_increased": st_[2],
+                "note": "every step: front-end + DA of the batch, ssk_build_observations_batch, download of the tracked matches, stage-1 windows of "
+                        "define_new_keyframe (the new edge optimised, the tracked landmarks held at the previous keyframe's triangulation) assembled on the "
+                        "host from that output, ssk_lm_batch_create, solve, results -- nothing prepared outside the timed region but the previous "
+                        "keyframes' state; serial (no overlap of host work with the device)"}
+
+    e2e = e2e_pass(3) if world == 1 and rank == 0 and not exchange else None
+
     # ---- the reference's real per-keyframe LM load (reported beside `value`): define_new_keyframe does TWO solves per keyframe
     # (EST.cpp:782-784): stage 1 = optimize_edges on the new edge with the landmarks held, stage 2 = optimize_local_area with
     # srba_max_optimize_depth = 5 (KITTI.ini:105): ~40 edges.  The headline's window is BASELINE configs[2]'s "window = 10".
@@ -709,6 +779,7 @@ def main():
             "value_incl_symbolic": symbolic["value_incl_symbolic"] if symbolic else None,
             "lm_symbolic_ms_per_window": symbolic["lm_symbolic_ms_per_window"] if symbolic else None,
             "lm_symbolic": symbolic,
+            "e2e": e2e,
             "exchange_ms_per_rank": exchange_ms_all if exchange else None,
             "pcie_inclusive": pcie,
             "unbatched": unbatched,
