@@ -471,7 +471,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	// (3) the batch-wide host images and tables filled, side by side again.  Nothing heavy is serial.
 	struct lean_win { int E = 0, L = 0, n_path = 0; std::vector<int> s_edge, s_lm; nd_host nh; nd_sizes off; char split = 0, bad = 0; };
 	std::vector<lean_win> lw((size_t)n_windows);
-	static const int n_thr_max = [] { const char* e = std::getenv("SSK_LM_BUILD_THREADS"); const int hc = (int)std::thread::hardware_concurrency(); return e ? std::max(1, std::atoi(e)) : std::max(1, std::min(hc / 2, 32)); }();
+	static const int n_thr_max = [] { const char* e = std::getenv("SSK_LM_BUILD_THREADS"); const int hc = (int)std::thread::hardware_concurrency(); return e ? std::max(1, std::atoi(e)) : std::max(1, std::min(hc / 2, 64)); }();
 	const int n_thr_used = std::max(1, std::min(n_thr_max, n_windows / 8));      // (a thread is worth it from a handful of windows on)
 	auto parallel = [&](auto&& fn) {
 		if (n_thr_used > 1) {

@@ -303,12 +303,19 @@ void lm_split_decide_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int init)
 	if (!c0.active) return;
 	const nd_win W = N.win[wi];
 	const nd_split SW = S.sw[wi];
+	// the tiles' partials: a thread per tile in turn, then the fixed shuffle tree of block_sum -- the same sum in every launch (one thread walking
+	// a local area's hundred tiles by dependent loads was 26 us per pass of the un-batched path)
+	__shared__ double s_part[NW];
+	double e_all = 0.0, dfn_all = 0.0;
+	if (init || c0.ok) {
+		double e1 = 0.0, f1 = 0.0;
+		for (int t = tid; t < W.n_tiles; t += NT) { e1 += S.epart[SW.gtile0 + t]; f1 += S.fpart[SW.gtile0 + t]; }
+		e_all = block_sum(e1, s_part);
+		dfn_all = block_sum(f1, s_part);
+	}
 	if (tid == 0) {
 		sp_ctl c = c0;
-		double e = 0.0, dfn = 0.0;
-		// tile order: the same sum in every launch
-		if (init || c.ok)
-			for (int t = 0; t < W.n_tiles; ++t) { e += S.epart[SW.gtile0 + t]; dfn += S.fpart[SW.gtile0 + t]; }
+		const double e = e_all, dfn = dfn_all;
 		int copy = 0;
 		ssk_lm_result& R = D.res[wi];
 		if (init) {
