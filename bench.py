@@ -513,9 +513,9 @@ def main():
             made[k] = capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar)
         create(0); create(1)                              # (slab allocations, code objects)
         made.pop(1).close()
-        sym_ms, sym_thr = made[0].symbolic_ms()
+        sym_thr = made[0].symbolic_ms()[1]
         torch.cuda.synchronize()
-        t_create = []
+        t_create, t_sym = [], []
         t0s = time.perf_counter()
         for k in range(n):
             th = threading.Thread(target=create, args=(k + 1,))
@@ -523,11 +523,12 @@ def main():
             step(lm=made[k], lm_ctx=ctx_lm)
             torch.cuda.synchronize()
             th.join()
-            t_create.append(made[k + 1].create_ms)
+            t_create.append(made[k + 1].create_ms); t_sym.append(made[k + 1].symbolic_ms()[0])
             made.pop(k).close()
         dts = time.perf_counter() - t0s
         made.pop(n).close()
         ctx_c.close()
+        sym_ms = float(np.mean(t_sym))
         return {"value_incl_symbolic": B * n / dts, "ms_per_step": 1e3 * dts / n, "steps": n,
                 "lm_symbolic_ms_per_window": sym_ms / B, "lm_symbolic_ms_per_batch": sym_ms, "host_threads": sym_thr,
                 "lm_batch_create_ms": float(np.mean(t_create)),
@@ -698,7 +699,7 @@ def main():
             return traffic[kernel]
         # executed FP64 flops from the PMC pass of the same command (tools/pmc_lm.sh: SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)
         pmc_flop = None
-        pl = os.path.join(ROOT, "profiles", "r03_pmc_lm_wave_time.json")
+        pl = os.path.join(ROOT, "profiles", "r04_pmc_lm_wave_time.json")
         if os.path.exists(pl):
             try:
                 pmc_flop = json.load(open(pl)).get(LM_KERNEL, {}).get("derived", {}).get("f64_flop")
@@ -761,7 +762,7 @@ def main():
                          "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic_of(LM_KERNEL, lm_avg_ms), "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
                          "note": "dominant kernel by time; not bandwidth bound: two persistent workgroups per CU, waves wait on LDS / FP64 dependencies "
-                                 "(profiles/r03_pmc_lm_wave_time.json, DESIGN.md 5); traffic is null when the committed PMC summary's kernel time differs from the live one by more than 5 %"},
+                                 "(profiles/r04_pmc_lm_wave_time.json, DESIGN.md 5); traffic is null when the committed PMC summary's kernel time differs from the live one by more than 5 %"},
             "roofline_fp64": {"kernel": LM_KERNEL, "bound": "fp64", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
                               "executed_flops_per_launch_pmc": pmc_flop,
