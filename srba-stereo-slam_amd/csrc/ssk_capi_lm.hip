@@ -87,7 +87,13 @@ int finalize(ssk_lm_batch* b)
 		SSK_HIP(ctx, hipMalloc(&b->slab, total + total / 4));          // head room: the next keyframe's window is a little larger
 		b->slab_bytes = total + total / 4;
 	}
-	const bool staged = up <= (size_t)8 << 20;
+	// host images that already live in the context's pinned LM arena (the lean builder's tables) go by DMA from where they are
+	const uint8_t* plo = static_cast<const uint8_t*>(ctx->pin_lm.base);
+	const uint8_t* phi = plo ? plo + ctx->pin_lm.cap : nullptr;
+	auto pinned = [&](const void* p) { return plo && (const uint8_t*)p >= plo && (const uint8_t*)p < phi; };
+	size_t up_rest = 0;
+	for (const ssk_lm_batch::req& r : b->reqs) if (r.copy > 0 && !pinned(r.src)) up_rest += ssk_pad(r.bytes);
+	const bool staged = up_rest <= (size_t)8 << 20;
 	uint8_t* st = nullptr;
 	if (staged && up) {
 		int rc = ssk_arena_reserve(ctx, ctx->pin, up + 256);
@@ -102,12 +108,23 @@ int finalize(ssk_lm_batch* b)
 			uint8_t* d = static_cast<uint8_t*>(b->slab) + off;
 			*r.dst = d;
 			if (pass == 0) {
-				if (staged) { std::memcpy(st + off, r.src, r.copy); std::memset(st + off + r.copy, 0, ssk_pad(r.bytes) - r.copy); }
+				if (pinned(r.src)) SSK_HIP(ctx, hipMemcpyAsync(d, r.src, r.copy, hipMemcpyHostToDevice, ctx->stream));
+				else if (staged) { std::memcpy(st + off, r.src, r.copy); std::memset(st + off + r.copy, 0, ssk_pad(r.bytes) - r.copy); }
 				else SSK_HIP(ctx, hipMemcpyAsync(d, r.src, r.copy, hipMemcpyHostToDevice, ctx->stream));
 			}
 			off += ssk_pad(r.bytes);
 		}
-	if (staged && up) SSK_HIP(ctx, hipMemcpyAsync(b->slab, st, up, hipMemcpyHostToDevice, ctx->stream));
+	if (staged && up) {
+		if (up_rest == up) SSK_HIP(ctx, hipMemcpyAsync(b->slab, st, up, hipMemcpyHostToDevice, ctx->stream));      // nothing pinned: one DMA
+		else {                                             // the staged pieces one by one (the pinned ones went directly)
+			size_t o2 = 0;
+			for (const ssk_lm_batch::req& r : b->reqs) {
+				if (r.copy == 0) continue;
+				if (!pinned(r.src)) SSK_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t*>(b->slab) + o2, st + o2, ssk_pad(r.bytes), hipMemcpyHostToDevice, ctx->stream));
+				o2 += ssk_pad(r.bytes);
+			}
+		}
+	}
 	if (total > up) SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + up, 0, total - up, ctx->stream));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // host images / pinned staging are free again when create returns
 	b->reqs.clear();
@@ -529,12 +546,32 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	}
 	if (n_edge_t > 0x7FFFFFFF || n_obs_t > 0x7FFFFFFF || n_path_t > 0x7FFFFFFF || zn.item > 0x7FFFFFFF || zs.item > 0x7FFFFFFF)
 		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: the batch's tables exceed 2^31 entries");
-	nd_vec<int> edge_slot(n_edge_t), lm_slot(n_lm_t), obs_lm(n_obs_t), obs_path_off(n_opo_t), path_edge(n_path_t), slot_edge(n_us_t), slot_lm(n_ls_t);
-	nd_vec<double> pose(12 * n_edge_t), lm(3 * n_lm_t);
-	nd_vec<float> obs_px(4 * n_obs_t);
+	// the batch-wide host images and tables in the context's pinned arena (up to 256 MB; larger batches: pageable memory)
+	nd_bump bump;
+	nd_bump* arena = nullptr;
+	{
+		auto tb = [](const nd_sizes& z) {
+			return sizeof(nd_i2) * (z.suf + z.obs + z.qs + z.gqs) + sizeof(nd_tile) * z.tile + sizeof(nd_group) * z.group + sizeof(nd_f4) * z.obs + sizeof(nd_i4) * (z.lane + z.sqs) +
+			       sizeof(int) * (z.item + z.gitem + z.poff + z.goff + z.gslot);
+		};
+		const size_t need = tb(zn) + tb(zs) + sizeof(int) * (n_edge_t + n_lm_t + n_obs_t + n_opo_t + n_path_t + n_us_t + n_ls_t) + sizeof(double) * (12 * n_edge_t + 3 * n_lm_t) +
+		                    sizeof(float) * 4 * n_obs_t + 64 * 64;
+		static const bool no_pin = std::getenv("SSK_LM_NO_PINNED") != nullptr;
+		if (!no_pin && need <= ((size_t)256 << 20)) {
+			const int rcp = ssk_arena_reserve(ctx, ctx->pin_lm, need);
+			if (rcp) return rcp;
+			bump.base = static_cast<char*>(ctx->pin_lm.base); bump.cap = ctx->pin_lm.cap; bump.used = 0;
+			arena = &bump;
+		}
+	}
+	using ai = nd_noinit<int>; using ad = nd_noinit<double>; using af = nd_noinit<float>;
+	nd_vec<int> edge_slot(n_edge_t, ai(arena)), lm_slot(n_lm_t, ai(arena)), obs_lm(n_obs_t, ai(arena)), obs_path_off(n_opo_t, ai(arena)), path_edge(n_path_t, ai(arena)),
+	            slot_edge(n_us_t, ai(arena)), slot_lm(n_ls_t, ai(arena));
+	nd_vec<double> pose(12 * n_edge_t, ad(arena)), lm(3 * n_lm_t, ad(arena));
+	nd_vec<float> obs_px(4 * n_obs_t, af(arena));
 	nd_host NHn, NHs;                                      // the two families' tables; win[] (and swin[]) of both are indexed by the batch's window number
-	if (n_node) nd_resize(NHn, zn, (size_t)n_windows, false);
-	if (n_split) nd_resize(NHs, zs, (size_t)n_windows, true);
+	if (n_node) nd_resize(NHn, zn, (size_t)n_windows, false, arena);
+	if (n_split) nd_resize(NHs, zs, (size_t)n_windows, true, arena);
 	std::vector<char> w_split((size_t)n_windows, 0);
 	// ---- (3) placement ----
 	parallel([&](int w) {

@@ -114,6 +114,7 @@ int ssk_create(ssk_ctx** out, int device, void* hip_stream)
 	ctx->device = device;
 	ctx->n_cu = prop.multiProcessorCount;
 	ctx->pin.pinned_host = true;
+	ctx->pin_lm.pinned_host = true;
 #define CREATE_HIP(call)                                                                           \
 	do { hipError_t e2 = (call); if (e2 != hipSuccess) {                                           \
 		int rc = ssk_set_error(nullptr, SSK_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2)); \
@@ -157,6 +158,7 @@ void ssk_destroy(ssk_ctx* ctx)
 	(void)hipStreamSynchronize(ctx->stream);
 	if (ctx->dev.base) (void)hipFree(ctx->dev.base);
 	if (ctx->pin.base) (void)hipHostFree(ctx->pin.base);
+	if (ctx->pin_lm.base) (void)hipHostFree(ctx->pin_lm.base);
 	if (ctx->single) ssk_kfbatch_destroy_internal(ctx->single);
 	if (ctx->lm_slab) (void)hipFree(ctx->lm_slab);
 	if (ctx->d_dir_thresh) (void)hipFree(ctx->d_dir_thresh);

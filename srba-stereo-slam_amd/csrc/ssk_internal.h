@@ -25,6 +25,7 @@ struct ssk_ctx {
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	std::string err;
 	ssk_arena dev, pin;
+	ssk_arena pin_lm;                  // pinned host memory the tables of an LM batch are built in (ssk_capi_lm.hip: one DMA per table, no pageable staging)
 	std::vector<void*> retired;        // arenas replaced by bigger ones; freed at destroy / next sync
 	// direction-filter bin thresholds (see ssk_da_filters.hip): smallest float quotient mapped to
 	// bin >= b for b = 9..27, computed once on the host with the host libm's atanf.

@@ -12,15 +12,36 @@
 #include "../../include/ssk_capi.h"
 #include "ssk_lm_node.h"
 
-// vectors whose resize() leaves new elements uninitialised: the batch-wide tables are sized by prefix sums and then filled by the builder's
-// threads -- a value-initialising resize wrote 100 MB of zeros on one thread first
+// Vectors of the node tables: resize() leaves new elements uninitialised (the batch-wide tables are sized by prefix sums and then filled by the
+// builder's threads: a value-initialising resize wrote 100 MB of zeros on one thread first), and an allocator bound to a bump arena takes its
+// storage from there -- the library hands over PINNED host memory, so that a batch's tables go to the device by DMA straight from where the
+// builder's threads wrote them (no pageable staging copy).  An arena allocation is never freed piecewise (the arena is reset as a whole).
+struct nd_bump { char* base = nullptr; size_t cap = 0, used = 0; };
 template <typename T>
-struct nd_noinit : std::allocator<T> {
-	template <typename U> struct rebind { using other = nd_noinit<U>; };
+struct nd_noinit {
+	using value_type = T;
+	nd_bump* arena = nullptr;
 	nd_noinit() = default;
-	template <typename U> nd_noinit(const nd_noinit<U>&) {}
+	explicit nd_noinit(nd_bump* a) : arena(a) {}
+	template <typename U> nd_noinit(const nd_noinit<U>& o) : arena(o.arena) {}
+	template <typename U> struct rebind { using other = nd_noinit<U>; };
+	T* allocate(size_t n)
+	{
+		if (arena) {
+			const size_t off = (arena->used + 63) & ~(size_t)63, bytes = n * sizeof(T);
+			if (off + bytes <= arena->cap) { arena->used = off + bytes; return reinterpret_cast<T*>(arena->base + off); }
+		}
+		return static_cast<T*>(::operator new(n * sizeof(T)));
+	}
+	void deallocate(T* p, size_t)
+	{
+		if (arena && (char*)p >= arena->base && (char*)p < arena->base + arena->cap) return;
+		::operator delete(p);
+	}
 	template <typename U> void construct(U* p) { ::new ((void*)p) U; }
 	template <typename U, typename... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+	template <typename U> bool operator==(const nd_noinit<U>& o) const { return arena == o.arena; }
+	template <typename U> bool operator!=(const nd_noinit<U>& o) const { return arena != o.arena; }
 };
 template <typename T> using nd_vec = std::vector<T, nd_noinit<T>>;
 
@@ -540,10 +561,16 @@ inline void nd_sizes_add(nd_sizes& a, const nd_sizes& b)
 	a.suf += b.suf; a.tile += b.tile; a.group += b.group; a.obs += b.obs; a.lane += b.lane; a.item += b.item; a.qs += b.qs; a.gitem += b.gitem; a.gqs += b.gqs;
 	a.sqs += b.sqs; a.poff += b.poff; a.goff += b.goff; a.gslot += b.gslot; a.tab += b.tab; a.hb += b.hb; a.part += b.part; a.gpart += b.gpart;
 }
-inline void nd_resize(nd_host& D, const nd_sizes& z, size_t n_windows, bool split)
+inline void nd_resize(nd_host& D, const nd_sizes& z, size_t n_windows, bool split, nd_bump* arena = nullptr)
 {
 	D.win.assign(n_windows, nd_win{});
 	if (split) D.swin.assign(n_windows, nd_split{});
+	if (arena) {
+#define ND_BIND(v) D.v = decltype(D.v)(typename decltype(D.v)::allocator_type(arena))
+		ND_BIND(suf); ND_BIND(tile); ND_BIND(group); ND_BIND(obs); ND_BIND(px); ND_BIND(lane); ND_BIND(item); ND_BIND(qs); ND_BIND(gitem); ND_BIND(gqs);
+		ND_BIND(sqs); ND_BIND(poff); ND_BIND(goff); ND_BIND(gslot);
+#undef ND_BIND
+	}
 	D.suf.resize(z.suf); D.tile.resize(z.tile); D.group.resize(z.group); D.obs.resize(z.obs); D.px.resize(z.obs); D.lane.resize(z.lane); D.item.resize(z.item);
 	D.qs.resize(z.qs); D.gitem.resize(z.gitem); D.gqs.resize(z.gqs); D.sqs.resize(z.sqs); D.poff.resize(z.poff); D.goff.resize(z.goff); D.gslot.resize(z.gslot);
 	D.tab_doubles = z.tab; D.hb_doubles = z.hb; D.part_slots = z.part; D.gpart_slots = z.gpart;
