@@ -17,6 +17,9 @@
 #include <cstring>
 #include <map>
 #include <dlfcn.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 
 struct ssk_lm_batch {
 	ssk_ctx* ctx = nullptr;
@@ -49,6 +52,7 @@ struct ssk_lm_batch {
 	nd_dev N2{};                      // the phase-split windows' node tables (N: the node kernel's); both families' win[] are indexed by the batch's window number
 	int node_n = 0, split_n = 0;      // windows per family (a mixed batch runs both)
 	double symbolic_ms = 0.0;         // host time of the symbolic build (ssk_lm_batch_symbolic_ms)
+	size_t up_bytes = 0, zero_bytes = 0;   // finalize: bytes uploaded / zeroed (SSK_TIMING)
 	int symbolic_threads = 1;
 	size_t split_solve_dyn_bytes = 0, split_init_dyn_bytes = 0;
 	bool coop_pending = false;
@@ -81,6 +85,7 @@ int finalize(ssk_lm_batch* b)
 	size_t up = 0, total = 0;
 	for (const ssk_lm_batch::req& r : b->reqs) { if (r.copy > 0) up += ssk_pad(r.bytes); total += ssk_pad(r.bytes); }
 	if (total == 0) total = 256;
+	b->up_bytes = up; b->zero_bytes = total - up;
 	if (ctx->lm_slab && ctx->lm_slab_bytes >= total) { b->slab = ctx->lm_slab; b->slab_bytes = ctx->lm_slab_bytes; ctx->lm_slab = nullptr; ctx->lm_slab_bytes = 0; }
 	else {
 		if (ctx->lm_slab) { SSK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->lm_slab); ctx->lm_slab = nullptr; ctx->lm_slab_bytes = 0; }
@@ -473,6 +478,59 @@ static int lm_validate_window(ssk_ctx* ctx, const ssk_lm_window& Wn, int w, int&
 	return SSK_OK;
 }
 
+// The symbolic build's worker threads: created once (spawning 64 threads costs ~1.5 ms, each of a create's two parallel phases paid it), asleep on
+// a condition variable between jobs.  run(): items 0 .. n-1 dealt out one at a time to `threads` workers and the caller; returns when all are done.
+// One job at a time (creates on several host threads take turns).
+struct lm_build_pool {
+	std::mutex job_mx, mx;
+	std::condition_variable cv, cv_done;
+	std::vector<std::thread> workers;
+	const std::function<void(int)>* fn = nullptr;
+	std::atomic<int> next{0};
+	int n_items = 0, gen = 0, want = 0, busy = 0;
+	bool stop = false;
+	void work()
+	{
+		int seen = 0;
+		for (;;) {
+			const std::function<void(int)>* f;
+			{
+				std::unique_lock<std::mutex> lk(mx);
+				cv.wait(lk, [&] { return stop || (gen != seen && want > 0); });
+				if (stop) return;
+				seen = gen; --want; f = fn;
+			}
+			for (int w = next++; w < n_items; w = next++) (*f)(w);
+			{
+				std::lock_guard<std::mutex> lk(mx);
+				if (--busy == 0) cv_done.notify_one();
+			}
+		}
+	}
+	void run(int threads, int n, const std::function<void(int)>& f)
+	{
+		std::lock_guard<std::mutex> job(job_mx);
+		const int helpers = std::max(0, threads - 1);
+		while ((int)workers.size() < helpers) workers.emplace_back([this] { work(); });
+		{
+			std::lock_guard<std::mutex> lk(mx);
+			fn = &f; n_items = n; next = 0; want = helpers; busy = helpers; ++gen;
+		}
+		cv.notify_all();
+		for (int w = next++; w < n; w = next++) f(w);
+		std::unique_lock<std::mutex> lk(mx);
+		cv_done.wait(lk, [&] { return busy == 0; });
+		fn = nullptr;
+	}
+	~lm_build_pool()
+	{
+		{ std::lock_guard<std::mutex> lk(mx); stop = true; }
+		cv.notify_all();
+		for (std::thread& th : workers) th.join();
+	}
+};
+static lm_build_pool& lm_pool() { static lm_build_pool p; return p; }
+
 // ---- lean batch: node tables only ----
 // A batch whose windows all fit the node builder (ssk_lm_node_build.h: <= 128 optimised edges, <= 64 observations and <= 63 nodes per landmark)
 // needs none of the tiled / general structures: every window small enough for lm_solve_node_kernel (reduced system + a tile of records in LDS)
@@ -490,13 +548,9 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	std::vector<lean_win> lw((size_t)n_windows);
 	static const int n_thr_max = [] { const char* e = std::getenv("SSK_LM_BUILD_THREADS"); const int hc = (int)std::thread::hardware_concurrency(); return e ? std::max(1, std::atoi(e)) : std::max(1, std::min(hc / 2, 64)); }();
 	const int n_thr_used = std::max(1, std::min(n_thr_max, n_windows / 8));      // (a thread is worth it from a handful of windows on)
-	auto parallel = [&](auto&& fn) {
-		if (n_thr_used > 1) {
-			std::vector<std::thread> pool;
-			std::atomic<int> next{0};
-			for (int t = 0; t < n_thr_used; ++t) pool.emplace_back([&] { for (int w = next++; w < n_windows; w = next++) fn(w); });
-			for (std::thread& th : pool) th.join();
-		} else
+	auto parallel = [&](const std::function<void(int)>& fn) {
+		if (n_thr_used > 1) lm_pool().run(n_thr_used, n_windows, fn);
+		else
 			for (int w = 0; w < n_windows; ++w) fn(w);
 	};
 	// ---- (1) per window: checks; its kernel family -- the persistent node kernel when the reduced system and a tile of records fit LDS, the
@@ -513,6 +567,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		if (sp && !nd_build_window(Wn, SSK_SP_WAVES, X.nh, nd_win{}, node_lds_limit / 8, true)) { X.bad = 1; return; }
 		X.split = sp;
 	});
+	const auto t_ph1 = std::chrono::steady_clock::now();
 	for (int w = 0; w < n_windows; ++w) {
 		if (lw[(size_t)w].bad == 2) { int E, L, np; std::vector<int> a, c; return lm_validate_window(ctx, windows[w], w, E, L, a, c, np); }      // (again, for the message)
 		if (lw[(size_t)w].bad) return 1;
@@ -546,7 +601,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	}
 	if (n_edge_t > 0x7FFFFFFF || n_obs_t > 0x7FFFFFFF || n_path_t > 0x7FFFFFFF || zn.item > 0x7FFFFFFF || zs.item > 0x7FFFFFFF)
 		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: the batch's tables exceed 2^31 entries");
-	// the batch-wide host images and tables in the context's pinned arena (up to 256 MB; larger batches: pageable memory)
+	// the batch-wide host images and tables in the context's pinned arena (up to 1 GB; larger batches: pageable memory)
 	nd_bump bump;
 	nd_bump* arena = nullptr;
 	{
@@ -557,7 +612,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		const size_t need = tb(zn) + tb(zs) + sizeof(int) * (n_edge_t + n_lm_t + n_obs_t + n_opo_t + n_path_t + n_us_t + n_ls_t) + sizeof(double) * (12 * n_edge_t + 3 * n_lm_t) +
 		                    sizeof(float) * 4 * n_obs_t + 64 * 64;
 		static const bool no_pin = std::getenv("SSK_LM_NO_PINNED") != nullptr;
-		if (!no_pin && need <= ((size_t)256 << 20)) {
+		if (!no_pin && need <= ((size_t)1 << 30)) {
 			const int rcp = ssk_arena_reserve(ctx, ctx->pin_lm, need);
 			if (rcp) return rcp;
 			bump.base = static_cast<char*>(ctx->pin_lm.base); bump.cap = ctx->pin_lm.cap; bump.used = 0;
@@ -573,6 +628,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (n_node) nd_resize(NHn, zn, (size_t)n_windows, false, arena);
 	if (n_split) nd_resize(NHs, zs, (size_t)n_windows, true, arena);
 	std::vector<char> w_split((size_t)n_windows, 0);
+	const auto t_ph2 = std::chrono::steady_clock::now();
 	// ---- (3) placement ----
 	parallel([&](int w) {
 		const ssk_lm_window& Wn = windows[w];
@@ -594,6 +650,11 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		nw.h0 = H.h0;
 		nd_place(X.split ? NHs : NHn, (size_t)w, X.off, X.nh);
 		w_split[(size_t)w] = X.split;
+		// the window's own tables are done with: freed here, by the thread that filled them (1 024 windows' worth freed on one thread cost 2.7 ms)
+		nd_host keep;
+		keep.lds_doubles = X.nh.lds_doubles; keep.lds_doubles_big = X.nh.lds_doubles_big; keep.max_items_per_lane = X.nh.max_items_per_lane; keep.max_tile_blocks = X.nh.max_tile_blocks;
+		X.nh = std::move(keep);
+		std::vector<int>().swap(X.s_edge); std::vector<int>().swap(X.s_lm);
 	});
 	for (int w = 0; w < n_windows; ++w) {
 		nd_host& Dh = lw[(size_t)w].split ? NHs : NHn;
@@ -601,6 +662,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		Dh.lds_doubles = std::max(Dh.lds_doubles, W1.lds_doubles); Dh.lds_doubles_big = std::max(Dh.lds_doubles_big, W1.lds_doubles_big);
 		Dh.max_items_per_lane = std::max(Dh.max_items_per_lane, W1.max_items_per_lane); Dh.max_tile_blocks = std::max(Dh.max_tile_blocks, W1.max_tile_blocks);
 	}
+	const auto t_ph3 = std::chrono::steady_clock::now();
 	lw.clear();
 	const auto t_sym = std::chrono::steady_clock::now();
 	ssk_lm_batch* b = new ssk_lm_batch();
@@ -721,6 +783,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		if (!rc) rc = scratch(b, 4, &b->S.n_active);
 	}
 	D.trace_on = trace ? 1 : 0;
+	const auto t_fin = std::chrono::steady_clock::now();
 	if (!rc) rc = finalize(b);
 	if (rc) { ssk_lm_batch_destroy(b); return rc; }
 	if (std::getenv("SSK_LM_DEBUG"))
@@ -731,8 +794,9 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	if (timing) {
 		(void)hipDeviceSynchronize();
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create, lean (%d windows: %d node, %d split): symbolic %.3f ms, allocate + upload %.3f ms\n", n_windows, n_node, n_split,
-		             ms(t_begin, t_sym), ms(t_sym, std::chrono::steady_clock::now()));
+		std::fprintf(stderr, "[ssk timing] ssk_lm_batch_create, lean (%d windows: %d node, %d split): symbolic %.3f ms (build %.3f, bases + arena %.3f, place %.3f, free %.3f), maps + requests %.3f ms, "
+		             "allocate + upload %.3f ms (%.1f MB up, %.1f MB zeroed)\n", n_windows, n_node, n_split,
+		             ms(t_begin, t_sym), ms(t_begin, t_ph1), ms(t_ph1, t_ph2), ms(t_ph2, t_ph3), ms(t_ph3, t_sym), ms(t_sym, t_fin), ms(t_fin, std::chrono::steady_clock::now()), b->up_bytes / 1e6, b->zero_bytes / 1e6);
 	}
 	*out = b;
 	return SSK_OK;

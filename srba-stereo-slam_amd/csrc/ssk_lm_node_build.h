@@ -20,6 +20,8 @@ struct nd_bump { char* base = nullptr; size_t cap = 0, used = 0; };
 template <typename T>
 struct nd_noinit {
 	using value_type = T;
+	using propagate_on_container_move_assignment = std::true_type;      // (v = vector(allocator(arena)) binds v to the arena)
+	using propagate_on_container_swap = std::true_type;
 	nd_bump* arena = nullptr;
 	nd_noinit() = default;
 	explicit nd_noinit(nd_bump* a) : arena(a) {}
