@@ -575,14 +575,15 @@ def main():
             lm_pos = np.ascontiguousarray(pos_p[bb, jj])                       # the landmarks: the previous keyframe's triangulation of its matches
             obs_lm = (np.arange(len(bb)) - off[bb]).astype(np.int32)
             lm_slot = -np.ones(len(bb), np.int32)
-            arr = (capi.LmWindow * B)()
-            p_es, p_id, p_ar, p_pe = es.ctypes.data, ident.ctypes.data, ar.ctypes.data, pe.ctypes.data
-            p_ls, p_lp, p_ol, p_px = lm_slot.ctypes.data, lm_pos.ctypes.data, obs_lm.ctypes.data, obs_px.ctypes.data
-            for b_ in range(B):
-                o_, c_ = int(off[b_]), int(cnt[b_])
-                arr[b_] = capi.LmWindow(1, p_es, p_id, c_, p_ls + 4 * o_, p_lp + 24 * o_, c_, p_ol + 4 * o_, p_px + 16 * o_, p_ar, p_pe)
+            rec = np.zeros(B, capi.LM_WINDOW_DTYPE)                            # the batch's ssk_lm_window array, column by column
+            o8 = off[:B].astype(np.uint64)
+            rec["n_edges_total"] = 1; rec["edge_unknown_slot"] = es.ctypes.data; rec["edge_inv_pose"] = ident.ctypes.data
+            rec["n_lms_total"] = cnt; rec["lm_unknown_slot"] = lm_slot.ctypes.data + 4 * o8; rec["lm_pos"] = lm_pos.ctypes.data + 24 * o8
+            rec["n_obs"] = cnt; rec["obs_lm"] = obs_lm.ctypes.data + 4 * o8; rec["obs_px"] = obs_px.ctypes.data + 16 * o8
+            rec["obs_path_off"] = ar.ctypes.data; rec["path_edge"] = pe.ctypes.data
+            arr = capi.lm_window_array(rec)
             t2 = time.perf_counter()
-            lb = capi.LmBatch(ctx, [None] * B, marshalled=(arr, [es, ident, ar, pe, lm_slot, lm_pos, obs_lm, obs_px]))
+            lb = capi.LmBatch(ctx, [None] * B, marshalled=(arr, [rec, es, ident, ar, pe, lm_slot, lm_pos, obs_lm, obs_px]))
             t3 = time.perf_counter()
             lb.run(lp)
             r = lb.results()

@@ -581,6 +581,18 @@ class LmWindow(C.Structure):
                 ("obs_path_off", C.c_void_p), ("path_edge", C.c_void_p)]
 
 
+# ssk_lm_window as a numpy record (C layout): a batch's array of windows filled column by column instead of one ctypes struct at a time
+LM_WINDOW_DTYPE = np.dtype([("n_edges_total", "<i4"), ("edge_unknown_slot", "<u8"), ("edge_inv_pose", "<u8"), ("n_lms_total", "<i4"), ("lm_unknown_slot", "<u8"),
+                            ("lm_pos", "<u8"), ("n_obs", "<i4"), ("obs_lm", "<u8"), ("obs_px", "<u8"), ("obs_path_off", "<u8"), ("path_edge", "<u8")], align=True)
+assert LM_WINDOW_DTYPE.itemsize == C.sizeof(LmWindow) and all(LM_WINDOW_DTYPE.fields[n][1] == getattr(LmWindow, n).offset for n, _ in LmWindow._fields_)
+
+
+def lm_window_array(rec):
+    """the ssk_lm_window array over a numpy record array of LM_WINDOW_DTYPE (shares its memory: keep `rec` alive)"""
+    assert rec.dtype == LM_WINDOW_DTYPE and rec.flags.c_contiguous
+    return (LmWindow * len(rec)).from_buffer(rec)
+
+
 class LmParams(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("fx_l", "fy_l", "cx_l", "cy_l", "fx_r", "fy_r", "cx_r", "cy_r", "baseline")] + \
                [("sensor_pose", C.c_double * 12), ("max_iters", C.c_int32), ("use_robust_kernel", C.c_int32),

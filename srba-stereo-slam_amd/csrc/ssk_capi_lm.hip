@@ -746,10 +746,19 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		if (!rc) rc = upload(b, tile_map, &b->S.tile_map);
 		if (!rc) rc = upload(b, win_map, &b->S.win_map);
 		size_t sd = 0, id = 0;
-		for (const nd_win& nw : NHs.win) {
-			sd = std::max(sd, ssk_sp_solve_lds_doubles(nw.n_edges, nw.n_suf, nw.E));
-			id = std::max(id, 12 * (size_t)nw.n_edges + (size_t)nw.n_suf + 2);
+		int E_max = 0;
+		for (const nd_win& nw : NHs.win) E_max = std::max(E_max, nw.E);
+		bool mfma = ssk_sp_solve_mfma(E_max);
+		for (int attempt = 0; attempt < 2; ++attempt) {
+			sd = 0; id = 0;
+			for (const nd_win& nw : NHs.win) {
+				sd = std::max(sd, ssk_sp_solve_lds_doubles(nw.n_edges, nw.n_suf, nw.E, mfma));
+				id = std::max(id, 12 * (size_t)nw.n_edges + (size_t)nw.n_suf + 2);
+			}
+			if (!mfma || 8 * sd <= node_lds_limit) break;
+			mfma = false;                                  // (a window with so many fixed edges that the MFMA solver's staging does not fit beside them)
 		}
+		b->S.solve_mfma = mfma ? 1 : 0;
 		b->split_solve_dyn_bytes = 8 * sd; b->split_init_dyn_bytes = 8 * id;
 		if (b->split_solve_dyn_bytes > node_lds_limit || b->split_init_dyn_bytes > node_lds_limit) { delete b; return 1; }
 	}

@@ -1,0 +1,415 @@
+// ssk_lm_ldl_mfma.h -- the dense bordered LDL^T solve of the phase-split LM's K2 (ssk_lm_split_solve.hip) with the WHOLE matrix in the
+// accumulator registers of the FP64 matrix cores.  Reference: solver_LM_schur_dense_cholesky, SRBA.h:34 (the dense Cholesky of the reduced
+// system H_pp - S + lambda I); same factorisation as the other solvers of ssk_lm_device.h (right-looking L' D L'^T, U = L' D unscaled, the
+// border row = right-hand side eliminated on the way) up to the order of an update's terms.
+//
+// Layout.  The (n + 1) x (n + 1) bordered system (n <= 255: 42 optimised edges) padded to 16 T rows is cut into 16 x 16 tiles of its lower
+// triangle, tile (J, I), J <= I, held TRANSPOSED as one v_mfma_f64_16x16x4_f64 accumulator: register r of lane l = A(16 I + l % 16, 16 J + 4 r + l / 16).
+// T (T + 1) / 2 <= 136 tiles dealt column-major over SEVEN of the workgroup's eight wavefronts (20 tiles = 160 VGPRs per lane at most; a tile
+// column retires evenly from all of them); the eighth is the FACTOR wave.  An accumulator tile is, register by register, exactly the B operand of
+// the instruction, so LEFT multiplication of a tile needs no data movement.  A panel step k (16 columns):
+//   A  the factor wave takes the diagonal tile (k, k) from LDS in a lane-per-row layout, factorises it (column broadcasts by v_readlane) and
+//      inverts the unit factor on the way (lanes 16 .. 31: column c of L'^-1 -- the same scalars L'(c, j) and the same instruction drive both),
+//      publishes L'^-1 and 1 / d and raises a flag;
+//   B  the owners of the tiles (k, I) below: U_Ik^T = L'^-1 A_Ik^T -- four MFMAs, A operand L'^-1 from LDS, B operand the tile's own registers --
+//      and publish the rows U^T (16 x 16 T doubles).  The critical chain first: tile (k, k + 1), then -- on a flag, not a barrier -- the owner of
+//      the NEXT diagonal tile (k + 1, k + 1) updates it with those 16 rows and hands it to the factor wave: step A of panel k + 1 runs beside the
+//      rest of B and all of C of panel k (measured, tools/ldl_bench.hip: the 16-column dependent chains of A cost 5 us of a 103 us solve);
+//   C  after a barrier among the seven tile waves (an LDS counter; the rows of consecutive panels alternate between two buffers): every tile (J, I),
+//      J > k: tile -= (U_Jk D^-1)(U_Ik^T): four MFMAs, both operands from the published rows (conflict-free: a lane reads row 4 q + l / 16,
+//      column 16 X + l % 16), the A operand scaled by -1 / d on the way, two tiles' MFMA chains interleaved.
+// No workgroup barrier inside the panel loop: the factor wave never waits for the tile waves' phases.
+// Back-substitution by 16-row blocks from the bottom, on flags as well: x_I = L'_II^-T (D^-1 (z_I - sum of the later blocks' contributions)) by the
+// factor wave (the inverses of all diagonal blocks stay in LDS; so do the tiles (k, k + 1), whose contribution -- the one the next block waits for --
+// the factor wave computes itself, x going round by v_readlane); the tile waves hand the contributions U_IJ^T x_I of their other tiles (row sums by
+// DPP) to the blocks above through LDS slots that are summed in a fixed order.  Every sum has one owner and a fixed order: bit-reproducible.
+// Measured (tools/ldl_bench.hip, one workgroup, per solve): 240 unknowns 103 us against 171 us of ldl_solve_regtile, 120: 41 / 79 us, 12: 9 / 12 us.
+// lds: LDLM_DOUBLES doubles (138 KB).  NT must be 512.
+#pragma once
+#include <type_traits>
+
+typedef double ldlm_v4d __attribute__((ext_vector_type(4)));
+#ifdef SSK_LM_STAMPS
+// diagnostics build (tools/split_variant.sh stamps): clock sums of workgroup 0 -- thread 0 (tile wave 0): 0 load, 1 wait for L'^-1, 6 B, 2 barrier among the tile waves, 3 C, 4 loop exit, 5 back-substitution;
+// lane 0 of the factor wave: 7 wait for the diagonal tile, 8 elimination + L'^-1; 15: solves
+__device__ unsigned long long g_k2_t[16];
+// (sums kept in registers and written once at the end: a global read-modify-write per stamp would put its latency into the next phase)
+#define K2_T0() unsigned long long k2_t_ = __builtin_amdgcn_s_memtime(), k2_a_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define K2_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); k2_a_[i] += t_ - k2_t_; k2_t_ = t_; } while (0)
+#define K2_D0() k2_t_ = __builtin_amdgcn_s_memtime()
+#define K2_D(i) K2_T(i)
+#define K2_FLUSH() do { if ((threadIdx.x == 0 || threadIdx.x == NT - 64) && blockIdx.x == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) if (k2_a_[i_]) atomicAdd(&g_k2_t[i_], k2_a_[i_]); } } while (0)
+#else
+#define K2_T0() do {} while (0)
+#define K2_T(i) do {} while (0)
+#define K2_D0() do {} while (0)
+#define K2_D(i) do {} while (0)
+#define K2_FLUSH() do {} while (0)
+#endif
+constexpr int LDLM_TW = 7;              // wavefronts that hold tiles (the eighth factorises the diagonal tiles)
+constexpr int LDLM_TS = 20;             // tile slots of a wavefront: ceil(136 / 7)
+constexpr int LDLM_UP = 256;            // pitch of the published rows U^T
+constexpr int LDLM_LP = 17;             // pitch of a 16 x 16 block in LDS
+constexpr int LDLM_NMAX = 255;          // largest system (n + 1 <= 256)
+constexpr int LDLM_DOUBLES = 2 * 16 * LDLM_UP + 16 * 16 * LDLM_LP + 15 * 16 * LDLM_LP + 16 * LDLM_LP + 3 * 256;
+
+#define LDLM_LD(x) __hip_atomic_load(&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDLM_ST(x, v) __hip_atomic_store(&x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDLM_PIN17(w, v) asm volatile("" : "+v"(w), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), \
+                                           "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+#define LDLM_PIN16(v) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), \
+                                        "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+
+// slot s (a wave-uniform value) -> f(integral_constant<s>): the tiles live in registers, a slot number must be a constant where a tile is touched;
+// a binary tree of scalar branches (five to a slot of twenty)
+template <int LO, int HI, class F>
+__device__ __forceinline__ void ldlm_dispatch(int s, F&& f)
+{
+	if constexpr (LO == HI) f(std::integral_constant<int, LO>{});
+	else {
+		constexpr int MID = (LO + HI) / 2;
+		if (s <= MID) ldlm_dispatch<LO, MID>(s, f);
+		else ldlm_dispatch<MID + 1, HI>(s, f);
+	}
+}
+
+// sum over the 16 lanes that share l / 16, in every one of them (fixed tree: quads, then the row's four quads)
+__device__ __forceinline__ double ldlm_row_sum16(double v)
+{
+	v += dpp_f64<0xB1>(v);              // quad_perm [1,0,3,2]
+	v += dpp_f64<0x4E>(v);              // quad_perm [2,3,0,1]
+	v += dpp_f64<0x124>(v);             // row_ror:4
+	v += dpp_f64<0x128>(v);             // row_ror:8
+	return v;
+}
+
+__device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ A, int np, int n, double* x_out, double* lds)
+{
+	static_assert(NT == 512, "ldl_solve_mfma_tiles: 8 wavefronts");
+	const int tid = threadIdx.x, lane = tid & 63, lc = lane & 15, lr = lane >> 4;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const bool tiles = wave < LDLM_TW;
+	const int T = (n + 16) >> 4;                       // tile rows, border row included
+	const int bcol = n - 16 * (T - 1);                 // the border row inside the last tile row
+	// the panel loop runs on flags, not barriers (the factor wave must not wait for the tile waves' phases):
+	// s_flag: diagonal tiles handed to the factor wave; s_flag_li: panels whose L'^-1 and 1 / d are published; s_flag_ut: panels whose rows of block
+	// k + 1 are published; s_cnt: tile waves past step B (7 per panel: the barrier among the tile waves between B and C)
+	__shared__ int s_bad, s_flag, s_flag_li, s_flag_ut, s_cnt;
+	__shared__ int s_xcnt, s_ccnt[16];                 // back-substitution: blocks solved; contributions received per block
+	double* Ut2 = lds;                                 // [2][16][LDLM_UP]: the eliminated rows U^T of panel k in buffer k & 1; after the factorisation: the contribution slots
+	double* Li = Ut2 + 2 * 16 * LDLM_UP;               // [T][16][LDLM_LP]: L'^-1 of every diagonal block
+	double* Usub = Li + 16 * 16 * LDLM_LP;             // [T - 1][16][LDLM_LP]: the tiles (k, k + 1) below the diagonal, U^T, kept for the back-substitution's critical chain
+	double* dgs = Usub + 15 * 16 * LDLM_LP;            // the diagonal tile on its way to the factor wave
+	double* ivd = dgs + 16 * LDLM_LP;                  // 1 / d (0 beyond the unknowns)
+	double* zs = ivd + 256;                            // the eliminated right-hand side
+	double* xs = zs + 256;                             // the solution
+	K2_T0();
+	if (tid == 0) { s_bad = 0; s_flag = 0; s_flag_li = 0; s_flag_ut = 0; s_cnt = 0; s_xcnt = 0; }
+	if (tid < 16) s_ccnt[tid] = 0;
+	__syncthreads();
+	// The factor wave and the tile waves run separate code from here on (the same barriers in both): the tiles' 160 registers are not live in
+	// the factor wave's code, nor its 16 x 16 block in theirs.
+	double* contrib = Ut2;                                 // back-substitution: [J][I][16]
+	if (!tiles) {
+		// ================= the factor wave =================
+		bool bad = false;
+		for (int k = 0; k < T && !bad; ++k) {
+			double* Lik = Li + k * 16 * LDLM_LP;
+			K2_D0();
+			while (LDLM_LD(s_flag) <= k) __builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			K2_D(7);
+			// lanes 0 .. 15: row lc of the tile; lanes 16 .. 31: column lc of L'^-1 (the same update v[c] -= v[j] L'(c, j) serves both: one instruction)
+			const bool inv_lane = (lane & 48) == 16;
+			double v[16];
+#pragma unroll
+			for (int j = 0; j < 16; ++j) { const double xv = dgs[j * LDLM_LP + lc]; v[j] = inv_lane ? (j == lc ? 1.0 : 0.0) : xv; }
+			// column j: the next pivot's reciprocal is started as soon as v[j + 1] has its update, so that its dependent chain (rcp + two Newton
+			// steps, ~100 cycles of latency on an in-order wave) runs under the column's remaining updates instead of after them
+			double d = readlane_f64(v[0], 0);
+			bad |= 0 < n - 16 * k && !(d > 0.0);
+			double ivj = 0 < n - 16 * k ? rcp_f64(d) : 0.0;
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				const double f = v[j] * ivj;                                // lanes 0 .. 15: L'(row, j) below the diagonal
+				if (lane == 0) ivd[16 * k + j] = ivj;
+				double iv_next = 0.0;
+				// the column's updates in five groups, one behind each stage of the next pivot's reciprocal (v_rcp_f64, two Newton steps): the pins keep
+				// the compiler from issuing the dependent stages back to back (an in-order wave would sit through their latencies) and from putting
+				// updates off (their 120 scalars would spill the SGPRs)
+#define LDLM_GROUP(g) \
+				_Pragma("unroll") for (int c = j + 2 + 3 * (g); c < 16 && (c < j + 5 + 3 * (g) || (g) == 4); ++c) { const double lcj = readlane_f64(f, c); v[c] -= v[j] * lcj; }
+				if (j + 1 < 16) {
+					const double l1 = readlane_f64(f, j + 1);               // L'(c, j): one scalar for the elimination and the inverse
+					v[j + 1] -= v[j] * l1;                                  // (rows above c carry unused values)
+					d = readlane_f64(v[j + 1], j + 1);
+					const bool real = 16 * k + j + 1 < n;
+					bad |= real && !(d > 0.0);
+					double r = __builtin_amdgcn_rcp(d);
+					LDLM_GROUP(0); LDLM_PIN17(r, v);
+					double e = fma(-d, r, 1.0);
+					LDLM_GROUP(1); LDLM_PIN17(e, v);
+					r = fma(e, r, r);
+					LDLM_GROUP(2); LDLM_PIN17(r, v);
+					e = fma(-d, r, 1.0);
+					LDLM_GROUP(3); LDLM_PIN17(e, v);
+					r = fma(e, r, r);
+					LDLM_GROUP(4); LDLM_PIN17(r, v);
+					iv_next = real ? r : 0.0;
+				}
+#undef LDLM_GROUP
+				ivj = iv_next;
+			}
+			if (inv_lane) {
+#pragma unroll
+				for (int i = 0; i < 16; ++i) Lik[i * LDLM_LP + lc] = v[i];
+			}
+			if (k == T - 1 && lane == bcol) {
+#pragma unroll
+				for (int j = 0; j < 16; ++j) zs[16 * k + j] = j < bcol ? v[j] : 0.0;
+			}
+			if (bad && lane == 0) s_bad = 1;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) LDLM_ST(s_flag_li, k + 1);
+			K2_D(8);
+		}
+		__syncthreads();                                   // the factorisation is complete
+		if (s_bad) return false;                           // uniform
+		// back-substitution, block by block from the bottom: this wave solves a block as soon as the contributions of all later blocks are in
+		// (counted per block), the tile waves take a block's solution as soon as it is published -- flags, no barriers
+		// (the contribution of the block just solved -- tile (I, I + 1), the one thing the next block waits for -- is this wave's own work, from the
+		// copy of the tile in LDS: x stays in the lanes' registers and goes round by v_readlane; the tile waves' contributions are a block or more old)
+		// Dependent FP64 operations cost ~30 cycles each on an in-order wave: every sum below runs as four chains, and the next block's tile and
+		// inverse are read while this block's chains run.
+		double xprev = 0.0;                                // lane (mod 16) b: x of block I + 1
+		double us[16], li[16];
+#pragma unroll
+		for (int b = 0; b < 16; ++b) { us[b] = 0.0; li[b] = Li[(T - 1) * 16 * LDLM_LP + b * LDLM_LP + lc]; }
+		for (int I = T - 1; I >= 0; --I) {
+			const int g = 16 * I + lc;
+			const double zg = zs[g], ig = ivd[g];
+			double c[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int b = 0; b < 16; ++b) c[b & 3] += us[b] * readlane_f64(xprev, b);          // (us = 0 for the last block)
+			while (LDLM_LD(s_ccnt[I]) < T - 2 - I) __builtin_amdgcn_s_sleep(0);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			double cv[14];
+#pragma unroll
+			for (int o = 0; o < 14; ++o) cv[o] = contrib[(I * 16 + min(I + 2 + o, 15)) * 16 + lc];
+			double lin[16];
+#pragma unroll
+			for (int b = 0; b < 16; ++b) lin[b] = li[b];
+			if (I > 0) {                                   // the next block's operands, on their way while the chains below run
+#pragma unroll
+				for (int b = 0; b < 16; ++b) {
+					us[b] = Usub[(I - 1) * 16 * LDLM_LP + lc * LDLM_LP + b];
+					li[b] = Li[(I - 1) * 16 * LDLM_LP + b * LDLM_LP + lc];
+				}
+			}
+#pragma unroll
+			for (int o = 0; o < 14; ++o) c[o & 3] += I + 2 + o < T ? cv[o] : 0.0;
+			const double sum = (c[0] + c[1]) + (c[2] + c[3]);
+			const double v = g < n ? ig * (zg - sum) : 0.0;
+			double xa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int cc = 0; cc < 16; ++cc) xa[cc & 3] += lin[cc] * readlane_f64(v, cc);
+			const double x = (xa[0] + xa[1]) + (xa[2] + xa[3]);
+			if (lane < 16) xs[g] = x;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) LDLM_ST(s_xcnt, T - I);
+			xprev = x;
+		}
+		__syncthreads();
+	} else {
+		// ================= the tile waves =================
+		// ---- load: slot s of tile wave w holds tile 7 s + w of the column-major order (the system's upper triangle is stored too: rows along the
+		// tile's columns, coalesced) ----
+		const int n_tiles = T * (T + 1) / 2;
+		ldlm_v4d t[LDLM_TS];
+		int sT[LDLM_TS];                                   // the slots' tiles, J | I << 8 (T | T << 8: none): the back-substitution's lookup
+		{
+			int J = 0, base = 0;
+	#pragma unroll
+			for (int s = 0; s < LDLM_TS; ++s) {
+				const int idx = LDLM_TW * s + wave;
+	#pragma unroll 1
+				while (J < T && idx >= base + (T - J)) { base += T - J; ++J; }
+				const int I = J + idx - base;
+				sT[s] = J < T ? (J | I << 8) : (T | T << 8);
+				if (J < T && I < T - 1) {             // an inner tile: every element inside the system
+					const double* At = A + (size_t)(16 * J) * np + 16 * I;
+	#pragma unroll
+					for (int r = 0; r < 4; ++r) t[s][r] = At[(4 * r + lr) * np + lc];
+				} else {                                       // the last tile row (border row, identity padding); an empty slot: zero
+					const bool used = J < T;
+	#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const int a = 16 * J + 4 * r + lr, b = 16 * I + lc;         // element (row b, column a) of the system
+						const int ac = min(a, n - 1), bc = min(b, n - 1);
+						const double v = A[(size_t)(b == n ? n : ac) * np + (b == n ? ac : bc)];
+						t[s][r] = !used ? 0.0 : (a < n && b <= n) ? v : (a == b ? 1.0 : 0.0);
+					}
+				}
+			}
+		}
+		if (wave == 0) {                                   // the first diagonal tile to the factor wave
+#pragma unroll
+			for (int r = 0; r < 4; ++r) dgs[(4 * r + lr) * LDLM_LP + lc] = t[0][r];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) LDLM_ST(s_flag, 1);
+		}
+		K2_T(0);
+		for (int k = 0; k < T; ++k) {
+			double* Lik = Li + k * 16 * LDLM_LP;
+			while (LDLM_LD(s_flag_li) <= k) __builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			K2_T(1);
+			if (LDLM_LD(s_bad)) break;                     // uniform
+			double* Ut = Ut2 + (k & 1) * 16 * LDLM_UP;
+			const int dk = k * T - k * (k - 1) / 2, dk1 = dk + T - k;  // column-major numbers of the diagonal tiles (k, k) and (k + 1, k + 1)
+			// this wave's slots of the panel (-1 / empty ranges: none): the tile (k, k + 1), the next diagonal tile, the column's other tiles
+			const int s_sub = (k + 1 < T && (dk + 1) % LDLM_TW == wave) ? (dk + 1) / LDLM_TW : -1;
+			const int s_dg = (k + 1 < T && dk1 % LDLM_TW == wave) ? dk1 / LDLM_TW : -1;
+			const int b_lo = (dk + 2 - wave + LDLM_TW - 1 + LDLM_TW) / LDLM_TW - 1, b_hi = (dk1 - 1 - wave + LDLM_TW) / LDLM_TW - 1;      // 7 s + wave in [dk + 2, dk1 - 1]
+			const int c_lo = (dk1 + 1 - wave + LDLM_TW - 1 + LDLM_TW) / LDLM_TW - 1, c_hi = (n_tiles - 1 - wave + LDLM_TW) / LDLM_TW - 1; // 7 s + wave in [dk1 + 1, n_tiles - 1]
+			{
+				double la[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) la[q] = Lik[lc * LDLM_LP + 4 * q + lr];
+				// U_Ik^T = L'^-1 A_Ik^T of the tile in slot sl, published as the rows' columns 16 I ..
+#define LDLM_TRSM(sl, I) do { \
+					ldlm_v4d c4 = {0.0, 0.0, 0.0, 0.0}; \
+					_Pragma("unroll") for (int q = 0; q < 4; ++q) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], t[sl][q], c4, 0, 0, 0); \
+					t[sl] = c4; \
+					_Pragma("unroll") for (int r = 0; r < 4; ++r) Ut[(4 * r + lr) * LDLM_UP + 16 * (I) + lc] = c4[r]; \
+					if ((I) == k + 1) { _Pragma("unroll") for (int r = 0; r < 4; ++r) Usub[k * 16 * LDLM_LP + (4 * r + lr) * LDLM_LP + lc] = c4[r]; } \
+					if ((I) == T - 1 && lc == bcol) {                       /* the border row's entries of this panel: the eliminated right-hand side */ \
+						_Pragma("unroll") for (int r = 0; r < 4; ++r) zs[16 * k + 4 * r + lr] = c4[r]; \
+					} \
+				} while (0)
+#pragma unroll
+				for (int s = 0; s < LDLM_TS; ++s) {
+					if (s == s_sub) {
+						LDLM_TRSM(s, k + 1);
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						if (lane == 0) LDLM_ST(s_flag_ut, k + 1);
+					}
+				}
+#pragma unroll
+				for (int s = 0; s < LDLM_TS; ++s) {
+					if (s == s_dg) {
+						while (LDLM_LD(s_flag_ut) <= k) __builtin_amdgcn_s_sleep(1);
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+						double a[4], b[4];
+#pragma unroll
+						for (int q = 0; q < 4; ++q) { b[q] = Ut[(4 * q + lr) * LDLM_UP + 16 * (k + 1) + lc]; a[q] = b[q] * -ivd[16 * k + 4 * q + lr]; }
+#pragma unroll
+						for (int q = 0; q < 4; ++q) t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], t[s], 0, 0, 0);
+#pragma unroll
+						for (int r = 0; r < 4; ++r) dgs[(4 * r + lr) * LDLM_LP + lc] = t[s][r];
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+						if (lane == 0) LDLM_ST(s_flag, k + 2);
+					}
+				}
+#pragma unroll
+				for (int s = 0; s < LDLM_TS; ++s) {
+					if (s >= b_lo && s <= b_hi) { const int I = k + LDLM_TW * s + wave - dk; LDLM_TRSM(s, I); }
+				}
+#undef LDLM_TRSM
+			}
+			K2_T(6);
+			// the tile waves' barrier between B and C (the rows of panel k + 1 go to the other buffer: a wave may run ahead into B of the next panel
+			// while a slower one still reads this panel's rows, and nobody reaches B of panel k + 2 before all have passed this point of panel k + 1)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) atomicAdd(&s_cnt, 1);
+			while (LDLM_LD(s_cnt) < LDLM_TW * (k + 1)) __builtin_amdgcn_s_sleep(1);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			K2_T(2);
+			// ---- C: the trailing tiles (the next diagonal tile has its update already), two slots at a time: the MFMAs of one accumulator depend on
+			// each other, those of two tiles alternate ----
+			{
+				double nd[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) nd[q] = -ivd[16 * k + 4 * q + lr];
+				int J = k + 1, base = dk1;                     // the column of the running tile and its first tile's number
+#pragma unroll
+				for (int s = 0; s < LDLM_TS; s += 2) {
+					const bool on0 = s >= c_lo && s <= c_hi, on1 = s + 1 >= c_lo && s + 1 <= c_hi;
+					if (!on0 && !on1) continue;
+					int cj0 = 0, ci0 = 0, cj1 = 0, ci1 = 0;
+					if (on0) {
+						const int idx = LDLM_TW * s + wave;
+#pragma unroll 1
+						while (idx >= base + (T - J)) { base += T - J; ++J; }
+						cj0 = 16 * J; ci0 = 16 * (J + idx - base);
+					}
+					if (on1) {
+						const int idx = LDLM_TW * (s + 1) + wave;
+#pragma unroll 1
+						while (idx >= base + (T - J)) { base += T - J; ++J; }
+						cj1 = 16 * J; ci1 = 16 * (J + idx - base);
+					}
+					if (on0 && on1) {
+						double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+						for (int q = 0; q < 4; ++q) {
+							a0[q] = Ut[(4 * q + lr) * LDLM_UP + cj0 + lc] * nd[q]; b0[q] = Ut[(4 * q + lr) * LDLM_UP + ci0 + lc];
+							a1[q] = Ut[(4 * q + lr) * LDLM_UP + cj1 + lc] * nd[q]; b1[q] = Ut[(4 * q + lr) * LDLM_UP + ci1 + lc];
+						}
+#pragma unroll
+						for (int q = 0; q < 4; ++q) {
+							t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], t[s], 0, 0, 0);
+							t[s + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], t[s + 1], 0, 0, 0);
+						}
+					} else if (on0) {
+						double a0[4], b0[4];
+#pragma unroll
+						for (int q = 0; q < 4; ++q) { a0[q] = Ut[(4 * q + lr) * LDLM_UP + cj0 + lc] * nd[q]; b0[q] = Ut[(4 * q + lr) * LDLM_UP + ci0 + lc]; }
+#pragma unroll
+						for (int q = 0; q < 4; ++q) t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], t[s], 0, 0, 0);
+					} else {
+						double a1[4], b1[4];
+#pragma unroll
+						for (int q = 0; q < 4; ++q) { a1[q] = Ut[(4 * q + lr) * LDLM_UP + cj1 + lc] * nd[q]; b1[q] = Ut[(4 * q + lr) * LDLM_UP + ci1 + lc]; }
+#pragma unroll
+						for (int q = 0; q < 4; ++q) t[s + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], t[s + 1], 0, 0, 0);
+					}
+				}
+			}
+			K2_T(3);
+		}
+		__syncthreads();                                   // the factorisation is complete
+		K2_T(4);
+		if (s_bad) return false;                           // uniform
+		for (int I = T - 1; I > 1; --I) {
+			while (LDLM_LD(s_xcnt) < T - I) __builtin_amdgcn_s_sleep(0);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			const double xb = xs[16 * I + lc];
+			// this wave's tiles (J, I), the largest J first: block I - 1 is the next to be solved
+#pragma unroll
+			for (int s = LDLM_TS - 1; s >= 0; --s) {
+				int st = sT[s];
+				asm volatile("" : "+s"(st));                                // (re-derived at every use: hoisted, the slots' indices and LDS addresses spill)
+				if ((st >> 8) == I && (st & 0xFF) < I - 1) {                // (tile (I - 1, I) is the factor wave's)
+					const int J = st & 0xFF, cj = (J * 16 + I) * 16;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const double p = ldlm_row_sum16(t[s][r] * xb);
+						if (lc == 0) contrib[cj + 4 * r + lr] = p;
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					if (lane == 0) atomicAdd(&s_ccnt[J], 1);
+				}
+			}
+		}
+		__syncthreads();
+	}
+	for (int i = tid; i < n; i += NT) x_out[i] = xs[i];
+	__syncthreads();
+	K2_T(5);
+	K2_FLUSH();
+#ifdef SSK_LM_STAMPS
+	if (threadIdx.x == 0 && blockIdx.x == 0) g_k2_t[15] += 1;
+#endif
+	return true;
+}

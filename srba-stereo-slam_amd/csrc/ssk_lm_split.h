@@ -11,7 +11,7 @@
 //       reduced-gradient partials per (tile, edge) likewise.
 //   K2a lm_split_reduce_kernel      grid = windows x chunks of 7 blocks: sums a block's partial slots in slot (= tile) order into the dense bordered
 //       system (a kernel of its own: the sums are latency-bound loads that want every CU's full occupancy, not the solver's 8 wavefronts)
-//   K2  lm_split_solve_kernel       grid = windows, 512 threads: LDL^T by the register-tile solver (ldl_solve_regtile: the solver in a kernel of its own), edge update exp(eps) (+) T, the
+//   K2  lm_split_solve_kernel       grid = windows, 512 threads: LDL^T with the system in MFMA accumulator tiles (ldl_solve_mfma_tiles, ssk_lm_ldl_mfma.h; beyond 255 unknowns the register-tile solver ldl_solve_regtile), edge update exp(eps) (+) T, the
 //       trial state's suffix table.  The lambda_0 pass ends after the diagonal blocks.
 //   K3  lm_split_score_kernel       grid = tiles: landmark steps + robust error of the trial state group by group (nd_score_group), one error /
 //       |delta_f|^2 partial per tile.
@@ -51,11 +51,15 @@ struct sp_dev {
 	const int* win_map;                 // K2 / K4: workgroup -> window or -1, the same XCD as its tiles
 	int n_tile_wgs, n_win_wgs;
 	int max_pairs;                      // most 6x6 blocks of a window's reduced system (K2a's grid)
+	int solve_mfma;                     // K2: 1 = ldl_solve_mfma_tiles for every window of the batch, 0 = ldl_solve_regtile (the host's choice: ssk_sp_solve_mfma + the LDS budget)
 };
 
 constexpr int SSK_SP_WAVES = 4;         // wavefronts per K1 / K3 workgroup = landmark groups per tile
-// K2: dynamic LDS of the solve kernel (doubles): the register-tile solver's staging + the window's edge poses and trie records
-size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E);
+// K2: the solver of a batch whose largest window optimises E_max edges: true = ldl_solve_mfma_tiles (ssk_lm_ldl_mfma.h: the system in MFMA
+// accumulator tiles, up to 255 unknowns; SSK_K2_SOLVER=regtile: never), false = ldl_solve_regtile
+bool ssk_sp_solve_mfma(int E_max);
+// K2: dynamic LDS of the solve kernel (doubles): the solver's staging + the window's edge poses and trie records
+size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma);
 
 int ssk_lm_launch_split(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp_dev& S, const lm_cam& P, int n_windows, size_t solve_dyn_bytes, size_t init_dyn_bytes);
 // (ssk_lm_split_solve.hip)

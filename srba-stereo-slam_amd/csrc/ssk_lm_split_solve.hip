@@ -3,6 +3,8 @@
 // ssk_lm_device.h -- the solver in a kernel of its own), applies the edge step exp(eps) (+) T (contract L3 of oracle/oracle_lm.c) and builds
 // the trial state's suffix table.  Reference: solver_LM_schur_dense_cholesky, SRBA.h:34; call EST.cpp:782-784.
 #include "ssk_lm_split.h"
+#include <cstdlib>
+#include <cstring>
 
 #pragma clang fp contract(fast)
 
@@ -16,6 +18,10 @@ namespace {
 constexpr int REC = SSK_ND_REC, STG = SSK_ND_STAGE, LREC = SSK_ND_LREC, SCR = SSK_ND_SCR;
 constexpr int R_Q = 9, R_P = 12, R_V = 21;
 #include "ssk_lm_node_dev.h"
+#include "ssk_lm_ldl_mfma.h"
+#ifndef SSK_K2_MFMA
+#define SSK_K2_MFMA 1                    // 1: ldl_solve_mfma_tiles (the matrix in MFMA accumulator tiles) for systems up to 255 unknowns, 0: SSK_LDL_BIG always (same-box A/B: tools/split_variant.sh)
+#endif
 
 // sum of the 36-double (6-double) partial slots [a, b) at component c: eight loads in flight, adds in slot order
 template <int PITCH>
@@ -40,6 +46,9 @@ __device__ __forceinline__ double slot_sum(const double* __restrict__ p, int a, 
 	return s;
 }
 
+// MFMA: every window of the batch has at most LDLM_NMAX unknowns (the host's choice: the solvers live in two instances of the kernel, each with its own
+// register budget)
+template <bool MFMA>
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
 void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubles)
 {
@@ -79,7 +88,10 @@ void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubl
 	double* A = D.Hred + W.h0;
 	__syncthreads();
 	bool ok = true;
-	if (n6 > 0) ok = SSK_LDL_BIG(A, np, n6, s_b, s_inv, lds, lds_doubles);
+	if (n6 > 0) {
+		if constexpr (MFMA) ok = ldl_solve_mfma_tiles(A, np, n6, s_b, lds);
+		else ok = SSK_LDL_BIG(A, np, n6, s_b, s_inv, lds, lds_doubles);
+	}
 	double dpn = 0.0;
 	if (ok) {
 		for (int i = tid; i < n6; i += NT) {
@@ -113,21 +125,40 @@ void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubl
 
 }  // namespace
 
-size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E)
+#ifdef SSK_LM_STAMPS
+extern "C" int ssk_lm_k2_stamps(unsigned long long* out16, int reset)
+{
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_k2_t), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+	if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_k2_t), z, sizeof z) != hipSuccess) return 1; }
+	return 0;
+}
+#endif
+
+bool ssk_sp_solve_mfma(int E_max)
+{
+	static const bool no_mfma = [] { const char* e = std::getenv("SSK_K2_SOLVER"); return e && std::strcmp(e, "regtile") == 0; }();
+	return SSK_K2_MFMA && !no_mfma && 6 * E_max <= LDLM_NMAX;
+}
+
+size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma)
 {
 	const size_t n6p = ((size_t)6 * E + 1) & ~(size_t)1;
-	// the register-tile solver's staging (ldl_solve_regtile: L_TOTAL = 8080 doubles) + a little head room
-	return 2 * n6p + 12 * (size_t)n_edges + (((size_t)n_suf + 1) & ~(size_t)1) + 8192;
+	// the solver's staging (ldl_solve_mfma_tiles: LDLM_DOUBLES = 17 680 doubles, ldl_solve_regtile: L_TOTAL = 8 080) + a little head room
+	return 2 * n6p + 12 * (size_t)n_edges + (((size_t)n_suf + 1) & ~(size_t)1) + (mfma ? LDLM_DOUBLES + 256 : 8192);
 }
 
 int ssk_lm_launch_split_solve(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp_dev& S, const lm_cam& P, size_t dyn_bytes)
 {
 	static bool attr_set = false;
 	if (!attr_set) {
-		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
 		attr_set = true;
 	}
 	dyn_bytes = (dyn_bytes + 15) & ~(size_t)15;
-	hipLaunchKernelGGL(lm_split_solve_kernel, dim3((unsigned)S.n_win_wgs), dim3(NT), dyn_bytes, ctx->stream, D, N, S, P, (int)(dyn_bytes / 8));
+	if (S.solve_mfma)
+		hipLaunchKernelGGL(lm_split_solve_kernel<true>, dim3((unsigned)S.n_win_wgs), dim3(NT), dyn_bytes, ctx->stream, D, N, S, P, (int)(dyn_bytes / 8));
+	else
+		hipLaunchKernelGGL(lm_split_solve_kernel<false>, dim3((unsigned)S.n_win_wgs), dim3(NT), dyn_bytes, ctx->stream, D, N, S, P, (int)(dyn_bytes / 8));
 	return SSK_OK;
 }

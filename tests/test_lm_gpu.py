@@ -497,10 +497,11 @@ def test_lm_split_bench_window_and_empty(ctx, oracle, monkeypatch):
     b.close()
 
 
-@pytest.mark.parametrize("n_kf", [24, 41, 45, 59, 91])
+@pytest.mark.parametrize("n_kf", [24, 38, 41, 43, 45, 59, 91])
 def test_lm_split_dense_solver_sizes(ctx, oracle, n_kf):
-    """the default path of windows beyond LDS at the sizes where the register-tile solver's paths change: 6E = 138 (fewer tiles than threads),
-    240, 264 (three leading six-column steps in front of the register tiles), 348, 540"""
+    """the default path of windows beyond LDS at the sizes where the dense solvers' paths change: 6E = 138 (nine tile rows of the MFMA-tile solver,
+    the border row inside the last), 222 (border row 14 of the last tile row), 240 (border row = a tile row of its own), 252 (the largest system
+    of the MFMA-tile solver); beyond it the register-tile solver: 264 (three leading six-column steps in front of the register tiles), 348, 540"""
     win, gt = sl.make_submap_problem(21 if n_kf < 91 else 23, n_kf=n_kf, n_lm=(20 * n_kf if n_kf < 91 else 1500), submap_size=3, max_tree_depth=6,
                                      opt_depth=n_kf, obs_per_kf=60 if n_kf < 91 else 40)
     assert win.E == n_kf - 1

@@ -1,0 +1,105 @@
+// ldl_bench.hip -- diagnostic: the dense bordered LDL^T solvers of the phase-split LM's K2 alone, on a synthetic SPD system, `reps` solves per
+// launch (hipEvent timing): per-solve latency of one workgroup and throughput of a full grid, ldl_solve_mfma_tiles against ldl_solve_regtile,
+// checked against a host solve.  Build (cross-compiles without a GPU):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I srba-stereo-slam_amd/csrc tools/ldl_bench.hip -o _ab/ldl_bench [-DLDLM_...]
+// Run on the GPU box: _ab/ldl_bench [n = 240] [reps = 200] [workgroups = 1]
+#include "ssk_lm_split.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+
+#pragma clang fp contract(fast)
+namespace {
+#define SSK_LM_NT 512
+#undef SSK_LM_WAVES
+#define SSK_LM_WAVES 2
+#include "ssk_lm_device.h"
+constexpr int REC = SSK_ND_REC, STG = SSK_ND_STAGE, LREC = SSK_ND_LREC, SCR = SSK_ND_SCR;
+constexpr int R_Q = 9, R_P = 12, R_V = 21;
+#include "ssk_lm_node_dev.h"
+#include "ssk_lm_ldl_mfma.h"
+
+template <int WHICH>
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void bench_kernel(const double* A, int np, int n, double* x, int reps, int dyn_doubles, int* ok_out)
+{
+	extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+	const int n6p = (n + 1) & ~1;
+	double* s_b = s_dyn;
+	double* s_inv = s_b + n6p;
+	double* lds = s_inv + n6p;
+	const int lds_doubles = dyn_doubles - 2 * n6p;
+	bool ok = true;
+	for (int r = 0; r < reps; ++r) {
+		if constexpr (WHICH == 1) ok &= ldl_solve_mfma_tiles(A, np, n, s_b, lds);
+		else ok &= ldl_solve_regtile(const_cast<double*>(A), np, n, s_b, s_inv, lds, lds_doubles);
+		__syncthreads();
+	}
+	if (blockIdx.x == 0) {
+		for (int i = threadIdx.x; i < n; i += NT) x[i] = s_b[i];
+		if (threadIdx.x == 0) *ok_out = ok ? 1 : 0;
+	}
+}
+}  // namespace
+
+#define CK(c) do { hipError_t e_ = (c); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #c, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv)
+{
+	const int n = argc > 1 ? std::atoi(argv[1]) : 240, reps = argc > 2 ? std::atoi(argv[2]) : 200, wgs = argc > 3 ? std::atoi(argv[3]) : 1;
+	const int np = n | 1;
+	std::vector<double> A((size_t)(n + 1) * np, 0.0), b(n);
+	// SPD: M M^T + n I with a banded-ish random M, both triangles; border row = right-hand side
+	std::srand(7);
+	std::vector<double> M((size_t)n * n);
+	for (double& v : M) v = (std::rand() / (double)RAND_MAX - 0.5);
+	for (int i = 0; i < n; ++i)
+		for (int j = 0; j <= i; ++j) {
+			double sacc = 0.0;
+			for (int k = 0; k < n; ++k) sacc += M[(size_t)i * n + k] * M[(size_t)j * n + k];
+			if (i == j) sacc += 0.05 * n;
+			A[(size_t)i * np + j] = sacc; A[(size_t)j * np + i] = sacc;
+		}
+	for (int i = 0; i < n; ++i) { b[i] = std::rand() / (double)RAND_MAX - 0.5; A[(size_t)n * np + i] = b[i]; }
+	// host solve (Cholesky)
+	std::vector<double> L((size_t)n * n, 0.0), xr(b);
+	for (int j = 0; j < n; ++j) {
+		double d = A[(size_t)j * np + j];
+		for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+		L[(size_t)j * n + j] = std::sqrt(d);
+		for (int i = j + 1; i < n; ++i) {
+			double v = A[(size_t)i * np + j];
+			for (int k = 0; k < j; ++k) v -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+			L[(size_t)i * n + j] = v / L[(size_t)j * n + j];
+		}
+	}
+	for (int i = 0; i < n; ++i) { for (int k = 0; k < i; ++k) xr[i] -= L[(size_t)i * n + k] * xr[k]; xr[i] /= L[(size_t)i * n + i]; }
+	for (int i = n - 1; i >= 0; --i) { for (int k = i + 1; k < n; ++k) xr[i] -= L[(size_t)k * n + i] * xr[k]; xr[i] /= L[(size_t)i * n + i]; }
+	double *dA, *dx; int* dok;
+	CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dx, n * 8)); CK(hipMalloc(&dok, 4));
+	CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+	const size_t dyn = 8 * (size_t)(2 * ((n + 1) & ~1) + LDLM_DOUBLES + 256);
+	CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+	CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bench_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	for (int which = 0; which < 2; ++which) {
+		if (which == 1 && n > LDLM_NMAX) break;
+		float best = 1e30f;
+		for (int rep = 0; rep < 4; ++rep) {
+			CK(hipEventRecord(e0));
+			if (which) hipLaunchKernelGGL(bench_kernel<1>, dim3(wgs), dim3(NT), dyn, 0, dA, np, n, dx, reps, (int)(dyn / 8), dok);
+			else hipLaunchKernelGGL(bench_kernel<0>, dim3(wgs), dim3(NT), dyn, 0, dA, np, n, dx, reps, (int)(dyn / 8), dok);
+			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+			if (rep) best = std::fmin(best, ms);
+		}
+		std::vector<double> x(n); int ok;
+		CK(hipMemcpy(x.data(), dx, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost));
+		double err = 0.0, nrm = 0.0;
+		for (int i = 0; i < n; ++i) { err = std::fmax(err, std::fabs(x[i] - xr[i])); nrm = std::fmax(nrm, std::fabs(xr[i])); }
+		std::printf("%-22s n %d, %d workgroups x %d solves: %.2f us per solve (per workgroup), ok %d, max |x - x_host| / max |x_host| = %.2e\n",
+		            which ? "ldl_solve_mfma_tiles" : "ldl_solve_regtile", n, wgs, reps, 1e3 * best / reps, ok, err / nrm);
+	}
+	return 0;
+}
