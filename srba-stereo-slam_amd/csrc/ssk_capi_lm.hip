@@ -92,13 +92,10 @@ int finalize(ssk_lm_batch* b)
 		SSK_HIP(ctx, hipMalloc(&b->slab, total + total / 4));          // head room: the next keyframe's window is a little larger
 		b->slab_bytes = total + total / 4;
 	}
-	// host images that already live in the context's pinned LM arena (the lean builder's tables) go by DMA from where they are
-	const uint8_t* plo = static_cast<const uint8_t*>(ctx->pin_lm.base);
-	const uint8_t* phi = plo ? plo + ctx->pin_lm.cap : nullptr;
-	auto pinned = [&](const void* p) { return plo && (const uint8_t*)p >= plo && (const uint8_t*)p < phi; };
-	size_t up_rest = 0;
-	for (const ssk_lm_batch::req& r : b->reqs) if (r.copy > 0 && !pinned(r.src)) up_rest += ssk_pad(r.bytes);
-	const bool staged = up_rest <= (size_t)8 << 20;
+	// A small upload (one keyframe's window) is packed into the pinned staging block and goes with ONE DMA (a hipMemcpyAsync costs ~8 us of host time,
+	// a batch has two dozen tables); a large one goes table by table, by DMA straight from the host images that live in the context's pinned LM
+	// arena (the lean builder's tables: the runtime recognises pinned memory) and through the runtime's own staging for the rest.
+	const bool staged = up <= (size_t)8 << 20;
 	uint8_t* st = nullptr;
 	if (staged && up) {
 		int rc = ssk_arena_reserve(ctx, ctx->pin, up + 256);
@@ -113,23 +110,12 @@ int finalize(ssk_lm_batch* b)
 			uint8_t* d = static_cast<uint8_t*>(b->slab) + off;
 			*r.dst = d;
 			if (pass == 0) {
-				if (pinned(r.src)) SSK_HIP(ctx, hipMemcpyAsync(d, r.src, r.copy, hipMemcpyHostToDevice, ctx->stream));
-				else if (staged) { std::memcpy(st + off, r.src, r.copy); std::memset(st + off + r.copy, 0, ssk_pad(r.bytes) - r.copy); }
+				if (staged) { std::memcpy(st + off, r.src, r.copy); std::memset(st + off + r.copy, 0, ssk_pad(r.bytes) - r.copy); }
 				else SSK_HIP(ctx, hipMemcpyAsync(d, r.src, r.copy, hipMemcpyHostToDevice, ctx->stream));
 			}
 			off += ssk_pad(r.bytes);
 		}
-	if (staged && up) {
-		if (up_rest == up) SSK_HIP(ctx, hipMemcpyAsync(b->slab, st, up, hipMemcpyHostToDevice, ctx->stream));      // nothing pinned: one DMA
-		else {                                             // the staged pieces one by one (the pinned ones went directly)
-			size_t o2 = 0;
-			for (const ssk_lm_batch::req& r : b->reqs) {
-				if (r.copy == 0) continue;
-				if (!pinned(r.src)) SSK_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t*>(b->slab) + o2, st + o2, ssk_pad(r.bytes), hipMemcpyHostToDevice, ctx->stream));
-				o2 += ssk_pad(r.bytes);
-			}
-		}
-	}
+	if (staged && up) SSK_HIP(ctx, hipMemcpyAsync(b->slab, st, up, hipMemcpyHostToDevice, ctx->stream));
 	if (total > up) SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + up, 0, total - up, ctx->stream));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // host images / pinned staging are free again when create returns
 	b->reqs.clear();

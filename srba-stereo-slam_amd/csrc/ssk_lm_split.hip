@@ -357,13 +357,32 @@ void lm_split_decide_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int init)
 		// accepted: the trial state becomes the state (the tables swapped by `cur`)
 		for (int e = tid; e < W.E; e += NT) {
 			const int ei = D.slot_edge[W.us0 + e];
+			double v[12];
 #pragma unroll
-			for (int k = 0; k < 12; ++k) D.pose[12 * (size_t)(W.edge0 + ei) + k] = D.pose_new[12 * (size_t)(W.edge0 + ei) + k];
+			for (int k = 0; k < 12; ++k) v[k] = D.pose_new[12 * (size_t)(W.edge0 + ei) + k];
+#pragma unroll
+			for (int k = 0; k < 12; ++k) D.pose[12 * (size_t)(W.edge0 + ei) + k] = v[k];
 		}
-		for (int l = tid; l < W.L; l += NT) {
-			const int li = D.slot_lm[W.ls0 + l];
+		// (four landmarks per thread at a time, every load before the first store: the compiler cannot tell that lm and lm_new do not overlap, and a
+		//  local area's 4 000 landmarks copied by dependent load -> store pairs cost ~15 us per accepted step of the un-batched path)
+		const int* __restrict__ slot_lm = D.slot_lm + W.ls0;
+		const double* __restrict__ src = D.lm_new + 3 * (size_t)W.lm0;
+		double* __restrict__ dst = D.lm + 3 * (size_t)W.lm0;
+		for (int l0 = tid; l0 < W.L; l0 += 4 * NT) {
+			int li[4];
+			double v[4][3];
 #pragma unroll
-			for (int k = 0; k < 3; ++k) D.lm[3 * (size_t)(W.lm0 + li) + k] = D.lm_new[3 * (size_t)(W.lm0 + li) + k];
+			for (int u = 0; u < 4; ++u) li[u] = slot_lm[min(l0 + u * NT, W.L - 1)];
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+#pragma unroll
+				for (int k = 0; k < 3; ++k) v[u][k] = src[3 * (size_t)li[u] + k];
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				if (l0 + u * NT < W.L) {
+#pragma unroll
+					for (int k = 0; k < 3; ++k) dst[3 * (size_t)li[u] + k] = v[u][k];
+				}
 		}
 	}
 }
