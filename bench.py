@@ -221,6 +221,20 @@ def cpu_baseline_all_cores(procs, n_kf):
             "host_cores": os.cpu_count()}
 
 
+def cpu_quota():
+    """CPUs the container may use (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +271,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    torch.set_num_threads(4)                               # (no CPU tensor work to speak of: idle intra-op threads spinning after an op would eat into the box's CPU quota beside the LM builder's threads)
     import __graft_entry__ as ge
     pkg = ge.load_package()
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -527,13 +542,22 @@ def main():
             made.pop(k).close()
         dts = time.perf_counter() - t0s
         made.pop(n).close()
+        t_alone = []
+        for _ in range(3):                                 # (the same create with nothing beside it, right after the loop)
+            bq = capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar)
+            t_alone.append((bq.create_ms, bq.symbolic_ms()[0])); bq.close()
         ctx_c.close()
         sym_ms = float(np.mean(t_sym))
         return {"value_incl_symbolic": B * n / dts, "ms_per_step": 1e3 * dts / n, "steps": n,
                 "lm_symbolic_ms_per_window": sym_ms / B, "lm_symbolic_ms_per_batch": sym_ms, "host_threads": sym_thr,
                 "lm_batch_create_ms": float(np.mean(t_create)),
+                "right_after": {"lm_batch_create_ms": float(np.mean([a for a, _ in t_alone])), "lm_symbolic_ms_per_batch": float(np.mean([b_ for _, b_ in t_alone]))},
+                "host_cpu_quota": cpu_quota(),
                 "note": "every step solves an LM batch created (ssk_lm_batch_create: symbolic build on `host_threads` threads, allocation, upload) beside "
-                        "the previous step by a second host thread; lm_symbolic_ms_per_window: host time of the symbolic part / windows of the batch"}
+                        "the previous step by a second host thread; lm_symbolic_ms_per_window: host time of the symbolic part / windows of the batch.  The "
+                        "builder's threads share the container's CPU quota (host_cpu_quota, cgroup cpu.max: 16 CPUs on the GPU boxes of this pool, whatever "
+                        "the core count): back-to-back creates are bound by it (~0.26 CPU-ms per bench window -> ~60 k windows/s on 16 CPUs), a single "
+                        "create in an idle process takes 9-10 ms (symbolic 5.6 ms; tools/lm_create_time.py)"}
 
     symbolic = symbolic_pass(max(3, min(args.steps, 8))) if world == 1 and rank == 0 and not exchange else None
 

@@ -56,6 +56,10 @@ struct ssk_lm_batch {
 	int symbolic_threads = 1;
 	size_t split_solve_dyn_bytes = 0, split_init_dyn_bytes = 0;
 	bool coop_pending = false;
+	// a large batch's create returns when its uploads are done; the zero fill of its scratch (queued behind them: it may have to wait for the CUs of
+	// whatever else runs on the device) is waited for by the first stream that touches the batch
+	hipEvent_t ev_ready = nullptr;
+	bool ready_pending = false;
 	lm_cam coop_P{};
 	double* pose_bak = nullptr; double* lm_bak = nullptr;
 };
@@ -116,8 +120,19 @@ int finalize(ssk_lm_batch* b)
 			off += ssk_pad(r.bytes);
 		}
 	if (staged && up) SSK_HIP(ctx, hipMemcpyAsync(b->slab, st, up, hipMemcpyHostToDevice, ctx->stream));
-	if (total > up) SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + up, 0, total - up, ctx->stream));
-	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // host images / pinned staging are free again when create returns
+	if (!staged && total > up) {
+		// the uploads' end marked, the fill queued behind it, only the uploads waited for
+		if (!ctx->ev_lm_up) SSK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_lm_up, hipEventDisableTiming));
+		SSK_HIP(ctx, hipEventRecord(ctx->ev_lm_up, ctx->stream));
+		SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + up, 0, total - up, ctx->stream));
+		SSK_HIP(ctx, hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
+		SSK_HIP(ctx, hipEventRecord(b->ev_ready, ctx->stream));
+		b->ready_pending = true;
+		SSK_HIP(ctx, hipEventSynchronize(ctx->ev_lm_up));    // host images are free again when create returns
+	} else {
+		if (total > up) SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + up, 0, total - up, ctx->stream));
+		SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // host images / pinned staging are free again when create returns
+	}
 	b->reqs.clear();
 	return SSK_OK;
 }
@@ -415,6 +430,7 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 {
 	if (!b) return;
 	if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
+	if (b->ev_ready) (void)hipEventDestroy(b->ev_ready);
 	if (b->slab) {
 		ssk_ctx* c = b->ctx;
 		if (c && (!c->lm_slab || c->lm_slab_bytes < b->slab_bytes)) {          // keep the larger slab for the next batch
@@ -1656,6 +1672,10 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 // started from and repeats the solve with one workgroup per window (no cross-workgroup barrier, same contract).
 static int lm_batch_settle(ssk_ctx* ctx, ssk_lm_batch* b)
 {
+	if (b->ready_pending) {                           // (the create's zero fill, possibly on another context's stream)
+		SSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_ready, 0));
+		b->ready_pending = false;
+	}
 	if (!b->coop_pending) return SSK_OK;
 	b->coop_pending = false;
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1677,6 +1697,7 @@ int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b)
 	if (!b) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_reset: batch is NULL");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	b->coop_pending = false;                          // (the state is overwritten: a timed-out launch needs no repair)
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (the create's zero fill)
 	return ssk_lm_launch_reset(ctx, b->D.pose, b->D.pose0, b->n_pose, b->D.lm, b->D.lm0, b->n_lm);
 }
 

@@ -166,6 +166,7 @@ void ssk_destroy(ssk_ctx* ctx)
 	for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+	if (ctx->ev_lm_up) (void)hipEventDestroy(ctx->ev_lm_up);
 	if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }

@@ -23,6 +23,7 @@ struct ssk_ctx {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	hipEvent_t ev_lm_up = nullptr;     // end of an LM batch's uploads (ssk_capi_lm.hip: create waits for this, not for the zero fill behind it)
 	std::string err;
 	ssk_arena dev, pin;
 	ssk_arena pin_lm;                  // pinned host memory the tables of an LM batch are built in (ssk_capi_lm.hip: one DMA per table, no pageable staging)
