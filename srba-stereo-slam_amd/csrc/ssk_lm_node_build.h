@@ -141,13 +141,24 @@ inline bool eset_less(const eset& a, const eset& b)
 }
 }  // namespace nd_detail
 
+#ifdef ND_BUILD_PROF
+#include <chrono>
+static double g_nd_prof[8];
+#define ND_PROF(i) do { const auto t_ = std::chrono::steady_clock::now(); g_nd_prof[i] += std::chrono::duration<double, std::micro>(t_ - nd_prof_t_).count(); nd_prof_t_ = t_; } while (0)
+#define ND_PROF0() auto nd_prof_t_ = std::chrono::steady_clock::now()
+#else
+#define ND_PROF(i) do {} while (0)
+#define ND_PROF0() do {} while (0)
+#endif
 inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */, size_t lds_limit_doubles = 20352, bool split = false)
 {
+	ND_PROF0();
 	const int n_obs = Wn.n_obs, n_lms = Wn.n_lms_total;
 	int E = 0, L = 0;
 	for (int e = 0; e < Wn.n_edges_total; ++e) if (Wn.edge_unknown_slot[e] >= 0) ++E;
 	for (int l = 0; l < n_lms; ++l) if (Wn.lm_unknown_slot[l] >= 0) ++L;
 	if (E > 128 || waves < 1 || waves > SSK_ND_MAX_WAVES) return false;
+	ND_PROF(0);
 	// ---- suffix trie (ids in creation order: the rest of a suffix always has a smaller id); chain[id][k] = the suffix of length k + 1 on id's
 	// chain of rests (chain[id][len - 1] = id) ----
 	constexpr int MAXP = 8;                                // (SSK_LM_MAX_PATH)
@@ -190,6 +201,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	}
 	// a is a suffix of b (or b itself)
 	auto is_suffix_of = [&](int a, int b) { const int la = suf_len[(size_t)a]; return la <= suf_len[(size_t)b] && (la == 0 || chain[(size_t)b * MAXP + la - 1] == a); };
+	ND_PROF(1);
 	// ---- landmarks: observations by landmark (counting sort), then per landmark sorted so that every trie subtree is a run; nodes ----
 	std::vector<int> lo_off((size_t)n_lms + 1, 0), lo_idx((size_t)n_obs);
 	for (int o = 0; o < n_obs; ++o) lo_off[(size_t)Wn.obs_lm[o] + 1]++;
@@ -272,6 +284,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		for (size_t m = 0; m < ord.size(); ++m) sorted[m] = lms[(size_t)ord[m]];
 		lms.swap(sorted);
 	}
+	ND_PROF(2);
 	// ---- groups: greedy runs of landmarks with <= 64 observations and <= 64 lanes ----
 	hdr.n_edges = Wn.n_edges_total; hdr.E = E; hdr.n_lms = n_lms; hdr.L = L; hdr.n_obs = n_obs; hdr.n_suf = n_suf;
 	hdr.suf0 = (int)H.suf.size(); hdr.tile0 = (int)H.tile.size(); hdr.grp0 = (int)H.group.size();
@@ -324,6 +337,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		flush();
 	}
 	const size_t n_groups = H.group.size() - r_group;
+	ND_PROF(3);
 	// ---- tiles: `waves` groups each; the items of a tile sorted by 6x6 block (counting sort over the blocks the tile touches) ----
 	const int NQ = waves * 16;
 	const int n_pairs = E * (E + 1) / 2;
@@ -497,6 +511,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	}
 	hdr.n_rounds = max_rounds; hdr.max_parts = 2;
 	hdr.n_tiles = (int)n_tiles; hdr.n_groups = (int)n_groups;
+	ND_PROF(4);
 	// ---- commit ----
 	H.suf.insert(H.suf.end(), suf.begin(), suf.end());
 	H.tab_doubles += 2LL * 12 * n_suf;
@@ -514,6 +529,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		H.swin.push_back(S);
 	}
 	H.win.push_back(hdr);
+	ND_PROF(5);
 	return true;
 }
 

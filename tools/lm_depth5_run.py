@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The depth-5 LM batch of bench.py's `lm_depth5` object by itself (1 024 stage-2 windows, 4 distinct; one warm-up launch, two timed), for
-rocprofv3 passes (tools/profile_r03.sh -> profiles/r03_lm_depth5_*).  With a directory argument: summarises a --pmc pass of FP64 / wave
+rocprofv3 passes (tools/profile_r04.sh -> profiles/r04_lm_depth5_*).  With a directory argument: summarises a --pmc pass of FP64 / wave
 counters found there into JSON on stdout instead of running."""
 import csv
 import ctypes as C
@@ -30,7 +30,10 @@ def summarise(src):
     for name, k in sorted(acc.items()):
         rec = {c: v[0] / v[1] for c, v in k.items()}
         rec["dispatches"] = max(v[1] for v in k.values())
-        rec["executed_fp64_flops"] = 64.0 * (2.0 * rec.get("SQ_INSTS_VALU_FMA_F64", 0) + rec.get("SQ_INSTS_VALU_MUL_F64", 0) + rec.get("SQ_INSTS_VALU_ADD_F64", 0))
+        if "SQ_INSTS_VALU_FMA_F64" in rec:
+            rec["executed_fp64_flops"] = 64.0 * (2.0 * rec.get("SQ_INSTS_VALU_FMA_F64", 0) + rec.get("SQ_INSTS_VALU_MUL_F64", 0) + rec.get("SQ_INSTS_VALU_ADD_F64", 0))
+        if "SQ_INSTS_VALU_MFMA_MOPS_F64" in rec:             # (its own --pmc pass: the matrix cores' FP64 work, 512 flop per unit)
+            rec["executed_mfma_fp64_flops"] = 512.0 * rec["SQ_INSTS_VALU_MFMA_MOPS_F64"]
         wc = rec.get("SQ_WAVE_CYCLES", 0)
         if wc:
             rec["valu_active"] = rec.get("SQ_ACTIVE_INST_VALU", 0) / wc

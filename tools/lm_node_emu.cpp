@@ -4,6 +4,7 @@
 // textbook form): it checks the symbolic structure and the bit fields without a GPU; the kernel's lane mechanics (DPP sums, LDS
 // overlays) are not modelled.  Build: g++ -O2 -shared -fPIC tools/lm_node_emu.cpp -o <out>/liblm_node_emu.so
 #include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -308,6 +309,9 @@ double nd_emu_build_ms(const ssk_lm_window* Wn, int waves, int split, int reps)
 		nd_win hdr{};
 		if (!nd_build_window(*Wn, waves, H, hdr, 20352, split != 0)) return -1.0;
 	}
+#ifdef ND_BUILD_PROF
+	for (int i = 0; i < 6; ++i) std::fprintf(stderr, "section %d: %.1f us\n", i, g_nd_prof[i] / reps), g_nd_prof[i] = 0;
+#endif
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 

@@ -5,7 +5,7 @@
 #   r04_pmc_traffic.json               separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/pmc_traffic.py), stamped with the kernels' durations + git head
 #   r04_pmc_sq.json                    one --pmc pass of SQ counters: VALU / LDS activity of every kernel (tools/pmc_sq.py)
 #   r04_pmc_lm_wave_time.json          where the LM node kernel's wave time goes (tools/pmc_lm.sh: four --pmc passes)
-#   r04_lm_depth5_kernel_stats.csv / r04_lm_depth5_pmc.json / r04_lm_depth5_pmc_lds.json / r04_lm_depth5_traffic.json
+#   r04_lm_depth5_kernel_stats.csv / r04_lm_depth5_pmc.json / r04_lm_depth5_pmc_lds.json / r04_lm_depth5_pmc_mfma.json / r04_lm_depth5_traffic.json
 #                                      the depth-5 LM batch (tools/lm_depth5_run.py, the phase-split kernels): --stats pass, FP64 / wave counters, LDS
 #                                      counters, FETCH / WRITE sizes
 set -u
@@ -32,12 +32,14 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d5_stats -o s -- python3 $ROOTD/tools/lm_depth5_run.py > $OUT/d5_stats.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "lm_split" --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/d5_pmc -o p -- python3 $ROOTD/tools/lm_depth5_run.py > $OUT/d5_pmc.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "lm_split" --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $OUT/d5_pmc2 -o p -- python3 $ROOTD/tools/lm_depth5_run.py > $OUT/d5_pmc2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "lm_split" --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/d5_pmc3 -o p -- python3 $ROOTD/tools/lm_depth5_run.py > $OUT/d5_pmc3.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "lm_split" --pmc FETCH_SIZE --output-format csv -d $OUT/d5_fetch -o f -- python3 $ROOTD/tools/lm_depth5_run.py > $OUT/d5_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --kernel-include-regex "lm_split" --pmc WRITE_SIZE --output-format csv -d $OUT/d5_write -o w -- python3 $ROOTD/tools/lm_depth5_run.py > $OUT/d5_write.log 2>&1
 cd $ROOTD
 cp $(find $OUT/d5_stats -name "*kernel_stats.csv" | head -1) $OUT/r04_lm_depth5_kernel_stats.csv
 python3 tools/lm_depth5_run.py $OUT/d5_pmc > $OUT/r04_lm_depth5_pmc.json
 python3 tools/lm_depth5_run.py $OUT/d5_pmc2 > $OUT/r04_lm_depth5_pmc_lds.json
+python3 tools/lm_depth5_run.py $OUT/d5_pmc3 > $OUT/r04_lm_depth5_pmc_mfma.json
 python3 tools/pmc_traffic.py $OUT/d5_fetch $OUT/d5_write $OUT/r04_lm_depth5_traffic.json $OUT/d5_stats
 tail -1 $OUT/d5_stats.log | cut -c1-300
 ls -la $OUT/*.json $OUT/*.csv
