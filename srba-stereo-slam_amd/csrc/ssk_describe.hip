@@ -22,10 +22,20 @@ namespace {
 
 constexpr int PR = 22;               // patch radius: 19 (rotated |(13,13)| rounded) + 3 (blur)
 constexpr int PD = 2 * PR + 1;       // 45
-constexpr int PP = 48;               // raw patch pitch in bytes (12 dwords); pixel c of a row sits at byte shift + c
+#ifndef SSK_DESC_PP
+#define SSK_DESC_PP 48
+#endif
+constexpr int PP = SSK_DESC_PP;      // raw patch pitch in bytes (>= 48: 12 dwords of data); pixel c of a row sits at byte shift + c
 constexpr int BD = PD - 6;           // 39: blurred patch side
-constexpr int HT = 48;               // pitch (u16) of a COLUMN of the transposed horizontal-pass tile (45 rows used, dword aligned)
-constexpr int BT = 40;               // pitch (bytes) of a column of the transposed blurred tile (39 rows used)
+// (pitches and the alias below are macros for same-box A/B: tools/desc_variant.sh)
+#ifndef SSK_DESC_HT
+#define SSK_DESC_HT 50                   // 25 dwords: the vertical pass's lanes (a column each) read conflict-free; 48 (24 dwords) put every fourth column into one bank
+#endif
+#ifndef SSK_DESC_BT
+#define SSK_DESC_BT 40
+#endif
+constexpr int HT = SSK_DESC_HT;      // pitch (u16) of a COLUMN of the transposed horizontal-pass tile (45 rows used, dword aligned, an ODD number of dwords)
+constexpr int BT = SSK_DESC_BT;      // pitch (bytes) of a column of the transposed blurred tile (39 rows used)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
@@ -62,7 +72,17 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_raw[PD * PP + 16];   // + slack: the dword window of the last segment may run 1 dword past a row
 	__shared__ __attribute__((aligned(16))) uint16_t s_h[BD * HT + 8];     // horizontal pass, transposed: [column 3..41][row 0..44]
+#ifndef SSK_DESC_ALIAS
+#define SSK_DESC_ALIAS 1
+#endif
+#if SSK_DESC_ALIAS
+	// (the blurred patch takes the raw patch's place: the raw rows are dead after the horizontal pass, and the kernel's occupancy is its LDS --
+	//  7.6 KB per keypoint wave hold 20 of a CU's 32 wave slots)
+	static_assert(BD * BT <= PD * PP + 16, "the blurred tile fits the raw patch's storage");
+	uint8_t* s_b = s_raw;                      // blurred patch, transposed: [column 3..41][row 3..41]
+#else
 	__shared__ uint8_t s_b[BD * BT];           // blurred patch, transposed: [column 3..41][row 3..41]
+#endif
 	const int img = img_begin + blockIdx.y;
 	const int k = blockIdx.x;
 	if (k >= nkp[img]) return;
@@ -76,8 +96,16 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 	if (lane < PD) {                                           // a lane per patch row: 3 x 16 bytes (global dwordx4 only needs dword alignment);
 		const uint4* g = reinterpret_cast<const uint4*>(src + (size_t)(y - PR + lane) * pitch + xa);      // (a chunk per lane and turn cost 3 x the address arithmetic)
 		const uint4 v0 = g[0], v1 = g[1], v2 = g[2];
-		uint4* d = reinterpret_cast<uint4*>(s_raw) + lane * (PP / 16);
-		d[0] = v0; d[1] = v1; d[2] = v2;
+		if constexpr (PP % 16 == 0) {
+			uint4* d = reinterpret_cast<uint4*>(s_raw) + lane * (PP / 16);
+			d[0] = v0; d[1] = v1; d[2] = v2;
+		} else if constexpr (PP % 8 == 0) {
+			uint2* d = reinterpret_cast<uint2*>(s_raw) + lane * (PP / 8);
+			d[0] = uint2{v0.x, v0.y}; d[1] = uint2{v0.z, v0.w}; d[2] = uint2{v1.x, v1.y}; d[3] = uint2{v1.z, v1.w}; d[4] = uint2{v2.x, v2.y}; d[5] = uint2{v2.z, v2.w};
+		} else {
+			uint32_t* d = reinterpret_cast<uint32_t*>(s_raw) + lane * (PP / 4);
+			d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w; d[8] = v2.x; d[9] = v2.y; d[10] = v2.z; d[11] = v2.w;
+		}
 	}
 	__syncthreads();
 
