@@ -613,7 +613,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		};
 		const size_t need = tb(zn) + tb(zs) + sizeof(int) * (n_edge_t + n_lm_t + n_obs_t + n_opo_t + n_path_t + n_us_t + n_ls_t) + sizeof(double) * (12 * n_edge_t + 3 * n_lm_t) +
 		                    sizeof(float) * 4 * n_obs_t + 64 * 64;
-		static const bool no_pin = std::getenv("SSK_LM_NO_PINNED") != nullptr;
+		const bool no_pin = std::getenv("SSK_LM_NO_PINNED") != nullptr;      // (read per create: tests switch it)
 		if (!no_pin && need <= ((size_t)1 << 30)) {
 			const int rcp = ssk_arena_reserve(ctx, ctx->pin_lm, need);
 			if (rcp) return rcp;

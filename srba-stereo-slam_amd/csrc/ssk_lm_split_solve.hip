@@ -136,7 +136,8 @@ extern "C" int ssk_lm_k2_stamps(unsigned long long* out16, int reset)
 
 bool ssk_sp_solve_mfma(int E_max)
 {
-	static const bool no_mfma = [] { const char* e = std::getenv("SSK_K2_SOLVER"); return e && std::strcmp(e, "regtile") == 0; }();
+	const char* e = std::getenv("SSK_K2_SOLVER");          // (read per create: tests and same-box A/B switch it)
+	const bool no_mfma = e && std::strcmp(e, "regtile") == 0;
 	return SSK_K2_MFMA && !no_mfma && 6 * E_max <= LDLM_NMAX;
 }
 

@@ -512,6 +512,35 @@ def test_lm_split_dense_solver_sizes(ctx, oracle, n_kf):
     check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8 if n_kf < 91 else 5))
 
 
+def test_lm_split_solver_and_table_memory_switches(ctx, oracle, monkeypatch):
+    """the fallbacks of the default path give the default path's results: SSK_K2_SOLVER=regtile (the register-tile solver for a depth-5 local area
+    instead of the MFMA-tile solver: the same update to rounding level, the same verdicts) and SSK_LM_NO_PINNED=1 (the batch's tables in pageable
+    memory instead of the context's pinned arena: the same bits)"""
+    from ssk_amd import capi
+    prm = sl.make_params()
+    wins = [sl.make_submap_problem(1, **DEPTH5)[0]] + [sl.make_submap_problem(20 + i, n_kf=10 + 2 * i, n_lm=200 + 50 * i, submap_size=5, obs_per_kf=50)[0] for i in range(3)]
+    def solve():
+        b = capi.LmBatch(ctx, wins)
+        b.run(to_capi(prm))
+        r = b.results()
+        st = [b.state(i) for i in range(len(wins))]
+        b.close()
+        return r, st
+    r0, s0 = solve()
+    monkeypatch.setenv("SSK_LM_NO_PINNED", "1")
+    r1, s1 = solve()
+    monkeypatch.delenv("SSK_LM_NO_PINNED")
+    for i in range(len(wins)):
+        assert (r0[i].iters, r0[i].accepted, r0[i].err_final) == (r1[i].iters, r1[i].accepted, r1[i].err_final)
+        assert np.array_equal(s0[i][0], s1[i][0]) and np.array_equal(s0[i][1], s1[i][1])
+    monkeypatch.setenv("SSK_K2_SOLVER", "regtile")
+    r2, s2 = solve()
+    for i in range(len(wins)):
+        assert r0[i].iters == r2[i].iters and abs(r0[i].accepted - r2[i].accepted) <= 1
+        assert abs(r0[i].err_final - r2[i].err_final) <= REL * r0[i].err_final
+        assert np.abs(s0[i][0] - s2[i][0]).max() <= 1e-6
+
+
 def test_lm_split_mixed_batch_is_reproducible(ctx, oracle):
     """windows of very different sizes in ONE batch (a depth-5 local area among bench windows and small ones: no all-or-nothing kernel choice):
     every window against the oracle; reset + rerun and the same windows in another batch order give the same bits (one owner and a fixed order
