@@ -51,6 +51,10 @@ struct ssk_lm_batch {
 	sp_dev S{};
 	nd_dev N2{};                      // the phase-split windows' node tables (N: the node kernel's); both families' win[] are indexed by the batch's window number
 	int node_n = 0, split_n = 0;      // windows per family (a mixed batch runs both)
+	// pose-only windows (ssk_lm_pose.hip: one or two optimised edges, no optimised landmark -- stage 1 of define_new_keyframe): no node tables
+	int pose_n = 0, pose_two = 0;
+	const int* pose_order = nullptr;
+	size_t pose_dyn_bytes = 0;
 	double symbolic_ms = 0.0;         // host time of the symbolic build (ssk_lm_batch_symbolic_ms)
 	size_t up_bytes = 0, zero_bytes = 0;   // finalize: bytes uploaded / zeroed (SSK_TIMING)
 	int symbolic_threads = 1;
@@ -555,12 +559,15 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		else
 			for (int w = 0; w < n_windows; ++w) fn(w);
 	};
-	// ---- (1) per window: checks; its kernel family -- the persistent node kernel when the reduced system and a tile of records fit LDS, the
+	// (a kernel forced by SSK_LM_KERNEL keeps every window; SSK_LM_POSE_ONLY=0: same-box A/B)
+	const bool pose_ok = !want_split && !(std::getenv("SSK_LM_POSE_ONLY") && std::atoi(std::getenv("SSK_LM_POSE_ONLY")) == 0);
+	// ---- (1) per window: checks; its kernel family -- the pose-only kernel for a window without optimised landmarks, the persistent node kernel when the reduced system and a tile of records fit LDS, the
 	// phase-split kernels otherwise (or for every window: SSK_LM_KERNEL=split): no all-or-nothing choice for a mixed batch --; its node tables ----
 	parallel([&](int w) {
 		const ssk_lm_window& Wn = windows[w];
 		lean_win& X = lw[(size_t)w];
 		if (lm_validate_window(nullptr, Wn, w, X.E, X.L, X.s_edge, X.s_lm, X.n_path)) { X.bad = 2; return; }
+		if (pose_ok && X.L == 0 && X.E >= 1 && X.E <= 2 && Wn.n_edges_total <= 1024) { X.split = 2; return; }      // pose-only: the kernel reads the raw arrays
 		bool sp = want_split || 8 * nd_lds_doubles(Wn.n_edges_total, X.E, 4, 0) > node_lds_limit;
 		if (!sp) {
 			if (!nd_build_window(Wn, SSK_SP_WAVES, X.nh, nd_win{}, node_lds_limit / 8, false)) { X.bad = 1; return; }
@@ -577,7 +584,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	// ---- (2) bases ----
 	std::vector<lm_win> hdr((size_t)n_windows);
 	long long h_total = 0, dpt = 0, dft = 0;
-	int max_n6 = 0, n_node = 0, n_split = 0;
+	int max_n6 = 0, n_node = 0, n_split = 0, n_pose = 0, n_pose2 = 0, max_pose_edges = 0;
 	size_t n_edge_t = 0, n_lm_t = 0, n_obs_t = 0, n_opo_t = 0, n_path_t = 0, n_us_t = 0, n_ls_t = 0;
 	nd_sizes zn, zs;
 	for (int w = 0; w < n_windows; ++w) {
@@ -596,6 +603,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		max_n6 = std::max(max_n6, 6 * E);
 		n_edge_t += (size_t)Wn.n_edges_total; n_lm_t += (size_t)Wn.n_lms_total; n_obs_t += (size_t)Wn.n_obs; n_opo_t += (size_t)Wn.n_obs + 1;
 		n_path_t += (size_t)X.n_path; n_us_t += (size_t)E; n_ls_t += (size_t)L;
+		if (X.split == 2) { ++n_pose; if (E == 2) ++n_pose2; max_pose_edges = std::max(max_pose_edges, Wn.n_edges_total); continue; }
 		nd_sizes& z = X.split ? zs : zn;
 		X.off = z;
 		nd_sizes_add(z, nd_sizes_of(X.nh));
@@ -647,6 +655,8 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		put(&path_edge[0] + H.path0, Wn.path_edge, (size_t)X.n_path);
 		put(&slot_edge[0] + H.us0, X.s_edge.data(), X.s_edge.size());
 		put(&slot_lm[0] + H.ls0, X.s_lm.data(), X.s_lm.size());
+		w_split[(size_t)w] = X.split;
+		if (X.split == 2) { std::vector<int>().swap(X.s_edge); std::vector<int>().swap(X.s_lm); return; }
 		nd_win& nw = X.nh.win[0];
 		nw.edge0 = H.edge0; nw.lm0 = H.lm0; nw.us0 = H.us0; nw.ls0 = H.ls0; nw.trace0 = H.trace0; nw.dp_trace0 = H.dp_trace0; nw.df_trace0 = H.df_trace0;
 		nw.h0 = H.h0;
@@ -659,6 +669,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		std::vector<int>().swap(X.s_edge); std::vector<int>().swap(X.s_lm);
 	});
 	for (int w = 0; w < n_windows; ++w) {
+		if (lw[(size_t)w].split == 2) continue;
 		nd_host& Dh = lw[(size_t)w].split ? NHs : NHn;
 		const nd_host& W1 = lw[(size_t)w].nh;
 		Dh.lds_doubles = std::max(Dh.lds_doubles, W1.lds_doubles); Dh.lds_doubles_big = std::max(Dh.lds_doubles_big, W1.lds_doubles_big);
@@ -683,7 +694,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	const bool by_size = [] { const char* oe = std::getenv("SSK_LM_ORDER"); return !oe || std::atoi(oe) != 0; }();
 	auto ordered = [&](const nd_host& NH, bool sp) {
 		std::vector<int> ord;
-		for (int w = 0; w < n_windows; ++w) if ((bool)w_split[(size_t)w] == sp) ord.push_back(w);
+		for (int w = 0; w < n_windows; ++w) if (w_split[(size_t)w] == (sp ? 1 : 0)) ord.push_back(w);
 		if (by_size)
 			std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return (long long)NH.win[(size_t)a].n_obs * (NH.win[(size_t)a].E + 4) > (long long)NH.win[(size_t)c].n_obs * (NH.win[(size_t)c].E + 4); });
 		return ord;
@@ -763,6 +774,13 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		b->S.solve_mfma = mfma ? 1 : 0;
 		b->split_solve_dyn_bytes = 8 * sd; b->split_init_dyn_bytes = 8 * id;
 		if (b->split_solve_dyn_bytes > node_lds_limit || b->split_init_dyn_bytes > node_lds_limit) { delete b; return 1; }
+	}
+	std::vector<int> ord_p;
+	if (n_pose) {
+		for (int w = 0; w < n_windows; ++w) if (w_split[(size_t)w] == 2) ord_p.push_back(w);
+		if (by_size) std::stable_sort(ord_p.begin(), ord_p.end(), [&](int a, int c) { return hdr[(size_t)a].n_obs > hdr[(size_t)c].n_obs; });
+		if (!rc) rc = upload(b, ord_p, &b->pose_order);
+		b->pose_n = n_pose; b->pose_two = n_pose2; b->pose_dyn_bytes = sizeof(double) * 24 * (size_t)max_pose_edges;
 	}
 	D.store_hff = 0;
 	if (!rc) rc = upload(b, pose, const_cast<const double**>(&D.pose));
@@ -1723,6 +1741,7 @@ int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a run on top of a timed-out cooperative launch continues from the repaired state)
 	if (b->lean) {
 		// a mixed batch: the small windows on the persistent node kernel, the others on the phase-split kernels, one after the other on the stream
+		if (b->pose_n) { const int rc1 = ssk_lm_launch_pose_only(ctx, b->D, b->pose_order, P, b->pose_n, b->pose_two, b->pose_dyn_bytes); if (rc1) return rc1; }
 		if (b->node_n) { const int rc1 = ssk_lm_launch_node(ctx, b->D, b->N, P, b->node_n, b->node_dyn_bytes, false); if (rc1) return rc1; }
 		if (b->split_n) return ssk_lm_launch_split(ctx, b->D, b->N2, b->S, P, b->split_n, b->split_solve_dyn_bytes, b->split_init_dyn_bytes);
 		return SSK_OK;
@@ -1767,6 +1786,7 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 	const char* name = "lm_solve_kernel";
 	if (b->split_ok) name = "lm_split_linearise_kernel";      // (the heaviest kernel of a pass; a mixed batch also runs lm_solve_node_kernel on its small windows)
 	else if (b->node_ok) name = b->node_big ? "lm_solve_node_big_kernel" : "lm_solve_node_kernel";
+	else if (b->lean && b->pose_n) name = "lm_pose_only_kernel";
 	else if (b->acc_ok) name = b->schur_mfma ? "lm_solve_acc_mfma_kernel" : "lm_solve_acc_kernel";
 	else if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) {
 		bool coop = false;

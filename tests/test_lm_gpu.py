@@ -114,6 +114,38 @@ def test_lm_stage1_edges_only_and_empty(ctx, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("n_free,robust", [(1, True), (1, False), (2, True), (2, False)])
+def test_lm_pose_only_windows_per_iteration(ctx, oracle, n_free, robust):
+    """windows that optimise one or two edges and no landmark (stage 1 of define_new_keyframe: the new edge(s), every landmark held) run on
+    lm_pose_only_kernel (no node tables): per iteration against the oracle, with and without the robust kernel, paths of several edges through the
+    optimised ones in both directions; in a batch beside a window of another family; reset + rerun gives the same bits"""
+    from ssk_amd import capi
+    win, gt = sl.make_submap_problem(31 + n_free, n_kf=16, n_lm=260, submap_size=5, obs_per_kf=70)
+    slots = np.full(len(win.edge_unknown_slot), -1, np.int32)
+    order = np.argsort(-win.edge_unknown_slot)[:n_free]            # the newest edges
+    for k, e in enumerate(sorted(order)):
+        slots[e] = k
+    w1 = sl.Window(slots, win.edge_inv_pose, -np.ones(len(win.lm_pos), np.int32), gt["gt_lm"], win.obs_lm, win.obs_px, win.obs_path_off, win.path_edge)
+    assert w1.E == n_free and w1.L == 0
+    b = capi.LmBatch(ctx, [w1])
+    assert b.kernel_name() == "lm_pose_only_kernel"
+    b.close()
+    prm = sl.make_params(robust=robust)
+    res = check_against_oracle(ctx, oracle, w1, prm)
+    assert res.err_final <= res.err_init
+    other = sl.make_submap_problem(5, n_kf=12, n_lm=200, submap_size=5, obs_per_kf=50)[0]
+    b = capi.LmBatch(ctx, [other, w1, w1])
+    b.run(to_capi(prm))
+    r1 = b.results(); s1 = b.state(1)
+    b.reset(); b.run(to_capi(prm))
+    r2 = b.results(); s2 = b.state(2)
+    assert (r1[1].iters, r1[1].err_final) == (res.iters, res.err_final) == (r2[2].iters, r2[2].err_final)
+    assert np.array_equal(s1[0], s2[0])
+    exp = oracle.lm_solve(other, prm, trace=False)
+    assert r1[0].iters == exp["res"].iters
+    b.close()
+
+
 def test_lm_batch_of_ragged_windows_and_reset(ctx, oracle):
     """several windows of different sizes in one launch; reset + rerun reproduces the result bit for bit
     (deterministic summation order, no float atomics)."""
