@@ -560,6 +560,8 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			for (int w = 0; w < n_windows; ++w) fn(w);
 	};
 	// (a kernel forced by SSK_LM_KERNEL keeps every window; SSK_LM_POSE_ONLY=0: same-box A/B)
+	// (SSK_LM_FEW_SPLIT=0: a small batch keeps the node kernel for every window that fits it -- tests of that kernel on single windows, same-box A/B)
+	const bool few_windows = n_windows <= 8 && !std::getenv("SSK_LM_KERNEL") && !(std::getenv("SSK_LM_FEW_SPLIT") && std::atoi(std::getenv("SSK_LM_FEW_SPLIT")) == 0);
 	const bool pose_ok = !want_split && !(std::getenv("SSK_LM_POSE_ONLY") && std::atoi(std::getenv("SSK_LM_POSE_ONLY")) == 0);
 	// ---- (1) per window: checks; its kernel family -- the pose-only kernel for a window without optimised landmarks, the persistent node kernel when the reduced system and a tile of records fit LDS, the
 	// phase-split kernels otherwise (or for every window: SSK_LM_KERNEL=split): no all-or-nothing choice for a mixed batch --; its node tables ----
@@ -568,7 +570,9 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		lean_win& X = lw[(size_t)w];
 		if (lm_validate_window(nullptr, Wn, w, X.E, X.L, X.s_edge, X.s_lm, X.n_path)) { X.bad = 2; return; }
 		if (pose_ok && X.L == 0 && X.E >= 1 && X.E <= 2 && Wn.n_edges_total <= 1024) { X.split = 2; return; }      // pose-only: the kernel reads the raw arrays
-		bool sp = want_split || 8 * nd_lds_doubles(Wn.n_edges_total, X.E, 4, 0) > node_lds_limit;
+		// (a handful of windows -- the un-batched drop-in -- cannot fill the device with one persistent workgroup each: a window of more than a few
+		//  tiles goes to the phase-split kernels, which spread its tiles over workgroups: 3.5 -> ~1 ms for the 14-edge local areas at a stream's start)
+		bool sp = want_split || 8 * nd_lds_doubles(Wn.n_edges_total, X.E, 4, 0) > node_lds_limit || (few_windows && Wn.n_obs > 1024);
 		if (!sp) {
 			if (!nd_build_window(Wn, SSK_SP_WAVES, X.nh, nd_win{}, node_lds_limit / 8, false)) { X.bad = 1; return; }
 			if (8 * X.nh.lds_doubles > node_lds_limit) { sp = true; X.nh = nd_host(); }

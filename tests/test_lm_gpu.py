@@ -371,12 +371,25 @@ def test_lm_golden_case_on_gpu(ctx):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_lm_bench_windows_against_oracle(ctx, oracle, seed):
+def test_lm_bench_windows_against_oracle(ctx, oracle, seed, monkeypatch):
     """The exact windows bench.py times (BASELINE configs[2]: 200 keyframes / 5000 landmarks, submap 10, tree depth 4, window =
-    the 10 most recent edges; seeds 0-7 on rank 0), per iteration against the oracle."""
+    the 10 most recent edges; seeds 0-7 on rank 0), per iteration against the oracle, on the kernel the bench's batch runs them on (the node
+    kernel; a batch of a few such windows would go to the phase-split kernels: SSK_LM_FEW_SPLIT=0 keeps the batch rule) -- and, for two seeds,
+    on the phase-split kernels a single window of this size takes by default."""
+    from ssk_amd import capi
     win = sl.make_submap_problem(seed, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2,
                                  obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0]
     assert win.E == 10 and len(win.obs_lm) > 1000
+    if seed < 2:
+        b = capi.LmBatch(ctx, [win])
+        assert b.kernel_name() == "lm_split_linearise_kernel"
+        b.close()
+        res = check_against_oracle(ctx, oracle, win, sl.make_params(), min_accept=2)
+        assert res.stop_reason in (1, 4) and res.err_final < res.err_init
+    monkeypatch.setenv("SSK_LM_FEW_SPLIT", "0")
+    b = capi.LmBatch(ctx, [win])
+    assert b.kernel_name() == "lm_solve_node_kernel"
+    b.close()
     res = check_against_oracle(ctx, oracle, win, sl.make_params(), min_accept=2)
     assert res.stop_reason in (1, 4) and res.err_final < res.err_init
 
