@@ -96,7 +96,7 @@ def test_configs4_at_its_stated_size_accelerated_rounds(ctx, oracle, pkg):
     J = oracle.lm_solve(joint, prm, trace=False)
     dev = torch.device("cuda:0")
     b = capi.LmBatch(ctx, wins)
-    assert b.kernel_name() == "lm_solve_node_kernel"
+    assert b.kernel_name() == "lm_split_linearise_kernel"   # (a batch of 8 windows of 1.4 k observations: the phase-split kernels; 9+ windows: the node kernel)
     cp = to_capi(prm)
     d_idx = [torch.from_numpy(i.astype(np.int32)).to(dev) for i in idxs]
     gathered = torch.zeros(n_sub * S * 12, dtype=torch.float64, device=dev)
