@@ -569,7 +569,8 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		const ssk_lm_window& Wn = windows[w];
 		lean_win& X = lw[(size_t)w];
 		if (lm_validate_window(nullptr, Wn, w, X.E, X.L, X.s_edge, X.s_lm, X.n_path)) { X.bad = 2; return; }
-		if (pose_ok && X.L == 0 && X.E >= 1 && X.E <= 2 && Wn.n_edges_total <= 1024) { X.split = 2; return; }      // pose-only: the kernel reads the raw arrays
+		// pose-only: the kernel reads the raw arrays (its edge poses, twice, in LDS: 48 KB at 256 edges -- inside the 64 KB a launch gets without asking)
+		if (pose_ok && X.L == 0 && X.E >= 1 && X.E <= 2 && Wn.n_edges_total <= 256) { X.split = 2; return; }
 		// (a handful of windows -- the un-batched drop-in -- cannot fill the device with one persistent workgroup each: a window of more than a few
 		//  tiles goes to the phase-split kernels, which spread its tiles over workgroups: 3.5 -> ~1 ms for the 14-edge local areas at a stream's start)
 		bool sp = want_split || 8 * nd_lds_doubles(Wn.n_edges_total, X.E, 4, 0) > node_lds_limit || (few_windows && Wn.n_obs > 1024);
