@@ -27,7 +27,7 @@ constexpr int PD = 2 * PR + 1;       // 45
 #endif
 constexpr int PP = SSK_DESC_PP;      // raw patch pitch in bytes (>= 48: 12 dwords of data); pixel c of a row sits at byte shift + c
 constexpr int BD = PD - 6;           // 39: blurred patch side
-// (pitches and the alias below are macros for same-box A/B: tools/desc_variant.sh)
+// (pitches and the alias below are macros for same-box A/B: tools/kernel_variant.sh ssk_describe)
 #ifndef SSK_DESC_HT
 #define SSK_DESC_HT 50                   // 25 dwords: the vertical pass's lanes (a column each) read conflict-free; 48 (24 dwords) put every fourth column into one bank
 #endif
