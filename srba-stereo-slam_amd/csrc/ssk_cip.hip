@@ -19,7 +19,10 @@
 
 namespace {
 
-constexpr int NT = 256, NW = NT / 64;
+#ifndef SSK_CIP_NT
+#define SSK_CIP_NT 128                  // (256: 0.46 ms per 1 024 pairs, 128 and 64: 0.21 -- the kernel is latency per Gauss-Newton pass at 256 VGPRs: the smaller the workgroup, the more pairs a CU holds)
+#endif
+constexpr int NT = SSK_CIP_NT, NW = NT / 64;
 constexpr int MAXM = SSK_MAX_FEATS;      // matches per keyframe
 
 struct cip_pose { double R[9], t[3]; };

@@ -17,7 +17,10 @@
 
 namespace {
 
-constexpr int NT = 256;
+#ifndef SSK_FM_NT
+#define SSK_FM_NT 256
+#endif
+constexpr int NT = SSK_FM_NT;
 #ifndef SSK_FM_HR
 #define SSK_FM_HR 8
 #endif
