@@ -4,7 +4,7 @@
 //
 // Why a kernel of its own.  With the landmarks held there is no Schur complement: H = sum J^T J is 6 x 6 (12 x 12 for two edges), g = sum J^T r.
 // The general node kernel (ssk_lm_node.hip) spends 21 us per LM attempt on such a window -- group phase, a pair phase whose single block keeps
-// 8 lanes busy, a tile solver with barriers per 4 columns, table rebuilds -- of which nothing is arithmetic.  Here: one 256-thread workgroup per
+// 8 lanes busy, a tile solver with barriers per 4 columns, table rebuilds -- of which nothing is arithmetic.  Here: one 128-thread workgroup per
 // window, a thread per observation in turn (chain of the path's edge poses -> stereo projection -> the 4 x 6 Jacobian block per optimised path
 // entry, registers only), the lower triangle of H and g summed by a fixed shuffle tree + the waves' partials in wave order (bit-reproducible),
 // the 6E x 6E system factorised (L D L^T, positive pivots as the contract's Cholesky) by one thread in registers, the trial error by all threads.
@@ -16,7 +16,10 @@
 
 namespace {
 
-#define SSK_LM_NT 256
+#ifndef SSK_PO_NT
+#define SSK_PO_NT 128                   // (1 024 stage-1 windows: 0.68 ms at 256 threads, 0.39 at 128, 0.49 at 64; one window: the same 0.30 ms)
+#endif
+#define SSK_LM_NT SSK_PO_NT
 #include "ssk_lm_device.h"
 
 // one observation at the current state: weighted residual and the weighted 4 x 6 Jacobian block of each optimised edge on its path
