@@ -17,7 +17,10 @@
 namespace {
 
 constexpr int TT = 512;
-constexpr int NT = 1024, NW = NT / 64;   // 16 waves: the batch gives one workgroup per CU, so latency is hidden inside it
+#ifndef SSK_ST_NT
+#define SSK_ST_NT 1024
+#endif
+constexpr int NT = SSK_ST_NT, NW = NT / 64;   // 16 waves: the batch gives one workgroup per CU, so latency is hidden inside it
 
 __global__ __launch_bounds__(NT)
 void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__ kp_xy, const int32_t* __restrict__ nkp,
