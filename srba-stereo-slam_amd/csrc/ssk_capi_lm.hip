@@ -552,7 +552,28 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	// (3) the batch-wide host images and tables filled, side by side again.  Nothing heavy is serial.
 	struct lean_win { int E = 0, L = 0, n_path = 0; std::vector<int> s_edge, s_lm; nd_host nh; nd_sizes off; char split = 0, bad = 0; };
 	std::vector<lean_win> lw((size_t)n_windows);
-	static const int n_thr_max = [] { const char* e = std::getenv("SSK_LM_BUILD_THREADS"); const int hc = (int)std::thread::hardware_concurrency(); return e ? std::max(1, std::atoi(e)) : std::max(1, std::min(hc / 2, 64)); }();
+	// host threads of the symbolic build: SSK_LM_BUILD_THREADS, else half the logical cores, at most 64 -- and at most TWICE the container's CPU quota
+	// (cgroup cpu.max; the GPU boxes of this pool: 16 CPUs of 256): measured back to back on such a box, 1 024 bench windows per create: 64 threads
+	// 14.9 ms, 32 threads 9.7 ms, 16 threads 13.8 ms, 8 threads 22.2 ms (bursts above the quota are fine, sustained oversubscription is throttled)
+	static const int n_thr_max = [] {
+		if (const char* e = std::getenv("SSK_LM_BUILD_THREADS")) return std::max(1, std::atoi(e));
+		const int hc = (int)std::thread::hardware_concurrency();
+		int n = std::max(1, std::min(hc / 2, 64));
+		double quota = 0.0;
+		if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                  // cgroup v2: "<quota us | max> <period us>"
+			char q[32]; double per = 0.0;
+			if (std::fscanf(f, "%31s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) quota = std::atof(q) / per;
+			std::fclose(f);
+		} else if (FILE* f1 = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
+			double qv = 0.0, per = 0.0;
+			if (std::fscanf(f1, "%lf", &qv) != 1) qv = 0.0;
+			std::fclose(f1);
+			if (FILE* f2 = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(f2, "%lf", &per) != 1) per = 0.0; std::fclose(f2); }
+			if (qv > 0 && per > 0) quota = qv / per;
+		}
+		if (quota > 0.0) n = std::max(2, std::min(n, (int)(2.0 * quota + 0.5)));
+		return n;
+	}();
 	const int n_thr_used = std::max(1, std::min(n_thr_max, n_windows / 8));      // (a thread is worth it from a handful of windows on)
 	auto parallel = [&](const std::function<void(int)>& fn) {
 		if (n_thr_used > 1) lm_pool().run(n_thr_used, n_windows, fn);
