@@ -556,8 +556,9 @@ def main():
                 "note": "every step solves an LM batch created (ssk_lm_batch_create: symbolic build on `host_threads` threads, allocation, upload) beside "
                         "the previous step by a second host thread; lm_symbolic_ms_per_window: host time of the symbolic part / windows of the batch.  The "
                         "builder's threads share the container's CPU quota (host_cpu_quota, cgroup cpu.max: 16 CPUs on the GPU boxes of this pool, whatever "
-                        "the core count): back-to-back creates are bound by it (~0.26 CPU-ms per bench window -> ~60 k windows/s on 16 CPUs), a single "
-                        "create in an idle process takes 9-10 ms (symbolic 5.6 ms; tools/lm_create_time.py)"}
+                        "the core count): back-to-back creates are bound by it, which is why the library caps its builder threads at twice the quota "
+                        "(64 threads: 14.9 ms per create, 32: 9.7, 16: 13.8; tools/sym_threads.sh); a single create in an idle process takes ~10 ms "
+                        "(symbolic 6.5 ms; tools/lm_create_time.py)"}
 
     symbolic = symbolic_pass(max(3, min(args.steps, 8))) if world == 1 and rank == 0 and not exchange else None
 
