@@ -258,7 +258,10 @@ void lm_split_reduce_kernel(lm_dev D, nd_dev N, sp_dev S)
 }
 
 // ---- K3: trial state of one tile: landmark steps + robust error (init != 0: the error of the initial state, no step) ----
-__global__ __launch_bounds__(NT, 4)
+#ifndef SP_K3_WAVES
+#define SP_K3_WAVES 5                   // (34.74 ms per 1 024 depth-5 windows at 4 waves per SIMD, 34.50 at 5, 34.70 at 6, 40.0 at 8: spills)
+#endif
+__global__ __launch_bounds__(NT, SP_K3_WAVES)
 void lm_split_score_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P_arg, int init)
 {
 	__shared__ lm_cam s_P;
