@@ -199,7 +199,10 @@ __device__ int run_stage(const ssk_cip_params& c, cip_pose& T, int n, const doub
 	return it;
 }
 
-__global__ __launch_bounds__(NT)
+#ifndef SSK_CIP_WAVES
+#define SSK_CIP_WAVES 1
+#endif
+__global__ __launch_bounds__(NT, SSK_CIP_WAVES)
 void cip_kernel(const int32_t* __restrict__ train_idx, int32_t* __restrict__ status, const int32_t* __restrict__ out_beg,
                 const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end, const int32_t* __restrict__ t_beg,
                 const float4* __restrict__ this_obs, const float4* __restrict__ other_obs, const double* __restrict__ init_poses,
