@@ -94,11 +94,22 @@ int finalize(ssk_lm_batch* b)
 	for (const ssk_lm_batch::req& r : b->reqs) { if (r.copy > 0) up += ssk_pad(r.bytes); total += ssk_pad(r.bytes); }
 	if (total == 0) total = 256;
 	b->up_bytes = up; b->zero_bytes = total - up;
-	if (ctx->lm_slab && ctx->lm_slab_bytes >= total) { b->slab = ctx->lm_slab; b->slab_bytes = ctx->lm_slab_bytes; ctx->lm_slab = nullptr; ctx->lm_slab_bytes = 0; }
-	else {
-		if (ctx->lm_slab) { SSK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->lm_slab); ctx->lm_slab = nullptr; ctx->lm_slab_bytes = 0; }
-		SSK_HIP(ctx, hipMalloc(&b->slab, total + total / 4));          // head room: the next keyframe's window is a little larger
-		b->slab_bytes = total + total / 4;
+	{
+		// the smallest cached slab that fits; none: a new one (a cached one that is too small makes room for it)
+		int pick = -1;
+		for (int k = 0; k < ssk_ctx::LM_SLABS; ++k)
+			if (ctx->lm_slab[k] && ctx->lm_slab_bytes[k] >= total && (pick < 0 || ctx->lm_slab_bytes[k] < ctx->lm_slab_bytes[pick])) pick = k;
+		if (pick >= 0) { b->slab = ctx->lm_slab[pick]; b->slab_bytes = ctx->lm_slab_bytes[pick]; ctx->lm_slab[pick] = nullptr; ctx->lm_slab_bytes[pick] = 0; }
+		else {
+			int small = -1;
+			for (int k = 0; k < ssk_ctx::LM_SLABS; ++k)
+				if (ctx->lm_slab[k] && (small < 0 || ctx->lm_slab_bytes[k] < ctx->lm_slab_bytes[small])) small = k;
+			bool full = true;
+			for (int k = 0; k < ssk_ctx::LM_SLABS; ++k) full = full && ctx->lm_slab[k];
+			if (full && small >= 0) { SSK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->lm_slab[small]); ctx->lm_slab[small] = nullptr; ctx->lm_slab_bytes[small] = 0; }
+			SSK_HIP(ctx, hipMalloc(&b->slab, total + total / 4));          // head room: the next keyframe's window is a little larger
+			b->slab_bytes = total + total / 4;
+		}
 	}
 	// A small upload (one keyframe's window) is packed into the pinned staging block and goes with ONE DMA (a hipMemcpyAsync costs ~8 us of host time,
 	// a batch has two dozen tables); a large one goes table by table, by DMA straight from the host images that live in the context's pinned LM
@@ -437,10 +448,18 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 	if (b->ev_ready) (void)hipEventDestroy(b->ev_ready);
 	if (b->slab) {
 		ssk_ctx* c = b->ctx;
-		if (c && (!c->lm_slab || c->lm_slab_bytes < b->slab_bytes)) {          // keep the larger slab for the next batch
-			if (c->lm_slab) (void)hipFree(c->lm_slab);
-			c->lm_slab = b->slab; c->lm_slab_bytes = b->slab_bytes;
-		} else (void)hipFree(b->slab);
+		// back to the context's cache: an empty place, else the place of a smaller slab (that one is freed), else freed
+		int place = -1;
+		if (c) {
+			for (int k = 0; k < ssk_ctx::LM_SLABS && place < 0; ++k) if (!c->lm_slab[k]) place = k;
+			if (place < 0) {
+				int small = 0;
+				for (int k = 1; k < ssk_ctx::LM_SLABS; ++k) if (c->lm_slab_bytes[k] < c->lm_slab_bytes[small]) small = k;
+				if (c->lm_slab_bytes[small] < b->slab_bytes) { (void)hipFree(c->lm_slab[small]); place = small; }
+			}
+		}
+		if (place >= 0) { c->lm_slab[place] = b->slab; c->lm_slab_bytes[place] = b->slab_bytes; }
+		else (void)hipFree(b->slab);
 	}
 	delete b;
 }

@@ -160,7 +160,7 @@ void ssk_destroy(ssk_ctx* ctx)
 	if (ctx->pin.base) (void)hipHostFree(ctx->pin.base);
 	if (ctx->pin_lm.base) (void)hipHostFree(ctx->pin_lm.base);
 	if (ctx->single) ssk_kfbatch_destroy_internal(ctx->single);
-	if (ctx->lm_slab) (void)hipFree(ctx->lm_slab);
+	for (void* sl : ctx->lm_slab) if (sl) (void)hipFree(sl);
 	if (ctx->d_dir_thresh) (void)hipFree(ctx->d_dir_thresh);
 	if (ctx->d_pattern) (void)hipFree(ctx->d_pattern);
 	for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);

@@ -36,8 +36,11 @@ struct ssk_ctx {
 	int8_t* d_pattern = nullptr;
 	int orb_steering = 1;              // C7: 1 = cv::ORB's (float)cos / (float)sin of the fastAtan2 angle (include/ssk_sincos.h), 0 = exact centroid direction
 	struct ssk_kfbatch* single = nullptr;   // 1-keyframe batch behind the host drop-in ssk_frontend_run
-	void* lm_slab = nullptr;                // device slab of the last destroyed LM batch, reused by the next one (the host
-	size_t lm_slab_bytes = 0;               // drop-in creates and destroys a batch per keyframe: no hipMalloc in steady state)
+	// device slabs of destroyed LM batches, reused by the next ones (the host drop-in creates and destroys two batches per keyframe -- the new edge's
+	// window and the local area's, the second one built while the first is solved: no hipMalloc in steady state)
+	static constexpr int LM_SLABS = 2;
+	void* lm_slab[LM_SLABS] = {nullptr, nullptr};
+	size_t lm_slab_bytes[LM_SLABS] = {0, 0};
 	int n_cu = 256;
 	// per-stage HIP-event profiler (ssk_profile_*): event pairs recorded around kernel launches on the
 	// context stream while enabled; resolved into per-stage sums at ssk_profile_read.

@@ -419,7 +419,11 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 	// -- on request (SSK_FACADE_OVERLAP=1).  Measured on one box, 401 frames, ms per keyframe frame: one after the other 8.53 / 8.54, overlapped
 	// 8.30 / 8.98 (the hand-over costs what it saves); with the batch creation on the second thread too: 9.13 (allocation and uploads beside a
 	// running solve serialise in the runtime).  Default: one after the other.
-	static const bool overlap = std::getenv("SSK_FACADE_OVERLAP") && std::atoi(std::getenv("SSK_FACADE_OVERLAP")) != 0;
+	// Round 4, the default (SSK_FACADE_OVERLAP=2 or unset): the SAME thread collects and creates the local-area window between the launch of stage 1
+	// and the read-back of its result -- the host work hides stage 1's solve (~0.25 ms of device time per keyframe), nothing is handed over; the
+	// library keeps two device slabs per context for the two batches that are alive together.  0: one after the other, 1: the second thread.
+	static const int overlap_mode = std::getenv("SSK_FACADE_OVERLAP") ? std::atoi(std::getenv("SSK_FACADE_OVERLAP")) : 2;
+	const bool overlap = overlap_mode == 1;
 	lm_job j2;
 	auto prepare_stage2 = [&]() {
 		// (the device solver's reduced system holds 128 edges, include/ssk_capi.h: a local area beyond that -- a revisit that ties several
@@ -450,14 +454,15 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 		lm_job j1;
 		lm_prepare(j1, opt, refs, false, true);
 		lm_launch(j1, parameters.use_robust_kernel_stage1, false);
+		if (overlap_mode == 2) prepare_stage2();           // (reads the map before stage 1's result is written to it: its poses are refreshed below)
 		// (lm_collect writes the new edges' poses to the map: only after the worker has stopped reading it)
 		if (overlap) m_worker->wait();
 		if (worker_error) std::rethrow_exception(worker_error);
 		lm_collect(j1, out.optimize_results_stg1);
 	}
-	if (!overlap) prepare_stage2();
-	else lm_create(j2);
-	lm_launch(j2, parameters.use_robust_kernel, overlap);
+	if (overlap_mode == 0) prepare_stage2();
+	else if (overlap) lm_create(j2);
+	lm_launch(j2, parameters.use_robust_kernel, overlap_mode != 0);
 	lm_collect(j2, out.optimize_results);
 }
 
