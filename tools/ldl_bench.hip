@@ -2,7 +2,7 @@
 // launch (hipEvent timing): per-solve latency of one workgroup and throughput of a full grid, ldl_solve_mfma_tiles against ldl_solve_regtile,
 // checked against a host solve.  Build (cross-compiles without a GPU):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I srba-stereo-slam_amd/csrc tools/ldl_bench.hip -o _ab/ldl_bench [-DLDLM_...]
-// Run on the GPU box: _ab/ldl_bench [n = 240] [reps = 200] [workgroups = 1]
+// Run on the GPU box: _ab/ldl_bench [n = 240] [reps = 200] [workgroups = 1] [index of a diagonal entry to make negative: the failure path]
 #include "ssk_lm_split.h"
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +48,7 @@ void bench_kernel(const double* A, int np, int n, double* x, int reps, int dyn_d
 int main(int argc, char** argv)
 {
 	const int n = argc > 1 ? std::atoi(argv[1]) : 240, reps = argc > 2 ? std::atoi(argv[2]) : 200, wgs = argc > 3 ? std::atoi(argv[3]) : 1;
+	const int bad_at = argc > 4 ? std::atoi(argv[4]) : -1;      // >= 0: that diagonal entry made negative -- both solvers must report failure (ok 0), not hang
 	const int np = n | 1;
 	std::vector<double> A((size_t)(n + 1) * np, 0.0), b(n);
 	// SPD: M M^T + n I with a banded-ish random M, both triangles; border row = right-hand side
@@ -62,6 +63,7 @@ int main(int argc, char** argv)
 			A[(size_t)i * np + j] = sacc; A[(size_t)j * np + i] = sacc;
 		}
 	for (int i = 0; i < n; ++i) { b[i] = std::rand() / (double)RAND_MAX - 0.5; A[(size_t)n * np + i] = b[i]; }
+	if (bad_at >= 0 && bad_at < n) A[(size_t)bad_at * np + bad_at] = -1.0e6;
 	// host solve (Cholesky)
 	std::vector<double> L((size_t)n * n, 0.0), xr(b);
 	for (int j = 0; j < n; ++j) {
