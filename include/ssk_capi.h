@@ -17,6 +17,14 @@
  *     asynchronous on the context's HIP stream.
  *   - there is NO CPU fallback anywhere behind this interface: without a usable gfx950 device
  *     ssk_create fails with SSK_ERR_NO_DEVICE and every other call needs a context.
+ *   - THREADS: a context serves ONE host thread at a time.  It owns staging state that calls reuse without
+ *     locks (the device / pinned arenas, the pinned arena an LM batch's tables are built in, the slab cache
+ *     of destroyed LM batches, the error text, the stage profiler).  Concurrent callers take a context
+ *     each (contexts are cheap: a stream and lazily grown arenas; bench.py's symbolic pass builds the next
+ *     batch on one context while another context's stream solves the current one).  Objects made by one
+ *     context may be USED through another (ssk_lm_batch_reset / _run / _results take the context whose
+ *     stream they enqueue on; ssk_lm_batch_destroy waits for the last such use before the creating
+ *     context's slab cache takes the memory back), but never by two threads at once.
  */
 #ifndef SSK_CAPI_H
 #define SSK_CAPI_H

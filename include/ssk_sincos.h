@@ -10,7 +10,7 @@
 #ifndef SSK_SINCOS_H
 #define SSK_SINCOS_H
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SSK_SINCOS_FN __host__ __device__ static inline
 #else
 #define SSK_SINCOS_FN static inline

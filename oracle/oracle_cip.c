@@ -141,7 +141,7 @@ int ssko_change_in_pose(const float* this_obs, int n_this, const float* other_ob
 	memset(out, 0, sizeof *out);
 	pair_t* pr = (pair_t*)malloc(sizeof(pair_t) * (size_t)(n_this > 0 ? n_this : 1));
 	int* idx = (int*)malloc(sizeof(int) * (size_t)(n_this > 0 ? n_this : 1));
-	unsigned char* act = (unsigned char*)malloc((size_t)(n_this > 0 ? n_this : 1));
+	unsigned char* act = (unsigned char*)calloc((size_t)(n_this > 0 ? n_this : 1), 1);      /* (zeroed: entries beyond the n tracked pairs are never read, gcc cannot see that) */
 	const ssko_stereo_cam cam = {c->fx_l, c->fy_l, c->cx_l, c->cy_l, c->fx_r, c->fy_r, c->cx_r, c->cy_r, c->baseline};
 	int n = 0;
 	for (int k = 0; k < n_this; ++k) {                     /* [literal EST.cpp:2120-2133] */

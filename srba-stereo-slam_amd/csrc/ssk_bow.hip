@@ -362,11 +362,11 @@ int launch_query(ssk_ctx* ctx, ssk_bow_db* db, const int32_t* q_word, const doub
 		static const bool no_bitmap = std::getenv("SSK_BOW_NO_BITMAP") != nullptr;
 		const int bm_dwords = (!no_bitmap && db->voc->n_words <= BOW_BITMAP_WORDS_MAX / 2) ? (db->voc->n_words + 31) / 32 : 0;
 		const size_t lds = 12 * (size_t)BOW_SORT_MAX + 8 * (size_t)bm_dwords;
-		static bool attr_set = false;
-		if (!attr_set) {
+		static ssk_dev_once attr_once;      // (the attribute is per device)
+		if (attr_once.need(ctx->device)) {
 			SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(bow_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 			                                 12 * BOW_SORT_MAX + BOW_BITMAP_WORDS_MAX / 8));
-			attr_set = true;
+			attr_once.done(ctx->device);
 		}
 		hipLaunchKernelGGL(bow_score_kernel, dim3(nq, (ne + 63) / 64), dim3(64), lds, ctx->stream, q_word, q_val, q_n, q_stride, q_begin, db->words,
 		                   db->vals, db->ent_n, db->stride, db->cap, ne, d_max_ids, bm_dwords, db->scores, db->cap);

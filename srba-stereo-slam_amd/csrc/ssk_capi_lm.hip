@@ -64,6 +64,10 @@ struct ssk_lm_batch {
 	// whatever else runs on the device) is waited for by the first stream that touches the batch
 	hipEvent_t ev_ready = nullptr;
 	bool ready_pending = false;
+	// a batch may be reset / run on ANOTHER context's stream than the one that created it (bench.py's symbolic pass: one thread creates, another
+	// runs): the end of the last such use, so that ssk_lm_batch_destroy does not recycle a slab that stream still writes (an event, not the context:
+	// the other context may be gone by then)
+	hipEvent_t ev_last = nullptr;
 	lm_cam coop_P{};
 	double* pose_bak = nullptr; double* lm_bak = nullptr;
 };
@@ -310,6 +314,15 @@ static lm_cam cam_of(const ssk_lm_params* p)
 	return P;
 }
 
+// end of an operation that queued work on the batch: remembered when the stream is not the creating context's (ssk_lm_batch_destroy waits for it)
+static int lm_batch_mark(ssk_ctx* ctx, ssk_lm_batch* b, int rc)
+{
+	if (ctx == b->ctx) return rc;
+	if (!b->ev_last) SSK_HIP(ctx, hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming));
+	SSK_HIP(ctx, hipEventRecord(b->ev_last, ctx->stream));
+	return rc;
+}
+
 int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, const int32_t* d_lm_idx, const ssk_lm_params* p, double* d_out)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
@@ -320,7 +333,7 @@ int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared,
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	hipLaunchKernelGGL(pack_shared_kernel, dim3((n_shared + 63) / 64), dim3(64), 0, ctx->stream, b->D, cam_of(p), w, n_shared, d_lm_idx, d_out);
 	SSK_LAUNCH_CHECK(ctx, "pack_shared_kernel");
-	return SSK_OK;
+	return lm_batch_mark(ctx, b, SSK_OK);
 }
 
 int ssk_lm_batch_set_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, const int32_t* d_lm_idx, const double* d_pos)
@@ -333,7 +346,7 @@ int ssk_lm_batch_set_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, 
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a timed-out cooperative launch is repaired first: its restore would overwrite what is written here)
 	hipLaunchKernelGGL(set_shared_kernel, dim3((n_shared + 255) / 256), dim3(256), 0, ctx->stream, b->D, const_cast<double*>(b->D.lm0), w, n_shared, d_lm_idx, d_pos);
 	SSK_LAUNCH_CHECK(ctx, "set_shared_kernel");
-	return SSK_OK;
+	return lm_batch_mark(ctx, b, SSK_OK);
 }
 
 int ssk_lm_batch_set_export(ssk_ctx* ctx, ssk_lm_batch* b, int on)
@@ -445,7 +458,10 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 {
 	if (!b) return;
 	if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
-	if (b->ev_ready) (void)hipEventDestroy(b->ev_ready);
+	// the slab goes back to the creating context's cache (a later create may take it, a later destroy may free it): nothing may still be in flight on
+	// it -- the create's own zero fill (when no stream waited for it yet) and whatever another context's stream was given to do on the batch
+	if (b->ev_ready) { if (b->ready_pending) (void)hipEventSynchronize(b->ev_ready); (void)hipEventDestroy(b->ev_ready); }
+	if (b->ev_last) { (void)hipEventSynchronize(b->ev_last); (void)hipEventDestroy(b->ev_last); }
 	if (b->slab) {
 		ssk_ctx* c = b->ctx;
 		// back to the context's cache: an empty place, else the place of a smaller slab (that one is freed), else freed
@@ -642,8 +658,10 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		H.n_pairs = E * (E + 1) / 2; H.n_tiles = -1;
 		H.edge0 = (int)n_edge_t; H.lm0 = (int)n_lm_t; H.obs0 = (int)n_obs_t; H.opo0 = (int)n_opo_t; H.path0 = (int)n_path_t;
 		H.us0 = (int)n_us_t; H.ls0 = (int)n_ls_t;
-		H.trace0 = w * MAX_ITERS_ALLOC; H.h0 = h_total; H.dp_trace0 = dpt; H.df_trace0 = dft;
-		h_total += (long long)(6 * E + 1) * (6 * E + 2);
+		H.trace0 = w * MAX_ITERS_ALLOC; H.h0 = 0; H.dp_trace0 = dpt; H.df_trace0 = dft;
+		// (the dense bordered system in HBM is the phase-split kernels': node and pose-only windows keep theirs on chip -- a mixed batch of 1 024
+		// windows would otherwise zero tens of MB per create for nothing)
+		if (X.split == 1) { H.h0 = h_total; h_total += (long long)(6 * E + 1) * (6 * E + 2); }
 		if (trace) { dpt += (long long)MAX_ITERS_ALLOC * 6 * E; dft += (long long)MAX_ITERS_ALLOC * 3 * L; }
 		max_n6 = std::max(max_n6, 6 * E);
 		n_edge_t += (size_t)Wn.n_edges_total; n_lm_t += (size_t)Wn.n_lms_total; n_obs_t += (size_t)Wn.n_obs; n_opo_t += (size_t)Wn.n_obs + 1;
@@ -668,6 +686,16 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		                    sizeof(float) * 4 * n_obs_t + 64 * 64;
 		const bool no_pin = std::getenv("SSK_LM_NO_PINNED") != nullptr;      // (read per create: tests switch it)
 		if (!no_pin && need <= ((size_t)1 << 30)) {
+			// the arena only grows inside ssk_arena_reserve: after one large batch a context would hold up to 1 GB of pinned host memory until
+			// ssk_destroy.  Eight creates in a row that need less than a quarter of it give it back (a streak, not one small create: bench.py and
+			// the facade alternate batch sizes, and hipHostMalloc of a few hundred MB costs tens of ms).  No create of this context is in flight
+			// here (a context serves one thread at a time, include/ssk_capi.h) and every earlier create waited for its uploads.
+			if (ctx->pin_lm.base && ctx->pin_lm.cap > ((size_t)64 << 20) && 4 * (need + 4096) < ctx->pin_lm.cap) {
+				if (++ctx->pin_lm_small_streak >= 8) {
+					(void)hipHostFree(ctx->pin_lm.base);
+					ctx->pin_lm.base = nullptr; ctx->pin_lm.cap = 0; ctx->pin_lm.used = 0; ctx->pin_lm_small_streak = 0;
+				}
+			} else ctx->pin_lm_small_streak = 0;
 			const int rcp = ssk_arena_reserve(ctx, ctx->pin_lm, need);
 			if (rcp) return rcp;
 			bump.base = static_cast<char*>(ctx->pin_lm.base); bump.cap = ctx->pin_lm.cap; bump.used = 0;
@@ -1761,12 +1789,18 @@ int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b)
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	b->coop_pending = false;                          // (the state is overwritten: a timed-out launch needs no repair)
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (the create's zero fill)
-	return ssk_lm_launch_reset(ctx, b->D.pose, b->D.pose0, b->n_pose, b->D.lm, b->D.lm0, b->n_lm);
+	return lm_batch_mark(ctx, b, ssk_lm_launch_reset(ctx, b->D.pose, b->D.pose0, b->n_pose, b->D.lm, b->D.lm0, b->n_lm));
 }
 
+static int lm_batch_run_impl(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p);
 int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
+	const int rc = lm_batch_run_impl(ctx, b, p);
+	return b ? lm_batch_mark(ctx, b, rc) : rc;
+}
+static int lm_batch_run_impl(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
+{
 	if (!b || !p) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: NULL argument");
 	if (p->max_iters < 0 || (b->trace && p->max_iters > b->max_iters_alloc))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_run: max_iters %d outside [0,%d] for a traced batch", p->max_iters, b->max_iters_alloc);

@@ -330,10 +330,10 @@ int ssk_launch_fm(ssk_ctx* ctx, const int32_t* d_train_idx, int32_t* d_status, c
 	if (cap < 1) cap = 1;
 	if (cap > MAXM) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "fundamental-matrix filter: %d matches per keyframe (> %d)", cap, MAXM);
 	cap = (cap + 15) & ~15;
-	static bool attr_set = false;
-	if (!attr_set) {
+	static ssk_dev_once attr_once;      // (the attribute is per device)
+	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * (MAXM + 16)));
-		attr_set = true;
+		attr_once.done(ctx->device);
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_FUND_MATRIX);
 	hipLaunchKernelGGL(fm_kernel, dim3(n_pairs), dim3(NT), 36 * (size_t)cap, ctx->stream, d_train_idx, d_status, d_out_beg, d_q_beg, d_q_end, d_t_beg,

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/ssk_capi.h"
@@ -27,6 +28,7 @@ struct ssk_ctx {
 	std::string err;
 	ssk_arena dev, pin;
 	ssk_arena pin_lm;                  // pinned host memory the tables of an LM batch are built in (ssk_capi_lm.hip: one DMA per table, no pageable staging)
+	int pin_lm_small_streak = 0;       // consecutive creates that used less than a quarter of pin_lm (eight: the arena is given back)
 	std::vector<void*> retired;        // arenas replaced by bigger ones; freed at destroy / next sync
 	// direction-filter bin thresholds (see ssk_da_filters.hip): smallest float quotient mapped to
 	// bin >= b for b = 9..27, computed once on the host with the host libm's atanf.
@@ -51,6 +53,14 @@ struct ssk_ctx {
 	std::vector<prof_rec> prof_open;
 	double prof_ms[SSK_STAGE_COUNT] = {0};
 	long long prof_calls[SSK_STAGE_COUNT] = {0};
+};
+
+// "once per device" for settings that belong to a device, not to the process (hipFuncSetAttribute: a second context on another GPU needs its own
+// call); two threads that both see `need` set the same value twice, which is harmless
+struct ssk_dev_once {
+	std::atomic<unsigned long long> mask{0};
+	bool need(int dev) const { return dev < 0 || dev >= 64 || !((mask.load(std::memory_order_acquire) >> dev) & 1ull); }
+	void done(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
 };
 
 hipEvent_t ssk_prof_event(ssk_ctx* ctx);

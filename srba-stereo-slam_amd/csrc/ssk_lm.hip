@@ -566,10 +566,10 @@ int ssk_lm_launch(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows,
 	const size_t red_bytes = (size_t)NW * RED_WAVE * sizeof(double);      // wave_sum36 scratch, aliased with the matrix
 	dyn = red_bytes;
 	if (need <= LDS_BUDGET && max_n6 <= 127) { cap = max_n6; dyn = need > red_bytes ? need : red_bytes; }
-	static bool attr_set = false;
-	if (!attr_set) {
+	static ssk_dev_once attr_once;      // (the attribute is per device)
+	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-		attr_set = true;
+		attr_once.done(ctx->device);
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	hipLaunchKernelGGL(lm_solve_kernel, dim3(n_windows), dim3(NT), dyn, ctx->stream, D, P, cap);

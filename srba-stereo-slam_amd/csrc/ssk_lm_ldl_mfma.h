@@ -168,7 +168,7 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 #pragma unroll
 				for (int j = 0; j < 16; ++j) zs[16 * k + j] = j < bcol ? v[j] : 0.0;
 			}
-			if (bad && lane == 0) s_bad = 1;
+			if (bad && lane == 0) s_bad = k + 1;                // (the failing panel + 1: the tile waves all leave AT that panel, see below)
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			if (lane == 0) LDLM_ST(s_flag_li, k + 1);
 			K2_D(8);
@@ -264,7 +264,12 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 			while (LDLM_LD(s_flag_li) <= k) __builtin_amdgcn_s_sleep(1);
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			K2_T(1);
-			if (LDLM_LD(s_bad)) break;                     // uniform
+			// A failed pivot (the contract's failed Cholesky) ends the factorisation for every wave at the SAME panel: the factor wave runs up to a
+			// panel ahead of the slowest tile wave (the owners of tile (k, k + 1) and of the next diagonal tile hand panel k + 1 over before the
+			// counter barrier of panel k), so a wave still on its way to panel k may already see the failure of panel k + 1 -- it must not leave
+			// before panel k's counter has its seven arrivals, or the waves that passed this check earlier spin on it for ever.  s_bad = failing
+			// panel + 1, written before that panel's s_flag_li: every tile wave reads it here at the failing panel itself.
+			{ const int sb = LDLM_LD(s_bad); if (sb != 0 && sb - 1 <= k) break; }      // uniform
 			double* Ut = Ut2 + (k & 1) * 16 * LDLM_UP;
 			const int dk = k * T - k * (k - 1) / 2, dk1 = dk + T - k;  // column-major numbers of the diagonal tiles (k, k) and (k + 1, k + 1)
 			// this wave's slots of the panel (-1 / empty ranges: none): the tile (k, k + 1), the next diagonal tile, the column's other tiles

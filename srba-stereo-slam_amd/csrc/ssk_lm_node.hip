@@ -395,11 +395,11 @@ void lm_solve_node_big_kernel(lm_dev D, nd_dev N, lm_cam P, int dyn_doubles)
 int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, bool big)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
-	static bool attr_set = false;
-	if (!attr_set) {
+	static ssk_dev_once attr_once;      // (the attribute is per device)
+	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_node_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_node_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-		attr_set = true;
+		attr_once.done(ctx->device);
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	if (big) hipLaunchKernelGGL(lm_solve_node_big_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, N, P, (int)(dyn_lds_bytes / 8));

@@ -404,11 +404,11 @@ extern "C" int ssk_lm_split_stamps(unsigned long long* out16, int reset)
 int ssk_lm_launch_split(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp_dev& S, const lm_cam& P, int n_windows, size_t solve_dyn_bytes, size_t init_dyn_bytes)
 {
 	(void)n_windows;
-	static bool attr_set = false;
-	if (!attr_set) {
+	static ssk_dev_once attr_once;      // (the attribute is per device)
+	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_linearise_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_init_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-		attr_set = true;
+		attr_once.done(ctx->device);
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	const size_t lin_lds = sizeof(double) * (size_t)NDW * 64 * REC;

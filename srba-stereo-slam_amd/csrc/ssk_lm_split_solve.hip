@@ -150,11 +150,11 @@ size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma)
 
 int ssk_lm_launch_split_solve(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp_dev& S, const lm_cam& P, size_t dyn_bytes)
 {
-	static bool attr_set = false;
-	if (!attr_set) {
+	static ssk_dev_once attr_once;      // (the attribute is per device)
+	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-		attr_set = true;
+		attr_once.done(ctx->device);
 	}
 	dyn_bytes = (dyn_bytes + 15) & ~(size_t)15;
 	if (S.solve_mfma)

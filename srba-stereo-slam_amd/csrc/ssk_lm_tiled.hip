@@ -1550,15 +1550,15 @@ int ssk_lm_coop_blocks_per_cu(ssk_ctx* ctx, size_t dyn_lds_bytes, int schur_mfma
 int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, int G, size_t dyn_lds_bytes, bool test_timeout, int schur_mfma)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
-	static bool attr_set = false;
-	if (!attr_set) {
+	static ssk_dev_once attr_once;      // (the attribute is per device)
+	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_coop_ldlm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
-		attr_set = true;
+		attr_once.done(ctx->device);
 	}
 	SSK_HIP(ctx, hipMemsetAsync(D.coop_i, 0, sizeof(int) * 4 * (size_t)n_windows, ctx->stream));
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
@@ -1577,11 +1577,11 @@ int ssk_lm_launch_coop(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_win
 int ssk_lm_launch_acc(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
-	static bool attr_set = false;
-	if (!attr_set) {
+	static ssk_dev_once attr_once;      // (the attribute is per device)
+	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_acc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_acc_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
-		attr_set = true;
+		attr_once.done(ctx->device);
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	if (schur_mfma) hipLaunchKernelGGL(lm_solve_acc_mfma_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));
@@ -1593,8 +1593,8 @@ int ssk_lm_launch_acc(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_wind
 int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma, bool lds_sys)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
-	static bool attr_set = false;
-	if (!attr_set) {
+	static ssk_dev_once attr_once;      // (the attribute is per device)
+	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1603,7 +1603,7 @@ int ssk_lm_launch_tiled(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_wi
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_tiled_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                                 SSK_LMT_LDS_TOTAL - SSK_LMT_STATIC));
-		attr_set = true;
+		attr_once.done(ctx->device);
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	if (schur_mfma == 2) hipLaunchKernelGGL(lm_solve_tiled_ldlm_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, P, (int)(dyn_lds_bytes / 8));

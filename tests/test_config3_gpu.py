@@ -16,9 +16,12 @@ sequence; the checks are properties of the domain:
     last 86 m to themselves, nothing ties the far end to the start, so what is checked is dead reckoning: a random walk whose size depends
     on the frame source's seed.  Round 4 measured the DISTRIBUTION (tools/drift_sweep.py, profiles/r04_drift_sweep.json: five seeds, both
     ORB steering forms): along track 0.008-0.25 %, 3-D 0.15-6.1 % of the path, seed 9 -- the only seed of rounds 1-3 -- the outlier in both
-    forms (6.1 % / 3.3 %); the medians are 0.011 % and 0.47 %.  The test runs seeds 9, 10, 11 and asserts the MEDIAN against the bounds of
-    rounds 1-2 (0.2 % along track, 3.5 % in 3-D, 0.1 rad of heading) and every single run against the 3 sigma bounds (0.5 %, 12 %, 0.25 rad),
-  * the pose-graph optimisation lowers its cost.
+    forms (6.1 % / 3.3 %); the medians are 0.011 % and 0.47 %.  The test runs seeds 9, 10, 13 -- the three of the sweep whose revisit links
+    keyframes to old local maps (6, 18 and 1 keyframes with extra edges; seeds 11 and 12 close no loop at all, so they cannot guard the
+    loop-closing path) -- and asserts the MEDIAN against the bounds of rounds 1-2 (0.2 % along track, 3.5 % in 3-D, 0.1 rad of heading) and
+    every single run against the 3 sigma bounds (0.5 %, 12 %, 0.25 rad),
+  * EVERY seed: loop-closing edges beyond the chain exist and the pose-graph optimisation lowers its cost (round 5, ADVICE r4: the checks
+    had become conditional on seed 9).
 Runs tools/stream_full.py's run(); the same function feeds bench.py's `unbatched` object."""
 import os
 import sys
@@ -46,7 +49,7 @@ def test_config3_full_length_stream(pkg):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import stream_full
     drifts = []
-    for seed in (9, 10, 11):
+    for seed in (9, 10, 13):
         o = stream_full.run(N_FRAMES, N_BACK, seed=seed, verbose=False)
         assert o["frames"] == N_FRAMES and o["invalid_odometry"] == [] and o["error_increased"] == [], seed
         kf = np.array(o["kf_frames"])
@@ -60,12 +63,12 @@ def test_config3_full_length_stream(pkg):
         X = o["poses"].reshape(-1, 3, 4)
         # the keyframes of the way back sit on the places of the way out
         assert abs(X[-1, 1, 3] + 0.54 * o["kf_pos"][-1]) < 0.005 * path
-        if o["multi_edge_kfs"] >= 1:            # (a chain without loop-closing edges is a tree: the pose graph has nothing to move)
-            assert o["pg_iters"] >= 1 and o["pg_cost_final"] < o["pg_cost_init"]
+        # loop-closing edges beyond the chain on every seed (a regression that loses them must not pass), and a pose graph that has something to move
+        assert o["multi_edge_kfs"] >= 1 and o["edges"] >= o["keyframes"] - 1 + 1, (seed, o["multi_edge_kfs"], o["edges"])
+        assert o["pg_iters"] >= 1 and o["pg_cost_final"] < o["pg_cost_init"], (seed, o["pg_cost_init"], o["pg_cost_final"])
         t = o["timing"]
         assert t["frames"] == N_FRAMES and t["kf_frames"] == o["keyframes"] - 1 and t["lm_solves"] == 2 * t["kf_frames"]       # stage 1 + stage 2 per keyframe
         if seed == 9:
-            assert o["edges"] >= o["keyframes"] - 1 + 1 and o["multi_edge_kfs"] >= 1      # loop-closing edges beyond the chain
             assert o["pg_cost_final"] < 0.1 * o["pg_cost_init"]
         print("configs[3] seed %d: %d frames, %d keyframes, %d edges, %.1f frames/s un-batched, %.2f ms per keyframe frame; confirmed_loop_closure flags %d, "
               "keyframes linked to an old local map %d; drift along track %.3f %%, 3-D %.2f %%, heading %.3f; pose graph %.4g -> %.4g"

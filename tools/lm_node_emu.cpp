@@ -315,6 +315,34 @@ double nd_emu_build_ms(const ssk_lm_window* Wn, int waves, int split, int reps)
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 
+// shape statistics of a window's node tables (tools: LDS budgeting): out[0..] = n_edges, E, n_suf, n_groups, n_tiles, n_obs, lanes, nodes, roots,
+// max nodes per group, max roots per group, max obs per group, max lanes per group, items, max blocks per tile, lds_doubles
+int nd_emu_shape(const ssk_lm_window* Wn, int waves, int* out /* 16 */)
+{
+	nd_host H;
+	nd_win hdr{};
+	if (!nd_build_window(*Wn, waves, H, hdr, 20352, false)) return -1;
+	const nd_win& W = H.win[0];
+	int nodes = 0, roots = 0, mxn = 0, mxr = 0, mxo = 0, mxl = 0;
+	for (int g = 0; g < W.n_groups; ++g) {
+		const nd_group& G = H.group[(size_t)g];
+		int gn = 0, gr = 0;
+		for (int a = 0; a < G.n_lanes; ++a) { const int k = H.lane[(size_t)G.lane0 + a].w & 0xFF; gn += k == 2; gr += k == 1; }
+		nodes += gn; roots += gr;
+		mxn = std::max(mxn, gn); mxr = std::max(mxr, gr); mxo = std::max(mxo, G.n_obs); mxl = std::max(mxl, G.n_lanes);
+	}
+	int mxb = 0;
+	for (int t = 0; t < W.n_tiles; ++t) {
+		const nd_tile& T = H.tile[(size_t)t];
+		int nb = 0;
+		for (int k = 0; k < T.n_rounds * waves * 16; ++k) nb += (H.qs[(size_t)T.qs0 + k].x & 0xFFFF) != 0xFFFF;
+		mxb = std::max(mxb, nb);
+	}
+	const int v[16] = {W.n_edges, W.E, W.n_suf, W.n_groups, W.n_tiles, W.n_obs, (int)H.lane.size(), nodes, roots, mxn, mxr, mxo, mxl, (int)H.item.size(), mxb, (int)H.lds_doubles};
+	std::memcpy(out, v, sizeof v);
+	return 0;
+}
+
 int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lambda, int pre, int waves, double* Hred, double* g, const double* dp, double* df,
                      double* vmax_out, int* stats /* tiles, groups, items, max items per lane */)
 {
