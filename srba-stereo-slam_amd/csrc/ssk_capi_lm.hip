@@ -43,6 +43,7 @@ struct ssk_lm_batch {
 	// node form (ssk_lm_node.hip): built when every window of the batch fits it (reduced system + a tile of node records in LDS)
 	bool gtab_multi = false;          // the per-workgroup suffix tables of the windows whose table lives in L2 scratch were sized for the cooperative kernel (64 copies)
 	bool node_ok = false, node_big = false;
+	bool node_small = false;          // every node-kernel window has E <= 10: the kernel variant whose only dense solver is ldl_solve_blocks6_wave
 	nd_dev N{};
 	size_t node_dyn_bytes = 0;
 	// phase-split node form (ssk_lm_split.hip): windows whose reduced system does not fit LDS (the depth-5 local areas) -- and lean batches:
@@ -782,6 +783,8 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		ord_n = ordered(NHn, false);
 		if (!rc) rc = upload(b, ord_n, &b->N.order);
 		b->node_dyn_bytes = 8 * NHn.lds_doubles;
+		b->node_small = true;
+		for (const nd_win& nw : NHn.win) b->node_small = b->node_small && nw.E <= 10;      // (placeholders of the other families: E = 0)
 	}
 	if (n_split) {
 #define UPN(vec, field) if (!rc) rc = upload(b, NHs.vec, &b->N2.field)
@@ -1666,6 +1669,8 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 #undef UPN
 		b->node_big = node_big;
 		b->node_dyn_bytes = 8 * (node_big ? NH.lds_doubles_big : NH.lds_doubles);
+		b->node_small = !node_big;
+		for (const nd_win& nw : NH.win) b->node_small = b->node_small && nw.E <= 10;
 		if (std::getenv("SSK_LM_DEBUG"))
 		{
 			long long rounds = 0;
@@ -1821,11 +1826,11 @@ static int lm_batch_run_impl(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params*
 	if (b->lean) {
 		// a mixed batch: the small windows on the persistent node kernel, the others on the phase-split kernels, one after the other on the stream
 		if (b->pose_n) { const int rc1 = ssk_lm_launch_pose_only(ctx, b->D, b->pose_order, P, b->pose_n, b->pose_two, b->pose_dyn_bytes); if (rc1) return rc1; }
-		if (b->node_n) { const int rc1 = ssk_lm_launch_node(ctx, b->D, b->N, P, b->node_n, b->node_dyn_bytes, false); if (rc1) return rc1; }
+		if (b->node_n) { const int rc1 = ssk_lm_launch_node(ctx, b->D, b->N, P, b->node_n, b->node_dyn_bytes, false, b->node_small); if (rc1) return rc1; }
 		if (b->split_n) return ssk_lm_launch_split(ctx, b->D, b->N2, b->S, P, b->split_n, b->split_solve_dyn_bytes, b->split_init_dyn_bytes);
 		return SSK_OK;
 	}
-	if (b->node_ok) return ssk_lm_launch_node(ctx, b->D, b->N, P, b->n_windows, b->node_dyn_bytes, b->node_big);
+	if (b->node_ok) return ssk_lm_launch_node(ctx, b->D, b->N, P, b->n_windows, b->node_dyn_bytes, b->node_big, b->node_small);
 	if (b->acc_ok) return ssk_lm_launch_acc(ctx, b->D, P, b->n_windows, b->tiled_dyn_bytes, b->schur_mfma);
 	if (b->tiled_ok && !(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
 		// the grid barrier of the cooperative kernel needs all n_windows * G workgroups resident: G from what the occupancy
@@ -1864,7 +1869,7 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 	const char* force = std::getenv("SSK_LM_KERNEL");
 	const char* name = "lm_solve_kernel";
 	if (b->split_ok) name = "lm_split_linearise_kernel";      // (the heaviest kernel of a pass; a mixed batch also runs lm_solve_node_kernel on its small windows)
-	else if (b->node_ok) name = b->node_big ? "lm_solve_node_big_kernel" : "lm_solve_node_kernel";
+	else if (b->node_ok) name = b->node_big ? "lm_solve_node_big_kernel" : b->node_small ? "lm_solve_node_e10_kernel" : "lm_solve_node_kernel";
 	else if (b->lean && b->pose_n) name = "lm_pose_only_kernel";
 	else if (b->acc_ok) name = b->schur_mfma ? "lm_solve_acc_mfma_kernel" : "lm_solve_acc_kernel";
 	else if (b->tiled_ok && !(force && std::strcmp(force, "l2") == 0 && b->has_general)) {

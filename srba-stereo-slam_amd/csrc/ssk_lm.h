@@ -163,7 +163,7 @@ inline int ssk_lma_row_tiles(int E) { return (6 * E + 15) / 16; }
 inline int ssk_lma_acc_doubles(int E) { const int T = ssk_lma_row_tiles(E); return 36 * (E * (E + 1) / 2) + 256 * (T * (T + 1) / 2) + ((6 * E + 1) & ~1); }
 int ssk_lm_launch_acc(ssk_ctx* ctx, const lm_dev& D, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, int schur_mfma);
 // node form (ssk_lm_node.hip): one 256-thread workgroup per window, dynamic LDS sized for the largest window of the batch
-int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, bool big);
+int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, bool big, bool small_e);
 // pose-only windows (ssk_lm_pose.hip): E in {1, 2}, no optimised landmark; d_order: the batch's window numbers of that family
 int ssk_lm_launch_pose_only(ssk_ctx* ctx, const lm_dev& D, const int* d_order, const lm_cam& P, int n_windows, int n_two_edges, size_t dyn_lds_bytes);
 int ssk_lm_launch_reset(ssk_ctx* ctx, double* pose, const double* pose0, size_t n_pose, double* lm, const double* lm0, size_t n_lm);

@@ -419,7 +419,8 @@ __device__ __forceinline__ bool ldl_factor_lookahead(double* A, const IX ix, int
 
 __device__ __forceinline__ bool ldl_solve_lds(double* A, int np, int n, double* x_out, double* inv)
 {
-	const int tid = threadIdx.x;
+	int tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));                      // (opaque: nothing derived from it is hoisted in front of a caller's LM loop, see ldl_solve_tiles4_lds)
 	// blocked by the 6 columns of one edge (n = 6E), with LOOK-AHEAD: while waves 1.. apply panel c0 to the columns
 	// beyond the next panel, wave 0 applies it to the next panel's 6 columns only, keeps its rows in registers, factorises
 	// the next 6x6 diagonal block (in every lane's registers, handed over by v_readlane) and eliminates inside those
@@ -1420,7 +1421,11 @@ __device__ __forceinline__ bool ldl_solve_tiles4_lds(const double* Hb, const dou
 {
 	constexpr int TP = 23;
 	constexpr int L_PN = 16 * TP, L_DG = 20, L_ZP = 4;
-	const int tid = threadIdx.x, T = (n + 3) >> 2;
+	// (the thread number made opaque: inside a caller's LM loop the tile coordinates and LDS addresses derived from a loop-invariant thread number are
+	// hoisted in front of that loop and held -- or spilled -- for the whole kernel)
+	int tid = threadIdx.x;
+	asm volatile("" : "+v"(tid));
+	const int T = (n + 3) >> 2;
 	__shared__ int s_ldl_bad_t;
 	double* Pn2 = lds;                                 // [buffer][(row in tile) * 4 + c][tile row]
 	double* dg = Pn2 + 2 * L_PN;                       // [buffer]: the diagonal tile's factor (16) and 1 / pivots (4)
@@ -1561,6 +1566,162 @@ __device__ __forceinline__ bool ldl_solve_tiles4_lds(const double* Hb, const dou
 	}
 	__syncthreads();
 	for (int k = tid; k < n; k += NT) x_out[k] = xs[k];
+	__syncthreads();
+	return true;
+}
+// The reduced system of a window with E <= 10 optimised edges (the bench windows: "local LM window = 10") by ONE wavefront with NO workgroup
+// barrier: the lower block triangle's E (E + 1) / 2 <= 55 blocks of 6 x 6 -- exactly the block accumulators Hb -- one per LANE (36 doubles in
+// registers; lane = block pair id).  A step eliminates a block column: (A) the diagonal block's lane factorises it (and eliminates the right-hand
+// side's six entries: it owns them) and publishes U, 1 / d, z; (B) the lanes below eliminate their six rows against it and publish them; (C) every
+// block right of the column takes block -= U_I D^-1 U_J^T (216 multiply-adds against 72 LDS reads, two of three as broadcasts).  The phases of a
+// step are ordered by the wavefront's own LDS counter (WAVE_SYNC), ten steps instead of ldl_solve_tiles4_lds's fifteen with three workgroup
+// barriers each and two per back-substitution step: a barrier of four wavefronts beside another workgroup's costs ~1 k cycles, and the 75 of them
+// were most of that solver's ~70 k cycles.  The other wavefronts of the workgroup wait at the final barrier (asleep: no issue slots).
+// Same factorisation (right-looking L' D L'^T, U = L' D unscaled) and the same sums in the same order for a given E: bit-reproducible.
+// lds: LDLB6_DOUBLES doubles.
+constexpr int LDLB6_BP = 37;            // pitch of a published block (odd: the panel's lanes write side by side)
+constexpr int LDLB6_DOUBLES = 48 + 10 * LDLB6_BP + 60 + 60;
+__device__ __forceinline__ bool ldl_solve_blocks6_wave(const double* Hb, const double* g, double lambda, int E, double* x_out, double* lds)
+{
+	__shared__ int s_ldl_bad_b;
+	double* Ud = lds;                                  // the diagonal block's U below the diagonal (6 i + j), 1 / d (36 ..), z (42 ..)
+	double* Pn = Ud + 48;                              // the column's eliminated blocks, [I][6 a + c]
+	double* xs = Pn + 10 * LDLB6_BP;                   // the solution
+	double* part = xs + 60;                            // back-substitution: a block row's contributions, [J][6]
+	const int tid = threadIdx.x, n = 6 * E;
+	if (tid < 64) {
+		int I = 0;
+		while ((I + 1) * (I + 2) / 2 <= tid) ++I;
+		const int J = tid - I * (I + 1) / 2;
+		const bool active = I < E, diag = active && I == J;
+		double B[6][6], z[6], iv[6], acc[6];
+		{
+			const double* hb = Hb + 36 * (active ? tid : 0);       // B(a, b) = A(6 I + a, 6 J + b) = H(6 J + b, 6 I + a): the stored (upper) triangle
+#pragma unroll
+			for (int b = 0; b < 6; ++b)
+#pragma unroll
+				for (int a = 0; a < 6; ++a) { const double v = hb[6 * b + a]; B[a][b] = (diag && a == b) ? v + lambda : v; }
+#pragma unroll
+			for (int b = 0; b < 6; ++b) { z[b] = diag ? g[6 * J + b] : 0.0; iv[b] = 1.0; acc[b] = 0.0; }
+		}
+		bool bad = false;
+		for (int k = 0; k < E; ++k) {
+			if (diag && I == k) {
+#pragma unroll
+				for (int j = 0; j < 6; ++j) {
+					const double d = B[j][j];
+					bad |= !(d > 0.0);
+					iv[j] = rcp_f64(d);
+#pragma unroll
+					for (int i = j + 1; i < 6; ++i) {
+						const double f = B[i][j] * iv[j];
+#pragma unroll
+						for (int c = j + 1; c <= i; ++c) B[i][c] -= f * B[c][j];
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < 5; ++j) {
+					const double f = z[j] * iv[j];
+#pragma unroll
+					for (int c = j + 1; c < 6; ++c) z[c] -= f * B[c][j];
+				}
+#pragma unroll
+				for (int i = 0; i < 6; ++i) {
+#pragma unroll
+					for (int j = 0; j < i; ++j) Ud[6 * i + j] = B[i][j];
+					Ud[36 + i] = iv[i];
+					Ud[42 + i] = z[i];
+				}
+			}
+			WAVE_SYNC();
+			if (__builtin_amdgcn_ballot_w64(bad) != 0) { bad = true; break; }      // (uniform)
+			if (active && J == k && I > k) {
+				double ivk[6];
+#pragma unroll
+				for (int j = 0; j < 6; ++j) ivk[j] = Ud[36 + j];
+#pragma unroll
+				for (int j = 0; j < 5; ++j) {
+					double ud[6];
+#pragma unroll
+					for (int c = j + 1; c < 6; ++c) ud[c] = Ud[6 * c + j];
+#pragma unroll
+					for (int a = 0; a < 6; ++a) {
+						const double f = B[a][j] * ivk[j];
+#pragma unroll
+						for (int c = j + 1; c < 6; ++c) B[a][c] -= f * ud[c];
+					}
+				}
+				double* o = Pn + LDLB6_BP * I;
+#pragma unroll
+				for (int a = 0; a < 6; ++a)
+#pragma unroll
+					for (int c = 0; c < 6; ++c) o[6 * a + c] = B[a][c];
+			}
+			WAVE_SYNC();
+			if (active && J > k) {
+				const double* pi = Pn + LDLB6_BP * I;
+				const double* pj = Pn + LDLB6_BP * J;
+#pragma unroll
+				for (int c = 0; c < 6; ++c) {
+					const double ivc = Ud[36 + c];
+					double ui[6], uj[6];
+#pragma unroll
+					for (int a = 0; a < 6; ++a) { ui[a] = pi[6 * a + c] * ivc; uj[a] = pj[6 * a + c]; }
+#pragma unroll
+					for (int a = 0; a < 6; ++a)
+#pragma unroll
+						for (int b = 0; b < 6; ++b) B[a][b] -= ui[a] * uj[b];
+					// (the right-hand side's entries in every lane, with a zero factor off the diagonal: a branch per column makes the compiler gather the
+					// six branches in front of ONE block of multiply-adds that then holds all 72 operands of the block pair in registers)
+					const double zc = Ud[42 + c];                   // (read by every lane: a guarded read is a branch again)
+					const double uz = diag ? zc * ivc : 0.0;
+#pragma unroll
+					for (int b = 0; b < 6; ++b) z[b] -= uz * uj[b];
+					__builtin_amdgcn_sched_barrier(0);             // (a column's twelve operands at a time)
+				}
+			}
+			WAVE_SYNC();
+		}
+		if (!bad) {
+			// ---- back-substitution x = D^-1 z - L'^T x, a block row per step from the bottom ----
+			for (int k = E - 1; k >= 0; --k) {
+				if (diag && I == k) {
+					double x[6];
+#pragma unroll
+					for (int b = 5; b >= 0; --b) {
+						double sacc = z[b] - acc[b];
+#pragma unroll
+						for (int a = b + 1; a < 6; ++a) sacc -= B[a][b] * x[a];
+						x[b] = sacc * iv[b];
+						xs[6 * k + b] = x[b];
+					}
+				}
+				WAVE_SYNC();
+				if (active && I == k && J < k) {
+					double xa[6];
+#pragma unroll
+					for (int a = 0; a < 6; ++a) xa[a] = xs[6 * k + a];
+#pragma unroll
+					for (int b = 0; b < 6; ++b) {
+						double p = 0.0;
+#pragma unroll
+						for (int a = 0; a < 6; ++a) p += B[a][b] * xa[a];
+						part[6 * J + b] = p;
+					}
+				}
+				WAVE_SYNC();
+				if (diag && J < k) {
+#pragma unroll
+					for (int b = 0; b < 6; ++b) acc[b] += part[6 * J + b];
+				}
+				WAVE_SYNC();
+			}
+		}
+		if (tid == 0) s_ldl_bad_b = bad ? 1 : 0;
+	}
+	__syncthreads();
+	if (s_ldl_bad_b) return false;                     // uniform
+	for (int i = tid; i < n; i += NT) x_out[i] = xs[i];
 	__syncthreads();
 	return true;
 }

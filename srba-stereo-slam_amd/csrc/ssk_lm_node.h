@@ -82,10 +82,10 @@ struct nd_group {
 
 // lane record (int4):
 //   x  landmark (window index)
-//   y  first observation lane | number of observation lanes << 8          (the run of the staging this lane sums)
+//   y  first observation lane | number of observation lanes << 8 | the run starts at the landmark's first observation << 16   (the run of the staging this lane sums)
 //   z  root: optimised slot of the landmark or -1;   node: transform suffix | edge slot << 16 | inverse step << 24
 //   w  kind (0 idle, 1 root, 2 node) | lane of the landmark's root << 8 | root: number of node lanes that follow << 16
-// observation record (int2): x landmark, y suffix of the whole path | lane of the landmark's root << 16
+// observation record (int2): x landmark, y suffix of the whole path | lane of the landmark's root << 16 | distance from the landmark's first observation lane << 24
 // item (int): record X: slot | P-part << 9;  record Y: slot << 10 | P-part << 19;  bit 20: not nested (D = -Zh Zh^T)
 // quad slot (int2): x block pair id (0xFFFF: none) | items << 16, y first item (window relative) | part of the block << 28 |
 //   block cut in two << 30 | this wavefront holds such blocks << 31

@@ -22,11 +22,14 @@ constexpr int REC = SSK_ND_REC, STG = SSK_ND_STAGE, LREC = SSK_ND_LREC, SCR = SS
 constexpr int R_Q = 9, R_P = 12, R_V = 21;
 
 #include "ssk_lm_node_dev.h"
+#include "ssk_lm_ldl_wave.h"
 
 // BIG: the reduced system does not fit LDS: block accumulators (global_atomic_add_f64, still one owner per block and tile, the tiles' barriers
 // order the adds: bit-reproducible) and the dense bordered system in HBM / L2, factorised by ldl_solve_hybrid with the node records' LDS
 // region (and everything behind it) as its staging
-template <bool BIG>
+// SMALL: every window of the launch has E <= 10 (the host checks): the only dense solver compiled in is ldl_solve_blocks6_wave -- the other solvers'
+// loop-invariant LDS addresses, hoisted in front of the LM loop, were what the kernel spilled
+template <bool BIG, bool SMALL = false>
 __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const lm_cam& P_arg, int dyn_doubles)
 {
 	__shared__ lm_cam s_P;
@@ -254,7 +257,17 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 		}
 		// ---- the reduced system: A = H_pp - S + lambda I, border row = reduced gradient; LDL^T ----
 		bool ok = true;
-		if (!BIG && ND_TILES4 && 2 * ((n6 + 3) >> 2) * (((n6 + 3) >> 2) + 1) <= 4 * NT) {
+		if (!BIG && ND_BLOCKS6 && SMALL) {
+			// E <= 10 (the bench windows): one wavefront, no workgroup barrier inside the solve
+			STAMP(6);
+#if ND_BLOCKS6 == 2
+			if (n6 > 0) ok = ldl_solve_mfma_wave(Hb, g_acc, lambda, n6, s_b, reg);          // one wavefront, the system in matrix-core accumulator tiles
+#else
+			if (n6 > 0) ok = ldl_solve_blocks6_wave(Hb, g_acc, lambda, W.E, s_b, reg);
+#endif
+		} else if (SMALL) {
+			ok = false;                                    // (not reached: the host launches this variant for batches of E <= 10 only)
+		} else if (!BIG && ND_TILES4 && 2 * ((n6 + 3) >> 2) * (((n6 + 3) >> 2) + 1) <= 4 * NT) {
 			// register tiles straight from the block accumulators (no dense copy)
 			STAMP(6);
 			if (n6 > 0) ok = ldl_solve_tiles4_lds(Hb, g_acc, lambda, n6, s_b, reg);
@@ -384,6 +397,12 @@ void lm_solve_node_kernel(lm_dev D, nd_dev N, lm_cam P, int dyn_doubles)
 	nd_body<false>(D, N, P, dyn_doubles);
 }
 
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void lm_solve_node_e10_kernel(lm_dev D, nd_dev N, lm_cam P, int dyn_doubles)
+{
+	nd_body<false, true>(D, N, P, dyn_doubles);
+}
+
 __global__ __launch_bounds__(NT, 1)
 void lm_solve_node_big_kernel(lm_dev D, nd_dev N, lm_cam P, int dyn_doubles)
 {
@@ -392,18 +411,20 @@ void lm_solve_node_big_kernel(lm_dev D, nd_dev N, lm_cam P, int dyn_doubles)
 
 }  // namespace
 
-int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, bool big)
+int ssk_lm_launch_node(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const lm_cam& P, int n_windows, size_t dyn_lds_bytes, bool big, bool small_e)
 {
 	dyn_lds_bytes = (dyn_lds_bytes + 15) & ~(size_t)15;
 	static ssk_dev_once attr_once;      // (the attribute is per device)
 	if (attr_once.need(ctx->device)) {
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_node_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
 		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_node_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_solve_node_e10_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
 		attr_once.done(ctx->device);
 	}
 	ssk_stage_scope prof(ctx, SSK_STAGE_LM_SOLVE);
 	if (big) hipLaunchKernelGGL(lm_solve_node_big_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, N, P, (int)(dyn_lds_bytes / 8));
+	else if (small_e && ND_BLOCKS6) hipLaunchKernelGGL(lm_solve_node_e10_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, N, P, (int)(dyn_lds_bytes / 8));
 	else hipLaunchKernelGGL(lm_solve_node_kernel, dim3(n_windows), dim3(NT), dyn_lds_bytes, ctx->stream, D, N, P, (int)(dyn_lds_bytes / 8));
-	SSK_LAUNCH_CHECK(ctx, big ? "lm_solve_node_big_kernel" : "lm_solve_node_kernel");
+	SSK_LAUNCH_CHECK(ctx, big ? "lm_solve_node_big_kernel" : (small_e && ND_BLOCKS6) ? "lm_solve_node_e10_kernel" : "lm_solve_node_kernel");
 	return SSK_OK;
 }

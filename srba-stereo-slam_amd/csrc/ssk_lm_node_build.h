@@ -319,17 +319,17 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			const int root_lane = G.n_lanes, obs_a = G.n_obs;
 			for (int k = 0; k < no; ++k) {
 				const int o = lm_sorted[(size_t)M.obs0 + k];
-				H.obs.push_back(nd_i2{M.l, obs_suf[(size_t)o] | (root_lane << 16)});
+				H.obs.push_back(nd_i2{M.l, obs_suf[(size_t)o] | (root_lane << 16) | (k << 24)});      // (k: distance from the landmark's first observation lane)
 				H.px.push_back(nd_f4{Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]});
 			}
-			H.lane.push_back(nd_i4{M.l, obs_a | (no << 8), Wn.lm_unknown_slot[M.l], 1 | (root_lane << 8) | (M.n_nodes << 16)});
+			H.lane.push_back(nd_i4{M.l, obs_a | (no << 8) | (1 << 16), Wn.lm_unknown_slot[M.l], 1 | (root_lane << 8) | (M.n_nodes << 16)});
 			glanes.push_back(gnode{(int)m, -1, root_lane});
 			for (int k = 0; k < M.n_nodes; ++k) {
 				const node& nd = nodes[(size_t)M.node0 + k];
 				const int code = suf[(size_t)nd.key].x, inv = code & 1;
 				const int tsuf = inv ? suf[(size_t)nd.key].y : nd.key;
 				const int es = suf_es[(size_t)nd.key];
-				H.lane.push_back(nd_i4{M.l, (obs_a + nd.a) | (nd.n << 8), tsuf | (es << 16) | (inv << 24), 2 | (root_lane << 8)});
+				H.lane.push_back(nd_i4{M.l, (obs_a + nd.a) | (nd.n << 8) | ((nd.a == 0 ? 1 : 0) << 16), tsuf | (es << 16) | (inv << 24), 2 | (root_lane << 8)});
 				glanes.push_back(gnode{(int)m, k, root_lane + 1 + k});
 			}
 			G.n_obs += no; G.n_lanes += nl;

@@ -165,15 +165,44 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 			for (int j = 0; j < 3; ++j) jf[3 * i + j] = w * (M[3 * i] * T[j] + M[3 * i + 1] * T[4 + j] + M[3 * i + 2] * T[8 + j]);
 		const double wr[4] = {w * r[0], w * r[1], w * r[2], w * r[3]};
 		double* o = stage + STG * lane;
-		o[0] = jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
-		o[1] = jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
-		o[2] = jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
-		o[3] = jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
-		o[4] = jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
-		o[5] = jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
-		o[6] = jf[0] * wr[0] + jf[3] * wr[1] + jf[6] * wr[2] + jf[9] * wr[3];
-		o[7] = jf[1] * wr[0] + jf[4] * wr[1] + jf[7] * wr[2] + jf[10] * wr[3];
-		o[8] = jf[2] * wr[0] + jf[5] * wr[1] + jf[8] * wr[2] + jf[11] * wr[3];
+		double vo[9];
+		vo[0] = jf[0] * jf[0] + jf[3] * jf[3] + jf[6] * jf[6] + jf[9] * jf[9];
+		vo[1] = jf[0] * jf[1] + jf[3] * jf[4] + jf[6] * jf[7] + jf[9] * jf[10];
+		vo[2] = jf[0] * jf[2] + jf[3] * jf[5] + jf[6] * jf[8] + jf[9] * jf[11];
+		vo[3] = jf[1] * jf[1] + jf[4] * jf[4] + jf[7] * jf[7] + jf[10] * jf[10];
+		vo[4] = jf[1] * jf[2] + jf[4] * jf[5] + jf[7] * jf[8] + jf[10] * jf[11];
+		vo[5] = jf[2] * jf[2] + jf[5] * jf[5] + jf[8] * jf[8] + jf[11] * jf[11];
+		vo[6] = jf[0] * wr[0] + jf[3] * wr[1] + jf[6] * wr[2] + jf[9] * wr[3];
+		vo[7] = jf[1] * wr[0] + jf[4] * wr[1] + jf[7] * wr[2] + jf[10] * wr[3];
+		vo[8] = jf[2] * wr[0] + jf[5] * wr[1] + jf[8] * wr[2] + jf[11] * wr[3];
+#if ND_SCAN
+		// Inclusive prefix sums INSIDE each landmark's run of observation lanes (a landmark's observations are consecutive lanes; orec.y bits 24..30:
+		// the lane's distance h from its landmark's first observation): six DPP steps for the nine sums -- shifts by 1, 2, 4, 8 inside a row of
+		// 16 lanes, then the totals of the rows before (row_bcast15 / row_bcast31).  A root / node lane then needs TWO staging rows whatever the
+		// length of its run (P[last] - P[first - 1]); walking the runs row by row made every wavefront wait for its longest landmark (3.2 k cycles of
+		// a group's 11 k).  Fixed order: deterministic; the difference of two prefix sums of at most 64 terms of one sign pattern costs ~1e-14
+		// relative, far inside the LM contract's 1e-6.
+		{
+			const int h = (orec.y >> 24) & 0x7F, lr = lane & 15;
+			const double m1 = h >= 1 ? 1.0 : 0.0, m2 = h >= 2 ? 1.0 : 0.0, m4 = h >= 4 ? 1.0 : 0.0, m8 = h >= 8 ? 1.0 : 0.0;
+			// (row_bcast15 for rows 1 and 3 only: row 2 takes the lanes 0 .. 31 in one piece from lane 31, which by then holds rows 0 + 1 of its landmark)
+			const double m16 = ((lane & 16) && h >= lr + 1) ? 1.0 : 0.0, m32 = (lane >= 32 && h >= lane - 31) ? 1.0 : 0.0;
+#pragma unroll
+			for (int c = 0; c < 9; ++c) vo[c] = fma(m1, dpp_f64<0x111>(vo[c]), vo[c]);       // row_shr:1 (a source outside the row: 0)
+#pragma unroll
+			for (int c = 0; c < 9; ++c) vo[c] = fma(m2, dpp_f64<0x112>(vo[c]), vo[c]);
+#pragma unroll
+			for (int c = 0; c < 9; ++c) vo[c] = fma(m4, dpp_f64<0x114>(vo[c]), vo[c]);
+#pragma unroll
+			for (int c = 0; c < 9; ++c) vo[c] = fma(m8, dpp_f64<0x118>(vo[c]), vo[c]);
+#pragma unroll
+			for (int c = 0; c < 9; ++c) vo[c] = fma(m16, dpp_f64<0x142>(vo[c]), vo[c]);      // row_bcast15: lane 15 of the row before
+#pragma unroll
+			for (int c = 0; c < 9; ++c) vo[c] = fma(m32, dpp_f64<0x143>(vo[c]), vo[c]);      // row_bcast31: lane 31 (rows 2 and 3)
+		}
+#endif
+#pragma unroll
+		for (int c = 0; c < 9; ++c) o[c] = vo[c];
 	}
 	WAVE_SYNC();
 	FINE(0);
@@ -185,8 +214,21 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 	// ---- lane = root / node: sums over its run of the staging (a landmark's observations are sorted so that a trie subtree is a run) ----
 	double vs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 	{
-		const int a = lrec.y & 0xFF, n = kind ? (lrec.y >> 8) : 0;
-#if ND_SUM4
+		const int a = lrec.y & 0xFF, n = kind ? ((lrec.y >> 8) & 0xFF) : 0;
+#if ND_SCAN
+		// the run's sums from the landmark's prefix sums: P[a + n - 1] - P[a - 1] (bit 16 of y: the run starts at the landmark's first observation)
+		if (n > 0) {
+			const double* pe = stage + STG * (a + n - 1);
+			const double* pb = stage + STG * max(a - 1, 0);
+			const double mb = ((lrec.y >> 16) & 1) ? 0.0 : 1.0;
+			double e9[9], b9[9];
+#pragma unroll
+			for (int c = 0; c < 9; ++c) { e9[c] = pe[c]; b9[c] = pb[c]; }
+#pragma unroll
+			for (int c = 0; c < 9; ++c) vs[c] = fma(-mb, b9[c], e9[c]);
+		}
+	}
+#elif ND_SUM4
 		// four rows per turn, loads first (rows past the run: the run's last row, weight 0); the order of the adds is the rows' order
 		for (int i = 0; i < n; i += ND_SUMROWS) {
 			double v[ND_SUMROWS][9];
@@ -347,6 +389,9 @@ __device__ __forceinline__ void nd_item_apply(const nd_item_ops& o, double sg, d
 #ifndef ND_PIPE
 #define ND_PIPE 0                       // 1: software-pipelined item turns (loads of item k + 1 in front of the products of item k)
 #endif
+#ifndef ND_SCAN
+#define ND_SCAN 1                       // run sums from per-landmark prefix sums over the observation lanes (DPP scan); 0: every root / node lane walks its run
+#endif
 #ifndef ND_SUM4
 #define ND_SUM4 1                       // 1: ND_SUMROWS staging rows per turn in the run sums
 #endif
@@ -355,6 +400,10 @@ __device__ __forceinline__ void nd_item_apply(const nd_item_ops& o, double sg, d
 #endif
 #ifndef ND_TILES4
 #define ND_TILES4 1                     // the reduced system of windows with E <= 14 as 4 x 4 register tiles (0: dense copy + ldl_solve_lds)
+#endif
+#ifndef ND_BLOCKS6
+#define ND_BLOCKS6 2                    // the reduced system of windows with E <= 10 by ONE wavefront: 2 = in matrix-core accumulator tiles (ldl_solve_mfma_wave,
+                                        // ssk_lm_ldl_wave.h), 1 = a 6 x 6 block per lane on the vector ALUs (ldl_solve_blocks6_wave), 0 = the 4 x 4 tiles of all threads
 #endif
 #ifndef ND_HB_ATOMIC
 #define ND_HB_ATOMIC 1                  // block accumulators: 1 = ds_add_f64 per component, 0 = 16-byte loads, adds, 16-byte stores

@@ -234,7 +234,10 @@ def test_lm_kernel_name_follows_the_batch(ctx, monkeypatch):
     from ssk_amd import capi
     small = sl.make_submap_problem(1, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60)[0]
     large = sl.make_submap_problem(21, n_kf=45, n_lm=900, submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)[0]
-    for wins, env, expect in (([small], None, "lm_solve_node_kernel"), ([small], "tiled", "lm_solve_tiled"), ([large], None, "lm_split_linearise_kernel"),
+    small10 = sl.make_submap_problem(6, n_kf=14, n_lm=220, submap_size=5, obs_per_kf=60, opt_depth=2)[0]
+    assert small.E > 10 and 0 < small10.E <= 10
+    for wins, env, expect in (([small], None, "lm_solve_node_kernel"), ([small10], None, "lm_solve_node_e10_kernel"), ([small, small10], None, "lm_solve_node_kernel"),
+                              ([small], "tiled", "lm_solve_tiled"), ([large], None, "lm_split_linearise_kernel"),
                               ([large] * 128, None, "lm_split_linearise_kernel"), ([large], "coop", "lm_solve_coop"), ([large] * 128, "tiled", "lm_solve_tiled_kernel"),
                               ([large], "node", "lm_solve_node_big_kernel"), ([small], "split", "lm_split_linearise_kernel"), ([small, large], None, "lm_split_linearise_kernel"),
                               ([small], "l2", "lm_solve_kernel")):
@@ -388,7 +391,7 @@ def test_lm_bench_windows_against_oracle(ctx, oracle, seed, monkeypatch):
         assert res.stop_reason in (1, 4) and res.err_final < res.err_init
     monkeypatch.setenv("SSK_LM_FEW_SPLIT", "0")
     b = capi.LmBatch(ctx, [win])
-    assert b.kernel_name() == "lm_solve_node_kernel"
+    assert b.kernel_name() == "lm_solve_node_e10_kernel"
     b.close()
     res = check_against_oracle(ctx, oracle, win, sl.make_params(), min_accept=2)
     assert res.stop_reason in (1, 4) and res.err_final < res.err_init
@@ -402,7 +405,7 @@ def test_lm_bench_windows_seeds_8_to_63(ctx, oracle):
             for seed in range(8, 64)]
     prm = sl.make_params()
     b = capi.LmBatch(ctx, wins)
-    assert b.kernel_name() == "lm_solve_node_kernel"
+    assert b.kernel_name() == "lm_solve_node_e10_kernel"       # (every window E = 10: the variant whose dense solver is ldl_solve_blocks6_wave)
     b.run(to_capi(prm))
     res = b.results()
     for i, w in enumerate(wins):
@@ -621,11 +624,11 @@ def test_lm_split_mixed_batch_is_reproducible(ctx, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("E", [15, 18])
+@pytest.mark.parametrize("E", [12, 15, 18])
 def test_lm_node_kernel_middle_branch(ctx, oracle, E, monkeypatch):
-    """lm_solve_node_kernel between the 4x4 register tiles (E <= 14) and the BIG form: the dense copy out of the block accumulators +
-    ldl_solve_lds at 256 threads -- the size of the facade's local areas at depth 3-5 early in a sequence.  With trace, robust on / off and
-    a window whose landmarks are partly held."""
+    """lm_solve_node_kernel beyond the one-wavefront block solver of the E <= 10 variant: the 4x4 register tiles (E = 12: 10 < E <= 14) and, between
+    them and the BIG form, the dense copy out of the block accumulators + ldl_solve_lds at 256 threads (E = 15, 18) -- the size of the facade's
+    local areas at depth 3-5 early in a sequence.  With trace, robust on / off and a window whose landmarks are partly held."""
     from ssk_amd import capi
     monkeypatch.setenv("SSK_LM_KERNEL", "node")
     win, gt = sl.make_submap_problem(21, n_kf=E + 1, n_lm=20 * (E + 1), submap_size=3, max_tree_depth=6, opt_depth=40, obs_per_kf=60)

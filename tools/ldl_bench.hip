@@ -19,6 +19,7 @@ constexpr int REC = SSK_ND_REC, STG = SSK_ND_STAGE, LREC = SSK_ND_LREC, SCR = SS
 constexpr int R_Q = 9, R_P = 12, R_V = 21;
 #include "ssk_lm_node_dev.h"
 #include "ssk_lm_ldl_mfma.h"
+#include "ssk_lm_ldl_wave.h"
 
 template <int WHICH>
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
@@ -34,6 +35,28 @@ void bench_kernel(const double* A, int np, int n, double* x, int reps, int dyn_d
 	for (int r = 0; r < reps; ++r) {
 		if constexpr (WHICH == 1) ok &= ldl_solve_mfma_tiles(A, np, n, s_b, lds);
 		else ok &= ldl_solve_regtile(const_cast<double*>(A), np, n, s_b, s_inv, lds, lds_doubles);
+		__syncthreads();
+	}
+	if (blockIdx.x == 0) {
+		for (int i = threadIdx.x; i < n; i += NT) x[i] = s_b[i];
+		if (threadIdx.x == 0) *ok_out = ok ? 1 : 0;
+	}
+}
+// the one-wavefront solvers of the persistent node kernel (E <= 10): input = 6 x 6 block accumulators + reduced gradient in LDS; WHICH 2: matrix cores
+// (ldl_solve_mfma_wave), 3: a block per lane on the vector ALUs (ldl_solve_blocks6_wave)
+template <int WHICH>
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void bench_wave_kernel(const double* Hb_g, const double* g_g, int n, double* x, int reps, int* ok_out)
+{
+	extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+	double* Hb = s_dyn; double* g = Hb + 36 * 55; double* s_b = g + 64; double* lds = s_b + 64;
+	for (int i = threadIdx.x; i < 36 * 55; i += NT) Hb[i] = Hb_g[i];
+	for (int i = threadIdx.x; i < 64; i += NT) g[i] = i < n ? g_g[i] : 0.0;
+	__syncthreads();
+	bool ok = true;
+	for (int r = 0; r < reps; ++r) {
+		if constexpr (WHICH == 2) ok &= ldl_solve_mfma_wave(Hb, g, 0.0, n, s_b, lds);
+		else ok &= ldl_solve_blocks6_wave(Hb, g, 0.0, n / 6, s_b, lds);
 		__syncthreads();
 	}
 	if (blockIdx.x == 0) {
@@ -102,6 +125,35 @@ int main(int argc, char** argv)
 		for (int i = 0; i < n; ++i) { err = std::fmax(err, std::fabs(x[i] - xr[i])); nrm = std::fmax(nrm, std::fabs(xr[i])); }
 		std::printf("%-22s n %d, %d workgroups x %d solves: %.2f us per solve (per workgroup), ok %d, max |x - x_host| / max |x_host| = %.2e\n",
 		            which ? "ldl_solve_mfma_tiles" : "ldl_solve_regtile", n, wgs, reps, 1e3 * best / reps, ok, err / nrm);
+	}
+	if (n <= 60 && n % 6 == 0) {
+		// the node kernel's one-wavefront solvers on the same system given as block accumulators (H(6 e + a, 6 e2 + b), e <= e2, at 36 (e2 (e2 + 1) / 2 + e) + 6 a + b)
+		std::vector<double> Hb(36 * 55, 0.0);
+		for (int e2 = 0; e2 < n / 6; ++e2)
+			for (int e = 0; e <= e2; ++e)
+				for (int a = 0; a < 6; ++a)
+					for (int c = 0; c < 6; ++c) Hb[(size_t)36 * (e2 * (e2 + 1) / 2 + e) + 6 * a + c] = A[(size_t)(6 * e + a) * np + 6 * e2 + c];
+		double *dHb, *dg;
+		CK(hipMalloc(&dHb, Hb.size() * 8)); CK(hipMalloc(&dg, 64 * 8));
+		CK(hipMemcpy(dHb, Hb.data(), Hb.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dg, b.data(), n * 8, hipMemcpyHostToDevice));
+		const size_t dynw = 8 * (size_t)(36 * 55 + 128 + (LDLW_DOUBLES > LDLB6_DOUBLES ? LDLW_DOUBLES : LDLB6_DOUBLES) + 64);
+		for (int which = 2; which < 4; ++which) {
+			float best = 1e30f;
+			for (int rep = 0; rep < 4; ++rep) {
+				CK(hipEventRecord(e0));
+				if (which == 2) hipLaunchKernelGGL(bench_wave_kernel<2>, dim3(wgs), dim3(NT), dynw, 0, dHb, dg, n, dx, reps, dok);
+				else hipLaunchKernelGGL(bench_wave_kernel<3>, dim3(wgs), dim3(NT), dynw, 0, dHb, dg, n, dx, reps, dok);
+				CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+				float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+				if (rep) best = std::fmin(best, ms);
+			}
+			std::vector<double> x(n); int ok;
+			CK(hipMemcpy(x.data(), dx, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost));
+			double err = 0.0, nrm = 0.0;
+			for (int i = 0; i < n; ++i) { err = std::fmax(err, std::fabs(x[i] - xr[i])); nrm = std::fmax(nrm, std::fabs(xr[i])); }
+			std::printf("%-22s n %d, %d workgroups x %d solves: %.2f us per solve (per workgroup), ok %d, max |x - x_host| / max |x_host| = %.2e\n",
+			            which == 2 ? "ldl_solve_mfma_wave" : "ldl_solve_blocks6_wave", n, wgs, reps, 1e3 * best / reps, ok, err / nrm);
+		}
 	}
 	return 0;
 }

@@ -102,13 +102,30 @@ int nd_emu_linearise_form(const ssk_lm_window* Wn, const ssk_lm_params* P, doubl
 					for (int b = a; b < 3; ++b) o[k++] = jf[a] * jf[b] + jf[3 + a] * jf[3 + b] + jf[6 + a] * jf[6 + b] + jf[9 + a] * jf[9 + b];
 				for (int b = 0; b < 3; ++b) o[6 + b] = w * (jf[b] * r[0] + jf[3 + b] * r[1] + jf[6 + b] * r[2] + jf[9 + b] * r[3]);
 			}
+			// the kernel's run sums (ND_SCAN): per-landmark inclusive prefix sums over the observation lanes by six masked lane-shift steps (row_shr 1, 2, 4, 8
+			// inside a row of 16 lanes, row_bcast15, row_bcast31; h = orec.y bits 24..30), then P[last] - P[first - 1] per root / node lane
+			for (int lane = G.n_obs; lane < 64; ++lane) for (int c = 0; c < 9; ++c) stage[9 * lane + c] = 0.0;
+			{
+				int hh[64];
+				for (int lane = 0; lane < 64; ++lane) hh[lane] = lane < G.n_obs ? (H.obs[(size_t)W.obs0 + G.obs0 + lane].y >> 24) & 0x7F : 0;
+				double nxt[64 * 9];
+				for (int step = 0; step < 6; ++step) {
+					for (int lane = 0; lane < 64; ++lane) {
+						const int lr = lane & 15, h = hh[lane];
+						int src = -1; bool on = false;
+						if (step < 4) { const int d = 1 << step; src = lr >= d ? lane - d : -1; on = h >= d; }
+						else if (step == 4) { src = (lane & 16) ? (lane & ~15) - 1 : -1; on = (lane & 16) && h >= lr + 1; }      // (rows 1 and 3: row 2 takes rows 0 + 1 in one piece below)
+						else { src = lane >= 32 ? 31 : -1; on = lane >= 32 && h >= lane - 31; }
+						for (int c = 0; c < 9; ++c) nxt[9 * lane + c] = stage[9 * lane + c] + ((on && src >= 0) ? stage[9 * src + c] : 0.0);
+					}
+					std::memcpy(stage, nxt, sizeof nxt);
+				}
+			}
 			double vs[64][9], lrec[64][16];
 			for (int lane = 0; lane < G.n_lanes; ++lane) {
 				const nd_i4 lr = H.lane[(size_t)W.lane0 + G.lane0 + lane];
-				const int a = lr.y & 0xFF, n = lr.y >> 8;
-				for (int c = 0; c < 9; ++c) vs[lane][c] = 0.0;
-				for (int i = 0; i < n; ++i)
-					for (int c = 0; c < 9; ++c) vs[lane][c] += stage[9 * (a + i) + c];
+				const int a = lr.y & 0xFF, n = (lr.y >> 8) & 0xFF, first = (lr.y >> 16) & 1;
+				for (int c = 0; c < 9; ++c) vs[lane][c] = n > 0 ? stage[9 * (a + n - 1) + c] - (first ? 0.0 : stage[9 * (a > 0 ? a - 1 : 0) + c]) : 0.0;
 			}
 			for (int lane = 0; lane < G.n_lanes; ++lane) {
 				const nd_i4 lr = H.lane[(size_t)W.lane0 + G.lane0 + lane];
@@ -341,6 +358,51 @@ int nd_emu_shape(const ssk_lm_window* Wn, int waves, int* out /* 16 */)
 	const int v[16] = {W.n_edges, W.E, W.n_suf, W.n_groups, W.n_tiles, W.n_obs, (int)H.lane.size(), nodes, roots, mxn, mxr, mxo, mxl, (int)H.item.size(), mxb, (int)H.lds_doubles};
 	std::memcpy(out, v, sizeof v);
 	return 0;
+}
+
+// per tile and wavefront of the pair phase: item turns (the longest lane run of the wavefront's 16 quads) and items; out[0] = number of (tile, wave) entries,
+// then pairs (turns, items)
+int nd_emu_pair_load(const ssk_lm_window* Wn, int waves, int* out, int cap)
+{
+	nd_host H;
+	nd_win hdr{};
+	if (!nd_build_window(*Wn, waves, H, hdr, 20352, false)) return -1;
+	const nd_win& W = H.win[0];
+	int k = 0;
+	for (int t = 0; t < W.n_tiles; ++t) {
+		const nd_tile& T = H.tile[(size_t)t];
+		for (int r = 0; r < T.n_rounds; ++r)
+			for (int wv = 0; wv < waves; ++wv) {
+				int turns = 0, items = 0;
+				for (int q = 0; q < 16; ++q) { const int n = (H.qs[(size_t)T.qs0 + r * waves * 16 + wv * 16 + q].x >> 16) & 0x7FFF; turns = std::max(turns, (n + 3) / 4); items += n; }
+				if (2 * k + 2 < cap) { out[1 + 2 * k] = turns; out[2 + 2 * k] = items; }
+				++k;
+			}
+	}
+	out[0] = k;
+	return 0;
+}
+
+// item counts of every (tile, block) pair of a window (quad-slot tables; a block cut in two: its parts joined): out[0] = tiles, then per tile: count, counts...
+int nd_emu_block_items(const ssk_lm_window* Wn, int waves, int* out, int cap)
+{
+	nd_host H;
+	nd_win hdr{};
+	if (!nd_build_window(*Wn, waves, H, hdr, 20352, false)) return -1;
+	const nd_win& W = H.win[0];
+	int k = 1;
+	out[0] = W.n_tiles;
+	for (int t = 0; t < W.n_tiles; ++t) {
+		const nd_tile& T = H.tile[(size_t)t];
+		std::vector<int> cnt((size_t)W.E * (W.E + 1) / 2, 0);
+		for (int q = 0; q < T.n_rounds * waves * 16; ++q) { const nd_i2 s = H.qs[(size_t)T.qs0 + q]; if ((s.x & 0xFFFF) != 0xFFFF) cnt[(size_t)(s.x & 0xFFFF)] += (s.x >> 16) & 0x7FFF; }
+		int nb = 0;
+		for (int c : cnt) nb += c > 0;
+		if (k + 1 + nb >= cap) return -2;
+		out[k++] = nb;
+		for (int c : cnt) if (c > 0) out[k++] = c;
+	}
+	return k;
 }
 
 int nd_emu_linearise(const ssk_lm_window* Wn, const ssk_lm_params* P, double lambda, int pre, int waves, double* Hred, double* g, const double* dp, double* df,
