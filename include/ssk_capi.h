@@ -72,6 +72,10 @@ int ssk_api_version(void);
 int ssk_create(ssk_ctx** out, int device, void* hip_stream);
 void ssk_destroy(ssk_ctx* ctx);
 const char* ssk_last_error(const ssk_ctx* ctx);   /* ctx may be NULL: returns the create-time error */
+/* The library reads its environment switches (SSK_LM_KERNEL, SSK_LM_SCHUR, ...: DESIGN.md 5 "Switches") ONCE, in ssk_create.  ssk_env_refresh reads them
+ * again for this context: a hook for tests and same-box A/Bs that switch kernels on a live context (the Python binding calls it in front of every
+ * LM batch create); a drop-in caller never needs it. */
+int ssk_env_refresh(ssk_ctx* ctx);
 int ssk_synchronize(ssk_ctx* ctx);                /* hipStreamSynchronize on the context stream */
 void* ssk_stream(ssk_ctx* ctx);                   /* the hipStream_t kernels are launched on */
 /* HIP-event timing on the context stream (bench.py measures kernels on the stream they run on). */

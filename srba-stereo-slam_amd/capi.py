@@ -636,6 +636,8 @@ class LmBatch:
         n = len(self.windows)
         arr, self._keep = marshalled if marshalled is not None else LmBatch.marshal(self.windows)
         h = C.c_void_p()
+        # the library reads its environment switches once per context (ssk_create); tests and A/B tools switch SSK_LM_KERNEL & co. on a live context
+        ctx.lib.ssk_env_refresh(ctx.h)
         t0 = time.perf_counter()
         ctx._chk(ctx.lib.ssk_lm_batch_create(ctx.h, arr, n, int(bool(trace)), C.byref(h)))
         self.create_ms = 1e3 * (time.perf_counter() - t0)      # the C call alone: symbolic build + allocation + upload (no Python marshalling)
@@ -662,6 +664,7 @@ class LmBatch:
 
     def run(self, prm, ctx=None):
         c = ctx or self.ctx
+        c.lib.ssk_env_refresh(c.h)                             # (test hooks of the cooperative kernel are switched between runs)
         c._chk(c.lib.ssk_lm_batch_run(c.h, self.h_, C.byref(prm)))
 
     def kernel_name(self):

@@ -69,6 +69,12 @@ struct ssk_lm_batch {
 	// runs): the end of the last such use, so that ssk_lm_batch_destroy does not recycle a slab that stream still writes (an event, not the context:
 	// the other context may be gone by then)
 	hipEvent_t ev_last = nullptr;
+	// COMPOSITE batch (round 5: per-window fallback): some windows of the batch do not fit the node builder (a landmark with more than 64 observations or
+	// 63 nodes, more than 128 optimised edges, a path of more than 8 steps) -- they alone go through the full builder (the tiled / general kernels of rounds
+	// 1-2) as a sub-batch of their own, every other window keeps the node / phase-split / pose-only kernels as the other sub-batch.  The composite owns no
+	// device memory; every entry point forwards (sub_of[w]: the window's sub-batch, idx_in[w]: its index there).
+	std::vector<ssk_lm_batch*> sub;
+	std::vector<int> sub_of, idx_in;
 	lm_cam coop_P{};
 	double* pose_bak = nullptr; double* lm_bak = nullptr;
 };
@@ -329,6 +335,7 @@ int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared,
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || w < 0 || w >= b->n_windows || n_shared < 0 || !p || (n_shared > 0 && (!d_out || !d_lm_idx)))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_pack_shared: bad argument");
+	if (!b->sub.empty()) return ssk_lm_batch_pack_shared(ctx, b->sub[(size_t)b->sub_of[(size_t)w]], b->idx_in[(size_t)w], n_shared, d_lm_idx, p, d_out);
 	if (n_shared == 0) return SSK_OK;
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
@@ -342,6 +349,7 @@ int ssk_lm_batch_set_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared, 
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || w < 0 || w >= b->n_windows || n_shared < 0 || (n_shared > 0 && (!d_pos || !d_lm_idx)))
 		return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_set_shared: bad argument");
+	if (!b->sub.empty()) return ssk_lm_batch_set_shared(ctx, b->sub[(size_t)b->sub_of[(size_t)w]], b->idx_in[(size_t)w], n_shared, d_lm_idx, d_pos);
 	if (n_shared == 0) return SSK_OK;
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a timed-out cooperative launch is repaired first: its restore would overwrite what is written here)
@@ -354,6 +362,7 @@ int ssk_lm_batch_set_export(ssk_ctx* ctx, ssk_lm_batch* b, int on)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_set_export: batch is NULL");
+	if (!b->sub.empty()) { for (ssk_lm_batch* sb : b->sub) { const int rcs = ssk_lm_batch_set_export(ctx, sb, on); if (rcs) return rcs; } return SSK_OK; }
 	b->D.store_hff = on ? 1 : 0;
 	return SSK_OK;
 }
@@ -458,6 +467,8 @@ int ssk_build_observations_batch(ssk_ctx* ctx, ssk_kfbatch* b, int kf_begin, int
 void ssk_lm_batch_destroy(ssk_lm_batch* b)
 {
 	if (!b) return;
+	for (ssk_lm_batch* sb : b->sub) ssk_lm_batch_destroy(sb);      // (a composite owns its sub-batches and nothing else)
+	b->sub.clear();
 	if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
 	// the slab goes back to the creating context's cache (a later create may take it, a later destroy may free it): nothing may still be in flight on
 	// it -- the create's own zero fill (when no stream waited for it yet) and whatever another context's stream was given to do on the batch
@@ -578,7 +589,7 @@ static lm_build_pool& lm_pool() { static lm_build_pool p; return p; }
 // needs none of the tiled / general structures: every window small enough for lm_solve_node_kernel (reduced system + a tile of records in LDS)
 // -> the persistent node kernel; otherwise -> the phase-split kernels (ssk_lm_split.h), whatever the windows' sizes.  Returns 1 when the
 // batch does not qualify (the caller falls back to the full builder), 0 with *out set, or an error code.
-static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out, bool want_split)
+static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out, bool want_split, std::vector<char>* unfit = nullptr)
 {
 	const int MAX_ITERS_ALLOC = 64;
 	static const bool timing = std::getenv("SSK_TIMING") != nullptr;
@@ -591,8 +602,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	// host threads of the symbolic build: SSK_LM_BUILD_THREADS, else half the logical cores, at most 64 -- and at most TWICE the container's CPU quota
 	// (cgroup cpu.max; the GPU boxes of this pool: 16 CPUs of 256): measured back to back on such a box, 1 024 bench windows per create: 64 threads
 	// 14.9 ms, 32 threads 9.7 ms, 16 threads 13.8 ms, 8 threads 22.2 ms (bursts above the quota are fine, sustained oversubscription is throttled)
-	static const int n_thr_max = [] {
-		if (const char* e = std::getenv("SSK_LM_BUILD_THREADS")) return std::max(1, std::atoi(e));
+	static const int n_thr_auto = [] {
 		const int hc = (int)std::thread::hardware_concurrency();
 		int n = std::max(1, std::min(hc / 2, 64));
 		double quota = 0.0;
@@ -610,6 +620,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		if (quota > 0.0) n = std::max(2, std::min(n, (int)(2.0 * quota + 0.5)));
 		return n;
 	}();
+	const int n_thr_max = ctx->env.lm_build_threads > 0 ? ctx->env.lm_build_threads : n_thr_auto;
 	const int n_thr_used = std::max(1, std::min(n_thr_max, n_windows / 8));      // (a thread is worth it from a handful of windows on)
 	auto parallel = [&](const std::function<void(int)>& fn) {
 		if (n_thr_used > 1) lm_pool().run(n_thr_used, n_windows, fn);
@@ -618,8 +629,8 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	};
 	// (a kernel forced by SSK_LM_KERNEL keeps every window; SSK_LM_POSE_ONLY=0: same-box A/B)
 	// (SSK_LM_FEW_SPLIT=0: a small batch keeps the node kernel for every window that fits it -- tests of that kernel on single windows, same-box A/B)
-	const bool few_windows = n_windows <= 8 && !std::getenv("SSK_LM_KERNEL") && !(std::getenv("SSK_LM_FEW_SPLIT") && std::atoi(std::getenv("SSK_LM_FEW_SPLIT")) == 0);
-	const bool pose_ok = !want_split && !(std::getenv("SSK_LM_POSE_ONLY") && std::atoi(std::getenv("SSK_LM_POSE_ONLY")) == 0);
+	const bool few_windows = n_windows <= 8 && ctx->env.lm_kernel.empty() && ctx->env.lm_few_split;
+	const bool pose_ok = !want_split && ctx->env.lm_pose_only;
 	// ---- (1) per window: checks; its kernel family -- the pose-only kernel for a window without optimised landmarks, the persistent node kernel when the reduced system and a tile of records fit LDS, the
 	// phase-split kernels otherwise (or for every window: SSK_LM_KERNEL=split): no all-or-nothing choice for a mixed batch --; its node tables ----
 	parallel([&](int w) {
@@ -641,7 +652,14 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	const auto t_ph1 = std::chrono::steady_clock::now();
 	for (int w = 0; w < n_windows; ++w) {
 		if (lw[(size_t)w].bad == 2) { int E, L, np; std::vector<int> a, c; return lm_validate_window(ctx, windows[w], w, E, L, a, c, np); }      // (again, for the message)
-		if (lw[(size_t)w].bad) return 1;
+	}
+	{
+		bool any = false;
+		for (int w = 0; w < n_windows; ++w) any = any || lw[(size_t)w].bad;
+		if (any) {                                        // (which windows: the caller solves THEM with the full builder's kernels, not the whole batch)
+			if (unfit) { unfit->assign((size_t)n_windows, 0); for (int w = 0; w < n_windows; ++w) (*unfit)[(size_t)w] = lw[(size_t)w].bad; }
+			return 1;
+		}
 	}
 	// ---- (2) bases ----
 	std::vector<lm_win> hdr((size_t)n_windows);
@@ -685,7 +703,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		};
 		const size_t need = tb(zn) + tb(zs) + sizeof(int) * (n_edge_t + n_lm_t + n_obs_t + n_opo_t + n_path_t + n_us_t + n_ls_t) + sizeof(double) * (12 * n_edge_t + 3 * n_lm_t) +
 		                    sizeof(float) * 4 * n_obs_t + 64 * 64;
-		const bool no_pin = std::getenv("SSK_LM_NO_PINNED") != nullptr;      // (read per create: tests switch it)
+		const bool no_pin = ctx->env.lm_no_pinned;
 		if (!no_pin && need <= ((size_t)1 << 30)) {
 			// the arena only grows inside ssk_arena_reserve: after one large batch a context would hold up to 1 GB of pinned host memory until
 			// ssk_destroy.  Eight creates in a row that need less than a quarter of it give it back (a streak, not one small create: bench.py and
@@ -765,7 +783,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	UP(pose, pose0); UP(lm, lm0);
 #undef UP
 	// launch order / XCD placement: windows by observations x optimised edges, largest first
-	const bool by_size = [] { const char* oe = std::getenv("SSK_LM_ORDER"); return !oe || std::atoi(oe) != 0; }();
+	const bool by_size = ctx->env.lm_order;
 	auto ordered = [&](const nd_host& NH, bool sp) {
 		std::vector<int> ord;
 		for (int w = 0; w < n_windows; ++w) if (w_split[(size_t)w] == (sp ? 1 : 0)) ord.push_back(w);
@@ -837,7 +855,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		size_t sd = 0, id = 0;
 		int E_max = 0;
 		for (const nd_win& nw : NHs.win) E_max = std::max(E_max, nw.E);
-		bool mfma = ssk_sp_solve_mfma(E_max);
+		bool mfma = ssk_sp_solve_mfma(E_max, ctx->env.k2_regtile);
 		for (int attempt = 0; attempt < 2; ++attempt) {
 			sd = 0; id = 0;
 			for (const nd_win& nw : NHs.win) {
@@ -891,7 +909,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	const auto t_fin = std::chrono::steady_clock::now();
 	if (!rc) rc = finalize(b);
 	if (rc) { ssk_lm_batch_destroy(b); return rc; }
-	if (std::getenv("SSK_LM_DEBUG"))
+	if (ctx->env.lm_debug)
 		std::fprintf(stderr, "[ssk lm] lean batch: %d windows for the node kernel, %d for the phase-split kernels (%zu tiles, %zu items, %lld partial slots, most blocks of a tile %d)\n",
 		             n_node, n_split, NHs.tile.size(), NHs.item.size(), NHs.part_slots, NHs.max_tile_blocks);
 	b->symbolic_ms = std::chrono::duration<double, std::milli>(t_sym - t_begin).count();
@@ -917,7 +935,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	// Default by size (profiles/r02_lm_mfma_vs_sparse.json: the two forms are within 1-7 % of each other at every size measured): matrix
 	// cores where the reduced system is larger than the on-chip accumulation limit (E > 12: the local areas of the un-batched drop-in
 	// path, E ~ 40), sparse items below it (the E = 10 windows of the batched bench: 8.59 ms against 8.72 per 1024 windows).
-	const char* schur_env = std::getenv("SSK_LM_SCHUR");
+	const char* schur_env = ctx->env.lm_schur == 1 ? "mfma" : ctx->env.lm_schur == 2 ? "sparse" : nullptr;
 	int max_E = 0;
 	for (int w = 0; windows && w < n_windows; ++w) {
 		int E = 0;
@@ -930,7 +948,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	// the matrix-core form keeps a landmark's 16-row-tile set in a 32-bit mask: 6E + 15 <= 16 * 31, i.e. E <= 80
 	const bool mfma_fits = ssk_lma_row_tiles(max_E) <= 31;
 	const int schur_mfma = mfma_fits && (schur_env ? (std::strcmp(schur_env, "sparse") != 0) : schur_mfma_default);
-	const char* force_k = std::getenv("SSK_LM_KERNEL");
+	const char* force_k = ctx->env.lm_kernel.empty() ? nullptr : ctx->env.lm_kernel.c_str();
 	const bool force_acc = force_k && std::strcmp(force_k, "acc") == 0;
 	if (want_acc && windows && n_windows > 0) {            // cheap look ahead: one window with too many optimised edges rules the acc kernel out
 		for (int w = 0; w < n_windows && want_acc; ++w) {
@@ -1390,7 +1408,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 						Rs = Rp;
 					}
 				}
-				if (w == 0 && std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm]   tile %d: H_pp items %zu (<= %d per lane), Schur items %zu (<= %d per lane), %d idle wavefronts\n", tile_no, pitems.size(), Rp, qitems.size(), Rs, idle);
+				if (w == 0 && ctx->env.lm_debug) std::fprintf(stderr, "[ssk lm]   tile %d: H_pp items %zu (<= %d per lane), Schur items %zu (<= %d per lane), %d idle wavefronts\n", tile_no, pitems.size(), Rp, qitems.size(), Rs, idle);
 				make_groups(pitems, Rp, w_pit, w_pgrp, w_pslot0, pslots_of, n_pslots, T.n_pg, T.n_pc);
 				T.sg0 = (int)w_sgrp.size(); T.sc0 = (int)w_sslot0.size();
 				make_groups(qitems, Rs, w_qit, w_sgrp, w_sslot0, sslots_of, n_sslots, T.n_sg, T.n_sc);
@@ -1496,7 +1514,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		}
 		if (!tiled) tiled_all = false;
 		const auto tp3 = tnow();
-		if (w == 0 && std::getenv("SSK_LM_DEBUG")) {
+		if (w == 0 && ctx->env.lm_debug) {
 			std::fprintf(stderr, "[ssk lm] window 0: E %d L %d obs %d path %d lme %d tiles %d (region %lld B) pslots %d sslots %d\n", E, L, Wn.n_obs, n_path, n_lme,
 			             tiled ? (int)w_tiles.size() : -1, region_bytes, n_pslots, n_sslots);
 			for (const lm_tile& T : w_tiles)
@@ -1661,8 +1679,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 			node_order.resize((size_t)n_windows);
 			std::vector<int>& ord = node_order;       // (lives until finalize() copies it)
 			for (int w = 0; w < n_windows; ++w) ord[(size_t)w] = w;
-			const char* oe = std::getenv("SSK_LM_ORDER");
-			if (!oe || std::atoi(oe) != 0)
+			if (ctx->env.lm_order)
 				std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return (long long)NH.win[a].n_obs * (NH.win[a].E + 4) > (long long)NH.win[c].n_obs * (NH.win[c].E + 4); });
 			if (!rc) rc = upload(b, ord, &b->N.order);
 		}
@@ -1671,7 +1688,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		b->node_dyn_bytes = 8 * (node_big ? NH.lds_doubles_big : NH.lds_doubles);
 		b->node_small = !node_big;
 		for (const nd_win& nw : NH.win) b->node_small = b->node_small && nw.E <= 10;
-		if (std::getenv("SSK_LM_DEBUG"))
+		if (ctx->env.lm_debug)
 		{
 			long long rounds = 0;
 			for (int t = 0; t < NH.win[0].n_tiles; ++t) rounds += NH.tile[NH.win[0].tile0 + t].n_rounds;
@@ -1685,7 +1702,7 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	// SSK_LM_LDL=mfma (needs the matrix-core Schur form): the kernels whose L2-resident reduced systems are factorised in 16-column panels
 	// with the trailing update on the matrix cores (lm_solve_*_ldlm_kernel); default: the six-column VALU solver -- measured faster,
 	// profiles/r02_lm_ldl_mfma_vs_valu.json
-	{ const char* ldl = std::getenv("SSK_LM_LDL"); D.ldl_mfma = ldl && std::strcmp(ldl, "mfma") == 0 && schur_mfma; if (D.ldl_mfma) b->schur_mfma = 2; }
+	{ D.ldl_mfma = ctx->env.lm_ldl_mfma && schur_mfma; if (D.ldl_mfma) b->schur_mfma = 2; }
 	b->max_tiles = 0;
 	for (const lm_win& hw : b->hdr) b->max_tiles = std::max(b->max_tiles, hw.n_tiles);
 	if (!rc) rc = upload(b, pose, const_cast<const double**>(&D.pose));     // working copies of the state (pose0 / lm0 keep the initial one)
@@ -1747,7 +1764,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 {
 	// SSK_LM_KERNEL: l2 = the general scratch-in-L2 kernel, tiled / coop = the slot kernels (one / several workgroups per window),
 	// acc = on-chip accumulation (windows with E <= SSK_LMA_MAX_E; on request: its accumulators cost LDS, i.e. more tiles per pass)
-	const char* force = std::getenv("SSK_LM_KERNEL");
+	const char* force = ctx->env.lm_kernel.empty() ? nullptr : ctx->env.lm_kernel.c_str();
 	const bool l2 = force && std::strcmp(force, "l2") == 0;
 	const bool want_acc = force && std::strcmp(force, "acc") == 0;
 	// the default: node tables only (node kernel for windows whose reduced system fits LDS, the phase-split kernels otherwise; =split forces
@@ -1756,9 +1773,32 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		if (!ctx) return SSK_ERR_BAD_ARG;
 		if (!windows || n_windows < 1 || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: bad argument");
 		SSK_HIP(ctx, hipSetDevice(ctx->device));
-		const int rc = lm_batch_create_lean(ctx, windows, n_windows, trace, out, force != nullptr);
+		std::vector<char> unfit;
+		const int rc = lm_batch_create_lean(ctx, windows, n_windows, trace, out, force != nullptr, &unfit);
 		if (rc != 1) return rc;
 		if (force) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: SSK_LM_KERNEL=split, but a window of the batch does not fit the node builder");
+		// per-window fallback: the windows the node builder cannot take go through the full builder ALONE (a sub-batch); the others keep their kernels
+		int n_unfit = 0;
+		for (char u : unfit) n_unfit += u != 0;
+		if (n_unfit > 0 && n_unfit < n_windows) {
+			std::unique_ptr<ssk_lm_batch, void (*)(ssk_lm_batch*)> c(new ssk_lm_batch(), ssk_lm_batch_destroy);
+			c->ctx = ctx; c->n_windows = n_windows; c->trace = trace; c->max_iters_alloc = 64;
+			c->sub_of.resize((size_t)n_windows); c->idx_in.resize((size_t)n_windows);
+			std::vector<ssk_lm_window> part[2];
+			for (int w = 0; w < n_windows; ++w) {
+				const int k = unfit[(size_t)w] ? 1 : 0;
+				c->sub_of[(size_t)w] = k; c->idx_in[(size_t)w] = (int)part[k].size();
+				part[k].push_back(windows[w]);
+			}
+			c->sub.assign(2, nullptr);
+			int rc2 = lm_batch_create_lean(ctx, part[0].data(), (int)part[0].size(), trace, &c->sub[0], false);
+			if (rc2 == 1) rc2 = ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: a window changed its mind about fitting the node builder");
+			if (rc2 == SSK_OK) rc2 = lm_batch_create_impl(ctx, part[1].data(), (int)part[1].size(), trace, &c->sub[1], false, false);
+			if (rc2 != SSK_OK) return rc2;                  // (the composite's destructor frees what was made)
+			for (ssk_lm_batch* sb : c->sub) { c->symbolic_ms += sb->symbolic_ms; c->symbolic_threads = std::max(c->symbolic_threads, sb->symbolic_threads); c->max_n6 = std::max(c->max_n6, sb->max_n6); }
+			*out = c.release();
+			return SSK_OK;
+		}
 	}
 	return lm_batch_create_impl(ctx, windows, n_windows, trace, out, l2, want_acc);
 }
@@ -1779,8 +1819,8 @@ static int lm_batch_settle(ssk_ctx* ctx, ssk_lm_batch* b)
 	SSK_HIP(ctx, hipMemcpy(r.data(), b->D.res, sizeof(ssk_lm_result) * r.size(), hipMemcpyDeviceToHost));
 	bool timed_out = false;
 	for (const ssk_lm_result& x : r) timed_out |= x.stop_reason == 5;
-	if (!timed_out || std::getenv("SSK_LM_COOP_NO_FALLBACK")) return SSK_OK;
-	static const bool verbose = std::getenv("SSK_LM_DEBUG") != nullptr;
+	if (!timed_out || ctx->env.lm_coop_no_fallback) return SSK_OK;
+	const bool verbose = ctx->env.lm_debug;
 	if (verbose) std::fprintf(stderr, "[ssk lm] cooperative launch timed out at a barrier: repeating with one workgroup per window\n");
 	SSK_HIP(ctx, hipMemcpyAsync(b->D.pose, b->pose_bak, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
 	SSK_HIP(ctx, hipMemcpyAsync(b->D.lm, b->lm_bak, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1791,6 +1831,7 @@ int ssk_lm_batch_reset(ssk_ctx* ctx, ssk_lm_batch* b)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_reset: batch is NULL");
+	if (!b->sub.empty()) { for (ssk_lm_batch* sb : b->sub) { const int rcs = ssk_lm_batch_reset(ctx, sb); if (rcs) return rcs; } return SSK_OK; }
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	b->coop_pending = false;                          // (the state is overwritten: a timed-out launch needs no repair)
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (the create's zero fill)
@@ -1801,6 +1842,10 @@ static int lm_batch_run_impl(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params*
 int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (b && !b->sub.empty()) {                        // (one after the other on the stream: the node / split kernels of the many, then the few windows of the full builder)
+		for (ssk_lm_batch* sb : b->sub) { const int rcs = ssk_lm_batch_run(ctx, sb, p); if (rcs) return rcs; }
+		return SSK_OK;
+	}
 	const int rc = lm_batch_run_impl(ctx, b, p);
 	return b ? lm_batch_mark(ctx, b, rc) : rc;
 }
@@ -1819,7 +1864,7 @@ static int lm_batch_run_impl(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params*
 	P.max_lambda = p->max_lambda; P.stop_rmse = p->max_error_per_obs_to_stop; P.conv_rel = p->converged_rel_decrease;
 	// two kernels, one contract: the LDS-tiled kernel when every window of the batch fits it (SSK_LM_KERNEL=l2 forces
 	// the general scratch-in-L2 kernel, which takes windows of any size)
-	const char* force = std::getenv("SSK_LM_KERNEL");
+	const char* force = ctx->env.lm_kernel.empty() ? nullptr : ctx->env.lm_kernel.c_str();
 	// few large windows (the un-batched drop-in: one local area of tens of tiles): G workgroups per window share its tiles,
 	// all resident at once (one per CU); SSK_LM_KERNEL=tiled keeps one workgroup per window, =coop forces the split
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }      // (a run on top of a timed-out cooperative launch continues from the repaired state)
@@ -1839,18 +1884,18 @@ static int lm_batch_run_impl(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params*
 		// at most 32 workgroups per window: beyond that the barriers (seven, then four per attempt) cost more than the shorter tile phase
 		// gives back (measured on 50- and 120-tile local areas: 32 beats 64 by 3 %, 16 loses 7 %); SSK_LM_COOP_G overrides
 		int gmax = 32;
-		if (const char* gcap = std::getenv("SSK_LM_COOP_G")) gmax = std::max(1, std::min(64, std::atoi(gcap)));
+		if (ctx->env.lm_coop_g > 0) gmax = ctx->env.lm_coop_g;
 		int G = std::min(std::min(b->max_tiles, gmax), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
 		// (windows whose suffix table lives in L2 scratch need one table per workgroup: sized for it only when the batch is small enough)
 		const bool want = b->gtab_multi && (force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu));
-		if (std::getenv("SSK_LM_DEBUG")) std::fprintf(stderr, "[ssk lm] run: %d windows, max tiles %d, %d workgroups per CU -> %s, G %d, max 6E %d, Schur %s\n", b->n_windows, b->max_tiles, per_cu,
+		if (ctx->env.lm_debug) std::fprintf(stderr, "[ssk lm] run: %d windows, max tiles %d, %d workgroups per CU -> %s, G %d, max 6E %d, Schur %s\n", b->n_windows, b->max_tiles, per_cu,
 		                                              want ? "cooperative" : "one workgroup per window", G, b->max_n6, b->schur_mfma ? "mfma" : "sparse");
 		if (want) {
 			// residency is still not guaranteed (another stream or process may hold CUs): keep the state the launch starts
 			// from, ssk_lm_batch_results repeats a launch that ended in stop_reason 5 with one workgroup per window
 			SSK_HIP(ctx, hipMemcpyAsync(b->pose_bak, b->D.pose, sizeof(double) * b->n_pose, hipMemcpyDeviceToDevice, ctx->stream));
 			SSK_HIP(ctx, hipMemcpyAsync(b->lm_bak, b->D.lm, sizeof(double) * b->n_lm, hipMemcpyDeviceToDevice, ctx->stream));
-			const bool test_timeout = std::getenv("SSK_LM_COOP_TEST_TIMEOUT") != nullptr;
+			const bool test_timeout = ctx->env.lm_coop_test_timeout;
 			const int rc = ssk_lm_launch_coop(ctx, b->D, P, b->n_windows, G, b->tiled_dyn_bytes, test_timeout, b->schur_mfma);
 			if (rc == SSK_OK) { b->coop_pending = true; b->coop_P = P; }
 			return rc;
@@ -1865,8 +1910,16 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || !out || cap < 1) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_kernel_name: bad argument");
+	if (!b->sub.empty()) {                            // "<kernel of the windows the node builder took>+<kernel of the others>"
+		char a0[96], a1[96];
+		int rcs = ssk_lm_batch_kernel_name(ctx, b->sub[0], a0, (int)sizeof a0);
+		if (!rcs) rcs = ssk_lm_batch_kernel_name(ctx, b->sub[1], a1, (int)sizeof a1);
+		if (rcs) return rcs;
+		std::snprintf(out, (size_t)cap, "%s+%s", a0, a1);
+		return SSK_OK;
+	}
 	// the same decisions as ssk_lm_batch_run
-	const char* force = std::getenv("SSK_LM_KERNEL");
+	const char* force = ctx->env.lm_kernel.empty() ? nullptr : ctx->env.lm_kernel.c_str();
 	const char* name = "lm_solve_kernel";
 	if (b->split_ok) name = "lm_split_linearise_kernel";      // (the heaviest kernel of a pass; a mixed batch also runs lm_solve_node_kernel on its small windows)
 	else if (b->node_ok) name = b->node_big ? "lm_solve_node_big_kernel" : b->node_small ? "lm_solve_node_e10_kernel" : "lm_solve_node_kernel";
@@ -1877,7 +1930,7 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 		if (!(force && (std::strcmp(force, "l2") == 0 || std::strcmp(force, "tiled") == 0))) {
 			const int per_cu = ssk_lm_coop_blocks_per_cu(ctx, b->tiled_dyn_bytes, b->schur_mfma);
 			int gmax = 32;
-			if (const char* gcap = std::getenv("SSK_LM_COOP_G")) gmax = std::max(1, std::min(64, std::atoi(gcap)));
+			if (ctx->env.lm_coop_g > 0) gmax = ctx->env.lm_coop_g;
 			const int G = std::min(std::min(b->max_tiles, gmax), per_cu * ctx->n_cu / std::max(b->n_windows, 1));
 			coop = b->gtab_multi && (force && std::strcmp(force, "coop") == 0 ? G >= 2 : (G >= 4 && b->n_windows * 4 <= ctx->n_cu));
 		}
@@ -1901,6 +1954,14 @@ int ssk_lm_batch_results(ssk_ctx* ctx, ssk_lm_batch* b, ssk_lm_result* out)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_results: NULL argument");
+	if (!b->sub.empty()) {
+		std::vector<ssk_lm_result> r0((size_t)b->sub[0]->n_windows), r1((size_t)b->sub[1]->n_windows);
+		int rcs = ssk_lm_batch_results(ctx, b->sub[0], r0.data());
+		if (!rcs) rcs = ssk_lm_batch_results(ctx, b->sub[1], r1.data());
+		if (rcs) return rcs;
+		for (int w = 0; w < b->n_windows; ++w) out[w] = (b->sub_of[(size_t)w] ? r1 : r0)[(size_t)b->idx_in[(size_t)w]];
+		return SSK_OK;
+	}
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1917,6 +1978,7 @@ int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_in
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || w < 0 || w >= b->n_windows) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_state: bad argument");
+	if (!b->sub.empty()) return ssk_lm_batch_get_state(ctx, b->sub[(size_t)b->sub_of[(size_t)w]], b->idx_in[(size_t)w], edge_inv_pose, lm_pos);
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1930,6 +1992,7 @@ int ssk_lm_batch_set_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, const double* e
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || w < 0 || w >= b->n_windows) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_set_state: bad argument");
+	if (!b->sub.empty()) return ssk_lm_batch_set_state(ctx, b->sub[(size_t)b->sub_of[(size_t)w]], b->idx_in[(size_t)w], edge_inv_pose, lm_pos);
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1953,6 +2016,7 @@ int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_en
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
 	if (!b || w < 0 || w >= b->n_windows || !entries || !n_entries) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_trace: bad argument");
+	if (!b->sub.empty()) return ssk_lm_batch_get_trace(ctx, b->sub[(size_t)b->sub_of[(size_t)w]], b->idx_in[(size_t)w], entries, cap, delta_p, delta_f, n_entries);
 	if (!b->trace) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_trace: the batch was created without trace");
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }

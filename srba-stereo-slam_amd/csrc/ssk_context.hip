@@ -1,5 +1,6 @@
 // ssk_context.hip -- context, error text, arenas, stream + HIP-event timer of libssk_hip.so.
 #include "ssk_internal.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cmath>
 #include "../../include/ssk_brief_pattern.h"
@@ -27,6 +28,35 @@ int ssk_set_error(ssk_ctx* ctx, int code, const char* fmt, ...)
 	va_end(ap);
 	if (ctx) ctx->err = buf; else g_create_error = buf;
 	return code;
+}
+
+void ssk_env_read(ssk_env& e)
+{
+	auto str = [](const char* k) { const char* v = std::getenv(k); return std::string(v ? v : ""); };
+	auto off = [](const char* k) { const char* v = std::getenv(k); return v && std::atoi(v) == 0; };      // "NAME=0" switches a default off
+	auto set = [](const char* k) { return std::getenv(k) != nullptr; };
+	e = ssk_env();
+	e.lm_kernel = str("SSK_LM_KERNEL");
+	e.lm_few_split = !off("SSK_LM_FEW_SPLIT");
+	e.lm_pose_only = !off("SSK_LM_POSE_ONLY");
+	e.lm_no_pinned = set("SSK_LM_NO_PINNED");
+	e.lm_order = !off("SSK_LM_ORDER");
+	e.lm_debug = set("SSK_LM_DEBUG");
+	{ const std::string v = str("SSK_LM_SCHUR"); e.lm_schur = v == "mfma" ? 1 : v == "sparse" ? 2 : 0; }
+	e.lm_ldl_mfma = str("SSK_LM_LDL") == "mfma";
+	if (const char* v = std::getenv("SSK_LM_COOP_G")) e.lm_coop_g = std::max(1, std::min(64, std::atoi(v)));
+	e.lm_coop_test_timeout = set("SSK_LM_COOP_TEST_TIMEOUT");
+	e.lm_coop_no_fallback = set("SSK_LM_COOP_NO_FALLBACK");
+	e.sp_no_poll = set("SSK_SP_NO_POLL");
+	e.k2_regtile = str("SSK_K2_SOLVER") == "regtile";
+	if (const char* v = std::getenv("SSK_LM_BUILD_THREADS")) e.lm_build_threads = std::max(1, std::atoi(v));
+}
+
+int ssk_env_refresh(ssk_ctx* ctx)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	ssk_env_read(ctx->env);
+	return SSK_OK;
 }
 
 int ssk_arena_reserve(ssk_ctx* ctx, ssk_arena& a, size_t bytes)
@@ -124,6 +154,7 @@ int ssk_create(ssk_ctx** out, int device, void* hip_stream)
 	else { CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
 	CREATE_HIP(hipEventCreate(&ctx->ev_start));
 	CREATE_HIP(hipEventCreate(&ctx->ev_stop));
+	ssk_env_read(ctx->env);
 	compute_dir_thresholds(ctx->dir_thresh);
 	CREATE_HIP(hipMalloc((void**)&ctx->d_dir_thresh, sizeof ctx->dir_thresh));
 	CREATE_HIP(hipMemcpy(ctx->d_dir_thresh, ctx->dir_thresh, sizeof ctx->dir_thresh, hipMemcpyHostToDevice));

@@ -19,8 +19,29 @@ struct ssk_arena {
 	bool pinned_host = false;
 };
 
+// The library's environment switches, read ONCE per context (ssk_create) -- not per call -- and again only when the caller asks (ssk_env_refresh: the
+// Python binding does so in front of an LM batch create, so that tests and same-box A/Bs can switch kernels on a live context).  Defaults = what
+// DESIGN.md 6's numbers were measured with; the switches are listed in DESIGN.md 5 "Switches".
+struct ssk_env {
+	std::string lm_kernel;              // SSK_LM_KERNEL: "" (default: node / phase-split / pose-only), split, node, tiled, coop, acc, l2
+	bool lm_few_split = true;           // SSK_LM_FEW_SPLIT=0: a batch of at most 8 windows keeps the node kernel for every window that fits it
+	bool lm_pose_only = true;           // SSK_LM_POSE_ONLY=0: pose-only windows on the node kernel
+	bool lm_no_pinned = false;          // SSK_LM_NO_PINNED: the batch's tables in pageable memory
+	bool lm_order = true;               // SSK_LM_ORDER=0: windows launched as given (default: largest first)
+	bool lm_debug = false;              // SSK_LM_DEBUG
+	int lm_schur = 0;                   // SSK_LM_SCHUR: 0 default (matrix cores for E > 12), 1 mfma, 2 sparse
+	bool lm_ldl_mfma = false;           // SSK_LM_LDL=mfma
+	int lm_coop_g = 0;                  // SSK_LM_COOP_G (0: default, at most 32)
+	bool lm_coop_test_timeout = false, lm_coop_no_fallback = false;      // test hooks of the cooperative kernel's barrier time-out
+	bool sp_no_poll = false;            // SSK_SP_NO_POLL
+	bool k2_regtile = false;            // SSK_K2_SOLVER=regtile
+	int lm_build_threads = 0;           // SSK_LM_BUILD_THREADS (0: from the core count and the cgroup's CPU quota)
+};
+void ssk_env_read(ssk_env& e);
+
 struct ssk_ctx {
 	int device = -1;
+	ssk_env env;
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;

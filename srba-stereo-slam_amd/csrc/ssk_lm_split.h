@@ -57,7 +57,7 @@ struct sp_dev {
 constexpr int SSK_SP_WAVES = 4;         // wavefronts per K1 / K3 workgroup = landmark groups per tile
 // K2: the solver of a batch whose largest window optimises E_max edges: true = ldl_solve_mfma_tiles (ssk_lm_ldl_mfma.h: the system in MFMA
 // accumulator tiles, up to 255 unknowns; SSK_K2_SOLVER=regtile: never), false = ldl_solve_regtile
-bool ssk_sp_solve_mfma(int E_max);
+bool ssk_sp_solve_mfma(int E_max, bool force_regtile /* SSK_K2_SOLVER=regtile */);
 // K2: dynamic LDS of the solve kernel (doubles): the solver's staging + the window's edge poses and trie records
 size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma);
 

@@ -422,7 +422,7 @@ int ssk_lm_launch_split(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp
 	// A small batch (the un-batched drop-in: one local area per keyframe) is latency bound: after the passes a solve usually takes the host asks
 	// how many windows still run and stops enqueueing when none does (a window's workgroups leave at once in a pass it does not need, but five
 	// launches per pass are not free).  A large batch is enqueued whole: ssk_lm_batch_run stays asynchronous there.
-	const bool poll = n_windows <= 8 && !std::getenv("SSK_SP_NO_POLL");
+	const bool poll = n_windows <= 8 && !ctx->env.sp_no_poll;
 	int* h_poll = nullptr;
 	if (poll) { if (ssk_arena_reserve(ctx, ctx->pin, 256)) return SSK_ERR_HIP; h_poll = reinterpret_cast<int*>(ctx->pin.base); }
 	int next_poll = 10;

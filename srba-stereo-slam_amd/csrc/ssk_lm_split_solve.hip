@@ -134,11 +134,9 @@ extern "C" int ssk_lm_k2_stamps(unsigned long long* out16, int reset)
 }
 #endif
 
-bool ssk_sp_solve_mfma(int E_max)
+bool ssk_sp_solve_mfma(int E_max, bool force_regtile)
 {
-	const char* e = std::getenv("SSK_K2_SOLVER");          // (read per create: tests and same-box A/B switch it)
-	const bool no_mfma = e && std::strcmp(e, "regtile") == 0;
-	return SSK_K2_MFMA && !no_mfma && 6 * E_max <= LDLM_NMAX;
+	return SSK_K2_MFMA && !force_regtile && 6 * E_max <= LDLM_NMAX;
 }
 
 size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma)
