@@ -1842,9 +1842,27 @@ static int lm_batch_run_impl(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params*
 int ssk_lm_batch_run(ssk_ctx* ctx, ssk_lm_batch* b, const ssk_lm_params* p)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
-	if (b && !b->sub.empty()) {                        // (one after the other on the stream: the node / split kernels of the many, then the few windows of the full builder)
-		for (ssk_lm_batch* sb : b->sub) { const int rcs = ssk_lm_batch_run(ctx, sb, p); if (rcs) return rcs; }
-		return SSK_OK;
+	if (b && !b->sub.empty()) {
+		// the few windows of the full builder run BESIDE the many (a side stream of the context, forked from and joined to its stream by events): one
+		// persistent workgroup per odd window would otherwise add its whole latency to the batch's
+		SSK_HIP(ctx, hipSetDevice(ctx->device));
+		if (!ctx->side_stream) {
+			SSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+			SSK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_a, hipEventDisableTiming));
+			SSK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_b, hipEventDisableTiming));
+		}
+		SSK_HIP(ctx, hipEventRecord(ctx->ev_side_a, ctx->stream));
+		SSK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_side_a, 0));
+		hipStream_t main_stream = ctx->stream;
+		ctx->stream = ctx->side_stream;                 // (a context serves one thread at a time: nobody else looks at it meanwhile)
+		const int rc1 = ssk_lm_batch_run(ctx, b->sub[1], p);
+		hipError_t e1 = hipEventRecord(ctx->ev_side_b, ctx->side_stream);
+		ctx->stream = main_stream;
+		if (rc1) return rc1;
+		if (e1 != hipSuccess) return ssk_set_error(ctx, SSK_ERR_HIP, "ssk_lm_batch_run: hipEventRecord failed: %s", hipGetErrorString(e1));
+		const int rc0 = ssk_lm_batch_run(ctx, b->sub[0], p);
+		SSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side_b, 0));
+		return rc0;
 	}
 	const int rc = lm_batch_run_impl(ctx, b, p);
 	return b ? lm_batch_mark(ctx, b, rc) : rc;

@@ -198,6 +198,9 @@ void ssk_destroy(ssk_ctx* ctx)
 	if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
 	if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
 	if (ctx->ev_lm_up) (void)hipEventDestroy(ctx->ev_lm_up);
+	if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+	if (ctx->ev_side_a) (void)hipEventDestroy(ctx->ev_side_a);
+	if (ctx->ev_side_b) (void)hipEventDestroy(ctx->ev_side_b);
 	if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }

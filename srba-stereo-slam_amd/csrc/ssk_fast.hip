@@ -82,6 +82,41 @@ __device__ __forceinline__ void ring_diffs_packed(const uint8_t* p, uint32_t (&A
 	for (int k = 0; k < 8; ++k) A[k] = as_u32(as_s16x2(r[2 * k] | (r[2 * k + 1] << 16)) - as_s16x2(cc));
 }
 
+// Round 5: the score of ONE polarity.  score = max(bright, -dark) with bright = max over the 16 arcs of 9 of the arc's min difference, -dark the same of
+// the negated differences.  A pixel whose compass test failed for a polarity at threshold t has no arc of that polarity at t, i.e. that polarity's
+// score is <= t -- it cannot be the maximum of a corner (whose other score is > t) and does not matter for a non-corner.  So the polarity the compass
+// test passed is enough: half of fast_s_packed's min / max chains.  sgn2 = (+1, +1) or (-1, -1) packed: the ring differences come out signed for
+// the polarity by ONE v_pk_mad_i16 per pair (r * sgn - c * sgn) -- what the plain subtraction cost.
+__device__ __forceinline__ void ring_diffs_signed(const uint8_t* p, uint32_t sgn2, uint32_t (&A)[8])
+{
+	const uint32_t c = p[0], cc = c | (c << 16);
+	const uint32_t r[16] = {p[3 * IW], p[3 * IW + 1], p[2 * IW + 2], p[IW + 3], p[3], p[-IW + 3], p[-2 * IW + 2], p[-3 * IW + 1],
+	                        p[-3 * IW], p[-3 * IW - 1], p[-2 * IW - 2], p[-IW - 3], p[-3], p[IW - 3], p[2 * IW - 2], p[3 * IW - 1]};
+	const s16x2 s2 = as_s16x2(sgn2), ncs = as_s16x2(0u) - as_s16x2(cc) * s2;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) A[k] = as_u32(as_s16x2(r[2 * k] | (r[2 * k + 1] << 16)) * s2 + ncs);
+}
+__device__ __forceinline__ int fast_s_one(const uint32_t (&A)[8])
+{
+	s16x2 a[8], b[8], lo[8], t[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) a[k] = as_s16x2(A[k]);
+#pragma unroll
+	for (int k = 0; k < 8; ++k) b[k] = as_s16x2(__builtin_amdgcn_alignbyte(A[(k + 1) & 7], A[k], 2u));   // (d[2k+1], d[2k+2])
+#pragma unroll
+	for (int k = 0; k < 8; ++k) lo[k] = __builtin_elementwise_min(a[k], b[k]);                      // runs of 2
+#pragma unroll
+	for (int k = 0; k < 8; ++k) t[k] = __builtin_elementwise_min(lo[k], lo[(k + 1) & 7]);           // runs of 4
+#pragma unroll
+	for (int k = 0; k < 8; ++k) lo[k] = __builtin_elementwise_min(t[k], t[(k + 2) & 7]);            // runs of 8
+#pragma unroll
+	for (int k = 0; k < 8; ++k) lo[k] = __builtin_elementwise_min(lo[k], a[(k + 4) & 7]);           // arcs of 9
+	s16x2 sb = lo[0];
+#pragma unroll
+	for (int k = 1; k < 8; ++k) sb = __builtin_elementwise_max(sb, lo[k]);
+	return max(max((int)sb.x, (int)sb.y), 0);
+}
+
 // append the values of the lanes with pred to an LDS queue: one ds atomic per wave
 __device__ __forceinline__ void wave_push(bool pred, uint16_t val, uint16_t* queue, int* counter)
 {
@@ -125,6 +160,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 	__shared__ __attribute__((aligned(16))) uint8_t s_img[IH * IW];
 	__shared__ __attribute__((aligned(16))) uint8_t s_sc[SH * SP];
 	__shared__ uint16_t s_q1[NQ];
+	__shared__ uint8_t s_pol[(SG * SH + 3) & ~3];      // per 4-pixel group: compass survivors as bright (bits 0..3) / dark (bits 4..7) candidates
 	__shared__ uint16_t s_q2[NQ];
 	__shared__ uint32_t s_out[TW * TH / 4 + 64];
 	__shared__ int s_q1n, s_q2n, s_on, s_base;
@@ -217,7 +253,9 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 					// one of {4,12}, all brighter than c+t or all darker than c-t.  Saturating packed subtracts turn the
 					// compares into "non-zero" and min() into AND: ~48 instructions for 4 pixels instead of ~100.
 					const u16x2 t2 = as_u16x2((uint32_t)threshold * 0x00010001u);
-					uint32_t res[2];
+					// (round 5: "N or S brighter than c + t" is max(N, S) > c + t, "darker" min(N, S) < c - t: a max / min and ONE saturating subtract per
+					// pair of compass points instead of two subtracts and an OR; bright and dark survivors kept apart for the one-polarity score)
+					uint32_t rb[2], rd[2];
 #pragma unroll
 					for (int hsel = 0; hsel < 2; ++hsel) {
 						const uint32_t sel = hsel ? 0x0c030c02u : 0x0c010c00u;   // bytes (0,1) or (2,3) -> the two 16-bit lanes
@@ -225,23 +263,29 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 						const u16x2 a0 = as_u16x2(__builtin_amdgcn_perm(0u, Dn, sel)), a8 = as_u16x2(__builtin_amdgcn_perm(0u, Up, sel));
 						const u16x2 a4 = as_u16x2(__builtin_amdgcn_perm(0u, E, sel)), a12 = as_u16x2(__builtin_amdgcn_perm(0u, Wd, sel));
 						const u16x2 hi = c + t2, lo = __builtin_elementwise_sub_sat(c, t2);
-						const u16x2 bv = as_u16x2(as_u32x(__builtin_elementwise_sub_sat(a0, hi)) | as_u32x(__builtin_elementwise_sub_sat(a8, hi)));
-						const u16x2 bh = as_u16x2(as_u32x(__builtin_elementwise_sub_sat(a4, hi)) | as_u32x(__builtin_elementwise_sub_sat(a12, hi)));
-						const u16x2 dv = as_u16x2(as_u32x(__builtin_elementwise_sub_sat(lo, a0)) | as_u32x(__builtin_elementwise_sub_sat(lo, a8)));
-						const u16x2 dh = as_u16x2(as_u32x(__builtin_elementwise_sub_sat(lo, a4)) | as_u32x(__builtin_elementwise_sub_sat(lo, a12)));
-						res[hsel] = as_u32x(__builtin_elementwise_min(bv, bh)) | as_u32x(__builtin_elementwise_min(dv, dh));
+						const u16x2 bv = __builtin_elementwise_sub_sat(__builtin_elementwise_max(a0, a8), hi);
+						const u16x2 bh = __builtin_elementwise_sub_sat(__builtin_elementwise_max(a4, a12), hi);
+						const u16x2 dv = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(a0, a8));
+						const u16x2 dh = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(a4, a12));
+						rb[hsel] = as_u32x(__builtin_elementwise_min(bv, bh));
+						rd[hsel] = as_u32x(__builtin_elementwise_min(dv, dh));
 					}
 					// non-zero 16-bit lanes -> bits: min(x, 1) per lane, then (lo | hi >> 15) of each pair; gx0 >= X_ORG - 4 >= 3 always, only the last
 					// tile column can pass w - 3: the pixels k < w - 3 - gx0 as one mask
 					// (v_pk_min_u16 by name: the compiler rewrites min(x, 1) as x != 0 and spends four compares, four selects and two
 					//  permutes on it)
 					const uint32_t one2 = 0x00010001u;
-					uint32_t n0, n1;
-					asm("v_pk_min_u16 %0, %1, %2" : "=v"(n0) : "v"(res[0]), "v"(one2));
-					asm("v_pk_min_u16 %0, %1, %2" : "=v"(n1) : "v"(res[1]), "v"(one2));
-					const unsigned bits = ((n0 | (n0 >> 15)) & 3u) | (((n1 | (n1 >> 15)) & 3u) << 2);
+					uint32_t b0, b1, d0, d1;
+					asm("v_pk_min_u16 %0, %1, %2" : "=v"(b0) : "v"(rb[0]), "v"(one2));
+					asm("v_pk_min_u16 %0, %1, %2" : "=v"(b1) : "v"(rb[1]), "v"(one2));
+					asm("v_pk_min_u16 %0, %1, %2" : "=v"(d0) : "v"(rd[0]), "v"(one2));
+					asm("v_pk_min_u16 %0, %1, %2" : "=v"(d1) : "v"(rd[1]), "v"(one2));
 					const int room = min(max(w - 3 - gx0, 0), 4);
-					m4 = bits & ((1u << room) - 1u);
+					const unsigned rm = (1u << room) - 1u;
+					const unsigned bits_b = (((b0 | (b0 >> 15)) & 3u) | (((b1 | (b1 >> 15)) & 3u) << 2)) & rm;
+					const unsigned bits_d = (((d0 | (d0 >> 15)) & 3u) | (((d1 | (d1 >> 15)) & 3u) << 2)) & rm;
+					m4 = bits_b | bits_d;
+					s_pol[it] = (uint8_t)(bits_b | (bits_d << 4));
 				}
 			}
 			all |= m4 << (4 * ra);
@@ -283,9 +327,20 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 				code = s_q1[q];
 				const int it = code >> 2, k = code & 3;
 				const int sy = it / SG, g = it - sy * SG;
+				// the polarity the compass test passed (both: bright first, dark below -- a wave-uniform branch almost never taken)
+				const unsigned pol = (unsigned)s_pol[it] >> k;
+				const bool pb = pol & 1u, pd = pol & 16u;
+				const uint8_t* px = s_img + (sy + 3) * IW + 4 * (g + 1) + k;
 				uint32_t A[8];
-				ring_diffs_packed(s_img + (sy + 3) * IW + 4 * (g + 1) + k, A);
-				const int sc = fast_s_packed(A);
+				ring_diffs_signed(px, pb ? 0x00010001u : 0xFFFFFFFFu, A);
+				int sc = fast_s_one(A);
+				if (__ballot(pb && pd) != 0ull) {                        // (wave uniform)
+					if (pb && pd) {
+						uint32_t A2[8];
+						ring_diffs_signed(px, 0xFFFFFFFFu, A2);
+						sc = max(sc, fast_s_one(A2));
+					}
+				}
 				corner = sc > threshold;
 				if (corner) s_sc[sy * SP + 4 * g + k] = (uint8_t)(sc - 1);
 			}

@@ -4,7 +4,7 @@
 // oracle's operation sequence in IEEE double without contraction (this file keeps the build's -ffp-contract=off),
 // so models, inlier sets and verdicts are bit-identical to it.
 //
-// Mapping (gfx950): one 256-thread workgroup per keyframe pair.  The tracked pairs are compacted in order into LDS.
+// Mapping (gfx950): one workgroup of SSK_FM_NT threads (64: one wavefront) per keyframe pair.  The tracked pairs are compacted in order into LDS.
 // RANSAC is evaluated HR = 8 hypotheses at a time: thread t handles hypothesis t % HR and the part t / HR of the points (32
 // parts) -- the threads of a hypothesis repeat its 7-point solver (the counter-based generator makes hypotheses
 // independent: Gauss-Jordan null space in registers with static indexing, cubic by bisection, up to 3 models) and
@@ -18,8 +18,8 @@
 namespace {
 
 #ifndef SSK_FM_NT
-#define SSK_FM_NT 256
-#endif
+#define SSK_FM_NT 64                 // round 5: one wavefront per keyframe pair (a hypothesis x an eighth of the points per lane): 0.227 ms per 1 024 pairs against
+#endif                             // 0.247 at 256 threads, 0.232 at 128 (same box, tools/stage_ab.sh) -- a latency kernel at 176 VGPRs is sized by the workgroups a CU holds
 constexpr int NT = SSK_FM_NT;
 #ifndef SSK_FM_HR
 #define SSK_FM_HR 8
@@ -59,7 +59,7 @@ __device__ __forceinline__ double det3(const double* M)
 
 __device__ __forceinline__ double cubic_eval(double a, double b, double c, double x) { return ((x + a) * x + b) * x + c; }
 
-__device__ double bisect(double a, double b, double c, double lo, double hi)
+__device__ __forceinline__ double bisect(double a, double b, double c, double lo, double hi)
 {
 	double flo = cubic_eval(a, b, c, lo);
 	for (int it = 0; it < 80; ++it) {
@@ -70,7 +70,7 @@ __device__ double bisect(double a, double b, double c, double lo, double hi)
 	return 0.5 * (lo + hi);
 }
 
-__device__ int cubic_roots(double c3, double c2, double c1, double c0, double (&roots)[3])
+__device__ __forceinline__ int cubic_roots(double c3, double c2, double c1, double c0, double (&roots)[3])
 {
 	const double m = fmax(fmax(fabs(c3), fabs(c2)), fmax(fabs(c1), fabs(c0)));
 	if (!(m > 0.0)) return 0;
@@ -94,17 +94,26 @@ __device__ int cubic_roots(double c3, double c2, double c1, double c0, double (&
 	const double sq = sqrt(disc);
 	const double x1 = (-a - sq) / 3.0, x2 = (-a + sq) / 3.0;
 	const double f1 = cubic_eval(a, b, c, x1), f2 = cubic_eval(a, b, c, x2);
-	int n = 0;
-	if (f1 >= 0.0) roots[n++] = bisect(a, b, c, -R, x1);
-	if (f1 >= 0.0 && f2 <= 0.0) roots[n++] = bisect(a, b, c, x1, x2);
-	if (f2 <= 0.0) roots[n++] = bisect(a, b, c, x2, R);
-	return n;
+	// x1 is the local maximum, x2 the local minimum (f1 >= f2): a root left of x1 iff f1 >= 0, right of x2 iff f2 <= 0, between them iff both.  The
+	// roots in ascending order with CONSTANT indices (round 5: `roots[n++]` put the array -- and, through the call, the caller's three models -- into
+	// scratch: 240 B per lane)
+	const bool left = f1 >= 0.0, right = f2 <= 0.0;
+	double rl = 0.0, rm = 0.0, rr = 0.0;
+	if (left) rl = bisect(a, b, c, -R, x1);
+	if (left && right) rm = bisect(a, b, c, x1, x2);
+	if (right) rr = bisect(a, b, c, x2, R);
+	roots[0] = left ? rl : rr; roots[1] = rm; roots[2] = rr;
+	return left && right ? 3 : 1;
 }
 
 // F3: the 7-point solver (static register indexing: every loop bound is a constant, the pivot row is applied by selects)
-__device__ int seven_point(const double2* m1, const double2* m2, const int (&idx)[7], const ssk_fm_params& P, double (&F)[3][9])
+__device__ __forceinline__ int seven_point(const double2* m1, const double2* m2, const int (&idx)[7], const ssk_fm_params& P, double (&F)[3][9])
 {
 	double A[7][9];
+#pragma unroll
+	for (int d = 0; d < 3; ++d)
+#pragma unroll
+		for (int i = 0; i < 9; ++i) F[d][i] = 0.0;
 #pragma unroll
 	for (int r = 0; r < 7; ++r) {
 		const double2 a = m1[idx[r]], b = m2[idx[r]];
@@ -173,12 +182,13 @@ __device__ int seven_point(const double2* m1, const double2* m2, const int (&idx
 		if (!(nrm > 0.0)) continue;
 		const double inv = 1.0 / sqrt(nrm);
 		// models are compacted in root order; nm is at most k, so the destination index is one of three constants
+		// (selects, not a guarded store: the compiler turns `if (d == nm) F[d][i] = ...` back into F[nm][i] -- a dynamic index, i.e. the models in scratch)
 #pragma unroll
-		for (int d = 0; d < 3; ++d)
-			if (d == nm) {
+		for (int d = 0; d < 3; ++d) {
+			const bool here = d == nm;
 #pragma unroll
-				for (int i = 0; i < 9; ++i) F[d][i] = Fp[i] * inv;
-			}
+			for (int i = 0; i < 9; ++i) F[d][i] = here ? Fp[i] * inv : F[d][i];
+		}
 		++nm;
 	}
 	return nm;
@@ -203,7 +213,10 @@ __device__ int fm_update_iters(double p, int good, int n, int max_iters)
 	return k;
 }
 
-__global__ __launch_bounds__(NT)
+#ifndef SSK_FM_WAVES
+#define SSK_FM_WAVES 2
+#endif
+__global__ __launch_bounds__(NT, SSK_FM_WAVES)
 void fm_kernel(const int32_t* __restrict__ train_idx, int32_t* __restrict__ status, const int32_t* __restrict__ out_beg,
                const int32_t* __restrict__ q_beg, const int32_t* __restrict__ q_end, const int32_t* __restrict__ t_beg,
                const float2* __restrict__ this_xy, const float2* __restrict__ other_xy, ssk_fm_params P, int cap,

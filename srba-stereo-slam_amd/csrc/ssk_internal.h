@@ -45,6 +45,8 @@ struct ssk_ctx {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	hipStream_t side_stream = nullptr;   // a composite LM batch's few full-builder windows run here, beside the many on `stream` (ssk_capi_lm.hip)
+	hipEvent_t ev_side_a = nullptr, ev_side_b = nullptr;
 	hipEvent_t ev_lm_up = nullptr;     // end of an LM batch's uploads (ssk_capi_lm.hip: create waits for this, not for the zero fill behind it)
 	std::string err;
 	ssk_arena dev, pin;
