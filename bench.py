@@ -16,6 +16,7 @@ kernels run on; `cpu_baseline` is the CPU oracle (the port, not the
 reference: the reference's path needs OpenCV/MRPT/SRBA/stereo-vo, absent here) timed on the host cores.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -262,6 +263,8 @@ def main():
     ap.add_argument("--unbatched-frames", type=int, default=401,
                     help="frames of the un-batched pass at N=1 (the estimator's frame loop, one ssk_slam_process_frame per stereo pair: what a "
                          "user of performStereoSLAM sees; reported as `unbatched`, never as `value`; 0 = skip)")
+    ap.add_argument("--e2e-streams", type=int, default=1024, help="streams of the `e2e_stage2` pass at N=1 (lock-step keyframe streams with stage 1 + stage 2 per keyframe; 0 = skip)")
+    ap.add_argument("--e2e-depth5-streams", type=int, default=128, help="streams of its optimise-depth-5 figure (0 = skip)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: LM solves on a second HIP stream beside the front-end / DA kernels (measured: +1 %, the LM workgroups fill every CU)")
     args = ap.parse_args()
@@ -640,6 +643,97 @@ def main():
 
     e2e = e2e_pass(3) if world == 1 and rank == 0 and not exchange else None
 
+    # ---- end-to-end pass WITH stage 2 (round 5; reported beside `value` as `e2e_stage2`): B independent keyframe streams advanced in LOCK-STEP.  Every
+    # step every stream adds one keyframe: front-end of the batch's images -> data association against the stream's previous keyframe (+ the
+    # fundamental-matrix and change-in-pose filters, place recognition) -> a10 / a11 (pixels, projectMatchTo3D (+) camera pose) -> landmark ids (a tracked
+    # match inherits the id of the previous keyframe's match, the others are new landmarks, EST.cpp:666-704) -> define_new_keyframe of every stream
+    # (EST.cpp:782-784) through ssk_rba_define_kf_batch: graph bookkeeping + both LM windows per stream on host threads, stage 1 of all streams ONE
+    # LM batch, the local areas (optimise depth `depth`) another, results written back to the streams' maps.  Everything is inside the timed region.
+    # The streams alternate between the batch's two image sets (each step the other set is the new keyframe: the same scene from the other
+    # viewpoint), so a stream's landmarks are re-observed keyframe after keyframe and its local areas reach their steady size after
+    # `warm` keyframes (submap_size 10, depth 2: the headline's E = 10 window shape; depth 5: the reference's KITTI.ini:104-106).
+    def e2e_stage2_pass(depth, n_streams, warm, timed):
+        Bs = n_streams
+        kfA = capi.KfBatch(ctx, Bs, W, H, 512); kfB = capi.KfBatch(ctx, Bs, W, H, 512)
+        kfA.image_tensor().copy_(cur.image_tensor()[:Bs]); kfB.image_tensor().copy_(prev.image_tensor()[:Bs])
+        sets = [kfA, kfB]
+        prs = np.stack([np.arange(Bs), np.arange(Bs)], 1).astype(np.int32)
+        s_idx = torch.empty(Bs * N, dtype=torch.int32, device=dev); s_dist = torch.empty(Bs * N, dtype=torch.int32, device=dev)
+        s_st = torch.empty(Bs * N, dtype=torch.int32, device=dev); s_tr = torch.empty(Bs, dtype=torch.int32, device=dev)
+        d_px = torch.zeros(Bs, N, 4, dtype=torch.float32, device=dev); d_pos = torch.zeros(Bs, N, 3, dtype=torch.float64, device=dev)
+        opts = capi.RbaOptions.kitti(submap_size=10, max_tree_depth=4, max_optimize_depth=depth)
+        engines = [capi.Rba(ctx, opts) for _ in range(Bs)]
+        ids_prev = None
+        next_id = np.zeros(Bs, np.int64)
+        obs = np.zeros((Bs, N), capi.RBA_OBS_DTYPE)
+        ar = np.arange(N)[None, :]
+        stream_base = (np.arange(Bs, dtype=np.int64) << 40)[:, None]
+        t_ph = np.zeros(4)
+        last_tm, stats = None, []
+        def one(k, timed_):
+            nonlocal ids_prev, last_tm, next_id
+            c, p = sets[k % 2], sets[(k + 1) % 2]
+            t0 = time.perf_counter()
+            c.run_frontend(fp)
+            if k > 0:
+                ctx.da_run_batch(c, p, prs, da, s_idx, s_dist, s_st, s_tr)
+                ctx.fm_run_batch(c, p, prs, fm, s_idx, s_st, s_tr)
+                ctx.cip_run_batch(c, p, prs, cp, s_idx, s_st, s_tr)
+                c.bow_transform(voc); c.bow_query(db, 4)
+            c.build_observations(lp, d_px, d_pos)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            _, nm = c.counts()
+            nm = np.minimum(np.asarray(nm, np.int64), N)
+            px = d_px.cpu().numpy(); pos = d_pos.cpu().numpy()
+            valid = ar < nm[:, None]
+            if k > 0:
+                st = s_st.view(Bs, N).cpu().numpy(); ti = s_idx.view(Bs, N).cpu().numpy()
+                tracked = valid & (st == 0) & (ti >= 0)
+                inherit = np.take_along_axis(ids_prev, np.clip(ti, 0, N - 1).astype(np.int64), 1)
+            else:
+                tracked = np.zeros((Bs, N), bool); inherit = np.zeros((Bs, N), np.int64)
+            fresh = valid & ~tracked
+            rank_new = np.cumsum(fresh, 1) - 1
+            ids = np.where(tracked, inherit, stream_base + next_id[:, None] + rank_new)
+            next_id += fresh.sum(1)
+            ids_prev = np.where(valid, ids, -1)
+            obs["feat_id"] = ids.astype(np.uint64)
+            obs["left_x"], obs["left_y"], obs["right_x"], obs["right_y"] = px[..., 0], px[..., 1], px[..., 2], px[..., 3]
+            obs["rel_pos"] = pos
+            t2 = time.perf_counter()
+            infos, tm = capi.rba_define_kf_batch(engines, (obs, nm.astype(np.int32)), optimize=k > 0)
+            t3 = time.perf_counter()
+            if timed_:
+                t_ph[:] += [t1 - t0, t2 - t1, t3 - t2, t3 - t0]
+                last_tm = tm
+                stats.append((float(tracked.sum(1).mean()), float(np.mean([i.total_sqr_error_final <= i.total_sqr_error_init * (1 + 1e-12) for i in infos]))))
+        for k in range(warm):
+            one(k, False)
+        for k in range(warm, warm + timed):
+            one(k, True)
+        t_ph /= timed
+        for e in engines:
+            e.close()
+        kfA.close(); kfB.close()
+        st_ = np.mean(np.array(stats), 0)
+        tmd = {k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in last_tm.items()}
+        return {"value": Bs / t_ph[3], "unit": "keyframes/s", "streams": Bs, "optimize_depth": depth, "keyframes_per_stream_before_timing": warm, "steps": timed,
+                "ms_per_step": 1e3 * t_ph[3],
+                "ms": {"front_end_da_a10_a11": 1e3 * t_ph[0], "download_and_landmark_ids": 1e3 * t_ph[1], "define_new_keyframe_batch": 1e3 * t_ph[2]},
+                "define_new_keyframe_batch": tmd, "mean_tracked_vs_prev": st_[0], "windows_with_error_not_increased": st_[1], "host_cpu_quota": cpu_quota(),
+                "note": "B independent streams in lock-step: per step and stream one new keyframe -- front-end, data association against the stream's previous "
+                        "keyframe, the two outlier filters, place recognition, a10 / a11, landmark ids, then define_new_keyframe (EST.cpp:782-784) of all "
+                        "streams by ssk_rba_define_kf_batch: stage 1 (the new edge, landmarks held: lm_pose_only_kernel) as ONE LM batch, the local area "
+                        "(optimise depth as stated; submap_size 10, max_tree_depth 4) as another, results written back to every stream's map.  Host parts "
+                        "(graph bookkeeping, window building, the LM batches' symbolic builds) run on `host_threads` threads under the box's CPU quota"}
+
+    e2e_stage2 = None
+    if world == 1 and rank == 0 and not exchange and args.e2e_streams > 0:
+        e2e_stage2 = e2e_stage2_pass(2, min(args.e2e_streams, B), 11, 10)      # (ten timed steps: one full cycle of a 10-keyframe submap, local areas of 1 .. 10 edges)
+        if args.e2e_depth5_streams > 0:
+            e2e_stage2["depth5"] = e2e_stage2_pass(5, min(args.e2e_depth5_streams, B), 44, 2)
+
     # ---- the reference's real per-keyframe LM load (reported beside `value`): define_new_keyframe does TWO solves per keyframe
     # (EST.cpp:782-784): stage 1 = optimize_edges on the new edge with the landmarks held, stage 2 = optimize_local_area with
     # srba_max_optimize_depth = 5 (KITTI.ini:105): ~40 edges.  The headline's window is BASELINE configs[2]'s "window = 10".
@@ -814,6 +908,7 @@ def main():
             "lm_symbolic_ms_per_window": symbolic["lm_symbolic_ms_per_window"] if symbolic else None,
             "lm_symbolic": symbolic,
             "e2e": e2e,
+            "e2e_stage2": e2e_stage2,
             "exchange_ms_per_rank": exchange_ms_all if exchange else None,
             "pcie_inclusive": pcie,
             "unbatched": unbatched,

@@ -493,11 +493,17 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap);
 /* Host time ssk_lm_batch_create spent on the batch's symbolic structure (suffix tries, landmark groups, block-sorted items: what SRBA's
  * define_new_keyframe does on the CPU before it optimises, EST.cpp:782-784), milliseconds, and the host threads it used.  Either may be NULL. */
 int ssk_lm_batch_symbolic_ms(ssk_ctx* ctx, ssk_lm_batch* b, double* ms, int* threads);
+/* the dense solver of the reduced camera system the batch's heaviest kernel family uses (solver_LM_schur_dense_cholesky, SRBA.h:34): diagnostics / tests */
+int ssk_lm_batch_solver_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap);
 /* Current state of window w: edge_inv_pose [n_edges_total*12], lm_pos [n_lms_total*3]. */
 int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_inv_pose, double* lm_pos);
 /* Replaces the state of window w (either pointer may be NULL: that part is kept) -- the structure of a window can be built before its
    initial values are final: the estimator's facade builds the local-area window of a keyframe beside the solve of its new edges
    (the reference runs the two solves back to back on one set of structures: rba.define_new_keyframe, EST.cpp:782-784).  Synchronous. */
+/* the state of EVERY window with one download per family: the windows' edge poses (12 doubles x n_edges_total each) and landmarks (3 doubles x
+ * n_lms_total each) back to back in window order -- what a caller of a 1 024-window batch wants instead of 1 024 ssk_lm_batch_get_state calls
+ * (ssk_rba_define_kf_batch, include/ssk_rba.h).  Either pointer may be NULL. */
+int ssk_lm_batch_get_state_all(ssk_ctx* ctx, ssk_lm_batch* b, double* edge_inv_pose, double* lm_pos);
 int ssk_lm_batch_set_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, const double* edge_inv_pose, const double* lm_pos);
 /* Trace of window w: entries [max_iters]; delta_p [max_iters][6E], delta_f [max_iters][3L] (may be NULL). */
 int ssk_lm_batch_get_trace(ssk_ctx* ctx, ssk_lm_batch* b, int w, ssk_lm_trace_entry* entries, int cap,

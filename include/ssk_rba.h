@@ -59,6 +59,21 @@ const char* ssk_rba_last_error(const ssk_rba* r);
 int ssk_rba_set_initial_kf_pose(ssk_rba* r, const double pose[12]);
 /* Throws nothing: an edge-creation failure ("the node becomes isolated", SRBA.h:304) or a solver failure comes back as a code. */
 int ssk_rba_define_kf(ssk_rba* r, const ssk_rba_obs* obs, int n_obs, int run_local_optimization, ssk_rba_kf_info* out);
+/* Round 5: n engines (independent streams, all created on the SAME ssk_ctx) advanced in LOCK-STEP: engine i takes one new keyframe with its own
+ * observation list obs[i][0 .. n_obs[i]).  What define_new_keyframe (EST.cpp:782-784) does per stream, for a batch of streams: the graph bookkeeping
+ * (alloc_keyframe, edge_creation_policy, add_observation) and both LM windows of every engine are built on host threads side by side; stage 1
+ * (optimize_edges on the new edges, landmarks held) of ALL engines is ONE ssk_lm_batch (the pose-only kernel), stage 2 (optimize_local_area,
+ * depth = max_optimize_depth) another (the node / phase-split kernels).  Every engine ends in the state ssk_rba_define_kf would have left it in.
+ * out: n records.  timing (may be NULL): host-clock milliseconds of the call's parts and the shape of the stage-2 batch. */
+typedef struct ssk_rba_batch_timing {
+	double bookkeeping_and_windows_ms, stage1_create_ms, stage1_solve_ms, stage2_refresh_ms, stage2_create_ms, stage2_solve_ms, writeback_ms;
+	double stage1_symbolic_ms, stage2_symbolic_ms;          /* ssk_lm_batch_symbolic_ms of the two batches (inside the create times) */
+	double stage1_mean_obs, stage2_mean_obs, stage2_mean_edges, stage1_mean_iters, stage2_mean_iters;
+	int32_t host_threads, n_stage1, n_stage2, stage2_max_edges, stage2_max_obs, reserved;
+	char stage1_kernel[96], stage2_kernel[96];
+} ssk_rba_batch_timing;
+int ssk_rba_define_kf_batch(ssk_rba* const* r, int n, const ssk_rba_obs* const* obs, const int32_t* n_obs, int run_local_optimization,
+                            ssk_rba_kf_info* out, ssk_rba_batch_timing* timing);
 int ssk_rba_num_keyframes(const ssk_rba* r);
 int ssk_rba_num_edges(const ssk_rba* r);
 int ssk_rba_num_landmarks(const ssk_rba* r);

@@ -383,6 +383,40 @@ class RbaKfInfo(C.Structure):
                 ("num_observations", C.c_int32), ("num_iters", C.c_int32)]
 
 
+class RbaBatchTiming(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("bookkeeping_and_windows_ms", "stage1_create_ms", "stage1_solve_ms", "stage2_refresh_ms", "stage2_create_ms",
+                                          "stage2_solve_ms", "writeback_ms", "stage1_symbolic_ms", "stage2_symbolic_ms", "stage1_mean_obs", "stage2_mean_obs",
+                                          "stage2_mean_edges", "stage1_mean_iters", "stage2_mean_iters")] + \
+               [(k, C.c_int32) for k in ("host_threads", "n_stage1", "n_stage2", "stage2_max_edges", "stage2_max_obs", "reserved")] + \
+               [("stage1_kernel", C.c_char * 96), ("stage2_kernel", C.c_char * 96)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["stage1_kernel"] = self.stage1_kernel.decode(); d["stage2_kernel"] = self.stage2_kernel.decode()
+        return d
+
+
+def rba_define_kf_batch(engines, obs_lists, optimize=True):
+    """ssk_rba_define_kf_batch: the engines (one context) advanced in lock-step, engine i with obs_lists[i].  Returns (infos, timing dict)."""
+    n = len(engines)
+    lib = engines[0].lib
+    if isinstance(obs_lists, tuple):                           # (records [n, cap] of RBA_OBS_DTYPE, counts [n]): rows used as they are, no copies
+        arr2, ns = obs_lists
+        assert arr2.dtype == RBA_OBS_DTYPE and arr2.flags.c_contiguous and arr2.shape[0] == n
+        ns = np.ascontiguousarray(ns, np.int32)
+        ps = (C.c_void_p * n)(*[arr2.ctypes.data + i * arr2.strides[0] for i in range(n)])
+    else:
+        arrs = [np.ascontiguousarray(o, RBA_OBS_DTYPE) for o in obs_lists]
+        ps = (C.c_void_p * n)(*[a.ctypes.data if len(a) else None for a in arrs])
+        ns = np.array([len(a) for a in arrs], np.int32)
+    hs = engines if isinstance(engines, C.Array) else (C.c_void_p * n)(*[e.h_ for e in engines])
+    infos = (RbaKfInfo * n)()
+    tm = RbaBatchTiming()
+    engines[0].ctx.lib.ssk_env_refresh(engines[0].ctx.h)
+    engines[0]._chk(lib.ssk_rba_define_kf_batch(hs, n, ps, _ptr(ns), int(optimize), infos, C.byref(tm)))
+    return list(infos), tm.as_dict()
+
+
 _FLIB = None
 
 
@@ -435,6 +469,7 @@ class Rba:
     def define_kf(self, obs, optimize=True):
         o = np.ascontiguousarray(obs, RBA_OBS_DTYPE)
         info = RbaKfInfo()
+        self.ctx.lib.ssk_env_refresh(self.ctx.h)               # (tests switch SSK_LM_* on a live context)
         self._chk(self.lib.ssk_rba_define_kf(self.h_, _ptr(o), len(o), int(optimize), C.byref(info)))
         return info
 
@@ -668,8 +703,13 @@ class LmBatch:
         c._chk(c.lib.ssk_lm_batch_run(c.h, self.h_, C.byref(prm)))
 
     def kernel_name(self):
-        buf = C.create_string_buffer(64)
-        self.ctx._chk(self.ctx.lib.ssk_lm_batch_kernel_name(self.ctx.h, self.h_, buf, 64))
+        buf = C.create_string_buffer(192)
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_kernel_name(self.ctx.h, self.h_, buf, 192))
+        return buf.value.decode()
+
+    def solver_name(self):
+        buf = C.create_string_buffer(96)
+        self.ctx._chk(self.ctx.lib.ssk_lm_batch_solver_name(self.ctx.h, self.h_, buf, 96))
         return buf.value.decode()
 
     def symbolic_ms(self):

@@ -118,8 +118,11 @@ int finalize(ssk_lm_batch* b)
 			bool full = true;
 			for (int k = 0; k < ssk_ctx::LM_SLABS; ++k) full = full && ctx->lm_slab[k];
 			if (full && small >= 0) { SSK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->lm_slab[small]); ctx->lm_slab[small] = nullptr; ctx->lm_slab_bytes[small] = 0; }
-			SSK_HIP(ctx, hipMalloc(&b->slab, total + total / 4));          // head room: the next keyframe's window is a little larger
-			b->slab_bytes = total + total / 4;
+			// head room: the next keyframe's window is a little larger (a quarter; a large batch -- local areas of many streams growing in step through
+			// their submap cycle -- a half: every regrowth is a hipMalloc of tens of milliseconds)
+			const size_t room = total >= ((size_t)64 << 20) ? total / 2 : total / 4;
+			SSK_HIP(ctx, hipMalloc(&b->slab, total + room));
+			b->slab_bytes = total + room;
 		}
 	}
 	// A small upload (one keyframe's window) is packed into the pinned staging block and goes with ONE DMA (a hipMemcpyAsync costs ~8 us of host time,
@@ -1959,6 +1962,19 @@ int ssk_lm_batch_kernel_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 	return SSK_OK;
 }
 
+int ssk_lm_batch_solver_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b || !out || cap < 1) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_solver_name: bad argument");
+	if (!b->sub.empty()) return ssk_lm_batch_solver_name(ctx, b->sub[0], out, cap);
+	const char* name = "ldl (rounds 1-3 kernels)";
+	if (b->split_ok) name = b->S.solve_mfma ? "ldl_solve_mfma_lead" : "ldl_solve_regtile";
+	else if (b->node_ok) name = b->node_big ? "ldl_solve_regtile" : b->node_small ? "ldl_solve_mfma_wave" : "ldl_solve_tiles4_lds / ldl_solve_lds";
+	else if (b->lean && b->pose_n) name = "in registers (pose-only)";
+	std::snprintf(out, (size_t)cap, "%s", name);
+	return SSK_OK;
+}
+
 int ssk_lm_batch_symbolic_ms(ssk_ctx* ctx, ssk_lm_batch* b, double* ms, int* threads)
 {
 	if (!ctx) return SSK_ERR_BAD_ARG;
@@ -2003,6 +2019,39 @@ int ssk_lm_batch_get_state(ssk_ctx* ctx, ssk_lm_batch* b, int w, double* edge_in
 	const lm_win& H = b->hdr[w];
 	if (edge_inv_pose && H.n_edges) SSK_HIP(ctx, hipMemcpy(edge_inv_pose, b->D.pose + 12 * (size_t)H.edge0, sizeof(double) * 12 * (size_t)H.n_edges, hipMemcpyDeviceToHost));
 	if (lm_pos && H.n_lms) SSK_HIP(ctx, hipMemcpy(lm_pos, b->D.lm + 3 * (size_t)H.lm0, sizeof(double) * 3 * (size_t)H.n_lms, hipMemcpyDeviceToHost));
+	return SSK_OK;
+}
+
+int ssk_lm_batch_get_state_all(ssk_ctx* ctx, ssk_lm_batch* b, double* edge_inv_pose, double* lm_pos)
+{
+	if (!ctx) return SSK_ERR_BAD_ARG;
+	if (!b) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_get_state_all: batch is NULL");
+	if (!b->sub.empty()) {
+		// a composite: every sub-batch's arrays, then window by window to the caller's order
+		std::vector<double> pe[2], pl[2];
+		std::vector<size_t> eo[2], lo[2];
+		for (int k = 0; k < 2; ++k) {
+			ssk_lm_batch* sb = b->sub[(size_t)k];
+			pe[k].resize(sb->n_pose); pl[k].resize(sb->n_lm);
+			const int rcs = ssk_lm_batch_get_state_all(ctx, sb, pe[k].data(), pl[k].data());
+			if (rcs) return rcs;
+		}
+		size_t oe = 0, ol = 0;
+		for (int w = 0; w < b->n_windows; ++w) {
+			const int k = b->sub_of[(size_t)w];
+			const lm_win& H = b->sub[(size_t)k]->hdr[(size_t)b->idx_in[(size_t)w]];
+			if (edge_inv_pose) std::memcpy(edge_inv_pose + oe, pe[k].data() + 12 * (size_t)H.edge0, sizeof(double) * 12 * (size_t)H.n_edges);
+			if (lm_pos) std::memcpy(lm_pos + ol, pl[k].data() + 3 * (size_t)H.lm0, sizeof(double) * 3 * (size_t)H.n_lms);
+			oe += 12 * (size_t)H.n_edges; ol += 3 * (size_t)H.n_lms;
+		}
+		return SSK_OK;
+	}
+	SSK_HIP(ctx, hipSetDevice(ctx->device));
+	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
+	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	// (the pose / landmark families of a batch are the windows' arrays back to back in window order)
+	if (edge_inv_pose && b->n_pose) SSK_HIP(ctx, hipMemcpy(edge_inv_pose, b->D.pose, sizeof(double) * b->n_pose, hipMemcpyDeviceToHost));
+	if (lm_pos && b->n_lm) SSK_HIP(ctx, hipMemcpy(lm_pos, b->D.lm, sizeof(double) * b->n_lm, hipMemcpyDeviceToHost));
 	return SSK_OK;
 }
 

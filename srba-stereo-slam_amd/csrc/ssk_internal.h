@@ -63,9 +63,10 @@ struct ssk_ctx {
 	struct ssk_kfbatch* single = nullptr;   // 1-keyframe batch behind the host drop-in ssk_frontend_run
 	// device slabs of destroyed LM batches, reused by the next ones (the host drop-in creates and destroys two batches per keyframe -- the new edge's
 	// window and the local area's, the second one built while the first is solved: no hipMalloc in steady state)
-	static constexpr int LM_SLABS = 2;
-	void* lm_slab[LM_SLABS] = {nullptr, nullptr};
-	size_t lm_slab_bytes[LM_SLABS] = {0, 0};
+	static constexpr int LM_SLABS = 3;     // (round 5: three -- a lock-step batch of streams alternates a small and a growing large batch; with two places the
+	                                       // large one's regrowth evicted the small one's slab every time: a hipMalloc of tens of ms in each create)
+	void* lm_slab[LM_SLABS] = {nullptr, nullptr, nullptr};
+	size_t lm_slab_bytes[LM_SLABS] = {0, 0, 0};
 	int n_cu = 256;
 	// per-stage HIP-event profiler (ssk_profile_*): event pairs recorded around kernel launches on the
 	// context stream while enabled; resolved into per-stage sums at ssk_profile_read.

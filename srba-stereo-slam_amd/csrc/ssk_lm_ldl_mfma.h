@@ -83,7 +83,12 @@ __device__ __forceinline__ double ldlm_row_sum16(double v)
 	return v;
 }
 
-__device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ A, int np, int n, double* x_out, double* lds)
+// lead > 0 (round 5: systems beyond 255 unknowns, ldl_solve_mfma_lead below): A is the TRAILING block of a larger system Afull whose `lead` leading columns
+// are factorised already (ldl_leading_panels: U = L' D unscaled in Afull's lower triangle, 1 / d in inv_lead); the tiles take the leading columns'
+// updates right after the load -- chunks of 16 leading columns staged by the whole workgroup in the layout of a panel's published rows, four MFMAs per
+// tile and chunk (the trailing update of the panel loop, applied to every tile).
+__device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ A, int np, int n, double* x_out, double* lds,
+                                                     int lead = 0, const double* __restrict__ Afull = nullptr, const double* inv_lead = nullptr)
 {
 	static_assert(NT == 512, "ldl_solve_mfma_tiles: 8 wavefronts");
 	const int tid = threadIdx.x, lane = tid & 63, lc = lane & 15, lr = lane >> 4;
@@ -110,8 +115,29 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 	// The factor wave and the tile waves run separate code from here on (the same barriers in both): the tiles' 160 registers are not live in
 	// the factor wave's code, nor its 16 x 16 block in theirs.
 	double* contrib = Ut2;                                 // back-substitution: [J][I][16]
+	// a chunk of 16 leading columns, rows lead .. lead + n (the border row last) of Afull, as published rows: Ut2[q][row] (rows beyond: zero)
+	const int n_chunks = lead > 0 ? (lead + 15) >> 4 : 0;
+	auto stage_chunk = [&](int p0) {
+		const int cnt = (n + 1) * 16;
+		for (int e0 = 0; e0 < cnt; e0 += 4 * NT) {
+			double v[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { const int e = min(e0 + tid + NT * j, cnt - 1), r = e >> 4, q = e & 15; v[j] = Afull[(size_t)(lead + r) * np + min(p0 + q, lead - 1)]; }
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { const int e = e0 + tid + NT * j, r = e >> 4, q = e & 15; if (e < cnt) Ut2[q * LDLM_UP + r] = p0 + q < lead ? v[j] : 0.0; }
+		}
+	};
+	if (n_chunks > 0) {
+		for (int e = tid; e < 16 * LDLM_UP; e += NT) Ut2[e] = 0.0;      // (rows beyond the border row stay zero: the identity padding takes no update)
+		__syncthreads();
+	}
 	if (!tiles) {
 		// ================= the factor wave =================
+		for (int ch = 0; ch < n_chunks; ++ch) {            // (the leading columns' chunks: this wave stages its share; the tile waves apply them)
+			stage_chunk(16 * ch);
+			__syncthreads();
+			__syncthreads();
+		}
 		bool bad = false;
 		for (int k = 0; k < T && !bad; ++k) {
 			double* Lik = Li + k * 16 * LDLM_LP;
@@ -251,6 +277,27 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 					}
 				}
 			}
+		}
+		for (int ch = 0; ch < n_chunks; ++ch) {
+			stage_chunk(16 * ch);
+			__syncthreads();
+			double nd[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { const int c = 16 * ch + 4 * q + lr; nd[q] = c < lead ? -inv_lead[c] : 0.0; }
+#pragma unroll
+			for (int s = 0; s < LDLM_TS; ++s) {
+				int st = sT[s];
+				asm volatile("" : "+s"(st));
+				if ((st & 0xFF) < T) {                         // (an empty slot: T | T << 8)
+					const int cj = 16 * (st & 0xFF), ci = 16 * (st >> 8);
+					double a[4], b[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) { a[q] = Ut2[(4 * q + lr) * LDLM_UP + cj + lc] * nd[q]; b[q] = Ut2[(4 * q + lr) * LDLM_UP + ci + lc]; }
+#pragma unroll
+					for (int q = 0; q < 4; ++q) t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], t[s], 0, 0, 0);
+				}
+			}
+			__syncthreads();
 		}
 		if (wave == 0) {                                   // the first diagonal tile to the factor wave
 #pragma unroll
@@ -416,5 +463,28 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 #ifdef SSK_LM_STAMPS
 	if (threadIdx.x == 0 && blockIdx.x == 0) g_k2_t[15] += 1;
 #endif
+	return true;
+}
+
+// Systems of up to LDLM_LEAD_NMAX unknowns (round 5: the local areas the facade's own stream grows -- 61 optimised edges = 366 unknowns -- ran the
+// register-tile solver): the leading n - 252 columns by ldl_leading_panels (left-looking block columns through LDS, U and 1 / d to the system in L2),
+// the trailing 252 x 252 block on the matrix cores (its tiles take the leading columns' updates as MFMAs right after the load), the leading
+// unknowns by ldl_backsub_leading.  Same factorisation, the update terms of an element in column order.  A is overwritten (as by ldl_solve_regtile).
+constexpr int LDLM_LEAD_NMAX = 396;     // 66 optimised edges
+__device__ __forceinline__ bool ldl_solve_mfma_lead(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
+{
+	const int tid = threadIdx.x;
+	const int m = n <= LDLM_NMAX ? n : 252, n1 = n - m;
+	if (n1 > 0) {
+		const int lead = ldl_leading_panels<12>(A, np, n, n1, inv, lds, lds_doubles);
+		if (lead == 1) return false;
+		if (lead == 2) return SSK_LDL_BIG(A, np, n, x_out, inv, lds, lds_doubles);      // (a block column does not fit the staging: not at these sizes)
+	}
+	if (!ldl_solve_mfma_tiles(A + (size_t)n1 * np + n1, np, m, x_out + n1, lds, n1, A, inv)) return false;
+	if (n1 > 0) {
+		for (int k = tid; k < n1; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
+		__syncthreads();
+		return ldl_backsub_leading(A, np, n, n1, x_out, inv, lds, lds_doubles);
+	}
 	return true;
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ double slot_sum(const double* __restrict__ p, int a, 
 	return s;
 }
 
-// MFMA: every window of the batch has at most LDLM_NMAX unknowns (the host's choice: the solvers live in two instances of the kernel, each with its own
+// MFMA: every window of the batch has at most LDLM_LEAD_NMAX unknowns (the host's choice: the solvers live in two instances of the kernel, each with its own
 // register budget)
 template <bool MFMA>
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
@@ -89,7 +89,7 @@ void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubl
 	__syncthreads();
 	bool ok = true;
 	if (n6 > 0) {
-		if constexpr (MFMA) ok = ldl_solve_mfma_tiles(A, np, n6, s_b, lds);
+		if constexpr (MFMA) ok = ldl_solve_mfma_lead(A, np, n6, s_b, s_inv, lds, lds_doubles);
 		else ok = SSK_LDL_BIG(A, np, n6, s_b, s_inv, lds, lds_doubles);
 	}
 	double dpn = 0.0;
@@ -136,7 +136,7 @@ extern "C" int ssk_lm_k2_stamps(unsigned long long* out16, int reset)
 
 bool ssk_sp_solve_mfma(int E_max, bool force_regtile)
 {
-	return SSK_K2_MFMA && !force_regtile && 6 * E_max <= LDLM_NMAX;
+	return SSK_K2_MFMA && !force_regtile && 6 * E_max <= LDLM_LEAD_NMAX;
 }
 
 size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma)

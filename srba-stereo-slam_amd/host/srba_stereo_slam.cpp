@@ -1,5 +1,7 @@
 // srba_stereo_slam.cpp -- see srba_stereo_slam.h.  SRBA.h = reference src/srba-stereo-slam.h.
 #include "srba_stereo_slam.h"
+#include <memory>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -371,6 +373,11 @@ void mySRBA::lm_collect(lm_job& j, TOptimizeResults& res)
 	if (timing) std::fprintf(stderr, "[facade timing]   run_lm (%d edges opt, %zu obs): window build %.2f ms, batch create %.2f ms, solve %.2f ms (%d iters), state+destroy %.2f ms\n",
 	                         j.n_opt, j.obs_lm.size(), j.build_ms, j.create_ms, lm_ms(j.t_launch, t3), (int)r.iters, lm_ms(t3, lm_now()));
 	m_ctx.check(rc, "LM solve");
+	lm_apply(j, r, res);
+}
+
+void mySRBA::lm_apply(lm_job& j, const ssk_lm_result& r, TOptimizeResults& res)
+{
 	for (size_t i = 0; i < j.edge_ids.size(); ++i)
 		if (j.edge_slot[i] >= 0) std::memcpy(m_state.k2k_edges[j.edge_ids[i]].inv_pose.m, &j.pose[12 * i], 12 * sizeof(double));
 	if (j.optimize_landmarks)
@@ -380,14 +387,14 @@ void mySRBA::lm_collect(lm_job& j, TOptimizeResults& res)
 	res.obs_rmse = r.n_obs ? std::sqrt(r.err_final / r.n_obs) : 0.0;
 }
 
-void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameInfo& out, bool run_local_optimization)
+void mySRBA::kf_begin(const new_kf_observations_t& obs, TNewKeyFrameInfo& out, std::vector<TNewEdgeInfo>& new_edges)
 {
 	const TKeyFrameID new_kf_id = m_state.kf_observations.size();               // alloc_keyframe
 	m_state.kf_observations.push_back(std::vector<kf_observation_t>());
 	if (m_adj.size() <= new_kf_id) m_adj.resize(new_kf_id + 1);
 	out = TNewKeyFrameInfo();
 	out.kf_id = new_kf_id;
-	std::vector<TNewEdgeInfo> new_edges;
+	new_edges.clear();
 	if (new_kf_id >= 1) edge_creation_policy(new_kf_id, obs, new_edges);        // virtual edge_creation_policy
 	for (const auto& e : new_edges) out.created_edge_ids.push_back(e.id);
 	// (a keyframe with one new edge is a leaf: no path between older keyframes changes; with several it may open shorter ones)
@@ -411,6 +418,43 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 		k.px[2] = o.obs.obs_data.right_px.x; k.px[3] = o.obs.obs_data.right_px.y;
 		m_state.kf_observations[new_kf_id].push_back(k);
 	}
+}
+
+// the window of stage 1: optimize_edges on the new edges only, with the new keyframe's observations, landmarks held
+void mySRBA::stage1_prepare(lm_job& j, TKeyFrameID new_kf_id, const std::vector<TNewEdgeInfo>& new_edges, bool create) const
+{
+	std::set<size_t> opt;
+	for (const auto& e : new_edges) opt.insert(e.id);
+	std::vector<std::pair<TKeyFrameID, size_t>> refs;
+	for (size_t i = 0; i < m_state.kf_observations[new_kf_id].size(); ++i) refs.push_back(std::make_pair(new_kf_id, i));
+	lm_prepare(j, opt, refs, false, create);
+}
+
+// the window of stage 2: optimize_local_area(root = new KF, depth = max_optimize_depth)
+void mySRBA::stage2_prepare(lm_job& j2, TKeyFrameID new_kf_id, bool create) const
+{
+	// (the device solver's reduced system holds 128 edges, include/ssk_capi.h: a local area beyond that -- a revisit that ties several
+	// old local maps to the new one within the depth -- is optimised to the largest depth that fits.  SRBA has no such limit.)
+	std::map<TKeyFrameID, step_t> area;
+	std::set<size_t> opt;
+	for (size_t depth = parameters.max_optimize_depth; ; --depth) {
+		area.clear(); opt.clear();
+		bfs(new_kf_id, depth, area);
+		for (size_t e = 0; e < m_state.k2k_edges.size(); ++e)
+			if (area.count(m_state.k2k_edges[e].from) && area.count(m_state.k2k_edges[e].to)) opt.insert(e);
+		if (opt.size() <= 128 || depth <= 1) break;
+	}
+	std::vector<std::pair<TKeyFrameID, size_t>> refs;
+	for (const auto& kv : area)
+		for (size_t i = 0; i < m_state.kf_observations[kv.first].size(); ++i) refs.push_back(std::make_pair(kv.first, i));
+	lm_prepare(j2, opt, refs, true, create);
+}
+
+void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameInfo& out, bool run_local_optimization)
+{
+	std::vector<TNewEdgeInfo> new_edges;
+	kf_begin(obs, out, new_edges);
+	const TKeyFrameID new_kf_id = out.kf_id;
 	if (!run_local_optimization || new_edges.empty()) return;
 	// stage 1: optimize_edges on the new edges only, with the new keyframe's observations, landmarks held
 	// stage 2: optimize_local_area(root = new KF, depth = max_optimize_depth)
@@ -425,34 +469,14 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 	static const int overlap_mode = std::getenv("SSK_FACADE_OVERLAP") ? std::atoi(std::getenv("SSK_FACADE_OVERLAP")) : 2;
 	const bool overlap = overlap_mode == 1;
 	lm_job j2;
-	auto prepare_stage2 = [&]() {
-		// (the device solver's reduced system holds 128 edges, include/ssk_capi.h: a local area beyond that -- a revisit that ties several
-		// old local maps to the new one within the depth -- is optimised to the largest depth that fits.  SRBA has no such limit.)
-		std::map<TKeyFrameID, step_t> area;
-		std::set<size_t> opt;
-		for (size_t depth = parameters.max_optimize_depth; ; --depth) {
-			area.clear(); opt.clear();
-			bfs(new_kf_id, depth, area);
-			for (size_t e = 0; e < m_state.k2k_edges.size(); ++e)
-				if (area.count(m_state.k2k_edges[e].from) && area.count(m_state.k2k_edges[e].to)) opt.insert(e);
-			if (opt.size() <= 128 || depth <= 1) break;
-		}
-		std::vector<std::pair<TKeyFrameID, size_t>> refs;
-		for (const auto& kv : area)
-			for (size_t i = 0; i < m_state.kf_observations[kv.first].size(); ++i) refs.push_back(std::make_pair(kv.first, i));
-		lm_prepare(j2, opt, refs, true, !overlap);
-	};
+	auto prepare_stage2 = [&]() { stage2_prepare(j2, new_kf_id, !overlap); };
 	std::exception_ptr worker_error;
 	if (overlap && !m_worker) m_worker = new worker_t();
 	if (overlap) m_worker->start([&]() { try { prepare_stage2(); } catch (...) { worker_error = std::current_exception(); } });
 	struct joiner { worker_t* w; ~joiner() { if (w) w->wait(); } } join_on_exit{overlap ? m_worker : nullptr};
 	{
-		std::set<size_t> opt;
-		for (const auto& e : new_edges) opt.insert(e.id);
-		std::vector<std::pair<TKeyFrameID, size_t>> refs;
-		for (size_t i = 0; i < m_state.kf_observations[new_kf_id].size(); ++i) refs.push_back(std::make_pair(new_kf_id, i));
 		lm_job j1;
-		lm_prepare(j1, opt, refs, false, true);
+		stage1_prepare(j1, new_kf_id, new_edges, true);
 		lm_launch(j1, parameters.use_robust_kernel_stage1, false);
 		if (overlap_mode == 2) prepare_stage2();           // (reads the map before stage 1's result is written to it: its poses are refreshed below)
 		// (lm_collect writes the new edges' poses to the map: only after the worker has stopped reading it)
@@ -464,6 +488,132 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 	else if (overlap) lm_create(j2);
 	lm_launch(j2, parameters.use_robust_kernel, overlap_mode != 0);
 	lm_collect(j2, out.optimize_results);
+}
+
+// ---- lock-step batch of engines (round 5) ----
+namespace {
+template <class F>
+void parallel_for(int n, int n_threads, F f)
+{
+	if (n_threads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+	std::atomic<int> next{0};
+	std::exception_ptr err;
+	std::mutex mx;
+	auto body = [&] {
+		try { for (int i = next++; i < n; i = next++) f(i); }
+		catch (...) { std::lock_guard<std::mutex> lk(mx); if (!err) err = std::current_exception(); }
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < std::min(n_threads, n); ++t) th.emplace_back(body);
+	body();
+	for (std::thread& t : th) t.join();
+	if (err) std::rethrow_exception(err);
+}
+int batch_host_threads()
+{
+	// as the LM builder: half the logical cores, at most 64 and at most twice the container's CPU quota (cgroup v2 cpu.max)
+	int n = std::max(1, std::min((int)std::thread::hardware_concurrency() / 2, 64));
+	if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[32]; double per = 0.0;
+		if (std::fscanf(f, "%31s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) n = std::max(2, std::min(n, (int)(2.0 * std::atof(q) / per + 0.5)));
+		std::fclose(f);
+	}
+	if (const char* e = std::getenv("SSK_RBA_BATCH_THREADS")) n = std::max(1, std::atoi(e));
+	return n;
+}
+}  // namespace
+
+void mySRBA::define_new_keyframe_batch(const std::vector<mySRBA*>& E, const std::vector<const new_kf_observations_t*>& obs,
+                                       std::vector<TNewKeyFrameInfo>& out, bool run_local_optimization, TBatchTiming* tm)
+{
+	const int n = (int)E.size();
+	if ((int)obs.size() != n) throw std::runtime_error("define_new_keyframe_batch: one observation list per engine");
+	out.assign((size_t)n, TNewKeyFrameInfo());
+	if (n == 0) return;
+	Context& ctx = E[0]->m_ctx;
+	for (const mySRBA* e : E) if (e->m_ctx.get() != ctx.get()) throw std::runtime_error("define_new_keyframe_batch: the engines of a batch share one context");
+	static const int n_thr = batch_host_threads();
+	TBatchTiming T;
+	T.host_threads = n_thr;
+	auto t0 = lm_now();
+	// (1) per engine, side by side: graph bookkeeping (alloc_keyframe, edge_creation_policy, add_observation) and BOTH windows -- they read the map only;
+	// stage 1's result is written to the map, and to the prepared local-area windows' edge poses, in (3)
+	std::vector<std::vector<TNewEdgeInfo>> new_edges((size_t)n);
+	std::vector<std::unique_ptr<lm_job>> j1((size_t)n), j2((size_t)n);
+	parallel_for(n, n_thr, [&](int i) {
+		E[(size_t)i]->kf_begin(*obs[(size_t)i], out[(size_t)i], new_edges[(size_t)i]);
+		if (!run_local_optimization || new_edges[(size_t)i].empty()) return;
+		j1[(size_t)i].reset(new lm_job()); j2[(size_t)i].reset(new lm_job());
+		E[(size_t)i]->stage1_prepare(*j1[(size_t)i], out[(size_t)i].kf_id, new_edges[(size_t)i], false);
+		E[(size_t)i]->stage2_prepare(*j2[(size_t)i], out[(size_t)i].kf_id, false);
+	});
+	std::vector<int> act;
+	for (int i = 0; i < n; ++i) if (j1[(size_t)i]) act.push_back(i);
+	T.bookkeeping_and_windows_ms = lm_ms(t0, lm_now());
+	if (act.empty()) { if (tm) *tm = T; return; }
+	const int na = (int)act.size();
+	struct batch_guard { ssk_lm_batch* b = nullptr; ~batch_guard() { if (b) ssk_lm_batch_destroy(b); } };
+	auto solve = [&](std::vector<std::unique_ptr<lm_job>>& J, bool robust, double& create_ms, double& solve_ms, double& sym_ms, char* kernel, std::vector<ssk_lm_result>& res, double& mean_iters) {
+		std::vector<ssk_lm_window> wins((size_t)na);
+		size_t n_pose = 0, n_lm = 0;
+		for (int k = 0; k < na; ++k) { wins[(size_t)k] = J[(size_t)act[(size_t)k]]->w; n_pose += 12 * (size_t)wins[(size_t)k].n_edges_total; n_lm += 3 * (size_t)wins[(size_t)k].n_lms_total; }
+		batch_guard g;
+		auto ta = lm_now();
+		ctx.check(ssk_lm_batch_create(ctx.get(), wins.data(), na, 0, &g.b), "ssk_lm_batch_create");
+		auto tb = lm_now();
+		create_ms = lm_ms(ta, tb);
+		const ssk_lm_params prm = E[0]->m_opts.lm(robust);
+		ctx.check(ssk_lm_batch_run(ctx.get(), g.b, &prm), "ssk_lm_batch_run");
+		res.resize((size_t)na);
+		ctx.check(ssk_lm_batch_results(ctx.get(), g.b, res.data()), "ssk_lm_batch_results");
+		std::vector<double> pose(n_pose), lmp(n_lm);
+		ctx.check(ssk_lm_batch_get_state_all(ctx.get(), g.b, pose.data(), lmp.data()), "ssk_lm_batch_get_state_all");
+		solve_ms = lm_ms(tb, lm_now());
+		int thr = 0;
+		(void)ssk_lm_batch_symbolic_ms(ctx.get(), g.b, &sym_ms, &thr);
+		(void)ssk_lm_batch_kernel_name(ctx.get(), g.b, kernel, 96);
+		size_t oe = 0, ol = 0;
+		double it = 0;
+		for (int k = 0; k < na; ++k) {
+			lm_job& j = *J[(size_t)act[(size_t)k]];
+			std::memcpy(j.pose.data(), pose.data() + oe, sizeof(double) * j.pose.size());
+			std::memcpy(j.lmpos.data(), lmp.data() + ol, sizeof(double) * j.lmpos.size());
+			oe += j.pose.size(); ol += j.lmpos.size();
+			it += res[(size_t)k].iters;
+		}
+		mean_iters = it / na;
+	};
+	// (2) stage 1 of every engine: one batch (one or two optimised edges, no optimised landmark: the pose-only kernel)
+	std::vector<ssk_lm_result> r1, r2;
+	solve(j1, E[0]->parameters.use_robust_kernel_stage1, T.stage1_create_ms, T.stage1_solve_ms, T.stage1_symbolic_ms, T.stage1_kernel, r1, T.stage1_mean_iters);
+	// (3) its result to the maps, and into the local-area windows prepared before it
+	auto t3 = lm_now();
+	parallel_for(na, n_thr, [&](int k) {
+		const int i = act[(size_t)k];
+		mySRBA& e = *E[(size_t)i];
+		e.lm_apply(*j1[(size_t)i], r1[(size_t)k], out[(size_t)i].optimize_results_stg1);
+		lm_job& j = *j2[(size_t)i];
+		for (size_t q = 0; q < j.edge_ids.size(); ++q) std::memcpy(&j.pose[12 * q], e.m_state.k2k_edges[j.edge_ids[q]].inv_pose.m, 12 * sizeof(double));
+	});
+	T.stage2_refresh_ms = lm_ms(t3, lm_now());
+	// (4) stage 2 of every engine: one batch
+	solve(j2, E[0]->parameters.use_robust_kernel, T.stage2_create_ms, T.stage2_solve_ms, T.stage2_symbolic_ms, T.stage2_kernel, r2, T.stage2_mean_iters);
+	auto t5 = lm_now();
+	parallel_for(na, n_thr, [&](int k) {
+		const int i = act[(size_t)k];
+		E[(size_t)i]->lm_apply(*j2[(size_t)i], r2[(size_t)k], out[(size_t)i].optimize_results);
+	});
+	T.writeback_ms = lm_ms(t5, lm_now());
+	T.n_stage1 = T.n_stage2 = na;
+	for (int k = 0; k < na; ++k) {
+		const lm_job& a = *j1[(size_t)act[(size_t)k]]; const lm_job& c = *j2[(size_t)act[(size_t)k]];
+		T.stage1_mean_obs += (double)a.obs_lm.size() / na; T.stage2_mean_obs += (double)c.obs_lm.size() / na; T.stage2_mean_edges += (double)c.n_opt / na;
+		T.stage2_max_edges = std::max(T.stage2_max_edges, c.n_opt); T.stage2_max_obs = std::max(T.stage2_max_obs, (int)c.obs_lm.size());
+		mySRBA& e = *E[(size_t)act[(size_t)k]];
+		e.timing.solves += 2; e.timing.iters += (size_t)r1[(size_t)k].iters + (size_t)r2[(size_t)k].iters;
+		e.timing.max_opt_edges = std::max(e.timing.max_opt_edges, (size_t)c.n_opt); e.timing.max_obs = std::max(e.timing.max_obs, c.obs_lm.size());
+	}
+	if (tm) *tm = T;
 }
 
 }  // namespace ssk

@@ -78,6 +78,20 @@ public:
 	// EST.cpp:166,782
 	void define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameInfo& out_new_kf_info, bool run_local_optimization);
 
+	// Round 5: B engines (independent streams on ONE context) advanced in lock-step -- every engine takes one new keyframe; the graph bookkeeping
+	// and both LM windows of every engine are prepared on host threads side by side; stage 1 (optimize_edges on the new edges, landmarks held) of ALL
+	// engines is ONE ssk_lm_batch, stage 2 (optimize_local_area) another.  Every engine ends in the state define_new_keyframe would have left it in
+	// (the same windows; the LM kernels' results do not depend on the batch around a window).
+	struct TBatchTiming {
+		double bookkeeping_and_windows_ms = 0, stage1_create_ms = 0, stage1_solve_ms = 0, stage2_refresh_ms = 0, stage2_create_ms = 0, stage2_solve_ms = 0, writeback_ms = 0;
+		double stage1_symbolic_ms = 0, stage2_symbolic_ms = 0;
+		int host_threads = 0, n_stage1 = 0, n_stage2 = 0, stage2_max_edges = 0, stage2_max_obs = 0;
+		double stage2_mean_edges = 0, stage2_mean_obs = 0, stage1_mean_obs = 0, stage1_mean_iters = 0, stage2_mean_iters = 0;
+		char stage1_kernel[96] = {0}, stage2_kernel[96] = {0};
+	};
+	static void define_new_keyframe_batch(const std::vector<mySRBA*>& engines, const std::vector<const new_kf_observations_t*>& obs,
+	                                      std::vector<TNewKeyFrameInfo>& out, bool run_local_optimization, TBatchTiming* timing = nullptr);
+
 	// pose of `target` as seen from `root` by composing edges along the breadth-first tree (depth limited):
 	// what create_complete_spanning_tree(root, ...)[target] gives the estimator (EST.cpp:909-915).
 	bool get_kf_relative_pose(TKeyFrameID root, TKeyFrameID target, size_t max_depth, Pose3D& out) const;
@@ -122,6 +136,11 @@ private:
 	void lm_create(lm_job& j) const;
 	void lm_launch(lm_job& j, bool robust, bool refresh);
 	void lm_collect(lm_job& j, TOptimizeResults& res);
+	// the pieces of define_new_keyframe the lock-step batch form shares with it
+	void kf_begin(const new_kf_observations_t& obs, TNewKeyFrameInfo& out, std::vector<TNewEdgeInfo>& new_edges);
+	void stage1_prepare(lm_job& j, TKeyFrameID new_kf_id, const std::vector<TNewEdgeInfo>& new_edges, bool create) const;
+	void stage2_prepare(lm_job& j, TKeyFrameID new_kf_id, bool create) const;
+	void lm_apply(lm_job& j, const ssk_lm_result& r, TOptimizeResults& res);      // a solved window's state (j.pose / j.lmpos) to the map
 
 	Context& m_ctx;
 	TSRBAStereoSLAMOptions m_opts;

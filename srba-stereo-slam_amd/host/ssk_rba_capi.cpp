@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <vector>
 #include "../../include/ssk_rba.h"
 #include "srba_stereo_slam.h"
 
@@ -83,6 +84,56 @@ int ssk_rba_define_kf(ssk_rba* r, const ssk_rba_obs* obs, int n_obs, int run_loc
 		out->stg1_obs_rmse = info.optimize_results_stg1.obs_rmse;
 		out->num_observations = (int32_t)info.optimize_results.num_observations;
 		out->num_iters = (int32_t)info.optimize_results.num_iters;
+	});
+}
+
+int ssk_rba_define_kf_batch(ssk_rba* const* r, int n, const ssk_rba_obs* const* obs, const int32_t* n_obs, int run_local_optimization,
+                            ssk_rba_kf_info* out, ssk_rba_batch_timing* timing)
+{
+	if (!r || n < 1 || !obs || !n_obs || !out) return SSK_ERR_BAD_ARG;
+	for (int i = 0; i < n; ++i) if (!r[i] || n_obs[i] < 0 || (n_obs[i] > 0 && !obs[i])) return SSK_ERR_BAD_ARG;
+	return guarded(r[0], [&] {
+		std::vector<ssk::new_kf_observations_t> lists((size_t)n);
+		std::vector<const ssk::new_kf_observations_t*> ptr((size_t)n);
+		std::vector<ssk::mySRBA*> eng((size_t)n);
+		for (int i = 0; i < n; ++i) {
+			lists[(size_t)i].resize((size_t)n_obs[i]);
+			for (int k = 0; k < n_obs[i]; ++k) {
+				ssk::new_kf_observation_t& o = lists[(size_t)i][(size_t)k];
+				const ssk_rba_obs& s = obs[i][k];
+				o.is_fixed = false; o.is_unknown_with_init_val = true;
+				o.obs.feat_id = s.feat_id;
+				o.obs.obs_data.left_px.x = s.left_x; o.obs.obs_data.left_px.y = s.left_y;
+				o.obs.obs_data.right_px.x = s.right_x; o.obs.obs_data.right_px.y = s.right_y;
+				o.setRelPos(s.rel_pos);
+			}
+			ptr[(size_t)i] = &lists[(size_t)i]; eng[(size_t)i] = r[i]->rba.get();
+		}
+		std::vector<ssk::TNewKeyFrameInfo> info;
+		ssk::mySRBA::TBatchTiming T;
+		ssk::mySRBA::define_new_keyframe_batch(eng, ptr, info, run_local_optimization != 0, &T);
+		for (int i = 0; i < n; ++i) {
+			ssk_rba_kf_info& o = out[i];
+			const ssk::TNewKeyFrameInfo& f = info[(size_t)i];
+			std::memset(&o, 0, sizeof o);
+			o.kf_id = (int32_t)f.kf_id;
+			o.n_created_edges = (int32_t)std::min<size_t>(f.created_edge_ids.size(), SSK_RBA_MAX_NEW_EDGES);
+			for (int k = 0; k < o.n_created_edges; ++k) o.created_edge_ids[k] = (int32_t)f.created_edge_ids[(size_t)k];
+			o.total_sqr_error_init = f.optimize_results.total_sqr_error_init; o.total_sqr_error_final = f.optimize_results.total_sqr_error_final;
+			o.stg1_obs_rmse = f.optimize_results_stg1.obs_rmse;
+			o.num_observations = (int32_t)f.optimize_results.num_observations; o.num_iters = (int32_t)f.optimize_results.num_iters;
+		}
+		if (timing) {
+			std::memset(timing, 0, sizeof *timing);
+			timing->bookkeeping_and_windows_ms = T.bookkeeping_and_windows_ms; timing->stage1_create_ms = T.stage1_create_ms; timing->stage1_solve_ms = T.stage1_solve_ms;
+			timing->stage2_refresh_ms = T.stage2_refresh_ms; timing->stage2_create_ms = T.stage2_create_ms; timing->stage2_solve_ms = T.stage2_solve_ms; timing->writeback_ms = T.writeback_ms;
+			timing->stage1_symbolic_ms = T.stage1_symbolic_ms; timing->stage2_symbolic_ms = T.stage2_symbolic_ms;
+			timing->stage1_mean_obs = T.stage1_mean_obs; timing->stage2_mean_obs = T.stage2_mean_obs; timing->stage2_mean_edges = T.stage2_mean_edges;
+			timing->stage1_mean_iters = T.stage1_mean_iters; timing->stage2_mean_iters = T.stage2_mean_iters;
+			timing->host_threads = T.host_threads; timing->n_stage1 = T.n_stage1; timing->n_stage2 = T.n_stage2;
+			timing->stage2_max_edges = T.stage2_max_edges; timing->stage2_max_obs = T.stage2_max_obs;
+			std::memcpy(timing->stage1_kernel, T.stage1_kernel, sizeof timing->stage1_kernel); std::memcpy(timing->stage2_kernel, T.stage2_kernel, sizeof timing->stage2_kernel);
+		}
 	});
 }
 

@@ -93,3 +93,47 @@ def test_rba_engine_errors(pkg, ctx):
     info = rba.define_kf(other)
     assert info.kf_id == 1 and info.n_created_edges == 1 and info.total_sqr_error_final <= info.total_sqr_error_init + 1e-9
     rba.close()
+
+
+def test_rba_lock_step_batch_equals_independent_engines(pkg, ctx, monkeypatch):
+    """Round 5: ssk_rba_define_kf_batch -- B streams advanced in lock-step, stage 1 of all of them ONE LM batch, the local areas another -- leaves
+    every engine in the state B independent ssk_rba_define_kf sequences leave it in: same edges, same keyframe infos, the same bits in every edge
+    pose and landmark (the windows are the same and the LM kernels' results do not depend on the batch around a window; SSK_LM_FEW_SPLIT=0 keeps
+    a single window on the kernel family its batch uses)."""
+    from ssk_amd import capi
+    monkeypatch.setenv("SSK_LM_FEW_SPLIT", "0")
+    B, n_kf = 12, 9
+    opts = capi.RbaOptions.kitti(submap_size=4, max_tree_depth=3, max_optimize_depth=2)
+    streams = []
+    for b in range(B):
+        rng = np.random.default_rng(100 + b)
+        P = np.stack([rng.uniform(-15, 40, 700), rng.uniform(-3, 3, 700), rng.uniform(6, 40, 700)], 1)
+        ids = np.arange(700, dtype=np.uint64) + 1000 * (b + 1)
+        streams.append([keyframe_observations(ctx, capi, k, P, ids, rng=rng) for k in range(n_kf)])
+    alone = [capi.Rba(ctx, opts) for _ in range(B)]
+    infos_a = [[alone[b].define_kf(streams[b][k], optimize=k > 0) for k in range(n_kf)] for b in range(B)]
+    batch = [capi.Rba(ctx, opts) for _ in range(B)]
+    tms = []
+    infos_b = [[] for _ in range(B)]
+    for k in range(n_kf):
+        inf, tm = capi.rba_define_kf_batch(batch, [streams[b][k] for b in range(B)], optimize=k > 0)
+        tms.append(tm)
+        for b in range(B):
+            infos_b[b].append(inf[b])
+    assert tms[-1]["n_stage1"] == B and tms[-1]["n_stage2"] == B and tms[-1]["stage1_kernel"] == "lm_pose_only_kernel"
+    assert tms[-1]["stage2_kernel"].startswith("lm_solve_node") and tms[-1]["stage2_mean_edges"] >= 3
+    for b in range(B):
+        assert alone[b].counts() == batch[b].counts()
+        for ia, ib in zip(infos_a[b], infos_b[b]):
+            assert ia.kf_id == ib.kf_id and ia.n_created_edges == ib.n_created_edges and list(ia.created_edge_ids) == list(ib.created_edge_ids)
+            assert ia.num_iters == ib.num_iters and ia.num_observations == ib.num_observations
+            assert ia.total_sqr_error_init == ib.total_sqr_error_init and ia.total_sqr_error_final == ib.total_sqr_error_final and ia.stg1_obs_rmse == ib.stg1_obs_rmse
+        for e in range(alone[b].counts()[1]):
+            fa, ta, pa = alone[b].edge(e); fb, tb, pb = batch[b].edge(e)
+            assert (fa, ta) == (fb, tb) and np.array_equal(pa, pb), (b, e)
+        for fid in streams[b][0]["feat_id"][:40]:
+            la, lb = alone[b].landmark(int(fid)), batch[b].landmark(int(fid))
+            assert la[0] == lb[0] and np.array_equal(la[1], lb[1])
+    for r in alone + batch:
+        r.close()
+    print("lock-step batch of %d streams, keyframe %d: %s" % (B, n_kf - 1, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tms[-1].items()}))

@@ -12,7 +12,7 @@ for ((p = 0; 16 * p < n; ++p)); do
     pos=$((16 * p + c)); [ $pos -lt $n ] || continue
     out=$(timeout 60 _ab/ldl_bench $n $reps $wgs $pos 2>&1); rc=$?
     runs=$((runs + 1))
-    if [ $rc -ne 0 ] || ! echo "$out" | grep -q "ldl_solve_mfma_tiles.*ok 0"; then echo "FAIL at pivot $pos (rc $rc): $out"; fail=$((fail + 1)); fi
+    if [ $rc -ne 0 ] || ! echo "$out" | grep -q "ldl_solve_mfma_lead.*ok 0"; then echo "FAIL at pivot $pos (rc $rc): $out"; fail=$((fail + 1)); fi
   done
 done
 echo "ldl_stress: n $n, $wgs workgroups x $reps solves, $runs failing-pivot positions, $fail failures"

@@ -1,7 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05e
+mkdir -p gpurun_out/r05g
 export TMPDIR=/tmp
-(timeout 900 python -m pytest tests/test_lm_gpu.py tests/test_fmat_gpu.py tests/test_frontend_gpu.py -x -q 2>&1 | tail -12) > gpurun_out/r05e/tests.log
-(bash tools/stage_ab.sh fund_matrix srba-stereo-slam_amd/libssk_hip.so _ab/libssk_fm128.so _ab/libssk_fm128w3.so _ab/libssk_fm64.so 2>&1) > gpurun_out/r05e/fm_ab.log
-cat gpurun_out/r05e/*.log
+(for n in 240 252 264 330 372 396; do timeout 60 _ab/ldl_bench $n 50 1 | head -2; done; timeout 120 _ab/ldl_bench 372 20 256 | head -2; timeout 60 _ab/ldl_bench 372 5 64 300 | head -2; timeout 60 _ab/ldl_bench 372 5 64 50 | head -2) > gpurun_out/r05g/ldl_bench.log 2>&1
+(timeout 600 bash tools/ldl_stress.sh 255 512 20 2>&1 | tail -3) > gpurun_out/r05g/ldl_stress.log
+(timeout 900 python -m pytest tests/test_lm_gpu.py -x -q 2>&1 | tail -8) > gpurun_out/r05g/lm_tests.log
+(SSK_TIMING=1 timeout 600 python bench.py --steps 3 --warmup 1 --unbatched-frames 0 --lm-depth5 0 --cpu-sample 0 --cpu-procs 0 --pcie-steps 0 --e2e-depth5-streams 0 2>&1 | grep -i "lean\|create\|ssk lm" | tail -30) > gpurun_out/r05g/timing.log
+cat gpurun_out/r05g/*.log
