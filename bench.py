@@ -664,6 +664,8 @@ def main():
         opts = capi.RbaOptions.kitti(submap_size=10, max_tree_depth=4, max_optimize_depth=depth)
         engines = [capi.Rba(ctx, opts) for _ in range(Bs)]
         ids_prev = None
+        ids_cur = np.empty((Bs, N), np.int64)
+        flib = capi.load_facade_library()
         next_id = np.zeros(Bs, np.int64)
         obs = np.zeros((Bs, N), capi.RBA_OBS_DTYPE)
         ar = np.arange(N)[None, :]
@@ -671,7 +673,7 @@ def main():
         t_ph = np.zeros(4)
         last_tm, stats = None, []
         def one(k, timed_):
-            nonlocal ids_prev, last_tm, next_id
+            nonlocal ids_prev, ids_cur, last_tm
             c, p = sets[k % 2], sets[(k + 1) % 2]
             t0 = time.perf_counter()
             c.run_frontend(fp)
@@ -686,28 +688,22 @@ def main():
             _, nm = c.counts()
             nm = np.minimum(np.asarray(nm, np.int64), N)
             px = d_px.cpu().numpy(); pos = d_pos.cpu().numpy()
-            valid = ar < nm[:, None]
-            if k > 0:
-                st = s_st.view(Bs, N).cpu().numpy(); ti = s_idx.view(Bs, N).cpu().numpy()
-                tracked = valid & (st == 0) & (ti >= 0)
-                inherit = np.take_along_axis(ids_prev, np.clip(ti, 0, N - 1).astype(np.int64), 1)
-            else:
-                tracked = np.zeros((Bs, N), bool); inherit = np.zeros((Bs, N), np.int64)
-            fresh = valid & ~tracked
-            rank_new = np.cumsum(fresh, 1) - 1
-            ids = np.where(tracked, inherit, stream_base + next_id[:, None] + rank_new)
-            next_id += fresh.sum(1)
-            ids_prev = np.where(valid, ids, -1)
-            obs["feat_id"] = ids.astype(np.uint64)
-            obs["left_x"], obs["left_y"], obs["right_x"], obs["right_y"] = px[..., 0], px[..., 1], px[..., 2], px[..., 3]
-            obs["rel_pos"] = pos
+            st = s_st.view(Bs, N).cpu().numpy() if k > 0 else None
+            ti = s_idx.view(Bs, N).cpu().numpy() if k > 0 else None
+            nm32 = nm.astype(np.int32)
+            # EST.cpp:666-704 for the batch: tracked matches inherit the previous keyframe's landmark ids, the others found new landmarks (library entry)
+            rc = flib.ssk_rba_obs_from_da_batch(Bs, N, capi._ptr(nm32), capi._ptr(st) if k > 0 else None, capi._ptr(ti) if k > 0 else None, capi._ptr(px), capi._ptr(pos),
+                                                capi._ptr(ids_prev) if k > 0 else None, capi._ptr(next_id), capi._ptr(ids_cur), capi._ptr(obs))
+            assert rc == 0
+            ids_prev, ids_cur = ids_cur, (ids_prev if ids_prev is not None else np.empty((Bs, N), np.int64))
             t2 = time.perf_counter()
-            infos, tm = capi.rba_define_kf_batch(engines, (obs, nm.astype(np.int32)), optimize=k > 0)
+            infos, tm = capi.rba_define_kf_batch(engines, (obs, nm32), optimize=k > 0)
             t3 = time.perf_counter()
             if timed_:
                 t_ph[:] += [t1 - t0, t2 - t1, t3 - t2, t3 - t0]
                 last_tm = tm
-                stats.append((float(tracked.sum(1).mean()), float(np.mean([i.total_sqr_error_final <= i.total_sqr_error_init * (1 + 1e-12) for i in infos]))))
+                tracked_n = float(((st == 0) & (ti >= 0) & (ar < nm[:, None])).sum(1).mean()) if k > 0 else 0.0      # (statistics: outside the timed interval)
+                stats.append((tracked_n, float(np.mean([i.total_sqr_error_final <= i.total_sqr_error_init * (1 + 1e-12) for i in infos]))))
         for k in range(warm):
             one(k, False)
         for k in range(warm, warm + timed):
@@ -778,7 +774,19 @@ def main():
         fl = float(np.mean([lm_algorithmic_flops(w) for w in wins5])) * it2 * n
         out["roofline_depth5"] = {"kernel": k2, "bound": "fp64", "achieved": fl / (ms2 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": fl / (ms2 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl, "avg_launch_ms": ms2,
-                                  "note": "host clock around ssk_lm_batch_run + results of %d windows (phase-split kernels: linearise / reduce / solve / score / decide per LM pass, ssk_lm_split.h); the dense solve of K2 runs on the matrix cores (v_mfma_f64_16x16x4_f64; FP64 matrix rate = vector rate on MI355X), the rest on the vector ALUs; kernel-trace and PMC summaries: profiles/r04_lm_depth5*" % n}
+                                  "note": "host clock around ssk_lm_batch_run + results of %d windows (phase-split kernels: linearise / reduce / solve / score / decide per LM pass, ssk_lm_split.h); the dense solve of K2 runs on the matrix cores (v_mfma_f64_16x16x4_f64; FP64 matrix rate = vector rate on MI355X), the rest on the vector ALUs; kernel-trace and PMC summaries: profiles/r05_lm_depth5*" % n}
+        # round 5: a window at the 90th percentile of what the full-length un-batched stream produces (profiles/r05_stream_stage2_windows.json: stage-2
+        # local areas of 32 / 38 / 68 / 94 optimised edges at the 10th / 50th / 90th percentile / maximum): optimise depth 8 -> 70 edges, 15 k observations
+        try:
+            w90 = [sl.make_submap_problem(s, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=8, obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0] for s in range(2)]
+            n90 = min(n, 256)
+            ms90, it90, k90 = timed_named([w90[k % 2] for k in range(n90)], 2)
+            l90, _, _ = timed_named([w90[0]], 5)
+            b90 = capi.LmBatch(ctx, [w90[0]]); sv90 = b90.solver_name(); b90.close()
+            out["p90_window"] = {"stage2_edges": int(w90[0].E), "stage2_observations": int(len(w90[0].obs_lm)), "windows": n90, "stage2_ms": ms90, "stage2_iters": it90,
+                                 "keyframes_per_s_stage2_only": n90 / (ms90 * 1e-3), "one_keyframe_stage2_ms": l90, "stage2_kernel": k90, "dense_solver": sv90}
+        except Exception as e:
+            out["p90_window"] = {"error": str(e)}
         l1, _, kk1 = timed_named([st1[0]], 10)
         l2, _, kk2 = timed_named([wins5[0]], 10)
         out["one_keyframe"] = {"stage1_ms": l1, "stage2_ms": l2, "stage1_kernel": kk1, "stage2_kernel": kk2,
@@ -802,7 +810,7 @@ def main():
         # (MI355X_MICROARCH.md "HBM"; re-calibrated in the same run on lm_reset_kernel, which reads exactly what it writes)
         LM_KERNEL = lm.kernel_name()
         traffic, traffic_src, pmc_ms = {}, None, {}
-        for tf in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # the newest summary collected at this batch size
+        for tf in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # the newest summary collected at this batch size
             tfp = os.path.join(ROOT, "profiles", tf)
             if traffic or not os.path.exists(tfp):
                 continue
@@ -826,7 +834,9 @@ def main():
             return traffic[kernel]
         # executed FP64 flops from the PMC pass of the same command (tools/pmc_lm.sh: SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)
         pmc_flop = None
-        pl = os.path.join(ROOT, "profiles", "r04_pmc_lm_wave_time.json")
+        pl = os.path.join(ROOT, "profiles", "r05_pmc_lm_wave_time.json")
+        if not os.path.exists(pl):
+            pl = os.path.join(ROOT, "profiles", "r04_pmc_lm_wave_time.json")
         if os.path.exists(pl):
             try:
                 pmc_flop = json.load(open(pl)).get(LM_KERNEL, {}).get("derived", {}).get("f64_flop")
@@ -889,7 +899,7 @@ def main():
                          "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic_of(LM_KERNEL, lm_avg_ms), "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
                          "note": "dominant kernel by time; not bandwidth bound: two persistent workgroups per CU, waves wait on LDS / FP64 dependencies "
-                                 "(profiles/r04_pmc_lm_wave_time.json, DESIGN.md 5); traffic is null when the committed PMC summary's kernel time differs from the live one by more than 8 %"},
+                                 "(profiles/r05_pmc_lm_wave_time.json, DESIGN.md 5); traffic is null when the committed PMC summary's kernel time differs from the live one by more than 8 %"},
             "roofline_fp64": {"kernel": LM_KERNEL, "bound": "fp64", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
                               "executed_flops_per_launch_pmc": pmc_flop,

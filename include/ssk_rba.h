@@ -74,6 +74,13 @@ typedef struct ssk_rba_batch_timing {
 } ssk_rba_batch_timing;
 int ssk_rba_define_kf_batch(ssk_rba* const* r, int n, const ssk_rba_obs* const* obs, const int32_t* n_obs, int run_local_optimization,
                             ssk_rba_kf_info* out, ssk_rba_batch_timing* timing);
+/* The observation lists of a batch of streams' new keyframes (EST.cpp:666-704, per stream): match i of stream b (i < n_matches[b]) carries the stereo
+ * pixels obs_px[b][i] (a11) and the triangulated position init_pos[b][i] (a10); a match the data association TRACKED (status == SSK_DA_TRACKED and
+ * train_idx >= 0) inherits the landmark id of the previous keyframe's match train_idx (ids_prev[b][train_idx]), every other match founds a new landmark
+ * with the id (b << 40) + next_id[b]++.  ids_prev == NULL: the streams' first keyframe (every match new).  Outputs: ids_out [n][cap] (-1 beyond the
+ * matches: the next call's ids_prev), obs_out [n][cap] records ready for ssk_rba_define_kf_batch (row b, n_matches[b] entries).  Host arrays. */
+int ssk_rba_obs_from_da_batch(int n, int cap, const int32_t* n_matches, const int32_t* status, const int32_t* train_idx, const float* obs_px,
+                              const double* init_pos, const int64_t* ids_prev, int64_t* next_id, int64_t* ids_out, ssk_rba_obs* obs_out);
 int ssk_rba_num_keyframes(const ssk_rba* r);
 int ssk_rba_num_edges(const ssk_rba* r);
 int ssk_rba_num_landmarks(const ssk_rba* r);

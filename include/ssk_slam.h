@@ -34,6 +34,8 @@ typedef struct ssk_slam_frame_report {     /* what one loop iteration decided (t
 	int32_t kf_id, n_created_edges;
 	double total_sqr_error_init, total_sqr_error_final;
 	int32_t n_keyframes, reserved;
+	/* the local area define_new_keyframe optimised for this keyframe (stage 2, EST.cpp:782-784): optimised edges and observations of its window */
+	int32_t lm_stage2_edges, lm_stage2_obs;
 } ssk_slam_frame_report;
 
 typedef struct ssk_slam_timing {           /* cumulative host-clock milliseconds since ssk_slam_create: what an un-batched caller pays */

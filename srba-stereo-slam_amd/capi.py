@@ -521,7 +521,7 @@ class SlamFrameReport(C.Structure):
                 ("confirmed_loop_closure", C.c_int32), ("lc_kf_id", C.c_int32), ("n_query", C.c_int32), ("query_ids", C.c_int32 * 4),
                 ("query_scores", C.c_double * 4), ("n_similar", C.c_int32), ("similar_kfs", C.c_int32 * 8), ("highest_tracked", C.c_int32),
                 ("kf_id", C.c_int32), ("n_created_edges", C.c_int32), ("total_sqr_error_init", C.c_double), ("total_sqr_error_final", C.c_double),
-                ("n_keyframes", C.c_int32), ("reserved", C.c_int32)]
+                ("n_keyframes", C.c_int32), ("reserved", C.c_int32), ("lm_stage2_edges", C.c_int32), ("lm_stage2_obs", C.c_int32)]
 
 
 class SlamTiming(C.Structure):

@@ -696,7 +696,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	}
 	if (n_edge_t > 0x7FFFFFFF || n_obs_t > 0x7FFFFFFF || n_path_t > 0x7FFFFFFF || zn.item > 0x7FFFFFFF || zs.item > 0x7FFFFFFF)
 		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: the batch's tables exceed 2^31 entries");
-	// the batch-wide host images and tables in the context's pinned arena (up to 1 GB; larger batches: pageable memory)
+	// the batch-wide host images and tables in the context's pinned arena (up to 4 GB; larger batches: pageable memory)
 	nd_bump bump;
 	nd_bump* arena = nullptr;
 	{
@@ -707,7 +707,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		const size_t need = tb(zn) + tb(zs) + sizeof(int) * (n_edge_t + n_lm_t + n_obs_t + n_opo_t + n_path_t + n_us_t + n_ls_t) + sizeof(double) * (12 * n_edge_t + 3 * n_lm_t) +
 		                    sizeof(float) * 4 * n_obs_t + 64 * 64;
 		const bool no_pin = ctx->env.lm_no_pinned;
-		if (!no_pin && need <= ((size_t)1 << 30)) {
+		if (!no_pin && need <= ((size_t)4 << 30)) {       // (round 5: 4 GB -- 1 024 local areas of 5 k observations are 1.5-2.5 GB of tables; beyond 1 GB they went through pageable memory: 150 ms per create)
 			// the arena only grows inside ssk_arena_reserve: after one large batch a context would hold up to 1 GB of pinned host memory until
 			// ssk_destroy.  Eight creates in a row that need less than a quarter of it give it back (a streak, not one small create: bench.py and
 			// the facade alternate batch sizes, and hipHostMalloc of a few hundred MB costs tens of ms).  No create of this context is in flight

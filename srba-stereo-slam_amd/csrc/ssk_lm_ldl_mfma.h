@@ -466,11 +466,12 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 	return true;
 }
 
-// Systems of up to LDLM_LEAD_NMAX unknowns (round 5: the local areas the facade's own stream grows -- 61 optimised edges = 366 unknowns -- ran the
-// register-tile solver): the leading n - 252 columns by ldl_leading_panels (left-looking block columns through LDS, U and 1 / d to the system in L2),
+// Systems beyond 255 unknowns (round 5: the local areas the facade's own stream grows -- 61 optimised edges = 366 unknowns in the bench's 401-frame pass,
+// up to 94 at KITTI-00 length -- ran the register-tile solver): the leading n - 252 columns by ldl_leading_panels (left-looking block columns through LDS, U and 1 / d to the system in L2),
 // the trailing 252 x 252 block on the matrix cores (its tiles take the leading columns' updates as MFMAs right after the load), the leading
 // unknowns by ldl_backsub_leading.  Same factorisation, the update terms of an element in column order.  A is overwritten (as by ldl_solve_regtile).
-constexpr int LDLM_LEAD_NMAX = 396;     // 66 optimised edges
+constexpr int LDLM_LEAD_NMAX = 768;     // 128 optimised edges: every window the node builder takes (the full-length stream's local areas: median 38 edges,
+                                        // 90th percentile 68, largest 94 -- profiles/r05_stream_stage2_windows.json)
 __device__ __forceinline__ bool ldl_solve_mfma_lead(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
 {
 	const int tid = threadIdx.x;

@@ -305,6 +305,9 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	struct gnode { int lmk, node, slot_lane; };            // per lane of a group: which landmark / node (-1 = root)
 	std::vector<gnode> glanes;                             // all groups' lanes, group after group (H.group[...].lane0 / n_lanes index it)
 	glanes.reserve(nodes.size() + lms.size());
+	// (the tables' final sizes are known here: growing them push by push re-copied them a dozen times per window)
+	H.obs.reserve(H.obs.size() + (size_t)n_sorted); H.px.reserve(H.px.size() + (size_t)n_sorted); H.lane.reserve(H.lane.size() + nodes.size() + lms.size());
+	H.group.reserve(H.group.size() + (nodes.size() + lms.size()) / 32 + (size_t)n_sorted / 32 + 4);
 	{
 		nd_group G{0, 0, 0, 0};
 		auto flush = [&] {
@@ -349,6 +352,16 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	std::vector<char> is_diag((size_t)n_pairs, 0);         // block (e, e): the only ones the lambda_0 pass needs (bit 30 of a lane slot's x)
 	for (int e = 0; e < E; ++e) is_diag[(size_t)pid_of(e, e)] = 1;
 	int max_per_lane = 0, max_rounds = 0, max_tile_blocks = 0;
+	{
+		// an upper estimate of the item count: a landmark with k nodes has at most k (k + 1) / 2 pairs (+ the doubled same-edge pairs: rare)
+		size_t est = 0;
+		for (const lmk& M : lms) est += (size_t)M.n_nodes * ((size_t)M.n_nodes + 1) / 2;
+		H.item.reserve(H.item.size() + est + est / 8 + 64);
+		H.gitem.reserve(H.gitem.size() + nodes.size());
+		H.tile.reserve(H.tile.size() + n_tiles); H.gqs.reserve(H.gqs.size() + n_tiles * (size_t)std::max(E, 1));
+		if (split) H.sqs.reserve(H.sqs.size() + n_tiles * (size_t)std::min(n_pairs, 4 * waves * 64));
+		else H.qs.reserve(H.qs.size() + n_tiles * (size_t)NQ * 2);
+	}
 	for (size_t t = 0; t < n_tiles; ++t) {
 		const size_t g0 = t * (size_t)waves;
 		const int n_grp = (int)std::min(n_groups - g0, (size_t)waves);

@@ -383,7 +383,7 @@ void mySRBA::lm_apply(lm_job& j, const ssk_lm_result& r, TOptimizeResults& res)
 	if (j.optimize_landmarks)
 		for (size_t i = 0; i < j.lm_ids.size(); ++i) std::memcpy(j.lm_ptr[i]->pos, &j.lmpos[3 * i], 3 * sizeof(double));
 	res.total_sqr_error_init = r.err_init; res.total_sqr_error_final = r.err_final;
-	res.num_observations = (size_t)r.n_obs; res.num_iters = (size_t)r.iters;
+	res.num_observations = (size_t)r.n_obs; res.num_iters = (size_t)r.iters; res.num_opt_edges = (size_t)j.n_opt;
 	res.obs_rmse = r.n_obs ? std::sqrt(r.err_final / r.n_obs) : 0.0;
 }
 

@@ -30,7 +30,7 @@ typedef std::vector<new_kf_observation_t> new_kf_observations_t;
 
 struct TOptimizeResults {
 	double total_sqr_error_init = 0, total_sqr_error_final = 0, obs_rmse = 0;
-	size_t num_observations = 0, num_iters = 0;
+	size_t num_observations = 0, num_iters = 0, num_opt_edges = 0;
 };
 struct TNewKeyFrameInfo {                      // EST.cpp:178-180,790,847-849
 	TKeyFrameID kf_id = 0;

@@ -137,6 +137,30 @@ int ssk_rba_define_kf_batch(ssk_rba* const* r, int n, const ssk_rba_obs* const* 
 	});
 }
 
+int ssk_rba_obs_from_da_batch(int n, int cap, const int32_t* n_matches, const int32_t* status, const int32_t* train_idx, const float* obs_px,
+                              const double* init_pos, const int64_t* ids_prev, int64_t* next_id, int64_t* ids_out, ssk_rba_obs* obs_out)
+{
+	if (n < 1 || cap < 1 || !n_matches || !obs_px || !init_pos || !next_id || !ids_out || !obs_out || (ids_prev && (!status || !train_idx))) return SSK_ERR_BAD_ARG;
+	for (int b = 0; b < n; ++b) {
+		const int nm = std::min(std::max(n_matches[b], 0), cap);
+		const size_t o = (size_t)b * (size_t)cap;
+		int64_t nid = next_id[b];
+		for (int i = 0; i < nm; ++i) {
+			int64_t id = -1;
+			if (ids_prev && status[o + i] == SSK_DA_TRACKED && train_idx[o + i] >= 0 && train_idx[o + i] < cap) id = ids_prev[o + (size_t)train_idx[o + i]];
+			if (id < 0) id = ((int64_t)b << 40) + nid++;
+			ids_out[o + i] = id;
+			ssk_rba_obs& r = obs_out[o + i];
+			r.feat_id = (uint64_t)id;
+			r.left_x = obs_px[4 * (o + i)]; r.left_y = obs_px[4 * (o + i) + 1]; r.right_x = obs_px[4 * (o + i) + 2]; r.right_y = obs_px[4 * (o + i) + 3];
+			r.rel_pos[0] = init_pos[3 * (o + i)]; r.rel_pos[1] = init_pos[3 * (o + i) + 1]; r.rel_pos[2] = init_pos[3 * (o + i) + 2];
+		}
+		for (int i = nm; i < cap; ++i) ids_out[o + i] = -1;
+		next_id[b] = nid;
+	}
+	return SSK_OK;
+}
+
 int ssk_rba_num_keyframes(const ssk_rba* r) { return r ? (int)r->rba->num_keyframes() : 0; }
 int ssk_rba_num_edges(const ssk_rba* r) { return r ? (int)r->rba->get_rba_state().k2k_edges.size() : 0; }
 int ssk_rba_num_landmarks(const ssk_rba* r) { return r ? (int)r->rba->get_rba_state().unknown_lms.size() : 0; }

@@ -164,6 +164,7 @@ int ssk_slam_process_frame(ssk_slam* s, const uint8_t* left, const uint8_t* righ
 		out->kf_id = (int32_t)r.kf_info.kf_id; out->n_created_edges = (int32_t)r.kf_info.created_edge_ids.size();
 		out->total_sqr_error_init = r.kf_info.optimize_results.total_sqr_error_init;
 		out->total_sqr_error_final = r.kf_info.optimize_results.total_sqr_error_final;
+		out->lm_stage2_edges = (int32_t)r.kf_info.optimize_results.num_opt_edges; out->lm_stage2_obs = (int32_t)r.kf_info.optimize_results.num_observations;
 		out->n_keyframes = (int32_t)s->get().m_keyframes.size();
 		if (r.checked_for_kf) { s->last_da = r.da; s->last_da_sorted = r.da_sorted; s->last_da_init = r.similar.similar_kfs_poses; }
 	});

@@ -551,14 +551,14 @@ def test_lm_split_dense_solver_sizes(ctx, oracle, n_kf):
     the border row inside the last), 222 (border row 14 of the last tile row), 240 (border row = a tile row of its own), 252 (the largest system
     held WHOLE in accumulator tiles); round 5: 264, 330, 348, 372, 396 ON THE MATRIX-CORE PATH too (ldl_solve_mfma_lead: 12 .. 144 leading columns by
     block columns through LDS, their updates applied to the trailing 252 x 252 tiles as MFMAs) -- the local areas the facade's own stream grows
-    reach 61 edges; beyond 396 the register-tile solver: 540"""
+    reach 61 edges (94 at KITTI-00 length); 540: 288 leading columns"""
     win, gt = sl.make_submap_problem(21 if n_kf < 91 else 23, n_kf=n_kf, n_lm=(20 * n_kf if n_kf < 91 else 1500), submap_size=3, max_tree_depth=6,
                                      opt_depth=n_kf, obs_per_kf=60 if n_kf < 91 else 40)
     assert win.E == n_kf - 1
     from ssk_amd import capi
     b = capi.LmBatch(ctx, [win])
     assert b.kernel_name() == "lm_split_linearise_kernel"
-    assert b.solver_name() == ("ldl_solve_mfma_lead" if win.E <= 66 else "ldl_solve_regtile")
+    assert b.solver_name() == "ldl_solve_mfma_lead"
     b.close()
     check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8 if n_kf < 91 else 5))
 

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 ROOTD=$PWD
 OUT=$ROOTD/gpurun_out/pmc_lm${1:+_$1}
 rm -rf $OUT; mkdir -p $OUT
-BS="--steps 3 --warmup 1 --cpu-sample 0 --cpu-procs 0 --pcie-steps 0 --unbatched-frames 0 --lm-depth5 0"
+BS="--steps 3 --warmup 1 --cpu-sample 0 --cpu-procs 0 --pcie-steps 0 --unbatched-frames 0 --lm-depth5 0 --e2e-streams 0"
 cd /tmp
 i=0
 for set in \

@@ -29,7 +29,7 @@ def run(n, n_back, seed=9, verbose=True, voc_every=None, **options):
     prm = capi.FrontendParams(**synth.KITTI_FRONTEND)
     step = voc_every or max(1, n // 32)
     train = [ctx.frontend_run(*get(pos[k], k), prm)["desc_left"] for k in range(0, n, step)][:32]
-    out = dict(frames=n, n_back=n_back, invalid_odometry=[], loop_closures=[], multi_edge_kfs=0, kf_frames=[], kf_pos=[], error_increased=[])
+    out = dict(frames=n, n_back=n_back, invalid_odometry=[], loop_closures=[], multi_edge_kfs=0, kf_frames=[], kf_pos=[], error_increased=[], stage2_edges=[], stage2_obs=[])
     with tempfile.TemporaryDirectory() as d:
         voc = os.path.join(d, "voc.yml.gz")
         bv.write_yaml(bv.train(train, k=8, L=4, seed=5), voc)
@@ -48,6 +48,8 @@ def run(n, n_back, seed=9, verbose=True, voc_every=None, **options):
                     t_kf += dt
             if rep.inserted_kf:
                 out["kf_frames"].append(k); out["kf_pos"].append(pos[k])
+                if k > 0:                                   # the local area define_new_keyframe optimised (stage 2): its size per keyframe
+                    out["stage2_edges"].append(int(rep.lm_stage2_edges)); out["stage2_obs"].append(int(rep.lm_stage2_obs))
                 if rep.n_created_edges > 1:
                     out["multi_edge_kfs"] += 1
                 if k > 0 and not rep.total_sqr_error_final <= rep.total_sqr_error_init:
@@ -91,6 +93,17 @@ def main():
              o["posegraph_s"], o["pg_stop"], o["pg_iters"], o["pg_cost_init"], o["pg_cost_final"], len(o["loop_closures"]), o["multi_edge_kfs"],
              len(o["invalid_odometry"]), err.max(), 100 * err.max() / path, path, err[-1]))
     print("timing", o["timing"])
+    # round 5: the distribution of the stage-2 windows the stream produces: percentiles + histogram -> JSON when SSK_STREAM_HIST names a file
+    e, ob = np.array(o["stage2_edges"]), np.array(o["stage2_obs"])
+    if len(e):
+        q = lambda a: {"p%d" % p: float(np.percentile(a, p)) for p in (10, 50, 90, 99)} | {"max": int(a.max()), "mean": float(a.mean())}
+        hist = {"frames": n, "keyframes": int(o["keyframes"]), "options": opts, "stage2_optimised_edges": q(e), "stage2_observations": q(ob),
+                "edges_histogram": {str(int(k)): int(v) for k, v in zip(*np.unique(e, return_counts=True))},
+                "observations_histogram_per_2000": {str(int(k) * 2000): int(v) for k, v in zip(*np.unique(ob // 2000, return_counts=True))}}
+        print("stage-2 windows:", hist["stage2_optimised_edges"], hist["stage2_observations"])
+        if os.environ.get("SSK_STREAM_HIST"):
+            import json
+            json.dump(hist, open(os.environ["SSK_STREAM_HIST"], "w"), indent=1)
 
 
 if __name__ == "__main__":
