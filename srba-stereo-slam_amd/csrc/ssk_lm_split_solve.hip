@@ -3,6 +3,7 @@
 // ssk_lm_device.h -- the solver in a kernel of its own), applies the edge step exp(eps) (+) T (contract L3 of oracle/oracle_lm.c) and builds
 // the trial state's suffix table.  Reference: solver_LM_schur_dense_cholesky, SRBA.h:34; call EST.cpp:782-784.
 #include "ssk_lm_split.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -78,20 +79,25 @@ void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubl
 	}
 	double* s_b = s_dyn;
 	double* s_inv = s_b + n6p;
-	double* pose = s_inv + n6p;                          // the window's edge poses: current, then trial
-	nd_i2* s_suf = reinterpret_cast<nd_i2*>(pose + 12 * W.n_edges);
-	double* lds = reinterpret_cast<double*>(s_suf + ((W.n_suf + 1) & ~1));
+	double* lds = s_inv + n6p;                           // the solver's staging; AFTER the solve: the window's edge poses and trie records
 	const int lds_doubles = dyn_doubles - (int)(lds - s_dyn);
-	for (int i = tid; i < 12 * W.n_edges; i += NT) pose[i] = D.pose[12 * (size_t)W.edge0 + i];
-	for (int i = tid; i < W.n_suf; i += NT) s_suf[i] = N.suf[W.suf0 + i];
+	// (round 5: poses and trie records OVERLAY the staging -- the solve needs neither, the edge step and the table need no staging --: a local area of
+	// 70 edges / 1 000 suffixes beside the matrix-core solver's 138 KB did not fit, and such windows fell back to the register-tile solver)
+	double* pose = lds;                                  // the window's edge poses: current, then trial
+	nd_i2* s_suf = reinterpret_cast<nd_i2*>(pose + 12 * W.n_edges);
 	// (the reduced system was assembled by lm_split_reduce_kernel: A = H_pp - S + lambda I, both triangles, border row = reduced gradient)
 	double* A = D.Hred + W.h0;
-	__syncthreads();
 	bool ok = true;
 	if (n6 > 0) {
 		if constexpr (MFMA) ok = ldl_solve_mfma_lead(A, np, n6, s_b, s_inv, lds, lds_doubles);
 		else ok = SSK_LDL_BIG(A, np, n6, s_b, s_inv, lds, lds_doubles);
 	}
+	__syncthreads();
+	if (ok) {
+		for (int i = tid; i < 12 * W.n_edges; i += NT) pose[i] = D.pose[12 * (size_t)W.edge0 + i];
+		for (int i = tid; i < W.n_suf; i += NT) s_suf[i] = N.suf[W.suf0 + i];
+	}
+	__syncthreads();
 	double dpn = 0.0;
 	if (ok) {
 		for (int i = tid; i < n6; i += NT) {
@@ -143,7 +149,7 @@ size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma)
 {
 	const size_t n6p = ((size_t)6 * E + 1) & ~(size_t)1;
 	// the solver's staging (ldl_solve_mfma_tiles: LDLM_DOUBLES = 17 680 doubles, ldl_solve_regtile: L_TOTAL = 8 080) + a little head room
-	return 2 * n6p + 12 * (size_t)n_edges + (((size_t)n_suf + 1) & ~(size_t)1) + (mfma ? LDLM_DOUBLES + 256 : 8192);
+	return 2 * n6p + std::max(12 * (size_t)n_edges + (((size_t)n_suf + 1) & ~(size_t)1), (size_t)(mfma ? LDLM_DOUBLES + 256 : 8192));      // (poses + trie records overlay the staging)
 }
 
 int ssk_lm_launch_split_solve(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, const sp_dev& S, const lm_cam& P, size_t dyn_bytes)

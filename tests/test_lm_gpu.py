@@ -558,7 +558,7 @@ def test_lm_split_dense_solver_sizes(ctx, oracle, n_kf):
     from ssk_amd import capi
     b = capi.LmBatch(ctx, [win])
     assert b.kernel_name() == "lm_split_linearise_kernel"
-    assert b.solver_name() == "ldl_solve_mfma_lead"
+    assert b.solver_name() == "ldl_solve_mfma_lead"                # (every window the node builder takes: the trailing 252 x 252 block on the matrix cores)
     b.close()
     check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8 if n_kf < 91 else 5))
 
