@@ -30,8 +30,9 @@ constexpr int R_Q = 9, R_P = 12, R_V = 21;
 // SMALL: every window of the launch has E <= 10 (the host checks): the only dense solver compiled in is ldl_solve_blocks6_wave -- the other solvers'
 // loop-invariant LDS addresses, hoisted in front of the LM loop, were what the kernel spilled
 template <bool BIG, bool SMALL = false>
-__device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const lm_cam& P_arg, int dyn_doubles)
+__device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const lm_cam& P_arg, int dyn_doubles)
 {
+	lm_dev D = D0;                                     // (lm / lm_new are swapped per accepted step below: ND_LM_FLIP)
 	__shared__ lm_cam s_P;
 	if (threadIdx.x == 0) s_P = P_arg;
 	extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [pose_cur | pose_new | delta | pivots | block accumulators | gradient | records / reduced system]
@@ -111,6 +112,11 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 		const bool pre = lambda < 0;                   // first pass of a solve: only diag(H_pp) and diag(V), for lambda_0
 		const int it_idx = s_iters, cur = s_cur;
 		const double* tab_cur = tabs[cur];
+#if ND_LM_FLIP
+		// (round 5) the landmarks double-buffered like the suffix tables: the trial positions of an accepted step ARE the next state (no copy pass, no
+		// barrier behind it); landmarks the window holds are equal in both buffers from the start
+		D.lm = cur ? D0.lm_new : D0.lm; D.lm_new = cur ? D0.lm : D0.lm_new;
+#endif
 		double vmax = 0.0;
 		STAMP(0);
 		if (BIG) {
@@ -122,6 +128,10 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 		STAMP(1);
 		// ---- linearisation: tile by tile ----
 		nd_recs nx = nd_fetch_recs(N, W, groups[min(wave, max(n_groups - 1, 0))], lane);
+#if ND_PREFETCH
+		nd_pre pf;
+		nd_prefetch_group(D, W, groups[min(wave, max(n_groups - 1, 0))], nx, tab_cur, lane, pf);
+#endif
 		for (int t = 0; t < W.n_tiles; ++t) {
 			const nd_tile T = s_tile[t];
 			nd_i2 q0 = nd_i2{0xFFFF, 0};               // (round 0's slot in flight behind the group phase)
@@ -132,7 +142,11 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 #endif
 			const nd_recs rc = nx;
 			if (t + 1 < W.n_tiles) nx = nd_fetch_recs(N, W, groups[min(s_tile[t + 1].grp0 + wave, n_groups - 1)], lane);      // the next tile's records: in flight during this one
+#if ND_PREFETCH
+			if (wave < T.n_grp) nd_linearise_group<false, true>(D, N, W, P, groups[T.grp0 + wave], rc, tab_cur, stage, lambda, pre, lane, vmax, &pf);
+#else
 			if (wave < T.n_grp) nd_linearise_group(D, N, W, P, groups[T.grp0 + wave], rc, tab_cur, stage, lambda, pre, lane, vmax);
+#endif
 #if SSK_ND_LANE_RUNS
 			nd_items its = nd_items_fetch(N.item + W.item0 + q0.y, (q0.x >> 16) & 0x7FFF, 0, 1);      // (in flight across the barrier)
 			STAMP(2);
@@ -240,6 +254,13 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 					}
 				}
 			STAMP(4);
+#if ND_PREFETCH
+			// the next tile's group-phase operands (its records arrived during this tile): in flight across the barrier
+			// (not a cycle earlier: hoisted into the pair phase their 60 registers are spilled)
+			__builtin_amdgcn_sched_barrier(0);
+			// (unconditional -- the last tile fetches its own group's again --: a guarded assignment keeps the OLD operands alive through the whole tile)
+			nd_prefetch_group(D, W, groups[min(s_tile[min(t + 1, W.n_tiles - 1)].grp0 + wave, n_groups - 1)], nx, tab_cur, lane, pf);
+#endif
 			__syncthreads();
 			STAMP(5);
 		}
@@ -322,6 +343,24 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 			__syncthreads();
 			STAMP(8);
 			double e = 0.0;
+#if ND_PREFETCH
+			{
+				// records two groups ahead, operands one group ahead (indices clamped: the fetches past the last group repeat it and are not used)
+				const int gl = max(n_groups - 1, 0);
+				nd_recs r0 = nd_fetch_recs(N, W, groups[min(wave, gl)], lane);
+				nd_recs r1 = nd_fetch_recs(N, W, groups[min(wave + NDW, gl)], lane);
+				nd_spre d0;
+				nd_prefetch_score(D, N, W, groups[min(wave, gl)], r0, tabs[cur ^ 1], lane, d0);
+				for (int g = wave; g < n_groups; g += NDW) {
+					const nd_recs rc = r0;
+					const nd_spre dc = d0;
+					r0 = r1;
+					r1 = nd_fetch_recs(N, W, groups[min(g + 2 * NDW, gl)], lane);
+					nd_prefetch_score(D, N, W, groups[min(g + NDW, gl)], r0, tabs[cur ^ 1], lane, d0);
+					nd_score_group<true>(D, N, W, P, groups[g], rc, tabs[cur ^ 1], stage, s_b, true, it_idx, lane, e, dfn, &dc);
+				}
+			}
+#else
 			{
 				nd_recs nx = nd_fetch_recs(N, W, groups[min(wave, max(n_groups - 1, 0))], lane);
 				for (int g = wave; g < n_groups; g += NDW) {
@@ -330,6 +369,7 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 					nd_score_group(D, N, W, P, groups[g], rc, tabs[cur ^ 1], stage, s_b, true, it_idx, lane, e, dfn);
 				}
 			}
+#endif
 			err_new = block_sum(e, s_part);
 			STAMP(9);
 		}
@@ -362,16 +402,30 @@ __device__ __forceinline__ void nd_body(const lm_dev& D, const nd_dev& N, const 
 				const int ei = D.slot_edge[W.us0 + e];
 				for (int c = 0; c < 12; ++c) pose_cur[12 * ei + c] = pose_new[12 * ei + c];
 			}
+#if !ND_LM_FLIP
 			for (int l = tid; l < W.L; l += NT) {
 				const int li = D.slot_lm[W.ls0 + l];
 				for (int c = 0; c < 3; ++c) D.lm[3 * (size_t)(W.lm0 + li) + c] = D.lm_new[3 * (size_t)(W.lm0 + li) + c];
 			}
+#endif
 		}
+#if !ND_LM_FLIP
 		__syncthreads();
+#endif
+		// (with the landmarks double-buffered the accepted state's copy is the edge poses in LDS alone: the barrier at the loop's head -- or the one
+		// behind the loop -- orders it before its readers; s_stop was written in front of the barrier above)
 		STAMP(10);
 		if (s_stop == 2 || s_stop == 4) break;
 	}
 	__syncthreads();
+#if ND_LM_FLIP
+	if (s_cur) {                                       // the final landmarks sit in the second buffer: to the batch's state array
+		for (int l = tid; l < W.L; l += NT) {
+			const int li = D0.slot_lm[W.ls0 + l];
+			for (int c = 0; c < 3; ++c) D0.lm[3 * (size_t)(W.lm0 + li) + c] = D0.lm_new[3 * (size_t)(W.lm0 + li) + c];
+		}
+	}
+#endif
 	// publish the final edge poses (they lived in LDS during the solve)
 	for (int e = tid; e < W.E; e += NT) {
 		const int ei = D.slot_edge[W.us0 + e];

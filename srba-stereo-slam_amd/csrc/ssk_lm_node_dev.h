@@ -51,6 +51,33 @@ __device__ __forceinline__ void nd_store12(double* __restrict__ p, const double 
 #pragma unroll
 	for (int i = 0; i < 6; ++i) { v2d_t x; x.x = o[2 * i]; x.y = o[2 * i + 1]; v[i] = x; }
 }
+// ND_NT = 1 (same-box A/B only): the STREAMING data of a pass -- the back-substitution scratch (96 B per lane out in the linearisation, back in the scoring),
+// the static lane / observation records and item codes -- with the non-temporal cache policy, meant to keep the suffix tables, landmarks and poses in the
+// XCD's 4 MB of L2 (64 resident windows stream ~37 MB per pass through it).  MEASURED WORSE, round 5: 3.80 -> 4.46 ms per 1 024 bench windows (the phase-split
+// path: 37.08 ms either way): the scratch that comes back in the same pass and the records the scoring re-reads DO profit from the L2 / the memory-side cache
+// -- the kernel is latency bound and its latency is largely that of these very streams.  Default 0.
+#ifndef ND_NT
+#define ND_NT 0
+#endif
+#if ND_NT
+#define ND_LDNT(p) __builtin_nontemporal_load(p)
+#define ND_STNT(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define ND_LDNT(p) (*(p))
+#define ND_STNT(v, p) (*(p) = (v))
+#endif
+__device__ __forceinline__ void nd_load12_nt(const double* __restrict__ p, double (&o)[12])
+{
+	const v2d_t* v = reinterpret_cast<const v2d_t*>(p);
+#pragma unroll
+	for (int i = 0; i < 6; ++i) { const v2d_t x = ND_LDNT(v + i); o[2 * i] = x.x; o[2 * i + 1] = x.y; }
+}
+__device__ __forceinline__ void nd_store12_nt(double* __restrict__ p, const double (&o)[12])
+{
+	v2d_t* v = reinterpret_cast<v2d_t*>(p);
+#pragma unroll
+	for (int i = 0; i < 6; ++i) { v2d_t x; x.x = o[2 * i]; x.y = o[2 * i + 1]; ND_STNT(x, v + i); }
+}
 
 // Suffix table of the window at the poses `pose` (LDS) -> tab (HBM, 12 doubles per suffix, id 0 = identity): a lane per suffix walks its
 // own chain -- the codes from the suffix down to the empty one, then the transforms from the innermost step outwards.
@@ -111,15 +138,45 @@ __device__ __forceinline__ nd_recs nd_fetch_recs(const nd_dev& N, const nd_win& 
 	const int oi = W.obs0 + G.obs0 + min(lane, max(G.n_obs - 1, 0));      // loads are unconditional on clamped indices
 	const int li = W.lane0 + G.lane0 + min(lane, max(G.n_lanes - 1, 0));
 	nd_recs r;
+#if ND_NT
+	{
+		typedef int nd_v2i __attribute__((ext_vector_type(2)));
+		typedef int nd_v4i __attribute__((ext_vector_type(4)));
+		typedef float nd_v4f __attribute__((ext_vector_type(4)));
+		const nd_v2i a = __builtin_nontemporal_load(reinterpret_cast<const nd_v2i*>(N.obs + oi));
+		const nd_v4f b = __builtin_nontemporal_load(reinterpret_cast<const nd_v4f*>(N.px + oi));
+		const nd_v4i c = __builtin_nontemporal_load(reinterpret_cast<const nd_v4i*>(N.lane + li));
+		r.orec = nd_i2{a.x, a.y}; r.px = nd_f4{b.x, b.y, b.z, b.w}; r.lrec = nd_i4{c.x, c.y, c.z, c.w};
+	}
+#else
 	r.orec = N.obs[oi]; r.px = N.px[oi]; r.lrec = N.lane[li];
+#endif
 	return r;
+}
+
+// Round 5 (persistent node kernel): the lane's operands of a group phase -- the observation's path transform and landmark, the node's transform and
+// landmark: gathers from the suffix table and the landmark array, L2 or beyond -- fetched a TILE ahead, at the end of the previous tile's pair phase (its
+// 36 accumulators are dead there): they fly during the tile's closing barrier instead of in front of the first flop of the next group phase.
+struct nd_pre { double T[12], f[3], Tn[12], fn[3]; };
+__device__ __forceinline__ void nd_prefetch_group(const lm_dev& D, const nd_win& W, const nd_group G, const nd_recs& rc, const double* __restrict__ tab, int lane, nd_pre& o)
+{
+	nd_i4 lrec = rc.lrec;
+	if (lane >= G.n_lanes) lrec.w = 0;
+	const bool is_node = (lrec.w & 0xFF) == 2;
+	nd_load12(tab + 12 * (size_t)(rc.orec.y & 0xFFFF), o.T);
+	const double* fp = D.lm + 3 * (size_t)(W.lm0 + rc.orec.x);
+	o.f[0] = fp[0]; o.f[1] = fp[1]; o.f[2] = fp[2];
+	nd_load12(tab + 12 * (size_t)(is_node ? (lrec.z & 0xFFFF) : 0), o.Tn);
+	const double* fq = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
+	o.fn[0] = fq[0]; o.fn[1] = fq[1]; o.fn[2] = fq[2];
 }
 
 // LATE_TN: the node lanes' transform and landmark are loaded behind the observation phase instead of in front of it (30 VGPRs fewer at the
 // function's pressure peak: the phase-split kernel runs three wavefronts per SIMD on 168 registers; the load then flies behind the run sums)
-template <bool LATE_TN = false>
+template <bool LATE_TN = false, bool PRE = false>
 __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G, const nd_recs rc,
-                                                   const double* __restrict__ tab, double* __restrict__ stage, double lambda, bool pre, int lane, double& vmax)
+                                                   const double* __restrict__ tab, double* __restrict__ stage, double lambda, bool pre, int lane, double& vmax,
+                                                   const nd_pre* pf = nullptr)
 {
 	const int li = W.lane0 + G.lane0 + min(lane, G.n_lanes - 1);
 	const nd_i2 orec = rc.orec;
@@ -130,7 +187,11 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 	const bool is_node = kind == 2, is_root = kind == 1;
 	// the node's transform and landmark (needed last: in flight behind everything else)
 	double Tn[12], fn[3];
-	if (!LATE_TN) {
+	if (PRE) {
+#pragma unroll
+		for (int i = 0; i < 12; ++i) Tn[i] = pf->Tn[i];
+		fn[0] = pf->fn[0]; fn[1] = pf->fn[1]; fn[2] = pf->fn[2];
+	} else if (!LATE_TN) {
 		nd_load12(tab + 12 * (size_t)(is_node ? (lrec.z & 0xFFFF) : 0), Tn);
 		const double* fp = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
 		fn[0] = fp[0]; fn[1] = fp[1]; fn[2] = fp[2];
@@ -139,9 +200,15 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 	// ---- lane = observation: V_o = Jf^T Jf (6), g_o = Jf^T w r (3) -> staging ----
 	{
 		double T[12], f[3], pc[3], iz, r[4];
-		nd_load12(tab + 12 * (size_t)(orec.y & 0xFFFF), T);
-		const double* fp = D.lm + 3 * (size_t)(W.lm0 + orec.x);
-		f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
+		if (PRE) {
+#pragma unroll
+			for (int i = 0; i < 12; ++i) T[i] = pf->T[i];
+			f[0] = pf->f[0]; f[1] = pf->f[1]; f[2] = pf->f[2];
+		} else {
+			nd_load12(tab + 12 * (size_t)(orec.y & 0xFFFF), T);
+			const double* fp = D.lm + 3 * (size_t)(W.lm0 + orec.x);
+			f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
+		}
 		nd_residual(P, T, f, px, pc, iz, r);
 		const double iz2 = iz * iz;
 		const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
@@ -206,7 +273,7 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 	}
 	WAVE_SYNC();
 	FINE(0);
-	if (LATE_TN) {
+	if (LATE_TN && !PRE) {
 		nd_load12(tab + 12 * (size_t)(is_node ? (lrec.z & 0xFFFF) : 0), Tn);
 		const double* fp = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
 		fn[0] = fp[0]; fn[1] = fp[1]; fn[2] = fp[2];
@@ -285,7 +352,7 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 #pragma unroll
 			for (int c = 0; c < 9; ++c) sc[c] = opt ? rec[6 + c] : 0.0;
 			sc[9] = sc[10] = sc[11] = 0.0;
-			nd_store12(N.scr + SCR * (size_t)li, sc);
+			nd_store12_nt(N.scr + SCR * (size_t)li, sc);
 			if (D.store_hff && opt) {                              // diagnostics: the landmark blocks of the last linearisation
 				double* Hm = D.Hff + 9 * (size_t)(W.ls0 + lrec.z);
 				Hm[0] = vs[0]; Hm[1] = vs[1]; Hm[2] = vs[2]; Hm[3] = vs[1]; Hm[4] = vs[3]; Hm[5] = vs[4]; Hm[6] = vs[2]; Hm[7] = vs[4]; Hm[8] = vs[5];
@@ -339,7 +406,7 @@ __device__ __forceinline__ void nd_linearise_group(const lm_dev& D, const nd_dev
 		for (int c = 0; c < 12; ++c) { v2d_t x; x.x = out[2 * c]; x.y = out[2 * c + 1]; o[c] = x; }
 		if (!pre) {
 			const double sc[12] = {out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], out[8], out[R_Q], out[R_Q + 1], out[R_Q + 2]};
-			nd_store12(N.scr + SCR * (size_t)li, sc);
+			nd_store12_nt(N.scr + SCR * (size_t)li, sc);
 		}
 	}
 	FINE(4);
@@ -389,6 +456,12 @@ __device__ __forceinline__ void nd_item_apply(const nd_item_ops& o, double sg, d
 #ifndef ND_PIPE
 #define ND_PIPE 0                       // 1: software-pipelined item turns (loads of item k + 1 in front of the products of item k)
 #endif
+#ifndef ND_LM_FLIP
+#define ND_LM_FLIP 1                    // persistent node kernel: landmarks double-buffered (an accepted step flips the buffers; 0: a copy pass per accepted step)
+#endif
+#ifndef ND_PREFETCH
+#define ND_PREFETCH 1                   // persistent node kernel: a group phase's transforms / landmarks fetched at the end of the previous tile's pair phase (0: at the group's start)
+#endif
 #ifndef ND_SCAN
 #define ND_SCAN 1                       // run sums from per-landmark prefix sums over the observation lanes (DPP scan); 0: every root / node lane walks its run
 #endif
@@ -415,7 +488,7 @@ __device__ __forceinline__ nd_items nd_items_fetch(const int* __restrict__ items
 {
 	nd_items r;
 #pragma unroll
-	for (int k = 0; k < ND_ITEMS_REG; ++k) r.it[k] = items[min(first + step * k, max(n - 1, 0))];      // unconditional, clamped
+	for (int k = 0; k < ND_ITEMS_REG; ++k) r.it[k] = ND_LDNT(items + min(first + step * k, max(n - 1, 0)));      // unconditional, clamped
 	return r;
 }
 __device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, const int* __restrict__ items, const nd_items& pre_it, int n, int ql, int step, bool pre, double (&acc)[36])
@@ -471,23 +544,43 @@ __device__ __forceinline__ void nd_quad_sum36(double (&acc)[36])
 // ---- trial state: landmark steps and robust error of one group by one wavefront ----
 // backsub: node lanes t_n = Zh_n^T (dt_e + dw_e x q_n) -> root lane delta_f = L^-T (c - sum t_n), f_new = f + delta_f -> the landmark's
 // observation lanes; !backsub: the error at the current landmarks (the solve's first pass)
+// (round 5, persistent kernel) the lane's operands of a scoring round with back-substitution -- the observation's trial transform, the lane's scratch
+// record, its landmark -- fetched a GROUP ahead: they fly during the previous group's dependent chain (node terms -> root sum -> landmark step -> residual)
+struct nd_spre { double T[12], sc[12], fl[3]; };
+__device__ __forceinline__ void nd_prefetch_score(const lm_dev& D, const nd_dev& N, const nd_win& W, const nd_group G, const nd_recs& rc, const double* __restrict__ tab, int lane, nd_spre& o)
+{
+	const int li = W.lane0 + G.lane0 + min(lane, G.n_lanes - 1);
+	nd_load12(tab + 12 * (size_t)(rc.orec.y & 0xFFFF), o.T);
+	nd_load12_nt(N.scr + SCR * (size_t)li, o.sc);
+	const double* fp = D.lm + 3 * (size_t)(W.lm0 + rc.lrec.x);
+	o.fl[0] = fp[0]; o.fl[1] = fp[1]; o.fl[2] = fp[2];
+}
+
+template <bool PRE = false>
 __device__ __forceinline__ void nd_score_group(const lm_dev& D, const nd_dev& N, const nd_win& W, const lm_cam& P, const nd_group G, const nd_recs rc,
                                                const double* __restrict__ tab, double* __restrict__ stage, const double* s_b, bool backsub, int it_idx,
-                                               int lane, double& err, double& dfn)
+                                               int lane, double& err, double& dfn, const nd_spre* pf = nullptr)
 {
 	const int li = W.lane0 + G.lane0 + min(lane, G.n_lanes - 1);
 	const nd_i2 orec = rc.orec;
 	const nd_f4 px = rc.px;
 	double T[12];
-	nd_load12(tab + 12 * (size_t)(orec.y & 0xFFFF), T);
+	if (PRE) {
+#pragma unroll
+		for (int i = 0; i < 12; ++i) T[i] = pf->T[i];
+	} else nd_load12(tab + 12 * (size_t)(orec.y & 0xFFFF), T);
 	double f[3];
 	if (backsub) {
 		nd_i4 lrec = rc.lrec;
 		if (lane >= G.n_lanes) lrec.w = 0;
 		const int kind = lrec.w & 0xFF;
 		double sc[12], fl[3];
-		nd_load12(N.scr + SCR * (size_t)li, sc);
-		{
+		if (PRE) {
+#pragma unroll
+			for (int i = 0; i < 12; ++i) sc[i] = pf->sc[i];
+			fl[0] = pf->fl[0]; fl[1] = pf->fl[1]; fl[2] = pf->fl[2];
+		} else {
+			nd_load12_nt(N.scr + SCR * (size_t)li, sc);
 			const double* fp = D.lm + 3 * (size_t)(W.lm0 + lrec.x);
 			fl[0] = fp[0]; fl[1] = fp[1]; fl[2] = fp[2];
 		}
