@@ -858,7 +858,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		size_t sd = 0, id = 0;
 		int E_max = 0;
 		for (const nd_win& nw : NHs.win) E_max = std::max(E_max, nw.E);
-		bool mfma = ssk_sp_solve_mfma(E_max, ctx->env.k2_regtile);
+		int mfma = ssk_sp_solve_mfma(E_max, ctx->env.k2_regtile);
 		for (int attempt = 0; attempt < 2; ++attempt) {
 			sd = 0; id = 0;
 			for (const nd_win& nw : NHs.win) {
@@ -866,9 +866,9 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 				id = std::max(id, 12 * (size_t)nw.n_edges + (size_t)nw.n_suf + 2);
 			}
 			if (!mfma || 8 * sd <= node_lds_limit) break;
-			mfma = false;                                  // (a window with so many fixed edges that the MFMA solver's staging does not fit beside them)
+			mfma = 0;                                  // (a window with so many fixed edges that the MFMA solver's staging does not fit beside them)
 		}
-		b->S.solve_mfma = mfma ? 1 : 0;
+		b->S.solve_mfma = mfma;
 		b->split_solve_dyn_bytes = 8 * sd; b->split_init_dyn_bytes = 8 * id;
 		if (b->split_solve_dyn_bytes > node_lds_limit || b->split_init_dyn_bytes > node_lds_limit) { delete b; return 1; }
 	}
@@ -1968,7 +1968,7 @@ int ssk_lm_batch_solver_name(ssk_ctx* ctx, ssk_lm_batch* b, char* out, int cap)
 	if (!b || !out || cap < 1) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_solver_name: bad argument");
 	if (!b->sub.empty()) return ssk_lm_batch_solver_name(ctx, b->sub[0], out, cap);
 	const char* name = "ldl (rounds 1-3 kernels)";
-	if (b->split_ok) name = b->S.solve_mfma ? "ldl_solve_mfma_lead" : "ldl_solve_regtile";
+	if (b->split_ok) name = b->S.solve_mfma == 2 ? "ldl_solve_mfma_tiles" : b->S.solve_mfma == 1 ? "ldl_solve_mfma_lead" : "ldl_solve_regtile";
 	else if (b->node_ok) name = b->node_big ? "ldl_solve_regtile" : b->node_small ? "ldl_solve_mfma_wave" : "ldl_solve_tiles4_lds / ldl_solve_lds";
 	else if (b->lean && b->pose_n) name = "in registers (pose-only)";
 	std::snprintf(out, (size_t)cap, "%s", name);

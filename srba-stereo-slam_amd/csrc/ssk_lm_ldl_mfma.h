@@ -53,6 +53,9 @@ constexpr int LDLM_LP = 17;             // pitch of a 16 x 16 block in LDS
 constexpr int LDLM_NMAX = 255;          // largest system (n + 1 <= 256)
 constexpr int LDLM_DOUBLES = 2 * 16 * LDLM_UP + 16 * 16 * LDLM_LP + 15 * 16 * LDLM_LP + 16 * LDLM_LP + 3 * 256;
 
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight (vmcnt(0)), which would put the latency of
+// the loads prefetched for the next chunk in front of this chunk's MFMAs
+#define LDLM_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define LDLM_LD(x) __hip_atomic_load(&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LDLM_ST(x, v) __hip_atomic_store(&x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LDLM_PIN17(w, v) asm volatile("" : "+v"(w), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), \
@@ -84,8 +87,8 @@ __device__ __forceinline__ double ldlm_row_sum16(double v)
 }
 
 // lead > 0 (round 5: systems beyond 255 unknowns, ldl_solve_mfma_lead below): A is the TRAILING block of a larger system Afull whose `lead` leading columns
-// are factorised already (ldl_leading_panels: U = L' D unscaled in Afull's lower triangle, 1 / d in inv_lead); the tiles take the leading columns'
-// updates right after the load -- chunks of 16 leading columns staged by the whole workgroup in the layout of a panel's published rows, four MFMAs per
+// are factorised already (ldl_leading_mfma: U = L' D unscaled in Afull's lower triangle, 1 / d in inv_lead); the tiles take the leading columns'
+// updates right after the load -- chunks of 32 leading columns staged by the whole workgroup in the layout of a panel's published rows, eight MFMAs per
 // tile and chunk (the trailing update of the panel loop, applied to every tile).
 __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ A, int np, int n, double* x_out, double* lds,
                                                      int lead = 0, const double* __restrict__ Afull = nullptr, const double* inv_lead = nullptr)
@@ -115,29 +118,47 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 	// The factor wave and the tile waves run separate code from here on (the same barriers in both): the tiles' 160 registers are not live in
 	// the factor wave's code, nor its 16 x 16 block in theirs.
 	double* contrib = Ut2;                                 // back-substitution: [J][I][16]
-	// a chunk of 16 leading columns, rows lead .. lead + n (the border row last) of Afull, as published rows: Ut2[q][row] (rows beyond: zero)
-	const int n_chunks = lead > 0 ? (lead + 15) >> 4 : 0;
-	auto stage_chunk = [&](int p0) {
-		const int cnt = (n + 1) * 16;
-		for (int e0 = 0; e0 < cnt; e0 += 4 * NT) {
-			double v[4];
+	// chunks of 32 leading columns, rows lead .. lead + n (the border row last) of Afull, staged like a panel's published rows: Sc[column][row] (rows beyond:
+	// zero -- the identity padding takes no update), pitch = 17 (mod 32): conflict-free transposing writes and operand reads.  The next chunk's loads are in
+	// flight under this one's MFMAs.  (32 x 273 doubles: over Ut2 into Li, which the factorisation has not touched yet.)
+	constexpr int CUP = 273;
+	const int n_chunks = lead > 0 ? (lead + 31) >> 5 : 0;
+	const int cntc = (16 * T) << 5;
+	double* Sc = lds;
+	double cv[16];
+	auto fetch_chunk = [&](int p0) {            // (thread: column tid % 32, rows tid / 32 + 16 j: a uniform row base per load, one offset register per thread)
+		int tq = tid;
+		asm volatile("" : "+v"(tq));                       // (the offsets are derived at every use: hoisted out of the chunk loop they spill)
+		const int col = min(p0 + (tq & 31), lead - 1), rq = tq >> 5;
 #pragma unroll
-			for (int j = 0; j < 4; ++j) { const int e = min(e0 + tid + NT * j, cnt - 1), r = e >> 4, q = e & 15; v[j] = Afull[(size_t)(lead + r) * np + min(p0 + q, lead - 1)]; }
-#pragma unroll
-			for (int j = 0; j < 4; ++j) { const int e = e0 + tid + NT * j, r = e >> 4, q = e & 15; if (e < cnt) Ut2[q * LDLM_UP + r] = p0 + q < lead ? v[j] : 0.0; }
+		for (int j = 0; j < 16; ++j) {
+			if (NT * j < cntc) {
+				const int rj = 16 * j, rb = min(rj, max(n - 15, 0));
+				const double* base = Afull + (size_t)(lead + rb) * np;
+				cv[j] = base[(min(rq + rj, n) - rb) * np + col];
+			}
 		}
 	};
-	if (n_chunks > 0) {
-		for (int e = tid; e < 16 * LDLM_UP; e += NT) Ut2[e] = 0.0;      // (rows beyond the border row stay zero: the identity padding takes no update)
-		__syncthreads();
-	}
+	auto commit_chunk = [&](int p0) {
+		int tq = tid;
+		asm volatile("" : "+v"(tq));
+		const int kk = tq & 31, rq = tq >> 5;
+		double* Sk = Sc + kk * CUP;
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			if (NT * j < cntc) { const int r = rq + 16 * j; Sk[r] = r <= n && p0 + kk < lead ? cv[j] : 0.0; }
+		}
+	};
+	if (n_chunks > 0) fetch_chunk(0);
 	if (!tiles) {
 		// ================= the factor wave =================
 		for (int ch = 0; ch < n_chunks; ++ch) {            // (the leading columns' chunks: this wave stages its share; the tile waves apply them)
-			stage_chunk(16 * ch);
-			__syncthreads();
-			__syncthreads();
+			LDLM_BARRIER_LDS();
+			commit_chunk(32 * ch);
+			if (ch + 1 < n_chunks) fetch_chunk(32 * (ch + 1));
+			LDLM_BARRIER_LDS();
 		}
+		if (n_chunks > 0) __syncthreads();                 // (the last chunk's reads are done: Li is the factorisation's from here on)
 		bool bad = false;
 		for (int k = 0; k < T && !bad; ++k) {
 			double* Lik = Li + k * 16 * LDLM_LP;
@@ -279,26 +300,38 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 			}
 		}
 		for (int ch = 0; ch < n_chunks; ++ch) {
-			stage_chunk(16 * ch);
-			__syncthreads();
-			double nd[4];
+			LDLM_BARRIER_LDS();
+			commit_chunk(32 * ch);
+			if (ch + 1 < n_chunks) fetch_chunk(32 * (ch + 1));
+			LDLM_BARRIER_LDS();
+#pragma unroll 1
+			for (int h = 0; h < 32; h += 16) {
+				double nd[4];
 #pragma unroll
-			for (int q = 0; q < 4; ++q) { const int c = 16 * ch + 4 * q + lr; nd[q] = c < lead ? -inv_lead[c] : 0.0; }
+				for (int q = 0; q < 4; ++q) { const int c = 32 * ch + h + 4 * q + lr; nd[q] = c < lead ? -inv_lead[min(c, lead - 1)] : 0.0; }
+				// two slots at a time, branch-free (an empty slot -- T | T << 8 -- works on its zero tile with clamped operands): all sixteen operands are
+				// read first, the two tiles' MFMA chains alternate
 #pragma unroll
-			for (int s = 0; s < LDLM_TS; ++s) {
-				int st = sT[s];
-				asm volatile("" : "+s"(st));
-				if ((st & 0xFF) < T) {                         // (an empty slot: T | T << 8)
-					const int cj = 16 * (st & 0xFF), ci = 16 * (st >> 8);
-					double a[4], b[4];
+				for (int s = 0; s < LDLM_TS; s += 2) {
+					int st0 = sT[s], st1 = sT[s + 1];
+					asm volatile("" : "+s"(st0), "+s"(st1));
+					const int cj0 = 16 * min(st0 & 0xFF, T - 1), ci0 = 16 * min(st0 >> 8, T - 1), cj1 = 16 * min(st1 & 0xFF, T - 1), ci1 = 16 * min(st1 >> 8, T - 1);
+					double a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
-					for (int q = 0; q < 4; ++q) { a[q] = Ut2[(4 * q + lr) * LDLM_UP + cj + lc] * nd[q]; b[q] = Ut2[(4 * q + lr) * LDLM_UP + ci + lc]; }
+					for (int q = 0; q < 4; ++q) {
+						const double* row = Sc + (h + 4 * q + lr) * CUP + lc;
+						a0[q] = row[cj0] * nd[q]; b0[q] = row[ci0];
+						a1[q] = row[cj1] * nd[q]; b1[q] = row[ci1];
+					}
 #pragma unroll
-					for (int q = 0; q < 4; ++q) t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], t[s], 0, 0, 0);
+					for (int q = 0; q < 4; ++q) {
+						t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], t[s], 0, 0, 0);
+						t[s + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], t[s + 1], 0, 0, 0);
+					}
 				}
 			}
-			__syncthreads();
 		}
+		if (n_chunks > 0) __syncthreads();                 // (Li and the published rows' buffers are the factorisation's from here on)
 		if (wave == 0) {                                   // the first diagonal tile to the factor wave
 #pragma unroll
 			for (int r = 0; r < 4; ++r) dgs[(4 * r + lr) * LDLM_LP + lc] = t[0][r];
@@ -466,26 +499,295 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 	return true;
 }
 
+// The LEADING columns of a system beyond 255 unknowns on the matrix cores (round 5, second step: ldl_leading_panels -- block columns through LDS on the
+// vector ALUs -- cost 3 us per column, 2/3 of a 372-unknown solve).  Left-looking by panels of 16 columns: the panel's rows c0 .. n (the border row last)
+// as accumulator tiles of the same transposed layout as above, tile i (rows c0 + 16 i ..) in slot i / 7 of tile wave i % 7; every EARLIER panel's rows
+// of these columns and of the tiles' rows come from the system in L2 into LDS (the whole workgroup, the next panel's loads in flight under this one's
+// MFMAs) and update every tile with four MFMAs; the factor wave factorises the diagonal tile (the chain of ldl_solve_mfma_tiles) and publishes L'^-1;
+// the other tiles take U^T = L'^-1 A^T (four MFMAs) and go back to the system's lower triangle with the pivots' reciprocals in inv -- what
+// ldl_solve_mfma_tiles' leading chunks and ldl_backsub_leading read.  n1: a multiple of 16.  Returns 0, or 1 for a non-positive pivot.
+#ifdef LDL_LEAD_STAMPS
+// diagnostics (tools/ldl_bench.hip -DLDL_LEAD_STAMPS): clock sums of thread 0 -- 0 tile load, 1 earlier panels' updates, 2 diagonal tile (factor wave), 3 TRSM + stores; 4 leading total, 5 trailing solve, 6 leading back-substitution
+__device__ unsigned long long g_lead_t[16];   // (8 .. 11: inside a chunk step -- wait at the first barrier, commit + next fetch issued, wait at the second barrier, MFMAs)
+#define LDLL_T0() unsigned long long ll_t_ = __builtin_amdgcn_s_memtime()
+#define LDLL_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_lead_t[i] += t_ - ll_t_; ll_t_ = t_; } while (0)
+#else
+#define LDLL_T0() do {} while (0)
+#define LDLL_T(i) do {} while (0)
+#endif
+constexpr int LDLL_TS = 7;              // tile slots of a wave: ceil(49 / 7) -- 769 rows
+constexpr int LDLL_SCAP = LDLM_DOUBLES - 2 * 16 * LDLM_LP;      // the staged rows' share of the solver's LDS
+// pitch of staged rows, = 17 (mod 32) doubles: the transposing writes (a lane per column) and the MFMA operand reads (lane l: row 4 q + l / 16,
+// column c + l % 16) both spread over the banks
+__device__ __forceinline__ int ldll_pitch(int rows) { return rows <= 17 ? 17 : (((rows - 17 + 31) >> 5) << 5) + 17; }
+__device__ __forceinline__ int ldl_leading_mfma(double* __restrict__ A, int np, int n, int n1, double* inv, double* lds)
+{
+	static_assert(NT == 512, "ldl_leading_mfma: 8 wavefronts");
+	const int tid = threadIdx.x, lane = tid & 63, lc = lane & 15, lr = lane >> 4;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	__shared__ int s_lbad;
+	double* Lik = lds;                                 // L'^-1 of the panel's diagonal tile
+	double* dgs = Lik + 16 * LDLM_LP;                  // the diagonal tile on its way to the factor wave
+	double* S = dgs + 16 * LDLM_LP;                    // [16 or 32][pitch]: earlier columns of rows c0 ..
+	if (tid == 0) s_lbad = 0;
+	// the panel's tiles (the system's upper triangle holds the same values along rows: coalesced; the border is stored as a row only).  Every load is
+	// unconditional, from a clamped address, and the masks come afterwards: behind per-slot conditions the compiler waited for every pair of loads before
+	// the next (measured: 6.6 us per panel for 28 loads)
+	auto load_tiles = [&](ldlm_v4d* tt, int c0) {
+		const int Tn = (n + 1 - c0 + 15) >> 4;
+		if (wave < LDLM_TW) {
+#pragma unroll
+			for (int s = 0; s < LDLL_TS; ++s) {
+				const int i = min(LDLM_TW * s + wave, Tn - 1);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int a = c0 + 4 * r + lr, b = c0 + 16 * i + lc;         // element (row b, column a)
+					tt[s][r] = A[b >= n ? (size_t)n * np + a : (size_t)a * np + b];
+				}
+			}
+#pragma unroll
+			for (int s = 0; s < LDLL_TS; ++s) {
+				const int i = LDLM_TW * s + wave;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) tt[s][r] = i < Tn && c0 + 16 * i + lc <= n ? tt[s][r] : 0.0;
+			}
+		}
+	};
+	for (int c0 = 0; c0 < n1; c0 += 16) {
+		const int R = n + 1 - c0, Tn = (R + 15) >> 4, UP = ldll_pitch(16 * Tn);
+		LDLL_T0();
+		ldlm_v4d t[LDLL_TS];
+		load_tiles(t, c0);                             // (in flight beside the first chunk's loads)
+		LDLL_T(0);
+		// ---- the earlier panels' updates: W = 32 earlier columns at a time where 32 staged columns fit, 16 otherwise (W a constant in either body).
+		//      Thread: column tid % W, rows tid / W + j NT / W -- one offset register per thread and a uniform row base per load (full addresses: 34 x 2
+		//      registers beside the tiles, or their arithmetic at every load: measured 3 us of instruction issue per chunk).  Nothing is zeroed: the
+		//      padding rows of the last tile row hold copies of the border row (they only reach dead rows of the tiles), and a last chunk with 16 columns
+		//      runs one 16-column group ----
+		auto run_updates = [&](auto sh_c) {
+			constexpr int SH = decltype(sh_c)::value, W = 1 << SH, RSTEP = NT >> SH, NV = SH == 5 ? 36 : 28;      // (33 / 25 loads in groups of four)
+			const int rows_ = 16 * Tn, R_ = R;
+			double v[NV];
+			// a load = one offset add + one load from a uniform base (two instructions; the conditions are per group of four loads: per load, with
+			// the row base's 64-bit arithmetic on the scalar unit, a fetch was 660 instructions a wave -- the chunk step is issue bound)
+			auto fetch = [&](int q0) {
+				int tq = tid;
+				asm volatile("" : "+v"(tq));               // (derived at every use: hoisted out of the chunk loop the offsets spill)
+				const int rq = tq >> SH, col = min(q0 + (tq & (W - 1)), c0 - 1);
+				int rows = rows_, R = R_;
+				asm volatile("" : "+s"(rows), "+s"(R));    // (the uniform conditions are compared at every use: hoisted, their masks spill the SGPRs)
+				const char* base = reinterpret_cast<const char*>(A + (size_t)c0 * np);
+				unsigned off = (unsigned)(rq * np + col) * 8u;
+				const unsigned step = (unsigned)(RSTEP * np) * 8u, off_last = (unsigned)((R - 1) * np + col) * 8u;
+#pragma unroll
+				for (int g = 0; g < NV; g += 4) {
+					if (RSTEP * g < rows) {
+						if (RSTEP * (g + 4) <= R) {
+#pragma unroll
+							for (int u = 0; u < 4; ++u) { v[g + u] = *reinterpret_cast<const double*>(base + off); off += step; }
+						} else {                           // (the border row's neighbourhood: clamped)
+#pragma unroll
+							for (int u = 0; u < 4; ++u) { v[g + u] = *reinterpret_cast<const double*>(base + (rq + RSTEP * (g + u) < R ? off : off_last)); off += step; }
+						}
+					}
+				}
+			};
+			// (the previous panel's columns went to the system by global stores: a chunk that holds them is fetched behind a barrier that waits for
+			// them -- the first barrier of a chunk step does: the loads it waits for are the ones the commit behind it needs anyway)
+			if (c0 <= W) __syncthreads();
+			fetch(0);
+			for (int q0 = 0; q0 < c0; q0 += W) {
+#ifdef LDL_LEAD_STAMPS
+				unsigned long long lc_t_ = __builtin_amdgcn_s_memtime();
+#define LDLL_C(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_lead_t[i] += t_ - lc_t_; lc_t_ = t_; } while (0)
+#else
+#define LDLL_C(i) do {} while (0)
+#endif
+				__syncthreads();                           // (the previous chunk's reads are done; global stores and loads complete)
+				LDLL_C(8);
+				{
+					int tq = tid;
+					asm volatile("" : "+v"(tq));
+					const int rq = tq >> SH;
+					double* Sk = S + (tq & (W - 1)) * UP + rq;
+					int rows = rows_;
+					asm volatile("" : "+s"(rows));
+#pragma unroll
+					for (int g = 0; g < NV; g += 4) {
+						if (RSTEP * g < rows) {
+							if (RSTEP * (g + 4) <= rows) {
+#pragma unroll
+								for (int u = 0; u < 4; ++u) Sk[RSTEP * (g + u)] = v[g + u];
+							} else {
+#pragma unroll
+								for (int u = 0; u < 4; ++u) if (rq + RSTEP * (g + u) < rows) Sk[RSTEP * (g + u)] = v[g + u];
+							}
+						}
+					}
+				}
+				if (q0 + W < c0) fetch(q0 + W);
+				LDLL_C(9);
+				LDLM_BARRIER_LDS();
+				LDLL_C(10);
+				if (wave < LDLM_TW) {
+					// the slots in use are the same number for every wave (a wave's last one may be beyond the panel: it works on a dead tile): branch-free
+					// bodies, one per count -- all operands of a 16-column group are read first, the MFMAs of the slots alternate (behind a scalar branch
+					// per slot the compiler issued read, wait, MFMA one by one: 160 cycles per MFMA)
+					const int hmax = min(W, c0 - q0);
+					int lro = lr, lco = lc;
+					asm volatile("" : "+v"(lro), "+v"(lco));   // (the operand addresses are derived in every chunk step: hoisted they spill, and a reload from
+					                                          //  scratch waits for every prefetched load in flight -- vmcnt counts both)
+					ldlm_dispatch<1, LDLL_TS>((Tn + LDLM_TW - 1) / LDLM_TW, [&](auto ns_c) {
+						constexpr int NS = decltype(ns_c)::value;
+						// (a dead tile's operand rows lie up to 96 doubles beyond the staged ones: inside the solver's LDS, their values reach nothing --
+						// one address per 4-column step, the slots at constant offsets: clamped, 28 addresses per body were hoisted and spilled)
+						auto group16 = [&](int h) {
+							double a[4], b[NS][4];
+#pragma unroll
+							for (int k4 = 0; k4 < 4; ++k4) {
+								const double* Sr = S + (h + 4 * k4 + lro) * UP + lco;
+								a[k4] = Sr[0] * -inv[q0 + h + 4 * k4 + lro];
+#pragma unroll
+								for (int s = 0; s < NS; ++s) b[s][k4] = Sr[16 * wave + 16 * LDLM_TW * s];
+							}
+#pragma unroll
+							for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+								for (int s = 0; s < NS; ++s) t[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k4], b[s][k4], t[s], 0, 0, 0);
+							}
+						};
+						// (one block for both groups of a full chunk where the operands fit: the second group's reads go under the first one's MFMAs)
+						if (NS <= 4 && hmax == 32) { group16(0); group16(16); }
+						else {
+#pragma unroll 1
+							for (int h = 0; h < hmax; h += 16) group16(h);
+						}
+					});
+				}
+				LDLL_C(11);
+			}
+		};
+		if (c0 > 0) {
+			if (32 * UP <= LDLL_SCAP) run_updates(std::integral_constant<int, 5>{});
+			else run_updates(std::integral_constant<int, 4>{});
+		}
+		LDLL_T(1);
+		// ---- the diagonal tile to the factor wave ----
+		if (wave == 0) {
+#pragma unroll
+			for (int r = 0; r < 4; ++r) dgs[(4 * r + lr) * LDLM_LP + lc] = t[0][r];
+		}
+		__syncthreads();
+		if (wave == LDLM_TW) {
+			// lanes 0 .. 15: row lc of the tile; lanes 16 .. 31: column lc of L'^-1 (ldl_solve_mfma_tiles' chain; every column is an unknown here)
+			const bool inv_lane = (lane & 48) == 16;
+			bool bad = false;
+			double w[16];
+#pragma unroll
+			for (int j = 0; j < 16; ++j) { const double xv = dgs[j * LDLM_LP + lc]; w[j] = inv_lane ? (j == lc ? 1.0 : 0.0) : xv; }
+			double d = readlane_f64(w[0], 0);
+			bad |= !(d > 0.0);
+			double ivj = rcp_f64(d);
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				const double f = w[j] * ivj;
+				if (lane == 0) inv[c0 + j] = ivj;
+				double iv_next = 0.0;
+#define LDLL_GROUP(g) \
+				_Pragma("unroll") for (int c = j + 2 + 3 * (g); c < 16 && (c < j + 5 + 3 * (g) || (g) == 4); ++c) { const double lcj = readlane_f64(f, c); w[c] -= w[j] * lcj; }
+				if (j + 1 < 16) {
+					const double l1 = readlane_f64(f, j + 1);
+					w[j + 1] -= w[j] * l1;
+					d = readlane_f64(w[j + 1], j + 1);
+					bad |= !(d > 0.0);
+					double r = __builtin_amdgcn_rcp(d);
+					LDLL_GROUP(0); LDLM_PIN17(r, w);
+					double e = fma(-d, r, 1.0);
+					LDLL_GROUP(1); LDLM_PIN17(e, w);
+					r = fma(e, r, r);
+					LDLL_GROUP(2); LDLM_PIN17(r, w);
+					e = fma(-d, r, 1.0);
+					LDLL_GROUP(3); LDLM_PIN17(e, w);
+					r = fma(e, r, r);
+					LDLL_GROUP(4); LDLM_PIN17(r, w);
+					iv_next = r;
+				}
+#undef LDLL_GROUP
+				ivj = iv_next;
+			}
+			if (inv_lane) {
+#pragma unroll
+				for (int i = 0; i < 16; ++i) Lik[i * LDLM_LP + lc] = w[i];
+			}
+			if (lane < 16) {                               // the diagonal tile's U (pivots on the diagonal) back to the lower triangle
+#pragma unroll
+				for (int j = 0; j < 16; ++j) if (j <= lane) A[(size_t)(c0 + lane) * np + c0 + j] = w[j];
+			}
+			if (bad && lane == 0) s_lbad = 1;
+		}
+		__syncthreads();
+		if (s_lbad) return 1;                              // uniform
+		LDLL_T(2);
+		if (wave < LDLM_TW) {
+			double la[4];
+#pragma unroll
+			for (int k4 = 0; k4 < 4; ++k4) la[k4] = Lik[lc * LDLM_LP + 4 * k4 + lr];
+#pragma unroll
+			for (int s = 0; s < LDLL_TS; ++s) {
+				const int i = LDLM_TW * s + wave;
+				if (i >= 1 && i < Tn) {
+					ldlm_v4d c4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+					for (int k4 = 0; k4 < 4; ++k4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[k4], t[s][k4], c4, 0, 0, 0);
+					const int b = c0 + 16 * i + lc;
+					if (b <= n) {
+#pragma unroll
+						for (int r = 0; r < 4; ++r) A[(size_t)b * np + c0 + 4 * r + lr] = c4[r];
+					}
+				}
+			}
+		}
+		LDLL_T(3);
+	}
+	__syncthreads();
+	return 0;
+}
+
 // Systems beyond 255 unknowns (round 5: the local areas the facade's own stream grows -- 61 optimised edges = 366 unknowns in the bench's 401-frame pass,
-// up to 94 at KITTI-00 length -- ran the register-tile solver): the leading n - 252 columns by ldl_leading_panels (left-looking block columns through LDS, U and 1 / d to the system in L2),
-// the trailing 252 x 252 block on the matrix cores (its tiles take the leading columns' updates as MFMAs right after the load), the leading
+// up to 94 at KITTI-00 length -- ran the register-tile solver): the leading 16 ceil((n - 255) / 16) columns by ldl_leading_mfma above (U and 1 / d to the
+// system in L2), the trailing 240 .. 255 unknowns by the tile solver (its tiles take the leading columns' updates as MFMAs right after the load), the leading
 // unknowns by ldl_backsub_leading.  Same factorisation, the update terms of an element in column order.  A is overwritten (as by ldl_solve_regtile).
+// Measured (tools/ldl_bench.hip, net of the restore copy): 396 unknowns 380 us (ldl_leading_panels for the leading columns: 551; register tiles: 600),
+// 564: 998 (1 735), 768: 2 320 (4 690).
 constexpr int LDLM_LEAD_NMAX = 768;     // 128 optimised edges: every window the node builder takes (the full-length stream's local areas: median 38 edges,
                                         // 90th percentile 68, largest 94 -- profiles/r05_stream_stage2_windows.json)
 __device__ __forceinline__ bool ldl_solve_mfma_lead(double* __restrict__ A, int np, int n, double* x_out, double* inv, double* lds, int lds_doubles)
 {
 	const int tid = threadIdx.x;
+#ifndef SSK_K2_LEAD_MFMA
+#define SSK_K2_LEAD_MFMA 1               // 1: the leading columns on the matrix cores (ldl_leading_mfma), 0: ldl_leading_panels (same-box A/B: tools/ldl_bench.hip)
+#endif
+	LDLL_T0();
+#if SSK_K2_LEAD_MFMA
+	const int n1 = n <= LDLM_NMAX ? 0 : 16 * ((n - LDLM_NMAX + 15) >> 4), m = n - n1;      // (240 .. 255 trailing unknowns)
+	if (n1 > 0 && ldl_leading_mfma(A, np, n, n1, inv, lds) != 0) return false;
+#else
 	const int m = n <= LDLM_NMAX ? n : 252, n1 = n - m;
 	if (n1 > 0) {
 		const int lead = ldl_leading_panels<12>(A, np, n, n1, inv, lds, lds_doubles);
 		if (lead == 1) return false;
 		if (lead == 2) return SSK_LDL_BIG(A, np, n, x_out, inv, lds, lds_doubles);      // (a block column does not fit the staging: not at these sizes)
 	}
+#endif
+	LDLL_T(4);
 	if (!ldl_solve_mfma_tiles(A + (size_t)n1 * np + n1, np, m, x_out + n1, lds, n1, A, inv)) return false;
+	LDLL_T(5);
 	if (n1 > 0) {
 		for (int k = tid; k < n1; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
 		__syncthreads();
-		return ldl_backsub_leading(A, np, n, n1, x_out, inv, lds, lds_doubles);
+		const bool ok_ = ldl_backsub_leading(A, np, n, n1, x_out, inv, lds, lds_doubles);
+		LDLL_T(6);
+		return ok_;
 	}
 	return true;
 }

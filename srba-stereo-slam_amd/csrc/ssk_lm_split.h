@@ -51,13 +51,13 @@ struct sp_dev {
 	const int* win_map;                 // K2 / K4: workgroup -> window or -1, the same XCD as its tiles
 	int n_tile_wgs, n_win_wgs;
 	int max_pairs;                      // most 6x6 blocks of a window's reduced system (K2a's grid)
-	int solve_mfma;                     // K2: 1 = ldl_solve_mfma_tiles for every window of the batch, 0 = ldl_solve_regtile (the host's choice: ssk_sp_solve_mfma + the LDS budget)
+	int solve_mfma;                     // K2: 2 = ldl_solve_mfma_tiles for every window of the batch, 1 = ldl_solve_mfma_lead (a window beyond 255 unknowns), 0 = ldl_solve_regtile (the host's choice: ssk_sp_solve_mfma + the LDS budget)
 };
 
 constexpr int SSK_SP_WAVES = 4;         // wavefronts per K1 / K3 workgroup = landmark groups per tile
 // K2: the solver of a batch whose largest window optimises E_max edges: true = ldl_solve_mfma_tiles (ssk_lm_ldl_mfma.h: the system in MFMA
 // accumulator tiles, up to 255 unknowns; SSK_K2_SOLVER=regtile: never), false = ldl_solve_regtile
-bool ssk_sp_solve_mfma(int E_max, bool force_regtile /* SSK_K2_SOLVER=regtile */);
+int ssk_sp_solve_mfma(int E_max, bool force_regtile /* SSK_K2_SOLVER=regtile */);      // 0 register tiles, 1 matrix cores incl. leading columns, 2 matrix cores, every window within 255 unknowns
 // K2: dynamic LDS of the solve kernel (doubles): the solver's staging + the window's edge poses and trie records
 size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma);
 

@@ -47,9 +47,10 @@ __device__ __forceinline__ double slot_sum(const double* __restrict__ p, int a, 
 	return s;
 }
 
-// MFMA: every window of the batch has at most LDLM_LEAD_NMAX unknowns (the host's choice: the solvers live in two instances of the kernel, each with its own
-// register budget)
-template <bool MFMA>
+// MODE (the host's choice, sp_dev::solve_mfma: the solvers live in three instances of the kernel, each with its own register budget):
+// 0 the register-tile solver; 1 matrix cores, windows up to LDLM_LEAD_NMAX unknowns (leading columns + the tile solver); 2 matrix cores, every window
+// of the batch within the tile solver's 255 unknowns (the leading columns' code beside it cost the tile solver 12 us a pass in registers: depth-5 A/B)
+template <int MODE>
 __global__ __launch_bounds__(NT, SSK_LM_WAVES)
 void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubles)
 {
@@ -89,7 +90,8 @@ void lm_split_solve_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P, int dyn_doubl
 	double* A = D.Hred + W.h0;
 	bool ok = true;
 	if (n6 > 0) {
-		if constexpr (MFMA) ok = ldl_solve_mfma_lead(A, np, n6, s_b, s_inv, lds, lds_doubles);
+		if constexpr (MODE == 1) ok = ldl_solve_mfma_lead(A, np, n6, s_b, s_inv, lds, lds_doubles);
+		else if constexpr (MODE == 2) ok = ldl_solve_mfma_tiles(A, np, n6, s_b, lds);
 		else ok = SSK_LDL_BIG(A, np, n6, s_b, s_inv, lds, lds_doubles);
 	}
 	__syncthreads();
@@ -140,9 +142,10 @@ extern "C" int ssk_lm_k2_stamps(unsigned long long* out16, int reset)
 }
 #endif
 
-bool ssk_sp_solve_mfma(int E_max, bool force_regtile)
+int ssk_sp_solve_mfma(int E_max, bool force_regtile)
 {
-	return SSK_K2_MFMA && !force_regtile && 6 * E_max <= LDLM_LEAD_NMAX;
+	if (!SSK_K2_MFMA || force_regtile || 6 * E_max > LDLM_LEAD_NMAX) return 0;
+	return 6 * E_max <= LDLM_NMAX ? 2 : 1;
 }
 
 size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma)
@@ -156,14 +159,17 @@ int ssk_lm_launch_split_solve(ssk_ctx* ctx, const lm_dev& D, const nd_dev& N, co
 {
 	static ssk_dev_once attr_once;      // (the attribute is per device)
 	if (attr_once.need(ctx->device)) {
-		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		SSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(lm_split_solve_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
 		attr_once.done(ctx->device);
 	}
 	dyn_bytes = (dyn_bytes + 15) & ~(size_t)15;
-	if (S.solve_mfma)
-		hipLaunchKernelGGL(lm_split_solve_kernel<true>, dim3((unsigned)S.n_win_wgs), dim3(NT), dyn_bytes, ctx->stream, D, N, S, P, (int)(dyn_bytes / 8));
+	if (S.solve_mfma == 2)
+		hipLaunchKernelGGL(lm_split_solve_kernel<2>, dim3((unsigned)S.n_win_wgs), dim3(NT), dyn_bytes, ctx->stream, D, N, S, P, (int)(dyn_bytes / 8));
+	else if (S.solve_mfma == 1)
+		hipLaunchKernelGGL(lm_split_solve_kernel<1>, dim3((unsigned)S.n_win_wgs), dim3(NT), dyn_bytes, ctx->stream, D, N, S, P, (int)(dyn_bytes / 8));
 	else
-		hipLaunchKernelGGL(lm_split_solve_kernel<false>, dim3((unsigned)S.n_win_wgs), dim3(NT), dyn_bytes, ctx->stream, D, N, S, P, (int)(dyn_bytes / 8));
+		hipLaunchKernelGGL(lm_split_solve_kernel<0>, dim3((unsigned)S.n_win_wgs), dim3(NT), dyn_bytes, ctx->stream, D, N, S, P, (int)(dyn_bytes / 8));
 	return SSK_OK;
 }

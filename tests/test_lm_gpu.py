@@ -549,16 +549,18 @@ def test_lm_split_bench_window_and_empty(ctx, oracle, monkeypatch):
 def test_lm_split_dense_solver_sizes(ctx, oracle, n_kf):
     """the default path of windows beyond LDS at the sizes where the dense solvers' paths change: 6E = 138 (nine tile rows of the MFMA-tile solver,
     the border row inside the last), 222 (border row 14 of the last tile row), 240 (border row = a tile row of its own), 252 (the largest system
-    held WHOLE in accumulator tiles); round 5: 264, 330, 348, 372, 396 ON THE MATRIX-CORE PATH too (ldl_solve_mfma_lead: 12 .. 144 leading columns by
-    block columns through LDS, their updates applied to the trailing 252 x 252 tiles as MFMAs) -- the local areas the facade's own stream grows
-    reach 61 edges (94 at KITTI-00 length); 540: 288 leading columns"""
+    held WHOLE in accumulator tiles); round 5: 264, 330, 348, 372, 396 ON THE MATRIX-CORE PATH too (ldl_solve_mfma_lead: 16 .. 144 leading columns by
+    16-column panels of accumulator tiles -- ldl_leading_mfma --, their updates applied to the trailing tiles as MFMAs) -- the local areas the
+    facade's own stream grows reach 61 edges (94 at KITTI-00 length); 540: 288 leading columns, 32 staged columns to a chunk step"""
     win, gt = sl.make_submap_problem(21 if n_kf < 91 else 23, n_kf=n_kf, n_lm=(20 * n_kf if n_kf < 91 else 1500), submap_size=3, max_tree_depth=6,
                                      opt_depth=n_kf, obs_per_kf=60 if n_kf < 91 else 40)
     assert win.E == n_kf - 1
     from ssk_amd import capi
     b = capi.LmBatch(ctx, [win])
     assert b.kernel_name() == "lm_split_linearise_kernel"
-    assert b.solver_name() == "ldl_solve_mfma_lead"                # (every window the node builder takes: the trailing 252 x 252 block on the matrix cores)
+    # (every window the node builder takes is solved on the matrix cores: within 255 unknowns the tile solver alone -- its own instance of K2 --,
+    # beyond them the leading columns first)
+    assert b.solver_name() == ("ldl_solve_mfma_tiles" if 6 * win.E <= 255 else "ldl_solve_mfma_lead")
     b.close()
     check_against_oracle(ctx, oracle, win, sl.make_params(max_iters=8 if n_kf < 91 else 5))
 

@@ -3,6 +3,9 @@
 // checked against a host solve.  Build (cross-compiles without a GPU):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I include -I srba-stereo-slam_amd/csrc tools/ldl_bench.hip -o _ab/ldl_bench [-DLDLM_...]
 // Run on the GPU box: _ab/ldl_bench [n = 240] [reps = 200] [workgroups = 1] [index of a diagonal entry to make negative: the failure path]
+// Beyond 255 unknowns it also times the leading panels alone (ldl_leading_mfma in a kernel of its own) and the restore copy of the system that every
+// timed solve includes; -DLDL_LEAD_STAMPS: clock sums of the leading panels' phases and of a chunk step; -DSSK_K2_LEAD_MFMA=0: the leading columns by
+// ldl_leading_panels (the first step of round 5).
 #include "ssk_lm_split.h"
 #include <cstdio>
 #include <cstdlib>
@@ -47,6 +50,26 @@ void bench_kernel(const double* A0, double* Awork, int np, int n, double* x, int
 		for (int i = threadIdx.x; i < n; i += NT) x[i] = s_b[i];
 		if (threadIdx.x == 0) *ok_out = ok ? 1 : 0;
 	}
+}
+// the leading panels alone (ldl_leading_mfma in a kernel of its own: its registers without the tile solver's beside them)
+__global__ __launch_bounds__(NT, SSK_LM_WAVES)
+void bench_lead_kernel(const double* A0, double* Awork, int np, int n, int reps, int* ok_out, int copy_only)
+{
+	const size_t words = (size_t)(n + 1) * np;
+	double* A = Awork + blockIdx.x * words;
+	extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+	const int n6p = (n + 1) & ~1;
+	double* s_inv = s_dyn + n6p;
+	double* lds = s_inv + n6p;
+	const int n1 = n <= LDLM_NMAX ? 0 : 16 * ((n - LDLM_NMAX + 15) >> 4);
+	int bad = 0;
+	for (int r = 0; r < reps; ++r) {
+		for (size_t i = threadIdx.x; i < words; i += NT) A[i] = A0[i];
+		__syncthreads();
+		if (!copy_only) bad |= ldl_leading_mfma(A, np, n, n1, s_inv, lds);
+		__syncthreads();
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) *ok_out = !bad;
 }
 // the one-wavefront solvers of the persistent node kernel (E <= 10): input = 6 x 6 block accumulators + reduced gradient in LDS; WHICH 2: matrix cores
 // (ldl_solve_mfma_wave), 3: a block per lane on the vector ALUs (ldl_solve_blocks6_wave)
@@ -132,6 +155,28 @@ int main(int argc, char** argv)
 		for (int i = 0; i < n; ++i) { err = std::fmax(err, std::fabs(x[i] - xr[i])); nrm = std::fmax(nrm, std::fabs(xr[i])); }
 		std::printf("%-22s n %d, %d workgroups x %d solves: %.2f us per solve (per workgroup), ok %d, max |x - x_host| / max |x_host| = %.2e\n",
 		            which ? "ldl_solve_mfma_lead" : "ldl_solve_regtile", n, wgs, reps, 1e3 * best / reps, ok, err / nrm);
+#ifdef LDL_LEAD_STAMPS
+		if (which) {
+			unsigned long long tt[16];
+			CK(hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_lead_t), sizeof tt));
+			// (s_memtime: 100 MHz; four launches of `reps` solves)
+			std::printf("  stamps, us per solve: tile load %.1f, earlier panels' updates %.1f, diagonal tile %.1f, TRSM + stores %.1f | leading %.1f, trailing %.1f, leading back-substitution %.1f\n",
+			            tt[0] / 100.0 / (4 * reps), tt[1] / 100.0 / (4 * reps), tt[2] / 100.0 / (4 * reps), tt[3] / 100.0 / (4 * reps), tt[4] / 100.0 / (4 * reps), tt[5] / 100.0 / (4 * reps), tt[6] / 100.0 / (4 * reps));
+			std::printf("  chunk step: first barrier %.1f, commit + fetch issue %.1f, second barrier %.1f, MFMAs %.1f\n", tt[8] / 100.0 / (4 * reps), tt[9] / 100.0 / (4 * reps), tt[10] / 100.0 / (4 * reps), tt[11] / 100.0 / (4 * reps));
+		}
+#endif
+	}
+	if (n > LDLM_NMAX && n <= LDLM_LEAD_NMAX) {
+		CK(hipFuncSetAttribute(reinterpret_cast<const void*>(bench_lead_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+		float best = 1e30f, best0 = 1e30f;
+		for (int rep = 0; rep < 8; ++rep) {
+			CK(hipEventRecord(e0));
+			hipLaunchKernelGGL(bench_lead_kernel, dim3(wgs), dim3(NT), dyn, 0, dA, dW, np, n, reps, dok, rep & 1);
+			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+			if (rep > 1) { if (rep & 1) best0 = std::fmin(best0, ms); else best = std::fmin(best, ms); }
+		}
+		std::printf("%-22s n %d: %.2f us per pass, of which the restore copy %.2f us; leading columns %d\n", "ldl_leading_mfma alone", n, 1e3 * best / reps, 1e3 * best0 / reps, 16 * ((n - LDLM_NMAX + 15) >> 4));
 	}
 	if (n <= 60 && n % 6 == 0) {
 		// the node kernel's one-wavefront solvers on the same system given as block accumulators (H(6 e + a, 6 e2 + b), e <= e2, at 36 (e2 (e2 + 1) / 2 + e) + 6 a + b)
