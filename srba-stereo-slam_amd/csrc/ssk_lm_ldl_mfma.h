@@ -283,19 +283,23 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 				while (J < T && idx >= base + (T - J)) { base += T - J; ++J; }
 				const int I = J + idx - base;
 				sT[s] = J < T ? (J | I << 8) : (T | T << 8);
-				if (J < T && I < T - 1) {             // an inner tile: every element inside the system
-					const double* At = A + (size_t)(16 * J) * np + 16 * I;
+				// every load unconditional, from a clamped address (an empty slot: tile (0, 0); beyond the border row: the border row), the masks
+				// afterwards: behind a branch per slot (inner tile / last tile row) every load of a last-row tile was followed by a wait for ALL loads
+				// in flight (round 5: the same pattern cost ldl_leading_mfma 6.6 us per panel)
+				const int Jc = J < T ? J : 0, Ic = J < T ? I : 0;
 	#pragma unroll
-					for (int r = 0; r < 4; ++r) t[s][r] = At[(4 * r + lr) * np + lc];
-				} else {                                       // the last tile row (border row, identity padding); an empty slot: zero
-					const bool used = J < T;
+				for (int r = 0; r < 4; ++r) {
+					const int a = min(16 * Jc + 4 * r + lr, n - 1), b = 16 * Ic + lc;      // element (row b, column a) of the system
+					t[s][r] = A[b >= n ? (size_t)n * np + a : (size_t)a * np + b];
+				}
+			}
 	#pragma unroll
-					for (int r = 0; r < 4; ++r) {
-						const int a = 16 * J + 4 * r + lr, b = 16 * I + lc;         // element (row b, column a) of the system
-						const int ac = min(a, n - 1), bc = min(b, n - 1);
-						const double v = A[(size_t)(b == n ? n : ac) * np + (b == n ? ac : bc)];
-						t[s][r] = !used ? 0.0 : (a < n && b <= n) ? v : (a == b ? 1.0 : 0.0);
-					}
+			for (int s = 0; s < LDLM_TS; ++s) {
+				const int J = sT[s] & 0xFF, I = sT[s] >> 8;
+	#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int a = 16 * J + 4 * r + lr, b = 16 * I + lc;
+					t[s][r] = J >= T ? 0.0 : (a < n && b <= n) ? t[s][r] : (a == b ? 1.0 : 0.0);
 				}
 			}
 		}
