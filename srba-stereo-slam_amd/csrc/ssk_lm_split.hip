@@ -187,6 +187,12 @@ void lm_split_linearise_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P)
 			v2d_t* o = reinterpret_cast<v2d_t*>(S.Hpart + 36 * (size_t)(SW.part0 + q.w));
 #pragma unroll
 			for (int i = 0; i < 18; ++i) { v2d_t x; x.x = acc[2 * i]; x.y = acc[2 * i + 1]; o[i] = x; }
+#ifdef SP_K1_STORE2
+			// diagnostics: every partial slot written twice (same address: the request count doubles, the HBM traffic does not)
+			asm volatile("" ::: "memory");
+#pragma unroll
+			for (int i = 0; i < 18; ++i) { v2d_t x; x.x = acc[2 * i]; x.y = acc[2 * i + 1]; __builtin_nontemporal_store(x, o + i); }
+#endif
 		}
 	}
 	SP_T(6);
@@ -247,7 +253,9 @@ void lm_split_reduce_kernel(lm_dev D, nd_dev N, sp_dev S)
 			const int row = 6 * e + a, col = 6 * e2 + bb;
 			if (row == col) v += c.lambda;
 			A[(size_t)row * np + col] = v;
-			A[(size_t)col * np + row] = v;
+			// (the matrix-core solvers read the upper triangle -- rows along a tile's columns -- and the lower one only inside the diagonal 16 x 16
+			// tiles: the mirror element elsewhere is 45 % of this kernel's writes, a column walk of 8-byte stores)
+			if (!S.solve_mfma || (row >> 4) == (col >> 4)) A[(size_t)col * np + row] = v;
 		}
 	}
 	if (blockIdx.y == 0) {
