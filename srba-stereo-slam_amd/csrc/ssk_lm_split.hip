@@ -185,6 +185,8 @@ void lm_split_linearise_kernel(lm_dev D, nd_dev N, sp_dev S, lm_cam P)
 		}
 		if (rank == 0) {
 			v2d_t* o = reinterpret_cast<v2d_t*>(S.Hpart + 36 * (size_t)(SW.part0 + q.w));
+			// (every byte of the slot is written, also the pairs of a diagonal block that K2a does not read: leaving those six 16-byte pairs out made the
+			// depth-5 batch 2.7 % SLOWER -- a line written in part is read from HBM when L2 evicts it, a line written whole is not)
 #pragma unroll
 			for (int i = 0; i < 18; ++i) { v2d_t x; x.x = acc[2 * i]; x.y = acc[2 * i + 1]; o[i] = x; }
 #ifdef SP_K1_STORE2
@@ -244,12 +246,12 @@ void lm_split_reduce_kernel(lm_dev D, nd_dev N, sp_dev S)
 	const int b = tid / 36, ab = tid - 36 * b, pid = (int)blockIdx.y * SP_RB + b;
 	if (b < SP_RB && pid < n_pairs) {
 		const int* poff = S.poff + SW.poff0;
-		double v = sp_slot_sum<36>(S.Hpart + 36 * (size_t)SW.part0, poff[pid], poff[pid + 1], ab);
 		int e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
 		while ((e2 + 1) * (e2 + 2) / 2 <= pid) ++e2;
 		while (e2 * (e2 + 1) / 2 > pid) --e2;
 		const int e = pid - e2 * (e2 + 1) / 2, a = ab / 6, bb = ab - 6 * a;
-		if (!(e == e2 && a > bb)) {
+		if (!(e == e2 && a > bb)) {                        // (below the diagonal of a diagonal block: the mirror of an element above; K1 does not even write all of them)
+			double v = sp_slot_sum<36>(S.Hpart + 36 * (size_t)SW.part0, poff[pid], poff[pid + 1], ab);
 			const int row = 6 * e + a, col = 6 * e2 + bb;
 			if (row == col) v += c.lambda;
 			A[(size_t)row * np + col] = v;
