@@ -952,7 +952,6 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	const bool mfma_fits = ssk_lma_row_tiles(max_E) <= 31;
 	const int schur_mfma = mfma_fits && (schur_env ? (std::strcmp(schur_env, "sparse") != 0) : schur_mfma_default);
 	const char* force_k = ctx->env.lm_kernel.empty() ? nullptr : ctx->env.lm_kernel.c_str();
-	const bool force_acc = force_k && std::strcmp(force_k, "acc") == 0;
 	if (want_acc && windows && n_windows > 0) {            // cheap look ahead: one window with too many optimised edges rules the acc kernel out
 		for (int w = 0; w < n_windows && want_acc; ++w) {
 			int E = 0;
