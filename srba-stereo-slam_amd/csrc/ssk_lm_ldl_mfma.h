@@ -53,8 +53,9 @@ constexpr int LDLM_LP = 17;             // pitch of a 16 x 16 block in LDS
 constexpr int LDLM_NMAX = 255;          // largest system (n + 1 <= 256)
 constexpr int LDLM_DOUBLES = 2 * 16 * LDLM_UP + 16 * 16 * LDLM_LP + 15 * 16 * LDLM_LP + 16 * LDLM_LP + 3 * 256;
 
-// a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight (vmcnt(0)), which would put the latency of
-// the loads prefetched for the next chunk in front of this chunk's MFMAs
+// a workgroup barrier that orders LDS traffic only: what a chunk step needs between its commit and its operand reads (the loads prefetched for the next
+// chunk stay in flight).  Measured no different from __syncthreads(): a workgroup-scope fence does not wait on vmcnt in this execution mode (the CU's
+// vector memory operations complete in order); kept because it states the intent
 #define LDLM_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define LDLM_LD(x) __hip_atomic_load(&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LDLM_ST(x, v) __hip_atomic_store(&x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
