@@ -629,6 +629,35 @@ def test_lm_split_mixed_batch_is_reproducible(ctx, oracle):
     b.close()
 
 
+def test_lm_k2_instance_does_not_change_a_windows_bits(ctx, oracle):
+    """K2 has an instance per batch shape (round 5): the tile solver alone when every window of the batch has at most 255 unknowns, leading columns +
+    tiles as soon as one window is larger.  A depth-5 local area (240 unknowns) and a 13-edge window give the same bits next to a 70-edge window
+    (420 unknowns: the second instance) as in a batch of their own (the first), and the large window agrees with the oracle."""
+    from ssk_amd import capi
+    prm = sl.make_params(max_iters=8)
+    small = [sl.make_submap_problem(1, **DEPTH5)[0], sl.make_submap_problem(13, n_kf=14, n_lm=400, submap_size=5, max_tree_depth=6, opt_depth=14, obs_per_kf=60)[0]]
+    big = sl.make_submap_problem(0, **dict(DEPTH5, opt_depth=8))[0]
+    assert 6 * big.E > 255 and all(6 * w.E <= 255 for w in small)
+    b = capi.LmBatch(ctx, small)
+    assert b.kernel_name() == "lm_split_linearise_kernel" and b.solver_name() == "ldl_solve_mfma_tiles"
+    b.run(to_capi(prm))
+    r0 = b.results(); st0 = [b.state(i) for i in range(2)]
+    b.close()
+    b = capi.LmBatch(ctx, [big] + small)
+    assert b.solver_name() == "ldl_solve_mfma_lead"
+    b.run(to_capi(prm))
+    r1 = b.results()
+    for i in range(2):
+        p, l = b.state(1 + i)
+        assert r1[1 + i].iters == r0[i].iters and r1[1 + i].err_final == r0[i].err_final
+        assert np.array_equal(p, st0[i][0]) and np.array_equal(l, st0[i][1])
+    exp = oracle.lm_solve(big, prm, trace=False)
+    pb, lb = b.state(0)
+    assert r1[0].iters == exp["res"].iters and abs(r1[0].err_final - exp["res"].err_final) <= REL * exp["res"].err_final
+    assert np.abs(pb - exp["poses"]).max() <= 1e-5 and np.abs(lb - exp["lms"]).max() <= 1e-4
+    b.close()
+
+
 @pytest.mark.parametrize("E", [12, 15, 18])
 def test_lm_node_kernel_middle_branch(ctx, oracle, E, monkeypatch):
     """lm_solve_node_kernel beyond the one-wavefront block solver of the E <= 10 variant: the 4x4 register tiles (E = 12: 10 < E <= 14) and, between
