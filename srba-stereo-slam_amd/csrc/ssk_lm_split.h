@@ -10,8 +10,8 @@
 //       items in registers and stores ONE 36-double partial to its own slot in HBM (no atomics; slots are numbered block-major by the host),
 //       reduced-gradient partials per (tile, edge) likewise.
 //   K2a lm_split_reduce_kernel      grid = windows x chunks of 7 blocks: sums a block's partial slots in slot (= tile) order into the dense bordered
-//       system (a kernel of its own: the sums are latency-bound loads that want every CU's full occupancy, not the solver's 8 wavefronts)
-//   K2  lm_split_solve_kernel       grid = windows, 512 threads: LDL^T with the system in MFMA accumulator tiles (ldl_solve_mfma_tiles, ssk_lm_ldl_mfma.h; beyond 255 unknowns the register-tile solver ldl_solve_regtile), edge update exp(eps) (+) T, the
+//       system -- the upper triangle and, for a matrix-core K2, the lower halves of the diagonal 16 x 16 tiles only (a kernel of its own: the sums are latency-bound loads that want every CU's full occupancy, not the solver's 8 wavefronts)
+//   K2  lm_split_solve_kernel       grid = windows, 512 threads: LDL^T with the system in MFMA accumulator tiles (ldl_solve_mfma_tiles, ssk_lm_ldl_mfma.h; beyond 255 unknowns the leading columns first, ldl_leading_mfma: three instances of the kernel, sp_dev::solve_mfma), edge update exp(eps) (+) T, the
 //       trial state's suffix table.  The lambda_0 pass ends after the diagonal blocks.
 //   K3  lm_split_score_kernel       grid = tiles: landmark steps + robust error of the trial state group by group (nd_score_group), one error /
 //       |delta_f|^2 partial per tile.
@@ -55,8 +55,8 @@ struct sp_dev {
 };
 
 constexpr int SSK_SP_WAVES = 4;         // wavefronts per K1 / K3 workgroup = landmark groups per tile
-// K2: the solver of a batch whose largest window optimises E_max edges: true = ldl_solve_mfma_tiles (ssk_lm_ldl_mfma.h: the system in MFMA
-// accumulator tiles, up to 255 unknowns; SSK_K2_SOLVER=regtile: never), false = ldl_solve_regtile
+// K2: the solver of a batch whose largest window optimises E_max edges (ssk_lm_ldl_mfma.h: the system in MFMA accumulator tiles up to 255 unknowns,
+// the leading columns of larger ones -- up to 768 -- by 16-column panels first; SSK_K2_SOLVER=regtile: the register-tile solver)
 int ssk_sp_solve_mfma(int E_max, bool force_regtile /* SSK_K2_SOLVER=regtile */);      // 0 register tiles, 1 matrix cores incl. leading columns, 2 matrix cores, every window within 255 unknowns
 // K2: dynamic LDS of the solve kernel (doubles): the solver's staging + the window's edge poses and trie records
 size_t ssk_sp_solve_lds_doubles(int n_edges, int n_suf, int E, bool mfma);
