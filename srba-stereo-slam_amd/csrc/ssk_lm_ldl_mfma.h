@@ -758,6 +758,55 @@ __device__ __forceinline__ int ldl_leading_mfma(double* __restrict__ A, int np, 
 	return 0;
 }
 
+// Back-substitution of the n1 leading unknowns (n1 a multiple of 16) by panels of 16 from the last one up: x_out[n1 .. n) is final, x_out[0 .. n1) holds
+// z_k / d_k.  Panel c0: every thread sums U(i, c0 + k) x_i over its share of the rows BELOW the panel (thread = column k x one of 32 row groups, eight
+// loads in flight; the matrix is read once, 16 doubles of a row per 16 threads), the 32 partials of a column are added in a fixed order, the panel's own
+// triangle by one wavefront (x of the later columns by v_readlane).  (ldl_backsub_leading staged ALL rows' leading columns through LDS and updated every
+// earlier unknown after each 16-row block: 49 us at 144 leading unknowns, 131 at 320.)
+__device__ __forceinline__ void ldl_backsub_leading16(const double* __restrict__ A, int np, int n, int n1, double* x_out, const double* inv, double* lds)
+{
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int kc = tid & 15, rg = tid >> 4;                // column of the panel, row group (32 of them)
+	double* part = lds;                                    // [32][17]
+	for (int c0 = n1 - 16; c0 >= 0; c0 -= 16) {
+		// the panel's own triangle, column k of lane k: U(c0 + j, c0 + k), j > k (wave 0; on their way during the sums)
+		double u[16];
+		if (wave == 0) {
+#pragma unroll
+			for (int j = 0; j < 16; ++j) u[j] = A[(size_t)(c0 + j) * np + c0 + (lane & 15)];
+		}
+		const double* col = A + (size_t)(c0 + 16) * np + c0 + kc;
+		const double* xb = x_out + c0 + 16;
+		const int rows = n - c0 - 16;                      // rows below the panel
+		double acc[4] = {0.0, 0.0, 0.0, 0.0};
+		for (int r0 = rg; r0 < rows; r0 += 8 * 32) {
+			double a[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) a[q] = col[(size_t)min(r0 + 32 * q, rows - 1) * np];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) acc[q & 3] += r0 + 32 * q < rows ? a[q] * xb[min(r0 + 32 * q, rows - 1)] : 0.0;
+		}
+		part[rg * 17 + kc] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+		__syncthreads();
+		if (wave == 0) {
+			const int k = lane & 15;
+			double sp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int r = 0; r < 32; ++r) sp[r & 3] += part[r * 17 + k];
+			const double ivk = inv[c0 + k];
+			double xv = x_out[c0 + k] - ((sp[0] + sp[1]) + (sp[2] + sp[3])) * ivk;
+#pragma unroll
+			for (int j = 15; j >= 1; --j) {
+				const double xj = readlane_f64(xv, j);
+				xv -= (j > k ? u[j] * ivk : 0.0) * xj;
+			}
+			if (lane < 16) x_out[c0 + lane] = xv;
+		}
+		__syncthreads();
+	}
+}
+
 // Systems beyond 255 unknowns (round 5: the local areas the facade's own stream grows -- 61 optimised edges = 366 unknowns in the bench's 401-frame pass,
 // up to 94 at KITTI-00 length -- ran the register-tile solver): the leading 16 ceil((n - 255) / 16) columns by ldl_leading_mfma above (U and 1 / d to the
 // system in L2), the trailing 240 .. 255 unknowns by the tile solver (its tiles take the leading columns' updates as MFMAs right after the load), the leading
@@ -790,9 +839,15 @@ __device__ __forceinline__ bool ldl_solve_mfma_lead(double* __restrict__ A, int 
 	if (n1 > 0) {
 		for (int k = tid; k < n1; k += NT) x_out[k] = A[(size_t)n * np + k] * inv[k];
 		__syncthreads();
+#if SSK_K2_LEAD_MFMA
+		ldl_backsub_leading16(A, np, n, n1, x_out, inv, lds);
+		LDLL_T(6);
+		return true;
+#else
 		const bool ok_ = ldl_backsub_leading(A, np, n, n1, x_out, inv, lds, lds_doubles);
 		LDLL_T(6);
 		return ok_;
+#endif
 	}
 	return true;
 }
