@@ -309,8 +309,9 @@ __device__ __forceinline__ bool ldl_solve_mfma_tiles(const double* __restrict__ 
 			commit_chunk(32 * ch);
 			if (ch + 1 < n_chunks) fetch_chunk(32 * (ch + 1));
 			LDLM_BARRIER_LDS();
+			const int hmax = min(32, lead - 32 * ch);          // (a last chunk of 16 columns: one group)
 #pragma unroll 1
-			for (int h = 0; h < 32; h += 16) {
+			for (int h = 0; h < hmax; h += 16) {
 				double nd[4];
 #pragma unroll
 				for (int q = 0; q < 4; ++q) { const int c = 32 * ch + h + 4 * q + lr; nd[q] = c < lead ? -inv_lead[min(c, lead - 1)] : 0.0; }
