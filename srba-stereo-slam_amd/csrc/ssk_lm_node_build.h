@@ -141,6 +141,33 @@ inline bool eset_less(const eset& a, const eset& b)
 }
 }  // namespace nd_detail
 
+namespace nd_detail {
+struct node { int key, a, n; };                       // key suffix, run of the landmark's sorted observations
+struct lmk { int l, obs0, n_obs, node0, n_nodes; };   // observations lm_sorted[obs0 ..), nodes nodes[node0 ..)
+struct gnode { int lmk, node, slot_lane; };           // per lane of a group: which landmark / node (-1 = root)
+struct skey { uint64_t yh, yl; int pc, l, m; };        // sort key of a landmark's set of optimised edge slots (split form)
+// The builder's temporaries, one set per host thread, kept between windows: a window of a batch is a few hundred microseconds of work, two dozen
+// vectors allocated and freed per window were a fifth of it (round 6).
+struct workspace {
+	suf_map ids;
+	std::vector<nd_i2> suf;
+	std::vector<int> suf_len, obs_suf, chain, suf_es, rank, child, sib, stack, node_mark, node_idx;
+	std::vector<char> suf_opt;
+	std::vector<uint64_t> path_key;                       // whole-path cache: hash -> (first path entry of a representative, length, id)
+	std::vector<int> path_p0, path_id;
+	std::vector<int> lo_off, lo_idx, next, lm_sorted, ord;
+	std::vector<uint64_t> okey;
+	std::vector<node> nodes;
+	std::vector<lmk> lms, lms2;
+	std::vector<eset> es;
+	std::vector<gnode> glanes;
+	std::vector<int> t_pid, t_code, cnt, start, fillp, used, used2, bucket, tri, sorted_code, e_cnt, e_fill, e_slot, e_of;
+	std::vector<char> is_diag;
+	std::vector<skey> sk;
+};
+inline workspace& ws() { static thread_local workspace w; return w; }
+}  // namespace nd_detail
+
 #ifdef ND_BUILD_PROF
 #include <chrono>
 static double g_nd_prof[8];
@@ -153,6 +180,8 @@ static double g_nd_prof[8];
 inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */, size_t lds_limit_doubles = 20352, bool split = false)
 {
 	ND_PROF0();
+	using nd_detail::node; using nd_detail::lmk; using nd_detail::gnode;
+	nd_detail::workspace& S = nd_detail::ws();
 	const int n_obs = Wn.n_obs, n_lms = Wn.n_lms_total;
 	int E = 0, L = 0;
 	for (int e = 0; e < Wn.n_edges_total; ++e) if (Wn.edge_unknown_slot[e] >= 0) ++E;
@@ -162,36 +191,55 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	// ---- suffix trie (ids in creation order: the rest of a suffix always has a smaller id); chain[id][k] = the suffix of length k + 1 on id's
 	// chain of rests (chain[id][len - 1] = id) ----
 	constexpr int MAXP = 8;                                // (SSK_LM_MAX_PATH)
-	std::vector<nd_i2> suf(1, nd_i2{-1, -1});
-	std::vector<int> suf_len(1, 0);
-	std::vector<int> obs_suf((size_t)n_obs, 0);
+	std::vector<nd_i2>& suf = S.suf;
+	std::vector<int>& suf_len = S.suf_len;
+	std::vector<int>& obs_suf = S.obs_suf;
+	suf.assign(1, nd_i2{-1, -1});
+	suf_len.assign(1, 0);
+	obs_suf.resize((size_t)n_obs);
 	{
-		nd_detail::suf_map ids;
+		nd_detail::suf_map& ids = S.ids;
 		ids.init(2048);
+		// whole paths seen before (direct mapped, 1024 entries): the observations of a keyframe reach a handful of base keyframes in turn, a path
+		// step by step is one trie lookup per edge
+		constexpr int PC = 1024;
+		S.path_key.assign(PC, ~(uint64_t)0); S.path_p0.resize(PC); S.path_id.resize(PC);
 		const int* prev = nullptr;
 		int prev_n = -1, prev_id = 0;
 		for (int o = 0; o < n_obs; ++o) {
 			const int p0 = Wn.obs_path_off[o], pn = Wn.obs_path_off[o + 1] - p0;
 			if (pn > MAXP) return false;
 			// the observations of one keyframe pair follow each other and share their path
-			if (pn == prev_n && (pn == 0 || std::memcmp(prev, Wn.path_edge + p0, sizeof(int) * (size_t)pn) == 0)) { obs_suf[o] = prev_id; continue; }
+			if (pn == prev_n && (pn == 0 || std::memcmp(prev, Wn.path_edge + p0, sizeof(int) * (size_t)pn) == 0)) { obs_suf[(size_t)o] = prev_id; continue; }
+			uint64_t hk = (uint64_t)pn;
+			for (int p = 0; p < pn; ++p) hk = (hk ^ (uint32_t)Wn.path_edge[p0 + p]) * 0x9E3779B97F4A7C15ull;
+			hk ^= hk >> 29;
+			if (hk == ~(uint64_t)0) hk = 0;
+			const size_t slot = (size_t)(hk >> 7) & (PC - 1);
 			int cur = 0;
-			for (int p = p0 + pn - 1; p >= p0; --p) {
-				const uint64_t key = ((uint64_t)(uint32_t)Wn.path_edge[p] << 32) | (uint32_t)cur;
-				bool ins;
-				const int id = ids.get(key, (int)suf.size(), ins);
-				if (ins) { suf.push_back(nd_i2{Wn.path_edge[p], cur}); suf_len.push_back(suf_len[(size_t)cur] + 1); }
-				cur = id;
+			if (S.path_key[slot] == hk && std::memcmp(Wn.path_edge + S.path_p0[slot], Wn.path_edge + p0, sizeof(int) * (size_t)pn) == 0) cur = S.path_id[slot];
+			else {
+				for (int p = p0 + pn - 1; p >= p0; --p) {
+					const uint64_t key = ((uint64_t)(uint32_t)Wn.path_edge[p] << 32) | (uint32_t)cur;
+					bool ins;
+					const int id = ids.get(key, (int)suf.size(), ins);
+					if (ins) { suf.push_back(nd_i2{Wn.path_edge[p], cur}); suf_len.push_back(suf_len[(size_t)cur] + 1); }
+					cur = id;
+				}
+				S.path_key[slot] = hk; S.path_p0[slot] = p0; S.path_id[slot] = cur;
 			}
-			obs_suf[o] = cur;
+			obs_suf[(size_t)o] = cur;
 			prev = Wn.path_edge + p0; prev_n = pn; prev_id = cur;
 		}
 	}
 	const int n_suf = (int)suf.size();
 	if (n_suf > 65535) return false;
-	std::vector<int> chain((size_t)n_suf * MAXP, 0);
-	std::vector<char> suf_opt((size_t)n_suf, 0);           // the suffix starts at an optimised edge
-	std::vector<int> suf_es((size_t)n_suf, -1);            // ... its slot
+	std::vector<int>& chain = S.chain;
+	std::vector<char>& suf_opt = S.suf_opt;                // the suffix starts at an optimised edge
+	std::vector<int>& suf_es = S.suf_es;                   // ... its slot
+	chain.assign((size_t)n_suf * MAXP, 0);
+	suf_opt.assign((size_t)n_suf, 0);
+	suf_es.assign((size_t)n_suf, -1);
 	for (int id = 1; id < n_suf; ++id) {
 		const int len = suf_len[(size_t)id], rest = suf[(size_t)id].y;
 		for (int k = 0; k + 1 < len; ++k) chain[(size_t)id * MAXP + k] = chain[(size_t)rest * MAXP + k];
@@ -199,57 +247,72 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		suf_es[(size_t)id] = Wn.edge_unknown_slot[suf[(size_t)id].x >> 1];
 		suf_opt[(size_t)id] = suf_es[(size_t)id] >= 0;
 	}
-	// a is a suffix of b (or b itself)
-	auto is_suffix_of = [&](int a, int b) { const int la = suf_len[(size_t)a]; return la <= suf_len[(size_t)b] && (la == 0 || chain[(size_t)b * MAXP + la - 1] == a); };
+	// rank[id]: position of the suffix in the depth-first walk of the trie that takes a node's children in ascending id -- the lexicographic order of
+	// the chains (the sequence of suffix ids from the shortest to the whole path, a prefix first): what a landmark's observations are sorted by
+	std::vector<int>& rank = S.rank;
+	{
+		std::vector<int>& child = S.child; std::vector<int>& sib = S.sib; std::vector<int>& stack = S.stack;
+		child.assign((size_t)n_suf, -1); sib.assign((size_t)n_suf, -1); rank.resize((size_t)n_suf);
+		for (int id = n_suf - 1; id >= 1; --id) { const int par = suf[(size_t)id].y; sib[(size_t)id] = child[(size_t)par]; child[(size_t)par] = id; }
+		stack.clear(); stack.push_back(0);
+		int r = 0;
+		while (!stack.empty()) {
+			const int id = stack.back(); stack.pop_back();
+			rank[(size_t)id] = r++;
+			// children pushed in descending id, popped ascending
+			int c = child[(size_t)id], n0 = (int)stack.size();
+			for (; c >= 0; c = sib[(size_t)c]) stack.push_back(c);
+			std::reverse(stack.begin() + n0, stack.end());
+		}
+	}
 	ND_PROF(1);
 	// ---- landmarks: observations by landmark (counting sort), then per landmark sorted so that every trie subtree is a run; nodes ----
-	std::vector<int> lo_off((size_t)n_lms + 1, 0), lo_idx((size_t)n_obs);
+	std::vector<int>& lo_off = S.lo_off; std::vector<int>& lo_idx = S.lo_idx;
+	lo_off.assign((size_t)n_lms + 1, 0); lo_idx.resize((size_t)n_obs);
 	for (int o = 0; o < n_obs; ++o) lo_off[(size_t)Wn.obs_lm[o] + 1]++;
 	for (int l = 0; l < n_lms; ++l) lo_off[(size_t)l + 1] += lo_off[(size_t)l];
 	{
-		std::vector<int> next(lo_off.begin(), lo_off.end() - 1);
+		std::vector<int>& next = S.next;
+		next.assign(lo_off.begin(), lo_off.end() - 1);
 		for (int o = 0; o < n_obs; ++o) lo_idx[(size_t)next[(size_t)Wn.obs_lm[o]]++] = o;
 	}
-	struct node { int key, a, n; };                       // key suffix, run of the landmark's sorted observations
-	struct lmk { int l, obs0, n_obs, node0, n_nodes; };   // observations lm_sorted[obs0 ..), nodes nodes[node0 ..)
-	std::vector<lmk> lms;
-	lms.reserve((size_t)n_lms);
-	std::vector<int> lm_sorted((size_t)n_obs);             // per landmark its observations, sorted
-	std::vector<node> nodes;
-	nodes.reserve((size_t)n_obs * 2);
+	std::vector<lmk>& lms = S.lms;
+	lms.clear(); lms.reserve((size_t)n_lms);
+	std::vector<int>& lm_sorted = S.lm_sorted;             // per landmark its observations, sorted
+	lm_sorted.resize((size_t)n_obs);
+	std::vector<node>& nodes = S.nodes;
+	nodes.clear(); nodes.reserve((size_t)n_obs * 2);
+	// node of (current landmark, suffix): node_mark[suffix] == landmark + 1 says node_idx[suffix] is this landmark's
+	std::vector<int>& node_mark = S.node_mark; std::vector<int>& node_idx = S.node_idx;
+	node_mark.assign((size_t)n_suf, 0); node_idx.resize((size_t)n_suf);
 	int n_sorted = 0;
 	for (int l = 0; l < n_lms; ++l) {
 		const int o0 = lo_off[(size_t)l], no = lo_off[(size_t)l + 1] - o0;
 		if (no == 0) continue;                            // never observed: nothing to linearise, nothing moves it
 		if (no > 64) return false;
-		// stable insertion sort by chain (the sequence of suffix ids from the shortest to the whole path), lexicographically
-		int ord[64];
-		auto chain_less = [&](int oa, int ob) {
-			const int sa = obs_suf[(size_t)oa], sb = obs_suf[(size_t)ob];
-			if (sa == sb) return false;
-			const int la = suf_len[(size_t)sa], lb = suf_len[(size_t)sb], lm = la < lb ? la : lb;
-			const int* ca = &chain[(size_t)sa * MAXP]; const int* cb = &chain[(size_t)sb * MAXP];
-			for (int k = 0; k < lm; ++k) if (ca[k] != cb[k]) return ca[k] < cb[k];
-			return la < lb;
-		};
+		// stable insertion sort by chain (= by the rank of the observation's suffix)
+		int ord[64], key[64];
 		for (int k = 0; k < no; ++k) {
-			const int o = lo_idx[(size_t)o0 + k];
+			const int o = lo_idx[(size_t)o0 + k], ko = rank[(size_t)obs_suf[(size_t)o]];
 			int j = k;
-			while (j > 0 && chain_less(o, ord[j - 1])) { ord[j] = ord[j - 1]; --j; }
-			ord[j] = o;
+			while (j > 0 && ko < key[j - 1]) { ord[j] = ord[j - 1]; key[j] = key[j - 1]; --j; }
+			ord[j] = o; key[j] = ko;
 		}
 		lmk M{l, n_sorted, no, (int)nodes.size(), 0};
 		for (int k = 0; k < no; ++k) lm_sorted[(size_t)n_sorted + k] = ord[k];
 		n_sorted += no;
 		// nodes in the order of their first observation (depth first): a node's observations are the run of those whose chain holds its key
+		const int mark = l + 1;
+		int prev_sid = -1;
 		for (int k = 0; k < no; ++k) {
 			const int sid = obs_suf[(size_t)ord[k]], len = suf_len[(size_t)sid];
+			const int* ch = &chain[(size_t)sid * MAXP];
+			(void)prev_sid;
 			for (int c = 0; c < len; ++c) {
-				const int s2 = chain[(size_t)sid * MAXP + c];
+				const int s2 = ch[c];
 				if (!suf_opt[(size_t)s2]) continue;
-				bool seen = false;
-				for (int i = M.node0; i < (int)nodes.size(); ++i) if (nodes[(size_t)i].key == s2) { nodes[(size_t)i].n = k + 1 - nodes[(size_t)i].a; seen = true; break; }
-				if (!seen) nodes.push_back(node{s2, k, 1});
+				if (node_mark[(size_t)s2] == mark) { node& nd = nodes[(size_t)node_idx[(size_t)s2]]; nd.n = k + 1 - nd.a; }
+				else { node_mark[(size_t)s2] = mark; node_idx[(size_t)s2] = (int)nodes.size(); nodes.push_back(node{s2, k, 1}); }
 			}
 		}
 		M.n_nodes = (int)nodes.size() - M.node0;
@@ -257,30 +320,58 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		lms.push_back(M);
 	}
 	{
-		std::vector<int> ord(lms.size());
-		for (size_t m = 0; m < ord.size(); ++m) ord[m] = (int)m;
+		std::vector<int>& ord = S.ord;
+		ord.resize(lms.size());
 		if (!split) {
-			// optimised landmarks first, in slot order, then the fixed ones
-			std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
-				const int sa = Wn.lm_unknown_slot[lms[(size_t)a].l], sb = Wn.lm_unknown_slot[lms[(size_t)b].l];
-				if ((sa >= 0) != (sb >= 0)) return sa >= 0;
-				return sa >= 0 ? sa < sb : lms[(size_t)a].l < lms[(size_t)b].l;
-			});
+			// optimised landmarks first, in slot order, then the fixed ones (by landmark index): the keys are distinct
+			std::vector<uint64_t>& okey = S.okey;
+			okey.resize(lms.size());
+			for (size_t m = 0; m < lms.size(); ++m) {
+				const int sa = Wn.lm_unknown_slot[lms[m].l];
+				okey[m] = ((uint64_t)(sa >= 0 ? (uint32_t)sa : 0x80000000u + (uint32_t)lms[m].l) << 32) | (uint32_t)m;
+			}
+			std::sort(okey.begin(), okey.end());
+			for (size_t m = 0; m < ord.size(); ++m) ord[m] = (int)(uint32_t)okey[m];
 		} else {
-			// by the sorted set of optimised edge slots of the landmark's nodes, lexicographically (ties: landmark index)
-			std::vector<nd_detail::eset> es(lms.size());
+			// by the sorted set of optimised edge slots of the landmark's nodes, lexicographically (a prefix first; ties: landmark index).  As ONE key
+			// per landmark: slot e -> bit 127 - e of a 128-bit number X; of two sets that differ first at list position i the one with the smaller
+			// element there has the larger X, and a proper prefix has the smaller X -- with every bit below X's lowest set bit filled (Y) the prefix
+			// comes out >= its extensions (equal only when the extension adds ALL slots up to 127: then the fewer elements first).  Order: Y
+			// descending, element count ascending, landmark index ascending (eset_less above is the definition; tests compare the tables' hashes).
+			std::vector<nd_detail::eset>& es = S.es;
+			es.assign(lms.size(), nd_detail::eset());
 			for (size_t m = 0; m < lms.size(); ++m)
 				for (int i = 0; i < lms[m].n_nodes; ++i) {
 					const int e = suf_es[(size_t)nodes[(size_t)lms[m].node0 + i].key];
 					if (e < 64) es[m].lo |= (uint64_t)1 << e; else es[m].hi |= (uint64_t)1 << (e - 64);
 				}
-			std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
-				if (nd_detail::eset_less(es[(size_t)a], es[(size_t)b])) return true;
-				if (nd_detail::eset_less(es[(size_t)b], es[(size_t)a])) return false;
-				return lms[(size_t)a].l < lms[(size_t)b].l;
+			using nd_detail::skey;
+			std::vector<skey>& sk = S.sk;
+			sk.resize(lms.size());
+			auto rev64 = [](uint64_t v) {
+				v = ((v >> 1) & 0x5555555555555555ull) | ((v & 0x5555555555555555ull) << 1);
+				v = ((v >> 2) & 0x3333333333333333ull) | ((v & 0x3333333333333333ull) << 2);
+				v = ((v >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((v & 0x0F0F0F0F0F0F0F0Full) << 4);
+				return __builtin_bswap64(v);
+			};
+			for (size_t m = 0; m < lms.size(); ++m) {
+				// slot e (bit e of lo / bit e - 64 of hi) -> bit 127 - e: the high word is the reversed lo, the low word the reversed hi
+				uint64_t xh = rev64(es[m].lo), xl = rev64(es[m].hi);
+				if (xl) xl |= (xl & (~xl + 1)) - 1;
+				else if (xh) { xh |= (xh & (~xh + 1)) - 1; xl = ~(uint64_t)0; }
+				else { xh = ~(uint64_t)0; xl = ~(uint64_t)0; }
+				sk[m] = skey{xh, xl, __builtin_popcountll(es[m].lo) + __builtin_popcountll(es[m].hi), lms[m].l, (int)m};
+			}
+			std::sort(sk.begin(), sk.end(), [](const skey& a, const skey& b) {
+				if (a.yh != b.yh) return a.yh > b.yh;
+				if (a.yl != b.yl) return a.yl > b.yl;
+				if (a.pc != b.pc) return a.pc < b.pc;
+				return a.l < b.l;
 			});
+			for (size_t m = 0; m < ord.size(); ++m) ord[m] = sk[m].m;
 		}
-		std::vector<lmk> sorted(lms.size());
+		std::vector<lmk>& sorted = S.lms2;
+		sorted.resize(lms.size());
 		for (size_t m = 0; m < ord.size(); ++m) sorted[m] = lms[(size_t)ord[m]];
 		lms.swap(sorted);
 	}
@@ -302,13 +393,16 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		H.goff.resize(r_goff); H.gslot.resize(r_gslot);
 		return false;
 	};
-	struct gnode { int lmk, node, slot_lane; };            // per lane of a group: which landmark / node (-1 = root)
-	std::vector<gnode> glanes;                             // all groups' lanes, group after group (H.group[...].lane0 / n_lanes index it)
-	glanes.reserve(nodes.size() + lms.size());
-	// (the tables' final sizes are known here: growing them push by push re-copied them a dozen times per window)
-	H.obs.reserve(H.obs.size() + (size_t)n_sorted); H.px.reserve(H.px.size() + (size_t)n_sorted); H.lane.reserve(H.lane.size() + nodes.size() + lms.size());
-	H.group.reserve(H.group.size() + (nodes.size() + lms.size()) / 32 + (size_t)n_sorted / 32 + 4);
+	std::vector<gnode>& glanes = S.glanes;                 // all groups' lanes, group after group (H.group[...].lane0 / n_lanes index it)
+	const size_t n_lanes_all = nodes.size() + lms.size();
+	glanes.resize(n_lanes_all);
+	// (the tables' final sizes are known here: the observation, pixel and lane records are written in place)
+	H.obs.resize(r_obs + (size_t)n_sorted); H.px.resize(r_px + (size_t)n_sorted); H.lane.resize(r_lane + n_lanes_all);
+	H.group.reserve(H.group.size() + n_lanes_all / 32 + (size_t)n_sorted / 32 + 4);
 	{
+		nd_i2* w_obs = H.obs.data() + r_obs; nd_f4* w_px = H.px.data() + r_px; nd_i4* w_lane = H.lane.data() + r_lane;
+		gnode* w_gl = glanes.data();
+		const nd_f4* in_px = reinterpret_cast<const nd_f4*>(Wn.obs_px);
 		nd_group G{0, 0, 0, 0};
 		auto flush = [&] {
 			if (G.n_lanes == 0) return;
@@ -320,20 +414,23 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			const int no = M.n_obs, nl = 1 + M.n_nodes;
 			if (G.n_obs + no > 64 || G.n_lanes + nl > 64) flush();
 			const int root_lane = G.n_lanes, obs_a = G.n_obs;
+			const int* so = &lm_sorted[(size_t)M.obs0];
 			for (int k = 0; k < no; ++k) {
-				const int o = lm_sorted[(size_t)M.obs0 + k];
-				H.obs.push_back(nd_i2{M.l, obs_suf[(size_t)o] | (root_lane << 16) | (k << 24)});      // (k: distance from the landmark's first observation lane)
-				H.px.push_back(nd_f4{Wn.obs_px[4 * o], Wn.obs_px[4 * o + 1], Wn.obs_px[4 * o + 2], Wn.obs_px[4 * o + 3]});
+				const int o = so[k];
+				w_obs[k] = nd_i2{M.l, obs_suf[(size_t)o] | (root_lane << 16) | (k << 24)};      // (k: distance from the landmark's first observation lane)
+				std::memcpy(&w_px[k], &in_px[o], sizeof(nd_f4));                               // (the caller's array need not be 16-byte aligned)
 			}
-			H.lane.push_back(nd_i4{M.l, obs_a | (no << 8) | (1 << 16), Wn.lm_unknown_slot[M.l], 1 | (root_lane << 8) | (M.n_nodes << 16)});
-			glanes.push_back(gnode{(int)m, -1, root_lane});
+			w_obs += no; w_px += no;
+			*w_lane++ = nd_i4{M.l, obs_a | (no << 8) | (1 << 16), Wn.lm_unknown_slot[M.l], 1 | (root_lane << 8) | (M.n_nodes << 16)};
+			*w_gl++ = gnode{(int)m, -1, root_lane};
+			const node* nd0 = &nodes[(size_t)M.node0];
 			for (int k = 0; k < M.n_nodes; ++k) {
-				const node& nd = nodes[(size_t)M.node0 + k];
+				const node& nd = nd0[k];
 				const int code = suf[(size_t)nd.key].x, inv = code & 1;
 				const int tsuf = inv ? suf[(size_t)nd.key].y : nd.key;
 				const int es = suf_es[(size_t)nd.key];
-				H.lane.push_back(nd_i4{M.l, (obs_a + nd.a) | (nd.n << 8) | ((nd.a == 0 ? 1 : 0) << 16), tsuf | (es << 16) | (inv << 24), 2 | (root_lane << 8)});
-				glanes.push_back(gnode{(int)m, k, root_lane + 1 + k});
+				*w_lane++ = nd_i4{M.l, (obs_a + nd.a) | (nd.n << 8) | ((nd.a == 0 ? 1 : 0) << 16), tsuf | (es << 16) | (inv << 24), 2 | (root_lane << 8)};
+				*w_gl++ = gnode{(int)m, k, root_lane + 1 + k};
 			}
 			G.n_obs += no; G.n_lanes += nl;
 		}
@@ -346,11 +443,17 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	const int n_pairs = E * (E + 1) / 2;
 	auto pid_of = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
 	const size_t n_tiles = (n_groups + (size_t)waves - 1) / (size_t)waves;
-	std::vector<int> t_pid, t_code;                        // the current tile's items, generation order
-	std::vector<int> cnt((size_t)n_pairs + 1, 0), start((size_t)n_pairs + 1, 0), used, sorted_code;
-	std::vector<int> e_cnt((size_t)E + 1, 0), e_start((size_t)E + 1, 0), e_slot, e_of;      // the tile's node slots by edge
-	std::vector<char> is_diag((size_t)n_pairs, 0);         // block (e, e): the only ones the lambda_0 pass needs (bit 30 of a lane slot's x)
+	std::vector<int>& t_pid = S.t_pid; std::vector<int>& t_code = S.t_code;      // the current tile's items, generation order
+	std::vector<int>& cnt = S.cnt; std::vector<int>& start = S.start; std::vector<int>& fillp = S.fillp; std::vector<int>& used = S.used; std::vector<int>& sorted_code = S.sorted_code;
+	std::vector<int>& e_cnt = S.e_cnt; std::vector<int>& e_fill = S.e_fill; std::vector<int>& e_slot = S.e_slot; std::vector<int>& e_of = S.e_of;      // the tile's node slots by edge
+	std::vector<char>& is_diag = S.is_diag;                // block (e, e): the only ones the lambda_0 pass needs (bit 30 of a lane slot's x)
+	cnt.assign((size_t)n_pairs + 1, 0); start.resize((size_t)n_pairs + 1); fillp.resize((size_t)n_pairs + 1);
+	e_cnt.assign((size_t)E + 1, 0); e_fill.resize((size_t)E + 1);
+	is_diag.assign((size_t)n_pairs + 1, 0);
 	for (int e = 0; e < E; ++e) is_diag[(size_t)pid_of(e, e)] = 1;
+	std::vector<int>& tri = S.tri;                         // tri[e2] = e2 (e2 + 1) / 2: block (e, e2), e <= e2, is tri[e2] + e
+	tri.resize((size_t)E + 1);
+	for (int e = 0; e <= E; ++e) tri[(size_t)e] = e * (e + 1) / 2;
 	int max_per_lane = 0, max_rounds = 0, max_tile_blocks = 0;
 	{
 		// an upper estimate of the item count: a landmark with k nodes has at most k (k + 1) / 2 pairs (+ the doubled same-edge pairs: rare)
@@ -370,46 +473,74 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			const nd_group& Gr = H.group[r_group + g0 + (size_t)wv];
 			const gnode* gl = &glanes[(size_t)Gr.lane0];
 			const int nl = Gr.n_lanes;
+			// per node lane: its edge slot and its run of the landmark's sorted observations [ra, rb).  Two nodes of a landmark are NESTED (one's suffix is a
+			// suffix of the other's) exactly when their runs meet -- both suffixes then lie on one observation's chain --, and of a nested pair the one
+			// LATER in the lane order is the far one (nodes are listed by first observation, an observation's chain from the shortest suffix up).
+			int l_es[64], l_ra[64], l_rb[64];
 			for (int a = 0; a < nl; ++a) {
 				if (gl[a].node < 0) continue;
-				const lmk& M = lms[(size_t)gl[a].lmk];
+				const node& nd = nodes[(size_t)lms[(size_t)gl[a].lmk].node0 + (size_t)gl[a].node];
+				l_es[a] = suf_es[(size_t)nd.key]; l_ra[a] = nd.a; l_rb[a] = nd.a + nd.n;
+			}
+			// item (row r, column c) of a node pair: the far node of a nested pair gives Zh, the near one Ph (bit 9 / bit 19: the P part of the row's / the
+			// column's record); not nested: Zh, Zh and the sign bit (20).  Row = the node of the lower edge slot.
+			auto emit = [&](int pid, int code) {
+				if (cnt[(size_t)pid]++ == 0) used.push_back(pid);
+				t_pid.push_back(pid);
+				t_code.push_back(code);
+			};
+			for (int r0 = 0; r0 < nl;) {                           // a root lane, then its landmark's node lanes
+				const lmk& M = lms[(size_t)gl[r0].lmk];
+				const int a0 = r0 + 1, a1 = a0 + M.n_nodes;
 				const bool opt = Wn.lm_unknown_slot[M.l] >= 0;
-				const int ka = nodes[(size_t)M.node0 + gl[a].node].key, ea = suf_es[(size_t)ka];
-				const int slot_a = 64 * wv + gl[a].slot_lane;
-				e_slot.push_back(slot_a); e_of.push_back(ea);
-				// partners: the later nodes of the same landmark (they follow in the lane order) and the node itself
-				for (int b = a; b < nl && gl[b].lmk == gl[a].lmk; ++b) {
-					const int kb = nodes[(size_t)M.node0 + gl[b].node].key, eb = suf_es[(size_t)kb];
-					const int slot_b = 64 * wv + gl[b].slot_lane;
-					int far = 0;                                   // 1: a far (b's key is a suffix of a's), 2: b far, 0: not nested
-					if (is_suffix_of(kb, ka)) far = 1; else if (is_suffix_of(ka, kb)) far = 2;
-					if (far == 0 && !opt) continue;
-					// item (row r, column c): the far node of a nested pair gives Zh, the near one Ph; not nested: Zh, Zh and the sign bit
-					auto emit = [&](int slot_r, int slot_c, bool r_far, bool c_far, int pid) {
-						const int xp = (far != 0 && !r_far) ? 1 : 0, yp = (far != 0 && !c_far) ? 1 : 0;
-						if (cnt[(size_t)pid]++ == 0) used.push_back(pid);
-						t_pid.push_back(pid);
-						t_code.push_back(slot_r | (xp << 9) | (slot_c << 10) | (yp << 19) | ((far == 0 ? 1 : 0) << 20));
-					};
-					if (a == b) emit(slot_a, slot_a, true, false, pid_of(ea, ea));
-					else if (ea < eb) emit(slot_a, slot_b, far == 1, far == 2, pid_of(ea, eb));
-					else if (eb < ea) emit(slot_b, slot_a, far == 2, far == 1, pid_of(eb, ea));
-					else {                                         // two nodes of one landmark on the same edge: both orders go to the diagonal block
-						emit(slot_a, slot_b, far == 1, far == 2, pid_of(ea, ea));
-						emit(slot_b, slot_a, far == 2, far == 1, pid_of(ea, ea));
+				const int sb = 64 * wv;
+				for (int a = a0; a < a1; ++a) {
+					const int ea = l_es[a], rb_a = l_rb[a];
+					const int slot_a = sb + a;                       // (a lane's slot in its group is its lane number)
+					e_slot.push_back(slot_a); e_of.push_back(ea);
+					// the node with itself: nested, "a far": Zh_a Ph_a^T on the diagonal block
+					emit(tri[(size_t)ea] + ea, slot_a | (slot_a << 10) | (1 << 19));
+					// partners: the later nodes of the same landmark
+					for (int b = a + 1; b < a1; ++b) {
+						const int eb = l_es[b], slot_b = sb + b;
+						if (l_ra[b] < rb_a) {                        // nested, b far: b's record gives Zh, a's Ph
+							if (ea < eb) emit(tri[(size_t)eb] + ea, slot_a | (1 << 9) | (slot_b << 10));
+							else if (eb < ea) emit(tri[(size_t)ea] + eb, slot_b | (slot_a << 10) | (1 << 19));
+							else {                                   // two nodes of one landmark on the same edge: both orders go to the diagonal block
+								emit(tri[(size_t)ea] + ea, slot_a | (1 << 9) | (slot_b << 10));
+								emit(tri[(size_t)ea] + ea, slot_b | (slot_a << 10) | (1 << 19));
+							}
+						} else if (opt) {                            // not nested: the Schur term only
+							if (ea < eb) emit(tri[(size_t)eb] + ea, slot_a | (slot_b << 10) | (1 << 20));
+							else if (eb < ea) emit(tri[(size_t)ea] + eb, slot_b | (slot_a << 10) | (1 << 20));
+							else {
+								emit(tri[(size_t)ea] + ea, slot_a | (slot_b << 10) | (1 << 20));
+								emit(tri[(size_t)ea] + ea, slot_b | (slot_a << 10) | (1 << 20));
+							}
+						}
 					}
 				}
+				r0 = a1;
 			}
 		}
-		// heaviest block first (ties: first appearance): the lanes of a wavefront run in lockstep
-		std::stable_sort(used.begin(), used.end(), [&](int a, int b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
+		// heaviest block first (ties: first appearance): the lanes of a wavefront run in lockstep.  A counting sort over the counts (a comparison
+		// sort of a depth-5 tile's ~500 blocks, 39 tiles a window, was a third of this section)
+		if (used.size() > 1) {
+			int cmax = 0;
+			for (int p2 : used) cmax = std::max(cmax, cnt[(size_t)p2]);
+			std::vector<int>& bk = S.bucket; std::vector<int>& tmp = S.used2;
+			bk.assign((size_t)cmax + 2, 0);
+			for (int p2 : used) bk[(size_t)(cmax - cnt[(size_t)p2]) + 1]++;
+			for (int c = 0; c <= cmax; ++c) bk[(size_t)c + 1] += bk[(size_t)c];
+			tmp.resize(used.size());
+			for (int p2 : used) tmp[(size_t)bk[(size_t)(cmax - cnt[(size_t)p2])]++] = p2;
+			used.swap(tmp);
+		}
 		{
 			int pos = 0;
-			for (int p2 : used) { start[(size_t)p2] = pos; pos += cnt[(size_t)p2]; }
+			for (int p2 : used) { start[(size_t)p2] = pos; fillp[(size_t)p2] = pos; pos += cnt[(size_t)p2]; }
 			sorted_code.resize(t_code.size());
-			std::vector<int>& fill = e_start;               // (scratch: the blocks' fill positions)
-			fill.assign((size_t)std::max(n_pairs, E) + 1, 0);
-			for (size_t i = 0; i < t_pid.size(); ++i) sorted_code[(size_t)(start[(size_t)t_pid[i]] + fill[(size_t)t_pid[i]]++)] = t_code[i];
+			for (size_t i = 0; i < t_pid.size(); ++i) sorted_code[(size_t)fillp[(size_t)t_pid[i]]++] = t_code[i];
 		}
 		nd_tile T{};
 		T.grp0 = (int)g0; T.n_grp = n_grp;
@@ -432,7 +563,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			for (int p2 : used) {
 				const int c = cnt[(size_t)p2];
 				const int k = lanes_of(c, R), kc = k == 4 ? 2 : (k == 2 ? 1 : 0);
-				if (c > 0xFFFF) return rollback();
+				if (c > 0xFFFF) { for (int p3 : used) cnt[(size_t)p3] = 0; return rollback(); }
 				for (int r = 0; r < k; ++r)
 					H.sqs.push_back(nd_i4{p2 | (is_diag[(size_t)p2] ? 1 << 30 : 0), c | (kc << 16) | (r << 20), item_base + start[(size_t)p2], -1});
 			}
@@ -466,9 +597,10 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 				const int first = (int)(H.item.size() - r_item);
 				const int* v = &sorted_code[(size_t)start[(size_t)pid]];
 				const int c = cnt[(size_t)pid];
-				for (int i = part; i < c; i += parts) H.item.push_back(v[i]);
+				if (parts == 1) H.item.insert(H.item.end(), v, v + c);
+				else for (int i = part; i < c; i += parts) H.item.push_back(v[i]);
 				const int n = (int)(H.item.size() - r_item) - first;
-				if (n > 32767 || first >= (1 << 28)) return rollback();
+				if (n > 32767 || first >= (1 << 28)) { for (int p3 : used) cnt[(size_t)p3] = 0; return rollback(); }
 				H.qs.push_back(nd_i2{pid | (n << 16), first | (part << 28) | (parts == 2 ? 1 << 30 : 0) | wave_flag});
 				max_per_lane = std::max(max_per_lane, (n + 3) / 4);
 			}
@@ -482,16 +614,14 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			int pos = (int)(H.gitem.size() - r_gitem);
 			const size_t base = H.gitem.size();
 			H.gitem.resize(base + e_slot.size());
-			std::vector<int>& fill = e_start;
-			fill.assign((size_t)std::max(n_pairs, E) + 1, 0);
 			for (int e = 0; e < E; ++e) {
 				if (e_cnt[(size_t)e] == 0) continue;
 				H.gqs.push_back(nd_i2{e | (e_cnt[(size_t)e] << 16), pos});
-				fill[(size_t)e] = pos - (int)(base - r_gitem);      // (position inside this tile's part)
+				e_fill[(size_t)e] = pos - (int)(base - r_gitem);      // (position inside this tile's part)
 				pos += e_cnt[(size_t)e];
 				++T.n_gqs;
 			}
-			for (size_t i = 0; i < e_slot.size(); ++i) H.gitem[base + (size_t)fill[(size_t)e_of[i]]++] = e_slot[i];
+			for (size_t i = 0; i < e_slot.size(); ++i) H.gitem[base + (size_t)e_fill[(size_t)e_of[i]]++] = e_slot[i];
 		}
 		H.tile.push_back(T);
 	}
@@ -499,24 +629,28 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	if (split) {
 		// partial slots, block-major (a block's slots are contiguous, in tile order); gradient slots, edge-major
 		const size_t p0 = H.poff.size(), g0 = H.goff.size();
-		H.poff.resize(p0 + (size_t)n_pairs + 1, 0);
+		H.poff.resize(p0 + (size_t)n_pairs + 1);
 		int* w_poff = &H.poff[p0];
+		std::fill(w_poff, w_poff + n_pairs + 1, 0);
 		for (size_t i = r_sqs; i < H.sqs.size(); ++i) if (((H.sqs[i].y >> 20) & 3) == 0) w_poff[(size_t)(H.sqs[i].x & 0xFFFF) + 1]++;
 		for (int p2 = 0; p2 < n_pairs; ++p2) w_poff[(size_t)p2 + 1] += w_poff[(size_t)p2];
 		{
-			std::vector<int> next(w_poff, w_poff + n_pairs);
+			std::vector<int>& next = S.next;
+			next.assign(w_poff, w_poff + n_pairs);
 			for (size_t i = r_sqs; i < H.sqs.size(); ++i) {
 				nd_i4& q = H.sqs[i];
 				q.w = ((q.y >> 20) & 3) == 0 ? next[(size_t)(q.x & 0xFFFF)]++ : next[(size_t)(q.x & 0xFFFF)] - 1;      // (the lanes of a block follow its first one)
 			}
 		}
 		n_part = w_poff[(size_t)n_pairs];
-		H.goff.resize(g0 + (size_t)E + 1, 0);
+		H.goff.resize(g0 + (size_t)E + 1);
 		int* w_goff = &H.goff[g0];
+		std::fill(w_goff, w_goff + E + 1, 0);
 		for (size_t i = r_gqs; i < H.gqs.size(); ++i) w_goff[(size_t)(H.gqs[i].x & 0xFFFF) + 1]++;
 		for (int e = 0; e < E; ++e) w_goff[(size_t)e + 1] += w_goff[(size_t)e];
 		{
-			std::vector<int> next(w_goff, w_goff + E);
+			std::vector<int>& next = S.next;
+			next.assign(w_goff, w_goff + E);
 			H.gslot.resize(r_gslot + (H.gqs.size() - r_gqs));
 			for (size_t k = r_gqs; k < H.gqs.size(); ++k) H.gslot[r_gslot + (k - r_gqs)] = next[(size_t)(H.gqs[k].x & 0xFFFF)]++;
 		}
@@ -533,13 +667,13 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	H.lds_doubles_big = std::max(H.lds_doubles_big, nd_lds_doubles(Wn.n_edges_total, E, waves, n_suf, (int)n_tiles, (int)n_groups, true, lds_limit_doubles));
 	H.max_items_per_lane = std::max(H.max_items_per_lane, max_per_lane);
 	if (split) {
-		nd_split S{};
-		S.sqs0 = (int)r_sqs; S.poff0 = (int)r_poff; S.goff0 = (int)r_goff; S.gslot0 = (int)r_gslot;
-		S.n_part = n_part; S.n_gpart = n_gpart; S.part0 = H.part_slots; S.gpart0 = H.gpart_slots;
-		S.gtile0 = (int)r_tile;
+		nd_split Sp{};
+		Sp.sqs0 = (int)r_sqs; Sp.poff0 = (int)r_poff; Sp.goff0 = (int)r_goff; Sp.gslot0 = (int)r_gslot;
+		Sp.n_part = n_part; Sp.n_gpart = n_gpart; Sp.part0 = H.part_slots; Sp.gpart0 = H.gpart_slots;
+		Sp.gtile0 = (int)r_tile;
 		H.part_slots += n_part; H.gpart_slots += n_gpart;
 		H.max_tile_blocks = std::max(H.max_tile_blocks, max_tile_blocks);
-		H.swin.push_back(S);
+		H.swin.push_back(Sp);
 	}
 	H.win.push_back(hdr);
 	ND_PROF(5);
