@@ -64,6 +64,9 @@ int ssk_rba_define_kf(ssk_rba* r, const ssk_rba_obs* obs, int n_obs, int run_loc
  * (alloc_keyframe, edge_creation_policy, add_observation) and both LM windows of every engine are built on host threads side by side; stage 1
  * (optimize_edges on the new edges, landmarks held) of ALL engines is ONE ssk_lm_batch (the pose-only kernel), stage 2 (optimize_local_area,
  * depth = max_optimize_depth) another (the node / phase-split kernels).  Every engine ends in the state ssk_rba_define_kf would have left it in.
+ * An engine whose bookkeeping fails ("the node becomes isolated", SRBA.h:304) has taken the keyframe and is left out of the solves, the batch goes on
+ * for the others; the call then returns the error code with the failed engines' indices in ssk_rba_last_error(r[0]) -- every other engine's record
+ * and state are valid, a failed engine's record has kf_id set and zeros otherwise.
  * out: n records.  timing (may be NULL): host-clock milliseconds of the call's parts and the shape of the stage-2 batch. */
 typedef struct ssk_rba_batch_timing {
 	double bookkeeping_and_windows_ms, stage1_create_ms, stage1_solve_ms, stage2_refresh_ms, stage2_create_ms, stage2_solve_ms, writeback_ms;
@@ -71,6 +74,7 @@ typedef struct ssk_rba_batch_timing {
 	double stage1_mean_obs, stage2_mean_obs, stage2_mean_edges, stage1_mean_iters, stage2_mean_iters;
 	int32_t host_threads, n_stage1, n_stage2, stage2_max_edges, stage2_max_obs, reserved;
 	char stage1_kernel[96], stage2_kernel[96];
+	double teardown_ms, total_ms;                            /* round 6: the windows' host arrays freed; the whole call inside the library */
 } ssk_rba_batch_timing;
 int ssk_rba_define_kf_batch(ssk_rba* const* r, int n, const ssk_rba_obs* const* obs, const int32_t* n_obs, int run_local_optimization,
                             ssk_rba_kf_info* out, ssk_rba_batch_timing* timing);

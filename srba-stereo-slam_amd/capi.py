@@ -388,7 +388,7 @@ class RbaBatchTiming(C.Structure):
                                           "stage2_solve_ms", "writeback_ms", "stage1_symbolic_ms", "stage2_symbolic_ms", "stage1_mean_obs", "stage2_mean_obs",
                                           "stage2_mean_edges", "stage1_mean_iters", "stage2_mean_iters")] + \
                [(k, C.c_int32) for k in ("host_threads", "n_stage1", "n_stage2", "stage2_max_edges", "stage2_max_obs", "reserved")] + \
-               [("stage1_kernel", C.c_char * 96), ("stage2_kernel", C.c_char * 96)]
+               [("stage1_kernel", C.c_char * 96), ("stage2_kernel", C.c_char * 96), ("teardown_ms", C.c_double), ("total_ms", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -43,7 +43,7 @@ struct ssk_lm_batch {
 	// node form (ssk_lm_node.hip): built when every window of the batch fits it (reduced system + a tile of node records in LDS)
 	bool gtab_multi = false;          // the per-workgroup suffix tables of the windows whose table lives in L2 scratch were sized for the cooperative kernel (64 copies)
 	bool node_ok = false, node_big = false;
-	bool node_small = false;          // every node-kernel window has E <= 10: the kernel variant whose only dense solver is ldl_solve_blocks6_wave
+	bool node_small = false;          // every node-kernel window has E <= 10: the kernel variant whose only dense solver is the one-wavefront matrix-core LDL^T (ldl_solve_mfma_wave; ND_BLOCKS6=1: ldl_solve_blocks6_wave)
 	nd_dev N{};
 	size_t node_dyn_bytes = 0;
 	// phase-split node form (ssk_lm_split.hip): windows whose reduced system does not fit LDS (the depth-5 local areas) -- and lean batches:
@@ -656,12 +656,21 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	for (int w = 0; w < n_windows; ++w) {
 		if (lw[(size_t)w].bad == 2) { int E, L, np; std::vector<int> a, c; return lm_validate_window(ctx, windows[w], w, E, L, a, c, np); }      // (again, for the message)
 	}
+	std::vector<ssk_lm_window> fit_windows;
 	{
-		bool any = false;
-		for (int w = 0; w < n_windows; ++w) any = any || lw[(size_t)w].bad;
-		if (any) {                                        // (which windows: the caller solves THEM with the full builder's kernels, not the whole batch)
+		int n_bad = 0;
+		for (int w = 0; w < n_windows; ++w) n_bad += lw[(size_t)w].bad != 0;
+		if (n_bad) {                                      // (which windows: the caller solves THEM with the full builder's kernels, not the whole batch)
 			if (unfit) { unfit->assign((size_t)n_windows, 0); for (int w = 0; w < n_windows; ++w) (*unfit)[(size_t)w] = lw[(size_t)w].bad; }
-			return 1;
+			if (!unfit || want_split || n_bad == n_windows) return 1;
+			// the batch of the windows that DO fit, from the tables just built (round 5 returned here and the caller ran this function again on the
+			// fitting windows: the symbolic build twice, and the small-batch decisions taken on the sub-batch's size instead of the batch's)
+			std::vector<lean_win> lw_fit;
+			lw_fit.reserve((size_t)(n_windows - n_bad));
+			for (int w = 0; w < n_windows; ++w)
+				if (!lw[(size_t)w].bad) { fit_windows.push_back(windows[w]); lw_fit.push_back(std::move(lw[(size_t)w])); }
+			lw.swap(lw_fit);
+			windows = fit_windows.data(); n_windows = (int)fit_windows.size();
 		}
 	}
 	// ---- (2) bases ----
@@ -718,10 +727,14 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 					ctx->pin_lm.base = nullptr; ctx->pin_lm.cap = 0; ctx->pin_lm.used = 0; ctx->pin_lm_small_streak = 0;
 				}
 			} else ctx->pin_lm_small_streak = 0;
-			const int rcp = ssk_arena_reserve(ctx, ctx->pin_lm, need);
-			if (rcp) return rcp;
-			bump.base = static_cast<char*>(ctx->pin_lm.base); bump.cap = ctx->pin_lm.cap; bump.used = 0;
-			arena = &bump;
+			// (capacity: the need + a quarter in steps of 64 MB, so "up to 4 GB" pins at most ~5; a refused pinned allocation -- locked-memory or
+			// cgroup limits are likelier at this size -- is not an error of the create: the tables then go through pageable memory)
+			const int rcp = ssk_arena_reserve(ctx, ctx->pin_lm, need, (size_t)64 << 20);
+			if (rcp) { (void)hipGetLastError(); ctx->err.clear(); }
+			else {
+				bump.base = static_cast<char*>(ctx->pin_lm.base); bump.cap = ctx->pin_lm.cap; bump.used = 0;
+				arena = &bump;
+			}
 		}
 	}
 	using ai = nd_noinit<int>; using ad = nd_noinit<double>; using af = nd_noinit<float>;
@@ -1776,26 +1789,29 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 		if (!windows || n_windows < 1 || !out) return ssk_set_error(ctx, SSK_ERR_BAD_ARG, "ssk_lm_batch_create: bad argument");
 		SSK_HIP(ctx, hipSetDevice(ctx->device));
 		std::vector<char> unfit;
-		const int rc = lm_batch_create_lean(ctx, windows, n_windows, trace, out, force != nullptr, &unfit);
-		if (rc != 1) return rc;
-		if (force) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: SSK_LM_KERNEL=split, but a window of the batch does not fit the node builder");
-		// per-window fallback: the windows the node builder cannot take go through the full builder ALONE (a sub-batch); the others keep their kernels
+		ssk_lm_batch* lean_b = nullptr;
+		const int rc = lm_batch_create_lean(ctx, windows, n_windows, trace, &lean_b, force != nullptr, &unfit);
+		if (rc != SSK_OK && rc != 1) return rc;
 		int n_unfit = 0;
 		for (char u : unfit) n_unfit += u != 0;
-		if (n_unfit > 0 && n_unfit < n_windows) {
+		if (rc == SSK_OK && n_unfit == 0) { *out = lean_b; return SSK_OK; }
+		if (force) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: SSK_LM_KERNEL=split, but a window of the batch does not fit the node builder");
+		// per-window fallback: the windows the node builder cannot take go through the full builder ALONE (a sub-batch); the others keep their kernels
+		// (lean_b: the batch of the fitting windows, made in the one pass above)
+		if (rc == SSK_OK) {
 			std::unique_ptr<ssk_lm_batch, void (*)(ssk_lm_batch*)> c(new ssk_lm_batch(), ssk_lm_batch_destroy);
 			c->ctx = ctx; c->n_windows = n_windows; c->trace = trace; c->max_iters_alloc = 64;
 			c->sub_of.resize((size_t)n_windows); c->idx_in.resize((size_t)n_windows);
-			std::vector<ssk_lm_window> part[2];
+			c->sub.assign(2, nullptr);
+			c->sub[0] = lean_b;
+			std::vector<ssk_lm_window> part1;
+			int n_fit = 0;
 			for (int w = 0; w < n_windows; ++w) {
 				const int k = unfit[(size_t)w] ? 1 : 0;
-				c->sub_of[(size_t)w] = k; c->idx_in[(size_t)w] = (int)part[k].size();
-				part[k].push_back(windows[w]);
+				c->sub_of[(size_t)w] = k; c->idx_in[(size_t)w] = k ? (int)part1.size() : n_fit++;
+				if (k) part1.push_back(windows[w]);
 			}
-			c->sub.assign(2, nullptr);
-			int rc2 = lm_batch_create_lean(ctx, part[0].data(), (int)part[0].size(), trace, &c->sub[0], false);
-			if (rc2 == 1) rc2 = ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_lm_batch_create: a window changed its mind about fitting the node builder");
-			if (rc2 == SSK_OK) rc2 = lm_batch_create_impl(ctx, part[1].data(), (int)part[1].size(), trace, &c->sub[1], false, false);
+			const int rc2 = lm_batch_create_impl(ctx, part1.data(), (int)part1.size(), trace, &c->sub[1], false, false);
 			if (rc2 != SSK_OK) return rc2;                  // (the composite's destructor frees what was made)
 			for (ssk_lm_batch* sb : c->sub) { c->symbolic_ms += sb->symbolic_ms; c->symbolic_threads = std::max(c->symbolic_threads, sb->symbolic_threads); c->max_n6 = std::max(c->max_n6, sb->max_n6); }
 			*out = c.release();

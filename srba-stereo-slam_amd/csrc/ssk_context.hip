@@ -59,19 +59,30 @@ int ssk_env_refresh(ssk_ctx* ctx)
 	return SSK_OK;
 }
 
-int ssk_arena_reserve(ssk_ctx* ctx, ssk_arena& a, size_t bytes)
+int ssk_arena_reserve(ssk_ctx* ctx, ssk_arena& a, size_t bytes, size_t sized_step)
 {
 	bytes += 4096;
 	if (bytes <= a.cap) return SSK_OK;
 	size_t ncap = a.cap ? a.cap : (size_t(1) << 20);
 	while (ncap < bytes) ncap *= 2;
+	// sized_step (the LM batches' pinned arena, hundreds of MB to GBs): a quarter of headroom rounded up to the step instead of the next power of
+	// two -- a need of 2.1 GB pinned 4 GB, one of exactly 4 GB would have pinned 8
+	if (sized_step) ncap = (bytes + bytes / 4 + sized_step - 1) / sized_step * sized_step;
 	// the old block may still be referenced by queued work: make the stream idle first
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	if (a.base) {
 		if (a.pinned_host) SSK_HIP(ctx, hipHostFree(a.base)); else SSK_HIP(ctx, hipFree(a.base));
 		a.base = nullptr; a.cap = 0;
 	}
-	if (a.pinned_host) SSK_HIP(ctx, hipHostMalloc(&a.base, ncap, hipHostMallocDefault));
+	if (a.pinned_host) {
+		hipError_t e = hipHostMalloc(&a.base, ncap, hipHostMallocDefault);
+		if (e != hipSuccess && sized_step && ncap > bytes) {        // (locked-memory limits: the exact need may still fit)
+			(void)hipGetLastError();
+			ncap = (bytes + 4095) & ~(size_t)4095;
+			e = hipHostMalloc(&a.base, ncap, hipHostMallocDefault);
+		}
+		if (e != hipSuccess) { a.base = nullptr; a.cap = 0; a.used = 0; SSK_HIP(ctx, e); }
+	}
 	else SSK_HIP(ctx, hipMalloc(&a.base, ncap));
 	a.cap = ncap;
 	a.used = 0;

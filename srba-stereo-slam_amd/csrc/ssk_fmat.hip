@@ -103,7 +103,8 @@ __device__ __forceinline__ int cubic_roots(double c3, double c2, double c1, doub
 	if (left && right) rm = bisect(a, b, c, x1, x2);
 	if (right) rr = bisect(a, b, c, x2, R);
 	roots[0] = left ? rl : rr; roots[1] = rm; roots[2] = rr;
-	return left && right ? 3 : 1;
+	// (neither: f1 < 0 < f2 -- a tiny positive disc with x1 ~ x2, rounding puts the maximum below and the minimum above zero: the oracle's form returns no root)
+	return left && right ? 3 : ((left || right) ? 1 : 0);
 }
 
 // F3: the 7-point solver (static register indexing: every loop bound is a constant, the pivot row is applied by selects)

@@ -122,7 +122,8 @@ int ssk_set_error(ssk_ctx* ctx, int code, const char* fmt, ...);
 	} while (0)
 
 // arena helpers: reset at the start of a host entry point, then carve 256-B aligned pieces.
-int ssk_arena_reserve(ssk_ctx* ctx, ssk_arena& a, size_t bytes);
+// sized_step != 0: capacity = the need + a quarter, rounded up to the step (not the next power of two); a failed pinned allocation is retried at the exact need
+int ssk_arena_reserve(ssk_ctx* ctx, ssk_arena& a, size_t bytes, size_t sized_step = 0);
 inline void ssk_arena_reset(ssk_arena& a) { a.used = 0; }
 template <typename T>
 inline T* ssk_arena_take(ssk_arena& a, size_t count)

@@ -535,6 +535,7 @@ __device__ __forceinline__ int ldl_leading_mfma(double* __restrict__ A, int np, 
 	double* Lik = lds;                                 // L'^-1 of the panel's diagonal tile
 	double* dgs = Lik + 16 * LDLM_LP;                  // the diagonal tile on its way to the factor wave
 	double* S = dgs + 16 * LDLM_LP;                    // [16 or 32][pitch]: earlier columns of rows c0 ..
+	__syncthreads();                                   // (a caller that solves again after a failed pivot: every reader of the last call's flag is past it)
 	if (tid == 0) s_lbad = 0;
 	// the panel's tiles (the system's upper triangle holds the same values along rows: coalesced; the border is stored as a row only).  Every load is
 	// unconditional, from a clamped address, and the masks come afterwards: behind per-slot conditions the compiler waited for every pair of loads before

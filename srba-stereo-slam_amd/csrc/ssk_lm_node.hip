@@ -27,7 +27,7 @@ constexpr int R_Q = 9, R_P = 12, R_V = 21;
 // BIG: the reduced system does not fit LDS: block accumulators (global_atomic_add_f64, still one owner per block and tile, the tiles' barriers
 // order the adds: bit-reproducible) and the dense bordered system in HBM / L2, factorised by ldl_solve_hybrid with the node records' LDS
 // region (and everything behind it) as its staging
-// SMALL: every window of the launch has E <= 10 (the host checks): the only dense solver compiled in is ldl_solve_blocks6_wave -- the other solvers'
+// SMALL: every window of the launch has E <= 10 (the host checks): the only dense solver compiled in is the one-wavefront ldl_solve_mfma_wave (ND_BLOCKS6 = 1: ldl_solve_blocks6_wave) -- the other solvers'
 // loop-invariant LDS addresses, hoisted in front of the LM loop, were what the kernel spilled
 template <bool BIG, bool SMALL = false>
 __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const lm_cam& P_arg, int dyn_doubles)

@@ -526,8 +526,21 @@ int batch_host_threads()
 void mySRBA::define_new_keyframe_batch(const std::vector<mySRBA*>& E, const std::vector<const new_kf_observations_t*>& obs,
                                        std::vector<TNewKeyFrameInfo>& out, bool run_local_optimization, TBatchTiming* tm)
 {
+	if (obs.size() != E.size()) throw std::runtime_error("define_new_keyframe_batch: one observation list per engine");
+	define_new_keyframe_batch_impl(E, &obs, nullptr, out, run_local_optimization, tm);
+}
+
+void mySRBA::define_new_keyframe_batch(const std::vector<mySRBA*>& E, const std::function<void(int, new_kf_observations_t&)>& fill,
+                                       std::vector<TNewKeyFrameInfo>& out, bool run_local_optimization, TBatchTiming* tm)
+{
+	define_new_keyframe_batch_impl(E, nullptr, &fill, out, run_local_optimization, tm);
+}
+
+void mySRBA::define_new_keyframe_batch_impl(const std::vector<mySRBA*>& E, const std::vector<const new_kf_observations_t*>* obs,
+                                            const std::function<void(int, new_kf_observations_t&)>* fill,
+                                            std::vector<TNewKeyFrameInfo>& out, bool run_local_optimization, TBatchTiming* tm)
+{
 	const int n = (int)E.size();
-	if ((int)obs.size() != n) throw std::runtime_error("define_new_keyframe_batch: one observation list per engine");
 	out.assign((size_t)n, TNewKeyFrameInfo());
 	if (n == 0) return;
 	Context& ctx = E[0]->m_ctx;
@@ -536,21 +549,44 @@ void mySRBA::define_new_keyframe_batch(const std::vector<mySRBA*>& E, const std:
 	TBatchTiming T;
 	T.host_threads = n_thr;
 	auto t0 = lm_now();
+	const auto t_call = t0;
 	// (1) per engine, side by side: graph bookkeeping (alloc_keyframe, edge_creation_policy, add_observation) and BOTH windows -- they read the map only;
-	// stage 1's result is written to the map, and to the prepared local-area windows' edge poses, in (3)
+	// stage 1's result is written to the map, and to the prepared local-area windows' edge poses, in (3).
+	// An engine whose bookkeeping throws (edge_creation_policy: "the node becomes isolated", SRBA.h:304) has taken the keyframe and is left out of the
+	// solves; the others go on.  The call then throws with the engines' indices in the text (the state of every OTHER engine is what
+	// define_new_keyframe would have left; the failed ones are as after define_new_keyframe's own throw).
 	std::vector<std::vector<TNewEdgeInfo>> new_edges((size_t)n);
 	std::vector<std::unique_ptr<lm_job>> j1((size_t)n), j2((size_t)n);
+	std::vector<std::string> failed((size_t)n);
 	parallel_for(n, n_thr, [&](int i) {
-		E[(size_t)i]->kf_begin(*obs[(size_t)i], out[(size_t)i], new_edges[(size_t)i]);
-		if (!run_local_optimization || new_edges[(size_t)i].empty()) return;
-		j1[(size_t)i].reset(new lm_job()); j2[(size_t)i].reset(new lm_job());
-		E[(size_t)i]->stage1_prepare(*j1[(size_t)i], out[(size_t)i].kf_id, new_edges[(size_t)i], false);
-		E[(size_t)i]->stage2_prepare(*j2[(size_t)i], out[(size_t)i].kf_id, false);
+		try {
+			if (fill) {
+				new_kf_observations_t list;
+				(*fill)(i, list);
+				E[(size_t)i]->kf_begin(list, out[(size_t)i], new_edges[(size_t)i]);
+			} else E[(size_t)i]->kf_begin(*(*obs)[(size_t)i], out[(size_t)i], new_edges[(size_t)i]);
+			if (!run_local_optimization || new_edges[(size_t)i].empty()) return;
+			std::unique_ptr<lm_job> a(new lm_job()), c(new lm_job());
+			E[(size_t)i]->stage1_prepare(*a, out[(size_t)i].kf_id, new_edges[(size_t)i], false);
+			E[(size_t)i]->stage2_prepare(*c, out[(size_t)i].kf_id, false);
+			j1[(size_t)i] = std::move(a); j2[(size_t)i] = std::move(c);
+		} catch (const std::exception& ex) { failed[(size_t)i] = ex.what()[0] ? ex.what() : "error"; }
 	});
+	std::string fail_text;
+	{
+		int nf = 0;
+		for (int i = 0; i < n; ++i) if (!failed[(size_t)i].empty()) { if (nf++ < 8) fail_text += (fail_text.empty() ? "" : "; ") + std::string("engine ") + std::to_string(i) + ": " + failed[(size_t)i]; }
+		if (nf > 8) fail_text += "; ... (" + std::to_string(nf) + " engines in all)";
+	}
 	std::vector<int> act;
 	for (int i = 0; i < n; ++i) if (j1[(size_t)i]) act.push_back(i);
 	T.bookkeeping_and_windows_ms = lm_ms(t0, lm_now());
-	if (act.empty()) { if (tm) *tm = T; return; }
+	auto finish = [&] {
+		T.total_ms = lm_ms(t_call, lm_now());
+		if (tm) *tm = T;
+		if (!fail_text.empty()) throw std::runtime_error("define_new_keyframe_batch: " + fail_text);
+	};
+	if (act.empty()) { finish(); return; }
 	const int na = (int)act.size();
 	struct batch_guard { ssk_lm_batch* b = nullptr; ~batch_guard() { if (b) ssk_lm_batch_destroy(b); } };
 	auto solve = [&](std::vector<std::unique_ptr<lm_job>>& J, bool robust, double& create_ms, double& solve_ms, double& sym_ms, char* kernel, std::vector<ssk_lm_result>& res, double& mean_iters) {
@@ -566,21 +602,26 @@ void mySRBA::define_new_keyframe_batch(const std::vector<mySRBA*>& E, const std:
 		ctx.check(ssk_lm_batch_run(ctx.get(), g.b, &prm), "ssk_lm_batch_run");
 		res.resize((size_t)na);
 		ctx.check(ssk_lm_batch_results(ctx.get(), g.b, res.data()), "ssk_lm_batch_results");
-		std::vector<double> pose(n_pose), lmp(n_lm);
-		ctx.check(ssk_lm_batch_get_state_all(ctx.get(), g.b, pose.data(), lmp.data()), "ssk_lm_batch_get_state_all");
+		// (uninitialised: the download fills them; zeroing 30 MB first cost milliseconds on one thread)
+		std::unique_ptr<double[]> pose(new double[n_pose ? n_pose : 1]), lmp(new double[n_lm ? n_lm : 1]);
+		ctx.check(ssk_lm_batch_get_state_all(ctx.get(), g.b, pose.get(), lmp.get()), "ssk_lm_batch_get_state_all");
 		solve_ms = lm_ms(tb, lm_now());
 		int thr = 0;
 		(void)ssk_lm_batch_symbolic_ms(ctx.get(), g.b, &sym_ms, &thr);
 		(void)ssk_lm_batch_kernel_name(ctx.get(), g.b, kernel, 96);
-		size_t oe = 0, ol = 0;
+		// every window's share to its job, side by side (30 MB through one thread were milliseconds)
+		std::vector<size_t> oe((size_t)na + 1, 0), ol((size_t)na + 1, 0);
 		double it = 0;
 		for (int k = 0; k < na; ++k) {
-			lm_job& j = *J[(size_t)act[(size_t)k]];
-			std::memcpy(j.pose.data(), pose.data() + oe, sizeof(double) * j.pose.size());
-			std::memcpy(j.lmpos.data(), lmp.data() + ol, sizeof(double) * j.lmpos.size());
-			oe += j.pose.size(); ol += j.lmpos.size();
+			const lm_job& j = *J[(size_t)act[(size_t)k]];
+			oe[(size_t)k + 1] = oe[(size_t)k] + j.pose.size(); ol[(size_t)k + 1] = ol[(size_t)k] + j.lmpos.size();
 			it += res[(size_t)k].iters;
 		}
+		parallel_for(na, n_thr, [&](int k) {
+			lm_job& j = *J[(size_t)act[(size_t)k]];
+			std::memcpy(j.pose.data(), pose.get() + oe[(size_t)k], sizeof(double) * j.pose.size());
+			std::memcpy(j.lmpos.data(), lmp.get() + ol[(size_t)k], sizeof(double) * j.lmpos.size());
+		});
 		mean_iters = it / na;
 	};
 	// (2) stage 1 of every engine: one batch (one or two optimised edges, no optimised landmark: the pose-only kernel)
@@ -613,7 +654,11 @@ void mySRBA::define_new_keyframe_batch(const std::vector<mySRBA*>& E, const std:
 		e.timing.solves += 2; e.timing.iters += (size_t)r1[(size_t)k].iters + (size_t)r2[(size_t)k].iters;
 		e.timing.max_opt_edges = std::max(e.timing.max_opt_edges, (size_t)c.n_opt); e.timing.max_obs = std::max(e.timing.max_obs, c.obs_lm.size());
 	}
-	if (tm) *tm = T;
+	// the windows' host arrays (a dozen vectors per engine and stage) go side by side too: one thread freeing 2 048 windows was milliseconds
+	auto t6 = lm_now();
+	parallel_for(n, n_thr, [&](int i) { j1[(size_t)i].reset(); j2[(size_t)i].reset(); });
+	T.teardown_ms = lm_ms(t6, lm_now());
+	finish();
 }
 
 }  // namespace ssk

@@ -10,6 +10,7 @@
 // "optimize_local_area"), through ssk_lm_batch_* (include/ssk_capi.h).
 #pragma once
 #include <deque>
+#include <functional>
 #include <map>
 #include <set>
 #include <unordered_map>
@@ -88,8 +89,13 @@ public:
 		int host_threads = 0, n_stage1 = 0, n_stage2 = 0, stage2_max_edges = 0, stage2_max_obs = 0;
 		double stage2_mean_edges = 0, stage2_mean_obs = 0, stage1_mean_obs = 0, stage1_mean_iters = 0, stage2_mean_iters = 0;
 		char stage1_kernel[96] = {0}, stage2_kernel[96] = {0};
+		double teardown_ms = 0, total_ms = 0;               // round 6: the windows' host arrays freed (side by side); the whole call
 	};
 	static void define_new_keyframe_batch(const std::vector<mySRBA*>& engines, const std::vector<const new_kf_observations_t*>& obs,
+	                                      std::vector<TNewKeyFrameInfo>& out, bool run_local_optimization, TBatchTiming* timing = nullptr);
+	// the same with the observation list of engine i produced by fill(i, list) ON the host thread that does the engine's bookkeeping (a C caller's
+	// records are converted there, side by side, instead of one list after the other in front of the call)
+	static void define_new_keyframe_batch(const std::vector<mySRBA*>& engines, const std::function<void(int, new_kf_observations_t&)>& fill,
 	                                      std::vector<TNewKeyFrameInfo>& out, bool run_local_optimization, TBatchTiming* timing = nullptr);
 
 	// pose of `target` as seen from `root` by composing edges along the breadth-first tree (depth limited):
@@ -137,6 +143,9 @@ private:
 	void lm_launch(lm_job& j, bool robust, bool refresh);
 	void lm_collect(lm_job& j, TOptimizeResults& res);
 	// the pieces of define_new_keyframe the lock-step batch form shares with it
+	static void define_new_keyframe_batch_impl(const std::vector<mySRBA*>& engines, const std::vector<const new_kf_observations_t*>* obs,
+	                                           const std::function<void(int, new_kf_observations_t&)>* fill, std::vector<TNewKeyFrameInfo>& out,
+	                                           bool run_local_optimization, TBatchTiming* timing);
 	void kf_begin(const new_kf_observations_t& obs, TNewKeyFrameInfo& out, std::vector<TNewEdgeInfo>& new_edges);
 	void stage1_prepare(lm_job& j, TKeyFrameID new_kf_id, const std::vector<TNewEdgeInfo>& new_edges, bool create) const;
 	void stage2_prepare(lm_job& j, TKeyFrameID new_kf_id, bool create) const;

@@ -2,6 +2,8 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <functional>
+#include <exception>
 #include <vector>
 #include "../../include/ssk_rba.h"
 #include "srba_stereo_slam.h"
@@ -93,13 +95,13 @@ int ssk_rba_define_kf_batch(ssk_rba* const* r, int n, const ssk_rba_obs* const* 
 	if (!r || n < 1 || !obs || !n_obs || !out) return SSK_ERR_BAD_ARG;
 	for (int i = 0; i < n; ++i) if (!r[i] || n_obs[i] < 0 || (n_obs[i] > 0 && !obs[i])) return SSK_ERR_BAD_ARG;
 	return guarded(r[0], [&] {
-		std::vector<ssk::new_kf_observations_t> lists((size_t)n);
-		std::vector<const ssk::new_kf_observations_t*> ptr((size_t)n);
 		std::vector<ssk::mySRBA*> eng((size_t)n);
-		for (int i = 0; i < n; ++i) {
-			lists[(size_t)i].resize((size_t)n_obs[i]);
+		for (int i = 0; i < n; ++i) eng[(size_t)i] = r[i]->rba.get();
+		// (the records of engine i become its observation list on the host thread that does the engine's bookkeeping)
+		const std::function<void(int, ssk::new_kf_observations_t&)> fill = [&](int i, ssk::new_kf_observations_t& list) {
+			list.resize((size_t)n_obs[i]);
 			for (int k = 0; k < n_obs[i]; ++k) {
-				ssk::new_kf_observation_t& o = lists[(size_t)i][(size_t)k];
+				ssk::new_kf_observation_t& o = list[(size_t)k];
 				const ssk_rba_obs& s = obs[i][k];
 				o.is_fixed = false; o.is_unknown_with_init_val = true;
 				o.obs.feat_id = s.feat_id;
@@ -107,11 +109,14 @@ int ssk_rba_define_kf_batch(ssk_rba* const* r, int n, const ssk_rba_obs* const* 
 				o.obs.obs_data.right_px.x = s.right_x; o.obs.obs_data.right_px.y = s.right_y;
 				o.setRelPos(s.rel_pos);
 			}
-			ptr[(size_t)i] = &lists[(size_t)i]; eng[(size_t)i] = r[i]->rba.get();
-		}
+		};
 		std::vector<ssk::TNewKeyFrameInfo> info;
 		ssk::mySRBA::TBatchTiming T;
-		ssk::mySRBA::define_new_keyframe_batch(eng, ptr, info, run_local_optimization != 0, &T);
+		// (a failure of some engines: the batch goes on for the others, the timing and every healthy engine's record are filled in, then the error
+		// -- with the failed engines' indices in its text -- is reported on r[0])
+		std::exception_ptr err;
+		try { ssk::mySRBA::define_new_keyframe_batch(eng, fill, info, run_local_optimization != 0, &T); }
+		catch (...) { err = std::current_exception(); if ((int)info.size() != n) std::rethrow_exception(err); }
 		for (int i = 0; i < n; ++i) {
 			ssk_rba_kf_info& o = out[i];
 			const ssk::TNewKeyFrameInfo& f = info[(size_t)i];
@@ -133,7 +138,9 @@ int ssk_rba_define_kf_batch(ssk_rba* const* r, int n, const ssk_rba_obs* const* 
 			timing->host_threads = T.host_threads; timing->n_stage1 = T.n_stage1; timing->n_stage2 = T.n_stage2;
 			timing->stage2_max_edges = T.stage2_max_edges; timing->stage2_max_obs = T.stage2_max_obs;
 			std::memcpy(timing->stage1_kernel, T.stage1_kernel, sizeof timing->stage1_kernel); std::memcpy(timing->stage2_kernel, T.stage2_kernel, sizeof timing->stage2_kernel);
+			timing->teardown_ms = T.teardown_ms; timing->total_ms = T.total_ms;
 		}
+		if (err) std::rethrow_exception(err);
 	});
 }
 

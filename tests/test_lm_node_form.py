@@ -181,3 +181,18 @@ def test_node_form_two_nodes_of_a_landmark_on_one_edge(emu):
     assert n_mod > 50
     w2 = sl.Window(win.edge_unknown_slot, win.edge_inv_pose, win.lm_unknown_slot, win.lm_pos, win.obs_lm, win.obs_px, off, pe)
     check(emu, w2, sl.make_params())
+
+
+def test_builder_tables_unchanged(emu):
+    """The symbolic builder's tables (all 16, node and split form) against the golden hashes written with the round-5 builder
+    (tests/golden/make_node_table_hashes.py): the round-6 rewrite of its loops -- per-thread workspace, rank sort, run-based nesting test,
+    counting sorts, one sort key per landmark -- changes no byte of any table."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_node_table_hashes as g
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "node_table_hashes.json")))
+    assert len(gold) == len(g.CASES)
+    for case in g.CASES:
+        got = g.hashes(emu, case)
+        assert got == gold["%s/%d" % (case[0], case[1])], case[:2]

@@ -26,6 +26,16 @@ def test_cubic_roots_known_answers(oracle):
     assert np.allclose(roots_of(oracle, 0, 0, 4, -2), [0.5], atol=1e-15) and roots_of(oracle, 0, 0, 0, 1) == []
     r = roots_of(oracle, 1e-3, 5.0, -2.0, -7.0)
     assert len(r) == 3 and np.allclose(np.polyval([1e-3, 5.0, -2.0, -7.0], r), 0, atol=1e-6) and r == sorted(r)
+    # a tiny positive discriminant of the derivative (x1 ~ x2) where rounding puts the computed maximum BELOW and the minimum ABOVE zero
+    # (f1 < 0 < f2): neither the left nor the right branch holds, the contract is "no root" -- the kernel's constant-index form
+    # (ssk_fmat.hip cubic_roots) returns 0 there too (round 5's form returned one root at 0.0)
+    for a, b, c in ((-1.6873137759738683, 0.9490092595303973, -0.1779195996813775), (1.7844254853258175, 1.0613914375600926, 0.21044154789875924),
+                    (2.31707748495605, 1.789616023763401, 0.4607421105976299)):
+        ev = lambda x: ((x + a) * x + b) * x + c
+        disc = a * a - 3.0 * b
+        x1, x2 = (-a - np.sqrt(disc)) / 3.0, (-a + np.sqrt(disc)) / 3.0
+        assert disc > 0 and ev(x1) < 0.0 < ev(x2)                                            # the case itself, in IEEE double
+        assert roots_of(oracle, 1.0, a, b, c) == []
 
 
 def test_sampler_is_counter_based_and_distinct(oracle):
