@@ -1775,8 +1775,35 @@ static int lm_batch_create_impl(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	return SSK_OK;
 }
 
+// SSK_LM_DUMP=<directory> (diagnostic, read per call): every window handed to ssk_lm_batch_create is written to <directory>/win_<counter>.bin -- eight
+// 64-bit counts (edges, 12 x edges, landmarks, 3 x landmarks, observations, 4 x observations, observations + 1, path entries), then the arrays in
+// that order: the format tools / tests replay through the symbolic builder on the CPU
+static void lm_dump_windows(const ssk_lm_window* windows, int n_windows)
+{
+	const char* dir = std::getenv("SSK_LM_DUMP");
+	if (!dir || !windows) return;
+	static std::atomic<int> counter{0};
+	for (int w = 0; w < n_windows; ++w) {
+		const ssk_lm_window& W = windows[w];
+		char path[512];
+		std::snprintf(path, sizeof path, "%s/win_%05d.bin", dir, counter++);
+		FILE* f = std::fopen(path, "wb");
+		if (!f) return;
+		const long long np = W.n_obs ? W.obs_path_off[W.n_obs] : 0;
+		const long long n[8] = {W.n_edges_total, 12LL * W.n_edges_total, W.n_lms_total, 3LL * W.n_lms_total, W.n_obs, 4LL * W.n_obs, W.n_obs + 1LL, np};
+		std::fwrite(n, sizeof n[0], 8, f);
+		std::fwrite(W.edge_unknown_slot, 4, (size_t)n[0], f); std::fwrite(W.edge_inv_pose, 8, (size_t)n[1], f);
+		std::fwrite(W.lm_unknown_slot, 4, (size_t)n[2], f); std::fwrite(W.lm_pos, 8, (size_t)n[3], f);
+		std::fwrite(W.obs_lm, 4, (size_t)n[4], f); std::fwrite(W.obs_px, 4, (size_t)n[5], f);
+		if (W.n_obs) std::fwrite(W.obs_path_off, 4, (size_t)n[6], f); else { const int z = 0; std::fwrite(&z, 4, 1, f); }
+		if (np) std::fwrite(W.path_edge, 4, (size_t)np, f);
+		std::fclose(f);
+	}
+}
+
 int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out)
 {
+	if (ctx && n_windows > 0) lm_dump_windows(windows, n_windows);
 	// SSK_LM_KERNEL: l2 = the general scratch-in-L2 kernel, tiled / coop = the slot kernels (one / several workgroups per window),
 	// acc = on-chip accumulation (windows with E <= SSK_LMA_MAX_E; on request: its accumulators cost LDS, i.e. more tiles per pass)
 	const char* force = ctx->env.lm_kernel.empty() ? nullptr : ctx->env.lm_kernel.c_str();

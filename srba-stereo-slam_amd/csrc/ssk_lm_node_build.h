@@ -154,7 +154,7 @@ struct workspace {
 	std::vector<int> suf_len, obs_suf, chain, suf_es, rank, child, sib, stack, node_mark, node_idx;
 	std::vector<char> suf_opt;
 	std::vector<uint64_t> path_key;                       // whole-path cache: hash -> (first path entry of a representative, length, id)
-	std::vector<int> path_p0, path_id;
+	std::vector<int> path_p0, path_n, path_id;
 	std::vector<int> lo_off, lo_idx, next, lm_sorted, ord;
 	std::vector<uint64_t> okey;
 	std::vector<node> nodes;
@@ -203,7 +203,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		// whole paths seen before (direct mapped, 1024 entries): the observations of a keyframe reach a handful of base keyframes in turn, a path
 		// step by step is one trie lookup per edge
 		constexpr int PC = 1024;
-		S.path_key.assign(PC, ~(uint64_t)0); S.path_p0.resize(PC); S.path_id.resize(PC);
+		S.path_key.assign(PC, ~(uint64_t)0); S.path_p0.resize(PC); S.path_n.resize(PC); S.path_id.resize(PC);
 		const int* prev = nullptr;
 		int prev_n = -1, prev_id = 0;
 		for (int o = 0; o < n_obs; ++o) {
@@ -211,13 +211,14 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 			if (pn > MAXP) return false;
 			// the observations of one keyframe pair follow each other and share their path
 			if (pn == prev_n && (pn == 0 || std::memcmp(prev, Wn.path_edge + p0, sizeof(int) * (size_t)pn) == 0)) { obs_suf[(size_t)o] = prev_id; continue; }
-			uint64_t hk = (uint64_t)pn;
-			for (int p = 0; p < pn; ++p) hk = (hk ^ (uint32_t)Wn.path_edge[p0 + p]) * 0x9E3779B97F4A7C15ull;
-			hk ^= hk >> 29;
+			// (the key is only a filter: a hit is a slot whose stored LENGTH and entries equal this path's -- a first version compared the entries over
+			//  this path's length alone and hashed [2, 0] to the empty path's key: the estimator's windows caught it, the seeded test windows did not)
+			uint64_t hk = 0x243F6A8885A308D3ull ^ (uint64_t)pn;
+			for (int p = 0; p < pn; ++p) { hk = (hk ^ (uint32_t)Wn.path_edge[p0 + p]) * 0x9E3779B97F4A7C15ull; hk ^= hk >> 32; }
 			if (hk == ~(uint64_t)0) hk = 0;
 			const size_t slot = (size_t)(hk >> 7) & (PC - 1);
 			int cur = 0;
-			if (S.path_key[slot] == hk && std::memcmp(Wn.path_edge + S.path_p0[slot], Wn.path_edge + p0, sizeof(int) * (size_t)pn) == 0) cur = S.path_id[slot];
+			if (S.path_key[slot] == hk && S.path_n[slot] == pn && (pn == 0 || std::memcmp(Wn.path_edge + S.path_p0[slot], Wn.path_edge + p0, sizeof(int) * (size_t)pn) == 0)) cur = S.path_id[slot];
 			else {
 				for (int p = p0 + pn - 1; p >= p0; --p) {
 					const uint64_t key = ((uint64_t)(uint32_t)Wn.path_edge[p] << 32) | (uint32_t)cur;
@@ -226,7 +227,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 					if (ins) { suf.push_back(nd_i2{Wn.path_edge[p], cur}); suf_len.push_back(suf_len[(size_t)cur] + 1); }
 					cur = id;
 				}
-				S.path_key[slot] = hk; S.path_p0[slot] = p0; S.path_id[slot] = cur;
+				S.path_key[slot] = hk; S.path_p0[slot] = p0; S.path_n[slot] = pn; S.path_id[slot] = cur;
 			}
 			obs_suf[(size_t)o] = cur;
 			prev = Wn.path_edge + p0; prev_n = pn; prev_id = cur;
