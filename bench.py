@@ -264,6 +264,7 @@ def main():
                     help="frames of the un-batched pass at N=1 (the estimator's frame loop, one ssk_slam_process_frame per stereo pair: what a "
                          "user of performStereoSLAM sees; reported as `unbatched`, never as `value`; 0 = skip)")
     ap.add_argument("--e2e-streams", type=int, default=1024, help="streams of the `e2e_stage2` pass at N=1 (lock-step keyframe streams with stage 1 + stage 2 per keyframe; 0 = skip)")
+    ap.add_argument("--e2e-groups", type=int, default=2, help="groups the e2e_stage2 streams are dealt out over (a host thread and a HIP stream each; 1 = serial)")
     ap.add_argument("--e2e-depth5-streams", type=int, default=128, help="streams of its optimise-depth-5 figure (0 = skip)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: LM solves on a second HIP stream beside the front-end / DA kernels (measured: +1 %, the LM workgroups fill every CU)")
@@ -652,68 +653,113 @@ def main():
     # The streams alternate between the batch's two image sets (each step the other set is the new keyframe: the same scene from the other
     # viewpoint), so a stream's landmarks are re-observed keyframe after keyframe and its local areas reach their steady size after
     # `warm` keyframes (submap_size 10, depth 2: the headline's E = 10 window shape; depth 5: the reference's KITTI.ini:104-106).
-    def e2e_stage2_pass(depth, n_streams, warm, timed):
-        Bs = n_streams
-        kfA = capi.KfBatch(ctx, Bs, W, H, 512); kfB = capi.KfBatch(ctx, Bs, W, H, 512)
-        kfA.image_tensor().copy_(cur.image_tensor()[:Bs]); kfB.image_tensor().copy_(prev.image_tensor()[:Bs])
-        sets = [kfA, kfB]
-        prs = np.stack([np.arange(Bs), np.arange(Bs)], 1).astype(np.int32)
-        s_idx = torch.empty(Bs * N, dtype=torch.int32, device=dev); s_dist = torch.empty(Bs * N, dtype=torch.int32, device=dev)
-        s_st = torch.empty(Bs * N, dtype=torch.int32, device=dev); s_tr = torch.empty(Bs, dtype=torch.int32, device=dev)
-        d_px = torch.zeros(Bs, N, 4, dtype=torch.float32, device=dev); d_pos = torch.zeros(Bs, N, 3, dtype=torch.float64, device=dev)
-        opts = capi.RbaOptions.kitti(submap_size=10, max_tree_depth=4, max_optimize_depth=depth)
-        engines = [capi.Rba(ctx, opts) for _ in range(Bs)]
-        ids_prev = None
-        ids_cur = np.empty((Bs, N), np.int64)
+    # Round 6: the streams are independent, so they are dealt out over `groups` host threads, each with a context (HIP stream) of its own and its share of
+    # the streams: while one group's host side builds windows / symbolic tables, another group's kernels run -- the serial form left the device idle for
+    # two thirds of a step.  groups = 1 is the serial form (reported as `serial`).
+    def e2e_stage2_pass(depth, n_streams, warm, timed, groups=1):
+        import threading
         flib = capi.load_facade_library()
-        next_id = np.zeros(Bs, np.int64)
-        obs = np.zeros((Bs, N), capi.RBA_OBS_DTYPE)
-        ar = np.arange(N)[None, :]
-        stream_base = (np.arange(Bs, dtype=np.int64) << 40)[:, None]
-        t_ph = np.zeros(4)
-        last_tm, stats, per_step = None, [], []
-        def one(k, timed_):
-            nonlocal ids_prev, ids_cur, last_tm
-            c, p = sets[k % 2], sets[(k + 1) % 2]
-            t0 = time.perf_counter()
-            c.run_frontend(fp)
-            if k > 0:
-                ctx.da_run_batch(c, p, prs, da, s_idx, s_dist, s_st, s_tr)
-                ctx.fm_run_batch(c, p, prs, fm, s_idx, s_st, s_tr)
-                ctx.cip_run_batch(c, p, prs, cp, s_idx, s_st, s_tr)
-                c.bow_transform(voc); c.bow_query(db, 4)
-            c.build_observations(lp, d_px, d_pos)
-            ctx.synchronize()
-            t1 = time.perf_counter()
-            _, nm = c.counts()
-            nm = np.minimum(np.asarray(nm, np.int64), N)
-            px = d_px.cpu().numpy(); pos = d_pos.cpu().numpy()
-            st = s_st.view(Bs, N).cpu().numpy() if k > 0 else None
-            ti = s_idx.view(Bs, N).cpu().numpy() if k > 0 else None
-            nm32 = nm.astype(np.int32)
-            # EST.cpp:666-704 for the batch: tracked matches inherit the previous keyframe's landmark ids, the others found new landmarks (library entry)
-            rc = flib.ssk_rba_obs_from_da_batch(Bs, N, capi._ptr(nm32), capi._ptr(st) if k > 0 else None, capi._ptr(ti) if k > 0 else None, capi._ptr(px), capi._ptr(pos),
-                                                capi._ptr(ids_prev) if k > 0 else None, capi._ptr(next_id), capi._ptr(ids_cur), capi._ptr(obs))
-            assert rc == 0
-            ids_prev, ids_cur = ids_cur, (ids_prev if ids_prev is not None else np.empty((Bs, N), np.int64))
-            t2 = time.perf_counter()
-            infos, tm = capi.rba_define_kf_batch(engines, (obs, nm32), optimize=k > 0)
-            t3 = time.perf_counter()
-            if timed_:
-                t_ph[:] += [t1 - t0, t2 - t1, t3 - t2, t3 - t0]
-                last_tm = tm
-                per_step.append(dict(tm, step_ms=1e3 * (t3 - t0)))
-                tracked_n = float(((st == 0) & (ti >= 0) & (ar < nm[:, None])).sum(1).mean()) if k > 0 else 0.0      # (statistics: outside the timed interval)
-                stats.append((tracked_n, float(np.mean([i.total_sqr_error_final <= i.total_sqr_error_init * (1 + 1e-12) for i in infos]))))
-        for k in range(warm):
-            one(k, False)
-        for k in range(warm, warm + timed):
-            one(k, True)
-        t_ph /= timed
-        for e in engines:
-            e.close()
-        kfA.close(); kfB.close()
-        st_ = np.mean(np.array(stats), 0)
+        opts = capi.RbaOptions.kitti(submap_size=10, max_tree_depth=4, max_optimize_depth=depth)
+        G = max(1, min(groups, n_streams))
+        bounds = [n_streams * g // G for g in range(G + 1)]
+
+        class Group:
+            def __init__(self, g):
+                self.lo, self.hi = bounds[g], bounds[g + 1]
+                Bs = self.Bs = self.hi - self.lo
+                self.ctx = ctx if G == 1 else pkg.Context(local)
+                self.kf = [capi.KfBatch(self.ctx, Bs, W, H, 512), capi.KfBatch(self.ctx, Bs, W, H, 512)]
+                self.kf[0].image_tensor().copy_(cur.image_tensor()[self.lo:self.hi]); self.kf[1].image_tensor().copy_(prev.image_tensor()[self.lo:self.hi])
+                self.prs = np.stack([np.arange(Bs), np.arange(Bs)], 1).astype(np.int32)
+                self.s_idx = torch.empty(Bs * N, dtype=torch.int32, device=dev); self.s_dist = torch.empty(Bs * N, dtype=torch.int32, device=dev)
+                self.s_st = torch.empty(Bs * N, dtype=torch.int32, device=dev); self.s_tr = torch.empty(Bs, dtype=torch.int32, device=dev)
+                self.d_px = torch.zeros(Bs, N, 4, dtype=torch.float32, device=dev); self.d_pos = torch.zeros(Bs, N, 3, dtype=torch.float64, device=dev)
+                self.engines = [capi.Rba(self.ctx, opts) for _ in range(Bs)]
+                self.handles = (C.c_void_p * Bs)(*[e.h_ for e in self.engines])
+                self.ids_prev = None
+                self.ids_cur = np.empty((Bs, N), np.int64)
+                self.next_id = np.zeros(Bs, np.int64)
+                self.obs = np.zeros((Bs, N), capi.RBA_OBS_DTYPE)
+                self.ar = np.arange(N)[None, :]
+                self.t_ph = np.zeros(4)
+                self.last_tm, self.stats, self.per_step = None, [], []
+                self.error = None
+
+            def one(self, k, timed_):
+                Bs = self.Bs
+                c, p = self.kf[k % 2], self.kf[(k + 1) % 2]
+                t0 = time.perf_counter()
+                c.run_frontend(fp)
+                if k > 0:
+                    self.ctx.da_run_batch(c, p, self.prs, da, self.s_idx, self.s_dist, self.s_st, self.s_tr)
+                    self.ctx.fm_run_batch(c, p, self.prs, fm, self.s_idx, self.s_st, self.s_tr)
+                    self.ctx.cip_run_batch(c, p, self.prs, cp, self.s_idx, self.s_st, self.s_tr)
+                    c.bow_transform(voc); c.bow_query(db, 4)
+                c.build_observations(lp, self.d_px, self.d_pos)
+                self.ctx.synchronize()
+                t1 = time.perf_counter()
+                _, nm = c.counts()
+                nm = np.minimum(np.asarray(nm, np.int64), N)
+                px = self.d_px.cpu().numpy(); pos = self.d_pos.cpu().numpy()
+                st = self.s_st.view(Bs, N).cpu().numpy() if k > 0 else None
+                ti = self.s_idx.view(Bs, N).cpu().numpy() if k > 0 else None
+                nm32 = nm.astype(np.int32)
+                # EST.cpp:666-704 for the batch: tracked matches inherit the previous keyframe's landmark ids, the others found new landmarks (library entry)
+                rc = flib.ssk_rba_obs_from_da_batch(Bs, N, capi._ptr(nm32), capi._ptr(st) if k > 0 else None, capi._ptr(ti) if k > 0 else None, capi._ptr(px), capi._ptr(pos),
+                                                    capi._ptr(self.ids_prev) if k > 0 else None, capi._ptr(self.next_id), capi._ptr(self.ids_cur), capi._ptr(self.obs))
+                assert rc == 0
+                self.ids_prev, self.ids_cur = self.ids_cur, (self.ids_prev if self.ids_prev is not None else np.empty((Bs, N), np.int64))
+                t2 = time.perf_counter()
+                infos, tm = capi.rba_define_kf_batch(self.engines, (self.obs, nm32), optimize=k > 0, handles=self.handles)
+                t3 = time.perf_counter()
+                if timed_:
+                    self.t_ph[:] += [t1 - t0, t2 - t1, t3 - t2, t3 - t0]
+                    self.last_tm = tm
+                    self.per_step.append(dict(tm, step_ms=1e3 * (t3 - t0)))
+                    tracked_n = float(((st == 0) & (ti >= 0) & (self.ar < nm[:, None])).sum(1).mean()) if k > 0 else 0.0      # (statistics: outside the timed interval)
+                    self.stats.append((tracked_n, float(np.mean([i.total_sqr_error_final <= i.total_sqr_error_init * (1 + 1e-12) for i in infos]))))
+
+            def close(self):
+                for e in self.engines:
+                    e.close()
+                self.kf[0].close(); self.kf[1].close()
+                if self.ctx is not ctx:
+                    self.ctx.close()
+
+        grp = [Group(g) for g in range(G)]
+        torch.cuda.synchronize()
+        gate = threading.Barrier(G + 1)
+        def run(gr):
+            try:
+                for k in range(warm):
+                    gr.one(k, False)
+                gate.wait()                                        # (every group warm: the clock starts)
+                for k in range(warm, warm + timed):
+                    gr.one(k, True)
+            except BaseException as ex:                          # (a failed group must not leave the others at the barrier)
+                gr.error = ex
+                gate.abort()
+        th = [threading.Thread(target=run, args=(gr,)) for gr in grp]
+        for t_ in th:
+            t_.start()
+        try:
+            gate.wait()
+        except threading.BrokenBarrierError:
+            pass
+        tw0 = time.perf_counter()
+        for t_ in th:
+            t_.join()
+        wall = time.perf_counter() - tw0
+        for gr in grp:
+            if gr.error is not None:
+                raise gr.error
+        g0 = grp[0]
+        t_ph = g0.t_ph / timed
+        last_tm, per_step = g0.last_tm, g0.per_step
+        st_ = np.mean(np.array([x for gr in grp for x in gr.stats]), 0)
+        for gr in grp:
+            gr.close()
+        Bs = n_streams
         # (means over the timed steps: a submap's cycle has local areas of 1 .. 10+ edges, the last step alone says little; maxima stay maxima)
         tmd = {}
         for k2, v in last_tm.items():
@@ -724,21 +770,30 @@ def main():
                 tmd[k2] = v
         if os.environ.get("SSK_BENCH_E2E_STEPS") == "1":
             tmd["per_step"] = [{k2: (round(v, 3) if isinstance(v, float) else v) for k2, v in d.items()} for d in per_step]
-        return {"value": Bs / t_ph[3], "unit": "keyframes/s", "streams": Bs, "optimize_depth": depth, "keyframes_per_stream_before_timing": warm, "steps": timed,
-                "ms_per_step": 1e3 * t_ph[3],
-                "ms": {"front_end_da_a10_a11": 1e3 * t_ph[0], "download_and_landmark_ids": 1e3 * t_ph[1], "define_new_keyframe_batch": 1e3 * t_ph[2]},
+        return {"value": Bs * timed / wall, "unit": "keyframes/s", "streams": Bs, "stream_groups": G, "optimize_depth": depth, "keyframes_per_stream_before_timing": warm, "steps": timed,
+                "ms_per_step": 1e3 * wall / timed,
+                "group0_streams": g0.Bs, "group0_ms_per_step": 1e3 * t_ph[3],
+                "group0_ms": {"front_end_da_a10_a11": 1e3 * t_ph[0], "download_and_landmark_ids": 1e3 * t_ph[1], "define_new_keyframe_batch": 1e3 * t_ph[2]},
                 "define_new_keyframe_batch": tmd, "mean_tracked_vs_prev": st_[0], "windows_with_error_not_increased": st_[1], "host_cpu_quota": cpu_quota(),
-                "note": "B independent streams in lock-step: per step and stream one new keyframe -- front-end, data association against the stream's previous "
+                "note": "B independent streams: per step and stream one new keyframe -- front-end, data association against the stream's previous "
                         "keyframe, the two outlier filters, place recognition, a10 / a11, landmark ids, then define_new_keyframe (EST.cpp:782-784) of all "
-                        "streams by ssk_rba_define_kf_batch: stage 1 (the new edge, landmarks held: lm_pose_only_kernel) as ONE LM batch, the local area "
+                        "streams of a group by ssk_rba_define_kf_batch: stage 1 (the new edge, landmarks held: lm_pose_only_kernel) as ONE LM batch, the local area "
                         "(optimise depth as stated; submap_size 10, max_tree_depth 4) as another, results written back to every stream's map.  Host parts "
-                        "(graph bookkeeping, window building, the LM batches' symbolic builds) run on `host_threads` threads under the box's CPU quota"}
+                        "(graph bookkeeping, window building, the LM batches' symbolic builds) run on `host_threads` threads under the box's CPU quota.  "
+                        "`stream_groups` groups of streams, each in lock-step on a host thread and a HIP stream of its own, run side by side (one group's host "
+                        "work beside another's kernels); value = streams x timed steps / wall time of all groups; group0_*: the first group's own clock "
+                        "(its steps overlap the other groups'); define_new_keyframe_batch: means over group 0's timed steps"}
 
     e2e_stage2 = None
     if world == 1 and rank == 0 and not exchange and args.e2e_streams > 0:
-        e2e_stage2 = e2e_stage2_pass(2, min(args.e2e_streams, B), 11, 10)      # (ten timed steps: one full cycle of a 10-keyframe submap, local areas of 1 .. 10 edges)
+        # (21 keyframes before the clock: two cycles of a 10-keyframe submap -- the pinned table arena and the slabs have their steady sizes; ten timed
+        # steps: one full cycle, local areas of 1 .. 10+ edges)
+        e2e_stage2 = e2e_stage2_pass(2, min(args.e2e_streams, B), 21, 10, groups=args.e2e_groups)
+        if args.e2e_groups > 1:
+            ser = e2e_stage2_pass(2, min(args.e2e_streams, B), 21, 10, groups=1)
+            e2e_stage2["serial"] = {k2: ser[k2] for k2 in ("value", "ms_per_step", "group0_ms", "define_new_keyframe_batch")}
         if args.e2e_depth5_streams > 0:
-            e2e_stage2["depth5"] = e2e_stage2_pass(5, min(args.e2e_depth5_streams, B), 44, 2)
+            e2e_stage2["depth5"] = e2e_stage2_pass(5, min(args.e2e_depth5_streams, B), 44, 2, groups=min(args.e2e_groups, 2))
 
     # ---- the reference's real per-keyframe LM load (reported beside `value`): define_new_keyframe does TWO solves per keyframe
     # (EST.cpp:782-784): stage 1 = optimize_edges on the new edge with the landmarks held, stage 2 = optimize_local_area with

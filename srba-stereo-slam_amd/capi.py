@@ -396,7 +396,7 @@ class RbaBatchTiming(C.Structure):
         return d
 
 
-def rba_define_kf_batch(engines, obs_lists, optimize=True):
+def rba_define_kf_batch(engines, obs_lists, optimize=True, handles=None):
     """ssk_rba_define_kf_batch: the engines (one context) advanced in lock-step, engine i with obs_lists[i].  Returns (infos, timing dict)."""
     n = len(engines)
     lib = engines[0].lib
@@ -409,7 +409,7 @@ def rba_define_kf_batch(engines, obs_lists, optimize=True):
         arrs = [np.ascontiguousarray(o, RBA_OBS_DTYPE) for o in obs_lists]
         ps = (C.c_void_p * n)(*[a.ctypes.data if len(a) else None for a in arrs])
         ns = np.array([len(a) for a in arrs], np.int32)
-    hs = engines if isinstance(engines, C.Array) else (C.c_void_p * n)(*[e.h_ for e in engines])
+    hs = handles if handles is not None else (engines if isinstance(engines, C.Array) else (C.c_void_p * n)(*[e.h_ for e in engines]))
     infos = (RbaKfInfo * n)()
     tm = RbaBatchTiming()
     engines[0].ctx.lib.ssk_env_refresh(engines[0].ctx.h)

@@ -492,22 +492,69 @@ void mySRBA::define_new_keyframe(const new_kf_observations_t& obs, TNewKeyFrameI
 
 // ---- lock-step batch of engines (round 5) ----
 namespace {
+// The batch form's host threads: a pool per CALLING thread (two groups of streams driven from two threads do not take turns), workers asleep on a
+// condition variable between jobs -- the round-5 form spawned and joined n_threads std::threads for each of a call's four parallel sections
+// (~100 thread creations per call).  run(): items 0 .. n-1 dealt out one at a time to the workers and the caller; the first exception is rethrown.
+struct host_pool {
+	std::mutex mx;
+	std::condition_variable cv, cv_done;
+	std::vector<std::thread> workers;
+	const std::function<void(int)>* fn = nullptr;
+	std::atomic<int> next{0};
+	int n_items = 0, gen = 0, want = 0, busy = 0;
+	bool stop = false;
+	std::exception_ptr err;
+	void body()
+	{
+		try { for (int i = next++; i < n_items; i = next++) (*fn)(i); }
+		catch (...) { std::lock_guard<std::mutex> lk(mx); if (!err) err = std::current_exception(); next = n_items; }
+	}
+	void work()
+	{
+		int seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(mx);
+				cv.wait(lk, [&] { return stop || (gen != seen && want > 0); });
+				if (stop) return;
+				seen = gen; --want;
+			}
+			body();
+			{
+				std::lock_guard<std::mutex> lk(mx);
+				if (--busy == 0) cv_done.notify_one();
+			}
+		}
+	}
+	void run(int threads, int n, const std::function<void(int)>& f)
+	{
+		const int helpers = std::max(0, std::min(threads, n) - 1);
+		while ((int)workers.size() < helpers) workers.emplace_back([this] { work(); });
+		{
+			std::lock_guard<std::mutex> lk(mx);
+			fn = &f; n_items = n; next = 0; want = helpers; busy = helpers; ++gen; err = nullptr;
+		}
+		if (helpers) cv.notify_all();
+		body();
+		std::unique_lock<std::mutex> lk(mx);
+		cv_done.wait(lk, [&] { return busy == 0; });
+		fn = nullptr;
+		if (err) { std::exception_ptr e = err; err = nullptr; std::rethrow_exception(e); }
+	}
+	~host_pool()
+	{
+		{ std::lock_guard<std::mutex> lk(mx); stop = true; }
+		cv.notify_all();
+		for (std::thread& th : workers) th.join();
+	}
+};
 template <class F>
 void parallel_for(int n, int n_threads, F f)
 {
 	if (n_threads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
-	std::atomic<int> next{0};
-	std::exception_ptr err;
-	std::mutex mx;
-	auto body = [&] {
-		try { for (int i = next++; i < n; i = next++) f(i); }
-		catch (...) { std::lock_guard<std::mutex> lk(mx); if (!err) err = std::current_exception(); }
-	};
-	std::vector<std::thread> th;
-	for (int t = 1; t < std::min(n_threads, n); ++t) th.emplace_back(body);
-	body();
-	for (std::thread& t : th) t.join();
-	if (err) std::rethrow_exception(err);
+	static thread_local host_pool pool;
+	const std::function<void(int)> fn = f;
+	pool.run(n_threads, n, fn);
 }
 int batch_host_threads()
 {

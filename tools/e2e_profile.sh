@@ -11,7 +11,8 @@ python3 - <<PY
 import json
 d=json.loads(open("$out/line.json").read().strip().splitlines()[-1])
 e=d["e2e_stage2"]
-print("e2e_stage2 value", e["value"], "ms_per_step", e["ms_per_step"], e["ms"])
+print("e2e_stage2 value", e["value"], "ms_per_step", e["ms_per_step"], "groups", e["stream_groups"], "group0", e["group0_ms_per_step"], e["group0_ms"])
+if "serial" in e: print("serial value", e["serial"]["value"], "ms_per_step", e["serial"]["ms_per_step"], e["serial"]["group0_ms"], {k: v for k, v in e["serial"]["define_new_keyframe_batch"].items() if k.endswith("_ms")})
 for s in e["define_new_keyframe_batch"].get("per_step", []):
     print({k:v for k,v in s.items() if not k.endswith("kernel")})
 print(e["define_new_keyframe_batch"]["stage2_kernel"])
