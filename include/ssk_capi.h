@@ -311,7 +311,8 @@ typedef struct ssk_kfbatch ssk_kfbatch;
 int ssk_kfbatch_create(ssk_ctx* ctx, int n_kf, int width, int height, int max_feats, ssk_kfbatch** out);
 void ssk_kfbatch_destroy(ssk_kfbatch* b);
 /* Device image storage: pixel (x,y) of eye e (0 left, 1 right) of keyframe k is at
- * d_images[((k*2+e)*height + y)*pitch + x]. */
+ * d_images[((k*2+e)*height + y)*pitch + x].  Zeroed and idle when ssk_kfbatch_create returns: the caller may fill it on any stream, and
+ * makes that stream's writes visible to the context's stream (an event or a synchronisation) before ssk_frontend_run_batch. */
 int ssk_kfbatch_images(ssk_kfbatch* b, uint8_t** d_images, int* pitch);
 int ssk_kfbatch_upload(ssk_ctx* ctx, ssk_kfbatch* b, int kf, const uint8_t* left, const uint8_t* right, int stride);
 /* Front-end over keyframes [kf_begin, kf_end) of the batch, asynchronous on the context stream. */

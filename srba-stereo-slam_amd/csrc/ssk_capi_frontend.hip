@@ -73,6 +73,9 @@ int batch_create(ssk_ctx* ctx, int n_kf, int w, int h, int max_feats, ssk_kfbatc
 	if (e == hipSuccess) e = hipMemsetAsync(b->nkp, 0, ni * 4, ctx->stream);
 	if (e == hipSuccess) e = hipMemsetAsync(b->nm, 0, (size_t)n_kf * 4, ctx->stream);
 	if (e == hipSuccess) e = hipMemsetAsync(b->ncand, 0, ni * 4, ctx->stream);
+	// the storage is the caller's to write when create returns -- through ssk_kfbatch_images on ANY stream (bench.py fills it with torch on the null
+	// stream): a fill still queued on the context's non-blocking stream raced such a write and zeroed the first images of a batch now and then
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 	if (e != hipSuccess) { ssk_kfbatch_destroy(b); return ssk_set_error(ctx, SSK_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
 	*out = b;
 	return SSK_OK;

@@ -65,6 +65,7 @@ struct ssk_lm_batch {
 	// whatever else runs on the device) is waited for by the first stream that touches the batch
 	hipEvent_t ev_ready = nullptr;
 	bool ready_pending = false;
+	size_t guard_off = 0, guard_bytes = 0;   // SSK_LM_GUARD (diagnostic)
 	// a batch may be reset / run on ANOTHER context's stream than the one that created it (bench.py's symbolic pass: one thread creates, another
 	// runs): the end of the last such use, so that ssk_lm_batch_destroy does not recycle a slab that stream still writes (an event, not the context:
 	// the other context may be gone by then)
@@ -105,6 +106,11 @@ int finalize(ssk_lm_batch* b)
 	for (const ssk_lm_batch::req& r : b->reqs) { if (r.copy > 0) up += ssk_pad(r.bytes); total += ssk_pad(r.bytes); }
 	if (total == 0) total = 256;
 	b->up_bytes = up; b->zero_bytes = total - up;
+	// SSK_LM_GUARD=1 (diagnostic): 1 MB behind the batch's arrays filled with a pattern, checked when the batch is destroyed (a kernel writing past its arrays)
+	static const bool guard_on = std::getenv("SSK_LM_GUARD") != nullptr;
+	const size_t guard = guard_on ? ((size_t)1 << 20) : 0;
+	b->guard_off = total; b->guard_bytes = guard;
+	total += guard;
 	{
 		// the smallest cached slab that fits; none: a new one (a cached one that is too small makes room for it)
 		int pick = -1;
@@ -162,6 +168,7 @@ int finalize(ssk_lm_batch* b)
 		if (total > up) SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + up, 0, total - up, ctx->stream));
 		SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // host images / pinned staging are free again when create returns
 	}
+	if (guard) { SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + b->guard_off, 0xA5, guard, ctx->stream)); SSK_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
 	b->reqs.clear();
 	return SSK_OK;
 }
@@ -477,6 +484,15 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 	// it -- the create's own zero fill (when no stream waited for it yet) and whatever another context's stream was given to do on the batch
 	if (b->ev_ready) { if (b->ready_pending) (void)hipEventSynchronize(b->ev_ready); (void)hipEventDestroy(b->ev_ready); }
 	if (b->ev_last) { (void)hipEventSynchronize(b->ev_last); (void)hipEventDestroy(b->ev_last); }
+	if (b->slab && b->guard_bytes) {
+		std::vector<uint8_t> g(b->guard_bytes);
+		(void)hipDeviceSynchronize();
+		(void)hipMemcpy(g.data(), static_cast<uint8_t*>(b->slab) + b->guard_off, b->guard_bytes, hipMemcpyDeviceToHost);
+		size_t bad = 0, first = 0;
+		for (size_t i = 0; i < g.size(); ++i) if (g[i] != 0xA5) { if (!bad) first = i; ++bad; }
+		if (bad) std::fprintf(stderr, "[ssk lm guard] batch of %d windows (node %d, split %d, pose %d): %zu guard bytes overwritten, first at +%zu behind %zu bytes of arrays\n",
+		                      b->n_windows, b->node_n, b->split_n, b->pose_n, bad, first, b->guard_off);
+	}
 	if (b->slab) {
 		ssk_ctx* c = b->ctx;
 		// back to the context's cache: an empty place, else the place of a smaller slab (that one is freed), else freed
