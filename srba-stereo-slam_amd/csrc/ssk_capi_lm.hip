@@ -52,6 +52,7 @@ struct ssk_lm_batch {
 	sp_dev S{};
 	nd_dev N2{};                      // the phase-split windows' node tables (N: the node kernel's); both families' win[] are indexed by the batch's window number
 	int node_n = 0, split_n = 0;      // windows per family (a mixed batch runs both)
+	std::vector<char> family;         // lean batch, per window: 0 node kernel, 1 phase-split kernels, 2 pose-only (the only family that keeps the raw observation arrays)
 	// pose-only windows (ssk_lm_pose.hip: one or two optimised edges, no optimised landmark -- stage 1 of define_new_keyframe): no node tables
 	int pose_n = 0, pose_two = 0;
 	const int* pose_order = nullptr;
@@ -279,6 +280,70 @@ __global__ void pack_shared_kernel(lm_dev D, lm_cam P, int w, int n_shared, cons
 	for (int c = 0; c < 9; ++c) o[3 + c] = acc[c];
 }
 
+// the same for a window of the node / phase-split families, from ITS tables (a lean batch keeps no raw observation arrays for them): the window's
+// observation records (landmark, suffix of the whole path), the suffix trie (first step, rest) unrolled into the path's steps and walked from the base's
+// end exactly as above, the pixel records.  The observations of a landmark come in the tables' order (by landmark group), not the caller's: the sums
+// are the same to rounding.
+__global__ void pack_shared_node_kernel(lm_dev D, nd_dev N, lm_cam P, int w, int n_shared, const int* __restrict__ lm_idx, double* __restrict__ out)
+{
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_shared) return;
+	const lm_win W = D.win[w];
+	const nd_win NW = N.win[w];
+	double* o = out + 12 * (size_t)s;
+	const int li = lm_idx[s];
+	double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // g (3), H upper (6)
+	double f[3] = {0, 0, 0};
+	if (li >= 0 && li < W.n_lms) {
+		const double* fp = D.lm + 3 * (size_t)(W.lm0 + li);
+		f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
+		const double* pose = D.pose + 12 * (size_t)W.edge0;
+		for (int ob = 0; ob < NW.n_obs; ++ob) {
+			const nd_i2 rec = N.obs[NW.obs0 + ob];
+			if (rec.x != li) continue;
+			int codes[8], np = 0;
+			for (int sf = rec.y & 0xFFFF; sf != 0 && np < 8; sf = N.suf[NW.suf0 + sf].y) codes[np++] = N.suf[NW.suf0 + sf].x;      // (first step first)
+			double q[3] = {f[0], f[1], f[2]}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+			for (int i = np - 1; i >= 0; --i) {
+				const int c = codes[i];
+				const double* T = pose + 12 * (c >> 1);
+				const int dir = c & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;
+				const double d0 = dir ? q[0] - T[3] : q[0], d1 = dir ? q[1] - T[7] : q[1], d2 = dir ? q[2] - T[11] : q[2];
+				double t[3], Rn[9];
+				for (int a = 0; a < 3; ++a) {
+					const double r0 = T[si * a], r1 = T[si * a + sj], r2 = T[si * a + 2 * sj];
+					t[a] = r0 * d0 + r1 * d1 + r2 * d2 + (dir ? 0.0 : T[4 * a + 3]);
+					for (int b = 0; b < 3; ++b) Rn[3 * a + b] = r0 * R[b] + r1 * R[3 + b] + r2 * R[6 + b];
+				}
+				for (int a = 0; a < 3; ++a) q[a] = t[a];
+				for (int a = 0; a < 9; ++a) R[a] = Rn[a];
+			}
+			const double e0 = q[0] - P.S[3], e1 = q[1] - P.S[7], e2 = q[2] - P.S[11];
+			double pc[3];
+			for (int a = 0; a < 3; ++a) pc[a] = P.S[a] * e0 + P.S[4 + a] * e1 + P.S[8 + a] * e2;
+			const double iz = 1.0 / pc[2], iz2 = iz * iz;
+			const nd_f4 z = N.px[NW.obs0 + ob];
+			const double r[4] = {(double)z.x - (P.cx_l + P.fx_l * pc[0] * iz), (double)z.y - (P.cy_l + P.fy_l * pc[1] * iz),
+			                     (double)z.z - (P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz), (double)z.w - (P.cy_r + P.fy_r * pc[1] * iz)};
+			const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+			const double wgt = P.robust ? 1.0 / sqrt(sqrt(1.0 + s2 / (P.kernel * P.kernel))) : 1.0;
+			const double Dm[12] = {P.fx_l * iz, 0, -P.fx_l * pc[0] * iz2, 0, P.fy_l * iz, -P.fy_l * pc[1] * iz2,
+			                       P.fx_r * iz, 0, -P.fx_r * (pc[0] - P.baseline) * iz2, 0, P.fy_r * iz, -P.fy_r * pc[1] * iz2};
+			double M[12], Jf[12];                               // M = D R_S^T, Jf = w M R
+			for (int a = 0; a < 4; ++a)
+				for (int b = 0; b < 3; ++b) M[3 * a + b] = Dm[3 * a] * P.S[4 * b] + Dm[3 * a + 1] * P.S[4 * b + 1] + Dm[3 * a + 2] * P.S[4 * b + 2];
+			for (int a = 0; a < 4; ++a)
+				for (int b = 0; b < 3; ++b) Jf[3 * a + b] = wgt * (M[3 * a] * R[b] + M[3 * a + 1] * R[3 + b] + M[3 * a + 2] * R[6 + b]);
+			for (int b = 0; b < 3; ++b) acc[b] += wgt * (Jf[b] * r[0] + Jf[3 + b] * r[1] + Jf[6 + b] * r[2] + Jf[9 + b] * r[3]);
+			int k = 3;
+			for (int a = 0; a < 3; ++a)
+				for (int b = a; b < 3; ++b) acc[k++] += Jf[a] * Jf[b] + Jf[3 + a] * Jf[3 + b] + Jf[6 + a] * Jf[6 + b] + Jf[9 + a] * Jf[9 + b];
+		}
+	}
+	o[0] = f[0]; o[1] = f[1]; o[2] = f[2];
+	for (int c = 0; c < 9; ++c) o[3 + c] = acc[c];
+}
+
 __global__ void stitch_shared_kernel(const double* __restrict__ g, int n_ranks, int n_shared, double lambda, double* __restrict__ pos)
 {
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -349,8 +414,13 @@ int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared,
 	if (n_shared == 0) return SSK_OK;
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
-	hipLaunchKernelGGL(pack_shared_kernel, dim3((n_shared + 63) / 64), dim3(64), 0, ctx->stream, b->D, cam_of(p), w, n_shared, d_lm_idx, d_out);
-	SSK_LAUNCH_CHECK(ctx, "pack_shared_kernel");
+	if (b->lean && b->family[(size_t)w] != 2) {
+		hipLaunchKernelGGL(pack_shared_node_kernel, dim3((n_shared + 63) / 64), dim3(64), 0, ctx->stream, b->D, b->family[(size_t)w] == 1 ? b->N2 : b->N, cam_of(p), w, n_shared, d_lm_idx, d_out);
+		SSK_LAUNCH_CHECK(ctx, "pack_shared_node_kernel");
+	} else {
+		hipLaunchKernelGGL(pack_shared_kernel, dim3((n_shared + 63) / 64), dim3(64), 0, ctx->stream, b->D, cam_of(p), w, n_shared, d_lm_idx, d_out);
+		SSK_LAUNCH_CHECK(ctx, "pack_shared_kernel");
+	}
 	return lm_batch_mark(ctx, b, SSK_OK);
 }
 
@@ -711,8 +781,11 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		if (X.split == 1) { H.h0 = h_total; h_total += (long long)(6 * E + 1) * (6 * E + 2); }
 		if (trace) { dpt += (long long)MAX_ITERS_ALLOC * 6 * E; dft += (long long)MAX_ITERS_ALLOC * 3 * L; }
 		max_n6 = std::max(max_n6, 6 * E);
-		n_edge_t += (size_t)Wn.n_edges_total; n_lm_t += (size_t)Wn.n_lms_total; n_obs_t += (size_t)Wn.n_obs; n_opo_t += (size_t)Wn.n_obs + 1;
-		n_path_t += (size_t)X.n_path; n_us_t += (size_t)E; n_ls_t += (size_t)L;
+		n_edge_t += (size_t)Wn.n_edges_total; n_lm_t += (size_t)Wn.n_lms_total; n_us_t += (size_t)E; n_ls_t += (size_t)L;
+		// the raw observation arrays (landmark, pixels, path offsets, path entries: 36 bytes an observation, a third of a batch's tables) are what the
+		// pose-only kernel reads; the node and phase-split families read their own tables -- the observation and pixel records hold the same -- and so
+		// does ssk_lm_batch_pack_shared for their windows (round 6: those windows' raw arrays are neither placed nor uploaded)
+		if (X.split == 2) { n_obs_t += (size_t)Wn.n_obs; n_opo_t += (size_t)Wn.n_obs + 1; n_path_t += (size_t)X.n_path; }
 		if (X.split == 2) { ++n_pose; if (E == 2) ++n_pose2; max_pose_edges = std::max(max_pose_edges, Wn.n_edges_total); continue; }
 		nd_sizes& z = X.split ? zs : zn;
 		X.off = z;
@@ -773,10 +846,12 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		put(&pose[0] + 12 * (size_t)H.edge0, Wn.edge_inv_pose, 12 * (size_t)Wn.n_edges_total);
 		put(&lm_slot[0] + H.lm0, Wn.lm_unknown_slot, (size_t)Wn.n_lms_total);
 		put(&lm[0] + 3 * (size_t)H.lm0, Wn.lm_pos, 3 * (size_t)Wn.n_lms_total);
-		put(&obs_lm[0] + H.obs0, Wn.obs_lm, (size_t)Wn.n_obs);
-		put(&obs_px[0] + 4 * (size_t)H.obs0, Wn.obs_px, 4 * (size_t)Wn.n_obs);
-		if (Wn.n_obs) put(&obs_path_off[0] + H.opo0, Wn.obs_path_off, (size_t)Wn.n_obs + 1); else obs_path_off[(size_t)H.opo0] = 0;
-		put(&path_edge[0] + H.path0, Wn.path_edge, (size_t)X.n_path);
+		if (X.split == 2) {
+			put(&obs_lm[0] + H.obs0, Wn.obs_lm, (size_t)Wn.n_obs);
+			put(&obs_px[0] + 4 * (size_t)H.obs0, Wn.obs_px, 4 * (size_t)Wn.n_obs);
+			if (Wn.n_obs) put(&obs_path_off[0] + H.opo0, Wn.obs_path_off, (size_t)Wn.n_obs + 1); else obs_path_off[(size_t)H.opo0] = 0;
+			put(&path_edge[0] + H.path0, Wn.path_edge, (size_t)X.n_path);
+		}
 		put(&slot_edge[0] + H.us0, X.s_edge.data(), X.s_edge.size());
 		put(&slot_lm[0] + H.ls0, X.s_lm.data(), X.s_lm.size());
 		w_split[(size_t)w] = X.split;
@@ -806,6 +881,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	b->ctx = ctx; b->n_windows = n_windows; b->trace = trace; b->max_iters_alloc = MAX_ITERS_ALLOC; b->max_n6 = max_n6;
 	b->hdr = hdr; b->n_pose = pose.size(); b->n_lm = lm.size();
 	b->lean = true; b->node_ok = n_node > 0; b->split_ok = n_split > 0; b->node_n = n_node; b->split_n = n_split;
+	b->family = w_split;
 	lm_dev& D = b->D;
 	int rc = SSK_OK;
 #define UP(vec, field) if (!rc) rc = upload(b, vec, &D.field)
