@@ -183,7 +183,28 @@ __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const
 #pragma unroll
 				for (int c = 0; c < 36; ++c) acc[c] = 0.0;
 				FINE0();
+#if ND_GRAD_FUSED
+				// the edge of a diagonal block (pid = e2 (e2 + 1) / 2 + e with e == e2), -1 otherwise: its quad sums the edge's reduced gradient beside
+				// the block (nd_item_grad); only the wavefronts that hold such a block run that form of the item loop
+				int ge = -1;
+				if (!pre && pid != 0xFFFF) {
+					int e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
+					e2 += ((e2 + 1) * (e2 + 2) / 2 <= pid) ? 1 : 0;
+					e2 -= (e2 * (e2 + 1) / 2 > pid) ? 1 : 0;
+					if (pid - e2 * (e2 + 1) / 2 == e2) ge = e2;
+				}
+				double ga[6] = {0, 0, 0, 0, 0, 0};
+#if ND_GRAD_FUSED == 2
+				const bool wave_grad = !pre;                       // (one form of the item loop for every wavefront)
+				nd_pair_items<true>(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc, ga);
+#else
+				const bool wave_grad = __ballot(ge >= 0) != 0ull;
+				if (wave_grad) nd_pair_items<true>(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc, ga);
+				else nd_pair_items<false>(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc, ga);
+#endif
+#else
 				nd_pair_items(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc);
+#endif
 				FINE(5);
 				nd_quad_sum36(acc);
 				// a block cut in two parts sits in the two quads of one aligned lane octet: the second quad's sums come over by a mirror step
@@ -193,6 +214,23 @@ __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const
 #pragma unroll
 					for (int c = 0; c < 36; ++c) acc[c] += on * dpp_f64<0x141>(acc[c]);      // row_half_mirror: lane i <-> 7 - i of its octet
 				}
+#if ND_GRAD_FUSED
+				if (wave_grad) {                                   // (uniform) the gradient sums the same way: the quad's four lanes, then the block's second part
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ga[c] += dpp_f64<0xB1>(ga[c]);
+#pragma unroll
+					for (int c = 0; c < 6; ++c) ga[c] += dpp_f64<0x4E>(ga[c]);
+					if (__builtin_amdgcn_readfirstlane(q.y) < 0) {
+						const double on = ((q.y >> 30) & 1) ? 1.0 : 0.0;
+#pragma unroll
+						for (int c = 0; c < 6; ++c) ga[c] += on * dpp_f64<0x141>(ga[c]);
+					}
+					if (ql == 0 && ge >= 0 && ((q.y >> 28) & 3) == 0) {
+#pragma unroll
+						for (int c = 0; c < 6; ++c) (void)__hip_atomic_fetch_add(g_acc + 6 * ge + c, ga[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+				}
+#endif
 				if (ql == 0 && pid != 0xFFFF && ((q.y >> 28) & 3) == 0) {
 #if ND_HB_ATOMIC
 					// one owner per block and tile: ds_add_f64 without a return is a plain read-modify-write in the LDS unit (no wait for a read)
@@ -216,7 +254,8 @@ __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const
 				FINE(6);
 			}
 #endif
-			if (!pre)
+			FINE0();
+			if (!pre && !(ND_GRAD_FUSED && !SSK_ND_LANE_RUNS))
 				for (int k = quad; k < T.n_gqs; k += NQ) {
 					// reduced gradient of one edge: sum over the tile's nodes on it of [vh; q x vh]
 					const nd_i2 q = N.gqs[W.gqs0 + T.gqs0 + k];
@@ -253,6 +292,7 @@ __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const
 						for (int c = 0; c < 6; ++c) (void)__hip_atomic_fetch_add(g_acc + 6 * e + c, ga[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 				}
+			FINE(7);
 			STAMP(4);
 #if ND_PREFETCH
 			// the next tile's group-phase operands (its records arrived during this tile): in flight across the barrier
@@ -439,8 +479,8 @@ __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const
 			printf("node stamps (cycles, window 0, %d iters, %d tiles): loop top %llu zero %llu | groups: own %llu + barrier %llu, pairs: own %llu + barrier %llu | assemble %llu solve %llu "
 			       "edges + table %llu score %llu decision + copy %llu\n", s_iters, W.n_tiles, s_acc[0], s_acc[1], s_acc[2], s_acc[3], s_acc[4], s_acc[5], s_acc[6], s_acc[7], s_acc[8], s_acc[9], s_acc[10]);
 		if (wi == 0)
-			printf("node fine (thread 0, cumulative over launches): group: loads + observation %llu, run sums %llu, roots %llu, nodes %llu, record stores %llu | pairs: items %llu, quad sum + adds %llu\n",
-			       g_nd_fine[0], g_nd_fine[1], g_nd_fine[2], g_nd_fine[3], g_nd_fine[4], g_nd_fine[5], g_nd_fine[6]);
+			printf("node fine (thread 0, cumulative over launches): group: loads + observation %llu, run sums %llu, roots %llu, nodes %llu, record stores %llu | pairs: items %llu, quad sum + adds %llu, gradient %llu\n",
+			       g_nd_fine[0], g_nd_fine[1], g_nd_fine[2], g_nd_fine[3], g_nd_fine[4], g_nd_fine[5], g_nd_fine[6], g_nd_fine[7]);
 #endif
 	}
 }
