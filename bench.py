@@ -246,9 +246,12 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=-1,
                     help="processes of the all-cores CPU baseline (-1: half the host's logical cores, at most 64; 0 = skip)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--side-stream", type=int, default=0,
-                    help="1: the place-recognition kernels on a second HIP stream beside the data-association chain (both depend only on the "
-                         "front-end); measured +0.8 % at --batch 256, nothing at 1024")
+    ap.add_argument("--side-stream", type=int, default=1,
+                    help="2: behind the front-end the data-association chain, place recognition and the LM batch on three HIP streams side by side; "
+                         "1: the place-recognition kernels on a second HIP stream beside the data-association chain (both depend only on the "
+                         "front-end; round 6, the default: 130.7 -> 135.6 k keyframes/s -- the small kernels of both chains are latency bound at one or two "
+                         "wavefronts per SIMD); 0: one stream.  2 (the LM batch beside both) measured 124 k: the small kernels take wave slots and LDS "
+                         "in front of the LM workgroups")
     ap.add_argument("--shared-landmarks", type=int, default=256)
     ap.add_argument("--pcie-steps", type=int, default=5,
                     help="steps of the PCIe-inclusive pass at N=1 (images uploaded from pinned host memory every step; reported as "
@@ -326,10 +329,28 @@ def main():
     vocab, voc, db = build_place_recognition(capi, ctx, prev)
     side = torch.cuda.Stream() if args.side_stream else None
     ctx_side = pkg.Context(local, stream=side.cuda_stream) if side else None
+    side2 = torch.cuda.Stream() if args.side_stream >= 2 else None
+    ctx_side2 = pkg.Context(local, stream=side2.cuda_stream) if side2 else None
 
     exch_events = []                 # (start, end) HIP events around the exchange of a step, on the LM stream
 
     def step(serial=False, cur=cur, lm=lm, lm_ctx=None):
+        if side2 and not serial and not exchange and lm_ctx is None:
+            # (round 6) behind the front-end three things that do not depend on each other run side by side: the data-association chain (matcher,
+            # direction / distance filters, RANSAC, change in pose) on one stream, place recognition on another, the LM batch on the main one.  The
+            # small kernels are latency bound at one or two wavefronts per SIMD (the RANSAC kernel takes 0.26 ms for 1 024 pairs and for 4 096)
+            # and are queued first: they sit in the gaps of the LM workgroups instead of in front of them
+            cur.run_frontend(fp)
+            side.wait_stream(main_stream); side2.wait_stream(main_stream)
+            ctx_side.da_run_batch(cur, prev, pairs, da, d_idx, d_dist, d_st, d_tr)
+            ctx_side.fm_run_batch(cur, prev, pairs, fm, d_idx, d_st, d_tr)
+            ctx_side.cip_run_batch(cur, prev, pairs, cp, d_idx, d_st, d_tr)
+            cur.bow_transform(voc, ctx=ctx_side2)
+            cur.bow_query(db, 4, ctx=ctx_side2)
+            lm.reset()
+            lm.run(lp)
+            main_stream.wait_stream(side); main_stream.wait_stream(side2)
+            return
         cur.run_frontend(fp)
         if side:
             side.wait_stream(main_stream)
@@ -393,7 +414,7 @@ def main():
     # ---- roofline pass: per-stage kernel time with HIP events on the same stream (all ranks run it, rank 0 reports)
     sync_all()
     ctx.profile_enable(True)
-    extra_ctx = [c for c in (ctx_lm, ctx_side) if c is not None and c is not ctx]
+    extra_ctx = [c for c in (ctx_lm, ctx_side, ctx_side2) if c is not None and c is not ctx]
     for c in extra_ctx:
         c.profile_enable(True)
     prof_steps = max(3, min(args.steps, 10))
