@@ -251,7 +251,8 @@ def main():
                          "1: the place-recognition kernels on a second HIP stream beside the data-association chain (both depend only on the "
                          "front-end; round 6, the default: 130.7 -> 135.6 k keyframes/s -- the small kernels of both chains are latency bound at one or two "
                          "wavefronts per SIMD); 0: one stream.  2 (the LM batch beside both) measured 124 k: the small kernels take wave slots and LDS "
-                         "in front of the LM workgroups")
+                         "in front of the LM workgroups; consecutive batches overlapped (the chains of batch k beside the front-end of batch k + 1, two "
+                         "resident keyframe batches) measured 125 k: kernels of different queues share the CUs badly when both sides want them")
     ap.add_argument("--shared-landmarks", type=int, default=256)
     ap.add_argument("--pcie-steps", type=int, default=5,
                     help="steps of the PCIe-inclusive pass at N=1 (images uploaded from pinned host memory every step; reported as "
