@@ -861,7 +861,7 @@ def main():
         fl = float(np.mean([lm_algorithmic_flops(w) for w in wins5])) * it2 * n
         out["roofline_depth5"] = {"kernel": k2, "bound": "fp64", "achieved": fl / (ms2 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": fl / (ms2 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl, "avg_launch_ms": ms2,
-                                  "note": "host clock around ssk_lm_batch_run + results of %d windows (phase-split kernels: linearise / reduce / solve / score / decide per LM pass, ssk_lm_split.h); the dense solve of K2 runs on the matrix cores (v_mfma_f64_16x16x4_f64; FP64 matrix rate = vector rate on MI355X), the rest on the vector ALUs; kernel-trace and PMC summaries: profiles/r05_lm_depth5*" % n}
+                                  "note": "host clock around ssk_lm_batch_run + results of %d windows (phase-split kernels: linearise / reduce / solve / score / decide per LM pass, ssk_lm_split.h); the dense solve of K2 runs on the matrix cores (v_mfma_f64_16x16x4_f64; FP64 matrix rate = vector rate on MI355X), the rest on the vector ALUs; kernel-trace and PMC summaries: profiles/r06_lm_depth5*" % n}
         # round 5: a window at the 90th percentile of what the full-length un-batched stream produces (profiles/r05_stream_stage2_windows.json: stage-2
         # local areas of 32 / 38 / 68 / 94 optimised edges at the 10th / 50th / 90th percentile / maximum): optimise depth 8 -> 70 edges, 15 k observations
         try:
@@ -897,7 +897,7 @@ def main():
         # (MI355X_MICROARCH.md "HBM"; re-calibrated in the same run on lm_reset_kernel, which reads exactly what it writes)
         LM_KERNEL = lm.kernel_name()
         traffic, traffic_src, pmc_ms = {}, None, {}
-        for tf in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # the newest summary collected at this batch size
+        for tf in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # the newest summary collected at this batch size
             tfp = os.path.join(ROOT, "profiles", tf)
             if traffic or not os.path.exists(tfp):
                 continue
@@ -986,7 +986,7 @@ def main():
                          "frac": lm_ach / HBM_PEAK_GBS, "traffic": traffic_of(LM_KERNEL, lm_avg_ms), "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": lm_algo, "avg_launch_ms": lm_avg_ms,
                          "note": "dominant kernel by time; not bandwidth bound: two persistent workgroups per CU, waves wait on LDS / FP64 dependencies "
-                                 "(profiles/r05_pmc_lm_wave_time.json, DESIGN.md 5); traffic is null when the committed PMC summary's kernel time differs from the live one by more than 8 %"},
+                                 "(profiles/r06_pmc_lm_wave_time.json, DESIGN.md 5); traffic is null when the committed PMC summary's kernel time differs from the live one by more than 8 %"},
             "roofline_fp64": {"kernel": LM_KERNEL, "bound": "fp64", "achieved": lm_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": lm_tflops / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": lm_flops,
                               "executed_flops_per_launch_pmc": pmc_flop,
