@@ -223,12 +223,67 @@ __global__ void build_obs_batch_kernel(const float4* __restrict__ m_obs, const i
 //   set      the new positions back into the window (state and initial state).
 // Alternating this with the windows' own LM solves is block-coordinate descent on the JOINT problem of all submaps: its fixed point is
 // the joint optimum (tests/test_shared_gpu.py, tests/test_dist_cpu.py: equal to a single-process solve of the union).
+// Round 6: ONE WAVEFRONT per shared landmark (a thread per landmark walked the window's whole observation list alone: 1.5 ms of an exchange step on the
+// bench's window): the lanes take the observations in turn, every lane adds up what ITS observations of the landmark say, and the 64 partial sums meet in
+// a fixed shuffle tree -- one owner per observation, a fixed order: the same bits on every run and every GPU (the sums differ from a sequential walk's in
+// the last place).
+__device__ __forceinline__ void pack_one_observation(const lm_cam& P, const double* __restrict__ pose, const int* codes, int np, const double (&f)[3], const float z0, const float z1,
+                                                     const float z2, const float z3, double (&acc)[9])
+{
+	double q[3] = {f[0], f[1], f[2]}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	for (int i = np - 1; i >= 0; --i) {                    // from the base's end of the path to the observer
+		const int c = codes[i];
+		const double* T = pose + 12 * (c >> 1);
+		const int dir = c & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;
+		const double d0 = dir ? q[0] - T[3] : q[0], d1 = dir ? q[1] - T[7] : q[1], d2 = dir ? q[2] - T[11] : q[2];
+		double t[3], Rn[9];
+		for (int a = 0; a < 3; ++a) {
+			const double r0 = T[si * a], r1 = T[si * a + sj], r2 = T[si * a + 2 * sj];
+			t[a] = r0 * d0 + r1 * d1 + r2 * d2 + (dir ? 0.0 : T[4 * a + 3]);
+			for (int b = 0; b < 3; ++b) Rn[3 * a + b] = r0 * R[b] + r1 * R[3 + b] + r2 * R[6 + b];
+		}
+		for (int a = 0; a < 3; ++a) q[a] = t[a];
+		for (int a = 0; a < 9; ++a) R[a] = Rn[a];
+	}
+	const double e0 = q[0] - P.S[3], e1 = q[1] - P.S[7], e2 = q[2] - P.S[11];
+	double pc[3];
+	for (int a = 0; a < 3; ++a) pc[a] = P.S[a] * e0 + P.S[4 + a] * e1 + P.S[8 + a] * e2;
+	const double iz = 1.0 / pc[2], iz2 = iz * iz;
+	const double r[4] = {(double)z0 - (P.cx_l + P.fx_l * pc[0] * iz), (double)z1 - (P.cy_l + P.fy_l * pc[1] * iz),
+	                     (double)z2 - (P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz), (double)z3 - (P.cy_r + P.fy_r * pc[1] * iz)};
+	const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+	const double wgt = P.robust ? 1.0 / sqrt(sqrt(1.0 + s2 / (P.kernel * P.kernel))) : 1.0;
+	const double Dm[12] = {P.fx_l * iz, 0, -P.fx_l * pc[0] * iz2, 0, P.fy_l * iz, -P.fy_l * pc[1] * iz2,
+	                       P.fx_r * iz, 0, -P.fx_r * (pc[0] - P.baseline) * iz2, 0, P.fy_r * iz, -P.fy_r * pc[1] * iz2};
+	double M[12], Jf[12];                                   // M = D R_S^T, Jf = w M R
+	for (int a = 0; a < 4; ++a)
+		for (int b = 0; b < 3; ++b) M[3 * a + b] = Dm[3 * a] * P.S[4 * b] + Dm[3 * a + 1] * P.S[4 * b + 1] + Dm[3 * a + 2] * P.S[4 * b + 2];
+	for (int a = 0; a < 4; ++a)
+		for (int b = 0; b < 3; ++b) Jf[3 * a + b] = wgt * (M[3 * a] * R[b] + M[3 * a + 1] * R[3 + b] + M[3 * a + 2] * R[6 + b]);
+	for (int b = 0; b < 3; ++b) acc[b] += wgt * (Jf[b] * r[0] + Jf[3 + b] * r[1] + Jf[6 + b] * r[2] + Jf[9 + b] * r[3]);
+	int k = 3;
+	for (int a = 0; a < 3; ++a)
+		for (int b = a; b < 3; ++b) acc[k++] += Jf[a] * Jf[b] + Jf[3 + a] * Jf[3 + b] + Jf[6 + a] * Jf[6 + b] + Jf[9 + a] * Jf[9 + b];
+}
+// the 64 lanes' partial sums, pairwise in a fixed tree; lane 0 writes position + g + H of the landmark
+__device__ __forceinline__ void pack_reduce_store(double (&acc)[9], const double (&f)[3], double* __restrict__ o)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+		for (int c = 0; c < 9; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+	if ((threadIdx.x & 63) == 0) {
+		o[0] = f[0]; o[1] = f[1]; o[2] = f[2];
+		for (int c = 0; c < 9; ++c) o[3 + c] = acc[c];
+	}
+}
+
+// from the raw observation arrays (pose-only windows, batches of the full builder)
 __global__ void pack_shared_kernel(lm_dev D, lm_cam P, int w, int n_shared, const int* __restrict__ lm_idx, double* __restrict__ out)
 {
-	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	const int s = blockIdx.x, lane = threadIdx.x & 63;
 	if (s >= n_shared) return;
 	const lm_win W = D.win[w];
-	double* o = out + 12 * (size_t)s;
 	const int li = lm_idx[s];
 	double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // g (3), H upper (6)
 	double f[3] = {0, 0, 0};
@@ -236,61 +291,26 @@ __global__ void pack_shared_kernel(lm_dev D, lm_cam P, int w, int n_shared, cons
 		const double* fp = D.lm + 3 * (size_t)(W.lm0 + li);
 		f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
 		const double* pose = D.pose + 12 * (size_t)W.edge0;
-		for (int ob = 0; ob < W.n_obs; ++ob) {
+		for (int ob = lane; ob < W.n_obs; ob += 64) {
 			if (D.obs_lm[W.obs0 + ob] != li) continue;
-			double q[3] = {f[0], f[1], f[2]}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-			const int pb = D.obs_path_off[W.opo0 + ob], pe = D.obs_path_off[W.opo0 + ob + 1];
-			for (int i = pe - 1; i >= pb; --i) {
-				const int c = D.path_edge[W.path0 + i];
-				const double* T = pose + 12 * (c >> 1);
-				const int dir = c & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;
-				const double d0 = dir ? q[0] - T[3] : q[0], d1 = dir ? q[1] - T[7] : q[1], d2 = dir ? q[2] - T[11] : q[2];
-				double t[3], Rn[9];
-				for (int a = 0; a < 3; ++a) {
-					const double r0 = T[si * a], r1 = T[si * a + sj], r2 = T[si * a + 2 * sj];
-					t[a] = r0 * d0 + r1 * d1 + r2 * d2 + (dir ? 0.0 : T[4 * a + 3]);
-					for (int b = 0; b < 3; ++b) Rn[3 * a + b] = r0 * R[b] + r1 * R[3 + b] + r2 * R[6 + b];
-				}
-				for (int a = 0; a < 3; ++a) q[a] = t[a];
-				for (int a = 0; a < 9; ++a) R[a] = Rn[a];
-			}
-			const double e0 = q[0] - P.S[3], e1 = q[1] - P.S[7], e2 = q[2] - P.S[11];
-			double pc[3];
-			for (int a = 0; a < 3; ++a) pc[a] = P.S[a] * e0 + P.S[4 + a] * e1 + P.S[8 + a] * e2;
-			const double iz = 1.0 / pc[2], iz2 = iz * iz;
+			const int pb = D.obs_path_off[W.opo0 + ob], np = min(D.obs_path_off[W.opo0 + ob + 1] - pb, 8);
+			int codes[8];
+			for (int i = 0; i < np; ++i) codes[i] = D.path_edge[W.path0 + pb + i];
 			const float* z = D.obs_px + 4 * (size_t)(W.obs0 + ob);
-			const double r[4] = {(double)z[0] - (P.cx_l + P.fx_l * pc[0] * iz), (double)z[1] - (P.cy_l + P.fy_l * pc[1] * iz),
-			                     (double)z[2] - (P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz), (double)z[3] - (P.cy_r + P.fy_r * pc[1] * iz)};
-			const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
-			const double wgt = P.robust ? 1.0 / sqrt(sqrt(1.0 + s2 / (P.kernel * P.kernel))) : 1.0;
-			const double Dm[12] = {P.fx_l * iz, 0, -P.fx_l * pc[0] * iz2, 0, P.fy_l * iz, -P.fy_l * pc[1] * iz2,
-			                       P.fx_r * iz, 0, -P.fx_r * (pc[0] - P.baseline) * iz2, 0, P.fy_r * iz, -P.fy_r * pc[1] * iz2};
-			double M[12], Jf[12];                               // M = D R_S^T, Jf = w M R
-			for (int a = 0; a < 4; ++a)
-				for (int b = 0; b < 3; ++b) M[3 * a + b] = Dm[3 * a] * P.S[4 * b] + Dm[3 * a + 1] * P.S[4 * b + 1] + Dm[3 * a + 2] * P.S[4 * b + 2];
-			for (int a = 0; a < 4; ++a)
-				for (int b = 0; b < 3; ++b) Jf[3 * a + b] = wgt * (M[3 * a] * R[b] + M[3 * a + 1] * R[3 + b] + M[3 * a + 2] * R[6 + b]);
-			for (int b = 0; b < 3; ++b) acc[b] += wgt * (Jf[b] * r[0] + Jf[3 + b] * r[1] + Jf[6 + b] * r[2] + Jf[9 + b] * r[3]);
-			int k = 3;
-			for (int a = 0; a < 3; ++a)
-				for (int b = a; b < 3; ++b) acc[k++] += Jf[a] * Jf[b] + Jf[3 + a] * Jf[3 + b] + Jf[6 + a] * Jf[6 + b] + Jf[9 + a] * Jf[9 + b];
+			pack_one_observation(P, pose, codes, np, f, z[0], z[1], z[2], z[3], acc);
 		}
 	}
-	o[0] = f[0]; o[1] = f[1]; o[2] = f[2];
-	for (int c = 0; c < 9; ++c) o[3 + c] = acc[c];
+	pack_reduce_store(acc, f, out + 12 * (size_t)s);
 }
 
 // the same for a window of the node / phase-split families, from ITS tables (a lean batch keeps no raw observation arrays for them): the window's
-// observation records (landmark, suffix of the whole path), the suffix trie (first step, rest) unrolled into the path's steps and walked from the base's
-// end exactly as above, the pixel records.  The observations of a landmark come in the tables' order (by landmark group), not the caller's: the sums
-// are the same to rounding.
+// observation records (landmark, suffix of the whole path), the suffix trie (first step, rest) unrolled into the path's steps, the pixel records
 __global__ void pack_shared_node_kernel(lm_dev D, nd_dev N, lm_cam P, int w, int n_shared, const int* __restrict__ lm_idx, double* __restrict__ out)
 {
-	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	const int s = blockIdx.x, lane = threadIdx.x & 63;
 	if (s >= n_shared) return;
 	const lm_win W = D.win[w];
 	const nd_win NW = N.win[w];
-	double* o = out + 12 * (size_t)s;
 	const int li = lm_idx[s];
 	double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};            // g (3), H upper (6)
 	double f[3] = {0, 0, 0};
@@ -298,50 +318,16 @@ __global__ void pack_shared_node_kernel(lm_dev D, nd_dev N, lm_cam P, int w, int
 		const double* fp = D.lm + 3 * (size_t)(W.lm0 + li);
 		f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
 		const double* pose = D.pose + 12 * (size_t)W.edge0;
-		for (int ob = 0; ob < NW.n_obs; ++ob) {
+		for (int ob = lane; ob < NW.n_obs; ob += 64) {
 			const nd_i2 rec = N.obs[NW.obs0 + ob];
 			if (rec.x != li) continue;
 			int codes[8], np = 0;
 			for (int sf = rec.y & 0xFFFF; sf != 0 && np < 8; sf = N.suf[NW.suf0 + sf].y) codes[np++] = N.suf[NW.suf0 + sf].x;      // (first step first)
-			double q[3] = {f[0], f[1], f[2]}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-			for (int i = np - 1; i >= 0; --i) {
-				const int c = codes[i];
-				const double* T = pose + 12 * (c >> 1);
-				const int dir = c & 1, si = dir ? 1 : 4, sj = dir ? 4 : 1;
-				const double d0 = dir ? q[0] - T[3] : q[0], d1 = dir ? q[1] - T[7] : q[1], d2 = dir ? q[2] - T[11] : q[2];
-				double t[3], Rn[9];
-				for (int a = 0; a < 3; ++a) {
-					const double r0 = T[si * a], r1 = T[si * a + sj], r2 = T[si * a + 2 * sj];
-					t[a] = r0 * d0 + r1 * d1 + r2 * d2 + (dir ? 0.0 : T[4 * a + 3]);
-					for (int b = 0; b < 3; ++b) Rn[3 * a + b] = r0 * R[b] + r1 * R[3 + b] + r2 * R[6 + b];
-				}
-				for (int a = 0; a < 3; ++a) q[a] = t[a];
-				for (int a = 0; a < 9; ++a) R[a] = Rn[a];
-			}
-			const double e0 = q[0] - P.S[3], e1 = q[1] - P.S[7], e2 = q[2] - P.S[11];
-			double pc[3];
-			for (int a = 0; a < 3; ++a) pc[a] = P.S[a] * e0 + P.S[4 + a] * e1 + P.S[8 + a] * e2;
-			const double iz = 1.0 / pc[2], iz2 = iz * iz;
 			const nd_f4 z = N.px[NW.obs0 + ob];
-			const double r[4] = {(double)z.x - (P.cx_l + P.fx_l * pc[0] * iz), (double)z.y - (P.cy_l + P.fy_l * pc[1] * iz),
-			                     (double)z.z - (P.cx_r + P.fx_r * (pc[0] - P.baseline) * iz), (double)z.w - (P.cy_r + P.fy_r * pc[1] * iz)};
-			const double s2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
-			const double wgt = P.robust ? 1.0 / sqrt(sqrt(1.0 + s2 / (P.kernel * P.kernel))) : 1.0;
-			const double Dm[12] = {P.fx_l * iz, 0, -P.fx_l * pc[0] * iz2, 0, P.fy_l * iz, -P.fy_l * pc[1] * iz2,
-			                       P.fx_r * iz, 0, -P.fx_r * (pc[0] - P.baseline) * iz2, 0, P.fy_r * iz, -P.fy_r * pc[1] * iz2};
-			double M[12], Jf[12];                               // M = D R_S^T, Jf = w M R
-			for (int a = 0; a < 4; ++a)
-				for (int b = 0; b < 3; ++b) M[3 * a + b] = Dm[3 * a] * P.S[4 * b] + Dm[3 * a + 1] * P.S[4 * b + 1] + Dm[3 * a + 2] * P.S[4 * b + 2];
-			for (int a = 0; a < 4; ++a)
-				for (int b = 0; b < 3; ++b) Jf[3 * a + b] = wgt * (M[3 * a] * R[b] + M[3 * a + 1] * R[3 + b] + M[3 * a + 2] * R[6 + b]);
-			for (int b = 0; b < 3; ++b) acc[b] += wgt * (Jf[b] * r[0] + Jf[3 + b] * r[1] + Jf[6 + b] * r[2] + Jf[9 + b] * r[3]);
-			int k = 3;
-			for (int a = 0; a < 3; ++a)
-				for (int b = a; b < 3; ++b) acc[k++] += Jf[a] * Jf[b] + Jf[3 + a] * Jf[3 + b] + Jf[6 + a] * Jf[6 + b] + Jf[9 + a] * Jf[9 + b];
+			pack_one_observation(P, pose, codes, np, f, z.x, z.y, z.z, z.w, acc);
 		}
 	}
-	o[0] = f[0]; o[1] = f[1]; o[2] = f[2];
-	for (int c = 0; c < 9; ++c) o[3 + c] = acc[c];
+	pack_reduce_store(acc, f, out + 12 * (size_t)s);
 }
 
 __global__ void stitch_shared_kernel(const double* __restrict__ g, int n_ranks, int n_shared, double lambda, double* __restrict__ pos)
@@ -415,10 +401,10 @@ int ssk_lm_batch_pack_shared(ssk_ctx* ctx, ssk_lm_batch* b, int w, int n_shared,
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	{ const int rc0 = lm_batch_settle(ctx, b); if (rc0) return rc0; }
 	if (b->lean && b->family[(size_t)w] != 2) {
-		hipLaunchKernelGGL(pack_shared_node_kernel, dim3((n_shared + 63) / 64), dim3(64), 0, ctx->stream, b->D, b->family[(size_t)w] == 1 ? b->N2 : b->N, cam_of(p), w, n_shared, d_lm_idx, d_out);
+		hipLaunchKernelGGL(pack_shared_node_kernel, dim3(n_shared), dim3(64), 0, ctx->stream, b->D, b->family[(size_t)w] == 1 ? b->N2 : b->N, cam_of(p), w, n_shared, d_lm_idx, d_out);
 		SSK_LAUNCH_CHECK(ctx, "pack_shared_node_kernel");
 	} else {
-		hipLaunchKernelGGL(pack_shared_kernel, dim3((n_shared + 63) / 64), dim3(64), 0, ctx->stream, b->D, cam_of(p), w, n_shared, d_lm_idx, d_out);
+		hipLaunchKernelGGL(pack_shared_kernel, dim3(n_shared), dim3(64), 0, ctx->stream, b->D, cam_of(p), w, n_shared, d_lm_idx, d_out);
 		SSK_LAUNCH_CHECK(ctx, "pack_shared_kernel");
 	}
 	return lm_batch_mark(ctx, b, SSK_OK);
