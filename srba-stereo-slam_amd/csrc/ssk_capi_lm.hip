@@ -909,9 +909,17 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		std::vector<std::vector<nd_i2>> tl(NX);
 		std::vector<std::vector<int>> wl(NX);
 		std::vector<long long> load(NX, 0);
+		// (a handful of windows -- the un-batched drop-in: ONE local area of 40-60 tiles -- cannot fill an XCD's L2 anyway: its tiles go round all eight
+		// XCDs, a CU each, instead of two or three to a CU of one XCD; SSK_SP_SPREAD=0 / 1 forces either form)
+		const bool spread = ctx->env.sp_spread >= 0 ? ctx->env.sp_spread != 0 : n_split <= 4;
 		for (int w : ord) {
 			int x = 0;
 			for (int k = 1; k < NX; ++k) if (load[k] < load[x]) x = k;
+			if (spread) {
+				for (int t = 0; t < NHs.win[(size_t)w].n_tiles; ++t) { tl[(size_t)((x + t) % NX)].push_back(nd_i2{w, t}); load[(size_t)((x + t) % NX)] += 1; }
+				wl[x].push_back(w);
+				continue;
+			}
 			for (int t = 0; t < NHs.win[(size_t)w].n_tiles; ++t) tl[x].push_back(nd_i2{w, t});
 			wl[x].push_back(w);
 			load[x] += NHs.win[(size_t)w].n_tiles;

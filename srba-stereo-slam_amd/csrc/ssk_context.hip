@@ -42,6 +42,7 @@ void ssk_env_read(ssk_env& e)
 	e.lm_no_pinned = set("SSK_LM_NO_PINNED");
 	e.lm_order = !off("SSK_LM_ORDER");
 	e.lm_debug = set("SSK_LM_DEBUG");
+	if (const char* v = std::getenv("SSK_SP_SPREAD")) e.sp_spread = std::atoi(v) ? 1 : 0;
 	{ const std::string v = str("SSK_LM_SCHUR"); e.lm_schur = v == "mfma" ? 1 : v == "sparse" ? 2 : 0; }
 	e.lm_ldl_mfma = str("SSK_LM_LDL") == "mfma";
 	if (const char* v = std::getenv("SSK_LM_COOP_G")) e.lm_coop_g = std::max(1, std::min(64, std::atoi(v)));

@@ -29,6 +29,7 @@ struct ssk_env {
 	bool lm_no_pinned = false;          // SSK_LM_NO_PINNED: the batch's tables in pageable memory
 	bool lm_order = true;               // SSK_LM_ORDER=0: windows launched as given (default: largest first)
 	bool lm_debug = false;              // SSK_LM_DEBUG
+	int sp_spread = -1;                 // SSK_SP_SPREAD: 1 = a phase-split window's tiles over all XCDs, 0 = on one XCD, unset: over all for batches of at most 4 such windows
 	int lm_schur = 0;                   // SSK_LM_SCHUR: 0 default (matrix cores for E > 12), 1 mfma, 2 sparse
 	bool lm_ldl_mfma = false;           // SSK_LM_LDL=mfma
 	int lm_coop_g = 0;                  // SSK_LM_COOP_G (0: default, at most 32)

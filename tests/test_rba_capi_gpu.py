@@ -137,3 +137,48 @@ def test_rba_lock_step_batch_equals_independent_engines(pkg, ctx, monkeypatch):
     for r in alone + batch:
         r.close()
     print("lock-step batch of %d streams, keyframe %d: %s" % (B, n_kf - 1, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tms[-1].items()}))
+
+
+def test_rba_lock_step_batch_reports_a_failed_engine_and_finishes_the_others(pkg, ctx, monkeypatch):
+    """Round 6: an engine whose bookkeeping fails -- here: the keyframe that opens a new local map shares nothing with the map, "the node
+    becomes isolated" (SRBA.h:304) -- is named by index in the error text, and the batch goes on for the other engines: they end the keyframe in the
+    state independent engines reach (round 5: the first failure aborted the call after every engine had taken its keyframe, none was optimised)."""
+    from ssk_amd import capi
+    monkeypatch.setenv("SSK_LM_FEW_SPLIT", "0")
+    B, n_kf, bad = 5, 5, 2
+    opts = capi.RbaOptions.kitti(submap_size=4, max_tree_depth=3, max_optimize_depth=2)
+    streams = []
+    for b in range(B):
+        rng = np.random.default_rng(300 + b)
+        P = np.stack([rng.uniform(-15, 40, 600), rng.uniform(-3, 3, 600), rng.uniform(6, 40, 600)], 1)
+        ids = np.arange(600, dtype=np.uint64) + 1000 * (b + 1)
+        streams.append([keyframe_observations(ctx, capi, k, P, ids, rng=rng) for k in range(n_kf)])
+    # keyframe 4 (submap_size 4: the first keyframe of the next local map) of stream `bad`: features nobody has seen
+    odd = streams[bad][4].copy(); odd["feat_id"] += 900000
+    alone = [capi.Rba(ctx, opts) for _ in range(B)]
+    for b in range(B):
+        for k in range(n_kf):
+            if b == bad and k == 4:
+                with pytest.raises(capi.SskError):
+                    alone[b].define_kf(odd)
+            else:
+                alone[b].define_kf(streams[b][k], optimize=k > 0)
+    batch = [capi.Rba(ctx, opts) for _ in range(B)]
+    for k in range(n_kf):
+        lists = [odd if (b == bad and k == 4) else streams[b][k] for b in range(B)]
+        if k == 4:
+            with pytest.raises(capi.SskError) as ei:
+                capi.rba_define_kf_batch(batch, lists, optimize=True)
+            msg = str(ei.value)
+            assert "engine %d:" % bad in msg and "isolated" in msg and all("engine %d:" % b not in msg for b in range(B) if b != bad), msg
+        else:
+            capi.rba_define_kf_batch(batch, lists, optimize=k > 0)
+    for b in range(B):
+        if b == bad:
+            continue
+        assert alone[b].counts() == batch[b].counts()
+        for e in range(alone[b].counts()[1]):
+            fa, ta, pa = alone[b].edge(e); fb, tb, pb = batch[b].edge(e)
+            assert (fa, ta) == (fb, tb) and np.array_equal(pa, pb), (b, e)
+    for r in alone + batch:
+        r.close()

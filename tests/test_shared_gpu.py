@@ -150,3 +150,32 @@ def test_pack_of_a_landmark_nobody_observes_and_bad_arguments(ctx):
     with pytest.raises(capi.SskError):
         b.pack_shared(1, d_idx, to_capi(sl.make_params()), out)       # no such window
     b.close()
+
+
+def test_pack_from_the_node_tables_equals_the_pack_from_the_raw_arrays(ctx, monkeypatch):
+    """Round 6: a lean batch keeps no raw observation arrays for its node / phase-split windows; ssk_lm_batch_pack_shared reads such a window's own
+    tables (pack_shared_node_kernel: the suffix trie unrolled into the path, the observations in table order).  Against the pack of the same window
+    in a batch of the full builder (SSK_LM_KERNEL=tiled: raw arrays, pack_shared_kernel): positions equal, g / H equal to rounding."""
+    import torch
+    from ssk_amd import capi
+    wins, idxs, sh = sl.make_shared_submaps(n_sub=2, n_shared=32, seed0=70, n_kf=40, n_lm=900, submap_size=6, obs_per_kf=120, opt_depth=2)
+    dev = torch.device("cuda:0")
+    d_idx = torch.from_numpy(idxs[0].astype(np.int32)).to(dev)
+    outs = []
+    for kernel in (None, "tiled"):
+        if kernel:
+            monkeypatch.setenv("SSK_LM_KERNEL", kernel)
+        else:
+            monkeypatch.delenv("SSK_LM_KERNEL", raising=False)
+        b = capi.LmBatch(ctx, wins[:1])
+        out = torch.zeros(32 * 12, dtype=torch.float64, device=dev)
+        b.pack_shared(0, d_idx, to_capi(sl.make_params()), out)
+        ctx.synchronize()
+        outs.append((b.kernel_name(), out.cpu().numpy().reshape(32, 12)))
+        b.close()
+    monkeypatch.delenv("SSK_LM_KERNEL", raising=False)
+    (n0, a), (n1, c) = outs
+    assert n0.startswith("lm_solve_node") or n0.startswith("lm_split"), n0
+    assert "tiled" in n1 or "coop" in n1, n1
+    assert np.array_equal(a[:, :3], c[:, :3]) and np.abs(a[:, 6]).min() > 0
+    assert np.allclose(a[:, 3:], c[:, 3:], rtol=1e-11, atol=1e-9 * np.abs(c[:, 3:]).max())
