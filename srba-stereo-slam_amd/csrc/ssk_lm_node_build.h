@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <utility>
 #include <vector>
@@ -148,6 +149,14 @@ struct gnode { int lmk, node, slot_lane; };           // per lane of a group: wh
 struct skey { uint64_t yh, yl; int pc, l, m; };        // sort key of a landmark's set of optimised edge slots (split form)
 // The builder's temporaries, one set per host thread, kept between windows: a window of a batch is a few hundred microseconds of work, two dozen
 // vectors allocated and freed per window were a fifth of it (round 6).
+// what a range of landmarks / a range of tiles leaves when helper threads build one window's parts side by side (nd_team): merged in range order, so the
+// window's tables come out byte for byte as from one thread
+struct alignas(128) part_lms { std::vector<lmk> lms; std::vector<node> nodes; bool fail = false; void clear() { lms.clear(); nodes.clear(); fail = false; } };
+struct alignas(128) part_tiles {      // (alignas: neighbouring parts' vector headers -- written at every push_back -- must not share a cache line)
+	std::vector<nd_i4> sqs; std::vector<nd_i2> qs, gqs; std::vector<int> item, gitem; std::vector<nd_tile> tile;
+	int max_per_lane = 0, max_rounds = 0, max_tile_blocks = 0; bool fail = false;
+	void clear() { sqs.clear(); qs.clear(); gqs.clear(); item.clear(); gitem.clear(); tile.clear(); max_per_lane = max_rounds = max_tile_blocks = 0; fail = false; }
+};
 struct workspace {
 	suf_map ids;
 	std::vector<nd_i2> suf;
@@ -164,9 +173,22 @@ struct workspace {
 	std::vector<int> t_pid, t_code, cnt, start, fillp, used, used2, bucket, tri, sorted_code, e_cnt, e_fill, e_slot, e_of;
 	std::vector<char> is_diag;
 	std::vector<skey> sk;
+	std::vector<part_lms> p_lms;                          // (the parts of a window built by helper threads: kept between windows like everything here)
+	std::vector<part_tiles> p_tiles;
 };
 inline workspace& ws() { static thread_local workspace w; return w; }
 }  // namespace nd_detail
+
+// Helper threads for ONE window (round 6: the un-batched drop-in builds a single local area of ~10^4 observations per keyframe: 0.85 ms on one thread).
+// run(n_parts, fn): fn(0 .. n_parts - 1), each exactly once, on the caller and up to n - 1 helpers; returns when all are done.  A batch of windows does not
+// use it (its windows are the parallel items).  MEASURED AND NOT USED BY THE LIBRARY: with spinning helpers woken ahead of the create (no wake-up latency)
+// the un-batched stream's creates took 103-112 ms per 100 keyframes against 88-96 on one thread (2-8 threads, GPU box: 256 cores under a 16-CPU quota, the
+// helpers land on other core complexes and the two parallel sections, 0.2-0.45 ms, move a megabyte of tables between their caches); the tables are the same
+// byte for byte (tests/test_lm_node_form.py builds the golden windows with 2, 3 and 8 threads).  Kept for a host with a known topology.
+struct nd_team {
+	int n = 1;
+	std::function<void(int, const std::function<void(int)>&)> run;
+};
 
 #ifdef ND_BUILD_PROF
 #include <chrono>
@@ -177,7 +199,8 @@ static double g_nd_prof[8];
 #define ND_PROF(i) do {} while (0)
 #define ND_PROF0() do {} while (0)
 #endif
-inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */, size_t lds_limit_doubles = 20352, bool split = false)
+inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_win hdr /* bases filled in by the caller */, size_t lds_limit_doubles = 20352, bool split = false,
+                            const nd_team* team = nullptr)
 {
 	ND_PROF0();
 	using nd_detail::node; using nd_detail::lmk; using nd_detail::gnode;
@@ -279,47 +302,70 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	}
 	std::vector<lmk>& lms = S.lms;
 	lms.clear(); lms.reserve((size_t)n_lms);
-	std::vector<int>& lm_sorted = S.lm_sorted;             // per landmark its observations, sorted
+	std::vector<int>& lm_sorted = S.lm_sorted;             // per landmark its observations, sorted (landmark l: [lo_off[l], lo_off[l + 1]))
 	lm_sorted.resize((size_t)n_obs);
 	std::vector<node>& nodes = S.nodes;
 	nodes.clear(); nodes.reserve((size_t)n_obs * 2);
-	// node of (current landmark, suffix): node_mark[suffix] == landmark + 1 says node_idx[suffix] is this landmark's
-	std::vector<int>& node_mark = S.node_mark; std::vector<int>& node_idx = S.node_idx;
-	node_mark.assign((size_t)n_suf, 0); node_idx.resize((size_t)n_suf);
-	int n_sorted = 0;
-	for (int l = 0; l < n_lms; ++l) {
-		const int o0 = lo_off[(size_t)l], no = lo_off[(size_t)l + 1] - o0;
-		if (no == 0) continue;                            // never observed: nothing to linearise, nothing moves it
-		if (no > 64) return false;
-		// stable insertion sort by chain (= by the rank of the observation's suffix)
-		int ord[64], key[64];
-		for (int k = 0; k < no; ++k) {
-			const int o = lo_idx[(size_t)o0 + k], ko = rank[(size_t)obs_suf[(size_t)o]];
-			int j = k;
-			while (j > 0 && ko < key[j - 1]) { ord[j] = ord[j - 1]; key[j] = key[j - 1]; --j; }
-			ord[j] = o; key[j] = ko;
-		}
-		lmk M{l, n_sorted, no, (int)nodes.size(), 0};
-		for (int k = 0; k < no; ++k) lm_sorted[(size_t)n_sorted + k] = ord[k];
-		n_sorted += no;
-		// nodes in the order of their first observation (depth first): a node's observations are the run of those whose chain holds its key
-		const int mark = l + 1;
-		int prev_sid = -1;
-		for (int k = 0; k < no; ++k) {
-			const int sid = obs_suf[(size_t)ord[k]], len = suf_len[(size_t)sid];
-			const int* ch = &chain[(size_t)sid * MAXP];
-			(void)prev_sid;
-			for (int c = 0; c < len; ++c) {
-				const int s2 = ch[c];
-				if (!suf_opt[(size_t)s2]) continue;
-				if (node_mark[(size_t)s2] == mark) { node& nd = nodes[(size_t)node_idx[(size_t)s2]]; nd.n = k + 1 - nd.a; }
-				else { node_mark[(size_t)s2] = mark; node_idx[(size_t)s2] = (int)nodes.size(); nodes.push_back(node{s2, k, 1}); }
+	// landmarks [l0, l1): observations sorted by chain, nodes in the order of their first observation.  WS: the executing thread's workspace (its
+	// per-suffix marks), out_lms / out_nodes: where the range's records go (node0 relative to out_nodes' start)
+	auto landmarks_range = [&](int l0, int l1, nd_detail::workspace& WS, std::vector<lmk>& out_lms, std::vector<node>& out_nodes) -> bool {
+		// node of (current landmark, suffix): node_mark[suffix] == landmark + 1 says node_idx[suffix] is this landmark's
+		std::vector<int>& node_mark = WS.node_mark; std::vector<int>& node_idx = WS.node_idx;
+		node_mark.assign((size_t)n_suf, 0); node_idx.resize((size_t)n_suf);
+		for (int l = l0; l < l1; ++l) {
+			const int o0 = lo_off[(size_t)l], no = lo_off[(size_t)l + 1] - o0;
+			if (no == 0) continue;                            // never observed: nothing to linearise, nothing moves it
+			if (no > 64) return false;
+			// stable insertion sort by chain (= by the rank of the observation's suffix)
+			int ord[64], key[64];
+			for (int k = 0; k < no; ++k) {
+				const int o = lo_idx[(size_t)o0 + k], ko = rank[(size_t)obs_suf[(size_t)o]];
+				int j = k;
+				while (j > 0 && ko < key[j - 1]) { ord[j] = ord[j - 1]; key[j] = key[j - 1]; --j; }
+				ord[j] = o; key[j] = ko;
 			}
+			lmk M{l, o0, no, (int)out_nodes.size(), 0};
+			for (int k = 0; k < no; ++k) lm_sorted[(size_t)o0 + k] = ord[k];
+			// nodes in the order of their first observation (depth first): a node's observations are the run of those whose chain holds its key
+			const int mark = l + 1;
+			for (int k = 0; k < no; ++k) {
+				const int sid = obs_suf[(size_t)ord[k]], len = suf_len[(size_t)sid];
+				const int* ch = &chain[(size_t)sid * MAXP];
+				for (int c = 0; c < len; ++c) {
+					const int s2 = ch[c];
+					if (!suf_opt[(size_t)s2]) continue;
+					if (node_mark[(size_t)s2] == mark) { node& nd = out_nodes[(size_t)node_idx[(size_t)s2]]; nd.n = k + 1 - nd.a; }
+					else { node_mark[(size_t)s2] = mark; node_idx[(size_t)s2] = (int)out_nodes.size(); out_nodes.push_back(node{s2, k, 1}); }
+				}
+			}
+			M.n_nodes = (int)out_nodes.size() - M.node0;
+			if (M.n_nodes > 63) return false;
+			out_lms.push_back(M);
 		}
-		M.n_nodes = (int)nodes.size() - M.node0;
-		if (M.n_nodes > 63) return false;
-		lms.push_back(M);
+		return true;
+	};
+	// (a single large window with helper threads at hand: ranges of landmarks side by side, merged in order)
+	const bool use_team = team && team->n > 1 && team->run && n_obs >= 2048 && n_lms >= 64;
+	if (!use_team) {
+		if (!landmarks_range(0, n_lms, S, lms, nodes)) return false;
+	} else {
+		const int n_parts = std::min(team->n, n_lms / 16);
+		std::vector<nd_detail::part_lms>& parts = S.p_lms;
+		if ((int)parts.size() < n_parts) parts.resize((size_t)n_parts);
+		for (int p = 0; p < n_parts; ++p) parts[(size_t)p].clear();
+		team->run(n_parts, [&](int p) {
+			const int l0 = (int)((long long)n_lms * p / n_parts), l1 = (int)((long long)n_lms * (p + 1) / n_parts);
+			parts[(size_t)p].fail = !landmarks_range(l0, l1, nd_detail::ws(), parts[(size_t)p].lms, parts[(size_t)p].nodes);
+		});
+		for (int p = 0; p < n_parts; ++p) if (parts[(size_t)p].fail) return false;
+		for (int p = 0; p < n_parts; ++p) {
+			const nd_detail::part_lms& P = parts[(size_t)p];
+			const int d = (int)nodes.size();
+			for (lmk M : P.lms) { M.node0 += d; lms.push_back(M); }
+			nodes.insert(nodes.end(), P.nodes.begin(), P.nodes.end());
+		}
 	}
+	const int n_sorted = n_obs;                            // (every observation belongs to an observed landmark)
 	{
 		std::vector<int>& ord = S.ord;
 		ord.resize(lms.size());
@@ -444,12 +490,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 	const int n_pairs = E * (E + 1) / 2;
 	auto pid_of = [](int e, int e2) { return e2 * (e2 + 1) / 2 + e; };   // e <= e2
 	const size_t n_tiles = (n_groups + (size_t)waves - 1) / (size_t)waves;
-	std::vector<int>& t_pid = S.t_pid; std::vector<int>& t_code = S.t_code;      // the current tile's items, generation order
-	std::vector<int>& cnt = S.cnt; std::vector<int>& start = S.start; std::vector<int>& fillp = S.fillp; std::vector<int>& used = S.used; std::vector<int>& sorted_code = S.sorted_code;
-	std::vector<int>& e_cnt = S.e_cnt; std::vector<int>& e_fill = S.e_fill; std::vector<int>& e_slot = S.e_slot; std::vector<int>& e_of = S.e_of;      // the tile's node slots by edge
 	std::vector<char>& is_diag = S.is_diag;                // block (e, e): the only ones the lambda_0 pass needs (bit 30 of a lane slot's x)
-	cnt.assign((size_t)n_pairs + 1, 0); start.resize((size_t)n_pairs + 1); fillp.resize((size_t)n_pairs + 1);
-	e_cnt.assign((size_t)E + 1, 0); e_fill.resize((size_t)E + 1);
 	is_diag.assign((size_t)n_pairs + 1, 0);
 	for (int e = 0; e < E; ++e) is_diag[(size_t)pid_of(e, e)] = 1;
 	std::vector<int>& tri = S.tri;                         // tri[e2] = e2 (e2 + 1) / 2: block (e, e2), e <= e2, is tri[e2] + e
@@ -466,7 +507,17 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		if (split) H.sqs.reserve(H.sqs.size() + n_tiles * (size_t)std::min(n_pairs, 4 * waves * 64));
 		else H.qs.reserve(H.qs.size() + n_tiles * (size_t)NQ * 2);
 	}
-	for (size_t t = 0; t < n_tiles; ++t) {
+	// tiles [tile0, tile1) into the tables of O (any vector types; o_r_*: their sizes where the window's -- or the part's -- entries start; the offsets
+	// stored in the tables are relative to those).  WS: the executing thread's workspace.  Returns false when a table entry would overflow its field.
+	auto tiles_range = [&](size_t tile0, size_t tile1, nd_detail::workspace& WS, auto& o_sqs, auto& o_qs, auto& o_gqs, auto& o_item, auto& o_gitem, auto& o_tile,
+	                       const size_t o_r_sqs, const size_t o_r_qs, const size_t o_r_gqs, const size_t o_r_item, const size_t o_r_gitem,
+	                       int& max_per_lane, int& max_rounds, int& max_tile_blocks) -> bool {
+	std::vector<int>& t_pid = WS.t_pid; std::vector<int>& t_code = WS.t_code;      // the current tile's items, generation order
+	std::vector<int>& cnt = WS.cnt; std::vector<int>& start = WS.start; std::vector<int>& fillp = WS.fillp; std::vector<int>& used = WS.used; std::vector<int>& sorted_code = WS.sorted_code;
+	std::vector<int>& e_cnt = WS.e_cnt; std::vector<int>& e_fill = WS.e_fill; std::vector<int>& e_slot = WS.e_slot; std::vector<int>& e_of = WS.e_of;      // the tile's node slots by edge
+	cnt.assign((size_t)n_pairs + 1, 0); start.resize((size_t)n_pairs + 1); fillp.resize((size_t)n_pairs + 1);
+	e_cnt.assign((size_t)E + 1, 0); e_fill.resize((size_t)E + 1);
+	for (size_t t = tile0; t < tile1; ++t) {
 		const size_t g0 = t * (size_t)waves;
 		const int n_grp = (int)std::min(n_groups - g0, (size_t)waves);
 		t_pid.clear(); t_code.clear(); e_slot.clear(); e_of.clear(); used.clear();
@@ -529,7 +580,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		if (used.size() > 1) {
 			int cmax = 0;
 			for (int p2 : used) cmax = std::max(cmax, cnt[(size_t)p2]);
-			std::vector<int>& bk = S.bucket; std::vector<int>& tmp = S.used2;
+			std::vector<int>& bk = WS.bucket; std::vector<int>& tmp = WS.used2;
 			bk.assign((size_t)cmax + 2, 0);
 			for (int p2 : used) bk[(size_t)(cmax - cnt[(size_t)p2]) + 1]++;
 			for (int c = 0; c <= cmax; ++c) bk[(size_t)c + 1] += bk[(size_t)c];
@@ -545,7 +596,7 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 		}
 		nd_tile T{};
 		T.grp0 = (int)g0; T.n_grp = n_grp;
-		const int item_base = (int)(H.item.size() - r_item);
+		const int item_base = (int)(o_item.size() - o_r_item);
 		if (split) {
 			// LANE slots: a block gets 1, 2 or 4 lanes (its items dealt out among them, the lanes' sums joined by one or two DPP steps), the fewest
 			// that keep a lane's run <= R items; R = the shortest run length whose lanes fit the fewest rounds of the workgroup.  Heaviest blocks first,
@@ -559,23 +610,23 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 				for (int p2 : used) lanes += lanes_of(cnt[(size_t)p2], R);
 				if (lanes <= (long long)NT_ * rounds_min) break;
 			}
-			T.qs0 = (int)(H.sqs.size() - r_sqs);
+			T.qs0 = (int)(o_sqs.size() - o_r_sqs);
 			max_tile_blocks = std::max(max_tile_blocks, (int)used.size());
 			for (int p2 : used) {
 				const int c = cnt[(size_t)p2];
 				const int k = lanes_of(c, R), kc = k == 4 ? 2 : (k == 2 ? 1 : 0);
-				if (c > 0xFFFF) { for (int p3 : used) cnt[(size_t)p3] = 0; return rollback(); }
+				if (c > 0xFFFF) return false;
 				for (int r = 0; r < k; ++r)
-					H.sqs.push_back(nd_i4{p2 | (is_diag[(size_t)p2] ? 1 << 30 : 0), c | (kc << 16) | (r << 20), item_base + start[(size_t)p2], -1});
+					o_sqs.push_back(nd_i4{p2 | (is_diag[(size_t)p2] ? 1 << 30 : 0), c | (kc << 16) | (r << 20), item_base + start[(size_t)p2], -1});
 			}
-			H.item.insert(H.item.end(), sorted_code.begin(), sorted_code.end());
-			T.n_rounds = (int)(H.sqs.size() - r_sqs) - T.qs0;     // (split form: n_rounds = number of lane slots of the tile)
+			o_item.insert(o_item.end(), sorted_code.begin(), sorted_code.end());
+			T.n_rounds = (int)(o_sqs.size() - o_r_sqs) - T.qs0;     // (split form: n_rounds = number of lane slots of the tile)
 			// bit 29: this wavefront (64 consecutive lane slots) holds blocks of several lanes
-			for (size_t w0 = r_sqs + (size_t)T.qs0; w0 < H.sqs.size(); w0 += 64) {
-				const size_t w1 = std::min(w0 + 64, H.sqs.size());
+			for (size_t w0 = o_r_sqs + (size_t)T.qs0; w0 < o_sqs.size(); w0 += 64) {
+				const size_t w1 = std::min(w0 + 64, o_sqs.size());
 				bool multi = false;
-				for (size_t i = w0; i < w1; ++i) multi |= ((H.sqs[i].y >> 16) & 3) != 0;
-				if (multi) for (size_t i = w0; i < w1; ++i) H.sqs[i].x |= 1 << 29;
+				for (size_t i = w0; i < w1; ++i) multi |= ((o_sqs[i].y >> 16) & 3) != 0;
+				if (multi) for (size_t i = w0; i < w1; ++i) o_sqs[i].x |= 1 << 29;
 			}
 		} else {
 			// quad slots of a tile: a block per quad, heaviest first (the 16 quads of a wavefront run in lockstep: similar loads share one); with quads
@@ -587,44 +638,80 @@ inline bool nd_build_window(const ssk_lm_window& Wn, int waves, nd_host& H, nd_w
 				while (n_split > 0 && cnt[(size_t)used[(size_t)n_split - 1]] < 8) --n_split;       // (a short run is not worth a second quad)
 			}
 			const int n_slots = (int)used.size() + n_split;
-			T.qs0 = (int)(H.qs.size() - r_qs);
+			T.qs0 = (int)(o_qs.size() - o_r_qs);
 			T.n_rounds = (n_slots + NQ - 1) / NQ;
 			max_rounds = std::max(max_rounds, T.n_rounds);
 			for (int k = 0; k < T.n_rounds * NQ; ++k) {
 				const int wave_flag = (k / 16) * 16 < 2 * n_split ? (int)0x80000000u : 0;      // this wavefront holds blocks cut in two
-				if (k >= n_slots) { H.qs.push_back(nd_i2{0xFFFF, wave_flag}); continue; }
+				if (k >= n_slots) { o_qs.push_back(nd_i2{0xFFFF, wave_flag}); continue; }
 				const int pid = k < 2 * n_split ? used[(size_t)(k >> 1)] : used[(size_t)(k - n_split)];
 				const int part = k < 2 * n_split ? (k & 1) : 0, parts = k < 2 * n_split ? 2 : 1;
-				const int first = (int)(H.item.size() - r_item);
+				const int first = (int)(o_item.size() - o_r_item);
 				const int* v = &sorted_code[(size_t)start[(size_t)pid]];
 				const int c = cnt[(size_t)pid];
-				if (parts == 1) H.item.insert(H.item.end(), v, v + c);
-				else for (int i = part; i < c; i += parts) H.item.push_back(v[i]);
-				const int n = (int)(H.item.size() - r_item) - first;
-				if (n > 32767 || first >= (1 << 28)) { for (int p3 : used) cnt[(size_t)p3] = 0; return rollback(); }
-				H.qs.push_back(nd_i2{pid | (n << 16), first | (part << 28) | (parts == 2 ? 1 << 30 : 0) | wave_flag});
+				if (parts == 1) o_item.insert(o_item.end(), v, v + c);
+				else for (int i = part; i < c; i += parts) o_item.push_back(v[i]);
+				const int n = (int)(o_item.size() - o_r_item) - first;
+				if (n > 32767 || first >= (1 << 28)) return false;
+				o_qs.push_back(nd_i2{pid | (n << 16), first | (part << 28) | (parts == 2 ? 1 << 30 : 0) | wave_flag});
 				max_per_lane = std::max(max_per_lane, (n + 3) / 4);
 			}
 		}
 		for (int p2 : used) cnt[(size_t)p2] = 0;
 		// gradient slots: the tile's node slots by edge (edge order; inside an edge the lane order)
-		T.gqs0 = (int)(H.gqs.size() - r_gqs); T.n_gqs = 0;
+		T.gqs0 = (int)(o_gqs.size() - o_r_gqs); T.n_gqs = 0;
 		{
 			std::fill(e_cnt.begin(), e_cnt.end(), 0);
 			for (int e : e_of) e_cnt[(size_t)e]++;
-			int pos = (int)(H.gitem.size() - r_gitem);
-			const size_t base = H.gitem.size();
-			H.gitem.resize(base + e_slot.size());
+			int pos = (int)(o_gitem.size() - o_r_gitem);
+			const size_t base = o_gitem.size();
+			o_gitem.resize(base + e_slot.size());
 			for (int e = 0; e < E; ++e) {
 				if (e_cnt[(size_t)e] == 0) continue;
-				H.gqs.push_back(nd_i2{e | (e_cnt[(size_t)e] << 16), pos});
-				e_fill[(size_t)e] = pos - (int)(base - r_gitem);      // (position inside this tile's part)
+				o_gqs.push_back(nd_i2{e | (e_cnt[(size_t)e] << 16), pos});
+				e_fill[(size_t)e] = pos - (int)(base - o_r_gitem);      // (position inside this tile's part)
 				pos += e_cnt[(size_t)e];
 				++T.n_gqs;
 			}
-			for (size_t i = 0; i < e_slot.size(); ++i) H.gitem[base + (size_t)e_fill[(size_t)e_of[i]]++] = e_slot[i];
+			for (size_t i = 0; i < e_slot.size(); ++i) o_gitem[base + (size_t)e_fill[(size_t)e_of[i]]++] = e_slot[i];
 		}
-		H.tile.push_back(T);
+		o_tile.push_back(T);
+	}
+	return true;
+	};
+	if (!use_team || n_tiles < 8) {
+		if (!tiles_range(0, n_tiles, S, H.sqs, H.qs, H.gqs, H.item, H.gitem, H.tile, r_sqs, r_qs, r_gqs, r_item, r_gitem, max_per_lane, max_rounds, max_tile_blocks)) return rollback();
+	} else {
+		// ranges of tiles side by side into tables of their own, then appended in order: the offsets a part stored are relative to ITS start
+		const int n_parts = (int)std::min<size_t>((size_t)team->n, n_tiles / 2);
+		std::vector<nd_detail::part_tiles>& parts = S.p_tiles;
+		if ((int)parts.size() < n_parts) parts.resize((size_t)n_parts);
+		for (int p = 0; p < n_parts; ++p) parts[(size_t)p].clear();
+		team->run(n_parts, [&](int p) {
+			nd_detail::part_tiles& P = parts[(size_t)p];
+			const size_t tile0 = n_tiles * (size_t)p / (size_t)n_parts, tile1 = n_tiles * ((size_t)p + 1) / (size_t)n_parts;
+			P.fail = !tiles_range(tile0, tile1, nd_detail::ws(), P.sqs, P.qs, P.gqs, P.item, P.gitem, P.tile, 0, 0, 0, 0, 0, P.max_per_lane, P.max_rounds, P.max_tile_blocks);
+		});
+		for (int p = 0; p < n_parts; ++p) if (parts[(size_t)p].fail) return rollback();
+		for (int p = 0; p < n_parts; ++p) {
+			const nd_detail::part_tiles& P = parts[(size_t)p];
+			const int d_sqs = (int)(H.sqs.size() - r_sqs), d_qs = (int)(H.qs.size() - r_qs), d_gqs = (int)(H.gqs.size() - r_gqs), d_item = (int)(H.item.size() - r_item),
+			          d_gitem = (int)(H.gitem.size() - r_gitem);
+			for (nd_tile T : P.tile) { T.qs0 += split ? d_sqs : d_qs; T.gqs0 += d_gqs; H.tile.push_back(T); }
+			for (nd_i4 q : P.sqs) { q.z += d_item; H.sqs.push_back(q); }
+			for (nd_i2 q : P.qs) {
+				if ((q.x & 0xFFFF) != 0xFFFF) {
+					const int first = (q.y & 0x0FFFFFFF) + d_item;
+					if (first >= (1 << 28)) return rollback();
+					q.y = (q.y & ~0x0FFFFFFF) | first;
+				}
+				H.qs.push_back(q);
+			}
+			for (nd_i2 q : P.gqs) { q.y += d_gitem; H.gqs.push_back(q); }
+			H.item.insert(H.item.end(), P.item.begin(), P.item.end());
+			H.gitem.insert(H.gitem.end(), P.gitem.begin(), P.gitem.end());
+			max_per_lane = std::max(max_per_lane, P.max_per_lane); max_rounds = std::max(max_rounds, P.max_rounds); max_tile_blocks = std::max(max_tile_blocks, P.max_tile_blocks);
+		}
 	}
 	int n_part = 0, n_gpart = 0;
 	if (split) {

@@ -32,14 +32,15 @@ def estimator_window(k):
                      np.arange(4 * no, dtype=np.float32), g("path_off"), g("path_edge"))
 
 
-def hashes(lib, case):
+def hashes(lib, case, threads=0):
+    """threads > 0: the window's ranges of landmarks / tiles built by that many threads side by side (nd_team, round 6)."""
     name, seed, kw = case
     w = estimator_window(seed) if kw is None else sl.make_submap_problem(seed, **kw)[0]
     wc = w.c()
     out = {}
     for split in (0, 1):
         h = (C.c_ulonglong * 16)()
-        rc = lib.nd_emu_tables_hash(C.byref(wc), 4, split, h)
+        rc = lib.nd_emu_tables_hash_team(C.byref(wc), 4, split, threads, h) if threads else lib.nd_emu_tables_hash(C.byref(wc), 4, split, h)
         out[str(split)] = [int(rc)] + [int(v) for v in h]
     return out
 

@@ -196,3 +196,8 @@ def test_builder_tables_unchanged(emu):
     for case in g.CASES:
         got = g.hashes(emu, case)
         assert got == gold["%s/%d" % (case[0], case[1])], case[:2]
+    # one window's landmark and tile ranges built by helper threads side by side (nd_team: the un-batched drop-in's single local area): the same bytes
+    for case in g.CASES:
+        if case[0] in ("d5", "est", "d2"):
+            for threads in (2, 3, 8):
+                assert g.hashes(emu, case, threads) == gold["%s/%d" % (case[0], case[1])], (case[:2], threads)

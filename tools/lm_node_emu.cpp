@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "../srba-stereo-slam_amd/csrc/ssk_lm_node_build.h"
 
@@ -310,6 +312,29 @@ int nd_emu_tables_hash(const ssk_lm_window* Wn, int waves, int split, unsigned l
 	nd_host H;
 	nd_win hdr{};
 	if (!nd_build_window(*Wn, waves, H, hdr, 20352, split != 0)) return -1;
+#define HV(i, v) out[i] = nd_fnv(H.v.data(), sizeof(H.v[0]) * H.v.size()) ^ (unsigned long long)H.v.size()
+	HV(0, win); HV(1, tile); HV(2, group); HV(3, suf); HV(4, obs); HV(5, px); HV(6, lane); HV(7, item); HV(8, qs); HV(9, gitem); HV(10, gqs);
+	HV(11, swin); HV(12, sqs); HV(13, poff); HV(14, goff); HV(15, gslot);
+#undef HV
+	return 0;
+}
+
+// the same with `n_threads` threads building the window's landmark / tile ranges side by side (nd_team): the tables must not depend on it
+int nd_emu_tables_hash_team(const ssk_lm_window* Wn, int waves, int split, int n_threads, unsigned long long* out /* 16 */)
+{
+	nd_team team;
+	team.n = n_threads;
+	team.run = [n_threads](int n_parts, const std::function<void(int)>& fn) {
+		std::atomic<int> next{0};
+		auto body = [&] { for (int i = next++; i < n_parts; i = next++) fn(i); };
+		std::vector<std::thread> th;
+		for (int t = 1; t < n_threads; ++t) th.emplace_back(body);
+		body();
+		for (std::thread& t : th) t.join();
+	};
+	nd_host H;
+	nd_win hdr{};
+	if (!nd_build_window(*Wn, waves, H, hdr, 20352, split != 0, &team)) return -1;
 #define HV(i, v) out[i] = nd_fnv(H.v.data(), sizeof(H.v[0]) * H.v.size()) ^ (unsigned long long)H.v.size()
 	HV(0, win); HV(1, tile); HV(2, group); HV(3, suf); HV(4, obs); HV(5, px); HV(6, lane); HV(7, item); HV(8, qs); HV(9, gitem); HV(10, gqs);
 	HV(11, swin); HV(12, sqs); HV(13, poff); HV(14, goff); HV(15, gslot);
