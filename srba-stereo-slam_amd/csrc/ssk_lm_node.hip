@@ -183,28 +183,7 @@ __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const
 #pragma unroll
 				for (int c = 0; c < 36; ++c) acc[c] = 0.0;
 				FINE0();
-#if ND_GRAD_FUSED
-				// the edge of a diagonal block (pid = e2 (e2 + 1) / 2 + e with e == e2), -1 otherwise: its quad sums the edge's reduced gradient beside
-				// the block (nd_item_grad); only the wavefronts that hold such a block run that form of the item loop
-				int ge = -1;
-				if (!pre && pid != 0xFFFF) {
-					int e2 = (int)((sqrtf(8.0f * (float)pid + 1.0f) - 1.0f) * 0.5f);
-					e2 += ((e2 + 1) * (e2 + 2) / 2 <= pid) ? 1 : 0;
-					e2 -= (e2 * (e2 + 1) / 2 > pid) ? 1 : 0;
-					if (pid - e2 * (e2 + 1) / 2 == e2) ge = e2;
-				}
-				double ga[6] = {0, 0, 0, 0, 0, 0};
-#if ND_GRAD_FUSED == 2
-				const bool wave_grad = !pre;                       // (one form of the item loop for every wavefront)
-				nd_pair_items<true>(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc, ga);
-#else
-				const bool wave_grad = __ballot(ge >= 0) != 0ull;
-				if (wave_grad) nd_pair_items<true>(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc, ga);
-				else nd_pair_items<false>(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc, ga);
-#endif
-#else
 				nd_pair_items(reg, N.item + W.item0 + (q.y & 0x0FFFFFFF), its, n, ql, 4, pre, acc);
-#endif
 				FINE(5);
 				nd_quad_sum36(acc);
 				// a block cut in two parts sits in the two quads of one aligned lane octet: the second quad's sums come over by a mirror step
@@ -214,23 +193,6 @@ __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const
 #pragma unroll
 					for (int c = 0; c < 36; ++c) acc[c] += on * dpp_f64<0x141>(acc[c]);      // row_half_mirror: lane i <-> 7 - i of its octet
 				}
-#if ND_GRAD_FUSED
-				if (wave_grad) {                                   // (uniform) the gradient sums the same way: the quad's four lanes, then the block's second part
-#pragma unroll
-					for (int c = 0; c < 6; ++c) ga[c] += dpp_f64<0xB1>(ga[c]);
-#pragma unroll
-					for (int c = 0; c < 6; ++c) ga[c] += dpp_f64<0x4E>(ga[c]);
-					if (__builtin_amdgcn_readfirstlane(q.y) < 0) {
-						const double on = ((q.y >> 30) & 1) ? 1.0 : 0.0;
-#pragma unroll
-						for (int c = 0; c < 6; ++c) ga[c] += on * dpp_f64<0x141>(ga[c]);
-					}
-					if (ql == 0 && ge >= 0 && ((q.y >> 28) & 3) == 0) {
-#pragma unroll
-						for (int c = 0; c < 6; ++c) (void)__hip_atomic_fetch_add(g_acc + 6 * ge + c, ga[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					}
-				}
-#endif
 				if (ql == 0 && pid != 0xFFFF && ((q.y >> 28) & 3) == 0) {
 #if ND_HB_ATOMIC
 					// one owner per block and tile: ds_add_f64 without a return is a plain read-modify-write in the LDS unit (no wait for a read)
@@ -255,7 +217,7 @@ __device__ __forceinline__ void nd_body(const lm_dev& D0, const nd_dev& N, const
 			}
 #endif
 			FINE0();
-			if (!pre && !(ND_GRAD_FUSED && !SSK_ND_LANE_RUNS))
+			if (!pre)
 				for (int k = quad; k < T.n_gqs; k += NQ) {
 					// reduced gradient of one edge: sum over the tile's nodes on it of [vh; q x vh]
 					const nd_i2 q = N.gqs[W.gqs0 + T.gqs0 + k];

@@ -491,29 +491,11 @@ __device__ __forceinline__ nd_items nd_items_fetch(const int* __restrict__ items
 	for (int k = 0; k < ND_ITEMS_REG; ++k) r.it[k] = ND_LDNT(items + min(first + step * k, max(n - 1, 0)));      // unconditional, clamped
 	return r;
 }
-// Round 6, measured and NOT the default (ND_GRAD_FUSED=1 / 2 builds it): the reduced gradient riding on the DIAGONAL blocks' items.  Block (e, e) holds
-// one item per node of edge e with itself (row = column slot, nested), and the edge's gradient is the sum over exactly those nodes of [vh; q x vh]: a
-// quad that owns a diagonal block adds them up beside the block's 36 sums (three more LDS doubles and a cross product per self item) and the separate
-// gradient pass -- ten quads of wavefront 0 walking an edge's nodes, 5.3 k of a tile's 17 k pair-phase cycles by thread 0's stamps, most of it the
-// round trip of the gradient item codes -- goes.  Same-box A/B (tools/lm_ab.py, 1 024 bench windows): 3.80 -> 3.77 ms, and the e10 kernel spills 2-3
-// VGPRs (16 B of scratch) at 256: the kernel is not bound by wavefront 0's chain (a CU's other workgroup fills the gap), the 1 % is not worth the scratch.
-#ifndef ND_GRAD_FUSED
-#define ND_GRAD_FUSED 0
-#endif
-template <bool GRAD>
-__device__ __forceinline__ void nd_item_grad(const double* __restrict__ rec, int it, const nd_item_ops& o, double (&ga)[6])
-{
-	if (!GRAD) return;
-	const double w = (((it ^ (it >> 10)) & 511) == 0 && ((it >> 20) & 1) == 0) ? 1.0 : 0.0;      // the item of a node with itself
-	const double* xr = rec + REC * (it & 511);
-	const double vh[3] = {w * xr[R_V], w * xr[R_V + 1], w * xr[R_V + 2]};
-	double x[3];
-	nd_cross(o.qr, vh, x);
-#pragma unroll
-	for (int c = 0; c < 3; ++c) { ga[c] += vh[c]; ga[3 + c] += x[c]; }
-}
-template <bool GRAD = false>
-__device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, const int* __restrict__ items, const nd_items& pre_it, int n, int ql, int step, bool pre, double (&acc)[36], double (&ga)[6])
+// (Round 6, measured and removed again -- commit 79535aa holds it, `ND_GRAD_FUSED`: the reduced gradient riding on the DIAGONAL blocks' items.  Block (e, e) holds one item per
+// node of edge e with itself, and the edge's gradient is the sum over exactly those nodes of [vh; q x vh]: the quad that owns the block added them up beside
+// its 36 sums and the separate gradient pass -- ten quads of wavefront 0 walking an edge's nodes, 5.3 k of a tile's 17 k pair-phase cycles by thread 0's
+// stamps -- went.  Same-box A/B, 1 024 bench windows: 3.80 -> 3.77 ms with 2-3 spilled VGPRs in the e10 kernel: the kernel is not bound by wavefront 0's chain.)
+__device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, const int* __restrict__ items, const nd_items& pre_it, int n, int ql, int step, bool pre, double (&acc)[36])
 {
 	const double neg = pre ? 0.0 : -1.0;
 #if ND_PIPE
@@ -532,7 +514,6 @@ __device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, co
 			const int it = pre_it.it[k];
 			if (k + 1 < ND_ITEMS_REG && k + 1 < turns) nd_item_load(rec, pre_it.it[k + 1], nxt);
 			nd_item_apply(cur, k < mine ? (((it >> 20) & 1) ? neg : 1.0) : 0.0, acc);
-			if (k < mine) nd_item_grad<GRAD>(rec, it, cur, ga);
 			cur = nxt;
 		}
 	}
@@ -544,7 +525,6 @@ __device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, co
 			nd_item_ops o;
 			nd_item_load(rec, it, o);
 			nd_item_apply(o, ((it >> 20) & 1) ? neg : 1.0, acc);
-			nd_item_grad<GRAD>(rec, it, o, ga);
 		}
 	}
 #endif
@@ -553,13 +533,7 @@ __device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, co
 		nd_item_ops o;
 		nd_item_load(rec, it, o);
 		nd_item_apply(o, ((it >> 20) & 1) ? neg : 1.0, acc);
-		nd_item_grad<GRAD>(rec, it, o, ga);
 	}
-}
-__device__ __forceinline__ void nd_pair_items(const double* __restrict__ rec, const int* __restrict__ items, const nd_items& pre_it, int n, int ql, int step, bool pre, double (&acc)[36])
-{
-	double ga[6];
-	nd_pair_items<false>(rec, items, pre_it, n, ql, step, pre, acc, ga);
 }
 
 // the four lanes' sums of a quad, in the fixed order (l0 + l1) + (l2 + l3): every lane ends with the total
