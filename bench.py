@@ -268,7 +268,7 @@ def main():
                     help="frames of the un-batched pass at N=1 (the estimator's frame loop, one ssk_slam_process_frame per stereo pair: what a "
                          "user of performStereoSLAM sees; reported as `unbatched`, never as `value`; 0 = skip)")
     ap.add_argument("--e2e-streams", type=int, default=1024, help="streams of the `e2e_stage2` pass at N=1 (lock-step keyframe streams with stage 1 + stage 2 per keyframe; 0 = skip)")
-    ap.add_argument("--e2e-groups", type=int, default=2, help="groups the e2e_stage2 streams are dealt out over (a host thread and a HIP stream each; 1 = serial)")
+    ap.add_argument("--e2e-groups", type=int, default=4, help="groups the e2e_stage2 streams are dealt out over (a host thread and a HIP stream each; 1 = serial)")
     ap.add_argument("--e2e-depth5-streams", type=int, default=128, help="streams of its optimise-depth-5 figure (0 = skip)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: LM solves on a second HIP stream beside the front-end / DA kernels (measured: +1 %, the LM workgroups fill every CU)")
@@ -750,6 +750,13 @@ def main():
 
         grp = [Group(g) for g in range(G)]
         torch.cuda.synchronize()
+        # groups side by side share the box's CPU quota: each gets its share of the host threads (1.5 x the one-group count in all -- 4 groups x 12
+        # threads measured best under a 16-CPU quota: 30.3 k keyframes/s against 21.6-26.6 k for 2 groups x 32); the library reads both per call
+        env_keep = {k_: os.environ.get(k_) for k_ in ("SSK_RBA_BATCH_THREADS", "SSK_LM_BUILD_THREADS")}
+        if G > 1 and all(v_ is None for v_ in env_keep.values()):
+            one_group = int(max(2, min((os.cpu_count() or 2) // 2, 64, round(2 * (cpu_quota() or 1e9)))))
+            per_group = str(max(4, (3 * one_group // 2) // G))
+            os.environ["SSK_RBA_BATCH_THREADS"] = per_group; os.environ["SSK_LM_BUILD_THREADS"] = per_group
         gate = threading.Barrier(G + 1)
         def run(gr):
             try:
@@ -772,6 +779,11 @@ def main():
         for t_ in th:
             t_.join()
         wall = time.perf_counter() - tw0
+        for k_, v_ in env_keep.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
         for gr in grp:
             if gr.error is not None:
                 raise gr.error

@@ -558,15 +558,18 @@ void parallel_for(int n, int n_threads, F f)
 }
 int batch_host_threads()
 {
+	if (const char* e = std::getenv("SSK_RBA_BATCH_THREADS")) return std::max(1, std::atoi(e));
 	// as the LM builder: half the logical cores, at most 64 and at most twice the container's CPU quota (cgroup v2 cpu.max)
-	int n = std::max(1, std::min((int)std::thread::hardware_concurrency() / 2, 64));
-	if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-		char q[32]; double per = 0.0;
-		if (std::fscanf(f, "%31s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) n = std::max(2, std::min(n, (int)(2.0 * std::atof(q) / per + 0.5)));
-		std::fclose(f);
-	}
-	if (const char* e = std::getenv("SSK_RBA_BATCH_THREADS")) n = std::max(1, std::atoi(e));
-	return n;
+	static const int n_auto = [] {
+		int n = std::max(1, std::min((int)std::thread::hardware_concurrency() / 2, 64));
+		if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+			char q[32]; double per = 0.0;
+			if (std::fscanf(f, "%31s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) n = std::max(2, std::min(n, (int)(2.0 * std::atof(q) / per + 0.5)));
+			std::fclose(f);
+		}
+		return n;
+	}();
+	return n_auto;
 }
 }  // namespace
 
@@ -592,7 +595,7 @@ void mySRBA::define_new_keyframe_batch_impl(const std::vector<mySRBA*>& E, const
 	if (n == 0) return;
 	Context& ctx = E[0]->m_ctx;
 	for (const mySRBA* e : E) if (e->m_ctx.get() != ctx.get()) throw std::runtime_error("define_new_keyframe_batch: the engines of a batch share one context");
-	static const int n_thr = batch_host_threads();
+	const int n_thr = batch_host_threads();             // (read per call: groups of streams driven side by side share the box's CPU quota -- SSK_RBA_BATCH_THREADS)
 	TBatchTiming T;
 	T.host_threads = n_thr;
 	auto t0 = lm_now();
