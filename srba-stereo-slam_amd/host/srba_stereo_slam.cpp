@@ -548,13 +548,14 @@ struct host_pool {
 		for (std::thread& th : workers) th.join();
 	}
 };
+// (ONE pool per calling thread: a thread_local inside the template below would be one per lambda type)
+host_pool& host_pool_of_this_thread() { static thread_local host_pool pool; return pool; }
 template <class F>
 void parallel_for(int n, int n_threads, F f)
 {
 	if (n_threads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
-	static thread_local host_pool pool;
 	const std::function<void(int)> fn = f;
-	pool.run(n_threads, n, fn);
+	host_pool_of_this_thread().run(n_threads, n, fn);
 }
 int batch_host_threads()
 {
