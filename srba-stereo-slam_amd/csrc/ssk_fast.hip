@@ -26,7 +26,7 @@
 namespace {
 
 #ifndef SSK_FAST_WAVES
-#define SSK_FAST_WAVES 4                   // min waves per SIMD = workgroups per CU the register budget must allow
+#define SSK_FAST_WAVES 5                   // min waves per SIMD = workgroups per CU the register budget must allow
 #endif
 constexpr int TW = 128, TH = 32;           // output tile; tile origin x is a multiple of 4
 constexpr int X_ORG = 28;                  // first tile column (<= SSK_EDGE, multiple of 4)
@@ -87,6 +87,8 @@ __device__ __forceinline__ void ring_diffs_packed(const uint8_t* p, uint32_t (&A
 // score is <= t -- it cannot be the maximum of a corner (whose other score is > t) and does not matter for a non-corner.  So the polarity the compass
 // test passed is enough: half of fast_s_packed's min / max chains.  sgn2 = (+1, +1) or (-1, -1) packed: the ring differences come out signed for
 // the polarity by ONE v_pk_mad_i16 per pair (r * sgn - c * sgn) -- what the plain subtraction cost.
+// Round 6: A[k] = (d[k], d[k + 8]) -- OPPOSITE ring pixels share a register, so every step below computes an arc and the arc half a turn on with one
+// packed instruction, and "the other half of the ring" is a swap of the two 16-bit lanes (op_sel of the packed instruction, no shuffle).
 __device__ __forceinline__ void ring_diffs_signed(const uint8_t* p, uint32_t sgn2, uint32_t (&A)[8])
 {
 	const uint32_t c = p[0], cc = c | (c << 16);
@@ -94,27 +96,29 @@ __device__ __forceinline__ void ring_diffs_signed(const uint8_t* p, uint32_t sgn
 	                        p[-3 * IW], p[-3 * IW - 1], p[-2 * IW - 2], p[-IW - 3], p[-3], p[IW - 3], p[2 * IW - 2], p[3 * IW - 1]};
 	const s16x2 s2 = as_s16x2(sgn2), ncs = as_s16x2(0u) - as_s16x2(cc) * s2;
 #pragma unroll
-	for (int k = 0; k < 8; ++k) A[k] = as_u32(as_s16x2(r[2 * k] | (r[2 * k + 1] << 16)) * s2 + ncs);
+	for (int k = 0; k < 8; ++k) A[k] = as_u32(as_s16x2(r[k] | (r[k + 8] << 16)) * s2 + ncs);
 }
+// max over the 16 arcs of 9 of the arc's min.  With M(j) = min d[2j+1 .. 2j+8], the arcs from 2j and from 2j+1 are min(d[2j], M) and
+// min(M, d[2j+9]): their max is min(M(j), max(d[2j], d[2j+9])) (the decomposition of cv's cornerScore<16>).  M(j) = min(d[2j+1], H[j+1], H[j+2], H[j+3],
+// d[2j+8]) with H[m] = min(d[2m], d[2m+1]).  Lane pairs hold (j, j+4): 31 packed instructions (the doubling scheme of round 5: 47 + 8 shuffles).
+__device__ __forceinline__ s16x2 swap16(s16x2 v) { return __builtin_shufflevector(v, v, 1, 0); }
 __device__ __forceinline__ int fast_s_one(const uint32_t (&A)[8])
 {
-	s16x2 a[8], b[8], lo[8], t[8];
+	s16x2 a[8], as[8], h[4], hs[4];
 #pragma unroll
-	for (int k = 0; k < 8; ++k) a[k] = as_s16x2(A[k]);
+	for (int k = 0; k < 8; ++k) { a[k] = as_s16x2(A[k]); as[k] = swap16(a[k]); }         // E(i) = a[i] for i < 8, as[i - 8] above: (d[i], d[i + 8])
 #pragma unroll
-	for (int k = 0; k < 8; ++k) b[k] = as_s16x2(__builtin_amdgcn_alignbyte(A[(k + 1) & 7], A[k], 2u));   // (d[2k+1], d[2k+2])
+	for (int j = 0; j < 4; ++j) { h[j] = __builtin_elementwise_min(a[2 * j], a[2 * j + 1]); hs[j] = swap16(h[j]); }   // (H[j], H[j+4]); HH(m >= 4) = hs[m - 4]
+	const s16x2 V = __builtin_elementwise_min(h[2], h[3]), W = __builtin_elementwise_min(hs[0], hs[1]);
+	const s16x2 T[4] = {__builtin_elementwise_min(h[1], V), __builtin_elementwise_min(V, hs[0]), __builtin_elementwise_min(h[3], W), __builtin_elementwise_min(W, hs[2])};
+	s16x2 best;
 #pragma unroll
-	for (int k = 0; k < 8; ++k) lo[k] = __builtin_elementwise_min(a[k], b[k]);                      // runs of 2
-#pragma unroll
-	for (int k = 0; k < 8; ++k) t[k] = __builtin_elementwise_min(lo[k], lo[(k + 1) & 7]);           // runs of 4
-#pragma unroll
-	for (int k = 0; k < 8; ++k) lo[k] = __builtin_elementwise_min(t[k], t[(k + 2) & 7]);            // runs of 8
-#pragma unroll
-	for (int k = 0; k < 8; ++k) lo[k] = __builtin_elementwise_min(lo[k], a[(k + 4) & 7]);           // arcs of 9
-	s16x2 sb = lo[0];
-#pragma unroll
-	for (int k = 1; k < 8; ++k) sb = __builtin_elementwise_max(sb, lo[k]);
-	return max(max((int)sb.x, (int)sb.y), 0);
+	for (int j = 0; j < 4; ++j) {
+		const s16x2 M = __builtin_elementwise_min(__builtin_elementwise_min(a[2 * j + 1], T[j]), as[2 * j]);            // E(2j+1), T, E(2j+8)
+		const s16x2 R = __builtin_elementwise_min(M, __builtin_elementwise_max(a[2 * j], as[2 * j + 1]));               // E(2j), E(2j+9)
+		best = j ? __builtin_elementwise_max(best, R) : R;
+	}
+	return max(max((int)best.x, (int)best.y), 0);
 }
 
 // append the values of the lanes with pred to an LDS queue: one ds atomic per wave
@@ -147,6 +151,16 @@ __device__ __forceinline__ void wave_push4(const bool (&pr)[4], const T (&val)[4
 	if (pr[3]) queue[base + n0 + n1 + n2 + __popcll(m3 & lt)] = val[3];
 }
 
+// queue entry -> score row and column of the pixel (the item map of phase A): bits 5..12 = the lane, bits 0..4 = 8 k + 1 + ra
+__device__ __forceinline__ void decode_item(uint32_t code, int& sy, int& col)
+{
+	const int tq = (code >> 5) & 255, i = code & 31, k = i >> 3, ra = (i & 7) - 1;
+	int g;
+	if (ra == 4 && tq >= 64) { const int hq = tq - 64; sy = hq >> 1; g = (hq & 1) * (SG - 1); }
+	else { sy = 8 * ra + (tq >> 5); g = 1 + (tq & 31); }
+	col = 4 * g + k;
+}
+
 // n / d for a wave-uniform tile index with d fixed per launch: n * ceil(2^32 / d) >> 32, exact for n * d < 2^32
 // (asserted by the launcher).  Runtime integer division has no hardware instruction: three of them per tile were
 // ~15% of the kernel's VALU work.
@@ -159,10 +173,11 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_img[IH * IW];
 	__shared__ __attribute__((aligned(16))) uint8_t s_sc[SH * SP];
-	__shared__ uint16_t s_q1[NQ];
-	__shared__ uint8_t s_pol[(SG * SH + 3) & ~3];      // per 4-pixel group: compass survivors as bright (bits 0..3) / dark (bits 4..7) candidates
+	__shared__ __attribute__((aligned(16))) uint16_t s_q1[NQ];
 	__shared__ uint16_t s_q2[NQ];
-	__shared__ uint32_t s_out[TW * TH / 4 + 64];
+	// the survivors of the NMS (at most one per 2 x 2 pixels of the tile) are listed where the pixel queue was: phase C reads the second queue only
+	static_assert(sizeof(uint32_t) * (TW * TH / 4 + 64) <= sizeof(uint16_t) * NQ, "the output list fits the first queue's storage");
+	uint32_t* const s_out = reinterpret_cast<uint32_t*>(s_q1);
 	__shared__ int s_q1n, s_q2n, s_on, s_base;
 
 	const int tid = threadIdx.x;
@@ -195,13 +210,10 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 				const int row = i / 9, c = i - row * 9;
 				const int gy = min(max(Y0 - 4 + row, 0), h - 1);
 				const int gx = X0 - 8 + 16 * c;                   // a multiple of 4: global dwordx4 loads only need dword alignment
-				const uint8_t* p = src + (size_t)gy * pitch + gx;
-				if (gx + 16 <= pitch) v = *reinterpret_cast<const uint4*>(p);
-				else {                                            // the last tile column runs past the row pitch: dword by dword, zero beyond
-					if (gx + 4 <= pitch) v.x = *reinterpret_cast<const uint32_t*>(p);
-					if (gx + 8 <= pitch) v.y = *reinterpret_cast<const uint32_t*>(p + 4);
-					if (gx + 12 <= pitch) v.z = *reinterpret_cast<const uint32_t*>(p + 8);
-				}
+				// the last tile column runs past the row pitch (by < 128 bytes: into the next row, or into the 256 bytes of slack behind the
+				// last image, ssk_kfbatch_create): those columns are >= w, and no pixel with a full ring reads them.  No branch here: the
+				// dword-by-dword tail this used to have made the compiler wait for the first chunk before issuing the second.
+				v = *reinterpret_cast<const uint4*>(src + (size_t)gy * pitch + gx);
 			}
 			pre[u] = v;
 		}
@@ -220,7 +232,9 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 				d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
 			}
 		}
-		for (int i = tid; i < SH * SP / 4; i += 256) reinterpret_cast<uint32_t*>(s_sc)[i] = 0u;
+		static_assert(SH * SP % 16 == 0 && SH * SP / 16 <= 512, "score tile cleared by two 16-byte stores per lane");
+		reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
+		if (tid + 256 < SH * SP / 16) reinterpret_cast<uint4*>(s_sc)[tid + 256] = make_uint4(0u, 0u, 0u, 0u);
 		if (tid == 0) { s_q1n = 0; s_q2n = 0; s_on = 0; }
 		__syncthreads();
 		if (t + stride < t_end) issue_loads(t + stride);
@@ -230,85 +244,78 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		const int img = img_begin + im;
 		const int X0 = X_ORG + bx * TW, Y0 = SSK_EDGE + by * TH;
 
-		// ---- phase A: compass test, 4 pixels per lane; the lane keeps the survivor bits of its five groups (4 bits each) and the wavefront
-		//      appends all of them to the pixel queue in ONE step (five ballots of the lanes' counts, one ds atomic): a push per round plus a
-		//      second pass that expanded queued groups to pixels were a fifth of the kernel ----
-		constexpr int NRA = (SG * SH + 255) / 256;
-		static_assert(4 * NRA <= 32, "survivor bits of a lane");
-		unsigned all = 0u;
+		// ---- phase A (round 6): compass test, 4 pixels per lane and round.  Item map without divisions: rounds 0..3 cover score rows 8 ra + (tid >> 5),
+		//      core groups 1 + (tid & 31) -- ONE address register, the rounds are immediate offsets; round 4 = rows 32, 33 on lanes 0..63 and the 68
+		//      items of the two halo group columns on lanes 64..131.  The tests leave their result as the SIGN of a packed 16-bit difference
+		//      (bright: c + t - min(max(N, S), max(E, W)) < 0; dark: max(min(N, S), min(E, W)) - (c - t) < 0; all values within +-510), whose high
+		//      byte is 0xff / 0x00-0x01: one v_perm gathers the four pixels' high bytes, one v_and_or files bit (1 + ra) of each into the lane's
+		//      survivor words (bit 8 k + 1 + ra: pixel k of round ra).  ~36 vector instructions per round (round 5: ~70). ----
+		const bool edge_tile = (X0 + TW + 4 > w - 3) || (h - 2 - Y0 < SH);       // (uniform) some pixel of the score region has no full ring
+		const int sy_lim = h - 2 - Y0;                                            // score rows sy < sy_lim have rows gy +- 3 inside the image
+		const u16x2 t2 = as_u16x2((uint32_t)threshold * 0x00010001u);
+		const uint32_t* const img32 = reinterpret_cast<const uint32_t*>(s_img);
+		const int a_core = ((tid >> 5) + 3) * (IW / 4) + (tid & 31) + 2;
+		const int hh = tid - 64;
+		const int a_r4 = tid < 64 ? a_core + 4 * 8 * (IW / 4) : ((hh >> 1) + 3) * (IW / 4) + (hh & 1) * (SG - 1) + 1;
+		uint32_t allb = 0u, alld = 0u;
 #pragma unroll
-		for (int ra = 0; ra < NRA; ++ra) {
-			const int it = 256 * ra + tid;
-			unsigned m4 = 0u;                                      // bit k: pixel k of the group passes the compass test
-			if (it < SG * SH) {
-				const int sy = it / SG, g = it - sy * SG;
-				const int gy = Y0 - 1 + sy, gx0 = X0 - 4 + 4 * g;
-				if (gy >= 3 && gy < h - 3) {
-					const uint32_t* r = reinterpret_cast<const uint32_t*>(s_img) + (sy + 3) * (IW / 4) + (g + 1);   // dword of (gx0, gy)
-					const uint32_t C = r[0], L = r[-1], R = r[1];
-					const uint32_t Dn = r[3 * (IW / 4)], Up = r[-3 * (IW / 4)];
-					const uint32_t E = (C >> 24) | (R << 8);          // bytes: x+3 of pixels 0..3
-					const uint32_t Wd = (L >> 8) | (C << 24);         // bytes: x-3 of pixels 0..3
-					// the four pixels as two packed 16-bit pairs: a 9-arc holds two ADJACENT compass points, one of {0,8} and
-					// one of {4,12}, all brighter than c+t or all darker than c-t.  Saturating packed subtracts turn the
-					// compares into "non-zero" and min() into AND: ~48 instructions for 4 pixels instead of ~100.
-					const u16x2 t2 = as_u16x2((uint32_t)threshold * 0x00010001u);
-					// (round 5: "N or S brighter than c + t" is max(N, S) > c + t, "darker" min(N, S) < c - t: a max / min and ONE saturating subtract per
-					// pair of compass points instead of two subtracts and an OR; bright and dark survivors kept apart for the one-polarity score)
-					uint32_t rb[2], rd[2];
+		for (int ra = 0; ra < 5; ++ra) {
+			if (ra == 4 && tid >= 64 + 2 * SH) break;
+			const uint32_t* r = img32 + (ra < 4 ? a_core + ra * 8 * (IW / 4) : a_r4);      // dword of the group's four pixels
+			const uint32_t C = r[0], L = r[-1], R = r[1];
+			const uint32_t Dn = r[3 * (IW / 4)], Up = r[-3 * (IW / 4)];
+			uint32_t rb[2], rd[2];
 #pragma unroll
-					for (int hsel = 0; hsel < 2; ++hsel) {
-						const uint32_t sel = hsel ? 0x0c030c02u : 0x0c010c00u;   // bytes (0,1) or (2,3) -> the two 16-bit lanes
-						const u16x2 c = as_u16x2(__builtin_amdgcn_perm(0u, C, sel));
-						const u16x2 a0 = as_u16x2(__builtin_amdgcn_perm(0u, Dn, sel)), a8 = as_u16x2(__builtin_amdgcn_perm(0u, Up, sel));
-						const u16x2 a4 = as_u16x2(__builtin_amdgcn_perm(0u, E, sel)), a12 = as_u16x2(__builtin_amdgcn_perm(0u, Wd, sel));
-						const u16x2 hi = c + t2, lo = __builtin_elementwise_sub_sat(c, t2);
-						const u16x2 bv = __builtin_elementwise_sub_sat(__builtin_elementwise_max(a0, a8), hi);
-						const u16x2 bh = __builtin_elementwise_sub_sat(__builtin_elementwise_max(a4, a12), hi);
-						const u16x2 dv = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(a0, a8));
-						const u16x2 dh = __builtin_elementwise_sub_sat(lo, __builtin_elementwise_min(a4, a12));
-						rb[hsel] = as_u32x(__builtin_elementwise_min(bv, bh));
-						rd[hsel] = as_u32x(__builtin_elementwise_min(dv, dh));
-					}
-					// non-zero 16-bit lanes -> bits: min(x, 1) per lane, then (lo | hi >> 15) of each pair; gx0 >= X_ORG - 4 >= 3 always, only the last
-					// tile column can pass w - 3: the pixels k < w - 3 - gx0 as one mask
-					// (v_pk_min_u16 by name: the compiler rewrites min(x, 1) as x != 0 and spends four compares, four selects and two
-					//  permutes on it)
-					const uint32_t one2 = 0x00010001u;
-					uint32_t b0, b1, d0, d1;
-					asm("v_pk_min_u16 %0, %1, %2" : "=v"(b0) : "v"(rb[0]), "v"(one2));
-					asm("v_pk_min_u16 %0, %1, %2" : "=v"(b1) : "v"(rb[1]), "v"(one2));
-					asm("v_pk_min_u16 %0, %1, %2" : "=v"(d0) : "v"(rd[0]), "v"(one2));
-					asm("v_pk_min_u16 %0, %1, %2" : "=v"(d1) : "v"(rd[1]), "v"(one2));
-					const int room = min(max(w - 3 - gx0, 0), 4);
-					const unsigned rm = (1u << room) - 1u;
-					const unsigned bits_b = (((b0 | (b0 >> 15)) & 3u) | (((b1 | (b1 >> 15)) & 3u) << 2)) & rm;
-					const unsigned bits_d = (((d0 | (d0 >> 15)) & 3u) | (((d1 | (d1 >> 15)) & 3u) << 2)) & rm;
-					m4 = bits_b | bits_d;
-					s_pol[it] = (uint8_t)(bits_b | (bits_d << 4));
-				}
+			for (int hsel = 0; hsel < 2; ++hsel) {
+				const uint32_t sel = hsel ? 0x0c030c02u : 0x0c010c00u;   // bytes (0,1) or (2,3) -> the two 16-bit lanes
+				const s16x2 c = as_s16x2(__builtin_amdgcn_perm(0u, C, sel));
+				const s16x2 a0 = as_s16x2(__builtin_amdgcn_perm(0u, Dn, sel)), a8 = as_s16x2(__builtin_amdgcn_perm(0u, Up, sel));
+				// x + 3 of pixels (0,1): bytes C3, R0; of (2,3): R1, R2.  x - 3 of (0,1): L1, L2; of (2,3): L3, C0
+				const s16x2 a4 = as_s16x2(hsel ? __builtin_amdgcn_perm(0u, R, 0x0c020c01u) : __builtin_amdgcn_perm(R, C, 0x0c040c03u));
+				const s16x2 a12 = as_s16x2(hsel ? __builtin_amdgcn_perm(C, L, 0x0c040c03u) : __builtin_amdgcn_perm(0u, L, 0x0c020c01u));
+				const s16x2 hi = c + as_s16x2(as_u32x(t2)), lo = c - as_s16x2(as_u32x(t2));
+				const s16x2 mb = __builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12));
+				const s16x2 xd = __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12));
+				rb[hsel] = as_u32(hi - mb);
+				rd[hsel] = as_u32(xd - lo);
 			}
-			all |= m4 << (4 * ra);
+			uint32_t FB = __builtin_amdgcn_perm(rb[1], rb[0], 0x07050301u);      // high bytes of pixels 0..3: 0xff = passes
+			uint32_t FD = __builtin_amdgcn_perm(rd[1], rd[0], 0x07050301u);
+			if (edge_tile) {                                                      // (uniform) right / bottom image border: pixels without a full ring leave
+				int sy, g;
+				if (ra < 4 || tid < 64) { sy = 8 * ra + (tid >> 5); g = 1 + (tid & 31); }
+				else { sy = hh >> 1; g = (hh & 1) * (SG - 1); }
+				const int room = min(max(w - 3 - (X0 - 4 + 4 * g), 0), 4);
+				const uint32_t rm = (sy < sy_lim && room > 0) ? (0xFFFFFFFFu >> (32 - 8 * room)) : 0u;
+				FB &= rm; FD &= rm;
+			}
+			const uint32_t mk = 0x02020202u << ra;
+			allb |= FB & mk;
+			alld |= FD & mk;
 		}
 		{
-			const unsigned cnt = __popc(all);                        // 0 .. 20
-			const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u), b3 = __ballot(cnt & 8u), b4 = __ballot(cnt & 16u);
-			const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3) + 16 * __popcll(b4);
+			// the wavefront appends all its survivors to the pixel queue in one step: inclusive scan of the lanes' counts over the rows of 16
+			// (row_shr 1, 2, 4, 8) and across them (row_bcast 15, 31), one ds atomic; a lane then walks its set bits.  Queue entry:
+			// tid << 5 | bit index, bit 13 = passes as bright, bit 14 = as dark.
+			uint32_t m = allb | alld;
+			const int cnt = __popc(m);
+			int x = cnt;
+			x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+			const int total = __builtin_amdgcn_readlane(x, 63);
 			if (total != 0) {                                      // (wave uniform)
-				const int lane = tid & 63;
-				const unsigned long long lt = (1ull << lane) - 1ull;
-				const int before = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt) + 8 * __popcll(b3 & lt) + 16 * __popcll(b4 & lt);
 				int qb = 0;
-				if (lane == 0) qb = atomicAdd(&s_q1n, total);
-				qb = __shfl(qb, 0, 64) + before;
-#pragma unroll
-				for (int ra = 0; ra < NRA; ++ra) {
-					const unsigned m4 = (all >> (4 * ra)) & 15u;
-					const unsigned code0 = (unsigned)(256 * ra + tid) << 2;      // code = 4 * group + pixel
-#pragma unroll
-					for (int k = 0; k < 4; ++k)
-						if (m4 & (1u << k)) s_q1[qb + __popc(m4 & ((1u << k) - 1u))] = (uint16_t)(code0 + k);
-					qb += __popc(m4);
+				if ((tid & 63) == 0) qb = atomicAdd(&s_q1n, total);
+				qb = __builtin_amdgcn_readfirstlane(qb) + x - cnt;
+				const uint32_t e0 = (uint32_t)tid << 5;
+				while (m != 0u) {
+					const int i = __builtin_ctz(m);
+					m &= m - 1u;
+					s_q1[qb++] = (uint16_t)(e0 | (uint32_t)i | (((allb >> i) & 1u) << 13) | (((alld >> i) & 1u) << 14));
 				}
 			}
 		}
@@ -325,12 +332,11 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 			uint16_t code = 0;
 			if (q < q1n) {
 				code = s_q1[q];
-				const int it = code >> 2, k = code & 3;
-				const int sy = it / SG, g = it - sy * SG;
+				int sy, col;
+				decode_item(code, sy, col);
 				// the polarity the compass test passed (both: bright first, dark below -- a wave-uniform branch almost never taken)
-				const unsigned pol = (unsigned)s_pol[it] >> k;
-				const bool pb = pol & 1u, pd = pol & 16u;
-				const uint8_t* px = s_img + (sy + 3) * IW + 4 * (g + 1) + k;
+				const bool pb = code & 0x2000u, pd = code & 0x4000u;
+				const uint8_t* px = s_img + (sy + 3) * IW + 4 + col;
 				uint32_t A[8];
 				ring_diffs_signed(px, pb ? 0x00010001u : 0xFFFFFFFFu, A);
 				int sc = fast_s_one(A);
@@ -342,7 +348,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 					}
 				}
 				corner = sc > threshold;
-				if (corner) s_sc[sy * SP + 4 * g + k] = (uint8_t)(sc - 1);
+				if (corner) s_sc[sy * SP + col] = (uint8_t)(sc - 1);
 			}
 			wave_push(corner, code, s_q2, &s_q2n);
 		}
@@ -359,10 +365,8 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 			bool pr = false;
 			uint32_t key = 0;
 			if (q < q2n) {
-				const int code = s_q2[q];
-				const int it = code >> 2, k = code & 3;
-				const int sy = it / SG, g = it - sy * SG;
-				const int col = 4 * g + k;                               // score tile column: gx - (X0 - 4)
+				int sy, col;                                             // col = score tile column: gx - (X0 - 4)
+				decode_item(s_q2[q], sy, col);
 				const int gy = Y0 - 1 + sy, gx = X0 - 4 + col;
 				const uint8_t* sc = s_sc + sy * SP + col;
 				const int own = sc[0];
