@@ -26,7 +26,7 @@
 namespace {
 
 #ifndef SSK_FAST_WAVES
-#define SSK_FAST_WAVES 5                   // min waves per SIMD = workgroups per CU the register budget must allow
+#define SSK_FAST_WAVES 7                   // min waves per SIMD = workgroups per CU the register budget must allow
 #endif
 constexpr int TW = 128, TH = 32;           // output tile; tile origin x is a multiple of 4
 constexpr int X_ORG = 28;                  // first tile column (<= SSK_EDGE, multiple of 4)
@@ -44,43 +44,6 @@ __device__ __forceinline__ uint32_t as_u32x(u16x2 v) { return __builtin_bit_cast
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
 __device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-
-// FAST score of a corner from its 16 ring differences, on PACKED 16-bit lanes (v_pk_min/max_i16): A[k] holds
-// (d[2k], d[2k+1]).  lo_n[i] = min of the n ring differences starting at i (doubling), score = max over the 16 arcs
-// of 9 of the arc's min (bright) or of minus the arc's max (dark).  Half the instructions and a third of the live
-// registers of the scalar form -- the scalar form made the whole kernel spill.
-__device__ __forceinline__ int fast_s_packed(const uint32_t (&A)[8])
-{
-	s16x2 a[8], b[8], lo[8], hi[8];
-#pragma unroll
-	for (int k = 0; k < 8; ++k) a[k] = as_s16x2(A[k]);
-#pragma unroll
-	for (int k = 0; k < 8; ++k) b[k] = as_s16x2(__builtin_amdgcn_alignbyte(A[(k + 1) & 7], A[k], 2u));   // (d[2k+1], d[2k+2])
-#pragma unroll
-	for (int k = 0; k < 8; ++k) { lo[k] = __builtin_elementwise_min(a[k], b[k]); hi[k] = __builtin_elementwise_max(a[k], b[k]); }   // runs of 2
-	s16x2 t[8], u[8];
-#pragma unroll
-	for (int k = 0; k < 8; ++k) { t[k] = __builtin_elementwise_min(lo[k], lo[(k + 1) & 7]); u[k] = __builtin_elementwise_max(hi[k], hi[(k + 1) & 7]); }   // runs of 4
-#pragma unroll
-	for (int k = 0; k < 8; ++k) { lo[k] = __builtin_elementwise_min(t[k], t[(k + 2) & 7]); hi[k] = __builtin_elementwise_max(u[k], u[(k + 2) & 7]); }     // runs of 8
-#pragma unroll
-	for (int k = 0; k < 8; ++k) { lo[k] = __builtin_elementwise_min(lo[k], a[(k + 4) & 7]); hi[k] = __builtin_elementwise_max(hi[k], a[(k + 4) & 7]); }   // arcs of 9
-	s16x2 sb = lo[0], hm = hi[0];
-#pragma unroll
-	for (int k = 1; k < 8; ++k) { sb = __builtin_elementwise_max(sb, lo[k]); hm = __builtin_elementwise_min(hm, hi[k]); }
-	const int bright = max(max((int)sb.x, (int)sb.y), 0), dark = min(min((int)hm.x, (int)hm.y), 255);
-	return max(bright, -dark);
-}
-
-// the 16 ring pixels around p (LDS, pitch IW) minus the centre, in ring order, packed in pairs
-__device__ __forceinline__ void ring_diffs_packed(const uint8_t* p, uint32_t (&A)[8])
-{
-	const uint32_t c = p[0], cc = c | (c << 16);
-	const uint32_t r[16] = {p[3 * IW], p[3 * IW + 1], p[2 * IW + 2], p[IW + 3], p[3], p[-IW + 3], p[-2 * IW + 2], p[-3 * IW + 1],
-	                        p[-3 * IW], p[-3 * IW - 1], p[-2 * IW - 2], p[-IW - 3], p[-3], p[IW - 3], p[2 * IW - 2], p[3 * IW - 1]};
-#pragma unroll
-	for (int k = 0; k < 8; ++k) A[k] = as_u32(as_s16x2(r[2 * k] | (r[2 * k + 1] << 16)) - as_s16x2(cc));
-}
 
 // Round 5: the score of ONE polarity.  score = max(bright, -dark) with bright = max over the 16 arcs of 9 of the arc's min difference, -dark the same of
 // the negated differences.  A pixel whose compass test failed for a polarity at threshold t has no arc of that polarity at t, i.e. that polarity's
@@ -121,36 +84,6 @@ __device__ __forceinline__ int fast_s_one(const uint32_t (&A)[8])
 	return max(max((int)best.x, (int)best.y), 0);
 }
 
-// append the values of the lanes with pred to an LDS queue: one ds atomic per wave
-__device__ __forceinline__ void wave_push(bool pred, uint16_t val, uint16_t* queue, int* counter)
-{
-	const unsigned long long m = __ballot(pred);
-	if (m == 0ull) return;                                   // wave uniform
-	const int lane = threadIdx.x & 63;
-	int base = 0;
-	if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, __popcll(m));
-	base = __shfl(base, __ffsll((long long)m) - 1, 64);
-	if (pred) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = val;
-}
-// the same for up to 4 flagged values per lane (4 ballots, still ONE atomic per wave)
-template <typename T>
-__device__ __forceinline__ void wave_push4(const bool (&pr)[4], const T (&val)[4], T* queue, int* counter)
-{
-	const unsigned long long m0 = __ballot(pr[0]), m1 = __ballot(pr[1]), m2 = __ballot(pr[2]), m3 = __ballot(pr[3]);
-	const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-	const int n = n0 + n1 + n2 + n3;
-	if (n == 0) return;                                      // wave uniform
-	const int lane = threadIdx.x & 63;
-	int base = 0;
-	if (lane == 0) base = atomicAdd(counter, n);
-	base = __shfl(base, 0, 64);
-	const unsigned long long lt = (1ull << lane) - 1ull;
-	if (pr[0]) queue[base + __popcll(m0 & lt)] = val[0];
-	if (pr[1]) queue[base + n0 + __popcll(m1 & lt)] = val[1];
-	if (pr[2]) queue[base + n0 + n1 + __popcll(m2 & lt)] = val[2];
-	if (pr[3]) queue[base + n0 + n1 + n2 + __popcll(m3 & lt)] = val[3];
-}
-
 // queue entry -> score row and column of the pixel (the item map of phase A): bits 5..12 = the lane, bits 0..4 = 8 k + 1 + ra
 __device__ __forceinline__ void decode_item(uint32_t code, int& sy, int& col)
 {
@@ -173,12 +106,11 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_img[IH * IW];
 	__shared__ __attribute__((aligned(16))) uint8_t s_sc[SH * SP];
-	__shared__ __attribute__((aligned(16))) uint16_t s_q1[NQ];
-	__shared__ uint16_t s_q2[NQ];
-	// the survivors of the NMS (at most one per 2 x 2 pixels of the tile) are listed where the pixel queue was: phase C reads the second queue only
-	static_assert(sizeof(uint32_t) * (TW * TH / 4 + 64) <= sizeof(uint16_t) * NQ, "the output list fits the first queue's storage");
-	uint32_t* const s_out = reinterpret_cast<uint32_t*>(s_q1);
-	__shared__ int s_q1n, s_q2n, s_on, s_base;
+	__shared__ uint16_t s_q1[NQ];
+	// the survivors of the NMS (at most one per 2 x 2 pixels of the tile) are listed where the image tile was: phase C reads scores and queue only
+	static_assert(sizeof(uint32_t) * (TW * TH / 4) <= sizeof(uint8_t) * IH * IW, "the output list fits the image tile's storage");
+	uint32_t* const s_out = reinterpret_cast<uint32_t*>(s_img);
+	__shared__ int s_q1n, s_on, s_base;
 
 	const int tid = threadIdx.x;
 #ifdef SSK_FAST_STAMPS
@@ -235,7 +167,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		static_assert(SH * SP % 16 == 0 && SH * SP / 16 <= 512, "score tile cleared by two 16-byte stores per lane");
 		reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
 		if (tid + 256 < SH * SP / 16) reinterpret_cast<uint4*>(s_sc)[tid + 256] = make_uint4(0u, 0u, 0u, 0u);
-		if (tid == 0) { s_q1n = 0; s_q2n = 0; s_on = 0; }
+		if (tid == 0) { s_q1n = 0; s_on = 0; }
 		__syncthreads();
 		if (t + stride < t_end) issue_loads(t + stride);
 		FSTAMP(0);
@@ -325,12 +257,17 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		// ---- phase B: the exact score of every queued pixel; a corner is a pixel whose score exceeds the threshold (an arc of 9 all brighter
 		//      than c + t or all darker than c - t  <=>  max over the arcs of the arc's min |difference| > t).  The separate corner test by 16-bit
 		//      ring masks that used to stand in front of the score (round 2) cost as much per pixel as the packed score itself. ----
+		// (round 6) each wavefront owns a quarter of the queue and packs its corners to the front of its own quarter -- the write index never
+		// passes the read index, and nobody else touches the quarter: no second queue (9 KiB of LDS: 6 workgroups per CU), no ds atomic per step.
 		const int q1n = s_q1n;
-		for (int base = 0; base < q1n; base += 256) {
-			const int q = base + tid;
+		const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+		const int seg = (q1n + 3) >> 2, seg0 = min(wv * seg, q1n), seg1 = min(seg0 + seg, q1n);
+		int nw = 0;                                                  // corners of this wavefront (uniform)
+		for (int base = seg0; base < seg1; base += 64) {
+			const int q = base + lane;
 			bool corner = false;
 			uint16_t code = 0;
-			if (q < q1n) {
+			if (q < seg1) {
 				code = s_q1[q];
 				int sy, col;
 				decode_item(code, sy, col);
@@ -350,23 +287,24 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 				corner = sc > threshold;
 				if (corner) s_sc[sy * SP + col] = (uint8_t)(sc - 1);
 			}
-			wave_push(corner, code, s_q2, &s_q2n);
+			const unsigned long long m = __ballot(corner);
+			if (corner) s_q1[seg0 + nw + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = code;
+			nw += __popcll(m);
 		}
 		__syncthreads();
-		const int q2n = s_q2n;
 
 		FSTAMP(2);
 		FSTAMP(3);
-		// ---- phase C: strict 3x3 NMS inside the emit region [31,W-31) x [31,H-31): a lane per CORNER (the second queue again: a few % of the
+		// ---- phase C: strict 3x3 NMS inside the emit region [31,W-31) x [31,H-31): a lane per CORNER (the wavefront's own corners: a few % of the
 		// pixels), its 8 neighbours' scores by byte reads.  (A sweep of all 1024 pixel groups of the tile ran every wavefront through the
 		// whole test with an eighth of its lanes holding a corner: ~350 of the kernel's ~1550 instructions per thread.) ----
-		for (int base = 0; base < q2n; base += 256) {
-			const int q = base + tid;
+		for (int base = 0; base < nw; base += 64) {
+			const int q = base + lane;
 			bool pr = false;
 			uint32_t key = 0;
-			if (q < q2n) {
+			if (q < nw) {
 				int sy, col;                                             // col = score tile column: gx - (X0 - 4)
-				decode_item(s_q2[q], sy, col);
+				decode_item(s_q1[seg0 + q], sy, col);
 				const int gy = Y0 - 1 + sy, gx = X0 - 4 + col;
 				const uint8_t* sc = s_sc + sy * SP + col;
 				const int own = sc[0];
@@ -381,11 +319,10 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 			}
 			const unsigned long long m = __ballot(pr);
 			if (m != 0ull) {                                             // (wave uniform)
-				const int lane = tid & 63;
 				int b0 = 0;
 				if (lane == 0) b0 = atomicAdd(&s_on, __popcll(m));
-				b0 = __shfl(b0, 0, 64);
-				if (pr) s_out[b0 + __popcll(m & ((1ull << lane) - 1ull))] = key;
+				b0 = __builtin_amdgcn_readfirstlane(b0);
+				if (pr) s_out[b0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = key;
 			}
 		}
 		__syncthreads();
@@ -401,7 +338,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		__syncthreads();     // LDS is rewritten by the next tile
 #ifdef SSK_FAST_STAMPS
 		FSTAMP(4);
-		if (tid == 0 && (blockIdx.x % 9973) == 77) printf("fast stamps (cycles) tile %d: load %llu A %llu (q1 %d) B1 %llu (q2 %d) B %llu C+out %llu (%d)\n", t, s_t[0], s_t[1], s_q1n, s_t[2], s_q2n, s_t[3], s_t[4], s_on);
+		if (tid == 0 && (blockIdx.x % 9973) == 77) printf("fast stamps (cycles) tile %d: load %llu A %llu (q1 %d) B1 %llu (q2 of wave 0: %d) B %llu C+out %llu (%d)\n", t, s_t[0], s_t[1], s_q1n, s_t[2], nw, s_t[3], s_t[4], s_on);
 #endif
 	}
 }
