@@ -26,13 +26,18 @@ FLAGS = [
 ] + os.environ.get("SSK_EXTRA_CFLAGS", "").split()     # e.g. -DSSK_LM_STAMPS for a diagnostic build
 
 
+# per-source flags.  ssk_fast.hip: its lane-0 atomics are already one per wavefront or workgroup, and the optimizer's aggregated form waits for the
+# returned value where the atomic is issued -- the tile draw of fast_nms_kernel is meant to return a whole tile later
+SRC_FLAGS = {"ssk_fast.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
 def _stamp(src):
     h = hashlib.sha1()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + SRC_FLAGS.get(src, [])).encode())
     inc = os.path.join(ROOT, "include")
     files = [os.path.join(CSRC, f) for f in [src] + sorted(x for x in os.listdir(CSRC) if x.endswith(".h"))]
     files += [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]     # every public header (ssk_brief_pattern.h too)
@@ -48,7 +53,7 @@ def _compile(src):
     stamp = _stamp(src)
     if os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC] + FLAGS + SRC_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr))

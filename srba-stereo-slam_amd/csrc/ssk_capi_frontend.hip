@@ -55,7 +55,7 @@ int batch_create(ssk_ctx* ctx, int n_kf, int w, int h, int max_feats, ssk_kfbatc
 	int rc = SSK_OK;
 	if (!rc) rc = dev_alloc(ctx, &b->img, ni * h * b->pitch + 256);
 	if (!rc) rc = dev_alloc(ctx, &b->cand, ni * b->cand_cap);
-	if (!rc) rc = dev_alloc(ctx, &b->ncand, ni);
+	if (!rc) rc = dev_alloc(ctx, &b->ncand, ni + SSK_FAST_CTR_INTS);      // + the tile counters of ssk_launch_fast
 	if (!rc) rc = dev_alloc(ctx, &b->kp_xy, nf);
 	if (!rc) rc = dev_alloc(ctx, &b->kp_resp, nf);
 	if (!rc) rc = dev_alloc(ctx, &b->kp_angle, nf);
@@ -72,7 +72,7 @@ int batch_create(ssk_ctx* ctx, int n_kf, int w, int h, int max_feats, ssk_kfbatc
 	hipError_t e = hipMemsetAsync(b->img, 0, ni * h * b->pitch + 256, ctx->stream);
 	if (e == hipSuccess) e = hipMemsetAsync(b->nkp, 0, ni * 4, ctx->stream);
 	if (e == hipSuccess) e = hipMemsetAsync(b->nm, 0, (size_t)n_kf * 4, ctx->stream);
-	if (e == hipSuccess) e = hipMemsetAsync(b->ncand, 0, ni * 4, ctx->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(b->ncand, 0, (ni + SSK_FAST_CTR_INTS) * 4, ctx->stream);
 	// the storage is the caller's to write when create returns -- through ssk_kfbatch_images on ANY stream (bench.py fills it with torch on the null
 	// stream): a fill still queued on the context's non-blocking stream raced such a write and zeroed the first images of a batch now and then
 	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -102,7 +102,7 @@ __device__ __forceinline__ int div_magic(int n, uint32_t magic) { return magic ?
 __global__ __launch_bounds__(256, SSK_FAST_WAVES)
 void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch, int img_begin, int n_img,
                      int tiles_x, int tiles_y, uint32_t magic_img, uint32_t magic_x, int threshold,
-                     uint32_t* __restrict__ cand, int cand_cap, int32_t* __restrict__ ncand)
+                     uint32_t* __restrict__ cand, int cand_cap, int32_t* __restrict__ ncand, int32_t* __restrict__ tile_ctr)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_img[IH * IW];
 	__shared__ __attribute__((aligned(16))) uint8_t s_sc[SH * SP];
@@ -110,7 +110,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 	// the survivors of the NMS (at most one per 2 x 2 pixels of the tile) are listed where the image tile was: phase C reads scores and queue only
 	static_assert(sizeof(uint32_t) * (TW * TH / 4) <= sizeof(uint8_t) * IH * IW, "the output list fits the image tile's storage");
 	uint32_t* const s_out = reinterpret_cast<uint32_t*>(s_img);
-	__shared__ int s_q1n, s_on, s_base;
+	__shared__ int s_q1n, s_on, s_base, s_next;
 
 	const int tid = threadIdx.x;
 #ifdef SSK_FAST_STAMPS
@@ -136,9 +136,9 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		const int X0 = X_ORG + bx * TW, Y0 = SSK_EDGE + by * TH;
 #pragma unroll
 		for (int u = 0; u < NLD; ++u) {
-			const int i = tid + 256 * u;
-			uint4 v = make_uint4(0u, 0u, 0u, 0u);
-			if (i < NCH) {
+			const int i = min(tid + 256 * u, NCH - 1);           // lanes past the last chunk re-read it (and do not store it): no branch around a load
+			uint4 v;
+			{
 				const int row = i / 9, c = i - row * 9;
 				const int gy = min(max(Y0 - 4 + row, 0), h - 1);
 				const int gx = X0 - 8 + 16 * c;                   // a multiple of 4: global dwordx4 loads only need dword alignment
@@ -151,25 +151,34 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		}
 	};
 
-	int t = xcd * per_x + jb;
+	// tile_ctr != NULL (round 6): persistent workgroups that DRAW their tiles -- the first one by position, the others from the XCD's counter, one
+	// draw ahead of the prefetch (the atomic's round trip hides behind a whole tile).  A fixed stride visits only tile positions j + k * stride mod
+	// (tiles per image): with 100 tiles per image and a stride of 224 a workgroup saw 25 of the 100 positions, always the same part of every
+	// image, and the heavy parts made some workgroups finish last (measured: 15 % slower than one tile per workgroup at threshold 20).
+	const bool draw = tile_ctr != nullptr;                    // (uniform)
+	// a draw is a PAIR of neighbouring tiles (2 p, 2 p + 1 of the XCD's range): one atomic per two tiles -- at one per tile the eight counters, 16 ns a
+	// draw each, were the floor of the kernel (0.40 ms per 204 800 tiles)
+	int t = xcd * per_x + (draw ? 2 * jb : jb), t_next = draw ? t + 1 : t + stride;
+	bool second = false;                                      // (uniform) the tile in work is the second of its pair
+	int drawn = 0;                                            // lane 0: the draw in flight
 	if (t < t_end) issue_loads(t);
-	for (; t < t_end; t += stride) {
+	for (; t < t_end; t = t_next, t_next = !draw ? t_next + stride : (second ? t_next + 1 : s_next), second = !second) {
 		// the prefetched tile goes to LDS; the next tile's loads are issued right after and fly during the phases
 #pragma unroll
 		for (int u = 0; u < NLD; ++u) {
-			const int i = tid + 256 * u;
-			if (i < NCH) {
-				const int row = i / 9, c = i - row * 9;
-				uint32_t* d = reinterpret_cast<uint32_t*>(s_img) + row * (IW / 4) + 4 * c;      // (row pitch 37 dwords: not 16-byte aligned)
-				d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
-			}
+			const int i = min(tid + 256 * u, NCH - 1);           // (the lanes past the last chunk write it once more: no branch around the wait for the loads)
+			const int row = i / 9, c = i - row * 9;
+			uint32_t* d = reinterpret_cast<uint32_t*>(s_img) + row * (IW / 4) + 4 * c;      // (row pitch 37 dwords: not 16-byte aligned)
+			d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
 		}
 		static_assert(SH * SP % 16 == 0 && SH * SP / 16 <= 512, "score tile cleared by two 16-byte stores per lane");
 		reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
 		if (tid + 256 < SH * SP / 16) reinterpret_cast<uint4*>(s_sc)[tid + 256] = make_uint4(0u, 0u, 0u, 0u);
 		if (tid == 0) { s_q1n = 0; s_on = 0; }
 		__syncthreads();
-		if (t + stride < t_end) issue_loads(t + stride);
+		if (t_next < t_end) issue_loads(t_next);
+		// (built with -amdgpu-atomic-optimizer-strategy=None, build.py: the optimizer's wave-aggregated form reads the result back at once)
+		if (draw && !second && tid == 0) drawn = atomicAdd(&tile_ctr[xcd * SSK_FAST_CTR_STRIDE], 1);
 		FSTAMP(0);
 
 		const int im = div_magic(t, magic_img), rr = t - im * tiles_img, by = div_magic(rr, magic_x), bx = rr - by * tiles_x;
@@ -335,6 +344,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 			for (int i = tid; i < on; i += 256)
 				if (base + i < cand_cap) dst[base + i] = s_out[i];
 		}
+		if (draw && !second && tid == 0) s_next = xcd * per_x + 2 * (stride + drawn);
 		__syncthreads();     // LDS is rewritten by the next tile
 #ifdef SSK_FAST_STAMPS
 		FSTAMP(4);
@@ -349,7 +359,14 @@ int ssk_launch_fast(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, in
 {
 	const int nimg = img_end - img_begin;
 	if (nimg <= 0) return SSK_OK;
-	SSK_HIP(ctx, hipMemsetAsync(b->ncand + img_begin, 0, sizeof(int32_t) * (size_t)nimg, ctx->stream));
+	// the candidate counts of the images and, behind the last image's (ssk_kfbatch_create), the eight tile counters of the persistent form -- a
+	// cache line apart and more: the counters of all eight XCDs in ONE line made that line travel between the L2s at every draw (92 ns per draw)
+	int32_t* const tile_ctr = b->ncand + (size_t)b->n_kf * 2 + SSK_FAST_CTR_STRIDE;
+	if (img_end == b->n_kf * 2) SSK_HIP(ctx, hipMemsetAsync(b->ncand + img_begin, 0, sizeof(int32_t) * (size_t)(nimg + SSK_FAST_CTR_INTS), ctx->stream));
+	else {
+		SSK_HIP(ctx, hipMemsetAsync(b->ncand + img_begin, 0, sizeof(int32_t) * (size_t)nimg, ctx->stream));
+		SSK_HIP(ctx, hipMemsetAsync(tile_ctr - SSK_FAST_CTR_STRIDE, 0, sizeof(int32_t) * SSK_FAST_CTR_INTS, ctx->stream));
+	}
 	const int ex = b->w - SSK_EDGE - X_ORG, eh = b->h - 2 * SSK_EDGE;     // columns X_ORG .. W-32, rows 31 .. H-32
 	const int tiles_x = (ex + TW - 1) / TW, tiles_y = (eh + TH - 1) / TH;
 	const long long n_tiles = (long long)tiles_x * tiles_y * nimg;
@@ -358,15 +375,23 @@ int ssk_launch_fast(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, in
 	const uint32_t magic_x = tiles_x > 1 ? (uint32_t)((0x100000000ull + (unsigned long long)tiles_x - 1) / (unsigned long long)tiles_x) : 0u;
 	if (n_tiles * tiles_x * tiles_y >= 0x100000000ll)
 		return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_launch_fast: %lld tiles of %d per image outside the tile index arithmetic", n_tiles, tiles_x * tiles_y);
-	// default: one tile per workgroup, tile ranges contiguous per XCD; SSK_FAST_WG_PER_CU=k switches to k persistent
-	// workgroups per CU that prefetch their next tile (measured slower on MI355X: the dispatcher overlaps better)
-	static const int wg_per_cu = [] { const char* e = getenv("SSK_FAST_WG_PER_CU"); return e ? atoi(e) : 0; }();
+	// default (round 6): as many persistent workgroups as the CUs hold at once (7 per CU: 20 KB of LDS, 70 VGPRs), drawing their tiles in pairs from
+	// the XCD's counter; SSK_FAST_WG_PER_CU=k: k per CU, 0: one tile per workgroup (the form up to round 5); SSK_FAST_DRAW=0: a fixed stride instead
+	// of the draw (measured slower: see the kernel)
+	static const int wg_per_cu = [] {
+		const char* e = getenv("SSK_FAST_WG_PER_CU");
+		if (e) return atoi(e);
+		int n = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fast_nms_kernel, 256, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 0; }
+		return n;
+	}();
+	static const int draw = [] { const char* e = getenv("SSK_FAST_DRAW"); return e ? atoi(e) : 1; }();
 	long long g = wg_per_cu > 0 ? (long long)ctx->n_cu * wg_per_cu : n_tiles;    // 0: one tile per workgroup
 	if (g > n_tiles) g = n_tiles;
 	g = (g + 7) / 8 * 8;
 	ssk_stage_scope prof(ctx, SSK_STAGE_FAST);
 	hipLaunchKernelGGL(fast_nms_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, b->img, b->w, b->h, b->pitch, img_begin, nimg,
-	                   tiles_x, tiles_y, magic_img, magic_x, threshold, b->cand, b->cand_cap, b->ncand);
+	                   tiles_x, tiles_y, magic_img, magic_x, threshold, b->cand, b->cand_cap, b->ncand, (wg_per_cu > 0 && draw) ? tile_ctr : nullptr);
 	SSK_LAUNCH_CHECK(ctx, "fast_nms_kernel");
 	return SSK_OK;
 }

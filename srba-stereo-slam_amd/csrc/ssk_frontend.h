@@ -4,6 +4,8 @@
 
 constexpr int SSK_EDGE = 31;         // cv::ORB edgeThreshold: keypoints only in [31, W-31) x [31, H-31)
 constexpr int SSK_MAX_FEATS = 2048;  // n_feats limit (reference: 500)
+constexpr int SSK_FAST_CTR_STRIDE = 64;                      // ints between the per-XCD tile counters of ssk_launch_fast (256 bytes: own cache lines)
+constexpr int SSK_FAST_CTR_INTS = 9 * SSK_FAST_CTR_STRIDE;   // behind ncand[B*2]: a stride of padding, then the eight counters
 
 // HBM layout of a batch of B keyframes (SoA; everything the per-keyframe hot path produces stays here):
 //   img     u8   [B*2][H][pitch]      eye-major inside a keyframe (left, right); pitch % 128 == 0
