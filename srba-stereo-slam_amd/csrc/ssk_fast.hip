@@ -3,20 +3,21 @@
 // Replaces the detection half of cv::ORB as driven by stereo-vo's processNewImagePair (reference call
 // sites EST.cpp:112,267); contract C2-C4 of DESIGN.md "Front-end contract".
 //
-// Mapping (gfx950): one 256-thread workgroup per 128x32 output tile (4 resident per CU: <= 128 VGPRs, 33 KiB
-// of LDS); each XCD owns a contiguous range of tiles, so halo re-reads stay in its L2.  Per tile:
-//   phase 0  the (128+16) x (32+8) pixel tile (ring + NMS halo, 4-byte aligned columns) is staged in LDS with
-//            aligned dword loads, 144 B per row coalesced (neighbouring tiles re-read the halo from L2);
-//   phase A  item = 4 horizontally adjacent pixels: FIVE dword LDS reads (rows y-3, y, y+3) feed the necessary
-//            test on the 4 compass ring pixels of all four (a 9-arc holds two adjacent compass points); a lane keeps
-//            the survivor bits of its five items and the wave appends them all to an LDS pixel queue in ONE step
-//            (five ballots of the counts, one ds atomic), so the later phases run on dense lanes;
-//   phase B  queued pixels: exact score s-1 (max over the 16 arcs of 9 of the min signed difference, by min/max doubling on packed
-//            16-bit pairs); score > threshold is the corner test (round 3: the separate 16-bit ring-mask test in front of it cost as
-//            much per pixel as the score) -> 8-bit score tile in LDS + second queue of real corners (a few % of the pixels);
-//   phase C  strict 3x3 NMS, 4 pixels per lane behind one dword read of their scores (all-zero groups skip),
-//            survivors packed score<<24|(4095-y)<<12|(4095-x) into an LDS list; ONE global atomicAdd per
-//            workgroup reserves the output range in the image's candidate list.
+// Mapping (gfx950, round 6): 256-thread workgroups over 128x32 output tiles, 7 resident per CU (70 VGPRs, 20 KiB of LDS), persistent: each XCD owns a
+// contiguous range of tiles (halo re-reads stay in its L2) and its workgroups DRAW tile pairs from the XCD's counter, the next tile's pixels in
+// flight during the phases of the one in work.  The kernel is bound by vector-instruction issue (~93 % of the SIMD cycles, ~580 instructions per
+// wavefront and tile), not by HBM: every phase below is written for instruction count.  Per tile:
+//   phase 0  the (128+16) x (32+8) pixel tile (ring + NMS halo, 4-byte aligned columns) goes from the prefetch registers to LDS (16-byte global
+//            loads, 144 B per row coalesced; neighbouring tiles re-read the halo from L2);
+//   phase A  item = 4 horizontally adjacent pixels: FIVE dword LDS reads (rows y-3, y, y+3) feed the necessary test on the 4 compass ring pixels
+//            of all four (a 9-arc holds two adjacent compass points), on packed 16-bit pairs, the verdict left in the sign of a difference; a
+//            lane keeps the survivor bits of its five items in two words (bright / dark) and the wavefront appends them all to an LDS pixel
+//            queue in ONE step (a DPP scan of the counts, one ds atomic), each lane walking its set bits;
+//   phase B  queued pixels, a quarter of the queue per wavefront: exact score s-1 of the polarity the compass test passed (max over the 16 arcs
+//            of 9 of the min signed difference; opposite ring pixels share a register, 31 packed min / max); score > threshold is the corner
+//            test -> 8-bit score tile in LDS, the corners packed to the front of the wavefront's quarter;
+//   phase C  strict 3x3 NMS, a lane per corner, its 8 neighbours' scores by byte reads; survivors packed score<<24|(4095-y)<<12|(4095-x) into an
+//            LDS list (in the image tile's storage); ONE global atomicAdd per workgroup reserves the output range in the image's candidate list.
 // The candidate order in HBM is not deterministic (atomic reservation order); every consumer orders by
 // the packed key, which is unique per pixel, so results are.
 // Algorithmic bytes: W*H per image read once (+ 4 B per surviving corner written); roofline: HBM.
@@ -35,7 +36,7 @@ constexpr int IW = IWV + 4;                // row pitch 148 B = 37 dwords (odd: 
 constexpr int IH = TH + 8;                 //                 rows    Y0-4 .. Y0+TH+3
 constexpr int SG = (TW + 8) / 4;           // score groups per row: columns X0-4 .. X0+TW+3
 constexpr int SH = TH + 2;                 // score rows Y0-1 .. Y0+TH
-constexpr int SP = IWV;                    // score tile pitch (column index = gx - (X0-4))
+constexpr int SP = IW;                     // score tile pitch (column index = gx - (X0-4)): the image tile's, so a pixel is ONE offset in both
 constexpr int NQ = SG * SH * 4;            // pixels in the score region
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -59,7 +60,8 @@ __device__ __forceinline__ void ring_diffs_signed(const uint8_t* p, uint32_t sgn
 	                        p[-3 * IW], p[-3 * IW - 1], p[-2 * IW - 2], p[-IW - 3], p[-3], p[IW - 3], p[2 * IW - 2], p[3 * IW - 1]};
 	const s16x2 s2 = as_s16x2(sgn2), ncs = as_s16x2(0u) - as_s16x2(cc) * s2;
 #pragma unroll
-	for (int k = 0; k < 8; ++k) A[k] = as_u32(as_s16x2(r[k] | (r[k + 8] << 16)) * s2 + ncs);
+	for (int k = 0; k < 8; ++k)      // (by name: the compiler rewrites r * s + (-c * s) as (r - c) * s, two packed instructions per pair)
+		asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(A[k]) : "v"(r[k] | (r[k + 8] << 16)), "v"(sgn2), "v"(as_u32(ncs)));
 }
 // max over the 16 arcs of 9 of the arc's min.  With M(j) = min d[2j+1 .. 2j+8], the arcs from 2j and from 2j+1 are min(d[2j], M) and
 // min(M, d[2j+9]): their max is min(M(j), max(d[2j], d[2j+9])) (the decomposition of cv's cornerScore<16>).  M(j) = min(d[2j+1], H[j+1], H[j+2], H[j+3],
@@ -105,7 +107,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
                      uint32_t* __restrict__ cand, int cand_cap, int32_t* __restrict__ ncand, int32_t* __restrict__ tile_ctr)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_img[IH * IW];
-	__shared__ __attribute__((aligned(16))) uint8_t s_sc[SH * SP];
+	__shared__ __attribute__((aligned(16))) uint8_t s_sc[(SH * SP + 15) & ~15];
 	__shared__ uint16_t s_q1[NQ];
 	// the survivors of the NMS (at most one per 2 x 2 pixels of the tile) are listed where the image tile was: phase C reads scores and queue only
 	static_assert(sizeof(uint32_t) * (TW * TH / 4) <= sizeof(uint8_t) * IH * IW, "the output list fits the image tile's storage");
@@ -171,9 +173,9 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 			uint32_t* d = reinterpret_cast<uint32_t*>(s_img) + row * (IW / 4) + 4 * c;      // (row pitch 37 dwords: not 16-byte aligned)
 			d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
 		}
-		static_assert(SH * SP % 16 == 0 && SH * SP / 16 <= 512, "score tile cleared by two 16-byte stores per lane");
+		static_assert((SH * SP + 15) / 16 <= 512, "score tile cleared by two 16-byte stores per lane");
 		reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
-		if (tid + 256 < SH * SP / 16) reinterpret_cast<uint4*>(s_sc)[tid + 256] = make_uint4(0u, 0u, 0u, 0u);
+		if (tid + 256 < (SH * SP + 15) / 16) reinterpret_cast<uint4*>(s_sc)[tid + 256] = make_uint4(0u, 0u, 0u, 0u);
 		if (tid == 0) { s_q1n = 0; s_on = 0; }
 		__syncthreads();
 		if (t_next < t_end) issue_loads(t_next);
@@ -256,7 +258,8 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 				while (m != 0u) {
 					const int i = __builtin_ctz(m);
 					m &= m - 1u;
-					s_q1[qb++] = (uint16_t)(e0 | (uint32_t)i | (((allb >> i) & 1u) << 13) | (((alld >> i) & 1u) << 14));
+					const uint32_t e = (__builtin_amdgcn_ubfe(alld, (uint32_t)i, 1u) << 14) | (__builtin_amdgcn_ubfe(allb, (uint32_t)i, 1u) << 13) | (e0 | (uint32_t)i);
+					s_q1[qb++] = (uint16_t)e;
 				}
 			}
 		}
@@ -282,7 +285,8 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 				decode_item(code, sy, col);
 				// the polarity the compass test passed (both: bright first, dark below -- a wave-uniform branch almost never taken)
 				const bool pb = code & 0x2000u, pd = code & 0x4000u;
-				const uint8_t* px = s_img + (sy + 3) * IW + 4 + col;
+				const int at = (int)__umul24((unsigned)sy, (unsigned)SP) + col;     // the pixel in the score tile; + 3 rows + 4 columns in the image tile
+				const uint8_t* px = s_img + at + 3 * IW + 4;
 				uint32_t A[8];
 				ring_diffs_signed(px, pb ? 0x00010001u : 0xFFFFFFFFu, A);
 				int sc = fast_s_one(A);
@@ -294,7 +298,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 					}
 				}
 				corner = sc > threshold;
-				if (corner) s_sc[sy * SP + col] = (uint8_t)(sc - 1);
+				if (corner) s_sc[at] = (uint8_t)(sc - 1);
 			}
 			const unsigned long long m = __ballot(corner);
 			if (corner) s_q1[seg0 + nw + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = code;
@@ -315,7 +319,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 				int sy, col;                                             // col = score tile column: gx - (X0 - 4)
 				decode_item(s_q1[seg0 + q], sy, col);
 				const int gy = Y0 - 1 + sy, gx = X0 - 4 + col;
-				const uint8_t* sc = s_sc + sy * SP + col;
+				const uint8_t* sc = s_sc + (int)__umul24((unsigned)sy, (unsigned)SP) + col;
 				const int own = sc[0];
 				if (own != 0 && sy >= 1 && sy <= TH && col >= 4 && col < TW + 4 && gy < h - SSK_EDGE && gx >= SSK_EDGE && gx < w - SSK_EDGE) {
 					const int m0 = max(max((int)sc[-SP - 1], (int)sc[-SP]), max((int)sc[-SP + 1], (int)sc[-1]));
