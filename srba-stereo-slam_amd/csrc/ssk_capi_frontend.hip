@@ -96,7 +96,7 @@ int ssk_set_brief_pattern(ssk_ctx* ctx, const int8_t* pattern1024)
 	SSK_HIP(ctx, hipSetDevice(ctx->device));
 	SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	std::memcpy(ctx->pattern, pattern1024, 1024);
-	SSK_HIP(ctx, hipMemcpy(ctx->d_pattern, ctx->pattern, 1024, hipMemcpyHostToDevice));
+	SSK_HIP(ctx, ssk_upload_pattern(ctx));
 	return SSK_OK;
 }
 

@@ -127,6 +127,17 @@ static void compute_dir_thresholds(float out[19])
 	}
 }
 
+// the BRIEF pattern on the device: 1024 int8 coordinates, then the same as floats (the describe kernel rotates them; converting there cost 16
+// instructions per keypoint wavefront)
+hipError_t ssk_upload_pattern(ssk_ctx* ctx)
+{
+	float f[1024];
+	for (int i = 0; i < 1024; ++i) f[i] = (float)ctx->pattern[i];
+	hipError_t e = hipMemcpy(ctx->d_pattern, ctx->pattern, 1024, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_pattern + 1024, f, sizeof f, hipMemcpyHostToDevice);
+	return e;
+}
+
 extern "C" {
 
 int ssk_api_version(void) { return SSK_API_VERSION; }
@@ -187,8 +198,8 @@ int ssk_create(ssk_ctx** out, int device, void* hip_stream)
 		}
 		std::memcpy(ctx->pattern, buf, sizeof buf);
 	}
-	CREATE_HIP(hipMalloc((void**)&ctx->d_pattern, sizeof ctx->pattern));
-	CREATE_HIP(hipMemcpy(ctx->d_pattern, ctx->pattern, sizeof ctx->pattern, hipMemcpyHostToDevice));
+	CREATE_HIP(hipMalloc((void**)&ctx->d_pattern, sizeof ctx->pattern * 5));          // the int8 table and its float copy (ssk_upload_pattern)
+	CREATE_HIP(ssk_upload_pattern(ctx));
 #undef CREATE_HIP
 	*out = ctx;
 	return SSK_OK;

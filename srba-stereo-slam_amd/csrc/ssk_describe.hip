@@ -40,7 +40,41 @@ constexpr int BT = SSK_DESC_BT;      // pitch (bytes) of a column of the transpo
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// Moments of the radius-15 disc (cv::ORB's umax table: |u| <= umax[|v|]): two lanes per row v (u in [-16, -1] and [0, 15]), the 16 pixels as four
+// realigned dwords.  Per lane (row, half) and dword k the table holds the packed |u| weights with ZERO bytes outside the disc (m10 = +-sum by
+// v_dot4_u32_u8) and the same bytes as ones (the row sum for m01): two 16-byte loads replace the mask arithmetic (round 5: ~50 instructions).
+struct moment_table {
+	uint32_t w[62][8];
+	constexpr moment_table() : w()
+	{
+		const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+		for (int lane = 0; lane < 62; ++lane) {
+			const int v = (lane >> 1) - 15, half = lane & 1, um = umax[v < 0 ? -v : v];
+			for (int k = 0; k < 4; ++k) {
+				uint32_t wt = 0, one = 0;
+				for (int i = 0; i < 4; ++i) {
+					const int u = half ? 4 * k + i : -16 + 4 * k + i;
+					const int au = u < 0 ? -u : u;
+					if (au <= um) { wt |= (uint32_t)au << (8 * i); one |= 1u << (8 * i); }
+				}
+				w[lane][k] = wt; w[lane][4 + k] = one;
+			}
+		}
+	}
+};
+__constant__ moment_table c_mom = moment_table();
+
+// sum over the wavefront's 64 lanes (all active), returned uniform: row_shr 1, 2, 4, 8 inside the rows of 16, row_bcast 15 / 31 across them
+__device__ __forceinline__ int wave_sum(int x)
+{
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+	return __builtin_amdgcn_readlane(x, 63);
+}
 
 __device__ __forceinline__ float atan2_deg(float y, float x)
 {
@@ -78,8 +112,8 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 #if SSK_DESC_ALIAS
 	// (the blurred patch takes the raw patch's place: the raw rows are dead after the horizontal pass, and the kernel's occupancy is its LDS --
 	//  7.6 KB per keypoint wave hold 20 of a CU's 32 wave slots)
-	static_assert(BD * BT <= PD * PP + 16, "the blurred tile fits the raw patch's storage");
-	uint8_t* s_b = s_raw;                      // blurred patch, transposed: [column 3..41][row 3..41]
+	static_assert(BD * BT + 48 <= PD * PP + 16, "the blurred tile fits the raw patch's storage");
+	uint8_t* s_b = s_raw + 48;                 // blurred patch, transposed: [column 3..41][row 3..41] (48 bytes in: the tests address it from (-1, -1))
 #else
 	__shared__ uint8_t s_b[BD * BT];           // blurred patch, transposed: [column 3..41][row 3..41]
 #endif
@@ -109,33 +143,27 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 	}
 	__syncthreads();
 
-	// moments over the radius-15 disc: two lanes per row v (u in [-16, -1] and [0, 15]; the disc's |u| <= umax(v) by a byte mask), the
-	// 16 pixels as 4 realigned dwords, sums by v_dot4_u32_u8 against packed |u| weights (a byte-by-byte loop was a sixth of the kernel)
+	// moments over the radius-15 disc (c_mom above): m10 = sum u I, m01 = sum v I
 	int m10 = 0, m01 = 0;
 	if (lane < 62) {
 		const int v = (lane >> 1) - 15, half = lane & 1;
-		const int um = c_umax[v < 0 ? -v : v];
 		const int b = (PR + v) * PP + shift + PR - (half ? 0 : 16);
 		const uint32_t* p = reinterpret_cast<const uint32_t*>(s_raw) + (b >> 2);
 		const uint32_t sub = (uint32_t)(b & 3);
+		const uint4 wt = reinterpret_cast<const uint4*>(c_mom.w[lane])[0], one = reinterpret_cast<const uint4*>(c_mom.w[lane])[1];
+		const uint32_t W[4] = {wt.x, wt.y, wt.z, wt.w}, O[4] = {one.x, one.y, one.z, one.w};
 		uint32_t D[5];
 #pragma unroll
 		for (int k = 0; k < 5; ++k) D[k] = p[k];
-		int rs = 0, mu = 0;
+		uint32_t rs = 0, mu = 0;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t I = __builtin_amdgcn_alignbyte(D[k + 1], D[k], sub);
-			// bytes inside the disc: upper half u = 4k + i <= um; lower half u = -16 + 4k + i >= -um
-			const int nlo = half ? min(max(um + 1 - 4 * k, 0), 4) : min(max(16 - um - 4 * k, 0), 4);      // upper: valid low bytes; lower: invalid low bytes
-			const uint32_t lowmask = nlo >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nlo)) - 1u);
-			const uint32_t Im = I & (half ? lowmask : ~lowmask);
-			const uint32_t wu = 0x03020100u + 0x04040404u * (uint32_t)k;                                   // u = 4k + (0, 1, 2, 3)
-			const uint32_t wl = 0x0D0E0F10u - 0x04040404u * (uint32_t)k;                                   // |u| = 16 - 4k - (0, 1, 2, 3)
-			mu = (int)__builtin_amdgcn_udot4(Im, half ? wu : wl, (uint32_t)mu, false);
-			rs = (int)__builtin_amdgcn_udot4(Im, 0x01010101u, (uint32_t)rs, false);
+			mu = __builtin_amdgcn_udot4(I, W[k], mu, false);
+			rs = __builtin_amdgcn_udot4(I, O[k], rs, false);
 		}
-		m10 = half ? mu : -mu;
-		m01 = v * rs;
+		m10 = half ? (int)mu : -(int)mu;
+		m01 = v * (int)rs;
 	}
 	// horizontal blur pass: item = (row r, segment s of 13 outputs).  The 19 input bytes come in as 6 dwords, are
 	// shifted to byte 0 once (v_alignbyte), and every output is two v_dot4_u32_u8 against the packed taps
@@ -167,8 +195,7 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 			if (j < 9 || s < 3) o[j * HT] = (uint16_t)sum;       // (39 = 10 + 10 + 10 + 9 columns)
 		}
 	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o, 64); m01 += __shfl_xor(m01, o, 64); }
+	m10 = wave_sum(m10); m01 = wave_sum(m01);
 	__syncthreads();
 	// vertical pass: item = (column j, segment s of 13 outputs): 19 contiguous u16 of the transposed tile as 10 dwords,
 	// shifted to an even start once; an output is four v_dot2_u32_u16 on the pairs of its window.  The blurred patch
@@ -220,21 +247,25 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 	if (lane == 0) kp_angle[(size_t)img * max_feats + k] = ang;
 	__syncthreads();
 
-	// lane L evaluates tests 4L..4L+3  (bits (4L..4L+3)&7 of byte L/2); blurred(px,py) = s_b[(px-3)*BT + py-3]
-	const uint8_t* bc = s_b + (PR - 3) * BT + (PR - 3);
+	// lane L evaluates tests 4L..4L+3  (bits (4L..4L+3)&7 of byte L/2); blurred(px,py) = s_b[(px-3)*BT + py-3].
+	// Round 6, by instruction count (the kernel is VALU-issue bound): the pattern comes as floats; a point's rotation is two packed multiplies and one
+	// packed add ((x ca - y sa, x sa + y ca): IEEE, no contraction -- the same roundings as the scalar form); round-half-even and the integer
+	// conversion are ONE packed add of 2^23 + 20 (an even offset keeps the ties of the sum on the ties of the coordinate; |coordinate| <= 19),
+	// after which the low 24 bits of the float ARE 20 + coordinate, and v_mad_i32_i24 (which reads just those bits) forms the tile index.
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	const uint8_t* bc = s_b + (PR - 3 - 20) * BT + (PR - 3 - 20);       // (the tile sits SSK_DESC_BOFF bytes into its storage: this offset stays >= 0)
 	unsigned bits = 0;
-	const uint4 pat4 = reinterpret_cast<const uint4*>(pattern)[lane];   // the lane's four tests (x0,y0,x1,y1 as int8) in one load
-	const uint32_t patw[4] = {pat4.x, pat4.y, pat4.z, pat4.w};
+	const float4* patf = reinterpret_cast<const float4*>(pattern + 1024) + 4 * lane;   // the lane's four tests (x0, y0, x1, y1)
+	const f32x2 cs = {ca, sa}, nsc = {-sa, ca}, magic = {8388628.f, 8388628.f};      // (y (-sa) = -(y sa) exactly: the subtraction is an add)
 #pragma unroll
 	for (int t = 0; t < 4; ++t) {
-		const char4 pt = __builtin_bit_cast(char4, patw[t]);
-		const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
-		const int ix0 = (int)rintf(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
-		const int iy0 = (int)rintf(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
-		const int ix1 = (int)rintf(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
-		const int iy1 = (int)rintf(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-		const int v0 = bc[ix0 * BT + iy0];
-		const int v1 = bc[ix1 * BT + iy1];
+		const float4 pt = patf[t];
+		const f32x2 a0 = (f32x2){pt.x, pt.x} * cs, b0 = (f32x2){pt.y, pt.y} * nsc;
+		const f32x2 a1 = (f32x2){pt.z, pt.z} * cs, b1 = (f32x2){pt.w, pt.w} * nsc;
+		const f32x2 r0 = (a0 + b0) + magic;                                    // (ix0, iy0) + 2^23 + 20
+		const f32x2 r1 = (a1 + b1) + magic;
+		const int v0 = bc[__mul24(__float_as_int(r0.x), BT) + (__float_as_int(r0.y) & 0xFFFFFF)];
+		const int v1 = bc[__mul24(__float_as_int(r1.x), BT) + (__float_as_int(r1.y) & 0xFFFFFF)];
 		bits |= (unsigned)(v0 < v1) << t;
 	}
 	// byte j = tests 8j..8j+7 = lanes 2j (low nibble) and 2j+1 (high nibble)

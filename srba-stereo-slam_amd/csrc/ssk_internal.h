@@ -59,7 +59,7 @@ struct ssk_ctx {
 	float dir_thresh[19];
 	float* d_dir_thresh = nullptr;
 	int8_t pattern[1024];              // BRIEF sampling pattern (default: include/ssk_brief_pattern.h)
-	int8_t* d_pattern = nullptr;
+	int8_t* d_pattern = nullptr;       // [1024] int8, then [1024] float (ssk_upload_pattern)
 	int orb_steering = 1;              // C7: 1 = cv::ORB's (float)cos / (float)sin of the fastAtan2 angle (include/ssk_sincos.h), 0 = exact centroid direction
 	struct ssk_kfbatch* single = nullptr;   // 1-keyframe batch behind the host drop-in ssk_frontend_run
 	// device slabs of destroyed LM batches, reused by the next ones (the host drop-in creates and destroys two batches per keyframe -- the new edge's
@@ -125,6 +125,7 @@ int ssk_set_error(ssk_ctx* ctx, int code, const char* fmt, ...);
 // arena helpers: reset at the start of a host entry point, then carve 256-B aligned pieces.
 // sized_step != 0: capacity = the need + a quarter, rounded up to the step (not the next power of two); a failed pinned allocation is retried at the exact need
 int ssk_arena_reserve(ssk_ctx* ctx, ssk_arena& a, size_t bytes, size_t sized_step = 0);
+hipError_t ssk_upload_pattern(ssk_ctx* ctx);   // ctx->pattern -> ctx->d_pattern (int8 table + float copy)
 inline void ssk_arena_reset(ssk_arena& a) { a.used = 0; }
 template <typename T>
 inline T* ssk_arena_take(ssk_arena& a, size_t count)
