@@ -32,15 +32,14 @@ SSK_SINCOS_FN void ssk_orb_sincos_deg(float angle_deg, float* c_out, float* s_ou
 	const double sn = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
 	const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
 	const double cs = 1.0 - (0.5 * z - z * pc);
-	double c, s;
-	switch (k & 3) {
-	case 0: c = cs; s = sn; break;
-	case 1: c = -sn; s = cs; break;
-	case 2: c = -cs; s = -sn; break;
-	default: c = sn; s = -cs; break;
+	/* quadrant k: (c, s) = (cs, sn), (-sn, cs), (-cs, -sn), (sn, -cs).  Rounded to float first, selected and signed after: (float)(-v) = -(float)v
+	 * exactly, and the GPU selects two floats instead of two doubles */
+	{
+		const float fs = (float)sn, fc = (float)cs;
+		const float c = (k & 1) ? fs : fc, s = (k & 1) ? fc : fs;
+		*c_out = ((k + 1) & 2) ? -c : c;
+		*s_out = (k & 2) ? -s : s;
 	}
-	*c_out = (float)c;
-	*s_out = (float)s;
 }
 
 #endif /* SSK_SINCOS_H */

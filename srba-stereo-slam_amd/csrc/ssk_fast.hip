@@ -395,7 +395,7 @@ int ssk_launch_fast(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end, in
 	g = (g + 7) / 8 * 8;
 	ssk_stage_scope prof(ctx, SSK_STAGE_FAST);
 	hipLaunchKernelGGL(fast_nms_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, b->img, b->w, b->h, b->pitch, img_begin, nimg,
-	                   tiles_x, tiles_y, magic_img, magic_x, threshold, b->cand, b->cand_cap, b->ncand, (wg_per_cu > 0 && draw) ? tile_ctr : nullptr);
+	                   tiles_x, tiles_y, magic_img, magic_x, threshold, b->cand, b->cand_cap, b->ncand, (wg_per_cu > 0 && draw && n_tiles >= 4 * g) ? tile_ctr : nullptr);    // few tiles (the per-keyframe drop-in: 200): one or a few per workgroup by stride
 	SSK_LAUNCH_CHECK(ctx, "fast_nms_kernel");
 	return SSK_OK;
 }
