@@ -100,7 +100,7 @@ __device__ __forceinline__ float atan2_deg(float y, float x)
 }
 
 __global__ __launch_bounds__(64)
-void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int img_begin, int max_feats,
+void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int img_begin, int n_img, int n_feats, int max_feats,
                      const short2* __restrict__ kp_xy, const int32_t* __restrict__ nkp,
                      const int8_t* __restrict__ pattern, int steering, float* __restrict__ kp_angle, uint8_t* __restrict__ desc)
 {
@@ -117,8 +117,13 @@ void describe_kernel(const uint8_t* __restrict__ images, int h, int pitch, int i
 #else
 	__shared__ uint8_t s_b[BD * BT];           // blurred patch, transposed: [column 3..41][row 3..41]
 #endif
-	const int img = img_begin + blockIdx.y;
-	const int k = blockIdx.x;
+	// workgroup b runs on XCD b % 8: an image's keypoints all go to ONE XCD (image i of the launch to XCD i % 8), so that the patches of an image --
+	// they overlap 2 x and more -- meet in one L2 (as grid (keypoint, image) the eight L2s each fetched the image: 4.4 GB of L2 misses per
+	// 1 M keypoints, r06_pmc_traffic.json, for 0.96 GB of images)
+	const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+	const int grp = slot / n_feats, k = slot - grp * n_feats;
+	if (8 * grp + xcd >= n_img) return;
+	const int img = img_begin + 8 * grp + xcd;
 	if (k >= nkp[img]) return;
 	const int lane = threadIdx.x;
 	const short2 xy = kp_xy[(size_t)img * max_feats + k];
@@ -281,8 +286,10 @@ int ssk_launch_describe(ssk_ctx* ctx, ssk_kfbatch* b, int img_begin, int img_end
 	const int nimg = img_end - img_begin;
 	if (nimg <= 0 || n_feats <= 0) return SSK_OK;
 	ssk_stage_scope prof(ctx, SSK_STAGE_DESCRIBE);
-	hipLaunchKernelGGL(describe_kernel, dim3(n_feats, nimg), dim3(64), 0, ctx->stream, b->img, b->h, b->pitch,
-	                   img_begin, b->max_feats, b->kp_xy, b->nkp, ctx->d_pattern, ctx->orb_steering, b->kp_angle, b->desc);
+	const long long n_wg = (long long)((nimg + 7) / 8) * 8 * n_feats;
+	if (n_wg >= 0x7FFFFFFFll) return ssk_set_error(ctx, SSK_ERR_CAPACITY, "ssk_launch_describe: %d images x %d features outside the grid", nimg, n_feats);
+	hipLaunchKernelGGL(describe_kernel, dim3((unsigned)n_wg), dim3(64), 0, ctx->stream, b->img, b->h, b->pitch,
+	                   img_begin, nimg, n_feats, b->max_feats, b->kp_xy, b->nkp, ctx->d_pattern, ctx->orb_steering, b->kp_angle, b->desc);
 	SSK_LAUNCH_CHECK(ctx, "describe_kernel");
 	return SSK_OK;
 }

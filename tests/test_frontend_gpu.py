@@ -191,3 +191,28 @@ def test_batch_equals_single_and_da_batch(ctx, oracle, pkg):
         assert np.array_equal(st[p * N:p * N + n], es) and tr[p] == et
     assert tr[0] > 30      # consecutive shifted keyframes really associate
     b.close()
+
+
+def test_large_batch_with_the_tile_draw_equals_single_keyframes(ctx, oracle, pkg):
+    """48 keyframes = 9 600 scan tiles: enough for fast_nms_kernel's persistent form to DRAW its tiles (ssk_launch_fast: four tiles or more per
+    resident workgroup; the small batches of the other tests take a tile or two per workgroup by stride).  Every keyframe of the batch must
+    equal the same pair run alone -- a tile drawn twice or never would show as a candidate list of another length -- and a few of them the oracle."""
+    from ssk_amd import capi
+    B = 48
+    base = [synth.synth_stereo_pair(40 + i) for i in range(6)]
+    pairs = [(np.roll(base[i % 6][0], (i // 6, 5 * (i // 6)), axis=(0, 1)), np.roll(base[i % 6][1], (i // 6, 5 * (i // 6)), axis=(0, 1))) for i in range(B)]
+    cp, op = params(pkg)
+    b = capi.KfBatch(ctx, B, synth.W, synth.H, 512)
+    for i, (l, r) in enumerate(pairs):
+        b.upload(i, l, r)
+    b.run_frontend(cp)
+    got = [b.download(i) for i in range(B)]
+    one = capi.KfBatch(ctx, 1, synth.W, synth.H, 512)
+    for i, (l, r) in enumerate(pairs):
+        one.upload(0, l, r)
+        one.run_frontend(cp)
+        assert_kf_equal(got[i], one.download(0))
+    for i in (0, 23, 47):
+        assert_kf_equal(got[i], oracle.frontend(pairs[i][0], pairs[i][1], op, ol.default_pattern()))
+    one.close()
+    b.close()
