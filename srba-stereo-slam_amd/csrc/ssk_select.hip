@@ -83,8 +83,48 @@ __device__ float harris_response(const uint8_t* __restrict__ img, int pitch, int
 // the pair (lo, lo + stride): for stride <= 64 the 64 pairs of a wave live in one 128-key span that no other wave
 // touches, so those steps only need the wave's own LDS ordering; a workgroup barrier separates steps only when
 // one of the two has stride > 64 (6 of the 55 steps at P = 1024).
+// P == 2 NT (1 024 keys, the usual case: K = 2 x 500 candidates): thread t keeps elements 2 t and 2 t + 1 in REGISTERS through the whole network.
+// Stride 1 is inside the thread, strides 2 .. 64 meet the partner lane of the same wavefront by a lane-xor shuffle (39 of the 55 steps: no LDS
+// round trip, no fence), strides 128 .. 512 (6 steps) go through LDS between two workgroup barriers.  (The LDS form below spent ~520 cycles a step
+// on a read - compare - write - fence chain: 28.5 k cycles per sort, two sorts = half the kernel.)
+__device__ __forceinline__ void cmpx(unsigned long long& mine, unsigned long long other, bool keep_max)
+{
+	const bool take = keep_max ? (other > mine) : (other < mine);
+	if (take) mine = other;
+}
+__device__ void bitonic_desc_regs(unsigned long long* s_key, int tid)
+{
+	static_assert(NT >= 128, "two wavefronts or more");
+	constexpr int P = 2 * NT;
+	const int e0 = 2 * tid;
+	unsigned long long a = s_key[e0], b = s_key[e0 + 1];
+	for (int size = 2; size <= P; size <<= 1) {
+		const bool desc = (e0 & size) == 0;                      // (both elements: size >= 2)
+		for (int stride = size >> 1; stride >= 128; stride >>= 1) {
+			// partner thread in another wavefront: through LDS
+			__syncthreads();
+			s_key[e0] = a; s_key[e0 + 1] = b;
+			__syncthreads();
+			const bool lower = (e0 & stride) == 0;                // this thread's elements are the lower ones of their pairs
+			const unsigned long long oa = s_key[e0 ^ stride], ob = s_key[(e0 ^ stride) + 1];
+			cmpx(a, oa, lower == desc); cmpx(b, ob, lower == desc);
+		}
+		for (int stride = min(size >> 1, 64); stride >= 2; stride >>= 1) {
+			const bool lower = (e0 & stride) == 0;
+			const unsigned long long oa = __shfl_xor(a, stride >> 1, 64), ob = __shfl_xor(b, stride >> 1, 64);
+			cmpx(a, oa, lower == desc); cmpx(b, ob, lower == desc);
+		}
+		// stride 1: the thread's own pair (descending: the larger one first)
+		if ((a < b) == desc) { const unsigned long long t = a; a = b; b = t; }
+	}
+	__syncthreads();
+	s_key[e0] = a; s_key[e0 + 1] = b;
+	__syncthreads();
+}
+
 __device__ void bitonic_desc(unsigned long long* s_key, int P, int tid)
 {
+	if (P == 2 * NT) { bitonic_desc_regs(s_key, tid); return; }   // (uniform)
 	for (int size = 2; size <= P; size <<= 1) {
 		for (int stride = size >> 1; stride > 0; stride >>= 1) {
 			for (int t = tid; t < P / 2; t += NT) {
