@@ -34,6 +34,10 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
 	__shared__ uint32_t s_part[NW][64];
 	__shared__ uint32_t s_best[SSK_MAX_FEATS];
 	__shared__ int s_scan[NT];
+	constexpr int NB = 1024;                                  // bins of four image rows (y < 4096: the packed candidate key's 12 bits)
+	static_assert(NB == NT, "a bin per thread in the counting sorts");
+	__shared__ int s_bin[NB];
+	__shared__ uint16_t s_rstart[NB + 2], s_ridx[TT], s_lperm[SSK_MAX_FEATS];
 
 	const int kf = kf_begin + blockIdx.x;
 	const int il = kf * 2, ir = kf * 2 + 1;
@@ -44,6 +48,77 @@ void stereo_match_kernel(int kf_begin, int max_feats, const short2* __restrict__
 	const short2* __restrict__ xl = kp_xy + (size_t)il * max_feats;
 	const short2* __restrict__ xr = kp_xy + (size_t)ir * max_feats;
 
+	if (nr <= TT) {
+		// Round 6: both sides in ROW order first.  The matcher's band is a few image rows wide, the keypoints come in response order: as it was, every
+		// left keypoint met every right one (the band test alone: 250 k pairs a keyframe, and two thirds of the right rows had SOME lane of the 64 in band, so
+		// their popcounts ran as well -- the kernel was vector-issue bound on that).  A counting sort by y / 4 (LDS histogram, one scan, a scatter: the order
+		// inside a bin does not matter) lets a wavefront of 64 row-neighbouring left keypoints visit only the right rows of its own bins +- the band: ~70 of
+		// 500.  Results do not depend on either order: the best key (distance << 16 | ORIGINAL right index) is a minimum, and it is stored by the original
+		// left index.  Each wavefront takes whole left tiles on its own: no partial minima across wavefronts, no barrier in the loop.
+		const int band = (int)max_y_diff + 2;                   // |yL - yR| <= max_y_diff can only hold inside this many rows
+		for (int side = 0; side < 2; ++side) {                    // 0: right (staged in bin order), 1: left (a permutation)
+			const int n = side ? nl : nr;
+			const short2* __restrict__ xy = side ? xl : xr;
+			s_bin[tid] = 0;                                          // (NT == NB)
+			__syncthreads();
+			short2 me = make_short2(0, 0);
+			if (tid < n) { me = xy[tid]; atomicAdd(&s_bin[min(max((int)me.y, 0) >> 2, NB - 1)], 1); }
+			__syncthreads();
+			// exclusive scan of the 1 024 bins: DPP scan inside the wavefront, the 16 wavefront totals through LDS
+			const int v = s_bin[tid];
+			int x = v;
+			x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+			x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+			if (lane == 63) s_scan[wave] = x;
+			__syncthreads();
+			int off = 0;
+			for (int w = 0; w < wave; ++w) off += s_scan[w];
+			const int excl = off + x - v;
+			__syncthreads();
+			s_bin[tid] = excl;
+			if (side == 0) { s_rstart[tid] = (uint16_t)excl; if (tid == NT - 1) s_rstart[NB] = (uint16_t)(excl + v); }
+			__syncthreads();
+			if (tid < n) {
+				const int pos = atomicAdd(&s_bin[min(max((int)me.y, 0) >> 2, NB - 1)], 1);
+				if (side == 0) {
+					s_rxy[pos] = me; s_ridx[pos] = (uint16_t)tid;
+					s_desc[2 * pos] = dr[2 * tid]; s_desc[2 * pos + 1] = dr[2 * tid + 1];
+				} else s_lperm[pos] = (uint16_t)tid;
+			}
+			__syncthreads();
+		}
+		for (int lbase = 64 * wave; lbase < nl; lbase += 64 * NW) {
+			const bool ok = lbase + lane < nl;
+			const int li = s_lperm[ok ? lbase + lane : lbase];       // (the tile's first keypoint again: inside its rows, never accepted)
+			const uint4 qa = dl[2 * li], qb = dl[2 * li + 1];
+			const short2 p = xl[li];
+			const float lx = (float)p.x, ly = (float)p.y;
+			// the tile's rows: bin order, so its first and its last valid lane bound them
+			const int y_first = __builtin_amdgcn_readfirstlane((int)p.y);
+			const int y_last = __builtin_amdgcn_readlane((int)p.y, min(nl - lbase, 64) - 1);
+			const int b_lo = min(max((((y_first >> 2) << 2) - band) >> 2, 0), NB - 1), b_hi = min(max((((y_last >> 2) << 2) + 3 + band) >> 2, 0), NB - 1);
+			const int r0 = s_rstart[b_lo], r1 = s_rstart[b_hi + 1];
+			uint32_t best = 0xFFFFFFFFu;
+			for (int r = r0; r < r1; ++r) {
+				const short2 rp = s_rxy[r];
+				const float disp = __fsub_rn(lx, (float)rp.x);
+				const bool cand = ok && !(fabsf(__fsub_rn(ly, (float)rp.y)) > max_y_diff) &&
+				                  !(disp < min_disp) && !(disp > max_disp);
+				if (__ballot(cand) == 0ull) continue;
+				const uint4 ta = s_desc[2 * r], tb = s_desc[2 * r + 1];
+				uint32_t d = __popc(qa.x ^ ta.x);
+				d += __popc(qa.y ^ ta.y); d += __popc(qa.z ^ ta.z); d += __popc(qa.w ^ ta.w);
+				d += __popc(qb.x ^ tb.x); d += __popc(qb.y ^ tb.y); d += __popc(qb.z ^ tb.z); d += __popc(qb.w ^ tb.w);
+				if (cand) best = min(best, (d << 16) | (uint32_t)s_ridx[r]);
+			}
+			if (ok) s_best[li] = best;
+		}
+		__syncthreads();
+	} else
 	for (int lbase = 0; lbase < nl; lbase += 64) {
 		const int li = lbase + lane;
 		const bool ok = li < nl;
