@@ -1011,7 +1011,7 @@ def main():
             "roofline_describe": {"kernel": "describe_kernel", "bound": "hbm", "achieved": desc_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": desc_ach / HBM_PEAK_GBS, "traffic": traffic_of("describe_kernel", desc_avg_ms),
                                   "algorithmic_bytes_per_launch": desc_algo, "avg_launch_ms": desc_avg_ms,
-                                  "note": "VALU-issue bound (one wavefront per keypoint, ~700 vector instructions each); patches of neighbouring keypoints overlap in L2"},
+                                  "note": "VALU-issue bound (one wavefront per keypoint, ~545 vector instructions each); an image's keypoints run on one XCD, so its patches meet in one L2"},
             "stage_ms_per_launch": stages,
             "value_incl_symbolic": symbolic["value_incl_symbolic"] if symbolic else None,
             "lm_symbolic_ms_per_window": symbolic["lm_symbolic_ms_per_window"] if symbolic else None,
