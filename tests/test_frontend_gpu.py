@@ -69,6 +69,10 @@ def test_rendered_forward_motion_frames_bit_exact(ctx, oracle, pkg):
     (7, dict(n_feats=512, fast_threshold=10, nms_radius=4, orb_max_distance=30, max_y_diff=0.0)),
     (8, dict(n_feats=37, fast_threshold=120)),                 # few corners: fewer keypoints than requested
     (9, dict(n_feats=500, min_disparity=10.0, max_disparity=40.0, max_y_diff=1.0)),
+    # more than 512 features a side: the selection sorts 2 048 keys (the LDS network, not the register one for 1 024), the stereo matcher stages the
+    # right side in tiles of 512 (its all-rows form, not the row-ordered one)
+    (10, dict(n_feats=900, fast_threshold=8)),
+    (11, dict(n_feats=1500, fast_threshold=5, max_y_diff=2.0)),
 ])
 def test_frontend_param_sweep(ctx, oracle, pkg, seed, over):
     left, right = synth.synth_stereo_pair(seed)
