@@ -273,7 +273,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		// passes the read index, and nobody else touches the quarter: no second queue (9 KiB of LDS: 6 workgroups per CU), no ds atomic per step.
 		const int q1n = s_q1n;
 		const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-		const int seg = (q1n + 3) >> 2, seg0 = min(wv * seg, q1n), seg1 = min(seg0 + seg, q1n);
+		const int seg = max(64, (q1n + 3) >> 2), seg0 = min(wv * seg, q1n), seg1 = min(seg0 + seg, q1n);   // (whole wavefronts first: 113 entries, the mean, are two wavefronts' work, not four quarter-filled ones)
 		int nw = 0;                                                  // corners of this wavefront (uniform)
 		for (int base = seg0; base < seg1; base += 64) {
 			const int q = base + lane;
