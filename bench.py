@@ -546,28 +546,38 @@ def main():
     # built once.  Here every step solves a batch whose ssk_lm_batch_create (symbolic build on the host's threads + allocation + upload, through
     # a context of its own) ran beside the previous step: two batches alive, a creator thread, the same step otherwise.
     def symbolic_pass(n):
-        import threading
+        import threading, queue
         ctx_c = pkg.Context(local)
-        made = {}
         mar = capi.LmBatch.marshal(lm_batch_wins)       # (the C view of the windows, once: the creator thread then spends its time inside the library)
-        def create(k):
-            made[k] = capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar)
-        create(0); create(1)                              # (slab allocations, code objects)
-        made.pop(1).close()
-        sym_thr = made[0].symbolic_ms()[1]
+        warm = [capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar) for _ in range(3)]      # (three slabs: one batch solved, one waiting, one built; code objects)
+        sym_thr = warm[0].symbolic_ms()[1]
+        cur = warm[0]
+        for w_ in warm[1:]: w_.close()
         torch.cuda.synchronize()
+        # The creator thread owns ctx_c: it builds batch after batch (at most one finished batch waits for the step) and closes the batches the
+        # step thread hands back -- a create returns with its uploads queued (round 6), so the next build runs beside them.
+        q_ready, q_done = queue.Queue(maxsize=1), queue.Queue()
+        def creator():
+            for _ in range(n):
+                while True:
+                    try: q_done.get_nowait().close()
+                    except queue.Empty: break
+                q_ready.put(capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar))
         t_create, t_sym = [], []
+        th = threading.Thread(target=creator)
         t0s = time.perf_counter()
+        th.start()
         for k in range(n):
-            th = threading.Thread(target=create, args=(k + 1,))
-            th.start()
-            step(lm=made[k], lm_ctx=ctx_lm)
+            step(lm=cur, lm_ctx=ctx_lm)
             torch.cuda.synchronize()
-            th.join()
-            t_create.append(made[k + 1].create_ms); t_sym.append(made[k + 1].symbolic_ms()[0])
-            made.pop(k).close()
+            nxt = q_ready.get()
+            t_create.append(nxt.create_ms); t_sym.append(nxt.symbolic_ms()[0])
+            q_done.put(cur)
+            cur = nxt
         dts = time.perf_counter() - t0s
-        made.pop(n).close()
+        th.join()
+        while not q_done.empty(): q_done.get().close()
+        cur.close()
         t_alone = []
         for _ in range(3):                                 # (the same create with nothing beside it, right after the loop)
             bq = capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar)
@@ -580,7 +590,8 @@ def main():
                 "right_after": {"lm_batch_create_ms": float(np.mean([a for a, _ in t_alone])), "lm_symbolic_ms_per_batch": float(np.mean([b_ for _, b_ in t_alone]))},
                 "host_cpu_quota": cpu_quota(),
                 "note": "every step solves an LM batch created (ssk_lm_batch_create: symbolic build on `host_threads` threads, allocation, upload) beside "
-                        "the previous step by a second host thread; lm_symbolic_ms_per_window: host time of the symbolic part / windows of the batch.  The "
+                        "the previous steps by a creator thread with a context of its own (it builds continuously, at most one finished batch waiting; a create "
+                        "returns with its uploads queued); lm_symbolic_ms_per_window: host time of the symbolic part / windows of the batch.  The "
                         "builder's threads share the container's CPU quota (host_cpu_quota, cgroup cpu.max: 16 CPUs on the GPU boxes of this pool, whatever "
                         "the core count): back-to-back creates are bound by it, which is why the library caps its builder threads at twice the quota "
                         "(64 threads: 14.9 ms per create, 32: 9.7, 16: 13.8; tools/sym_threads.sh); a single create in an idle process takes ~10 ms "

@@ -481,7 +481,10 @@ typedef struct ssk_lm_trace_entry {
 
 typedef struct ssk_lm_batch ssk_lm_batch;
 /* Uploads n windows (state + symbolic structure) to HBM.  trace != 0 additionally keeps, per attempt, the
- * trace entry and the full update vectors (tests).  */
+ * trace entry and the full update vectors (tests).  The caller's arrays are read before the call returns and may be freed then.  A large batch's
+ * tables may still be on their way to the device at that point (queued on the context's stream from the library's own pinned memory; every use of
+ * the batch, through any context, is ordered behind them): the context's next ssk_lm_batch_create waits for them before it reuses that memory, and
+ * ssk_lm_batch_destroy waits for whatever was queued on the batch.  SSK_LM_SYNC_UPLOAD=1: the create waits itself (the form up to round 5). */
 int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_windows, int trace, ssk_lm_batch** out);
 void ssk_lm_batch_destroy(ssk_lm_batch* b);
 /* Restores every window's state to what was uploaded (so a benchmark can repeat the same solve). Async. */

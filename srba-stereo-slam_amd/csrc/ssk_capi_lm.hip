@@ -66,6 +66,12 @@ struct ssk_lm_batch {
 	// whatever else runs on the device) is waited for by the first stream that touches the batch
 	hipEvent_t ev_ready = nullptr;
 	bool ready_pending = false;
+	// (round 6) the lean create does not wait for its uploads either: its big tables sit in the context's pinned arena, which the NEXT lean create of the
+	// context waits for before it writes there (lm_wait_uploads) -- by then a symbolic build has passed and the DMA is long done; the few host images that
+	// live elsewhere are copied here first and die with the batch (whose destroy waits for the stream)
+	bool defer_upload_wait = false;
+	std::vector<std::unique_ptr<uint8_t[]>> keep;
+	bool used_own = false;            // some operation after the create went through the creating context (its stream): ssk_lm_batch_destroy drains that stream
 	size_t guard_off = 0, guard_bytes = 0;   // SSK_LM_GUARD (diagnostic)
 	// a batch may be reset / run on ANOTHER context's stream than the one that created it (bench.py's symbolic pass: one thread creates, another
 	// runs): the end of the last such use, so that ssk_lm_batch_destroy does not recycle a slab that stream still writes (an event, not the context:
@@ -96,6 +102,16 @@ template <typename T>
 int scratch(ssk_lm_batch* b, size_t count, T** out)
 {
 	b->reqs.push_back({sizeof(T) * (count + 4), 0, nullptr, (void**)out});
+	return SSK_OK;
+}
+
+// the uploads of the context's last lean create (their sources: the pinned arena) are done -- called before the arena is written or freed
+int lm_wait_uploads(ssk_ctx* ctx)
+{
+	if (ctx->lm_up_pending) {
+		ctx->lm_up_pending = false;
+		SSK_HIP(ctx, hipEventSynchronize(ctx->ev_lm_up));
+	}
 	return SSK_OK;
 }
 
@@ -136,6 +152,7 @@ int finalize(ssk_lm_batch* b)
 	// a batch has two dozen tables); a large one goes table by table, by DMA straight from the host images that live in the context's pinned LM
 	// arena (the lean builder's tables: the runtime recognises pinned memory) and through the runtime's own staging for the rest.
 	const bool staged = up <= (size_t)8 << 20;
+	const bool defer = b->defer_upload_wait && !staged && total > up;
 	uint8_t* st = nullptr;
 	if (staged && up) {
 		int rc = ssk_arena_reserve(ctx, ctx->pin, up + 256);
@@ -151,7 +168,17 @@ int finalize(ssk_lm_batch* b)
 			*r.dst = d;
 			if (pass == 0) {
 				if (staged) { std::memcpy(st + off, r.src, r.copy); std::memset(st + off + r.copy, 0, ssk_pad(r.bytes) - r.copy); }
-				else SSK_HIP(ctx, hipMemcpyAsync(d, r.src, r.copy, hipMemcpyHostToDevice, ctx->stream));
+				else {
+					const void* src = r.src;
+					const char* a0 = static_cast<const char*>(ctx->pin_lm.base);
+					if (defer && !(a0 && static_cast<const char*>(src) >= a0 && static_cast<const char*>(src) + r.copy <= a0 + ctx->pin_lm.cap)) {
+						std::unique_ptr<uint8_t[]> k(new uint8_t[r.copy]);
+						std::memcpy(k.get(), src, r.copy);
+						src = k.get();
+						b->keep.push_back(std::move(k));
+					}
+					SSK_HIP(ctx, hipMemcpyAsync(d, src, r.copy, hipMemcpyHostToDevice, ctx->stream));
+				}
 			}
 			off += ssk_pad(r.bytes);
 		}
@@ -164,7 +191,13 @@ int finalize(ssk_lm_batch* b)
 		SSK_HIP(ctx, hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming));
 		SSK_HIP(ctx, hipEventRecord(b->ev_ready, ctx->stream));
 		b->ready_pending = true;
-		SSK_HIP(ctx, hipEventSynchronize(ctx->ev_lm_up));    // host images are free again when create returns
+		if (defer) {
+			ctx->lm_up_pending = true;                           // (the arena's next writer waits: lm_wait_uploads)
+			// nobody waits here any more, and the runtime hands queued work to the device when somebody does: without this query the copies started
+			// at the caller's next synchronisation -- a step later (measured: the step that solves the batch 8.2 -> 9.6 ms)
+			(void)hipStreamQuery(ctx->stream);
+		}
+		else SSK_HIP(ctx, hipEventSynchronize(ctx->ev_lm_up));    // host images are free again when create returns
 	} else {
 		if (total > up) SSK_HIP(ctx, hipMemsetAsync(static_cast<uint8_t*>(b->slab) + up, 0, total - up, ctx->stream));
 		SSK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // host images / pinned staging are free again when create returns
@@ -385,7 +418,7 @@ static lm_cam cam_of(const ssk_lm_params* p)
 // end of an operation that queued work on the batch: remembered when the stream is not the creating context's (ssk_lm_batch_destroy waits for it)
 static int lm_batch_mark(ssk_ctx* ctx, ssk_lm_batch* b, int rc)
 {
-	if (ctx == b->ctx) return rc;
+	if (ctx == b->ctx) { b->used_own = true; return rc; }
 	if (!b->ev_last) SSK_HIP(ctx, hipEventCreateWithFlags(&b->ev_last, hipEventDisableTiming));
 	SSK_HIP(ctx, hipEventRecord(b->ev_last, ctx->stream));
 	return rc;
@@ -535,7 +568,9 @@ void ssk_lm_batch_destroy(ssk_lm_batch* b)
 	if (!b) return;
 	for (ssk_lm_batch* sb : b->sub) ssk_lm_batch_destroy(sb);      // (a composite owns its sub-batches and nothing else)
 	b->sub.clear();
-	if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
+	// (a batch that was only ever run through OTHER contexts -- bench.py's creator thread, whose context is already queuing the next batch's uploads --
+	//  waits for its own events below, not for everything its creating context has queued since)
+	if (b->ctx) { (void)hipSetDevice(b->ctx->device); if (b->used_own || !b->lean) (void)hipStreamSynchronize(b->ctx->stream); }
 	// the slab goes back to the creating context's cache (a later create may take it, a later destroy may free it): nothing may still be in flight on
 	// it -- the create's own zero fill (when no stream waited for it yet) and whatever another context's stream was given to do on the batch
 	if (b->ev_ready) { if (b->ready_pending) (void)hipEventSynchronize(b->ev_ready); (void)hipEventDestroy(b->ev_ready); }
@@ -791,6 +826,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 		const size_t need = tb(zn) + tb(zs) + sizeof(int) * (n_edge_t + n_lm_t + n_obs_t + n_opo_t + n_path_t + n_us_t + n_ls_t) + sizeof(double) * (12 * n_edge_t + 3 * n_lm_t) +
 		                    sizeof(float) * 4 * n_obs_t + 64 * 64;
 		const bool no_pin = ctx->env.lm_no_pinned;
+		{ const int rcw = lm_wait_uploads(ctx); if (rcw) return rcw; }      // (the previous create's DMA reads the arena this one is about to fill)
 		if (!no_pin && need <= ((size_t)4 << 30)) {       // (round 5: 4 GB -- 1 024 local areas of 5 k observations are 1.5-2.5 GB of tables; beyond 1 GB they went through pageable memory: 150 ms per create)
 			// the arena only grows inside ssk_arena_reserve: after one large batch a context would hold up to 1 GB of pinned host memory until
 			// ssk_destroy.  Eight creates in a row that need less than a quarter of it give it back (a streak, not one small create: bench.py and
@@ -1009,6 +1045,7 @@ static int lm_batch_create_lean(ssk_ctx* ctx, const ssk_lm_window* windows, int 
 	}
 	D.trace_on = trace ? 1 : 0;
 	const auto t_fin = std::chrono::steady_clock::now();
+	b->defer_upload_wait = arena != nullptr && !ctx->env.lm_sync_upload;
 	if (!rc) rc = finalize(b);
 	if (rc) { ssk_lm_batch_destroy(b); return rc; }
 	if (ctx->env.lm_debug)
@@ -1939,6 +1976,7 @@ int ssk_lm_batch_create(ssk_ctx* ctx, const ssk_lm_window* windows, int n_window
 // started from and repeats the solve with one workgroup per window (no cross-workgroup barrier, same contract).
 static int lm_batch_settle(ssk_ctx* ctx, ssk_lm_batch* b)
 {
+	if (ctx == b->ctx) b->used_own = true;
 	if (b->ready_pending) {                           // (the create's zero fill, possibly on another context's stream)
 		SSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_ready, 0));
 		b->ready_pending = false;

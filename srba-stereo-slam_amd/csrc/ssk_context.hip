@@ -40,6 +40,7 @@ void ssk_env_read(ssk_env& e)
 	e.lm_few_split = !off("SSK_LM_FEW_SPLIT");
 	e.lm_pose_only = !off("SSK_LM_POSE_ONLY");
 	e.lm_no_pinned = set("SSK_LM_NO_PINNED");
+	e.lm_sync_upload = set("SSK_LM_SYNC_UPLOAD");
 	e.lm_order = !off("SSK_LM_ORDER");
 	e.lm_debug = set("SSK_LM_DEBUG");
 	if (const char* v = std::getenv("SSK_SP_SPREAD")) e.sp_spread = std::atoi(v) ? 1 : 0;
@@ -212,6 +213,7 @@ void ssk_destroy(ssk_ctx* ctx)
 	(void)hipStreamSynchronize(ctx->stream);
 	if (ctx->dev.base) (void)hipFree(ctx->dev.base);
 	if (ctx->pin.base) (void)hipHostFree(ctx->pin.base);
+	if (ctx->lm_up_pending && ctx->ev_lm_up) (void)hipEventSynchronize(ctx->ev_lm_up);      // (a lean create's uploads still read pin_lm)
 	if (ctx->pin_lm.base) (void)hipHostFree(ctx->pin_lm.base);
 	if (ctx->single) ssk_kfbatch_destroy_internal(ctx->single);
 	for (void* sl : ctx->lm_slab) if (sl) (void)hipFree(sl);

@@ -27,6 +27,7 @@ struct ssk_env {
 	bool lm_few_split = true;           // SSK_LM_FEW_SPLIT=0: a batch of at most 8 windows keeps the node kernel for every window that fits it
 	bool lm_pose_only = true;           // SSK_LM_POSE_ONLY=0: pose-only windows on the node kernel
 	bool lm_no_pinned = false;          // SSK_LM_NO_PINNED: the batch's tables in pageable memory
+	bool lm_sync_upload = false;        // SSK_LM_SYNC_UPLOAD: a lean create waits for its uploads before it returns (the form up to round 5)
 	bool lm_order = true;               // SSK_LM_ORDER=0: windows launched as given (default: largest first)
 	bool lm_debug = false;              // SSK_LM_DEBUG
 	int sp_spread = -1;                 // SSK_SP_SPREAD: 1 = a phase-split window's tiles over all XCDs, 0 = on one XCD, unset: over all for batches of at most 4 such windows
@@ -49,6 +50,7 @@ struct ssk_ctx {
 	hipStream_t side_stream = nullptr;   // a composite LM batch's few full-builder windows run here, beside the many on `stream` (ssk_capi_lm.hip)
 	hipEvent_t ev_side_a = nullptr, ev_side_b = nullptr;
 	hipEvent_t ev_lm_up = nullptr;     // end of an LM batch's uploads (ssk_capi_lm.hip: create waits for this, not for the zero fill behind it)
+	bool lm_up_pending = false;        // a lean create returned with its uploads (from pin_lm) still queued: waited for before pin_lm is written or freed
 	std::string err;
 	ssk_arena dev, pin;
 	ssk_arena pin_lm;                  // pinned host memory the tables of an LM batch are built in (ssk_capi_lm.hip: one DMA per table, no pageable staging)

@@ -779,3 +779,37 @@ def test_lm_one_oversize_window_in_a_batch_keeps_the_others_on_their_kernels(ctx
     # (a wall-clock ratio on a shared box: the bar is loose -- the kernel names and the bit equality above are the test; measured 1.2-1.3 x)
     assert t_mixed <= 3.0 * t_plain, (t_mixed, t_plain)
     print("64 bench windows: %.3f ms; with one window of a %d-observation landmark (%s): %.3f ms" % (1e3 * t_plain, n_obs_l, name1, 1e3 * t_mixed))
+
+
+def test_lm_large_batches_created_back_to_back_and_run_through_another_context(ctx, pkg):
+    """Round 6: a large lean batch's ssk_lm_batch_create returns with its uploads (from the context's pinned arena) still queued; the context's NEXT
+    create waits for them before it writes the arena, and a batch that only ever ran through ANOTHER context is destroyed without draining the creating
+    context's stream.  Three 128-window batches (~15 MB of tables each: the table-by-table upload path) created back to back by one context, run through
+    another, must give the results of a batch created and run the ordinary way -- bit for bit -- and so must a batch created after one was destroyed."""
+    from ssk_amd import capi
+    wins = [sl.make_submap_problem(seed, n_kf=200, n_lm=5000, submap_size=10, max_tree_depth=4, opt_depth=2, obs_per_kf=250, lm_fwd=(3, 20), z_vis=(2.5, 22))[0]
+            for seed in range(8)]
+    sets = [[wins[(k + s) % 8] for k in range(128)] for s in range(3)]
+    prm = to_capi(sl.make_params())
+
+    def outcome(b, run_ctx=None):
+        b.run(prm, ctx=run_ctx)
+        if run_ctx is not None:
+            run_ctx.synchronize()
+        return [(r.iters, r.stop_reason, r.accepted, r.err_init, r.err_final) for r in b.results()]
+
+    ref = []
+    for s in range(3):
+        b = capi.LmBatch(ctx, sets[s])
+        ref.append(outcome(b))
+        b.close()
+    ctx_c = pkg.Context(0)
+    made = [capi.LmBatch(ctx_c, sets[s]) for s in range(3)]          # back to back: each create finds the previous one's uploads pending
+    for s in (2, 0, 1):
+        assert outcome(made[s], run_ctx=ctx) == ref[s], s
+    made[1].close()
+    again = capi.LmBatch(ctx_c, sets[1])                              # (takes the freed slab while the other two batches are alive)
+    assert outcome(again, run_ctx=ctx) == ref[1]
+    for b in (made[0], made[2], again):
+        b.close()
+    ctx_c.close()
