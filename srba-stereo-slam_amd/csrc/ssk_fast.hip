@@ -270,7 +270,7 @@ void fast_nms_kernel(const uint8_t* __restrict__ images, int w, int h, int pitch
 		//      than c + t or all darker than c - t  <=>  max over the arcs of the arc's min |difference| > t).  The separate corner test by 16-bit
 		//      ring masks that used to stand in front of the score (round 2) cost as much per pixel as the packed score itself. ----
 		// (round 6) each wavefront owns a quarter of the queue and packs its corners to the front of its own quarter -- the write index never
-		// passes the read index, and nobody else touches the quarter: no second queue (9 KiB of LDS: 6 workgroups per CU), no ds atomic per step.
+		// passes the read index, and nobody else touches the quarter: no second queue (9 KiB of LDS less: with the output list in the image tile's storage, 7 workgroups per CU), no ds atomic per step.
 		const int q1n = s_q1n;
 		const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 		const int seg = max(64, (q1n + 3) >> 2), seg0 = min(wv * seg, q1n), seg1 = min(seg0 + seg, q1n);   // (whole wavefronts first: 113 entries, the mean, are two wavefronts' work, not four quarter-filled ones)
