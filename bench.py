@@ -557,12 +557,17 @@ def main():
         # The creator thread owns ctx_c: it builds batch after batch (at most one finished batch waits for the step) and closes the batches the
         # step thread hands back -- a create returns with its uploads queued (round 6), so the next build runs beside them.
         q_ready, q_done = queue.Queue(maxsize=1), queue.Queue()
+        failed = []
         def creator():
-            for _ in range(n):
-                while True:
-                    try: q_done.get_nowait().close()
-                    except queue.Empty: break
-                q_ready.put(capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar))
+            try:
+                for _ in range(n):
+                    while True:
+                        try: q_done.get_nowait().close()
+                        except queue.Empty: break
+                    q_ready.put(capi.LmBatch(ctx_c, lm_batch_wins, marshalled=mar))
+            except BaseException as e:                       # (the step thread must not wait for a batch that will not come)
+                failed.append(e)
+                q_ready.put(None)
         t_create, t_sym = [], []
         th = threading.Thread(target=creator)
         t0s = time.perf_counter()
@@ -571,6 +576,8 @@ def main():
             step(lm=cur, lm_ctx=ctx_lm)
             torch.cuda.synchronize()
             nxt = q_ready.get()
+            if nxt is None:
+                raise RuntimeError("symbolic pass: the creator thread failed: %r" % (failed[0],))
             t_create.append(nxt.create_ms); t_sym.append(nxt.symbolic_ms()[0])
             q_done.put(cur)
             cur = nxt
